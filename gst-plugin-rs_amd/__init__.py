@@ -1,0 +1,194 @@
+"""ctypes binding of libmi355vfx.so (the C ABI declared in include/mi355vfx.h).
+
+This package is test/bench plumbing around the product: the product itself is the HIP
+library under ``csrc/`` plus the C++ element layer under ``host/``.  Nothing here computes
+pixels; every call goes through the C ABI and therefore through the HIP kernels.  There is
+no CPU fallback: if ``libmi355vfx.so`` is missing, importing :func:`lib` raises.
+
+The directory name (``gst-plugin-rs_amd``) is not a valid Python identifier, so the repo
+root's ``_pkg.py`` loads this package under the module name ``gst_plugin_rs_amd``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t,
+                    c_uint32, c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355vfx.so")
+
+# mvfx_format (include/mi355vfx.h)
+FORMATS = {
+    "RGBx": 0, "xRGB": 1, "BGRx": 2, "xBGR": 3, "RGBA": 4, "ARGB": 5, "BGRA": 6, "ABGR": 7,
+    "RGB": 8, "BGR": 9, "RGBA64_LE": 10, "RGBA64_BE": 11, "I420": 12, "A420": 13,
+}
+FORMAT_NAMES = {v: k for k, v in FORMATS.items()}
+BYTES_PER_PIXEL = {0: 4, 1: 4, 2: 4, 3: 4, 4: 4, 5: 4, 6: 4, 7: 4, 8: 3, 9: 3, 10: 8, 11: 8}
+
+# mvfx_status
+OK = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_UNSUPPORTED_FORMAT = -2
+ERR_NOT_NEGOTIATED = -3
+ERR_DEVICE = -4
+ERR_NO_DEVICE = -5
+ERR_PARSE = -6
+ERR_IO = -7
+ERR_REFERENCE_PANIC = -8
+ERR_NO_LUT = -9
+ERR_OUT_OF_MEMORY = -10
+
+
+class Frame(Structure):
+    """struct mvfx_frame"""
+    _fields_ = [("data", c_void_p), ("width", c_uint32), ("height", c_uint32),
+                ("stride", c_uint32), ("format", c_int32)]
+
+
+class HsvFilterSettings(Structure):
+    """struct mvfx_hsvfilter_settings == hsvfilter/imp.rs:32-39"""
+    _fields_ = [("hue_shift", c_float), ("saturation_mul", c_float), ("saturation_off", c_float),
+                ("value_mul", c_float), ("value_off", c_float)]
+
+    @classmethod
+    def default(cls):  # hsvfilter/imp.rs:25-29
+        return cls(0.0, 1.0, 0.0, 1.0, 0.0)
+
+
+class HsvDetectorSettings(Structure):
+    """struct mvfx_hsvdetector_settings == hsvdetector/imp.rs:34-42"""
+    _fields_ = [("hue_ref", c_float), ("hue_var", c_float), ("saturation_ref", c_float),
+                ("saturation_var", c_float), ("value_ref", c_float), ("value_var", c_float)]
+
+    @classmethod
+    def default(cls):  # hsvdetector/imp.rs:26-31
+        return cls(0.0, 10.0, 0.0, 0.15, 0.0, 0.3)
+
+
+class MvfxError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"mvfx status {status}: {message}")
+        self.status = status
+        self.message = message
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/mi355vfx.h declares (tests/test_abi.py
+# cross-checks this table against the header text)
+SIGNATURES = {
+    "mvfx_abi_version": (c_int, []),
+    "mvfx_last_error": (c_char_p, []),
+    "mvfx_status_string": (c_char_p, [c_int]),
+    "mvfx_device_count": (c_int, []),
+    "mvfx_set_device": (c_int, [c_int]),
+    "mvfx_stream_synchronize": (c_int, [c_void_p]),
+    "mvfx_device_alloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "mvfx_device_free": (c_int, [c_void_p]),
+    "mvfx_copy_to_device": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mvfx_copy_to_host": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mvfx_hsvfilter_transform_frame_ip": (c_int, [POINTER(Frame), POINTER(HsvFilterSettings), c_void_p]),
+    "mvfx_hsvfilter_transform_frames_ip": (c_int, [POINTER(Frame), c_uint32, POINTER(HsvFilterSettings), c_void_p]),
+    "mvfx_hsvfilter_transform_frame_ip_host": (c_int, [POINTER(Frame), POINTER(HsvFilterSettings)]),
+    "mvfx_hsvfilter_set_variant": (c_int, [c_int]),
+    "mvfx_hsvdetector_transform_frame": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(HsvDetectorSettings), c_void_p]),
+    "mvfx_hsvdetector_transform_frame_host": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(HsvDetectorSettings)]),
+    "mvfx_hsv_from_frame": (c_int, [POINTER(Frame), c_void_p, c_void_p]),
+}
+
+
+def lib() -> ctypes.CDLL:
+    """Loads libmi355vfx.so (built in-tree by `make -C gst-plugin-rs_amd`); fails loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with __graft_entry__.build() or "
+                "`make -C gst-plugin-rs_amd`. There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status: int) -> int:
+    if status != OK:
+        raise MvfxError(status, lib().mvfx_last_error().decode("utf-8", "replace"))
+    return status
+
+
+def last_error() -> str:
+    return lib().mvfx_last_error().decode("utf-8", "replace")
+
+
+def make_frame(ptr: int, width: int, height: int, stride: int, fmt) -> Frame:
+    f = FORMATS[fmt] if isinstance(fmt, str) else int(fmt)
+    return Frame(c_void_p(ptr), width, height, stride, f)
+
+
+class DeviceBuffer:
+    """A hipMalloc'ed buffer owned through the C ABI (no torch needed)."""
+
+    def __init__(self, nbytes: int):
+        p = c_void_p()
+        check(lib().mvfx_device_alloc(ctypes.byref(p), nbytes))
+        self.ptr = p.value
+        self.nbytes = nbytes
+
+    def upload(self, host) -> "DeviceBuffer":
+        import numpy as np
+        a = np.ascontiguousarray(host)
+        assert a.nbytes <= self.nbytes
+        check(lib().mvfx_copy_to_device(c_void_p(self.ptr), a.ctypes.data_as(c_void_p), a.nbytes, None))
+        return self
+
+    def download(self, nbytes: int | None = None, dtype="uint8"):
+        import numpy as np
+        n = self.nbytes if nbytes is None else nbytes
+        out = np.empty(n, dtype=np.uint8)
+        check(lib().mvfx_copy_to_host(out.ctypes.data_as(c_void_p), c_void_p(self.ptr), n, None))
+        return out.view(dtype)
+
+    def free(self):
+        if self.ptr:
+            lib().mvfx_device_free(c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ---- thin, numpy-friendly wrappers used by tests / smoke / bench ---------------------------
+
+def hsvfilter_host(frame_bytes, width, height, stride, fmt, settings: HsvFilterSettings):
+    """In-place hsvfilter on a host numpy buffer through the *_host entry point."""
+    import numpy as np
+    assert frame_bytes.dtype == np.uint8 and frame_bytes.flags["C_CONTIGUOUS"]
+    f = make_frame(frame_bytes.ctypes.data, width, height, stride, fmt)
+    check(lib().mvfx_hsvfilter_transform_frame_ip_host(ctypes.byref(f), ctypes.byref(settings)))
+    return frame_bytes
+
+
+def hsvfilter_device(ptr, width, height, stride, fmt, settings: HsvFilterSettings, stream=None):
+    f = make_frame(ptr, width, height, stride, fmt)
+    check(lib().mvfx_hsvfilter_transform_frame_ip(ctypes.byref(f), ctypes.byref(settings), stream))
+
+
+def hsvfilter_device_batch(ptrs, width, height, stride, fmt, settings: HsvFilterSettings, stream=None):
+    arr = (Frame * len(ptrs))(*[make_frame(p, width, height, stride, fmt) for p in ptrs])
+    check(lib().mvfx_hsvfilter_transform_frames_ip(arr, len(ptrs), ctypes.byref(settings), stream))
+
+
+def hsvdetector_host(in_bytes, in_stride, in_fmt, out_bytes, out_stride, out_fmt, width, height,
+                     settings: HsvDetectorSettings):
+    fi = make_frame(in_bytes.ctypes.data, width, height, in_stride, in_fmt)
+    fo = make_frame(out_bytes.ctypes.data, width, height, out_stride, out_fmt)
+    check(lib().mvfx_hsvdetector_transform_frame_host(ctypes.byref(fi), ctypes.byref(fo), ctypes.byref(settings)))
+    return out_bytes

@@ -1,0 +1,191 @@
+// Library-level pieces of the C ABI: error reporting, device selection, device buffers,
+// the staging scratch behind the *_host entry points.
+#include "mvfx_internal.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace mvfx {
+
+namespace {
+thread_local char t_last_error[512] = "";
+
+struct Scratch {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+constexpr int kScratchSlots = 4;
+thread_local Scratch t_scratch[kScratchSlots];
+thread_local hipStream_t t_stream = nullptr;
+thread_local int t_stream_device = -1;
+} // namespace
+
+int fail(int status, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_last_error, sizeof(t_last_error), fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(MVFX_ERR_NO_DEVICE,
+                    "no HIP device available (%s); libmi355vfx has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    }
+    return MVFX_OK;
+}
+
+int check_packed_frame(const mvfx_frame *f, const char *what)
+{
+    if (!f)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "%s: NULL frame", what);
+    const int bpp = bytes_per_pixel(f->format);
+    if (bpp == 0)
+        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "%s: format %d is not a packed format", what, f->format);
+    if (f->width != 0 && f->height != 0) {
+        if (!f->data)
+            return fail(MVFX_ERR_INVALID_ARGUMENT, "%s: NULL plane pointer", what);
+        if (f->stride == 0)
+            return fail(MVFX_ERR_INVALID_ARGUMENT, "%s: zero stride", what);
+        if ((uint64_t)f->width * (uint64_t)bpp > f->stride)
+            return fail(MVFX_ERR_INVALID_ARGUMENT, "%s: row of %u pixels x %d bytes exceeds stride %u", what,
+                        f->width, bpp, f->stride);
+    }
+    return MVFX_OK;
+}
+
+int host_scratch(size_t bytes, int slot, void **out)
+{
+    if (slot < 0 || slot >= kScratchSlots)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "bad scratch slot %d", slot);
+    Scratch &s = t_scratch[slot];
+    if (s.cap < bytes) {
+        if (s.ptr) {
+            MVFX_HIP_TRY(hipFree(s.ptr));
+            s.ptr = nullptr;
+            s.cap = 0;
+        }
+        const size_t want = bytes + (bytes >> 2); // head-room for the next, slightly larger, frame
+        hipError_t e = hipMalloc(&s.ptr, want);
+        if (e != hipSuccess)
+            return fail(MVFX_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        s.cap = want;
+    }
+    *out = s.ptr;
+    return MVFX_OK;
+}
+
+hipStream_t host_stream()
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (t_stream == nullptr || t_stream_device != dev) {
+        if (hipStreamCreateWithFlags(&t_stream, hipStreamNonBlocking) != hipSuccess)
+            t_stream = nullptr; // fall back to the null stream
+        t_stream_device = dev;
+    }
+    return t_stream;
+}
+
+} // namespace mvfx
+
+using namespace mvfx;
+
+extern "C" {
+
+int mvfx_abi_version(void) { return MVFX_ABI_VERSION; }
+
+const char *mvfx_last_error(void) { return t_last_error; }
+
+const char *mvfx_status_string(int status)
+{
+    switch (status) {
+    case MVFX_OK: return "ok";
+    case MVFX_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case MVFX_ERR_UNSUPPORTED_FORMAT: return "unsupported format";
+    case MVFX_ERR_NOT_NEGOTIATED: return "not negotiated";
+    case MVFX_ERR_DEVICE: return "device error";
+    case MVFX_ERR_NO_DEVICE: return "no device";
+    case MVFX_ERR_PARSE: return "parse error";
+    case MVFX_ERR_IO: return "i/o error";
+    case MVFX_ERR_REFERENCE_PANIC: return "reference would panic";
+    case MVFX_ERR_NO_LUT: return "no LUT configured";
+    case MVFX_ERR_OUT_OF_MEMORY: return "out of memory";
+    default: return "unknown status";
+    }
+}
+
+int mvfx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int mvfx_set_device(int ordinal)
+{
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    MVFX_HIP_TRY(hipSetDevice(ordinal));
+    return MVFX_OK;
+}
+
+int mvfx_stream_synchronize(mvfx_stream stream)
+{
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    MVFX_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return MVFX_OK;
+}
+
+int mvfx_device_alloc(void **out_ptr, size_t bytes)
+{
+    if (!out_ptr)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "device_alloc: NULL out pointer");
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    *out_ptr = nullptr;
+    hipError_t e = hipMalloc(out_ptr, bytes ? bytes : 1);
+    if (e != hipSuccess)
+        return fail(MVFX_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return MVFX_OK;
+}
+
+int mvfx_device_free(void *ptr)
+{
+    if (!ptr) return MVFX_OK;
+    MVFX_HIP_TRY(hipFree(ptr));
+    return MVFX_OK;
+}
+
+int mvfx_copy_to_device(void *dst_device, const void *src_host, size_t bytes, mvfx_stream stream)
+{
+    if (bytes == 0) return MVFX_OK;
+    if (!dst_device || !src_host)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "copy_to_device: NULL pointer");
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    MVFX_HIP_TRY(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    MVFX_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return MVFX_OK;
+}
+
+int mvfx_copy_to_host(void *dst_host, const void *src_device, size_t bytes, mvfx_stream stream)
+{
+    if (bytes == 0) return MVFX_OK;
+    if (!dst_host || !src_device)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "copy_to_host: NULL pointer");
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    MVFX_HIP_TRY(hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    MVFX_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return MVFX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,641 @@
+// hsvfilter / hsvdetector kernels for gfx950 and their C-ABI launchers.
+//
+// Replaces the per-pixel loops of
+//   video/hsv/src/hsvfilter/imp.rs:76-120 (+ format dispatch :322-377)
+//   video/hsv/src/hsvdetector/imp.rs:100-160 (+ 24 closure pairs :422-707)
+//
+// Memory plan (HBM-bound streaming, no LDS needed: every pixel is independent):
+//   4-byte formats: one lane owns 4 consecutive pixels = one 16-byte global_load_dwordx4 /
+//   global_store_dwordx4, so a wave64 touches 1 KiB contiguous per instruction.  A frame whose
+//   stride equals width*4 is treated as ONE row of width*height pixels (no per-row tail).
+//   3-byte formats: one lane owns 4 pixels = 12 bytes = global_load_dwordx3, rows stay
+//   dword-coalesced; the <4-pixel row tail is done bytewise by the owning lane.
+//   Frames that are not 16-byte (4-byte formats) / 4-byte (3-byte formats) aligned fall back to
+//   a dword-per-pixel or byte-per-channel kernel: slower, still on the GPU, same results.
+//   Grid: x = pixel groups (grid-stride), y = rows, z = frame of the batch; >= 8K workgroups
+//   for a 4K frame so all 256 CUs / 8 XCDs are covered many times over; consecutive
+//   workgroups stream consecutive addresses so each XCD's L2 sees disjoint lines (no reuse to
+//   exploit, so no XCD remap is needed).
+#include "hsv_math.hpp"
+#include "mvfx_internal.h"
+
+#include <cmath>
+
+namespace mvfx {
+namespace {
+
+constexpr int kBlock = 256;
+
+enum : int { kModeBytes = 0, kModeVec4 = 1, kModeDword = 2 };
+
+// ---- channel placement -------------------------------------------------------------------
+// hsvfilter/imp.rs:327-373: OFF = index of the first colour byte, BGR = byte order of the triple
+template <int OFF, bool BGR>
+__device__ __forceinline__ void unpack4(uint32_t px, uint32_t &R, uint32_t &G, uint32_t &B)
+{
+    const uint32_t c0 = (px >> (8 * OFF)) & 0xffu;
+    const uint32_t c1 = (px >> (8 * OFF + 8)) & 0xffu;
+    const uint32_t c2 = (px >> (8 * OFF + 16)) & 0xffu;
+    R = BGR ? c2 : c0;
+    G = c1;
+    B = BGR ? c0 : c2;
+}
+
+template <int OFF, bool BGR>
+__device__ __forceinline__ uint32_t repack4(uint32_t px, uint32_t R, uint32_t G, uint32_t B)
+{
+    const uint32_t c0 = BGR ? B : R, c2 = BGR ? R : B;
+    const uint32_t keep = OFF == 0 ? 0xff000000u : 0x000000ffu; // alpha / x byte untouched
+    return (px & keep) | (c0 << (8 * OFF)) | (G << (8 * OFF + 8)) | (c2 << (8 * OFF + 16));
+}
+
+template <int OFF, bool BGR, int VARIANT>
+__device__ __forceinline__ uint32_t filter_px4(uint32_t px, const HsvFilterParams &p)
+{
+    uint32_t R, G, B;
+    unpack4<OFF, BGR>(px, R, G, B);
+    hsvfilter_pixel<VARIANT>(R, G, B, p);
+    return repack4<OFF, BGR>(px, R, G, B);
+}
+
+// ---- hsvfilter, 4-byte formats -------------------------------------------------------------
+// width = pixels per row, rows/stride describe one frame, fb.base[blockIdx.z] its plane 0.
+template <int OFF, bool BGR, int VARIANT, int MODE>
+__global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint64_t width,
+                                                            uint32_t rows, uint64_t stride,
+                                                            HsvFilterParams p)
+{
+    uint8_t *frame = fb.base[blockIdx.z];
+    for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        uint8_t *line = frame + (uint64_t)row * stride;
+        if constexpr (MODE == kModeVec4) {
+            const uint64_t groups = (width + 3) >> 2;
+            for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < groups;
+                 g += (uint64_t)gridDim.x * kBlock) {
+                const uint64_t x = g << 2;
+                if (x + 4 <= width) {
+                    uint4 v = *reinterpret_cast<const uint4 *>(line + x * 4);
+                    v.x = filter_px4<OFF, BGR, VARIANT>(v.x, p);
+                    v.y = filter_px4<OFF, BGR, VARIANT>(v.y, p);
+                    v.z = filter_px4<OFF, BGR, VARIANT>(v.z, p);
+                    v.w = filter_px4<OFF, BGR, VARIANT>(v.w, p);
+                    *reinterpret_cast<uint4 *>(line + x * 4) = v;
+                } else {
+                    for (uint64_t xx = x; xx < width; xx++) {
+                        uint32_t *q = reinterpret_cast<uint32_t *>(line + xx * 4);
+                        *q = filter_px4<OFF, BGR, VARIANT>(*q, p);
+                    }
+                }
+            }
+        } else if constexpr (MODE == kModeDword) {
+            for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < width;
+                 x += (uint64_t)gridDim.x * kBlock) {
+                uint32_t *q = reinterpret_cast<uint32_t *>(line + x * 4);
+                *q = filter_px4<OFF, BGR, VARIANT>(*q, p);
+            }
+        } else {
+            for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < width;
+                 x += (uint64_t)gridDim.x * kBlock) {
+                uint8_t *q = line + x * 4 + OFF;
+                uint32_t R = BGR ? q[2] : q[0], G = q[1], B = BGR ? q[0] : q[2];
+                hsvfilter_pixel<VARIANT>(R, G, B, p);
+                q[0] = (uint8_t)(BGR ? B : R);
+                q[1] = (uint8_t)G;
+                q[2] = (uint8_t)(BGR ? R : B);
+            }
+        }
+    }
+}
+
+// ---- hsvfilter, 3-byte formats (RGB / BGR) ---------------------------------------------------
+struct __attribute__((aligned(4))) U3 {
+    uint32_t a, b, c;
+};
+
+template <bool BGR, int VARIANT>
+__device__ __forceinline__ void filter_triplet(uint32_t &c0, uint32_t &c1, uint32_t &c2,
+                                               const HsvFilterParams &p)
+{
+    uint32_t R = BGR ? c2 : c0, G = c1, B = BGR ? c0 : c2;
+    hsvfilter_pixel<VARIANT>(R, G, B, p);
+    c0 = BGR ? B : R;
+    c1 = G;
+    c2 = BGR ? R : B;
+}
+
+template <bool BGR, int VARIANT, int MODE>
+__global__ __launch_bounds__(kBlock) void hsvfilter3_kernel(FrameBatch fb, uint64_t width,
+                                                            uint32_t rows, uint64_t stride,
+                                                            HsvFilterParams p)
+{
+    uint8_t *frame = fb.base[blockIdx.z];
+    for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        uint8_t *line = frame + (uint64_t)row * stride;
+        if constexpr (MODE == kModeVec4) {
+            const uint64_t groups = (width + 3) >> 2;
+            for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < groups;
+                 g += (uint64_t)gridDim.x * kBlock) {
+                const uint64_t x = g << 2;
+                if (x + 4 <= width) {
+                    U3 v = *reinterpret_cast<const U3 *>(line + x * 3);
+                    // 12 bytes = 4 pixels: p0 = a[0..2], p1 = a[3] b[0..1], p2 = b[2..3] c[0], p3 = c[1..3]
+                    uint32_t k[12];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        k[i] = (v.a >> (8 * i)) & 0xffu;
+                        k[4 + i] = (v.b >> (8 * i)) & 0xffu;
+                        k[8 + i] = (v.c >> (8 * i)) & 0xffu;
+                    }
+#pragma unroll
+                    for (int px = 0; px < 4; px++)
+                        filter_triplet<BGR, VARIANT>(k[3 * px], k[3 * px + 1], k[3 * px + 2], p);
+                    v.a = k[0] | (k[1] << 8) | (k[2] << 16) | (k[3] << 24);
+                    v.b = k[4] | (k[5] << 8) | (k[6] << 16) | (k[7] << 24);
+                    v.c = k[8] | (k[9] << 8) | (k[10] << 16) | (k[11] << 24);
+                    *reinterpret_cast<U3 *>(line + x * 3) = v;
+                } else {
+                    for (uint64_t xx = x; xx < width; xx++) {
+                        uint8_t *q = line + xx * 3;
+                        uint32_t c0 = q[0], c1 = q[1], c2 = q[2];
+                        filter_triplet<BGR, VARIANT>(c0, c1, c2, p);
+                        q[0] = (uint8_t)c0; q[1] = (uint8_t)c1; q[2] = (uint8_t)c2;
+                    }
+                }
+            }
+        } else {
+            for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < width;
+                 x += (uint64_t)gridDim.x * kBlock) {
+                uint8_t *q = line + x * 3;
+                uint32_t c0 = q[0], c1 = q[1], c2 = q[2];
+                filter_triplet<BGR, VARIANT>(c0, c1, c2, p);
+                q[0] = (uint8_t)c0; q[1] = (uint8_t)c1; q[2] = (uint8_t)c2;
+            }
+        }
+    }
+}
+
+// ---- hsvdetector ----------------------------------------------------------------------------
+// IN_BPP 3|4, IN_OFF first colour byte, IN_BGR byte order; OUT_A0 alpha first (ARGB/ABGR),
+// OUT_BGR colour order of the output.  One lane per pixel group of 4 when aligned.
+template <int IN_BPP, int IN_OFF, bool IN_BGR, bool OUT_A0, bool OUT_BGR, int VARIANT>
+__device__ __forceinline__ uint32_t detect_px(uint32_t c0, uint32_t c1, uint32_t c2,
+                                              const HsvDetectorParams &p)
+{
+    const uint32_t R = IN_BGR ? c2 : c0, G = c1, B = IN_BGR ? c0 : c2;
+    const Hsv hsv = from_rgb<VARIANT>(R, G, B);
+    const uint32_t a = detect_alpha_general(hsv, p);
+    const uint32_t o0 = OUT_BGR ? B : R, o2 = OUT_BGR ? R : B;
+    return OUT_A0 ? (a | (o0 << 8) | (G << 16) | (o2 << 24))
+                  : (o0 | (G << 8) | (o2 << 16) | (a << 24));
+}
+
+template <int IN_BPP, int IN_OFF, bool IN_BGR, bool OUT_A0, bool OUT_BGR, int VARIANT, int MODE>
+__global__ __launch_bounds__(kBlock) void hsvdetector_kernel(const uint8_t *in, uint8_t *out,
+                                                             uint64_t width, uint32_t rows,
+                                                             uint64_t in_stride,
+                                                             uint64_t out_stride,
+                                                             HsvDetectorParams p)
+{
+    for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const uint8_t *iline = in + (uint64_t)row * in_stride;
+        uint8_t *oline = out + (uint64_t)row * out_stride;
+        if constexpr (MODE == kModeVec4) {
+            const uint64_t groups = (width + 3) >> 2;
+            for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < groups;
+                 g += (uint64_t)gridDim.x * kBlock) {
+                const uint64_t x = g << 2;
+                if (x + 4 <= width) {
+                    uint4 o;
+                    if constexpr (IN_BPP == 4) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(iline + x * 4);
+                        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                        uint32_t r[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            r[i] = detect_px<IN_BPP, IN_OFF, IN_BGR, OUT_A0, OUT_BGR, VARIANT>(
+                                (w[i] >> (8 * IN_OFF)) & 0xffu, (w[i] >> (8 * IN_OFF + 8)) & 0xffu,
+                                (w[i] >> (8 * IN_OFF + 16)) & 0xffu, p);
+                        o = make_uint4(r[0], r[1], r[2], r[3]);
+                    } else {
+                        const U3 v = *reinterpret_cast<const U3 *>(iline + x * 3);
+                        uint32_t k[12];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            k[i] = (v.a >> (8 * i)) & 0xffu;
+                            k[4 + i] = (v.b >> (8 * i)) & 0xffu;
+                            k[8 + i] = (v.c >> (8 * i)) & 0xffu;
+                        }
+                        uint32_t r[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            r[i] = detect_px<IN_BPP, IN_OFF, IN_BGR, OUT_A0, OUT_BGR, VARIANT>(
+                                k[3 * i], k[3 * i + 1], k[3 * i + 2], p);
+                        o = make_uint4(r[0], r[1], r[2], r[3]);
+                    }
+                    *reinterpret_cast<uint4 *>(oline + x * 4) = o;
+                } else {
+                    for (uint64_t xx = x; xx < width; xx++) {
+                        const uint8_t *q = iline + xx * IN_BPP + IN_OFF;
+                        const uint32_t r = detect_px<IN_BPP, IN_OFF, IN_BGR, OUT_A0, OUT_BGR, VARIANT>(
+                            q[0], q[1], q[2], p);
+                        *reinterpret_cast<uint32_t *>(oline + xx * 4) = r;
+                    }
+                }
+            }
+        } else {
+            for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < width;
+                 x += (uint64_t)gridDim.x * kBlock) {
+                const uint8_t *q = iline + x * IN_BPP + IN_OFF;
+                const uint32_t r = detect_px<IN_BPP, IN_OFF, IN_BGR, OUT_A0, OUT_BGR, VARIANT>(
+                    q[0], q[1], q[2], p);
+                uint8_t *o = oline + x * 4;
+                o[0] = (uint8_t)r; o[1] = (uint8_t)(r >> 8); o[2] = (uint8_t)(r >> 16); o[3] = (uint8_t)(r >> 24);
+            }
+        }
+    }
+}
+
+// ---- f32 HSV dump (tests) -------------------------------------------------------------------
+template <int OFF, bool BGR, int VARIANT>
+__global__ __launch_bounds__(kBlock) void hsv_from_frame_kernel(const uint8_t *in, float *out,
+                                                                uint32_t width, uint32_t rows,
+                                                                uint64_t stride)
+{
+    for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        for (uint32_t x = blockIdx.x * kBlock + threadIdx.x; x < width; x += gridDim.x * kBlock) {
+            const uint8_t *q = in + (uint64_t)row * stride + (uint64_t)x * 4 + OFF;
+            const uint32_t R = BGR ? q[2] : q[0], G = q[1], B = BGR ? q[0] : q[2];
+            const Hsv hsv = from_rgb<VARIANT>(R, G, B);
+            float *o = out + ((uint64_t)row * width + x) * 3;
+            o[0] = hsv.h; o[1] = hsv.s; o[2] = hsv.v;
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+
+int g_variant = 0; // mvfx_hsvfilter_set_variant
+
+// Domain of the FAST kernels (hsv_math.hpp): finite settings, |shift| <= 360, shift not in
+// (0,1e-30) in magnitude.
+bool fast_domain_ok(const mvfx_hsvfilter_settings &s)
+{
+    const float v[5] = {s.hue_shift, s.saturation_mul, s.saturation_off, s.value_mul, s.value_off};
+    for (float f : v)
+        if (!std::isfinite(f))
+            return false;
+    const float a = std::fabs(s.hue_shift);
+    return a <= 360.0f && (a == 0.0f || a >= 1e-30f);
+}
+
+int filter_layout(int format, int *bpp, int *off, bool *bgr)
+{
+    switch (format) {
+    case MVFX_FORMAT_RGBX: case MVFX_FORMAT_RGBA: *bpp = 4; *off = 0; *bgr = false; return 0;
+    case MVFX_FORMAT_XRGB: case MVFX_FORMAT_ARGB: *bpp = 4; *off = 1; *bgr = false; return 0;
+    case MVFX_FORMAT_BGRX: case MVFX_FORMAT_BGRA: *bpp = 4; *off = 0; *bgr = true; return 0;
+    case MVFX_FORMAT_XBGR: case MVFX_FORMAT_ABGR: *bpp = 4; *off = 1; *bgr = true; return 0;
+    case MVFX_FORMAT_RGB: *bpp = 3; *off = 0; *bgr = false; return 0;
+    case MVFX_FORMAT_BGR: *bpp = 3; *off = 0; *bgr = true; return 0;
+    default: return -1;
+    }
+}
+
+struct Geometry {
+    uint64_t width;  // pixels per logical row
+    uint32_t rows;
+    uint64_t stride;
+    int mode;
+    dim3 grid;
+};
+
+// Picks flat/row layout, access mode and grid for a packed frame batch.
+Geometry plan(const mvfx_frame *frames, uint32_t n, int bpp, uint32_t n_frames_z)
+{
+    Geometry g;
+    const mvfx_frame &f = frames[0];
+    uint64_t base_or = 0;
+    for (uint32_t i = 0; i < n; i++)
+        base_or |= (uint64_t)(uintptr_t)frames[i].data;
+    const uint64_t align_or = base_or | f.stride;
+    const uint64_t need = bpp == 4 ? 15 : 3;
+    const bool flat = (uint64_t)f.width * bpp == f.stride;
+    if (flat) {
+        g.width = (uint64_t)f.width * f.height;
+        g.rows = 1;
+        g.stride = 0;
+        g.mode = (base_or & need) == 0 ? kModeVec4 : ((bpp == 4 && (base_or & 3) == 0) ? kModeDword : kModeBytes);
+    } else {
+        g.width = f.width;
+        g.rows = f.height;
+        g.stride = f.stride;
+        g.mode = (align_or & need) == 0 ? kModeVec4 : ((bpp == 4 && (align_or & 3) == 0) ? kModeDword : kModeBytes);
+    }
+    const uint64_t work = g.mode == kModeVec4 ? (g.width + 3) / 4 : g.width;
+    uint64_t bx = (work + kBlock - 1) / kBlock;
+    if (bx == 0) bx = 1;
+    if (bx > 65535u * 16u) bx = 65535u * 16u; // grid-stride covers the rest
+    g.grid = dim3((uint32_t)bx, g.rows < 65535u ? (g.rows ? g.rows : 1) : 65535u, n_frames_z);
+    return g;
+}
+
+template <int VARIANT>
+void launch_filter(int bpp, int off, bool bgr, const Geometry &g, const FrameBatch &fb,
+                   const HsvFilterParams &p, hipStream_t stream)
+{
+#define MVFX_L4(O, B, M) \
+    hipLaunchKernelGGL((hsvfilter4_kernel<O, B, VARIANT, M>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p)
+#define MVFX_L3(B, M) \
+    hipLaunchKernelGGL((hsvfilter3_kernel<B, VARIANT, M>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p)
+    if (bpp == 4) {
+        const int key = (off ? 2 : 0) | (bgr ? 1 : 0);
+        switch (g.mode) {
+        case kModeVec4:
+            switch (key) { case 0: MVFX_L4(0, false, kModeVec4); break; case 1: MVFX_L4(0, true, kModeVec4); break;
+                           case 2: MVFX_L4(1, false, kModeVec4); break; default: MVFX_L4(1, true, kModeVec4); break; }
+            break;
+        case kModeDword:
+            switch (key) { case 0: MVFX_L4(0, false, kModeDword); break; case 1: MVFX_L4(0, true, kModeDword); break;
+                           case 2: MVFX_L4(1, false, kModeDword); break; default: MVFX_L4(1, true, kModeDword); break; }
+            break;
+        default:
+            switch (key) { case 0: MVFX_L4(0, false, kModeBytes); break; case 1: MVFX_L4(0, true, kModeBytes); break;
+                           case 2: MVFX_L4(1, false, kModeBytes); break; default: MVFX_L4(1, true, kModeBytes); break; }
+            break;
+        }
+    } else {
+        if (g.mode == kModeVec4) { if (bgr) MVFX_L3(true, kModeVec4); else MVFX_L3(false, kModeVec4); }
+        else { if (bgr) MVFX_L3(true, kModeBytes); else MVFX_L3(false, kModeBytes); }
+    }
+#undef MVFX_L4
+#undef MVFX_L3
+}
+
+int hsvfilter_impl(const mvfx_frame *frames, uint32_t n, const mvfx_hsvfilter_settings *s,
+                   hipStream_t stream)
+{
+    if (!frames || !s || n == 0)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvfilter: NULL frame/settings or empty batch");
+    int bpp, off;
+    bool bgr;
+    if (filter_layout(frames[0].format, &bpp, &off, &bgr) != 0)
+        return fail(MVFX_ERR_UNSUPPORTED_FORMAT,
+                    "hsvfilter: format %d is not one of RGBx xRGB BGRx xBGR RGBA ARGB BGRA ABGR RGB BGR "
+                    "(hsvfilter/imp.rs:372 unreachable!())", frames[0].format);
+    for (uint32_t i = 0; i < n; i++) {
+        int rc = check_packed_frame(&frames[i], "hsvfilter");
+        if (rc != MVFX_OK)
+            return rc;
+        if (frames[i].width != frames[0].width || frames[i].height != frames[0].height ||
+            frames[i].stride != frames[0].stride || frames[i].format != frames[0].format)
+            return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvfilter: frames of one batch must share geometry and format");
+    }
+    // assert_eq!(data.len() % nb_channels, 0) hsvfilter/imp.rs:92
+    if (((uint64_t)frames[0].stride * frames[0].height) % (uint64_t)bpp != 0)
+        return fail(MVFX_ERR_REFERENCE_PANIC,
+                    "hsvfilter: plane size %llu is not a multiple of %d bytes per pixel; the reference "
+                    "asserts on this (hsvfilter/imp.rs:92)",
+                    (unsigned long long)((uint64_t)frames[0].stride * frames[0].height), bpp);
+    if (int rc = require_device(); rc != MVFX_OK)
+        return rc;
+
+    const bool fast_ok = fast_domain_ok(*s);
+    if (g_variant == 2 && !fast_ok)
+        return fail(MVFX_ERR_INVALID_ARGUMENT,
+                    "hsvfilter: settings are outside the proven domain of the strength-reduced kernel");
+    const bool use_fast = g_variant == 2 || (g_variant == 0 && fast_ok);
+    const HsvFilterParams p{s->hue_shift, s->saturation_mul, s->saturation_off, s->value_mul, s->value_off};
+
+    if (frames[0].width == 0 || frames[0].height == 0)
+        return MVFX_OK;
+    for (uint32_t done = 0; done < n; done += kMaxBatch) {
+        const uint32_t m = (n - done) < (uint32_t)kMaxBatch ? (n - done) : (uint32_t)kMaxBatch;
+        FrameBatch fb{};
+        for (uint32_t i = 0; i < m; i++)
+            fb.base[i] = static_cast<uint8_t *>(frames[done + i].data);
+        const Geometry g = plan(frames + done, m, bpp, m);
+        if (use_fast)
+            launch_filter<kFast>(bpp, off, bgr, g, fb, p, stream);
+        else
+            launch_filter<kGeneral>(bpp, off, bgr, g, fb, p, stream);
+        MVFX_HIP_TRY(hipGetLastError());
+    }
+    return MVFX_OK;
+}
+
+int detect_in_layout(int format, int *bpp, int *off, bool *bgr)
+{
+    switch (format) { // hsvdetector/imp.rs:78-87
+    case MVFX_FORMAT_RGBX: *bpp = 4; *off = 0; *bgr = false; return 0;
+    case MVFX_FORMAT_XRGB: *bpp = 4; *off = 1; *bgr = false; return 0;
+    case MVFX_FORMAT_BGRX: *bpp = 4; *off = 0; *bgr = true; return 0;
+    case MVFX_FORMAT_XBGR: *bpp = 4; *off = 1; *bgr = true; return 0;
+    case MVFX_FORMAT_RGB: *bpp = 3; *off = 0; *bgr = false; return 0;
+    case MVFX_FORMAT_BGR: *bpp = 3; *off = 0; *bgr = true; return 0;
+    default: return -1;
+    }
+}
+
+int detect_out_layout(int format, bool *a0, bool *bgr)
+{
+    switch (format) { // hsvdetector/imp.rs:89-96
+    case MVFX_FORMAT_RGBA: *a0 = false; *bgr = false; return 0;
+    case MVFX_FORMAT_ARGB: *a0 = true; *bgr = false; return 0;
+    case MVFX_FORMAT_BGRA: *a0 = false; *bgr = true; return 0;
+    case MVFX_FORMAT_ABGR: *a0 = true; *bgr = true; return 0;
+    default: return -1;
+    }
+}
+
+template <int IN_BPP, int IN_OFF, bool IN_BGR, int VARIANT, int MODE>
+void launch_detect_out(bool a0, bool obgr, dim3 grid, hipStream_t stream, const uint8_t *in,
+                       uint8_t *out, uint64_t width, uint32_t rows, uint64_t is, uint64_t os,
+                       const HsvDetectorParams &p)
+{
+#define MVFX_LD(A, B) \
+    hipLaunchKernelGGL((hsvdetector_kernel<IN_BPP, IN_OFF, IN_BGR, A, B, VARIANT, MODE>), grid, dim3(kBlock), 0, stream, in, out, width, rows, is, os, p)
+    if (a0) { if (obgr) MVFX_LD(true, true); else MVFX_LD(true, false); }
+    else { if (obgr) MVFX_LD(false, true); else MVFX_LD(false, false); }
+#undef MVFX_LD
+}
+
+template <int VARIANT, int MODE>
+void launch_detect(int bpp, int off, bool ibgr, bool a0, bool obgr, dim3 grid, hipStream_t stream,
+                   const uint8_t *in, uint8_t *out, uint64_t width, uint32_t rows, uint64_t is,
+                   uint64_t os, const HsvDetectorParams &p)
+{
+#define MVFX_ARGS a0, obgr, grid, stream, in, out, width, rows, is, os, p
+    if (bpp == 4) {
+        if (off == 0) { if (ibgr) launch_detect_out<4, 0, true, VARIANT, MODE>(MVFX_ARGS); else launch_detect_out<4, 0, false, VARIANT, MODE>(MVFX_ARGS); }
+        else { if (ibgr) launch_detect_out<4, 1, true, VARIANT, MODE>(MVFX_ARGS); else launch_detect_out<4, 1, false, VARIANT, MODE>(MVFX_ARGS); }
+    } else {
+        if (ibgr) launch_detect_out<3, 0, true, VARIANT, MODE>(MVFX_ARGS); else launch_detect_out<3, 0, false, VARIANT, MODE>(MVFX_ARGS);
+    }
+#undef MVFX_ARGS
+}
+
+int hsvdetector_impl(const mvfx_frame *in, const mvfx_frame *out,
+                     const mvfx_hsvdetector_settings *s, hipStream_t stream)
+{
+    if (!in || !out || !s)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvdetector: NULL frame or settings");
+    int bpp, off;
+    bool ibgr, a0, obgr;
+    if (detect_in_layout(in->format, &bpp, &off, &ibgr) != 0)
+        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "hsvdetector: input format %d not in RGBx xRGB BGRx xBGR RGB BGR (hsvdetector/imp.rs:78-87)", in->format);
+    if (detect_out_layout(out->format, &a0, &obgr) != 0)
+        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "hsvdetector: output format %d not in RGBA ARGB BGRA ABGR (hsvdetector/imp.rs:89-96)", out->format);
+    if (int rc = check_packed_frame(in, "hsvdetector input"); rc != MVFX_OK) return rc;
+    if (int rc = check_packed_frame(out, "hsvdetector output"); rc != MVFX_OK) return rc;
+    if (in->width != out->width || in->height != out->height)
+        return fail(MVFX_ERR_NOT_NEGOTIATED, "hsvdetector: input %ux%u and output %ux%u differ (assert_eq! hsvdetector/imp.rs:121)",
+                    in->width, in->height, out->width, out->height);
+    if (((uint64_t)in->stride * in->height) % (uint64_t)bpp != 0)
+        return fail(MVFX_ERR_REFERENCE_PANIC, "hsvdetector: input plane size is not a multiple of %d bytes per pixel; the reference asserts on this (hsvdetector/imp.rs:122)", bpp);
+    if (int rc = require_device(); rc != MVFX_OK)
+        return rc;
+    if (in->width == 0 || in->height == 0)
+        return MVFX_OK;
+
+    const HsvDetectorParams p{180.0f - s->hue_ref, s->hue_var, s->saturation_ref,
+                              s->saturation_var, s->value_ref, s->value_var};
+    const uint64_t in_need = bpp == 4 ? 15 : 3;
+    const bool flat = (uint64_t)in->width * bpp == in->stride && (uint64_t)out->width * 4 == out->stride;
+    uint64_t width = in->width, is = in->stride, os = out->stride;
+    uint32_t rows = in->height;
+    uint64_t in_or = (uint64_t)(uintptr_t)in->data, out_or = (uint64_t)(uintptr_t)out->data;
+    if (flat) {
+        width = (uint64_t)in->width * in->height; rows = 1; is = 0; os = 0;
+    } else {
+        in_or |= is; out_or |= os;
+    }
+    const bool vec = (in_or & in_need) == 0 && (out_or & 15) == 0;
+    const uint64_t work = vec ? (width + 3) / 4 : width;
+    uint64_t bx = (work + kBlock - 1) / kBlock;
+    if (bx > 65535u * 16u) bx = 65535u * 16u;
+    const dim3 grid((uint32_t)bx, rows < 65535u ? rows : 65535u, 1);
+    const uint8_t *ip = static_cast<const uint8_t *>(in->data);
+    uint8_t *op = static_cast<uint8_t *>(out->data);
+    // from_rgb's FAST form is settings-independent, so it is always valid here
+    const bool fast = g_variant != 1;
+    if (vec) {
+        if (fast) launch_detect<kFast, kModeVec4>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
+        else launch_detect<kGeneral, kModeVec4>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
+    } else {
+        if (fast) launch_detect<kFast, kModeBytes>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
+        else launch_detect<kGeneral, kModeBytes>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
+    }
+    MVFX_HIP_TRY(hipGetLastError());
+    return MVFX_OK;
+}
+
+} // namespace
+} // namespace mvfx
+
+using namespace mvfx;
+
+extern "C" {
+
+int mvfx_hsvfilter_set_variant(int variant)
+{
+    if (variant < 0 || variant > 2)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvfilter variant must be 0 (auto), 1 (general) or 2 (fast)");
+    g_variant = variant;
+    return MVFX_OK;
+}
+
+int mvfx_hsvfilter_transform_frame_ip(const mvfx_frame *frame, const mvfx_hsvfilter_settings *settings,
+                                      mvfx_stream stream)
+{
+    return hsvfilter_impl(frame, 1, settings, as_stream(stream));
+}
+
+int mvfx_hsvfilter_transform_frames_ip(const mvfx_frame *frames, uint32_t n_frames,
+                                       const mvfx_hsvfilter_settings *settings, mvfx_stream stream)
+{
+    return hsvfilter_impl(frames, n_frames, settings, as_stream(stream));
+}
+
+int mvfx_hsvfilter_transform_frame_ip_host(const mvfx_frame *frame, const mvfx_hsvfilter_settings *settings)
+{
+    if (!frame || !settings)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvfilter: NULL frame or settings");
+    if (int rc = check_packed_frame(frame, "hsvfilter"); rc != MVFX_OK) return rc;
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    const size_t bytes = (size_t)frame->stride * frame->height;
+    if (bytes == 0)
+        return MVFX_OK;
+    void *dev = nullptr;
+    if (int rc = host_scratch(bytes, 0, &dev); rc != MVFX_OK) return rc;
+    hipStream_t st = host_stream();
+    MVFX_HIP_TRY(hipMemcpyAsync(dev, frame->data, bytes, hipMemcpyHostToDevice, st));
+    mvfx_frame d = *frame;
+    d.data = dev;
+    if (int rc = hsvfilter_impl(&d, 1, settings, st); rc != MVFX_OK) return rc;
+    MVFX_HIP_TRY(hipMemcpyAsync(frame->data, dev, bytes, hipMemcpyDeviceToHost, st));
+    MVFX_HIP_TRY(hipStreamSynchronize(st));
+    return MVFX_OK;
+}
+
+int mvfx_hsvdetector_transform_frame(const mvfx_frame *in_frame, const mvfx_frame *out_frame,
+                                     const mvfx_hsvdetector_settings *settings, mvfx_stream stream)
+{
+    return hsvdetector_impl(in_frame, out_frame, settings, as_stream(stream));
+}
+
+int mvfx_hsvdetector_transform_frame_host(const mvfx_frame *in_frame, const mvfx_frame *out_frame,
+                                          const mvfx_hsvdetector_settings *settings)
+{
+    if (!in_frame || !out_frame || !settings)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvdetector: NULL frame or settings");
+    if (int rc = check_packed_frame(in_frame, "hsvdetector input"); rc != MVFX_OK) return rc;
+    if (int rc = check_packed_frame(out_frame, "hsvdetector output"); rc != MVFX_OK) return rc;
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    const size_t ib = (size_t)in_frame->stride * in_frame->height;
+    const size_t ob = (size_t)out_frame->stride * out_frame->height;
+    if (ib == 0 || ob == 0)
+        return hsvdetector_impl(in_frame, out_frame, settings, nullptr);
+    void *din = nullptr, *dout = nullptr;
+    if (int rc = host_scratch(ib, 0, &din); rc != MVFX_OK) return rc;
+    if (int rc = host_scratch(ob, 1, &dout); rc != MVFX_OK) return rc;
+    hipStream_t st = host_stream();
+    MVFX_HIP_TRY(hipMemcpyAsync(din, in_frame->data, ib, hipMemcpyHostToDevice, st));
+    // row padding of the output buffer is not written by the kernel: keep the caller's bytes
+    if ((size_t)out_frame->width * 4 != out_frame->stride)
+        MVFX_HIP_TRY(hipMemcpyAsync(dout, out_frame->data, ob, hipMemcpyHostToDevice, st));
+    mvfx_frame di = *in_frame, dof = *out_frame;
+    di.data = din;
+    dof.data = dout;
+    if (int rc = hsvdetector_impl(&di, &dof, settings, st); rc != MVFX_OK) return rc;
+    MVFX_HIP_TRY(hipMemcpyAsync(out_frame->data, dout, ob, hipMemcpyDeviceToHost, st));
+    MVFX_HIP_TRY(hipStreamSynchronize(st));
+    return MVFX_OK;
+}
+
+int mvfx_hsv_from_frame(const mvfx_frame *frame, float *hsv_out_device, mvfx_stream stream)
+{
+    if (!frame || !hsv_out_device)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "hsv_from_frame: NULL argument");
+    int bpp, off;
+    bool bgr;
+    if (filter_layout(frame->format, &bpp, &off, &bgr) != 0 || bpp != 4)
+        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "hsv_from_frame: needs a 4-byte packed format");
+    if (int rc = check_packed_frame(frame, "hsv_from_frame"); rc != MVFX_OK) return rc;
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    if (frame->width == 0 || frame->height == 0)
+        return MVFX_OK;
+    const dim3 grid((frame->width + kBlock - 1) / kBlock, frame->height < 65535u ? frame->height : 65535u, 1);
+    const uint8_t *in = static_cast<const uint8_t *>(frame->data);
+    hipStream_t st = as_stream(stream);
+    const bool fast = g_variant != 1;
+#define MVFX_LH(O, B) \
+    do { if (fast) hipLaunchKernelGGL((hsv_from_frame_kernel<O, B, kFast>), grid, dim3(kBlock), 0, st, in, hsv_out_device, frame->width, frame->height, (uint64_t)frame->stride); \
+         else hipLaunchKernelGGL((hsv_from_frame_kernel<O, B, kGeneral>), grid, dim3(kBlock), 0, st, in, hsv_out_device, frame->width, frame->height, (uint64_t)frame->stride); } while (0)
+    if (off == 0) { if (bgr) MVFX_LH(0, true); else MVFX_LH(0, false); }
+    else { if (bgr) MVFX_LH(1, true); else MVFX_LH(1, false); }
+#undef MVFX_LH
+    MVFX_HIP_TRY(hipGetLastError());
+    return MVFX_OK;
+}
+
+} // extern "C"

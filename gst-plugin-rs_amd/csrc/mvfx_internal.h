@@ -1,0 +1,60 @@
+// Internal helpers shared by the HIP translation units of libmi355vfx (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "mi355vfx.h"
+
+namespace mvfx {
+
+// Records the message returned by mvfx_last_error() for this thread and returns `status`.
+int fail(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// Fails with MVFX_ERR_NO_DEVICE when no HIP device is usable; otherwise MVFX_OK.
+int require_device();
+
+inline hipStream_t as_stream(mvfx_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define MVFX_HIP_TRY(expr)                                                                    \
+    do {                                                                                      \
+        hipError_t mvfx_e_ = (expr);                                                          \
+        if (mvfx_e_ != hipSuccess)                                                            \
+            return ::mvfx::fail(mvfx_e_ == hipErrorNoDevice ? MVFX_ERR_NO_DEVICE              \
+                                                            : MVFX_ERR_DEVICE,                \
+                                "%s failed: %s", #expr, hipGetErrorString(mvfx_e_));          \
+    } while (0)
+
+// pixel_stride()[0] of the packed formats; 0 for planar / unknown
+inline int bytes_per_pixel(int format)
+{
+    switch (format) {
+    case MVFX_FORMAT_RGBX: case MVFX_FORMAT_XRGB: case MVFX_FORMAT_BGRX: case MVFX_FORMAT_XBGR:
+    case MVFX_FORMAT_RGBA: case MVFX_FORMAT_ARGB: case MVFX_FORMAT_BGRA: case MVFX_FORMAT_ABGR:
+        return 4;
+    case MVFX_FORMAT_RGB: case MVFX_FORMAT_BGR:
+        return 3;
+    case MVFX_FORMAT_RGBA64_LE: case MVFX_FORMAT_RGBA64_BE:
+        return 8;
+    default:
+        return 0;
+    }
+}
+
+// Basic validation shared by every packed-frame entry point.
+int check_packed_frame(const mvfx_frame *f, const char *what);
+
+// Grow-only device scratch used by the *_host entry points (one per thread).
+int host_scratch(size_t bytes, int slot, void **out);
+hipStream_t host_stream();
+
+constexpr int kMaxBatch = 32; // frames per launch of the batched entry points
+
+struct FrameBatch {
+    uint8_t *base[kMaxBatch];
+};
+
+} // namespace mvfx

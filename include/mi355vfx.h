@@ -1,0 +1,166 @@
+/*
+ * mi355vfx.h -- C ABI of the MI355X-native per-pixel video-filter kernels.
+ *
+ * This is the drop-in boundary for the `VideoFilterImpl::transform_frame*` hot loops of
+ * sdroege/gst-plugin-rs `video/hsv`, `video/colorlut` and `video/videofx`.  Every entry
+ * point names the reference loop it replaces (file:line under the reference tree).  A Rust
+ * `imp.rs` (or the C++ element layer in gst-plugin-rs_amd/host) maps the GstVideoFrame,
+ * fills an `mvfx_frame` from `plane_data(0)` / `plane_stride()[0]` / `width()` / `height()` /
+ * `format()` and calls one function; see INTEGRATION.md for the `extern "C"` block.
+ *
+ * Conventions
+ *   - plain C, no GLib/GStreamer/torch types; all structs are POD with fixed-width fields.
+ *   - every function returns MVFX_OK (0) or a negative mvfx_status; the message of the last
+ *     failure on the calling thread is available from mvfx_last_error().
+ *   - `*_device` style entry points (no suffix) take DEVICE pointers and are asynchronous on
+ *     `stream` (a hipStream_t cast to void*, NULL = null stream).  The caller owns all frame
+ *     memory.  `*_host` entry points take HOST pointers (a mapped GstBuffer), stage through
+ *     library-owned device scratch and return after the result is back in host memory, which
+ *     is what a GstVideoFilter vfunc needs (frames are borrowed, SURVEY.md 8b "Ownership").
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails with
+ *     MVFX_ERR_NO_DEVICE / MVFX_ERR_DEVICE.
+ */
+#ifndef MI355VFX_H
+#define MI355VFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVFX_ABI_VERSION 1
+
+/* Pixel formats on the path (GstVideoFormat names).  hsvfilter: the first ten
+ * (hsvfilter/imp.rs:278-289); hsvdetector sink RGBx..BGR, src RGBA..ABGR
+ * (hsvdetector/imp.rs:78-96); colorlut RGBA, RGBA64_LE/BE (colorlut/imp.rs:122-134);
+ * colordetect RGB,RGBA,ARGB,BGR,BGRA (colordetect/imp.rs:214-221); videocompare RGB,RGBA;
+ * roundedcorners I420 -> A420 (border/imp.rs:345-365). */
+typedef enum mvfx_format {
+    MVFX_FORMAT_RGBX = 0,
+    MVFX_FORMAT_XRGB = 1,
+    MVFX_FORMAT_BGRX = 2,
+    MVFX_FORMAT_XBGR = 3,
+    MVFX_FORMAT_RGBA = 4,
+    MVFX_FORMAT_ARGB = 5,
+    MVFX_FORMAT_BGRA = 6,
+    MVFX_FORMAT_ABGR = 7,
+    MVFX_FORMAT_RGB = 8,
+    MVFX_FORMAT_BGR = 9,
+    MVFX_FORMAT_RGBA64_LE = 10,
+    MVFX_FORMAT_RGBA64_BE = 11,
+    MVFX_FORMAT_I420 = 12,
+    MVFX_FORMAT_A420 = 13
+} mvfx_format;
+
+typedef enum mvfx_status {
+    MVFX_OK = 0,
+    MVFX_ERR_INVALID_ARGUMENT = -1,  /* NULL pointer, zero stride, row longer than stride ... */
+    MVFX_ERR_UNSUPPORTED_FORMAT = -2,/* format not in the element's caps (reference: unreachable!()) */
+    MVFX_ERR_NOT_NEGOTIATED = -3,    /* frame sizes differ (videocompare/imp.rs:337-346) */
+    MVFX_ERR_DEVICE = -4,            /* a HIP call failed; maps to GST_FLOW_ERROR */
+    MVFX_ERR_NO_DEVICE = -5,         /* no HIP device: the product has no CPU fallback */
+    MVFX_ERR_PARSE = -6,             /* .cube text rejected (parser.rs CubeParseError::InvalidLut) */
+    MVFX_ERR_IO = -7,                /* .cube file unreadable (CubeParseError::Io) */
+    MVFX_ERR_REFERENCE_PANIC = -8,   /* input on which the reference panics (assert_eq!, slice range) */
+    MVFX_ERR_NO_LUT = -9,            /* colorlut without a parsed LUT (colorlut/imp.rs:209-213) */
+    MVFX_ERR_OUT_OF_MEMORY = -10
+} mvfx_status;
+
+/* hipStream_t passed through as an opaque pointer; NULL selects the null stream. */
+typedef void *mvfx_stream;
+
+/* One mapped plane-0 view of a packed frame == what the reference reads from
+ * gst_video::VideoFrameRef: plane_data(0) (stride*height bytes), plane_stride()[0],
+ * width(), height(), format().  Planar I420/A420 frames use mvfx_planar_frame. */
+typedef struct mvfx_frame {
+    void *data;      /* first byte of plane 0 */
+    uint32_t width;  /* pixels */
+    uint32_t height; /* rows; plane_data(0).len() == stride * height */
+    uint32_t stride; /* bytes between rows */
+    int32_t format;  /* mvfx_format */
+} mvfx_frame;
+
+/* ---- library / device ---- */
+int mvfx_abi_version(void);
+const char *mvfx_last_error(void);        /* thread-local, never NULL */
+const char *mvfx_status_string(int status);
+int mvfx_device_count(void);              /* 0 when no HIP device is visible */
+int mvfx_set_device(int ordinal);
+int mvfx_stream_synchronize(mvfx_stream stream);
+
+/* Device buffers for callers that do not bring their own allocator (tests, the element
+ * layer's staging, bench).  Plain hipMalloc/hipFree/hipMemcpy underneath. */
+int mvfx_device_alloc(void **out_ptr, size_t bytes);
+int mvfx_device_free(void *ptr);
+int mvfx_copy_to_device(void *dst_device, const void *src_host, size_t bytes, mvfx_stream stream);
+int mvfx_copy_to_host(void *dst_host, const void *src_device, size_t bytes, mvfx_stream stream);
+
+/* ---- hsvfilter : video/hsv/src/hsvfilter/imp.rs ----
+ * Settings == `struct Settings` hsvfilter/imp.rs:32-39 (defaults :25-29: 0,1,0,1,0). */
+typedef struct mvfx_hsvfilter_settings {
+    float hue_shift;
+    float saturation_mul;
+    float saturation_off;
+    float value_mul;
+    float value_off;
+} mvfx_hsvfilter_settings;
+
+/* Replaces HsvFilter::transform_frame_ip + hsv_filter (hsvfilter/imp.rs:322-377, :76-120):
+ * in place, per pixel from_rgb|from_bgr -> hue shift / sat, val affine+clamp -> to_rgb|to_bgr;
+ * the 4th byte of 4-byte formats and all row padding are left untouched.
+ * Formats: RGBx xRGB BGRx xBGR RGBA ARGB BGRA ABGR RGB BGR.  Device memory, async. */
+int mvfx_hsvfilter_transform_frame_ip(const mvfx_frame *frame,
+                                      const mvfx_hsvfilter_settings *settings,
+                                      mvfx_stream stream);
+
+/* Same loop over `n_frames` independent frames of identical geometry and format (e.g. one
+ * frame from each of N streams) in a single launch: amortises the ~1.5 us kernel boundary
+ * that a 12 us 4K frame would otherwise pay per buffer. */
+int mvfx_hsvfilter_transform_frames_ip(const mvfx_frame *frames, uint32_t n_frames,
+                                       const mvfx_hsvfilter_settings *settings,
+                                       mvfx_stream stream);
+
+/* Host-memory variant for a GstVideoFilter vfunc working on system-memory buffers:
+ * H2D -> kernel -> D2H on an internal stream, returns when `frame->data` holds the result. */
+int mvfx_hsvfilter_transform_frame_ip_host(const mvfx_frame *frame,
+                                           const mvfx_hsvfilter_settings *settings);
+
+/* Selects the kernel variant used by the three calls above (per process, for A/B and
+ * parity tests): 0 = automatic (default), 1 = force the literal transcription (IEEE divides,
+ * fmodf), 2 = force the strength-reduced kernel (fails with MVFX_ERR_INVALID_ARGUMENT when
+ * the settings are outside its proven domain instead of silently falling back). */
+int mvfx_hsvfilter_set_variant(int variant);
+
+/* ---- hsvdetector : video/hsv/src/hsvdetector/imp.rs ----
+ * Settings == `struct Settings` hsvdetector/imp.rs:34-42 (defaults :26-31). */
+typedef struct mvfx_hsvdetector_settings {
+    float hue_ref;
+    float hue_var;
+    float saturation_ref;
+    float saturation_var;
+    float value_ref;
+    float value_var;
+} mvfx_hsvdetector_settings;
+
+/* Replaces HsvDetector::transform_frame + hsv_detect (hsvdetector/imp.rs:422-707, :100-160):
+ * out of place; input RGBx xRGB BGRx xBGR RGB BGR, output RGBA ARGB BGRA ABGR; the colour is
+ * copied in the output order and alpha is 255 where the pixel's HSV lies within
+ * ref +- var (hue circular), else 0.  in/out must have equal width and height. */
+int mvfx_hsvdetector_transform_frame(const mvfx_frame *in_frame, const mvfx_frame *out_frame,
+                                     const mvfx_hsvdetector_settings *settings,
+                                     mvfx_stream stream);
+int mvfx_hsvdetector_transform_frame_host(const mvfx_frame *in_frame, const mvfx_frame *out_frame,
+                                          const mvfx_hsvdetector_settings *settings);
+
+/* f32 HSV of every pixel of a packed 4-byte frame (hsvutils::from_rgb / from_bgr,
+ * hsvutils.rs:44-128) as 3 floats per pixel, row-major without padding.  Exists so the
+ * "within 1 ULP on the f32 HSV path" claim can be checked directly (tests only need it;
+ * an element never calls it). */
+int mvfx_hsv_from_frame(const mvfx_frame *frame, float *hsv_out_device, mvfx_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355VFX_H */

@@ -1,0 +1,284 @@
+"""GPU parity tests for hsvfilter / hsvdetector: HIP path (through the C ABI) vs the oracle.
+
+Bit-exact u8 is the bar.  The exhaustive frame (all 2^24 RGB triples) makes each settings
+vector a complete proof for the per-pixel function.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests import frames
+from tests import oracle_binding as orc
+
+pytestmark = pytest.mark.gpu
+
+BENCH_SETTINGS = (90.0, 1.25, -0.05, 0.9, 0.02)
+FILTER_SETTINGS = [
+    (0.0, 1.0, 0.0, 1.0, 0.0),          # defaults (not an identity: SURVEY F5)
+    BENCH_SETTINGS,
+    (-123.4, 0.5, 0.3, 1.7, -0.2),
+    (360.0, 1.0, 0.0, 1.0, 0.0),        # h + 360 can reach exactly 360 / wrap
+    (-360.0, 2.0, -0.5, 0.25, 0.5),
+    (359.99997, 3.0, -1.0, 3.0, -1.0),
+    (1e-3, 1.0, 1e-3, 1.0, -1e-3),
+]
+GENERAL_ONLY_SETTINGS = [               # outside the strength-reduced kernel's domain
+    (720.5, 1.0, 0.0, 1.0, 0.0),
+    (-1e6, 1.1, 0.0, 0.9, 0.0),
+    (float("nan"), 1.0, 0.0, 1.0, 0.0),
+    (10.0, float("inf"), 0.0, float("nan"), 0.0),
+    (float("inf"), 1.0, float("-inf"), 1.0, 0.0),
+    (1e-35, 1.0, 0.0, 1.0, 0.0),
+]
+
+
+def _device_filter(vfx, host_frame, w, h, stride, fmt, settings, variant=0, batch=False):
+    buf = vfx.DeviceBuffer(host_frame.nbytes).upload(host_frame)
+    vfx.check(vfx.lib().mvfx_hsvfilter_set_variant(variant))
+    try:
+        s = vfx.HsvFilterSettings(*settings)
+        if batch:
+            vfx.hsvfilter_device_batch([buf.ptr], w, h, stride, fmt, s)
+        else:
+            vfx.hsvfilter_device(buf.ptr, w, h, stride, fmt, s)
+        vfx.check(vfx.lib().mvfx_stream_synchronize(None))
+    finally:
+        vfx.lib().mvfx_hsvfilter_set_variant(0)
+    return buf.download().reshape(host_frame.shape)
+
+
+@pytest.fixture(scope="module")
+def exhaustive():
+    return frames.exhaustive_rgbx()
+
+
+@pytest.mark.parametrize("settings", FILTER_SETTINGS)
+@pytest.mark.parametrize("variant", [2, 1], ids=["fast", "general"])
+def test_hsvfilter_exhaustive_rgba(gpu, exhaustive, settings, variant):
+    """All 2^24 triples, RGBA, both kernel variants, bit-exact vs oracle; alpha untouched."""
+    expect = exhaustive.copy()
+    assert orc.hsvfilter(expect, 4096, 4096 * 4, "RGBA", settings) == 0
+    got = _device_filter(gpu, exhaustive, 4096, 4096, 4096 * 4, "RGBA", settings, variant)
+    bad = np.count_nonzero(got != expect)
+    assert bad == 0, f"{bad} bytes differ for settings {settings}"
+
+
+@pytest.mark.parametrize("settings", GENERAL_ONLY_SETTINGS)
+def test_hsvfilter_exhaustive_general_domain(gpu, exhaustive, settings):
+    """NaN / inf / huge / denormal-range settings: auto mode must pick the literal kernel."""
+    expect = exhaustive.copy()
+    assert orc.hsvfilter(expect, 4096, 4096 * 4, "RGBA", settings) == 0
+    got = _device_filter(gpu, exhaustive, 4096, 4096, 4096 * 4, "RGBA", settings, 0)
+    assert np.array_equal(got, expect)
+    # and the fast kernel must refuse rather than silently produce something
+    buf = gpu.DeviceBuffer(16)
+    gpu.lib().mvfx_hsvfilter_set_variant(2)
+    try:
+        f = gpu.make_frame(buf.ptr, 2, 2, 8, "RGBA")
+        rc = gpu.lib().mvfx_hsvfilter_transform_frame_ip(ctypes.byref(f), ctypes.byref(gpu.HsvFilterSettings(*settings)), None)
+        assert rc == gpu.ERR_INVALID_ARGUMENT
+    finally:
+        gpu.lib().mvfx_hsvfilter_set_variant(0)
+
+
+@pytest.mark.parametrize("variant", [2, 1], ids=["fast", "general"])
+def test_from_rgb_f32_exhaustive(gpu, exhaustive, variant):
+    """f32 HSV of every RGB triple: bit-identical floats (stronger than the 1-ULP bar)."""
+    vfx = gpu
+    src = vfx.DeviceBuffer(exhaustive.nbytes).upload(exhaustive)
+    out = vfx.DeviceBuffer((1 << 24) * 3 * 4)
+    vfx.lib().mvfx_hsvfilter_set_variant(variant)
+    try:
+        f = vfx.make_frame(src.ptr, 4096, 4096, 4096 * 4, "RGBx")
+        vfx.check(vfx.lib().mvfx_hsv_from_frame(ctypes.byref(f), ctypes.c_void_p(out.ptr), None))
+        vfx.check(vfx.lib().mvfx_stream_synchronize(None))
+    finally:
+        vfx.lib().mvfx_hsvfilter_set_variant(0)
+    got = out.download(dtype=np.float32).reshape(-1, 3)
+    expect = orc.hsv_from_rgbx(exhaustive)
+    diff = got.view(np.uint32) != expect.view(np.uint32)
+    # +0.0 vs -0.0 would be a bit difference without being a value difference
+    diff &= ~((got == 0) & (expect == 0))
+    assert np.count_nonzero(diff) == 0, f"{np.count_nonzero(diff)} f32 values differ"
+
+
+ALL_FILTER_FORMATS = ["RGBx", "xRGB", "BGRx", "xBGR", "RGBA", "ARGB", "BGRA", "ABGR", "RGB", "BGR"]
+
+
+@pytest.mark.parametrize("fmt", ALL_FILTER_FORMATS)
+@pytest.mark.parametrize("geom", [(64, 48, 0), (641, 37, 0), (67, 33, 12), (1, 1, 0), (3, 5, 4), (1918, 9, 0)],
+                         ids=lambda g: f"{g[0]}x{g[1]}+pad{g[2]}")
+def test_hsvfilter_formats_and_strides(gpu, fmt, geom):
+    """Every format, odd widths, row padding (must stay untouched), host entry point."""
+    w, h, pad = geom
+    bpp = 3 if fmt in ("RGB", "BGR") else 4
+    stride = (w * bpp + 3) // 4 * 4 + pad
+    if (stride * h) % bpp != 0:
+        pytest.skip("reference asserts on this size (covered by test_reference_panic_sizes)")
+    frame = frames.random_frame(0x5EED0100 + w * 131 + h, w, h, bpp, stride)
+    for settings in (BENCH_SETTINGS, (0.0, 1.0, 0.0, 1.0, 0.0), (720.5, 0.7, 0.1, 1.2, -0.1)):
+        expect = frame.copy()
+        assert orc.hsvfilter(expect, w, stride, fmt, settings) == 0
+        got = frame.copy()
+        gpu.hsvfilter_host(got.reshape(-1), w, h, stride, fmt, gpu.HsvFilterSettings(*settings))
+        assert np.array_equal(got, expect), f"{fmt} {geom} {settings}"
+
+
+@pytest.mark.parametrize("fmt", ["RGBA", "BGR"])
+def test_hsvfilter_unaligned_base(gpu, fmt):
+    """Plane pointer not 16-byte (or even 4-byte) aligned: dword / byte kernels, same result."""
+    w, h = 124, 17
+    bpp = 3 if fmt == "BGR" else 4
+    stride = w * bpp  # 496 / 372: multiple of 4, and stride*h is a multiple of bpp
+    frame = frames.random_frame(0x5EED0777, w, h, bpp, stride)
+    expect = frame.copy()
+    assert orc.hsvfilter(expect, w, stride, fmt, BENCH_SETTINGS) == 0
+    for offset in (4, 1):
+        buf = gpu.DeviceBuffer(frame.nbytes + 64)
+        host = np.zeros(frame.nbytes + 64, dtype=np.uint8)
+        host[offset:offset + frame.nbytes] = frame.reshape(-1)
+        buf.upload(host)
+        gpu.hsvfilter_device(buf.ptr + offset, w, h, stride, fmt, gpu.HsvFilterSettings(*BENCH_SETTINGS))
+        gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+        out = buf.download()
+        assert np.array_equal(out[offset:offset + frame.nbytes], expect.reshape(-1))
+        assert not out[:offset].any() and not out[offset + frame.nbytes:].any()
+
+
+def test_hsvfilter_batch_matches_single(gpu):
+    """The batched entry point == N single-frame calls (33 frames crosses the 32-frame launch split)."""
+    w, h = 256, 64
+    n = 33
+    host = [frames.random_frame(0x5EED0100 + k, w, h) for k in range(n)]
+    bufs = [gpu.DeviceBuffer(f.nbytes).upload(f) for f in host]
+    gpu.hsvfilter_device_batch([b.ptr for b in bufs], w, h, w * 4, "BGRA", gpu.HsvFilterSettings(*BENCH_SETTINGS))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    for k in range(n):
+        expect = host[k].copy()
+        orc.hsvfilter(expect, w, w * 4, "BGRA", BENCH_SETTINGS)
+        assert np.array_equal(bufs[k].download().reshape(h, w * 4), expect), f"frame {k}"
+
+
+def test_hsvfilter_4k_full_size(gpu):
+    """BASELINE config: 3840x2160 RGBA, uniform random + smpte-like, full-frame compare."""
+    w, h = 3840, 2160
+    for frame in (frames.random_frame(0x5EED0001, w, h), frames.smpte_like(w, h)):
+        expect = frame.copy()
+        assert orc.hsvfilter(expect, w, w * 4, "RGBA", BENCH_SETTINGS) == 0
+        got = _device_filter(gpu, frame, w, h, w * 4, "RGBA", BENCH_SETTINGS, 0, batch=True)
+        assert np.array_equal(got, expect)
+
+
+def test_reference_panic_sizes(gpu):
+    """642x481 RGB: stride 1928 * 481 % 3 == 2 -> the reference's assert_eq! fires."""
+    w, h, stride = 642, 481, 1928
+    frame = frames.random_frame(1, w, h, 3, stride)
+    assert orc.hsvfilter(frame.copy(), w, stride, "RGB", BENCH_SETTINGS) == -1
+    f = gpu.make_frame(frame.ctypes.data, w, h, stride, "RGB")
+    rc = gpu.lib().mvfx_hsvfilter_transform_frame_ip_host(ctypes.byref(f), ctypes.byref(gpu.HsvFilterSettings(*BENCH_SETTINGS)))
+    assert rc == gpu.ERR_REFERENCE_PANIC
+    assert "hsvfilter/imp.rs:92" in gpu.last_error()
+
+
+def test_hsvfilter_rejects_bad_arguments(gpu):
+    s = gpu.HsvFilterSettings.default()
+    buf = np.zeros(64, dtype=np.uint8)
+    f = gpu.make_frame(buf.ctypes.data, 4, 4, 16, "RGBA64_LE")
+    assert gpu.lib().mvfx_hsvfilter_transform_frame_ip_host(ctypes.byref(f), ctypes.byref(s)) == gpu.ERR_UNSUPPORTED_FORMAT
+    f = gpu.make_frame(buf.ctypes.data, 8, 4, 16, "RGBA")  # row longer than stride
+    assert gpu.lib().mvfx_hsvfilter_transform_frame_ip_host(ctypes.byref(f), ctypes.byref(s)) == gpu.ERR_INVALID_ARGUMENT
+    f = gpu.make_frame(0, 4, 4, 16, "RGBA")
+    assert gpu.lib().mvfx_hsvfilter_transform_frame_ip_host(ctypes.byref(f), ctypes.byref(s)) == gpu.ERR_INVALID_ARGUMENT
+    f = gpu.make_frame(buf.ctypes.data, 0, 0, 16, "RGBA")  # empty frame is a no-op
+    assert gpu.lib().mvfx_hsvfilter_transform_frame_ip_host(ctypes.byref(f), ctypes.byref(s)) == gpu.OK
+
+
+# ---------------------------------------------------------------- hsvdetector
+
+DETECT_SETTINGS = [
+    (0.0, 10.0, 0.0, 0.15, 0.0, 0.3),           # defaults
+    (120.0, 40.0, 0.6, 0.4, 0.6, 0.4),          # bench settings
+    (350.0, 25.0, 0.5, 0.5, 0.5, 0.5),          # wraps through 0
+    (-200.0, 180.0, 1.0, 1.0, 1.0, 1.0),        # everything matches
+    (1e6, 90.0, 0.5, 0.3, 0.5, 0.3),            # huge hue_ref -> general fmod
+    (float("nan"), 10.0, 0.0, 0.15, 0.0, 0.3),  # nothing matches
+]
+DET_IN = ["RGBx", "xRGB", "BGRx", "xBGR", "RGB", "BGR"]
+DET_OUT = ["RGBA", "ARGB", "BGRA", "ABGR"]
+
+
+@pytest.mark.parametrize("in_fmt", DET_IN)
+@pytest.mark.parametrize("out_fmt", DET_OUT)
+def test_hsvdetector_all_24_pairs(gpu, in_fmt, out_fmt):
+    for (w, h, pad) in ((64, 16, 0), (45, 7, 8)):
+        bpp = 3 if in_fmt in ("RGB", "BGR") else 4
+        in_stride = (w * bpp + 3) // 4 * 4 + pad
+        while (in_stride * h) % bpp:
+            in_stride += 4
+        out_stride = w * 4 + pad
+        src = frames.random_frame(0x5EED0200 + w, w, h, bpp, in_stride)
+        for settings in DETECT_SETTINGS[:3]:
+            sentinel = np.full((h, out_stride), 0xA5, dtype=np.uint8)
+            expect = sentinel.copy()
+            assert orc.hsvdetector(src, in_stride, in_fmt, expect, out_stride, out_fmt, w, settings) == 0
+            got = sentinel.copy()
+            gpu.hsvdetector_host(src.reshape(-1), in_stride, in_fmt, got.reshape(-1), out_stride, out_fmt, w, h,
+                                 gpu.HsvDetectorSettings(*settings))
+            assert np.array_equal(got, expect), f"{in_fmt}->{out_fmt} {w}x{h} {settings}"
+
+
+@pytest.mark.parametrize("settings", DETECT_SETTINGS)
+@pytest.mark.parametrize("variant", [0, 1], ids=["auto", "general"])
+def test_hsvdetector_exhaustive(gpu, exhaustive, settings, variant):
+    """All 2^24 triples RGBx -> RGBA: colour copied, alpha 0/255 exactly as the reference."""
+    expect = np.empty_like(exhaustive)
+    assert orc.hsvdetector(exhaustive, 4096 * 4, "RGBx", expect, 4096 * 4, "RGBA", 4096, settings) == 0
+    src = gpu.DeviceBuffer(exhaustive.nbytes).upload(exhaustive)
+    dst = gpu.DeviceBuffer(exhaustive.nbytes)
+    fi = gpu.make_frame(src.ptr, 4096, 4096, 4096 * 4, "RGBx")
+    fo = gpu.make_frame(dst.ptr, 4096, 4096, 4096 * 4, "RGBA")
+    gpu.lib().mvfx_hsvfilter_set_variant(variant)
+    try:
+        gpu.check(gpu.lib().mvfx_hsvdetector_transform_frame(ctypes.byref(fi), ctypes.byref(fo),
+                                                             ctypes.byref(gpu.HsvDetectorSettings(*settings)), None))
+        gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    finally:
+        gpu.lib().mvfx_hsvfilter_set_variant(0)
+    got = dst.download().reshape(exhaustive.shape)
+    assert np.array_equal(got, expect)
+    if not np.isnan(settings[0]):
+        assert got[:, 3::4].max() == 255  # the settings do select something
+
+
+def test_hsvdetector_1080p_after_hsvfilter(gpu):
+    """BASELINE config 2: hsvfilter (RGBx, in place) then hsvdetector RGBx->RGBA at 1920x1080."""
+    w, h = 1920, 1080
+    frame = frames.random_frame(0x5EED0002, w, h)
+    expect_mid = frame.copy()
+    orc.hsvfilter(expect_mid, w, w * 4, "RGBx", BENCH_SETTINGS)
+    expect = np.empty_like(frame)
+    orc.hsvdetector(expect_mid, w * 4, "RGBx", expect, w * 4, "RGBA", w, DETECT_SETTINGS[1])
+    src = gpu.DeviceBuffer(frame.nbytes).upload(frame)
+    dst = gpu.DeviceBuffer(frame.nbytes)
+    gpu.hsvfilter_device(src.ptr, w, h, w * 4, "RGBx", gpu.HsvFilterSettings(*BENCH_SETTINGS))
+    fi = gpu.make_frame(src.ptr, w, h, w * 4, "RGBx")
+    fo = gpu.make_frame(dst.ptr, w, h, w * 4, "RGBA")
+    gpu.check(gpu.lib().mvfx_hsvdetector_transform_frame(ctypes.byref(fi), ctypes.byref(fo),
+                                                         ctypes.byref(gpu.HsvDetectorSettings(*DETECT_SETTINGS[1])), None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    assert np.array_equal(src.download().reshape(h, w * 4), expect_mid)
+    assert np.array_equal(dst.download().reshape(h, w * 4), expect)
+
+
+def test_hsvdetector_size_mismatch(gpu):
+    a = np.zeros(64, dtype=np.uint8)
+    fi = gpu.make_frame(a.ctypes.data, 4, 4, 16, "RGBx")
+    fo = gpu.make_frame(a.ctypes.data, 4, 2, 16, "RGBA")
+    rc = gpu.lib().mvfx_hsvdetector_transform_frame_host(ctypes.byref(fi), ctypes.byref(fo),
+                                                         ctypes.byref(gpu.HsvDetectorSettings.default()))
+    assert rc == gpu.ERR_NOT_NEGOTIATED
+    fo = gpu.make_frame(a.ctypes.data, 4, 4, 16, "RGBx")  # RGBx is not an output format
+    rc = gpu.lib().mvfx_hsvdetector_transform_frame_host(ctypes.byref(fi), ctypes.byref(fo),
+                                                         ctypes.byref(gpu.HsvDetectorSettings.default()))
+    assert rc == gpu.ERR_UNSUPPORTED_FORMAT
