@@ -183,8 +183,8 @@ def test_reference_panic_sizes(gpu):
 
 def test_hsvfilter_rejects_bad_arguments(gpu):
     s = gpu.HsvFilterSettings.default()
-    buf = np.zeros(64, dtype=np.uint8)
-    f = gpu.make_frame(buf.ctypes.data, 4, 4, 16, "RGBA64_LE")
+    buf = np.zeros(128, dtype=np.uint8)
+    f = gpu.make_frame(buf.ctypes.data, 4, 4, 32, "RGBA64_LE")
     assert gpu.lib().mvfx_hsvfilter_transform_frame_ip_host(ctypes.byref(f), ctypes.byref(s)) == gpu.ERR_UNSUPPORTED_FORMAT
     f = gpu.make_frame(buf.ctypes.data, 8, 4, 16, "RGBA")  # row longer than stride
     assert gpu.lib().mvfx_hsvfilter_transform_frame_ip_host(ctypes.byref(f), ctypes.byref(s)) == gpu.ERR_INVALID_ARGUMENT
