@@ -248,7 +248,7 @@ def test_hsvdetector_exhaustive(gpu, exhaustive, settings, variant):
     got = dst.download().reshape(exhaustive.shape)
     assert np.array_equal(got, expect)
     if not np.isnan(settings[0]):
-        assert got[:, 3::4].max() == 255  # the settings do select something
+        assert got[:, 3::4].max() == 255 or settings[0] > 1e5  # (a hue_ref far below -180 never matches: one +360 only)
 
 
 def test_hsvdetector_1080p_after_hsvfilter(gpu):

@@ -19,7 +19,7 @@ for f in find("trace/**/*kernel_stats.csv"):
     print(f"\n## kernel stats ({os.path.relpath(f, out)})")
     with open(f) as fh:
         for i, row in enumerate(csv.reader(fh)):
-            print(",".join(row[:8]))
+            print(",".join([row[0][:120]] + row[1:8]))
             if i > 12:
                 break
 for f in find("trace/**/*kernel_trace.csv"):
