@@ -95,6 +95,17 @@ SIGNATURES = {
     "mvfx_hsvdetector_transform_frame": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(HsvDetectorSettings), c_void_p]),
     "mvfx_hsvdetector_transform_frame_host": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(HsvDetectorSettings)]),
     "mvfx_hsv_from_frame": (c_int, [POINTER(Frame), c_void_p, c_void_p]),
+    "mvfx_cube_lut_parse": (c_int, [c_char_p, c_size_t, POINTER(c_void_p)]),
+    "mvfx_cube_lut_parse_file": (c_int, [c_char_p, POINTER(c_void_p)]),
+    "mvfx_cube_lut_free": (None, [c_void_p]),
+    "mvfx_cube_lut_is_3d": (c_int, [c_void_p]),
+    "mvfx_cube_lut_size": (c_uint32, [c_void_p]),
+    "mvfx_cube_lut_domain": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float)]),
+    "mvfx_cube_lut_rgba": (POINTER(c_float), [c_void_p]),
+    "mvfx_cube_lut_table_1d": (POINTER(c_float), [c_void_p, c_int]),
+    "mvfx_colorlut_transform_frame": (c_int, [c_void_p, POINTER(Frame), POINTER(Frame), c_void_p]),
+    "mvfx_colorlut_transform_frame_host": (c_int, [c_void_p, POINTER(Frame), POINTER(Frame)]),
+    "mvfx_colorlut_set_placement": (c_int, [c_int]),
 }
 
 
@@ -192,3 +203,63 @@ def hsvdetector_host(in_bytes, in_stride, in_fmt, out_bytes, out_stride, out_fmt
     fo = make_frame(out_bytes.ctypes.data, width, height, out_stride, out_fmt)
     check(lib().mvfx_hsvdetector_transform_frame_host(ctypes.byref(fi), ctypes.byref(fo), ctypes.byref(settings)))
     return out_bytes
+
+
+class CubeLut:
+    """mvfx_cube_lut handle (colorlut's parsed .cube); parse errors raise MvfxError."""
+
+    def __init__(self, text=None, path=None):
+        h = c_void_p()
+        if path is not None:
+            check(lib().mvfx_cube_lut_parse_file(os.fsencode(path), ctypes.byref(h)))
+        else:
+            raw = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+            check(lib().mvfx_cube_lut_parse(raw, len(raw), ctypes.byref(h)))
+        self.h = h
+
+    @property
+    def is_3d(self):
+        return bool(lib().mvfx_cube_lut_is_3d(self.h))
+
+    @property
+    def size(self):
+        return lib().mvfx_cube_lut_size(self.h)
+
+    def domain(self):
+        import numpy as np
+        sc = (c_float * 3)()
+        of = (c_float * 3)()
+        check(lib().mvfx_cube_lut_domain(self.h, sc, of))
+        return np.array(list(sc), dtype=np.float32), np.array(list(of), dtype=np.float32)
+
+    def rgba(self):
+        import numpy as np
+        p = lib().mvfx_cube_lut_rgba(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.size ** 3 * 4,)).reshape(-1, 4).copy()
+
+    def table(self, c):
+        import numpy as np
+        p = lib().mvfx_cube_lut_table_1d(self.h, c)
+        return np.ctypeslib.as_array(p, shape=(self.size,)).copy()
+
+    def apply_host(self, src, src_stride, dst, dst_stride, width, height, fmt):
+        fi = make_frame(src.ctypes.data, width, height, src_stride, fmt)
+        fo = make_frame(dst.ctypes.data, width, height, dst_stride, fmt)
+        check(lib().mvfx_colorlut_transform_frame_host(self.h, ctypes.byref(fi), ctypes.byref(fo)))
+        return dst
+
+    def apply_device(self, src_ptr, src_stride, dst_ptr, dst_stride, width, height, fmt, stream=None):
+        fi = make_frame(src_ptr, width, height, src_stride, fmt)
+        fo = make_frame(dst_ptr, width, height, dst_stride, fmt)
+        check(lib().mvfx_colorlut_transform_frame(self.h, ctypes.byref(fi), ctypes.byref(fo), stream))
+
+    def free(self):
+        if getattr(self, "h", None):
+            lib().mvfx_cube_lut_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,533 @@
+// colorlut kernels for gfx950 + C ABI (parsing lives in host/cube_parser.cpp).
+//
+// Replaces video/colorlut/src/colorlut/imp.rs:226-543:
+//   transform_rgba_{1d,3d}, transform_rgba64_{1d,3d}<LE>, apply_*, norm_comp*, sample_1d,
+//   sample_3d, lerp4, float_to_u8/u16.
+// Arithmetic is transcribed literally (one rounding per op, no FMA contraction, std clamp with
+// NaN propagation, round-half-away, saturating casts); only u8/255 and u16/65535 use the
+// mul+fma+fma form proven exact in tools/prove_exact.c (P1, P6).
+//
+// Data layout: the 3-D cube stays in the reference's layout ([r,g,b,1.0] float4 per node,
+// R fastest, parser.rs:43-53) so a corner is ONE aligned 16-byte gather and the x0/x1 pair of a
+// cell is 32 contiguous bytes.  A 33^3 cube is 575 KB: it does not fit the 160 KB LDS
+//  but is resident in every XCD's 4 MiB L2 after first touch.  Cubes with
+// size <= 21 (148 KB as float4) are staged in LDS instead (one 1024-thread workgroup per CU
+// walking the frame), which turns the 8 gathers into ds_read_b128.
+// 1-D tables (<= 65536 entries x 3) are read from global/L2; tables with size <= 4096 are staged
+// in LDS.
+// Pixels: RGBA8 -> one lane owns 4 pixels (16 B in, 16 B out); RGBA64 -> 2 pixels (16 B).
+#include "mvfx_internal.h"
+
+#include "cube_parser.h"
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+struct mvfx_cube_lut {
+    mvfx::CubeLut lut;
+    std::mutex mu;
+    int device = -1;       // device the copies below live on
+    float *d_rgba = nullptr;
+    float *d_table[3] = {nullptr, nullptr, nullptr};
+};
+
+namespace mvfx {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kLds3dMaxSize = 21;   // 21^3 * 16 B = 148,176 B
+constexpr uint32_t kLds1dMaxSize = 4096; // 3 * 4096 * 4 B = 48 KB
+constexpr int kLdsBlock = 1024;
+
+struct LutParams {
+    const float4 *cube;   // 3-D nodes
+    const float *t[3];    // 1-D tables
+    uint32_t size;
+    float size_m1;        // `size as f32 - 1.0` (imp.rs:408, :438)
+    float scale[3], offset[3];
+};
+
+// f32::clamp(0.0, 1.0): NaN propagates (imp.rs:473, :478, :538, :542)
+__device__ __forceinline__ float std_clamp01(float v)
+{
+    v = (v < 0.0f) ? 0.0f : v;
+    v = (v > 1.0f) ? 1.0f : v;
+    return v;
+}
+
+__device__ __forceinline__ float div255_exact(float x) // prove_exact P1
+{
+    const float c = 1.0f / 255.0f;
+    const float q0 = x * c;
+    return __builtin_fmaf(__builtin_fmaf(-255.0f, q0, x), c, q0);
+}
+
+__device__ __forceinline__ float div65535_exact(float x) // prove_exact P6
+{
+    const float c = 1.0f / 65535.0f;
+    const float q0 = x * c;
+    return __builtin_fmaf(__builtin_fmaf(-65535.0f, q0, x), c, q0);
+}
+
+// norm_comp / norm_comp_u16 (imp.rs:471-479) followed by `* (size as f32 - 1.0)`
+template <bool WIDE>
+__device__ __forceinline__ float lattice_coord(uint32_t value, float scale, float offset, float size_m1)
+{
+    const float v = WIDE ? div65535_exact((float)value) : div255_exact((float)value);
+    return std_clamp01(v * scale + offset) * size_m1;
+}
+
+// `(x.floor() as usize).min(max_idx)`: NaN -> 0 (x is never negative here)
+__device__ __forceinline__ uint32_t lattice_index(float x, uint32_t max_idx)
+{
+    const float f = floorf(x);
+    const uint32_t i = (f == f) ? (uint32_t)__float2uint_rz(fmaxf(f, 0.0f)) : 0u;
+    return min(i, max_idx);
+}
+
+// f32::round(): half away from zero.  v is in [0, 65535] or NaN.
+__device__ __forceinline__ float round_half_away(float v)
+{
+    const float t = truncf(v);
+    return (v - t >= 0.5f) ? t + 1.0f : t; // v - t is exact; NaN compares false and t is NaN
+}
+
+// float_to_u8 / float_to_u16 (imp.rs:537-543)
+template <bool WIDE>
+__device__ __forceinline__ uint32_t float_to_unorm(float v)
+{
+    const float r = round_half_away(std_clamp01(v) * (WIDE ? 65535.0f : 255.0f));
+    return (r == r) ? (uint32_t)__float2uint_rz(r) : 0u; // NaN as u8 == 0
+}
+
+__device__ __forceinline__ float lerp(float a, float b, float t) { return a + (b - a) * t; } // imp.rs:528-535
+
+// sample_1d (imp.rs:482-490); TABLE is a global or LDS pointer
+template <typename TABLE>
+__device__ __forceinline__ float sample_1d(TABLE lut, uint32_t max_idx, float x)
+{
+    const uint32_t x0 = lattice_index(x, max_idx);
+    const uint32_t x1 = min(x0 + 1, max_idx);
+    const float t = x - (float)x0;
+    const float a = lut[x0], b = lut[x1];
+    return a + (b - a) * t;
+}
+
+// sample_3d (imp.rs:493-526), RGB lanes only (the alpha lane of lerp4 is never read)
+template <typename CUBE>
+__device__ __forceinline__ void sample_3d(CUBE cube, uint32_t size, float x, float y, float z,
+                                          float &r, float &g, float &b)
+{
+    const uint32_t max_idx = size - 1;
+    const uint32_t x0 = lattice_index(x, max_idx), y0 = lattice_index(y, max_idx), z0 = lattice_index(z, max_idx);
+    const uint32_t x1 = min(x0 + 1, max_idx), y1 = min(y0 + 1, max_idx), z1 = min(z0 + 1, max_idx);
+    const float tx = x - (float)x0, ty = y - (float)y0, tz = z - (float)z0;
+    const uint32_t s2 = size * size;
+    const uint32_t r00 = y0 * size + z0 * s2, r10 = y1 * size + z0 * s2;
+    const uint32_t r01 = y0 * size + z1 * s2, r11 = y1 * size + z1 * s2;
+    const float4 c000 = cube[x0 + r00], c100 = cube[x1 + r00];
+    const float4 c010 = cube[x0 + r10], c110 = cube[x1 + r10];
+    const float4 c001 = cube[x0 + r01], c101 = cube[x1 + r01];
+    const float4 c011 = cube[x0 + r11], c111 = cube[x1 + r11];
+#define MVFX_TRI(ch)                                                                           \
+    lerp(lerp(lerp(c000.ch, c100.ch, tx), lerp(c010.ch, c110.ch, tx), ty),                     \
+         lerp(lerp(c001.ch, c101.ch, tx), lerp(c011.ch, c111.ch, tx), ty), tz)
+    r = MVFX_TRI(x);
+    g = MVFX_TRI(y);
+    b = MVFX_TRI(z);
+#undef MVFX_TRI
+}
+
+__device__ __forceinline__ uint32_t bswap16(uint32_t v) { return ((v & 0xffu) << 8) | ((v >> 8) & 0xffu); }
+
+// One RGBA8 pixel (dword) through the LUT; alpha byte copied (imp.rs:262, :291)
+template <bool IS3D, typename CUBE, typename TABLE>
+__device__ __forceinline__ uint32_t lut_px8(uint32_t px, const LutParams &p, CUBE cube, TABLE t0, TABLE t1, TABLE t2)
+{
+    const float x = lattice_coord<false>(px & 0xffu, p.scale[0], p.offset[0], p.size_m1);
+    const float y = lattice_coord<false>((px >> 8) & 0xffu, p.scale[1], p.offset[1], p.size_m1);
+    const float z = lattice_coord<false>((px >> 16) & 0xffu, p.scale[2], p.offset[2], p.size_m1);
+    float r, g, b;
+    if constexpr (IS3D) {
+        sample_3d(cube, p.size, x, y, z, r, g, b);
+    } else {
+        r = sample_1d(t0, p.size - 1, x);
+        g = sample_1d(t1, p.size - 1, y);
+        b = sample_1d(t2, p.size - 1, z);
+    }
+    return float_to_unorm<false>(r) | (float_to_unorm<false>(g) << 8) | (float_to_unorm<false>(b) << 16) |
+           (px & 0xff000000u);
+}
+
+// One RGBA64 pixel (two dwords: [r,g] [b,a]); per-sample endian swap, alpha word copied raw
+template <bool IS3D, bool LE, typename CUBE, typename TABLE>
+__device__ __forceinline__ void lut_px16(uint32_t &w0, uint32_t &w1, const LutParams &p, CUBE cube, TABLE t0, TABLE t1, TABLE t2)
+{
+    uint32_t rv = w0 & 0xffffu, gv = w0 >> 16, bv = w1 & 0xffffu;
+    if constexpr (!LE) { rv = bswap16(rv); gv = bswap16(gv); bv = bswap16(bv); }
+    const float x = lattice_coord<true>(rv, p.scale[0], p.offset[0], p.size_m1);
+    const float y = lattice_coord<true>(gv, p.scale[1], p.offset[1], p.size_m1);
+    const float z = lattice_coord<true>(bv, p.scale[2], p.offset[2], p.size_m1);
+    float r, g, b;
+    if constexpr (IS3D) {
+        sample_3d(cube, p.size, x, y, z, r, g, b);
+    } else {
+        r = sample_1d(t0, p.size - 1, x);
+        g = sample_1d(t1, p.size - 1, y);
+        b = sample_1d(t2, p.size - 1, z);
+    }
+    uint32_t ro = float_to_unorm<true>(r), go = float_to_unorm<true>(g), bo = float_to_unorm<true>(b);
+    if constexpr (!LE) { ro = bswap16(ro); go = bswap16(go); bo = bswap16(bo); }
+    w0 = ro | (go << 16);
+    w1 = bo | (w1 & 0xffff0000u);
+}
+
+// Processes row `row` of a frame; one lane = 16 bytes (4 RGBA8 or 2 RGBA64 pixels) when VEC.
+template <bool IS3D, bool WIDE, bool LE, bool VEC, typename CUBE, typename TABLE>
+__device__ __forceinline__ void lut_rows(const uint8_t *in, uint8_t *out, uint64_t width, uint32_t rows,
+                                         uint64_t in_stride, uint64_t out_stride, const LutParams &p,
+                                         CUBE cube, TABLE t0, TABLE t1, TABLE t2, uint32_t first_group,
+                                         uint32_t group_stride, uint32_t first_row, uint32_t row_stride)
+{
+    constexpr uint32_t PXV = WIDE ? 2 : 4; // pixels per 16-byte vector
+    constexpr uint32_t BPP = WIDE ? 8 : 4;
+    for (uint32_t row = first_row; row < rows; row += row_stride) {
+        const uint8_t *iline = in + (uint64_t)row * in_stride;
+        uint8_t *oline = out + (uint64_t)row * out_stride;
+        if constexpr (VEC) {
+            const uint64_t groups = (width + PXV - 1) / PXV;
+            for (uint64_t g = first_group; g < groups; g += group_stride) {
+                const uint64_t x = g * PXV;
+                if (x + PXV <= width) {
+                    uint4 v = *reinterpret_cast<const uint4 *>(iline + x * BPP);
+                    if constexpr (WIDE) {
+                        lut_px16<IS3D, LE>(v.x, v.y, p, cube, t0, t1, t2);
+                        lut_px16<IS3D, LE>(v.z, v.w, p, cube, t0, t1, t2);
+                    } else {
+                        v.x = lut_px8<IS3D>(v.x, p, cube, t0, t1, t2);
+                        v.y = lut_px8<IS3D>(v.y, p, cube, t0, t1, t2);
+                        v.z = lut_px8<IS3D>(v.z, p, cube, t0, t1, t2);
+                        v.w = lut_px8<IS3D>(v.w, p, cube, t0, t1, t2);
+                    }
+                    *reinterpret_cast<uint4 *>(oline + x * BPP) = v;
+                } else {
+                    for (uint64_t xx = x; xx < width; xx++) {
+                        const uint32_t *q = reinterpret_cast<const uint32_t *>(iline + xx * BPP);
+                        uint32_t *o = reinterpret_cast<uint32_t *>(oline + xx * BPP);
+                        if constexpr (WIDE) {
+                            uint32_t w0 = q[0], w1 = q[1];
+                            lut_px16<IS3D, LE>(w0, w1, p, cube, t0, t1, t2);
+                            o[0] = w0; o[1] = w1;
+                        } else {
+                            o[0] = lut_px8<IS3D>(q[0], p, cube, t0, t1, t2);
+                        }
+                    }
+                }
+            }
+        } else { // byte-granular fallback for unaligned planes
+            for (uint64_t x = first_group; x < width; x += group_stride) {
+                const uint8_t *q = iline + x * BPP;
+                uint8_t *o = oline + x * BPP;
+                if constexpr (WIDE) {
+                    uint32_t w0 = q[0] | (q[1] << 8) | (q[2] << 16) | ((uint32_t)q[3] << 24);
+                    uint32_t w1 = q[4] | (q[5] << 8) | (q[6] << 16) | ((uint32_t)q[7] << 24);
+                    lut_px16<IS3D, LE>(w0, w1, p, cube, t0, t1, t2);
+                    for (int i = 0; i < 4; i++) { o[i] = (uint8_t)(w0 >> (8 * i)); o[4 + i] = (uint8_t)(w1 >> (8 * i)); }
+                } else {
+                    const uint32_t px = q[0] | (q[1] << 8) | (q[2] << 16) | ((uint32_t)q[3] << 24);
+                    const uint32_t r = lut_px8<IS3D>(px, p, cube, t0, t1, t2);
+                    for (int i = 0; i < 4; i++) o[i] = (uint8_t)(r >> (8 * i));
+                }
+            }
+        }
+    }
+}
+
+// LUT read from global memory (L2-resident)
+template <bool IS3D, bool WIDE, bool LE, bool VEC>
+__global__ __launch_bounds__(kBlock) void colorlut_global_kernel(const uint8_t *in, uint8_t *out, uint64_t width,
+                                                                 uint32_t rows, uint64_t in_stride,
+                                                                 uint64_t out_stride, LutParams p)
+{
+    lut_rows<IS3D, WIDE, LE, VEC>(in, out, width, rows, in_stride, out_stride, p, p.cube, p.t[0], p.t[1], p.t[2],
+                                  blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, blockIdx.y, gridDim.y);
+}
+
+// LUT staged in LDS: persistent 1024-thread workgroups (one per CU) walk the frame
+template <bool IS3D, bool WIDE, bool LE, bool VEC>
+__global__ __launch_bounds__(kLdsBlock) void colorlut_lds_kernel(const uint8_t *in, uint8_t *out, uint64_t width,
+                                                                 uint32_t rows, uint64_t in_stride,
+                                                                 uint64_t out_stride, LutParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    if constexpr (IS3D) {
+        float4 *cube = reinterpret_cast<float4 *>(lds_raw);
+        const uint32_t n = p.size * p.size * p.size;
+        for (uint32_t i = threadIdx.x; i < n; i += kLdsBlock)
+            cube[i] = p.cube[i];
+        __syncthreads();
+        lut_rows<IS3D, WIDE, LE, VEC>(in, out, width, rows, in_stride, out_stride, p, (const float4 *)cube,
+                                      (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                                      blockIdx.x * kLdsBlock + threadIdx.x, gridDim.x * kLdsBlock, blockIdx.y, gridDim.y);
+    } else {
+        float *t = reinterpret_cast<float *>(lds_raw);
+        for (uint32_t i = threadIdx.x; i < p.size; i += kLdsBlock) {
+            t[i] = p.t[0][i];
+            t[p.size + i] = p.t[1][i];
+            t[2 * p.size + i] = p.t[2][i];
+        }
+        __syncthreads();
+        lut_rows<IS3D, WIDE, LE, VEC>(in, out, width, rows, in_stride, out_stride, p, (const float4 *)nullptr,
+                                      (const float *)t, (const float *)(t + p.size), (const float *)(t + 2 * p.size),
+                                      blockIdx.x * kLdsBlock + threadIdx.x, gridDim.x * kLdsBlock, blockIdx.y, gridDim.y);
+    }
+}
+
+int g_lut_placement = 0; // 0 auto, 1 force global, 2 force LDS (tests / A-B)
+
+int ensure_uploaded(mvfx_cube_lut *h)
+{
+    int dev = 0;
+    MVFX_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (h->device == dev && (h->d_rgba || h->d_table[0]))
+        return MVFX_OK;
+    // (re)upload for this device
+    if (h->d_rgba) { (void)hipFree(h->d_rgba); h->d_rgba = nullptr; }
+    for (auto &t : h->d_table) if (t) { (void)hipFree(t); t = nullptr; }
+    const CubeLut &l = h->lut;
+    if (l.is_3d) {
+        const size_t bytes = l.rgba.size() * sizeof(float);
+        MVFX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_rgba), bytes));
+        MVFX_HIP_TRY(hipMemcpy(h->d_rgba, l.rgba.data(), bytes, hipMemcpyHostToDevice));
+    } else {
+        for (int c = 0; c < 3; c++) {
+            const size_t bytes = l.table[c].size() * sizeof(float);
+            MVFX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_table[c]), bytes));
+            MVFX_HIP_TRY(hipMemcpy(h->d_table[c], l.table[c].data(), bytes, hipMemcpyHostToDevice));
+        }
+    }
+    h->device = dev;
+    return MVFX_OK;
+}
+
+template <bool IS3D, bool WIDE, bool LE, bool VEC>
+int launch_one(bool use_lds, dim3 grid, size_t lds_bytes, hipStream_t st, const uint8_t *in, uint8_t *out,
+               uint64_t width, uint32_t rows, uint64_t is, uint64_t os, const LutParams &p)
+{
+    if (use_lds) {
+        auto k = colorlut_lds_kernel<IS3D, WIDE, LE, VEC>;
+        MVFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds_bytes));
+        hipLaunchKernelGGL(k, grid, dim3(kLdsBlock), lds_bytes, st, in, out, width, rows, is, os, p);
+    } else {
+        hipLaunchKernelGGL((colorlut_global_kernel<IS3D, WIDE, LE, VEC>), grid, dim3(kBlock), 0, st, in, out, width,
+                           rows, is, os, p);
+    }
+    MVFX_HIP_TRY(hipGetLastError());
+    return MVFX_OK;
+}
+
+int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *in, const mvfx_frame *out, hipStream_t st)
+{
+    if (!h)
+        return fail(MVFX_ERR_NO_LUT, "colorlut: No LUT configured (colorlut/imp.rs:209-213)");
+    if (!in || !out)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: NULL frame");
+    if (in->format != MVFX_FORMAT_RGBA && in->format != MVFX_FORMAT_RGBA64_LE && in->format != MVFX_FORMAT_RGBA64_BE)
+        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "colorlut: format %d is not RGBA / RGBA64_LE / RGBA64_BE (colorlut/imp.rs:122-134)", in->format);
+    if (out->format != in->format)
+        return fail(MVFX_ERR_NOT_NEGOTIATED, "colorlut: input and output formats differ");
+    if (int rc = check_packed_frame(in, "colorlut input"); rc != MVFX_OK) return rc;
+    if (int rc = check_packed_frame(out, "colorlut output"); rc != MVFX_OK) return rc;
+    if (in->width != out->width || in->height != out->height)
+        return fail(MVFX_ERR_NOT_NEGOTIATED, "colorlut: input %ux%u and output %ux%u differ", in->width, in->height, out->width, out->height);
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    if (in->width == 0 || in->height == 0)
+        return MVFX_OK;
+    if (int rc = ensure_uploaded(h); rc != MVFX_OK) return rc;
+
+    const CubeLut &l = h->lut;
+    LutParams p{};
+    p.cube = reinterpret_cast<const float4 *>(h->d_rgba);
+    for (int c = 0; c < 3; c++) {
+        p.t[c] = h->d_table[c];
+        p.scale[c] = l.domain_scale[c];
+        p.offset[c] = l.domain_offset[c];
+    }
+    p.size = l.size;
+    p.size_m1 = (float)l.size - 1.0f;
+
+    const bool wide = in->format != MVFX_FORMAT_RGBA;
+    const bool le = in->format != MVFX_FORMAT_RGBA64_BE;
+    const uint32_t bpp = wide ? 8 : 4, pxv = wide ? 2 : 4;
+    const bool flat = (uint64_t)in->width * bpp == in->stride && (uint64_t)out->width * bpp == out->stride;
+    uint64_t width = in->width, is = in->stride, os = out->stride;
+    uint32_t rows = in->height;
+    uint64_t align_or = (uint64_t)(uintptr_t)in->data | (uint64_t)(uintptr_t)out->data;
+    if (flat) { width = (uint64_t)in->width * in->height; rows = 1; is = os = 0; }
+    else align_or |= is | os;
+    const bool vec = (align_or & 15) == 0;
+
+    bool use_lds = l.is_3d ? l.size <= kLds3dMaxSize : l.size <= kLds1dMaxSize;
+    if (g_lut_placement == 1) use_lds = false;
+    if (g_lut_placement == 2 && !use_lds)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: LUT of size %u does not fit in LDS", l.size);
+    const size_t lds_bytes = l.is_3d ? (size_t)l.size * l.size * l.size * 16 : (size_t)l.size * 12;
+
+    const uint64_t work = vec ? (width + pxv - 1) / pxv : width;
+    dim3 grid;
+    if (use_lds) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        uint64_t bx = (work + kLdsBlock - 1) / kLdsBlock;
+        if (bx > (uint64_t)cus) bx = (uint64_t)cus; // persistent: one workgroup per CU pays the LDS fill once
+        const uint32_t by = rows > 1 ? 1 : 1;
+        grid = dim3((uint32_t)bx, by, 1);
+        if (rows > 1) { // row-structured frame: spread workgroups over rows instead
+            grid = dim3(1, rows < (uint32_t)cus ? rows : (uint32_t)cus, 1);
+        }
+    } else {
+        uint64_t bx = (work + kBlock - 1) / kBlock;
+        if (bx > 65535u * 16u) bx = 65535u * 16u;
+        grid = dim3((uint32_t)bx, rows < 65535u ? rows : 65535u, 1);
+    }
+    const uint8_t *ip = static_cast<const uint8_t *>(in->data);
+    uint8_t *op = static_cast<uint8_t *>(out->data);
+
+#define MVFX_GO(IS3D, WIDE, LE, VEC) \
+    return launch_one<IS3D, WIDE, LE, VEC>(use_lds, grid, lds_bytes, st, ip, op, width, rows, is, os, p)
+    if (l.is_3d) {
+        if (!wide) { if (vec) MVFX_GO(true, false, true, true); else MVFX_GO(true, false, true, false); }
+        else if (le) { if (vec) MVFX_GO(true, true, true, true); else MVFX_GO(true, true, true, false); }
+        else { if (vec) MVFX_GO(true, true, false, true); else MVFX_GO(true, true, false, false); }
+    } else {
+        if (!wide) { if (vec) MVFX_GO(false, false, true, true); else MVFX_GO(false, false, true, false); }
+        else if (le) { if (vec) MVFX_GO(false, true, true, true); else MVFX_GO(false, true, true, false); }
+        else { if (vec) MVFX_GO(false, true, false, true); else MVFX_GO(false, true, false, false); }
+    }
+#undef MVFX_GO
+}
+
+} // namespace
+} // namespace mvfx
+
+using namespace mvfx;
+
+extern "C" {
+
+int mvfx_cube_lut_parse(const char *text, size_t len, mvfx_cube_lut **out)
+{
+    if (!out || (!text && len))
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "cube_lut_parse: NULL argument");
+    *out = nullptr;
+    auto *h = new (std::nothrow) mvfx_cube_lut();
+    if (!h)
+        return fail(MVFX_ERR_OUT_OF_MEMORY, "cube_lut_parse: out of memory");
+    std::string err;
+    if (!parse_cube(std::string_view(text ? text : "", len), h->lut, err)) {
+        delete h;
+        return fail(MVFX_ERR_PARSE, "Invalid LUT: %s", err.c_str());
+    }
+    *out = h;
+    return MVFX_OK;
+}
+
+int mvfx_cube_lut_parse_file(const char *path, mvfx_cube_lut **out)
+{
+    if (!out || !path)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "cube_lut_parse_file: NULL argument");
+    *out = nullptr;
+    auto *h = new (std::nothrow) mvfx_cube_lut();
+    if (!h)
+        return fail(MVFX_ERR_OUT_OF_MEMORY, "cube_lut_parse_file: out of memory");
+    std::string err;
+    bool io = false;
+    if (!parse_cube_file(path, h->lut, err, io)) {
+        delete h;
+        return fail(io ? MVFX_ERR_IO : MVFX_ERR_PARSE, "Failed to parse LUT file %s: %s", path, err.c_str());
+    }
+    *out = h;
+    return MVFX_OK;
+}
+
+void mvfx_cube_lut_free(mvfx_cube_lut *lut)
+{
+    if (!lut) return;
+    if (lut->d_rgba) (void)hipFree(lut->d_rgba);
+    for (auto &t : lut->d_table) if (t) (void)hipFree(t);
+    delete lut;
+}
+
+int mvfx_cube_lut_is_3d(const mvfx_cube_lut *lut) { return lut && lut->lut.is_3d ? 1 : 0; }
+uint32_t mvfx_cube_lut_size(const mvfx_cube_lut *lut) { return lut ? lut->lut.size : 0; }
+
+int mvfx_cube_lut_domain(const mvfx_cube_lut *lut, float scale[3], float offset[3])
+{
+    if (!lut || !scale || !offset)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "cube_lut_domain: NULL argument");
+    std::memcpy(scale, lut->lut.domain_scale, sizeof(float) * 3);
+    std::memcpy(offset, lut->lut.domain_offset, sizeof(float) * 3);
+    return MVFX_OK;
+}
+
+const float *mvfx_cube_lut_rgba(const mvfx_cube_lut *lut)
+{
+    return lut && lut->lut.is_3d ? lut->lut.rgba.data() : nullptr;
+}
+
+const float *mvfx_cube_lut_table_1d(const mvfx_cube_lut *lut, int channel)
+{
+    if (!lut || lut->lut.is_3d || channel < 0 || channel > 2) return nullptr;
+    return lut->lut.table[channel].data();
+}
+
+int mvfx_colorlut_set_placement(int placement)
+{
+    if (placement < 0 || placement > 2)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut placement must be 0 (auto), 1 (global/L2) or 2 (LDS)");
+    g_lut_placement = placement;
+    return MVFX_OK;
+}
+
+int mvfx_colorlut_transform_frame(mvfx_cube_lut *lut, const mvfx_frame *in_frame, const mvfx_frame *out_frame,
+                                  mvfx_stream stream)
+{
+    return colorlut_impl(lut, in_frame, out_frame, as_stream(stream));
+}
+
+int mvfx_colorlut_transform_frame_host(mvfx_cube_lut *lut, const mvfx_frame *in_frame, const mvfx_frame *out_frame)
+{
+    if (!lut)
+        return fail(MVFX_ERR_NO_LUT, "colorlut: No LUT configured (colorlut/imp.rs:209-213)");
+    if (!in_frame || !out_frame)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: NULL frame");
+    if (int rc = check_packed_frame(in_frame, "colorlut input"); rc != MVFX_OK) return rc;
+    if (int rc = check_packed_frame(out_frame, "colorlut output"); rc != MVFX_OK) return rc;
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    const size_t ib = (size_t)in_frame->stride * in_frame->height;
+    const size_t ob = (size_t)out_frame->stride * out_frame->height;
+    if (ib == 0 || ob == 0)
+        return colorlut_impl(lut, in_frame, out_frame, nullptr);
+    void *din = nullptr, *dout = nullptr;
+    if (int rc = host_scratch(ib, 0, &din); rc != MVFX_OK) return rc;
+    if (int rc = host_scratch(ob, 1, &dout); rc != MVFX_OK) return rc;
+    hipStream_t st = host_stream();
+    MVFX_HIP_TRY(hipMemcpyAsync(din, in_frame->data, ib, hipMemcpyHostToDevice, st));
+    const uint32_t bpp = (uint32_t)bytes_per_pixel(out_frame->format);
+    if ((size_t)out_frame->width * bpp != out_frame->stride) // keep the caller's row padding bytes
+        MVFX_HIP_TRY(hipMemcpyAsync(dout, out_frame->data, ob, hipMemcpyHostToDevice, st));
+    mvfx_frame di = *in_frame, dof = *out_frame;
+    di.data = din;
+    dof.data = dout;
+    if (int rc = colorlut_impl(lut, &di, &dof, st); rc != MVFX_OK) return rc;
+    MVFX_HIP_TRY(hipMemcpyAsync(out_frame->data, dout, ob, hipMemcpyDeviceToHost, st));
+    MVFX_HIP_TRY(hipStreamSynchronize(st));
+    return MVFX_OK;
+}
+
+} // extern "C"

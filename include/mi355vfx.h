@@ -160,6 +160,36 @@ int mvfx_hsvdetector_transform_frame_host(const mvfx_frame *in_frame, const mvfx
  * an element never calls it). */
 int mvfx_hsv_from_frame(const mvfx_frame *frame, float *hsv_out_device, mvfx_stream stream);
 
+/* ---- colorlut : video/colorlut/src/parser.rs + colorlut/imp.rs ----
+ * mvfx_cube_lut mirrors `CubeLut` (parser.rs:68-74): domain_scale/offset + 1-D tables or the
+ * 3-D [r,g,b,1.0] node array, R fastest.  Parsing is host-only (works without a GPU); the device
+ * copy is made lazily by the first transform on each device.  The handle is owned by the
+ * caller: create in `start()` (colorlut/imp.rs:168-194), free in `stop()` (:196-199). */
+typedef struct mvfx_cube_lut mvfx_cube_lut;
+
+/* Replaces CubeLut::parse (parser.rs:110-282).  MVFX_ERR_PARSE + message on rejection. */
+int mvfx_cube_lut_parse(const char *text, size_t len, mvfx_cube_lut **out);
+/* Replaces CubeLut::parse_file (parser.rs:105-108).  MVFX_ERR_IO when unreadable / not UTF-8. */
+int mvfx_cube_lut_parse_file(const char *path, mvfx_cube_lut **out);
+void mvfx_cube_lut_free(mvfx_cube_lut *lut);
+int mvfx_cube_lut_is_3d(const mvfx_cube_lut *lut);
+uint32_t mvfx_cube_lut_size(const mvfx_cube_lut *lut);
+int mvfx_cube_lut_domain(const mvfx_cube_lut *lut, float scale[3], float offset[3]);
+const float *mvfx_cube_lut_rgba(const mvfx_cube_lut *lut);               /* host, size^3*4 or NULL */
+const float *mvfx_cube_lut_table_1d(const mvfx_cube_lut *lut, int channel); /* host, size or NULL */
+
+/* Replaces ColorLut::transform_frame -> transform_rgba{,64}_{1d,3d} (colorlut/imp.rs:203-397):
+ * out of place, RGBA / RGBA64_LE / RGBA64_BE (in and out the same format), alpha copied.
+ * lut == NULL -> MVFX_ERR_NO_LUT (FlowError::Error, colorlut/imp.rs:209-213). */
+int mvfx_colorlut_transform_frame(mvfx_cube_lut *lut, const mvfx_frame *in_frame,
+                                  const mvfx_frame *out_frame, mvfx_stream stream);
+int mvfx_colorlut_transform_frame_host(mvfx_cube_lut *lut, const mvfx_frame *in_frame,
+                                       const mvfx_frame *out_frame);
+/* Where the LUT is read from (per process, for A/B and parity tests): 0 = automatic (LDS when
+ * the table fits: 3-D size <= 21, 1-D size <= 4096; else global/L2), 1 = always global/L2,
+ * 2 = LDS (MVFX_ERR_INVALID_ARGUMENT if it does not fit). */
+int mvfx_colorlut_set_placement(int placement);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,124 @@
+"""GPU parity tests for colorlut: HIP path (C ABI) vs the oracle, bit-exact u8 / u16."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests import cubes, frames
+from tests import oracle_binding as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    return {
+        "identity17": cubes.identity_3d(17),
+        "analytic9": cubes.analytic_3d(9),
+        "analytic21": cubes.analytic_3d(21),   # largest cube that is staged in LDS
+        "analytic33": cubes.analytic_3d(33),   # BASELINE config 3 (L2-resident)
+        "curve1d_256": cubes.curve_1d(256),
+        "curve1d_2": cubes.curve_1d(2),
+        "curve1d_4096": cubes.curve_1d(4096),
+        "curve1d_65536": cubes.curve_1d(65536),
+        "curve1d_domain": cubes.curve_1d(64, ((-0.25, 0.0, 0.1), (1.5, 1.0, 0.9))),
+        "nan_nodes": "LUT_3D_SIZE 2\n" + "nan 0.5 inf\n" * 4 + "0.25 -inf 2\n" * 4,
+        "nan_domain": "LUT_1D_SIZE 2\nDOMAIN_MIN nan 0 0\n0 0.1 0.2\n1 0.9 0.8\n",
+    }
+
+
+@pytest.fixture(scope="module")
+def luts(gpu):
+    out = {}
+    for name, text in _cases().items():
+        o = orc.CubeLut(text)
+        assert o.ok, o.error
+        out[name] = (gpu.CubeLut(text), o)
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(_cases()))
+@pytest.mark.parametrize("fmt", ["RGBA", "RGBA64_LE", "RGBA64_BE"])
+@pytest.mark.parametrize("placement", [0, 1], ids=["auto", "global"])
+def test_colorlut_random_frames(gpu, luts, name, fmt, placement):
+    """ragged width, row padding (kept), host entry point, both LUT placements"""
+    dev, o = luts[name]
+    gpu.check(gpu.lib().mvfx_colorlut_set_placement(placement))
+    try:
+        for (w, h, pad) in ((257, 9, 16), (64, 8, 0), (1, 1, 0), (1023, 3, 0)):
+            bpp = 8 if fmt != "RGBA" else 4
+            stride = w * bpp + pad
+            src = frames.random_frame(0x5EED0500 + w, w, h, bpp, stride)
+            exp = np.full((h, stride), 0xC3, np.uint8)
+            assert o.apply(src, stride, exp, stride, w, h, fmt) == 0
+            got = np.full((h, stride), 0xC3, np.uint8)
+            dev.apply_host(src.reshape(-1), stride, got.reshape(-1), stride, w, h, fmt)
+            bad = np.count_nonzero(got != exp)
+            assert bad == 0, f"{name} {fmt} {w}x{h}: {bad} bytes differ"
+    finally:
+        gpu.lib().mvfx_colorlut_set_placement(0)
+
+
+@pytest.mark.parametrize("name", ["analytic33", "analytic21", "identity17", "curve1d_256", "nan_nodes"])
+def test_colorlut_exhaustive_rgba8(gpu, luts, name):
+    """all 2^24 RGB triples through the LUT (RGBA8), device entry point"""
+    dev, o = luts[name]
+    ex = frames.exhaustive_rgbx()
+    exp = np.empty_like(ex)
+    assert o.apply(ex, 4096 * 4, exp, 4096 * 4, 4096, 4096, "RGBA") == 0
+    src = gpu.DeviceBuffer(ex.nbytes).upload(ex)
+    dst = gpu.DeviceBuffer(ex.nbytes)
+    dev.apply_device(src.ptr, 4096 * 4, dst.ptr, 4096 * 4, 4096, 4096, "RGBA")
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    got = dst.download().reshape(ex.shape)
+    assert np.array_equal(got, exp)
+
+
+def test_colorlut_4k_rgba_33(gpu, luts):
+    """BASELINE config 3: 33^3 cube, 3840x2160 (RGBx in BASELINE == RGBA here)"""
+    dev, o = luts["analytic33"]
+    w, h = 3840, 2160
+    for frame in (frames.random_frame(0x5EED0001, w, h), frames.smpte_like(w, h)):
+        exp = np.empty_like(frame)
+        assert o.apply(frame, w * 4, exp, w * 4, w, h, "RGBA") == 0
+        src = gpu.DeviceBuffer(frame.nbytes).upload(frame)
+        dst = gpu.DeviceBuffer(frame.nbytes)
+        dev.apply_device(src.ptr, w * 4, dst.ptr, w * 4, w, h, "RGBA")
+        gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+        assert np.array_equal(dst.download().reshape(h, w * 4), exp)
+
+
+def test_colorlut_rgba64_wide_values(gpu, luts):
+    """RGBA64: every 16-bit value on each channel at least once (65536 px ramp + random)"""
+    dev, o = luts["analytic33"]
+    w, h = 4096, 16
+    ramp = np.arange(65536, dtype=np.uint16)
+    px = np.zeros((h * w, 4), np.uint16)
+    px[:, 0] = ramp
+    px[:, 1] = ramp[::-1]
+    px[:, 2] = (ramp * 7 + 13)
+    px[:, 3] = ramp ^ 0x5555
+    for fmt, dt in (("RGBA64_LE", "<u2"), ("RGBA64_BE", ">u2")):
+        src = px.astype(dt).view(np.uint8).reshape(h, w * 8)
+        exp = np.empty_like(src)
+        assert o.apply(src, w * 8, exp, w * 8, w, h, fmt) == 0
+        got = np.empty_like(src)
+        dev.apply_host(src.reshape(-1), w * 8, got.reshape(-1), w * 8, w, h, fmt)
+        assert np.array_equal(got, exp)
+
+
+def test_colorlut_errors(gpu, luts):
+    dev, _ = luts["identity17"]
+    a = np.zeros(256, np.uint8)
+    fi = gpu.make_frame(a.ctypes.data, 4, 4, 16, "RGBA")
+    fo = gpu.make_frame(a.ctypes.data, 4, 4, 16, "RGBA")
+    assert gpu.lib().mvfx_colorlut_transform_frame_host(None, ctypes.byref(fi), ctypes.byref(fo)) == gpu.ERR_NO_LUT
+    fx = gpu.make_frame(a.ctypes.data, 4, 4, 16, "RGBx")
+    assert gpu.lib().mvfx_colorlut_transform_frame_host(dev.h, ctypes.byref(fx), ctypes.byref(fo)) == gpu.ERR_UNSUPPORTED_FORMAT
+    f2 = gpu.make_frame(a.ctypes.data, 4, 2, 16, "RGBA")
+    assert gpu.lib().mvfx_colorlut_transform_frame_host(dev.h, ctypes.byref(fi), ctypes.byref(f2)) == gpu.ERR_NOT_NEGOTIATED
+    big, _o = luts["analytic33"]
+    gpu.lib().mvfx_colorlut_set_placement(2)
+    try:
+        assert gpu.lib().mvfx_colorlut_transform_frame_host(big.h, ctypes.byref(fi), ctypes.byref(fo)) == gpu.ERR_INVALID_ARGUMENT
+    finally:
+        gpu.lib().mvfx_colorlut_set_placement(0)
