@@ -46,6 +46,12 @@ class Frame(Structure):
                 ("stride", c_uint32), ("format", c_int32)]
 
 
+class PlanarFrame(Structure):
+    """struct mvfx_planar_frame"""
+    _fields_ = [("data", c_void_p * 4), ("stride", c_uint32 * 4), ("width", c_uint32),
+                ("height", c_uint32), ("format", c_int32)]
+
+
 class HsvFilterSettings(Structure):
     """struct mvfx_hsvfilter_settings == hsvfilter/imp.rs:32-39"""
     _fields_ = [("hue_shift", c_float), ("saturation_mul", c_float), ("saturation_off", c_float),
@@ -106,6 +112,19 @@ SIGNATURES = {
     "mvfx_colorlut_transform_frame": (c_int, [c_void_p, POINTER(Frame), POINTER(Frame), c_void_p]),
     "mvfx_colorlut_transform_frame_host": (c_int, [c_void_p, POINTER(Frame), POINTER(Frame)]),
     "mvfx_colorlut_set_placement": (c_int, [c_int]),
+    "mvfx_colordetect_histogram": (c_int, [POINTER(Frame), c_uint32, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
+    "mvfx_mmcq_palette_from_histogram": (c_int, [c_void_p, POINTER(c_uint32), c_uint32, POINTER(c_uint32), POINTER(c_uint32)]),
+    "mvfx_colordetect_palette": (c_int, [POINTER(Frame), c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_uint32), c_void_p]),
+    "mvfx_colordetect_palette_host": (c_int, [POINTER(Frame), c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_uint32)]),
+    "mvfx_css_color_similar": (c_char_p, [ctypes.c_uint8, ctypes.c_uint8, ctypes.c_uint8]),
+    "mvfx_blockhash_sums": (c_int, [POINTER(Frame), c_uint32, c_uint32, c_void_p, c_void_p]),
+    "mvfx_blockhash_bits": (c_int, [POINTER(c_uint32), c_uint32, c_uint32, POINTER(c_uint64)]),
+    "mvfx_hash_distance": (c_uint32, [c_uint64, c_uint64]),
+    "mvfx_blockhash": (c_int, [POINTER(Frame), POINTER(c_uint64), c_void_p]),
+    "mvfx_blockhash_host": (c_int, [POINTER(Frame), POINTER(c_uint64)]),
+    "mvfx_videocompare_distance": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(ctypes.c_double), c_void_p]),
+    "mvfx_roundedcorners_mask": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_void_p]),
+    "mvfx_roundedcorners_compose_a420": (c_int, [POINTER(PlanarFrame), c_void_p, c_uint32, POINTER(PlanarFrame), c_void_p]),
 }
 
 
@@ -263,3 +282,25 @@ class CubeLut:
             self.free()
         except Exception:
             pass
+
+
+ALL_SAMPLES = (1 << 64) - 1
+
+
+def colordetect_palette_host(frame_bytes, width, height, stride, fmt, quality=10, max_colors=2):
+    """-> (palette [0xRRGGBB...], dominant css name) like ColorDetect::detect_color (imp.rs:57-86)"""
+    f = make_frame(frame_bytes.ctypes.data, width, height, stride, fmt)
+    pal = (c_uint32 * 256)()
+    n = c_uint32()
+    check(lib().mvfx_colordetect_palette_host(ctypes.byref(f), quality, max_colors, pal, ctypes.byref(n)))
+    palette = [pal[i] for i in range(n.value)]
+    p0 = palette[0]
+    name = lib().mvfx_css_color_similar((p0 >> 16) & 255, (p0 >> 8) & 255, p0 & 255).decode()
+    return palette, name
+
+
+def blockhash_host(frame_bytes, width, height, stride, fmt):
+    f = make_frame(frame_bytes.ctypes.data, width, height, stride, fmt)
+    h = c_uint64()
+    check(lib().mvfx_blockhash_host(ctypes.byref(f), ctypes.byref(h)))
+    return h.value

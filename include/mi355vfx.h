@@ -190,6 +190,76 @@ int mvfx_colorlut_transform_frame_host(mvfx_cube_lut *lut, const mvfx_frame *in_
  * 2 = LDS (MVFX_ERR_INVALID_ARGUMENT if it does not fit). */
 int mvfx_colorlut_set_placement(int placement);
 
+/* ---- colordetect : video/videofx/src/colordetect/imp.rs ----
+ * The reference calls color_thief::get_palette(plane, format, quality, max_colors) (crate
+ * color-thief 0.2.2, imp.rs:68-74) and names palette[0] with color_name::css::Color::similar
+ * (imp.rs:77-79).  Here the O(pixels) half (5-5-5 histogram of every `quality`-th pixel of the flat
+ * plane, row padding included) runs on the GPU; the serial median cut runs on the host. */
+
+/* Histogram + 5-bit channel min/max of samples [first_sample, first_sample+n_samples) of the
+ * frame (sample k = pixel k*quality of the flat plane); pass n_samples = UINT64_MAX for all.
+ * hist_device: 32768 u32, minmax_device: 6 u32 {rmin,rmax,gmin,gmax,bmin,bmax}; both are
+ * overwritten.  A sample range exists so that ranks can split one frame and all-reduce
+ * (sum the histogram, min/max the bounds).  Formats RGB RGBA ARGB BGR BGRA; quality 1..=10. */
+int mvfx_colordetect_histogram(const mvfx_frame *frame, uint32_t quality, uint64_t first_sample,
+                               uint64_t n_samples, uint32_t *hist_device,
+                               uint32_t *minmax_device, mvfx_stream stream);
+/* Host-only median cut over a (possibly all-reduced) histogram.  palette_out: max_colors
+ * entries packed 0x00RRGGBB, most dominant first (colordetect/imp.rs:95-99). */
+int mvfx_mmcq_palette_from_histogram(const uint32_t *hist_host, const uint32_t minmax[6],
+                                     uint32_t max_colors, uint32_t *palette_out, uint32_t *n_out);
+/* histogram + D2H + median cut in one call (synchronous) */
+int mvfx_colordetect_palette(const mvfx_frame *frame, uint32_t quality, uint32_t max_colors,
+                             uint32_t *palette_out, uint32_t *n_out, mvfx_stream stream);
+int mvfx_colordetect_palette_host(const mvfx_frame *frame, uint32_t quality, uint32_t max_colors,
+                                  uint32_t *palette_out, uint32_t *n_out);
+/* lower-case CSS colour name nearest to (r,g,b); static storage */
+const char *mvfx_css_color_similar(uint8_t r, uint8_t g, uint8_t b);
+
+/* ---- videocompare : video/videofx/src/videocompare/{imp,hashed_image}.rs ----
+ * Default hash-algo Blockhash (image_hasher 3.1.1, 8x8 bits, hashed_image.rs:37-45,104):
+ * 64 block sums of r+g+b (765 when alpha == 0) over an 8x8 grid, bits against the band
+ * median, distance = Hamming distance as f64 (hashed_image.rs:70).  Width and height must be
+ * multiples of 8 (true for every BASELINE shape); row padding never counts (the reference
+ * packs the frame first, hashed_image.rs:110-130). */
+
+/* Partial block sums of image rows [row_begin,row_end) -> sums_device[64] (overwritten).
+ * Ranks that each own a row band all-reduce(sum) the 64 u32 and then call
+ * mvfx_blockhash_bits on the total. */
+int mvfx_blockhash_sums(const mvfx_frame *frame, uint32_t row_begin, uint32_t row_end,
+                        uint32_t *sums_device, mvfx_stream stream);
+int mvfx_blockhash_bits(const uint32_t sums_host[64], uint32_t width, uint32_t height,
+                        uint64_t *hash_out);
+uint32_t mvfx_hash_distance(uint64_t a, uint64_t b);
+int mvfx_blockhash(const mvfx_frame *frame, uint64_t *hash_out, mvfx_stream stream); /* sync */
+int mvfx_blockhash_host(const mvfx_frame *frame, uint64_t *hash_out);
+/* HasherEngine::hash_image x2 + compare (videocompare/imp.rs:316,349-353); sizes must match
+ * (MVFX_ERR_NOT_NEGOTIATED, imp.rs:337-346). */
+int mvfx_videocompare_distance(const mvfx_frame *reference_frame, const mvfx_frame *other_frame,
+                               double *distance_out, mvfx_stream stream);
+
+/* ---- roundedcorners : video/videofx/src/border/imp.rs ----
+ * Planar view for I420 / A420 (GstVideoFrame plane pointers + strides). */
+typedef struct mvfx_planar_frame {
+    void *data[4];
+    uint32_t stride[4];
+    uint32_t width, height;
+    int32_t format; /* MVFX_FORMAT_I420 or MVFX_FORMAT_A420 */
+} mvfx_planar_frame;
+
+/* Replaces generate_alpha_mask + draw_rounded_corners (border/imp.rs:57-180): writes the A8
+ * plane (stride x round_up_2(height) bytes): 0xFF everywhere when border_radius_px == 0, else 0
+ * outside / 255 inside the rounded rectangle with anti-aliased corner arcs (fill + 1 px stroke).
+ * Anti-aliased values follow area coverage, not cairo's scan converter bit for bit (tolerance in
+ * DESIGN.md); everything that is not on a corner arc is exact. */
+int mvfx_roundedcorners_mask(uint8_t *mask_device, uint32_t width, uint32_t height,
+                             uint32_t stride, uint32_t border_radius_px, mvfx_stream stream);
+/* I420 -> A420 into one device buffer: copies Y, U, V and the mask as plane 3 (what
+ * prepare_output_buffer does by appending the shared alpha GstMemory, border/imp.rs:482-559). */
+int mvfx_roundedcorners_compose_a420(const mvfx_planar_frame *i420_in, const uint8_t *mask_device,
+                                     uint32_t mask_stride, const mvfx_planar_frame *a420_out,
+                                     mvfx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,228 @@
+"""GPU parity tests for the videofx kernels (colordetect histogram + palette, videocompare
+blockhash, roundedcorners mask / compose) against the oracle and the libcairo goldens."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from tests import frames
+from tests import oracle_binding as orc
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CD_FORMATS = {"RGB": 3, "RGBA": 4, "ARGB": 4, "BGR": 3, "BGRA": 4}
+
+
+def _gpu_hist(gpu, frame, w, h, stride, fmt, quality, first=0, n=None):
+    buf = gpu.DeviceBuffer(frame.nbytes).upload(frame)
+    hist = gpu.DeviceBuffer(32768 * 4)
+    mm = gpu.DeviceBuffer(6 * 4)
+    f = gpu.make_frame(buf.ptr, w, h, stride, fmt)
+    gpu.check(gpu.lib().mvfx_colordetect_histogram(ctypes.byref(f), quality, first, gpu.ALL_SAMPLES if n is None else n,
+                                                   ctypes.c_void_p(hist.ptr), ctypes.c_void_p(mm.ptr), None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    return hist.download(dtype=np.uint32), mm.download(dtype=np.uint32)
+
+
+@pytest.mark.parametrize("fmt", sorted(CD_FORMATS))
+@pytest.mark.parametrize("quality", [1, 3, 10])
+def test_colordetect_histogram_matches_oracle(gpu, fmt, quality):
+    """whole plane incl. padding, every quality-th pixel, skip rules (a<125, near-white)"""
+    bpp = CD_FORMATS[fmt]
+    for (w, h, pad) in ((320, 240, 0), (101, 37, 8)):
+        stride = (w * bpp + 3) // 4 * 4 + pad
+        f = frames.random_frame(0x5EED0700 + w, w, h, bpp, stride)
+        f[: h // 4] = 252  # a band of near-white pixels that must be skipped
+        rc, hist, mm, n = orc.colordetect_histogram(f, fmt, quality)
+        assert rc == 0
+        ghist, gmm = _gpu_hist(gpu, f, w, h, stride, fmt, quality)
+        assert np.array_equal(ghist, hist.astype(np.uint32))
+        assert gmm.tolist() == mm
+        assert int(ghist.sum()) == n
+
+
+def test_colordetect_histogram_sample_ranges_add_up(gpu):
+    """two sample ranges (as two ranks would take) sum to the full histogram"""
+    w, h = 640, 480
+    f = frames.random_frame(0x5EED0701, w, h)
+    full, mm = _gpu_hist(gpu, f, w, h, w * 4, "RGBA", 10)
+    total = (w * h + 9) // 10
+    a, mma = _gpu_hist(gpu, f, w, h, w * 4, "RGBA", 10, 0, total // 2)
+    b, mmb = _gpu_hist(gpu, f, w, h, w * 4, "RGBA", 10, total // 2, total - total // 2)
+    assert np.array_equal(a + b, full)
+    assert [min(mma[0], mmb[0]), max(mma[1], mmb[1])] == mm[:2].tolist()
+
+
+@pytest.mark.parametrize("settings", [(10, 2), (1, 8), (5, 255), (10, 16)])
+def test_colordetect_palette_matches_oracle(gpu, settings):
+    quality, max_colors = settings
+    w, h = 3840, 2160
+    for f in (frames.smpte_like(w, h), frames.random_frame(0x5EED0001, w, h)):
+        rc, pal = orc.colordetect_palette(f, "RGBA", quality, max_colors)
+        assert rc > 0
+        gpal, name = gpu.colordetect_palette_host(f.reshape(-1), w, h, w * 4, "RGBA", quality, max_colors)
+        assert gpal == pal
+        assert name == orc.css_similar((pal[0] >> 16) & 255, (pal[0] >> 8) & 255, pal[0] & 255)
+
+
+def test_colordetect_reference_pin_red(gpu):
+    """tests/colordetect.rs:21-68: solid red => dominant-color 'red' (palette[0] = 252,4,4)"""
+    w, h = 320, 240
+    red = np.tile(np.array((255, 0, 0, 255), np.uint8), w * h).reshape(h, w * 4)
+    pal, name = gpu.colordetect_palette_host(red.reshape(-1), w, h, w * 4, "RGBA", 10, 2)
+    assert name == "red" and pal[0] == 0xFC0404
+
+
+def test_colordetect_errors(gpu):
+    a = np.zeros(64, np.uint8)
+    pal = (ctypes.c_uint32 * 4)()
+    n = ctypes.c_uint32()
+    f = gpu.make_frame(a.ctypes.data, 4, 4, 16, "RGBA")
+    L = gpu.lib()
+    assert L.mvfx_colordetect_palette_host(ctypes.byref(f), 0, 2, pal, ctypes.byref(n)) == gpu.ERR_REFERENCE_PANIC  # quality=0
+    assert L.mvfx_colordetect_palette_host(ctypes.byref(f), 10, 1, pal, ctypes.byref(n)) == gpu.ERR_REFERENCE_PANIC
+    fx = gpu.make_frame(a.ctypes.data, 4, 4, 16, "RGBx")
+    assert L.mvfx_colordetect_palette_host(ctypes.byref(fx), 10, 2, pal, ctypes.byref(n)) == gpu.ERR_UNSUPPORTED_FORMAT
+
+
+# ---------------------------------------------------------------- videocompare
+
+@pytest.mark.parametrize("fmt", ["RGBA", "RGB"])
+@pytest.mark.parametrize("geom", [(640, 480, 0), (64, 48, 12), (1920, 1080, 0), (8, 8, 0), (72, 40, 4)])
+def test_blockhash_sums_and_hash_match_oracle(gpu, fmt, geom):
+    w, h, pad = geom
+    bpp = 3 if fmt == "RGB" else 4
+    stride = (w * bpp + 3) // 4 * 4 + pad
+    f = frames.random_frame(0x5EED0800 + w, w, h, bpp, stride)
+    if bpp == 4:
+        f[::5, 3:w * 4:8] = 0  # transparent pixels count as 765
+    rc, sums = orc.blockhash_sums(f, w, h, stride, fmt)
+    assert rc == 0
+    buf = gpu.DeviceBuffer(f.nbytes).upload(f)
+    dsums = gpu.DeviceBuffer(256)
+    fr = gpu.make_frame(buf.ptr, w, h, stride, fmt)
+    gpu.check(gpu.lib().mvfx_blockhash_sums(ctypes.byref(fr), 0, h, ctypes.c_void_p(dsums.ptr), None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    assert np.array_equal(dsums.download(dtype=np.uint32), sums)
+    rc, hh = orc.blockhash(f, w, h, stride, fmt)
+    assert gpu.blockhash_host(f.reshape(-1), w, h, stride, fmt) == hh
+
+
+def test_blockhash_row_bands_add_up(gpu):
+    """8 row bands (one block-row per rank) sum to the full-frame block sums"""
+    w, h = 7680, 4320 // 4  # keeps the test light: 8 block rows of 135 rows
+    f = frames.random_frame(0x5EED0801, w, h)
+    buf = gpu.DeviceBuffer(f.nbytes).upload(f)
+    fr = gpu.make_frame(buf.ptr, w, h, w * 4, "RGBA")
+    total = np.zeros(64, np.uint64)
+    d = gpu.DeviceBuffer(256)
+    for r in range(8):
+        gpu.check(gpu.lib().mvfx_blockhash_sums(ctypes.byref(fr), r * h // 8, (r + 1) * h // 8, ctypes.c_void_p(d.ptr), None))
+        gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+        part = d.download(dtype=np.uint32)
+        assert not part[:r * 8].any() and not part[(r + 1) * 8:].any()
+        total += part
+    rc, sums = orc.blockhash_sums(f, w, h, w * 4, "RGBA")
+    assert np.array_equal(total.astype(np.uint32), sums)
+
+
+def test_videocompare_reference_pins(gpu):
+    """tests/videocompare.rs:57-139: red vs red -> 0; snow vs red -> > 0; perturbation ladder"""
+    w, h = 320, 240
+    red = np.tile(np.array((255, 0, 0, 255), np.uint8), w * h).reshape(h, w * 4)
+    snow = frames.random_frame(0x5EED0600, w, h)
+    snow[:, 3::4] = 255
+    a = gpu.DeviceBuffer(red.nbytes).upload(red)
+    b = gpu.DeviceBuffer(red.nbytes).upload(red)
+    c = gpu.DeviceBuffer(snow.nbytes).upload(snow)
+    fa, fb, fc = (gpu.make_frame(x.ptr, w, h, w * 4, "RGBA") for x in (a, b, c))
+    d = ctypes.c_double()
+    gpu.check(gpu.lib().mvfx_videocompare_distance(ctypes.byref(fa), ctypes.byref(fb), ctypes.byref(d), None))
+    assert d.value == 0.0
+    gpu.check(gpu.lib().mvfx_videocompare_distance(ctypes.byref(fa), ctypes.byref(fc), ctypes.byref(d), None))
+    rc, hr = orc.blockhash(red, w, h, w * 4, "RGBA")
+    rc, hs = orc.blockhash(snow, w, h, w * 4, "RGBA")
+    assert d.value == float(orc.hamming(hr, hs)) and d.value > 0
+    f2 = gpu.make_frame(c.ptr, w, h // 2, w * 4, "RGBA")
+    assert gpu.lib().mvfx_videocompare_distance(ctypes.byref(fa), ctypes.byref(f2), ctypes.byref(d), None) == gpu.ERR_NOT_NEGOTIATED
+
+
+def test_blockhash_8k_pair(gpu):
+    """BASELINE config 5 shape: 7680x4320 RGBA pair, A vs A = 0, A vs perturbed/inverted"""
+    w, h = 7680, 4320
+    a = frames.random_frame(0x5EED0001, w, h)
+    a[:, 3::4] |= 1
+    rc, ha = orc.blockhash(a, w, h, w * 4, "RGBA")
+    assert gpu.blockhash_host(a.reshape(-1), w, h, w * 4, "RGBA") == ha
+    inv = a.copy()
+    inv[:, 0::4] = 255 - inv[:, 0::4]
+    inv[:, 1::4] = 255 - inv[:, 1::4]
+    inv[:, 2::4] = 255 - inv[:, 2::4]
+    rc, hi = orc.blockhash(inv, w, h, w * 4, "RGBA")
+    assert gpu.blockhash_host(inv.reshape(-1), w, h, w * 4, "RGBA") == hi
+
+
+# ---------------------------------------------------------------- roundedcorners
+
+MASK_TOLERANCE = 40  # max |HIP - cairo| on anti-aliased arc pixels (documented in DESIGN.md)
+
+
+@pytest.fixture(scope="module")
+def cairo_masks():
+    return np.load(os.path.join(GOLDEN, "roundedcorners_masks.npz"))
+
+
+@pytest.mark.parametrize("case", ["w32_h24_r8", "w64_h48_r10", "w641_h481_r33", "w640_h480_r0", "w1920_h1080_r1",
+                                  "w1920_h1080_r50", "w1920_h1080_r540", "w3840_h2160_r100"])
+def test_roundedcorners_mask_vs_cairo_golden(gpu, cairo_masks, case):
+    gold = cairo_masks[case]
+    w, h, r = (int(t[1:]) for t in case.split("_"))
+    rows, stride = gold.shape
+    buf = gpu.DeviceBuffer(gold.nbytes)
+    buf.upload(np.full(gold.nbytes, 0x77, np.uint8))
+    gpu.check(gpu.lib().mvfx_roundedcorners_mask(ctypes.c_void_p(buf.ptr), w, h, stride, r, None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    got = buf.download().reshape(rows, stride)
+    if r == 0:
+        assert np.array_equal(got, gold)  # exact: 0xFF everywhere (border/imp.rs:123-128)
+        return
+    # fully covered / fully empty pixels are exact
+    solid = (gold == 0) | (gold == 255)
+    diff = np.abs(got.astype(np.int32) - gold.astype(np.int32))
+    assert diff.max() <= MASK_TOLERANCE, f"max |diff| {diff.max()}"
+    frac_exact_solid = np.count_nonzero(diff[solid] == 0) / np.count_nonzero(solid)
+    assert frac_exact_solid > 0.9999
+    # padding columns / the extra row of an odd height stay 0
+    assert not got[:, w:].any() and not got[h:].any()
+    print(case, "max diff", diff.max(), "mean diff on partial px", diff[~solid].mean() if (~solid).any() else 0)
+
+
+def test_roundedcorners_compose_a420(gpu, cairo_masks):
+    """I420 -> A420: planes copied bit-exactly, plane 3 = mask"""
+    w, h, r = 64, 48, 10
+    ys, cs = 64, 32
+    i420 = frames.splitmix64_bytes(5, ys * h + 2 * cs * (h // 2))
+    src = gpu.DeviceBuffer(i420.nbytes).upload(i420)
+    mask = gpu.DeviceBuffer(64 * 48)
+    gpu.check(gpu.lib().mvfx_roundedcorners_mask(ctypes.c_void_p(mask.ptr), w, h, 64, r, None))
+    out_size = ys * h + 2 * cs * (h // 2) + 64 * h
+    dst = gpu.DeviceBuffer(out_size)
+    fi = gpu.PlanarFrame()
+    fo = gpu.PlanarFrame()
+    offs = [0, ys * h, ys * h + cs * (h // 2), ys * h + 2 * cs * (h // 2)]
+    for p in range(3):
+        fi.data[p] = src.ptr + offs[p]
+        fo.data[p] = dst.ptr + offs[p]
+        fi.stride[p] = fo.stride[p] = ys if p == 0 else cs
+    fo.data[3] = dst.ptr + offs[3]
+    fo.stride[3] = 64
+    fi.width = fo.width = w
+    fi.height = fo.height = h
+    fi.format, fo.format = gpu.FORMATS["I420"], gpu.FORMATS["A420"]
+    gpu.check(gpu.lib().mvfx_roundedcorners_compose_a420(ctypes.byref(fi), ctypes.c_void_p(mask.ptr), 64, ctypes.byref(fo), None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    out = dst.download()
+    assert np.array_equal(out[:offs[3]], i420)
+    assert np.array_equal(out[offs[3]:], mask.download())
