@@ -296,10 +296,11 @@ __device__ __forceinline__ uint32_t rounded_alpha(uint32_t px, uint32_t py, floa
 {
     // distance of the pixel's nearest / farthest point to the relevant corner centre decides
     // quickly whether the pixel is trivially inside or outside
-    const float cx = (px + 0.5f < w * 0.5f) ? r : w - r;
-    const float cy = (py + 0.5f < h * 0.5f) ? r : h - r;
-    const bool in_corner_x = (px + 1.0f <= r + 1.0f) || (px >= w - r - 1.0f);
-    const bool in_corner_y = (py + 1.0f <= r + 1.0f) || (py >= h - r - 1.0f);
+    const bool left = px + 0.5f < w * 0.5f, top = py + 0.5f < h * 0.5f;
+    const float cx = left ? r : w - r;
+    const float cy = top ? r : h - r;
+    const bool in_corner_x = left ? (float)px < r : (float)(px + 1) > w - r;
+    const bool in_corner_y = top ? (float)py < r : (float)(py + 1) > h - r;
     if (!(in_corner_x && in_corner_y))
         return 255u; // straight edges lie on the frame border: fill covers the pixel completely
     uint32_t fill = 0, stroke = 0;
@@ -308,8 +309,8 @@ __device__ __forceinline__ uint32_t rounded_alpha(uint32_t px, uint32_t py, floa
         for (int sx = 0; sx < kSub; sx++) {
             const float x = px + (sx + 0.5f) / kSub;
             // only the quadrant beyond the arc centre is rounded
-            const bool beyond_x = (cx == r) ? (x < cx) : (x > cx);
-            const bool beyond_y = (cy == r) ? (y < cy) : (y > cy);
+            const bool beyond_x = left ? (x < cx) : (x > cx);
+            const bool beyond_y = top ? (y < cy) : (y > cy);
             if (beyond_x && beyond_y) {
                 const float d = sqrtf((x - cx) * (x - cx) + (y - cy) * (y - cy));
                 fill += d <= r;
@@ -515,6 +516,10 @@ int mvfx_roundedcorners_mask(uint8_t *mask_device, uint32_t width, uint32_t heig
 {
     if (!mask_device || stride < width || width == 0 || height == 0)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "roundedcorners: bad mask geometry %ux%u stride %u", width, height, stride);
+    if ((uint64_t)border_radius_px * 2 > width || (uint64_t)border_radius_px * 2 > height)
+        return fail(MVFX_ERR_INVALID_ARGUMENT,
+                    "roundedcorners: border-radius-px %u exceeds half of %ux%u; cairo's self-intersecting path for that "
+                    "case is not modelled by the HIP mask kernel", border_radius_px, width, height);
     if (int rc = require_device(); rc != MVFX_OK) return rc;
     const uint32_t rows = (height + 1) & ~1u; // border/imp.rs:469-470 round_up_2(height)
     const dim3 grid((stride + 255) / 256, rows, 1);

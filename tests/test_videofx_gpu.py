@@ -166,7 +166,7 @@ def test_blockhash_8k_pair(gpu):
 
 # ---------------------------------------------------------------- roundedcorners
 
-MASK_TOLERANCE = 40  # max |HIP - cairo| on anti-aliased arc pixels (documented in DESIGN.md)
+MASK_TOLERANCE = 32  # max |HIP - cairo| on anti-aliased arc pixels (documented in DESIGN.md)
 
 
 @pytest.fixture(scope="module")
