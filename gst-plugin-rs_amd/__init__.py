@@ -124,6 +124,7 @@ SIGNATURES = {
     "mvfx_blockhash_host": (c_int, [POINTER(Frame), POINTER(c_uint64)]),
     "mvfx_videocompare_distance": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(ctypes.c_double), c_void_p]),
     "mvfx_roundedcorners_mask": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_void_p]),
+    "mvfx_roundedcorners_mask_host": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_uint32]),
     "mvfx_roundedcorners_compose_a420": (c_int, [POINTER(PlanarFrame), c_void_p, c_uint32, POINTER(PlanarFrame), c_void_p]),
 }
 

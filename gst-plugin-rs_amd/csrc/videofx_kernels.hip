@@ -530,6 +530,23 @@ int mvfx_roundedcorners_mask(uint8_t *mask_device, uint32_t width, uint32_t heig
     return MVFX_OK;
 }
 
+int mvfx_roundedcorners_mask_host(uint8_t *mask_host, uint32_t width, uint32_t height, uint32_t stride,
+                                  uint32_t border_radius_px)
+{
+    if (!mask_host)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "roundedcorners: NULL mask");
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    const size_t bytes = (size_t)stride * ((height + 1) & ~1u);
+    void *dev = nullptr;
+    if (int rc = host_scratch(bytes ? bytes : 16, 0, &dev); rc != MVFX_OK) return rc;
+    hipStream_t st = host_stream();
+    if (int rc = mvfx_roundedcorners_mask(static_cast<uint8_t *>(dev), width, height, stride, border_radius_px, st); rc != MVFX_OK)
+        return rc;
+    MVFX_HIP_TRY(hipMemcpyAsync(mask_host, dev, bytes, hipMemcpyDeviceToHost, st));
+    MVFX_HIP_TRY(hipStreamSynchronize(st));
+    return MVFX_OK;
+}
+
 int mvfx_roundedcorners_compose_a420(const mvfx_planar_frame *i420_in, const uint8_t *mask_device,
                                      uint32_t mask_stride, const mvfx_planar_frame *a420_out, mvfx_stream stream)
 {

@@ -1,0 +1,146 @@
+// libgstcolorlut.so -- plugin `colorlut` with element `colorlut`.
+// Same surface as video/colorlut/src/{lib.rs,colorlut/imp.rs}; LUT application runs in the HIP
+// kernels behind include/mi355vfx.h, .cube parsing in host/cube_parser.cpp.
+#include "mvfx_gst_common.h"
+
+#include <mutex>
+#include <string>
+
+GST_DEBUG_CATEGORY_STATIC(colorlut_debug); // colorlut/imp.rs:41-43
+
+struct GstColorLut {
+    GstVideoFilter parent;
+    std::mutex *lock;
+    std::string *location; // Settings { location: Option<String> } (:45-48); empty + !has_location = None
+    gboolean has_location;
+    mvfx_cube_lut *lut;    // State { lut: Option<CubeLut> } (:50-53)
+};
+struct GstColorLutClass {
+    GstVideoFilterClass parent_class;
+};
+G_DEFINE_TYPE(GstColorLut, gst_color_lut, GST_TYPE_VIDEO_FILTER)
+
+enum { PROP_0, PROP_LOCATION };
+
+static void gst_color_lut_set_property(GObject *obj, guint id, const GValue *value, GParamSpec *pspec)
+{
+    GstColorLut *self = reinterpret_cast<GstColorLut *>(obj);
+    if (id != PROP_LOCATION) { G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec); return; }
+    std::lock_guard<std::mutex> g(*self->lock);
+    const gchar *s = g_value_get_string(value);
+    self->has_location = s != NULL;
+    *self->location = s ? s : "";
+}
+
+static void gst_color_lut_get_property(GObject *obj, guint id, GValue *value, GParamSpec *pspec)
+{
+    GstColorLut *self = reinterpret_cast<GstColorLut *>(obj);
+    if (id != PROP_LOCATION) { G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec); return; }
+    std::lock_guard<std::mutex> g(*self->lock);
+    g_value_set_string(value, self->has_location ? self->location->c_str() : NULL);
+}
+
+// BaseTransformImpl::start (colorlut/imp.rs:168-194)
+static gboolean gst_color_lut_start(GstBaseTransform *trans)
+{
+    GstColorLut *self = reinterpret_cast<GstColorLut *>(trans);
+    std::string location;
+    {
+        std::lock_guard<std::mutex> g(*self->lock);
+        if (!self->has_location) {
+            GST_ELEMENT_ERROR(self, RESOURCE, SETTINGS, ("LUT file location is not configured"), (NULL));
+            return FALSE;
+        }
+        location = *self->location;
+    }
+    mvfx_cube_lut *lut = nullptr;
+    if (mvfx_cube_lut_parse_file(location.c_str(), &lut) != MVFX_OK) {
+        GST_ELEMENT_ERROR(self, RESOURCE, READ, ("%s", mvfx_last_error()), (NULL));
+        return FALSE;
+    }
+    GST_CAT_TRACE_OBJECT(colorlut_debug, self, "Parsed LUT: %s size %u", mvfx_cube_lut_is_3d(lut) ? "3D" : "1D",
+                         mvfx_cube_lut_size(lut));
+    std::lock_guard<std::mutex> g(*self->lock);
+    if (self->lut) mvfx_cube_lut_free(self->lut);
+    self->lut = lut;
+    return TRUE;
+}
+
+// BaseTransformImpl::stop (:196-199)
+static gboolean gst_color_lut_stop(GstBaseTransform *trans)
+{
+    GstColorLut *self = reinterpret_cast<GstColorLut *>(trans);
+    std::lock_guard<std::mutex> g(*self->lock);
+    if (self->lut) mvfx_cube_lut_free(self->lut);
+    self->lut = nullptr;
+    return TRUE;
+}
+
+// VideoFilterImpl::transform_frame (:203-223)
+static GstFlowReturn gst_color_lut_transform_frame(GstVideoFilter *filter, GstVideoFrame *in, GstVideoFrame *out)
+{
+    GstColorLut *self = reinterpret_cast<GstColorLut *>(filter);
+    std::lock_guard<std::mutex> g(*self->lock); // state lock held for the frame, like the reference
+    if (!self->lut) {
+        GST_CAT_ERROR_OBJECT(colorlut_debug, self, "No LUT configured");
+        return GST_FLOW_ERROR;
+    }
+    const mvfx_frame fi = mvfx_frame_from_gst(in), fo = mvfx_frame_from_gst(out);
+    const int rc = mvfx_colorlut_transform_frame_host(self->lut, &fi, &fo);
+    return MVFX_GST_FLOW(self, rc);
+}
+
+static void gst_color_lut_finalize(GObject *obj)
+{
+    GstColorLut *self = reinterpret_cast<GstColorLut *>(obj);
+    if (self->lut) mvfx_cube_lut_free(self->lut);
+    delete self->location;
+    delete self->lock;
+    G_OBJECT_CLASS(gst_color_lut_parent_class)->finalize(obj);
+}
+
+static void gst_color_lut_class_init(GstColorLutClass *klass)
+{
+    GObjectClass *gobject = G_OBJECT_CLASS(klass);
+    GstElementClass *element = GST_ELEMENT_CLASS(klass);
+    gobject->set_property = gst_color_lut_set_property;
+    gobject->get_property = gst_color_lut_get_property;
+    gobject->finalize = gst_color_lut_finalize;
+    g_object_class_install_property(gobject, PROP_LOCATION, // colorlut/imp.rs:68-81
+        g_param_spec_string("location", "Location", "Location of the LUT file to read from", NULL,
+                            (GParamFlags)(G_PARAM_READWRITE | GST_PARAM_MUTABLE_READY | G_PARAM_STATIC_STRINGS)));
+    gst_element_class_set_static_metadata(element, "Color LUT", "Filter/Effect/Video", "Apply color lookup table",
+                                          "Seungha Yang <seungha@centricular.com>"); // :107-118
+    // :120-158.  RGBA64_LE/BE exist only in newer GStreamer: advertise them when the
+    // running library knows the names, RGBA always.
+    const gboolean has64 = gst_video_format_from_string("RGBA64_LE") != GST_VIDEO_FORMAT_UNKNOWN;
+    static const gchar *const all[] = {"RGBA64_LE", "RGBA64_BE", "RGBA", NULL};
+    static const gchar *const only8[] = {"RGBA", NULL};
+    mvfx_add_pad_templates(element, mvfx_video_caps(has64 ? all : only8), mvfx_video_caps(has64 ? all : only8));
+    GST_BASE_TRANSFORM_CLASS(klass)->start = gst_color_lut_start;
+    GST_BASE_TRANSFORM_CLASS(klass)->stop = gst_color_lut_stop;
+    GST_VIDEO_FILTER_CLASS(klass)->transform_frame = gst_color_lut_transform_frame; // NeverInPlace (:162-166)
+}
+
+static void gst_color_lut_init(GstColorLut *self)
+{
+    self->lock = new std::mutex();
+    self->location = new std::string();
+    self->has_location = FALSE;
+    self->lut = nullptr;
+}
+
+static gboolean plugin_init(GstPlugin *plugin) // colorlut/src/lib.rs:22-31
+{
+    GST_DEBUG_CATEGORY_INIT(colorlut_debug, "colorlut", 0, "Color LUT");
+    return gst_element_register(plugin, "colorlut", GST_RANK_NONE, gst_color_lut_get_type());
+}
+
+// "MPL-2.0" is only a known licence string since GStreamer 1.20 (videofx/src/lib.rs:41 FIXME)
+#if GST_CHECK_VERSION(1, 20, 0)
+#define MVFX_COLORLUT_LICENSE "MPL-2.0"
+#else
+#define MVFX_COLORLUT_LICENSE "MPL"
+#endif
+GST_PLUGIN_DEFINE(GST_VERSION_MAJOR, GST_VERSION_MINOR, colorlut, "GStreamer Color LUT Plugin", plugin_init,
+                  MVFX_GST_VERSION, MVFX_COLORLUT_LICENSE, "gst-plugin-colorlut", MVFX_GST_ORIGIN)

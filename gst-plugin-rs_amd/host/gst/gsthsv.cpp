@@ -1,0 +1,252 @@
+// libgsthsv.so -- plugin `hsv` with elements `hsvfilter` and `hsvdetector`.
+// Same surface as video/hsv/src/{lib.rs,hsvfilter,hsvdetector} of the reference; the per-pixel
+// work is done by the HIP kernels behind include/mi355vfx.h.
+#include "mvfx_gst_common.h"
+
+#include <mutex>
+
+GST_DEBUG_CATEGORY_STATIC(hsvfilter_debug);   // hsvfilter/imp.rs:59-65
+GST_DEBUG_CATEGORY_STATIC(hsvdetector_debug); // hsvdetector/imp.rs:64-70
+
+// ------------------------------------------------------------------------- hsvfilter
+
+struct GstHsvFilter {
+    GstVideoFilter parent;
+    std::mutex *lock;                 // settings: Mutex<Settings> (hsvfilter/imp.rs:55-57)
+    mvfx_hsvfilter_settings settings;
+};
+struct GstHsvFilterClass {
+    GstVideoFilterClass parent_class;
+};
+G_DEFINE_TYPE(GstHsvFilter, gst_hsv_filter, GST_TYPE_VIDEO_FILTER)
+
+enum { PROP_F_0, PROP_HUE_SHIFT, PROP_SAT_MUL, PROP_SAT_OFF, PROP_VAL_MUL, PROP_VAL_OFF };
+
+static void gst_hsv_filter_set_property(GObject *obj, guint id, const GValue *value, GParamSpec *pspec)
+{
+    GstHsvFilter *self = reinterpret_cast<GstHsvFilter *>(obj);
+    std::lock_guard<std::mutex> g(*self->lock);
+    float *dst = nullptr;
+    switch (id) {
+    case PROP_HUE_SHIFT: dst = &self->settings.hue_shift; break;
+    case PROP_SAT_MUL: dst = &self->settings.saturation_mul; break;
+    case PROP_SAT_OFF: dst = &self->settings.saturation_off; break;
+    case PROP_VAL_MUL: dst = &self->settings.value_mul; break;
+    case PROP_VAL_OFF: dst = &self->settings.value_off; break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec); return;
+    }
+    GST_CAT_INFO_OBJECT(hsvfilter_debug, obj, "Changing %s from %f to %f", pspec->name, *dst, g_value_get_float(value));
+    *dst = g_value_get_float(value);
+}
+
+static void gst_hsv_filter_get_property(GObject *obj, guint id, GValue *value, GParamSpec *pspec)
+{
+    GstHsvFilter *self = reinterpret_cast<GstHsvFilter *>(obj);
+    std::lock_guard<std::mutex> g(*self->lock);
+    switch (id) {
+    case PROP_HUE_SHIFT: g_value_set_float(value, self->settings.hue_shift); break;
+    case PROP_SAT_MUL: g_value_set_float(value, self->settings.saturation_mul); break;
+    case PROP_SAT_OFF: g_value_set_float(value, self->settings.saturation_off); break;
+    case PROP_VAL_MUL: g_value_set_float(value, self->settings.value_mul); break;
+    case PROP_VAL_OFF: g_value_set_float(value, self->settings.value_off); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec); break;
+    }
+}
+
+// VideoFilterImpl::transform_frame_ip (hsvfilter/imp.rs:322-377)
+static GstFlowReturn gst_hsv_filter_transform_frame_ip(GstVideoFilter *filter, GstVideoFrame *frame)
+{
+    GstHsvFilter *self = reinterpret_cast<GstHsvFilter *>(filter);
+    mvfx_hsvfilter_settings s;
+    {
+        std::lock_guard<std::mutex> g(*self->lock); // snapshot once per frame (hsvfilter/imp.rs:85)
+        s = self->settings;
+    }
+    const mvfx_frame f = mvfx_frame_from_gst(frame);
+    const int rc = mvfx_hsvfilter_transform_frame_ip_host(&f, &s);
+    return MVFX_GST_FLOW(self, rc);
+}
+
+static void gst_hsv_filter_finalize(GObject *obj)
+{
+    delete reinterpret_cast<GstHsvFilter *>(obj)->lock;
+    G_OBJECT_CLASS(gst_hsv_filter_parent_class)->finalize(obj);
+}
+
+static void gst_hsv_filter_class_init(GstHsvFilterClass *klass)
+{
+    GObjectClass *gobject = G_OBJECT_CLASS(klass);
+    GstElementClass *element = GST_ELEMENT_CLASS(klass);
+    GstVideoFilterClass *vfilter = GST_VIDEO_FILTER_CLASS(klass);
+    gobject->set_property = gst_hsv_filter_set_property;
+    gobject->get_property = gst_hsv_filter_get_property;
+    gobject->finalize = gst_hsv_filter_finalize;
+    const GParamFlags flags = (GParamFlags)(G_PARAM_READWRITE | GST_PARAM_MUTABLE_PLAYING | G_PARAM_STATIC_STRINGS);
+    // hsvfilter/imp.rs:124-161 (defaults :25-29)
+    g_object_class_install_property(gobject, PROP_HUE_SHIFT,
+        g_param_spec_float("hue-shift", "Hue shift", "Hue shifting in degrees", -G_MAXFLOAT, G_MAXFLOAT, 0.0f, flags));
+    g_object_class_install_property(gobject, PROP_SAT_MUL,
+        g_param_spec_float("saturation-mul", "Saturation multiplier",
+                           "Saturation multiplier to apply to the saturation value (before offset)", -G_MAXFLOAT, G_MAXFLOAT, 1.0f, flags));
+    g_object_class_install_property(gobject, PROP_SAT_OFF,
+        g_param_spec_float("saturation-off", "Saturation offset",
+                           "Saturation offset to add to the saturation value (after multiplier)", -G_MAXFLOAT, G_MAXFLOAT, 0.0f, flags));
+    g_object_class_install_property(gobject, PROP_VAL_MUL,
+        g_param_spec_float("value-mul", "Value multiplier", "Value multiplier to apply to the value (before offset)",
+                           -G_MAXFLOAT, G_MAXFLOAT, 1.0f, flags));
+    g_object_class_install_property(gobject, PROP_VAL_OFF,
+        g_param_spec_float("value-off", "Value offset", "Value offset to add to the value (after multiplier)",
+                           -G_MAXFLOAT, G_MAXFLOAT, 0.0f, flags));
+    gst_element_class_set_static_metadata(element, "HSV filter", "Filter/Effect/Converter/Video",
+        "Works within the HSV colorspace to apply transformations to incoming frames",
+        "Julien Bardagi <julien.bardagi@gmail.com>"); // hsvfilter/imp.rs:261-272
+    static const gchar *const formats[] = {"RGBx", "xRGB", "BGRx", "xBGR", "RGBA", "ARGB", "BGRA", "ABGR", "RGB", "BGR", NULL};
+    mvfx_add_pad_templates(element, mvfx_video_caps(formats), mvfx_video_caps(formats)); // :274-312
+    vfilter->transform_frame_ip = gst_hsv_filter_transform_frame_ip; // AlwaysInPlace (:315-320)
+}
+
+static void gst_hsv_filter_init(GstHsvFilter *self)
+{
+    self->lock = new std::mutex();
+    self->settings = mvfx_hsvfilter_settings{0.0f, 1.0f, 0.0f, 1.0f, 0.0f};
+}
+
+// ------------------------------------------------------------------------- hsvdetector
+
+struct GstHsvDetector {
+    GstVideoFilter parent;
+    std::mutex *lock;
+    mvfx_hsvdetector_settings settings;
+};
+struct GstHsvDetectorClass {
+    GstVideoFilterClass parent_class;
+};
+G_DEFINE_TYPE(GstHsvDetector, gst_hsv_detector, GST_TYPE_VIDEO_FILTER)
+
+enum { PROP_D_0, PROP_HUE_REF, PROP_HUE_VAR, PROP_SAT_REF, PROP_SAT_VAR, PROP_VAL_REF, PROP_VAL_VAR };
+
+static float *hsv_detector_field(GstHsvDetector *self, guint id)
+{
+    switch (id) {
+    case PROP_HUE_REF: return &self->settings.hue_ref;
+    case PROP_HUE_VAR: return &self->settings.hue_var;
+    case PROP_SAT_REF: return &self->settings.saturation_ref;
+    case PROP_SAT_VAR: return &self->settings.saturation_var;
+    case PROP_VAL_REF: return &self->settings.value_ref;
+    case PROP_VAL_VAR: return &self->settings.value_var;
+    default: return nullptr;
+    }
+}
+
+static void gst_hsv_detector_set_property(GObject *obj, guint id, const GValue *value, GParamSpec *pspec)
+{
+    GstHsvDetector *self = reinterpret_cast<GstHsvDetector *>(obj);
+    std::lock_guard<std::mutex> g(*self->lock);
+    float *dst = hsv_detector_field(self, id);
+    if (!dst) { G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec); return; }
+    GST_CAT_INFO_OBJECT(hsvdetector_debug, obj, "Changing %s from %f to %f", pspec->name, *dst, g_value_get_float(value));
+    *dst = g_value_get_float(value);
+}
+
+static void gst_hsv_detector_get_property(GObject *obj, guint id, GValue *value, GParamSpec *pspec)
+{
+    GstHsvDetector *self = reinterpret_cast<GstHsvDetector *>(obj);
+    std::lock_guard<std::mutex> g(*self->lock);
+    float *src = hsv_detector_field(self, id);
+    if (!src) { G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec); return; }
+    g_value_set_float(value, *src);
+}
+
+static const gchar *const kDetectorIn[] = {"RGBx", "xRGB", "BGRx", "xBGR", "RGB", "BGR", NULL};  // hsvdetector/imp.rs:78-87
+static const gchar *const kDetectorOut[] = {"RGBA", "ARGB", "BGRA", "ABGR", NULL};              // :89-96
+
+// BaseTransformImpl::transform_caps (hsvdetector/imp.rs:386-419): replace the `format` field of
+// every structure with the list of the other side, then intersect with the filter (First mode)
+static GstCaps *gst_hsv_detector_transform_caps(GstBaseTransform *trans, GstPadDirection direction, GstCaps *caps,
+                                                GstCaps *filter)
+{
+    GstCaps *other = gst_caps_copy(caps);
+    GstCaps *tmpl = mvfx_video_caps(direction == GST_PAD_SRC ? kDetectorIn : kDetectorOut);
+    const GValue *formats = gst_structure_get_value(gst_caps_get_structure(tmpl, 0), "format");
+    for (guint i = 0; i < gst_caps_get_size(other); i++)
+        gst_structure_set_value(gst_caps_get_structure(other, i), "format", formats);
+    gst_caps_unref(tmpl);
+    GST_CAT_DEBUG_OBJECT(hsvdetector_debug, trans, "Transformed caps from %" GST_PTR_FORMAT " to %" GST_PTR_FORMAT " in direction %d",
+                         caps, other, (int)direction);
+    if (filter) {
+        GstCaps *r = gst_caps_intersect_full(filter, other, GST_CAPS_INTERSECT_FIRST);
+        gst_caps_unref(other);
+        return r;
+    }
+    return other;
+}
+
+// VideoFilterImpl::transform_frame (hsvdetector/imp.rs:422-707)
+static GstFlowReturn gst_hsv_detector_transform_frame(GstVideoFilter *filter, GstVideoFrame *in, GstVideoFrame *out)
+{
+    GstHsvDetector *self = reinterpret_cast<GstHsvDetector *>(filter);
+    mvfx_hsvdetector_settings s;
+    {
+        std::lock_guard<std::mutex> g(*self->lock);
+        s = self->settings;
+    }
+    const mvfx_frame fi = mvfx_frame_from_gst(in), fo = mvfx_frame_from_gst(out);
+    const int rc = mvfx_hsvdetector_transform_frame_host(&fi, &fo, &s);
+    return MVFX_GST_FLOW(self, rc);
+}
+
+static void gst_hsv_detector_finalize(GObject *obj)
+{
+    delete reinterpret_cast<GstHsvDetector *>(obj)->lock;
+    G_OBJECT_CLASS(gst_hsv_detector_parent_class)->finalize(obj);
+}
+
+static void gst_hsv_detector_class_init(GstHsvDetectorClass *klass)
+{
+    GObjectClass *gobject = G_OBJECT_CLASS(klass);
+    GstElementClass *element = GST_ELEMENT_CLASS(klass);
+    gobject->set_property = gst_hsv_detector_set_property;
+    gobject->get_property = gst_hsv_detector_get_property;
+    gobject->finalize = gst_hsv_detector_finalize;
+    const GParamFlags flags = (GParamFlags)(G_PARAM_READWRITE | GST_PARAM_MUTABLE_PLAYING | G_PARAM_STATIC_STRINGS);
+    // hsvdetector/imp.rs:164-212 (defaults :26-31)
+    g_object_class_install_property(gobject, PROP_HUE_REF,
+        g_param_spec_float("hue-ref", "Hue reference", "Hue reference in degrees", -G_MAXFLOAT, G_MAXFLOAT, 0.0f, flags));
+    g_object_class_install_property(gobject, PROP_HUE_VAR,
+        g_param_spec_float("hue-var", "Hue variation", "Allowed hue variation from the reference hue angle, in degrees",
+                           0.0f, 180.0f, 10.0f, flags));
+    g_object_class_install_property(gobject, PROP_SAT_REF,
+        g_param_spec_float("saturation-ref", "Saturation reference", "Reference saturation value", 0.0f, 1.0f, 0.0f, flags));
+    g_object_class_install_property(gobject, PROP_SAT_VAR,
+        g_param_spec_float("saturation-var", "Saturation variation", "Allowed saturation variation from the reference value",
+                           0.0f, 1.0f, 0.15f, flags));
+    g_object_class_install_property(gobject, PROP_VAL_REF,
+        g_param_spec_float("value-ref", "Value reference", "Reference value value", 0.0f, 1.0f, 0.0f, flags));
+    g_object_class_install_property(gobject, PROP_VAL_VAR,
+        g_param_spec_float("value-var", "Value variation", "Allowed value variation from the reference value",
+                           0.0f, 1.0f, 0.3f, flags));
+    gst_element_class_set_static_metadata(element, "HSV detector", "Filter/Effect/Converter/Video",
+        "Works within the HSV colorspace to mark positive pixels", "Julien Bardagi <julien.bardagi@gmail.com>");
+    mvfx_add_pad_templates(element, mvfx_video_caps(kDetectorIn), mvfx_video_caps(kDetectorOut));
+    GST_BASE_TRANSFORM_CLASS(klass)->transform_caps = gst_hsv_detector_transform_caps;
+    GST_VIDEO_FILTER_CLASS(klass)->transform_frame = gst_hsv_detector_transform_frame; // NeverInPlace (:380-384)
+}
+
+static void gst_hsv_detector_init(GstHsvDetector *self)
+{
+    self->lock = new std::mutex();
+    self->settings = mvfx_hsvdetector_settings{0.0f, 10.0f, 0.0f, 0.15f, 0.0f, 0.3f};
+}
+
+// ------------------------------------------------------------------------- plugin (hsv/src/lib.rs:23-42)
+
+static gboolean plugin_init(GstPlugin *plugin)
+{
+    GST_DEBUG_CATEGORY_INIT(hsvfilter_debug, "hsvfilter", 0, "Rust HSV transformation filter");
+    GST_DEBUG_CATEGORY_INIT(hsvdetector_debug, "hsvdetector", 0, "Rust HSV-based detection filter");
+    return gst_element_register(plugin, "hsvfilter", GST_RANK_NONE, gst_hsv_filter_get_type()) &&
+           gst_element_register(plugin, "hsvdetector", GST_RANK_NONE, gst_hsv_detector_get_type());
+}
+
+GST_PLUGIN_DEFINE(GST_VERSION_MAJOR, GST_VERSION_MINOR, hsv, "GStreamer plugin with HSV manipulation elements", plugin_init,
+                  MVFX_GST_VERSION, "MIT/X11", "gst-plugin-hsv", MVFX_GST_ORIGIN)

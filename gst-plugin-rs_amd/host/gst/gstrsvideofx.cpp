@@ -1,0 +1,434 @@
+// libgstrsvideofx.so -- plugin `rsvideofx` with elements `colordetect` and `roundedcorners`.
+// Same surface as video/videofx/src/{lib.rs,colordetect,border}.  `videocompare` is a
+// GstVideoAggregator in the reference; the GStreamer 1.14 of the build image has no
+// GstVideoAggregator, so its element glue is a later step -- its
+// compute (block sums, hash, distance, sharded all-reduce) is in the C ABI already.
+#include "mvfx_gst_common.h"
+
+#include <gst/video/gstvideometa.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+GST_DEBUG_CATEGORY_STATIC(colordetect_debug);
+GST_DEBUG_CATEGORY_STATIC(roundedcorners_debug);
+
+// ------------------------------------------------------------------------- colordetect
+
+struct GstColorDetect {
+    GstVideoFilter parent;
+    std::mutex *lock;
+    guint quality, max_colors;       // Settings (colordetect/imp.rs:30-43)
+    gboolean have_state;             // State { color_format, current_color } (:45-48)
+    std::string *current_color;
+    gboolean have_color;
+};
+struct GstColorDetectClass {
+    GstVideoFilterClass parent_class;
+};
+G_DEFINE_TYPE(GstColorDetect, gst_color_detect, GST_TYPE_VIDEO_FILTER)
+
+enum { PROP_C_0, PROP_QUALITY, PROP_MAX_COLORS };
+
+static void gst_color_detect_set_property(GObject *obj, guint id, const GValue *value, GParamSpec *pspec)
+{
+    GstColorDetect *self = reinterpret_cast<GstColorDetect *>(obj);
+    std::lock_guard<std::mutex> g(*self->lock);
+    switch (id) {
+    case PROP_QUALITY:
+        GST_CAT_INFO_OBJECT(colordetect_debug, obj, "Changing quality from %u to %u", self->quality, g_value_get_uint(value));
+        self->quality = g_value_get_uint(value);
+        break;
+    case PROP_MAX_COLORS:
+        GST_CAT_INFO_OBJECT(colordetect_debug, obj, "Changing max_colors from %u to %u", self->max_colors, g_value_get_uint(value));
+        self->max_colors = g_value_get_uint(value);
+        break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec); break;
+    }
+}
+
+static void gst_color_detect_get_property(GObject *obj, guint id, GValue *value, GParamSpec *pspec)
+{
+    GstColorDetect *self = reinterpret_cast<GstColorDetect *>(obj);
+    std::lock_guard<std::mutex> g(*self->lock);
+    switch (id) {
+    case PROP_QUALITY: g_value_set_uint(value, self->quality); break;
+    case PROP_MAX_COLORS: g_value_set_uint(value, self->max_colors); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec); break;
+    }
+}
+
+// VideoFilterImpl::set_info (colordetect/imp.rs:260-294): keeps the previous colour
+static gboolean gst_color_detect_set_info(GstVideoFilter *filter, GstCaps *incaps, GstVideoInfo *, GstCaps *outcaps, GstVideoInfo *)
+{
+    GstColorDetect *self = reinterpret_cast<GstColorDetect *>(filter);
+    GST_CAT_DEBUG_OBJECT(colordetect_debug, self, "Configured for caps %" GST_PTR_FORMAT " to %" GST_PTR_FORMAT, incaps, outcaps);
+    self->have_state = TRUE;
+    return TRUE;
+}
+
+static gboolean gst_color_detect_stop(GstBaseTransform *trans) // :252-256
+{
+    GstColorDetect *self = reinterpret_cast<GstColorDetect *>(trans);
+    self->have_state = FALSE;
+    self->have_color = FALSE;
+    GST_CAT_INFO_OBJECT(colordetect_debug, self, "Stopped");
+    return TRUE;
+}
+
+// transform_frame_ip_passthrough (:296-305) -> detect_color (:57-86) -> color_changed (:88-112)
+static GstFlowReturn gst_color_detect_transform_frame_ip(GstVideoFilter *filter, GstVideoFrame *frame)
+{
+    GstColorDetect *self = reinterpret_cast<GstColorDetect *>(filter);
+    if (!self->have_state) {
+        GST_ELEMENT_ERROR(self, CORE, NEGOTIATION, ("Have no state yet"), (NULL));
+        return GST_FLOW_NOT_NEGOTIATED;
+    }
+    guint quality, max_colors;
+    {
+        std::lock_guard<std::mutex> g(*self->lock);
+        quality = self->quality;
+        max_colors = self->max_colors;
+    }
+    const mvfx_frame f = mvfx_frame_from_gst(frame);
+    uint32_t palette[256];
+    uint32_t n = 0;
+    const int rc = mvfx_colordetect_palette_host(&f, quality, max_colors, palette, &n);
+    if (rc != MVFX_OK) {
+        GST_CAT_ERROR_OBJECT(colordetect_debug, self, "%s", mvfx_last_error());
+        return GST_FLOW_ERROR; // get_palette(..).map_err(|_| FlowError::Error) (:74)
+    }
+    const char *name = mvfx_css_color_similar((palette[0] >> 16) & 0xff, (palette[0] >> 8) & 0xff, palette[0] & 0xff);
+    if (self->have_color && *self->current_color == name)
+        return GST_FLOW_OK;
+    *self->current_color = name;
+    self->have_color = TRUE;
+    GST_CAT_DEBUG_OBJECT(colordetect_debug, self, "Dominant color changed to %s", name);
+    GValue list = G_VALUE_INIT;
+    g_value_init(&list, GST_TYPE_LIST);
+    for (uint32_t i = 0; i < n; i++) {
+        GValue v = G_VALUE_INIT;
+        g_value_init(&v, G_TYPE_UINT);
+        g_value_set_uint(&v, palette[i]);
+        gst_value_list_append_and_take_value(&list, &v);
+    }
+    GstStructure *s = gst_structure_new("colordetect", "dominant-color", G_TYPE_STRING, name, NULL);
+    gst_structure_take_value(s, "palette", &list);
+    gst_element_post_message(GST_ELEMENT(self), gst_message_new_element(GST_OBJECT(self), s));
+    return GST_FLOW_OK;
+}
+
+static void gst_color_detect_finalize(GObject *obj)
+{
+    GstColorDetect *self = reinterpret_cast<GstColorDetect *>(obj);
+    delete self->current_color;
+    delete self->lock;
+    G_OBJECT_CLASS(gst_color_detect_parent_class)->finalize(obj);
+}
+
+static void gst_color_detect_class_init(GstColorDetectClass *klass)
+{
+    GObjectClass *gobject = G_OBJECT_CLASS(klass);
+    GstElementClass *element = GST_ELEMENT_CLASS(klass);
+    GstBaseTransformClass *bt = GST_BASE_TRANSFORM_CLASS(klass);
+    gobject->set_property = gst_color_detect_set_property;
+    gobject->get_property = gst_color_detect_get_property;
+    gobject->finalize = gst_color_detect_finalize;
+    const GParamFlags flags = (GParamFlags)(G_PARAM_READWRITE | GST_PARAM_MUTABLE_PLAYING | G_PARAM_STATIC_STRINGS);
+    g_object_class_install_property(gobject, PROP_QUALITY, // colordetect/imp.rs:126-133
+        g_param_spec_uint("quality", "Quality of an output colors", "A step in pixels to improve performance", 0, 10, 10, flags));
+    g_object_class_install_property(gobject, PROP_MAX_COLORS, // :134-141
+        g_param_spec_uint("max-colors", "Number of colors in the output palette",
+                          "Actual colors count can be lower depending on the image", 2, 255, 2, flags));
+    gst_element_class_set_static_metadata(element, "Dominant color detection", "Filter/Video",
+                                          "Detects the dominant color of a video", "Philippe Normand <philn@igalia.com>");
+    static const gchar *const formats[] = {"RGB", "RGBA", "ARGB", "BGR", "BGRA", NULL}; // :212-240
+    mvfx_add_pad_templates(element, mvfx_video_caps(formats), mvfx_video_caps(formats));
+    bt->passthrough_on_same_caps = TRUE;   // :246-250
+    bt->transform_ip_on_passthrough = TRUE;
+    bt->stop = gst_color_detect_stop;
+    GST_VIDEO_FILTER_CLASS(klass)->set_info = gst_color_detect_set_info;
+    GST_VIDEO_FILTER_CLASS(klass)->transform_frame_ip = gst_color_detect_transform_frame_ip;
+}
+
+static void gst_color_detect_init(GstColorDetect *self)
+{
+    self->lock = new std::mutex();
+    self->current_color = new std::string();
+    self->quality = 10;
+    self->max_colors = 2;
+    self->have_state = FALSE;
+    self->have_color = FALSE;
+}
+
+// ------------------------------------------------------------------------- roundedcorners
+
+struct GstRoundedCorners {
+    GstBaseTransform parent;
+    std::mutex *lock;
+    guint border_radius_px; // Settings { border_radius_px, changed } (border/imp.rs:27-43)
+    gboolean changed;
+    GstMemory *alpha_mem;   // State { alpha_mem, out_info } (:45-48)
+    GstVideoInfo out_info;
+    gboolean have_state;
+};
+struct GstRoundedCornersClass {
+    GstBaseTransformClass parent_class;
+};
+G_DEFINE_TYPE(GstRoundedCorners, gst_rounded_corners, GST_TYPE_BASE_TRANSFORM)
+
+enum { PROP_R_0, PROP_BORDER_RADIUS };
+
+static void gst_rounded_corners_set_property(GObject *obj, guint id, const GValue *value, GParamSpec *pspec)
+{
+    GstRoundedCorners *self = reinterpret_cast<GstRoundedCorners *>(obj);
+    if (id != PROP_BORDER_RADIUS) { G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec); return; }
+    gboolean reconfigure = FALSE;
+    {
+        std::lock_guard<std::mutex> g(*self->lock);
+        const guint r = g_value_get_uint(value);
+        if (self->border_radius_px != r) { // border/imp.rs:299-310
+            self->changed = TRUE;
+            GST_CAT_INFO_OBJECT(roundedcorners_debug, obj, "Changing border radius from %u to %u", self->border_radius_px, r);
+            self->border_radius_px = r;
+            reconfigure = TRUE;
+        }
+    }
+    if (reconfigure)
+        gst_base_transform_reconfigure_src(GST_BASE_TRANSFORM(self));
+}
+
+static void gst_rounded_corners_get_property(GObject *obj, guint id, GValue *value, GParamSpec *pspec)
+{
+    GstRoundedCorners *self = reinterpret_cast<GstRoundedCorners *>(obj);
+    if (id != PROP_BORDER_RADIUS) { G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec); return; }
+    std::lock_guard<std::mutex> g(*self->lock);
+    g_value_set_uint(value, self->border_radius_px);
+}
+
+static gboolean gst_rounded_corners_stop(GstBaseTransform *trans) // :380-386
+{
+    GstRoundedCorners *self = reinterpret_cast<GstRoundedCorners *>(trans);
+    std::lock_guard<std::mutex> g(*self->lock);
+    if (self->alpha_mem) gst_memory_unref(self->alpha_mem);
+    self->alpha_mem = nullptr;
+    self->have_state = FALSE;
+    GST_CAT_INFO_OBJECT(roundedcorners_debug, self, "Stopped");
+    return TRUE;
+}
+
+// transform_caps (:388-442)
+static GstCaps *gst_rounded_corners_transform_caps(GstBaseTransform *trans, GstPadDirection direction, GstCaps *caps, GstCaps *filter)
+{
+    GstRoundedCorners *self = reinterpret_cast<GstRoundedCorners *>(trans);
+    GstCaps *other = gst_caps_copy(caps);
+    if (direction == GST_PAD_SRC) {
+        for (guint i = 0; i < gst_caps_get_size(other); i++)
+            gst_structure_set(gst_caps_get_structure(other, i), "format", G_TYPE_STRING, "I420", NULL);
+    } else {
+        guint radius;
+        {
+            std::lock_guard<std::mutex> g(*self->lock);
+            radius = self->border_radius_px;
+        }
+        for (guint i = 0; i < gst_caps_get_size(other); i++) {
+            GstStructure *s = gst_caps_get_structure(other, i);
+            if (radius == 0) {
+                GValue list = G_VALUE_INIT;
+                g_value_init(&list, GST_TYPE_LIST);
+                for (const char *f : {"I420", "A420"}) {
+                    GValue v = G_VALUE_INIT;
+                    g_value_init(&v, G_TYPE_STRING);
+                    g_value_set_string(&v, f);
+                    gst_value_list_append_and_take_value(&list, &v);
+                }
+                gst_structure_take_value(s, "format", &list);
+            } else {
+                gst_structure_set(s, "format", G_TYPE_STRING, "A420", NULL);
+            }
+        }
+    }
+    GST_CAT_DEBUG_OBJECT(roundedcorners_debug, self, "Transformed caps from %" GST_PTR_FORMAT " to %" GST_PTR_FORMAT " in direction %d",
+                         caps, other, (int)direction);
+    if (filter) {
+        GstCaps *r = gst_caps_intersect_full(filter, other, GST_CAPS_INTERSECT_FIRST);
+        gst_caps_unref(other);
+        return r;
+    }
+    return other;
+}
+
+// set_caps (:444-480)
+static gboolean gst_rounded_corners_set_caps(GstBaseTransform *trans, GstCaps *incaps, GstCaps *outcaps)
+{
+    GstRoundedCorners *self = reinterpret_cast<GstRoundedCorners *>(trans);
+    GstVideoInfo info;
+    if (!gst_video_info_from_caps(&info, outcaps)) {
+        GST_CAT_ERROR_OBJECT(roundedcorners_debug, self, "Failed to parse output caps");
+        return FALSE;
+    }
+    GST_CAT_DEBUG_OBJECT(roundedcorners_debug, self, "Configured for caps %" GST_PTR_FORMAT " to %" GST_PTR_FORMAT, incaps, outcaps);
+    if (GST_VIDEO_INFO_FORMAT(&info) == GST_VIDEO_FORMAT_I420) {
+        gst_base_transform_set_passthrough(trans, TRUE);
+        return TRUE;
+    }
+    gst_base_transform_set_passthrough(trans, FALSE);
+    const guint ru2_height = (GST_VIDEO_INFO_HEIGHT(&info) + 1) & ~1u;
+    const gsize alpha_size = (gsize)GST_VIDEO_INFO_PLANE_STRIDE(&info, 3) * ru2_height;
+    std::lock_guard<std::mutex> g(*self->lock);
+    if (self->alpha_mem) gst_memory_unref(self->alpha_mem);
+    self->alpha_mem = gst_allocator_alloc(NULL, alpha_size, NULL);
+    self->out_info = info;
+    self->have_state = TRUE;
+    self->changed = TRUE;
+    return TRUE;
+}
+
+// generate_alpha_mask (:108-180): the mask is rendered by the HIP kernel and copied into the
+// shared alpha GstMemory
+static gboolean rounded_corners_generate_mask(GstRoundedCorners *self, guint radius)
+{
+    // make_mut(): the memory may be shared with in-flight buffers -> copy on write
+    if (!gst_mini_object_is_writable(GST_MINI_OBJECT_CAST(self->alpha_mem))) {
+        GstMemory *copy = gst_memory_copy(self->alpha_mem, 0, -1);
+        gst_memory_unref(self->alpha_mem);
+        self->alpha_mem = copy;
+    }
+    GstMapInfo map;
+    if (!gst_memory_map(self->alpha_mem, &map, GST_MAP_WRITE)) {
+        GST_CAT_ERROR_OBJECT(roundedcorners_debug, self, "Failed to map alpha memory as writable");
+        return FALSE;
+    }
+    const int rc = mvfx_roundedcorners_mask_host(map.data, (uint32_t)GST_VIDEO_INFO_WIDTH(&self->out_info),
+                                                 (uint32_t)GST_VIDEO_INFO_HEIGHT(&self->out_info),
+                                                 (uint32_t)GST_VIDEO_INFO_PLANE_STRIDE(&self->out_info, 3), radius);
+    gst_memory_unmap(self->alpha_mem, &map);
+    if (rc != MVFX_OK) {
+        GST_CAT_ERROR_OBJECT(roundedcorners_debug, self, "Failed to draw rounded corners: %s", mvfx_last_error());
+        return FALSE;
+    }
+    return TRUE;
+}
+
+// prepare_output_buffer (:482-559) + add_video_meta (:182-268)
+static GstFlowReturn gst_rounded_corners_prepare_output_buffer(GstBaseTransform *trans, GstBuffer *inbuf, GstBuffer **outbuf)
+{
+    GstRoundedCorners *self = reinterpret_cast<GstRoundedCorners *>(trans);
+    if (gst_base_transform_is_passthrough(trans)) {
+        *outbuf = inbuf;
+        return GST_FLOW_OK;
+    }
+    std::lock_guard<std::mutex> g(*self->lock);
+    if (!self->have_state) {
+        GST_ELEMENT_ERROR(self, CORE, NEGOTIATION, ("Have no state yet"), (NULL));
+        return GST_FLOW_NOT_NEGOTIATED;
+    }
+    if (self->changed) {
+        self->changed = FALSE;
+        GST_CAT_DEBUG_OBJECT(roundedcorners_debug, self, "Caps or border radius changed, generating alpha mask");
+        if (GST_VIDEO_INFO_FORMAT(&self->out_info) == GST_VIDEO_FORMAT_I420) {
+            *outbuf = inbuf;
+            return GST_FLOW_OK;
+        }
+        if (!rounded_corners_generate_mask(self, self->border_radius_px)) {
+            GST_ELEMENT_ERROR(self, CORE, NEGOTIATION, ("Failed to generate alpha mask"), (NULL));
+            return GST_FLOW_NOT_NEGOTIATED;
+        }
+    }
+    GstBuffer *buf;
+    if (gst_buffer_is_writable(inbuf)) {
+        buf = inbuf;
+    } else {
+        buf = gst_buffer_copy(inbuf);
+    }
+    const gsize alpha_plane_offset = gst_buffer_get_size(buf);
+    gst_buffer_append_memory(buf, gst_memory_ref(self->alpha_mem));
+
+    gint strides[GST_VIDEO_MAX_PLANES] = {0, 0, 0, 0};
+    gsize offsets[GST_VIDEO_MAX_PLANES] = {0, 0, 0, 0};
+    GstVideoFrameFlags vflags = GST_VIDEO_FRAME_FLAG_NONE;
+    GstVideoMeta *meta = gst_buffer_get_video_meta(buf);
+    if (meta) {
+        vflags = meta->flags;
+        for (guint p = 0; p < meta->n_planes && p < 3; p++) {
+            offsets[p] = meta->offset[p];
+            strides[p] = meta->stride[p];
+        }
+        gst_buffer_remove_meta(buf, GST_META_CAST(meta));
+    } else {
+        for (guint p = 0; p < 3; p++) {
+            offsets[p] = GST_VIDEO_INFO_PLANE_OFFSET(&self->out_info, p);
+            strides[p] = GST_VIDEO_INFO_PLANE_STRIDE(&self->out_info, p);
+        }
+    }
+    offsets[3] = alpha_plane_offset;
+    strides[3] = GST_VIDEO_INFO_PLANE_STRIDE(&self->out_info, 3);
+    gst_buffer_add_video_meta_full(buf, vflags, GST_VIDEO_INFO_FORMAT(&self->out_info), GST_VIDEO_INFO_WIDTH(&self->out_info),
+                                   GST_VIDEO_INFO_HEIGHT(&self->out_info), 4, offsets, strides);
+    *outbuf = buf;
+    return GST_FLOW_OK;
+}
+
+static GstFlowReturn gst_rounded_corners_transform_ip(GstBaseTransform *, GstBuffer *) { return GST_FLOW_OK; } // :561-563
+
+static gboolean gst_rounded_corners_propose_allocation(GstBaseTransform *trans, GstQuery *decide_query, GstQuery *query) // :565-572
+{
+    gst_query_add_allocation_meta(query, GST_VIDEO_META_API_TYPE, NULL);
+    return GST_BASE_TRANSFORM_CLASS(gst_rounded_corners_parent_class)->propose_allocation(trans, decide_query, query);
+}
+
+static void gst_rounded_corners_finalize(GObject *obj)
+{
+    GstRoundedCorners *self = reinterpret_cast<GstRoundedCorners *>(obj);
+    if (self->alpha_mem) gst_memory_unref(self->alpha_mem);
+    delete self->lock;
+    G_OBJECT_CLASS(gst_rounded_corners_parent_class)->finalize(obj);
+}
+
+static void gst_rounded_corners_class_init(GstRoundedCornersClass *klass)
+{
+    GObjectClass *gobject = G_OBJECT_CLASS(klass);
+    GstElementClass *element = GST_ELEMENT_CLASS(klass);
+    GstBaseTransformClass *bt = GST_BASE_TRANSFORM_CLASS(klass);
+    gobject->set_property = gst_rounded_corners_set_property;
+    gobject->get_property = gst_rounded_corners_get_property;
+    gobject->finalize = gst_rounded_corners_finalize;
+    g_object_class_install_property(gobject, PROP_BORDER_RADIUS, // border/imp.rs:279-294
+        g_param_spec_uint("border-radius-px", "Border radius in pixels", "Draw rounded corners with given border radius",
+                          0, G_MAXUINT, 0, (GParamFlags)(G_PARAM_READWRITE | GST_PARAM_MUTABLE_PLAYING | G_PARAM_STATIC_STRINGS)));
+    gst_element_class_set_static_metadata(element, "Rounded Corners", "Filter/Effect/Converter/Video",
+                                          "Adds rounded corners to video", "Sanchayan Maity <sanchayan@asymptotic.io>");
+    static const gchar *const sink_formats[] = {"I420", NULL};
+    static const gchar *const src_formats[] = {"I420", "A420", NULL};
+    mvfx_add_pad_templates(element, mvfx_video_caps(sink_formats), mvfx_video_caps(src_formats)); // :343-370
+    bt->stop = gst_rounded_corners_stop;
+    bt->transform_caps = gst_rounded_corners_transform_caps;
+    bt->set_caps = gst_rounded_corners_set_caps;
+    bt->prepare_output_buffer = gst_rounded_corners_prepare_output_buffer;
+    bt->transform_ip = gst_rounded_corners_transform_ip; // AlwaysInPlace (:374-378)
+    bt->propose_allocation = gst_rounded_corners_propose_allocation;
+}
+
+static void gst_rounded_corners_init(GstRoundedCorners *self)
+{
+    self->lock = new std::mutex();
+    self->border_radius_px = 0;
+    self->changed = FALSE;
+    self->alpha_mem = nullptr;
+    self->have_state = FALSE;
+    gst_base_transform_set_in_place(GST_BASE_TRANSFORM(self), TRUE);
+}
+
+// ------------------------------------------------------------------------- plugin (videofx/src/lib.rs:25-48)
+
+static gboolean plugin_init(GstPlugin *plugin)
+{
+    GST_DEBUG_CATEGORY_INIT(colordetect_debug, "colordetect", 0, "Dominant color detection");
+    GST_DEBUG_CATEGORY_INIT(roundedcorners_debug, "roundedcorners", 0, "Rounded corners");
+    return gst_element_register(plugin, "roundedcorners", GST_RANK_NONE, gst_rounded_corners_get_type()) &&
+           gst_element_register(plugin, "colordetect", GST_RANK_NONE, gst_color_detect_get_type());
+}
+
+GST_PLUGIN_DEFINE(GST_VERSION_MAJOR, GST_VERSION_MINOR, rsvideofx, "GStreamer Rust Video Effects Plugin", plugin_init,
+                  MVFX_GST_VERSION, "MPL", "gst-plugin-videofx", MVFX_GST_ORIGIN)

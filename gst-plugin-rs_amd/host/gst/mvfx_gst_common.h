@@ -1,0 +1,105 @@
+// Shared glue for the GStreamer elements that sit on top of the C ABI (include/mi355vfx.h).
+// The elements keep the reference's factory names, GType names, klass strings, pad caps and
+// GObject properties and forward the mapped GstVideoFrame to the HIP kernels
+// through the *_host entry points (system-memory buffers: H2D -> kernel -> D2H inside the call,
+// because a GstVideoFilter vfunc only borrows the frame).
+#pragma once
+
+#include <gst/base/gstbasetransform.h>
+#include <gst/gst.h>
+#include <gst/video/gstvideofilter.h>
+#include <gst/video/video.h>
+
+#include "mi355vfx.h"
+
+#ifndef PACKAGE
+#define PACKAGE "mi355vfx"
+#endif
+#ifndef MVFX_GST_VERSION
+#define MVFX_GST_VERSION "0.16.0-mi355vfx"
+#endif
+#define MVFX_GST_ORIGIN "https://gitlab.freedesktop.org/gstreamer/gst-plugins-rs"
+
+// GstVideoFormat -> mvfx_format; -1 for formats outside the path
+static inline int mvfx_format_from_gst(GstVideoFormat f)
+{
+    switch (f) {
+    case GST_VIDEO_FORMAT_RGBx: return MVFX_FORMAT_RGBX;
+    case GST_VIDEO_FORMAT_xRGB: return MVFX_FORMAT_XRGB;
+    case GST_VIDEO_FORMAT_BGRx: return MVFX_FORMAT_BGRX;
+    case GST_VIDEO_FORMAT_xBGR: return MVFX_FORMAT_XBGR;
+    case GST_VIDEO_FORMAT_RGBA: return MVFX_FORMAT_RGBA;
+    case GST_VIDEO_FORMAT_ARGB: return MVFX_FORMAT_ARGB;
+    case GST_VIDEO_FORMAT_BGRA: return MVFX_FORMAT_BGRA;
+    case GST_VIDEO_FORMAT_ABGR: return MVFX_FORMAT_ABGR;
+    case GST_VIDEO_FORMAT_RGB: return MVFX_FORMAT_RGB;
+    case GST_VIDEO_FORMAT_BGR: return MVFX_FORMAT_BGR;
+    case GST_VIDEO_FORMAT_I420: return MVFX_FORMAT_I420;
+    case GST_VIDEO_FORMAT_A420: return MVFX_FORMAT_A420;
+    default: break;
+    }
+    // RGBA64_LE / RGBA64_BE only exist in newer GStreamer; resolve them by name at run time
+    const gchar *name = gst_video_format_to_string(f);
+    if (name && g_strcmp0(name, "RGBA64_LE") == 0) return MVFX_FORMAT_RGBA64_LE;
+    if (name && g_strcmp0(name, "RGBA64_BE") == 0) return MVFX_FORMAT_RGBA64_BE;
+    return -1;
+}
+
+// plane 0 of a mapped frame as the C ABI's view (plane_data(0), plane_stride()[0], ...)
+static inline mvfx_frame mvfx_frame_from_gst(GstVideoFrame *frame)
+{
+    mvfx_frame f;
+    f.data = GST_VIDEO_FRAME_PLANE_DATA(frame, 0);
+    f.width = (uint32_t)GST_VIDEO_FRAME_WIDTH(frame);
+    f.height = (uint32_t)GST_VIDEO_FRAME_HEIGHT(frame);
+    f.stride = (uint32_t)GST_VIDEO_FRAME_PLANE_STRIDE(frame, 0);
+    f.format = mvfx_format_from_gst(GST_VIDEO_FRAME_FORMAT(frame));
+    return f;
+}
+
+// mvfx status -> GstFlowReturn, posting an element error like the reference's
+// element_imp_error! / panic-to-error conversion does (SURVEY.md 8b "Errors")
+static inline GstFlowReturn mvfx_gst_flow(GstElement *element, int rc)
+{
+    if (rc == MVFX_OK)
+        return GST_FLOW_OK;
+    GST_ELEMENT_ERROR(element, LIBRARY, FAILED, ("%s", mvfx_last_error()),
+                      ("mvfx status %d (%s)", rc, mvfx_status_string(rc)));
+    return rc == MVFX_ERR_NOT_NEGOTIATED ? GST_FLOW_NOT_NEGOTIATED : GST_FLOW_ERROR;
+}
+#define MVFX_GST_FLOW(element, rc) mvfx_gst_flow(GST_ELEMENT(element), (rc))
+
+// "video/x-raw, format={...}, width=[1,max], height=[1,max], framerate=[0/1,max]" -- what
+// gst_video::VideoCapsBuilder::new().format_list(..).build() produces
+static inline GstCaps *mvfx_video_caps(const gchar *const *formats)
+{
+    GValue list = G_VALUE_INIT;
+    g_value_init(&list, GST_TYPE_LIST);
+    guint n = 0;
+    for (const gchar *const *f = formats; *f; f++) {
+        GValue v = G_VALUE_INIT;
+        g_value_init(&v, G_TYPE_STRING);
+        g_value_set_string(&v, *f);
+        gst_value_list_append_and_take_value(&list, &v);
+        n++;
+    }
+    GstCaps *caps = gst_caps_new_simple("video/x-raw", "width", GST_TYPE_INT_RANGE, 1, G_MAXINT, "height",
+                                        GST_TYPE_INT_RANGE, 1, G_MAXINT, "framerate", GST_TYPE_FRACTION_RANGE, 0, 1,
+                                        G_MAXINT, 1, NULL);
+    GstStructure *s = gst_caps_get_structure(caps, 0);
+    if (n == 1) {
+        gst_structure_set(s, "format", G_TYPE_STRING, formats[0], NULL);
+        g_value_unset(&list);
+    } else {
+        gst_structure_take_value(s, "format", &list);
+    }
+    return caps;
+}
+
+static inline void mvfx_add_pad_templates(GstElementClass *klass, GstCaps *sink_caps, GstCaps *src_caps)
+{
+    gst_element_class_add_pad_template(klass, gst_pad_template_new("sink", GST_PAD_SINK, GST_PAD_ALWAYS, sink_caps));
+    gst_element_class_add_pad_template(klass, gst_pad_template_new("src", GST_PAD_SRC, GST_PAD_ALWAYS, src_caps));
+    gst_caps_unref(sink_caps);
+    gst_caps_unref(src_caps);
+}

@@ -254,6 +254,9 @@ typedef struct mvfx_planar_frame {
  * DESIGN.md); everything that is not on a corner arc is exact. */
 int mvfx_roundedcorners_mask(uint8_t *mask_device, uint32_t width, uint32_t height,
                              uint32_t stride, uint32_t border_radius_px, mvfx_stream stream);
+/* same, into host memory (the shared alpha GstMemory of the element); synchronous */
+int mvfx_roundedcorners_mask_host(uint8_t *mask_host, uint32_t width, uint32_t height,
+                                  uint32_t stride, uint32_t border_radius_px);
 /* I420 -> A420 into one device buffer: copies Y, U, V and the mask as plane 3 (what
  * prepare_output_buffer does by appending the shared alpha GstMemory, border/imp.rs:482-559). */
 int mvfx_roundedcorners_compose_a420(const mvfx_planar_frame *i420_in, const uint8_t *mask_device,

@@ -1,0 +1,36 @@
+"""Locates the GStreamer tools of the image (conda GStreamer 1.14 under /opt/conda) and our
+plugins; shared by the CPU surface test and the GPU pipeline tests."""
+import os
+import shutil
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PLUGIN_DIR = os.path.join(ROOT, "gst-plugin-rs_amd", "gst-plugins")
+PLUGINS = ["libgsthsv.so", "libgstcolorlut.so", "libgstrsvideofx.so"]
+
+
+def tool(name):
+    for cand in (os.path.join("/opt/conda/bin", name), shutil.which(name)):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def available():
+    return tool("gst-launch-1.0") is not None and all(os.path.exists(os.path.join(PLUGIN_DIR, p)) for p in PLUGINS)
+
+
+def env(tmpdir):
+    e = dict(os.environ)
+    e["PATH"] = "/opt/conda/bin:" + e.get("PATH", "")
+    if os.path.isdir("/opt/conda/lib/gstreamer-1.0"):
+        e["GST_PLUGIN_SYSTEM_PATH"] = "/opt/conda/lib/gstreamer-1.0"
+    e["GST_PLUGIN_PATH"] = PLUGIN_DIR
+    e["GST_REGISTRY"] = os.path.join(str(tmpdir), "registry.bin")
+    e["GST_REGISTRY_FORK"] = "no"
+    e.pop("LD_PRELOAD", None)
+    return e
+
+
+def run(args, tmpdir, timeout=120):
+    return subprocess.run(args, env=env(tmpdir), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)

@@ -1,0 +1,101 @@
+"""GPU tests that drive the real GStreamer elements with gst-launch-1.0, written after the
+reference's own pipeline tests (video/videofx/tests/colordetect.rs) and BASELINE config 1/2.
+Skipped when the image has no GStreamer tools (the kernels + C ABI are tested without them)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests import cubes, gst_env
+from tests import oracle_binding as orc
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not gst_env.available(), reason="GStreamer tools or our gst plugins not present")]
+
+LAUNCH = gst_env.tool("gst-launch-1.0")
+
+
+def _capture(tmp, pipeline, out_name="out.raw"):
+    out = os.path.join(str(tmp), out_name)
+    r = gst_env.run([LAUNCH, "-q"] + pipeline.split() + ["!", "filesink", f"location={out}"], tmp)
+    assert r.returncode == 0, r.stdout
+    return np.fromfile(out, dtype=np.uint8)
+
+
+def test_config1_hsvfilter_hue_shift_640x480_rgba(gpu, tmp_path):
+    """BASELINE config 1: videotestsrc 640x480 RGBA ! hsvfilter hue-shift=90"""
+    src = "videotestsrc num-buffers=3 ! video/x-raw,format=RGBA,width=640,height=480"
+    raw = _capture(tmp_path, src, "in.raw")
+    got = _capture(tmp_path, src + " ! hsvfilter hue-shift=90")
+    assert raw.size == got.size == 3 * 640 * 480 * 4
+    exp = raw.copy().reshape(3 * 480, 640 * 4)
+    assert orc.hsvfilter(exp, 640, 640 * 4, "RGBA", (90.0, 1.0, 0.0, 1.0, 0.0)) == 0
+    assert np.array_equal(got.reshape(exp.shape), exp)
+
+
+def test_config2_hsvfilter_then_hsvdetector_negotiates_rgbx(gpu, tmp_path):
+    """hsvfilter ! hsvdetector: RGBx between them, RGBA out"""
+    src = "videotestsrc num-buffers=2 pattern=smpte ! video/x-raw,format=RGBx,width=320,height=240"
+    raw = _capture(tmp_path, src, "in.raw")
+    got = _capture(tmp_path, src + " ! hsvfilter hue-shift=45 saturation-mul=1.25 value-off=0.02 ! hsvdetector hue-ref=120 "
+                   "hue-var=60 saturation-ref=0.6 saturation-var=0.4 value-ref=0.6 value-var=0.4 ! video/x-raw,format=RGBA")
+    mid = raw.copy().reshape(2 * 240, 320 * 4)
+    orc.hsvfilter(mid, 320, 320 * 4, "RGBx", (45.0, 1.25, 0.0, 1.0, 0.02))
+    exp = np.empty_like(mid)
+    orc.hsvdetector(mid, 320 * 4, "RGBx", exp, 320 * 4, "RGBA", 320, (120.0, 60.0, 0.6, 0.4, 0.6, 0.4))
+    assert np.array_equal(got.reshape(exp.shape), exp)
+    assert 0 < np.count_nonzero(exp[:, 3::4]) < exp[:, 3::4].size
+
+
+def test_colordetect_red_posts_exactly_one_message(gpu, tmp_path):
+    """video/videofx/tests/colordetect.rs:21-68"""
+    r = gst_env.run([LAUNCH, "-m"] + "videotestsrc pattern=red num-buffers=2 ! video/x-raw,format=RGBA,width=320,height=240 "
+                    "! colordetect ! fakesink".split(), tmp_path)
+    assert r.returncode == 0, r.stdout
+    msgs = re.findall(r"colordetect, dominant-color=\(string\)(\w+), palette=\(uint\)\{([^}]*)\}", r.stdout)
+    assert len(msgs) == 1, r.stdout
+    assert msgs[0][0] == "red"
+    palette = [int(x) for x in msgs[0][1].split(",")]
+    assert palette[0] == 0xFC0404 and len(palette) == 2
+
+
+def test_colorlut_pipeline(gpu, tmp_path):
+    cube = tmp_path / "look.cube"
+    cube.write_text(cubes.analytic_3d(17))
+    src = "videotestsrc num-buffers=2 pattern=smpte ! video/x-raw,format=RGBA,width=320,height=240"
+    raw = _capture(tmp_path, src, "in.raw")
+    got = _capture(tmp_path, src + f" ! colorlut location={cube}")
+    o = orc.CubeLut(cube.read_text())
+    exp = np.empty_like(raw).reshape(2 * 240, 320 * 4)
+    assert o.apply(raw.reshape(exp.shape), 320 * 4, exp, 320 * 4, 320, 2 * 240, "RGBA") == 0
+    assert np.array_equal(got.reshape(exp.shape), exp)
+
+
+def test_colorlut_without_location_fails_like_the_reference(gpu, tmp_path):
+    """colorlut/imp.rs:175-180: start() -> ResourceError::Settings"""
+    r = gst_env.run([LAUNCH] + "videotestsrc num-buffers=1 ! video/x-raw,format=RGBA ! colorlut ! fakesink".split(), tmp_path)
+    assert r.returncode != 0
+    assert "LUT file location is not configured" in r.stdout
+    bad = tmp_path / "bad.cube"
+    bad.write_text("LUT_1D_SIZE 2\nLUT_3D_SIZE 2\n0 0 0\n1 1 1\n")
+    r = gst_env.run([LAUNCH] + f"videotestsrc num-buffers=1 ! video/x-raw,format=RGBA ! colorlut location={bad} ! fakesink".split(), tmp_path)
+    assert r.returncode != 0 and "Failed to parse LUT file" in r.stdout
+
+
+def test_roundedcorners_i420_to_a420(gpu, tmp_path):
+    """I420 in, A420 out: YUV planes untouched, alpha plane appended (border/imp.rs:482-559)"""
+    w, h, rad = 64, 48, 10
+    src = f"videotestsrc num-buffers=1 ! video/x-raw,format=I420,width={w},height={h}"
+    raw = _capture(tmp_path, src, "in.raw")
+    got = _capture(tmp_path, src + f" ! roundedcorners border-radius-px={rad} ! video/x-raw,format=A420")
+    i420 = w * h * 3 // 2
+    assert raw.size == i420 and got.size == i420 + w * h
+    assert np.array_equal(got[:i420], raw)
+    alpha = got[i420:].reshape(h, w)
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "roundedcorners_masks.npz"))["w64_h48_r10"]
+    assert np.abs(alpha.astype(int) - gold[:h, :w].astype(int)).max() <= 32
+    assert alpha[0, 0] == 0 and alpha[h // 2, w // 2] == 255
+    # radius 0 negotiates I420 passthrough (border/imp.rs:405-409, 460-465)
+    same = _capture(tmp_path, src + " ! roundedcorners ! video/x-raw,format=I420", "pt.raw")
+    assert np.array_equal(same, raw)

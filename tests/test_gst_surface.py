@@ -1,0 +1,97 @@
+"""CPU test of the drop-in element surface: gst-inspect-1.0 of OUR plugins (built against the
+image's GStreamer 1.14) must show the factory names, klass/description/author strings, GType
+hierarchy, pad-template formats and properties (type, default, range, mutability) recorded in
+the reference's docs cache (fixture tests/golden/element_surface.json)."""
+import json
+import os
+import re
+
+import pytest
+
+from tests import gst_env
+
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "element_surface.json")) as f:
+    SURFACE = json.load(f)
+
+pytestmark = pytest.mark.skipif(not gst_env.available(), reason="GStreamer tools or our gst plugins not present (make -C gst-plugin-rs_amd gst)")
+
+BUILT = [("hsv", "hsvfilter"), ("hsv", "hsvdetector"), ("colorlut", "colorlut"), ("rsvideofx", "colordetect"),
+         ("rsvideofx", "roundedcorners")]
+TYPE_WORD = {"gfloat": "Float", "guint": "Unsigned Integer", "gchararray": "String", "gdouble": "Double"}
+MUTABLE = {"playing": "changeable in NULL, READY, PAUSED or PLAYING state", "ready": "changeable only in NULL or READY state"}
+
+
+@pytest.fixture(scope="module")
+def inspect(tmp_path_factory):
+    tmp = tmp_path_factory.mktemp("gst")
+    cache = {}
+
+    def get(element):
+        if element not in cache:
+            r = gst_env.run([gst_env.tool("gst-inspect-1.0"), element], tmp)
+            assert r.returncode == 0, r.stdout
+            cache[element] = r.stdout
+        return cache[element]
+    return get
+
+
+@pytest.mark.parametrize("plugin,element", BUILT)
+def test_factory_details(inspect, plugin, element):
+    text = inspect(element)
+    exp = SURFACE[plugin]["elements"][element]
+    if exp["long-name"]:
+        assert re.search(r"Long-name\s+" + re.escape(exp["long-name"]) + r"\s*$", text, re.M)
+    assert re.search(r"Klass\s+" + re.escape(exp["klass"]) + r"\s*$", text, re.M)
+    assert re.search(r"Description\s+" + re.escape(exp["description"]) + r"\s*$", text, re.M)
+    assert re.search(r"Author\s+" + re.escape(exp["author"]) + r"\s*$", text, re.M)
+    assert re.search(r"Rank\s+none \(0\)", text)
+    assert re.search(r"Name\s+" + plugin + r"\s*$", text, re.M)
+    assert SURFACE[plugin]["description"] in text
+    for gtype in exp["hierarchy"]:
+        assert gtype in text, f"{gtype} missing from the hierarchy of {element}"
+
+
+@pytest.mark.parametrize("plugin,element", BUILT)
+def test_pad_templates(inspect, plugin, element):
+    text = inspect(element)
+    exp = SURFACE[plugin]["elements"][element]["pads"]
+    for pad, info in exp.items():
+        m = re.search(rf"{info['direction'].upper()} template: '{pad}'(.*?)(?:\n\s*\n|Element has)", text, re.S)
+        assert m, f"pad template {pad} missing"
+        block = m.group(1)
+        assert "Availability: Always" in block
+        fm = re.search(r"format: (\{[^}]*\}|\S+)", block)
+        got = [t.strip().replace("(string)", "") for t in fm.group(1).strip("{} ").split(",")]
+        want = info["formats"]
+        if element == "colorlut" and "RGBA64_LE" not in got:
+            want = [f for f in want if not f.startswith("RGBA64")]  # GStreamer 1.14 has no RGBA64
+        assert got == want, f"{element}.{pad}: {got} != {want}"
+        assert "width: [ 1, 2147483647 ]" in block and "framerate: [ 0/1, 2147483647/1 ]" in block
+
+
+@pytest.mark.parametrize("plugin,element", BUILT)
+def test_properties(inspect, plugin, element):
+    text = inspect(element)
+    for name, p in SURFACE[plugin]["elements"][element]["properties"].items():
+        m = re.search(rf"^  {re.escape(name)}\s+: (.*?)\n\s+flags: (.*?)\n\s+(.*?)$", text, re.M)
+        assert m, f"property {name} missing on {element}"
+        blurb, flags, typeline = m.group(1), m.group(2), m.group(3)
+        assert blurb == p["blurb"]
+        assert ("readable" in flags) == p["readable"] and ("writable" in flags) == p["writable"]
+        assert MUTABLE[p["mutable"]] in flags
+        assert typeline.startswith(TYPE_WORD[p["type"]])
+        if p["type"] in ("gfloat", "guint"):
+            rng = re.search(r"Range:\s*(\S+)\s*-\s*(\S+)\s+Default:\s*(\S+)", typeline)
+            lo, hi, default = (float(x) for x in rng.groups())
+            exp_max = float(p["max"]) if p["max"] != "-1" else 4294967295.0  # guint max printed as -1 in the cache
+            assert abs(lo - float(p["min"])) <= 1e-6 * max(1.0, abs(lo))
+            assert abs(hi - exp_max) <= 1e-5 * max(1.0, abs(hi))
+            assert abs(default - float(p["default"])) <= 1e-6
+        else:
+            assert "Default: null" in typeline and p["default"] == "NULL"
+
+
+def test_plugin_licenses(inspect):
+    assert re.search(r"License\s+MIT/X11", inspect("hsvfilter"))
+    assert re.search(r"License\s+MPL", inspect("colordetect"))
+    assert re.search(r"License\s+MPL", inspect("colorlut"))
