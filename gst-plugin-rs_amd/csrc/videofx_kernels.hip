@@ -448,6 +448,26 @@ int mvfx_blockhash_sums(const mvfx_frame *frame, uint32_t row_begin, uint32_t ro
     return blockhash_sums_impl(frame, row_begin, row_end, sums_device, as_stream(stream));
 }
 
+int mvfx_blockhash_sums_band(const mvfx_frame *band, uint32_t full_height, uint32_t band_first_row,
+                             uint32_t *sums_device, mvfx_stream stream)
+{
+    if (!band || !sums_device)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "blockhash: NULL argument");
+    if ((uint64_t)band_first_row + band->height > full_height)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "blockhash: band rows %u..%u exceed the frame height %u", band_first_row,
+                    band_first_row + band->height, full_height);
+    // view of the whole frame whose rows outside the band are never touched
+    mvfx_frame whole = *band;
+    whole.height = full_height;
+    whole.data = static_cast<uint8_t *>(band->data) - (ptrdiff_t)((uint64_t)band_first_row * band->stride);
+    if (band->height == 0 || band->width == 0) {
+        if (int rc = require_device(); rc != MVFX_OK) return rc;
+        MVFX_HIP_TRY(hipMemsetAsync(sums_device, 0, 64 * sizeof(uint32_t), as_stream(stream)));
+        return MVFX_OK;
+    }
+    return blockhash_sums_impl(&whole, band_first_row, band_first_row + band->height, sums_device, as_stream(stream));
+}
+
 int mvfx_blockhash_bits(const uint32_t sums_host[64], uint32_t width, uint32_t height, uint64_t *hash_out)
 {
     if (!sums_host || !hash_out)

@@ -1,0 +1,71 @@
+"""Multi-GPU orchestration of the path (one process per GPU, torch.distributed; backend "nccl" is
+RCCL over xGMI on the GPU node, "gloo" in the CPU tests).
+
+What shards and how (DESIGN.md "Multi-GPU"):
+  * hsvfilter / hsvdetector / colorlut / roundedcorners / colordetect on independent streams:
+    streams are dealt round-robin to ranks; NO data-path collective (`shard_streams`).
+  * videocompare on frames whose rows are already distributed (rank r holds block-row band r of
+    every pad's frame): each rank reduces its band to 64 partial block sums per frame, then ONE
+    all-reduce(sum) of n_pads x 64 u32 (512 B for a pair) makes the totals visible everywhere and
+    every rank derives the hash bits and Hamming distances redundantly (`videocompare_sharded`).
+  * colordetect on one distributed frame: all-reduce(sum) of the 32768-bin histogram plus
+    min/max of the six channel bounds, then the host median cut on every rank
+    (`colordetect_sharded`).
+
+The compute callables are injected so that the same orchestration runs with the HIP kernels
+(through the C ABI) on GPUs and with a CPU stand-in in the world_size-2 gloo tests.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_streams(n_streams: int, rank: int, world: int) -> List[int]:
+    """Independent streams: stream k runs on rank k % world.  No collective is involved."""
+    return [k for k in range(n_streams) if k % world == rank]
+
+
+def band_rows(height: int, rank: int, world: int) -> Tuple[int, int]:
+    """Row band of `rank`: block-row aligned when height % (8*world) allows it (8K: 8 ranks <-> the 8
+    block rows of the 8x8 blockhash grid), otherwise an even split of rows."""
+    if height % 8 == 0 and 8 % world == 0:
+        rows_per_block_row = height // 8
+        per_rank = 8 // world
+        return rank * per_rank * rows_per_block_row, (rank + 1) * per_rank * rows_per_block_row
+    return height * rank // world, height * (rank + 1) // world
+
+
+def videocompare_sharded(partial_sums: Callable[[int], torch.Tensor], n_pads: int, width: int, height: int,
+                         bits_from_sums: Callable[[Sequence[int], int, int], int], device: torch.device,
+                         group=None) -> List[float]:
+    """partial_sums(pad) -> uint32[64] tensor (on `device`) of THIS rank's band of pad's frame
+    (pad 0 = the reference pad, videocompare/imp.rs:210-233).
+    Returns the distances of pads 1.. to the reference pad (videocompare/imp.rs:349-353)."""
+    parts = torch.stack([partial_sums(p).to(torch.int64) for p in range(n_pads)]).to(device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(parts, op=dist.ReduceOp.SUM, group=group)  # n_pads x 64 values, latency-bound
+    totals = parts.cpu().tolist()
+    hashes = [bits_from_sums(t, width, height) for t in totals]
+    return [float(bin(hashes[0] ^ h).count("1")) for h in hashes[1:]]
+
+
+def colordetect_sharded(partial_hist: Callable[[], Tuple[torch.Tensor, torch.Tensor]],
+                        palette_from_hist: Callable[[Sequence[int], Sequence[int]], List[int]],
+                        device: torch.device, group=None) -> List[int]:
+    """partial_hist() -> (uint32[32768] histogram, uint32[6] {rmin,rmax,gmin,gmax,bmin,bmax}) of THIS
+    rank's sample range.  All ranks return the same palette."""
+    hist, mm = partial_hist()
+    hist = hist.to(torch.int64).to(device)
+    lo = mm[0::2].to(torch.int64).to(device)
+    hi = mm[1::2].to(torch.int64).to(device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    minmax = [0] * 6
+    minmax[0::2] = lo.cpu().tolist()
+    minmax[1::2] = hi.cpu().tolist()
+    return palette_from_hist(hist.cpu().tolist(), minmax)

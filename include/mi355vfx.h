@@ -228,6 +228,11 @@ const char *mvfx_css_color_similar(uint8_t r, uint8_t g, uint8_t b);
  * mvfx_blockhash_bits on the total. */
 int mvfx_blockhash_sums(const mvfx_frame *frame, uint32_t row_begin, uint32_t row_end,
                         uint32_t *sums_device, mvfx_stream stream);
+/* Same for a rank that holds ONLY its row band in memory: `band` describes rows
+ * [band_first_row, band_first_row + band->height) of a frame of `full_height` rows. */
+int mvfx_blockhash_sums_band(const mvfx_frame *band, uint32_t full_height,
+                             uint32_t band_first_row, uint32_t *sums_device,
+                             mvfx_stream stream);
 int mvfx_blockhash_bits(const uint32_t sums_host[64], uint32_t width, uint32_t height,
                         uint64_t *hash_out);
 uint32_t mvfx_hash_distance(uint64_t a, uint64_t b);

@@ -128,6 +128,24 @@ def test_blockhash_row_bands_add_up(gpu):
     assert np.array_equal(total.astype(np.uint32), sums)
 
 
+def test_blockhash_band_only_buffers(gpu):
+    """pre-sharded input: each 'rank' holds only its band (mvfx_blockhash_sums_band)"""
+    w, h = 640, 480
+    f = frames.random_frame(0x5EED0802, w, h)
+    total = np.zeros(64, np.uint64)
+    d = gpu.DeviceBuffer(256)
+    for r in range(4):
+        r0, r1 = h * r // 4, h * (r + 1) // 4
+        band = np.ascontiguousarray(f[r0:r1])
+        buf = gpu.DeviceBuffer(band.nbytes).upload(band)
+        fr = gpu.make_frame(buf.ptr, w, r1 - r0, w * 4, "RGBA")
+        gpu.check(gpu.lib().mvfx_blockhash_sums_band(ctypes.byref(fr), h, r0, ctypes.c_void_p(d.ptr), None))
+        gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+        total += d.download(dtype=np.uint32)
+    rc, sums = orc.blockhash_sums(f, w, h, w * 4, "RGBA")
+    assert np.array_equal(total.astype(np.uint32), sums)
+
+
 def test_videocompare_reference_pins(gpu):
     """tests/videocompare.rs:57-139: red vs red -> 0; snow vs red -> > 0; perturbation ladder"""
     w, h = 320, 240
