@@ -20,6 +20,7 @@
 #include "mvfx_internal.h"
 
 #include <cmath>
+#include <cstring>
 
 namespace mvfx {
 namespace {
@@ -50,12 +51,35 @@ __device__ __forceinline__ uint32_t repack4(uint32_t px, uint32_t R, uint32_t G,
 }
 
 template <int OFF, bool BGR, int VARIANT>
-__device__ __forceinline__ uint32_t filter_px4(uint32_t px, const HsvFilterParams &p)
+__device__ __forceinline__ uint32_t filter_px4(uint32_t px, const FastConsts &k, const uint32_t *lut)
 {
-    uint32_t R, G, B;
-    unpack4<OFF, BGR>(px, R, G, B);
-    hsvfilter_pixel<VARIANT>(R, G, B, p);
-    return repack4<OFF, BGR>(px, R, G, B);
+    if constexpr (VARIANT == kGeneral) {
+        uint32_t R, G, B;
+        unpack4<OFF, BGR>(px, R, G, B);
+        hsvfilter_pixel<VARIANT>(R, G, B, k, lut);
+        return repack4<OFF, BGR>(px, R, G, B);
+    } else {
+        // v_cvt_f32_ubyteN straight from the pixel dword; the three candidate output bytes come back
+        // in T and ONE v_perm_b32 with the sextant's selector (8-entry LDS table, built for this
+        // format) places R,G,B and keeps the alpha / x byte of the source pixel.
+        const float c0 = (float)((px >> (8 * OFF)) & 0xffu);
+        const float c1 = (float)((px >> (8 * OFF + 8)) & 0xffu);
+        const float c2 = (float)((px >> (8 * OFF + 16)) & 0xffu);
+        uint32_t T;
+        const uint32_t sext = hsvfilter_fast<VARIANT == kFastNeg>(BGR ? c2 : c0, c1, BGR ? c0 : c2, k, T);
+        return __builtin_amdgcn_perm(T, px, lut[sext]);
+    }
+}
+
+// Fills the 8-entry sextant selector table of this workgroup (no-op for the literal variant).
+template <int VARIANT>
+__device__ __forceinline__ void init_sextant_lut(uint32_t *lut, int off, bool bgr)
+{
+    if constexpr (VARIANT != kGeneral) {
+        if (threadIdx.x < 8)
+            lut[threadIdx.x] = sextant_selector(threadIdx.x, off, bgr);
+        __syncthreads();
+    }
 }
 
 // ---- hsvfilter, 4-byte formats -------------------------------------------------------------
@@ -63,8 +87,11 @@ __device__ __forceinline__ uint32_t filter_px4(uint32_t px, const HsvFilterParam
 template <int OFF, bool BGR, int VARIANT, int MODE>
 __global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint64_t width,
                                                             uint32_t rows, uint64_t stride,
-                                                            HsvFilterParams p)
+                                                            FastConsts p)
 {
+    __shared__ uint32_t lut[8];
+    // vec4 / dword modes permute straight into the pixel layout; the byte mode uses (off 0, RGB)
+    init_sextant_lut<VARIANT>(lut, MODE == kModeBytes ? 0 : OFF, MODE == kModeBytes ? false : BGR);
     uint8_t *frame = fb.base[blockIdx.z];
     for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
         uint8_t *line = frame + (uint64_t)row * stride;
@@ -75,15 +102,15 @@ __global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint6
                 const uint64_t x = g << 2;
                 if (x + 4 <= width) {
                     uint4 v = *reinterpret_cast<const uint4 *>(line + x * 4);
-                    v.x = filter_px4<OFF, BGR, VARIANT>(v.x, p);
-                    v.y = filter_px4<OFF, BGR, VARIANT>(v.y, p);
-                    v.z = filter_px4<OFF, BGR, VARIANT>(v.z, p);
-                    v.w = filter_px4<OFF, BGR, VARIANT>(v.w, p);
+                    v.x = filter_px4<OFF, BGR, VARIANT>(v.x, p, lut);
+                    v.y = filter_px4<OFF, BGR, VARIANT>(v.y, p, lut);
+                    v.z = filter_px4<OFF, BGR, VARIANT>(v.z, p, lut);
+                    v.w = filter_px4<OFF, BGR, VARIANT>(v.w, p, lut);
                     *reinterpret_cast<uint4 *>(line + x * 4) = v;
                 } else {
                     for (uint64_t xx = x; xx < width; xx++) {
                         uint32_t *q = reinterpret_cast<uint32_t *>(line + xx * 4);
-                        *q = filter_px4<OFF, BGR, VARIANT>(*q, p);
+                        *q = filter_px4<OFF, BGR, VARIANT>(*q, p, lut);
                     }
                 }
             }
@@ -91,14 +118,14 @@ __global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint6
             for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < width;
                  x += (uint64_t)gridDim.x * kBlock) {
                 uint32_t *q = reinterpret_cast<uint32_t *>(line + x * 4);
-                *q = filter_px4<OFF, BGR, VARIANT>(*q, p);
+                *q = filter_px4<OFF, BGR, VARIANT>(*q, p, lut);
             }
         } else {
             for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < width;
                  x += (uint64_t)gridDim.x * kBlock) {
                 uint8_t *q = line + x * 4 + OFF;
                 uint32_t R = BGR ? q[2] : q[0], G = q[1], B = BGR ? q[0] : q[2];
-                hsvfilter_pixel<VARIANT>(R, G, B, p);
+                hsvfilter_pixel<VARIANT>(R, G, B, p, lut);
                 q[0] = (uint8_t)(BGR ? B : R);
                 q[1] = (uint8_t)G;
                 q[2] = (uint8_t)(BGR ? R : B);
@@ -114,10 +141,10 @@ struct __attribute__((aligned(4))) U3 {
 
 template <bool BGR, int VARIANT>
 __device__ __forceinline__ void filter_triplet(uint32_t &c0, uint32_t &c1, uint32_t &c2,
-                                               const HsvFilterParams &p)
+                                               const FastConsts &p, const uint32_t *lut)
 {
     uint32_t R = BGR ? c2 : c0, G = c1, B = BGR ? c0 : c2;
-    hsvfilter_pixel<VARIANT>(R, G, B, p);
+    hsvfilter_pixel<VARIANT>(R, G, B, p, lut);
     c0 = BGR ? B : R;
     c1 = G;
     c2 = BGR ? R : B;
@@ -126,8 +153,10 @@ __device__ __forceinline__ void filter_triplet(uint32_t &c0, uint32_t &c1, uint3
 template <bool BGR, int VARIANT, int MODE>
 __global__ __launch_bounds__(kBlock) void hsvfilter3_kernel(FrameBatch fb, uint64_t width,
                                                             uint32_t rows, uint64_t stride,
-                                                            HsvFilterParams p)
+                                                            FastConsts p)
 {
+    __shared__ uint32_t lut[8];
+    init_sextant_lut<VARIANT>(lut, 0, false);
     uint8_t *frame = fb.base[blockIdx.z];
     for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
         uint8_t *line = frame + (uint64_t)row * stride;
@@ -148,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void hsvfilter3_kernel(FrameBatch fb, uint6
                     }
 #pragma unroll
                     for (int px = 0; px < 4; px++)
-                        filter_triplet<BGR, VARIANT>(k[3 * px], k[3 * px + 1], k[3 * px + 2], p);
+                        filter_triplet<BGR, VARIANT>(k[3 * px], k[3 * px + 1], k[3 * px + 2], p, lut);
                     v.a = k[0] | (k[1] << 8) | (k[2] << 16) | (k[3] << 24);
                     v.b = k[4] | (k[5] << 8) | (k[6] << 16) | (k[7] << 24);
                     v.c = k[8] | (k[9] << 8) | (k[10] << 16) | (k[11] << 24);
@@ -157,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void hsvfilter3_kernel(FrameBatch fb, uint6
                     for (uint64_t xx = x; xx < width; xx++) {
                         uint8_t *q = line + xx * 3;
                         uint32_t c0 = q[0], c1 = q[1], c2 = q[2];
-                        filter_triplet<BGR, VARIANT>(c0, c1, c2, p);
+                        filter_triplet<BGR, VARIANT>(c0, c1, c2, p, lut);
                         q[0] = (uint8_t)c0; q[1] = (uint8_t)c1; q[2] = (uint8_t)c2;
                     }
                 }
@@ -167,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void hsvfilter3_kernel(FrameBatch fb, uint6
                  x += (uint64_t)gridDim.x * kBlock) {
                 uint8_t *q = line + x * 3;
                 uint32_t c0 = q[0], c1 = q[1], c2 = q[2];
-                filter_triplet<BGR, VARIANT>(c0, c1, c2, p);
+                filter_triplet<BGR, VARIANT>(c0, c1, c2, p, lut);
                 q[0] = (uint8_t)c0; q[1] = (uint8_t)c1; q[2] = (uint8_t)c2;
             }
         }
@@ -182,7 +211,7 @@ __device__ __forceinline__ uint32_t detect_px(uint32_t c0, uint32_t c1, uint32_t
                                               const HsvDetectorParams &p)
 {
     const uint32_t R = IN_BGR ? c2 : c0, G = c1, B = IN_BGR ? c0 : c2;
-    const Hsv hsv = from_rgb<VARIANT>(R, G, B);
+    const Hsv hsv = from_rgb<VARIANT>(R, G, B, p.consts);
     const uint32_t a = detect_alpha_general(hsv, p);
     const uint32_t o0 = OUT_BGR ? B : R, o2 = OUT_BGR ? R : B;
     return OUT_A0 ? (a | (o0 << 8) | (G << 16) | (o2 << 24))
@@ -259,13 +288,13 @@ __global__ __launch_bounds__(kBlock) void hsvdetector_kernel(const uint8_t *in, 
 template <int OFF, bool BGR, int VARIANT>
 __global__ __launch_bounds__(kBlock) void hsv_from_frame_kernel(const uint8_t *in, float *out,
                                                                 uint32_t width, uint32_t rows,
-                                                                uint64_t stride)
+                                                                uint64_t stride, FastConsts k)
 {
     for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
         for (uint32_t x = blockIdx.x * kBlock + threadIdx.x; x < width; x += gridDim.x * kBlock) {
             const uint8_t *q = in + (uint64_t)row * stride + (uint64_t)x * 4 + OFF;
             const uint32_t R = BGR ? q[2] : q[0], G = q[1], B = BGR ? q[0] : q[2];
-            const Hsv hsv = from_rgb<VARIANT>(R, G, B);
+            const Hsv hsv = from_rgb<VARIANT>(R, G, B, k);
             float *o = out + ((uint64_t)row * width + x) * 3;
             o[0] = hsv.h; o[1] = hsv.s; o[2] = hsv.v;
         }
@@ -286,6 +315,30 @@ bool fast_domain_ok(const mvfx_hsvfilter_settings &s)
             return false;
     const float a = std::fabs(s.hue_shift);
     return a <= 360.0f && (a == 0.0f || a >= 1e-30f);
+}
+
+FastConsts make_consts(const mvfx_hsvfilter_settings *s)
+{
+    FastConsts k{};
+    k.c255 = 1.0f / 255.0f;
+    k.c255lo = (float)(1.0 / 255.0 - (double)k.c255);
+    k.c60 = 1.0f / 60.0f;
+    k.c60lo = (float)(1.0 / 60.0 - (double)k.c60);
+    k.k255 = 255.0f;
+    k.k60 = 60.0f;
+    k.k360 = 360.0f;
+    k.pred360 = std::nextafterf(360.0f, 0.0f);
+    k.tiny = 1e-30f;
+    const float f360 = 360.0f;
+    std::memcpy(&k.bits360, &f360, 4);
+    if (s) {
+        k.hue_shift = s->hue_shift;
+        k.saturation_mul = s->saturation_mul;
+        k.saturation_off = s->saturation_off;
+        k.value_mul = s->value_mul;
+        k.value_off = s->value_off;
+    }
+    return k;
 }
 
 int filter_layout(int format, int *bpp, int *off, bool *bgr)
@@ -341,7 +394,7 @@ Geometry plan(const mvfx_frame *frames, uint32_t n, int bpp, uint32_t n_frames_z
 
 template <int VARIANT>
 void launch_filter(int bpp, int off, bool bgr, const Geometry &g, const FrameBatch &fb,
-                   const HsvFilterParams &p, hipStream_t stream)
+                   const FastConsts &p, hipStream_t stream)
 {
 #define MVFX_L4(O, B, M) \
     hipLaunchKernelGGL((hsvfilter4_kernel<O, B, VARIANT, M>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p)
@@ -404,7 +457,7 @@ int hsvfilter_impl(const mvfx_frame *frames, uint32_t n, const mvfx_hsvfilter_se
         return fail(MVFX_ERR_INVALID_ARGUMENT,
                     "hsvfilter: settings are outside the proven domain of the strength-reduced kernel");
     const bool use_fast = g_variant == 2 || (g_variant == 0 && fast_ok);
-    const HsvFilterParams p{s->hue_shift, s->saturation_mul, s->saturation_off, s->value_mul, s->value_off};
+    const FastConsts p = make_consts(s);
 
     if (frames[0].width == 0 || frames[0].height == 0)
         return MVFX_OK;
@@ -414,7 +467,9 @@ int hsvfilter_impl(const mvfx_frame *frames, uint32_t n, const mvfx_hsvfilter_se
         for (uint32_t i = 0; i < m; i++)
             fb.base[i] = static_cast<uint8_t *>(frames[done + i].data);
         const Geometry g = plan(frames + done, m, bpp, m);
-        if (use_fast)
+        if (use_fast && std::signbit(s->hue_shift) && s->hue_shift != 0.0f)
+            launch_filter<kFastNeg>(bpp, off, bgr, g, fb, p, stream);
+        else if (use_fast)
             launch_filter<kFast>(bpp, off, bgr, g, fb, p, stream);
         else
             launch_filter<kGeneral>(bpp, off, bgr, g, fb, p, stream);
@@ -498,7 +553,7 @@ int hsvdetector_impl(const mvfx_frame *in, const mvfx_frame *out,
         return MVFX_OK;
 
     const HsvDetectorParams p{180.0f - s->hue_ref, s->hue_var, s->saturation_ref,
-                              s->saturation_var, s->value_ref, s->value_var};
+                              s->saturation_var, s->value_ref, s->value_var, make_consts(nullptr)};
     const uint64_t in_need = bpp == 4 ? 15 : 3;
     const bool flat = (uint64_t)in->width * bpp == in->stride && (uint64_t)out->width * 4 == out->stride;
     uint64_t width = in->width, is = in->stride, os = out->stride;
@@ -628,9 +683,10 @@ int mvfx_hsv_from_frame(const mvfx_frame *frame, float *hsv_out_device, mvfx_str
     const uint8_t *in = static_cast<const uint8_t *>(frame->data);
     hipStream_t st = as_stream(stream);
     const bool fast = g_variant != 1;
+    const FastConsts kc = make_consts(nullptr);
 #define MVFX_LH(O, B) \
-    do { if (fast) hipLaunchKernelGGL((hsv_from_frame_kernel<O, B, kFast>), grid, dim3(kBlock), 0, st, in, hsv_out_device, frame->width, frame->height, (uint64_t)frame->stride); \
-         else hipLaunchKernelGGL((hsv_from_frame_kernel<O, B, kGeneral>), grid, dim3(kBlock), 0, st, in, hsv_out_device, frame->width, frame->height, (uint64_t)frame->stride); } while (0)
+    do { if (fast) hipLaunchKernelGGL((hsv_from_frame_kernel<O, B, kFast>), grid, dim3(kBlock), 0, st, in, hsv_out_device, frame->width, frame->height, (uint64_t)frame->stride, kc); \
+         else hipLaunchKernelGGL((hsv_from_frame_kernel<O, B, kGeneral>), grid, dim3(kBlock), 0, st, in, hsv_out_device, frame->width, frame->height, (uint64_t)frame->stride, kc); } while (0)
     if (off == 0) { if (bgr) MVFX_LH(0, true); else MVFX_LH(0, false); }
     else { if (bgr) MVFX_LH(1, true); else MVFX_LH(1, false); }
 #undef MVFX_LH

@@ -36,8 +36,20 @@ struct HsvFilterParams { // hsvfilter/imp.rs:32-39
     float hue_shift, saturation_mul, saturation_off, value_mul, value_off;
 };
 
+struct FastConsts {
+    float c255, c255lo;   // 1/255 = c255 + c255lo   (prove_exact P8)
+    float c60, c60lo;     // 1/60  = c60 + c60lo     (P8)
+    float k255, k60, k360;
+    float pred360;        // largest float below 360 (P9)
+    float tiny;           // 1e-30: keeps rcp() away from 0 without changing any non-zero value
+    uint32_t bits360;     // bit pattern of 360.0f
+    // hsvfilter settings (hsvfilter/imp.rs:32-39)
+    float hue_shift, saturation_mul, saturation_off, value_mul, value_off;
+};
+
 struct HsvDetectorParams { // hsvdetector/imp.rs:34-42, plus ref_hue_offset = 180 - hue_ref (:141)
     float ref_hue_offset, hue_var, saturation_ref, saturation_var, value_ref, value_var;
+    FastConsts consts;
 };
 
 struct Hsv {
@@ -45,7 +57,8 @@ struct Hsv {
 };
 
 constexpr int kGeneral = 0;
-constexpr int kFast = 1;
+constexpr int kFast = 1;    // strength-reduced, 0 <= hue_shift <= 360
+constexpr int kFastNeg = 2; // strength-reduced, -360 <= hue_shift < 0
 
 // hsvutils.rs:16-38 custom Clamp: self.max(lo).min(hi), NaN-ignoring => clamp(NaN) == lo
 __device__ __forceinline__ float hsv_clamp(float v, float lo, float hi)
@@ -148,39 +161,63 @@ __device__ __forceinline__ uint32_t detect_alpha_general(const Hsv hsv, const Hs
 }
 
 // ---------------------------------------------------------------- FAST (exact reductions)
+//
+// Instruction-class budget (tools/probe_isa2.hip on MI355X, T lane-inst/s): VOP1/VOP2 e32
+// mul/add/sub/fmac/and/or/xor/ashr ~57 ("fast"); the same with a 64-bit encoding (VOP3 modifiers,
+// literal constants) ~43; cndmask/cmp/max/min/med3/cvt/perm/alignbyte/VOP3 fma ~36 ("slow");
+// v_rcp_f32 ~19; v_pk_* f32 ~21 per instruction (slower per element than unpacked).  Hence:
+// constants come in through SGPRs (kernel arguments, struct FastConsts) so the VOP2 forms stay
+// 32-bit, a*b+c is written as v_fmac_f32 where one operand dies, sign tests use
+// v_ashrrev_i32 + v_and_b32 instead of v_cmp + v_cndmask, the [0,1] clamps ride on the VOP3 clamp
+// bit, and the 6-way sextant select of to_rgb is a byte rotation (v_alignbyte_b32) of the three
+// converted channel values instead of 5 compares + 10 selects.
 
-// RN(x/255) for x an integer-valued float in [0,255]  (prove_exact P1)
-__device__ __forceinline__ float div255(float x)
+__device__ __forceinline__ float fmac_sv(float acc, float s, float v) // acc + s*v, s in an SGPR
 {
-    const float c = 1.0f / 255.0f;
-    const float q0 = x * c;
-    return __builtin_fmaf(__builtin_fmaf(-255.0f, q0, x), c, q0);
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(s), "v"(v));
+    return acc;
 }
 
-// RN(h/60) for h == 0 or h in [1e-30,360]  (prove_exact P2)
-__device__ __forceinline__ float div60(float h)
+__device__ __forceinline__ float fmac_vv(float acc, float a, float b) // acc + a*b (one rounding)
 {
-    const float c = 1.0f / 60.0f;
-    const float q0 = h * c;
-    return __builtin_fmaf(__builtin_fmaf(-60.0f, q0, h), c, q0);
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+    return acc;
 }
 
-// RN(n/d) for the two from_rgb quotients, d in [1/255,1] (never 0 here), |n| <= d.
-// v_rcp_f32 (<= 1 ulp) seeds one residual correction of the quotient.  Correct rounding on all
-// 2^24 (R,G,B) is established by the exhaustive GPU parity test, not by analysis.
+__device__ __forceinline__ uint32_t sign_mask(float x) // 0xffffffff if the sign bit is set, else 0
+{
+    uint32_t r;
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+__device__ __forceinline__ float add_clamp01(float a, float s) // clamp(a + s, 0, 1) in one VOP3
+{
+    float r;
+    asm("v_add_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(s));
+    return r;
+}
+
+// RN(x/255) for integer-valued x in [0,255]: x*C + RN(x*Clo)  (P8)
+__device__ __forceinline__ float div255(float x, const FastConsts &k) { return fmac_sv(x * k.c255lo, k.c255, x); }
+// RN(h/60) for h == 0 or h in [1e-30,360]  (P8)
+__device__ __forceinline__ float div60(float h, const FastConsts &k) { return fmac_sv(h * k.c60lo, k.c60, h); }
+
+// RN(n/d) for the two from_rgb quotients, d in [1/255,1] (or `tiny`), |n| <= d.  v_rcp_f32
+// (<= 1 ulp) seeds one residual correction of the quotient.  Correct rounding on all 2^24
+// (R,G,B) is established by the exhaustive GPU parity test, not by analysis.
 __device__ __forceinline__ float div_rgb(float n, float d)
 {
     const float y = __builtin_amdgcn_rcpf(d);
     const float q0 = n * y;
     const float r = __builtin_fmaf(-d, q0, n);
-    return __builtin_fmaf(r, y, q0);
+    return fmac_vv(q0, r, y);
 }
 
-__device__ __forceinline__ Hsv from_rgb_fast(uint32_t R, uint32_t G, uint32_t B)
+// hsvutils.rs:44-84 on the byte values as floats (fR = (float)R ...)
+__device__ __forceinline__ Hsv from_rgb_fast(float fR, float fG, float fB, const FastConsts &k)
 {
-    const float r = div255((float)R);
-    const float g = div255((float)G);
-    const float b = div255((float)B);
+    const float r = div255(fR, k), g = div255(fG, k), b = div255(fB, k);
     // RN is monotone, so max/min of the quotients == quotient of the max/min byte
     const float value = fmaxf(r, fmaxf(g, b));
     const float minv = fminf(r, fminf(g, b));
@@ -192,73 +229,105 @@ __device__ __forceinline__ Hsv from_rgb_fast(uint32_t R, uint32_t G, uint32_t B)
     const float n1 = is_r ? g : (is_g ? b : r);
     const float n2 = is_r ? b : (is_g ? r : g);
     const float off = is_r ? 0.0f : (is_g ? 2.0f : 4.0f);
-    // chroma == 0 => all channels equal => n1 - n2 == 0, is_r => hue = 60*(0+0) = 0 as required;
-    // the denominator only has to be non-zero there.
-    const float q = div_rgb(n1 - n2, fmaxf(chroma, 1e-30f));
-    float hue = 60.0f * (off + q); // off == 0: q + 0 is exact, matches the un-added branch
-    const float wrapped = hue + 360.0f;
-    hue = (hue < 0.0f) ? wrapped : hue;
-
+    // chroma == 0 => all channels equal => n1 - n2 == 0 and is_r => hue = 60*(0+0) = 0 as required;
+    // the denominator only has to be non-zero there (chroma + 1e-30 == chroma otherwise).
+    const float q = div_rgb(n1 - n2, chroma + k.tiny);
+    const float hue = (off + q) * k.k60; // off == 0: q + 0 is exact, matches the un-added branch
     Hsv o;
-    o.h = hue;                                         // P4: hue % 360 == hue
-    o.s = div_rgb(chroma, fmaxf(value, 1e-30f));      // value == 0 => chroma == 0 => 0
-    o.v = value;                                       // P4: clamps are identities
+    // `if hue < 0 { hue += 360 }`; hue is never -0.0 (n1 == n2 gives +0), P4: hue % 360 == hue
+    o.h = hue + __uint_as_float(sign_mask(hue) & k.bits360);
+    o.s = div_rgb(chroma, value + k.tiny); // value == 0 => chroma == 0 => 0; P4: clamps are identities
+    o.v = value;
     return o;
 }
 
-// hsvfilter/imp.rs:102-115 for finite settings with |hue_shift| <= 360  (P7)
-__device__ __forceinline__ Hsv filter_hsv_fast(Hsv hsv, const HsvFilterParams &p)
+// hsvfilter/imp.rs:102-115 for finite settings; NEG_SHIFT selects -360 <= shift < 0 vs 0 <= shift <= 360
+template <bool NEG_SHIFT>
+__device__ __forceinline__ Hsv filter_hsv_fast(Hsv hsv, const FastConsts &k)
 {
-    const float x = hsv.h + p.hue_shift;
-    const float t = (x >= 360.0f) ? x - 360.0f : x;
-    hsv.h = (t < 0.0f) ? t + 360.0f : t;
-    // finite settings => no NaN => med3 == max(.,0).min(1)
-    hsv.s = __builtin_amdgcn_fmed3f(p.saturation_mul * hsv.s + p.saturation_off, 0.0f, 1.0f);
-    hsv.v = __builtin_amdgcn_fmed3f(p.value_mul * hsv.v + p.value_off, 0.0f, 1.0f);
+    const float x = hsv.h + k.hue_shift;
+    if constexpr (NEG_SHIFT) { // x in [-360,360): fmod is the identity, then `if <0 {+=360}`  (P9)
+        hsv.h = x + __uint_as_float(sign_mask(x) & k.bits360);
+    } else {                   // x in [0,720): subtract 360 iff x >= 360  (P9)
+        hsv.h = x - __uint_as_float(sign_mask(k.pred360 - x) & k.bits360);
+    }
+    // finite settings => no NaN => the VOP3 clamp == max(.,0).min(1)
+    hsv.s = add_clamp01(k.saturation_mul * hsv.s, k.saturation_off);
+    hsv.v = add_clamp01(k.value_mul * hsv.v, k.value_off);
     return hsv;
 }
 
-// hsvutils.rs:132-163 for h in {0} U [1e-30,360], s,v in [0,1]
-__device__ __forceinline__ void to_rgb_fast(const Hsv in, uint32_t &R, uint32_t &G, uint32_t &B)
+// Sextant table for to_rgb_fast: v_perm_b32 selector that places (R,G,B) of sextant k = floor(h/60)
+// out of the candidate dword T = [Vc, Vx, V0, *] (selector values 4,5,6) and keeps the
+// alpha / x byte of the source pixel (selector values 0..3).  The reference's ladder
+// (hsvutils.rs:138-154) uses closed upper bounds; on the boundaries (h' integer) both neighbours
+// give the same triple because x is 0 or c there, so half-open sextants [k,k+1) are equivalent;
+// k = 6 only occurs for h == 360 where x == 0 (Vx == V0).
+//   k:      0      1      2      3      4      5      6,7
+//   R,G,B:  c,x,0  x,c,0  0,c,x  0,x,c  x,0,c  c,0,x  c,x,0
+// OFF = index of the first colour byte in the pixel, BGR = byte order of the triple.
+__device__ __forceinline__ uint32_t sextant_selector(uint32_t k, int off, bool bgr)
+{
+    // selector byte of R, G, B for sextant k, packed as 0x00BBGGRR
+    const uint32_t rgb = k == 1 ? 0x060405u : k == 2 ? 0x050406u : k == 3 ? 0x040506u
+                       : k == 4 ? 0x040605u : k == 5 ? 0x050604u : 0x060504u;
+    const uint32_t r = rgb & 0xffu, g = (rgb >> 8) & 0xffu, b = rgb >> 16;
+    const uint32_t c0 = bgr ? b : r, c2 = bgr ? r : b;
+    return off == 0 ? (c0 | (g << 8) | (c2 << 16) | (3u << 24)) : (0u | (c0 << 8) | (g << 16) | (c2 << 24));
+}
+
+// hsvutils.rs:132-163 for h in {0} U [1e-30,360], s,v in [0,1].  Writes T = [Vc, Vx, V0, 0] (the
+// three candidate channel bytes) and returns the sextant k in 0..6.
+__device__ __forceinline__ uint32_t to_rgb_fast(const Hsv in, const FastConsts &k, uint32_t &T)
 {
     const float c = in.v * in.s;
-    const float hp = div60(in.h);
-    const float f = __builtin_amdgcn_fractf(0.5f * hp);          // P3
-    const float a = __builtin_fmaf(f, 2.0f, -1.0f);              // RN(fmod(hp,2) - 1), 2f exact
+    const float hp = div60(in.h, k);
+    const float f = __builtin_amdgcn_fractf(0.5f * hp);   // P3: fmod(hp,2) == 2*fract(hp/2)
+    const float a = __builtin_fmaf(f, 2.0f, -1.0f);       // RN(fmod(hp,2) - 1), 2f exact
     const float x = c * (1.0f - fabsf(a));
-
-    // hp in [0,6]: the `< 0` and `> 6` arms of the ladder are unreachable
-    const bool le1 = hp <= 1.0f, le2 = hp <= 2.0f, le3 = hp <= 3.0f, le4 = hp <= 4.0f,
-               le5 = hp <= 5.0f;
-    const float p0 = le1 ? c : le2 ? x : le4 ? 0.0f : le5 ? x : c;
-    const float p1 = le1 ? x : le3 ? c : le4 ? x : 0.0f;
-    const float p2 = le2 ? 0.0f : le3 ? x : le5 ? c : x;
-
     const float m = in.v - c;
-    R = trunc_u8(__builtin_amdgcn_fmed3f((p0 + m) * 255.0f, 0.0f, 255.0f));
-    G = trunc_u8(__builtin_amdgcn_fmed3f((p1 + m) * 255.0f, 0.0f, 255.0f));
-    B = trunc_u8(__builtin_amdgcn_fmed3f((p2 + m) * 255.0f, 0.0f, 255.0f));
+    // (p + m) * 255 with p in {c, x, 0}; all lie in [0,255], `as u8` truncates
+    const float yc = (c + m) * k.k255, yx = (x + m) * k.k255, y0 = m * k.k255;
+    asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD" : "=v"(T) : "v"(yc));
+    asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(T) : "v"(yx));
+    asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(T) : "v"(y0));
+    return (uint32_t)__float2uint_rz(hp);
+}
+
+// One pixel of hsvfilter: byte values as floats in, candidate dword T and sextant out.
+template <bool NEG_SHIFT>
+__device__ __forceinline__ uint32_t hsvfilter_fast(float fR, float fG, float fB, const FastConsts &k, uint32_t &T)
+{
+    return to_rgb_fast(filter_hsv_fast<NEG_SHIFT>(from_rgb_fast(fR, fG, fB, k), k), k, T);
 }
 
 // ---------------------------------------------------------------- dispatch helpers
 
 template <int VARIANT>
-__device__ __forceinline__ Hsv from_rgb(uint32_t R, uint32_t G, uint32_t B)
+__device__ __forceinline__ Hsv from_rgb(uint32_t R, uint32_t G, uint32_t B, const FastConsts &k)
 {
-    if constexpr (VARIANT == kFast)
-        return from_rgb_fast(R, G, B);
-    else
+    if constexpr (VARIANT == kGeneral)
         return from_rgb_general(R, G, B);
+    else
+        return from_rgb_fast((float)R, (float)G, (float)B, k);
 }
 
+// (R,G,B) -> (R,G,B) of hsvfilter for one pixel.  VARIANT: kGeneral, kFast (0 <= shift <= 360),
+// kFastNeg (-360 <= shift < 0).  `lut` = 8 sextant selectors in LDS for layout (off 0, RGB).
 template <int VARIANT>
-__device__ __forceinline__ void hsvfilter_pixel(uint32_t &R, uint32_t &G, uint32_t &B,
-                                                const HsvFilterParams &p)
+__device__ __forceinline__ void hsvfilter_pixel(uint32_t &R, uint32_t &G, uint32_t &B, const FastConsts &k,
+                                                const uint32_t *lut)
 {
-    if constexpr (VARIANT == kFast) {
-        to_rgb_fast(filter_hsv_fast(from_rgb_fast(R, G, B), p), R, G, B);
-    } else {
+    if constexpr (VARIANT == kGeneral) {
+        const HsvFilterParams p{k.hue_shift, k.saturation_mul, k.saturation_off, k.value_mul, k.value_off};
         to_rgb_general(filter_hsv_general(from_rgb_general(R, G, B), p), R, G, B);
+    } else {
+        uint32_t T;
+        const uint32_t sext = hsvfilter_fast<VARIANT == kFastNeg>((float)R, (float)G, (float)B, k, T);
+        const uint32_t rot = __builtin_amdgcn_perm(T, 0u, lut[sext]);
+        R = rot & 0xffu;
+        G = (rot >> 8) & 0xffu;
+        B = (rot >> 16) & 0xffu;
     }
 }
 

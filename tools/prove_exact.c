@@ -13,6 +13,11 @@
  *      in [1e-30,360]  (below ~4.7e-38 the quotient is denormal and the residual underflows;
  *      the FAST kernel's host-side gate keeps h out of (0,1e-30), see hsv_math.hpp)
  *  P3  fmodf(hp,2)    == 2*(t - floorf(t)), t = 0.5*hp, for hp = 0 and every float hp in [1e-32,6]
+ *  P8  2-op forms: u8/255 == fma(x, C, x*Clo) and h/60 == fma(h, C60, h*C60lo) and u16/65535 likewise,
+ *      with Clo = (float)(1/255 - (double)C) etc.  (same domains as P1, P2, P6)
+ *  P9  hue wrap by sign masks: for x in [0,720): x >= 360  <=>  signbit(PRED360 - x), PRED360 = 359.99997
+ *      (largest float below 360), and the result x - (mask & 360) equals P7's; for x in [-360,360):
+ *      signbit(x) ? x + 360 : x equals the reference (x = -0.0 does not occur, see hsv_math.hpp)
  *  P7  fmodf(x,360) followed by `if <0 {+=360}` == conditional +-360 for every float x in
  *      [-360,720) (results compared as floats, +0 == -0)
  *  P4  from_rgb hue is in [0,360) for all 2^24 (R,G,B) => `hue % 360` is the identity
@@ -135,6 +140,50 @@ int main(void)
         }
         printf("P7  hue wrap over %llu floats in [-360,720): %s (%llu mismatches)\n",
                (unsigned long long)n, bad ? "FAIL" : "PASS", (unsigned long long)bad);
+        ok_all &= !bad;
+    }
+    { /* P8 */
+        const float C255lo = (float)(1.0 / 255.0 - (double)C255), C60lo = (float)(1.0 / 60.0 - (double)C60),
+                    C65535lo = (float)(1.0 / 65535.0 - (double)C65535);
+        int bad = 0;
+        for (int x = 0; x < 256; x++) {
+            float fx = (float)x;
+            if (f2u(fmaf(fx, C255, fx * C255lo)) != f2u(fx / 255.0f)) bad++;
+        }
+        for (int x = 0; x < 65536; x++) {
+            float fx = (float)x;
+            if (f2u(fmaf(fx, C65535, fx * C65535lo)) != f2u(fx / 65535.0f)) bad++;
+        }
+        uint64_t bad60 = 0;
+        for (uint32_t u = f2u(1e-30f) - 1; u <= f2u(360.0f); u++) {
+            float h = (u == f2u(1e-30f) - 1) ? 0.0f : u2f(u);
+            if (f2u(fmaf(h, C60, h * C60lo)) != f2u(h / 60.0f)) bad60++;
+        }
+        printf("P8  2-op div255/div65535: %s (%d); 2-op div60: %s (%llu)  [C255lo=%a C60lo=%a C65535lo=%a]\n",
+               bad ? "FAIL" : "PASS", bad, bad60 ? "FAIL" : "PASS", (unsigned long long)bad60, C255lo, C60lo, C65535lo);
+        ok_all &= !bad && !bad60;
+    }
+    { /* P9 */
+        const float PRED360 = u2f(f2u(360.0f) - 1);
+        uint64_t bad = 0;
+        for (uint32_t u = 0; u <= f2u(720.0f) - 1; u++) {
+            float x = u2f(u);
+            float ref = fmodf(x, 360.0f);
+            if (ref < 0.0f) ref += 360.0f;
+            float w = PRED360 - x;
+            uint32_t mask = (uint32_t)((int32_t)f2u(w) >> 31);
+            float fast = x - u2f(mask & f2u(360.0f));
+            if (!(ref == fast)) bad++;
+        }
+        for (uint32_t u = 1; u <= f2u(360.0f); u++) { /* negative x, -0.0 excluded */
+            float x = -u2f(u);
+            float ref = fmodf(x, 360.0f);
+            if (ref < 0.0f) ref += 360.0f;
+            uint32_t mask = (uint32_t)((int32_t)f2u(x) >> 31);
+            float fast = x + u2f(mask & f2u(360.0f));
+            if (!(ref == fast)) bad++;
+        }
+        printf("P9  sign-mask hue wraps: %s (%llu mismatches)\n", bad ? "FAIL" : "PASS", (unsigned long long)bad);
         ok_all &= !bad;
     }
     printf("%s\n", ok_all ? "ALL PASS" : "SOME FAILED");
