@@ -24,13 +24,16 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <algorithm>
 #include <string>
+#include <vector>
 
 struct mvfx_cube_lut {
     mvfx::CubeLut lut;
     std::mutex mu;
     int device = -1;       // device the copies below live on
     float *d_rgba = nullptr;
+    float *d_cells = nullptr; // cell-packed copy: size^3 cells x 8 corners x float4 (3-D, size <= kCellMaxSize)
     float *d_table[3] = {nullptr, nullptr, nullptr};
 };
 
@@ -41,8 +44,19 @@ constexpr int kBlock = 256;
 constexpr uint32_t kLds3dMaxSize = 21;   // 21^3 * 16 B = 148,176 B
 constexpr uint32_t kLds1dMaxSize = 4096; // 3 * 4096 * 4 B = 48 KB
 constexpr int kLdsBlock = 1024;
+constexpr uint32_t kCellMaxSize = 65;    // 65^3 * 128 B = 35 MB; larger cubes keep the node layout only
+
+// Constants of the FAST kernels, passed as kernel arguments so they sit in SGPRs (32-bit VOP2
+// encodings; see hsv_math.hpp for the instruction-class measurements).
+struct LutFast {
+    float c_lo, c_hi;   // 1/255 (or 1/65535) = c_hi + c_lo   (tools/prove_exact.c P8)
+    float out_scale;    // 255 or 65535
+    float pred_half;    // 0.49999997: round-half-away == trunc(v + pred_half)   (P10)
+};
 
 struct LutParams {
+    LutFast fast;
+    const float4 *cells;  // 3-D cell-packed copy (8 corners per cell) or nullptr
     const float4 *cube;   // 3-D nodes
     const float *t[3];    // 1-D tables
     uint32_t size;
@@ -286,7 +300,218 @@ __global__ __launch_bounds__(kLdsBlock) void colorlut_lds_kernel(const uint8_t *
     }
 }
 
-int g_lut_placement = 0; // 0 auto, 1 force global, 2 force LDS (tests / A-B)
+
+// ---------------------------------------------------------------- FAST path (finite domain)
+//
+// Same values as the literal functions above through exact reductions: u8/255 and u16/65535 as
+// mul+fmac (P8), the [0,1] clamps on the VOP3 clamp bit (domain scale/offset finite => no NaN
+// before the LUT; NaN/inf LUT nodes still propagate through the lerps and the final clamp maps
+// NaN to 0 exactly like `NaN as u8`), floor(x) as the truncating convert (x >= 0),
+// round-half-away as trunc(v + 0.49999997) (P10).  3-D cubes up to 65^3 are read from a
+// cell-packed copy (all 8 corners of a cell in one aligned 128-byte line: one L1 line per pixel
+// instead of four, immediate offsets instead of 7 address computations).
+
+__device__ __forceinline__ float lf_fmac_sv(float acc, float s, float v)
+{
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(s), "v"(v));
+    return acc;
+}
+
+__device__ __forceinline__ float lf_add_clamp(float a, float b) // clamp(a + b, 0, 1): NaN -> 0
+{
+    float r;
+    asm("v_add_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// lattice coordinate of one channel: byte/word value as float -> (index, fraction)
+__device__ __forceinline__ void lf_coord(float raw, const LutFast &k, float scale, float offset, float size_m1,
+                                         uint32_t &i0, float &t)
+{
+    const float v = lf_fmac_sv(raw * k.c_lo, k.c_hi, raw);       // RN(raw / 255) or RN(raw / 65535)
+    const float x = lf_add_clamp(v * scale, offset) * size_m1;   // norm_comp * (size - 1), in [0, size-1]
+    i0 = (uint32_t)__float2uint_rz(x);                           // floor (x >= 0); <= size-1 by construction
+    t = x - (float)i0;
+}
+
+__device__ __forceinline__ float lf_lerp(float a, float b, float t) { return a + (b - a) * t; }
+
+// trilinear over the 8 corners c[0..7] = c000,c100,c010,c110,c001,c101,c011,c111; returns the
+// clamped [0,1] channel values
+__device__ __forceinline__ void lf_trilinear(const float4 (&c)[8], float tx, float ty, float tz, float &r, float &g, float &b)
+{
+#define MVFX_CH(ch)                                                                              \
+    {                                                                                            \
+        const float c00 = lf_lerp(c[0].ch, c[1].ch, tx), c10 = lf_lerp(c[2].ch, c[3].ch, tx);    \
+        const float c01 = lf_lerp(c[4].ch, c[5].ch, tx), c11 = lf_lerp(c[6].ch, c[7].ch, tx);    \
+        const float c0 = lf_lerp(c00, c10, ty), c1 = lf_lerp(c01, c11, ty);                      \
+        ch##_out = lf_add_clamp(c0, (c1 - c0) * tz);                                             \
+    }
+    float x_out, y_out, z_out;
+    MVFX_CH(x) MVFX_CH(y) MVFX_CH(z)
+#undef MVFX_CH
+    r = x_out; g = y_out; b = z_out;
+}
+
+template <bool CELLS, typename CUBE>
+__device__ __forceinline__ void lf_sample_3d(CUBE cube, const float4 *cells, uint32_t size, uint32_t x0, uint32_t y0,
+                                             uint32_t z0, float tx, float ty, float tz, float &r, float &g, float &b)
+{
+    float4 c[8];
+    if constexpr (CELLS) {
+        const float4 *cell = cells + (size_t)(x0 + size * (y0 + size * z0)) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            c[i] = cell[i];
+    } else {
+        const uint32_t m = size - 1;
+        const uint32_t x1 = min(x0 + 1, m), y1 = min(y0 + 1, m), z1 = min(z0 + 1, m);
+        const uint32_t s2 = size * size;
+        const uint32_t r00 = y0 * size + z0 * s2, r10 = y1 * size + z0 * s2, r01 = y0 * size + z1 * s2, r11 = y1 * size + z1 * s2;
+        c[0] = cube[x0 + r00]; c[1] = cube[x1 + r00]; c[2] = cube[x0 + r10]; c[3] = cube[x1 + r10];
+        c[4] = cube[x0 + r01]; c[5] = cube[x1 + r01]; c[6] = cube[x0 + r11]; c[7] = cube[x1 + r11];
+    }
+    lf_trilinear(c, tx, ty, tz, r, g, b);
+}
+
+// RGBA8 pixel: converted channels are written into bytes 0..2 of the pixel register in place, so
+// the alpha byte is carried over without a merge instruction.
+template <bool IS3D, bool CELLS, typename CUBE, typename TABLE>
+__device__ __forceinline__ uint32_t lf_px8(uint32_t px, const LutParams &p, CUBE cube, TABLE t0, TABLE t1, TABLE t2)
+{
+    uint32_t ix, iy, iz;
+    float tx, ty, tz;
+    lf_coord((float)(px & 0xffu), p.fast, p.scale[0], p.offset[0], p.size_m1, ix, tx);
+    lf_coord((float)((px >> 8) & 0xffu), p.fast, p.scale[1], p.offset[1], p.size_m1, iy, ty);
+    lf_coord((float)((px >> 16) & 0xffu), p.fast, p.scale[2], p.offset[2], p.size_m1, iz, tz);
+    float r, g, b;
+    if constexpr (IS3D) {
+        lf_sample_3d<CELLS>(cube, p.cells, p.size, ix, iy, iz, tx, ty, tz, r, g, b);
+    } else {
+        const uint32_t m = p.size - 1;
+        const float a0 = t0[ix], b0 = t0[min(ix + 1, m)], a1 = t1[iy], b1 = t1[min(iy + 1, m)], a2 = t2[iz], b2 = t2[min(iz + 1, m)];
+        r = lf_add_clamp(a0, (b0 - a0) * tx);
+        g = lf_add_clamp(a1, (b1 - a1) * ty);
+        b = lf_add_clamp(a2, (b2 - a2) * tz);
+    }
+    const float yr = r * p.fast.out_scale + p.fast.pred_half, yg = g * p.fast.out_scale + p.fast.pred_half,
+                yb = b * p.fast.out_scale + p.fast.pred_half;
+    asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(yr));
+    asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(yg));
+    asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(yb));
+    return px;
+}
+
+template <bool IS3D, bool CELLS, bool LE, typename CUBE, typename TABLE>
+__device__ __forceinline__ void lf_px16(uint32_t &w0, uint32_t &w1, const LutParams &p, CUBE cube, TABLE t0, TABLE t1, TABLE t2)
+{
+    uint32_t rv = w0 & 0xffffu, gv = w0 >> 16, bv = w1 & 0xffffu;
+    if constexpr (!LE) { rv = bswap16(rv); gv = bswap16(gv); bv = bswap16(bv); }
+    uint32_t ix, iy, iz;
+    float tx, ty, tz;
+    lf_coord((float)rv, p.fast, p.scale[0], p.offset[0], p.size_m1, ix, tx);
+    lf_coord((float)gv, p.fast, p.scale[1], p.offset[1], p.size_m1, iy, ty);
+    lf_coord((float)bv, p.fast, p.scale[2], p.offset[2], p.size_m1, iz, tz);
+    float r, g, b;
+    if constexpr (IS3D) {
+        lf_sample_3d<CELLS>(cube, p.cells, p.size, ix, iy, iz, tx, ty, tz, r, g, b);
+    } else {
+        const uint32_t m = p.size - 1;
+        const float a0 = t0[ix], b0 = t0[min(ix + 1, m)], a1 = t1[iy], b1 = t1[min(iy + 1, m)], a2 = t2[iz], b2 = t2[min(iz + 1, m)];
+        r = lf_add_clamp(a0, (b0 - a0) * tx);
+        g = lf_add_clamp(a1, (b1 - a1) * ty);
+        b = lf_add_clamp(a2, (b2 - a2) * tz);
+    }
+    uint32_t ro = (uint32_t)__float2uint_rz(r * p.fast.out_scale + p.fast.pred_half);
+    uint32_t go = (uint32_t)__float2uint_rz(g * p.fast.out_scale + p.fast.pred_half);
+    uint32_t bo = (uint32_t)__float2uint_rz(b * p.fast.out_scale + p.fast.pred_half);
+    if constexpr (!LE) { ro = bswap16(ro); go = bswap16(go); bo = bswap16(bo); }
+    w0 = ro | (go << 16);
+    w1 = bo | (w1 & 0xffff0000u);
+}
+
+// FAST row walker: aligned 16-byte vectors only (the launcher falls back to the literal kernels otherwise)
+template <bool IS3D, bool CELLS, bool WIDE, bool LE, typename CUBE, typename TABLE>
+__device__ __forceinline__ void lf_rows(const uint8_t *in, uint8_t *out, uint64_t width, uint32_t rows, uint64_t in_stride,
+                                        uint64_t out_stride, const LutParams &p, CUBE cube, TABLE t0, TABLE t1, TABLE t2,
+                                        uint32_t first_group, uint32_t group_stride, uint32_t first_row, uint32_t row_stride)
+{
+    constexpr uint32_t PXV = WIDE ? 2 : 4;
+    constexpr uint32_t BPP = WIDE ? 8 : 4;
+    for (uint32_t row = first_row; row < rows; row += row_stride) {
+        const uint8_t *iline = in + (uint64_t)row * in_stride;
+        uint8_t *oline = out + (uint64_t)row * out_stride;
+        const uint64_t groups = (width + PXV - 1) / PXV;
+        for (uint64_t g = first_group; g < groups; g += group_stride) {
+            const uint64_t x = g * PXV;
+            if (x + PXV <= width) {
+                uint4 v = *reinterpret_cast<const uint4 *>(iline + x * BPP);
+                if constexpr (WIDE) {
+                    lf_px16<IS3D, CELLS, LE>(v.x, v.y, p, cube, t0, t1, t2);
+                    lf_px16<IS3D, CELLS, LE>(v.z, v.w, p, cube, t0, t1, t2);
+                } else {
+                    v.x = lf_px8<IS3D, CELLS>(v.x, p, cube, t0, t1, t2);
+                    v.y = lf_px8<IS3D, CELLS>(v.y, p, cube, t0, t1, t2);
+                    v.z = lf_px8<IS3D, CELLS>(v.z, p, cube, t0, t1, t2);
+                    v.w = lf_px8<IS3D, CELLS>(v.w, p, cube, t0, t1, t2);
+                }
+                *reinterpret_cast<uint4 *>(oline + x * BPP) = v;
+            } else {
+                for (uint64_t xx = x; xx < width; xx++) {
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(iline + xx * BPP);
+                    uint32_t *o = reinterpret_cast<uint32_t *>(oline + xx * BPP);
+                    if constexpr (WIDE) {
+                        uint32_t w0 = q[0], w1 = q[1];
+                        lf_px16<IS3D, CELLS, LE>(w0, w1, p, cube, t0, t1, t2);
+                        o[0] = w0; o[1] = w1;
+                    } else {
+                        o[0] = lf_px8<IS3D, CELLS>(q[0], p, cube, t0, t1, t2);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <bool IS3D, bool CELLS, bool WIDE, bool LE>
+__global__ __launch_bounds__(kBlock) void colorlut_fast_global_kernel(const uint8_t *in, uint8_t *out, uint64_t width,
+                                                                      uint32_t rows, uint64_t in_stride,
+                                                                      uint64_t out_stride, LutParams p)
+{
+    lf_rows<IS3D, CELLS, WIDE, LE>(in, out, width, rows, in_stride, out_stride, p, p.cube, p.t[0], p.t[1], p.t[2],
+                                   blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, blockIdx.y, gridDim.y);
+}
+
+template <bool IS3D, bool WIDE, bool LE>
+__global__ __launch_bounds__(kLdsBlock) void colorlut_fast_lds_kernel(const uint8_t *in, uint8_t *out, uint64_t width,
+                                                                      uint32_t rows, uint64_t in_stride,
+                                                                      uint64_t out_stride, LutParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    if constexpr (IS3D) {
+        float4 *cube = reinterpret_cast<float4 *>(lds_raw);
+        const uint32_t n = p.size * p.size * p.size;
+        for (uint32_t i = threadIdx.x; i < n; i += kLdsBlock)
+            cube[i] = p.cube[i];
+        __syncthreads();
+        lf_rows<IS3D, false, WIDE, LE>(in, out, width, rows, in_stride, out_stride, p, (const float4 *)cube,
+                                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                                       blockIdx.x * kLdsBlock + threadIdx.x, gridDim.x * kLdsBlock, blockIdx.y, gridDim.y);
+    } else {
+        float *t = reinterpret_cast<float *>(lds_raw);
+        for (uint32_t i = threadIdx.x; i < p.size; i += kLdsBlock) {
+            t[i] = p.t[0][i];
+            t[p.size + i] = p.t[1][i];
+            t[2 * p.size + i] = p.t[2][i];
+        }
+        __syncthreads();
+        lf_rows<IS3D, false, WIDE, LE>(in, out, width, rows, in_stride, out_stride, p, (const float4 *)nullptr,
+                                       (const float *)t, (const float *)(t + p.size), (const float *)(t + 2 * p.size),
+                                       blockIdx.x * kLdsBlock + threadIdx.x, gridDim.x * kLdsBlock, blockIdx.y, gridDim.y);
+    }
+}
+
+int g_lut_placement = 0; // 0 auto, 1 global node layout, 2 LDS, 3 global cell-packed, 4 literal kernels
 
 int ensure_uploaded(mvfx_cube_lut *h)
 {
@@ -297,12 +522,26 @@ int ensure_uploaded(mvfx_cube_lut *h)
         return MVFX_OK;
     // (re)upload for this device
     if (h->d_rgba) { (void)hipFree(h->d_rgba); h->d_rgba = nullptr; }
+    if (h->d_cells) { (void)hipFree(h->d_cells); h->d_cells = nullptr; }
     for (auto &t : h->d_table) if (t) { (void)hipFree(t); t = nullptr; }
     const CubeLut &l = h->lut;
     if (l.is_3d) {
         const size_t bytes = l.rgba.size() * sizeof(float);
         MVFX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_rgba), bytes));
         MVFX_HIP_TRY(hipMemcpy(h->d_rgba, l.rgba.data(), bytes, hipMemcpyHostToDevice));
+        if (l.size <= kCellMaxSize) { // cell-packed copy: corner (i,j,k) of cell (x,y,z) = node(min(x+i,m), ...)
+            const size_t n = (size_t)l.size, m = n - 1;
+            std::vector<float> cells(n * n * n * 32);
+            for (size_t z = 0; z < n; z++)
+                for (size_t y = 0; y < n; y++)
+                    for (size_t x = 0; x < n; x++)
+                        for (size_t c = 0; c < 8; c++) {
+                            const size_t xx = std::min(x + (c & 1), m), yy = std::min(y + ((c >> 1) & 1), m), zz = std::min(z + (c >> 2), m);
+                            std::memcpy(&cells[((x + n * (y + n * z)) * 8 + c) * 4], &l.rgba[(xx + n * (yy + n * zz)) * 4], 16);
+                        }
+            MVFX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_cells), cells.size() * sizeof(float)));
+            MVFX_HIP_TRY(hipMemcpy(h->d_cells, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     } else {
         for (int c = 0; c < 3; c++) {
             const size_t bytes = l.table[c].size() * sizeof(float);
@@ -372,11 +611,32 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *in, const mvfx_frame *out,
     else align_or |= is | os;
     const bool vec = (align_or & 15) == 0;
 
-    bool use_lds = l.is_3d ? l.size <= kLds3dMaxSize : l.size <= kLds1dMaxSize;
-    if (g_lut_placement == 1) use_lds = false;
-    if (g_lut_placement == 2 && !use_lds)
-        return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: LUT of size %u does not fit in LDS", l.size);
+    const bool fits_lds = l.is_3d ? l.size <= kLds3dMaxSize : l.size <= kLds1dMaxSize;
+    bool finite = true;
+    for (int c = 0; c < 3; c++)
+        finite = finite && std::isfinite(l.domain_scale[c]) && std::isfinite(l.domain_offset[c]);
+    // 0 auto | 1 node layout in global/L2 | 2 LDS | 3 cell-packed global | 4 literal kernels
+    bool use_lds = fits_lds, use_cells = false, use_fast = finite && vec;
+    switch (g_lut_placement) {
+    case 1: use_lds = false; break;
+    case 2:
+        if (!fits_lds) return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: LUT of size %u does not fit in LDS", l.size);
+        use_lds = true; break;
+    case 3:
+        if (!h->d_cells) return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: no cell-packed copy for this LUT (1-D or size > %u)", kCellMaxSize);
+        use_lds = false; use_cells = true; break;
+    case 4: use_fast = false; break;
+    default:
+        use_cells = !use_lds && h->d_cells != nullptr;
+        break;
+    }
+    if (!use_fast) use_cells = false; // the literal kernels read the node layout
     const size_t lds_bytes = l.is_3d ? (size_t)l.size * l.size * l.size * 16 : (size_t)l.size * 12;
+    p.cells = reinterpret_cast<const float4 *>(h->d_cells);
+    p.fast.c_hi = wide ? 1.0f / 65535.0f : 1.0f / 255.0f;
+    p.fast.c_lo = (float)((wide ? 1.0 / 65535.0 : 1.0 / 255.0) - (double)p.fast.c_hi);
+    p.fast.out_scale = wide ? 65535.0f : 255.0f;
+    p.fast.pred_half = std::nextafterf(0.5f, 0.0f);
 
     const uint64_t work = vec ? (width + pxv - 1) / pxv : width;
     dim3 grid;
@@ -386,11 +646,9 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *in, const mvfx_frame *out,
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         uint64_t bx = (work + kLdsBlock - 1) / kLdsBlock;
         if (bx > (uint64_t)cus) bx = (uint64_t)cus; // persistent: one workgroup per CU pays the LDS fill once
-        const uint32_t by = rows > 1 ? 1 : 1;
-        grid = dim3((uint32_t)bx, by, 1);
-        if (rows > 1) { // row-structured frame: spread workgroups over rows instead
+        grid = dim3((uint32_t)bx, 1, 1);
+        if (rows > 1) // row-structured frame: spread workgroups over rows instead
             grid = dim3(1, rows < (uint32_t)cus ? rows : (uint32_t)cus, 1);
-        }
     } else {
         uint64_t bx = (work + kBlock - 1) / kBlock;
         if (bx > 65535u * 16u) bx = 65535u * 16u;
@@ -398,6 +656,29 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *in, const mvfx_frame *out,
     }
     const uint8_t *ip = static_cast<const uint8_t *>(in->data);
     uint8_t *op = static_cast<uint8_t *>(out->data);
+
+    if (use_fast) {
+#define MVFX_FG(IS3D, CELLS, WIDE, LE) \
+    do { hipLaunchKernelGGL((colorlut_fast_global_kernel<IS3D, CELLS, WIDE, LE>), grid, dim3(kBlock), 0, st, ip, op, width, rows, is, os, p); \
+         MVFX_HIP_TRY(hipGetLastError()); return MVFX_OK; } while (0)
+#define MVFX_FL(IS3D, WIDE, LE) \
+    do { auto k = colorlut_fast_lds_kernel<IS3D, WIDE, LE>; \
+         MVFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+         hipLaunchKernelGGL(k, grid, dim3(kLdsBlock), lds_bytes, st, ip, op, width, rows, is, os, p); \
+         MVFX_HIP_TRY(hipGetLastError()); return MVFX_OK; } while (0)
+        if (use_lds) {
+            if (l.is_3d) { if (!wide) MVFX_FL(true, false, true); else if (le) MVFX_FL(true, true, true); else MVFX_FL(true, true, false); }
+            else { if (!wide) MVFX_FL(false, false, true); else if (le) MVFX_FL(false, true, true); else MVFX_FL(false, true, false); }
+        } else if (l.is_3d && use_cells) {
+            if (!wide) MVFX_FG(true, true, false, true); else if (le) MVFX_FG(true, true, true, true); else MVFX_FG(true, true, true, false);
+        } else if (l.is_3d) {
+            if (!wide) MVFX_FG(true, false, false, true); else if (le) MVFX_FG(true, false, true, true); else MVFX_FG(true, false, true, false);
+        } else {
+            if (!wide) MVFX_FG(false, false, false, true); else if (le) MVFX_FG(false, false, true, true); else MVFX_FG(false, false, true, false);
+        }
+#undef MVFX_FG
+#undef MVFX_FL
+    }
 
 #define MVFX_GO(IS3D, WIDE, LE, VEC) \
     return launch_one<IS3D, WIDE, LE, VEC>(use_lds, grid, lds_bytes, st, ip, op, width, rows, is, os, p)
@@ -459,6 +740,7 @@ void mvfx_cube_lut_free(mvfx_cube_lut *lut)
 {
     if (!lut) return;
     if (lut->d_rgba) (void)hipFree(lut->d_rgba);
+    if (lut->d_cells) (void)hipFree(lut->d_cells);
     for (auto &t : lut->d_table) if (t) (void)hipFree(t);
     delete lut;
 }
@@ -488,8 +770,8 @@ const float *mvfx_cube_lut_table_1d(const mvfx_cube_lut *lut, int channel)
 
 int mvfx_colorlut_set_placement(int placement)
 {
-    if (placement < 0 || placement > 2)
-        return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut placement must be 0 (auto), 1 (global/L2) or 2 (LDS)");
+    if (placement < 0 || placement > 4)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut placement must be 0 (auto), 1 (global node layout), 2 (LDS), 3 (global cell-packed) or 4 (literal kernels)");
     g_lut_placement = placement;
     return MVFX_OK;
 }

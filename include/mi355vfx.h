@@ -185,9 +185,12 @@ int mvfx_colorlut_transform_frame(mvfx_cube_lut *lut, const mvfx_frame *in_frame
                                   const mvfx_frame *out_frame, mvfx_stream stream);
 int mvfx_colorlut_transform_frame_host(mvfx_cube_lut *lut, const mvfx_frame *in_frame,
                                        const mvfx_frame *out_frame);
-/* Where the LUT is read from (per process, for A/B and parity tests): 0 = automatic (LDS when
- * the table fits: 3-D size <= 21, 1-D size <= 4096; else global/L2), 1 = always global/L2,
- * 2 = LDS (MVFX_ERR_INVALID_ARGUMENT if it does not fit). */
+/* Where the LUT is read from / which kernel runs (per process, for A/B and parity tests):
+ * 0 = automatic (LDS when the table fits: 3-D size <= 21, 1-D size <= 4096; else the cell-packed
+ * copy for 3-D size <= 65; else the node layout in global/L2), 1 = node layout in global/L2,
+ * 2 = LDS (MVFX_ERR_INVALID_ARGUMENT if it does not fit), 3 = cell-packed global copy,
+ * 4 = the literal-transcription kernels (also used automatically when the LUT's domain
+ * scale/offset are not finite). */
 int mvfx_colorlut_set_placement(int placement);
 
 /* ---- colordetect : video/videofx/src/colordetect/imp.rs ----

@@ -38,10 +38,12 @@ def luts(gpu):
 
 @pytest.mark.parametrize("name", sorted(_cases()))
 @pytest.mark.parametrize("fmt", ["RGBA", "RGBA64_LE", "RGBA64_BE"])
-@pytest.mark.parametrize("placement", [0, 1], ids=["auto", "global"])
+@pytest.mark.parametrize("placement", [0, 1, 3, 4], ids=["auto", "global", "cells", "literal"])
 def test_colorlut_random_frames(gpu, luts, name, fmt, placement):
-    """ragged width, row padding (kept), host entry point, both LUT placements"""
+    """ragged width, row padding (kept), host entry point, every LUT placement / kernel family"""
     dev, o = luts[name]
+    if placement == 3 and not dev.is_3d:
+        pytest.skip("cell-packed layout is 3-D only")
     gpu.check(gpu.lib().mvfx_colorlut_set_placement(placement))
     try:
         for (w, h, pad) in ((257, 9, 16), (64, 8, 0), (1, 1, 0), (1023, 3, 0)):
@@ -58,9 +60,9 @@ def test_colorlut_random_frames(gpu, luts, name, fmt, placement):
         gpu.lib().mvfx_colorlut_set_placement(0)
 
 
-@pytest.mark.parametrize("name", ["analytic33", "analytic21", "identity17", "curve1d_256", "nan_nodes"])
+@pytest.mark.parametrize("name", ["analytic33", "analytic21", "identity17", "curve1d_256", "nan_nodes", "nan_domain"])
 def test_colorlut_exhaustive_rgba8(gpu, luts, name):
-    """all 2^24 RGB triples through the LUT (RGBA8), device entry point"""
+    """all 2^24 RGB triples through the LUT (RGBA8), device entry point, automatic kernel choice"""
     dev, o = luts[name]
     ex = frames.exhaustive_rgbx()
     exp = np.empty_like(ex)

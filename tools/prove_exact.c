@@ -18,6 +18,8 @@
  *  P9  hue wrap by sign masks: for x in [0,720): x >= 360  <=>  signbit(PRED360 - x), PRED360 = 359.99997
  *      (largest float below 360), and the result x - (mask & 360) equals P7's; for x in [-360,360):
  *      signbit(x) ? x + 360 : x equals the reference (x = -0.0 does not occur, see hsv_math.hpp)
+ *  P10 f32::round (half away from zero) of v in [0,65535.5] == truncf(v + PRED_HALF), PRED_HALF = 0.49999997
+ *      (largest float below 0.5); used by colorlut's float_to_u8 / float_to_u16
  *  P7  fmodf(x,360) followed by `if <0 {+=360}` == conditional +-360 for every float x in
  *      [-360,720) (results compared as floats, +0 == -0)
  *  P4  from_rgb hue is in [0,360) for all 2^24 (R,G,B) => `hue % 360` is the identity
@@ -184,6 +186,18 @@ int main(void)
             if (!(ref == fast)) bad++;
         }
         printf("P9  sign-mask hue wraps: %s (%llu mismatches)\n", bad ? "FAIL" : "PASS", (unsigned long long)bad);
+        ok_all &= !bad;
+    }
+    { /* P10 */
+        const float PRED_HALF = u2f(f2u(0.5f) - 1);
+        uint64_t bad = 0, n = 0;
+        for (uint32_t u = 0; u <= f2u(65535.5f); u++) {
+            float v = u2f(u);
+            if (truncf(v + PRED_HALF) != roundf(v)) bad++;
+            n++;
+        }
+        printf("P10 round-half-away == trunc(v + pred(0.5)) over %llu floats in [0,65535.5]: %s (%llu)\n",
+               (unsigned long long)n, bad ? "FAIL" : "PASS", (unsigned long long)bad);
         ok_all &= !bad;
     }
     printf("%s\n", ok_all ? "ALL PASS" : "SOME FAILED");
