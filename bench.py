@@ -224,6 +224,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
+    # HBM traffic per launch from the committed rocprofv3 PMC passes (cannot be collected live)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "hsvfilter_traffic.json")) as f:
+            t = json.load(f)
+        traffic = t["hbm_bytes_per_launch"] * args.batch / t["frames_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     total_frames = args.steps * args.batch * world
     fps = total_frames / elapsed
     bytes_per_launch = args.batch * 2 * FRAME_BYTES  # 4 B read + 4 B written per pixel
@@ -247,7 +255,7 @@ def main():
                    "parallelism": f"{world} independent stream shards, no data-path collective",
                    "kernel_variant": {0: "auto", 1: "literal", 2: "strength-reduced"}[args.variant]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "hsvfilter4_kernel<RGBA, vec4>", "bytes_per_launch": bytes_per_launch,
                      "avg_launch_ms": kernel_ms, "read_side_GBs": achieved / 2},
     }

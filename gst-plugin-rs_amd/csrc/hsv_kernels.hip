@@ -212,10 +212,31 @@ __device__ __forceinline__ uint32_t detect_px(uint32_t c0, uint32_t c1, uint32_t
 {
     const uint32_t R = IN_BGR ? c2 : c0, G = c1, B = IN_BGR ? c0 : c2;
     const Hsv hsv = from_rgb<VARIANT>(R, G, B, p.consts);
-    const uint32_t a = detect_alpha_general(hsv, p);
+    uint32_t a;
+    if constexpr (VARIANT == kDetFast)
+        a = ~detect_miss_mask_fast(hsv, p) & 0xffu;
+    else
+        a = detect_alpha_general(hsv, p);
     const uint32_t o0 = OUT_BGR ? B : R, o2 = OUT_BGR ? R : B;
     return OUT_A0 ? (a | (o0 << 8) | (G << 16) | (o2 << 24))
                   : (o0 | (G << 8) | (o2 << 16) | (a << 24));
+}
+
+// 4-byte input pixel -> output pixel in one v_perm_b32: colour bytes come straight from the source
+// dword, the alpha byte from the hit mask.
+template <int IN_OFF, bool IN_BGR, bool OUT_A0, bool OUT_BGR>
+__device__ __forceinline__ uint32_t detect_px4_fast(uint32_t px, const HsvDetectorParams &p)
+{
+    const float c0 = (float)((px >> (8 * IN_OFF)) & 0xffu);
+    const float c1 = (float)((px >> (8 * IN_OFF + 8)) & 0xffu);
+    const float c2 = (float)((px >> (8 * IN_OFF + 16)) & 0xffu);
+    const Hsv hsv = from_rgb_fast(IN_BGR ? c2 : c0, c1, IN_BGR ? c0 : c2, p.consts);
+    const uint32_t hit = ~detect_miss_mask_fast(hsv, p); // 0xffffffff on a hit: any byte of it is the alpha
+    // selector: 0..3 = bytes of px, 4 = alpha
+    constexpr uint32_t iR = IN_OFF + (IN_BGR ? 2 : 0), iG = IN_OFF + 1, iB = IN_OFF + (IN_BGR ? 0 : 2);
+    constexpr uint32_t o0 = OUT_BGR ? iB : iR, o2 = OUT_BGR ? iR : iB;
+    constexpr uint32_t sel = OUT_A0 ? (4u | (o0 << 8) | (iG << 16) | (o2 << 24)) : (o0 | (iG << 8) | (o2 << 16) | (4u << 24));
+    return __builtin_amdgcn_perm(hit, px, sel);
 }
 
 template <int IN_BPP, int IN_OFF, bool IN_BGR, bool OUT_A0, bool OUT_BGR, int VARIANT, int MODE>
@@ -240,10 +261,14 @@ __global__ __launch_bounds__(kBlock) void hsvdetector_kernel(const uint8_t *in, 
                         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
                         uint32_t r[4];
 #pragma unroll
-                        for (int i = 0; i < 4; i++)
-                            r[i] = detect_px<IN_BPP, IN_OFF, IN_BGR, OUT_A0, OUT_BGR, VARIANT>(
-                                (w[i] >> (8 * IN_OFF)) & 0xffu, (w[i] >> (8 * IN_OFF + 8)) & 0xffu,
-                                (w[i] >> (8 * IN_OFF + 16)) & 0xffu, p);
+                        for (int i = 0; i < 4; i++) {
+                            if constexpr (VARIANT == kDetFast)
+                                r[i] = detect_px4_fast<IN_OFF, IN_BGR, OUT_A0, OUT_BGR>(w[i], p);
+                            else
+                                r[i] = detect_px<IN_BPP, IN_OFF, IN_BGR, OUT_A0, OUT_BGR, VARIANT>(
+                                    (w[i] >> (8 * IN_OFF)) & 0xffu, (w[i] >> (8 * IN_OFF + 8)) & 0xffu,
+                                    (w[i] >> (8 * IN_OFF + 16)) & 0xffu, p);
+                        }
                         o = make_uint4(r[0], r[1], r[2], r[3]);
                     } else {
                         const U3 v = *reinterpret_cast<const U3 *>(iline + x * 3);
@@ -552,8 +577,13 @@ int hsvdetector_impl(const mvfx_frame *in, const mvfx_frame *out,
     if (in->width == 0 || in->height == 0)
         return MVFX_OK;
 
-    const HsvDetectorParams p{180.0f - s->hue_ref, s->hue_var, s->saturation_ref,
-                              s->saturation_var, s->value_ref, s->value_var, make_consts(nullptr)};
+    // |a - ref| <= -0.0  <=>  |a - ref| <= +0.0: canonicalise so the sign-based test sees +0
+    const auto pz = [](float v) { return v == 0.0f ? 0.0f : v; };
+    const HsvDetectorParams p{180.0f - s->hue_ref, pz(s->hue_var), s->saturation_ref, pz(s->saturation_var),
+                              s->value_ref, pz(s->value_var), 180.0f, make_consts(nullptr)};
+    const float dv[6] = {s->hue_ref, s->hue_var, s->saturation_ref, s->saturation_var, s->value_ref, s->value_var};
+    bool det_fast_ok = std::fabs(p.ref_hue_offset) <= 360.0f;
+    for (float f : dv) det_fast_ok = det_fast_ok && std::isfinite(f);
     const uint64_t in_need = bpp == 4 ? 15 : 3;
     const bool flat = (uint64_t)in->width * bpp == in->stride && (uint64_t)out->width * 4 == out->stride;
     uint64_t width = in->width, is = in->stride, os = out->stride;
@@ -571,13 +601,18 @@ int hsvdetector_impl(const mvfx_frame *in, const mvfx_frame *out,
     const dim3 grid((uint32_t)bx, rows < 65535u ? rows : 65535u, 1);
     const uint8_t *ip = static_cast<const uint8_t *>(in->data);
     uint8_t *op = static_cast<uint8_t *>(out->data);
-    // from_rgb's FAST form is settings-independent, so it is always valid here
-    const bool fast = g_variant != 1;
+    // from_rgb's FAST form is settings-independent, so it is always valid here; the hue test has
+    // its own domain (det_fast_ok).  g_variant: 0 auto, 1 everything literal, 2 force both fast.
+    if (g_variant == 2 && !det_fast_ok)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvdetector: settings are outside the proven domain of the strength-reduced hue test");
+    const int variant = g_variant == 1 ? kGeneral : (det_fast_ok ? kDetFast : kFast);
     if (vec) {
-        if (fast) launch_detect<kFast, kModeVec4>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
+        if (variant == kDetFast) launch_detect<kDetFast, kModeVec4>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
+        else if (variant == kFast) launch_detect<kFast, kModeVec4>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
         else launch_detect<kGeneral, kModeVec4>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
     } else {
-        if (fast) launch_detect<kFast, kModeBytes>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
+        if (variant == kDetFast) launch_detect<kDetFast, kModeBytes>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
+        else if (variant == kFast) launch_detect<kFast, kModeBytes>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
         else launch_detect<kGeneral, kModeBytes>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
     }
     MVFX_HIP_TRY(hipGetLastError());

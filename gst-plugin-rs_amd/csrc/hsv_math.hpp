@@ -49,6 +49,7 @@ struct FastConsts {
 
 struct HsvDetectorParams { // hsvdetector/imp.rs:34-42, plus ref_hue_offset = 180 - hue_ref (:141)
     float ref_hue_offset, hue_var, saturation_ref, saturation_var, value_ref, value_var;
+    float k180;
     FastConsts consts;
 };
 
@@ -59,6 +60,7 @@ struct Hsv {
 constexpr int kGeneral = 0;
 constexpr int kFast = 1;    // strength-reduced, 0 <= hue_shift <= 360
 constexpr int kFastNeg = 2; // strength-reduced, -360 <= hue_shift < 0
+constexpr int kDetFast = 3; // hsvdetector: strength-reduced from_rgb AND hue test (finite settings, |180 - hue_ref| <= 360)
 
 // hsvutils.rs:16-38 custom Clamp: self.max(lo).min(hi), NaN-ignoring => clamp(NaN) == lo
 __device__ __forceinline__ float hsv_clamp(float v, float lo, float hi)
@@ -299,6 +301,24 @@ template <bool NEG_SHIFT>
 __device__ __forceinline__ uint32_t hsvfilter_fast(float fR, float fG, float fB, const FastConsts &k, uint32_t &T)
 {
     return to_rgb_fast(filter_hsv_fast<NEG_SHIFT>(from_rgb_fast(fR, fG, fB, k), k), k, T);
+}
+
+// hsvdetector/imp.rs:141-155 for finite settings with |ref_hue_offset| <= 360: the `+= 360` and the
+// `% 360` become sign-mask +-360 (P9: x in [-360,720) after one conditional +360 lies in [0,720)),
+// each `|a - ref| <= var` becomes the sign of RN(var - |a - ref|) (exact sign, +0 on equality; the
+// host maps a -0.0 var to +0.0).  Returns 0xffffffff for a MISS and 0 for a hit.
+__device__ __forceinline__ uint32_t detect_miss_mask_fast(const Hsv hsv, const HsvDetectorParams &p)
+{
+    const FastConsts &k = p.consts;
+    const float x = hsv.h + p.ref_hue_offset;
+    const float x1 = x + __uint_as_float(sign_mask(x) & k.bits360);
+    const float x2 = x1 - __uint_as_float(sign_mask(k.pred360 - x1) & k.bits360);
+    const float d1 = p.hue_var - fabsf(x2 - p.k180);
+    const float d2 = p.saturation_var - fabsf(hsv.s - p.saturation_ref);
+    const float d3 = p.value_var - fabsf(hsv.v - p.value_ref);
+    uint32_t m = __float_as_uint(d1) | __float_as_uint(d2) | __float_as_uint(d3);
+    asm("v_ashrrev_i32 %0, 31, %0" : "+v"(m));
+    return m;
 }
 
 // ---------------------------------------------------------------- dispatch helpers

@@ -197,6 +197,8 @@ def test_hsvfilter_rejects_bad_arguments(gpu):
 # ---------------------------------------------------------------- hsvdetector
 
 DETECT_SETTINGS = [
+    (540.0, 0.0, 0.5, 0.5, 0.5, 0.5),           # ref_off = -360 (domain edge), hue_var = 0: exact-equality hits only
+    (-180.0, 180.0, 0.25, 0.0, 1.0, 0.0),       # ref_off = +360 (other edge), zero sat/val tolerance
     (0.0, 10.0, 0.0, 0.15, 0.0, 0.3),           # defaults
     (120.0, 40.0, 0.6, 0.4, 0.6, 0.4),          # bench settings
     (350.0, 25.0, 0.5, 0.5, 0.5, 0.5),          # wraps through 0
@@ -218,7 +220,7 @@ def test_hsvdetector_all_24_pairs(gpu, in_fmt, out_fmt):
             in_stride += 4
         out_stride = w * 4 + pad
         src = frames.random_frame(0x5EED0200 + w, w, h, bpp, in_stride)
-        for settings in DETECT_SETTINGS[:3]:
+        for settings in DETECT_SETTINGS[:5]:
             sentinel = np.full((h, out_stride), 0xA5, dtype=np.uint8)
             expect = sentinel.copy()
             assert orc.hsvdetector(src, in_stride, in_fmt, expect, out_stride, out_fmt, w, settings) == 0
@@ -229,9 +231,11 @@ def test_hsvdetector_all_24_pairs(gpu, in_fmt, out_fmt):
 
 
 @pytest.mark.parametrize("settings", DETECT_SETTINGS)
-@pytest.mark.parametrize("variant", [0, 1], ids=["auto", "general"])
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=["auto", "general", "fast"])
 def test_hsvdetector_exhaustive(gpu, exhaustive, settings, variant):
     """All 2^24 triples RGBx -> RGBA: colour copied, alpha 0/255 exactly as the reference."""
+    if variant == 2 and not (np.isfinite(settings[0]) and abs(180.0 - settings[0]) <= 360.0):
+        pytest.skip("outside the strength-reduced hue test's domain (auto mode covers it with the literal test)")
     expect = np.empty_like(exhaustive)
     assert orc.hsvdetector(exhaustive, 4096 * 4, "RGBx", expect, 4096 * 4, "RGBA", 4096, settings) == 0
     src = gpu.DeviceBuffer(exhaustive.nbytes).upload(exhaustive)
@@ -247,7 +251,7 @@ def test_hsvdetector_exhaustive(gpu, exhaustive, settings, variant):
         gpu.lib().mvfx_hsvfilter_set_variant(0)
     got = dst.download().reshape(exhaustive.shape)
     assert np.array_equal(got, expect)
-    if not np.isnan(settings[0]):
+    if not np.isnan(settings[0]) and settings[1] > 0 and settings[3] > 0:
         assert got[:, 3::4].max() == 255 or settings[0] > 1e5  # (a hue_ref far below -180 never matches: one +360 only)
 
 
@@ -258,14 +262,14 @@ def test_hsvdetector_1080p_after_hsvfilter(gpu):
     expect_mid = frame.copy()
     orc.hsvfilter(expect_mid, w, w * 4, "RGBx", BENCH_SETTINGS)
     expect = np.empty_like(frame)
-    orc.hsvdetector(expect_mid, w * 4, "RGBx", expect, w * 4, "RGBA", w, DETECT_SETTINGS[1])
+    orc.hsvdetector(expect_mid, w * 4, "RGBx", expect, w * 4, "RGBA", w, DETECT_SETTINGS[3])
     src = gpu.DeviceBuffer(frame.nbytes).upload(frame)
     dst = gpu.DeviceBuffer(frame.nbytes)
     gpu.hsvfilter_device(src.ptr, w, h, w * 4, "RGBx", gpu.HsvFilterSettings(*BENCH_SETTINGS))
     fi = gpu.make_frame(src.ptr, w, h, w * 4, "RGBx")
     fo = gpu.make_frame(dst.ptr, w, h, w * 4, "RGBA")
     gpu.check(gpu.lib().mvfx_hsvdetector_transform_frame(ctypes.byref(fi), ctypes.byref(fo),
-                                                         ctypes.byref(gpu.HsvDetectorSettings(*DETECT_SETTINGS[1])), None))
+                                                         ctypes.byref(gpu.HsvDetectorSettings(*DETECT_SETTINGS[3])), None))
     gpu.check(gpu.lib().mvfx_stream_synchronize(None))
     assert np.array_equal(src.download().reshape(h, w * 4), expect_mid)
     assert np.array_equal(dst.download().reshape(h, w * 4), expect)

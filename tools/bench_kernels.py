@@ -130,6 +130,50 @@ def main():
         ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fi[i % 8]), ctypes.byref(fo[i % 8]), sptr)), iters=16)
         report("colorlut 3D 33^3 RGBA64_LE 4K random", ms, 4 * NB, 1)
 
+    if want("colordetect"):
+        src = rand_frames(POOL, NB, 9)
+        hist = torch.zeros(32768 + 8, dtype=torch.int32, device=dev)
+        fr = [vfx.make_frame(src[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
+        for q in (10, 1):
+            ms = timeit(lambda i=0: vfx.check(lib.mvfx_colordetect_histogram(ctypes.byref(fr[i % POOL]), q, 0, vfx.ALL_SAMPLES,
+                        ctypes.c_void_p(hist.data_ptr()), ctypes.c_void_p(hist.data_ptr() + 32768 * 4), sptr)), iters=32)
+            report(f"colordetect histogram 4K RGBA quality={q}", ms, NB, 1)
+
+    if want("blockhash"):
+        W8, H8 = 7680, 4320
+        src = rand_frames(4, W8 * H8 * 4, 10)
+        sums = torch.zeros(64, dtype=torch.int32, device=dev)
+        fr = [vfx.make_frame(src[i].data_ptr(), W8, H8, W8 * 4, "RGBA") for i in range(4)]
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_blockhash_sums(ctypes.byref(fr[i % 4]), 0, H8, ctypes.c_void_p(sums.data_ptr()), sptr)), iters=16)
+        report("blockhash sums 8K RGBA (one frame)", ms, W8 * H8 * 4, 1)
+        src4 = rand_frames(POOL, NB, 11)
+        fr = [vfx.make_frame(src4[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_blockhash_sums(ctypes.byref(fr[i % POOL]), 0, H, ctypes.c_void_p(sums.data_ptr()), sptr)), iters=32)
+        report("blockhash sums 4K RGBA", ms, NB, 1)
+
+    if want("roundedcorners"):
+        mask = torch.empty(W * H, dtype=torch.uint8, device=dev)
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_roundedcorners_mask(ctypes.c_void_p(mask.data_ptr()), W, H, W, 100, sptr)), iters=32)
+        report("roundedcorners mask 4K r=100 (once per config)", ms, W * H, 1)
+        i420 = rand_frames(POOL, W * H * 3 // 2, 12)
+        a420 = torch.empty((POOL, W * H * 5 // 2), dtype=torch.uint8, device=dev)
+        def compose(i=0):
+            k = i % POOL
+            fi, fo = vfx.PlanarFrame(), vfx.PlanarFrame()
+            offs = [0, W * H, W * H * 5 // 4, W * H * 3 // 2]
+            for p_ in range(3):
+                fi.data[p_] = i420[k].data_ptr() + offs[p_]
+                fo.data[p_] = a420[k].data_ptr() + offs[p_]
+                fi.stride[p_] = fo.stride[p_] = W if p_ == 0 else W // 2
+            fo.data[3] = a420[k].data_ptr() + offs[3]
+            fo.stride[3] = W
+            fi.width = fo.width = W
+            fi.height = fo.height = H
+            fi.format, fo.format = vfx.FORMATS["I420"], vfx.FORMATS["A420"]
+            vfx.check(lib.mvfx_roundedcorners_compose_a420(ctypes.byref(fi), ctypes.c_void_p(mask.data_ptr()), W, ctypes.byref(fo), sptr))
+        ms = timeit(compose, iters=32)
+        report("roundedcorners I420->A420 compose 4K", ms, W * H * 4, 1)
+
     # d2d copy ceiling measured on this box (SURVEY 8d asks for it next to the 8 TB/s spec)
     if want("copy"):
         a = rand_frames(POOL, NB, 8)
