@@ -50,34 +50,39 @@ __device__ __forceinline__ uint32_t repack4(uint32_t px, uint32_t R, uint32_t G,
     return (px & keep) | (c0 << (8 * OFF)) | (G << (8 * OFF + 8)) | (c2 << (8 * OFF + 16));
 }
 
+// LDS tables of one workgroup of the FAST hsvfilter kernels
+struct FilterLds {
+    uint32_t sextant[8]; // v_perm_b32 selectors, see sextant_selector()
+};
+
 template <int OFF, bool BGR, int VARIANT>
-__device__ __forceinline__ uint32_t filter_px4(uint32_t px, const FastConsts &k, const uint32_t *lut)
+__device__ __forceinline__ uint32_t filter_px4(uint32_t px, const FastConsts &k, const FilterLds &lds)
 {
     if constexpr (VARIANT == kGeneral) {
         uint32_t R, G, B;
         unpack4<OFF, BGR>(px, R, G, B);
-        hsvfilter_pixel<VARIANT>(R, G, B, k, lut);
+        hsvfilter_pixel<VARIANT>(R, G, B, k, lds.sextant);
         return repack4<OFF, BGR>(px, R, G, B);
     } else {
-        // v_cvt_f32_ubyteN straight from the pixel dword; the three candidate output bytes come back
-        // in T and ONE v_perm_b32 with the sextant's selector (8-entry LDS table, built for this
-        // format) places R,G,B and keeps the alpha / x byte of the source pixel.
-        const float c0 = (float)((px >> (8 * OFF)) & 0xffu);
-        const float c1 = (float)((px >> (8 * OFF + 8)) & 0xffu);
-        const float c2 = (float)((px >> (8 * OFF + 16)) & 0xffu);
+        // v_cvt_f32_ubyteN straight from the pixel dword + the exact 2-op divide.  (A 256-entry LDS
+        // table of RN(b/255) was measured slower: 3 more random ds_read_b32 per pixel cost more in
+        // bank conflicts than the 5 fast VALU ops they replace: 60.3 k vs 68.2 k frames/s.)
+        const float c0 = div255((float)((px >> (8 * OFF)) & 0xffu), k);
+        const float c1 = div255((float)((px >> (8 * OFF + 8)) & 0xffu), k);
+        const float c2 = div255((float)((px >> (8 * OFF + 16)) & 0xffu), k);
         uint32_t T;
-        const uint32_t sext = hsvfilter_fast<VARIANT == kFastNeg>(BGR ? c2 : c0, c1, BGR ? c0 : c2, k, T);
-        return __builtin_amdgcn_perm(T, px, lut[sext]);
+        const uint32_t sext = hsvfilter_fast_unit<VARIANT == kFastNeg>(BGR ? c2 : c0, c1, BGR ? c0 : c2, k, T);
+        return __builtin_amdgcn_perm(T, px, lds.sextant[sext]);
     }
 }
 
-// Fills the 8-entry sextant selector table of this workgroup (no-op for the literal variant).
+// Fills the LDS tables of this workgroup (no-op for the literal variant). blockDim.x == 256.
 template <int VARIANT>
-__device__ __forceinline__ void init_sextant_lut(uint32_t *lut, int off, bool bgr)
+__device__ __forceinline__ void init_filter_lds(FilterLds &lds, int off, bool bgr)
 {
     if constexpr (VARIANT != kGeneral) {
         if (threadIdx.x < 8)
-            lut[threadIdx.x] = sextant_selector(threadIdx.x, off, bgr);
+            lds.sextant[threadIdx.x] = sextant_selector(threadIdx.x, off, bgr);
         __syncthreads();
     }
 }
@@ -89,9 +94,10 @@ __global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint6
                                                             uint32_t rows, uint64_t stride,
                                                             FastConsts p)
 {
-    __shared__ uint32_t lut[8];
+    __shared__ FilterLds lds;
     // vec4 / dword modes permute straight into the pixel layout; the byte mode uses (off 0, RGB)
-    init_sextant_lut<VARIANT>(lut, MODE == kModeBytes ? 0 : OFF, MODE == kModeBytes ? false : BGR);
+    init_filter_lds<VARIANT>(lds, MODE == kModeBytes ? 0 : OFF, MODE == kModeBytes ? false : BGR);
+    const uint32_t *lut = lds.sextant;
     uint8_t *frame = fb.base[blockIdx.z];
     for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
         uint8_t *line = frame + (uint64_t)row * stride;
@@ -102,15 +108,15 @@ __global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint6
                 const uint64_t x = g << 2;
                 if (x + 4 <= width) {
                     uint4 v = *reinterpret_cast<const uint4 *>(line + x * 4);
-                    v.x = filter_px4<OFF, BGR, VARIANT>(v.x, p, lut);
-                    v.y = filter_px4<OFF, BGR, VARIANT>(v.y, p, lut);
-                    v.z = filter_px4<OFF, BGR, VARIANT>(v.z, p, lut);
-                    v.w = filter_px4<OFF, BGR, VARIANT>(v.w, p, lut);
+                    v.x = filter_px4<OFF, BGR, VARIANT>(v.x, p, lds);
+                    v.y = filter_px4<OFF, BGR, VARIANT>(v.y, p, lds);
+                    v.z = filter_px4<OFF, BGR, VARIANT>(v.z, p, lds);
+                    v.w = filter_px4<OFF, BGR, VARIANT>(v.w, p, lds);
                     *reinterpret_cast<uint4 *>(line + x * 4) = v;
                 } else {
                     for (uint64_t xx = x; xx < width; xx++) {
                         uint32_t *q = reinterpret_cast<uint32_t *>(line + xx * 4);
-                        *q = filter_px4<OFF, BGR, VARIANT>(*q, p, lut);
+                        *q = filter_px4<OFF, BGR, VARIANT>(*q, p, lds);
                     }
                 }
             }
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint6
             for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < width;
                  x += (uint64_t)gridDim.x * kBlock) {
                 uint32_t *q = reinterpret_cast<uint32_t *>(line + x * 4);
-                *q = filter_px4<OFF, BGR, VARIANT>(*q, p, lut);
+                *q = filter_px4<OFF, BGR, VARIANT>(*q, p, lds);
             }
         } else {
             for (uint64_t x = (uint64_t)blockIdx.x * kBlock + threadIdx.x; x < width;
@@ -155,8 +161,9 @@ __global__ __launch_bounds__(kBlock) void hsvfilter3_kernel(FrameBatch fb, uint6
                                                             uint32_t rows, uint64_t stride,
                                                             FastConsts p)
 {
-    __shared__ uint32_t lut[8];
-    init_sextant_lut<VARIANT>(lut, 0, false);
+    __shared__ FilterLds lds;
+    init_filter_lds<VARIANT>(lds, 0, false);
+    const uint32_t *lut = lds.sextant;
     uint8_t *frame = fb.base[blockIdx.z];
     for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
         uint8_t *line = frame + (uint64_t)row * stride;

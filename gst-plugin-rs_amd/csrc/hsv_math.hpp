@@ -216,31 +216,38 @@ __device__ __forceinline__ float div_rgb(float n, float d)
     return fmac_vv(q0, r, y);
 }
 
-// hsvutils.rs:44-84 on the byte values as floats (fR = (float)R ...)
-__device__ __forceinline__ Hsv from_rgb_fast(float fR, float fG, float fB, const FastConsts &k)
+// hsvutils.rs:44-84 given r,g,b = RN(byte/255) (from div255() or from the 256-entry LDS table)
+__device__ __forceinline__ Hsv from_unit_rgb_fast(float r, float g, float b, const FastConsts &k)
 {
-    const float r = div255(fR, k), g = div255(fG, k), b = div255(fB, k);
     // RN is monotone, so max/min of the quotients == quotient of the max/min byte
     const float value = fmaxf(r, fmaxf(g, b));
     const float minv = fminf(r, fminf(g, b));
     const float chroma = value - minv;
 
-    // branch ladder of hsvutils.rs:61-71 as selects (P5: eps test == "is the max")
+    // branch ladder of hsvutils.rs:61-71 as selects (P5: eps test == "is the max"); the three
+    // candidate numerators are cheap e32 subtractions, so only the numerator and the sextant
+    // offset are selected (4 v_cndmask instead of 6)
     const bool is_r = (r == value);
     const bool is_g = (g == value);
-    const float n1 = is_r ? g : (is_g ? b : r);
-    const float n2 = is_r ? b : (is_g ? r : g);
+    const float dgb = g - b, dbr = b - r, drg = r - g;
+    const float n = is_r ? dgb : (is_g ? dbr : drg);
     const float off = is_r ? 0.0f : (is_g ? 2.0f : 4.0f);
-    // chroma == 0 => all channels equal => n1 - n2 == 0 and is_r => hue = 60*(0+0) = 0 as required;
+    // chroma == 0 => all channels equal => n == 0 and is_r => hue = 60*(0+0) = 0 as required;
     // the denominator only has to be non-zero there (chroma + 1e-30 == chroma otherwise).
-    const float q = div_rgb(n1 - n2, chroma + k.tiny);
+    const float q = div_rgb(n, chroma + k.tiny);
     const float hue = (off + q) * k.k60; // off == 0: q + 0 is exact, matches the un-added branch
     Hsv o;
-    // `if hue < 0 { hue += 360 }`; hue is never -0.0 (n1 == n2 gives +0), P4: hue % 360 == hue
+    // `if hue < 0 { hue += 360 }`; hue is never -0.0 (equal channels give +0), P4: hue % 360 == hue
     o.h = hue + __uint_as_float(sign_mask(hue) & k.bits360);
     o.s = div_rgb(chroma, value + k.tiny); // value == 0 => chroma == 0 => 0; P4: clamps are identities
     o.v = value;
     return o;
+}
+
+// the same from the byte values as floats (fR = (float)R ...)
+__device__ __forceinline__ Hsv from_rgb_fast(float fR, float fG, float fB, const FastConsts &k)
+{
+    return from_unit_rgb_fast(div255(fR, k), div255(fG, k), div255(fB, k), k);
 }
 
 // hsvfilter/imp.rs:102-115 for finite settings; NEG_SHIFT selects -360 <= shift < 0 vs 0 <= shift <= 360
@@ -294,6 +301,13 @@ __device__ __forceinline__ uint32_t to_rgb_fast(const Hsv in, const FastConsts &
     asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(T) : "v"(yx));
     asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(T) : "v"(y0));
     return (uint32_t)__float2uint_rz(hp);
+}
+
+// One pixel of hsvfilter from r,g,b = RN(byte/255): candidate dword T and sextant out.
+template <bool NEG_SHIFT>
+__device__ __forceinline__ uint32_t hsvfilter_fast_unit(float r, float g, float b, const FastConsts &k, uint32_t &T)
+{
+    return to_rgb_fast(filter_hsv_fast<NEG_SHIFT>(from_unit_rgb_fast(r, g, b, k), k), k, T);
 }
 
 // One pixel of hsvfilter: byte values as floats in, candidate dword T and sextant out.
