@@ -1,9 +1,12 @@
-// libgstrsvideofx.so -- plugin `rsvideofx` with elements `colordetect` and `roundedcorners`.
-// Same surface as video/videofx/src/{lib.rs,colordetect,border}.  `videocompare` is a
-// GstVideoAggregator in the reference; the GStreamer 1.14 of the build image has no
-// GstVideoAggregator, so its element glue is a later step -- its
-// compute (block sums, hash, distance, sharded all-reduce) is in the C ABI already.
+// libgstrsvideofx.so -- plugin `rsvideofx` with elements `roundedcorners`, `colordetect` and
+// `videocompare`.  Same surface as video/videofx/src/{lib.rs,border,colordetect,videocompare}.
+// `videocompare` is a GstVideoAggregator subclass in the reference; the GStreamer 1.14 of the
+// build image only has GstAggregator, so here it derives from GstAggregator directly
+// and keeps per-pad GstVideoInfo itself; names, request pads, properties, reference-pad rule,
+// output buffer and bus message are the reference's.
 #include "mvfx_gst_common.h"
+
+#include <gst/base/gstaggregator.h>
 
 #include <gst/video/gstvideometa.h>
 
@@ -420,14 +423,298 @@ static void gst_rounded_corners_init(GstRoundedCorners *self)
     gst_base_transform_set_in_place(GST_BASE_TRANSFORM(self), TRUE);
 }
 
+
+// ------------------------------------------------------------------------- videocompare
+
+GST_DEBUG_CATEGORY_STATIC(videocompare_debug);
+
+// enum HashAlgorithm (videocompare/mod.rs:57-92); `dssim` is a non-default cargo feature there
+enum { MVFX_HASH_MEAN = 0, MVFX_HASH_GRADIENT = 1, MVFX_HASH_VERTGRADIENT = 2, MVFX_HASH_DOUBLEGRADIENT = 3, MVFX_HASH_BLOCKHASH = 4 };
+
+static GType gst_video_compare_hash_algorithm_get_type(void)
+{
+    static gsize type = 0;
+    if (g_once_init_enter(&type)) {
+        static const GEnumValue values[] = {
+            {MVFX_HASH_MEAN, "Mean: The Mean hashing algorithm.", "mean"},
+            {MVFX_HASH_GRADIENT, "Gradient: The Gradient hashing algorithm.", "gradient"},
+            {MVFX_HASH_VERTGRADIENT, "VertGradient: The Vertical-Gradient hashing algorithm.", "vertgradient"},
+            {MVFX_HASH_DOUBLEGRADIENT, "DoubleGradient: The Double-Gradient hashing algorithm.", "doublegradient"},
+            {MVFX_HASH_BLOCKHASH, "Blockhash: The Blockhash (block median value perceptual hash) algorithm.", "blockhash"},
+            {0, NULL, NULL}};
+        g_once_init_leave(&type, g_enum_register_static("GstVideoCompareHashAlgorithm", values));
+    }
+    return (GType)type;
+}
+
+struct GstVideoCompare {
+    GstAggregator parent;
+    std::mutex *lock;
+    gint hash_algo;                  // Settings (videocompare/imp.rs:27-43)
+    gdouble max_distance_threshold;
+    GstPad *reference_pad;           // first requested sink pad (imp.rs:210-233), not ref-counted
+};
+struct GstVideoCompareClass {
+    GstAggregatorClass parent_class;
+};
+G_DEFINE_TYPE(GstVideoCompare, gst_video_compare, GST_TYPE_AGGREGATOR)
+
+enum { PROP_V_0, PROP_HASH_ALGO, PROP_MAX_DIST };
+
+static void gst_video_compare_set_property(GObject *obj, guint id, const GValue *value, GParamSpec *pspec)
+{
+    GstVideoCompare *self = reinterpret_cast<GstVideoCompare *>(obj);
+    std::lock_guard<std::mutex> g(*self->lock);
+    switch (id) {
+    case PROP_HASH_ALGO:
+        GST_CAT_INFO_OBJECT(videocompare_debug, obj, "Changing hash-algo from %d to %d", self->hash_algo, g_value_get_enum(value));
+        self->hash_algo = g_value_get_enum(value);
+        break;
+    case PROP_MAX_DIST:
+        GST_CAT_INFO_OBJECT(videocompare_debug, obj, "Changing max-dist-threshold from %f to %f", self->max_distance_threshold, g_value_get_double(value));
+        self->max_distance_threshold = g_value_get_double(value);
+        break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec); break;
+    }
+}
+
+static void gst_video_compare_get_property(GObject *obj, guint id, GValue *value, GParamSpec *pspec)
+{
+    GstVideoCompare *self = reinterpret_cast<GstVideoCompare *>(obj);
+    std::lock_guard<std::mutex> g(*self->lock);
+    switch (id) {
+    case PROP_HASH_ALGO: g_value_set_enum(value, self->hash_algo); break;
+    case PROP_MAX_DIST: g_value_set_double(value, self->max_distance_threshold); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec); break;
+    }
+}
+
+// AggregatorImpl::create_new_pad (imp.rs:210-233): the first sink pad is the reference
+static GstAggregatorPad *gst_video_compare_create_new_pad(GstAggregator *agg, GstPadTemplate *templ, const gchar *req_name, const GstCaps *caps)
+{
+    GstVideoCompare *self = reinterpret_cast<GstVideoCompare *>(agg);
+    GstAggregatorPad *pad = GST_AGGREGATOR_CLASS(gst_video_compare_parent_class)->create_new_pad(agg, templ, req_name, caps);
+    if (pad) {
+        std::lock_guard<std::mutex> g(*self->lock);
+        if (!self->reference_pad && GST_PAD_DIRECTION(pad) == GST_PAD_SINK) {
+            GST_CAT_INFO_OBJECT(videocompare_debug, self, "Reference sink pad selected: %s", GST_PAD_NAME(pad));
+            self->reference_pad = GST_PAD(pad);
+        }
+    }
+    return pad;
+}
+
+// ElementImpl::release_pad (imp.rs:188-206): re-pick a reference when it goes away
+static void gst_video_compare_release_pad(GstElement *element, GstPad *pad)
+{
+    GstVideoCompare *self = reinterpret_cast<GstVideoCompare *>(element);
+    {
+        std::lock_guard<std::mutex> g(*self->lock);
+        if (self->reference_pad == pad) {
+            self->reference_pad = nullptr;
+            for (GList *l = element->sinkpads; l; l = l->next)
+                if (l->data != pad)
+                    self->reference_pad = GST_PAD(l->data);
+        }
+    }
+    GST_ELEMENT_CLASS(gst_video_compare_parent_class)->release_pad(element, pad);
+}
+
+// update_src_caps (imp.rs:235-255): the src caps are the reference pad's caps
+static GstFlowReturn gst_video_compare_update_src_caps(GstAggregator *agg, GstCaps *caps, GstCaps **ret)
+{
+    GstVideoCompare *self = reinterpret_cast<GstVideoCompare *>(agg);
+    GstCaps *sink_caps = nullptr;
+    {
+        std::lock_guard<std::mutex> g(*self->lock);
+        if (self->reference_pad)
+            sink_caps = gst_pad_get_current_caps(self->reference_pad);
+    }
+    if (!sink_caps)
+        sink_caps = gst_caps_ref(caps); // allow any caps for now
+    if (!gst_caps_can_intersect(sink_caps, caps)) {
+        GST_CAT_ERROR_OBJECT(videocompare_debug, self, "Proposed src caps (%" GST_PTR_FORMAT ") not supported, needs to intersect with the reference sink caps (%" GST_PTR_FORMAT ")", caps, sink_caps);
+        gst_caps_unref(sink_caps);
+        return GST_FLOW_NOT_NEGOTIATED;
+    }
+    GST_CAT_INFO_OBJECT(videocompare_debug, self, "Caps for src pad: %" GST_PTR_FORMAT, sink_caps);
+    *ret = sink_caps;
+    return GST_FLOW_OK;
+}
+
+// HasherEngine::hash_image (hashed_image.rs:24-64) on one pad's buffer
+static int video_compare_hash(GstPad *pad, GstBuffer *buf, uint64_t *hash, guint *w, guint *h)
+{
+    GstCaps *caps = gst_pad_get_current_caps(pad);
+    GstVideoInfo info;
+    if (!caps || !gst_video_info_from_caps(&info, caps)) {
+        if (caps) gst_caps_unref(caps);
+        return MVFX_ERR_NOT_NEGOTIATED;
+    }
+    gst_caps_unref(caps);
+    GstVideoFrame frame;
+    if (!gst_video_frame_map(&frame, &info, buf, GST_MAP_READ))
+        return MVFX_ERR_INVALID_ARGUMENT;
+    const mvfx_frame f = mvfx_frame_from_gst(&frame);
+    *w = f.width;
+    *h = f.height;
+    const int rc = mvfx_blockhash_host(&f, hash);
+    gst_video_frame_unmap(&frame);
+    return rc;
+}
+
+// VideoAggregatorImpl::aggregate_frames (imp.rs:259-389)
+static GstFlowReturn gst_video_compare_aggregate(GstAggregator *agg, gboolean timeout)
+{
+    GstVideoCompare *self = reinterpret_cast<GstVideoCompare *>(agg);
+    GstPad *reference_pad;
+    gint algo;
+    gdouble threshold;
+    {
+        std::lock_guard<std::mutex> g(*self->lock);
+        reference_pad = self->reference_pad;
+        algo = self->hash_algo;
+        threshold = self->max_distance_threshold;
+    }
+    if (!reference_pad) {
+        GST_CAT_WARNING_OBJECT(videocompare_debug, self, "No reference sink pad exists");
+        return GST_FLOW_EOS;
+    }
+    if (algo != MVFX_HASH_BLOCKHASH) {
+        GST_ELEMENT_ERROR(self, LIBRARY, SETTINGS, ("hash-algo %d is not implemented by the MI355X build (only blockhash, the default)", algo), (NULL));
+        return GST_FLOW_ERROR;
+    }
+    GstAggregatorPad *ref_apad = GST_AGGREGATOR_PAD(reference_pad);
+    GstBuffer *ref_buf = gst_aggregator_pad_pop_buffer(ref_apad);
+    if (!ref_buf) {
+        if (gst_aggregator_pad_is_eos(ref_apad))
+            return GST_FLOW_EOS;
+        GST_CAT_WARNING_OBJECT(videocompare_debug, self, "The reference sink pad '%s' has not produced a buffer, image comparison not possible", GST_PAD_NAME(reference_pad));
+        return GST_FLOW_OK;
+    }
+    // running time of the reference buffer (imp.rs:300-306)
+    guint64 running_time = GST_CLOCK_TIME_NONE;
+    if (GST_BUFFER_PTS_IS_VALID(ref_buf) && ref_apad->segment.format == GST_FORMAT_TIME)
+        running_time = gst_segment_to_running_time(&ref_apad->segment, GST_FORMAT_TIME, GST_BUFFER_PTS(ref_buf));
+
+    uint64_t ref_hash = 0;
+    guint rw = 0, rh = 0;
+    int rc = video_compare_hash(reference_pad, ref_buf, &ref_hash, &rw, &rh);
+    if (rc != MVFX_OK) {
+        gst_buffer_unref(ref_buf);
+        return MVFX_GST_FLOW(self, rc);
+    }
+
+    GValue distances = G_VALUE_INIT;
+    g_value_init(&distances, GST_TYPE_ARRAY);
+    gboolean any_below = FALSE;
+    GstFlowReturn ret = GST_FLOW_OK;
+    GList *pads = nullptr;
+    GST_OBJECT_LOCK(self);
+    for (GList *l = GST_ELEMENT(self)->sinkpads; l; l = l->next)
+        pads = g_list_prepend(pads, gst_object_ref(l->data));
+    GST_OBJECT_UNLOCK(self);
+    pads = g_list_reverse(pads);
+    for (GList *l = pads; l && ret == GST_FLOW_OK; l = l->next) {
+        GstPad *pad = GST_PAD(l->data);
+        if (pad == reference_pad)
+            continue; // do not compare the reference pad with itself
+        GstBuffer *buf = gst_aggregator_pad_pop_buffer(GST_AGGREGATOR_PAD(pad));
+        if (!buf)
+            break; // imp.rs:331-334: no frame on this pad yet
+        uint64_t hash = 0;
+        guint w = 0, h = 0;
+        rc = video_compare_hash(pad, buf, &hash, &w, &h);
+        gst_buffer_unref(buf);
+        if (rc == MVFX_OK && (w != rw || h != rh)) { // imp.rs:337-346
+            GST_CAT_ERROR_OBJECT(videocompare_debug, self, "Video streams do not have the same sizes (add videoscale and force the sizes to be equal on all sink pads)");
+            ret = GST_FLOW_NOT_NEGOTIATED;
+            break;
+        }
+        if (rc != MVFX_OK) {
+            ret = MVFX_GST_FLOW(self, rc);
+            break;
+        }
+        const gdouble distance = (gdouble)mvfx_hash_distance(ref_hash, hash); // hashed_image.rs:70
+        if (distance <= threshold)
+            any_below = TRUE;
+        GstStructure *pd = gst_structure_new("pad-distance", "pad", GST_TYPE_PAD, pad, "distance", G_TYPE_DOUBLE, distance, NULL); // mod.rs:162-169
+        GValue v = G_VALUE_INIT;
+        g_value_init(&v, GST_TYPE_STRUCTURE);
+        g_value_take_boxed(&v, pd);
+        gst_value_array_append_and_take_value(&distances, &v);
+    }
+    g_list_free_full(pads, gst_object_unref);
+
+    if (ret == GST_FLOW_OK && any_below) { // imp.rs:356-377, message layout mod.rs:110-123
+        GstStructure *s = gst_structure_new("videocompare", "running-time", G_TYPE_UINT64, running_time, NULL);
+        gst_structure_take_value(s, "pad-distances", &distances);
+        GST_CAT_DEBUG_OBJECT(videocompare_debug, self, "Image detected %" GST_TIME_FORMAT, GST_TIME_ARGS(running_time));
+        gst_element_post_message(GST_ELEMENT(self), gst_message_new_element(GST_OBJECT(self), s));
+    } else {
+        g_value_unset(&distances);
+    }
+    if (ret != GST_FLOW_OK) {
+        gst_buffer_unref(ref_buf);
+        return ret;
+    }
+    // output the reference buffer (imp.rs:308-313)
+    return gst_aggregator_finish_buffer(agg, ref_buf);
+}
+
+static void gst_video_compare_finalize(GObject *obj)
+{
+    delete reinterpret_cast<GstVideoCompare *>(obj)->lock;
+    G_OBJECT_CLASS(gst_video_compare_parent_class)->finalize(obj);
+}
+
+static void gst_video_compare_class_init(GstVideoCompareClass *klass)
+{
+    GObjectClass *gobject = G_OBJECT_CLASS(klass);
+    GstElementClass *element = GST_ELEMENT_CLASS(klass);
+    GstAggregatorClass *agg = GST_AGGREGATOR_CLASS(klass);
+    gobject->set_property = gst_video_compare_set_property;
+    gobject->get_property = gst_video_compare_get_property;
+    gobject->finalize = gst_video_compare_finalize;
+    const GParamFlags flags = (GParamFlags)(G_PARAM_READWRITE | GST_PARAM_MUTABLE_READY | G_PARAM_STATIC_STRINGS);
+    g_object_class_install_property(gobject, PROP_HASH_ALGO, // imp.rs:78-83
+        g_param_spec_enum("hash-algo", "Hashing Algorithm", "Which hashing algorithm to use for image comparisons",
+                          gst_video_compare_hash_algorithm_get_type(), MVFX_HASH_BLOCKHASH, flags));
+    g_object_class_install_property(gobject, PROP_MAX_DIST, // imp.rs:84-89
+        g_param_spec_double("max-dist-threshold", "Maximum Distance Threshold",
+                            "Maximum distance threshold to emit messages when an image is detected, by default emits only on exact match",
+                            0.0, G_MAXDOUBLE, 0.0, flags));
+    gst_element_class_set_static_metadata(element, "Image comparison", "Filter/Video", "Compare similarity of video frames",
+                                          "Rafael Caricio <rafael@caricio.com>"); // imp.rs:145-156
+    static const gchar *const formats[] = {"RGB", "RGBA", NULL}; // imp.rs:158-186
+    GstCaps *caps = mvfx_video_caps(formats);
+    gst_element_class_add_pad_template(element, gst_pad_template_new_with_gtype("sink_%u", GST_PAD_SINK, GST_PAD_REQUEST, caps, GST_TYPE_AGGREGATOR_PAD));
+    gst_element_class_add_pad_template(element, gst_pad_template_new_with_gtype("src", GST_PAD_SRC, GST_PAD_ALWAYS, caps, GST_TYPE_AGGREGATOR_PAD));
+    gst_caps_unref(caps);
+    element->release_pad = gst_video_compare_release_pad;
+    agg->create_new_pad = gst_video_compare_create_new_pad;
+    agg->update_src_caps = gst_video_compare_update_src_caps;
+    agg->aggregate = gst_video_compare_aggregate;
+}
+
+static void gst_video_compare_init(GstVideoCompare *self)
+{
+    self->lock = new std::mutex();
+    self->hash_algo = MVFX_HASH_BLOCKHASH;
+    self->max_distance_threshold = 0.0;
+    self->reference_pad = nullptr;
+}
+
 // ------------------------------------------------------------------------- plugin (videofx/src/lib.rs:25-48)
 
 static gboolean plugin_init(GstPlugin *plugin)
 {
     GST_DEBUG_CATEGORY_INIT(colordetect_debug, "colordetect", 0, "Dominant color detection");
     GST_DEBUG_CATEGORY_INIT(roundedcorners_debug, "roundedcorners", 0, "Rounded corners");
+    GST_DEBUG_CATEGORY_INIT(videocompare_debug, "videocompare", 0, "Video frames comparison");
     return gst_element_register(plugin, "roundedcorners", GST_RANK_NONE, gst_rounded_corners_get_type()) &&
-           gst_element_register(plugin, "colordetect", GST_RANK_NONE, gst_color_detect_get_type());
+           gst_element_register(plugin, "colordetect", GST_RANK_NONE, gst_color_detect_get_type()) &&
+           gst_element_register(plugin, "videocompare", GST_RANK_NONE, gst_video_compare_get_type());
 }
 
 GST_PLUGIN_DEFINE(GST_VERSION_MAJOR, GST_VERSION_MINOR, rsvideofx, "GStreamer Rust Video Effects Plugin", plugin_init,

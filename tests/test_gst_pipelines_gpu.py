@@ -99,3 +99,40 @@ def test_roundedcorners_i420_to_a420(gpu, tmp_path):
     # radius 0 negotiates I420 passthrough (border/imp.rs:405-409, 460-465)
     same = _capture(tmp_path, src + " ! roundedcorners ! video/x-raw,format=I420", "pt.raw")
     assert np.array_equal(same, raw)
+
+
+def _videocompare(tmp_path, pattern_a, pattern_b, extra=""):
+    """tests/videocompare.rs setup_pipeline: two videotestsrc -> videocompare -> fakesink"""
+    caps = "video/x-raw,format=RGBA,width=320,height=240"
+    pipeline = (f"videocompare name=compare {extra} ! fakesink "
+                f"videotestsrc pattern={pattern_a} num-buffers=2 ! {caps} ! compare.sink_0 "
+                f"videotestsrc pattern={pattern_b} num-buffers=2 ! {caps} ! compare.sink_1")
+    r = gst_env.run([LAUNCH, "-m"] + pipeline.split(), tmp_path)
+    assert r.returncode == 0, r.stdout
+    return r.stdout
+
+
+def test_videocompare_red_vs_red_detects(gpu, tmp_path):
+    """video/videofx/tests/videocompare.rs:57-103: identical frames => message, distance 0 on sink_1"""
+    out = _videocompare(tmp_path, "red", "red")
+    msgs = re.findall(r"videocompare, running-time=\(guint64\)(\d+), pad-distances=\(structure\)<([^>]*)>", out)
+    assert len(msgs) >= 1, out
+    assert "sink_1" in msgs[0][1] and "distance" in msgs[0][1]
+    assert re.search(r"distance\\=\\\(double\\\)0", msgs[0][1]), msgs[0][1]
+
+
+def test_videocompare_snow_vs_red_is_silent(gpu, tmp_path):
+    """tests/videocompare.rs:105-139: different frames at max-dist-threshold=0 => no message"""
+    out = _videocompare(tmp_path, "red", "snow")
+    assert "videocompare, running-time" not in out
+    # a generous threshold reports the (non-zero) distance instead
+    out = _videocompare(tmp_path, "red", "snow", "max-dist-threshold=64")
+    m = re.search(r"distance\\=\\\(double\\\)(\d+)", out)
+    assert m and int(m.group(1)) > 0
+
+
+def test_videocompare_unimplemented_algo_errors(gpu, tmp_path):
+    caps = "video/x-raw,format=RGBA,width=64,height=48"
+    r = gst_env.run([LAUNCH] + (f"videocompare name=c hash-algo=mean ! fakesink videotestsrc num-buffers=1 ! {caps} ! c.sink_0 "
+                                f"videotestsrc num-buffers=1 ! {caps} ! c.sink_1").split(), tmp_path)
+    assert r.returncode != 0 and "not implemented" in r.stdout
