@@ -133,6 +133,116 @@ def videocompare_main(args):
         dist.destroy_process_group()
 
 
+def config_main(args):
+    """BASELINE configs 2-4 as device-resident per-GPU stream workloads (no data-path collective)."""
+    import torch
+    import torch.distributed as dist
+    import _pkg
+    from tests import cubes
+    vfx = _pkg.vfx
+    lib = vfx.lib()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    vfx.check(lib.mvfx_set_device(local_rank))
+    stream = torch.cuda.current_stream(dev)
+    sptr = ctypes.c_void_p(stream.cuda_stream)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0100 + rank)
+
+    def rnd(n, nbytes):
+        return torch.randint(0, 256, (n, nbytes), dtype=torch.uint8, device=dev, generator=gen)
+
+    if args.workload == "hsv1080p":
+        W, H, pool = 1920, 1080, 64
+        src, dst = rnd(pool, W * H * 4), torch.empty((pool, W * H * 4), dtype=torch.uint8, device=dev)
+        fs = vfx.HsvFilterSettings(*SETTINGS)
+        ds = vfx.HsvDetectorSettings(120.0, 40.0, 0.6, 0.4, 0.6, 0.4)
+        fi = [vfx.make_frame(src[i].data_ptr(), W, H, W * 4, "RGBx") for i in range(pool)]
+        fo = [vfx.make_frame(dst[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(pool)]
+
+        def step(i):
+            k = i % pool
+            vfx.check(lib.mvfx_hsvfilter_transform_frame_ip(ctypes.byref(fi[k]), ctypes.byref(fs), sptr))
+            vfx.check(lib.mvfx_hsvdetector_transform_frame(ctypes.byref(fi[k]), ctypes.byref(fo[k]), ctypes.byref(ds), sptr))
+        bytes_per_step, name = 4 * W * H * 4, "hsvfilter (RGBx, in place) + hsvdetector RGBx->RGBA, 1920x1080"
+    elif args.workload == "colorlut":
+        W, H, pool = W4K, H4K, 16
+        lut = vfx.CubeLut(cubes.analytic_3d(33))
+        src, dst = rnd(pool, FRAME_BYTES), torch.empty((pool, FRAME_BYTES), dtype=torch.uint8, device=dev)
+        fi = [vfx.make_frame(src[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(pool)]
+        fo = [vfx.make_frame(dst[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(pool)]
+
+        def step(i):
+            k = i % pool
+            vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fi[k]), ctypes.byref(fo[k]), sptr))
+        bytes_per_step, name = 2 * FRAME_BYTES, "colorlut 33^3 .cube, 3840x2160 RGBA, uniform-random colours (worst case for the LUT gathers)"
+    else:  # videofx: one 4K stream per GPU: I420 -> A420 compose with the r=100 mask + colordetect on the RGBA twin
+        W, H, pool = W4K, H4K, 16
+        i420, a420 = rnd(pool, W * H * 3 // 2), torch.empty((pool, W * H * 5 // 2), dtype=torch.uint8, device=dev)
+        rgba = rnd(pool, FRAME_BYTES)
+        mask = torch.empty(W * H, dtype=torch.uint8, device=dev)
+        vfx.check(lib.mvfx_roundedcorners_mask(ctypes.c_void_p(mask.data_ptr()), W, H, W, 100, sptr))
+        hist = torch.zeros(32768 + 8, dtype=torch.int32, device=dev)
+        offs = [0, W * H, W * H * 5 // 4, W * H * 3 // 2]
+        planes = []
+        for k in range(pool):
+            a, b = vfx.PlanarFrame(), vfx.PlanarFrame()
+            for p_ in range(3):
+                a.data[p_] = i420[k].data_ptr() + offs[p_]
+                b.data[p_] = a420[k].data_ptr() + offs[p_]
+                a.stride[p_] = b.stride[p_] = W if p_ == 0 else W // 2
+            b.data[3] = a420[k].data_ptr() + offs[3]
+            b.stride[3] = W
+            a.width = b.width = W
+            a.height = b.height = H
+            a.format, b.format = vfx.FORMATS["I420"], vfx.FORMATS["A420"]
+            planes.append((a, b))
+        fr = [vfx.make_frame(rgba[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(pool)]
+
+        def step(i):
+            k = i % pool
+            vfx.check(lib.mvfx_roundedcorners_compose_a420(ctypes.byref(planes[k][0]), ctypes.c_void_p(mask.data_ptr()), W,
+                                                           ctypes.byref(planes[k][1]), sptr))
+            vfx.check(lib.mvfx_colordetect_histogram(ctypes.byref(fr[k]), 10, 0, vfx.ALL_SAMPLES, ctypes.c_void_p(hist.data_ptr()),
+                                                     ctypes.c_void_p(hist.data_ptr() + 32768 * 4), sptr))
+        bytes_per_step, name = W * H * 4 + FRAME_BYTES, "roundedcorners I420->A420 compose (r=100) + colordetect histogram (quality=10), one 3840x2160 stream per GPU"
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    achieved = bytes_per_step * args.steps / elapsed / 1e9
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"{args.workload}_frames_per_sec", "value": args.steps * world / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.workload != "videofx" else "u8",
+            "data": "synthetic uniform-random u8, device-resident", "config": {"workload": name, "parallelism": f"{world} independent streams"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "note": "wall clock over single-frame launches (per GPU)"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,11 +253,16 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 literal kernel, 2 strength-reduced")
-    ap.add_argument("--workload", default="hsvfilter", choices=["hsvfilter", "videocompare"],
-                    help="hsvfilter = the headline metric (default); videocompare = BASELINE config 5")
+    ap.add_argument("--workload", default="hsvfilter",
+                    choices=["hsvfilter", "hsv1080p", "colorlut", "videofx", "videocompare"],
+                    help="hsvfilter = the headline metric (default, BASELINE metric); hsv1080p = config 2 "
+                         "(hsvfilter + hsvdetector 1920x1080); colorlut = config 3 (33^3 cube, 4K); videofx = config 4 "
+                         "(roundedcorners compose + colordetect, one 4K stream per GPU); videocompare = config 5")
     args = ap.parse_args()
     if args.workload == "videocompare":
         return videocompare_main(args)
+    if args.workload != "hsvfilter":
+        return config_main(args)
 
     import torch
     import torch.distributed as dist
