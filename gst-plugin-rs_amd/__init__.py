@@ -94,6 +94,8 @@ SIGNATURES = {
     "mvfx_device_free": (c_int, [c_void_p]),
     "mvfx_copy_to_device": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mvfx_copy_to_host": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mvfx_copy_device_to_device": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mvfx_thread_stream": (c_void_p, []),
     "mvfx_hsvfilter_transform_frame_ip": (c_int, [POINTER(Frame), POINTER(HsvFilterSettings), c_void_p]),
     "mvfx_hsvfilter_transform_frames_ip": (c_int, [POINTER(Frame), c_uint32, POINTER(HsvFilterSettings), c_void_p]),
     "mvfx_hsvfilter_transform_frame_ip_host": (c_int, [POINTER(Frame), POINTER(HsvFilterSettings)]),

@@ -188,4 +188,17 @@ int mvfx_copy_to_host(void *dst_host, const void *src_device, size_t bytes, mvfx
     return MVFX_OK;
 }
 
+int mvfx_copy_device_to_device(void *dst_device, const void *src_device, size_t bytes, mvfx_stream stream)
+{
+    if (bytes == 0) return MVFX_OK;
+    if (!dst_device || !src_device)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "copy_device_to_device: NULL pointer");
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    MVFX_HIP_TRY(hipMemcpyAsync(dst_device, src_device, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    MVFX_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return MVFX_OK;
+}
+
+mvfx_stream mvfx_thread_stream(void) { return reinterpret_cast<mvfx_stream>(host_stream()); }
+
 } // extern "C"

@@ -90,6 +90,44 @@ static GstFlowReturn gst_color_lut_transform_frame(GstVideoFilter *filter, GstVi
     return MVFX_GST_FLOW(self, rc);
 }
 
+static GstFlowReturn gst_color_lut_prepare_output_buffer(GstBaseTransform *bt, GstBuffer *inbuf, GstBuffer **outbuf)
+{
+    if (!mvfx_buffer_is_hip(inbuf))
+        return GST_BASE_TRANSFORM_CLASS(gst_color_lut_parent_class)->prepare_output_buffer(bt, inbuf, outbuf);
+    return mvfx_hip_new_output(bt, inbuf, GST_VIDEO_INFO_SIZE(&GST_VIDEO_FILTER(bt)->out_info), outbuf);
+}
+
+// Device-resident path (cf. d3d12colorlut/imp.rs:544-719): LUT applied HBM -> HBM
+static GstFlowReturn gst_color_lut_bt_transform(GstBaseTransform *bt, GstBuffer *inbuf, GstBuffer *outbuf)
+{
+    if (!mvfx_buffer_is_hip(inbuf) || !mvfx_buffer_is_hip(outbuf))
+        return GST_BASE_TRANSFORM_CLASS(gst_color_lut_parent_class)->transform(bt, inbuf, outbuf);
+    GstColorLut *self = reinterpret_cast<GstColorLut *>(bt);
+    GstVideoFilter *vf = GST_VIDEO_FILTER(bt);
+    if (!vf->negotiated)
+        return GST_FLOW_NOT_NEGOTIATED;
+    std::lock_guard<std::mutex> g(*self->lock);
+    if (!self->lut) {
+        GST_CAT_ERROR_OBJECT(colorlut_debug, self, "No LUT configured");
+        return GST_FLOW_ERROR;
+    }
+    GstMapInfo imap, omap;
+    mvfx_frame fi, fo;
+    if (!mvfx_hip_map_frame(inbuf, &vf->in_info, GST_MAP_READ, &imap, &fi))
+        return GST_FLOW_ERROR;
+    if (!mvfx_hip_map_frame(outbuf, &vf->out_info, GST_MAP_WRITE, &omap, &fo)) {
+        gst_buffer_unmap(inbuf, &imap);
+        return GST_FLOW_ERROR;
+    }
+    mvfx_stream st = mvfx_thread_stream();
+    int rc = mvfx_colorlut_transform_frame(self->lut, &fi, &fo, st);
+    if (rc == MVFX_OK)
+        rc = mvfx_stream_synchronize(st);
+    gst_buffer_unmap(outbuf, &omap);
+    gst_buffer_unmap(inbuf, &imap);
+    return MVFX_GST_FLOW(self, rc);
+}
+
 static void gst_color_lut_finalize(GObject *obj)
 {
     GstColorLut *self = reinterpret_cast<GstColorLut *>(obj);
@@ -116,7 +154,9 @@ static void gst_color_lut_class_init(GstColorLutClass *klass)
     const gboolean has64 = gst_video_format_from_string("RGBA64_LE") != GST_VIDEO_FORMAT_UNKNOWN;
     static const gchar *const all[] = {"RGBA64_LE", "RGBA64_BE", "RGBA", NULL};
     static const gchar *const only8[] = {"RGBA", NULL};
-    mvfx_add_pad_templates(element, mvfx_video_caps(has64 ? all : only8), mvfx_video_caps(has64 ? all : only8));
+    mvfx_add_pad_templates(element, mvfx_caps_plus_hip(mvfx_video_caps(has64 ? all : only8)), mvfx_caps_plus_hip(mvfx_video_caps(has64 ? all : only8)));
+    GST_BASE_TRANSFORM_CLASS(klass)->prepare_output_buffer = gst_color_lut_prepare_output_buffer;
+    GST_BASE_TRANSFORM_CLASS(klass)->transform = gst_color_lut_bt_transform;
     GST_BASE_TRANSFORM_CLASS(klass)->start = gst_color_lut_start;
     GST_BASE_TRANSFORM_CLASS(klass)->stop = gst_color_lut_stop;
     GST_VIDEO_FILTER_CLASS(klass)->transform_frame = gst_color_lut_transform_frame; // NeverInPlace (:162-166)

@@ -67,6 +67,32 @@ static GstFlowReturn gst_hsv_filter_transform_frame_ip(GstVideoFilter *filter, G
     return MVFX_GST_FLOW(self, rc);
 }
 
+// Device-resident path: a `video/x-raw(memory:HIPMemory)` buffer is filtered in HBM, no PCIe copy.
+static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuffer *buf)
+{
+    if (!mvfx_buffer_is_hip(buf))
+        return GST_BASE_TRANSFORM_CLASS(gst_hsv_filter_parent_class)->transform_ip(bt, buf); // GstVideoFilter: map + transform_frame_ip
+    GstHsvFilter *self = reinterpret_cast<GstHsvFilter *>(bt);
+    GstVideoFilter *vf = GST_VIDEO_FILTER(bt);
+    if (!vf->negotiated)
+        return GST_FLOW_NOT_NEGOTIATED;
+    mvfx_hsvfilter_settings s;
+    {
+        std::lock_guard<std::mutex> g(*self->lock);
+        s = self->settings;
+    }
+    GstMapInfo map;
+    mvfx_frame f;
+    if (!mvfx_hip_map_frame(buf, &vf->in_info, GST_MAP_READWRITE, &map, &f))
+        return GST_FLOW_ERROR;
+    mvfx_stream st = mvfx_thread_stream();
+    int rc = mvfx_hsvfilter_transform_frame_ip(&f, &s, st);
+    if (rc == MVFX_OK)
+        rc = mvfx_stream_synchronize(st); // the buffer may be consumed on another streaming thread
+    gst_buffer_unmap(buf, &map);
+    return MVFX_GST_FLOW(self, rc);
+}
+
 static void gst_hsv_filter_finalize(GObject *obj)
 {
     delete reinterpret_cast<GstHsvFilter *>(obj)->lock;
@@ -101,8 +127,9 @@ static void gst_hsv_filter_class_init(GstHsvFilterClass *klass)
         "Works within the HSV colorspace to apply transformations to incoming frames",
         "Julien Bardagi <julien.bardagi@gmail.com>"); // hsvfilter/imp.rs:261-272
     static const gchar *const formats[] = {"RGBx", "xRGB", "BGRx", "xBGR", "RGBA", "ARGB", "BGRA", "ABGR", "RGB", "BGR", NULL};
-    mvfx_add_pad_templates(element, mvfx_video_caps(formats), mvfx_video_caps(formats)); // :274-312
+    mvfx_add_pad_templates(element, mvfx_caps_plus_hip(mvfx_video_caps(formats)), mvfx_caps_plus_hip(mvfx_video_caps(formats))); // :274-312 (+ HIP twin)
     vfilter->transform_frame_ip = gst_hsv_filter_transform_frame_ip; // AlwaysInPlace (:315-320)
+    GST_BASE_TRANSFORM_CLASS(klass)->transform_ip = gst_hsv_filter_bt_transform_ip;
 }
 
 static void gst_hsv_filter_init(GstHsvFilter *self)
@@ -195,6 +222,43 @@ static GstFlowReturn gst_hsv_detector_transform_frame(GstVideoFilter *filter, Gs
     return MVFX_GST_FLOW(self, rc);
 }
 
+static GstFlowReturn gst_hsv_detector_prepare_output_buffer(GstBaseTransform *bt, GstBuffer *inbuf, GstBuffer **outbuf)
+{
+    if (!mvfx_buffer_is_hip(inbuf))
+        return GST_BASE_TRANSFORM_CLASS(gst_hsv_detector_parent_class)->prepare_output_buffer(bt, inbuf, outbuf);
+    return mvfx_hip_new_output(bt, inbuf, GST_VIDEO_INFO_SIZE(&GST_VIDEO_FILTER(bt)->out_info), outbuf);
+}
+
+static GstFlowReturn gst_hsv_detector_bt_transform(GstBaseTransform *bt, GstBuffer *inbuf, GstBuffer *outbuf)
+{
+    if (!mvfx_buffer_is_hip(inbuf) || !mvfx_buffer_is_hip(outbuf))
+        return GST_BASE_TRANSFORM_CLASS(gst_hsv_detector_parent_class)->transform(bt, inbuf, outbuf);
+    GstHsvDetector *self = reinterpret_cast<GstHsvDetector *>(bt);
+    GstVideoFilter *vf = GST_VIDEO_FILTER(bt);
+    if (!vf->negotiated)
+        return GST_FLOW_NOT_NEGOTIATED;
+    mvfx_hsvdetector_settings s;
+    {
+        std::lock_guard<std::mutex> g(*self->lock);
+        s = self->settings;
+    }
+    GstMapInfo imap, omap;
+    mvfx_frame fi, fo;
+    if (!mvfx_hip_map_frame(inbuf, &vf->in_info, GST_MAP_READ, &imap, &fi))
+        return GST_FLOW_ERROR;
+    if (!mvfx_hip_map_frame(outbuf, &vf->out_info, GST_MAP_WRITE, &omap, &fo)) {
+        gst_buffer_unmap(inbuf, &imap);
+        return GST_FLOW_ERROR;
+    }
+    mvfx_stream st = mvfx_thread_stream();
+    int rc = mvfx_hsvdetector_transform_frame(&fi, &fo, &s, st);
+    if (rc == MVFX_OK)
+        rc = mvfx_stream_synchronize(st);
+    gst_buffer_unmap(outbuf, &omap);
+    gst_buffer_unmap(inbuf, &imap);
+    return MVFX_GST_FLOW(self, rc);
+}
+
 static void gst_hsv_detector_finalize(GObject *obj)
 {
     delete reinterpret_cast<GstHsvDetector *>(obj)->lock;
@@ -227,8 +291,10 @@ static void gst_hsv_detector_class_init(GstHsvDetectorClass *klass)
                            0.0f, 1.0f, 0.3f, flags));
     gst_element_class_set_static_metadata(element, "HSV detector", "Filter/Effect/Converter/Video",
         "Works within the HSV colorspace to mark positive pixels", "Julien Bardagi <julien.bardagi@gmail.com>");
-    mvfx_add_pad_templates(element, mvfx_video_caps(kDetectorIn), mvfx_video_caps(kDetectorOut));
+    mvfx_add_pad_templates(element, mvfx_caps_plus_hip(mvfx_video_caps(kDetectorIn)), mvfx_caps_plus_hip(mvfx_video_caps(kDetectorOut)));
     GST_BASE_TRANSFORM_CLASS(klass)->transform_caps = gst_hsv_detector_transform_caps;
+    GST_BASE_TRANSFORM_CLASS(klass)->prepare_output_buffer = gst_hsv_detector_prepare_output_buffer;
+    GST_BASE_TRANSFORM_CLASS(klass)->transform = gst_hsv_detector_bt_transform;
     GST_VIDEO_FILTER_CLASS(klass)->transform_frame = gst_hsv_detector_transform_frame; // NeverInPlace (:380-384)
 }
 

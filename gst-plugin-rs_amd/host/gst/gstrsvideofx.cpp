@@ -80,7 +80,29 @@ static gboolean gst_color_detect_stop(GstBaseTransform *trans) // :252-256
     return TRUE;
 }
 
-// transform_frame_ip_passthrough (:296-305) -> detect_color (:57-86) -> color_changed (:88-112)
+// color_changed (:88-112) preceded by the name-change test of detect_color (:76-85)
+static void color_detect_report(GstColorDetect *self, const uint32_t *palette, uint32_t n)
+{
+    const char *name = mvfx_css_color_similar((palette[0] >> 16) & 0xff, (palette[0] >> 8) & 0xff, palette[0] & 0xff);
+    if (self->have_color && *self->current_color == name)
+        return;
+    *self->current_color = name;
+    self->have_color = TRUE;
+    GST_CAT_DEBUG_OBJECT(colordetect_debug, self, "Dominant color changed to %s", name);
+    GValue list = G_VALUE_INIT;
+    g_value_init(&list, GST_TYPE_LIST);
+    for (uint32_t i = 0; i < n; i++) {
+        GValue v = G_VALUE_INIT;
+        g_value_init(&v, G_TYPE_UINT);
+        g_value_set_uint(&v, palette[i]);
+        gst_value_list_append_and_take_value(&list, &v);
+    }
+    GstStructure *s = gst_structure_new("colordetect", "dominant-color", G_TYPE_STRING, name, NULL);
+    gst_structure_take_value(s, "palette", &list);
+    gst_element_post_message(GST_ELEMENT(self), gst_message_new_element(GST_OBJECT(self), s));
+}
+
+// transform_frame_ip_passthrough (:296-305) -> detect_color (:57-86)
 static GstFlowReturn gst_color_detect_transform_frame_ip(GstVideoFilter *filter, GstVideoFrame *frame)
 {
     GstColorDetect *self = reinterpret_cast<GstColorDetect *>(filter);
@@ -102,23 +124,38 @@ static GstFlowReturn gst_color_detect_transform_frame_ip(GstVideoFilter *filter,
         GST_CAT_ERROR_OBJECT(colordetect_debug, self, "%s", mvfx_last_error());
         return GST_FLOW_ERROR; // get_palette(..).map_err(|_| FlowError::Error) (:74)
     }
-    const char *name = mvfx_css_color_similar((palette[0] >> 16) & 0xff, (palette[0] >> 8) & 0xff, palette[0] & 0xff);
-    if (self->have_color && *self->current_color == name)
-        return GST_FLOW_OK;
-    *self->current_color = name;
-    self->have_color = TRUE;
-    GST_CAT_DEBUG_OBJECT(colordetect_debug, self, "Dominant color changed to %s", name);
-    GValue list = G_VALUE_INIT;
-    g_value_init(&list, GST_TYPE_LIST);
-    for (uint32_t i = 0; i < n; i++) {
-        GValue v = G_VALUE_INIT;
-        g_value_init(&v, G_TYPE_UINT);
-        g_value_set_uint(&v, palette[i]);
-        gst_value_list_append_and_take_value(&list, &v);
+    color_detect_report(self, palette, n);
+    return GST_FLOW_OK;
+}
+
+// Device-resident path: histogram straight from HBM, only 128 KB come back for the median cut
+static GstFlowReturn gst_color_detect_bt_transform_ip(GstBaseTransform *bt, GstBuffer *buf)
+{
+    if (!mvfx_buffer_is_hip(buf))
+        return GST_BASE_TRANSFORM_CLASS(gst_color_detect_parent_class)->transform_ip(bt, buf);
+    GstColorDetect *self = reinterpret_cast<GstColorDetect *>(bt);
+    GstVideoFilter *vf = GST_VIDEO_FILTER(bt);
+    if (!vf->negotiated || !self->have_state)
+        return GST_FLOW_NOT_NEGOTIATED;
+    guint quality, max_colors;
+    {
+        std::lock_guard<std::mutex> g(*self->lock);
+        quality = self->quality;
+        max_colors = self->max_colors;
     }
-    GstStructure *s = gst_structure_new("colordetect", "dominant-color", G_TYPE_STRING, name, NULL);
-    gst_structure_take_value(s, "palette", &list);
-    gst_element_post_message(GST_ELEMENT(self), gst_message_new_element(GST_OBJECT(self), s));
+    GstMapInfo map;
+    mvfx_frame f;
+    if (!mvfx_hip_map_frame(buf, &vf->in_info, GST_MAP_READ, &map, &f))
+        return GST_FLOW_ERROR;
+    uint32_t palette[256];
+    uint32_t n = 0;
+    const int rc = mvfx_colordetect_palette(&f, quality, max_colors, palette, &n, mvfx_thread_stream());
+    gst_buffer_unmap(buf, &map);
+    if (rc != MVFX_OK) {
+        GST_CAT_ERROR_OBJECT(colordetect_debug, self, "%s", mvfx_last_error());
+        return GST_FLOW_ERROR;
+    }
+    color_detect_report(self, palette, n);
     return GST_FLOW_OK;
 }
 
@@ -147,7 +184,8 @@ static void gst_color_detect_class_init(GstColorDetectClass *klass)
     gst_element_class_set_static_metadata(element, "Dominant color detection", "Filter/Video",
                                           "Detects the dominant color of a video", "Philippe Normand <philn@igalia.com>");
     static const gchar *const formats[] = {"RGB", "RGBA", "ARGB", "BGR", "BGRA", NULL}; // :212-240
-    mvfx_add_pad_templates(element, mvfx_video_caps(formats), mvfx_video_caps(formats));
+    mvfx_add_pad_templates(element, mvfx_caps_plus_hip(mvfx_video_caps(formats)), mvfx_caps_plus_hip(mvfx_video_caps(formats)));
+    bt->transform_ip = gst_color_detect_bt_transform_ip;
     bt->passthrough_on_same_caps = TRUE;   // :246-250
     bt->transform_ip_on_passthrough = TRUE;
     bt->stop = gst_color_detect_stop;

@@ -11,6 +11,7 @@
 #include <gst/video/video.h>
 
 #include "mi355vfx.h"
+#include "mvfxhipmemory.h"
 
 #ifndef PACKAGE
 #define PACKAGE "mi355vfx"
@@ -94,6 +95,44 @@ static inline GstCaps *mvfx_video_caps(const gchar *const *formats)
         gst_structure_take_value(s, "format", &list);
     }
     return caps;
+}
+
+// ---- video/x-raw(memory:HIPMemory) support shared by the elements ----
+
+// appends the memory:HIPMemory twin of every structure
+static inline GstCaps *mvfx_caps_plus_hip(GstCaps *caps)
+{
+    GstCaps *hip = mvfx_caps_with_hip_feature(caps);
+    gst_caps_append(caps, hip);
+    return caps;
+}
+
+// plane 0 of a HIP buffer (default GstVideoInfo layout) as the C ABI's view; data = DEVICE pointer
+static inline gboolean mvfx_hip_map_frame(GstBuffer *buf, const GstVideoInfo *info, GstMapFlags rw, GstMapInfo *map, mvfx_frame *f)
+{
+    if (!gst_buffer_map(buf, map, (GstMapFlags)(MVFX_MAP_HIP | rw)))
+        return FALSE;
+    f->data = map->data + GST_VIDEO_INFO_PLANE_OFFSET(info, 0);
+    f->width = (uint32_t)GST_VIDEO_INFO_WIDTH(info);
+    f->height = (uint32_t)GST_VIDEO_INFO_HEIGHT(info);
+    f->stride = (uint32_t)GST_VIDEO_INFO_PLANE_STRIDE(info, 0);
+    f->format = mvfx_format_from_gst(GST_VIDEO_INFO_FORMAT(info));
+    return TRUE;
+}
+
+// prepare_output_buffer for elements whose negotiated OUTPUT is HIP memory: a device buffer of
+// the output frame size with the input's flags and timestamps
+static inline GstFlowReturn mvfx_hip_new_output(GstBaseTransform *trans, GstBuffer *inbuf, gsize size, GstBuffer **outbuf)
+{
+    GstAllocator *alloc = mvfx_hip_allocator_get();
+    *outbuf = gst_buffer_new_allocate(alloc, size, NULL);
+    gst_object_unref(alloc);
+    if (!*outbuf) {
+        GST_ELEMENT_ERROR(trans, RESOURCE, NO_SPACE_LEFT, ("%s", mvfx_last_error()), (NULL));
+        return GST_FLOW_ERROR;
+    }
+    gst_buffer_copy_into(*outbuf, inbuf, (GstBufferCopyFlags)(GST_BUFFER_COPY_FLAGS | GST_BUFFER_COPY_TIMESTAMPS), 0, -1);
+    return GST_FLOW_OK;
 }
 
 static inline void mvfx_add_pad_templates(GstElementClass *klass, GstCaps *sink_caps, GstCaps *src_caps)

@@ -96,6 +96,10 @@ int mvfx_device_alloc(void **out_ptr, size_t bytes);
 int mvfx_device_free(void *ptr);
 int mvfx_copy_to_device(void *dst_device, const void *src_host, size_t bytes, mvfx_stream stream);
 int mvfx_copy_to_host(void *dst_host, const void *src_device, size_t bytes, mvfx_stream stream);
+int mvfx_copy_device_to_device(void *dst_device, const void *src_device, size_t bytes, mvfx_stream stream);
+/* The calling thread's private non-blocking stream (the one the *_host entry points use); lets an
+ * element layer issue the device entry points of one streaming thread in order. */
+mvfx_stream mvfx_thread_stream(void);
 
 /* ---- hsvfilter : video/hsv/src/hsvfilter/imp.rs ----
  * Settings == `struct Settings` hsvfilter/imp.rs:32-39 (defaults :25-29: 0,1,0,1,0). */

@@ -6,7 +6,7 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PLUGIN_DIR = os.path.join(ROOT, "gst-plugin-rs_amd", "gst-plugins")
-PLUGINS = ["libgsthsv.so", "libgstcolorlut.so", "libgstrsvideofx.so"]
+PLUGINS = ["libgsthsv.so", "libgstcolorlut.so", "libgstrsvideofx.so", "libgstmi355hip.so"]
 
 
 def tool(name):

@@ -136,3 +136,49 @@ def test_videocompare_unimplemented_algo_errors(gpu, tmp_path):
     r = gst_env.run([LAUNCH] + (f"videocompare name=c hash-algo=mean ! fakesink videotestsrc num-buffers=1 ! {caps} ! c.sink_0 "
                                 f"videotestsrc num-buffers=1 ! {caps} ! c.sink_1").split(), tmp_path)
     assert r.returncode != 0 and "not implemented" in r.stdout
+
+
+# ---------------------------------------------------------------- memory:HIPMemory
+
+def test_hipmemory_hsvfilter_matches_host_path(gpu, tmp_path):
+    """videotestsrc ! hipupload ! hsvfilter ! hipdownload: same bytes as the oracle; frames stay in HBM between"""
+    src = "videotestsrc num-buffers=3 ! video/x-raw,format=RGBA,width=640,height=480"
+    raw = _capture(tmp_path, src, "in.raw")
+    got = _capture(tmp_path, src + " ! hipupload ! hsvfilter hue-shift=90 saturation-mul=1.25 ! hipdownload")
+    exp = raw.copy().reshape(3 * 480, 640 * 4)
+    assert orc.hsvfilter(exp, 640, 640 * 4, "RGBA", (90.0, 1.25, 0.0, 1.0, 0.0)) == 0
+    assert np.array_equal(got.reshape(exp.shape), exp)
+
+
+def test_hipmemory_chain_stays_on_device(gpu, tmp_path):
+    """hsvfilter ! hsvdetector ! colorlut on memory:HIPMemory caps end to end (one upload, one download)"""
+    cube = tmp_path / "look.cube"
+    cube.write_text(cubes.analytic_3d(17))
+    src = "videotestsrc num-buffers=2 pattern=smpte ! video/x-raw,format=RGBx,width=320,height=240"
+    raw = _capture(tmp_path, src, "in.raw")
+    r = gst_env.run([LAUNCH, "-q", "-v"] + (src + " ! hipupload ! hsvfilter hue-shift=45 ! hsvdetector hue-ref=120 hue-var=60 "
+                    "saturation-ref=0.6 saturation-var=0.4 value-ref=0.6 value-var=0.4 ! video/x-raw(memory:HIPMemory),format=RGBA "
+                    f"! colorlut location={cube} name=lut ! hipdownload ! filesink location={tmp_path}/out.raw").split(), tmp_path)
+    assert r.returncode == 0, r.stdout
+    assert "lut.GstPad:sink: caps = video/x-raw(memory:HIPMemory)" in r.stdout  # negotiated on device memory
+    got = np.fromfile(f"{tmp_path}/out.raw", dtype=np.uint8)
+    mid = raw.copy().reshape(2 * 240, 320 * 4)
+    orc.hsvfilter(mid, 320, 320 * 4, "RGBx", (45.0, 1.0, 0.0, 1.0, 0.0))
+    det = np.empty_like(mid)
+    orc.hsvdetector(mid, 320 * 4, "RGBx", det, 320 * 4, "RGBA", 320, (120.0, 60.0, 0.6, 0.4, 0.6, 0.4))
+    o = orc.CubeLut(cube.read_text())
+    exp = np.empty_like(det)
+    assert o.apply(det, 320 * 4, exp, 320 * 4, 320, 2 * 240, "RGBA") == 0
+    assert np.array_equal(got.reshape(exp.shape), exp)
+
+
+def test_hipmemory_colordetect_and_cpu_consumer(gpu, tmp_path):
+    """colordetect reads the device buffer; a CPU element downstream (filesink) can still map HIP memory"""
+    r = gst_env.run([LAUNCH, "-m"] + ("videotestsrc pattern=red num-buffers=2 ! video/x-raw,format=RGBA,width=320,height=240 "
+                    f"! hipupload ! colordetect ! hsvfilter hue-shift=120 ! filesink location={tmp_path}/o.raw").split(), tmp_path)
+    assert r.returncode == 0, r.stdout
+    assert len(re.findall(r"colordetect, dominant-color=\(string\)red", r.stdout)) == 1
+    got = np.fromfile(f"{tmp_path}/o.raw", dtype=np.uint8).reshape(2 * 240, 320 * 4)
+    exp = np.tile(np.array((255, 0, 0, 255), np.uint8), 2 * 240 * 320).reshape(2 * 240, 320 * 4)
+    orc.hsvfilter(exp, 320, 320 * 4, "RGBA", (120.0, 1.0, 0.0, 1.0, 0.0))
+    assert np.array_equal(got, exp)
