@@ -16,9 +16,21 @@ struct Scratch {
     size_t cap = 0;
 };
 constexpr int kScratchSlots = 4;
-thread_local Scratch t_scratch[kScratchSlots];
-thread_local hipStream_t t_stream = nullptr;
-thread_local int t_stream_device = -1;
+
+// Per-thread staging state of the *_host entry points; released when the thread (e.g. a GStreamer
+// streaming thread) exits so pipelines that come and go do not leak device memory.
+struct ThreadState {
+    Scratch scratch[kScratchSlots];
+    hipStream_t stream = nullptr;
+    int stream_device = -1;
+    ~ThreadState()
+    {
+        for (Scratch &s : scratch)
+            if (s.ptr) (void)hipFree(s.ptr);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+thread_local ThreadState t_state;
 } // namespace
 
 int fail(int status, const char *fmt, ...)
@@ -66,7 +78,7 @@ int host_scratch(size_t bytes, int slot, void **out)
 {
     if (slot < 0 || slot >= kScratchSlots)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "bad scratch slot %d", slot);
-    Scratch &s = t_scratch[slot];
+    Scratch &s = t_state.scratch[slot];
     if (s.cap < bytes) {
         if (s.ptr) {
             MVFX_HIP_TRY(hipFree(s.ptr));
@@ -87,12 +99,13 @@ hipStream_t host_stream()
 {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (t_stream == nullptr || t_stream_device != dev) {
-        if (hipStreamCreateWithFlags(&t_stream, hipStreamNonBlocking) != hipSuccess)
-            t_stream = nullptr; // fall back to the null stream
-        t_stream_device = dev;
+    if (t_state.stream == nullptr || t_state.stream_device != dev) {
+        if (t_state.stream) (void)hipStreamDestroy(t_state.stream);
+        if (hipStreamCreateWithFlags(&t_state.stream, hipStreamNonBlocking) != hipSuccess)
+            t_state.stream = nullptr; // fall back to the null stream
+        t_state.stream_device = dev;
     }
-    return t_stream;
+    return t_state.stream;
 }
 
 } // namespace mvfx

@@ -156,7 +156,7 @@ def test_hipmemory_chain_stays_on_device(gpu, tmp_path):
     cube.write_text(cubes.analytic_3d(17))
     src = "videotestsrc num-buffers=2 pattern=smpte ! video/x-raw,format=RGBx,width=320,height=240"
     raw = _capture(tmp_path, src, "in.raw")
-    r = gst_env.run([LAUNCH, "-q", "-v"] + (src + " ! hipupload ! hsvfilter hue-shift=45 ! hsvdetector hue-ref=120 hue-var=60 "
+    r = gst_env.run([LAUNCH, "-v"] + (src + " ! hipupload ! hsvfilter hue-shift=45 ! hsvdetector hue-ref=120 hue-var=60 "
                     "saturation-ref=0.6 saturation-var=0.4 value-ref=0.6 value-var=0.4 ! video/x-raw(memory:HIPMemory),format=RGBA "
                     f"! colorlut location={cube} name=lut ! hipdownload ! filesink location={tmp_path}/out.raw").split(), tmp_path)
     assert r.returncode == 0, r.stdout
