@@ -146,6 +146,32 @@ def test_hsvfilter_unaligned_base(gpu, fmt):
         assert not out[:offset].any() and not out[offset + frame.nbytes:].any()
 
 
+@pytest.mark.parametrize("case", [("RGB", 5, 4, 15), ("BGR", 7, 3, 23), ("RGBA", 3, 5, 13), ("xRGB", 9, 2, 38)],
+                         ids=lambda c: f"{c[0]}_{c[1]}x{c[2]}_stride{c[3]}")
+def test_hsvfilter_strides_that_are_not_multiples_of_four(gpu, case):
+    """A GstVideoMeta may carry any stride: rows that are not dword aligned take the byte kernels."""
+    fmt, w, h, stride = case
+    bpp = 3 if fmt in ("RGB", "BGR") else 4
+    if (stride * h) % bpp:
+        h = bpp * h  # keep the reference's plane-size assert satisfied
+    frame = frames.random_frame(0x5EED0999, w, h, bpp, stride)
+    expect = frame.copy()
+    assert orc.hsvfilter(expect, w, stride, fmt, BENCH_SETTINGS) == 0
+    got = frame.copy()
+    gpu.hsvfilter_host(got.reshape(-1), w, h, stride, fmt, gpu.HsvFilterSettings(*BENCH_SETTINGS))
+    assert np.array_equal(got, expect)
+
+
+def test_hsvfilter_8k_full_size(gpu):
+    """largest BASELINE shape (7680x4320 RGBA, 132.7 MB): full-frame compare on uniform-random data"""
+    w, h = 7680, 4320
+    frame = frames.random_frame(0x5EED0002, w, h)
+    expect = frame.copy()
+    assert orc.hsvfilter(expect, w, w * 4, "RGBA", (-77.0, 0.8, 0.1, 1.1, -0.03)) == 0
+    got = _device_filter(gpu, frame, w, h, w * 4, "RGBA", (-77.0, 0.8, 0.1, 1.1, -0.03), 0)
+    assert np.array_equal(got, expect)
+
+
 def test_hsvfilter_batch_matches_single(gpu):
     """The batched entry point == N single-frame calls (33 frames crosses the 32-frame launch split)."""
     w, h = 256, 64
