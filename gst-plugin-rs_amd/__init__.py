@@ -126,6 +126,12 @@ SIGNATURES = {
     "mvfx_blockhash": (c_int, [POINTER(Frame), POINTER(c_uint64), c_void_p]),
     "mvfx_blockhash_host": (c_int, [POINTER(Frame), POINTER(c_uint64)]),
     "mvfx_videocompare_distance": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(ctypes.c_double), c_void_p]),
+    "mvfx_ssim_partial_sums": (c_int, [POINTER(Frame), POINTER(Frame), c_uint32, c_uint32, POINTER(ctypes.c_double),
+                                       POINTER(ctypes.c_double), POINTER(c_uint32), c_void_p]),
+    "mvfx_ssim_partial_deviation": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_void_p]),
+    "mvfx_ssim_combine": (ctypes.c_double, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_uint32]),
+    "mvfx_ssim_distance": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(ctypes.c_double), c_void_p]),
+    "mvfx_ssim_distance_host": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(ctypes.c_double)]),
     "mvfx_roundedcorners_mask": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_void_p]),
     "mvfx_roundedcorners_mask_host": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_uint32]),
     "mvfx_roundedcorners_compose_a420": (c_int, [POINTER(PlanarFrame), c_void_p, c_uint32, POINTER(PlanarFrame), c_void_p]),
@@ -308,3 +314,36 @@ def blockhash_host(frame_bytes, width, height, stride, fmt):
     h = c_uint64()
     check(lib().mvfx_blockhash_host(ctypes.byref(f), ctypes.byref(h)))
     return h.value
+
+
+def ssim_distance_host(a_bytes, b_bytes, width, height, stride_a, stride_b, fmt):
+    """`hash-algo=dssim` distance of two host frames (videocompare/hashed_image.rs:49-59,72-75)."""
+    a = (ctypes.c_uint8 * len(a_bytes)).from_buffer_copy(bytes(a_bytes))
+    b = (ctypes.c_uint8 * len(b_bytes)).from_buffer_copy(bytes(b_bytes))
+    fa = make_frame(ctypes.addressof(a), width, height, stride_a, fmt)
+    fb = make_frame(ctypes.addressof(b), width, height, stride_b, fmt)
+    out = ctypes.c_double(0.0)
+    check(lib().mvfx_ssim_distance_host(ctypes.byref(fa), ctypes.byref(fb), ctypes.byref(out)))
+    return out.value
+
+
+def ssim_partial_sums(frame_a: Frame, frame_b: Frame, row_begin: int, row_end: int, stream=None):
+    """Pass 1 of the shardable SSIM distance: (sums[5], counts[5], n_scales) of rows [row_begin,row_end)."""
+    sums = (ctypes.c_double * 5)()
+    counts = (ctypes.c_double * 5)()
+    n = c_uint32(0)
+    check(lib().mvfx_ssim_partial_sums(ctypes.byref(frame_a), ctypes.byref(frame_b), row_begin, row_end, sums, counts,
+                                       ctypes.byref(n), stream))
+    return list(sums), list(counts), n.value
+
+
+def ssim_partial_deviation(mean, stream=None):
+    """Pass 2: per-scale sum of |map - mean| over the band given to `ssim_partial_sums` on this thread."""
+    m = (ctypes.c_double * 5)(*mean)
+    out = (ctypes.c_double * 5)()
+    check(lib().mvfx_ssim_partial_deviation(m, out, stream))
+    return list(out)
+
+
+def ssim_combine(mean, mad, n_scales):
+    return lib().mvfx_ssim_combine((ctypes.c_double * 5)(*mean), (ctypes.c_double * 5)(*mad), n_scales)

@@ -8,6 +8,8 @@ What shards and how (DESIGN.md "Multi-GPU"):
     every pad's frame): each rank reduces its band to 64 partial block sums per frame, then ONE
     all-reduce(sum) of n_pads x 64 u32 (512 B for a pair) makes the totals visible everywhere and
     every rank derives the hash bits and Hamming distances redundantly (`videocompare_sharded`).
+  * videocompare `hash-algo=dssim`: two all-reduces of 10 f64 each (per-scale sums + counts, then
+    per-scale absolute deviations) around the two map passes (`ssim_sharded`).
   * colordetect on one distributed frame: all-reduce(sum) of the 32768-bin histogram plus
     min/max of the six channel bounds, then the host median cut on every rank
     (`colordetect_sharded`).
@@ -50,6 +52,37 @@ def videocompare_sharded(partial_sums: Callable[[int], torch.Tensor], n_pads: in
     totals = parts.cpu().tolist()
     hashes = [bits_from_sums(t, width, height) for t in totals]
     return [float(bin(hashes[0] ^ h).count("1")) for h in hashes[1:]]
+
+
+def ssim_band_rows(height: int, rank: int, world: int) -> Tuple[int, int]:
+    """Row band for the SSIM distance: boundaries are multiples of 16 rows so that every one of the
+    five pyramid levels partitions exactly (the last rank takes the remainder)."""
+    units = (height + 15) // 16
+    lo = min(units * rank // world * 16, height)
+    hi = height if rank == world - 1 else min(units * (rank + 1) // world * 16, height)
+    return lo, hi
+
+
+def ssim_sharded(partial_sums: Callable[[], Tuple[Sequence[float], Sequence[float], int]],
+                 partial_deviation: Callable[[Sequence[float]], Sequence[float]],
+                 combine: Callable[[Sequence[float], Sequence[float], int], float],
+                 device: torch.device, group=None) -> float:
+    """partial_sums() -> (sums[5], counts[5], n_scales) of THIS rank's band; partial_deviation(mean[5])
+    -> sums of |map - mean| over the same band.  Two 80-byte all-reduces; every rank returns the
+    same distance (videocompare/hashed_image.rs:72-75)."""
+    sums, counts, n_scales = partial_sums()
+    t = torch.tensor([list(sums), list(counts)], dtype=torch.float64, device=device)
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    if multi:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    tot = t.cpu().tolist()
+    mean = [tot[0][s] / tot[1][s] if tot[1][s] else 0.0 for s in range(5)]
+    d = torch.tensor(list(partial_deviation(mean)), dtype=torch.float64, device=device)
+    if multi:
+        dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
+    dev = d.cpu().tolist()
+    mad = [dev[s] / tot[1][s] if tot[1][s] else 0.0 for s in range(5)]
+    return combine(mean, mad, n_scales)
 
 
 def colordetect_sharded(partial_hist: Callable[[], Tuple[torch.Tensor, torch.Tensor]],

@@ -467,7 +467,8 @@ static void gst_rounded_corners_init(GstRoundedCorners *self)
 GST_DEBUG_CATEGORY_STATIC(videocompare_debug);
 
 // enum HashAlgorithm (videocompare/mod.rs:57-92); `dssim` is a non-default cargo feature there
-enum { MVFX_HASH_MEAN = 0, MVFX_HASH_GRADIENT = 1, MVFX_HASH_VERTGRADIENT = 2, MVFX_HASH_DOUBLEGRADIENT = 3, MVFX_HASH_BLOCKHASH = 4 };
+enum { MVFX_HASH_MEAN = 0, MVFX_HASH_GRADIENT = 1, MVFX_HASH_VERTGRADIENT = 2, MVFX_HASH_DOUBLEGRADIENT = 3, MVFX_HASH_BLOCKHASH = 4,
+       MVFX_HASH_DSSIM = 5 /* mod.rs:86-91 */ };
 
 static GType gst_video_compare_hash_algorithm_get_type(void)
 {
@@ -479,6 +480,7 @@ static GType gst_video_compare_hash_algorithm_get_type(void)
             {MVFX_HASH_VERTGRADIENT, "VertGradient: The Vertical-Gradient hashing algorithm.", "vertgradient"},
             {MVFX_HASH_DOUBLEGRADIENT, "DoubleGradient: The Double-Gradient hashing algorithm.", "doublegradient"},
             {MVFX_HASH_BLOCKHASH, "Blockhash: The Blockhash (block median value perceptual hash) algorithm.", "blockhash"},
+            {MVFX_HASH_DSSIM, "Dssim: Image similarity comparison simulating human perception.", "dssim"},
             {0, NULL, NULL}};
         g_once_init_leave(&type, g_enum_register_static("GstVideoCompareHashAlgorithm", values));
     }
@@ -580,6 +582,39 @@ static GstFlowReturn gst_video_compare_update_src_caps(GstAggregator *agg, GstCa
     return GST_FLOW_OK;
 }
 
+// HashedImage::Dssim + compare (hashed_image.rs:49-59,72-75): both frames mapped, one distance
+static int video_compare_ssim(GstPad *ref_pad, GstBuffer *ref_buf, GstPad *pad, GstBuffer *buf, double *distance,
+                              gboolean *size_mismatch)
+{
+    GstPad *pads[2] = {ref_pad, pad};
+    GstBuffer *bufs[2] = {ref_buf, buf};
+    GstVideoFrame frames[2];
+    mvfx_frame f[2];
+    int mapped = 0, rc = MVFX_OK;
+    for (int i = 0; i < 2 && rc == MVFX_OK; i++) {
+        GstCaps *caps = gst_pad_get_current_caps(pads[i]);
+        GstVideoInfo info;
+        if (!caps || !gst_video_info_from_caps(&info, caps))
+            rc = MVFX_ERR_NOT_NEGOTIATED;
+        else if (!gst_video_frame_map(&frames[i], &info, bufs[i], GST_MAP_READ))
+            rc = MVFX_ERR_INVALID_ARGUMENT;
+        else {
+            f[i] = mvfx_frame_from_gst(&frames[i]);
+            mapped++;
+        }
+        if (caps) gst_caps_unref(caps);
+    }
+    if (rc == MVFX_OK) {
+        if (f[0].width != f[1].width || f[0].height != f[1].height)
+            *size_mismatch = TRUE;
+        else
+            rc = mvfx_ssim_distance_host(&f[0], &f[1], distance);
+    }
+    for (int i = 0; i < mapped; i++)
+        gst_video_frame_unmap(&frames[i]);
+    return rc;
+}
+
 // HasherEngine::hash_image (hashed_image.rs:24-64) on one pad's buffer
 static int video_compare_hash(GstPad *pad, GstBuffer *buf, uint64_t *hash, guint *w, guint *h)
 {
@@ -618,8 +653,8 @@ static GstFlowReturn gst_video_compare_aggregate(GstAggregator *agg, gboolean ti
         GST_CAT_WARNING_OBJECT(videocompare_debug, self, "No reference sink pad exists");
         return GST_FLOW_EOS;
     }
-    if (algo != MVFX_HASH_BLOCKHASH) {
-        GST_ELEMENT_ERROR(self, LIBRARY, SETTINGS, ("hash-algo %d is not implemented by the MI355X build (only blockhash, the default)", algo), (NULL));
+    if (algo != MVFX_HASH_BLOCKHASH && algo != MVFX_HASH_DSSIM) {
+        GST_ELEMENT_ERROR(self, LIBRARY, SETTINGS, ("hash-algo %d is not implemented by the MI355X build (blockhash, the default, and dssim are)", algo), (NULL));
         return GST_FLOW_ERROR;
     }
     GstAggregatorPad *ref_apad = GST_AGGREGATOR_PAD(reference_pad);
@@ -637,7 +672,7 @@ static GstFlowReturn gst_video_compare_aggregate(GstAggregator *agg, gboolean ti
 
     uint64_t ref_hash = 0;
     guint rw = 0, rh = 0;
-    int rc = video_compare_hash(reference_pad, ref_buf, &ref_hash, &rw, &rh);
+    int rc = algo == MVFX_HASH_DSSIM ? MVFX_OK : video_compare_hash(reference_pad, ref_buf, &ref_hash, &rw, &rh);
     if (rc != MVFX_OK) {
         gst_buffer_unref(ref_buf);
         return MVFX_GST_FLOW(self, rc);
@@ -662,9 +697,14 @@ static GstFlowReturn gst_video_compare_aggregate(GstAggregator *agg, gboolean ti
             break; // imp.rs:331-334: no frame on this pad yet
         uint64_t hash = 0;
         guint w = 0, h = 0;
-        rc = video_compare_hash(pad, buf, &hash, &w, &h);
+        gdouble ssim_distance = 0.0;
+        gboolean size_mismatch = FALSE;
+        if (algo == MVFX_HASH_DSSIM)
+            rc = video_compare_ssim(reference_pad, ref_buf, pad, buf, &ssim_distance, &size_mismatch);
+        else
+            rc = video_compare_hash(pad, buf, &hash, &w, &h);
         gst_buffer_unref(buf);
-        if (rc == MVFX_OK && (w != rw || h != rh)) { // imp.rs:337-346
+        if (rc == MVFX_OK && (size_mismatch || w != rw || h != rh)) { // imp.rs:337-346
             GST_CAT_ERROR_OBJECT(videocompare_debug, self, "Video streams do not have the same sizes (add videoscale and force the sizes to be equal on all sink pads)");
             ret = GST_FLOW_NOT_NEGOTIATED;
             break;
@@ -673,7 +713,8 @@ static GstFlowReturn gst_video_compare_aggregate(GstAggregator *agg, gboolean ti
             ret = MVFX_GST_FLOW(self, rc);
             break;
         }
-        const gdouble distance = (gdouble)mvfx_hash_distance(ref_hash, hash); // hashed_image.rs:70
+        const gdouble distance = algo == MVFX_HASH_DSSIM ? ssim_distance // hashed_image.rs:72-75
+                                                         : (gdouble)mvfx_hash_distance(ref_hash, hash); // hashed_image.rs:70
         if (distance <= threshold)
             any_below = TRUE;
         GstStructure *pd = gst_structure_new("pad-distance", "pad", GST_TYPE_PAD, pad, "distance", G_TYPE_DOUBLE, distance, NULL); // mod.rs:162-169

@@ -250,6 +250,30 @@ int mvfx_blockhash_host(const mvfx_frame *frame, uint64_t *hash_out);
 int mvfx_videocompare_distance(const mvfx_frame *reference_frame, const mvfx_frame *other_frame,
                                double *distance_out, mvfx_stream stream);
 
+/* `hash-algo=dssim` (HashAlg::Dssim, videocompare/hashed_image.rs:49-59,72-75, cargo feature
+ * `dssim`, NOT in the default build).  dssim-core 3.4.0 is not vendored under the reference:
+ * this is the published multi-scale SSIM structure, PARITY UNPINNED against the
+ * crate; identical frames give exactly 0.0 (tests/videocompare.rs:141-182).  RGB / RGBA only.
+ *
+ * Two-pass, shardable by row bands (boundaries multiples of 16, or the frame height):
+ *   1. mvfx_ssim_partial_sums: per-scale sum of the SSIM map over the band + pixel counts;
+ *      the maps stay in device scratch owned by the calling thread.
+ *   2. (all-reduce sums and counts; mean = sum / count)
+ *   3. mvfx_ssim_partial_deviation: per-scale sum of |map - mean| over the same band.
+ *   4. (all-reduce; mvfx_ssim_combine(mean, deviation_sum / count, n_scales) -> distance)
+ * mvfx_ssim_distance does 1-4 for one device. */
+int mvfx_ssim_partial_sums(const mvfx_frame *reference_frame, const mvfx_frame *other_frame,
+                           uint32_t row_begin, uint32_t row_end, double sums_out[5],
+                           double counts_out[5], uint32_t *n_scales_out, mvfx_stream stream);
+int mvfx_ssim_partial_deviation(const double mean[5], double deviation_sums_out[5],
+                                mvfx_stream stream);
+double mvfx_ssim_combine(const double mean[5], const double mean_abs_deviation[5],
+                         uint32_t n_scales);
+int mvfx_ssim_distance(const mvfx_frame *reference_frame, const mvfx_frame *other_frame,
+                       double *distance_out, mvfx_stream stream);
+int mvfx_ssim_distance_host(const mvfx_frame *reference_frame, const mvfx_frame *other_frame,
+                            double *distance_out);
+
 /* ---- roundedcorners : video/videofx/src/border/imp.rs ----
  * Planar view for I420 / A420 (GstVideoFrame plane pointers + strides). */
 typedef struct mvfx_planar_frame {

@@ -123,6 +123,16 @@ int orc_blockhash(const uint8_t *data, uint32_t width, uint32_t height, uint32_t
                   int format, uint64_t *hash);
 uint32_t orc_hamming64(uint64_t a, uint64_t b);
 
+/* SSIM-family distance behind hash-algo=dssim (dssim-core 3.4.0, non-default feature; PARITY
+ * UNPINNED, see ssim_oracle.c): f64, formats RGB / RGBA. */
+int orc_ssim_distance(const uint8_t *a, const uint8_t *b, uint32_t width, uint32_t height, uint32_t stride_a,
+                      uint32_t stride_b, int format, double *distance, double *per_scale);
+/* Row-band partial sums of the same maps (mean == NULL: map sums + counts; else |map - mean| sums). */
+int orc_ssim_band(const uint8_t *a, const uint8_t *b, uint32_t width, uint32_t height, uint32_t stride_a,
+                  uint32_t stride_b, int format, uint32_t row_begin, uint32_t row_end, const double *mean,
+                  double *sums, double *counts, int *n_scales);
+double orc_ssim_combine(const double *mean, const double *mad, int n_scales);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,15 @@ def lib():
         L.orc_blockhash.restype = c_int
         L.orc_hamming64.argtypes = [c_uint64, c_uint64]
         L.orc_hamming64.restype = c_uint32
+        L.orc_ssim_distance.argtypes = [c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_int,
+                                        POINTER(ctypes.c_double), POINTER(ctypes.c_double)]
+        L.orc_ssim_distance.restype = c_int
+        L.orc_ssim_band.argtypes = [c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_int, c_uint32, c_uint32,
+                                    POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double),
+                                    POINTER(c_int)]
+        L.orc_ssim_band.restype = c_int
+        L.orc_ssim_combine.argtypes = [POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_int]
+        L.orc_ssim_combine.restype = ctypes.c_double
         _lib = L
     return _lib
 
@@ -204,3 +213,25 @@ def blockhash(data: np.ndarray, width, height, stride, fmt):
 
 def hamming(a, b):
     return lib().orc_hamming64(a, b)
+
+
+def ssim_distance(a: np.ndarray, b: np.ndarray, width, height, stride_a, stride_b, fmt):
+    d = ctypes.c_double()
+    per = (ctypes.c_double * 5)()
+    rc = lib().orc_ssim_distance(a.ctypes.data, b.ctypes.data, width, height, stride_a, stride_b, _fmt(fmt), ctypes.byref(d), per)
+    return rc, d.value, [per[i] for i in range(5)]
+
+
+def ssim_band(a: np.ndarray, b: np.ndarray, width, height, stride_a, stride_b, fmt, row_begin, row_end, mean=None):
+    sums = (ctypes.c_double * 5)()
+    counts = (ctypes.c_double * 5)()
+    n = c_int(0)
+    m = (ctypes.c_double * 5)(*mean) if mean is not None else None
+    rc = lib().orc_ssim_band(a.ctypes.data, b.ctypes.data, width, height, stride_a, stride_b, _fmt(fmt), row_begin, row_end,
+                             m, sums, counts, ctypes.byref(n))
+    assert rc == 0, rc
+    return list(sums), list(counts), n.value
+
+
+def ssim_combine(mean, mad, n_scales):
+    return lib().orc_ssim_combine((ctypes.c_double * 5)(*mean), (ctypes.c_double * 5)(*mad), n_scales)

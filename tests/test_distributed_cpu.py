@@ -69,7 +69,16 @@ def _worker(rank, world, port, q):
             return p
 
         palette = D.colordetect_sharded(lambda: (torch.from_numpy(hist.astype(np.int64)), torch.tensor(mm, dtype=torch.int64)), pal, dev)
-        q.put((rank, d, palette, D.shard_streams(5, rank, world)))
+        # hash-algo=dssim: two small all-reduces around the two map passes
+        sw, sh = 96, 80
+        sa = frames.random_frame(0x5EED0002, sw, sh)
+        sb = sa.copy()
+        sb[5::7, 3:sw * 4:11] ^= 0x15
+        y0, y1 = D.ssim_band_rows(sh, rank, world)
+        ssim = D.ssim_sharded(lambda: orc.ssim_band(sa, sb, sw, sh, sw * 4, sw * 4, "RGBA", y0, y1),
+                              lambda mean: orc.ssim_band(sa, sb, sw, sh, sw * 4, sw * 4, "RGBA", y0, y1, mean)[0],
+                              orc.ssim_combine, dev)
+        q.put((rank, d, palette, D.shard_streams(5, rank, world), ssim))
     finally:
         dist.destroy_process_group()
 
@@ -97,10 +106,18 @@ def test_world2_videocompare_and_colordetect_match_single_process():
     hs = [orc.blockhash(f, w, h, w * 4, "RGBA")[1] for f in (a, b, c, a)]
     truth = [float(orc.hamming(hs[0], x)) for x in hs[1:]]
     rc, pal = orc.colordetect_palette(a, "RGBA", 10, 5)
-    for rank, d, palette, streams in results:
+    sw, sh = 96, 80
+    sa = frames.random_frame(0x5EED0002, sw, sh)
+    sb = sa.copy()
+    sb[5::7, 3:sw * 4:11] ^= 0x15
+    rc, ssim_truth, _ = orc.ssim_distance(sa, sb, sw, sh, sw * 4, sw * 4, "RGBA")
+    assert rc == 0 and ssim_truth > 0
+    for rank, d, palette, streams, ssim in results:
         assert d == truth and d[2] == 0.0
         assert palette == pal
         assert streams == [k for k in range(5) if k % world == rank]
+        assert ssim == pytest.approx(ssim_truth, rel=1e-12)
+    assert results[0][4] == results[1][4]  # every rank derives the same value
 
 
 def test_band_rows_cover_the_frame():
@@ -111,3 +128,8 @@ def test_band_rows_cover_the_frame():
         assert bands[0][0] == 0 and bands[-1][1] == h
         assert all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
     assert D.band_rows(4320, 3, 8) == (3 * 540, 4 * 540)  # one block row per rank at 8K
+    for h, world in ((4320, 8), (1080, 8), (100, 3), (17, 2), (8, 4)):
+        bands = [D.ssim_band_rows(h, r, world) for r in range(world)]
+        assert bands[0][0] == 0 and bands[-1][1] == h
+        assert all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
+        assert all(b[0] % 16 == 0 and (b[1] % 16 == 0 or b[1] == h) for b in bands)

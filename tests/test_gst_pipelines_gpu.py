@@ -138,6 +138,20 @@ def test_videocompare_unimplemented_algo_errors(gpu, tmp_path):
     assert r.returncode != 0 and "not implemented" in r.stdout
 
 
+def test_videocompare_dssim_red_vs_red_and_snow(gpu, tmp_path):
+    """tests/videocompare.rs:141-182 (feature dssim): identical frames => message with distance 0;
+    snow vs red => silent at threshold 0, a positive non-integer distance with a generous threshold"""
+    out = _videocompare(tmp_path, "red", "red", "hash-algo=dssim")
+    msgs = re.findall(r"videocompare, running-time=\(guint64\)(\d+), pad-distances=\(structure\)<([^>]*)>", out)
+    assert len(msgs) >= 1, out
+    assert re.search(r"distance\\=\\\(double\\\)0[;\\]", msgs[0][1]), msgs[0][1]
+    out = _videocompare(tmp_path, "red", "snow", "hash-algo=dssim")
+    assert "videocompare, running-time" not in out
+    out = _videocompare(tmp_path, "red", "snow", "hash-algo=dssim max-dist-threshold=1000")
+    m = re.search(r"distance\\=\\\(double\\\)([0-9.e+-]+)", out)
+    assert m and float(m.group(1)) > 0.01, out
+
+
 # ---------------------------------------------------------------- memory:HIPMemory (SURVEY 8f-1)
 
 def test_hipmemory_hsvfilter_matches_host_path(gpu, tmp_path):

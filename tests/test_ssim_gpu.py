@@ -1,0 +1,117 @@
+"""videocompare hash-algo=dssim on the GPU (gst-plugin-rs_amd/csrc/ssim_kernels.hip) against the f64
+restatement oracle/ssim_oracle.c.  PARITY UNPINNED against dssim-core itself (see the oracle's
+header); pinned here: the reference test's property (identical -> 0.0, tests/videocompare.rs:141-182),
+agreement with the oracle to 1e-9 relative, band partials == whole frame."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests import frames
+from tests import oracle_binding as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(seed, w, h, bpp, amp, every=97, stride=None):
+    a = frames.random_frame(seed, w, h, bpp, stride)
+    b = a.copy()
+    flat = b.reshape(-1)
+    idx = np.arange(0, flat.size, every)
+    flat[idx] = np.clip(flat[idx].astype(np.int32) + amp, 0, 255).astype(np.uint8)
+    return a, b
+
+
+@pytest.mark.parametrize("fmt,bpp,w,h", [("RGBA", 4, 320, 240), ("RGB", 3, 131, 77), ("RGBA", 4, 8, 8), ("RGB", 3, 1920, 1080)])
+def test_identical_frames_distance_is_exactly_zero(gpu, fmt, bpp, w, h):
+    a = frames.random_frame(0xD5510 + w, w, h, bpp)
+    assert gpu.ssim_distance_host(a.reshape(-1), a.reshape(-1), w, h, w * bpp, w * bpp, fmt) == 0.0
+
+
+@pytest.mark.parametrize("fmt,bpp,w,h,stride", [
+    ("RGBA", 4, 64, 48, None), ("RGB", 3, 131, 77, 131 * 3 + 5), ("RGBA", 4, 320, 240, 320 * 4 + 64),
+    ("RGB", 3, 17, 9, None), ("RGBA", 4, 640, 360, None)])
+def test_matches_f64_oracle(gpu, fmt, bpp, w, h, stride):
+    stride = stride or w * bpp
+    for amp, every in ((1, 97), (25, 13), (120, 5)):
+        a, b = _pair(0xD5520 + w + amp, w, h, bpp, amp, every, stride)
+        rc, want, _ = orc.ssim_distance(a, b, w, h, stride, stride, fmt)
+        assert rc == 0
+        got = gpu.ssim_distance_host(a.reshape(-1), b.reshape(-1), w, h, stride, stride, fmt)
+        assert got == pytest.approx(want, rel=1e-9, abs=1e-12)  # distance = 1/ssim - 1: 1e-12 absolute on ssim ~ 1
+        assert got > 0.0
+
+
+def test_monotone_ladder_and_inverted(gpu):
+    w, h = 256, 192
+    last = 0.0
+    for amp in (1, 3, 10, 40, 120):
+        a, b = _pair(0xD553, w, h, 4, amp)
+        d = gpu.ssim_distance_host(a.reshape(-1), b.reshape(-1), w, h, w * 4, w * 4, "RGBA")
+        assert d > last
+        last = d
+    a = frames.random_frame(0xD554, w, h)
+    inv = 255 - a
+    inv[:, 3::4] = a[:, 3::4]
+    assert gpu.ssim_distance_host(a.reshape(-1), inv.reshape(-1), w, h, w * 4, w * 4, "RGBA") > last
+
+
+def test_band_partials_equal_whole_frame(gpu):
+    """The sharded path (distributed.ssim_sharded) on one GPU: 3 bands, reduced by hand."""
+    w, h = 200, 150
+    a, b = _pair(0xD555, w, h, 4, 30, every=11)
+    da = gpu.DeviceBuffer(a.nbytes).upload(a)
+    db = gpu.DeviceBuffer(b.nbytes).upload(b)
+    fa, fb = gpu.make_frame(da.ptr, w, h, w * 4, "RGBA"), gpu.make_frame(db.ptr, w, h, w * 4, "RGBA")
+    d = ctypes.c_double()
+    gpu.check(gpu.lib().mvfx_ssim_distance(ctypes.byref(fa), ctypes.byref(fb), ctypes.byref(d), None))
+    bands = ((0, 48), (48, 112), (112, h))
+    # pass 1 for every band, then pass 2 needs the per-band maps again: the state is per call,
+    # so each band runs pass 1 -> (global mean) -> pass 2 in turn.
+    firsts = [gpu.ssim_partial_sums(fa, fb, r0, r1) for r0, r1 in bands]
+    n = firsts[0][2]
+    tot_s = [sum(f[0][s] for f in firsts) for s in range(5)]
+    tot_c = [sum(f[1][s] for f in firsts) for s in range(5)]
+    o_s, o_c, o_n = orc.ssim_band(a, b, w, h, w * 4, w * 4, "RGBA", 0, h)
+    assert n == o_n and tot_c == o_c
+    assert tot_s == pytest.approx(o_s, rel=1e-12)
+    mean = [tot_s[s] / tot_c[s] if tot_c[s] else 0.0 for s in range(5)]
+    dev = [0.0] * 5
+    for r0, r1 in bands:
+        gpu.ssim_partial_sums(fa, fb, r0, r1)
+        part = gpu.ssim_partial_deviation(mean)
+        dev = [dev[s] + part[s] for s in range(5)]
+    mad = [dev[s] / tot_c[s] if tot_c[s] else 0.0 for s in range(5)]
+    assert gpu.ssim_combine(mean, mad, n) == pytest.approx(d.value, rel=1e-9, abs=1e-12)
+    rc, want, _ = orc.ssim_distance(a, b, w, h, w * 4, w * 4, "RGBA")
+    assert d.value == pytest.approx(want, rel=1e-9, abs=1e-12)
+
+
+def test_argument_errors(gpu):
+    w, h = 64, 48
+    a = frames.random_frame(1, w, h)
+    da = gpu.DeviceBuffer(a.nbytes).upload(a)
+    fa = gpu.make_frame(da.ptr, w, h, w * 4, "RGBA")
+    d = ctypes.c_double()
+    bad = gpu.make_frame(da.ptr, w, h, w * 4, "BGRA")
+    assert gpu.lib().mvfx_ssim_distance(ctypes.byref(fa), ctypes.byref(bad), ctypes.byref(d), None) == gpu.ERR_UNSUPPORTED_FORMAT
+    half = gpu.make_frame(da.ptr, w, h // 2, w * 4, "RGBA")
+    assert gpu.lib().mvfx_ssim_distance(ctypes.byref(fa), ctypes.byref(half), ctypes.byref(d), None) == gpu.ERR_NOT_NEGOTIATED
+    tiny = gpu.make_frame(da.ptr, 4, 4, w * 4, "RGBA")
+    assert gpu.lib().mvfx_ssim_distance(ctypes.byref(tiny), ctypes.byref(tiny), ctypes.byref(d), None) == gpu.ERR_INVALID_ARGUMENT
+    sums = (ctypes.c_double * 5)()
+    n = ctypes.c_uint32()
+    assert gpu.lib().mvfx_ssim_partial_sums(ctypes.byref(fa), ctypes.byref(fa), 8, 32, sums, sums, ctypes.byref(n), None) == gpu.ERR_INVALID_ARGUMENT
+    assert gpu.lib().mvfx_ssim_partial_deviation(sums, sums, None) in (gpu.ERR_INVALID_ARGUMENT, 0)
+
+
+def test_4k_pair_identical_and_perturbed(gpu):
+    w, h = 3840, 2160
+    a = frames.random_frame(0xD556, w, h)
+    assert gpu.ssim_distance_host(a.reshape(-1), a.reshape(-1), w, h, w * 4, w * 4, "RGBA") == 0.0
+    b = a.copy()
+    b[1000:1100, 4000:4400] ^= 0x40
+    d1 = gpu.ssim_distance_host(a.reshape(-1), b.reshape(-1), w, h, w * 4, w * 4, "RGBA")
+    b[500:1500, 2000:8000] ^= 0x40
+    d2 = gpu.ssim_distance_host(a.reshape(-1), b.reshape(-1), w, h, w * 4, w * 4, "RGBA")
+    assert 0.0 < d1 < d2
