@@ -16,7 +16,8 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_siz
                     c_uint32, c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355vfx.so")
+# MVFX_LIB: another build of the same library (kernel A/B runs, tools/ab_bench.sh); never a different backend
+LIB_PATH = os.environ.get("MVFX_LIB") or os.path.join(_HERE, "libmi355vfx.so")
 
 # mvfx_format (include/mi355vfx.h)
 FORMATS = {

@@ -26,6 +26,10 @@ namespace mvfx {
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef MVFX_HSV_TILE
+#define MVFX_HSV_TILE 1
+#endif
+constexpr int kTile = MVFX_HSV_TILE; // 16-byte pixel groups per lane in hsvfilter4_kernel (vec4 mode)
 
 enum : int { kModeBytes = 0, kModeVec4 = 1, kModeDword = 2 };
 
@@ -67,12 +71,24 @@ __device__ __forceinline__ uint32_t filter_px4(uint32_t px, const FastConsts &k,
         // v_cvt_f32_ubyteN straight from the pixel dword + the exact 2-op divide.  (A 256-entry LDS
         // table of RN(b/255) was measured slower: 3 more random ds_read_b32 per pixel cost more in
         // bank conflicts than the 5 fast VALU ops they replace: 60.3 k vs 68.2 k frames/s.)
+#if defined(MVFX_EXP) && MVFX_EXP == 1 // experiment: memory shape only
+        return px ^ 0x00010203u;
+#elif defined(MVFX_EXP) && MVFX_EXP >= 3 // experiment: the arithmetic applied MVFX_EXP-1 times per pixel
+        for (int rep = 0; rep < MVFX_EXP - 2; rep++) {
+            const float e0 = div255((float)((px >> (8 * OFF)) & 0xffu), k);
+            const float e1 = div255((float)((px >> (8 * OFF + 8)) & 0xffu), k);
+            const float e2 = div255((float)((px >> (8 * OFF + 16)) & 0xffu), k);
+            uint32_t T2;
+            const uint32_t so = hsvfilter_fast_unit<VARIANT == kFastNeg>(BGR ? e2 : e0, e1, BGR ? e0 : e2, k, T2);
+            px = __builtin_amdgcn_perm(T2, px, sextant_at(lds.sextant, so));
+        }
+#endif
         const float c0 = div255((float)((px >> (8 * OFF)) & 0xffu), k);
         const float c1 = div255((float)((px >> (8 * OFF + 8)) & 0xffu), k);
         const float c2 = div255((float)((px >> (8 * OFF + 16)) & 0xffu), k);
         uint32_t T;
-        const uint32_t sext = hsvfilter_fast_unit<VARIANT == kFastNeg>(BGR ? c2 : c0, c1, BGR ? c0 : c2, k, T);
-        return __builtin_amdgcn_perm(T, px, lds.sextant[sext]);
+        const uint32_t sel_off = hsvfilter_fast_unit<VARIANT == kFastNeg>(BGR ? c2 : c0, c1, BGR ? c0 : c2, k, T);
+        return __builtin_amdgcn_perm(T, px, sextant_at(lds.sextant, sel_off));
     }
 }
 
@@ -92,9 +108,10 @@ __device__ __forceinline__ void init_filter_lds(FilterLds &lds, int off, bool bg
 template <int OFF, bool BGR, int VARIANT, int MODE>
 __global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint64_t width,
                                                             uint32_t rows, uint64_t stride,
-                                                            FastConsts p)
+                                                            FastConsts p_arg)
 {
     __shared__ FilterLds lds;
+    const FastConsts p = consts_to_vgpr(p_arg);
     // vec4 / dword modes permute straight into the pixel layout; the byte mode uses (off 0, RGB)
     init_filter_lds<VARIANT>(lds, MODE == kModeBytes ? 0 : OFF, MODE == kModeBytes ? false : BGR);
     const uint32_t *lut = lds.sextant;
@@ -102,21 +119,34 @@ __global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint6
     for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
         uint8_t *line = frame + (uint64_t)row * stride;
         if constexpr (MODE == kModeVec4) {
+            // One workgroup owns a tile of kTile x 256 pixel groups: every lane issues its kTile
+            // 16-byte loads first, then runs the arithmetic, so the loads of group u+1.. are in
+            // flight while group u is computed (the wave stays in its VALU phase for kTile x 272
+            // instructions instead of dying after one group).
             const uint64_t groups = (width + 3) >> 2;
-            for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < groups;
-                 g += (uint64_t)gridDim.x * kBlock) {
-                const uint64_t x = g << 2;
-                if (x + 4 <= width) {
-                    uint4 v = *reinterpret_cast<const uint4 *>(line + x * 4);
-                    v.x = filter_px4<OFF, BGR, VARIANT>(v.x, p, lds);
-                    v.y = filter_px4<OFF, BGR, VARIANT>(v.y, p, lds);
-                    v.z = filter_px4<OFF, BGR, VARIANT>(v.z, p, lds);
-                    v.w = filter_px4<OFF, BGR, VARIANT>(v.w, p, lds);
-                    *reinterpret_cast<uint4 *>(line + x * 4) = v;
-                } else {
-                    for (uint64_t xx = x; xx < width; xx++) {
-                        uint32_t *q = reinterpret_cast<uint32_t *>(line + xx * 4);
-                        *q = filter_px4<OFF, BGR, VARIANT>(*q, p, lds);
+            for (uint64_t t0 = (uint64_t)blockIdx.x * (kBlock * kTile); t0 < groups;
+                 t0 += (uint64_t)gridDim.x * (kBlock * kTile)) {
+                uint4 v[kTile];
+#pragma unroll
+                for (int u = 0; u < kTile; u++) {
+                    const uint64_t x = (t0 + (uint64_t)u * kBlock + threadIdx.x) << 2;
+                    if (x + 4 <= width)
+                        v[u] = *reinterpret_cast<const uint4 *>(line + x * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < kTile; u++) {
+                    const uint64_t x = (t0 + (uint64_t)u * kBlock + threadIdx.x) << 2;
+                    if (x + 4 <= width) {
+                        v[u].x = filter_px4<OFF, BGR, VARIANT>(v[u].x, p, lds);
+                        v[u].y = filter_px4<OFF, BGR, VARIANT>(v[u].y, p, lds);
+                        v[u].z = filter_px4<OFF, BGR, VARIANT>(v[u].z, p, lds);
+                        v[u].w = filter_px4<OFF, BGR, VARIANT>(v[u].w, p, lds);
+                        *reinterpret_cast<uint4 *>(line + x * 4) = v[u];
+                    } else {
+                        for (uint64_t xx = x; xx < width; xx++) {
+                            uint32_t *q = reinterpret_cast<uint32_t *>(line + xx * 4);
+                            *q = filter_px4<OFF, BGR, VARIANT>(*q, p, lds);
+                        }
                     }
                 }
             }
@@ -237,7 +267,7 @@ __device__ __forceinline__ uint32_t detect_px4_fast(uint32_t px, const HsvDetect
     const float c0 = (float)((px >> (8 * IN_OFF)) & 0xffu);
     const float c1 = (float)((px >> (8 * IN_OFF + 8)) & 0xffu);
     const float c2 = (float)((px >> (8 * IN_OFF + 16)) & 0xffu);
-    const Hsv hsv = from_rgb_fast(IN_BGR ? c2 : c0, c1, IN_BGR ? c0 : c2, p.consts);
+    const HsvN hsv = from_rgb_fast_n(IN_BGR ? c2 : c0, c1, IN_BGR ? c0 : c2, p.consts);
     const uint32_t hit = ~detect_miss_mask_fast(hsv, p); // 0xffffffff on a hit: any byte of it is the alpha
     // selector: 0..3 = bytes of px, 4 = alpha
     constexpr uint32_t iR = IN_OFF + (IN_BGR ? 2 : 0), iG = IN_OFF + 1, iB = IN_OFF + (IN_BGR ? 0 : 2);
@@ -356,9 +386,13 @@ FastConsts make_consts(const mvfx_hsvfilter_settings *s)
     k.c255lo = (float)(1.0 / 255.0 - (double)k.c255);
     k.c60 = 1.0f / 60.0f;
     k.c60lo = (float)(1.0 / 60.0 - (double)k.c60);
+    k.c120 = 0.5f * k.c60;
+    k.c120lo = 0.5f * k.c60lo;
+    k.sext_magic = 1048575.9375f;
     k.k255 = 255.0f;
     k.k60 = 60.0f;
     k.k360 = 360.0f;
+    k.neg_k60 = -60.0f;
     k.pred360 = std::nextafterf(360.0f, 0.0f);
     k.tiny = 1e-30f;
     const float f360 = 360.0f;
@@ -369,6 +403,7 @@ FastConsts make_consts(const mvfx_hsvfilter_settings *s)
         k.saturation_off = s->saturation_off;
         k.value_mul = s->value_mul;
         k.value_off = s->value_off;
+        k.neg_saturation_mul = -s->saturation_mul;
     }
     return k;
 }
@@ -395,7 +430,7 @@ struct Geometry {
 };
 
 // Picks flat/row layout, access mode and grid for a packed frame batch.
-Geometry plan(const mvfx_frame *frames, uint32_t n, int bpp, uint32_t n_frames_z)
+Geometry plan(const mvfx_frame *frames, uint32_t n, int bpp, uint32_t n_frames_z, int tile)
 {
     Geometry g;
     const mvfx_frame &f = frames[0];
@@ -417,7 +452,8 @@ Geometry plan(const mvfx_frame *frames, uint32_t n, int bpp, uint32_t n_frames_z
         g.mode = (align_or & need) == 0 ? kModeVec4 : ((bpp == 4 && (align_or & 3) == 0) ? kModeDword : kModeBytes);
     }
     const uint64_t work = g.mode == kModeVec4 ? (g.width + 3) / 4 : g.width;
-    uint64_t bx = (work + kBlock - 1) / kBlock;
+    const uint64_t per_block = (uint64_t)kBlock * (g.mode == kModeVec4 ? tile : 1);
+    uint64_t bx = (work + per_block - 1) / per_block;
     if (bx == 0) bx = 1;
     if (bx > 65535u * 16u) bx = 65535u * 16u; // grid-stride covers the rest
     g.grid = dim3((uint32_t)bx, g.rows < 65535u ? (g.rows ? g.rows : 1) : 65535u, n_frames_z);
@@ -428,6 +464,7 @@ template <int VARIANT>
 void launch_filter(int bpp, int off, bool bgr, const Geometry &g, const FrameBatch &fb,
                    const FastConsts &p, hipStream_t stream)
 {
+
 #define MVFX_L4(O, B, M) \
     hipLaunchKernelGGL((hsvfilter4_kernel<O, B, VARIANT, M>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p)
 #define MVFX_L3(B, M) \
@@ -498,7 +535,7 @@ int hsvfilter_impl(const mvfx_frame *frames, uint32_t n, const mvfx_hsvfilter_se
         FrameBatch fb{};
         for (uint32_t i = 0; i < m; i++)
             fb.base[i] = static_cast<uint8_t *>(frames[done + i].data);
-        const Geometry g = plan(frames + done, m, bpp, m);
+        const Geometry g = plan(frames + done, m, bpp, m, bpp == 4 ? kTile : 1);
         if (use_fast && std::signbit(s->hue_shift) && s->hue_shift != 0.0f)
             launch_filter<kFastNeg>(bpp, off, bgr, g, fb, p, stream);
         else if (use_fast)

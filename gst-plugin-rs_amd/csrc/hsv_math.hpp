@@ -39,13 +39,34 @@ struct HsvFilterParams { // hsvfilter/imp.rs:32-39
 struct FastConsts {
     float c255, c255lo;   // 1/255 = c255 + c255lo   (prove_exact P8)
     float c60, c60lo;     // 1/60  = c60 + c60lo     (P8)
+    float c120, c120lo;   // halves of the above: RN(h/120) == 0.5*RN(h/60) (P11)
+    float sext_magic;     // 2^20 - 1/16 (P12)
     float k255, k60, k360;
+    float neg_k60;        // -60: the hue quotient is carried negated (see quot_neg)
     float pred360;        // largest float below 360 (P9)
     float tiny;           // 1e-30: keeps rcp() away from 0 without changing any non-zero value
     uint32_t bits360;     // bit pattern of 360.0f
     // hsvfilter settings (hsvfilter/imp.rs:32-39)
     float hue_shift, saturation_mul, saturation_off, value_mul, value_off;
+    float neg_saturation_mul; // -saturation_mul: from_rgb hands over -s
 };
+
+// Per-thread copy of the constants in VGPRs: a VALU instruction with an SGPR source operand issues at the
+// slow rate on gfx950 (tools/probe_isa3.hip: v_add_f32 v,s,v 37 vs 58 T lane-inst/s for v,v,v)
+__device__ __forceinline__ FastConsts consts_to_vgpr(const FastConsts &k)
+{
+#ifdef MVFX_KCONST_VGPR
+    FastConsts o;
+    const uint32_t *in = reinterpret_cast<const uint32_t *>(&k);
+    uint32_t *out = reinterpret_cast<uint32_t *>(&o);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(FastConsts) / 4; i++)
+        asm("v_mov_b32 %0, %1" : "=v"(out[i]) : "s"(in[i]));
+    return o;
+#else
+    return k;
+#endif
+}
 
 struct HsvDetectorParams { // hsvdetector/imp.rs:34-42, plus ref_hue_offset = 180 - hue_ref (:141)
     float ref_hue_offset, hue_var, saturation_ref, saturation_var, value_ref, value_var;
@@ -55,6 +76,10 @@ struct HsvDetectorParams { // hsvdetector/imp.rs:34-42, plus ref_hue_offset = 18
 
 struct Hsv {
     float h, s, v;
+};
+
+struct HsvN { // FAST path: saturation carried NEGATED (ns == -s), see quot_neg()
+    float h, ns, v;
 };
 
 constexpr int kGeneral = 0;
@@ -174,9 +199,14 @@ __device__ __forceinline__ uint32_t detect_alpha_general(const Hsv hsv, const Hs
 // bit, and the 6-way sextant select of to_rgb is a byte rotation (v_alignbyte_b32) of the three
 // converted channel values instead of 5 compares + 10 selects.
 
-__device__ __forceinline__ float fmac_sv(float acc, float s, float v) // acc + s*v, s in an SGPR
+#ifdef MVFX_KCONST_VGPR // experiment knob (tools/hsv_valu_bench.hip): kernel constants held in VGPRs
+#define MVFX_KC "v"
+#else
+#define MVFX_KC "s"
+#endif
+__device__ __forceinline__ float fmac_sv(float acc, float s, float v) // acc + s*v, s a kernel constant
 {
-    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(s), "v"(v));
+    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : MVFX_KC(s), "v"(v));
     return acc;
 }
 
@@ -196,8 +226,30 @@ __device__ __forceinline__ uint32_t sign_mask(float x) // 0xffffffff if the sign
 __device__ __forceinline__ float add_clamp01(float a, float s) // clamp(a + s, 0, 1) in one VOP3
 {
     float r;
-    asm("v_add_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(s));
+    asm("v_add_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), MVFX_KC(s));
     return r;
+}
+
+// `if x < 0 { x += 360 }` for x in [-360,360) \ {-0}: a negative x has the larger unsigned bit pattern,
+// a non-negative x the smaller one than x + 360  (P13): v_add_f32 + v_min_u32
+__device__ __forceinline__ float wrap_up(float x, const FastConsts &k)
+{
+#ifdef MVFX_OLD_WRAP
+    return x + __uint_as_float(sign_mask(x) & k.bits360);
+#else
+    const float y = x + k.k360;
+    return __uint_as_float(min(__float_as_uint(x), __float_as_uint(y)));
+#endif
+}
+// fmod(x, 360) for x in [0,720): x - 360 is exact there, negative (larger pattern) iff x < 360  (P13)
+__device__ __forceinline__ float wrap_down(float x, const FastConsts &k)
+{
+#ifdef MVFX_OLD_WRAP
+    return x - __uint_as_float(sign_mask(k.pred360 - x) & k.bits360);
+#else
+    const float y = x - k.k360;
+    return __uint_as_float(min(__float_as_uint(y), __float_as_uint(x)));
+#endif
 }
 
 // RN(x/255) for integer-valued x in [0,255]: x*C + RN(x*Clo)  (P8)
@@ -205,19 +257,25 @@ __device__ __forceinline__ float div255(float x, const FastConsts &k) { return f
 // RN(h/60) for h == 0 or h in [1e-30,360]  (P8)
 __device__ __forceinline__ float div60(float h, const FastConsts &k) { return fmac_sv(h * k.c60lo, k.c60, h); }
 
-// RN(n/d) for the two from_rgb quotients, d in [1/255,1] (or `tiny`), |n| <= d.  v_rcp_f32
-// (<= 1 ulp) seeds one residual correction of the quotient.  Correct rounding on all 2^24
-// (R,G,B) is established by the exhaustive GPU parity test, not by analysis.
-__device__ __forceinline__ float div_rgb(float n, float d)
+// -RN(n/d) for the two from_rgb quotients, d in [1/255,1] (or `tiny`), |n| <= d.
+// v_rcp_f32 (<= 1 ulp) of -d seeds one residual correction of the quotient; carrying the NEGATED
+// quotient lets both correction steps be VOP2 v_fmac_f32 (no VOP3 neg modifier, measured 16 % of
+// the pixel time, tools/hsv_valu_bench.hip):  yn = -1/d,  q0n = n*yn = -q0,
+// r = n + d*q0n = n - d*q0 (same residual),  -q = q0n + r*yn.  Every step is the exact mirror image
+// of q0 = n*y, r = fma(-d,q0,n), q = q0 + r*y, so the result is -RN(n/d) whenever that was RN(n/d).
+// Correct rounding on all 2^24 (R,G,B) is established by the exhaustive GPU parity test
+// (tests/test_hsv_gpu.py::test_from_rgb_f32_exhaustive), not by analysis.
+__device__ __forceinline__ float quot_neg(float n, float d)
 {
-    const float y = __builtin_amdgcn_rcpf(d);
-    const float q0 = n * y;
-    const float r = __builtin_fmaf(-d, q0, n);
-    return fmac_vv(q0, r, y);
+    float yn;
+    asm("v_rcp_f32_e64 %0, -%1" : "=v"(yn) : "v"(d));
+    const float q0n = n * yn;
+    const float r = fmac_vv(n, d, q0n);
+    return fmac_vv(q0n, r, yn);
 }
 
 // hsvutils.rs:44-84 given r,g,b = RN(byte/255) (from div255() or from the 256-entry LDS table)
-__device__ __forceinline__ Hsv from_unit_rgb_fast(float r, float g, float b, const FastConsts &k)
+__device__ __forceinline__ HsvN from_unit_rgb_fast_n(float r, float g, float b, const FastConsts &k)
 {
     // RN is monotone, so max/min of the quotients == quotient of the max/min byte
     const float value = fmaxf(r, fmaxf(g, b));
@@ -234,17 +292,29 @@ __device__ __forceinline__ Hsv from_unit_rgb_fast(float r, float g, float b, con
     const float off = is_r ? 0.0f : (is_g ? 2.0f : 4.0f);
     // chroma == 0 => all channels equal => n == 0 and is_r => hue = 60*(0+0) = 0 as required;
     // the denominator only has to be non-zero there (chroma + 1e-30 == chroma otherwise).
-    const float q = div_rgb(n, chroma + k.tiny);
-    const float hue = (off + q) * k.k60; // off == 0: q + 0 is exact, matches the un-added branch
-    Hsv o;
+    const float qn = quot_neg(n, chroma + k.tiny);
+    // (off + q) * 60 == (-q - off) * -60 (RN is sign-symmetric; off == 0, q == +0 gives -0 * -60 = +0)
+    const float hue = (qn - off) * k.neg_k60;
+    HsvN o;
     // `if hue < 0 { hue += 360 }`; hue is never -0.0 (equal channels give +0), P4: hue % 360 == hue
-    o.h = hue + __uint_as_float(sign_mask(hue) & k.bits360);
-    o.s = div_rgb(chroma, value + k.tiny); // value == 0 => chroma == 0 => 0; P4: clamps are identities
+    o.h = wrap_up(hue, k);
+    o.ns = quot_neg(chroma, value + k.tiny); // value == 0 => chroma == 0 => -0; P4: clamps are identities
     o.v = value;
     return o;
 }
 
+__device__ __forceinline__ Hsv from_unit_rgb_fast(float r, float g, float b, const FastConsts &k)
+{
+    const HsvN n = from_unit_rgb_fast_n(r, g, b, k);
+    return Hsv{n.h, -n.ns, n.v};
+}
+
 // the same from the byte values as floats (fR = (float)R ...)
+__device__ __forceinline__ HsvN from_rgb_fast_n(float fR, float fG, float fB, const FastConsts &k)
+{
+    return from_unit_rgb_fast_n(div255(fR, k), div255(fG, k), div255(fB, k), k);
+}
+
 __device__ __forceinline__ Hsv from_rgb_fast(float fR, float fG, float fB, const FastConsts &k)
 {
     return from_unit_rgb_fast(div255(fR, k), div255(fG, k), div255(fB, k), k);
@@ -252,17 +322,18 @@ __device__ __forceinline__ Hsv from_rgb_fast(float fR, float fG, float fB, const
 
 // hsvfilter/imp.rs:102-115 for finite settings; NEG_SHIFT selects -360 <= shift < 0 vs 0 <= shift <= 360
 template <bool NEG_SHIFT>
-__device__ __forceinline__ Hsv filter_hsv_fast(Hsv hsv, const FastConsts &k)
+__device__ __forceinline__ Hsv filter_hsv_fast(const HsvN in, const FastConsts &k)
 {
-    const float x = hsv.h + k.hue_shift;
-    if constexpr (NEG_SHIFT) { // x in [-360,360): fmod is the identity, then `if <0 {+=360}`  (P9)
-        hsv.h = x + __uint_as_float(sign_mask(x) & k.bits360);
-    } else {                   // x in [0,720): subtract 360 iff x >= 360  (P9)
-        hsv.h = x - __uint_as_float(sign_mask(k.pred360 - x) & k.bits360);
+    Hsv hsv;
+    const float x = in.h + k.hue_shift;
+    if constexpr (NEG_SHIFT) { // x in [-360,360): fmod is the identity, then `if <0 {+=360}`  (P9, P13)
+        hsv.h = wrap_up(x, k);
+    } else {                   // x in [0,720): subtract 360 iff x >= 360  (P9, P13)
+        hsv.h = wrap_down(x, k);
     }
     // finite settings => no NaN => the VOP3 clamp == max(.,0).min(1)
-    hsv.s = add_clamp01(k.saturation_mul * hsv.s, k.saturation_off);
-    hsv.v = add_clamp01(k.value_mul * hsv.v, k.value_off);
+    hsv.s = add_clamp01(k.neg_saturation_mul * in.ns, k.saturation_off); // (-mul)*(-s) == mul*s, signed zeros included
+    hsv.v = add_clamp01(k.value_mul * in.v, k.value_off);
     return hsv;
 }
 
@@ -286,53 +357,79 @@ __device__ __forceinline__ uint32_t sextant_selector(uint32_t k, int off, bool b
 }
 
 // hsvutils.rs:132-163 for h in {0} U [1e-30,360], s,v in [0,1].  Writes T = [Vc, Vx, V0, 0] (the
-// three candidate channel bytes) and returns the sextant k in 0..6.
+// three candidate channel bytes) and returns the BYTE offset (4*k, k in 0..7) of the sextant's selector
+// in the 8-entry table.
 __device__ __forceinline__ uint32_t to_rgb_fast(const Hsv in, const FastConsts &k, uint32_t &T)
 {
     const float c = in.v * in.s;
+#ifdef MVFX_OLD_SEXT
     const float hp = div60(in.h, k);
     const float f = __builtin_amdgcn_fractf(0.5f * hp);   // P3: fmod(hp,2) == 2*fract(hp/2)
+    const uint32_t sel_off = (uint32_t)__float2uint_rz(hp) << 2;
+#else
+    // hh = RN(h/120) == hp/2 exactly (P11); the sextant comes out of the mantissa of hh + (2^20 - 1/16):
+    // ulp is 1/8 there, so bits 2..4 hold floor(2*hh) = floor(hp) (P12; on integer hp the neighbour it may
+    // name instead yields the same triple, entries 6,7 of the table repeat entry 0)
+    const float hh = fmac_sv(in.h * k.c120lo, k.c120, in.h);
+    const float f = __builtin_amdgcn_fractf(hh);          // P3: fmod(hp,2) == 2*fract(hp/2)
+    const uint32_t sel_off = __float_as_uint(hh + k.sext_magic) & 28u;
+#endif
+#ifdef MVFX_OLD_W
     const float a = __builtin_fmaf(f, 2.0f, -1.0f);       // RN(fmod(hp,2) - 1), 2f exact
     const float x = c * (1.0f - fabsf(a));
+#else
+    // 1 - |RN(2f - 1)| == fma(-2, |f - 0.5|, 1): RN(2f-1) == 2*RN(f-0.5) (scaling by 2 is exact)  (P14)
+    const float x = c * __builtin_fmaf(-2.0f, fabsf(f - 0.5f), 1.0f);
+#endif
     const float m = in.v - c;
     // (p + m) * 255 with p in {c, x, 0}; all lie in [0,255], `as u8` truncates
     const float yc = (c + m) * k.k255, yx = (x + m) * k.k255, y0 = m * k.k255;
     asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD" : "=v"(T) : "v"(yc));
     asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(T) : "v"(yx));
     asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(T) : "v"(y0));
-    return (uint32_t)__float2uint_rz(hp);
+    return sel_off;
+}
+
+__device__ __forceinline__ uint32_t sextant_at(const uint32_t *lut, uint32_t byte_off)
+{
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lut) + byte_off);
 }
 
 // One pixel of hsvfilter from r,g,b = RN(byte/255): candidate dword T and sextant out.
 template <bool NEG_SHIFT>
 __device__ __forceinline__ uint32_t hsvfilter_fast_unit(float r, float g, float b, const FastConsts &k, uint32_t &T)
 {
-    return to_rgb_fast(filter_hsv_fast<NEG_SHIFT>(from_unit_rgb_fast(r, g, b, k), k), k, T);
+    return to_rgb_fast(filter_hsv_fast<NEG_SHIFT>(from_unit_rgb_fast_n(r, g, b, k), k), k, T);
 }
 
 // One pixel of hsvfilter: byte values as floats in, candidate dword T and sextant out.
 template <bool NEG_SHIFT>
 __device__ __forceinline__ uint32_t hsvfilter_fast(float fR, float fG, float fB, const FastConsts &k, uint32_t &T)
 {
-    return to_rgb_fast(filter_hsv_fast<NEG_SHIFT>(from_rgb_fast(fR, fG, fB, k), k), k, T);
+    return to_rgb_fast(filter_hsv_fast<NEG_SHIFT>(from_rgb_fast_n(fR, fG, fB, k), k), k, T);
 }
 
 // hsvdetector/imp.rs:141-155 for finite settings with |ref_hue_offset| <= 360: the `+= 360` and the
 // `% 360` become sign-mask +-360 (P9: x in [-360,720) after one conditional +360 lies in [0,720)),
 // each `|a - ref| <= var` becomes the sign of RN(var - |a - ref|) (exact sign, +0 on equality; the
 // host maps a -0.0 var to +0.0).  Returns 0xffffffff for a MISS and 0 for a hit.
-__device__ __forceinline__ uint32_t detect_miss_mask_fast(const Hsv hsv, const HsvDetectorParams &p)
+__device__ __forceinline__ uint32_t detect_miss_mask_fast(const HsvN hsv, const HsvDetectorParams &p)
 {
     const FastConsts &k = p.consts;
     const float x = hsv.h + p.ref_hue_offset;
-    const float x1 = x + __uint_as_float(sign_mask(x) & k.bits360);
-    const float x2 = x1 - __uint_as_float(sign_mask(k.pred360 - x1) & k.bits360);
+    const float x1 = wrap_up(x, k);
+    const float x2 = wrap_down(x1, k);
     const float d1 = p.hue_var - fabsf(x2 - p.k180);
-    const float d2 = p.saturation_var - fabsf(hsv.s - p.saturation_ref);
+    const float d2 = p.saturation_var - fabsf(hsv.ns + p.saturation_ref); // |s - ref| == |-s + ref|
     const float d3 = p.value_var - fabsf(hsv.v - p.value_ref);
     uint32_t m = __float_as_uint(d1) | __float_as_uint(d2) | __float_as_uint(d3);
     asm("v_ashrrev_i32 %0, 31, %0" : "+v"(m));
     return m;
+}
+
+__device__ __forceinline__ uint32_t detect_miss_mask_fast(const Hsv hsv, const HsvDetectorParams &p)
+{
+    return detect_miss_mask_fast(HsvN{hsv.h, -hsv.s, hsv.v}, p);
 }
 
 // ---------------------------------------------------------------- dispatch helpers
@@ -357,8 +454,8 @@ __device__ __forceinline__ void hsvfilter_pixel(uint32_t &R, uint32_t &G, uint32
         to_rgb_general(filter_hsv_general(from_rgb_general(R, G, B), p), R, G, B);
     } else {
         uint32_t T;
-        const uint32_t sext = hsvfilter_fast<VARIANT == kFastNeg>((float)R, (float)G, (float)B, k, T);
-        const uint32_t rot = __builtin_amdgcn_perm(T, 0u, lut[sext]);
+        const uint32_t sel_off = hsvfilter_fast<VARIANT == kFastNeg>((float)R, (float)G, (float)B, k, T);
+        const uint32_t rot = __builtin_amdgcn_perm(T, 0u, sextant_at(lut, sel_off));
         R = rot & 0xffu;
         G = (rot >> 8) & 0xffu;
         B = (rot >> 16) & 0xffu;

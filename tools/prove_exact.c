@@ -18,6 +18,12 @@
  *  P9  hue wrap by sign masks: for x in [0,720): x >= 360  <=>  signbit(PRED360 - x), PRED360 = 359.99997
  *      (largest float below 360), and the result x - (mask & 360) equals P7's; for x in [-360,360):
  *      signbit(x) ? x + 360 : x equals the reference (x = -0.0 does not occur, see hsv_math.hpp)
+ *  P11 h/120: fma(h, C60/2, h*(C60lo/2)) == 0.5f*(h/60.0f) bit for bit (same domain as P2)
+ *  P12 sextant from the mantissa: (bits(hh + (2^20 - 1/16)) & 28) / 4, hh = h/120, names the same v_perm
+ *      selector as floor(h/60) (entries 6,7 == entry 0; on integer h/60 either neighbour is valid)
+ *  P13 hue wraps as unsigned-integer minima: x in [0,720): fmod(x,360) == min_u32(bits(x-360), bits(x));
+ *      x in [-360,360) \ {-0}: (x<0 ? x+360 : x) == min_u32(bits(x), bits(x+360))
+ *  P14 1 - |fma(f,2,-1)| == fma(-2, |f-0.5|, 1) for every float f in [0,1)
  *  P10 f32::round (half away from zero) of v in [0,65535.5] == truncf(v + PRED_HALF), PRED_HALF = 0.49999997
  *      (largest float below 0.5); used by colorlut's float_to_u8 / float_to_u16
  *  P7  fmodf(x,360) followed by `if <0 {+=360}` == conditional +-360 for every float x in
@@ -198,6 +204,54 @@ int main(void)
         }
         printf("P10 round-half-away == trunc(v + pred(0.5)) over %llu floats in [0,65535.5]: %s (%llu)\n",
                (unsigned long long)n, bad ? "FAIL" : "PASS", (unsigned long long)bad);
+        ok_all &= !bad;
+    }
+    { /* P11 + P12 */
+        const float C60lo = (float)(1.0 / 60.0 - (double)C60);
+        const float C120 = 0.5f * C60, C120lo = 0.5f * C60lo, K = 1048575.9375f;
+        uint64_t bad11 = 0, bad12 = 0;
+        for (uint32_t u = f2u(1e-30f) - 1; u <= f2u(360.0f); u++) {
+            float h = (u == f2u(1e-30f) - 1) ? 0.0f : u2f(u);
+            float hp = h / 60.0f, hh = fmaf(h, C120, h * C120lo);
+            if (f2u(hh) != f2u(0.5f * hp)) bad11++;
+            uint32_t idx = (f2u(hh + K) & 28u) >> 2, k0 = (uint32_t)hp;
+            uint32_t ci = idx >= 6 ? 0 : idx, c0 = k0 >= 6 ? 0 : k0, cm = (k0 == 0 ? 0 : (k0 - 1 >= 6 ? 0 : k0 - 1));
+            int integer = (hp == (float)k0);
+            if (!(ci == c0 || (integer && ci == cm))) bad12++;
+        }
+        printf("P11 2-op h/120 == 0.5*(h/60): %s (%llu);  P12 mantissa sextant: %s (%llu)\n", bad11 ? "FAIL" : "PASS",
+               (unsigned long long)bad11, bad12 ? "FAIL" : "PASS", (unsigned long long)bad12);
+        ok_all &= !bad11 && !bad12;
+    }
+    { /* P13 */
+        uint64_t bad = 0;
+        for (uint32_t u = 0; u <= f2u(720.0f) - 1; u++) { /* x in [0,720) */
+            float x = u2f(u), ref = fmodf(x, 360.0f), y = x - 360.0f;
+            uint32_t m = f2u(y) < f2u(x) ? f2u(y) : f2u(x);
+            if (f2u(ref) != m) bad++;
+            if (u <= f2u(360.0f) - 1) { /* x in [0,360): `if x < 0 { x += 360 }` leaves x */
+                float z = x + 360.0f;
+                uint32_t m2 = f2u(x) < f2u(z) ? f2u(x) : f2u(z);
+                if (m2 != f2u(x)) bad++;
+            }
+        }
+        for (uint32_t u = 1; u <= f2u(360.0f); u++) { /* x in [-360,0), -0.0 excluded */
+            float x = -u2f(u), ref = x + 360.0f;
+            uint32_t m = f2u(x) < f2u(ref) ? f2u(x) : f2u(ref);
+            if (m != f2u(ref)) bad++;
+        }
+        printf("P13 min_u32 hue wraps: %s (%llu mismatches)\n", bad ? "FAIL" : "PASS", (unsigned long long)bad);
+        ok_all &= !bad;
+    }
+    { /* P14 */
+        uint64_t bad = 0;
+        for (uint32_t u = 0; u < f2u(1.0f); u++) {
+            float f = u2f(u);
+            float a = fmaf(f, 2.0f, -1.0f), w0 = 1.0f - fabsf(a);
+            float w1 = fmaf(-2.0f, fabsf(f - 0.5f), 1.0f);
+            if (f2u(w0) != f2u(w1)) bad++;
+        }
+        printf("P14 1-|2f-1| == fma(-2,|f-0.5|,1) on [0,1): %s (%llu mismatches)\n", bad ? "FAIL" : "PASS", (unsigned long long)bad);
         ok_all &= !bad;
     }
     printf("%s\n", ok_all ? "ALL PASS" : "SOME FAILED");
