@@ -71,18 +71,6 @@ __device__ __forceinline__ uint32_t filter_px4(uint32_t px, const FastConsts &k,
         // v_cvt_f32_ubyteN straight from the pixel dword + the exact 2-op divide.  (A 256-entry LDS
         // table of RN(b/255) was measured slower: 3 more random ds_read_b32 per pixel cost more in
         // bank conflicts than the 5 fast VALU ops they replace: 60.3 k vs 68.2 k frames/s.)
-#if defined(MVFX_EXP) && MVFX_EXP == 1 // experiment: memory shape only
-        return px ^ 0x00010203u;
-#elif defined(MVFX_EXP) && MVFX_EXP >= 3 // experiment: the arithmetic applied MVFX_EXP-1 times per pixel
-        for (int rep = 0; rep < MVFX_EXP - 2; rep++) {
-            const float e0 = div255((float)((px >> (8 * OFF)) & 0xffu), k);
-            const float e1 = div255((float)((px >> (8 * OFF + 8)) & 0xffu), k);
-            const float e2 = div255((float)((px >> (8 * OFF + 16)) & 0xffu), k);
-            uint32_t T2;
-            const uint32_t so = hsvfilter_fast_unit<VARIANT == kFastNeg>(BGR ? e2 : e0, e1, BGR ? e0 : e2, k, T2);
-            px = __builtin_amdgcn_perm(T2, px, sextant_at(lds.sextant, so));
-        }
-#endif
         const float c0 = div255((float)((px >> (8 * OFF)) & 0xffu), k);
         const float c1 = div255((float)((px >> (8 * OFF + 8)) & 0xffu), k);
         const float c2 = div255((float)((px >> (8 * OFF + 16)) & 0xffu), k);
@@ -108,10 +96,9 @@ __device__ __forceinline__ void init_filter_lds(FilterLds &lds, int off, bool bg
 template <int OFF, bool BGR, int VARIANT, int MODE>
 __global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint64_t width,
                                                             uint32_t rows, uint64_t stride,
-                                                            FastConsts p_arg)
+                                                            FastConsts p)
 {
     __shared__ FilterLds lds;
-    const FastConsts p = consts_to_vgpr(p_arg);
     // vec4 / dword modes permute straight into the pixel layout; the byte mode uses (off 0, RGB)
     init_filter_lds<VARIANT>(lds, MODE == kModeBytes ? 0 : OFF, MODE == kModeBytes ? false : BGR);
     const uint32_t *lut = lds.sextant;

@@ -51,23 +51,6 @@ struct FastConsts {
     float neg_saturation_mul; // -saturation_mul: from_rgb hands over -s
 };
 
-// Per-thread copy of the constants in VGPRs: a VALU instruction with an SGPR source operand issues at the
-// slow rate on gfx950 (tools/probe_isa3.hip: v_add_f32 v,s,v 37 vs 58 T lane-inst/s for v,v,v)
-__device__ __forceinline__ FastConsts consts_to_vgpr(const FastConsts &k)
-{
-#ifdef MVFX_KCONST_VGPR
-    FastConsts o;
-    const uint32_t *in = reinterpret_cast<const uint32_t *>(&k);
-    uint32_t *out = reinterpret_cast<uint32_t *>(&o);
-#pragma unroll
-    for (unsigned i = 0; i < sizeof(FastConsts) / 4; i++)
-        asm("v_mov_b32 %0, %1" : "=v"(out[i]) : "s"(in[i]));
-    return o;
-#else
-    return k;
-#endif
-}
-
 struct HsvDetectorParams { // hsvdetector/imp.rs:34-42, plus ref_hue_offset = 180 - hue_ref (:141)
     float ref_hue_offset, hue_var, saturation_ref, saturation_var, value_ref, value_var;
     float k180;
@@ -189,15 +172,18 @@ __device__ __forceinline__ uint32_t detect_alpha_general(const Hsv hsv, const Hs
 
 // ---------------------------------------------------------------- FAST (exact reductions)
 //
-// Instruction-class budget (tools/probe_isa2.hip on MI355X, T lane-inst/s): VOP1/VOP2 e32
-// mul/add/sub/fmac/and/or/xor/ashr ~57 ("fast"); the same with a 64-bit encoding (VOP3 modifiers,
-// literal constants) ~43; cndmask/cmp/max/min/med3/cvt/perm/alignbyte/VOP3 fma ~36 ("slow");
-// v_rcp_f32 ~19; v_pk_* f32 ~21 per instruction (slower per element than unpacked).  Hence:
-// constants come in through SGPRs (kernel arguments, struct FastConsts) so the VOP2 forms stay
-// 32-bit, a*b+c is written as v_fmac_f32 where one operand dies, sign tests use
-// v_ashrrev_i32 + v_and_b32 instead of v_cmp + v_cndmask, the [0,1] clamps ride on the VOP3 clamp
-// bit, and the 6-way sextant select of to_rgb is a byte rotation (v_alignbyte_b32) of the three
-// converted channel values instead of 5 compares + 10 selects.
+// What the instruction mix costs on MI355X (tools/probe_isa2..4.hip, tools/hsv_valu_bench.hip,
+// profiles/r1/probe_isa*.txt, hsv_valu_bench_deletions.txt):
+//   * in a homogeneous stream VOP1/VOP2 e32 mul/add/sub/fmac/and/ashr issue at ~2.4 cycles per wave64,
+//     cvt/cmp/cndmask/max/min/fract and anything with an SGPR source at ~3.9, three-VGPR VOP3
+//     (v_fma, v_perm, v_max3) ~3.7, SDWA with a preserved destination ~4.6, v_rcp_f32 ~7.6;
+//   * in the real mix the pixel function averages 3.4 cycles per instruction (rocprofv3: SQ_INSTS_VALU x
+//     cycles), and removing instructions pays ~1.5 % each while changing their class (SGPR -> VGPR
+//     operands, tested) pays nothing: the kernel is bound by instruction COUNT at the sustained clock.
+// Hence: every step below is there to delete instructions -- a*b+c as v_fmac_f32 where one operand
+// dies, the two divides carried negated so that their correction steps are plain v_fmac (quot_neg),
+// hue wraps as add + v_min_u32, the [0,1] clamps on the VOP3 clamp bit, the sextant read out of a
+// float's mantissa, and the 6-way select of to_rgb as one v_perm_b32 through an 8-entry LDS table.
 
 #ifdef MVFX_KCONST_VGPR // experiment knob (tools/hsv_valu_bench.hip): kernel constants held in VGPRs
 #define MVFX_KC "v"
@@ -234,22 +220,14 @@ __device__ __forceinline__ float add_clamp01(float a, float s) // clamp(a + s, 0
 // a non-negative x the smaller one than x + 360  (P13): v_add_f32 + v_min_u32
 __device__ __forceinline__ float wrap_up(float x, const FastConsts &k)
 {
-#ifdef MVFX_OLD_WRAP
-    return x + __uint_as_float(sign_mask(x) & k.bits360);
-#else
     const float y = x + k.k360;
     return __uint_as_float(min(__float_as_uint(x), __float_as_uint(y)));
-#endif
 }
 // fmod(x, 360) for x in [0,720): x - 360 is exact there, negative (larger pattern) iff x < 360  (P13)
 __device__ __forceinline__ float wrap_down(float x, const FastConsts &k)
 {
-#ifdef MVFX_OLD_WRAP
-    return x - __uint_as_float(sign_mask(k.pred360 - x) & k.bits360);
-#else
     const float y = x - k.k360;
     return __uint_as_float(min(__float_as_uint(y), __float_as_uint(x)));
-#endif
 }
 
 // RN(x/255) for integer-valued x in [0,255]: x*C + RN(x*Clo)  (P8)
@@ -362,25 +340,14 @@ __device__ __forceinline__ uint32_t sextant_selector(uint32_t k, int off, bool b
 __device__ __forceinline__ uint32_t to_rgb_fast(const Hsv in, const FastConsts &k, uint32_t &T)
 {
     const float c = in.v * in.s;
-#ifdef MVFX_OLD_SEXT
-    const float hp = div60(in.h, k);
-    const float f = __builtin_amdgcn_fractf(0.5f * hp);   // P3: fmod(hp,2) == 2*fract(hp/2)
-    const uint32_t sel_off = (uint32_t)__float2uint_rz(hp) << 2;
-#else
     // hh = RN(h/120) == hp/2 exactly (P11); the sextant comes out of the mantissa of hh + (2^20 - 1/16):
     // ulp is 1/8 there, so bits 2..4 hold floor(2*hh) = floor(hp) (P12; on integer hp the neighbour it may
     // name instead yields the same triple, entries 6,7 of the table repeat entry 0)
     const float hh = fmac_sv(in.h * k.c120lo, k.c120, in.h);
     const float f = __builtin_amdgcn_fractf(hh);          // P3: fmod(hp,2) == 2*fract(hp/2)
     const uint32_t sel_off = __float_as_uint(hh + k.sext_magic) & 28u;
-#endif
-#ifdef MVFX_OLD_W
-    const float a = __builtin_fmaf(f, 2.0f, -1.0f);       // RN(fmod(hp,2) - 1), 2f exact
-    const float x = c * (1.0f - fabsf(a));
-#else
     // 1 - |RN(2f - 1)| == fma(-2, |f - 0.5|, 1): RN(2f-1) == 2*RN(f-0.5) (scaling by 2 is exact)  (P14)
     const float x = c * __builtin_fmaf(-2.0f, fabsf(f - 0.5f), 1.0f);
-#endif
     const float m = in.v - c;
     // (p + m) * 255 with p in {c, x, 0}; all lie in [0,255], `as u8` truncates
     const float yc = (c + m) * k.k255, yx = (x + m) * k.k255, y0 = m * k.k255;
