@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 30 --warmup 5 --no-cpu-baseline $*"
+ARGS="--steps 500 --warmup 100 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/trace" -o trace -- python3 "$REPO/bench.py" $ARGS > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -f csv -d "$OUT/pmc_sq" -o pmc -- python3 "$REPO/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_sq.err"
 rocprofv3 --pmc FETCH_SIZE -f csv -d "$OUT/pmc_fetch" -o pmc -- python3 "$REPO/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_fetch.err"
