@@ -353,23 +353,35 @@ __device__ __forceinline__ void lf_trilinear(const float4 (&c)[8], float tx, flo
     r = x_out; g = y_out; b = z_out;
 }
 
+// The 24 floats of the cell the lane used last: consecutive pixels of real pictures mostly fall into
+// the same LUT cell (a 33^3 cell spans 8 byte values per axis), and a lane owns 4 (RGBA8) or 2 (RGBA64)
+// consecutive pixels, so the 96-byte gather is skipped (exec-masked off) whenever the cell repeats.
+struct CellCache {
+    uint32_t index = 0xffffffffu;
+    float f[24];
+};
+
 template <bool CELLS, typename CUBE>
 __device__ __forceinline__ void lf_sample_3d(CUBE cube, const float4 *cells, uint32_t size, uint32_t x0, uint32_t y0,
-                                             uint32_t z0, float tx, float ty, float tz, float &r, float &g, float &b)
+                                             uint32_t z0, float tx, float ty, float tz, float &r, float &g, float &b,
+                                             CellCache &cache)
 {
     float4 c[8];
     if constexpr (CELLS) {
         // 96-byte cell: 8 corners x (r,g,b) f32, 3.45 MB for 33^3 (fits one XCD's 4 MiB L2)
-        const float4 *cell = cells + (size_t)(x0 + size * (y0 + size * z0)) * 6;
-        float f[24];
+        const uint32_t index = x0 + size * (y0 + size * z0);
+        if (index != cache.index) {
+            const float4 *cell = cells + (size_t)index * 6;
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const float4 v = cell[i];
-            f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+            for (int i = 0; i < 6; i++) {
+                const float4 v = cell[i];
+                cache.f[4 * i] = v.x; cache.f[4 * i + 1] = v.y; cache.f[4 * i + 2] = v.z; cache.f[4 * i + 3] = v.w;
+            }
+            cache.index = index;
         }
 #pragma unroll
         for (int i = 0; i < 8; i++)
-            c[i] = make_float4(f[3 * i], f[3 * i + 1], f[3 * i + 2], 0.0f);
+            c[i] = make_float4(cache.f[3 * i], cache.f[3 * i + 1], cache.f[3 * i + 2], 0.0f);
     } else {
         const uint32_t m = size - 1;
         const uint32_t x1 = min(x0 + 1, m), y1 = min(y0 + 1, m), z1 = min(z0 + 1, m);
@@ -384,8 +396,11 @@ __device__ __forceinline__ void lf_sample_3d(CUBE cube, const float4 *cells, uin
 // RGBA8 pixel: converted channels are written into bytes 0..2 of the pixel register in place, so
 // the alpha byte is carried over without a merge instruction.
 template <bool IS3D, bool CELLS, typename CUBE, typename TABLE>
-__device__ __forceinline__ uint32_t lf_px8(uint32_t px, const LutParams &p, CUBE cube, TABLE t0, TABLE t1, TABLE t2)
+__device__ __forceinline__ uint32_t lf_px8(uint32_t px, const LutParams &p, CUBE cube, TABLE t0, TABLE t1, TABLE t2,
+                                           CellCache &cache)
 {
+    // (a 3 x 256 LDS table of the per-byte (index, fraction) pairs was measured SLOWER than these 27 VALU
+    // instructions: 31.5 k vs 36.2 k frames/s on the smpte frame -- random ds_read_b64 bank conflicts)
     uint32_t ix, iy, iz;
     float tx, ty, tz;
     lf_coord((float)(px & 0xffu), p.fast, p.scale[0], p.offset[0], p.size_m1, ix, tx);
@@ -393,7 +408,7 @@ __device__ __forceinline__ uint32_t lf_px8(uint32_t px, const LutParams &p, CUBE
     lf_coord((float)((px >> 16) & 0xffu), p.fast, p.scale[2], p.offset[2], p.size_m1, iz, tz);
     float r, g, b;
     if constexpr (IS3D) {
-        lf_sample_3d<CELLS>(cube, p.cells, p.size, ix, iy, iz, tx, ty, tz, r, g, b);
+        lf_sample_3d<CELLS>(cube, p.cells, p.size, ix, iy, iz, tx, ty, tz, r, g, b, cache);
     } else {
         const uint32_t m = p.size - 1;
         const float a0 = t0[ix], b0 = t0[min(ix + 1, m)], a1 = t1[iy], b1 = t1[min(iy + 1, m)], a2 = t2[iz], b2 = t2[min(iz + 1, m)];
@@ -410,7 +425,8 @@ __device__ __forceinline__ uint32_t lf_px8(uint32_t px, const LutParams &p, CUBE
 }
 
 template <bool IS3D, bool CELLS, bool LE, typename CUBE, typename TABLE>
-__device__ __forceinline__ void lf_px16(uint32_t &w0, uint32_t &w1, const LutParams &p, CUBE cube, TABLE t0, TABLE t1, TABLE t2)
+__device__ __forceinline__ void lf_px16(uint32_t &w0, uint32_t &w1, const LutParams &p, CUBE cube, TABLE t0, TABLE t1, TABLE t2,
+                                        CellCache &cache)
 {
     uint32_t rv = w0 & 0xffffu, gv = w0 >> 16, bv = w1 & 0xffffu;
     if constexpr (!LE) { rv = bswap16(rv); gv = bswap16(gv); bv = bswap16(bv); }
@@ -421,7 +437,7 @@ __device__ __forceinline__ void lf_px16(uint32_t &w0, uint32_t &w1, const LutPar
     lf_coord((float)bv, p.fast, p.scale[2], p.offset[2], p.size_m1, iz, tz);
     float r, g, b;
     if constexpr (IS3D) {
-        lf_sample_3d<CELLS>(cube, p.cells, p.size, ix, iy, iz, tx, ty, tz, r, g, b);
+        lf_sample_3d<CELLS>(cube, p.cells, p.size, ix, iy, iz, tx, ty, tz, r, g, b, cache);
     } else {
         const uint32_t m = p.size - 1;
         const float a0 = t0[ix], b0 = t0[min(ix + 1, m)], a1 = t1[iy], b1 = t1[min(iy + 1, m)], a2 = t2[iz], b2 = t2[min(iz + 1, m)];
@@ -445,6 +461,7 @@ __device__ __forceinline__ void lf_rows(const uint8_t *in, uint8_t *out, uint64_
 {
     constexpr uint32_t PXV = WIDE ? 2 : 4;
     constexpr uint32_t BPP = WIDE ? 8 : 4;
+    CellCache cache;
     for (uint32_t row = first_row; row < rows; row += row_stride) {
         const uint8_t *iline = in + (uint64_t)row * in_stride;
         uint8_t *oline = out + (uint64_t)row * out_stride;
@@ -454,13 +471,13 @@ __device__ __forceinline__ void lf_rows(const uint8_t *in, uint8_t *out, uint64_
             if (x + PXV <= width) {
                 uint4 v = *reinterpret_cast<const uint4 *>(iline + x * BPP);
                 if constexpr (WIDE) {
-                    lf_px16<IS3D, CELLS, LE>(v.x, v.y, p, cube, t0, t1, t2);
-                    lf_px16<IS3D, CELLS, LE>(v.z, v.w, p, cube, t0, t1, t2);
+                    lf_px16<IS3D, CELLS, LE>(v.x, v.y, p, cube, t0, t1, t2, cache);
+                    lf_px16<IS3D, CELLS, LE>(v.z, v.w, p, cube, t0, t1, t2, cache);
                 } else {
-                    v.x = lf_px8<IS3D, CELLS>(v.x, p, cube, t0, t1, t2);
-                    v.y = lf_px8<IS3D, CELLS>(v.y, p, cube, t0, t1, t2);
-                    v.z = lf_px8<IS3D, CELLS>(v.z, p, cube, t0, t1, t2);
-                    v.w = lf_px8<IS3D, CELLS>(v.w, p, cube, t0, t1, t2);
+                    v.x = lf_px8<IS3D, CELLS>(v.x, p, cube, t0, t1, t2, cache);
+                    v.y = lf_px8<IS3D, CELLS>(v.y, p, cube, t0, t1, t2, cache);
+                    v.z = lf_px8<IS3D, CELLS>(v.z, p, cube, t0, t1, t2, cache);
+                    v.w = lf_px8<IS3D, CELLS>(v.w, p, cube, t0, t1, t2, cache);
                 }
                 *reinterpret_cast<uint4 *>(oline + x * BPP) = v;
             } else {
@@ -469,10 +486,10 @@ __device__ __forceinline__ void lf_rows(const uint8_t *in, uint8_t *out, uint64_
                     uint32_t *o = reinterpret_cast<uint32_t *>(oline + xx * BPP);
                     if constexpr (WIDE) {
                         uint32_t w0 = q[0], w1 = q[1];
-                        lf_px16<IS3D, CELLS, LE>(w0, w1, p, cube, t0, t1, t2);
+                        lf_px16<IS3D, CELLS, LE>(w0, w1, p, cube, t0, t1, t2, cache);
                         o[0] = w0; o[1] = w1;
                     } else {
-                        o[0] = lf_px8<IS3D, CELLS>(q[0], p, cube, t0, t1, t2);
+                        o[0] = lf_px8<IS3D, CELLS>(q[0], p, cube, t0, t1, t2, cache);
                     }
                 }
             }

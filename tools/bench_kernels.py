@@ -25,9 +25,18 @@ sptr = ctypes.c_void_p(stream.cuda_stream)
 PEAK = 8000.0
 
 
-def timeit(fn, iters=20, warm=3):
+def timeit(fn, iters=300, warm=3, settle_s=0.4):
+    """Steady clock state first (the governor needs ~0.2 s of load, profiles/r1/exp_ramp_launch_series.txt)."""
+    import time
     for _ in range(warm):
         fn()
+    t = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t < settle_s:
+        for _ in range(20):
+            fn(k)
+            k += 1
+        torch.cuda.synchronize()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
@@ -51,6 +60,21 @@ def report(name, ms, bytes_per_call, frames_per_call, extra=None):
     if extra:
         o.update(extra)
     print(json.dumps(o), flush=True)
+
+
+def natural_like_gpu(n, w, h, seed):
+    """Smooth 2-D colour gradients + sensor-like noise of +-3 codes: neighbouring pixels mostly share a LUT cell."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    x = torch.linspace(0, 1, w, device=dev).view(1, 1, w)
+    y = torch.linspace(0, 1, h, device=dev).view(1, h, 1)
+    ph = torch.rand((n, 1, 1), device=dev, generator=g) * 6.28
+    r = 0.5 + 0.45 * torch.sin(3.0 * x + 2.0 * y + ph)
+    gch = 0.5 + 0.45 * torch.sin(5.0 * y - 1.5 * x + 2 * ph)
+    b = 0.5 + 0.45 * torch.cos(4.0 * x * y + ph)
+    img = torch.stack([r.expand(n, h, w), gch.expand(n, h, w), b.expand(n, h, w), torch.ones((n, h, w), device=dev)], dim=-1) * 255.0
+    img = img + torch.randint(-3, 4, img.shape, device=dev, generator=g).float() * torch.tensor([1, 1, 1, 0], device=dev)
+    return img.clamp(0, 255).to(torch.uint8).view(n, -1).contiguous()
 
 
 def smpte_like_gpu(n, w, h):
@@ -78,7 +102,7 @@ def main():
             ms = timeit(lambda i=0: vfx.check(lib.mvfx_hsvfilter_transform_frames_ip(arr, POOL, ctypes.byref(s), sptr)))
             report(f"hsvfilter {fmt} 4K batch16", ms, POOL * 2 * NB, POOL)
             one = [(vfx.Frame * 1)(vfx.make_frame(p, W, H, W * 4, fmt)) for p in ptrs]
-            ms = timeit(lambda i=0: vfx.check(lib.mvfx_hsvfilter_transform_frames_ip(one[i % POOL], 1, ctypes.byref(s), sptr)), iters=64)
+            ms = timeit(lambda i=0: vfx.check(lib.mvfx_hsvfilter_transform_frames_ip(one[i % POOL], 1, ctypes.byref(s), sptr)), iters=300)
             report(f"hsvfilter {fmt} 4K single-frame launches", ms, 2 * NB, 1)
         fr = rand_frames(POOL, W * H * 3, 2)
         arr = (vfx.Frame * POOL)(*[vfx.make_frame(fr[i].data_ptr(), W, H, W * 3, "RGB") for i in range(POOL)])
@@ -93,26 +117,26 @@ def main():
         s = vfx.HsvDetectorSettings(120.0, 40.0, 0.6, 0.4, 0.6, 0.4)
         fi = [vfx.make_frame(src[i].data_ptr(), W2, H2, W2 * 4, "RGBx") for i in range(n)]
         fo = [vfx.make_frame(dst[i].data_ptr(), W2, H2, W2 * 4, "RGBA") for i in range(n)]
-        ms = timeit(lambda i=0: vfx.check(lib.mvfx_hsvdetector_transform_frame(ctypes.byref(fi[i % n]), ctypes.byref(fo[i % n]), ctypes.byref(s), sptr)), iters=128)
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_hsvdetector_transform_frame(ctypes.byref(fi[i % n]), ctypes.byref(fo[i % n]), ctypes.byref(s), sptr)), iters=300)
         report("hsvdetector RGBx->RGBA 1080p", ms, 2 * W2 * H2 * 4, 1)
         src = rand_frames(POOL, NB, 4)
         dst = torch.empty_like(src)
         fi = [vfx.make_frame(src[i].data_ptr(), W, H, W * 4, "RGBx") for i in range(POOL)]
         fo = [vfx.make_frame(dst[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
-        ms = timeit(lambda i=0: vfx.check(lib.mvfx_hsvdetector_transform_frame(ctypes.byref(fi[i % POOL]), ctypes.byref(fo[i % POOL]), ctypes.byref(s), sptr)), iters=64)
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_hsvdetector_transform_frame(ctypes.byref(fi[i % POOL]), ctypes.byref(fo[i % POOL]), ctypes.byref(s), sptr)), iters=300)
         report("hsvdetector RGBx->RGBA 4K", ms, 2 * NB, 1)
 
     if want("colorlut"):
         for size in (33, 17):
             lut = vfx.CubeLut(cubes.analytic_3d(size))
-            for data in ("random", "smpte"):
-                src = rand_frames(POOL, NB, 5) if data == "random" else smpte_like_gpu(POOL, W, H)
+            for data in ("random", "smpte", "natural"):
+                src = rand_frames(POOL, NB, 5) if data == "random" else (smpte_like_gpu(POOL, W, H) if data == "smpte" else natural_like_gpu(POOL, W, H, 11))
                 dst = torch.empty_like(src)
                 fi = [vfx.make_frame(src[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
                 fo = [vfx.make_frame(dst[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
                 for placement in ((0, 1) if size <= 21 else (0,)):
                     vfx.check(lib.mvfx_colorlut_set_placement(placement))
-                    ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fi[i % POOL]), ctypes.byref(fo[i % POOL]), sptr)), iters=32)
+                    ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fi[i % POOL]), ctypes.byref(fo[i % POOL]), sptr)), iters=300)
                     report(f"colorlut 3D {size}^3 RGBA 4K {data} placement={'auto' if placement == 0 else 'global'}", ms, 2 * NB, 1)
                 vfx.check(lib.mvfx_colorlut_set_placement(0))
         lut = vfx.CubeLut(cubes.curve_1d(1024))
@@ -120,14 +144,14 @@ def main():
         dst = torch.empty_like(src)
         fi = [vfx.make_frame(src[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
         fo = [vfx.make_frame(dst[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
-        ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fi[i % POOL]), ctypes.byref(fo[i % POOL]), sptr)), iters=32)
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fi[i % POOL]), ctypes.byref(fo[i % POOL]), sptr)), iters=300)
         report("colorlut 1D 1024 RGBA 4K random", ms, 2 * NB, 1)
         lut = vfx.CubeLut(cubes.analytic_3d(33))
         src = rand_frames(8, NB * 2, 7)
         dst = torch.empty_like(src)
         fi = [vfx.make_frame(src[i].data_ptr(), W, H, W * 8, "RGBA64_LE") for i in range(8)]
         fo = [vfx.make_frame(dst[i].data_ptr(), W, H, W * 8, "RGBA64_LE") for i in range(8)]
-        ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fi[i % 8]), ctypes.byref(fo[i % 8]), sptr)), iters=16)
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fi[i % 8]), ctypes.byref(fo[i % 8]), sptr)), iters=300)
         report("colorlut 3D 33^3 RGBA64_LE 4K random", ms, 4 * NB, 1)
 
     if want("colordetect"):
@@ -136,7 +160,7 @@ def main():
         fr = [vfx.make_frame(src[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
         for q in (10, 1):
             ms = timeit(lambda i=0: vfx.check(lib.mvfx_colordetect_histogram(ctypes.byref(fr[i % POOL]), q, 0, vfx.ALL_SAMPLES,
-                        ctypes.c_void_p(hist.data_ptr()), ctypes.c_void_p(hist.data_ptr() + 32768 * 4), sptr)), iters=32)
+                        ctypes.c_void_p(hist.data_ptr()), ctypes.c_void_p(hist.data_ptr() + 32768 * 4), sptr)), iters=300)
             report(f"colordetect histogram 4K RGBA quality={q}", ms, NB, 1)
 
     if want("blockhash"):
@@ -144,16 +168,16 @@ def main():
         src = rand_frames(4, W8 * H8 * 4, 10)
         sums = torch.zeros(64, dtype=torch.int32, device=dev)
         fr = [vfx.make_frame(src[i].data_ptr(), W8, H8, W8 * 4, "RGBA") for i in range(4)]
-        ms = timeit(lambda i=0: vfx.check(lib.mvfx_blockhash_sums(ctypes.byref(fr[i % 4]), 0, H8, ctypes.c_void_p(sums.data_ptr()), sptr)), iters=16)
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_blockhash_sums(ctypes.byref(fr[i % 4]), 0, H8, ctypes.c_void_p(sums.data_ptr()), sptr)), iters=300)
         report("blockhash sums 8K RGBA (one frame)", ms, W8 * H8 * 4, 1)
         src4 = rand_frames(POOL, NB, 11)
         fr = [vfx.make_frame(src4[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
-        ms = timeit(lambda i=0: vfx.check(lib.mvfx_blockhash_sums(ctypes.byref(fr[i % POOL]), 0, H, ctypes.c_void_p(sums.data_ptr()), sptr)), iters=32)
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_blockhash_sums(ctypes.byref(fr[i % POOL]), 0, H, ctypes.c_void_p(sums.data_ptr()), sptr)), iters=300)
         report("blockhash sums 4K RGBA", ms, NB, 1)
 
     if want("roundedcorners"):
         mask = torch.empty(W * H, dtype=torch.uint8, device=dev)
-        ms = timeit(lambda i=0: vfx.check(lib.mvfx_roundedcorners_mask(ctypes.c_void_p(mask.data_ptr()), W, H, W, 100, sptr)), iters=32)
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_roundedcorners_mask(ctypes.c_void_p(mask.data_ptr()), W, H, W, 100, sptr)), iters=300)
         report("roundedcorners mask 4K r=100 (once per config)", ms, W * H, 1)
         i420 = rand_frames(POOL, W * H * 3 // 2, 12)
         a420 = torch.empty((POOL, W * H * 5 // 2), dtype=torch.uint8, device=dev)
@@ -171,14 +195,14 @@ def main():
             fi.height = fo.height = H
             fi.format, fo.format = vfx.FORMATS["I420"], vfx.FORMATS["A420"]
             vfx.check(lib.mvfx_roundedcorners_compose_a420(ctypes.byref(fi), ctypes.c_void_p(mask.data_ptr()), W, ctypes.byref(fo), sptr))
-        ms = timeit(compose, iters=32)
+        ms = timeit(compose, iters=300)
         report("roundedcorners I420->A420 compose 4K", ms, W * H * 4, 1)
 
     # d2d copy ceiling measured on this box (SURVEY 8d asks for it next to the 8 TB/s spec)
     if want("copy"):
         a = rand_frames(POOL, NB, 8)
         b = torch.empty_like(a)
-        ms = timeit(lambda i=0: b.copy_(a), iters=10)
+        ms = timeit(lambda i=0: b.copy_(a), iters=300)
         report("torch d2d copy 531 MB", ms, 2 * POOL * NB, POOL)
 
 
