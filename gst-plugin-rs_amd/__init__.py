@@ -102,6 +102,7 @@ SIGNATURES = {
     "mvfx_hsvfilter_transform_frame_ip_host": (c_int, [POINTER(Frame), POINTER(HsvFilterSettings)]),
     "mvfx_hsvfilter_set_variant": (c_int, [c_int]),
     "mvfx_hsvdetector_transform_frame": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(HsvDetectorSettings), c_void_p]),
+    "mvfx_hsvdetector_transform_frames": (c_int, [POINTER(Frame), POINTER(Frame), c_uint32, POINTER(HsvDetectorSettings), c_void_p]),
     "mvfx_hsvdetector_transform_frame_host": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(HsvDetectorSettings)]),
     "mvfx_hsv_from_frame": (c_int, [POINTER(Frame), c_void_p, c_void_p]),
     "mvfx_cube_lut_parse": (c_int, [c_char_p, c_size_t, POINTER(c_void_p)]),

@@ -264,12 +264,14 @@ __device__ __forceinline__ uint32_t detect_px4_fast(uint32_t px, const HsvDetect
 }
 
 template <int IN_BPP, int IN_OFF, bool IN_BGR, bool OUT_A0, bool OUT_BGR, int VARIANT, int MODE>
-__global__ __launch_bounds__(kBlock) void hsvdetector_kernel(const uint8_t *in, uint8_t *out,
+__global__ __launch_bounds__(kBlock) void hsvdetector_kernel(FrameBatch in_fb, FrameBatch out_fb,
                                                              uint64_t width, uint32_t rows,
                                                              uint64_t in_stride,
                                                              uint64_t out_stride,
                                                              HsvDetectorParams p)
 {
+    const uint8_t *in = in_fb.base[blockIdx.z]; // one frame pair of the batch per grid z
+    uint8_t *out = out_fb.base[blockIdx.z];
     for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
         const uint8_t *iline = in + (uint64_t)row * in_stride;
         uint8_t *oline = out + (uint64_t)row * out_stride;
@@ -559,8 +561,8 @@ int detect_out_layout(int format, bool *a0, bool *bgr)
 }
 
 template <int IN_BPP, int IN_OFF, bool IN_BGR, int VARIANT, int MODE>
-void launch_detect_out(bool a0, bool obgr, dim3 grid, hipStream_t stream, const uint8_t *in,
-                       uint8_t *out, uint64_t width, uint32_t rows, uint64_t is, uint64_t os,
+void launch_detect_out(bool a0, bool obgr, dim3 grid, hipStream_t stream, const FrameBatch &in,
+                       const FrameBatch &out, uint64_t width, uint32_t rows, uint64_t is, uint64_t os,
                        const HsvDetectorParams &p)
 {
 #define MVFX_LD(A, B) \
@@ -572,7 +574,7 @@ void launch_detect_out(bool a0, bool obgr, dim3 grid, hipStream_t stream, const 
 
 template <int VARIANT, int MODE>
 void launch_detect(int bpp, int off, bool ibgr, bool a0, bool obgr, dim3 grid, hipStream_t stream,
-                   const uint8_t *in, uint8_t *out, uint64_t width, uint32_t rows, uint64_t is,
+                   const FrameBatch &in, const FrameBatch &out, uint64_t width, uint32_t rows, uint64_t is,
                    uint64_t os, const HsvDetectorParams &p)
 {
 #define MVFX_ARGS a0, obgr, grid, stream, in, out, width, rows, is, os, p
@@ -585,24 +587,40 @@ void launch_detect(int bpp, int off, bool ibgr, bool a0, bool obgr, dim3 grid, h
 #undef MVFX_ARGS
 }
 
-int hsvdetector_impl(const mvfx_frame *in, const mvfx_frame *out,
-                     const mvfx_hsvdetector_settings *s, hipStream_t stream)
+// One frame pair of a batch: formats, sizes, the reference's asserts.
+int check_detect_pair(const mvfx_frame *in, const mvfx_frame *out, int *bpp, int *off, bool *ibgr, bool *a0, bool *obgr)
 {
-    if (!in || !out || !s)
-        return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvdetector: NULL frame or settings");
-    int bpp, off;
-    bool ibgr, a0, obgr;
-    if (detect_in_layout(in->format, &bpp, &off, &ibgr) != 0)
+    if (detect_in_layout(in->format, bpp, off, ibgr) != 0)
         return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "hsvdetector: input format %d not in RGBx xRGB BGRx xBGR RGB BGR (hsvdetector/imp.rs:78-87)", in->format);
-    if (detect_out_layout(out->format, &a0, &obgr) != 0)
+    if (detect_out_layout(out->format, a0, obgr) != 0)
         return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "hsvdetector: output format %d not in RGBA ARGB BGRA ABGR (hsvdetector/imp.rs:89-96)", out->format);
     if (int rc = check_packed_frame(in, "hsvdetector input"); rc != MVFX_OK) return rc;
     if (int rc = check_packed_frame(out, "hsvdetector output"); rc != MVFX_OK) return rc;
     if (in->width != out->width || in->height != out->height)
         return fail(MVFX_ERR_NOT_NEGOTIATED, "hsvdetector: input %ux%u and output %ux%u differ (assert_eq! hsvdetector/imp.rs:121)",
                     in->width, in->height, out->width, out->height);
-    if (((uint64_t)in->stride * in->height) % (uint64_t)bpp != 0)
-        return fail(MVFX_ERR_REFERENCE_PANIC, "hsvdetector: input plane size is not a multiple of %d bytes per pixel; the reference asserts on this (hsvdetector/imp.rs:122)", bpp);
+    if (((uint64_t)in->stride * in->height) % (uint64_t)*bpp != 0)
+        return fail(MVFX_ERR_REFERENCE_PANIC, "hsvdetector: input plane size is not a multiple of %d bytes per pixel; the reference asserts on this (hsvdetector/imp.rs:122)", *bpp);
+    return MVFX_OK;
+}
+
+// n frame pairs sharing geometry and formats (n == 1: the reference's transform_frame); <= kMaxBatch per launch.
+int hsvdetector_impl(const mvfx_frame *ins, const mvfx_frame *outs, uint32_t n,
+                     const mvfx_hsvdetector_settings *s, hipStream_t stream)
+{
+    if (!ins || !outs || !s || n == 0)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvdetector: NULL frame/settings or empty batch");
+    const mvfx_frame *in = &ins[0], *out = &outs[0];
+    int bpp, off;
+    bool ibgr, a0, obgr;
+    if (int rc = check_detect_pair(in, out, &bpp, &off, &ibgr, &a0, &obgr); rc != MVFX_OK) return rc;
+    for (uint32_t i = 1; i < n; i++) {
+        if (ins[i].width != in->width || ins[i].height != in->height || ins[i].stride != in->stride || ins[i].format != in->format ||
+            outs[i].width != out->width || outs[i].height != out->height || outs[i].stride != out->stride || outs[i].format != out->format)
+            return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvdetector: frames of one batch must share geometry and formats");
+        if (int rc = check_packed_frame(&ins[i], "hsvdetector input"); rc != MVFX_OK) return rc;
+        if (int rc = check_packed_frame(&outs[i], "hsvdetector output"); rc != MVFX_OK) return rc;
+    }
     if (int rc = require_device(); rc != MVFX_OK)
         return rc;
     if (in->width == 0 || in->height == 0)
@@ -615,38 +633,47 @@ int hsvdetector_impl(const mvfx_frame *in, const mvfx_frame *out,
     const float dv[6] = {s->hue_ref, s->hue_var, s->saturation_ref, s->saturation_var, s->value_ref, s->value_var};
     bool det_fast_ok = std::fabs(p.ref_hue_offset) <= 360.0f;
     for (float f : dv) det_fast_ok = det_fast_ok && std::isfinite(f);
-    const uint64_t in_need = bpp == 4 ? 15 : 3;
-    const bool flat = (uint64_t)in->width * bpp == in->stride && (uint64_t)out->width * 4 == out->stride;
-    uint64_t width = in->width, is = in->stride, os = out->stride;
-    uint32_t rows = in->height;
-    uint64_t in_or = (uint64_t)(uintptr_t)in->data, out_or = (uint64_t)(uintptr_t)out->data;
-    if (flat) {
-        width = (uint64_t)in->width * in->height; rows = 1; is = 0; os = 0;
-    } else {
-        in_or |= is; out_or |= os;
-    }
-    const bool vec = (in_or & in_need) == 0 && (out_or & 15) == 0;
-    const uint64_t work = vec ? (width + 3) / 4 : width;
-    uint64_t bx = (work + kBlock - 1) / kBlock;
-    if (bx > 65535u * 16u) bx = 65535u * 16u;
-    const dim3 grid((uint32_t)bx, rows < 65535u ? rows : 65535u, 1);
-    const uint8_t *ip = static_cast<const uint8_t *>(in->data);
-    uint8_t *op = static_cast<uint8_t *>(out->data);
     // from_rgb's FAST form is settings-independent, so it is always valid here; the hue test has
     // its own domain (det_fast_ok).  g_variant: 0 auto, 1 everything literal, 2 force both fast.
     if (g_variant == 2 && !det_fast_ok)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvdetector: settings are outside the proven domain of the strength-reduced hue test");
     const int variant = g_variant == 1 ? kGeneral : (det_fast_ok ? kDetFast : kFast);
-    if (vec) {
-        if (variant == kDetFast) launch_detect<kDetFast, kModeVec4>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
-        else if (variant == kFast) launch_detect<kFast, kModeVec4>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
-        else launch_detect<kGeneral, kModeVec4>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
-    } else {
-        if (variant == kDetFast) launch_detect<kDetFast, kModeBytes>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
-        else if (variant == kFast) launch_detect<kFast, kModeBytes>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
-        else launch_detect<kGeneral, kModeBytes>(bpp, off, ibgr, a0, obgr, grid, stream, ip, op, width, rows, is, os, p);
+    const uint64_t in_need = bpp == 4 ? 15 : 3;
+    const bool flat = (uint64_t)in->width * bpp == in->stride && (uint64_t)out->width * 4 == out->stride;
+
+    for (uint32_t done = 0; done < n; done += kMaxBatch) {
+        const uint32_t m = (n - done) < (uint32_t)kMaxBatch ? (n - done) : (uint32_t)kMaxBatch;
+        FrameBatch ifb{}, ofb{};
+        uint64_t in_or = 0, out_or = 0;
+        for (uint32_t i = 0; i < m; i++) {
+            ifb.base[i] = static_cast<uint8_t *>(ins[done + i].data);
+            ofb.base[i] = static_cast<uint8_t *>(outs[done + i].data);
+            in_or |= (uint64_t)(uintptr_t)ins[done + i].data;
+            out_or |= (uint64_t)(uintptr_t)outs[done + i].data;
+        }
+        uint64_t width = in->width, is = in->stride, os = out->stride;
+        uint32_t rows = in->height;
+        if (flat) {
+            width = (uint64_t)in->width * in->height; rows = 1; is = 0; os = 0;
+        } else {
+            in_or |= is; out_or |= os;
+        }
+        const bool vec = (in_or & in_need) == 0 && (out_or & 15) == 0;
+        const uint64_t work = vec ? (width + 3) / 4 : width;
+        uint64_t bx = (work + kBlock - 1) / kBlock;
+        if (bx > 65535u * 16u) bx = 65535u * 16u;
+        const dim3 grid((uint32_t)bx, rows < 65535u ? rows : 65535u, m);
+        if (vec) {
+            if (variant == kDetFast) launch_detect<kDetFast, kModeVec4>(bpp, off, ibgr, a0, obgr, grid, stream, ifb, ofb, width, rows, is, os, p);
+            else if (variant == kFast) launch_detect<kFast, kModeVec4>(bpp, off, ibgr, a0, obgr, grid, stream, ifb, ofb, width, rows, is, os, p);
+            else launch_detect<kGeneral, kModeVec4>(bpp, off, ibgr, a0, obgr, grid, stream, ifb, ofb, width, rows, is, os, p);
+        } else {
+            if (variant == kDetFast) launch_detect<kDetFast, kModeBytes>(bpp, off, ibgr, a0, obgr, grid, stream, ifb, ofb, width, rows, is, os, p);
+            else if (variant == kFast) launch_detect<kFast, kModeBytes>(bpp, off, ibgr, a0, obgr, grid, stream, ifb, ofb, width, rows, is, os, p);
+            else launch_detect<kGeneral, kModeBytes>(bpp, off, ibgr, a0, obgr, grid, stream, ifb, ofb, width, rows, is, os, p);
+        }
+        MVFX_HIP_TRY(hipGetLastError());
     }
-    MVFX_HIP_TRY(hipGetLastError());
     return MVFX_OK;
 }
 
@@ -701,7 +728,13 @@ int mvfx_hsvfilter_transform_frame_ip_host(const mvfx_frame *frame, const mvfx_h
 int mvfx_hsvdetector_transform_frame(const mvfx_frame *in_frame, const mvfx_frame *out_frame,
                                      const mvfx_hsvdetector_settings *settings, mvfx_stream stream)
 {
-    return hsvdetector_impl(in_frame, out_frame, settings, as_stream(stream));
+    return hsvdetector_impl(in_frame, out_frame, 1, settings, as_stream(stream));
+}
+
+int mvfx_hsvdetector_transform_frames(const mvfx_frame *in_frames, const mvfx_frame *out_frames, uint32_t n_frames,
+                                      const mvfx_hsvdetector_settings *settings, mvfx_stream stream)
+{
+    return hsvdetector_impl(in_frames, out_frames, n_frames, settings, as_stream(stream));
 }
 
 int mvfx_hsvdetector_transform_frame_host(const mvfx_frame *in_frame, const mvfx_frame *out_frame,
@@ -715,7 +748,7 @@ int mvfx_hsvdetector_transform_frame_host(const mvfx_frame *in_frame, const mvfx
     const size_t ib = (size_t)in_frame->stride * in_frame->height;
     const size_t ob = (size_t)out_frame->stride * out_frame->height;
     if (ib == 0 || ob == 0)
-        return hsvdetector_impl(in_frame, out_frame, settings, nullptr);
+        return hsvdetector_impl(in_frame, out_frame, 1, settings, nullptr);
     void *din = nullptr, *dout = nullptr;
     if (int rc = host_scratch(ib, 0, &din); rc != MVFX_OK) return rc;
     if (int rc = host_scratch(ob, 1, &dout); rc != MVFX_OK) return rc;
@@ -727,7 +760,7 @@ int mvfx_hsvdetector_transform_frame_host(const mvfx_frame *in_frame, const mvfx
     mvfx_frame di = *in_frame, dof = *out_frame;
     di.data = din;
     dof.data = dout;
-    if (int rc = hsvdetector_impl(&di, &dof, settings, st); rc != MVFX_OK) return rc;
+    if (int rc = hsvdetector_impl(&di, &dof, 1, settings, st); rc != MVFX_OK) return rc;
     MVFX_HIP_TRY(hipMemcpyAsync(out_frame->data, dout, ob, hipMemcpyDeviceToHost, st));
     MVFX_HIP_TRY(hipStreamSynchronize(st));
     return MVFX_OK;

@@ -155,6 +155,12 @@ typedef struct mvfx_hsvdetector_settings {
 int mvfx_hsvdetector_transform_frame(const mvfx_frame *in_frame, const mvfx_frame *out_frame,
                                      const mvfx_hsvdetector_settings *settings,
                                      mvfx_stream stream);
+/* n_frames independent streams in one launch (frame i of in_frames -> frame i of out_frames; all
+ * pairs share geometry and formats; <= 32 pairs per launch, more are split).  One 1080p frame is
+ * only ~6 us of GPU work, so single-frame launches are launch-bound; this is the multi-stream form. */
+int mvfx_hsvdetector_transform_frames(const mvfx_frame *in_frames, const mvfx_frame *out_frames,
+                                      uint32_t n_frames, const mvfx_hsvdetector_settings *settings,
+                                      mvfx_stream stream);
 int mvfx_hsvdetector_transform_frame_host(const mvfx_frame *in_frame, const mvfx_frame *out_frame,
                                           const mvfx_hsvdetector_settings *settings);
 

@@ -281,6 +281,32 @@ def test_hsvdetector_exhaustive(gpu, exhaustive, settings, variant):
         assert got[:, 3::4].max() == 255 or settings[0] > 1e5  # (a hue_ref far below -180 never matches: one +360 only)
 
 
+@pytest.mark.parametrize("in_fmt,bpp,out_fmt,w,h,stride_pad", [("RGBx", 4, "RGBA", 256, 64, 0), ("BGR", 3, "ABGR", 101, 37, 6),
+                                                               ("xBGR", 4, "BGRA", 320, 48, 16)])
+def test_hsvdetector_batch_matches_single(gpu, in_fmt, bpp, out_fmt, w, h, stride_pad):
+    """mvfx_hsvdetector_transform_frames == N single-frame calls (33 pairs cross the 32-pair launch split);
+    padded / unaligned layouts take the byte path, the row padding of the outputs stays untouched."""
+    n = 33
+    istride, ostride = w * bpp + stride_pad, w * 4 + stride_pad
+    ins = [frames.random_frame(0x5EED0200 + k, w, h, bpp, istride) for k in range(n)]
+    outs0 = [frames.random_frame(0x5EED0300 + k, w, h, 4, ostride) for k in range(n)]
+    din = [gpu.DeviceBuffer(f.nbytes).upload(f) for f in ins]
+    dout = [gpu.DeviceBuffer(f.nbytes).upload(f) for f in outs0]
+    fi = (gpu.Frame * n)(*[gpu.make_frame(b.ptr, w, h, istride, in_fmt) for b in din])
+    fo = (gpu.Frame * n)(*[gpu.make_frame(b.ptr, w, h, ostride, out_fmt) for b in dout])
+    s = DETECT_SETTINGS[3]
+    gpu.check(gpu.lib().mvfx_hsvdetector_transform_frames(fi, fo, n, ctypes.byref(gpu.HsvDetectorSettings(*s)), None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    for k in range(n):
+        expect = outs0[k].copy()
+        assert orc.hsvdetector(ins[k], istride, in_fmt, expect, ostride, out_fmt, w, s) == 0
+        assert np.array_equal(dout[k].download().reshape(h, ostride), expect), f"pair {k}"
+    # mixed geometry inside one batch is refused
+    fo[1].width = w - 1
+    assert gpu.lib().mvfx_hsvdetector_transform_frames(fi, fo, 2, ctypes.byref(gpu.HsvDetectorSettings(*s)), None) == gpu.ERR_INVALID_ARGUMENT
+    assert gpu.lib().mvfx_hsvdetector_transform_frames(fi, fo, 0, ctypes.byref(gpu.HsvDetectorSettings(*s)), None) == gpu.ERR_INVALID_ARGUMENT
+
+
 def test_hsvdetector_1080p_after_hsvfilter(gpu):
     """BASELINE config 2: hsvfilter (RGBx, in place) then hsvdetector RGBx->RGBA at 1920x1080."""
     w, h = 1920, 1080
