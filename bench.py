@@ -289,6 +289,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 literal kernel, 2 strength-reduced")
+    ap.add_argument("--streaming", type=int, default=1,
+                    help="mvfx_hsvfilter_set_streaming: 1 = non-temporal loads/stores (the frames of this workload are not "
+                         "read again on the GPU: standalone filter), 0 = normal caching (element chains)")
     ap.add_argument("--workload", default="hsvfilter",
                     choices=["hsvfilter", "hsv1080p", "colorlut", "videofx", "videocompare"],
                     help="hsvfilter = the headline metric (default, BASELINE metric); hsv1080p = config 2 "
@@ -325,6 +328,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
     vfx.check(lib.mvfx_set_device(local_rank))
     vfx.check(lib.mvfx_hsvfilter_set_variant(args.variant))
+    vfx.check(lib.mvfx_hsvfilter_set_streaming(args.streaming))
 
     # ---- resident frame pool: pool x batch distinct uniform-random 4K RGBA frames -------------
     pool = max(1, args.pool)
@@ -407,7 +411,8 @@ def main():
                    "frames_per_step_per_gpu": args.batch, "resident_batches": pool,
                    "settle_seconds_before_warmup": args.settle_seconds, "settle_steps": settle_steps,
                    "parallelism": f"{world} independent stream shards, no data-path collective",
-                   "kernel_variant": {0: "auto", 1: "literal", 2: "strength-reduced"}[args.variant]},
+                   "kernel_variant": {0: "auto", 1: "literal", 2: "strength-reduced"}[args.variant],
+                   "cache_policy": "non-temporal (mvfx_hsvfilter_set_streaming(1))" if args.streaming else "default"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "hsvfilter4_kernel<RGBA, vec4>", "bytes_per_launch": bytes_per_launch,

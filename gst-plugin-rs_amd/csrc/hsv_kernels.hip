@@ -25,13 +25,11 @@
 namespace mvfx {
 namespace {
 
-constexpr int kBlock = 256;
-#ifndef MVFX_HSV_TILE
-#define MVFX_HSV_TILE 1
-#endif
-constexpr int kTile = MVFX_HSV_TILE; // 16-byte pixel groups per lane in hsvfilter4_kernel (vec4 mode)
+constexpr int kBlock = 256; // 128 / 512 / 1024 measured slower (profiles/r1/ab_steady_block_nt.txt)
+constexpr int kTile = 2;    // 16-byte pixel groups per lane in hsvfilter4_kernel (vec4 mode): both loads are issued first
 
 enum : int { kModeBytes = 0, kModeVec4 = 1, kModeDword = 2 };
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- channel placement -------------------------------------------------------------------
 // hsvfilter/imp.rs:327-373: OFF = index of the first colour byte, BGR = byte order of the triple
@@ -93,7 +91,8 @@ __device__ __forceinline__ void init_filter_lds(FilterLds &lds, int off, bool bg
 
 // ---- hsvfilter, 4-byte formats -------------------------------------------------------------
 // width = pixels per row, rows/stride describe one frame, fb.base[blockIdx.z] its plane 0.
-template <int OFF, bool BGR, int VARIANT, int MODE>
+// NT: non-temporal loads/stores (vec4 mode), for frames that are not read again on the GPU right away.
+template <int OFF, bool BGR, int VARIANT, int MODE, bool NT = false>
 __global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint64_t width,
                                                             uint32_t rows, uint64_t stride,
                                                             FastConsts p)
@@ -111,14 +110,21 @@ __global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint6
             // flight while group u is computed (the wave stays in its VALU phase for kTile x 272
             // instructions instead of dying after one group).
             const uint64_t groups = (width + 3) >> 2;
+            // (giving every XCD one contiguous eighth of the frame instead of every 8th tile: -1 %)
             for (uint64_t t0 = (uint64_t)blockIdx.x * (kBlock * kTile); t0 < groups;
                  t0 += (uint64_t)gridDim.x * (kBlock * kTile)) {
                 uint4 v[kTile];
 #pragma unroll
                 for (int u = 0; u < kTile; u++) {
                     const uint64_t x = (t0 + (uint64_t)u * kBlock + threadIdx.x) << 2;
-                    if (x + 4 <= width)
-                        v[u] = *reinterpret_cast<const uint4 *>(line + x * 4);
+                    if (x + 4 <= width) {
+                        if constexpr (NT) {
+                            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(line + x * 4));
+                            v[u] = make_uint4(t.x, t.y, t.z, t.w);
+                        } else {
+                            v[u] = *reinterpret_cast<const uint4 *>(line + x * 4);
+                        }
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < kTile; u++) {
@@ -128,7 +134,12 @@ __global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint6
                         v[u].y = filter_px4<OFF, BGR, VARIANT>(v[u].y, p, lds);
                         v[u].z = filter_px4<OFF, BGR, VARIANT>(v[u].z, p, lds);
                         v[u].w = filter_px4<OFF, BGR, VARIANT>(v[u].w, p, lds);
-                        *reinterpret_cast<uint4 *>(line + x * 4) = v[u];
+                        if constexpr (NT) {
+                            const u32x4 t = {v[u].x, v[u].y, v[u].z, v[u].w};
+                            __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(line + x * 4));
+                        } else {
+                            *reinterpret_cast<uint4 *>(line + x * 4) = v[u];
+                        }
                     } else {
                         for (uint64_t xx = x; xx < width; xx++) {
                             uint32_t *q = reinterpret_cast<uint32_t *>(line + xx * 4);
@@ -354,7 +365,8 @@ __global__ __launch_bounds__(kBlock) void hsv_from_frame_kernel(const uint8_t *i
 
 // ---- host side ------------------------------------------------------------------------------
 
-int g_variant = 0; // mvfx_hsvfilter_set_variant
+int g_variant = 0;   // mvfx_hsvfilter_set_variant
+int g_streaming = 0; // mvfx_hsvfilter_set_streaming
 
 // Domain of the FAST kernels (hsv_math.hpp): finite settings, |shift| <= 360, shift not in
 // (0,1e-30) in magnitude.
@@ -456,14 +468,20 @@ void launch_filter(int bpp, int off, bool bgr, const Geometry &g, const FrameBat
 
 #define MVFX_L4(O, B, M) \
     hipLaunchKernelGGL((hsvfilter4_kernel<O, B, VARIANT, M>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p)
+#define MVFX_L4NT(O, B) \
+    hipLaunchKernelGGL((hsvfilter4_kernel<O, B, VARIANT, kModeVec4, true>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p)
 #define MVFX_L3(B, M) \
     hipLaunchKernelGGL((hsvfilter3_kernel<B, VARIANT, M>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p)
     if (bpp == 4) {
         const int key = (off ? 2 : 0) | (bgr ? 1 : 0);
         switch (g.mode) {
         case kModeVec4:
-            switch (key) { case 0: MVFX_L4(0, false, kModeVec4); break; case 1: MVFX_L4(0, true, kModeVec4); break;
-                           case 2: MVFX_L4(1, false, kModeVec4); break; default: MVFX_L4(1, true, kModeVec4); break; }
+            if (g_streaming && VARIANT != kGeneral)
+                switch (key) { case 0: MVFX_L4NT(0, false); break; case 1: MVFX_L4NT(0, true); break;
+                               case 2: MVFX_L4NT(1, false); break; default: MVFX_L4NT(1, true); break; }
+            else
+                switch (key) { case 0: MVFX_L4(0, false, kModeVec4); break; case 1: MVFX_L4(0, true, kModeVec4); break;
+                               case 2: MVFX_L4(1, false, kModeVec4); break; default: MVFX_L4(1, true, kModeVec4); break; }
             break;
         case kModeDword:
             switch (key) { case 0: MVFX_L4(0, false, kModeDword); break; case 1: MVFX_L4(0, true, kModeDword); break;
@@ -479,6 +497,7 @@ void launch_filter(int bpp, int off, bool bgr, const Geometry &g, const FrameBat
         else { if (bgr) MVFX_L3(true, kModeBytes); else MVFX_L3(false, kModeBytes); }
     }
 #undef MVFX_L4
+#undef MVFX_L4NT
 #undef MVFX_L3
 }
 
@@ -689,6 +708,12 @@ int mvfx_hsvfilter_set_variant(int variant)
     if (variant < 0 || variant > 2)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvfilter variant must be 0 (auto), 1 (general) or 2 (fast)");
     g_variant = variant;
+    return MVFX_OK;
+}
+
+int mvfx_hsvfilter_set_streaming(int on)
+{
+    g_streaming = on ? 1 : 0;
     return MVFX_OK;
 }
 

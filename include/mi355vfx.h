@@ -137,6 +137,12 @@ int mvfx_hsvfilter_transform_frame_ip_host(const mvfx_frame *frame,
  * the settings are outside its proven domain instead of silently falling back). */
 int mvfx_hsvfilter_set_variant(int variant);
 
+/* Cache policy of the hsvfilter kernels on 16-byte aligned 4-byte frames (per process): 0 (default)
+ * = normal caching, right when the next element reads the frame on the GPU (hsvfilter ! hsvdetector
+ * on device memory: +4 % for the pair); 1 = non-temporal loads and stores, for frames that leave the
+ * GPU or are not touched again before ~256 MB of other traffic (+3 % on a standalone stream). */
+int mvfx_hsvfilter_set_streaming(int on);
+
 /* ---- hsvdetector : video/hsv/src/hsvdetector/imp.rs ----
  * Settings == `struct Settings` hsvdetector/imp.rs:34-42 (defaults :26-31). */
 typedef struct mvfx_hsvdetector_settings {

@@ -186,6 +186,21 @@ def test_hsvfilter_batch_matches_single(gpu):
         assert np.array_equal(bufs[k].download().reshape(h, w * 4), expect), f"frame {k}"
 
 
+@pytest.mark.parametrize("w,h", [(3840, 2160), (1021, 7), (8, 1), (2047, 3)])
+def test_hsvfilter_streaming_policy_same_bytes(gpu, w, h):
+    """mvfx_hsvfilter_set_streaming(1) (non-temporal loads/stores, 2 pixel groups per lane) changes no byte;
+    sizes with partial tiles / 1-3 pixel tails included."""
+    frame = frames.random_frame(0x5EED0400 + w, w, h)
+    expect = frame.copy()
+    assert orc.hsvfilter(expect, w, w * 4, "RGBA", BENCH_SETTINGS) == 0
+    try:
+        gpu.check(gpu.lib().mvfx_hsvfilter_set_streaming(1))
+        got = _device_filter(gpu, frame, w, h, w * 4, "RGBA", BENCH_SETTINGS, 0)
+    finally:
+        gpu.check(gpu.lib().mvfx_hsvfilter_set_streaming(0))
+    assert np.array_equal(got, expect)
+
+
 def test_hsvfilter_4k_full_size(gpu):
     """BASELINE config: 3840x2160 RGBA, uniform random + smpte-like, full-frame compare."""
     w, h = 3840, 2160

@@ -19,7 +19,7 @@ else
         name=$(basename "$so" .so); name=${name#lib_}
         for rep in 1 2; do
             MVFX_LIB=$so python "$ROOT/bench.py" --no-cpu-baseline --steps 1500 --warmup 1500 "$@" | \
-                python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$name', 'fps=%.0f' % d['value'], 'kernel_ms=%.4f' % d['roofline']['avg_launch_ms'], 'frac=%.3f' % d['roofline']['frac'])"
+                python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$name', 'fps=%.0f' % d['value'], 'ms_per_step=%.4f' % d['ms_per_step'], 'frac=%.3f' % d['roofline']['frac'])"
         done
     done
 fi
