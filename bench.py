@@ -116,14 +116,31 @@ def videocompare_main(args):
         vfx.check(lib.mvfx_blockhash_bits(arr, w, h, ctypes.byref(out)))
         return out.value
 
-    def step(i):
-        def partial(p):
-            f = vfx.make_frame(pairs[i % pool, p].data_ptr(), W, rows, W * 4, "RGBA")
-            vfx.check(lib.mvfx_blockhash_sums_band(ctypes.byref(f), H, r0, ctypes.c_void_p(sums[p].data_ptr()), sptr))
-            return sums[p]
-        return D.videocompare_sharded(partial, 2, W, H, bits, dev)
+    if args.hash_algo == "dssim":
+        # every rank holds both full frames (a band's 5-level pyramid needs a halo of up to 64 rows) and maps only its band;
+        # two all-reduces of 10 f64 per pair (distributed.ssim_sharded)
+        del pairs
+        pool = 2
+        gen.manual_seed(0x5EED0002)
+        full = torch.randint(0, 256, (pool, 2, H * W * 4), dtype=torch.uint8, device=dev, generator=gen)
+        full[:, 1] = full[:, 0]
+        full[:, 1, ::97] ^= 0x10
+        y0, y1 = D.ssim_band_rows(H, rank, world)
+        fr = [[vfx.make_frame(full[k, p].data_ptr(), W, H, W * 4, "RGBA") for p in range(2)] for k in range(pool)]
 
-    settle(step, args.settle_seconds, lambda: torch.cuda.synchronize(dev), fixed_steps=400)  # all-reduce inside the step
+        def step(i):
+            k = i % pool
+            return [D.ssim_sharded(lambda: vfx.ssim_partial_sums(fr[k][0], fr[k][1], y0, y1, sptr),
+                                   lambda mean: vfx.ssim_partial_deviation(mean, sptr), vfx.ssim_combine, dev)]
+    else:
+        def step(i):
+            def partial(p):
+                f = vfx.make_frame(pairs[i % pool, p].data_ptr(), W, rows, W * 4, "RGBA")
+                vfx.check(lib.mvfx_blockhash_sums_band(ctypes.byref(f), H, r0, ctypes.c_void_p(sums[p].data_ptr()), sptr))
+                return sums[p]
+            return D.videocompare_sharded(partial, 2, W, H, bits, dev)
+
+    settle(step, args.settle_seconds, lambda: torch.cuda.synchronize(dev), fixed_steps=400 if args.hash_algo == "blockhash" else 20)  # all-reduce inside the step
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(dev)
@@ -149,8 +166,9 @@ def videocompare_main(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic uniform-random u8 RGBA, device-resident, rows pre-sharded by block-row band",
-            "config": {"workload": "videocompare blockhash 7680x4320 RGBA pair, band-sharded + all-reduce(2x64 u32)",
-                       "parallelism": f"{world} row bands, one RCCL all-reduce per pair", "last_distance": d[0]},
+            "config": {"workload": "videocompare blockhash 7680x4320 RGBA pair, band-sharded + all-reduce(2x64 u32)" if args.hash_algo == "blockhash"
+                       else "videocompare dssim (multi-scale SSIM, f64) 7680x4320 RGBA pair, row bands + 2 all-reduces of 10 f64",
+                       "parallelism": f"{world} row bands, RCCL all-reduce per pair", "last_distance": d[0]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
                          "note": "end-to-end per pair incl. all-reduce, D2H of 64 sums and host bit derivation"}}), flush=True)
@@ -292,6 +310,8 @@ def main():
     ap.add_argument("--streaming", type=int, default=1,
                     help="mvfx_hsvfilter_set_streaming: 1 = non-temporal loads/stores (the frames of this workload are not "
                          "read again on the GPU: standalone filter), 0 = normal caching (element chains)")
+    ap.add_argument("--hash-algo", default="blockhash", choices=["blockhash", "dssim"],
+                    help="videocompare workload: blockhash (the element's default) or the SSIM-family distance")
     ap.add_argument("--workload", default="hsvfilter",
                     choices=["hsvfilter", "hsv1080p", "colorlut", "videofx", "videocompare"],
                     help="hsvfilter = the headline metric (default, BASELINE metric); hsv1080p = config 2 "

@@ -20,6 +20,10 @@
 #include <cstring>
 #include <vector>
 
+// The library is built with -ffp-contract=off for the bit-exact u8 paths; this file is a tolerance-checked
+// f64 metric, so multiply-adds may fuse here.
+#pragma clang fp contract(fast)
+
 namespace mvfx {
 namespace {
 
@@ -27,17 +31,20 @@ constexpr int kScales = 5;
 const double kWeights[kScales] = {0.028, 0.197, 0.322, 0.298, 0.155};
 constexpr double kC1 = 0.01 * 0.01, kC2 = 0.03 * 0.03;
 constexpr int kBlock = 256;
+constexpr int kSlots = 256; // accumulators per (pass, scale): one f64 atomic per workgroup, spread so they do not serialise
 
 struct Planes {
     double *p[3];
     int w, h;
 };
 
-__global__ __launch_bounds__(kBlock) void ssim_linearize_kernel(const uint8_t *frame, int w, int h, uint64_t stride, int bpp,
+// All kernels work on the row range [y0, y0 + gridDim.y) of absolutely indexed full-size planes: a rank that
+// owns a row band only fills the band plus the halo the coarser scales and the 5x5 window need.
+__global__ __launch_bounds__(kBlock) void ssim_linearize_kernel(const uint8_t *frame, int w, int y0, uint64_t stride, int bpp,
                                                                 const double *lut, Planes out)
 {
-    const int x = blockIdx.x * kBlock + threadIdx.x, y = blockIdx.y;
-    if (x >= w || y >= h) return;
+    const int x = blockIdx.x * kBlock + threadIdx.x, y = y0 + blockIdx.y;
+    if (x >= w) return;
     const uint8_t *p = frame + (uint64_t)y * stride + (uint64_t)x * bpp;
     const double a = bpp == 4 ? p[3] / 255.0 : 1.0; // premultiplied alpha
     const size_t i = (size_t)y * w + x;
@@ -46,10 +53,10 @@ __global__ __launch_bounds__(kBlock) void ssim_linearize_kernel(const uint8_t *f
     out.p[2][i] = lut[p[2]] * a;
 }
 
-__global__ __launch_bounds__(kBlock) void ssim_downsample_kernel(Planes in, Planes out)
+__global__ __launch_bounds__(kBlock) void ssim_downsample_kernel(Planes in, Planes out, int y0)
 {
-    const int x = blockIdx.x * kBlock + threadIdx.x, y = blockIdx.y;
-    if (x >= out.w || y >= out.h) return;
+    const int x = blockIdx.x * kBlock + threadIdx.x, y = y0 + blockIdx.y;
+    if (x >= out.w) return;
     for (int c = 0; c < 3; c++) {
         const double *r0 = in.p[c] + (size_t)(2 * y) * in.w + 2 * x, *r1 = r0 + in.w;
         out.p[c][(size_t)y * out.w + x] = (r0[0] + r0[1] + r1[0] + r1[1]) * 0.25;
@@ -62,10 +69,11 @@ __device__ __forceinline__ double lab_f(double t)
     return t > eps ? cbrt(t) : (kappa * t + 16.0) / 116.0;
 }
 
-__global__ __launch_bounds__(kBlock) void ssim_lab_kernel(Planes lin, Planes lab)
+__global__ __launch_bounds__(kBlock) void ssim_lab_kernel(Planes lin, Planes lab, int y0)
 {
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= (size_t)lin.w * lin.h) return;
+    const int x = blockIdx.x * kBlock + threadIdx.x;
+    if (x >= lin.w) return;
+    const size_t i = (size_t)(y0 + blockIdx.y) * lin.w + x;
     const double r = lin.p[0][i], g = lin.p[1][i], b = lin.p[2][i];
     const double X = (0.4124 * r + 0.3576 * g + 0.1805 * b) / 0.9505;
     const double Y = 0.2126 * r + 0.7152 * g + 0.0722 * b;
@@ -89,35 +97,72 @@ __device__ __forceinline__ double block_sum(double v)
     return t; // valid in thread 0
 }
 
-// SSIM map of rows [y0,y1) of one scale + its sum
+// SSIM map of rows [y0,y1) of one scale + its sum.  The 5x5 binomial window is separable: a lane owns one
+// column of a kSeg-row segment and walks down it, per row 5 + 5 loads (the neighbours' loads hit L1) give the
+// five horizontally blurred moments, a 5-row ring of them in registers gives the vertical pass -- 10 loads
+// and ~50 f64 FMAs per pixel and channel instead of 50 loads and ~125 (first version: 313 us average per call).
+constexpr int kSeg = 16;
+
 __global__ __launch_bounds__(kBlock) void ssim_map_kernel(Planes a, Planes b, int y0, int y1, double *map, double *sum)
 {
-    const int x = blockIdx.x * kBlock + threadIdx.x, y = y0 + blockIdx.y;
     const int w = a.w, h = a.h;
-    double val = 0.0;
-    if (x < w && y < y1) {
-        const double B[5] = {1.0 / 16, 4.0 / 16, 6.0 / 16, 4.0 / 16, 1.0 / 16};
-        double acc = 0.0;
-        for (int c = 0; c < 3; c++) {
-            double m1 = 0, m2 = 0, s11 = 0, s22 = 0, s12 = 0;
-            for (int dy = -2; dy <= 2; dy++) {
-                const int yy = min(max(y + dy, 0), h - 1);
-                for (int dx = -2; dx <= 2; dx++) {
-                    const int xx = min(max(x + dx, 0), w - 1);
-                    const double wgt = B[dy + 2] * B[dx + 2];
-                    const double v1 = a.p[c][(size_t)yy * w + xx], v2 = b.p[c][(size_t)yy * w + xx];
-                    m1 += wgt * v1; m2 += wgt * v2;
-                    s11 += wgt * v1 * v1; s22 += wgt * v2 * v2; s12 += wgt * v1 * v2;
-                }
+    const int x = blockIdx.x * kBlock + threadIdx.x;
+    const int seg0 = y0 + blockIdx.y * kSeg;
+    const bool live = x < w;
+    const double B0 = 1.0 / 16, B1 = 4.0 / 16, B2 = 6.0 / 16;
+    int xs[5];
+#pragma unroll
+    for (int d = 0; d < 5; d++)
+        xs[d] = min(max(x + d - 2, 0), w - 1);
+    double acc[kSeg];
+#pragma unroll
+    for (int r = 0; r < kSeg; r++) acc[r] = 0.0;
+#pragma unroll 1
+    for (int c = 0; c < 3; c++) {
+        const double *pa = a.p[c], *pb = b.p[c];
+        double ring[5][5]; // [row slot][moment]: m1, m2, s11, s22, s12 after the horizontal pass
+#pragma unroll
+        for (int i = 0; i < kSeg + 4; i++) {
+            const int yy = min(max(seg0 + i - 2, 0), h - 1);
+            const size_t row = (size_t)yy * w;
+            double v1[5], v2[5];
+#pragma unroll
+            for (int d = 0; d < 5; d++) { v1[d] = pa[row + xs[d]]; v2[d] = pb[row + xs[d]]; }
+            double hm[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+            for (int d = 0; d < 5; d++) {
+                const double wgt = d == 2 ? B2 : ((d == 1 || d == 3) ? B1 : B0);
+                hm[0] += wgt * v1[d]; hm[1] += wgt * v2[d];
+                hm[2] += wgt * v1[d] * v1[d]; hm[3] += wgt * v2[d] * v2[d]; hm[4] += wgt * v1[d] * v2[d];
             }
-            s11 -= m1 * m1; s22 -= m2 * m2; s12 -= m1 * m2;
-            acc += ((2.0 * m1 * m2 + kC1) * (2.0 * s12 + kC2)) / ((m1 * m1 + m2 * m2 + kC1) * (s11 + s22 + kC2));
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                ring[0][q] = ring[1][q]; ring[1][q] = ring[2][q]; ring[2][q] = ring[3][q]; ring[3][q] = ring[4][q];
+                ring[4][q] = hm[q];
+            }
+            if (i >= 4) { // rows seg0 + i - 4 - 2 .. seg0 + i - 2 are in the ring: output row r = i - 4
+                double m[5];
+#pragma unroll
+                for (int q = 0; q < 5; q++)
+                    m[q] = B0 * (ring[0][q] + ring[4][q]) + B1 * (ring[1][q] + ring[3][q]) + B2 * ring[2][q];
+                const double m1 = m[0], m2 = m[1];
+                const double s11 = m[2] - m1 * m1, s22 = m[3] - m2 * m2, s12 = m[4] - m1 * m2;
+                acc[i - 4] += ((2.0 * m1 * m2 + kC1) * (2.0 * s12 + kC2)) / ((m1 * m1 + m2 * m2 + kC1) * (s11 + s22 + kC2));
+            }
         }
-        val = acc / 3.0;
-        map[(size_t)y * w + x] = val;
     }
-    const double t = block_sum(val);
-    if (threadIdx.x == 0) atomicAdd(sum, t);
+    double total = 0.0;
+#pragma unroll
+    for (int r = 0; r < kSeg; r++) {
+        const int y = seg0 + r;
+        if (live && y < y1) {
+            const double val = acc[r] / 3.0;
+            map[(size_t)y * w + x] = val;
+            total += val;
+        }
+    }
+    const double t = block_sum(total);
+    if (threadIdx.x == 0) atomicAdd(sum + ((blockIdx.x + blockIdx.y * gridDim.x) % kSlots), t);
 }
 
 __global__ __launch_bounds__(kBlock) void ssim_dev_kernel(const double *map, int w, int y0, int y1, double avg, double *sum)
@@ -127,22 +172,26 @@ __global__ __launch_bounds__(kBlock) void ssim_dev_kernel(const double *map, int
     if (x < w && y < y1)
         val = fabs(map[(size_t)y * w + x] - avg);
     const double t = block_sum(val);
-    if (threadIdx.x == 0) atomicAdd(sum, t);
+    if (threadIdx.x == 0) atomicAdd(sum + ((blockIdx.x + blockIdx.y * gridDim.x) % kSlots), t);
 }
 
-// Per-thread state carried from the mean pass to the deviation pass
+// Per-thread scratch, kept across calls while the frame size stays the same (a videocompare pad pair per
+// buffer): f64 planes of both images (linear RGB, ping-pong for the pyramid, Lab) and the five maps.
 struct SsimState {
     std::vector<void *> allocations;
+    int w0 = 0, h0 = 0, device = -1;
+    Planes lin[2], nxt[2], lab[2];
     double *map[kScales] = {};
     int w[kScales] = {}, h[kScales] = {}, y0[kScales] = {}, y1[kScales] = {};
-    int scales = 0;
-    double *d_sums = nullptr; // 2 * kScales doubles
+    int scales = 0;        // of the last mvfx_ssim_partial_sums on this thread (0: none pending)
+    double *d_sums = nullptr; // [2 passes][kScales][kSlots] doubles
     double *d_lut = nullptr;
     void release()
     {
         for (void *p : allocations) (void)hipFree(p);
         allocations.clear();
         scales = 0;
+        w0 = h0 = 0;
         d_sums = nullptr;
         d_lut = nullptr;
     }
@@ -164,6 +213,41 @@ int alloc_planes(SsimState &st, int w, int h, Planes *pl)
     pl->w = w; pl->h = h;
     for (int c = 0; c < 3; c++)
         if (int rc = dalloc(st, sizeof(double) * (size_t)w * h, reinterpret_cast<void **>(&pl->p[c])); rc != MVFX_OK) return rc;
+    return MVFX_OK;
+}
+
+// (Re)allocates the scratch of this thread for w0 x h0 frames on the current device.
+int ensure_scratch(SsimState &S, int w0, int h0, hipStream_t st)
+{
+    int dev = 0;
+    MVFX_HIP_TRY(hipGetDevice(&dev));
+    if (S.w0 == w0 && S.h0 == h0 && S.device == dev && !S.allocations.empty())
+        return MVFX_OK;
+    S.release();
+    S.device = dev;
+    if (int rc = dalloc(S, sizeof(double) * 2 * kScales * kSlots, reinterpret_cast<void **>(&S.d_sums)); rc != MVFX_OK) return rc;
+    if (int rc = dalloc(S, sizeof(double) * 256, reinterpret_cast<void **>(&S.d_lut)); rc != MVFX_OK) return rc;
+    double lut[256];
+    for (int i = 0; i < 256; i++) {
+        const double x = i / 255.0;
+        lut[i] = x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4);
+    }
+    MVFX_HIP_TRY(hipMemcpyAsync(S.d_lut, lut, sizeof(lut), hipMemcpyHostToDevice, st));
+    MVFX_HIP_TRY(hipStreamSynchronize(st)); // `lut` is a stack buffer
+    for (int i = 0; i < 2; i++) {
+        if (int rc = alloc_planes(S, w0, h0, &S.lin[i]); rc != MVFX_OK) return rc;
+        if (int rc = alloc_planes(S, w0, h0, &S.lab[i]); rc != MVFX_OK) return rc;
+        if (int rc = alloc_planes(S, w0 / 2, h0 / 2, &S.nxt[i]); rc != MVFX_OK) return rc;
+    }
+    int w = w0, h = h0;
+    for (int s = 0; s < kScales; s++) {
+        if (s > 0) {
+            if (w / 2 < 8 || h / 2 < 8) break;
+            w /= 2; h /= 2;
+        }
+        if (int rc = dalloc(S, sizeof(double) * (size_t)w * h, reinterpret_cast<void **>(&S.map[s])); rc != MVFX_OK) return rc;
+    }
+    S.w0 = w0; S.h0 = h0;
     return MVFX_OK;
 }
 
@@ -201,56 +285,72 @@ int mvfx_ssim_partial_sums(const mvfx_frame *reference_frame, const mvfx_frame *
 
     hipStream_t st = as_stream(stream);
     SsimState &S = t_ssim;
-    S.release();
-    if (int rc = dalloc(S, sizeof(double) * 2 * kScales, reinterpret_cast<void **>(&S.d_sums)); rc != MVFX_OK) return rc;
-    if (int rc = dalloc(S, sizeof(double) * 256, reinterpret_cast<void **>(&S.d_lut)); rc != MVFX_OK) return rc;
-    double lut[256];
-    for (int i = 0; i < 256; i++) {
-        const double x = i / 255.0;
-        lut[i] = x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4);
-    }
-    MVFX_HIP_TRY(hipMemcpyAsync(S.d_lut, lut, sizeof(lut), hipMemcpyHostToDevice, st));
-    MVFX_HIP_TRY(hipMemsetAsync(S.d_sums, 0, sizeof(double) * 2 * kScales, st));
+    if (int rc = ensure_scratch(S, w0, h0, st); rc != MVFX_OK) return rc;
+    MVFX_HIP_TRY(hipMemsetAsync(S.d_sums, 0, sizeof(double) * 2 * kScales * kSlots, st));
 
-    Planes lin[2], nxt[2], lab[2];
-    for (int i = 0; i < 2; i++) {
-        if (int rc = alloc_planes(S, w0, h0, &lin[i]); rc != MVFX_OK) return rc;
-        if (int rc = alloc_planes(S, w0, h0, &lab[i]); rc != MVFX_OK) return rc;
-        if (int rc = alloc_planes(S, w0 / 2, h0 / 2, &nxt[i]); rc != MVFX_OK) return rc;
-        const int bpp = fr[i]->format == MVFX_FORMAT_RGBA ? 4 : 3;
-        hipLaunchKernelGGL(ssim_linearize_kernel, grid2d(w0, h0), dim3(kBlock), 0, st, static_cast<const uint8_t *>(fr[i]->data),
-                           w0, h0, (uint64_t)fr[i]->stride, bpp, S.d_lut, lin[i]);
-    }
-    int w = w0, h = h0;
-    for (int s = 0; s < kScales; s++) {
+    // geometry of every scale, the band's rows [y0,y1) at that scale, and the rows [a,b) of the planes that must
+    // exist there: the band +-2 (5x5 window) and twice the range the next coarser scale needs
+    int ws[kScales], hs[kScales], a[kScales], b[kScales], n_scales = 0;
+    for (int s = 0, w = w0, h = h0; s < kScales; s++) {
         if (s > 0) {
             if (w / 2 < 8 || h / 2 < 8) break;
-            for (int i = 0; i < 2; i++) {
-                Planes out = nxt[i];
-                out.w = w / 2; out.h = h / 2;
-                Planes in = lin[i];
-                in.w = w; in.h = h;
-                hipLaunchKernelGGL(ssim_downsample_kernel, grid2d(out.w, out.h), dim3(kBlock), 0, st, in, out);
-                std::swap(lin[i], nxt[i]); // buffers are sized for scale 0 / scale 1: both large enough further down
-            }
             w /= 2; h /= 2;
         }
-        for (int i = 0; i < 2; i++) {
-            lin[i].w = w; lin[i].h = h;
-            lab[i].w = w; lab[i].h = h;
-            hipLaunchKernelGGL(ssim_lab_kernel, dim3((unsigned)(((size_t)w * h + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, lin[i], lab[i]);
-        }
-        const int y0 = (int)(row_begin >> s), y1 = row_end == (uint32_t)h0 ? h : std::min((int)(row_end >> s), h);
-        if (int rc = dalloc(S, sizeof(double) * (size_t)w * h, reinterpret_cast<void **>(&S.map[s])); rc != MVFX_OK) return rc;
-        S.w[s] = w; S.h[s] = h; S.y0[s] = y0; S.y1[s] = y1;
-        if (y1 > y0)
-            hipLaunchKernelGGL(ssim_map_kernel, grid2d(w, y1 - y0), dim3(kBlock), 0, st, lab[0], lab[1], y0, y1, S.map[s], S.d_sums + s);
-        S.scales = s + 1;
+        ws[s] = w; hs[s] = h;
+        S.w[s] = w; S.h[s] = h;
+        S.y0[s] = std::min((int)(row_begin >> s), h);
+        S.y1[s] = row_end == (uint32_t)h0 ? h : std::min((int)(row_end >> s), h);
+        n_scales = s + 1;
     }
+    for (int s = n_scales - 1; s >= 0; s--) {
+        a[s] = std::max(S.y0[s] - 2, 0);
+        b[s] = std::min(S.y1[s] + 2, hs[s]);
+        if (S.y1[s] <= S.y0[s]) { a[s] = 0; b[s] = 0; }
+        if (s + 1 < n_scales && b[s + 1] > a[s + 1]) {
+            const int lo = 2 * a[s + 1], hi = std::min(2 * b[s + 1], hs[s]);
+            if (b[s] > a[s]) { a[s] = std::min(a[s], lo); b[s] = std::max(b[s], hi); }
+            else { a[s] = lo; b[s] = hi; }
+        }
+    }
+
+    Planes lin[2] = {S.lin[0], S.lin[1]}, nxt[2] = {S.nxt[0], S.nxt[1]}, lab[2] = {S.lab[0], S.lab[1]};
+    if (b[0] > a[0])
+        for (int i = 0; i < 2; i++) {
+            const int bpp = fr[i]->format == MVFX_FORMAT_RGBA ? 4 : 3;
+            lin[i].w = w0; lin[i].h = h0;
+            hipLaunchKernelGGL(ssim_linearize_kernel, grid2d(w0, b[0] - a[0]), dim3(kBlock), 0, st,
+                               static_cast<const uint8_t *>(fr[i]->data), w0, a[0], (uint64_t)fr[i]->stride, bpp, S.d_lut, lin[i]);
+        }
+    for (int s = 0; s < n_scales; s++) {
+        const int w = ws[s], h = hs[s];
+        if (s > 0 && b[s] > a[s])
+            for (int i = 0; i < 2; i++) {
+                Planes out = nxt[i], in = lin[i];
+                out.w = w; out.h = h;
+                in.w = ws[s - 1]; in.h = hs[s - 1];
+                hipLaunchKernelGGL(ssim_downsample_kernel, grid2d(w, b[s] - a[s]), dim3(kBlock), 0, st, in, out, a[s]);
+                std::swap(lin[i], nxt[i]); // buffers are sized for scale 0 / scale 1: both large enough further down
+            }
+        if (b[s] > a[s])
+            for (int i = 0; i < 2; i++) {
+                lin[i].w = w; lin[i].h = h;
+                lab[i].w = w; lab[i].h = h;
+                hipLaunchKernelGGL(ssim_lab_kernel, grid2d(w, b[s] - a[s]), dim3(kBlock), 0, st, lin[i], lab[i], a[s]);
+            }
+        if (S.y1[s] > S.y0[s])
+            hipLaunchKernelGGL(ssim_map_kernel, grid2d(w, (S.y1[s] - S.y0[s] + kSeg - 1) / kSeg), dim3(kBlock), 0, st, lab[0], lab[1], S.y0[s], S.y1[s],
+                               S.map[s], S.d_sums + s * kSlots);
+    }
+    S.scales = n_scales;
     MVFX_HIP_TRY(hipGetLastError());
-    double sums[2 * kScales];
-    MVFX_HIP_TRY(hipMemcpyAsync(sums, S.d_sums, sizeof(sums), hipMemcpyDeviceToHost, st));
+    std::vector<double> slots((size_t)kScales * kSlots);
+    MVFX_HIP_TRY(hipMemcpyAsync(slots.data(), S.d_sums, slots.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     MVFX_HIP_TRY(hipStreamSynchronize(st));
+    double sums[kScales];
+    for (int s = 0; s < kScales; s++) {
+        sums[s] = 0.0;
+        for (int k = 0; k < kSlots; k++) sums[s] += slots[(size_t)s * kSlots + k];
+    }
     for (int s = 0; s < kScales; s++) {
         sums_out[s] = s < S.scales ? sums[s] : 0.0;
         counts_out[s] = s < S.scales ? (double)S.w[s] * (double)std::max(S.y1[s] - S.y0[s], 0) : 0.0;
@@ -270,14 +370,19 @@ int mvfx_ssim_partial_deviation(const double mean[5], double deviation_sums_out[
     for (int s = 0; s < S.scales; s++)
         if (S.y1[s] > S.y0[s])
             hipLaunchKernelGGL(ssim_dev_kernel, grid2d(S.w[s], S.y1[s] - S.y0[s]), dim3(kBlock), 0, st, S.map[s], S.w[s], S.y0[s],
-                               S.y1[s], mean[s], S.d_sums + kScales + s);
+                               S.y1[s], mean[s], S.d_sums + (kScales + s) * kSlots);
     MVFX_HIP_TRY(hipGetLastError());
-    double sums[kScales];
-    MVFX_HIP_TRY(hipMemcpyAsync(sums, S.d_sums + kScales, sizeof(sums), hipMemcpyDeviceToHost, st));
+    std::vector<double> slots((size_t)kScales * kSlots);
+    MVFX_HIP_TRY(hipMemcpyAsync(slots.data(), S.d_sums + (size_t)kScales * kSlots, slots.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     MVFX_HIP_TRY(hipStreamSynchronize(st));
+    double sums[kScales];
+    for (int s = 0; s < kScales; s++) {
+        sums[s] = 0.0;
+        for (int k = 0; k < kSlots; k++) sums[s] += slots[(size_t)s * kSlots + k];
+    }
     for (int s = 0; s < kScales; s++)
         deviation_sums_out[s] = s < S.scales ? sums[s] : 0.0;
-    S.release();
+    S.scales = 0; // the maps are consumed; the scratch stays for the next pair of the same size
     return MVFX_OK;
 }
 

@@ -175,6 +175,17 @@ def main():
         ms = timeit(lambda i=0: vfx.check(lib.mvfx_blockhash_sums(ctypes.byref(fr[i % POOL]), 0, H, ctypes.c_void_p(sums.data_ptr()), sptr)), iters=300)
         report("blockhash sums 4K RGBA", ms, NB, 1)
 
+    if want("ssim"):
+        for (w, h, tag) in ((W, H, "4K"), (7680, 4320, "8K")):
+            src = rand_frames(2, w * h * 4, 12)
+            src[1] = src[0]
+            src[1, :: 97] ^= 0x10
+            fa = vfx.make_frame(src[0].data_ptr(), w, h, w * 4, "RGBA")
+            fb = vfx.make_frame(src[1].data_ptr(), w, h, w * 4, "RGBA")
+            d = ctypes.c_double()
+            ms = timeit(lambda i=0: vfx.check(lib.mvfx_ssim_distance(ctypes.byref(fa), ctypes.byref(fb), ctypes.byref(d), sptr)), iters=10, settle_s=0.5)
+            report(f"videocompare dssim {tag} RGBA pair (5 scales, f64)", ms, 2 * w * h * 4, 1, {"distance": d.value})
+
     if want("roundedcorners"):
         mask = torch.empty(W * H, dtype=torch.uint8, device=dev)
         ms = timeit(lambda i=0: vfx.check(lib.mvfx_roundedcorners_mask(ctypes.c_void_p(mask.data_ptr()), W, H, W, 100, sptr)), iters=300)
