@@ -219,17 +219,20 @@ def config_main(args):
         frames_per_step = nb
         bytes_per_step, name = nb * 4 * W * H * 4, f"hsvfilter (RGBx, in place) + hsvdetector RGBx->RGBA, {nb} streams of 1920x1080 per launch"
     elif args.workload == "colorlut":
-        W, H, pool = W4K, H4K, 16
+        # args.batch streams graded with the same 33^3 LUT, one frame of each per launch
+        W, H, nb = W4K, H4K, args.batch
+        pool = max(2, 32 // nb)
         lut = vfx.CubeLut(cubes.analytic_3d(33))
-        src, dst = rnd(pool, FRAME_BYTES), torch.empty((pool, FRAME_BYTES), dtype=torch.uint8, device=dev)
-        fi = [vfx.make_frame(src[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(pool)]
-        fo = [vfx.make_frame(dst[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(pool)]
+        src, dst = rnd(pool * nb, FRAME_BYTES), torch.empty((pool * nb, FRAME_BYTES), dtype=torch.uint8, device=dev)
+        fi = [(vfx.Frame * nb)(*[vfx.make_frame(src[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
+        fo = [(vfx.Frame * nb)(*[vfx.make_frame(dst[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
 
         def step(i):
             k = i % pool
-            vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fi[k]), ctypes.byref(fo[k]), sptr))
-        frames_per_step = 1
-        bytes_per_step, name = 2 * FRAME_BYTES, "colorlut 33^3 .cube, 3840x2160 RGBA, uniform-random colours (worst case for the LUT gathers)"
+            vfx.check(lib.mvfx_colorlut_transform_frames(lut.h, fi[k], fo[k], nb, sptr))
+        frames_per_step = nb
+        bytes_per_step, name = nb * 2 * FRAME_BYTES, (f"colorlut 33^3 .cube, {nb} streams of 3840x2160 RGBA per launch, uniform-random colours "
+                                                      "(worst case for the LUT gathers)")
     else:  # videofx: one 4K stream per GPU: I420 -> A420 compose with the r=100 mask + colordetect on the RGBA twin
         W, H, pool = W4K, H4K, 16
         i420, a420 = rnd(pool, W * H * 3 // 2), torch.empty((pool, W * H * 5 // 2), dtype=torch.uint8, device=dev)

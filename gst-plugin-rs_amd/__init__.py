@@ -115,6 +115,7 @@ SIGNATURES = {
     "mvfx_cube_lut_rgba": (POINTER(c_float), [c_void_p]),
     "mvfx_cube_lut_table_1d": (POINTER(c_float), [c_void_p, c_int]),
     "mvfx_colorlut_transform_frame": (c_int, [c_void_p, POINTER(Frame), POINTER(Frame), c_void_p]),
+    "mvfx_colorlut_transform_frames": (c_int, [c_void_p, POINTER(Frame), POINTER(Frame), c_uint32, c_void_p]),
     "mvfx_colorlut_transform_frame_host": (c_int, [c_void_p, POINTER(Frame), POINTER(Frame)]),
     "mvfx_colorlut_set_placement": (c_int, [c_int]),
     "mvfx_colordetect_histogram": (c_int, [POINTER(Frame), c_uint32, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),

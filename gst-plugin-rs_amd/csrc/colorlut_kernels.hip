@@ -262,20 +262,24 @@ __device__ __forceinline__ void lut_rows(const uint8_t *in, uint8_t *out, uint64
 
 // LUT read from global memory (L2-resident)
 template <bool IS3D, bool WIDE, bool LE, bool VEC>
-__global__ __launch_bounds__(kBlock) void colorlut_global_kernel(const uint8_t *in, uint8_t *out, uint64_t width,
+__global__ __launch_bounds__(kBlock) void colorlut_global_kernel(FrameBatch in_fb, FrameBatch out_fb, uint64_t width,
                                                                  uint32_t rows, uint64_t in_stride,
                                                                  uint64_t out_stride, LutParams p)
 {
+    const uint8_t *in = in_fb.base[blockIdx.z]; // one frame pair of the batch per grid z
+    uint8_t *out = out_fb.base[blockIdx.z];
     lut_rows<IS3D, WIDE, LE, VEC>(in, out, width, rows, in_stride, out_stride, p, p.cube, p.t[0], p.t[1], p.t[2],
                                   blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, blockIdx.y, gridDim.y);
 }
 
 // LUT staged in LDS: persistent 1024-thread workgroups (one per CU) walk the frame
 template <bool IS3D, bool WIDE, bool LE, bool VEC>
-__global__ __launch_bounds__(kLdsBlock) void colorlut_lds_kernel(const uint8_t *in, uint8_t *out, uint64_t width,
+__global__ __launch_bounds__(kLdsBlock) void colorlut_lds_kernel(FrameBatch in_fb, FrameBatch out_fb, uint64_t width,
                                                                  uint32_t rows, uint64_t in_stride,
                                                                  uint64_t out_stride, LutParams p)
 {
+    const uint8_t *in = in_fb.base[blockIdx.z]; // one frame pair of the batch per grid z
+    uint8_t *out = out_fb.base[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     if constexpr (IS3D) {
         float4 *cube = reinterpret_cast<float4 *>(lds_raw);
@@ -498,19 +502,23 @@ __device__ __forceinline__ void lf_rows(const uint8_t *in, uint8_t *out, uint64_
 }
 
 template <bool IS3D, bool CELLS, bool WIDE, bool LE>
-__global__ __launch_bounds__(kBlock) void colorlut_fast_global_kernel(const uint8_t *in, uint8_t *out, uint64_t width,
+__global__ __launch_bounds__(kBlock) void colorlut_fast_global_kernel(FrameBatch in_fb, FrameBatch out_fb, uint64_t width,
                                                                       uint32_t rows, uint64_t in_stride,
                                                                       uint64_t out_stride, LutParams p)
 {
+    const uint8_t *in = in_fb.base[blockIdx.z]; // one frame pair of the batch per grid z
+    uint8_t *out = out_fb.base[blockIdx.z];
     lf_rows<IS3D, CELLS, WIDE, LE>(in, out, width, rows, in_stride, out_stride, p, p.cube, p.t[0], p.t[1], p.t[2],
                                    blockIdx.x * kBlock + threadIdx.x, gridDim.x * kBlock, blockIdx.y, gridDim.y);
 }
 
 template <bool IS3D, bool WIDE, bool LE>
-__global__ __launch_bounds__(kLdsBlock) void colorlut_fast_lds_kernel(const uint8_t *in, uint8_t *out, uint64_t width,
+__global__ __launch_bounds__(kLdsBlock) void colorlut_fast_lds_kernel(FrameBatch in_fb, FrameBatch out_fb, uint64_t width,
                                                                       uint32_t rows, uint64_t in_stride,
                                                                       uint64_t out_stride, LutParams p)
 {
+    const uint8_t *in = in_fb.base[blockIdx.z]; // one frame pair of the batch per grid z
+    uint8_t *out = out_fb.base[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     if constexpr (IS3D) {
         float4 *cube = reinterpret_cast<float4 *>(lds_raw);
@@ -578,7 +586,7 @@ int ensure_uploaded(mvfx_cube_lut *h)
 }
 
 template <bool IS3D, bool WIDE, bool LE, bool VEC>
-int launch_one(bool use_lds, dim3 grid, size_t lds_bytes, hipStream_t st, const uint8_t *in, uint8_t *out,
+int launch_one(bool use_lds, dim3 grid, size_t lds_bytes, hipStream_t st, const FrameBatch &in, const FrameBatch &out,
                uint64_t width, uint32_t rows, uint64_t is, uint64_t os, const LutParams &p)
 {
     if (use_lds) {
@@ -594,12 +602,28 @@ int launch_one(bool use_lds, dim3 grid, size_t lds_bytes, hipStream_t st, const 
     return MVFX_OK;
 }
 
-int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *in, const mvfx_frame *out, hipStream_t st)
+// n frame pairs sharing geometry and format through one LUT (n == 1: the reference's transform_frame)
+int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *outs, uint32_t n, hipStream_t st)
 {
     if (!h)
         return fail(MVFX_ERR_NO_LUT, "colorlut: No LUT configured (colorlut/imp.rs:209-213)");
-    if (!in || !out)
-        return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: NULL frame");
+    if (!ins || !outs || n == 0)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: NULL frame or empty batch");
+    if (n > (uint32_t)kMaxBatch) { // split into launches of <= kMaxBatch pairs
+        for (uint32_t done = 0; done < n; done += kMaxBatch) {
+            const uint32_t m = (n - done) < (uint32_t)kMaxBatch ? (n - done) : (uint32_t)kMaxBatch;
+            if (int rc = colorlut_impl(h, ins + done, outs + done, m, st); rc != MVFX_OK) return rc;
+        }
+        return MVFX_OK;
+    }
+    const mvfx_frame *in = &ins[0], *out = &outs[0];
+    for (uint32_t i = 1; i < n; i++) {
+        if (ins[i].width != in->width || ins[i].height != in->height || ins[i].stride != in->stride || ins[i].format != in->format ||
+            outs[i].width != out->width || outs[i].height != out->height || outs[i].stride != out->stride || outs[i].format != out->format)
+            return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: frames of one batch must share geometry and format");
+        if (int rc = check_packed_frame(&ins[i], "colorlut input"); rc != MVFX_OK) return rc;
+        if (int rc = check_packed_frame(&outs[i], "colorlut output"); rc != MVFX_OK) return rc;
+    }
     if (in->format != MVFX_FORMAT_RGBA && in->format != MVFX_FORMAT_RGBA64_LE && in->format != MVFX_FORMAT_RGBA64_BE)
         return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "colorlut: format %d is not RGBA / RGBA64_LE / RGBA64_BE (colorlut/imp.rs:122-134)", in->format);
     if (out->format != in->format)
@@ -630,7 +654,13 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *in, const mvfx_frame *out,
     const bool flat = (uint64_t)in->width * bpp == in->stride && (uint64_t)out->width * bpp == out->stride;
     uint64_t width = in->width, is = in->stride, os = out->stride;
     uint32_t rows = in->height;
-    uint64_t align_or = (uint64_t)(uintptr_t)in->data | (uint64_t)(uintptr_t)out->data;
+    FrameBatch ifb{}, ofb{};
+    uint64_t align_or = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        ifb.base[i] = static_cast<uint8_t *>(ins[i].data);
+        ofb.base[i] = static_cast<uint8_t *>(outs[i].data);
+        align_or |= (uint64_t)(uintptr_t)ins[i].data | (uint64_t)(uintptr_t)outs[i].data;
+    }
     if (flat) { width = (uint64_t)in->width * in->height; rows = 1; is = os = 0; }
     else align_or |= is | os;
     const bool vec = (align_or & 15) == 0;
@@ -670,16 +700,22 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *in, const mvfx_frame *out,
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         uint64_t bx = (work + kLdsBlock - 1) / kLdsBlock;
         if (bx > (uint64_t)cus) bx = (uint64_t)cus; // persistent: one workgroup per CU pays the LDS fill once
-        grid = dim3((uint32_t)bx, 1, 1);
-        if (rows > 1) // row-structured frame: spread workgroups over rows instead
-            grid = dim3(1, rows < (uint32_t)cus ? rows : (uint32_t)cus, 1);
+        if (n > 1) { // the CUs are shared by the frames of the batch
+            bx = (bx + n - 1) / n;
+            if (bx == 0) bx = 1;
+        }
+        grid = dim3((uint32_t)bx, 1, n);
+        if (rows > 1) { // row-structured frame: spread workgroups over rows instead
+            uint32_t by = rows < (uint32_t)cus ? rows : (uint32_t)cus;
+            if (n > 1) by = (by + n - 1) / n;
+            grid = dim3(1, by ? by : 1, n);
+        }
     } else {
         uint64_t bx = (work + kBlock - 1) / kBlock;
         if (bx > 65535u * 16u) bx = 65535u * 16u;
-        grid = dim3((uint32_t)bx, rows < 65535u ? rows : 65535u, 1);
+        grid = dim3((uint32_t)bx, rows < 65535u ? rows : 65535u, n);
     }
-    const uint8_t *ip = static_cast<const uint8_t *>(in->data);
-    uint8_t *op = static_cast<uint8_t *>(out->data);
+    const FrameBatch &ip = ifb, &op = ofb;
 
     if (use_fast) {
 #define MVFX_FG(IS3D, CELLS, WIDE, LE) \
@@ -803,7 +839,13 @@ int mvfx_colorlut_set_placement(int placement)
 int mvfx_colorlut_transform_frame(mvfx_cube_lut *lut, const mvfx_frame *in_frame, const mvfx_frame *out_frame,
                                   mvfx_stream stream)
 {
-    return colorlut_impl(lut, in_frame, out_frame, as_stream(stream));
+    return colorlut_impl(lut, in_frame, out_frame, 1, as_stream(stream));
+}
+
+int mvfx_colorlut_transform_frames(mvfx_cube_lut *lut, const mvfx_frame *in_frames, const mvfx_frame *out_frames,
+                                   uint32_t n_frames, mvfx_stream stream)
+{
+    return colorlut_impl(lut, in_frames, out_frames, n_frames, as_stream(stream));
 }
 
 int mvfx_colorlut_transform_frame_host(mvfx_cube_lut *lut, const mvfx_frame *in_frame, const mvfx_frame *out_frame)
@@ -818,7 +860,7 @@ int mvfx_colorlut_transform_frame_host(mvfx_cube_lut *lut, const mvfx_frame *in_
     const size_t ib = (size_t)in_frame->stride * in_frame->height;
     const size_t ob = (size_t)out_frame->stride * out_frame->height;
     if (ib == 0 || ob == 0)
-        return colorlut_impl(lut, in_frame, out_frame, nullptr);
+        return colorlut_impl(lut, in_frame, out_frame, 1, nullptr);
     void *din = nullptr, *dout = nullptr;
     if (int rc = host_scratch(ib, 0, &din); rc != MVFX_OK) return rc;
     if (int rc = host_scratch(ob, 1, &dout); rc != MVFX_OK) return rc;
@@ -830,7 +872,7 @@ int mvfx_colorlut_transform_frame_host(mvfx_cube_lut *lut, const mvfx_frame *in_
     mvfx_frame di = *in_frame, dof = *out_frame;
     di.data = din;
     dof.data = dout;
-    if (int rc = colorlut_impl(lut, &di, &dof, st); rc != MVFX_OK) return rc;
+    if (int rc = colorlut_impl(lut, &di, &dof, 1, st); rc != MVFX_OK) return rc;
     MVFX_HIP_TRY(hipMemcpyAsync(out_frame->data, dout, ob, hipMemcpyDeviceToHost, st));
     MVFX_HIP_TRY(hipStreamSynchronize(st));
     return MVFX_OK;

@@ -199,6 +199,11 @@ const float *mvfx_cube_lut_table_1d(const mvfx_cube_lut *lut, int channel); /* h
  * lut == NULL -> MVFX_ERR_NO_LUT (FlowError::Error, colorlut/imp.rs:209-213). */
 int mvfx_colorlut_transform_frame(mvfx_cube_lut *lut, const mvfx_frame *in_frame,
                                   const mvfx_frame *out_frame, mvfx_stream stream);
+/* n_frames frames (e.g. one of each of n streams graded with the same LUT) in one launch; all pairs share
+ * geometry and format; <= 32 pairs per launch, more are split. */
+int mvfx_colorlut_transform_frames(mvfx_cube_lut *lut, const mvfx_frame *in_frames,
+                                   const mvfx_frame *out_frames, uint32_t n_frames,
+                                   mvfx_stream stream);
 int mvfx_colorlut_transform_frame_host(mvfx_cube_lut *lut, const mvfx_frame *in_frame,
                                        const mvfx_frame *out_frame);
 /* Where the LUT is read from / which kernel runs (per process, for A/B and parity tests):

@@ -75,6 +75,33 @@ def test_colorlut_exhaustive_rgba8(gpu, luts, name):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("name,fmt,w,h,pad", [("analytic33", "RGBA", 256, 33, 0), ("analytic21", "RGBA", 127, 9, 8),
+                                               ("curve1d_4096", "RGBA64_LE", 64, 17, 0), ("analytic9", "RGBA64_BE", 33, 5, 16)])
+def test_colorlut_batch_matches_single(gpu, luts, name, fmt, w, h, pad):
+    """mvfx_colorlut_transform_frames == N single calls (33 pairs cross the 32-pair launch split); LDS-staged, cell-packed,
+    1-D and byte-path layouts; output row padding is left alone."""
+    dev, o = luts[name]
+    n = 33
+    bpp = 8 if fmt != "RGBA" else 4
+    stride = w * bpp + pad
+    ins = [frames.random_frame(0x5EED0600 + k, w, h, bpp, stride) for k in range(n)]
+    din = [gpu.DeviceBuffer(f.nbytes).upload(f) for f in ins]
+    fill = np.full((h, stride), 0x5A, np.uint8)
+    dout = [gpu.DeviceBuffer(fill.nbytes).upload(fill) for _ in range(n)]
+    fi = (gpu.Frame * n)(*[gpu.make_frame(b.ptr, w, h, stride, fmt) for b in din])
+    fo = (gpu.Frame * n)(*[gpu.make_frame(b.ptr, w, h, stride, fmt) for b in dout])
+    gpu.check(gpu.lib().mvfx_colorlut_transform_frames(dev.h, fi, fo, n, None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    for k in range(n):
+        exp = fill.copy()
+        assert o.apply(ins[k], stride, exp, stride, w, h, fmt) == 0
+        assert np.array_equal(dout[k].download().reshape(h, stride), exp), f"pair {k}"
+    fo[1].height = h - 1
+    assert gpu.lib().mvfx_colorlut_transform_frames(dev.h, fi, fo, 2, None) == gpu.ERR_INVALID_ARGUMENT
+    assert gpu.lib().mvfx_colorlut_transform_frames(dev.h, fi, fo, 0, None) == gpu.ERR_INVALID_ARGUMENT
+    assert gpu.lib().mvfx_colorlut_transform_frames(None, fi, fo, 1, None) == gpu.ERR_NO_LUT
+
+
 def test_colorlut_4k_rgba_33(gpu, luts):
     """BASELINE config 3: 33^3 cube, 3840x2160 (RGBx in BASELINE == RGBA here)"""
     dev, o = luts["analytic33"]

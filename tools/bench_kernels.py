@@ -139,6 +139,13 @@ def main():
                     ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fi[i % POOL]), ctypes.byref(fo[i % POOL]), sptr)), iters=300)
                     report(f"colorlut 3D {size}^3 RGBA 4K {data} placement={'auto' if placement == 0 else 'global'}", ms, 2 * NB, 1)
                 vfx.check(lib.mvfx_colorlut_set_placement(0))
+        lut = vfx.CubeLut(cubes.analytic_3d(33))
+        src = natural_like_gpu(POOL, W, H, 11)
+        dst = torch.empty_like(src)
+        fi = (vfx.Frame * POOL)(*[vfx.make_frame(src[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)])
+        fo = (vfx.Frame * POOL)(*[vfx.make_frame(dst[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)])
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frames(lut.h, fi, fo, POOL, sptr)), iters=40)
+        report(f"colorlut 3D 33^3 RGBA 4K natural batch{POOL} (one launch)", ms, 2 * NB * POOL, POOL)
         lut = vfx.CubeLut(cubes.curve_1d(1024))
         src = rand_frames(POOL, NB, 6)
         dst = torch.empty_like(src)
