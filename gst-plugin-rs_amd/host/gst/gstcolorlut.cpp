@@ -90,6 +90,8 @@ static GstFlowReturn gst_color_lut_transform_frame(GstVideoFilter *filter, GstVi
     return MVFX_GST_FLOW(self, rc);
 }
 
+MVFX_DEFINE_HIP_ALLOCATION_VFUNCS(gst_color_lut, gst_color_lut_parent_class)
+
 static GstFlowReturn gst_color_lut_prepare_output_buffer(GstBaseTransform *bt, GstBuffer *inbuf, GstBuffer **outbuf)
 {
     if (!mvfx_buffer_is_hip(inbuf))
@@ -156,6 +158,8 @@ static void gst_color_lut_class_init(GstColorLutClass *klass)
     static const gchar *const only8[] = {"RGBA", NULL};
     mvfx_add_pad_templates(element, mvfx_caps_plus_hip(mvfx_video_caps(has64 ? all : only8)), mvfx_caps_plus_hip(mvfx_video_caps(has64 ? all : only8)));
     GST_BASE_TRANSFORM_CLASS(klass)->prepare_output_buffer = gst_color_lut_prepare_output_buffer;
+    GST_BASE_TRANSFORM_CLASS(klass)->propose_allocation = gst_color_lut_propose_allocation; // d3d12colorlut/imp.rs:385-492
+    GST_BASE_TRANSFORM_CLASS(klass)->decide_allocation = gst_color_lut_decide_allocation;
     GST_BASE_TRANSFORM_CLASS(klass)->transform = gst_color_lut_bt_transform;
     GST_BASE_TRANSFORM_CLASS(klass)->start = gst_color_lut_start;
     GST_BASE_TRANSFORM_CLASS(klass)->stop = gst_color_lut_stop;

@@ -68,6 +68,8 @@ static GstFlowReturn gst_hsv_filter_transform_frame_ip(GstVideoFilter *filter, G
 }
 
 // Device-resident path: a `video/x-raw(memory:HIPMemory)` buffer is filtered in HBM, no PCIe copy.
+MVFX_DEFINE_HIP_ALLOCATION_VFUNCS(gst_hsv_filter, gst_hsv_filter_parent_class)
+
 static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuffer *buf)
 {
     if (!mvfx_buffer_is_hip(buf))
@@ -130,6 +132,8 @@ static void gst_hsv_filter_class_init(GstHsvFilterClass *klass)
     mvfx_add_pad_templates(element, mvfx_caps_plus_hip(mvfx_video_caps(formats)), mvfx_caps_plus_hip(mvfx_video_caps(formats))); // :274-312 (+ HIP twin)
     vfilter->transform_frame_ip = gst_hsv_filter_transform_frame_ip; // AlwaysInPlace (:315-320)
     GST_BASE_TRANSFORM_CLASS(klass)->transform_ip = gst_hsv_filter_bt_transform_ip;
+    GST_BASE_TRANSFORM_CLASS(klass)->propose_allocation = gst_hsv_filter_propose_allocation; // d3d12colorlut/imp.rs:385-492
+    GST_BASE_TRANSFORM_CLASS(klass)->decide_allocation = gst_hsv_filter_decide_allocation;
 }
 
 static void gst_hsv_filter_init(GstHsvFilter *self)
@@ -222,6 +226,8 @@ static GstFlowReturn gst_hsv_detector_transform_frame(GstVideoFilter *filter, Gs
     return MVFX_GST_FLOW(self, rc);
 }
 
+MVFX_DEFINE_HIP_ALLOCATION_VFUNCS(gst_hsv_detector, gst_hsv_detector_parent_class)
+
 static GstFlowReturn gst_hsv_detector_prepare_output_buffer(GstBaseTransform *bt, GstBuffer *inbuf, GstBuffer **outbuf)
 {
     if (!mvfx_buffer_is_hip(inbuf))
@@ -294,6 +300,8 @@ static void gst_hsv_detector_class_init(GstHsvDetectorClass *klass)
     mvfx_add_pad_templates(element, mvfx_caps_plus_hip(mvfx_video_caps(kDetectorIn)), mvfx_caps_plus_hip(mvfx_video_caps(kDetectorOut)));
     GST_BASE_TRANSFORM_CLASS(klass)->transform_caps = gst_hsv_detector_transform_caps;
     GST_BASE_TRANSFORM_CLASS(klass)->prepare_output_buffer = gst_hsv_detector_prepare_output_buffer;
+    GST_BASE_TRANSFORM_CLASS(klass)->propose_allocation = gst_hsv_detector_propose_allocation;
+    GST_BASE_TRANSFORM_CLASS(klass)->decide_allocation = gst_hsv_detector_decide_allocation;
     GST_BASE_TRANSFORM_CLASS(klass)->transform = gst_hsv_detector_bt_transform;
     GST_VIDEO_FILTER_CLASS(klass)->transform_frame = gst_hsv_detector_transform_frame; // NeverInPlace (:380-384)
 }

@@ -46,15 +46,45 @@ static GstFlowReturn hipcopy_prepare_output_buffer(GstBaseTransform *trans, GstB
     const gboolean upload = ((GstMi355HipCopyClass *)G_OBJECT_GET_CLASS(trans))->upload;
     if (!self->have_info)
         return GST_FLOW_NOT_NEGOTIATED;
-    GstAllocator *alloc = upload ? mvfx_hip_allocator_get() : NULL;
-    *outbuf = gst_buffer_new_allocate(alloc, GST_VIDEO_INFO_SIZE(&self->info), NULL);
-    if (alloc) gst_object_unref(alloc);
+    *outbuf = NULL;
+    if (upload) { // device buffers come from the pool negotiated with downstream (hipcopy_decide_allocation)
+        GstBufferPool *pool = gst_base_transform_get_buffer_pool(trans);
+        if (pool) {
+            if (mvfx_is_hip_buffer_pool(pool)) {
+                if (!gst_buffer_pool_is_active(pool))
+                    gst_buffer_pool_set_active(pool, TRUE);
+                if (gst_buffer_pool_acquire_buffer(pool, outbuf, NULL) != GST_FLOW_OK)
+                    *outbuf = NULL;
+            }
+            gst_object_unref(pool);
+        }
+    }
+    if (!*outbuf) {
+        GstAllocator *alloc = upload ? mvfx_hip_allocator_get() : NULL;
+        *outbuf = gst_buffer_new_allocate(alloc, GST_VIDEO_INFO_SIZE(&self->info), NULL);
+        if (alloc) gst_object_unref(alloc);
+    }
     if (!*outbuf) {
         GST_ELEMENT_ERROR(trans, RESOURCE, NO_SPACE_LEFT, ("%s", mvfx_last_error()), (NULL));
         return GST_FLOW_ERROR;
     }
     gst_buffer_copy_into(*outbuf, inbuf, (GstBufferCopyFlags)(GST_BUFFER_COPY_FLAGS | GST_BUFFER_COPY_TIMESTAMPS), 0, -1);
     return GST_FLOW_OK;
+}
+
+// hipupload: SRC caps are HIP -> HIP pool for the output; hipdownload: SINK caps are HIP -> offer one upstream
+static gboolean hipcopy_decide_allocation(GstBaseTransform *trans, GstQuery *query)
+{
+    mvfx_hip_decide_allocation(query); // no-op unless the src caps carry memory:HIPMemory
+    return GST_BASE_TRANSFORM_CLASS(hipcopy_parent_class)->decide_allocation(trans, query);
+}
+
+static gboolean hipcopy_propose_allocation(GstBaseTransform *trans, GstQuery *decide_query, GstQuery *query)
+{
+    if (!GST_BASE_TRANSFORM_CLASS(hipcopy_parent_class)->propose_allocation(trans, decide_query, query))
+        return FALSE;
+    mvfx_hip_propose_allocation(query); // no-op unless the sink caps carry memory:HIPMemory
+    return TRUE;
 }
 
 static GstFlowReturn hipcopy_transform(GstBaseTransform *trans, GstBuffer *inbuf, GstBuffer *outbuf)
@@ -111,6 +141,8 @@ static void hipcopy_class_init_common(GstMi355HipCopyClass *klass, gboolean uplo
     bt->transform_caps = hipcopy_transform_caps;
     bt->set_caps = hipcopy_set_caps;
     bt->prepare_output_buffer = hipcopy_prepare_output_buffer;
+    bt->decide_allocation = hipcopy_decide_allocation;
+    bt->propose_allocation = hipcopy_propose_allocation;
     bt->transform = hipcopy_transform;
     bt->passthrough_on_same_caps = FALSE;
 }

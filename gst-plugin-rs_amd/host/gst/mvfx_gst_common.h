@@ -124,9 +124,22 @@ static inline gboolean mvfx_hip_map_frame(GstBuffer *buf, const GstVideoInfo *in
 // the output frame size with the input's flags and timestamps
 static inline GstFlowReturn mvfx_hip_new_output(GstBaseTransform *trans, GstBuffer *inbuf, gsize size, GstBuffer **outbuf)
 {
-    GstAllocator *alloc = mvfx_hip_allocator_get();
-    *outbuf = gst_buffer_new_allocate(alloc, size, NULL);
-    gst_object_unref(alloc);
+    *outbuf = NULL;
+    GstBufferPool *pool = gst_base_transform_get_buffer_pool(trans); // negotiated by decide_allocation
+    if (pool) {
+        if (mvfx_is_hip_buffer_pool(pool)) {
+            if (!gst_buffer_pool_is_active(pool))
+                gst_buffer_pool_set_active(pool, TRUE);
+            if (gst_buffer_pool_acquire_buffer(pool, outbuf, NULL) != GST_FLOW_OK)
+                *outbuf = NULL;
+        }
+        gst_object_unref(pool);
+    }
+    if (!*outbuf) { // no ALLOCATION query answered yet / foreign pool: a one-off device buffer
+        GstAllocator *alloc = mvfx_hip_allocator_get();
+        *outbuf = gst_buffer_new_allocate(alloc, size, NULL);
+        gst_object_unref(alloc);
+    }
     if (!*outbuf) {
         GST_ELEMENT_ERROR(trans, RESOURCE, NO_SPACE_LEFT, ("%s", mvfx_last_error()), (NULL));
         return GST_FLOW_ERROR;
@@ -134,6 +147,22 @@ static inline GstFlowReturn mvfx_hip_new_output(GstBaseTransform *trans, GstBuff
     gst_buffer_copy_into(*outbuf, inbuf, (GstBufferCopyFlags)(GST_BUFFER_COPY_FLAGS | GST_BUFFER_COPY_TIMESTAMPS), 0, -1);
     return GST_FLOW_OK;
 }
+
+// propose_allocation / decide_allocation shared by the elements: the base class first, then the HIP pool
+// when the negotiated caps carry memory:HIPMemory (no-ops on system-memory caps)
+#define MVFX_DEFINE_HIP_ALLOCATION_VFUNCS(prefix, parent_class_ptr)                                                   \
+    static gboolean prefix##_propose_allocation(GstBaseTransform *trans, GstQuery *decide_query, GstQuery *query)     \
+    {                                                                                                                 \
+        if (!GST_BASE_TRANSFORM_CLASS(parent_class_ptr)->propose_allocation(trans, decide_query, query))              \
+            return FALSE;                                                                                             \
+        mvfx_hip_propose_allocation(query);                                                                           \
+        return TRUE;                                                                                                  \
+    }                                                                                                                 \
+    static gboolean prefix##_decide_allocation(GstBaseTransform *trans, GstQuery *query)                              \
+    {                                                                                                                 \
+        mvfx_hip_decide_allocation(query);                                                                            \
+        return GST_BASE_TRANSFORM_CLASS(parent_class_ptr)->decide_allocation(trans, query);                           \
+    }
 
 static inline void mvfx_add_pad_templates(GstElementClass *klass, GstCaps *sink_caps, GstCaps *src_caps)
 {

@@ -183,3 +183,169 @@ GstCaps *mvfx_caps_with_hip_feature(const GstCaps *system_caps)
 {
     return mvfx_caps_set_hip_feature(system_caps, TRUE);
 }
+
+// ------------------------------------------------------------------------------------ buffer pool
+
+typedef struct {
+    GstBufferPool parent;
+    GstVideoInfo info;
+    gboolean have_info;
+    gsize size;
+} MvfxHipBufferPool;
+typedef struct { GstBufferPoolClass parent_class; } MvfxHipBufferPoolClass;
+
+G_DEFINE_TYPE(MvfxHipBufferPool, mvfx_hip_buffer_pool, GST_TYPE_BUFFER_POOL)
+
+GST_DEBUG_CATEGORY_STATIC(mvfx_hip_pool_debug);
+static volatile gint64 pool_allocated = 0, pool_acquired = 0;
+
+static const gchar **mvfx_hip_pool_get_options(GstBufferPool *)
+{
+    static const gchar *options[] = {GST_BUFFER_POOL_OPTION_VIDEO_META, NULL};
+    return options;
+}
+
+static gboolean mvfx_hip_pool_set_config(GstBufferPool *pool, GstStructure *config)
+{
+    MvfxHipBufferPool *self = (MvfxHipBufferPool *)pool;
+    GstCaps *caps = NULL;
+    guint size = 0, min = 0, max = 0;
+    if (!gst_buffer_pool_config_get_params(config, &caps, &size, &min, &max) || !caps)
+        return FALSE;
+    self->have_info = gst_video_info_from_caps(&self->info, caps);
+    if (self->have_info && GST_VIDEO_INFO_SIZE(&self->info) > size) {
+        size = (guint)GST_VIDEO_INFO_SIZE(&self->info);
+        gst_buffer_pool_config_set_params(config, caps, size, min, max);
+    }
+    self->size = size;
+    GST_CAT_DEBUG_OBJECT(mvfx_hip_pool_debug, pool, "configured: %" GST_PTR_FORMAT " size %u min %u max %u", caps, size, min, max);
+    return GST_BUFFER_POOL_CLASS(mvfx_hip_buffer_pool_parent_class)->set_config(pool, config);
+}
+
+static GstFlowReturn mvfx_hip_pool_alloc_buffer(GstBufferPool *pool, GstBuffer **buffer, GstBufferPoolAcquireParams *)
+{
+    MvfxHipBufferPool *self = (MvfxHipBufferPool *)pool;
+    GstAllocator *alloc = mvfx_hip_allocator_get();
+    GstBuffer *buf = gst_buffer_new_allocate(alloc, self->size, NULL);
+    gst_object_unref(alloc);
+    if (!buf)
+        return GST_FLOW_ERROR;
+    if (self->have_info) // device buffers always use the default GstVideoInfo layout
+        gst_buffer_add_video_meta_full(buf, GST_VIDEO_FRAME_FLAG_NONE, GST_VIDEO_INFO_FORMAT(&self->info),
+                                       GST_VIDEO_INFO_WIDTH(&self->info), GST_VIDEO_INFO_HEIGHT(&self->info),
+                                       GST_VIDEO_INFO_N_PLANES(&self->info), self->info.offset, self->info.stride);
+    __atomic_add_fetch(&pool_allocated, 1, __ATOMIC_RELAXED);
+    GST_CAT_LOG_OBJECT(mvfx_hip_pool_debug, pool, "allocated device buffer %p (%" G_GSIZE_FORMAT " bytes)", (void *)buf, self->size);
+    *buffer = buf;
+    return GST_FLOW_OK;
+}
+
+static GstFlowReturn mvfx_hip_pool_acquire_buffer(GstBufferPool *pool, GstBuffer **buffer, GstBufferPoolAcquireParams *params)
+{
+    const GstFlowReturn ret = GST_BUFFER_POOL_CLASS(mvfx_hip_buffer_pool_parent_class)->acquire_buffer(pool, buffer, params);
+    if (ret == GST_FLOW_OK)
+        __atomic_add_fetch(&pool_acquired, 1, __ATOMIC_RELAXED);
+    return ret;
+}
+
+static void mvfx_hip_buffer_pool_class_init(MvfxHipBufferPoolClass *klass)
+{
+    GstBufferPoolClass *pc = GST_BUFFER_POOL_CLASS(klass);
+    pc->get_options = mvfx_hip_pool_get_options;
+    pc->set_config = mvfx_hip_pool_set_config;
+    pc->alloc_buffer = mvfx_hip_pool_alloc_buffer;
+    pc->acquire_buffer = mvfx_hip_pool_acquire_buffer;
+    GST_DEBUG_CATEGORY_INIT(mvfx_hip_pool_debug, "mvfxhippool", 0, "MI355X HIP device-memory buffer pool");
+}
+
+static void mvfx_hip_buffer_pool_init(MvfxHipBufferPool *self)
+{
+    self->have_info = FALSE;
+    self->size = 0;
+}
+
+GstBufferPool *mvfx_hip_buffer_pool_new(void)
+{
+    GstBufferPool *pool = (GstBufferPool *)g_object_new(mvfx_hip_buffer_pool_get_type(), NULL);
+    gst_object_ref_sink(pool);
+    return pool;
+}
+
+gboolean mvfx_is_hip_buffer_pool(GstBufferPool *pool)
+{
+    return pool && G_TYPE_CHECK_INSTANCE_TYPE(pool, mvfx_hip_buffer_pool_get_type());
+}
+
+guint64 mvfx_hip_pool_buffers_allocated(void) { return (guint64)__atomic_load_n(&pool_allocated, __ATOMIC_RELAXED); }
+guint64 mvfx_hip_pool_buffers_acquired(void) { return (guint64)__atomic_load_n(&pool_acquired, __ATOMIC_RELAXED); }
+
+static GstBufferPool *new_configured_pool(GstCaps *caps, guint size)
+{
+    GstBufferPool *pool = mvfx_hip_buffer_pool_new();
+    GstStructure *config = gst_buffer_pool_get_config(pool);
+    gst_buffer_pool_config_set_params(config, caps, size, 0, 0);
+    gst_buffer_pool_config_add_option(config, GST_BUFFER_POOL_OPTION_VIDEO_META);
+    if (!gst_buffer_pool_set_config(pool, config)) {
+        gst_object_unref(pool);
+        return NULL;
+    }
+    return pool;
+}
+
+gboolean mvfx_hip_propose_allocation(GstQuery *query)
+{
+    GstCaps *caps = NULL;
+    gboolean need_pool = FALSE;
+    gst_query_parse_allocation(query, &caps, &need_pool);
+    GstVideoInfo info;
+    if (!caps || !mvfx_caps_has_hip_feature(caps) || !gst_video_info_from_caps(&info, caps))
+        return FALSE;
+    const guint size = (guint)GST_VIDEO_INFO_SIZE(&info);
+    GstBufferPool *pool = need_pool ? new_configured_pool(caps, size) : NULL;
+    gst_query_add_allocation_pool(query, pool, size, 0, 0);
+    if (pool)
+        gst_object_unref(pool);
+    GstAllocator *alloc = mvfx_hip_allocator_get();
+    gst_query_add_allocation_param(query, alloc, NULL);
+    gst_object_unref(alloc);
+    gst_query_add_allocation_meta(query, GST_VIDEO_META_API_TYPE, NULL);
+    return TRUE;
+}
+
+gboolean mvfx_hip_decide_allocation(GstQuery *query)
+{
+    GstCaps *caps = NULL;
+    gst_query_parse_allocation(query, &caps, NULL);
+    GstVideoInfo info;
+    if (!caps || !mvfx_caps_has_hip_feature(caps) || !gst_video_info_from_caps(&info, caps))
+        return FALSE;
+    guint size = (guint)GST_VIDEO_INFO_SIZE(&info), min = 0, max = 0;
+    GstBufferPool *pool = NULL;
+    const gboolean have = gst_query_get_n_allocation_pools(query) > 0;
+    if (have) {
+        guint psize = 0;
+        gst_query_parse_nth_allocation_pool(query, 0, &pool, &psize, &min, &max);
+        if (psize > size)
+            size = psize;
+        if (pool && !mvfx_is_hip_buffer_pool(pool)) { // a system-memory pool cannot back memory:HIPMemory caps
+            gst_object_unref(pool);
+            pool = NULL;
+        }
+    }
+    if (!pool)
+        pool = new_configured_pool(caps, size);
+    if (!pool)
+        return FALSE;
+    if (have)
+        gst_query_set_nth_allocation_pool(query, 0, pool, size, min, max);
+    else
+        gst_query_add_allocation_pool(query, pool, size, min, max);
+    gst_object_unref(pool);
+    // the base class would otherwise hand the pool a system-memory allocator from the query's params
+    while (gst_query_get_n_allocation_params(query) > 0)
+        gst_query_remove_nth_allocation_param(query, 0);
+    GstAllocator *alloc = mvfx_hip_allocator_get();
+    gst_query_add_allocation_param(query, alloc, NULL);
+    gst_object_unref(alloc);
+    return TRUE;
+}

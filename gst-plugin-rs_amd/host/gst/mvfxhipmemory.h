@@ -26,4 +26,18 @@ GstCaps *mvfx_caps_with_hip_feature(const GstCaps *system_caps);
 // copy of `caps` with every structure's features replaced by memory:HIPMemory / system memory
 GstCaps *mvfx_caps_set_hip_feature(const GstCaps *caps, gboolean hip);
 
+
+// ---- buffer pool + ALLOCATION query helpers (the reference's d3d12colorlut does the same with
+// GstD3D12BufferPool: video/colorlut/src/d3d12colorlut/imp.rs:385-492) ----
+GstBufferPool *mvfx_hip_buffer_pool_new(void);        // buffers = ONE HIP memory of the configured size + GstVideoMeta
+gboolean mvfx_is_hip_buffer_pool(GstBufferPool *pool);
+// propose_allocation of an element whose SINK caps carry memory:HIPMemory: offers a HIP pool of the frame
+// size, the HIP allocator and GstVideoMeta support.  Returns FALSE (nothing added) for system-memory caps.
+gboolean mvfx_hip_propose_allocation(GstQuery *query);
+// decide_allocation of an element whose SRC caps carry memory:HIPMemory: makes sure pool 0 of the query is a
+// HIP pool (the one downstream proposed, or a new one).  Call before chaining up to the base class.
+gboolean mvfx_hip_decide_allocation(GstQuery *query);
+guint64 mvfx_hip_pool_buffers_allocated(void);        // process-wide counters for tests / debugging
+guint64 mvfx_hip_pool_buffers_acquired(void);
+
 G_END_DECLS

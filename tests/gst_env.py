@@ -32,5 +32,8 @@ def env(tmpdir):
     return e
 
 
-def run(args, tmpdir, timeout=120):
-    return subprocess.run(args, env=env(tmpdir), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+def run(args, tmpdir, timeout=120, extra_env=None):
+    e = env(tmpdir)
+    if extra_env:
+        e.update(extra_env)
+    return subprocess.run(args, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)

@@ -196,3 +196,21 @@ def test_hipmemory_colordetect_and_cpu_consumer(gpu, tmp_path):
     exp = np.tile(np.array((255, 0, 0, 255), np.uint8), 2 * 240 * 320).reshape(2 * 240, 320 * 4)
     orc.hsvfilter(exp, 320, 320 * 4, "RGBA", (120.0, 1.0, 0.0, 1.0, 0.0))
     assert np.array_equal(got, exp)
+
+
+def test_hipmemory_buffers_come_from_the_negotiated_pool(gpu, tmp_path):
+    """ALLOCATION query (SURVEY 8f-1, d3d12colorlut/imp.rs:385-492): hipupload, hsvdetector and colorlut take their
+    device output buffers from MvfxHipBufferPool instances negotiated with their peers, and the pools recycle:
+    40 frames through three out-of-place elements need a handful of device buffers, not 120."""
+    cube = tmp_path / "look.cube"
+    cube.write_text(cubes.analytic_3d(9))
+    n = 40
+    pipeline = (f"videotestsrc num-buffers={n} ! video/x-raw,format=RGBx,width=320,height=240 ! hipupload ! hsvfilter hue-shift=30 "
+                "! hsvdetector ! video/x-raw(memory:HIPMemory),format=RGBA "
+                f"! colorlut location={cube} ! hipdownload ! fakesink")
+    r = gst_env.run([LAUNCH] + pipeline.split(), tmp_path, extra_env={"GST_DEBUG": "mvfxhippool:6", "GST_DEBUG_NO_COLOR": "1"})
+    assert r.returncode == 0, r.stdout
+    configured = re.findall(r"mvfxhippool.*configured: video/x-raw\(memory:HIPMemory\)", r.stdout)
+    allocated = re.findall(r"mvfxhippool.*allocated device buffer", r.stdout)
+    assert len(configured) >= 3, r.stdout[-2000:]          # upload, detector and colorlut outputs
+    assert 3 <= len(allocated) <= 24, (len(allocated), r.stdout[-2000:])  # recycled, far fewer than 3 * 40

@@ -184,6 +184,8 @@ def main():
 
     if want("ssim"):
         for (w, h, tag) in ((W, H, "4K"), (7680, 4320, "8K")):
+            if os.environ.get("SSIM_ONLY", tag) != tag:
+                continue
             src = rand_frames(2, w * h * 4, 12)
             src[1] = src[0]
             src[1, :: 97] ^= 0x10
