@@ -222,7 +222,7 @@ int mvfx_colorlut_set_placement(int placement);
 
 /* Histogram + 5-bit channel min/max of samples [first_sample, first_sample+n_samples) of the
  * frame (sample k = pixel k*quality of the flat plane); pass n_samples = UINT64_MAX for all.
- * hist_device: 32768 u32, minmax_device: 6 u32 {rmin,rmax,gmin,gmax,bmin,bmax}; both are
+ * hist_device: 32768 u32 (16-byte aligned), minmax_device: 6 u32 {rmin,rmax,gmin,gmax,bmin,bmax}; both are
  * overwritten.  A sample range exists so that ranks can split one frame and all-reduce
  * (sum the histogram, min/max the bounds).  Formats RGB RGBA ARGB BGR BGRA; quality 1..=10. */
 int mvfx_colordetect_histogram(const mvfx_frame *frame, uint32_t quality, uint64_t first_sample,

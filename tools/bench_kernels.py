@@ -169,6 +169,11 @@ def main():
             ms = timeit(lambda i=0: vfx.check(lib.mvfx_colordetect_histogram(ctypes.byref(fr[i % POOL]), q, 0, vfx.ALL_SAMPLES,
                         ctypes.c_void_p(hist.data_ptr()), ctypes.c_void_p(hist.data_ptr() + 32768 * 4), sptr)), iters=300)
             report(f"colordetect histogram 4K RGBA quality={q}", ms, NB, 1)
+        srcn = natural_like_gpu(POOL, W, H, 13)
+        frn = [vfx.make_frame(srcn[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_colordetect_histogram(ctypes.byref(frn[i % POOL]), 10, 0, vfx.ALL_SAMPLES,
+                    ctypes.c_void_p(hist.data_ptr()), ctypes.c_void_p(hist.data_ptr() + 32768 * 4), sptr)), iters=300)
+        report("colordetect histogram 4K RGBA quality=10 natural content", ms, NB, 1)
 
     if want("blockhash"):
         W8, H8 = 7680, 4320
