@@ -40,41 +40,17 @@ struct Planes {
 
 // All kernels work on the row range [y0, y0 + gridDim.y) of absolutely indexed full-size planes: a rank that
 // owns a row band only fills the band plus the halo the coarser scales and the 5x5 window need.
-__global__ __launch_bounds__(kBlock) void ssim_linearize_kernel(const uint8_t *frame, int w, int y0, uint64_t stride, int bpp,
-                                                                const double *lut, Planes out)
-{
-    const int x = blockIdx.x * kBlock + threadIdx.x, y = y0 + blockIdx.y;
-    if (x >= w) return;
-    const uint8_t *p = frame + (uint64_t)y * stride + (uint64_t)x * bpp;
-    const double a = bpp == 4 ? p[3] / 255.0 : 1.0; // premultiplied alpha
-    const size_t i = (size_t)y * w + x;
-    out.p[0][i] = lut[p[0]] * a;
-    out.p[1][i] = lut[p[1]] * a;
-    out.p[2][i] = lut[p[2]] * a;
-}
-
-__global__ __launch_bounds__(kBlock) void ssim_downsample_kernel(Planes in, Planes out, int y0)
-{
-    const int x = blockIdx.x * kBlock + threadIdx.x, y = y0 + blockIdx.y;
-    if (x >= out.w) return;
-    for (int c = 0; c < 3; c++) {
-        const double *r0 = in.p[c] + (size_t)(2 * y) * in.w + 2 * x, *r1 = r0 + in.w;
-        out.p[c][(size_t)y * out.w + x] = (r0[0] + r0[1] + r1[0] + r1[1]) * 0.25;
-    }
-}
-
+// Full-resolution linear RGB is never stored: scale 0 goes straight from the bytes to the Lab planes, scale 1
+// averages the four source pixels itself, and every coarser level writes its linear planes (for the next
+// level) and its Lab planes (for the map) in one pass -- 1.8 GB instead of 4.3 GB of f64 traffic per 8K image.
 __device__ __forceinline__ double lab_f(double t)
 {
     const double eps = 216.0 / 24389.0, kappa = 24389.0 / 27.0;
     return t > eps ? cbrt(t) : (kappa * t + 16.0) / 116.0;
 }
 
-__global__ __launch_bounds__(kBlock) void ssim_lab_kernel(Planes lin, Planes lab, int y0)
+__device__ __forceinline__ void store_lab(const Planes &lab, size_t i, double r, double g, double b)
 {
-    const int x = blockIdx.x * kBlock + threadIdx.x;
-    if (x >= lin.w) return;
-    const size_t i = (size_t)(y0 + blockIdx.y) * lin.w + x;
-    const double r = lin.p[0][i], g = lin.p[1][i], b = lin.p[2][i];
     const double X = (0.4124 * r + 0.3576 * g + 0.1805 * b) / 0.9505;
     const double Y = 0.2126 * r + 0.7152 * g + 0.0722 * b;
     const double Z = (0.0193 * r + 0.1192 * g + 0.9505 * b) / 1.089;
@@ -82,6 +58,61 @@ __global__ __launch_bounds__(kBlock) void ssim_lab_kernel(Planes lin, Planes lab
     lab.p[0][i] = (116.0 * fy - 16.0) / 100.0;
     lab.p[1][i] = (86.2 + 500.0 * (fx - fy)) / 220.0;
     lab.p[2][i] = (107.9 + 200.0 * (fy - fz)) / 220.0;
+}
+
+// linear RGB of one source pixel, alpha premultiplied
+__device__ __forceinline__ void linear_px(const uint8_t *p, int bpp, const double *lut, double &r, double &g, double &b)
+{
+    const double a = bpp == 4 ? p[3] / 255.0 : 1.0;
+    r = lut[p[0]] * a; g = lut[p[1]] * a; b = lut[p[2]] * a;
+}
+
+// scale 0: bytes -> Lab
+__global__ __launch_bounds__(kBlock) void ssim_lab0_kernel(const uint8_t *frame, int y0, uint64_t stride, int bpp,
+                                                           const double *lut, Planes lab)
+{
+    const int x = blockIdx.x * kBlock + threadIdx.x, y = y0 + blockIdx.y;
+    if (x >= lab.w) return;
+    double r, g, b;
+    linear_px(frame + (uint64_t)y * stride + (uint64_t)x * bpp, bpp, lut, r, g, b);
+    store_lab(lab, (size_t)y * lab.w + x, r, g, b);
+}
+
+// scale 1: 2x2 box of the linearised source pixels -> linear planes + Lab planes of the half-size image
+__global__ __launch_bounds__(kBlock) void ssim_down1_kernel(const uint8_t *frame, int y0, uint64_t stride, int bpp,
+                                                            const double *lut, Planes lin, Planes lab)
+{
+    const int x = blockIdx.x * kBlock + threadIdx.x, y = y0 + blockIdx.y;
+    if (x >= lin.w) return;
+    const uint8_t *r0 = frame + (uint64_t)(2 * y) * stride + (uint64_t)(2 * x) * bpp, *r1 = r0 + stride;
+    double v[4][3];
+    linear_px(r0, bpp, lut, v[0][0], v[0][1], v[0][2]);
+    linear_px(r0 + bpp, bpp, lut, v[1][0], v[1][1], v[1][2]);
+    linear_px(r1, bpp, lut, v[2][0], v[2][1], v[2][2]);
+    linear_px(r1 + bpp, bpp, lut, v[3][0], v[3][1], v[3][2]);
+    double o[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+        o[c] = (v[0][c] + v[1][c] + v[2][c] + v[3][c]) * 0.25;
+    const size_t i = (size_t)y * lin.w + x;
+    lin.p[0][i] = o[0]; lin.p[1][i] = o[1]; lin.p[2][i] = o[2];
+    store_lab(lab, i, o[0], o[1], o[2]);
+}
+
+// scale >= 2: 2x2 box of the previous level's linear planes -> this level's linear + Lab planes
+__global__ __launch_bounds__(kBlock) void ssim_downlab_kernel(Planes in, Planes lin, Planes lab, int y0)
+{
+    const int x = blockIdx.x * kBlock + threadIdx.x, y = y0 + blockIdx.y;
+    if (x >= lin.w) return;
+    double o[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double *r0 = in.p[c] + (size_t)(2 * y) * in.w + 2 * x, *r1 = r0 + in.w;
+        o[c] = (r0[0] + r0[1] + r1[0] + r1[1]) * 0.25;
+    }
+    const size_t i = (size_t)y * lin.w + x;
+    lin.p[0][i] = o[0]; lin.p[1][i] = o[1]; lin.p[2][i] = o[2];
+    store_lab(lab, i, o[0], o[1], o[2]);
 }
 
 __device__ __forceinline__ double block_sum(double v)
@@ -97,65 +128,62 @@ __device__ __forceinline__ double block_sum(double v)
     return t; // valid in thread 0
 }
 
-// SSIM map of rows [y0,y1) of one scale + its sum.  The 5x5 binomial window is separable: a lane owns one
-// column of a kSeg-row segment and walks down it, per row 5 + 5 loads (the neighbours' loads hit L1) give the
-// five horizontally blurred moments, a 5-row ring of them in registers gives the vertical pass -- 10 loads
-// and ~50 f64 FMAs per pixel and channel instead of 50 loads and ~125 (first version: 313 us average per call).
+// SSIM map of rows [y0,y1) of one scale + its sum.  The 5x5 binomial window is separable: a workgroup owns a
+// 64 x kSeg tile; pass A computes the five horizontally blurred moments of the tile's kSeg + 4 rows (every
+// (row, column) entry is an independent 5 + 5 load job, so the loads of a tile are all in flight together) into
+// LDS, pass B runs the vertical blur down each column from LDS (8 rows x 5 moments per 4 outputs) and the
+// SSIM term.  First version (25-tap window per pixel from global memory): 1.7 ms for the 8K scale-0 map.
 constexpr int kSeg = 16;
+constexpr int kTileW = 64;
 
 __global__ __launch_bounds__(kBlock) void ssim_map_kernel(Planes a, Planes b, int y0, int y1, double *map, double *sum)
 {
+    __shared__ double H[5][kSeg + 4][kTileW]; // 51 KB
     const int w = a.w, h = a.h;
-    const int x = blockIdx.x * kBlock + threadIdx.x;
-    const int seg0 = y0 + blockIdx.y * kSeg;
-    const bool live = x < w;
+    const int tx0 = blockIdx.x * kTileW, ty0 = y0 + blockIdx.y * kSeg;
     const double B0 = 1.0 / 16, B1 = 4.0 / 16, B2 = 6.0 / 16;
-    int xs[5];
-#pragma unroll
-    for (int d = 0; d < 5; d++)
-        xs[d] = min(max(x + d - 2, 0), w - 1);
-    double acc[kSeg];
-#pragma unroll
-    for (int r = 0; r < kSeg; r++) acc[r] = 0.0;
+    const int col = threadIdx.x % kTileW, rg = threadIdx.x / kTileW; // pass B: column, group of 4 rows
+    double acc[4] = {0, 0, 0, 0};
 #pragma unroll 1
     for (int c = 0; c < 3; c++) {
         const double *pa = a.p[c], *pb = b.p[c];
-        double ring[5][5]; // [row slot][moment]: m1, m2, s11, s22, s12 after the horizontal pass
-#pragma unroll
-        for (int i = 0; i < kSeg + 4; i++) {
-            const int yy = min(max(seg0 + i - 2, 0), h - 1);
-            const size_t row = (size_t)yy * w;
-            double v1[5], v2[5];
-#pragma unroll
-            for (int d = 0; d < 5; d++) { v1[d] = pa[row + xs[d]]; v2[d] = pb[row + xs[d]]; }
+        for (int e = threadIdx.x; e < (kSeg + 4) * kTileW; e += kBlock) {
+            const int row = e / kTileW, cc = e % kTileW;
+            const int yy = min(max(ty0 - 2 + row, 0), h - 1);
+            const size_t base = (size_t)yy * w;
+            const int x = tx0 + cc;
             double hm[5] = {0, 0, 0, 0, 0};
 #pragma unroll
             for (int d = 0; d < 5; d++) {
+                const int xx = min(max(x + d - 2, 0), w - 1);
+                const double v1 = pa[base + xx], v2 = pb[base + xx];
                 const double wgt = d == 2 ? B2 : ((d == 1 || d == 3) ? B1 : B0);
-                hm[0] += wgt * v1[d]; hm[1] += wgt * v2[d];
-                hm[2] += wgt * v1[d] * v1[d]; hm[3] += wgt * v2[d] * v2[d]; hm[4] += wgt * v1[d] * v2[d];
+                hm[0] += wgt * v1; hm[1] += wgt * v2;
+                hm[2] += wgt * v1 * v1; hm[3] += wgt * v2 * v2; hm[4] += wgt * v1 * v2;
             }
 #pragma unroll
-            for (int q = 0; q < 5; q++) {
-                ring[0][q] = ring[1][q]; ring[1][q] = ring[2][q]; ring[2][q] = ring[3][q]; ring[3][q] = ring[4][q];
-                ring[4][q] = hm[q];
-            }
-            if (i >= 4) { // rows seg0 + i - 4 - 2 .. seg0 + i - 2 are in the ring: output row r = i - 4
-                double m[5];
-#pragma unroll
-                for (int q = 0; q < 5; q++)
-                    m[q] = B0 * (ring[0][q] + ring[4][q]) + B1 * (ring[1][q] + ring[3][q]) + B2 * ring[2][q];
-                const double m1 = m[0], m2 = m[1];
-                const double s11 = m[2] - m1 * m1, s22 = m[3] - m2 * m2, s12 = m[4] - m1 * m2;
-                acc[i - 4] += ((2.0 * m1 * m2 + kC1) * (2.0 * s12 + kC2)) / ((m1 * m1 + m2 * m2 + kC1) * (s11 + s22 + kC2));
-            }
+            for (int q = 0; q < 5; q++) H[q][row][cc] = hm[q];
         }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int tr = rg * 4 + r; // output row of the tile; window rows tr .. tr + 4 of H
+            double m[5];
+#pragma unroll
+            for (int q = 0; q < 5; q++)
+                m[q] = B0 * (H[q][tr][col] + H[q][tr + 4][col]) + B1 * (H[q][tr + 1][col] + H[q][tr + 3][col]) + B2 * H[q][tr + 2][col];
+            const double m1 = m[0], m2 = m[1];
+            const double s11 = m[2] - m1 * m1, s22 = m[3] - m2 * m2, s12 = m[4] - m1 * m2;
+            acc[r] += ((2.0 * m1 * m2 + kC1) * (2.0 * s12 + kC2)) / ((m1 * m1 + m2 * m2 + kC1) * (s11 + s22 + kC2));
+        }
+        __syncthreads();
     }
     double total = 0.0;
+    const int x = tx0 + col;
 #pragma unroll
-    for (int r = 0; r < kSeg; r++) {
-        const int y = seg0 + r;
-        if (live && y < y1) {
+    for (int r = 0; r < 4; r++) {
+        const int y = ty0 + rg * 4 + r;
+        if (x < w && y < y1) {
             const double val = acc[r] / 3.0;
             map[(size_t)y * w + x] = val;
             total += val;
@@ -180,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void ssim_dev_kernel(const double *map, int
 struct SsimState {
     std::vector<void *> allocations;
     int w0 = 0, h0 = 0, device = -1;
-    Planes lin[2], nxt[2], lab[2];
+    Planes half[2], quarter[2], lab[2]; // linear RGB of the odd / even coarser scales (ping-pong), Lab of the current scale
     double *map[kScales] = {};
     int w[kScales] = {}, h[kScales] = {}, y0[kScales] = {}, y1[kScales] = {};
     int scales = 0;        // of the last mvfx_ssim_partial_sums on this thread (0: none pending)
@@ -235,9 +263,9 @@ int ensure_scratch(SsimState &S, int w0, int h0, hipStream_t st)
     MVFX_HIP_TRY(hipMemcpyAsync(S.d_lut, lut, sizeof(lut), hipMemcpyHostToDevice, st));
     MVFX_HIP_TRY(hipStreamSynchronize(st)); // `lut` is a stack buffer
     for (int i = 0; i < 2; i++) {
-        if (int rc = alloc_planes(S, w0, h0, &S.lin[i]); rc != MVFX_OK) return rc;
         if (int rc = alloc_planes(S, w0, h0, &S.lab[i]); rc != MVFX_OK) return rc;
-        if (int rc = alloc_planes(S, w0 / 2, h0 / 2, &S.nxt[i]); rc != MVFX_OK) return rc;
+        if (int rc = alloc_planes(S, w0 / 2, h0 / 2, &S.half[i]); rc != MVFX_OK) return rc;
+        if (int rc = alloc_planes(S, std::max(w0 / 4, 1), std::max(h0 / 4, 1), &S.quarter[i]); rc != MVFX_OK) return rc;
     }
     int w = w0, h = h0;
     for (int s = 0; s < kScales; s++) {
@@ -313,32 +341,30 @@ int mvfx_ssim_partial_sums(const mvfx_frame *reference_frame, const mvfx_frame *
         }
     }
 
-    Planes lin[2] = {S.lin[0], S.lin[1]}, nxt[2] = {S.nxt[0], S.nxt[1]}, lab[2] = {S.lab[0], S.lab[1]};
-    if (b[0] > a[0])
-        for (int i = 0; i < 2; i++) {
-            const int bpp = fr[i]->format == MVFX_FORMAT_RGBA ? 4 : 3;
-            lin[i].w = w0; lin[i].h = h0;
-            hipLaunchKernelGGL(ssim_linearize_kernel, grid2d(w0, b[0] - a[0]), dim3(kBlock), 0, st,
-                               static_cast<const uint8_t *>(fr[i]->data), w0, a[0], (uint64_t)fr[i]->stride, bpp, S.d_lut, lin[i]);
-        }
     for (int s = 0; s < n_scales; s++) {
         const int w = ws[s], h = hs[s];
-        if (s > 0 && b[s] > a[s])
-            for (int i = 0; i < 2; i++) {
-                Planes out = nxt[i], in = lin[i];
-                out.w = w; out.h = h;
-                in.w = ws[s - 1]; in.h = hs[s - 1];
-                hipLaunchKernelGGL(ssim_downsample_kernel, grid2d(w, b[s] - a[s]), dim3(kBlock), 0, st, in, out, a[s]);
-                std::swap(lin[i], nxt[i]); // buffers are sized for scale 0 / scale 1: both large enough further down
-            }
+        Planes lab[2];
         if (b[s] > a[s])
             for (int i = 0; i < 2; i++) {
-                lin[i].w = w; lin[i].h = h;
+                const int bpp = fr[i]->format == MVFX_FORMAT_RGBA ? 4 : 3;
+                const uint8_t *src = static_cast<const uint8_t *>(fr[i]->data);
+                lab[i] = S.lab[i];
                 lab[i].w = w; lab[i].h = h;
-                hipLaunchKernelGGL(ssim_lab_kernel, grid2d(w, b[s] - a[s]), dim3(kBlock), 0, st, lin[i], lab[i], a[s]);
+                Planes out = (s & 1) ? S.half[i] : S.quarter[i]; // scale 1, 3 -> half-size buffer; 2, 4 -> quarter-size buffer
+                out.w = w; out.h = h;
+                const dim3 grid = grid2d(w, b[s] - a[s]);
+                if (s == 0) {
+                    hipLaunchKernelGGL(ssim_lab0_kernel, grid, dim3(kBlock), 0, st, src, a[0], (uint64_t)fr[i]->stride, bpp, S.d_lut, lab[i]);
+                } else if (s == 1) {
+                    hipLaunchKernelGGL(ssim_down1_kernel, grid, dim3(kBlock), 0, st, src, a[1], (uint64_t)fr[i]->stride, bpp, S.d_lut, out, lab[i]);
+                } else {
+                    Planes in = (s & 1) ? S.quarter[i] : S.half[i];
+                    in.w = ws[s - 1]; in.h = hs[s - 1];
+                    hipLaunchKernelGGL(ssim_downlab_kernel, grid, dim3(kBlock), 0, st, in, out, lab[i], a[s]);
+                }
             }
         if (S.y1[s] > S.y0[s])
-            hipLaunchKernelGGL(ssim_map_kernel, grid2d(w, (S.y1[s] - S.y0[s] + kSeg - 1) / kSeg), dim3(kBlock), 0, st, lab[0], lab[1], S.y0[s], S.y1[s],
+            hipLaunchKernelGGL(ssim_map_kernel, dim3((w + kTileW - 1) / kTileW, (S.y1[s] - S.y0[s] + kSeg - 1) / kSeg), dim3(kBlock), 0, st, lab[0], lab[1], S.y0[s], S.y1[s],
                                S.map[s], S.d_sums + s * kSlots);
     }
     S.scales = n_scales;
