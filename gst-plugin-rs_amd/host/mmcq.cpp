@@ -26,19 +26,22 @@ struct Box {
     // Recomputes the cached population, volume and population-weighted mean colour.
     void refresh(const uint32_t *hist)
     {
-        long long total = 0;
-        int n_i32 = 0, sum[3] = {0, 0, 0};
+        // i32 accumulators as in the crate; a release build of the reference wraps on overflow (first possible at
+        // ~8.5 M samples in one box: 8K frames at quality <= 3), so they are carried as u32 and read back as i32
+        uint32_t total_u = 0, n_u = 0, sum_u[3] = {0, 0, 0};
         for (int r = lo[0]; r <= hi[0]; r++)
             for (int g = lo[1]; g <= hi[1]; g++)
                 for (int b = lo[2]; b <= hi[2]; b++) {
                     const double h = static_cast<double>(static_cast<int32_t>(hist[bin_of(r, g, b)]));
-                    n_i32 += static_cast<int>(h);
-                    sum[0] += static_cast<int>(h * (r + 0.5) * kMult);
-                    sum[1] += static_cast<int>(h * (g + 0.5) * kMult);
-                    sum[2] += static_cast<int>(h * (b + 0.5) * kMult);
-                    total += static_cast<int32_t>(hist[bin_of(r, g, b)]);
+                    n_u += static_cast<uint32_t>(static_cast<int32_t>(h));
+                    sum_u[0] += static_cast<uint32_t>(static_cast<int32_t>(h * (r + 0.5) * kMult));
+                    sum_u[1] += static_cast<uint32_t>(static_cast<int32_t>(h * (g + 0.5) * kMult));
+                    sum_u[2] += static_cast<uint32_t>(static_cast<int32_t>(h * (b + 0.5) * kMult));
+                    total_u += hist[bin_of(r, g, b)];
                 }
-        count = static_cast<int>(total);
+        const int n_i32 = static_cast<int32_t>(n_u);
+        const int sum[3] = {static_cast<int32_t>(sum_u[0]), static_cast<int32_t>(sum_u[1]), static_cast<int32_t>(sum_u[2])};
+        count = static_cast<int32_t>(total_u);
         volume = (hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
         if (n_i32 > 0) {
             average = Rgb8{static_cast<uint8_t>(sum[0] / n_i32), static_cast<uint8_t>(sum[1] / n_i32),

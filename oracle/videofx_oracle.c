@@ -89,17 +89,21 @@ typedef struct {
 
 static void vbox_recalc(vbox_t *v, const int32_t *hist)
 {
-    int ntot = 0, r_sum = 0, g_sum = 0, b_sum = 0, count = 0;
+    /* i32 accumulators as in the crate; a release build of the reference wraps on overflow (first possible at
+     * ~8.5 M samples in one box, i.e. 8K frames at quality <= 3), so the sums are carried as u32 and read back as i32 */
+    uint32_t ntot_u = 0, r_u = 0, g_u = 0, b_u = 0, count_u = 0;
     for (int i = v->r_min; i <= v->r_max; i++)
         for (int j = v->g_min; j <= v->g_max; j++)
             for (int k = v->b_min; k <= v->b_max; k++) {
                 double hval = (double)hist[color_index(i, j, k)];
-                ntot += (int)hval;
-                r_sum += (int)(hval * ((double)i + 0.5) * (double)MULTIPLIER);
-                g_sum += (int)(hval * ((double)j + 0.5) * (double)MULTIPLIER);
-                b_sum += (int)(hval * ((double)k + 0.5) * (double)MULTIPLIER);
-                count += hist[color_index(i, j, k)];
+                ntot_u += (uint32_t)(int32_t)hval;
+                r_u += (uint32_t)(int32_t)(hval * ((double)i + 0.5) * (double)MULTIPLIER);
+                g_u += (uint32_t)(int32_t)(hval * ((double)j + 0.5) * (double)MULTIPLIER);
+                b_u += (uint32_t)(int32_t)(hval * ((double)k + 0.5) * (double)MULTIPLIER);
+                count_u += (uint32_t)hist[color_index(i, j, k)];
             }
+    const int ntot = (int)(int32_t)ntot_u, r_sum = (int)(int32_t)r_u, g_sum = (int)(int32_t)g_u, b_sum = (int)(int32_t)b_u,
+              count = (int)(int32_t)count_u;
     if (ntot > 0) {
         v->avg[0] = (r_sum / ntot) & 0xff; /* `as u8` on i32 wraps */
         v->avg[1] = (g_sum / ntot) & 0xff;
