@@ -67,6 +67,18 @@ def test_colordetect_palette_matches_oracle(gpu, settings):
         assert name == orc.css_similar((pal[0] >> 16) & 255, (pal[0] >> 8) & 255, pal[0] & 255)
 
 
+def test_colordetect_8k_quality1_i32_sums_wrap(gpu):
+    """33 M samples in the first box: the crate's i32 colour sums wrap in a release build (8.3e9 > 2^31); the
+    median cut on the host and the oracle both carry them as wrapping 32-bit values and must agree."""
+    w, h = 7680, 4320
+    f = frames.random_frame(0x5EED0700, w, h)
+    f[:, 3::4] |= 0x80  # opaque enough for every sample to count
+    rc, pal = orc.colordetect_palette(f, "RGBA", 1, 5)
+    assert rc > 0
+    gpal, _ = gpu.colordetect_palette_host(f.reshape(-1), w, h, w * 4, "RGBA", 1, 5)
+    assert gpal == pal
+
+
 def test_colordetect_reference_pin_red(gpu):
     """tests/colordetect.rs:21-68: solid red => dominant-color 'red' (palette[0] = 252,4,4)"""
     w, h = 320, 240
