@@ -27,6 +27,7 @@ namespace {
 
 constexpr int kBlock = 256; // 128 / 512 / 1024 measured slower (profiles/r1/ab_steady_block_nt.txt)
 constexpr int kTile = 2;    // 16-byte pixel groups per lane in hsvfilter4_kernel (vec4 mode): both loads are issued first
+                            // (1: -8 %, 3: -0.4 %, 4: -2 % under the ILP scheduling strategy, ab_steady_sched_strategy.txt)
 
 enum : int { kModeBytes = 0, kModeVec4 = 1, kModeDword = 2 };
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

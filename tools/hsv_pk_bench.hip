@@ -77,6 +77,14 @@ __global__ __launch_bounds__(256) void valu_kernel(uint4 *io, FastConsts k, PkCo
     if (threadIdx.x < 8) lut[threadIdx.x] = sextant_selector(threadIdx.x, 0, false);
     __syncthreads();
     uint4 v = io[blockIdx.x * 256 + threadIdx.x];
+#ifdef MVFX_KCONST_VGPR // constants in VGPRs (experiment)
+    {
+        uint32_t *w = reinterpret_cast<uint32_t *>(&k);
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(FastConsts) / 4; i++)
+            asm volatile("v_mov_b32 %0, %1" : "=v"(w[i]) : "s"(w[i]));
+    }
+#endif
     if (iters < 0) { // parity check of the packed variant against the shipped one on this thread's pixels
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         for (int i = 0; i < 4; i++)
