@@ -26,7 +26,10 @@ namespace mvfx {
 namespace {
 
 constexpr int kBlock = 256; // 128 / 512 / 1024 measured slower (profiles/r1/ab_steady_block_nt.txt)
-constexpr int kTile = 2;    // 16-byte pixel groups per lane in hsvfilter4_kernel (vec4 mode): both loads are issued first
+constexpr int kTile = 2;    // 16-byte pixel groups per lane in hsvfilter4_kernel (vec4 mode) for multi-frame launches: both loads are
+                            // issued first; launches of fewer than kTileMinGroups groups (one or two 4K frames) keep one group
+                            // per lane (twice the workgroups: 16.8 vs 18.4 us for a single 4K frame)
+constexpr uint64_t kTileMinGroups = 3ull * 3840 * 2160 / 4;
                             // (1: -8 %, 3: -0.4 %, 4: -2 % under the ILP scheduling strategy, ab_steady_sched_strategy.txt)
 
 enum : int { kModeBytes = 0, kModeVec4 = 1, kModeDword = 2 };
@@ -93,7 +96,7 @@ __device__ __forceinline__ void init_filter_lds(FilterLds &lds, int off, bool bg
 // ---- hsvfilter, 4-byte formats -------------------------------------------------------------
 // width = pixels per row, rows/stride describe one frame, fb.base[blockIdx.z] its plane 0.
 // NT: non-temporal loads/stores (vec4 mode), for frames that are not read again on the GPU right away.
-template <int OFF, bool BGR, int VARIANT, int MODE, bool NT = false>
+template <int OFF, bool BGR, int VARIANT, int MODE, bool NT = false, int TILE = 1>
 __global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint64_t width,
                                                             uint32_t rows, uint64_t stride,
                                                             FastConsts p)
@@ -106,17 +109,17 @@ __global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint6
     for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
         uint8_t *line = frame + (uint64_t)row * stride;
         if constexpr (MODE == kModeVec4) {
-            // One workgroup owns a tile of kTile x 256 pixel groups: every lane issues its kTile
+            // One workgroup owns a tile of TILE x 256 pixel groups: every lane issues its TILE
             // 16-byte loads first, then runs the arithmetic, so the loads of group u+1.. are in
-            // flight while group u is computed (the wave stays in its VALU phase for kTile x 272
+            // flight while group u is computed (the wave stays in its VALU phase for TILE x 272
             // instructions instead of dying after one group).
             const uint64_t groups = (width + 3) >> 2;
             // (giving every XCD one contiguous eighth of the frame instead of every 8th tile: -1 %)
-            for (uint64_t t0 = (uint64_t)blockIdx.x * (kBlock * kTile); t0 < groups;
-                 t0 += (uint64_t)gridDim.x * (kBlock * kTile)) {
-                uint4 v[kTile];
+            for (uint64_t t0 = (uint64_t)blockIdx.x * (kBlock * TILE); t0 < groups;
+                 t0 += (uint64_t)gridDim.x * (kBlock * TILE)) {
+                uint4 v[TILE];
 #pragma unroll
-                for (int u = 0; u < kTile; u++) {
+                for (int u = 0; u < TILE; u++) {
                     const uint64_t x = (t0 + (uint64_t)u * kBlock + threadIdx.x) << 2;
                     if (x + 4 <= width) {
                         if constexpr (NT) {
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint6
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < kTile; u++) {
+                for (int u = 0; u < TILE; u++) {
                     const uint64_t x = (t0 + (uint64_t)u * kBlock + threadIdx.x) << 2;
                     if (x + 4 <= width) {
                         v[u].x = filter_px4<OFF, BGR, VARIANT>(v[u].x, p, lds);
@@ -428,6 +431,7 @@ struct Geometry {
     uint32_t rows;
     uint64_t stride;
     int mode;
+    int tile; // pixel groups per lane (vec4 mode)
     dim3 grid;
 };
 
@@ -454,7 +458,10 @@ Geometry plan(const mvfx_frame *frames, uint32_t n, int bpp, uint32_t n_frames_z
         g.mode = (align_or & need) == 0 ? kModeVec4 : ((bpp == 4 && (align_or & 3) == 0) ? kModeDword : kModeBytes);
     }
     const uint64_t work = g.mode == kModeVec4 ? (g.width + 3) / 4 : g.width;
-    const uint64_t per_block = (uint64_t)kBlock * (g.mode == kModeVec4 ? tile : 1);
+    g.tile = 1;
+    if (g.mode == kModeVec4 && tile > 1 && work * n_frames_z >= kTileMinGroups)
+        g.tile = tile;
+    const uint64_t per_block = (uint64_t)kBlock * g.tile;
     uint64_t bx = (work + per_block - 1) / per_block;
     if (bx == 0) bx = 1;
     if (bx > 65535u * 16u) bx = 65535u * 16u; // grid-stride covers the rest
@@ -469,8 +476,9 @@ void launch_filter(int bpp, int off, bool bgr, const Geometry &g, const FrameBat
 
 #define MVFX_L4(O, B, M) \
     hipLaunchKernelGGL((hsvfilter4_kernel<O, B, VARIANT, M>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p)
-#define MVFX_L4NT(O, B) \
-    hipLaunchKernelGGL((hsvfilter4_kernel<O, B, VARIANT, kModeVec4, true>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p)
+#define MVFX_L4V(O, B, NT_) \
+    do { if (g.tile == kTile) hipLaunchKernelGGL((hsvfilter4_kernel<O, B, VARIANT, kModeVec4, NT_, kTile>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p); \
+         else hipLaunchKernelGGL((hsvfilter4_kernel<O, B, VARIANT, kModeVec4, NT_, 1>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p); } while (0)
 #define MVFX_L3(B, M) \
     hipLaunchKernelGGL((hsvfilter3_kernel<B, VARIANT, M>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p)
     if (bpp == 4) {
@@ -478,11 +486,11 @@ void launch_filter(int bpp, int off, bool bgr, const Geometry &g, const FrameBat
         switch (g.mode) {
         case kModeVec4:
             if (g_streaming && VARIANT != kGeneral)
-                switch (key) { case 0: MVFX_L4NT(0, false); break; case 1: MVFX_L4NT(0, true); break;
-                               case 2: MVFX_L4NT(1, false); break; default: MVFX_L4NT(1, true); break; }
+                switch (key) { case 0: MVFX_L4V(0, false, true); break; case 1: MVFX_L4V(0, true, true); break;
+                               case 2: MVFX_L4V(1, false, true); break; default: MVFX_L4V(1, true, true); break; }
             else
-                switch (key) { case 0: MVFX_L4(0, false, kModeVec4); break; case 1: MVFX_L4(0, true, kModeVec4); break;
-                               case 2: MVFX_L4(1, false, kModeVec4); break; default: MVFX_L4(1, true, kModeVec4); break; }
+                switch (key) { case 0: MVFX_L4V(0, false, false); break; case 1: MVFX_L4V(0, true, false); break;
+                               case 2: MVFX_L4V(1, false, false); break; default: MVFX_L4V(1, true, false); break; }
             break;
         case kModeDword:
             switch (key) { case 0: MVFX_L4(0, false, kModeDword); break; case 1: MVFX_L4(0, true, kModeDword); break;
@@ -498,7 +506,7 @@ void launch_filter(int bpp, int off, bool bgr, const Geometry &g, const FrameBat
         else { if (bgr) MVFX_L3(true, kModeBytes); else MVFX_L3(false, kModeBytes); }
     }
 #undef MVFX_L4
-#undef MVFX_L4NT
+#undef MVFX_L4V
 #undef MVFX_L3
 }
 
