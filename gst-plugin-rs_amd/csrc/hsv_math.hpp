@@ -9,12 +9,13 @@
 //           => VALU-bound at roughly a quarter of the HBM roofline.
 //
 //  FAST     the same values through exact strength reductions, each proven exhaustively:
-//           - u8/255, h/60 as mul+fma+fma          (tools/prove_exact.c P1, P2; Markstein)
-//           - fmod(h',2) as 2*fract(h'/2)           (P3)
+//           - u8/255, h/120 as mul + fmac          (tools/prove_exact.c P8, P11)
+//           - fmod(h',2) as 2*fract(h'/2)           (P3); 1-|2f-1| as fma(-2,|f-1/2|,1) (P14)
 //           - `hue % 360` and the [0,1] clamps in from_rgb dropped (P4: identities on all 2^24
 //             inputs); epsilon compares == "channel is the max" (P5)
-//           - hue wrap as conditional +-360         (P7), needs |hue_shift| <= 360
-//           - (g-b)/chroma and chroma/value as v_rcp_f32 + one Newton step on the quotient;
+//           - hue wraps as add + unsigned min       (P9, P13), needs |hue_shift| <= 360
+//           - the sextant index out of a float's mantissa (P12)
+//           - (g-b)/chroma and chroma/value as v_rcp_f32 + one residual step, carried negated (quot_neg);
 //             proven on the GPU by the exhaustive 2^24-triple parity test
 //             (tests/test_hsv_gpu.py::test_from_rgb_f32_exhaustive), since both divides depend
 //             only on (R,G,B), never on the settings.
