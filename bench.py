@@ -223,7 +223,26 @@ def config_main(args):
         W, H, nb = W4K, H4K, args.batch
         pool = max(2, 32 // nb)
         lut = vfx.CubeLut(cubes.analytic_3d(33))
-        src, dst = rnd(pool * nb, FRAME_BYTES), torch.empty((pool * nb, FRAME_BYTES), dtype=torch.uint8, device=dev)
+        if args.content == "random":
+            src = rnd(pool * nb, FRAME_BYTES)
+        elif args.content == "smpte":
+            from tests import frames as _frames
+            one = torch.from_numpy(_frames.smpte_like(W, H).reshape(-1)).to(dev)
+            src = one.unsqueeze(0).repeat(pool * nb, 1).contiguous()
+        else:  # smooth 2-D colour gradients (different phase per frame) + sensor-like noise of +-3 codes
+            x = torch.linspace(0, 1, W, device=dev).view(1, 1, W)
+            y = torch.linspace(0, 1, H, device=dev).view(1, H, 1)
+            src = torch.empty((pool * nb, FRAME_BYTES), dtype=torch.uint8, device=dev)
+            for k in range(pool * nb):
+                ph = 0.37 * k
+                img = torch.stack([(0.5 + 0.45 * torch.sin(3.0 * x + 2.0 * y + ph)).expand(1, H, W),
+                                   (0.5 + 0.45 * torch.sin(5.0 * y - 1.5 * x + 2 * ph)).expand(1, H, W),
+                                   (0.5 + 0.45 * torch.cos(4.0 * x * y + ph)).expand(1, H, W),
+                                   torch.ones((1, H, W), device=dev)], dim=-1) * 255.0
+                noise = torch.randint(-3, 4, img.shape, device=dev, generator=gen).float()
+                noise[..., 3] = 0
+                src[k] = (img + noise).clamp(0, 255).to(torch.uint8).view(-1)
+        dst = torch.empty((pool * nb, FRAME_BYTES), dtype=torch.uint8, device=dev)
         fi = [(vfx.Frame * nb)(*[vfx.make_frame(src[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
         fo = [(vfx.Frame * nb)(*[vfx.make_frame(dst[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
 
@@ -231,8 +250,8 @@ def config_main(args):
             k = i % pool
             vfx.check(lib.mvfx_colorlut_transform_frames(lut.h, fi[k], fo[k], nb, sptr))
         frames_per_step = nb
-        bytes_per_step, name = nb * 2 * FRAME_BYTES, (f"colorlut 33^3 .cube, {nb} streams of 3840x2160 RGBA per launch, uniform-random colours "
-                                                      "(worst case for the LUT gathers)")
+        bytes_per_step, name = nb * 2 * FRAME_BYTES, (f"colorlut 33^3 .cube, {nb} streams of 3840x2160 RGBA per launch, content={args.content} "
+                                                      "(the LUT gathers are content dependent: random colours are the worst case, flat bars the best)")
     else:  # videofx: one 4K stream per GPU: I420 -> A420 compose with the r=100 mask + colordetect on the RGBA twin
         W, H, pool = W4K, H4K, 16
         i420, a420 = rnd(pool, W * H * 3 // 2), torch.empty((pool, W * H * 5 // 2), dtype=torch.uint8, device=dev)
@@ -313,6 +332,10 @@ def main():
     ap.add_argument("--streaming", type=int, default=1,
                     help="mvfx_hsvfilter_set_streaming: 1 = non-temporal loads/stores (the frames of this workload are not "
                          "read again on the GPU: standalone filter), 0 = normal caching (element chains)")
+    ap.add_argument("--content", default="natural", choices=["natural", "random", "smpte"],
+                    help="colorlut workload: frame content. The LUT gathers are content dependent: smooth gradients with +-3 "
+                         "codes of noise (default), uniform-random colours (worst case: every pixel another LUT cell), or flat "
+                         "videotestsrc-smpte-like bars (best case)")
     ap.add_argument("--hash-algo", default="blockhash", choices=["blockhash", "dssim"],
                     help="videocompare workload: blockhash (the element's default) or the SSIM-family distance")
     ap.add_argument("--workload", default="hsvfilter",
