@@ -582,42 +582,20 @@ static GstFlowReturn gst_video_compare_update_src_caps(GstAggregator *agg, GstCa
     return GST_FLOW_OK;
 }
 
-// HashedImage::Dssim + compare (hashed_image.rs:49-59,72-75): both frames mapped, one distance
-static int video_compare_ssim(GstPad *ref_pad, GstBuffer *ref_buf, GstPad *pad, GstBuffer *buf, double *distance,
-                              gboolean *size_mismatch)
-{
-    GstPad *pads[2] = {ref_pad, pad};
-    GstBuffer *bufs[2] = {ref_buf, buf};
-    GstVideoFrame frames[2];
-    mvfx_frame f[2];
-    int mapped = 0, rc = MVFX_OK;
-    for (int i = 0; i < 2 && rc == MVFX_OK; i++) {
-        GstCaps *caps = gst_pad_get_current_caps(pads[i]);
-        GstVideoInfo info;
-        if (!caps || !gst_video_info_from_caps(&info, caps))
-            rc = MVFX_ERR_NOT_NEGOTIATED;
-        else if (!gst_video_frame_map(&frames[i], &info, bufs[i], GST_MAP_READ))
-            rc = MVFX_ERR_INVALID_ARGUMENT;
-        else {
-            f[i] = mvfx_frame_from_gst(&frames[i]);
-            mapped++;
-        }
-        if (caps) gst_caps_unref(caps);
-    }
-    if (rc == MVFX_OK) {
-        if (f[0].width != f[1].width || f[0].height != f[1].height)
-            *size_mismatch = TRUE;
-        else
-            rc = mvfx_ssim_distance_host(&f[0], &f[1], distance);
-    }
-    for (int i = 0; i < mapped; i++)
-        gst_video_frame_unmap(&frames[i]);
-    return rc;
-}
+// One pad's buffer as the C ABI's frame view.  memory:HIPMemory buffers are mapped to their DEVICE pointer (no copy,
+// `device` set); system-memory buffers through GstVideoFrame (strides from GstVideoMeta honoured).
+struct CompareView {
+    mvfx_frame f;
+    gboolean device, mapped_frame, mapped_hip;
+    GstVideoFrame frame;
+    GstMapInfo map;
+    GstBuffer *buf;
+};
 
-// HasherEngine::hash_image (hashed_image.rs:24-64) on one pad's buffer
-static int video_compare_hash(GstPad *pad, GstBuffer *buf, uint64_t *hash, guint *w, guint *h)
+static int compare_view_open(GstPad *pad, GstBuffer *buf, CompareView *v)
 {
+    v->device = v->mapped_frame = v->mapped_hip = FALSE;
+    v->buf = buf;
     GstCaps *caps = gst_pad_get_current_caps(pad);
     GstVideoInfo info;
     if (!caps || !gst_video_info_from_caps(&info, caps)) {
@@ -625,14 +603,58 @@ static int video_compare_hash(GstPad *pad, GstBuffer *buf, uint64_t *hash, guint
         return MVFX_ERR_NOT_NEGOTIATED;
     }
     gst_caps_unref(caps);
-    GstVideoFrame frame;
-    if (!gst_video_frame_map(&frame, &info, buf, GST_MAP_READ))
+    if (mvfx_buffer_is_hip(buf)) {
+        if (!mvfx_hip_map_frame(buf, &info, GST_MAP_READ, &v->map, &v->f))
+            return MVFX_ERR_INVALID_ARGUMENT;
+        v->device = v->mapped_hip = TRUE;
+        return MVFX_OK;
+    }
+    if (!gst_video_frame_map(&v->frame, &info, buf, GST_MAP_READ))
         return MVFX_ERR_INVALID_ARGUMENT;
-    const mvfx_frame f = mvfx_frame_from_gst(&frame);
-    *w = f.width;
-    *h = f.height;
-    const int rc = mvfx_blockhash_host(&f, hash);
-    gst_video_frame_unmap(&frame);
+    v->mapped_frame = TRUE;
+    v->f = mvfx_frame_from_gst(&v->frame);
+    return MVFX_OK;
+}
+
+static void compare_view_close(CompareView *v)
+{
+    if (v->mapped_hip) gst_buffer_unmap(v->buf, &v->map);
+    if (v->mapped_frame) gst_video_frame_unmap(&v->frame);
+    v->mapped_hip = v->mapped_frame = FALSE;
+}
+
+// HashedImage::Dssim + compare (hashed_image.rs:49-59,72-75): both frames mapped, one distance
+static int video_compare_ssim(GstPad *ref_pad, GstBuffer *ref_buf, GstPad *pad, GstBuffer *buf, double *distance,
+                              gboolean *size_mismatch)
+{
+    CompareView a, b;
+    int rc = compare_view_open(ref_pad, ref_buf, &a);
+    if (rc != MVFX_OK) return rc;
+    rc = compare_view_open(pad, buf, &b);
+    if (rc != MVFX_OK) { compare_view_close(&a); return rc; }
+    if (a.f.width != b.f.width || a.f.height != b.f.height)
+        *size_mismatch = TRUE;
+    else if (a.device && b.device)
+        rc = mvfx_ssim_distance(&a.f, &b.f, distance, mvfx_thread_stream()); // both frames already in HBM
+    else if (!a.device && !b.device)
+        rc = mvfx_ssim_distance_host(&a.f, &b.f, distance);
+    else
+        rc = MVFX_ERR_NOT_NEGOTIATED; // one pad on device memory, the other on system memory
+    compare_view_close(&b);
+    compare_view_close(&a);
+    return rc;
+}
+
+// HasherEngine::hash_image (hashed_image.rs:24-64) on one pad's buffer
+static int video_compare_hash(GstPad *pad, GstBuffer *buf, uint64_t *hash, guint *w, guint *h)
+{
+    CompareView v;
+    int rc = compare_view_open(pad, buf, &v);
+    if (rc != MVFX_OK) return rc;
+    *w = v.f.width;
+    *h = v.f.height;
+    rc = v.device ? mvfx_blockhash(&v.f, hash, mvfx_thread_stream()) : mvfx_blockhash_host(&v.f, hash);
+    compare_view_close(&v);
     return rc;
 }
 
@@ -766,7 +788,7 @@ static void gst_video_compare_class_init(GstVideoCompareClass *klass)
     gst_element_class_set_static_metadata(element, "Image comparison", "Filter/Video", "Compare similarity of video frames",
                                           "Rafael Caricio <rafael@caricio.com>"); // imp.rs:145-156
     static const gchar *const formats[] = {"RGB", "RGBA", NULL}; // imp.rs:158-186
-    GstCaps *caps = mvfx_video_caps(formats);
+    GstCaps *caps = mvfx_caps_plus_hip(mvfx_video_caps(formats)); // + the memory:HIPMemory twin
     gst_element_class_add_pad_template(element, gst_pad_template_new_with_gtype("sink_%u", GST_PAD_SINK, GST_PAD_REQUEST, caps, GST_TYPE_AGGREGATOR_PAD));
     gst_element_class_add_pad_template(element, gst_pad_template_new_with_gtype("src", GST_PAD_SRC, GST_PAD_ALWAYS, caps, GST_TYPE_AGGREGATOR_PAD));
     gst_caps_unref(caps);

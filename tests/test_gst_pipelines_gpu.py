@@ -214,3 +214,28 @@ def test_hipmemory_buffers_come_from_the_negotiated_pool(gpu, tmp_path):
     allocated = re.findall(r"mvfxhippool.*allocated device buffer", r.stdout)
     assert len(configured) >= 3, r.stdout[-2000:]          # upload, detector and colorlut outputs
     assert 3 <= len(allocated) <= 24, (len(allocated), r.stdout[-2000:])  # recycled, far fewer than 3 * 40
+
+
+@pytest.mark.parametrize("algo", ["blockhash", "dssim"])
+def test_videocompare_on_hipmemory_pads(gpu, tmp_path, algo):
+    """Both pads fed with memory:HIPMemory buffers: the frames are hashed / compared where they are (no download);
+    same messages as the system-memory pipelines of tests/videocompare.rs."""
+    caps = "video/x-raw,format=RGBA,width=320,height=240"
+
+    def run(pattern_b, extra=""):
+        pipeline = (f"videocompare name=compare hash-algo={algo} {extra} ! fakesink "
+                    f"videotestsrc pattern=red num-buffers=2 ! {caps} ! hipupload ! compare.sink_0 "
+                    f"videotestsrc pattern={pattern_b} num-buffers=2 ! {caps} ! hipupload ! compare.sink_1")
+        r = gst_env.run([LAUNCH, "-m", "-v"] + pipeline.split(), tmp_path)
+        assert r.returncode == 0, r.stdout
+        return r.stdout
+
+    out = run("red")
+    assert re.search(r"sink_0: caps = video/x-raw\(memory:HIPMemory\)", out), [l for l in out.splitlines() if "sink_0" in l][:5]
+    msgs = re.findall(r"videocompare, running-time=\(guint64\)(\d+), pad-distances=\(structure\)<([^>]*)>", out)
+    assert len(msgs) >= 1 and re.search(r"distance\\=\\\(double\\\)0", msgs[0][1]), out[-1500:]
+    out = run("snow")
+    assert "videocompare, running-time" not in out
+    out = run("snow", "max-dist-threshold=1000")
+    m = re.search(r"distance\\=\\\(double\\\)([0-9.e+-]+)", out)
+    assert m and float(m.group(1)) > 0.01, out[-1500:]
