@@ -210,8 +210,10 @@ struct GstRoundedCorners {
     std::mutex *lock;
     guint border_radius_px; // Settings { border_radius_px, changed } (border/imp.rs:27-43)
     gboolean changed;
-    GstMemory *alpha_mem;   // State { alpha_mem, out_info } (:45-48)
+    GstMemory *alpha_mem;   // State { alpha_mem, out_info } (:45-48); a memory:HIPMemory block on the device path
     GstVideoInfo out_info;
+    GstVideoInfo in_info;
+    gboolean hip;           // negotiated on memory:HIPMemory: the A420 frame is composed in HBM
     gboolean have_state;
 };
 struct GstRoundedCornersClass {
@@ -319,7 +321,18 @@ static gboolean gst_rounded_corners_set_caps(GstBaseTransform *trans, GstCaps *i
     const gsize alpha_size = (gsize)GST_VIDEO_INFO_PLANE_STRIDE(&info, 3) * ru2_height;
     std::lock_guard<std::mutex> g(*self->lock);
     if (self->alpha_mem) gst_memory_unref(self->alpha_mem);
-    self->alpha_mem = gst_allocator_alloc(NULL, alpha_size, NULL);
+    self->hip = mvfx_caps_has_hip_feature(outcaps);
+    if (self->hip) {
+        GstAllocator *alloc = mvfx_hip_allocator_get();
+        self->alpha_mem = gst_allocator_alloc(alloc, alpha_size, NULL);
+        gst_object_unref(alloc);
+        if (!self->alpha_mem || !gst_video_info_from_caps(&self->in_info, incaps)) {
+            GST_CAT_ERROR_OBJECT(roundedcorners_debug, self, "Failed to set up the device alpha plane: %s", mvfx_last_error());
+            return FALSE;
+        }
+    } else {
+        self->alpha_mem = gst_allocator_alloc(NULL, alpha_size, NULL);
+    }
     self->out_info = info;
     self->have_state = TRUE;
     self->changed = TRUE;
@@ -337,13 +350,19 @@ static gboolean rounded_corners_generate_mask(GstRoundedCorners *self, guint rad
         self->alpha_mem = copy;
     }
     GstMapInfo map;
-    if (!gst_memory_map(self->alpha_mem, &map, GST_MAP_WRITE)) {
+    if (!gst_memory_map(self->alpha_mem, &map, (GstMapFlags)(GST_MAP_WRITE | (self->hip ? MVFX_MAP_HIP : 0)))) {
         GST_CAT_ERROR_OBJECT(roundedcorners_debug, self, "Failed to map alpha memory as writable");
         return FALSE;
     }
-    const int rc = mvfx_roundedcorners_mask_host(map.data, (uint32_t)GST_VIDEO_INFO_WIDTH(&self->out_info),
-                                                 (uint32_t)GST_VIDEO_INFO_HEIGHT(&self->out_info),
-                                                 (uint32_t)GST_VIDEO_INFO_PLANE_STRIDE(&self->out_info, 3), radius);
+    const uint32_t mw = (uint32_t)GST_VIDEO_INFO_WIDTH(&self->out_info), mh = (uint32_t)GST_VIDEO_INFO_HEIGHT(&self->out_info),
+                   ms = (uint32_t)GST_VIDEO_INFO_PLANE_STRIDE(&self->out_info, 3);
+    int rc;
+    if (self->hip) { // rendered where it will be read
+        rc = mvfx_roundedcorners_mask(map.data, mw, mh, ms, radius, mvfx_thread_stream());
+        if (rc == MVFX_OK) rc = mvfx_stream_synchronize(mvfx_thread_stream());
+    } else {
+        rc = mvfx_roundedcorners_mask_host(map.data, mw, mh, ms, radius);
+    }
     gst_memory_unmap(self->alpha_mem, &map);
     if (rc != MVFX_OK) {
         GST_CAT_ERROR_OBJECT(roundedcorners_debug, self, "Failed to draw rounded corners: %s", mvfx_last_error());
@@ -376,6 +395,53 @@ static GstFlowReturn gst_rounded_corners_prepare_output_buffer(GstBaseTransform 
             GST_ELEMENT_ERROR(self, CORE, NEGOTIATION, ("Failed to generate alpha mask"), (NULL));
             return GST_FLOW_NOT_NEGOTIATED;
         }
+    }
+    if (self->hip) {
+        // device path: one A420 buffer in HBM, Y/U/V + the mask copied by ONE kernel launch (the zero-copy
+        // "append the shared alpha memory" trick of the system-memory path would leave a two-memory buffer that
+        // no device kernel downstream could address as one frame)
+        if (!mvfx_buffer_is_hip(inbuf)) {
+            GST_ELEMENT_ERROR(self, CORE, NEGOTIATION, ("negotiated memory:HIPMemory but got a system-memory buffer"), (NULL));
+            return GST_FLOW_NOT_NEGOTIATED;
+        }
+        GstBuffer *out = NULL;
+        GstFlowReturn fr = mvfx_hip_new_output(trans, inbuf, GST_VIDEO_INFO_SIZE(&self->out_info), &out);
+        if (fr != GST_FLOW_OK)
+            return fr;
+        GstMapInfo imap, omap, amap;
+        if (!gst_buffer_map(inbuf, &imap, (GstMapFlags)(GST_MAP_READ | MVFX_MAP_HIP)) ||
+            !gst_buffer_map(out, &omap, (GstMapFlags)(GST_MAP_WRITE | MVFX_MAP_HIP)) ||
+            !gst_memory_map(self->alpha_mem, &amap, (GstMapFlags)(GST_MAP_READ | MVFX_MAP_HIP))) {
+            gst_buffer_unref(out);
+            return GST_FLOW_ERROR;
+        }
+        mvfx_planar_frame pi, po;
+        memset(&pi, 0, sizeof(pi));
+        memset(&po, 0, sizeof(po));
+        for (guint p = 0; p < 3; p++) {
+            pi.data[p] = imap.data + GST_VIDEO_INFO_PLANE_OFFSET(&self->in_info, p);
+            pi.stride[p] = (uint32_t)GST_VIDEO_INFO_PLANE_STRIDE(&self->in_info, p);
+        }
+        for (guint p = 0; p < 4; p++) {
+            po.data[p] = omap.data + GST_VIDEO_INFO_PLANE_OFFSET(&self->out_info, p);
+            po.stride[p] = (uint32_t)GST_VIDEO_INFO_PLANE_STRIDE(&self->out_info, p);
+        }
+        pi.width = po.width = (uint32_t)GST_VIDEO_INFO_WIDTH(&self->out_info);
+        pi.height = po.height = (uint32_t)GST_VIDEO_INFO_HEIGHT(&self->out_info);
+        pi.format = MVFX_FORMAT_I420;
+        po.format = MVFX_FORMAT_A420;
+        int rc = mvfx_roundedcorners_compose_a420(&pi, amap.data, (uint32_t)GST_VIDEO_INFO_PLANE_STRIDE(&self->out_info, 3), &po,
+                                                  mvfx_thread_stream());
+        if (rc == MVFX_OK) rc = mvfx_stream_synchronize(mvfx_thread_stream());
+        gst_memory_unmap(self->alpha_mem, &amap);
+        gst_buffer_unmap(out, &omap);
+        gst_buffer_unmap(inbuf, &imap);
+        if (rc != MVFX_OK) {
+            gst_buffer_unref(out);
+            return MVFX_GST_FLOW(self, rc);
+        }
+        *outbuf = out;
+        return GST_FLOW_OK;
     }
     GstBuffer *buf;
     if (gst_buffer_is_writable(inbuf)) {
@@ -442,7 +508,7 @@ static void gst_rounded_corners_class_init(GstRoundedCornersClass *klass)
                                           "Adds rounded corners to video", "Sanchayan Maity <sanchayan@asymptotic.io>");
     static const gchar *const sink_formats[] = {"I420", NULL};
     static const gchar *const src_formats[] = {"I420", "A420", NULL};
-    mvfx_add_pad_templates(element, mvfx_video_caps(sink_formats), mvfx_video_caps(src_formats)); // :343-370
+    mvfx_add_pad_templates(element, mvfx_caps_plus_hip(mvfx_video_caps(sink_formats)), mvfx_caps_plus_hip(mvfx_video_caps(src_formats))); // :343-370 (+ HIP twin)
     bt->stop = gst_rounded_corners_stop;
     bt->transform_caps = gst_rounded_corners_transform_caps;
     bt->set_caps = gst_rounded_corners_set_caps;
@@ -457,6 +523,7 @@ static void gst_rounded_corners_init(GstRoundedCorners *self)
     self->border_radius_px = 0;
     self->changed = FALSE;
     self->alpha_mem = nullptr;
+    self->hip = FALSE;
     self->have_state = FALSE;
     gst_base_transform_set_in_place(GST_BASE_TRANSFORM(self), TRUE);
 }
@@ -607,6 +674,7 @@ static int compare_view_open(GstPad *pad, GstBuffer *buf, CompareView *v)
         if (!mvfx_hip_map_frame(buf, &info, GST_MAP_READ, &v->map, &v->f))
             return MVFX_ERR_INVALID_ARGUMENT;
         v->device = v->mapped_hip = TRUE;
+        GST_CAT_LOG_OBJECT(videocompare_debug, pad, "frame of %" GST_PTR_FORMAT " stays in device memory", pad);
         return MVFX_OK;
     }
     if (!gst_video_frame_map(&v->frame, &info, buf, GST_MAP_READ))

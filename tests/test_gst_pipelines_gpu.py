@@ -226,12 +226,12 @@ def test_videocompare_on_hipmemory_pads(gpu, tmp_path, algo):
         pipeline = (f"videocompare name=compare hash-algo={algo} {extra} ! fakesink "
                     f"videotestsrc pattern=red num-buffers=2 ! {caps} ! hipupload ! compare.sink_0 "
                     f"videotestsrc pattern={pattern_b} num-buffers=2 ! {caps} ! hipupload ! compare.sink_1")
-        r = gst_env.run([LAUNCH, "-m", "-v"] + pipeline.split(), tmp_path)
+        r = gst_env.run([LAUNCH, "-m"] + pipeline.split(), tmp_path, extra_env={"GST_DEBUG": "videocompare:7", "GST_DEBUG_NO_COLOR": "1"})
         assert r.returncode == 0, r.stdout
         return r.stdout
 
     out = run("red")
-    assert re.search(r"sink_0: caps = video/x-raw\(memory:HIPMemory\)", out), [l for l in out.splitlines() if "sink_0" in l][:5]
+    assert "stays in device memory" in out, out[-1500:]
     msgs = re.findall(r"videocompare, running-time=\(guint64\)(\d+), pad-distances=\(structure\)<([^>]*)>", out)
     assert len(msgs) >= 1 and re.search(r"distance\\=\\\(double\\\)0", msgs[0][1]), out[-1500:]
     out = run("snow")
@@ -239,3 +239,39 @@ def test_videocompare_on_hipmemory_pads(gpu, tmp_path, algo):
     out = run("snow", "max-dist-threshold=1000")
     m = re.search(r"distance\\=\\\(double\\\)([0-9.e+-]+)", out)
     assert m and float(m.group(1)) > 0.01, out[-1500:]
+
+
+@pytest.mark.parametrize("w,h,rad", [(64, 48, 10), (322, 242, 40)])
+def test_roundedcorners_on_hipmemory(gpu, tmp_path, w, h, rad):
+    """hipupload ! roundedcorners ! hipdownload: the A420 frame is composed in HBM (one launch) and is byte-identical
+    to what the system-memory element produces (Y/U/V untouched + the same mask); radius 0 stays a passthrough."""
+    src = f"videotestsrc num-buffers=2 ! video/x-raw,format=I420,width={w},height={h}"
+    host = _capture(tmp_path, src + f" ! roundedcorners border-radius-px={rad} ! video/x-raw,format=A420", "host.raw")
+    r = gst_env.run([LAUNCH, "-v"] + (src + f" ! hipupload ! roundedcorners name=rc border-radius-px={rad} ! "
+                    f"video/x-raw(memory:HIPMemory),format=A420 ! hipdownload ! filesink location={tmp_path}/dev.raw").split(), tmp_path)
+    assert r.returncode == 0, r.stdout
+    assert re.search(r"rc\.GstPad:src: caps = video/x-raw\(memory:HIPMemory\)", r.stdout), r.stdout[-1500:]
+    dev = np.fromfile(f"{tmp_path}/dev.raw", dtype=np.uint8)
+    assert dev.size == host.size
+
+    def planes(buf):  # default GstVideoInfo layout of A420; row padding is not part of the picture
+        ru4 = lambda v: (v + 3) & ~3
+        ys, cs, cw, ch = ru4(w), ru4((w + 1) // 2), (w + 1) // 2, (h + 1) // 2
+        rh = (h + 1) & ~1
+        sizes = [(ys, rh, w, h), (cs, rh // 2, cw, ch), (cs, rh // 2, cw, ch), (ys, rh, w, h)]
+        frame = sum(st * rows for st, rows, _, _ in sizes)
+        out = []
+        for k in range(buf.size // frame):
+            off = k * frame
+            for st, rows, pw, ph in sizes:
+                out.append(buf[off:off + st * rows].reshape(rows, st)[:ph, :pw].copy())
+                off += st * rows
+        return out
+
+    for a, b in zip(planes(dev), planes(host)):
+        assert np.array_equal(a, b)
+    raw = _capture(tmp_path, src, "in.raw")
+    same = _capture(tmp_path, src + " ! hipupload ! roundedcorners ! video/x-raw(memory:HIPMemory),format=I420 ! hipdownload", "pt.raw")
+    assert same.size == raw.size
+    if w % 4 == 0 and h % 2 == 0:  # no row padding: whole buffers comparable
+        assert np.array_equal(same, raw)
