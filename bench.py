@@ -133,12 +133,14 @@ def videocompare_main(args):
             return [D.ssim_sharded(lambda: vfx.ssim_partial_sums(fr[k][0], fr[k][1], y0, y1, sptr),
                                    lambda mean: vfx.ssim_partial_deviation(mean, sptr), vfx.ssim_combine, dev)]
     else:
+        bands = [(vfx.Frame * 2)(*[vfx.make_frame(pairs[k, p].data_ptr(), W, rows, W * 4, "RGBA") for p in range(2)])
+                 for k in range(pool)]
+
         def step(i):
-            def partial(p):
-                f = vfx.make_frame(pairs[i % pool, p].data_ptr(), W, rows, W * 4, "RGBA")
-                vfx.check(lib.mvfx_blockhash_sums_band(ctypes.byref(f), H, r0, ctypes.c_void_p(sums[p].data_ptr()), sptr))
-                return sums[p]
-            return D.videocompare_sharded(partial, 2, W, H, bits, dev)
+            def partial():  # both pads' bands in one launch
+                vfx.check(lib.mvfx_blockhash_sums_pads(bands[i % pool], 2, H, r0, ctypes.c_void_p(sums.data_ptr()), sptr))
+                return sums
+            return D.videocompare_sharded(partial, 2, W, H, bits, dev, all_pads=True)
 
     settle(step, args.settle_seconds, lambda: torch.cuda.synchronize(dev), fixed_steps=400 if args.hash_algo == "blockhash" else 20)  # all-reduce inside the step
     for i in range(args.warmup):

@@ -125,6 +125,7 @@ SIGNATURES = {
     "mvfx_css_color_similar": (c_char_p, [ctypes.c_uint8, ctypes.c_uint8, ctypes.c_uint8]),
     "mvfx_blockhash_sums": (c_int, [POINTER(Frame), c_uint32, c_uint32, c_void_p, c_void_p]),
     "mvfx_blockhash_sums_band": (c_int, [POINTER(Frame), c_uint32, c_uint32, c_void_p, c_void_p]),
+    "mvfx_blockhash_sums_pads": (c_int, [POINTER(Frame), c_uint32, c_uint32, c_uint32, c_void_p, c_void_p]),
     "mvfx_blockhash_bits": (c_int, [POINTER(c_uint32), c_uint32, c_uint32, POINTER(c_uint64)]),
     "mvfx_hash_distance": (c_uint32, [c_uint64, c_uint64]),
     "mvfx_blockhash": (c_int, [POINTER(Frame), POINTER(c_uint64), c_void_p]),

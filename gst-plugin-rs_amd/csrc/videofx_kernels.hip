@@ -12,7 +12,9 @@
 //     does in the reference.
 //  videocompare (video/videofx/src/videocompare/hashed_image.rs:24-79 -> image_hasher Blockhash)
 //     64 block sums (u32) of r+g+b (765 when alpha==0) over an 8x8 grid of W/8 x H/8 blocks:
-//     16-byte coalesced reads, wave shuffle reduction, one atomicAdd per workgroup per block.
+//     16-byte non-temporal reads (4 rows in flight per lane), wave shuffle reduction, one plain store per
+//     workgroup, then a 64-wave launch that adds the partials (no same-address atomics, no memset);
+//     every pad of an aggregate in one launch (blockIdx.z).
 //     A row range can be given so that 8 ranks each reduce one block-row and all-reduce 64 u32.
 //  roundedcorners (video/videofx/src/border/imp.rs:57-180)
 //     A8 mask of a rounded rectangle (fill + 1 px stroke, anti-aliased).  cairo's scan converter
@@ -172,53 +174,92 @@ int colordetect_hist_impl(const mvfx_frame *frame, uint32_t quality, uint64_t fi
 
 // ------------------------------------------------------------------ videocompare / blockhash
 
+typedef uint32_t sum_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kSumBlock = 256;
+constexpr int kSumMaxPads = 16;      // frames per launch (blockIdx.z); more pads take more launches
+constexpr int kSumRowsPerLane = 4;   // loads a lane has in flight (one unrolled batch), then the tail
 
-template <int BPP>
-__global__ __launch_bounds__(kSumBlock) void blockhash_sums_kernel(const uint8_t *plane, uint32_t bw, uint32_t bh,
-                                                                   uint64_t stride, uint32_t row_begin,
-                                                                   uint32_t row_end, uint32_t chunks,
-                                                                   uint32_t *sums)
+struct SumPads {
+    const uint8_t *plane[kSumMaxPads];
+    uint64_t stride[kSumMaxPads];
+};
+
+// r+g+b of one RGBA pixel held in a dword (byte 3 = alpha): v_and + v_sad_u8; a fully transparent pixel counts as
+// white (765).  alpha == 0  <=>  the dword is < 2^24.
+__device__ __forceinline__ uint32_t rgba_brightness(uint32_t px)
+{
+    return px < 0x01000000u ? 765u : __builtin_amdgcn_sad_u8(px & 0x00ffffffu, 0u, 0u);
+}
+
+// One workgroup = 256 lanes laid out as LX x RY (LX = 2^lx_log2 lanes along the row, RY rows) inside ONE of the 64
+// blocks (blockIdx.y) of ONE pad (blockIdx.z).  UNIT is what a lane loads at a time: 16 bytes = 4 RGBA px (uint4),
+// 12 bytes = 4 RGB px (three dwords), or one pixel through byte loads when the frame is not aligned for those.
+// No division in the loop; kSumRowsPerLane independent loads are issued before the first add.
+template <int BPP, bool VEC>
+__global__ __launch_bounds__(kSumBlock) void blockhash_sums_kernel(SumPads pads, uint32_t bw, uint32_t bh,
+                                                                   uint32_t row_begin, uint32_t row_end,
+                                                                   uint32_t lx_log2, uint32_t *partials)
 {
     const uint32_t block = blockIdx.y;            // 0..63
     const uint32_t bx = block & 7, by = block >> 3;
+    const uint8_t *plane = pads.plane[blockIdx.z];
+    const uint64_t stride = pads.stride[blockIdx.z];
     uint32_t y0 = by * bh, y1 = y0 + bh;
     if (y0 < row_begin) y0 = row_begin;
     if (y1 > row_end) y1 = row_end;
+    const uint32_t lx = 1u << lx_log2, ry = kSumBlock >> lx_log2;
+    const uint32_t tx = threadIdx.x & (lx - 1), ty = threadIdx.x >> lx_log2;
+    const uint32_t step = gridDim.x * ry;
     uint32_t acc = 0;
-    if (y0 < y1) {
-        const uint32_t rows = y1 - y0;
-        if constexpr (BPP == 4) {
-            const bool vec = (bw & 3) == 0 && ((((uintptr_t)plane) | stride) & 15) == 0;
-            if (vec) {
-                const uint32_t gpr = bw >> 2; // uint4 groups per block row
-                const uint64_t total = (uint64_t)rows * gpr;
-                for (uint64_t i = (uint64_t)blockIdx.x * kSumBlock + threadIdx.x; i < total; i += (uint64_t)chunks * kSumBlock) {
-                    const uint32_t r = (uint32_t)(i / gpr), gx = (uint32_t)(i % gpr);
-                    const uint4 v = *reinterpret_cast<const uint4 *>(plane + (uint64_t)(y0 + r) * stride + ((uint64_t)bx * bw + gx * 4) * 4);
-                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint8_t *base = plane + (uint64_t)bx * bw * BPP;
+    uint32_t r = y0 + blockIdx.x * ry + ty;
+    if constexpr (VEC && BPP == 4) {
+        const uint32_t units = bw >> 2; // uint4 per block row
+        for (; r < y1 && y1 - r > (kSumRowsPerLane - 1) * step; r += kSumRowsPerLane * step) {
+            for (uint32_t u = tx; u < units; u += lx) {
+                sum_u32x4 v[kSumRowsPerLane];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t s = (w[k] & 0xff) + ((w[k] >> 8) & 0xff) + ((w[k] >> 16) & 0xff);
-                        acc += (w[k] >> 24) == 0 ? 765u : s; // fully transparent counts as white
-                    }
-                }
-            } else {
-                const uint64_t total = (uint64_t)rows * bw;
-                for (uint64_t i = (uint64_t)blockIdx.x * kSumBlock + threadIdx.x; i < total; i += (uint64_t)chunks * kSumBlock) {
-                    const uint32_t r = (uint32_t)(i / bw), x = (uint32_t)(i % bw);
-                    const uint8_t *p = plane + (uint64_t)(y0 + r) * stride + ((uint64_t)bx * bw + x) * 4;
-                    acc += p[3] == 0 ? 765u : (uint32_t)p[0] + p[1] + p[2];
-                }
-            }
-        } else {
-            const uint64_t total = (uint64_t)rows * bw;
-            for (uint64_t i = (uint64_t)blockIdx.x * kSumBlock + threadIdx.x; i < total; i += (uint64_t)chunks * kSumBlock) {
-                const uint32_t r = (uint32_t)(i / bw), x = (uint32_t)(i % bw);
-                const uint8_t *p = plane + (uint64_t)(y0 + r) * stride + ((uint64_t)bx * bw + x) * 3;
-                acc += (uint32_t)p[0] + p[1] + p[2];
+                for (int k = 0; k < kSumRowsPerLane; k++)
+                    v[k] = __builtin_nontemporal_load(reinterpret_cast<const sum_u32x4 *>(base + (uint64_t)(r + k * step) * stride) + u);
+#pragma unroll
+                for (int k = 0; k < kSumRowsPerLane; k++)
+                    acc += rgba_brightness(v[k].x) + rgba_brightness(v[k].y) + rgba_brightness(v[k].z) + rgba_brightness(v[k].w);
             }
         }
+        for (; r < y1; r += step)
+            for (uint32_t u = tx; u < units; u += lx) {
+                const sum_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const sum_u32x4 *>(base + (uint64_t)r * stride) + u);
+                acc += rgba_brightness(v.x) + rgba_brightness(v.y) + rgba_brightness(v.z) + rgba_brightness(v.w);
+            }
+    } else if constexpr (VEC && BPP == 3) {
+        const uint32_t units = bw >> 2; // 12 bytes = 4 RGB px: every byte counts, three v_sad_u8
+        for (; r < y1 && y1 - r > (kSumRowsPerLane - 1) * step; r += kSumRowsPerLane * step) {
+            for (uint32_t u = tx; u < units; u += lx) {
+                uint32_t v[kSumRowsPerLane][3];
+#pragma unroll
+                for (int k = 0; k < kSumRowsPerLane; k++) {
+                    const uint32_t *p = reinterpret_cast<const uint32_t *>(base + (uint64_t)(r + k * step) * stride) + 3 * u;
+                    v[k][0] = p[0]; v[k][1] = p[1]; v[k][2] = p[2];
+                }
+#pragma unroll
+                for (int k = 0; k < kSumRowsPerLane; k++)
+                    acc = __builtin_amdgcn_sad_u8(v[k][2], 0u, __builtin_amdgcn_sad_u8(v[k][1], 0u, __builtin_amdgcn_sad_u8(v[k][0], 0u, acc)));
+            }
+        }
+        for (; r < y1; r += step)
+            for (uint32_t u = tx; u < units; u += lx) {
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(base + (uint64_t)r * stride) + 3 * u;
+                acc = __builtin_amdgcn_sad_u8(p[2], 0u, __builtin_amdgcn_sad_u8(p[1], 0u, __builtin_amdgcn_sad_u8(p[0], 0u, acc)));
+            }
+    } else {
+        for (; r < y1; r += step)
+            for (uint32_t x = tx; x < bw; x += lx) {
+                const uint8_t *p = base + (uint64_t)r * stride + (uint64_t)x * BPP;
+                if constexpr (BPP == 4)
+                    acc += p[3] == 0 ? 765u : (uint32_t)p[0] + p[1] + p[2];
+                else
+                    acc += (uint32_t)p[0] + p[1] + p[2];
+            }
     }
     for (int off = 32; off > 0; off >>= 1)
         acc += __shfl_down(acc, off);
@@ -228,38 +269,87 @@ __global__ __launch_bounds__(kSumBlock) void blockhash_sums_kernel(const uint8_t
     if (threadIdx.x == 0) {
         uint32_t t = 0;
         for (int i = 0; i < kSumBlock / 64; i++) t += wave_sum[i];
-        if (t) atomicAdd(&sums[block], t);
+        partials[(blockIdx.z * 64 + block) * gridDim.x + blockIdx.x] = t; // plain store, see blockhash_reduce_kernel
     }
 }
 
-int blockhash_sums_impl(const mvfx_frame *frame, uint32_t row_begin, uint32_t row_end, uint32_t *sums_dev, hipStream_t st)
+// Second (tiny) launch: one wave per (pad, block) adds that block's per-workgroup partials and OVERWRITES sums[].
+// Same-address atomics straight from the first kernel cost ~0.25 us each once a few hundred workgroups hit one of
+// the 64 addresses (8K frame: 65 us with 135 atomics per address against 23.5 us with stores + this launch,
+// tools/probe_blockhash.hip); this launch also replaces the memset the atomics needed.
+__global__ __launch_bounds__(64) void blockhash_reduce_kernel(const uint32_t *partials, uint32_t per_block, uint32_t *sums)
 {
-    if (!frame || !sums_dev)
+    uint32_t a = 0;
+    for (uint32_t i = threadIdx.x; i < per_block; i += 64) a += partials[blockIdx.x * per_block + i];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+    if (threadIdx.x == 0) sums[blockIdx.x] = a;
+}
+
+// Block sums of rows [row_begin,row_end) of n_pads frames of one size and format -> sums_dev[n_pads][64]
+int blockhash_sums_impl(const mvfx_frame *frames, uint32_t n_pads, uint32_t row_begin, uint32_t row_end,
+                        uint32_t *sums_dev, hipStream_t st)
+{
+    if (!frames || !sums_dev || n_pads == 0)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "blockhash: NULL argument");
-    if (frame->format != MVFX_FORMAT_RGB && frame->format != MVFX_FORMAT_RGBA)
-        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "videocompare: format %d is not RGB / RGBA (videocompare/imp.rs:160-162)", frame->format);
-    if (int rc = check_packed_frame(frame, "videocompare"); rc != MVFX_OK) return rc;
-    if (frame->width == 0 || frame->height == 0 || frame->width % 8 != 0 || frame->height % 8 != 0)
+    const mvfx_frame *f0 = &frames[0];
+    for (uint32_t p = 0; p < n_pads; p++) {
+        const mvfx_frame *frame = &frames[p];
+        if (frame->format != MVFX_FORMAT_RGB && frame->format != MVFX_FORMAT_RGBA)
+            return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "videocompare: format %d is not RGB / RGBA (videocompare/imp.rs:160-162)", frame->format);
+        if (int rc = check_packed_frame(frame, "videocompare"); rc != MVFX_OK) return rc;
+        if (frame->width != f0->width || frame->height != f0->height)
+            return fail(MVFX_ERR_NOT_NEGOTIATED, "Video streams do not have the same sizes (videocompare/imp.rs:337-346)");
+        if (frame->format != f0->format)
+            return fail(MVFX_ERR_INVALID_ARGUMENT, "blockhash: the frames of one multi-pad call must share one format");
+    }
+    if (f0->width == 0 || f0->height == 0 || f0->width % 8 != 0 || f0->height % 8 != 0)
         return fail(MVFX_ERR_INVALID_ARGUMENT,
                     "blockhash: %ux%u is not a multiple of 8 in both dimensions; only the integer fast path of the "
-                    "blockhash algorithm is implemented", frame->width, frame->height);
+                    "blockhash algorithm is implemented", f0->width, f0->height);
     if (int rc = require_device(); rc != MVFX_OK) return rc;
-    if (row_end > frame->height) row_end = frame->height;
-    MVFX_HIP_TRY(hipMemsetAsync(sums_dev, 0, 64 * sizeof(uint32_t), st));
-    if (row_begin >= row_end)
+    if (row_end > f0->height) row_end = f0->height;
+    if (row_begin >= row_end) {
+        MVFX_HIP_TRY(hipMemsetAsync(sums_dev, 0, (size_t)n_pads * 64 * sizeof(uint32_t), st));
         return MVFX_OK;
-    const uint32_t bw = frame->width / 8, bh = frame->height / 8;
-    const uint64_t px_per_block = (uint64_t)bw * bh;
-    uint32_t chunks = (uint32_t)((px_per_block / 4 + kSumBlock * 8 - 1) / (kSumBlock * 8)); // ~8 uint4 per lane
-    if (chunks < 1) chunks = 1;
-    if (chunks > 256) chunks = 256;
-    const dim3 grid(chunks, 64, 1);
-    const uint8_t *p = static_cast<const uint8_t *>(frame->data);
-    if (frame->format == MVFX_FORMAT_RGBA)
-        hipLaunchKernelGGL(blockhash_sums_kernel<4>, grid, dim3(kSumBlock), 0, st, p, bw, bh, (uint64_t)frame->stride, row_begin, row_end, chunks, sums_dev);
-    else
-        hipLaunchKernelGGL(blockhash_sums_kernel<3>, grid, dim3(kSumBlock), 0, st, p, bw, bh, (uint64_t)frame->stride, row_begin, row_end, chunks, sums_dev);
-    MVFX_HIP_TRY(hipGetLastError());
+    }
+    const uint32_t bw = f0->width / 8, bh = f0->height / 8;
+    const int bpp = f0->format == MVFX_FORMAT_RGBA ? 4 : 3;
+    for (uint32_t first = 0; first < n_pads; first += kSumMaxPads) {
+        const uint32_t n = std::min<uint32_t>(kSumMaxPads, n_pads - first);
+        SumPads pads{};
+        bool vec = (bw & 3) == 0;
+        for (uint32_t p = 0; p < n; p++) {
+            pads.plane[p] = static_cast<const uint8_t *>(frames[first + p].data);
+            pads.stride[p] = frames[first + p].stride;
+            // 16-byte groups need 16-byte aligned block rows (RGBA); 12-byte groups need dword alignment (RGB)
+            const uintptr_t bits = reinterpret_cast<uintptr_t>(pads.plane[p]) | pads.stride[p] | (uintptr_t)((uint64_t)bw * bpp);
+            vec = vec && (bits & (bpp == 4 ? 15 : 3)) == 0;
+        }
+        const uint32_t units = vec ? bw >> 2 : bw;
+        uint32_t lx_log2 = 0;
+        while ((1u << lx_log2) < units && lx_log2 < 8) lx_log2++;
+        const uint32_t ry = kSumBlock >> lx_log2;
+        const uint32_t passes = (units + (1u << lx_log2) - 1) >> lx_log2; // loads per lane per row
+        // each lane: kSumRowsPerLane rows of `passes` loads (passes > 1 only for frames wider than 8192 px)
+        (void)passes;
+        uint32_t chunks = (bh + ry * kSumRowsPerLane - 1) / (ry * kSumRowsPerLane);
+        if (chunks < 1) chunks = 1;
+        if (chunks > 1024) chunks = 1024;
+        const dim3 grid(chunks, 64, n);
+        void *scratch = nullptr; // per-workgroup partials [pad][block][chunk], owned by the calling thread
+        if (int rc = host_scratch((size_t)n * 64 * chunks * sizeof(uint32_t), 2, &scratch); rc != MVFX_OK) return rc;
+        uint32_t *out = static_cast<uint32_t *>(scratch);
+        if (bpp == 4 && vec)
+            hipLaunchKernelGGL((blockhash_sums_kernel<4, true>), grid, dim3(kSumBlock), 0, st, pads, bw, bh, row_begin, row_end, lx_log2, out);
+        else if (bpp == 4)
+            hipLaunchKernelGGL((blockhash_sums_kernel<4, false>), grid, dim3(kSumBlock), 0, st, pads, bw, bh, row_begin, row_end, lx_log2, out);
+        else if (vec)
+            hipLaunchKernelGGL((blockhash_sums_kernel<3, true>), grid, dim3(kSumBlock), 0, st, pads, bw, bh, row_begin, row_end, lx_log2, out);
+        else
+            hipLaunchKernelGGL((blockhash_sums_kernel<3, false>), grid, dim3(kSumBlock), 0, st, pads, bw, bh, row_begin, row_end, lx_log2, out);
+        hipLaunchKernelGGL(blockhash_reduce_kernel, dim3(64 * n), dim3(64), 0, st, out, chunks, sums_dev + (size_t)first * 64);
+        MVFX_HIP_TRY(hipGetLastError());
+    }
     return MVFX_OK;
 }
 
@@ -468,27 +558,45 @@ int mvfx_colordetect_palette_host(const mvfx_frame *frame, uint32_t quality, uin
 int mvfx_blockhash_sums(const mvfx_frame *frame, uint32_t row_begin, uint32_t row_end, uint32_t *sums_device,
                         mvfx_stream stream)
 {
-    return blockhash_sums_impl(frame, row_begin, row_end, sums_device, as_stream(stream));
+    return blockhash_sums_impl(frame, 1, row_begin, row_end, sums_device, as_stream(stream));
+}
+
+// views of whole frames whose rows outside the band are never touched
+static int blockhash_bands_impl(const mvfx_frame *bands, uint32_t n_pads, uint32_t full_height, uint32_t band_first_row,
+                                uint32_t *sums_device, hipStream_t st)
+{
+    if (!bands || !sums_device || n_pads == 0)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "blockhash: NULL argument");
+    std::vector<mvfx_frame> whole(bands, bands + n_pads);
+    bool empty = false;
+    for (uint32_t p = 0; p < n_pads; p++) {
+        if ((uint64_t)band_first_row + bands[p].height > full_height)
+            return fail(MVFX_ERR_INVALID_ARGUMENT, "blockhash: band rows %u..%u exceed the frame height %u", band_first_row,
+                        band_first_row + bands[p].height, full_height);
+        if (bands[p].height != bands[0].height)
+            return fail(MVFX_ERR_NOT_NEGOTIATED, "Video streams do not have the same sizes (videocompare/imp.rs:337-346)");
+        empty = empty || bands[p].height == 0 || bands[p].width == 0;
+        whole[p].height = full_height;
+        whole[p].data = static_cast<uint8_t *>(bands[p].data) - (ptrdiff_t)((uint64_t)band_first_row * bands[p].stride);
+    }
+    if (empty) {
+        if (int rc = require_device(); rc != MVFX_OK) return rc;
+        MVFX_HIP_TRY(hipMemsetAsync(sums_device, 0, (size_t)n_pads * 64 * sizeof(uint32_t), st));
+        return MVFX_OK;
+    }
+    return blockhash_sums_impl(whole.data(), n_pads, band_first_row, band_first_row + bands[0].height, sums_device, st);
 }
 
 int mvfx_blockhash_sums_band(const mvfx_frame *band, uint32_t full_height, uint32_t band_first_row,
                              uint32_t *sums_device, mvfx_stream stream)
 {
-    if (!band || !sums_device)
-        return fail(MVFX_ERR_INVALID_ARGUMENT, "blockhash: NULL argument");
-    if ((uint64_t)band_first_row + band->height > full_height)
-        return fail(MVFX_ERR_INVALID_ARGUMENT, "blockhash: band rows %u..%u exceed the frame height %u", band_first_row,
-                    band_first_row + band->height, full_height);
-    // view of the whole frame whose rows outside the band are never touched
-    mvfx_frame whole = *band;
-    whole.height = full_height;
-    whole.data = static_cast<uint8_t *>(band->data) - (ptrdiff_t)((uint64_t)band_first_row * band->stride);
-    if (band->height == 0 || band->width == 0) {
-        if (int rc = require_device(); rc != MVFX_OK) return rc;
-        MVFX_HIP_TRY(hipMemsetAsync(sums_device, 0, 64 * sizeof(uint32_t), as_stream(stream)));
-        return MVFX_OK;
-    }
-    return blockhash_sums_impl(&whole, band_first_row, band_first_row + band->height, sums_device, as_stream(stream));
+    return blockhash_bands_impl(band, 1, full_height, band_first_row, sums_device, as_stream(stream));
+}
+
+int mvfx_blockhash_sums_pads(const mvfx_frame *bands, uint32_t n_pads, uint32_t full_height, uint32_t band_first_row,
+                             uint32_t *sums_device, mvfx_stream stream)
+{
+    return blockhash_bands_impl(bands, n_pads, full_height, band_first_row, sums_device, as_stream(stream));
 }
 
 int mvfx_blockhash_bits(const uint32_t sums_host[64], uint32_t width, uint32_t height, uint64_t *hash_out)
@@ -510,7 +618,7 @@ static int blockhash_common(const mvfx_frame *dev_frame, uint64_t *hash_out, hip
     void *scratch = nullptr;
     if (int rc = host_scratch(64 * sizeof(uint32_t), 3, &scratch); rc != MVFX_OK) return rc;
     uint32_t *sums_dev = static_cast<uint32_t *>(scratch);
-    if (int rc = blockhash_sums_impl(dev_frame, 0, dev_frame ? dev_frame->height : 0, sums_dev, st); rc != MVFX_OK) return rc;
+    if (int rc = blockhash_sums_impl(dev_frame, 1, 0, dev_frame ? dev_frame->height : 0, sums_dev, st); rc != MVFX_OK) return rc;
     uint32_t sums[64];
     MVFX_HIP_TRY(hipMemcpyAsync(sums, sums_dev, sizeof(sums), hipMemcpyDeviceToHost, st));
     MVFX_HIP_TRY(hipStreamSynchronize(st));
@@ -547,9 +655,23 @@ int mvfx_videocompare_distance(const mvfx_frame *reference_frame, const mvfx_fra
         return fail(MVFX_ERR_INVALID_ARGUMENT, "videocompare: NULL argument");
     if (reference_frame->width != other_frame->width || reference_frame->height != other_frame->height)
         return fail(MVFX_ERR_NOT_NEGOTIATED, "Video streams do not have the same sizes (videocompare/imp.rs:337-346)");
-    uint64_t a = 0, b = 0;
-    if (int rc = blockhash_common(reference_frame, &a, as_stream(stream)); rc != MVFX_OK) return rc;
-    if (int rc = blockhash_common(other_frame, &b, as_stream(stream)); rc != MVFX_OK) return rc;
+    // both pads in ONE launch, one D2H of 2 x 64 sums, one synchronisation
+    void *scratch = nullptr;
+    if (int rc = host_scratch(2 * 64 * sizeof(uint32_t), 3, &scratch); rc != MVFX_OK) return rc;
+    uint32_t *sums_dev = static_cast<uint32_t *>(scratch);
+    hipStream_t st = as_stream(stream);
+    uint32_t sums[128];
+    if (reference_frame->format == other_frame->format) {
+        const mvfx_frame pair[2] = {*reference_frame, *other_frame};
+        if (int rc = blockhash_sums_impl(pair, 2, 0, pair[0].height, sums_dev, st); rc != MVFX_OK) return rc;
+    } else { // RGB against RGBA: one launch per pad
+        if (int rc = blockhash_sums_impl(reference_frame, 1, 0, reference_frame->height, sums_dev, st); rc != MVFX_OK) return rc;
+        if (int rc = blockhash_sums_impl(other_frame, 1, 0, other_frame->height, sums_dev + 64, st); rc != MVFX_OK) return rc;
+    }
+    MVFX_HIP_TRY(hipMemcpyAsync(sums, sums_dev, sizeof(sums), hipMemcpyDeviceToHost, st));
+    MVFX_HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t a = blockhash_bits(sums, reference_frame->width, reference_frame->height);
+    const uint64_t b = blockhash_bits(sums + 64, other_frame->width, other_frame->height);
     *distance_out = (double)mvfx_hash_distance(a, b); // hashed_image.rs:70 `left.dist(right) as f64`
     return MVFX_OK;
 }

@@ -42,14 +42,21 @@ def band_rows(height: int, rank: int, world: int) -> Tuple[int, int]:
 
 def videocompare_sharded(partial_sums: Callable[[int], torch.Tensor], n_pads: int, width: int, height: int,
                          bits_from_sums: Callable[[Sequence[int], int, int], int], device: torch.device,
-                         group=None) -> List[float]:
+                         group=None, all_pads: bool = False) -> List[float]:
     """partial_sums(pad) -> uint32[64] tensor (on `device`) of THIS rank's band of pad's frame
-    (pad 0 = the reference pad, videocompare/imp.rs:210-233).
+    (pad 0 = the reference pad, videocompare/imp.rs:210-233); with all_pads=True, partial_sums()
+    -> [n_pads, 64] from ONE launch over every pad (mvfx_blockhash_sums_pads).
     Returns the distances of pads 1.. to the reference pad (videocompare/imp.rs:349-353)."""
-    parts = torch.stack([partial_sums(p).to(torch.int64) for p in range(n_pads)]).to(device)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    sharded = dist.is_initialized() and dist.get_world_size(group) > 1
+    if all_pads:
+        parts = partial_sums()
+        if sharded:  # u32 block sums travel as int64 so that the all-reduce cannot wrap a signed 32-bit lane
+            parts = (parts.to(torch.int64) & 0xFFFFFFFF).to(device)
+    else:
+        parts = (torch.stack([partial_sums(p).to(torch.int64) for p in range(n_pads)]) & 0xFFFFFFFF).to(device)
+    if sharded:
         dist.all_reduce(parts, op=dist.ReduceOp.SUM, group=group)  # n_pads x 64 values, latency-bound
-    totals = parts.cpu().tolist()
+    totals = [[int(v) & 0xFFFFFFFF for v in row] for row in parts.cpu().tolist()]  # u32 sums (int32 views wrap back)
     hashes = [bits_from_sums(t, width, height) for t in totals]
     return [float(bin(hashes[0] ^ h).count("1")) for h in hashes[1:]]
 

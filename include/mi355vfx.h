@@ -257,6 +257,12 @@ int mvfx_blockhash_sums(const mvfx_frame *frame, uint32_t row_begin, uint32_t ro
 int mvfx_blockhash_sums_band(const mvfx_frame *band, uint32_t full_height,
                              uint32_t band_first_row, uint32_t *sums_device,
                              mvfx_stream stream);
+/* The same for n_pads frames (or bands) of one size and format in ONE launch (what
+ * aggregate_frames hashes per output buffer: the reference pad + every other pad,
+ * videocompare/imp.rs:316,349-353) -> sums_device[n_pads][64].  Whole frames: full_height =
+ * height, band_first_row = 0. */
+int mvfx_blockhash_sums_pads(const mvfx_frame *bands, uint32_t n_pads, uint32_t full_height,
+                             uint32_t band_first_row, uint32_t *sums_device, mvfx_stream stream);
 int mvfx_blockhash_bits(const uint32_t sums_host[64], uint32_t width, uint32_t height,
                         uint64_t *hash_out);
 uint32_t mvfx_hash_distance(uint64_t a, uint64_t b);

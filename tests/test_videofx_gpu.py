@@ -102,7 +102,8 @@ def test_colordetect_errors(gpu):
 # ---------------------------------------------------------------- videocompare
 
 @pytest.mark.parametrize("fmt", ["RGBA", "RGB"])
-@pytest.mark.parametrize("geom", [(640, 480, 0), (64, 48, 12), (1920, 1080, 0), (8, 8, 0), (72, 40, 4)])
+@pytest.mark.parametrize("geom", [(640, 480, 0), (64, 48, 12), (1920, 1080, 0), (8, 8, 0), (72, 40, 4), (3840, 2160, 0),
+                                  (32, 1000, 0), (8224, 16, 16), (96, 8, 2)])
 def test_blockhash_sums_and_hash_match_oracle(gpu, fmt, geom):
     w, h, pad = geom
     bpp = 3 if fmt == "RGB" else 4
@@ -156,6 +157,44 @@ def test_blockhash_band_only_buffers(gpu):
         total += d.download(dtype=np.uint32)
     rc, sums = orc.blockhash_sums(f, w, h, w * 4, "RGBA")
     assert np.array_equal(total.astype(np.uint32), sums)
+
+
+@pytest.mark.parametrize("fmt", ["RGBA", "RGB"])
+def test_blockhash_multi_pad_launch(gpu, fmt):
+    """aggregate_frames hashes every pad per output buffer (videocompare/imp.rs:316,349-353): n pads in one launch,
+    per-pad strides, also as bands of a taller frame"""
+    w, h, n = 256, 64, 5
+    bpp = 3 if fmt == "RGB" else 4
+    strides = [w * bpp + 16 * (p % 3) for p in range(n)]
+    fs = [frames.random_frame(0x5EED0810 + p, w, h, bpp, strides[p]) for p in range(n)]
+    bufs = [gpu.DeviceBuffer(f.nbytes).upload(f) for f in fs]
+    arr = (gpu.Frame * n)(*[gpu.make_frame(bufs[p].ptr, w, h, strides[p], fmt) for p in range(n)])
+    d = gpu.DeviceBuffer(n * 256)
+    gpu.check(gpu.lib().mvfx_blockhash_sums_pads(arr, n, h, 0, ctypes.c_void_p(d.ptr), None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    got = d.download(dtype=np.uint32).reshape(n, 64)
+    for p in range(n):
+        rc, sums = orc.blockhash_sums(fs[p], w, h, strides[p], fmt)
+        assert rc == 0 and np.array_equal(got[p], sums)
+    # bands: rows 16..40 of every pad, each in its own buffer
+    r0, r1 = 16, 40
+    bands = [np.ascontiguousarray(f[r0:r1]) for f in fs]
+    bbufs = [gpu.DeviceBuffer(b.nbytes).upload(b) for b in bands]
+    barr = (gpu.Frame * n)(*[gpu.make_frame(bbufs[p].ptr, w, r1 - r0, strides[p], fmt) for p in range(n)])
+    gpu.check(gpu.lib().mvfx_blockhash_sums_pads(barr, n, h, r0, ctypes.c_void_p(d.ptr), None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    got = d.download(dtype=np.uint32).reshape(n, 64)
+    for p in range(n):
+        masked = fs[p].copy()
+        rc, full = orc.blockhash_sums(masked, w, h, strides[p], fmt)
+        masked[r0:r1] = 0
+        if bpp == 4:
+            masked[r0:r1, 3::4] = 255  # alpha 0 would count as white
+        rc, rest = orc.blockhash_sums(masked, w, h, strides[p], fmt)
+        assert np.array_equal(got[p], full - rest)
+    # sizes must match (videocompare/imp.rs:337-346)
+    arr[2].height = h // 2
+    assert gpu.lib().mvfx_blockhash_sums_pads(arr, n, h, 0, ctypes.c_void_p(d.ptr), None) == gpu.ERR_NOT_NEGOTIATED
 
 
 def test_videocompare_reference_pins(gpu):

@@ -182,6 +182,10 @@ def main():
         fr = [vfx.make_frame(src[i].data_ptr(), W8, H8, W8 * 4, "RGBA") for i in range(4)]
         ms = timeit(lambda i=0: vfx.check(lib.mvfx_blockhash_sums(ctypes.byref(fr[i % 4]), 0, H8, ctypes.c_void_p(sums.data_ptr()), sptr)), iters=300)
         report("blockhash sums 8K RGBA (one frame)", ms, W8 * H8 * 4, 1)
+        sums2 = torch.zeros(128, dtype=torch.int32, device=dev)
+        pairs = [(vfx.Frame * 2)(fr[(2 * k) % 4], fr[(2 * k + 1) % 4]) for k in range(2)]
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_blockhash_sums_pads(pairs[i % 2], 2, H8, 0, ctypes.c_void_p(sums2.data_ptr()), sptr)), iters=300)
+        report("blockhash sums 8K RGBA pair (one launch)", ms, 2 * W8 * H8 * 4, 2)
         src4 = rand_frames(POOL, NB, 11)
         fr = [vfx.make_frame(src4[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
         ms = timeit(lambda i=0: vfx.check(lib.mvfx_blockhash_sums(ctypes.byref(fr[i % POOL]), 0, H, ctypes.c_void_p(sums.data_ptr()), sptr)), iters=300)
