@@ -131,6 +131,10 @@ SIGNATURES = {
     "mvfx_blockhash": (c_int, [POINTER(Frame), POINTER(c_uint64), c_void_p]),
     "mvfx_blockhash_host": (c_int, [POINTER(Frame), POINTER(c_uint64)]),
     "mvfx_videocompare_distance": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(ctypes.c_double), c_void_p]),
+    "mvfx_image_hash": (c_int, [POINTER(Frame), ctypes.c_int32, POINTER(c_uint64), POINTER(c_uint32), c_void_p]),
+    "mvfx_image_hash_host": (c_int, [POINTER(Frame), ctypes.c_int32, POINTER(c_uint64), POINTER(c_uint32)]),
+    "mvfx_image_gray_resize_lanczos3": (c_int, [POINTER(Frame), c_uint32, c_uint32, c_void_p, c_void_p]),
+    "mvfx_videocompare_distance_algo": (c_int, [POINTER(Frame), POINTER(Frame), ctypes.c_int32, POINTER(ctypes.c_double), c_void_p]),
     "mvfx_ssim_partial_sums": (c_int, [POINTER(Frame), POINTER(Frame), c_uint32, c_uint32, POINTER(ctypes.c_double),
                                        POINTER(ctypes.c_double), POINTER(c_uint32), c_void_p]),
     "mvfx_ssim_partial_deviation": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_void_p]),
@@ -319,6 +323,18 @@ def blockhash_host(frame_bytes, width, height, stride, fmt):
     h = c_uint64()
     check(lib().mvfx_blockhash_host(ctypes.byref(f), ctypes.byref(h)))
     return h.value
+
+
+HASH_ALGOS = {"mean": 0, "gradient": 1, "vertgradient": 2, "doublegradient": 3, "blockhash": 4, "dssim": 5}
+
+
+def image_hash_host(frame_bytes, width, height, stride, fmt, algo):
+    """hash-algo mean / gradient / vertgradient / doublegradient of a host frame -> (hash bits, n_bits)"""
+    f = make_frame(frame_bytes.ctypes.data, width, height, stride, fmt)
+    h = c_uint64()
+    n = c_uint32()
+    check(lib().mvfx_image_hash_host(ctypes.byref(f), HASH_ALGOS[algo], ctypes.byref(h), ctypes.byref(n)))
+    return h.value, n.value
 
 
 def ssim_distance_host(a_bytes, b_bytes, width, height, stride_a, stride_b, fmt):

@@ -1,0 +1,343 @@
+// videocompare hash-algo = mean / gradient / vertgradient / doublegradient for gfx950
+// (HashAlg::{Mean,Gradient,VertGradient,DoubleGradient}, video/videofx/src/videocompare/hashed_image.rs:89-107
+//  -> image_hasher 3.1.1 `hash_image` on image 0.25.10: to_grayscale, imageops::resize(.., Lanczos3), then
+//  compare-to-mean / neighbour compares on the 8x8 / 9x8 / 8x9 / 5x5 bytes).  Neither crate is under
+//  /root/reference: PARITY UNPINNED against them; bit-exact against oracle/videofx_oracle.c.
+//
+// The resampler accumulates `t += px * w` in f32 in tap order, so each output value is one sequential chain of up
+// to 6 * (size / out) additions whose roundings all matter (a different order flips u8 values on rounding
+// boundaries).  What is parallel is everything around the chain:
+//   vsample_kernel   one lane per (column, output row): the lane walks its column's taps in order; the wave reads
+//                    64 consecutive pixels per tap (coalesced), integer Rec.709 luma on the fly, tap weights staged
+//                    through LDS (every lane of the group needs the same weight at the same time: broadcast reads).
+//                    8K frame -> 8 rows x 7680 columns = 61 440 chains of <= 3 240 taps.
+//   hsample_kernel   one workgroup per output pixel: 256 lanes form the products row[i] * w[i] into LDS, lane 0
+//                    adds them in order (the chain), clamps, rounds half away from zero, stores the byte.
+//   gray_kernel      the copy path of imageops::resize (frame already has the target size).
+// Tap tables come from the host (host/lanczos.cpp), cached per thread and frame size.
+#include "mvfx_internal.h"
+
+#include "lanczos.h"
+
+#include <cstring>
+#include <vector>
+
+namespace mvfx {
+namespace {
+
+constexpr int kVBlock = 256;
+constexpr uint32_t kVChunk = 2048;  // weights staged per LDS refill (8 KiB)
+constexpr int kHBlock = 256;
+constexpr uint32_t kHChunk = 4096;  // products per LDS refill (16 KiB)
+constexpr uint32_t kMaxOut = 64;    // largest resize target per axis (the hashes need <= 9)
+
+struct AxisDev {
+    uint32_t left[kMaxOut], count[kMaxOut], offset[kMaxOut];
+};
+
+// image 0.25 color.rs rgb_to_luma for u8: (2126 r + 7152 g + 722 b) / 10000 in u32
+__device__ __forceinline__ uint32_t luma709(uint32_t r, uint32_t g, uint32_t b) { return (2126u * r + 7152u * g + 722u * b) / 10000u; }
+
+template <int BPP, bool DWORD>
+__device__ __forceinline__ uint32_t load_luma(const uint8_t *p)
+{
+    if constexpr (BPP == 4 && DWORD) {
+        const uint32_t px = *reinterpret_cast<const uint32_t *>(p);
+        return luma709(px & 0xffu, (px >> 8) & 0xffu, (px >> 16) & 0xffu);
+    } else {
+        return luma709(p[0], p[1], p[2]);
+    }
+}
+
+template <int BPP, bool DWORD>
+__global__ __launch_bounds__(kVBlock) void vsample_kernel(const uint8_t *plane, uint64_t stride, uint32_t width,
+                                                          AxisDev ax, const float *weights, float *tmp)
+{
+    __shared__ float lw[kVChunk];
+    const uint32_t oy = blockIdx.y;
+    const uint32_t x = blockIdx.x * kVBlock + threadIdx.x;
+    const uint32_t n = ax.count[oy];
+    const float *w = weights + ax.offset[oy];
+    const uint8_t *col = plane + (uint64_t)ax.left[oy] * stride + (uint64_t)(x < width ? x : 0) * BPP;
+    float t = 0.0f;
+    for (uint32_t base = 0; base < n; base += kVChunk) {
+        const uint32_t m = min(kVChunk, n - base);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < m; i += kVBlock) lw[i] = w[base + i];
+        __syncthreads();
+        if (x < width) {
+            const uint8_t *p = col + (uint64_t)base * stride;
+            uint32_t i = 0;
+            for (; i + 8 <= m; i += 8) { // 8 independent loads in flight, then the 8 chained additions
+                uint32_t g[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) g[k] = load_luma<BPP, DWORD>(p + (uint64_t)(i + k) * stride);
+#pragma unroll
+                for (int k = 0; k < 8; k++) t = t + (float)g[k] * lw[i + k];
+            }
+            for (; i < m; i++) t = t + (float)load_luma<BPP, DWORD>(p + (uint64_t)i * stride) * lw[i];
+        }
+    }
+    if (x < width) tmp[(uint64_t)oy * width + x] = t;
+}
+
+__global__ __launch_bounds__(kHBlock) void hsample_kernel(const float *tmp, uint32_t width, AxisDev ax,
+                                                          const float *weights, uint8_t *out, uint32_t nw)
+{
+    __shared__ __attribute__((aligned(16))) float prod[kHChunk];
+    const uint32_t ox = blockIdx.x, oy = blockIdx.y;
+    const uint32_t n = ax.count[ox];
+    const float *w = weights + ax.offset[ox];
+    const float *row = tmp + (uint64_t)oy * width + ax.left[ox];
+    float t = 0.0f;
+    for (uint32_t base = 0; base < n; base += kHChunk) {
+        const uint32_t m = min(kHChunk, n - base);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < m; i += kHBlock) prod[i] = row[base + i] * w[base + i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t i = 0;
+            for (; i + 4 <= m; i += 4) {
+                const float4 q = *reinterpret_cast<const float4 *>(&prod[i]);
+                t = t + q.x; t = t + q.y; t = t + q.z; t = t + q.w;
+            }
+            for (; i < m; i++) t = t + prod[i];
+        }
+    }
+    if (threadIdx.x == 0) {
+        t = t < 0.0f ? 0.0f : (t > 255.0f ? 255.0f : t);  // image's clamp(): NaN passes through
+        const float r = roundf(t);                          // FloatNearest: half away from zero
+        out[oy * nw + ox] = r != r ? (uint8_t)0 : (uint8_t)r;
+    }
+}
+
+template <int BPP>
+__global__ __launch_bounds__(256) void gray_kernel(const uint8_t *plane, uint64_t stride, uint32_t width, uint32_t height, uint8_t *out)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= width * height) return;
+    const uint32_t y = i / width, x = i % width;
+    out[i] = (uint8_t)load_luma<BPP, false>(plane + (uint64_t)y * stride + (uint64_t)x * BPP);
+}
+
+// Per-thread plan cache: tap tables on the device for (width, height) -> (nw, nh), plus the f32 row buffer and the
+// output bytes.  The four hash algorithms need four targets; a new frame size replaces the oldest plan.
+struct Plan {
+    uint32_t w = 0, h = 0, nw = 0, nh = 0;
+    int device = -1;
+    AxisDev v{}, hz{};
+    float *weights = nullptr; // vertical weights followed by horizontal weights
+    size_t v_floats = 0;
+    float *tmp = nullptr;     // nh x w
+    uint8_t *out = nullptr;   // nw x nh
+    uint64_t stamp = 0;
+    void release()
+    {
+        if (weights) (void)hipFree(weights);
+        if (tmp) (void)hipFree(tmp);
+        if (out) (void)hipFree(out);
+        weights = nullptr; tmp = nullptr; out = nullptr; w = h = nw = nh = 0;
+    }
+};
+struct PlanCache {
+    Plan plans[4];
+    uint64_t clock = 0;
+    ~PlanCache() { for (Plan &p : plans) p.release(); }
+};
+thread_local PlanCache t_plans;
+
+int get_plan(uint32_t w, uint32_t h, uint32_t nw, uint32_t nh, hipStream_t st, Plan **out)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Plan *victim = &t_plans.plans[0];
+    for (Plan &p : t_plans.plans) {
+        if (p.w == w && p.h == h && p.nw == nw && p.nh == nh && p.device == dev) {
+            p.stamp = ++t_plans.clock;
+            *out = &p;
+            return MVFX_OK;
+        }
+        if (p.stamp < victim->stamp) victim = &p;
+    }
+    Plan &p = *victim;
+    MVFX_HIP_TRY(hipStreamSynchronize(st)); // an evicted plan may still be read by queued kernels
+    p.release();
+    const LanczosAxis va = lanczos3_axis(h, nh), ha = lanczos3_axis(w, nw);
+    for (uint32_t o = 0; o < nh; o++) { p.v.left[o] = va.left[o]; p.v.count[o] = va.count[o]; p.v.offset[o] = va.offset[o]; }
+    for (uint32_t o = 0; o < nw; o++) { p.hz.left[o] = ha.left[o]; p.hz.count[o] = ha.count[o]; p.hz.offset[o] = ha.offset[o]; }
+    p.v_floats = va.weights.size();
+    const size_t total = va.weights.size() + ha.weights.size();
+    if (hipMalloc(&p.weights, total * sizeof(float)) != hipSuccess || hipMalloc(&p.tmp, (size_t)nh * w * sizeof(float)) != hipSuccess ||
+        hipMalloc(&p.out, (size_t)nw * nh) != hipSuccess) {
+        p.release();
+        return fail(MVFX_ERR_OUT_OF_MEMORY, "videocompare: device allocation for the %ux%u -> %ux%u resize plan failed", w, h, nw, nh);
+    }
+    MVFX_HIP_TRY(hipMemcpy(p.weights, va.weights.data(), va.weights.size() * sizeof(float), hipMemcpyHostToDevice));
+    MVFX_HIP_TRY(hipMemcpy(p.weights + p.v_floats, ha.weights.data(), ha.weights.size() * sizeof(float), hipMemcpyHostToDevice));
+    p.w = w; p.h = h; p.nw = nw; p.nh = nh; p.device = dev;
+    p.stamp = ++t_plans.clock;
+    *out = &p;
+    return MVFX_OK;
+}
+
+// to_grayscale + imageops::resize(gray, nw, nh, Lanczos3) of a device frame -> nw*nh bytes on the host (synchronous)
+int gray_resize_impl(const mvfx_frame *frame, uint32_t nw, uint32_t nh, uint8_t *out_host, hipStream_t st)
+{
+    if (!frame || !out_host)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "videocompare: NULL argument");
+    if (frame->format != MVFX_FORMAT_RGB && frame->format != MVFX_FORMAT_RGBA)
+        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "videocompare: format %d is not RGB / RGBA (videocompare/imp.rs:160-162)", frame->format);
+    if (int rc = check_packed_frame(frame, "videocompare"); rc != MVFX_OK) return rc;
+    if (nw == 0 || nh == 0 || nw > kMaxOut || nh > kMaxOut)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "videocompare: resize target %ux%u outside 1..%u", nw, nh, kMaxOut);
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    const uint32_t w = frame->width, h = frame->height;
+    if (w == 0 || h == 0) { // imageops::resize of an empty image: a zeroed buffer
+        std::memset(out_host, 0, (size_t)nw * nh);
+        return MVFX_OK;
+    }
+    const uint8_t *plane = static_cast<const uint8_t *>(frame->data);
+    const bool rgba = frame->format == MVFX_FORMAT_RGBA;
+    if (nw == w && nh == h) { // same dimensions: imageops::resize copies, no resampling
+        void *scratch = nullptr;
+        if (int rc = host_scratch((size_t)w * h, 2, &scratch); rc != MVFX_OK) return rc;
+        uint8_t *out = static_cast<uint8_t *>(scratch);
+        const dim3 grid((w * h + 255) / 256);
+        if (rgba) hipLaunchKernelGGL(gray_kernel<4>, grid, dim3(256), 0, st, plane, (uint64_t)frame->stride, w, h, out);
+        else hipLaunchKernelGGL(gray_kernel<3>, grid, dim3(256), 0, st, plane, (uint64_t)frame->stride, w, h, out);
+        MVFX_HIP_TRY(hipGetLastError());
+        MVFX_HIP_TRY(hipMemcpyAsync(out_host, out, (size_t)w * h, hipMemcpyDeviceToHost, st));
+        MVFX_HIP_TRY(hipStreamSynchronize(st));
+        return MVFX_OK;
+    }
+    Plan *plan = nullptr;
+    if (int rc = get_plan(w, h, nw, nh, st, &plan); rc != MVFX_OK) return rc;
+    const dim3 vgrid((w + kVBlock - 1) / kVBlock, nh);
+    const bool dword = rgba && ((reinterpret_cast<uintptr_t>(plane) | frame->stride) & 3) == 0;
+    if (rgba && dword)
+        hipLaunchKernelGGL((vsample_kernel<4, true>), vgrid, dim3(kVBlock), 0, st, plane, (uint64_t)frame->stride, w, plan->v, plan->weights, plan->tmp);
+    else if (rgba)
+        hipLaunchKernelGGL((vsample_kernel<4, false>), vgrid, dim3(kVBlock), 0, st, plane, (uint64_t)frame->stride, w, plan->v, plan->weights, plan->tmp);
+    else
+        hipLaunchKernelGGL((vsample_kernel<3, false>), vgrid, dim3(kVBlock), 0, st, plane, (uint64_t)frame->stride, w, plan->v, plan->weights, plan->tmp);
+    hipLaunchKernelGGL(hsample_kernel, dim3(nw, nh), dim3(kHBlock), 0, st, plan->tmp, w, plan->hz, plan->weights + plan->v_floats, plan->out, nw);
+    MVFX_HIP_TRY(hipGetLastError());
+    MVFX_HIP_TRY(hipMemcpyAsync(out_host, plan->out, (size_t)nw * nh, hipMemcpyDeviceToHost, st));
+    MVFX_HIP_TRY(hipStreamSynchronize(st));
+    return MVFX_OK;
+}
+
+// image_hasher HashAlg::resize_dimensions for the default 8x8 hash size
+bool resize_dimensions(int algo, uint32_t *rw, uint32_t *rh)
+{
+    switch (algo) {
+    case MVFX_HASH_MEAN: *rw = 8; *rh = 8; return true;
+    case MVFX_HASH_GRADIENT: *rw = 9; *rh = 8; return true;
+    case MVFX_HASH_VERTGRADIENT: *rw = 8; *rh = 9; return true;
+    case MVFX_HASH_DOUBLEGRADIENT: *rw = 5; *rh = 5; return true;
+    default: return false;
+    }
+}
+
+// mean_hash_u8 / gradient_hash / vert_gradient_hash / double_gradient_hash on the resized bytes; bit k = the k-th
+// bool of the crate's iterator (the Hamming distance does not depend on the packing)
+uint64_t hash_bits(int algo, const uint8_t *px, uint32_t rw, uint32_t rh, uint32_t *n_bits)
+{
+    uint64_t h = 0;
+    uint32_t k = 0;
+    if (algo == MVFX_HASH_MEAN) {
+        uint32_t sum = 0;
+        for (uint32_t i = 0; i < rw * rh; i++) sum += px[i];
+        const uint8_t mean = (uint8_t)(sum / (rw * rh));
+        for (uint32_t i = 0; i < rw * rh; i++, k++)
+            if (px[i] >= mean) h |= 1ull << k;
+    }
+    if (algo == MVFX_HASH_GRADIENT || algo == MVFX_HASH_DOUBLEGRADIENT)
+        for (uint32_t y = 0; y < rh; y++)
+            for (uint32_t x = 0; x + 1 < rw; x++, k++)
+                if (px[y * rw + x] < px[y * rw + x + 1]) h |= 1ull << k;
+    if (algo == MVFX_HASH_VERTGRADIENT || algo == MVFX_HASH_DOUBLEGRADIENT)
+        for (uint32_t x = 0; x < rw; x++)
+            for (uint32_t y = 0; y + 1 < rh; y++, k++)
+                if (px[y * rw + x] < px[(y + 1) * rw + x]) h |= 1ull << k;
+    *n_bits = k;
+    return h;
+}
+
+int image_hash_impl(const mvfx_frame *frame, int algo, uint64_t *hash_out, uint32_t *n_bits_out, hipStream_t st)
+{
+    if (!hash_out)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "videocompare: NULL output");
+    uint32_t rw = 0, rh = 0;
+    if (!resize_dimensions(algo, &rw, &rh))
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "videocompare: hash algorithm %d is not mean / gradient / vertgradient / doublegradient", algo);
+    uint8_t px[kMaxOut * kMaxOut];
+    if (int rc = gray_resize_impl(frame, rw, rh, px, st); rc != MVFX_OK) return rc;
+    uint32_t n = 0;
+    *hash_out = hash_bits(algo, px, rw, rh, &n);
+    if (n_bits_out) *n_bits_out = n;
+    return MVFX_OK;
+}
+
+int upload_frame(const mvfx_frame *frame, int slot, mvfx_frame *dev_frame, hipStream_t st)
+{
+    if (!frame)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "videocompare: NULL frame");
+    if (int rc = check_packed_frame(frame, "videocompare"); rc != MVFX_OK) return rc;
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    const size_t bytes = (size_t)frame->stride * frame->height;
+    void *dev = nullptr;
+    if (int rc = host_scratch(bytes ? bytes : 16, slot, &dev); rc != MVFX_OK) return rc;
+    if (bytes)
+        MVFX_HIP_TRY(hipMemcpyAsync(dev, frame->data, bytes, hipMemcpyHostToDevice, st));
+    *dev_frame = *frame;
+    dev_frame->data = dev;
+    return MVFX_OK;
+}
+
+} // namespace
+} // namespace mvfx
+
+using namespace mvfx;
+
+extern "C" {
+
+int mvfx_image_gray_resize_lanczos3(const mvfx_frame *frame, uint32_t new_width, uint32_t new_height, uint8_t *out_host,
+                                    mvfx_stream stream)
+{
+    return gray_resize_impl(frame, new_width, new_height, out_host, as_stream(stream));
+}
+
+int mvfx_image_hash(const mvfx_frame *frame, int32_t hash_algo, uint64_t *hash_out, uint32_t *n_bits_out, mvfx_stream stream)
+{
+    return image_hash_impl(frame, hash_algo, hash_out, n_bits_out, as_stream(stream));
+}
+
+int mvfx_image_hash_host(const mvfx_frame *frame, int32_t hash_algo, uint64_t *hash_out, uint32_t *n_bits_out)
+{
+    mvfx_frame d;
+    hipStream_t st = host_stream();
+    if (int rc = upload_frame(frame, 0, &d, st); rc != MVFX_OK) return rc;
+    return image_hash_impl(&d, hash_algo, hash_out, n_bits_out, st);
+}
+
+// HasherEngine::from(algo) + hash_image x2 + compare (hashed_image.rs:24-107) for any hash-algo value
+int mvfx_videocompare_distance_algo(const mvfx_frame *reference_frame, const mvfx_frame *other_frame, int32_t hash_algo,
+                                    double *distance_out, mvfx_stream stream)
+{
+    if (!reference_frame || !other_frame || !distance_out)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "videocompare: NULL argument");
+    if (hash_algo == MVFX_HASH_BLOCKHASH)
+        return mvfx_videocompare_distance(reference_frame, other_frame, distance_out, stream);
+    if (hash_algo == MVFX_HASH_DSSIM)
+        return mvfx_ssim_distance(reference_frame, other_frame, distance_out, stream);
+    if (reference_frame->width != other_frame->width || reference_frame->height != other_frame->height)
+        return fail(MVFX_ERR_NOT_NEGOTIATED, "Video streams do not have the same sizes (videocompare/imp.rs:337-346)");
+    uint64_t a = 0, b = 0;
+    if (int rc = image_hash_impl(reference_frame, hash_algo, &a, nullptr, as_stream(stream)); rc != MVFX_OK) return rc;
+    if (int rc = image_hash_impl(other_frame, hash_algo, &b, nullptr, as_stream(stream)); rc != MVFX_OK) return rc;
+    *distance_out = (double)mvfx_hash_distance(a, b); // hashed_image.rs:70
+    return MVFX_OK;
+}
+
+} // extern "C"

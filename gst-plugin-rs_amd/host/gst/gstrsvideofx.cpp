@@ -533,9 +533,7 @@ static void gst_rounded_corners_init(GstRoundedCorners *self)
 
 GST_DEBUG_CATEGORY_STATIC(videocompare_debug);
 
-// enum HashAlgorithm (videocompare/mod.rs:57-92); `dssim` is a non-default cargo feature there
-enum { MVFX_HASH_MEAN = 0, MVFX_HASH_GRADIENT = 1, MVFX_HASH_VERTGRADIENT = 2, MVFX_HASH_DOUBLEGRADIENT = 3, MVFX_HASH_BLOCKHASH = 4,
-       MVFX_HASH_DSSIM = 5 /* mod.rs:86-91 */ };
+// enum HashAlgorithm (videocompare/mod.rs:57-92) = mvfx_hash_algo; `dssim` is a non-default cargo feature there
 
 static GType gst_video_compare_hash_algorithm_get_type(void)
 {
@@ -713,15 +711,18 @@ static int video_compare_ssim(GstPad *ref_pad, GstBuffer *ref_buf, GstPad *pad, 
     return rc;
 }
 
-// HasherEngine::hash_image (hashed_image.rs:24-64) on one pad's buffer
-static int video_compare_hash(GstPad *pad, GstBuffer *buf, uint64_t *hash, guint *w, guint *h)
+// HasherEngine::hash_image (hashed_image.rs:24-64) on one pad's buffer with the ImageHasher algorithms
+static int video_compare_hash(GstPad *pad, GstBuffer *buf, gint algo, uint64_t *hash, guint *w, guint *h)
 {
     CompareView v;
     int rc = compare_view_open(pad, buf, &v);
     if (rc != MVFX_OK) return rc;
     *w = v.f.width;
     *h = v.f.height;
-    rc = v.device ? mvfx_blockhash(&v.f, hash, mvfx_thread_stream()) : mvfx_blockhash_host(&v.f, hash);
+    if (algo == MVFX_HASH_BLOCKHASH)
+        rc = v.device ? mvfx_blockhash(&v.f, hash, mvfx_thread_stream()) : mvfx_blockhash_host(&v.f, hash);
+    else // mean / gradient / vertgradient / doublegradient
+        rc = v.device ? mvfx_image_hash(&v.f, algo, hash, NULL, mvfx_thread_stream()) : mvfx_image_hash_host(&v.f, algo, hash, NULL);
     compare_view_close(&v);
     return rc;
 }
@@ -743,8 +744,8 @@ static GstFlowReturn gst_video_compare_aggregate(GstAggregator *agg, gboolean ti
         GST_CAT_WARNING_OBJECT(videocompare_debug, self, "No reference sink pad exists");
         return GST_FLOW_EOS;
     }
-    if (algo != MVFX_HASH_BLOCKHASH && algo != MVFX_HASH_DSSIM) {
-        GST_ELEMENT_ERROR(self, LIBRARY, SETTINGS, ("hash-algo %d is not implemented by the MI355X build (blockhash, the default, and dssim are)", algo), (NULL));
+    if (algo < MVFX_HASH_MEAN || algo > MVFX_HASH_DSSIM) {
+        GST_ELEMENT_ERROR(self, LIBRARY, SETTINGS, ("unknown hash-algo %d", algo), (NULL));
         return GST_FLOW_ERROR;
     }
     GstAggregatorPad *ref_apad = GST_AGGREGATOR_PAD(reference_pad);
@@ -762,7 +763,7 @@ static GstFlowReturn gst_video_compare_aggregate(GstAggregator *agg, gboolean ti
 
     uint64_t ref_hash = 0;
     guint rw = 0, rh = 0;
-    int rc = algo == MVFX_HASH_DSSIM ? MVFX_OK : video_compare_hash(reference_pad, ref_buf, &ref_hash, &rw, &rh);
+    int rc = algo == MVFX_HASH_DSSIM ? MVFX_OK : video_compare_hash(reference_pad, ref_buf, algo, &ref_hash, &rw, &rh);
     if (rc != MVFX_OK) {
         gst_buffer_unref(ref_buf);
         return MVFX_GST_FLOW(self, rc);
@@ -792,7 +793,7 @@ static GstFlowReturn gst_video_compare_aggregate(GstAggregator *agg, gboolean ti
         if (algo == MVFX_HASH_DSSIM)
             rc = video_compare_ssim(reference_pad, ref_buf, pad, buf, &ssim_distance, &size_mismatch);
         else
-            rc = video_compare_hash(pad, buf, &hash, &w, &h);
+            rc = video_compare_hash(pad, buf, algo, &hash, &w, &h);
         gst_buffer_unref(buf);
         if (rc == MVFX_OK && (size_mismatch || w != rw || h != rh)) { // imp.rs:337-346
             GST_CAT_ERROR_OBJECT(videocompare_debug, self, "Video streams do not have the same sizes (add videoscale and force the sizes to be equal on all sink pads)");

@@ -273,6 +273,34 @@ int mvfx_blockhash_host(const mvfx_frame *frame, uint64_t *hash_out);
 int mvfx_videocompare_distance(const mvfx_frame *reference_frame, const mvfx_frame *other_frame,
                                double *distance_out, mvfx_stream stream);
 
+/* GstVideoCompareHashAlgorithm values (videocompare/mod.rs:57-92) */
+typedef enum mvfx_hash_algo {
+    MVFX_HASH_MEAN = 0,
+    MVFX_HASH_GRADIENT = 1,
+    MVFX_HASH_VERTGRADIENT = 2,
+    MVFX_HASH_DOUBLEGRADIENT = 3,
+    MVFX_HASH_BLOCKHASH = 4,
+    MVFX_HASH_DSSIM = 5
+} mvfx_hash_algo;
+
+/* hash-algo = mean / gradient / vertgradient / doublegradient (HasherEngine::from, hashed_image.rs:89-107 ->
+ * image_hasher 3.1.1 on image 0.25.10; crates not vendored under the reference: PARITY UNPINNED): integer
+ * Rec.709 grayscale, Lanczos3 resize to 8x8 / 9x8 / 8x9 / 5x5 with image 0.25's f32 accumulation order, then
+ * compare-to-mean / neighbour compares.  hash_out bit k = k-th bool of the crate's iterator; n_bits_out (may
+ * be NULL) = 64, 64, 64, 40.  RGB / RGBA only; synchronous. */
+int mvfx_image_hash(const mvfx_frame *frame, int32_t hash_algo, uint64_t *hash_out,
+                    uint32_t *n_bits_out, mvfx_stream stream);
+int mvfx_image_hash_host(const mvfx_frame *frame, int32_t hash_algo, uint64_t *hash_out,
+                         uint32_t *n_bits_out);
+/* The resampling step alone (image::imageops::grayscale + resize(.., FilterType::Lanczos3)):
+ * new_width x new_height bytes into host memory; targets up to 64 x 64.  Synchronous. */
+int mvfx_image_gray_resize_lanczos3(const mvfx_frame *frame, uint32_t new_width,
+                                    uint32_t new_height, uint8_t *out_host, mvfx_stream stream);
+/* hash_image x2 + compare for ANY hash-algo value (dispatches to the blockhash / dssim paths for 4 / 5) */
+int mvfx_videocompare_distance_algo(const mvfx_frame *reference_frame,
+                                    const mvfx_frame *other_frame, int32_t hash_algo,
+                                    double *distance_out, mvfx_stream stream);
+
 /* `hash-algo=dssim` (HashAlg::Dssim, videocompare/hashed_image.rs:49-59,72-75, cargo feature
  * `dssim`, NOT in the default build).  dssim-core 3.4.0 is not vendored under the reference:
  * this is the published multi-scale SSIM structure, PARITY UNPINNED against the

@@ -122,6 +122,13 @@ uint64_t orc_blockhash_bits(const uint32_t sums[64], uint32_t width, uint32_t he
 int orc_blockhash(const uint8_t *data, uint32_t width, uint32_t height, uint32_t stride,
                   int format, uint64_t *hash);
 uint32_t orc_hamming64(uint64_t a, uint64_t b);
+/* image_hasher 3.1.1 Mean / Gradient / VertGradient / DoubleGradient on image 0.25.10's grayscale +
+ * Lanczos3 resize (hashed_image.rs:89-107); algo = GstVideoCompareHashAlgorithm value 0..3.
+ * PARITY UNPINNED (crates not under /root/reference). */
+int orc_gray_resize_lanczos3(const uint8_t *data, uint32_t width, uint32_t height, uint32_t stride, int format,
+                             uint32_t nw, uint32_t nh, uint8_t *out);
+int orc_image_hash(const uint8_t *data, uint32_t width, uint32_t height, uint32_t stride, int format, int algo,
+                   uint64_t *hash, uint32_t *n_bits);
 
 /* SSIM-family distance behind hash-algo=dssim (dssim-core 3.4.0, non-default feature; PARITY
  * UNPINNED, see ssim_oracle.c): f64, formats RGB / RGBA. */

@@ -408,3 +408,147 @@ int orc_blockhash(const uint8_t *data, uint32_t width, uint32_t height, uint32_t
 }
 
 uint32_t orc_hamming64(uint64_t a, uint64_t b) { return (uint32_t)__builtin_popcountll(a ^ b); }
+
+/* ------------------------------------------------------------------ videocompare: Mean / Gradient /
+ * VertGradient / DoubleGradient (HashAlg::{Mean,Gradient,VertGradient,DoubleGradient},
+ * hashed_image.rs:89-107 -> image_hasher 3.1.1 on image 0.25.10; neither crate is under
+ * /root/reference: PARITY UNPINNED, restated from the crates' published sources).
+ *
+ * image_hasher: hash_image = to_grayscale -> imageops::resize(gray, w', h', Lanczos3) -> bytes ->
+ *   Mean (8x8):           mean = (sum / len) as u8; bit = px >= mean
+ *   Gradient (9x8):       per row, bit = px[i] < px[i+1]
+ *   VertGradient (8x9):   per column, bit = px[r] < px[r+1]
+ *   DoubleGradient (5x5): Gradient bits followed by VertGradient bits (40 bits)
+ * image::imageops::grayscale: Luma = (2126 r + 7152 g + 722 b) / 10000 in u32 (alpha ignored).
+ * image::imageops::resize: same size => copy; else vertical_sample (u8 -> f32 rows) then
+ *   horizontal_sample (f32 -> clamp -> round -> u8), weights lanczos3((i - centre) / sratio)
+ *   normalised by their f32 running sum, accumulation `t += px * w` in f32, in tap order. */
+
+static float lanczos_sinc(float t)
+{
+    float a = t * 3.14159274101257324f; /* f32::consts::PI */
+    return t == 0.0f ? 1.0f : sinf(a) / a;
+}
+
+static float lanczos3_kernel(float x)
+{
+    return fabsf(x) < 3.0f ? lanczos_sinc(x) * lanczos_sinc(x / 3.0f) : 0.0f;
+}
+
+/* taps of output sample `out` when resampling `in_size` -> `out_size`: [*left, *left + n) and n normalised weights */
+static uint32_t lanczos3_taps(uint32_t in_size, uint32_t out_size, uint32_t out, uint32_t *left_out, float *ws)
+{
+    float ratio = (float)in_size / (float)out_size;
+    float sratio = ratio < 1.0f ? 1.0f : ratio;
+    float src_support = 3.0f * sratio;
+    float input = ((float)out + 0.5f) * ratio;
+    int64_t left = (int64_t)floorf(input - src_support);
+    if (left < 0) left = 0;
+    if (left > (int64_t)in_size - 1) left = (int64_t)in_size - 1;
+    int64_t right = (int64_t)ceilf(input + src_support);
+    if (right < left + 1) right = left + 1;
+    if (right > (int64_t)in_size) right = (int64_t)in_size;
+    input = input - 0.5f;
+    float sum = 0.0f;
+    uint32_t n = 0;
+    for (int64_t i = left; i < right; i++) {
+        float w = lanczos3_kernel(((float)i - input) / sratio);
+        ws[n++] = w;
+        sum += w;
+    }
+    for (uint32_t k = 0; k < n; k++)
+        ws[k] /= sum;
+    *left_out = (uint32_t)left;
+    return n;
+}
+
+int orc_gray_resize_lanczos3(const uint8_t *data, uint32_t width, uint32_t height, uint32_t stride, int format,
+                             uint32_t nw, uint32_t nh, uint8_t *out)
+{
+    int bpp;
+    if (format == ORC_FORMAT_RGB) bpp = 3;
+    else if (format == ORC_FORMAT_RGBA) bpp = 4;
+    else return ORC_ERR_FORMAT;
+    if (width == 0 || height == 0) { /* resize of an empty image: a zeroed buffer */
+        memset(out, 0, (size_t)nw * nh);
+        return ORC_OK;
+    }
+    uint8_t *gray = (uint8_t *)malloc((size_t)width * height);
+    for (uint32_t y = 0; y < height; y++)
+        for (uint32_t x = 0; x < width; x++) {
+            const uint8_t *p = data + (size_t)y * stride + (size_t)x * (size_t)bpp;
+            uint32_t l = 2126u * p[0] + 7152u * p[1] + 722u * p[2];
+            gray[(size_t)y * width + x] = (uint8_t)(l / 10000u);
+        }
+    if (nw == width && nh == height) { /* same dimensions: a copy, no resampling */
+        memcpy(out, gray, (size_t)width * height);
+        free(gray);
+        return ORC_OK;
+    }
+    float *tmp = (float *)malloc((size_t)width * nh * sizeof(float));
+    float *ws = (float *)malloc(((size_t)(height > width ? height : width) + 8) * sizeof(float));
+    for (uint32_t oy = 0; oy < nh; oy++) { /* vertical_sample */
+        uint32_t left;
+        uint32_t n = lanczos3_taps(height, nh, oy, &left, ws);
+        for (uint32_t x = 0; x < width; x++) {
+            float t = 0.0f;
+            for (uint32_t i = 0; i < n; i++)
+                t += (float)gray[(size_t)(left + i) * width + x] * ws[i];
+            tmp[(size_t)oy * width + x] = t;
+        }
+    }
+    for (uint32_t ox = 0; ox < nw; ox++) { /* horizontal_sample */
+        uint32_t left;
+        uint32_t n = lanczos3_taps(width, nw, ox, &left, ws);
+        for (uint32_t y = 0; y < nh; y++) {
+            float t = 0.0f;
+            for (uint32_t i = 0; i < n; i++)
+                t += tmp[(size_t)y * width + left + i] * ws[i];
+            t = t < 0.0f ? 0.0f : (t > 255.0f ? 255.0f : t); /* NaN passes through; `as u8` makes it 0 */
+            float r = roundf(t);
+            out[(size_t)y * nw + ox] = r != r ? 0 : (uint8_t)r;
+        }
+    }
+    free(ws);
+    free(tmp);
+    free(gray);
+    return ORC_OK;
+}
+
+/* algo: 0 Mean, 1 Gradient, 2 VertGradient, 3 DoubleGradient (GstVideoCompareHashAlgorithm values,
+ * videocompare/mod.rs:57-92).  bit k of *hash = k-th bool the crate's iterator yields. */
+int orc_image_hash(const uint8_t *data, uint32_t width, uint32_t height, uint32_t stride, int format, int algo,
+                   uint64_t *hash, uint32_t *n_bits)
+{
+    uint32_t rw, rh;
+    switch (algo) {
+    case 0: rw = 8; rh = 8; break;
+    case 1: rw = 9; rh = 8; break;
+    case 2: rw = 8; rh = 9; break;
+    case 3: rw = 5; rh = 5; break;
+    default: return ORC_ERR_FORMAT;
+    }
+    uint8_t px[81];
+    int rc = orc_gray_resize_lanczos3(data, width, height, stride, format, rw, rh, px);
+    if (rc != ORC_OK) return rc;
+    uint64_t h = 0;
+    uint32_t k = 0;
+    if (algo == 0) {
+        uint32_t sum = 0;
+        for (uint32_t i = 0; i < rw * rh; i++) sum += px[i];
+        uint8_t mean = (uint8_t)(sum / (rw * rh));
+        for (uint32_t i = 0; i < rw * rh; i++, k++)
+            if (px[i] >= mean) h |= (uint64_t)1 << k;
+    }
+    if (algo == 1 || algo == 3)
+        for (uint32_t y = 0; y < rh; y++)
+            for (uint32_t x = 0; x + 1 < rw; x++, k++)
+                if (px[y * rw + x] < px[y * rw + x + 1]) h |= (uint64_t)1 << k;
+    if (algo == 2 || algo == 3)
+        for (uint32_t x = 0; x < rw; x++)
+            for (uint32_t y = 0; y + 1 < rh; y++, k++)
+                if (px[y * rw + x] < px[(y + 1) * rw + x]) h |= (uint64_t)1 << k;
+    *hash = h;
+    *n_bits = k;
+    return ORC_OK;
+}

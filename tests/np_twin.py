@@ -164,3 +164,89 @@ def colorlut_1d(rgb_values, maxv, tables, size, scale, offset):
         tab = _f(tables[c])
         out[:, c] = float_to_unorm(lerp(tab[i0], tab[i1], t), maxv)
     return out
+
+
+f32 = np.float32
+
+# ---------------------------------------------------------------- image 0.25 grayscale + Lanczos3 resize, image_hasher bits
+# Second, independent restatement (numpy float32, vectorised over the axis that is NOT summed; the tap loop stays
+# sequential so that every f32 rounding happens in the crate's order).  Shares only libm's sinf with the C oracle
+# (numpy's own float32 sin is a different implementation and need not agree with glibc in the last bit).
+
+def _sinf(x):
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.sinf.argtypes = [ctypes.c_float]
+    libm.sinf.restype = ctypes.c_float
+    return f32(libm.sinf(float(x)))
+
+
+def _lanczos3(x):
+    x = f32(x)
+    if not abs(x) < f32(3.0):
+        return f32(0.0)
+
+    def sinc(t):
+        a = f32(t * f32(np.pi))
+        return f32(1.0) if t == 0 else f32(_sinf(a) / a)
+    return f32(sinc(x) * sinc(f32(x / f32(3.0))))
+
+
+def lanczos3_taps(in_size, out_size, out):
+    ratio = f32(f32(in_size) / f32(out_size))
+    sratio = f32(1.0) if ratio < 1 else ratio
+    support = f32(f32(3.0) * sratio)
+    centre = f32(f32(f32(out) + f32(0.5)) * ratio)
+    left = int(np.floor(f32(centre - support)))
+    left = min(max(left, 0), in_size - 1)
+    right = int(np.ceil(f32(centre + support)))
+    right = min(max(right, left + 1), in_size)
+    centre = f32(centre - f32(0.5))
+    ws = [_lanczos3(f32(f32(f32(i) - centre) / sratio)) for i in range(left, right)]
+    total = f32(0.0)
+    for w in ws:
+        total = f32(total + w)
+    return left, np.array([f32(w / total) for w in ws], dtype=np.float32)
+
+
+def gray_resize_lanczos3(frame, width, height, bpp, nw, nh):
+    """frame: height x stride uint8 -> nh x nw uint8"""
+    px = frame[:, :width * bpp].reshape(height, width, bpp).astype(np.uint32)
+    gray = ((2126 * px[..., 0] + 7152 * px[..., 1] + 722 * px[..., 2]) // 10000).astype(np.uint8)
+    if (nw, nh) == (width, height):
+        return gray.copy()
+    g = gray.astype(np.float32)
+    tmp = np.zeros((nh, width), np.float32)
+    for oy in range(nh):
+        left, ws = lanczos3_taps(height, nh, oy)
+        t = np.zeros(width, np.float32)
+        for i, w in enumerate(ws):
+            t = t + g[left + i] * w          # float32 arrays: mul rounds, then add rounds
+        tmp[oy] = t
+    out = np.zeros((nh, nw), np.uint8)
+    for ox in range(nw):
+        left, ws = lanczos3_taps(width, nw, ox)
+        t = np.zeros(nh, np.float32)
+        for i, w in enumerate(ws):
+            t = t + tmp[:, left + i] * w
+        t = np.where(t < 0, f32(0), np.where(t > 255, f32(255), t))
+        r = np.sign(t) * np.floor(np.abs(t) + f32(0.5))   # round half away from zero (t >= 0 here)
+        out[:, ox] = np.nan_to_num(r, nan=0.0).astype(np.uint8)
+    return out
+
+
+def image_hash_bits(px, algo):
+    """px: the resized gray image (rows x cols uint8); returns the list of bools in the crate's iteration order"""
+    rows, cols = px.shape
+    bits = []
+    if algo == "mean":
+        mean = int(px.astype(np.uint32).sum()) // px.size
+        bits = [int(v) >= mean for v in px.reshape(-1)]
+    if algo in ("gradient", "doublegradient"):
+        bits += [bool(px[y, x] < px[y, x + 1]) for y in range(rows) for x in range(cols - 1)]
+    if algo in ("vertgradient", "doublegradient"):
+        bits += [bool(px[y, x] < px[y + 1, x]) for x in range(cols) for y in range(rows - 1)]
+    return bits
+
+
+HASH_RESIZE = {"mean": (8, 8), "gradient": (9, 8), "vertgradient": (8, 9), "doublegradient": (5, 5)}

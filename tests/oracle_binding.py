@@ -64,6 +64,10 @@ def lib():
         L.orc_blockhash_bits.restype = c_uint64
         L.orc_blockhash.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_int, POINTER(c_uint64)]
         L.orc_blockhash.restype = c_int
+        L.orc_gray_resize_lanczos3.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_int, c_uint32, c_uint32, c_void_p]
+        L.orc_gray_resize_lanczos3.restype = c_int
+        L.orc_image_hash.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_int, c_int, POINTER(c_uint64), POINTER(c_uint32)]
+        L.orc_image_hash.restype = c_int
         L.orc_hamming64.argtypes = [c_uint64, c_uint64]
         L.orc_hamming64.restype = c_uint32
         L.orc_ssim_distance.argtypes = [c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_int,
@@ -209,6 +213,23 @@ def blockhash(data: np.ndarray, width, height, stride, fmt):
     h = c_uint64()
     rc = lib().orc_blockhash(data.ctypes.data, width, height, stride, _fmt(fmt), ctypes.byref(h))
     return rc, h.value
+
+
+HASH_ALGOS = {"mean": 0, "gradient": 1, "vertgradient": 2, "doublegradient": 3, "blockhash": 4, "dssim": 5}
+
+
+def gray_resize_lanczos3(data: np.ndarray, width, height, stride, fmt, nw, nh):
+    out = np.zeros((nh, nw), np.uint8)
+    rc = lib().orc_gray_resize_lanczos3(data.ctypes.data, width, height, stride, _fmt(fmt), nw, nh, out.ctypes.data)
+    return rc, out
+
+
+def image_hash(data: np.ndarray, width, height, stride, fmt, algo):
+    """(rc, hash bits as int, n_bits) for algo in mean / gradient / vertgradient / doublegradient"""
+    h = c_uint64()
+    n = c_uint32()
+    rc = lib().orc_image_hash(data.ctypes.data, width, height, stride, _fmt(fmt), HASH_ALGOS[algo], ctypes.byref(h), ctypes.byref(n))
+    return rc, h.value, n.value
 
 
 def hamming(a, b):

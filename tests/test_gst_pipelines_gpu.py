@@ -131,11 +131,19 @@ def test_videocompare_snow_vs_red_is_silent(gpu, tmp_path):
     assert m and int(m.group(1)) > 0
 
 
-def test_videocompare_unimplemented_algo_errors(gpu, tmp_path):
-    caps = "video/x-raw,format=RGBA,width=64,height=48"
-    r = gst_env.run([LAUNCH] + (f"videocompare name=c hash-algo=mean ! fakesink videotestsrc num-buffers=1 ! {caps} ! c.sink_0 "
-                                f"videotestsrc num-buffers=1 ! {caps} ! c.sink_1").split(), tmp_path)
-    assert r.returncode != 0 and "not implemented" in r.stdout
+@pytest.mark.parametrize("algo", ["mean", "gradient", "vertgradient", "doublegradient"])
+def test_videocompare_resize_hashes(gpu, tmp_path, algo):
+    """tests/videocompare.rs:57-139 with the other ImageHasher algorithms (hashed_image.rs:89-107): identical frames =>
+    message with distance 0; smpte vs snow => silent at threshold 0, a positive distance with a generous threshold"""
+    out = _videocompare(tmp_path, "red", "red", f"hash-algo={algo}")
+    msgs = re.findall(r"videocompare, running-time=\(guint64\)(\d+), pad-distances=\(structure\)<([^>]*)>", out)
+    assert len(msgs) >= 1, out
+    assert re.search(r"distance\\=\\\(double\\\)0", msgs[0][1]), msgs[0][1]
+    out = _videocompare(tmp_path, "smpte", "snow", f"hash-algo={algo}")
+    assert "videocompare, running-time" not in out
+    out = _videocompare(tmp_path, "smpte", "snow", f"hash-algo={algo} max-dist-threshold=64")
+    m = re.search(r"distance\\=\\\(double\\\)(\d+)", out)
+    assert m and int(m.group(1)) > 0, out
 
 
 def test_videocompare_dssim_red_vs_red_and_snow(gpu, tmp_path):
@@ -216,7 +224,7 @@ def test_hipmemory_buffers_come_from_the_negotiated_pool(gpu, tmp_path):
     assert 3 <= len(allocated) <= 24, (len(allocated), r.stdout[-2000:])  # recycled, far fewer than 3 * 40
 
 
-@pytest.mark.parametrize("algo", ["blockhash", "dssim"])
+@pytest.mark.parametrize("algo", ["blockhash", "dssim", "gradient"])
 def test_videocompare_on_hipmemory_pads(gpu, tmp_path, algo):
     """Both pads fed with memory:HIPMemory buffers: the frames are hashed / compared where they are (no download);
     same messages as the system-memory pipelines of tests/videocompare.rs."""

@@ -191,6 +191,15 @@ def main():
         ms = timeit(lambda i=0: vfx.check(lib.mvfx_blockhash_sums(ctypes.byref(fr[i % POOL]), 0, H, ctypes.c_void_p(sums.data_ptr()), sptr)), iters=300)
         report("blockhash sums 4K RGBA", ms, NB, 1)
 
+    if want("imghash"):
+        W8, H8 = 7680, 4320
+        src = rand_frames(4, W8 * H8 * 4, 14)
+        fr = [vfx.make_frame(src[i].data_ptr(), W8, H8, W8 * 4, "RGBA") for i in range(4)]
+        hv = ctypes.c_uint64()
+        for name, algo in (("mean 8x8", 0), ("gradient 9x8", 1), ("doublegradient 5x5", 3)):
+            ms = timeit(lambda i=0: vfx.check(lib.mvfx_image_hash(ctypes.byref(fr[i % 4]), algo, ctypes.byref(hv), None, sptr)), iters=50, settle_s=0.3)
+            report(f"videocompare {name} hash 8K RGBA (gray + Lanczos3 resize, synchronous)", ms, W8 * H8 * 4, 1)
+
     if want("ssim"):
         for (w, h, tag) in ((W, H, "4K"), (7680, 4320, "8K")):
             if os.environ.get("SSIM_ONLY", tag) != tag:
