@@ -6,9 +6,9 @@
 //     flat plane (padding included, colordetect/imp.rs:69).  Kernel: 1024-thread workgroups,
 //     LDS-privatised 32768-bin histogram packed as 16-bit pairs (64 KiB, two workgroups per CU;
 //     each workgroup is given < 65536 samples so a 16-bit bin cannot overflow), per-wave
-//     min/max folded through LDS, then one device-scope atomic per NON-EMPTY bin into the 128 KiB
-//     global table (dense partial histograms + a reduce kernel were 3x slower: 47 us vs the
-//     frame's 6.6 us read time).  The serial median cut runs on the host (host/mmcq.cpp), as it
+//     min/max folded through LDS, then one 64-bit device-scope atomic per NON-EMPTY pair of bins into
+//     the 128 KiB global table (dense partial histograms + a reduce kernel were 3x slower: 47 us vs
+//     the frame's 6.6 us read time).  The serial median cut runs on the host (host/mmcq.cpp), as it
 //     does in the reference.
 //  videocompare (video/videofx/src/videocompare/hashed_image.rs:24-79 -> image_hasher Blockhash)
 //     64 block sums (u32) of r+g+b (765 when alpha==0) over an 8x8 grid of W/8 x H/8 blocks:
@@ -39,6 +39,7 @@ constexpr int kHistBlock = 1024;
 constexpr uint32_t kHistWords = kHistBins / 2;         // packed u16 pairs
 constexpr uint32_t kMaxSamplesPerGroup = 65535;        // 16-bit bins cannot overflow
 constexpr uint32_t kMaxGroupsPerLaunch = 2048;
+constexpr int kHistInFlight = 1;                       // sample loads a lane issues before binning
 
 struct HistLayout {
     int bpp, ir, ig, ib, ia; // ia < 0: no alpha (255)
@@ -59,25 +60,41 @@ __global__ __launch_bounds__(kHistBlock) void colordetect_hist_kernel(
     const uint64_t g_begin = (uint64_t)blockIdx.x * samples_per_group;
     const uint64_t g_end = min(g_begin + samples_per_group, n_samples);
     uint32_t mn[3] = {255, 255, 255}, mx[3] = {0, 0, 0};
-    for (uint64_t k = g_begin + threadIdx.x; k < g_end; k += kHistBlock) {
-        const uint8_t *p = plane + (first_sample + k) * quality * (uint64_t)lay.bpp;
-        uint32_t r, g, b, a;
-        if (lay.bpp == 4 && (((uintptr_t)p) & 3) == 0) {
-            const uint32_t px = *reinterpret_cast<const uint32_t *>(p);
-            r = (px >> (8 * lay.ir)) & 0xff; g = (px >> (8 * lay.ig)) & 0xff;
-            b = (px >> (8 * lay.ib)) & 0xff; a = (px >> (8 * lay.ia)) & 0xff;
-        } else {
-            r = p[lay.ir]; g = p[lay.ig]; b = p[lay.ib];
-            a = lay.ia >= 0 ? p[lay.ia] : 255u;
+    // kHistInFlight sample loads per lane are issued before the first one is binned.  Measured on 4K q=10: 1 / 2 / 4 / 8
+    // in flight = 14.5 / 14.7 / 15.4 / 17.0 us on smooth content (binning a burst of samples at once piles same-bin
+    // LDS atomics on top of each other), 24.6 / 24.8 / 22.6 / 23.9 us on uniform-random colours => 1.
+    const bool dword = lay.bpp == 4 && ((reinterpret_cast<uintptr_t>(plane) | (uintptr_t)(quality * 4u)) & 3) == 0;
+    for (uint64_t k0 = g_begin + threadIdx.x; k0 < g_end; k0 += (uint64_t)kHistBlock * kHistInFlight) {
+        uint32_t px[kHistInFlight];
+#pragma unroll
+        for (int j = 0; j < kHistInFlight; j++) {
+            const uint64_t k = k0 + (uint64_t)j * kHistBlock;
+            px[j] = 0; // alpha 0: skipped below
+            if (k < g_end) {
+                const uint8_t *p = plane + (first_sample + k) * quality * (uint64_t)lay.bpp;
+                if (dword) {
+                    const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p));
+                    px[j] = ((v >> (8 * lay.ir)) & 0xff) | (((v >> (8 * lay.ig)) & 0xff) << 8) |
+                            (((v >> (8 * lay.ib)) & 0xff) << 16) | (((v >> (8 * lay.ia)) & 0xff) << 24);
+                } else {
+                    px[j] = (uint32_t)p[lay.ir] | ((uint32_t)p[lay.ig] << 8) | ((uint32_t)p[lay.ib] << 16) |
+                            ((lay.ia >= 0 ? (uint32_t)p[lay.ia] : 255u) << 24);
+                }
+            }
         }
-        if (a < 125 || (r > 250 && g > 250 && b > 250)) // mostly transparent or white: skipped
-            continue;
-        r >>= 3; g >>= 3; b >>= 3;
-        mn[0] = min(mn[0], r); mx[0] = max(mx[0], r);
-        mn[1] = min(mn[1], g); mx[1] = max(mx[1], g);
-        mn[2] = min(mn[2], b); mx[2] = max(mx[2], b);
-        const uint32_t bin = (r << 10) | (g << 5) | b;
-        atomicAdd(&bins[bin >> 1], 1u << ((bin & 1) * 16));
+#pragma unroll
+        for (int j = 0; j < kHistInFlight; j++) {
+            uint32_t r = px[j] & 0xff, g = (px[j] >> 8) & 0xff, b = (px[j] >> 16) & 0xff;
+            const uint32_t a = px[j] >> 24;
+            if (a < 125 || (r > 250 && g > 250 && b > 250)) // mostly transparent or white: skipped
+                continue;
+            r >>= 3; g >>= 3; b >>= 3;
+            mn[0] = min(mn[0], r); mx[0] = max(mx[0], r);
+            mn[1] = min(mn[1], g); mx[1] = max(mx[1], g);
+            mn[2] = min(mn[2], b); mx[2] = max(mx[2], b);
+            const uint32_t bin = (r << 10) | (g << 5) | b;
+            atomicAdd(&bins[bin >> 1], 1u << ((bin & 1) * 16));
+        }
     }
     // wave-level min/max, then one LDS atomic per wave
 #pragma unroll
@@ -92,13 +109,16 @@ __global__ __launch_bounds__(kHistBlock) void colordetect_hist_kernel(
         }
     }
     __syncthreads();
-    // flush: only the non-empty bins, one device-scope atomic each (a frame of natural video
-    // touches a small part of the 32768 bins; the worst case, every sample in its own bin, is no
-    // more atomics than there are samples)
+    // flush: only the non-empty LDS words, ONE 64-bit device-scope atomic per word = two neighbouring bins (their u32
+    // counters sit side by side in the 8-byte aligned global table and a bin cannot reach 2^32 samples, so the low half
+    // never carries into the high one).  Device-scope atomics run at ~55 G/s on this part, which is what bounds
+    // uniform-random colours (every sample its own bin): 32.2 us with one 32-bit atomic per bin, 24.6 us packed;
+    // natural video touches a few thousand bins per group and spends ~1.5 us here.
     for (uint32_t i = threadIdx.x; i < kHistWords; i += kHistBlock) {
         const uint32_t v = bins[i];
-        if (v & 0xffffu) atomicAdd(&hist[2 * i], v & 0xffffu);
-        if (v >> 16) atomicAdd(&hist[2 * i + 1], v >> 16);
+        if (v)
+            atomicAdd(reinterpret_cast<unsigned long long *>(hist) + i,
+                      (unsigned long long)(v & 0xffffu) | ((unsigned long long)(v >> 16) << 32));
     }
     if (threadIdx.x < 3) {
         atomicMin(&minmax[2 * threadIdx.x], s_min[threadIdx.x]);
