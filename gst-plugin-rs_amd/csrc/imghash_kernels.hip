@@ -49,6 +49,87 @@ __device__ __forceinline__ uint32_t load_luma(const uint8_t *p)
     }
 }
 
+
+// vsample_block_kernel: the vertical pass for targets of <= 16 rows (every hash needs <= 9) reading the frame ONCE.
+// A 1024-lane workgroup owns kVCols columns for ALL output rows.  Per chunk of kVRows input rows:
+//   produce  all 16 waves load their pixels of the NEXT chunk (issued before the adds of the current one, so the HBM
+//            round trip overlaps them), convert to integer Rec.709 luma and park it in LDS as f32;
+//   add      wave `oy` (< nh) walks the rows of the chunk that fall into its tap window, lane = column:
+//            t = t + G[row][column] * w[row - left], the crate's order; the weight index is wave-uniform (scalar loads).
+// 8K frame, vertical pass: 220 us for the first version (vsample_kernel below: one lane per (column, output row), every
+// row re-read by the ~6 output rows whose windows cover it, one wave per SIMD, one HBM round trip per 8 taps) and for
+// this kernel while the adders fetched their weights from global memory; 128 us with the weights staged in LDS and 16
+// taps read before they are added.  What is left is adder VALU time: 9 chains x 3 240 taps x 3 instructions per 32
+// columns, on the 5 SIMD-slots the adder waves of a workgroup occupy.
+constexpr int kVBlockAll = 1024;
+constexpr uint32_t kVCols = 32;   // columns per workgroup (128-byte row segments for RGBA)
+constexpr uint32_t kVRows = 128;  // input rows per chunk: G = 128 x 32 f32 = 16 KiB
+constexpr uint32_t kVPasses = kVRows * kVCols / kVBlockAll; // loads per lane per chunk (4)
+
+template <int BPP, bool DWORD>
+__global__ __launch_bounds__(kVBlockAll) void vsample_block_kernel(const uint8_t *__restrict__ plane, uint64_t stride, uint32_t width,
+                                                                   uint32_t height, uint32_t nh, AxisDev ax,
+                                                                   const float *__restrict__ weights, float *__restrict__ tmp)
+{
+    __shared__ float G[kVRows][kVCols];                       // luma of the chunk, f32
+    __shared__ __attribute__((aligned(16))) float W[kVBlockAll / 64][kVRows]; // weights of the chunk per output row, 0 outside its window
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    // producer role: lane -> (row within pass, column) for pixels, (output row, row of the chunk) for weights
+    const uint32_t pc = threadIdx.x % kVCols, pr = threadIdx.x / kVCols; // pr in 0..31
+    const uint32_t x = blockIdx.x * kVCols + pc;
+    const bool px_ok = x < width;
+    const uint8_t *col = plane + (uint64_t)(px_ok ? x : 0) * BPP;
+    constexpr uint32_t kWPasses = (kVBlockAll / 64) * kVRows / kVBlockAll; // 2
+    // adder role: wave = output row, lane = column
+    const bool adder = wave < nh && lane < kVCols;
+    const uint32_t a_left = wave < nh ? ax.left[wave] : 0, a_count = wave < nh ? ax.count[wave] : 0;
+    float t = 0.0f;
+
+    uint32_t g[kVPasses];
+    float wv[kWPasses];
+    auto load_chunk = [&](uint32_t base) {
+#pragma unroll
+        for (uint32_t k = 0; k < kVPasses; k++) {
+            const uint32_t r = base + pr + (kVBlockAll / kVCols) * k;
+            g[k] = (px_ok && r < height) ? load_luma<BPP, DWORD>(col + (uint64_t)r * stride) : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kWPasses; k++) {
+            const uint32_t idx = threadIdx.x + kVBlockAll * k, oy = idx / kVRows, r = base + idx % kVRows;
+            // a weight of exactly 0 outside the tap window: t + G * 0 == t, so the adders run whole chunks
+            wv[k] = (oy < nh && r >= ax.left[oy] && r - ax.left[oy] < ax.count[oy]) ? weights[ax.offset[oy] + (r - ax.left[oy])] : 0.0f;
+        }
+    };
+    load_chunk(0);
+    for (uint32_t base = 0; base < height; base += kVRows) {
+#pragma unroll
+        for (uint32_t k = 0; k < kVPasses; k++) G[pr + (kVBlockAll / kVCols) * k][pc] = (float)g[k];
+#pragma unroll
+        for (uint32_t k = 0; k < kWPasses; k++) (&W[0][0])[threadIdx.x + kVBlockAll * k] = wv[k];
+        __syncthreads();
+        if (base + kVRows < height) load_chunk(base + kVRows); // in flight while the adders run
+        if (adder && base < a_left + a_count && base + kVRows > a_left) {
+            for (uint32_t i = 0; i < kVRows; i += 16) { // 16 LDS pixel reads + 4 weight reads issued, then the 16 chained additions
+                float gv[16];
+                float4 wq[4];
+#pragma unroll
+                for (int k = 0; k < 16; k++) gv[k] = G[i + k][lane];
+#pragma unroll
+                for (int k = 0; k < 4; k++) wq[k] = *reinterpret_cast<const float4 *>(&W[wave][i + 4 * k]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    t = t + gv[4 * k] * wq[k].x; t = t + gv[4 * k + 1] * wq[k].y;
+                    t = t + gv[4 * k + 2] * wq[k].z; t = t + gv[4 * k + 3] * wq[k].w;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const uint32_t ax_x = blockIdx.x * kVCols + lane;
+    if (adder && ax_x < width) tmp[(uint64_t)wave * width + ax_x] = t;
+}
+
 template <int BPP, bool DWORD>
 __global__ __launch_bounds__(kVBlock) void vsample_kernel(const uint8_t *plane, uint64_t stride, uint32_t width,
                                                           AxisDev ax, const float *weights, float *tmp)
@@ -97,9 +178,12 @@ __global__ __launch_bounds__(kHBlock) void hsample_kernel(const float *tmp, uint
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t i = 0;
-            for (; i + 4 <= m; i += 4) {
-                const float4 q = *reinterpret_cast<const float4 *>(&prod[i]);
-                t = t + q.x; t = t + q.y; t = t + q.z; t = t + q.w;
+            for (; i + 16 <= m; i += 16) { // four 16-byte LDS reads in flight, then the 16 chained additions
+                float4 q[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) q[k] = *reinterpret_cast<const float4 *>(&prod[i + 4 * k]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) { t = t + q[k].x; t = t + q[k].y; t = t + q[k].z; t = t + q[k].w; }
             }
             for (; i < m; i++) t = t + prod[i];
         }
@@ -212,14 +296,24 @@ int gray_resize_impl(const mvfx_frame *frame, uint32_t nw, uint32_t nh, uint8_t 
     }
     Plan *plan = nullptr;
     if (int rc = get_plan(w, h, nw, nh, st, &plan); rc != MVFX_OK) return rc;
-    const dim3 vgrid((w + kVBlock - 1) / kVBlock, nh);
     const bool dword = rgba && ((reinterpret_cast<uintptr_t>(plane) | frame->stride) & 3) == 0;
-    if (rgba && dword)
-        hipLaunchKernelGGL((vsample_kernel<4, true>), vgrid, dim3(kVBlock), 0, st, plane, (uint64_t)frame->stride, w, plan->v, plan->weights, plan->tmp);
-    else if (rgba)
-        hipLaunchKernelGGL((vsample_kernel<4, false>), vgrid, dim3(kVBlock), 0, st, plane, (uint64_t)frame->stride, w, plan->v, plan->weights, plan->tmp);
-    else
-        hipLaunchKernelGGL((vsample_kernel<3, false>), vgrid, dim3(kVBlock), 0, st, plane, (uint64_t)frame->stride, w, plan->v, plan->weights, plan->tmp);
+    if (nh <= kVBlockAll / 64) { // one pass over the frame, all output rows at once
+        const dim3 bgrid((w + kVCols - 1) / kVCols);
+        if (rgba && dword)
+            hipLaunchKernelGGL((vsample_block_kernel<4, true>), bgrid, dim3(kVBlockAll), 0, st, plane, (uint64_t)frame->stride, w, h, nh, plan->v, plan->weights, plan->tmp);
+        else if (rgba)
+            hipLaunchKernelGGL((vsample_block_kernel<4, false>), bgrid, dim3(kVBlockAll), 0, st, plane, (uint64_t)frame->stride, w, h, nh, plan->v, plan->weights, plan->tmp);
+        else
+            hipLaunchKernelGGL((vsample_block_kernel<3, false>), bgrid, dim3(kVBlockAll), 0, st, plane, (uint64_t)frame->stride, w, h, nh, plan->v, plan->weights, plan->tmp);
+    } else {
+        const dim3 vgrid((w + kVBlock - 1) / kVBlock, nh);
+        if (rgba && dword)
+            hipLaunchKernelGGL((vsample_kernel<4, true>), vgrid, dim3(kVBlock), 0, st, plane, (uint64_t)frame->stride, w, plan->v, plan->weights, plan->tmp);
+        else if (rgba)
+            hipLaunchKernelGGL((vsample_kernel<4, false>), vgrid, dim3(kVBlock), 0, st, plane, (uint64_t)frame->stride, w, plan->v, plan->weights, plan->tmp);
+        else
+            hipLaunchKernelGGL((vsample_kernel<3, false>), vgrid, dim3(kVBlock), 0, st, plane, (uint64_t)frame->stride, w, plan->v, plan->weights, plan->tmp);
+    }
     hipLaunchKernelGGL(hsample_kernel, dim3(nw, nh), dim3(kHBlock), 0, st, plan->tmp, w, plan->hz, plan->weights + plan->v_floats, plan->out, nw);
     MVFX_HIP_TRY(hipGetLastError());
     MVFX_HIP_TRY(hipMemcpyAsync(out_host, plan->out, (size_t)nw * nh, hipMemcpyDeviceToHost, st));

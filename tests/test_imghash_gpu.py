@@ -32,7 +32,7 @@ def test_resize_matches_oracle(gpu, fmt, bpp, geom):
     w, h, pad = geom
     stride = w * bpp + pad
     f = frames.random_frame(0x5EED0900 + w * 31 + h, w, h, bpp, stride)
-    for (nw, nh) in [(8, 8), (9, 8), (8, 9), (5, 5)]:
+    for (nw, nh) in [(8, 8), (9, 8), (8, 9), (5, 5), (3, 20), (64, 17), (16, 16)]:  # > 16 rows: the per-row kernel
         rc, want = orc.gray_resize_lanczos3(f, w, h, stride, fmt, nw, nh)
         assert rc == 0
         got = _resize_gpu(gpu, f, w, h, stride, fmt, nw, nh)
