@@ -130,6 +130,16 @@ int orc_gray_resize_lanczos3(const uint8_t *data, uint32_t width, uint32_t heigh
 int orc_image_hash(const uint8_t *data, uint32_t width, uint32_t height, uint32_t stride, int format, int algo,
                    uint64_t *hash, uint32_t *n_bits);
 
+/* GStreamer 1.14.0 videoconvert I420 <-> RGBA with default caps (convert_oracle.c; gst-plugins-base is not under
+ * /root/reference; PINNED by goldens made with the image's own GStreamer 1.14.0).  standard: 0 by height,
+ * 1 BT.601 + chroma-site none, 2 BT.709 + h-cosited, 3 BT.2020 + h-cosited. */
+int orc_convert_i420_to_rgba(const uint8_t *y_plane, const uint8_t *u_plane, const uint8_t *v_plane, uint32_t y_stride,
+                             uint32_t u_stride, uint32_t v_stride, uint32_t width, uint32_t height, int standard,
+                             uint8_t *rgba, uint32_t rgba_stride);
+int orc_convert_rgba_to_i420(const uint8_t *rgba, uint32_t rgba_stride, uint32_t width, uint32_t height, int standard,
+                             uint8_t *y_plane, uint8_t *u_plane, uint8_t *v_plane, uint32_t y_stride, uint32_t u_stride,
+                             uint32_t v_stride);
+
 /* SSIM-family distance behind hash-algo=dssim (dssim-core 3.4.0, non-default feature; PARITY
  * UNPINNED, see ssim_oracle.c): f64, formats RGB / RGBA. */
 int orc_ssim_distance(const uint8_t *a, const uint8_t *b, uint32_t width, uint32_t height, uint32_t stride_a,

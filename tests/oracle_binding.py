@@ -68,6 +68,10 @@ def lib():
         L.orc_gray_resize_lanczos3.restype = c_int
         L.orc_image_hash.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_int, c_int, POINTER(c_uint64), POINTER(c_uint32)]
         L.orc_image_hash.restype = c_int
+        L.orc_convert_i420_to_rgba.argtypes = [c_void_p, c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_int, c_void_p, c_uint32]
+        L.orc_convert_i420_to_rgba.restype = c_int
+        L.orc_convert_rgba_to_i420.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_int, c_void_p, c_void_p, c_void_p, c_uint32, c_uint32, c_uint32]
+        L.orc_convert_rgba_to_i420.restype = c_int
         L.orc_hamming64.argtypes = [c_uint64, c_uint64]
         L.orc_hamming64.restype = c_uint32
         L.orc_ssim_distance.argtypes = [c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_int,
@@ -230,6 +234,34 @@ def image_hash(data: np.ndarray, width, height, stride, fmt, algo):
     n = c_uint32()
     rc = lib().orc_image_hash(data.ctypes.data, width, height, stride, _fmt(fmt), HASH_ALGOS[algo], ctypes.byref(h), ctypes.byref(n))
     return rc, h.value, n.value
+
+
+def i420_layout(w, h):
+    """GstVideoInfo layout of I420: (y stride, chroma stride, y rows, chroma rows, u offset, v offset, size)"""
+    ru = lambda v, a: (v + a - 1) // a * a
+    ys, cs = ru(w, 4), ru(ru(w, 2) // 2, 4)
+    yr, cr = ru(h, 2), ru(h, 2) // 2
+    return ys, cs, yr, cr, ys * yr, ys * yr + cs * cr, ys * yr + 2 * cs * cr
+
+
+def convert_i420_to_rgba(raw: np.ndarray, w, h, standard=0):
+    """raw: one I420 frame in the GstVideoInfo layout -> (rc, h x w*4 RGBA)"""
+    ys, cs, yr, cr, uo, vo, size = i420_layout(w, h)
+    assert raw.size >= size
+    out = np.zeros((h, w * 4), np.uint8)
+    base = raw.ctypes.data
+    rc = lib().orc_convert_i420_to_rgba(base, base + uo, base + vo, ys, cs, cs, w, h, standard, out.ctypes.data, w * 4)
+    return rc, out
+
+
+def convert_rgba_to_i420(px: np.ndarray, w, h, stride, standard=0):
+    """-> (rc, Y[h,w], U[h/2,w/2], V[h/2,w/2]) tightly packed"""
+    Y = np.zeros((h, w), np.uint8)
+    U = np.zeros((h // 2, max(w // 2, 1)), np.uint8)
+    V = np.zeros((h // 2, max(w // 2, 1)), np.uint8)
+    rc = lib().orc_convert_rgba_to_i420(px.ctypes.data, stride, w, h, standard, Y.ctypes.data, U.ctypes.data, V.ctypes.data,
+                                        w, max(w // 2, 1), max(w // 2, 1))
+    return rc, Y, U, V
 
 
 def hamming(a, b):
