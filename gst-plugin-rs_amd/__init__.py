@@ -143,6 +143,8 @@ SIGNATURES = {
     "mvfx_ssim_distance_host": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(ctypes.c_double)]),
     "mvfx_roundedcorners_mask": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_void_p]),
     "mvfx_roundedcorners_mask_host": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_uint32]),
+    "mvfx_convert_i420_to_rgba": (c_int, [POINTER(PlanarFrame), POINTER(Frame), ctypes.c_int32, c_void_p]),
+    "mvfx_convert_rgba_to_i420": (c_int, [POINTER(Frame), POINTER(PlanarFrame), ctypes.c_int32, c_void_p]),
     "mvfx_roundedcorners_compose_a420": (c_int, [POINTER(PlanarFrame), c_void_p, c_uint32, POINTER(PlanarFrame), c_void_p]),
 }
 
@@ -323,6 +325,15 @@ def blockhash_host(frame_bytes, width, height, stride, fmt):
     h = c_uint64()
     check(lib().mvfx_blockhash_host(ctypes.byref(f), ctypes.byref(h)))
     return h.value
+
+
+def make_i420(base_ptr: int, width: int, height: int, y_stride: int, c_stride: int, u_offset: int, v_offset: int) -> PlanarFrame:
+    """mvfx_planar_frame view of one I420 frame inside a device buffer"""
+    f = PlanarFrame()
+    f.data[0], f.data[1], f.data[2] = base_ptr, base_ptr + u_offset, base_ptr + v_offset
+    f.stride[0], f.stride[1], f.stride[2] = y_stride, c_stride, c_stride
+    f.width, f.height, f.format = width, height, FORMATS["I420"]
+    return f
 
 
 HASH_ALGOS = {"mean": 0, "gradient": 1, "vertgradient": 2, "doublegradient": 3, "blockhash": 4, "dssim": 5}

@@ -1,0 +1,252 @@
+// I420 <-> RGBA converters for gfx950: what `videoconvert` does on either side of the filters in the reference's own
+// example pipelines (video/colorlut/src/colorlut/imp.rs:17-19), bit-exact with GStreamer 1.14.0's
+// default-caps behaviour (arithmetic and its provenance: convert_math.hpp; oracle: oracle/convert_oracle.c, pinned
+// against the real element).
+//
+// Layout: one lane owns an 8 x 2 pixel tile = 4 chroma samples: 2 x 8 luma bytes (two 8-byte accesses), 4 + 4 chroma
+// bytes (two dword accesses) and 2 x 32 RGBA bytes (four 16-byte accesses), so a wave covers 512 contiguous pixels of
+// two rows.  HBM traffic 1.5 + 4 = 5.5 B/px either way; no reuse across lanes except the co-sited chroma filter's
+// left neighbour column (one extra dword per row and lane, an L1/L2 hit).  Frames that are not aligned for these
+// accesses, and the last partial tile of a row, take the per-sample path of the same kernel.
+#include "mvfx_internal.h"
+
+#include "convert_math.hpp"
+
+namespace mvfx {
+namespace {
+
+constexpr int kCvtBlock = 256;
+
+struct PlanesIn {
+    const uint8_t *y, *u, *v;
+    uint64_t ys, us, vs;
+};
+struct PlanesOut {
+    uint8_t *y, *u, *v;
+    uint64_t ys, us, vs;
+};
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(kCvtBlock) void i420_to_rgba_kernel(PlanesIn in, uint32_t width, uint32_t height, YuvToRgbCoef k,
+                                                                 uint8_t *out, uint64_t out_stride)
+{
+    const uint32_t x0 = (blockIdx.x * kCvtBlock + threadIdx.x) * 8;
+    const uint32_t y0 = blockIdx.y * 2;
+    if (x0 >= width) return;
+    const bool row1 = y0 + 1 < height;
+    const uint8_t *yr0 = in.y + (uint64_t)y0 * in.ys, *yr1 = yr0 + in.ys;
+    const uint8_t *ur = in.u + (uint64_t)blockIdx.y * in.us, *vr = in.v + (uint64_t)blockIdx.y * in.vs;
+    uint8_t *o0 = out + (uint64_t)y0 * out_stride, *o1 = o0 + out_stride;
+    if (ALIGNED && x0 + 8 <= width) {
+        const uint2 ya = *reinterpret_cast<const uint2 *>(yr0 + x0);
+        const uint2 yb = row1 ? *reinterpret_cast<const uint2 *>(yr1 + x0) : make_uint2(0, 0);
+        const uint32_t u4 = *reinterpret_cast<const uint32_t *>(ur + x0 / 2), v4 = *reinterpret_cast<const uint32_t *>(vr + x0 / 2);
+        uint32_t pa[8], pb[8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const ChromaTerms c = chroma_terms((u4 >> (8 * j)) & 0xffu, (v4 >> (8 * j)) & 0xffu, k);
+            const uint32_t wa = j < 2 ? ya.x : ya.y, wb = j < 2 ? yb.x : yb.y;
+            const int s = (2 * j & 3) * 8;
+            pa[2 * j] = yuv_pixel((wa >> s) & 0xffu, c, k);
+            pa[2 * j + 1] = yuv_pixel((wa >> (s + 8)) & 0xffu, c, k);
+            pb[2 * j] = yuv_pixel((wb >> s) & 0xffu, c, k);
+            pb[2 * j + 1] = yuv_pixel((wb >> (s + 8)) & 0xffu, c, k);
+        }
+        uint4 *d0 = reinterpret_cast<uint4 *>(o0 + (uint64_t)x0 * 4);
+        d0[0] = make_uint4(pa[0], pa[1], pa[2], pa[3]);
+        d0[1] = make_uint4(pa[4], pa[5], pa[6], pa[7]);
+        if (row1) {
+            uint4 *d1 = reinterpret_cast<uint4 *>(o1 + (uint64_t)x0 * 4);
+            d1[0] = make_uint4(pb[0], pb[1], pb[2], pb[3]);
+            d1[1] = make_uint4(pb[4], pb[5], pb[6], pb[7]);
+        }
+        return;
+    }
+    for (uint32_t x = x0; x < min(x0 + 8, width); x++) {
+        const ChromaTerms c = chroma_terms(ur[x / 2], vr[x / 2], k);
+        const uint32_t a = yuv_pixel(yr0[x], c, k);
+        uint8_t *q = o0 + (uint64_t)x * 4;
+        q[0] = (uint8_t)a; q[1] = (uint8_t)(a >> 8); q[2] = (uint8_t)(a >> 16); q[3] = 255;
+        if (row1) {
+            const uint32_t b = yuv_pixel(yr1[x], c, k);
+            q = o1 + (uint64_t)x * 4;
+            q[0] = (uint8_t)b; q[1] = (uint8_t)(b >> 8); q[2] = (uint8_t)(b >> 16); q[3] = 255;
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t load_px(const uint8_t *p, bool dword)
+{
+    if (dword) return *reinterpret_cast<const uint32_t *>(p);
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+// horizontal chroma filter of video-chroma.c for sample ci of cw: l / c / r = the vertically averaged values of the
+// columns 2ci-1, 2ci, 2ci+1
+__device__ __forceinline__ uint32_t chroma_h(int32_t l, int32_t c, int32_t r, uint32_t ci, uint32_t cw, bool cosited)
+{
+    if (!cosited) return (uint32_t)((c + r + 1) >> 1);
+    if (ci == 0) return (uint32_t)((3 * c + r + 2) >> 2);
+    if (ci == cw - 1) return (uint32_t)((l + 3 * c + 2) >> 2);
+    return (uint32_t)((l + 2 * c + r + 2) >> 2);
+}
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(kCvtBlock) void rgba_to_i420_kernel(const uint8_t *in, uint64_t in_stride, uint32_t width, uint32_t height,
+                                                                 RgbToYuvCoef k, PlanesOut out, bool dword_ok)
+{
+    const uint32_t x0 = (blockIdx.x * kCvtBlock + threadIdx.x) * 8;
+    const uint32_t y0 = blockIdx.y * 2;
+    if (x0 >= width) return;
+    const uint8_t *r0 = in + (uint64_t)y0 * in_stride, *r1 = r0 + in_stride;
+    uint8_t *oy0 = out.y + (uint64_t)y0 * out.ys, *oy1 = oy0 + out.ys;
+    uint8_t *ou = out.u + (uint64_t)blockIdx.y * out.us, *ov = out.v + (uint64_t)blockIdx.y * out.vs;
+    const uint32_t cw = width / 2;
+    const bool cosited = k.cosited != 0;
+    if (ALIGNED && x0 + 8 <= width) {
+        uint32_t pa[8], pb[8];
+        {
+            const uint4 a0 = reinterpret_cast<const uint4 *>(r0 + (uint64_t)x0 * 4)[0], a1 = reinterpret_cast<const uint4 *>(r0 + (uint64_t)x0 * 4)[1];
+            const uint4 b0 = reinterpret_cast<const uint4 *>(r1 + (uint64_t)x0 * 4)[0], b1 = reinterpret_cast<const uint4 *>(r1 + (uint64_t)x0 * 4)[1];
+            pa[0] = a0.x; pa[1] = a0.y; pa[2] = a0.z; pa[3] = a0.w; pa[4] = a1.x; pa[5] = a1.y; pa[6] = a1.z; pa[7] = a1.w;
+            pb[0] = b0.x; pb[1] = b0.y; pb[2] = b0.z; pb[3] = b0.w; pb[4] = b1.x; pb[5] = b1.y; pb[6] = b1.z; pb[7] = b1.w;
+        }
+        uint32_t ya0 = 0, ya1 = 0, yb0 = 0, yb1 = 0;
+        int32_t cu[8], cv[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t la = rgb_luma(pa[j], k), lb = rgb_luma(pb[j], k);
+            if (j < 4) { ya0 |= la << (8 * j); yb0 |= lb << (8 * j); }
+            else { ya1 |= la << (8 * (j - 4)); yb1 |= lb << (8 * (j - 4)); }
+            cu[j] = (rgb_u(pa[j], k) + rgb_u(pb[j], k) + 1) >> 1; // vertical first
+            cv[j] = (rgb_v(pa[j], k) + rgb_v(pb[j], k) + 1) >> 1;
+        }
+        *reinterpret_cast<uint2 *>(oy0 + x0) = make_uint2(ya0, ya1);
+        *reinterpret_cast<uint2 *>(oy1 + x0) = make_uint2(yb0, yb1);
+        int32_t lu = 0, lv = 0; // column x0 - 1 (co-sited filter only)
+        if (cosited && x0 > 0) {
+            const uint32_t qa = *reinterpret_cast<const uint32_t *>(r0 + (uint64_t)(x0 - 1) * 4), qb = *reinterpret_cast<const uint32_t *>(r1 + (uint64_t)(x0 - 1) * 4);
+            lu = (rgb_u(qa, k) + rgb_u(qb, k) + 1) >> 1;
+            lv = (rgb_v(qa, k) + rgb_v(qb, k) + 1) >> 1;
+        }
+        uint32_t u4 = 0, v4 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t ci = x0 / 2 + i;
+            u4 |= chroma_h(i ? cu[2 * i - 1] : lu, cu[2 * i], cu[2 * i + 1], ci, cw, cosited) << (8 * i);
+            v4 |= chroma_h(i ? cv[2 * i - 1] : lv, cv[2 * i], cv[2 * i + 1], ci, cw, cosited) << (8 * i);
+        }
+        *reinterpret_cast<uint32_t *>(ou + x0 / 2) = u4;
+        *reinterpret_cast<uint32_t *>(ov + x0 / 2) = v4;
+        return;
+    }
+    // per-sample path: 2 x 2 block per chroma sample, neighbours read again
+    for (uint32_t x = x0; x < min(x0 + 8, width); x += 2) {
+        const uint32_t ci = x / 2;
+        int32_t vu[3] = {0, 0, 0}, vv[3] = {0, 0, 0}; // columns x-1, x, x+1
+        for (int d = -1; d <= 1; d++) {
+            if ((d < 0 && x == 0)) continue;
+            const uint32_t xx = x + d; // x + 1 < width because width is even
+            const uint32_t qa = load_px(r0 + (uint64_t)xx * 4, dword_ok), qb = load_px(r1 + (uint64_t)xx * 4, dword_ok);
+            vu[d + 1] = (rgb_u(qa, k) + rgb_u(qb, k) + 1) >> 1;
+            vv[d + 1] = (rgb_v(qa, k) + rgb_v(qb, k) + 1) >> 1;
+            if (d >= 0) {
+                oy0[xx] = (uint8_t)rgb_luma(qa, k);
+                oy1[xx] = (uint8_t)rgb_luma(qb, k);
+            }
+        }
+        ou[ci] = (uint8_t)chroma_h(vu[0], vu[1], vu[2], ci, cw, cosited);
+        ov[ci] = (uint8_t)chroma_h(vv[0], vv[1], vv[2], ci, cw, cosited);
+    }
+}
+
+int check_i420(const mvfx_planar_frame *f, const char *what)
+{
+    if (!f)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "%s: NULL frame", what);
+    if (f->format != MVFX_FORMAT_I420)
+        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "%s: planar format %d is not I420", what, f->format);
+    if (f->width == 0 || f->height == 0)
+        return MVFX_OK;
+    const uint32_t cw = (f->width + 1) / 2;
+    if (!f->data[0] || !f->data[1] || !f->data[2])
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "%s: NULL plane", what);
+    if (f->stride[0] < f->width || f->stride[1] < cw || f->stride[2] < cw)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "%s: plane stride smaller than its row", what);
+    return MVFX_OK;
+}
+
+} // namespace
+} // namespace mvfx
+
+using namespace mvfx;
+
+extern "C" {
+
+int mvfx_convert_i420_to_rgba(const mvfx_planar_frame *i420_in, const mvfx_frame *rgba_out, int32_t yuv_standard, mvfx_stream stream)
+{
+    if (int rc = check_i420(i420_in, "convert input"); rc != MVFX_OK) return rc;
+    if (int rc = check_packed_frame(rgba_out, "convert output"); rc != MVFX_OK) return rc;
+    if (rgba_out->format != MVFX_FORMAT_RGBA)
+        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "convert: output format %d is not RGBA", rgba_out->format);
+    if (i420_in->width != rgba_out->width || i420_in->height != rgba_out->height)
+        return fail(MVFX_ERR_NOT_NEGOTIATED, "convert: input %ux%u and output %ux%u differ", i420_in->width, i420_in->height, rgba_out->width, rgba_out->height);
+    if (yuv_standard < 0 || yuv_standard > 3)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "convert: yuv_standard %d is not 0 (by height), 1 (BT.601), 2 (BT.709), 3 (BT.2020)", yuv_standard);
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    const uint32_t w = i420_in->width, h = i420_in->height;
+    if (w == 0 || h == 0) return MVFX_OK;
+    const PlanesIn in{static_cast<const uint8_t *>(i420_in->data[0]), static_cast<const uint8_t *>(i420_in->data[1]),
+                      static_cast<const uint8_t *>(i420_in->data[2]), i420_in->stride[0], i420_in->stride[1], i420_in->stride[2]};
+    const YuvToRgbCoef k = yuv_to_rgb_coef(pick_yuv_standard(h, yuv_standard));
+    const bool aligned = ((reinterpret_cast<uintptr_t>(in.y) | in.ys) & 7) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(in.u) | in.us | reinterpret_cast<uintptr_t>(in.v) | in.vs) & 3) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(rgba_out->data) | rgba_out->stride) & 15) == 0;
+    const uint32_t rows2 = (h + 1) / 2;
+    if (rows2 > 65535u)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "convert: height %u too large", h);
+    const dim3 grid(((w + 7) / 8 + kCvtBlock - 1) / kCvtBlock, rows2);
+    uint8_t *out = static_cast<uint8_t *>(rgba_out->data);
+    if (aligned)
+        hipLaunchKernelGGL(i420_to_rgba_kernel<true>, grid, dim3(kCvtBlock), 0, as_stream(stream), in, w, h, k, out, (uint64_t)rgba_out->stride);
+    else
+        hipLaunchKernelGGL(i420_to_rgba_kernel<false>, grid, dim3(kCvtBlock), 0, as_stream(stream), in, w, h, k, out, (uint64_t)rgba_out->stride);
+    MVFX_HIP_TRY(hipGetLastError());
+    return MVFX_OK;
+}
+
+int mvfx_convert_rgba_to_i420(const mvfx_frame *rgba_in, const mvfx_planar_frame *i420_out, int32_t yuv_standard, mvfx_stream stream)
+{
+    if (int rc = check_packed_frame(rgba_in, "convert input"); rc != MVFX_OK) return rc;
+    if (int rc = check_i420(i420_out, "convert output"); rc != MVFX_OK) return rc;
+    if (rgba_in->format != MVFX_FORMAT_RGBA)
+        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "convert: input format %d is not RGBA", rgba_in->format);
+    if (i420_out->width != rgba_in->width || i420_out->height != rgba_in->height)
+        return fail(MVFX_ERR_NOT_NEGOTIATED, "convert: input %ux%u and output %ux%u differ", rgba_in->width, rgba_in->height, i420_out->width, i420_out->height);
+    if (yuv_standard < 0 || yuv_standard > 3)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "convert: yuv_standard %d is not 0 (by height), 1 (BT.601), 2 (BT.709), 3 (BT.2020)", yuv_standard);
+    const uint32_t w = rgba_in->width, h = rgba_in->height;
+    if ((w & 1) || (h & 1))
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "convert: RGBA -> I420 of an odd-sized frame (%ux%u) is not implemented (chroma down-sampling of the last row / column)", w, h);
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    if (w == 0 || h == 0) return MVFX_OK;
+    const PlanesOut out{static_cast<uint8_t *>(i420_out->data[0]), static_cast<uint8_t *>(i420_out->data[1]),
+                        static_cast<uint8_t *>(i420_out->data[2]), i420_out->stride[0], i420_out->stride[1], i420_out->stride[2]};
+    const RgbToYuvCoef k = rgb_to_yuv_coef(pick_yuv_standard(h, yuv_standard));
+    const uint8_t *in = static_cast<const uint8_t *>(rgba_in->data);
+    const bool dword_ok = ((reinterpret_cast<uintptr_t>(in) | rgba_in->stride) & 3) == 0;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(out.y) | out.ys) & 7) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(out.u) | out.us | reinterpret_cast<uintptr_t>(out.v) | out.vs) & 3) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(in) | rgba_in->stride) & 15) == 0;
+    if (h / 2 > 65535u)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "convert: height %u too large", h);
+    const dim3 grid(((w + 7) / 8 + kCvtBlock - 1) / kCvtBlock, h / 2);
+    if (aligned)
+        hipLaunchKernelGGL(rgba_to_i420_kernel<true>, grid, dim3(kCvtBlock), 0, as_stream(stream), in, (uint64_t)rgba_in->stride, w, h, k, out, dword_ok);
+    else
+        hipLaunchKernelGGL(rgba_to_i420_kernel<false>, grid, dim3(kCvtBlock), 0, as_stream(stream), in, (uint64_t)rgba_in->stride, w, h, k, out, dword_ok);
+    MVFX_HIP_TRY(hipGetLastError());
+    return MVFX_OK;
+}
+
+} // extern "C"

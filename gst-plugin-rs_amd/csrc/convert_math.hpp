@@ -1,0 +1,107 @@
+// Per-pixel arithmetic of GStreamer 1.14.0's `videoconvert` for I420 <-> RGBA with default caps -- the element the
+// reference's colorlut example wraps around the filter (video/colorlut/src/colorlut/imp.rs:17-19).
+// gst-plugins-base is not under the reference tree; oracle/convert_oracle.c restates the same arithmetic on the CPU and
+// is pinned byte for byte against the real element (tests/golden/make_videoconvert_golden.py).
+//
+//  I420 -> RGBA  (video-converter.c convert_I420_pack_ARGB -> orc video_orc_convert_I420_BGRA):
+//      w(c)  = splatbw(c - 128)                       the byte c^0x80 repeated in both halves of an int16
+//      wy    = mulhsw(w(Y), p1)                        (a * b) >> 16
+//      R     = convssswb(addssw(wy, mulhsw(w(V), p2))) + 128, B with w(U), p3, G with w(U), p4 and w(V), p5
+//      The 16-bit saturating adds can never saturate (|wy| <= 148, the chroma terms <= 273), so
+//      byte = clamp(wy + terms + 128, 0, 255): one v_med3_i32 per channel.
+//  RGBA -> I420  (video_orc_matrix8 + video-chroma.c):  c = clamp(((a R + b G + c B) >> 8) + offset, 0, 255);
+//      chroma averaged vertically first ((a + b + 1) >> 1), then horizontally: site none (a + b + 1) >> 1,
+//      h-cosited (l + 2c + r + 2) >> 2 with (3a + b + 2) >> 2 at the first and (l + 3c + 2) >> 2 at the last sample.
+//      All Y coefficients are positive bytes => one v_dot4_u32_u8; U / V = (positive dot - negative dot) >> 8.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mvfx {
+
+struct YuvToRgbCoef {
+    int32_t p1, p2, p3, p4, p5; // Y gain, V->R, U->B, U->G, V->G, all x256
+};
+
+struct RgbToYuvCoef {
+    uint32_t y;             // bytes {R,G,B,0} coefficients of Y (all positive)
+    uint32_t u_pos, u_neg;  // U = (dot(px, u_pos) - dot(px, u_neg)) >> 8 + 128
+    uint32_t v_pos, v_neg;
+    int32_t cosited;        // horizontal chroma filter: 0 = pair average, 1 = 1-2-1 co-sited
+};
+
+// standard: 1 BT.601 (site none), 2 BT.709 (h-cosited), 3 BT.2020 (h-cosited); 0 = GStreamer 1.14's default by height
+__host__ __device__ inline int pick_yuv_standard(uint32_t height, int standard)
+{
+    if (standard >= 1 && standard <= 3) return standard;
+    return height <= 576 ? 1 : (height < 2160 ? 2 : 3);
+}
+
+inline YuvToRgbCoef yuv_to_rgb_coef(int std_)
+{
+    switch (std_) {
+    case 1: return {298, 409, 516, -100, -208};
+    case 2: return {298, 459, 541, -55, -136};
+    default: return {298, 430, 548, -48, -167};
+    }
+}
+
+inline RgbToYuvCoef rgb_to_yuv_coef(int std_)
+{
+    auto pack = [](uint32_t r, uint32_t g, uint32_t b) { return r | (g << 8) | (b << 16); };
+    switch (std_) {
+    case 1: return {pack(66, 129, 25), pack(0, 0, 112), pack(38, 74, 0), pack(112, 0, 0), pack(0, 94, 18), 0};
+    case 2: return {pack(47, 157, 16), pack(0, 0, 112), pack(26, 87, 0), pack(112, 0, 0), pack(0, 102, 10), 1};
+    default: return {pack(58, 149, 13), pack(0, 0, 112), pack(31, 81, 0), pack(112, 0, 0), pack(0, 103, 9), 1};
+    }
+}
+
+// splatbw(c - 128) as a sign-extended int
+__device__ __forceinline__ int32_t splat_s16(uint32_t byte_value)
+{
+    const uint32_t ub = byte_value ^ 0x80u;
+    return (int32_t)(int16_t)(ub * 257u);
+}
+
+// chroma terms shared by the (up to) four pixels of one chroma sample
+struct ChromaTerms {
+    int32_t r, g, b;
+};
+
+__device__ __forceinline__ ChromaTerms chroma_terms(uint32_t u, uint32_t v, const YuvToRgbCoef &k)
+{
+    const int32_t wu = splat_s16(u), wv = splat_s16(v);
+    return {(wv * k.p2) >> 16, ((wu * k.p4) >> 16) + ((wv * k.p5) >> 16), (wu * k.p3) >> 16};
+}
+
+__device__ __forceinline__ int32_t clamp_u8(int32_t v) { return min(max(v, 0), 255); }
+
+// one RGBA pixel (alpha 255) from a luma byte and the chroma terms
+__device__ __forceinline__ uint32_t yuv_pixel(uint32_t y, const ChromaTerms &c, const YuvToRgbCoef &k)
+{
+    const int32_t wy = ((splat_s16(y) * k.p1) >> 16) + 128;
+    return (uint32_t)clamp_u8(wy + c.r) | ((uint32_t)clamp_u8(wy + c.g) << 8) | ((uint32_t)clamp_u8(wy + c.b) << 16) | 0xff000000u;
+}
+
+__device__ __forceinline__ uint32_t rgb_luma(uint32_t px, const RgbToYuvCoef &k)
+{
+    return (uint32_t)clamp_u8((int32_t)(__builtin_amdgcn_udot4(px & 0x00ffffffu, k.y, 0u, false) >> 8) + 16);
+}
+
+__device__ __forceinline__ int32_t rgb_u(uint32_t px, const RgbToYuvCoef &k)
+{
+    const uint32_t q = px & 0x00ffffffu;
+    const int32_t d = (int32_t)__builtin_amdgcn_udot4(q, k.u_pos, 0u, false) - (int32_t)__builtin_amdgcn_udot4(q, k.u_neg, 0u, false);
+    return clamp_u8((d >> 8) + 128);
+}
+
+__device__ __forceinline__ int32_t rgb_v(uint32_t px, const RgbToYuvCoef &k)
+{
+    const uint32_t q = px & 0x00ffffffu;
+    const int32_t d = (int32_t)__builtin_amdgcn_udot4(q, k.v_pos, 0u, false) - (int32_t)__builtin_amdgcn_udot4(q, k.v_neg, 0u, false);
+    return clamp_u8((d >> 8) + 128);
+}
+
+} // namespace mvfx

@@ -350,6 +350,21 @@ int mvfx_roundedcorners_compose_a420(const mvfx_planar_frame *i420_in, const uin
                                      uint32_t mask_stride, const mvfx_planar_frame *a420_out,
                                      mvfx_stream stream);
 
+/* ---- videoconvert-equivalent I420 <-> RGBA ----
+ * What GStreamer's `videoconvert` does on either side of the filters in the reference's own example pipeline
+ * (`... ! videoconvert ! colorlut ! videoconvert ! ...`, video/colorlut/src/colorlut/imp.rs:17-19), for device-resident
+ * pipelines.  Bit-exact with GStreamer 1.14.0's default-caps conversion (I420 -> RGBA: the orc fast path with chroma
+ * duplication; RGBA -> I420: 8-bit matrix, chroma averaged vertically then horizontally, co-sited 1-2-1 for HD / UHD);
+ * gst-plugins-base is not under the reference tree: pinned against the real element through goldens
+ * (tests/golden/make_videoconvert_golden.py).
+ * yuv_standard: 0 = GStreamer 1.14's default for the frame height (<= 576 lines BT.601 + chroma-site none, < 2160
+ * BT.709 + h-cosited, else BT.2020 + h-cosited), 1 / 2 / 3 force BT.601 / BT.709 / BT.2020.
+ * RGBA -> I420 needs even width and height.  Device pointers; asynchronous on `stream`. */
+int mvfx_convert_i420_to_rgba(const mvfx_planar_frame *i420_in, const mvfx_frame *rgba_out,
+                              int32_t yuv_standard, mvfx_stream stream);
+int mvfx_convert_rgba_to_i420(const mvfx_frame *rgba_in, const mvfx_planar_frame *i420_out,
+                              int32_t yuv_standard, mvfx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

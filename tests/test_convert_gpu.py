@@ -1,0 +1,124 @@
+"""I420 <-> RGBA converters (csrc/convert_kernels.hip) against the oracle and against outputs of the REAL GStreamer
+1.14.0 videoconvert (tests/golden/videoconvert_kat.npz): bit-exact, every size incl. 4K, odd sizes, unaligned planes."""
+import ctypes
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from tests import frames
+from tests import oracle_binding as orc
+
+pytestmark = pytest.mark.gpu
+
+KAT = np.load(os.path.join(os.path.dirname(__file__), "golden", "videoconvert_kat.npz"))
+META = [m.split("|") for m in KAT["meta"].tolist()]
+
+
+def _to_rgba(gpu, raw, w, h, standard=0, shift=0, out_pad=0):
+    """raw: I420 frame in the GstVideoInfo layout; shift: bytes of misalignment of the device copy"""
+    ys, cs, yr, cr, uo, vo, size = orc.i420_layout(w, h)
+    dbuf = gpu.DeviceBuffer(size + 64)
+    gpu.check(gpu.lib().mvfx_copy_to_device(ctypes.c_void_p(dbuf.ptr + shift), raw.ctypes.data_as(ctypes.c_void_p), size, None))
+    fin = gpu.make_i420(dbuf.ptr + shift, w, h, ys, cs, uo, vo)
+    ostride = w * 4 + out_pad
+    dout = gpu.DeviceBuffer(ostride * h + 64)
+    fout = gpu.make_frame(dout.ptr, w, h, ostride, "RGBA")
+    gpu.check(gpu.lib().mvfx_convert_i420_to_rgba(ctypes.byref(fin), ctypes.byref(fout), standard, None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    return dout.download(ostride * h).reshape(h, ostride)[:, : w * 4]
+
+
+def _to_i420(gpu, px, w, h, stride, standard=0, shift=0):
+    ys, cs, yr, cr, uo, vo, size = orc.i420_layout(w, h)
+    din = gpu.DeviceBuffer(px.nbytes + 64)
+    gpu.check(gpu.lib().mvfx_copy_to_device(ctypes.c_void_p(din.ptr + shift), px.ctypes.data_as(ctypes.c_void_p), px.nbytes, None))
+    fin = gpu.make_frame(din.ptr + shift, w, h, stride, "RGBA")
+    dout = gpu.DeviceBuffer(size + 64)
+    fout = gpu.make_i420(dout.ptr, w, h, ys, cs, uo, vo)
+    gpu.check(gpu.lib().mvfx_convert_rgba_to_i420(ctypes.byref(fin), ctypes.byref(fout), standard, None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    d = dout.download(size)
+    Y = d[: ys * yr].reshape(yr, ys)[:h, :w]
+    U = d[uo: uo + cs * cr].reshape(cr, cs)[: h // 2, : w // 2]
+    V = d[vo: vo + cs * cr].reshape(cr, cs)[: h // 2, : w // 2]
+    return Y, U, V
+
+
+@pytest.mark.parametrize("meta", [m for m in META if m[0].startswith("i420_to_rgba")], ids=lambda m: m[0])
+def test_i420_to_rgba_matches_gstreamer_goldens(gpu, meta):
+    key, seed, w, h, digest = meta[0], int(meta[1]), int(meta[2]), int(meta[3]), meta[4]
+    raw = frames.splitmix64_bytes(seed, orc.i420_layout(w, h)[6])
+    got = _to_rgba(gpu, raw, w, h)
+    assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == digest
+
+
+@pytest.mark.parametrize("meta", [m for m in META if m[0].startswith("rgba_to_i420")], ids=lambda m: m[0])
+def test_rgba_to_i420_matches_gstreamer_goldens(gpu, meta):
+    key, seed, w, h, digest = meta[0], int(meta[1]), int(meta[2]), int(meta[3]), meta[4]
+    px = frames.random_frame(seed, w, h)
+    Y, U, V = _to_i420(gpu, px, w, h, w * 4)
+    packed = np.concatenate([Y.reshape(-1), U.reshape(-1), V.reshape(-1)])
+    assert hashlib.sha256(packed.tobytes()).hexdigest() == digest
+
+
+@pytest.mark.parametrize("geom", [(64, 32), (66, 34), (65, 33), (1, 1), (7, 5), (9, 3), (24, 578), (8, 2160), (1920, 1080), (2, 2)])
+@pytest.mark.parametrize("standard", [0, 1, 2, 3])
+def test_i420_to_rgba_matches_oracle(gpu, geom, standard):
+    w, h = geom
+    raw = frames.splitmix64_bytes(0x5EED0D00 + w * 13 + h, orc.i420_layout(w, h)[6])
+    rc, want = orc.convert_i420_to_rgba(raw, w, h, standard)
+    assert rc == 0
+    assert np.array_equal(_to_rgba(gpu, raw, w, h, standard), want)
+    if standard == 0:  # misaligned planes and a padded output stride: the per-sample path
+        assert np.array_equal(_to_rgba(gpu, raw, w, h, standard, shift=1, out_pad=4), want)
+
+
+@pytest.mark.parametrize("geom", [(64, 32), (66, 34), (2, 2), (4, 2), (10, 6), (24, 578), (8, 2160), (1920, 1080), (18, 600)])
+@pytest.mark.parametrize("standard", [0, 1, 2, 3])
+def test_rgba_to_i420_matches_oracle(gpu, geom, standard):
+    w, h = geom
+    stride = w * 4 + (16 if w % 8 else 0)
+    px = frames.random_frame(0x5EED0E00 + w * 13 + h, w, h, 4, stride)
+    rc, Yw, Uw, Vw = orc.convert_rgba_to_i420(px, w, h, stride, standard)
+    assert rc == 0
+    Y, U, V = _to_i420(gpu, px, w, h, stride, standard)
+    assert np.array_equal(Y, Yw) and np.array_equal(U, Uw) and np.array_equal(V, Vw)
+    if standard in (0, 2):
+        Y, U, V = _to_i420(gpu, px, w, h, stride, standard, shift=4)  # 4-byte aligned only: per-sample path
+        assert np.array_equal(Y, Yw) and np.array_equal(U, Uw) and np.array_equal(V, Vw)
+
+
+def test_round_trip_is_close_and_grey_is_exact(gpu):
+    """RGBA -> I420 -> RGBA of a flat grey frame at full 4K size: chroma exactly 128, luma flat, and the frame comes back
+    within 4 levels (videoconvert's orc fast path multiplies splatbw(Y-128) = 257 (Y-128) by 298 >> 16, a gain of 1.1686
+    instead of 1.1644, and adds 128 instead of 16 * 1.164: 180 -> 177 in the real element too)"""
+    w, h = 3840, 2160
+    g = np.full((h, w * 4), 180, np.uint8)
+    g[:, 3::4] = 255
+    Y, U, V = _to_i420(gpu, g, w, h, w * 4)
+    assert (U == 128).all() and (V == 128).all() and (Y == Y[0, 0]).all()
+    ys, cs, yr, cr, uo, vo, size = orc.i420_layout(w, h)
+    raw = np.zeros(size, np.uint8)
+    raw[: ys * yr].reshape(yr, ys)[:h, :w] = Y
+    raw[uo: uo + cs * cr] = 128
+    raw[vo: vo + cs * cr] = 128
+    back = _to_rgba(gpu, raw, w, h)
+    assert np.abs(back.astype(int) - g.astype(int)).max() <= 4 and (back == back[0, 0:4].tolist() * w).all()
+
+
+def test_errors(gpu):
+    w, h = 16, 8
+    buf = gpu.DeviceBuffer(4096)
+    i420 = gpu.make_i420(buf.ptr, w, h, 16, 8, 128, 192)
+    rgba = gpu.make_frame(buf.ptr + 1024, w, h, w * 4, "RGBA")
+    L = gpu.lib()
+    assert L.mvfx_convert_i420_to_rgba(ctypes.byref(i420), ctypes.byref(rgba), 7, None) == gpu.ERR_INVALID_ARGUMENT
+    bgra = gpu.make_frame(buf.ptr + 1024, w, h, w * 4, "BGRA")
+    assert L.mvfx_convert_i420_to_rgba(ctypes.byref(i420), ctypes.byref(bgra), 0, None) == gpu.ERR_UNSUPPORTED_FORMAT
+    small = gpu.make_frame(buf.ptr + 1024, w, h // 2, w * 4, "RGBA")
+    assert L.mvfx_convert_i420_to_rgba(ctypes.byref(i420), ctypes.byref(small), 0, None) == gpu.ERR_NOT_NEGOTIATED
+    odd_i = gpu.make_i420(buf.ptr, 15, 7, 16, 8, 128, 192)
+    odd = gpu.make_frame(buf.ptr + 1024, 15, 7, 64, "RGBA")
+    assert L.mvfx_convert_rgba_to_i420(ctypes.byref(odd), ctypes.byref(odd_i), 0, None) == gpu.ERR_INVALID_ARGUMENT

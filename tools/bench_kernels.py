@@ -236,6 +236,20 @@ def main():
         ms = timeit(compose, iters=300)
         report("roundedcorners I420->A420 compose 4K", ms, W * H * 4, 1)
 
+    if want("convert"):
+        ys, cs = W, W // 2
+        isz = W * H * 3 // 2
+        i420 = rand_frames(POOL, isz, 15)
+        rgba = torch.empty((POOL, NB), dtype=torch.uint8, device=dev)
+        fi = [vfx.make_i420(i420[i].data_ptr(), W, H, ys, cs, W * H, W * H * 5 // 4) for i in range(POOL)]
+        fo = [vfx.make_frame(rgba[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_convert_i420_to_rgba(ctypes.byref(fi[i % POOL]), ctypes.byref(fo[i % POOL]), 0, sptr)), iters=300)
+        report("convert I420->RGBA 4K (videoconvert-equivalent)", ms, W * H * 11 // 2, 1)
+        src = rand_frames(POOL, NB, 16)
+        fr = [vfx.make_frame(src[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_convert_rgba_to_i420(ctypes.byref(fr[i % POOL]), ctypes.byref(fi[i % POOL]), 0, sptr)), iters=300)
+        report("convert RGBA->I420 4K (videoconvert-equivalent, BT.2020 h-cosited)", ms, W * H * 11 // 2, 1)
+
     # d2d copy ceiling measured on this box (SURVEY 8d asks for it next to the 8 TB/s spec)
     if want("copy"):
         a = rand_frames(POOL, NB, 8)
