@@ -364,6 +364,13 @@ int mvfx_convert_i420_to_rgba(const mvfx_planar_frame *i420_in, const mvfx_frame
                               int32_t yuv_standard, mvfx_stream stream);
 int mvfx_convert_rgba_to_i420(const mvfx_frame *rgba_in, const mvfx_planar_frame *i420_out,
                               int32_t yuv_standard, mvfx_stream stream);
+/* `videoconvert ! colorlut ! videoconvert` on a device-resident I420 frame (colorlut/imp.rs:17-19): I420 -> RGBA,
+ * the LUT (colorlut/imp.rs:226-294), RGBA -> I420 -- fused into ONE kernel when the frame allows it (width % 8 == 0,
+ * even height, planes aligned to 8 / 4 bytes, finite LUT domain), the same three steps through scratch frames
+ * otherwise; identical bytes either way (= the three separate entry points in sequence). */
+int mvfx_colorlut_transform_i420(mvfx_cube_lut *lut, const mvfx_planar_frame *i420_in,
+                                 const mvfx_planar_frame *i420_out, int32_t yuv_standard,
+                                 mvfx_stream stream);
 
 #ifdef __cplusplus
 }

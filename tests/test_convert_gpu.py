@@ -122,3 +122,49 @@ def test_errors(gpu):
     odd_i = gpu.make_i420(buf.ptr, 15, 7, 16, 8, 128, 192)
     odd = gpu.make_frame(buf.ptr + 1024, 15, 7, 64, "RGBA")
     assert L.mvfx_convert_rgba_to_i420(ctypes.byref(odd), ctypes.byref(odd_i), 0, None) == gpu.ERR_INVALID_ARGUMENT
+
+
+# ---------------------------------------------------------------- colorlut on I420 frames (fused videoconvert ! colorlut ! videoconvert)
+
+def _oracle_lut_i420(o, raw, w, h, standard):
+    rc, rgba = orc.convert_i420_to_rgba(raw, w, h, standard)
+    assert rc == 0
+    lut_out = np.zeros_like(rgba)
+    assert o.apply(rgba, w * 4, lut_out, w * 4, w, h, "RGBA") == 0
+    rc, Y, U, V = orc.convert_rgba_to_i420(lut_out, w, h, w * 4, standard)
+    assert rc == 0
+    return Y, U, V
+
+
+@pytest.mark.parametrize("lut_name", ["analytic33", "analytic9", "curve1d_256", "big_nodes70", "nan_domain"])
+@pytest.mark.parametrize("geom", [(64, 32, 0), (2056, 6, 0), (24, 578, 0), (8, 2160, 0), (1920, 1080, 0), (36, 10, 0), (64, 32, 2)])
+def test_colorlut_i420_matches_three_oracles(gpu, lut_name, geom):
+    """fused kernel (width % 8 == 0, aligned) and the three-step path (w = 36; misaligned planes; NaN domain) against
+    oracle(i420->rgba) -> oracle(colorlut) -> oracle(rgba->i420); SD / HD co-sited / UHD defaults by height"""
+    from tests import cubes
+    text = {"analytic33": cubes.analytic_3d(33), "analytic9": cubes.analytic_3d(9), "curve1d_256": cubes.curve_1d(256),
+            "big_nodes70": cubes.identity_3d(70, 4),  # > 65: no cell-packed copy, node layout
+            "nan_domain": "LUT_1D_SIZE 2\nDOMAIN_MIN nan 0 0\n0 0.1 0.2\n1 0.9 0.8\n"}[lut_name]
+    if lut_name == "big_nodes70" and geom[0] * geom[1] > 100000:
+        pytest.skip("one large case per LUT family is enough")
+    o = orc.CubeLut(text)
+    assert o.ok
+    dev = gpu.CubeLut(text)
+    w, h, shift = geom
+    ys, cs, yr, cr, uo, vo, size = orc.i420_layout(w, h)
+    raw = frames.splitmix64_bytes(0x5EED0F00 + w + h, size)
+    Yw, Uw, Vw = _oracle_lut_i420(o, raw, w, h, 0)
+    din = gpu.DeviceBuffer(size + 64)
+    gpu.check(gpu.lib().mvfx_copy_to_device(ctypes.c_void_p(din.ptr + shift), raw.ctypes.data_as(ctypes.c_void_p), size, None))
+    dout = gpu.DeviceBuffer(size + 64)
+    fin = gpu.make_i420(din.ptr + shift, w, h, ys, cs, uo, vo)
+    fout = gpu.make_i420(dout.ptr, w, h, ys, cs, uo, vo)
+    gpu.check(gpu.lib().mvfx_colorlut_transform_i420(dev.h, ctypes.byref(fin), ctypes.byref(fout), 0, None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    d = dout.download(size)
+    Y = d[: ys * yr].reshape(yr, ys)[:h, :w]
+    U = d[uo: uo + cs * cr].reshape(cr, cs)[: h // 2, : w // 2]
+    V = d[vo: vo + cs * cr].reshape(cr, cs)[: h // 2, : w // 2]
+    assert np.array_equal(Y, Yw), np.argwhere(Y != Yw)[:5]
+    assert np.array_equal(U, Uw), np.argwhere(U != Uw)[:5]
+    assert np.array_equal(V, Vw), np.argwhere(V != Vw)[:5]

@@ -250,6 +250,35 @@ def main():
         ms = timeit(lambda i=0: vfx.check(lib.mvfx_convert_rgba_to_i420(ctypes.byref(fr[i % POOL]), ctypes.byref(fi[i % POOL]), 0, sptr)), iters=300)
         report("convert RGBA->I420 4K (videoconvert-equivalent, BT.2020 h-cosited)", ms, W * H * 11 // 2, 1)
 
+    if want("lut420"):
+        from tests import cubes as _c
+        lut = vfx.CubeLut(_c.analytic_3d(33))
+        isz = W * H * 3 // 2
+        # natural-like I420: convert the natural RGBA frames with our own converter
+        srcn = natural_like_gpu(POOL, W, H, 17)
+        i420 = torch.empty((POOL, isz), dtype=torch.uint8, device=dev)
+        o420 = torch.empty((POOL, isz), dtype=torch.uint8, device=dev)
+        fr = [vfx.make_frame(srcn[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
+        fi = [vfx.make_i420(i420[i].data_ptr(), W, H, W, W // 2, W * H, W * H * 5 // 4) for i in range(POOL)]
+        fo = [vfx.make_i420(o420[i].data_ptr(), W, H, W, W // 2, W * H, W * H * 5 // 4) for i in range(POOL)]
+        for i in range(POOL):
+            vfx.check(lib.mvfx_convert_rgba_to_i420(ctypes.byref(fr[i]), ctypes.byref(fi[i]), 0, sptr))
+        torch.cuda.synchronize()
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_i420(lut.h, ctypes.byref(fi[i % POOL]), ctypes.byref(fo[i % POOL]), 0, sptr)), iters=200)
+        report("colorlut 33^3 on I420 4K natural, fused videoconvert!colorlut!videoconvert (one kernel)", ms, W * H * 3, 1)
+        tmp_a = torch.empty((POOL, NB), dtype=torch.uint8, device=dev)
+        tmp_b = torch.empty((POOL, NB), dtype=torch.uint8, device=dev)
+        fa = [vfx.make_frame(tmp_a[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
+        fb = [vfx.make_frame(tmp_b[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
+
+        def three(i=0):
+            k = i % POOL
+            vfx.check(lib.mvfx_convert_i420_to_rgba(ctypes.byref(fi[k]), ctypes.byref(fa[k]), 0, sptr))
+            vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fa[k]), ctypes.byref(fb[k]), sptr))
+            vfx.check(lib.mvfx_convert_rgba_to_i420(ctypes.byref(fb[k]), ctypes.byref(fo[k]), 0, sptr))
+        ms = timeit(three, iters=200)
+        report("colorlut 33^3 on I420 4K natural, three launches through RGBA frames", ms, W * H * 3, 1)
+
     # d2d copy ceiling measured on this box (SURVEY 8d asks for it next to the 8 TB/s spec)
     if want("copy"):
         a = rand_frames(POOL, NB, 8)
