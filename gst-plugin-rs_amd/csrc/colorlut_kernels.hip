@@ -508,88 +508,15 @@ __device__ __forceinline__ void lf_rows(const uint8_t *in, uint8_t *out, uint64_
 // `videoconvert ! colorlut ! videoconvert` of the reference's example pipeline (colorlut/imp.rs:17-19) in ONE kernel:
 // I420 -> RGBA (convert_math.hpp), the FAST LUT path above, RGBA -> I420, with the two RGBA frames never leaving the
 // registers: 1.5 B/px read + 1.5 B/px written instead of 1.5+4 | 4+4 | 4+1.5 = 19 B/px through three launches.
-// One lane owns an 8 x 2 pixel tile = 4 chroma samples, processed as four 2 x 2 blocks (one chroma sample each).
-// The co-sited chroma filter (HD / UHD) needs the vertically averaged LUT output of the column left of the tile: lanes
-// hand their last column to their right neighbour through LDS; the first lane of a workgroup evaluates that column itself.
-constexpr int kI420Block = 256;
-
-struct I420Planes {
-    const uint8_t *iy, *iu, *iv;
-    uint8_t *oy, *ou, *ov;
-    uint64_t iys, ius, ivs, oys, ous, ovs;
-};
-
+// The tile walk (i420_fused_tile) is shared with hsvfilter's I420 entry point: convert_math.hpp.
 template <bool IS3D, bool CELLS>
 __global__ __launch_bounds__(kI420Block) void colorlut_i420_kernel(I420Planes pl, uint32_t width, uint32_t height, LutParams p,
                                                                    YuvToRgbCoef kin, RgbToYuvCoef kout)
 {
     __shared__ int2 edge[kI420Block];
-    const uint32_t x0 = (blockIdx.x * kI420Block + threadIdx.x) * 8;
-    const uint32_t y0 = blockIdx.y * 2;
-    const bool active = x0 < width; // width % 8 == 0: tiles are whole
-    const bool cosited = kout.cosited != 0;
     CellCache cache;
-    int32_t cu[8], cv[8];
-    uint32_t ya0 = 0, ya1 = 0, yb0 = 0, yb1 = 0;
-    const uint8_t *yr0 = pl.iy + (uint64_t)y0 * pl.iys, *yr1 = yr0 + pl.iys;
-    const uint8_t *ur = pl.iu + (uint64_t)blockIdx.y * pl.ius, *vr = pl.iv + (uint64_t)blockIdx.y * pl.ivs;
-    auto lut = [&](uint32_t px) { return lf_px8<IS3D, CELLS>(px, p, p.cube, p.t[0], p.t[1], p.t[2], cache); };
-    if (active) {
-        const uint2 ya = *reinterpret_cast<const uint2 *>(yr0 + x0), yb = *reinterpret_cast<const uint2 *>(yr1 + x0);
-        const uint32_t u4 = *reinterpret_cast<const uint32_t *>(ur + x0 / 2), v4 = *reinterpret_cast<const uint32_t *>(vr + x0 / 2);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const ChromaTerms c = chroma_terms((u4 >> (8 * j)) & 0xffu, (v4 >> (8 * j)) & 0xffu, kin);
-            const uint32_t wa = j < 2 ? ya.x : ya.y, wb = j < 2 ? yb.x : yb.y;
-            const int s = (2 * j & 3) * 8;
-#pragma unroll
-            for (int e = 0; e < 2; e++) { // the two columns of the block
-                const uint32_t qa = lut(yuv_pixel((wa >> (s + 8 * e)) & 0xffu, c, kin));
-                const uint32_t qb = lut(yuv_pixel((wb >> (s + 8 * e)) & 0xffu, c, kin));
-                const uint32_t la = rgb_luma(qa, kout), lb = rgb_luma(qb, kout);
-                const int col = 2 * j + e;
-                if (col < 4) { ya0 |= la << (8 * col); yb0 |= lb << (8 * col); }
-                else { ya1 |= la << (8 * (col - 4)); yb1 |= lb << (8 * (col - 4)); }
-                cu[col] = (rgb_u(qa, kout) + rgb_u(qb, kout) + 1) >> 1;
-                cv[col] = (rgb_v(qa, kout) + rgb_v(qb, kout) + 1) >> 1;
-            }
-        }
-        *reinterpret_cast<uint2 *>(pl.oy + (uint64_t)y0 * pl.oys + x0) = make_uint2(ya0, ya1);
-        *reinterpret_cast<uint2 *>(pl.oy + (uint64_t)(y0 + 1) * pl.oys + x0) = make_uint2(yb0, yb1);
-    }
-    int32_t lu = 0, lv = 0;
-    if (cosited) { // uniform branch
-        edge[threadIdx.x] = active ? make_int2(cu[7], cv[7]) : make_int2(0, 0);
-        __syncthreads();
-        if (active && x0 > 0) {
-            if (threadIdx.x > 0) {
-                lu = edge[threadIdx.x - 1].x;
-                lv = edge[threadIdx.x - 1].y;
-            } else { // left neighbour lives in another workgroup: evaluate column x0 - 1 here
-                const ChromaTerms c = chroma_terms(ur[(x0 - 1) / 2], vr[(x0 - 1) / 2], kin);
-                const uint32_t qa = lut(yuv_pixel(yr0[x0 - 1], c, kin)), qb = lut(yuv_pixel(yr1[x0 - 1], c, kin));
-                lu = (rgb_u(qa, kout) + rgb_u(qb, kout) + 1) >> 1;
-                lv = (rgb_v(qa, kout) + rgb_v(qb, kout) + 1) >> 1;
-            }
-        }
-    }
-    if (!active) return;
-    const uint32_t cw = width / 2;
-    uint32_t u4o = 0, v4o = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t ci = x0 / 2 + i;
-        int32_t l_u = i ? cu[2 * i - 1] : lu, l_v = i ? cv[2 * i - 1] : lv;
-        uint32_t ru, rv;
-        if (!cosited) { ru = (uint32_t)((cu[2 * i] + cu[2 * i + 1] + 1) >> 1); rv = (uint32_t)((cv[2 * i] + cv[2 * i + 1] + 1) >> 1); }
-        else if (ci == 0) { ru = (uint32_t)((3 * cu[0] + cu[1] + 2) >> 2); rv = (uint32_t)((3 * cv[0] + cv[1] + 2) >> 2); }
-        else if (ci == cw - 1) { ru = (uint32_t)((l_u + 3 * cu[2 * i] + 2) >> 2); rv = (uint32_t)((l_v + 3 * cv[2 * i] + 2) >> 2); }
-        else { ru = (uint32_t)((l_u + 2 * cu[2 * i] + cu[2 * i + 1] + 2) >> 2); rv = (uint32_t)((l_v + 2 * cv[2 * i] + cv[2 * i + 1] + 2) >> 2); }
-        u4o |= ru << (8 * i);
-        v4o |= rv << (8 * i);
-    }
-    *reinterpret_cast<uint32_t *>(pl.ou + (uint64_t)blockIdx.y * pl.ous + x0 / 2) = u4o;
-    *reinterpret_cast<uint32_t *>(pl.ov + (uint64_t)blockIdx.y * pl.ovs + x0 / 2) = v4o;
+    i420_fused_tile(pl, width, height, kin, kout, edge,
+                    [&](uint32_t px) { return lf_px8<IS3D, CELLS>(px, p, p.cube, p.t[0], p.t[1], p.t[2], cache); });
 }
 
 template <bool IS3D, bool CELLS, bool WIDE, bool LE>
@@ -871,6 +798,9 @@ int colorlut_i420_impl(mvfx_cube_lut *h, const mvfx_planar_frame *in, const mvfx
         if (!in->data[pidx] || !out->data[pidx] || in->stride[pidx] < need || out->stride[pidx] < need)
             return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut_i420: bad plane %d", pidx);
     }
+    for (int pidx = 0; pidx < 3; pidx++)
+        if (in->data[pidx] == out->data[pidx]) // colorlut is NeverInPlace (colorlut/imp.rs:162-166); the fused kernel also reads
+            return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut_i420: input and output planes must not alias"); // neighbour input pixels
     if (int rc = ensure_uploaded(h); rc != MVFX_OK) return rc;
     const CubeLut &l = h->lut;
     bool finite = true;

@@ -104,4 +104,92 @@ __device__ __forceinline__ int32_t rgb_v(uint32_t px, const RgbToYuvCoef &k)
     return clamp_u8((d >> 8) + 128);
 }
 
+// ---- a per-pixel RGBA filter applied to an I420 frame in one pass (videoconvert ! filter ! videoconvert fused) ----
+// One lane owns an 8 x 2 pixel tile = 4 chroma samples, processed as four 2 x 2 blocks: decode (chroma terms shared by
+// the block), px_fn on every RGBA pixel (alpha 255 in, alpha ignored out), luma bytes and the vertically averaged
+// chroma of the 8 columns, then the horizontal chroma filter.  The co-sited filter (HD / UHD) needs the averaged
+// chroma of the column LEFT of the tile: lanes hand their last column to their right neighbour through `edge` (LDS,
+// kI420Block int2); the first lane of a workgroup evaluates that column itself (it reads INPUT pixels of the
+// neighbouring workgroup's tile, so input and output planes must not alias).
+// Requires width % 8 == 0, even height, luma rows 8-byte and chroma rows 4-byte aligned; blockDim.x == kI420Block,
+// grid = (ceil(width / 8 / kI420Block), height / 2).
+constexpr int kI420Block = 256;
+
+struct I420Planes {
+    const uint8_t *iy, *iu, *iv;
+    uint8_t *oy, *ou, *ov;
+    uint64_t iys, ius, ivs, oys, ous, ovs;
+};
+
+template <typename F>
+__device__ __forceinline__ void i420_fused_tile(const I420Planes &pl, uint32_t width, uint32_t height, const YuvToRgbCoef &kin,
+                                                const RgbToYuvCoef &kout, int2 *edge, F &&px_fn)
+{
+    const uint32_t x0 = (blockIdx.x * kI420Block + threadIdx.x) * 8;
+    const uint32_t y0 = blockIdx.y * 2;
+    const bool active = x0 < width;
+    const bool cosited = kout.cosited != 0;
+    int32_t cu[8], cv[8];
+    uint32_t ya0 = 0, ya1 = 0, yb0 = 0, yb1 = 0;
+    const uint8_t *yr0 = pl.iy + (uint64_t)y0 * pl.iys, *yr1 = yr0 + pl.iys;
+    const uint8_t *ur = pl.iu + (uint64_t)blockIdx.y * pl.ius, *vr = pl.iv + (uint64_t)blockIdx.y * pl.ivs;
+    (void)height;
+    if (active) {
+        const uint2 ya = *reinterpret_cast<const uint2 *>(yr0 + x0), yb = *reinterpret_cast<const uint2 *>(yr1 + x0);
+        const uint32_t u4 = *reinterpret_cast<const uint32_t *>(ur + x0 / 2), v4 = *reinterpret_cast<const uint32_t *>(vr + x0 / 2);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const ChromaTerms c = chroma_terms((u4 >> (8 * j)) & 0xffu, (v4 >> (8 * j)) & 0xffu, kin);
+            const uint32_t wa = j < 2 ? ya.x : ya.y, wb = j < 2 ? yb.x : yb.y;
+            const int s = (2 * j & 3) * 8;
+#pragma unroll
+            for (int e = 0; e < 2; e++) { // the two columns of the block
+                const uint32_t qa = px_fn(yuv_pixel((wa >> (s + 8 * e)) & 0xffu, c, kin));
+                const uint32_t qb = px_fn(yuv_pixel((wb >> (s + 8 * e)) & 0xffu, c, kin));
+                const uint32_t la = rgb_luma(qa, kout), lb = rgb_luma(qb, kout);
+                const int col = 2 * j + e;
+                if (col < 4) { ya0 |= la << (8 * col); yb0 |= lb << (8 * col); }
+                else { ya1 |= la << (8 * (col - 4)); yb1 |= lb << (8 * (col - 4)); }
+                cu[col] = (rgb_u(qa, kout) + rgb_u(qb, kout) + 1) >> 1; // vertical first
+                cv[col] = (rgb_v(qa, kout) + rgb_v(qb, kout) + 1) >> 1;
+            }
+        }
+        *reinterpret_cast<uint2 *>(pl.oy + (uint64_t)y0 * pl.oys + x0) = make_uint2(ya0, ya1);
+        *reinterpret_cast<uint2 *>(pl.oy + (uint64_t)(y0 + 1) * pl.oys + x0) = make_uint2(yb0, yb1);
+    }
+    int32_t lu = 0, lv = 0;
+    if (cosited) { // uniform branch
+        edge[threadIdx.x] = active ? make_int2(cu[7], cv[7]) : make_int2(0, 0);
+        __syncthreads();
+        if (active && x0 > 0) {
+            if (threadIdx.x > 0) {
+                lu = edge[threadIdx.x - 1].x;
+                lv = edge[threadIdx.x - 1].y;
+            } else { // left neighbour lives in another workgroup: evaluate column x0 - 1 here
+                const ChromaTerms c = chroma_terms(ur[(x0 - 1) / 2], vr[(x0 - 1) / 2], kin);
+                const uint32_t qa = px_fn(yuv_pixel(yr0[x0 - 1], c, kin)), qb = px_fn(yuv_pixel(yr1[x0 - 1], c, kin));
+                lu = (rgb_u(qa, kout) + rgb_u(qb, kout) + 1) >> 1;
+                lv = (rgb_v(qa, kout) + rgb_v(qb, kout) + 1) >> 1;
+            }
+        }
+    }
+    if (!active) return;
+    const uint32_t cw = width / 2;
+    uint32_t u4o = 0, v4o = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t ci = x0 / 2 + i;
+        const int32_t l_u = i ? cu[2 * i - 1] : lu, l_v = i ? cv[2 * i - 1] : lv;
+        uint32_t ru, rv;
+        if (!cosited) { ru = (uint32_t)((cu[2 * i] + cu[2 * i + 1] + 1) >> 1); rv = (uint32_t)((cv[2 * i] + cv[2 * i + 1] + 1) >> 1); }
+        else if (ci == 0) { ru = (uint32_t)((3 * cu[0] + cu[1] + 2) >> 2); rv = (uint32_t)((3 * cv[0] + cv[1] + 2) >> 2); }
+        else if (ci == cw - 1) { ru = (uint32_t)((l_u + 3 * cu[2 * i] + 2) >> 2); rv = (uint32_t)((l_v + 3 * cv[2 * i] + 2) >> 2); }
+        else { ru = (uint32_t)((l_u + 2 * cu[2 * i] + cu[2 * i + 1] + 2) >> 2); rv = (uint32_t)((l_v + 2 * cv[2 * i] + cv[2 * i + 1] + 2) >> 2); }
+        u4o |= ru << (8 * i);
+        v4o |= rv << (8 * i);
+    }
+    *reinterpret_cast<uint32_t *>(pl.ou + (uint64_t)blockIdx.y * pl.ous + x0 / 2) = u4o;
+    *reinterpret_cast<uint32_t *>(pl.ov + (uint64_t)blockIdx.y * pl.ovs + x0 / 2) = v4o;
+}
+
 } // namespace mvfx

@@ -371,6 +371,11 @@ int mvfx_convert_rgba_to_i420(const mvfx_frame *rgba_in, const mvfx_planar_frame
 int mvfx_colorlut_transform_i420(mvfx_cube_lut *lut, const mvfx_planar_frame *i420_in,
                                  const mvfx_planar_frame *i420_out, int32_t yuv_standard,
                                  mvfx_stream stream);
+/* `videoconvert ! hsvfilter ! videoconvert` on a device-resident I420 frame, same construction (hsvfilter takes RGB
+ * formats only, hsvfilter/imp.rs:278-289).  Input and output planes must not alias. */
+int mvfx_hsvfilter_transform_i420(const mvfx_planar_frame *i420_in, const mvfx_planar_frame *i420_out,
+                                  const mvfx_hsvfilter_settings *settings, int32_t yuv_standard,
+                                  mvfx_stream stream);
 
 #ifdef __cplusplus
 }

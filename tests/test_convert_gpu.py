@@ -137,7 +137,8 @@ def _oracle_lut_i420(o, raw, w, h, standard):
 
 
 @pytest.mark.parametrize("lut_name", ["analytic33", "analytic9", "curve1d_256", "big_nodes70", "nan_domain"])
-@pytest.mark.parametrize("geom", [(64, 32, 0), (2056, 6, 0), (24, 578, 0), (8, 2160, 0), (1920, 1080, 0), (36, 10, 0), (64, 32, 2)])
+@pytest.mark.parametrize("geom", [(64, 32, 0), (2056, 6, 0), (24, 578, 0), (8, 2160, 0), (1920, 1080, 0), (36, 10, 0), (64, 32, 2),
+                                  (4104, 578, 0)])  # last: co-sited filter across workgroup boundaries (> 2048 px wide, HD)
 def test_colorlut_i420_matches_three_oracles(gpu, lut_name, geom):
     """fused kernel (width % 8 == 0, aligned) and the three-step path (w = 36; misaligned planes; NaN domain) against
     oracle(i420->rgba) -> oracle(colorlut) -> oracle(rgba->i420); SD / HD co-sited / UHD defaults by height"""
@@ -168,3 +169,37 @@ def test_colorlut_i420_matches_three_oracles(gpu, lut_name, geom):
     assert np.array_equal(Y, Yw), np.argwhere(Y != Yw)[:5]
     assert np.array_equal(U, Uw), np.argwhere(U != Uw)[:5]
     assert np.array_equal(V, Vw), np.argwhere(V != Vw)[:5]
+
+
+@pytest.mark.parametrize("settings", [(90.0, 1.25, -0.05, 0.9, 0.02), (-45.0, 0.8, 0.1, 1.1, -0.03), (0.0, 1.0, 0.0, 1.0, 0.0),
+                                      (float("nan"), 1.0, 0.0, 1.0, 0.0), (725.0, 2.0, 0.0, 0.5, 0.25)],
+                         ids=["bench", "negshift", "identity", "nan-literal", "bigshift-literal"])
+@pytest.mark.parametrize("geom", [(64, 32, 0), (24, 578, 0), (8, 2160, 0), (1920, 1080, 0), (4104, 578, 0), (36, 10, 0), (64, 32, 4)])
+def test_hsvfilter_i420_matches_three_oracles(gpu, settings, geom):
+    """videoconvert ! hsvfilter ! videoconvert fused (and the three-step path for w = 36 / misaligned planes) against
+    oracle(i420->rgba) -> oracle(hsvfilter in place) -> oracle(rgba->i420)"""
+    w, h, shift = geom
+    ys, cs, yr, cr, uo, vo, size = orc.i420_layout(w, h)
+    raw = frames.splitmix64_bytes(0x5EED1000 + w + h, size)
+    rc, rgba = orc.convert_i420_to_rgba(raw, w, h, 0)
+    assert rc == 0
+    orc.hsvfilter(rgba, w, w * 4, "RGBA", settings)
+    rc, Yw, Uw, Vw = orc.convert_rgba_to_i420(rgba, w, h, w * 4, 0)
+    assert rc == 0
+    din = gpu.DeviceBuffer(size + 64)
+    gpu.check(gpu.lib().mvfx_copy_to_device(ctypes.c_void_p(din.ptr + shift), raw.ctypes.data_as(ctypes.c_void_p), size, None))
+    dout = gpu.DeviceBuffer(size + 64)
+    fin = gpu.make_i420(din.ptr + shift, w, h, ys, cs, uo, vo)
+    fout = gpu.make_i420(dout.ptr, w, h, ys, cs, uo, vo)
+    st = gpu.HsvFilterSettings(*settings)
+    gpu.check(gpu.lib().mvfx_hsvfilter_transform_i420(ctypes.byref(fin), ctypes.byref(fout), ctypes.byref(st), 0, None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    d = dout.download(size)
+    Y = d[: ys * yr].reshape(yr, ys)[:h, :w]
+    U = d[uo: uo + cs * cr].reshape(cr, cs)[: h // 2, : w // 2]
+    V = d[vo: vo + cs * cr].reshape(cr, cs)[: h // 2, : w // 2]
+    assert np.array_equal(Y, Yw), np.argwhere(Y != Yw)[:5]
+    assert np.array_equal(U, Uw), np.argwhere(U != Uw)[:5]
+    assert np.array_equal(V, Vw), np.argwhere(V != Vw)[:5]
+    # aliasing input and output is refused
+    assert gpu.lib().mvfx_hsvfilter_transform_i420(ctypes.byref(fin), ctypes.byref(fin), ctypes.byref(st), 0, None) == gpu.ERR_INVALID_ARGUMENT

@@ -278,6 +278,19 @@ def main():
             vfx.check(lib.mvfx_convert_rgba_to_i420(ctypes.byref(fb[k]), ctypes.byref(fo[k]), 0, sptr))
         ms = timeit(three, iters=200)
         report("colorlut 33^3 on I420 4K natural, three launches through RGBA frames", ms, W * H * 3, 1)
+        hs = vfx.HsvFilterSettings(90.0, 1.25, -0.05, 0.9, 0.02)
+        r420 = rand_frames(POOL, isz, 18)
+        fri = [vfx.make_i420(r420[i].data_ptr(), W, H, W, W // 2, W * H, W * H * 5 // 4) for i in range(POOL)]
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_hsvfilter_transform_i420(ctypes.byref(fri[i % POOL]), ctypes.byref(fo[i % POOL]), ctypes.byref(hs), 0, sptr)), iters=300)
+        report("hsvfilter on I420 4K random, fused videoconvert!hsvfilter!videoconvert (one kernel)", ms, W * H * 3, 1)
+
+        def three_h(i=0):
+            k = i % POOL
+            vfx.check(lib.mvfx_convert_i420_to_rgba(ctypes.byref(fri[k]), ctypes.byref(fa[k]), 0, sptr))
+            vfx.check(lib.mvfx_hsvfilter_transform_frame_ip(ctypes.byref(fa[k]), ctypes.byref(hs), sptr))
+            vfx.check(lib.mvfx_convert_rgba_to_i420(ctypes.byref(fa[k]), ctypes.byref(fo[k]), 0, sptr))
+        ms = timeit(three_h, iters=300)
+        report("hsvfilter on I420 4K random, three launches through an RGBA frame", ms, W * H * 3, 1)
 
     # d2d copy ceiling measured on this box (SURVEY 8d asks for it next to the 8 TB/s spec)
     if want("copy"):
