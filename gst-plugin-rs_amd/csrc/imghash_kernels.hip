@@ -81,24 +81,44 @@ __global__ __launch_bounds__(kVBlockAll) void vsample_block_kernel(const uint8_t
     const bool px_ok = x < width;
     const uint8_t *col = plane + (uint64_t)(px_ok ? x : 0) * BPP;
     constexpr uint32_t kWPasses = (kVBlockAll / 64) * kVRows / kVBlockAll; // 2
-    // adder role: wave = output row, lane = column
-    const bool adder = wave < nh && lane < kVCols;
-    const uint32_t a_left = wave < nh ? ax.left[wave] : 0, a_count = wave < nh ? ax.count[wave] : 0;
+    // adder role: wave a owns the output rows 2a (lanes 0..31) and 2a+1 (lanes 32..63), lane & 31 = column: neighbouring
+    // rows share 5/6 of their tap windows, so the wave walks the union once with all 64 lanes busy
+    const uint32_t a_oy = 2 * wave + (lane >> 5), a_col = lane & (kVCols - 1);
+    const bool adder = a_oy < nh;
+    const uint32_t oy_lo = min(2 * wave, nh - 1), oy_hi = min(2 * wave + 1, nh - 1);
+    const uint32_t u_begin = ax.left[oy_lo], u_end = ax.left[oy_hi] + ax.count[oy_hi]; // union of the two windows (wave-uniform)
+    const bool adder_wave = 2 * wave < nh;
     float t = 0.0f;
 
     uint32_t g[kVPasses];
     float wv[kWPasses];
+    // the weight slots of this lane: (output row, row of the chunk) never change, so their window is looked up once
+    uint32_t w_left[kWPasses], w_count[kWPasses], w_row[kWPasses];
+    const float *w_ptr[kWPasses];
+#pragma unroll
+    for (uint32_t k = 0; k < kWPasses; k++) {
+        const uint32_t idx = threadIdx.x + kVBlockAll * k, oy = idx / kVRows;
+        w_row[k] = idx % kVRows;
+        w_left[k] = oy < nh ? ax.left[oy] : 0;
+        w_count[k] = oy < nh ? ax.count[oy] : 0;
+        w_ptr[k] = weights + (oy < nh ? ax.offset[oy] : 0);
+    }
+    // All loads are unconditional (clamped addresses, results masked afterwards): a load inside a divergent branch gets
+    // its own s_waitcnt, which serialised the six loads of a chunk into six memory round trips (220 -> 128 us was the
+    // LDS staging, 128 -> see DESIGN.md was this).
     auto load_chunk = [&](uint32_t base) {
 #pragma unroll
         for (uint32_t k = 0; k < kVPasses; k++) {
             const uint32_t r = base + pr + (kVBlockAll / kVCols) * k;
-            g[k] = (px_ok && r < height) ? load_luma<BPP, DWORD>(col + (uint64_t)r * stride) : 0u;
+            const uint32_t v = load_luma<BPP, DWORD>(col + (uint64_t)min(r, height - 1) * stride);
+            g[k] = (px_ok && r < height) ? v : 0u;
         }
 #pragma unroll
         for (uint32_t k = 0; k < kWPasses; k++) {
-            const uint32_t idx = threadIdx.x + kVBlockAll * k, oy = idx / kVRows, r = base + idx % kVRows;
+            const uint32_t rel = base + w_row[k] - w_left[k]; // wraps for rows above the window: fails the unsigned test
+            const float v = w_ptr[k][w_count[k] ? min(rel, w_count[k] - 1) : 0];
             // a weight of exactly 0 outside the tap window: t + G * 0 == t, so the adders run whole chunks
-            wv[k] = (oy < nh && r >= ax.left[oy] && r - ax.left[oy] < ax.count[oy]) ? weights[ax.offset[oy] + (r - ax.left[oy])] : 0.0f;
+            wv[k] = rel < w_count[k] ? v : 0.0f;
         }
     };
     load_chunk(0);
@@ -109,14 +129,15 @@ __global__ __launch_bounds__(kVBlockAll) void vsample_block_kernel(const uint8_t
         for (uint32_t k = 0; k < kWPasses; k++) (&W[0][0])[threadIdx.x + kVBlockAll * k] = wv[k];
         __syncthreads();
         if (base + kVRows < height) load_chunk(base + kVRows); // in flight while the adders run
-        if (adder && base < a_left + a_count && base + kVRows > a_left) {
+        if (adder_wave && base < u_end && base + kVRows > u_begin) {
+            const uint32_t w_row = adder ? a_oy : 2 * wave; // idle upper half (odd nh): reads a valid row, result dropped
             for (uint32_t i = 0; i < kVRows; i += 16) { // 16 LDS pixel reads + 4 weight reads issued, then the 16 chained additions
                 float gv[16];
                 float4 wq[4];
 #pragma unroll
-                for (int k = 0; k < 16; k++) gv[k] = G[i + k][lane];
+                for (int k = 0; k < 16; k++) gv[k] = G[i + k][a_col];
 #pragma unroll
-                for (int k = 0; k < 4; k++) wq[k] = *reinterpret_cast<const float4 *>(&W[wave][i + 4 * k]);
+                for (int k = 0; k < 4; k++) wq[k] = *reinterpret_cast<const float4 *>(&W[w_row][i + 4 * k]);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     t = t + gv[4 * k] * wq[k].x; t = t + gv[4 * k + 1] * wq[k].y;
@@ -126,8 +147,8 @@ __global__ __launch_bounds__(kVBlockAll) void vsample_block_kernel(const uint8_t
         }
         __syncthreads();
     }
-    const uint32_t ax_x = blockIdx.x * kVCols + lane;
-    if (adder && ax_x < width) tmp[(uint64_t)wave * width + ax_x] = t;
+    const uint32_t ax_x = blockIdx.x * kVCols + a_col;
+    if (adder && ax_x < width) tmp[(uint64_t)a_oy * width + ax_x] = t;
 }
 
 template <int BPP, bool DWORD>
@@ -174,18 +195,37 @@ __global__ __launch_bounds__(kHBlock) void hsample_kernel(const float *tmp, uint
     for (uint32_t base = 0; base < n; base += kHChunk) {
         const uint32_t m = min(kHChunk, n - base);
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < m; i += kHBlock) prod[i] = row[base + i] * w[base + i];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t i = 0;
-            for (; i + 16 <= m; i += 16) { // four 16-byte LDS reads in flight, then the 16 chained additions
-                float4 q[4];
+        // products: four unconditional (clamped) load pairs per lane and pass, zero-padded to a multiple of 16 taps
+        // (t + 0 == t), so the adder below runs whole batches
+        const uint32_t mp = (m + 15) & ~15u;
+        for (uint32_t i = threadIdx.x; i < mp; i += 4 * kHBlock) {
+            float a[4], b[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) q[k] = *reinterpret_cast<const float4 *>(&prod[i + 4 * k]);
+            for (int k = 0; k < 4; k++) {
+                const uint32_t idx = min(i + k * kHBlock, m - 1);
+                a[k] = row[base + idx];
+                b[k] = w[base + idx];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t idx = i + k * kHBlock;
+                if (idx < mp) prod[idx] = idx < m ? a[k] * b[k] : 0.0f;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { // the chain: the next 16 products are read from LDS while the current 16 are added
+            float4 q[4], nx[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) q[k] = *reinterpret_cast<const float4 *>(&prod[4 * k]);
+            for (uint32_t i = 0; i < mp; i += 16) {
+                const uint32_t j = i + 16 < mp ? i + 16 : i;
+#pragma unroll
+                for (int k = 0; k < 4; k++) nx[k] = *reinterpret_cast<const float4 *>(&prod[j + 4 * k]);
 #pragma unroll
                 for (int k = 0; k < 4; k++) { t = t + q[k].x; t = t + q[k].y; t = t + q[k].z; t = t + q[k].w; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) q[k] = nx[k];
             }
-            for (; i < m; i++) t = t + prod[i];
         }
     }
     if (threadIdx.x == 0) {
@@ -297,6 +337,7 @@ int gray_resize_impl(const mvfx_frame *frame, uint32_t nw, uint32_t nh, uint8_t 
     Plan *plan = nullptr;
     if (int rc = get_plan(w, h, nw, nh, st, &plan); rc != MVFX_OK) return rc;
     const bool dword = rgba && ((reinterpret_cast<uintptr_t>(plane) | frame->stride) & 3) == 0;
+    static_assert(kVCols == 32, "the adder waves pair two output rows of 32 columns");
     if (nh <= kVBlockAll / 64) { // one pass over the frame, all output rows at once
         const dim3 bgrid((w + kVCols - 1) / kVCols);
         if (rgba && dword)
