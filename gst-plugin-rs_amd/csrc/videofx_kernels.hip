@@ -39,7 +39,7 @@ constexpr int kHistBlock = 1024;
 constexpr uint32_t kHistWords = kHistBins / 2;         // packed u16 pairs
 constexpr uint32_t kMaxSamplesPerGroup = 65535;        // 16-bit bins cannot overflow
 constexpr uint32_t kMaxGroupsPerLaunch = 2048;
-constexpr int kHistInFlight = 1;                       // sample loads a lane issues before binning
+constexpr int kHistInFlight = 8;                       // sample loads a lane issues before binning
 
 struct HistLayout {
     int bpp, ir, ig, ib, ia; // ia < 0: no alpha (255)
@@ -60,26 +60,36 @@ __global__ __launch_bounds__(kHistBlock) void colordetect_hist_kernel(
     const uint64_t g_begin = (uint64_t)blockIdx.x * samples_per_group;
     const uint64_t g_end = min(g_begin + samples_per_group, n_samples);
     uint32_t mn[3] = {255, 255, 255}, mx[3] = {0, 0, 0};
-    // kHistInFlight sample loads per lane are issued before the first one is binned.  Measured on 4K q=10: 1 / 2 / 4 / 8
-    // in flight = 14.5 / 14.7 / 15.4 / 17.0 us on smooth content (binning a burst of samples at once piles same-bin
-    // LDS atomics on top of each other), 24.6 / 24.8 / 22.6 / 23.9 us on uniform-random colours => 1.
+    // kHistInFlight sample loads per lane are issued before the first one is binned.  4K, 1 / 2 / 4 / 8 in flight:
+    // q=1 (64 samples per lane) 55.9 / 46.1 / 45.2 / 41.2 us; q=10 (6 samples per lane) 14.3 / 14.2 / 15.0 / 14.5 us on smooth
+    // content, 22.9 / 22.0 / 22.6 / 22.3 us on uniform-random colours.  (A first attempt with the loads inside
+    // `if (k < g_end)` was slower with every batch size: see the comment below.)
     const bool dword = lay.bpp == 4 && ((reinterpret_cast<uintptr_t>(plane) | (uintptr_t)(quality * 4u)) & 3) == 0;
     for (uint64_t k0 = g_begin + threadIdx.x; k0 < g_end; k0 += (uint64_t)kHistBlock * kHistInFlight) {
         uint32_t px[kHistInFlight];
+        // unconditional loads from clamped sample indices, masked afterwards (a load inside a divergent branch gets its
+        // own s_waitcnt and the loads of a batch would go one memory round trip after the other)
+        if (dword) {
+            uint32_t v[kHistInFlight];
 #pragma unroll
-        for (int j = 0; j < kHistInFlight; j++) {
-            const uint64_t k = k0 + (uint64_t)j * kHistBlock;
-            px[j] = 0; // alpha 0: skipped below
-            if (k < g_end) {
+            for (int j = 0; j < kHistInFlight; j++) {
+                const uint64_t k = min(k0 + (uint64_t)j * kHistBlock, g_end - 1);
+                v[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(plane + (first_sample + k) * quality * 4ull));
+            }
+#pragma unroll
+            for (int j = 0; j < kHistInFlight; j++) {
+                const uint32_t q = ((v[j] >> (8 * lay.ir)) & 0xff) | (((v[j] >> (8 * lay.ig)) & 0xff) << 8) |
+                                   (((v[j] >> (8 * lay.ib)) & 0xff) << 16) | (((v[j] >> (8 * lay.ia)) & 0xff) << 24);
+                px[j] = k0 + (uint64_t)j * kHistBlock < g_end ? q : 0u; // alpha 0: skipped below
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kHistInFlight; j++) {
+                const uint64_t k = min(k0 + (uint64_t)j * kHistBlock, g_end - 1);
                 const uint8_t *p = plane + (first_sample + k) * quality * (uint64_t)lay.bpp;
-                if (dword) {
-                    const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p));
-                    px[j] = ((v >> (8 * lay.ir)) & 0xff) | (((v >> (8 * lay.ig)) & 0xff) << 8) |
-                            (((v >> (8 * lay.ib)) & 0xff) << 16) | (((v >> (8 * lay.ia)) & 0xff) << 24);
-                } else {
-                    px[j] = (uint32_t)p[lay.ir] | ((uint32_t)p[lay.ig] << 8) | ((uint32_t)p[lay.ib] << 16) |
-                            ((lay.ia >= 0 ? (uint32_t)p[lay.ia] : 255u) << 24);
-                }
+                const uint32_t q = (uint32_t)p[lay.ir] | ((uint32_t)p[lay.ig] << 8) | ((uint32_t)p[lay.ib] << 16) |
+                                   ((lay.ia >= 0 ? (uint32_t)p[lay.ia] : 255u) << 24);
+                px[j] = k0 + (uint64_t)j * kHistBlock < g_end ? q : 0u;
             }
         }
 #pragma unroll
