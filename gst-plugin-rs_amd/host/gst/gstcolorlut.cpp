@@ -114,6 +114,24 @@ static GstFlowReturn gst_color_lut_bt_transform(GstBaseTransform *bt, GstBuffer 
         return GST_FLOW_ERROR;
     }
     GstMapInfo imap, omap;
+    if (GST_VIDEO_INFO_FORMAT(&vf->in_info) == GST_VIDEO_FORMAT_I420) {
+        // memory:HIPMemory I420 (decoder output): the `videoconvert ! colorlut ! videoconvert` of the reference's example
+        // pipeline (colorlut/imp.rs:17-19) in one kernel, no RGBA frame in HBM
+        mvfx_planar_frame pi, po;
+        if (!mvfx_hip_map_i420(inbuf, &vf->in_info, GST_MAP_READ, &imap, &pi))
+            return GST_FLOW_ERROR;
+        if (!mvfx_hip_map_i420(outbuf, &vf->out_info, GST_MAP_WRITE, &omap, &po)) {
+            gst_buffer_unmap(inbuf, &imap);
+            return GST_FLOW_ERROR;
+        }
+        mvfx_stream st = mvfx_thread_stream();
+        int rc = mvfx_colorlut_transform_i420(self->lut, &pi, &po, 0, st);
+        if (rc == MVFX_OK)
+            rc = mvfx_stream_synchronize(st);
+        gst_buffer_unmap(outbuf, &omap);
+        gst_buffer_unmap(inbuf, &imap);
+        return MVFX_GST_FLOW(self, rc);
+    }
     mvfx_frame fi, fo;
     if (!mvfx_hip_map_frame(inbuf, &vf->in_info, GST_MAP_READ, &imap, &fi))
         return GST_FLOW_ERROR;
@@ -156,7 +174,16 @@ static void gst_color_lut_class_init(GstColorLutClass *klass)
     const gboolean has64 = gst_video_format_from_string("RGBA64_LE") != GST_VIDEO_FORMAT_UNKNOWN;
     static const gchar *const all[] = {"RGBA64_LE", "RGBA64_BE", "RGBA", NULL};
     static const gchar *const only8[] = {"RGBA", NULL};
-    mvfx_add_pad_templates(element, mvfx_caps_plus_hip(mvfx_video_caps(has64 ? all : only8)), mvfx_caps_plus_hip(mvfx_video_caps(has64 ? all : only8)));
+    // the reference's system-memory caps first, then their memory:HIPMemory twin, then HIP-only I420 (fused converters)
+    static const gchar *const i420[] = {"I420", NULL};
+    GstCaps *tmpl[2];
+    for (GstCaps *&c : tmpl) {
+        c = mvfx_caps_plus_hip(mvfx_video_caps(has64 ? all : only8));
+        GstCaps *sys420 = mvfx_video_caps(i420);
+        gst_caps_append(c, mvfx_caps_with_hip_feature(sys420));
+        gst_caps_unref(sys420);
+    }
+    mvfx_add_pad_templates(element, tmpl[0], tmpl[1]);
     GST_BASE_TRANSFORM_CLASS(klass)->prepare_output_buffer = gst_color_lut_prepare_output_buffer;
     GST_BASE_TRANSFORM_CLASS(klass)->propose_allocation = gst_color_lut_propose_allocation; // d3d12colorlut/imp.rs:385-492
     GST_BASE_TRANSFORM_CLASS(klass)->decide_allocation = gst_color_lut_decide_allocation;

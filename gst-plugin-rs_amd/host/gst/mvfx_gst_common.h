@@ -120,6 +120,22 @@ static inline gboolean mvfx_hip_map_frame(GstBuffer *buf, const GstVideoInfo *in
     return TRUE;
 }
 
+// all planes of a HIP buffer holding an I420 frame (default GstVideoInfo layout); data = DEVICE pointers
+static inline gboolean mvfx_hip_map_i420(GstBuffer *buf, const GstVideoInfo *info, GstMapFlags rw, GstMapInfo *map, mvfx_planar_frame *f)
+{
+    if (GST_VIDEO_INFO_FORMAT(info) != GST_VIDEO_FORMAT_I420 || !gst_buffer_map(buf, map, (GstMapFlags)(MVFX_MAP_HIP | rw)))
+        return FALSE;
+    memset(f, 0, sizeof(*f));
+    for (guint p = 0; p < 3; p++) {
+        f->data[p] = map->data + GST_VIDEO_INFO_PLANE_OFFSET(info, p);
+        f->stride[p] = (uint32_t)GST_VIDEO_INFO_PLANE_STRIDE(info, p);
+    }
+    f->width = (uint32_t)GST_VIDEO_INFO_WIDTH(info);
+    f->height = (uint32_t)GST_VIDEO_INFO_HEIGHT(info);
+    f->format = MVFX_FORMAT_I420;
+    return TRUE;
+}
+
 // prepare_output_buffer for elements whose negotiated OUTPUT is HIP memory: a device buffer of
 // the output frame size with the input's flags and timestamps
 static inline GstFlowReturn mvfx_hip_new_output(GstBaseTransform *trans, GstBuffer *inbuf, gsize size, GstBuffer **outbuf)

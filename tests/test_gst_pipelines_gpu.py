@@ -283,3 +283,25 @@ def test_roundedcorners_on_hipmemory(gpu, tmp_path, w, h, rad):
     assert same.size == raw.size
     if w % 4 == 0 and h % 2 == 0:  # no row padding: whole buffers comparable
         assert np.array_equal(same, raw)
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (1280, 720)])
+def test_colorlut_on_hipmemory_i420_equals_the_videoconvert_sandwich(gpu, tmp_path, w, h):
+    """The reference's example pipeline `... ! videoconvert ! colorlut location=... ! videoconvert ! ...`
+    (colorlut/imp.rs:17-19) with the image's REAL videoconvert elements around our colorlut, against
+    `hipupload ! colorlut ! hipdownload` on I420 buffers in HBM (one fused kernel, no RGBA frame): the I420 output
+    must be identical byte for byte (SD: BT.601 / chroma-site none; HD: BT.709 / co-sited)."""
+    from tests import cubes
+    cube = os.path.join(str(tmp_path), "look.cube")
+    with open(cube, "w") as f:
+        f.write(cubes.analytic_3d(17))
+    src = f"videotestsrc num-buffers=2 pattern=smpte ! video/x-raw,format=I420,width={w},height={h}"
+    sandwich = _capture(tmp_path, src + f" ! videoconvert ! video/x-raw,format=RGBA ! colorlut location={cube} ! videoconvert ! video/x-raw,format=I420", "ref.raw")
+    r = gst_env.run([LAUNCH, "-v"] + (src + f" ! hipupload ! colorlut name=lut location={cube} ! hipdownload ! filesink location={tmp_path}/dev.raw").split(), tmp_path)
+    assert r.returncode == 0, r.stdout
+    assert re.search(r"lut\.GstPad:src: caps = video/x-raw\(memory:HIPMemory\).*format=\(string\)I420", r.stdout), r.stdout[-1500:]
+    fused = np.fromfile(f"{tmp_path}/dev.raw", dtype=np.uint8)
+    assert fused.size == sandwich.size == 2 * w * h * 3 // 2
+    assert np.array_equal(fused, sandwich), np.argwhere(fused != sandwich)[:8]
+    raw = _capture(tmp_path, src, "in.raw")
+    assert not np.array_equal(fused, raw)  # the LUT did something
