@@ -84,6 +84,28 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
         s = self->settings;
     }
     GstMapInfo map;
+    if (GST_VIDEO_INFO_FORMAT(&vf->in_info) == GST_VIDEO_FORMAT_I420) {
+        // memory:HIPMemory I420: `videoconvert ! hsvfilter ! videoconvert` in one kernel (out of place: the co-sited chroma
+        // filter reads neighbour input pixels), then the result replaces the buffer's planes (the element is AlwaysInPlace)
+        mvfx_planar_frame pin, pout;
+        if (!mvfx_hip_map_i420(buf, &vf->in_info, GST_MAP_READWRITE, &map, &pin))
+            return GST_FLOW_ERROR;
+        const gsize size = GST_VIDEO_INFO_SIZE(&vf->in_info);
+        void *scratch = NULL;
+        int rc = mvfx_device_alloc(&scratch, size);
+        if (rc == MVFX_OK) {
+            pout = pin;
+            for (guint p = 0; p < 3; p++)
+                pout.data[p] = (guint8 *)scratch + GST_VIDEO_INFO_PLANE_OFFSET(&vf->in_info, p);
+            mvfx_stream st = mvfx_thread_stream();
+            rc = mvfx_hsvfilter_transform_i420(&pin, &pout, &s, 0, st);
+            if (rc == MVFX_OK)
+                rc = mvfx_copy_device_to_device(map.data, scratch, size, st); // synchronises the stream
+            mvfx_device_free(scratch);
+        }
+        gst_buffer_unmap(buf, &map);
+        return MVFX_GST_FLOW(self, rc);
+    }
     mvfx_frame f;
     if (!mvfx_hip_map_frame(buf, &vf->in_info, GST_MAP_READWRITE, &map, &f))
         return GST_FLOW_ERROR;
@@ -129,7 +151,16 @@ static void gst_hsv_filter_class_init(GstHsvFilterClass *klass)
         "Works within the HSV colorspace to apply transformations to incoming frames",
         "Julien Bardagi <julien.bardagi@gmail.com>"); // hsvfilter/imp.rs:261-272
     static const gchar *const formats[] = {"RGBx", "xRGB", "BGRx", "xBGR", "RGBA", "ARGB", "BGRA", "ABGR", "RGB", "BGR", NULL};
-    mvfx_add_pad_templates(element, mvfx_caps_plus_hip(mvfx_video_caps(formats)), mvfx_caps_plus_hip(mvfx_video_caps(formats))); // :274-312 (+ HIP twin)
+    // :274-312, then the memory:HIPMemory twin, then HIP-only I420 (fused converters)
+    static const gchar *const i420[] = {"I420", NULL};
+    GstCaps *tmpl[2];
+    for (GstCaps *&c : tmpl) {
+        c = mvfx_caps_plus_hip(mvfx_video_caps(formats));
+        GstCaps *sys420 = mvfx_video_caps(i420);
+        gst_caps_append(c, mvfx_caps_with_hip_feature(sys420));
+        gst_caps_unref(sys420);
+    }
+    mvfx_add_pad_templates(element, tmpl[0], tmpl[1]);
     vfilter->transform_frame_ip = gst_hsv_filter_transform_frame_ip; // AlwaysInPlace (:315-320)
     GST_BASE_TRANSFORM_CLASS(klass)->transform_ip = gst_hsv_filter_bt_transform_ip;
     GST_BASE_TRANSFORM_CLASS(klass)->propose_allocation = gst_hsv_filter_propose_allocation; // d3d12colorlut/imp.rs:385-492

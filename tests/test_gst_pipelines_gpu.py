@@ -305,3 +305,18 @@ def test_colorlut_on_hipmemory_i420_equals_the_videoconvert_sandwich(gpu, tmp_pa
     assert np.array_equal(fused, sandwich), np.argwhere(fused != sandwich)[:8]
     raw = _capture(tmp_path, src, "in.raw")
     assert not np.array_equal(fused, raw)  # the LUT did something
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (1280, 720)])
+def test_hsvfilter_on_hipmemory_i420_equals_the_videoconvert_sandwich(gpu, tmp_path, w, h):
+    """`videoconvert ! hsvfilter ! videoconvert` with the image's real videoconvert elements against
+    `hipupload ! hsvfilter ! hipdownload` on I420 buffers in HBM (fused kernel): identical I420 bytes."""
+    props = "hue-shift=90 saturation-mul=1.25 saturation-off=-0.05 value-mul=0.9 value-off=0.02"
+    src = f"videotestsrc num-buffers=2 pattern=smpte ! video/x-raw,format=I420,width={w},height={h}"
+    sandwich = _capture(tmp_path, src + f" ! videoconvert ! video/x-raw,format=RGBA ! hsvfilter {props} ! videoconvert ! video/x-raw,format=I420", "ref.raw")
+    r = gst_env.run([LAUNCH, "-v"] + (src + f" ! hipupload ! hsvfilter name=f {props} ! hipdownload ! filesink location={tmp_path}/dev.raw").split(), tmp_path)
+    assert r.returncode == 0, r.stdout
+    assert re.search(r"f\.GstPad:src: caps = video/x-raw\(memory:HIPMemory\).*format=\(string\)I420", r.stdout), r.stdout[-1500:]
+    fused = np.fromfile(f"{tmp_path}/dev.raw", dtype=np.uint8)
+    assert fused.size == sandwich.size == 2 * w * h * 3 // 2
+    assert np.array_equal(fused, sandwich), np.argwhere(fused != sandwich)[:8]
