@@ -14,6 +14,8 @@ struct GstHsvFilter {
     GstVideoFilter parent;
     std::mutex *lock;                 // settings: Mutex<Settings> (hsvfilter/imp.rs:55-57)
     mvfx_hsvfilter_settings settings;
+    void *i420_scratch;               // device frame for the fused I420 path (streaming thread only)
+    gsize i420_scratch_size;
 };
 struct GstHsvFilterClass {
     GstVideoFilterClass parent_class;
@@ -91,8 +93,15 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
         if (!mvfx_hip_map_i420(buf, &vf->in_info, GST_MAP_READWRITE, &map, &pin))
             return GST_FLOW_ERROR;
         const gsize size = GST_VIDEO_INFO_SIZE(&vf->in_info);
-        void *scratch = NULL;
-        int rc = mvfx_device_alloc(&scratch, size);
+        int rc = MVFX_OK;
+        if (self->i420_scratch_size < size) { // kept across frames; sized by the first frame of each caps
+            mvfx_device_free(self->i420_scratch);
+            self->i420_scratch = NULL;
+            self->i420_scratch_size = 0;
+            rc = mvfx_device_alloc(&self->i420_scratch, size);
+            if (rc == MVFX_OK) self->i420_scratch_size = size;
+        }
+        void *scratch = self->i420_scratch;
         if (rc == MVFX_OK) {
             pout = pin;
             for (guint p = 0; p < 3; p++)
@@ -101,7 +110,6 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
             rc = mvfx_hsvfilter_transform_i420(&pin, &pout, &s, 0, st);
             if (rc == MVFX_OK)
                 rc = mvfx_copy_device_to_device(map.data, scratch, size, st); // synchronises the stream
-            mvfx_device_free(scratch);
         }
         gst_buffer_unmap(buf, &map);
         return MVFX_GST_FLOW(self, rc);
@@ -119,6 +127,7 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
 
 static void gst_hsv_filter_finalize(GObject *obj)
 {
+    mvfx_device_free(reinterpret_cast<GstHsvFilter *>(obj)->i420_scratch);
     delete reinterpret_cast<GstHsvFilter *>(obj)->lock;
     G_OBJECT_CLASS(gst_hsv_filter_parent_class)->finalize(obj);
 }
@@ -171,6 +180,8 @@ static void gst_hsv_filter_init(GstHsvFilter *self)
 {
     self->lock = new std::mutex();
     self->settings = mvfx_hsvfilter_settings{0.0f, 1.0f, 0.0f, 1.0f, 0.0f};
+    self->i420_scratch = NULL;
+    self->i420_scratch_size = 0;
 }
 
 // ------------------------------------------------------------------------- hsvdetector
