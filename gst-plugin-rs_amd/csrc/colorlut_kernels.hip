@@ -334,6 +334,8 @@ __device__ __forceinline__ void lf_coord(float raw, const LutFast &k, float scal
                                          uint32_t &i0, float &t)
 {
     const float v = lf_fmac_sv(raw * k.c_lo, k.c_hi, raw);       // RN(raw / 255) or RN(raw / 65535)
+    // (skipping `* scale + offset` + clamp for the default domain -- exact there: v * 1.0 == v, v + -0.0 == v -- through
+    // a wave-uniform branch made uniform-random frames 15 % SLOWER: the branches split the scheduling regions)
     const float x = lf_add_clamp(v * scale, offset) * size_m1;   // norm_comp * (size - 1), in [0, size-1]
     i0 = (uint32_t)__float2uint_rz(x);                           // floor (x >= 0); <= size-1 by construction
     t = x - (float)i0;
@@ -343,18 +345,23 @@ __device__ __forceinline__ float lf_lerp(float a, float b, float t) { return a +
 
 // trilinear over the 8 corners c[0..7] = c000,c100,c010,c110,c001,c101,c011,c111; returns the
 // clamped [0,1] channel values
+// DIFF: the odd corners hold the x-differences c1-c0, c3-c2, ... (RN(b - a), formed once on the host when the cell
+// table is packed: the same IEEE subtraction the lerp would do), so the four x-lerps are a + d * t
+template <bool DIFF = false>
 __device__ __forceinline__ void lf_trilinear(const float4 (&c)[8], float tx, float ty, float tz, float &r, float &g, float &b)
 {
+#define MVFX_LX(a, b_) (DIFF ? (a) + (b_) * tx : lf_lerp(a, b_, tx))
 #define MVFX_CH(ch)                                                                              \
     {                                                                                            \
-        const float c00 = lf_lerp(c[0].ch, c[1].ch, tx), c10 = lf_lerp(c[2].ch, c[3].ch, tx);    \
-        const float c01 = lf_lerp(c[4].ch, c[5].ch, tx), c11 = lf_lerp(c[6].ch, c[7].ch, tx);    \
+        const float c00 = MVFX_LX(c[0].ch, c[1].ch), c10 = MVFX_LX(c[2].ch, c[3].ch);            \
+        const float c01 = MVFX_LX(c[4].ch, c[5].ch), c11 = MVFX_LX(c[6].ch, c[7].ch);            \
         const float c0 = lf_lerp(c00, c10, ty), c1 = lf_lerp(c01, c11, ty);                      \
         ch##_out = lf_add_clamp(c0, (c1 - c0) * tz);                                             \
     }
     float x_out, y_out, z_out;
     MVFX_CH(x) MVFX_CH(y) MVFX_CH(z)
 #undef MVFX_CH
+#undef MVFX_LX
     r = x_out; g = y_out; b = z_out;
 }
 
@@ -395,7 +402,7 @@ __device__ __forceinline__ void lf_sample_3d(CUBE cube, const float4 *cells, uin
         c[0] = cube[x0 + r00]; c[1] = cube[x1 + r00]; c[2] = cube[x0 + r10]; c[3] = cube[x1 + r10];
         c[4] = cube[x0 + r01]; c[5] = cube[x1 + r01]; c[6] = cube[x0 + r11]; c[7] = cube[x1 + r11];
     }
-    lf_trilinear(c, tx, ty, tz, r, g, b);
+    lf_trilinear<CELLS>(c, tx, ty, tz, r, g, b); // the cell-packed table stores x-differences in its odd corners
 }
 
 // RGBA8 pixel: converted channels are written into bytes 0..2 of the pixel register in place, so
@@ -589,6 +596,13 @@ int ensure_uploaded(mvfx_cube_lut *h)
                             const size_t xx = std::min(x + (c & 1), m), yy = std::min(y + ((c >> 1) & 1), m), zz = std::min(z + (c >> 2), m);
                             std::memcpy(&cells[((x + n * (y + n * z)) * 8 + c) * 3], &l.rgba[(xx + n * (yy + n * zz)) * 4], 12);
                         }
+            // odd corners (x+1) become the x-differences RN(c_odd - c_even): what `a + (b - a) * t` subtracts per pixel
+            for (size_t cell = 0; cell < n * n * n; cell++)
+                for (size_t pair = 0; pair < 4; pair++)
+                    for (size_t ch = 0; ch < 3; ch++) {
+                        float *even = &cells[(cell * 8 + 2 * pair) * 3 + ch], *odd = even + 3;
+                        *odd = *odd - *even;
+                    }
             MVFX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_cells), cells.size() * sizeof(float)));
             MVFX_HIP_TRY(hipMemcpy(h->d_cells, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice));
         }
