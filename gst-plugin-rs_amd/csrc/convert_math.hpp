@@ -62,7 +62,7 @@ inline RgbToYuvCoef rgb_to_yuv_coef(int std_)
 __device__ __forceinline__ int32_t splat_s16(uint32_t byte_value)
 {
     const uint32_t ub = byte_value ^ 0x80u;
-    return (int32_t)(int16_t)(ub * 257u);
+    return (int32_t)(int16_t)((ub << 8) | ub);
 }
 
 // chroma terms shared by the (up to) four pixels of one chroma sample
@@ -72,8 +72,9 @@ struct ChromaTerms {
 
 __device__ __forceinline__ ChromaTerms chroma_terms(uint32_t u, uint32_t v, const YuvToRgbCoef &k)
 {
+    // 16-bit x 11-bit signed products: v_mul_i32_i24 (full rate) is exact, a 32-bit v_mul_lo is quarter rate
     const int32_t wu = splat_s16(u), wv = splat_s16(v);
-    return {(wv * k.p2) >> 16, ((wu * k.p4) >> 16) + ((wv * k.p5) >> 16), (wu * k.p3) >> 16};
+    return {__mul24(wv, k.p2) >> 16, (__mul24(wu, k.p4) >> 16) + (__mul24(wv, k.p5) >> 16), __mul24(wu, k.p3) >> 16};
 }
 
 __device__ __forceinline__ int32_t clamp_u8(int32_t v) { return min(max(v, 0), 255); }
@@ -81,7 +82,7 @@ __device__ __forceinline__ int32_t clamp_u8(int32_t v) { return min(max(v, 0), 2
 // one RGBA pixel (alpha 255) from a luma byte and the chroma terms
 __device__ __forceinline__ uint32_t yuv_pixel(uint32_t y, const ChromaTerms &c, const YuvToRgbCoef &k)
 {
-    const int32_t wy = ((splat_s16(y) * k.p1) >> 16) + 128;
+    const int32_t wy = (__mul24(splat_s16(y), k.p1) >> 16) + 128;
     return (uint32_t)clamp_u8(wy + c.r) | ((uint32_t)clamp_u8(wy + c.g) << 8) | ((uint32_t)clamp_u8(wy + c.b) << 16) | 0xff000000u;
 }
 
