@@ -12,30 +12,38 @@
 
 #include "convert_math.hpp"
 
+#include <algorithm>
+
 namespace mvfx {
 namespace {
 
 constexpr int kCvtBlock = 256;
 
+// one launch covers one frame from each of up to kMaxBatch streams (blockIdx.z): a 4K frame is ~8 us of traffic, so
+// single-frame launches are bound by the launch itself (13.4 us)
 struct PlanesIn {
-    const uint8_t *y, *u, *v;
+    const uint8_t *y[kMaxBatch], *u[kMaxBatch], *v[kMaxBatch];
     uint64_t ys, us, vs;
 };
 struct PlanesOut {
-    uint8_t *y, *u, *v;
+    uint8_t *y[kMaxBatch], *u[kMaxBatch], *v[kMaxBatch];
     uint64_t ys, us, vs;
+};
+struct PackedBatch {
+    uint8_t *base[kMaxBatch];
 };
 
 template <bool ALIGNED>
 __global__ __launch_bounds__(kCvtBlock) void i420_to_rgba_kernel(PlanesIn in, uint32_t width, uint32_t height, YuvToRgbCoef k,
-                                                                 uint8_t *out, uint64_t out_stride)
+                                                                 PackedBatch outs, uint64_t out_stride)
 {
+    uint8_t *out = outs.base[blockIdx.z];
     const uint32_t x0 = (blockIdx.x * kCvtBlock + threadIdx.x) * 8;
     const uint32_t y0 = blockIdx.y * 2;
     if (x0 >= width) return;
     const bool row1 = y0 + 1 < height;
-    const uint8_t *yr0 = in.y + (uint64_t)y0 * in.ys, *yr1 = yr0 + in.ys;
-    const uint8_t *ur = in.u + (uint64_t)blockIdx.y * in.us, *vr = in.v + (uint64_t)blockIdx.y * in.vs;
+    const uint8_t *yr0 = in.y[blockIdx.z] + (uint64_t)y0 * in.ys, *yr1 = yr0 + in.ys;
+    const uint8_t *ur = in.u[blockIdx.z] + (uint64_t)blockIdx.y * in.us, *vr = in.v[blockIdx.z] + (uint64_t)blockIdx.y * in.vs;
     uint8_t *o0 = out + (uint64_t)y0 * out_stride, *o1 = o0 + out_stride;
     if (ALIGNED && x0 + 8 <= width) {
         const uint2 ya = *reinterpret_cast<const uint2 *>(yr0 + x0);
@@ -92,15 +100,16 @@ __device__ __forceinline__ uint32_t chroma_h(int32_t l, int32_t c, int32_t r, ui
 }
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(kCvtBlock) void rgba_to_i420_kernel(const uint8_t *in, uint64_t in_stride, uint32_t width, uint32_t height,
+__global__ __launch_bounds__(kCvtBlock) void rgba_to_i420_kernel(PackedBatch ins, uint64_t in_stride, uint32_t width, uint32_t height,
                                                                  RgbToYuvCoef k, PlanesOut out, bool dword_ok)
 {
+    const uint8_t *in = ins.base[blockIdx.z];
     const uint32_t x0 = (blockIdx.x * kCvtBlock + threadIdx.x) * 8;
     const uint32_t y0 = blockIdx.y * 2;
     if (x0 >= width) return;
     const uint8_t *r0 = in + (uint64_t)y0 * in_stride, *r1 = r0 + in_stride;
-    uint8_t *oy0 = out.y + (uint64_t)y0 * out.ys, *oy1 = oy0 + out.ys;
-    uint8_t *ou = out.u + (uint64_t)blockIdx.y * out.us, *ov = out.v + (uint64_t)blockIdx.y * out.vs;
+    uint8_t *oy0 = out.y[blockIdx.z] + (uint64_t)y0 * out.ys, *oy1 = oy0 + out.ys;
+    uint8_t *ou = out.u[blockIdx.z] + (uint64_t)blockIdx.y * out.us, *ov = out.v[blockIdx.z] + (uint64_t)blockIdx.y * out.vs;
     const uint32_t cw = width / 2;
     const bool cosited = k.cosited != 0;
     if (ALIGNED && x0 + 8 <= width) {
@@ -181,48 +190,76 @@ int check_i420(const mvfx_planar_frame *f, const char *what)
 
 using namespace mvfx;
 
-extern "C" {
-
-int mvfx_convert_i420_to_rgba(const mvfx_planar_frame *i420_in, const mvfx_frame *rgba_out, int32_t yuv_standard, mvfx_stream stream)
+// n frame pairs sharing geometry, strides and formats (n == 1: one frame); <= kMaxBatch per launch
+static int i420_to_rgba_impl(const mvfx_planar_frame *ins, const mvfx_frame *outs, uint32_t n, int32_t yuv_standard, hipStream_t st)
 {
-    if (int rc = check_i420(i420_in, "convert input"); rc != MVFX_OK) return rc;
-    if (int rc = check_packed_frame(rgba_out, "convert output"); rc != MVFX_OK) return rc;
-    if (rgba_out->format != MVFX_FORMAT_RGBA)
-        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "convert: output format %d is not RGBA", rgba_out->format);
-    if (i420_in->width != rgba_out->width || i420_in->height != rgba_out->height)
-        return fail(MVFX_ERR_NOT_NEGOTIATED, "convert: input %ux%u and output %ux%u differ", i420_in->width, i420_in->height, rgba_out->width, rgba_out->height);
+    if (!ins || !outs || n == 0)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "convert: NULL frame or empty batch");
+    const mvfx_planar_frame *i420_in = &ins[0];
+    const mvfx_frame *rgba_out = &outs[0];
+    for (uint32_t i = 0; i < n; i++) {
+        if (int rc = check_i420(&ins[i], "convert input"); rc != MVFX_OK) return rc;
+        if (int rc = check_packed_frame(&outs[i], "convert output"); rc != MVFX_OK) return rc;
+        if (outs[i].format != MVFX_FORMAT_RGBA)
+            return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "convert: output format %d is not RGBA", outs[i].format);
+        if (ins[i].width != outs[i].width || ins[i].height != outs[i].height)
+            return fail(MVFX_ERR_NOT_NEGOTIATED, "convert: input %ux%u and output %ux%u differ", ins[i].width, ins[i].height, outs[i].width, outs[i].height);
+        if (ins[i].width != i420_in->width || ins[i].height != i420_in->height || outs[i].stride != rgba_out->stride ||
+            ins[i].stride[0] != i420_in->stride[0] || ins[i].stride[1] != i420_in->stride[1] || ins[i].stride[2] != i420_in->stride[2])
+            return fail(MVFX_ERR_INVALID_ARGUMENT, "convert: frames of one batch must share geometry and strides");
+    }
     if (yuv_standard < 0 || yuv_standard > 3)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "convert: yuv_standard %d is not 0 (by height), 1 (BT.601), 2 (BT.709), 3 (BT.2020)", yuv_standard);
     if (int rc = require_device(); rc != MVFX_OK) return rc;
     const uint32_t w = i420_in->width, h = i420_in->height;
     if (w == 0 || h == 0) return MVFX_OK;
-    const PlanesIn in{static_cast<const uint8_t *>(i420_in->data[0]), static_cast<const uint8_t *>(i420_in->data[1]),
-                      static_cast<const uint8_t *>(i420_in->data[2]), i420_in->stride[0], i420_in->stride[1], i420_in->stride[2]};
     const YuvToRgbCoef k = yuv_to_rgb_coef(pick_yuv_standard(h, yuv_standard));
-    const bool aligned = ((reinterpret_cast<uintptr_t>(in.y) | in.ys) & 7) == 0 &&
-                         ((reinterpret_cast<uintptr_t>(in.u) | in.us | reinterpret_cast<uintptr_t>(in.v) | in.vs) & 3) == 0 &&
-                         ((reinterpret_cast<uintptr_t>(rgba_out->data) | rgba_out->stride) & 15) == 0;
     const uint32_t rows2 = (h + 1) / 2;
     if (rows2 > 65535u)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "convert: height %u too large", h);
-    const dim3 grid(((w + 7) / 8 + kCvtBlock - 1) / kCvtBlock, rows2);
-    uint8_t *out = static_cast<uint8_t *>(rgba_out->data);
-    if (aligned)
-        hipLaunchKernelGGL(i420_to_rgba_kernel<true>, grid, dim3(kCvtBlock), 0, as_stream(stream), in, w, h, k, out, (uint64_t)rgba_out->stride);
-    else
-        hipLaunchKernelGGL(i420_to_rgba_kernel<false>, grid, dim3(kCvtBlock), 0, as_stream(stream), in, w, h, k, out, (uint64_t)rgba_out->stride);
-    MVFX_HIP_TRY(hipGetLastError());
+    for (uint32_t done = 0; done < n; done += kMaxBatch) {
+        const uint32_t m = std::min<uint32_t>(kMaxBatch, n - done);
+        PlanesIn in{};
+        PackedBatch out{};
+        in.ys = i420_in->stride[0]; in.us = i420_in->stride[1]; in.vs = i420_in->stride[2];
+        uint64_t a8 = in.ys, a4 = in.us | in.vs, a16 = rgba_out->stride;
+        for (uint32_t i = 0; i < m; i++) {
+            in.y[i] = static_cast<const uint8_t *>(ins[done + i].data[0]);
+            in.u[i] = static_cast<const uint8_t *>(ins[done + i].data[1]);
+            in.v[i] = static_cast<const uint8_t *>(ins[done + i].data[2]);
+            out.base[i] = static_cast<uint8_t *>(outs[done + i].data);
+            a8 |= reinterpret_cast<uintptr_t>(in.y[i]);
+            a4 |= reinterpret_cast<uintptr_t>(in.u[i]) | reinterpret_cast<uintptr_t>(in.v[i]);
+            a16 |= reinterpret_cast<uintptr_t>(out.base[i]);
+        }
+        const bool aligned = (a8 & 7) == 0 && (a4 & 3) == 0 && (a16 & 15) == 0;
+        const dim3 grid(((w + 7) / 8 + kCvtBlock - 1) / kCvtBlock, rows2, m);
+        if (aligned)
+            hipLaunchKernelGGL(i420_to_rgba_kernel<true>, grid, dim3(kCvtBlock), 0, st, in, w, h, k, out, (uint64_t)rgba_out->stride);
+        else
+            hipLaunchKernelGGL(i420_to_rgba_kernel<false>, grid, dim3(kCvtBlock), 0, st, in, w, h, k, out, (uint64_t)rgba_out->stride);
+        MVFX_HIP_TRY(hipGetLastError());
+    }
     return MVFX_OK;
 }
 
-int mvfx_convert_rgba_to_i420(const mvfx_frame *rgba_in, const mvfx_planar_frame *i420_out, int32_t yuv_standard, mvfx_stream stream)
+static int rgba_to_i420_impl(const mvfx_frame *ins, const mvfx_planar_frame *outs, uint32_t n, int32_t yuv_standard, hipStream_t st)
 {
-    if (int rc = check_packed_frame(rgba_in, "convert input"); rc != MVFX_OK) return rc;
-    if (int rc = check_i420(i420_out, "convert output"); rc != MVFX_OK) return rc;
-    if (rgba_in->format != MVFX_FORMAT_RGBA)
-        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "convert: input format %d is not RGBA", rgba_in->format);
-    if (i420_out->width != rgba_in->width || i420_out->height != rgba_in->height)
-        return fail(MVFX_ERR_NOT_NEGOTIATED, "convert: input %ux%u and output %ux%u differ", rgba_in->width, rgba_in->height, i420_out->width, i420_out->height);
+    if (!ins || !outs || n == 0)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "convert: NULL frame or empty batch");
+    const mvfx_frame *rgba_in = &ins[0];
+    const mvfx_planar_frame *i420_out = &outs[0];
+    for (uint32_t i = 0; i < n; i++) {
+        if (int rc = check_packed_frame(&ins[i], "convert input"); rc != MVFX_OK) return rc;
+        if (int rc = check_i420(&outs[i], "convert output"); rc != MVFX_OK) return rc;
+        if (ins[i].format != MVFX_FORMAT_RGBA)
+            return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "convert: input format %d is not RGBA", ins[i].format);
+        if (outs[i].width != ins[i].width || outs[i].height != ins[i].height)
+            return fail(MVFX_ERR_NOT_NEGOTIATED, "convert: input %ux%u and output %ux%u differ", ins[i].width, ins[i].height, outs[i].width, outs[i].height);
+        if (ins[i].width != rgba_in->width || ins[i].height != rgba_in->height || ins[i].stride != rgba_in->stride ||
+            outs[i].stride[0] != i420_out->stride[0] || outs[i].stride[1] != i420_out->stride[1] || outs[i].stride[2] != i420_out->stride[2])
+            return fail(MVFX_ERR_INVALID_ARGUMENT, "convert: frames of one batch must share geometry and strides");
+    }
     if (yuv_standard < 0 || yuv_standard > 3)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "convert: yuv_standard %d is not 0 (by height), 1 (BT.601), 2 (BT.709), 3 (BT.2020)", yuv_standard);
     const uint32_t w = rgba_in->width, h = rgba_in->height;
@@ -230,23 +267,58 @@ int mvfx_convert_rgba_to_i420(const mvfx_frame *rgba_in, const mvfx_planar_frame
         return fail(MVFX_ERR_INVALID_ARGUMENT, "convert: RGBA -> I420 of an odd-sized frame (%ux%u) is not implemented (chroma down-sampling of the last row / column)", w, h);
     if (int rc = require_device(); rc != MVFX_OK) return rc;
     if (w == 0 || h == 0) return MVFX_OK;
-    const PlanesOut out{static_cast<uint8_t *>(i420_out->data[0]), static_cast<uint8_t *>(i420_out->data[1]),
-                        static_cast<uint8_t *>(i420_out->data[2]), i420_out->stride[0], i420_out->stride[1], i420_out->stride[2]};
     const RgbToYuvCoef k = rgb_to_yuv_coef(pick_yuv_standard(h, yuv_standard));
-    const uint8_t *in = static_cast<const uint8_t *>(rgba_in->data);
-    const bool dword_ok = ((reinterpret_cast<uintptr_t>(in) | rgba_in->stride) & 3) == 0;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(out.y) | out.ys) & 7) == 0 &&
-                         ((reinterpret_cast<uintptr_t>(out.u) | out.us | reinterpret_cast<uintptr_t>(out.v) | out.vs) & 3) == 0 &&
-                         ((reinterpret_cast<uintptr_t>(in) | rgba_in->stride) & 15) == 0;
     if (h / 2 > 65535u)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "convert: height %u too large", h);
-    const dim3 grid(((w + 7) / 8 + kCvtBlock - 1) / kCvtBlock, h / 2);
-    if (aligned)
-        hipLaunchKernelGGL(rgba_to_i420_kernel<true>, grid, dim3(kCvtBlock), 0, as_stream(stream), in, (uint64_t)rgba_in->stride, w, h, k, out, dword_ok);
-    else
-        hipLaunchKernelGGL(rgba_to_i420_kernel<false>, grid, dim3(kCvtBlock), 0, as_stream(stream), in, (uint64_t)rgba_in->stride, w, h, k, out, dword_ok);
-    MVFX_HIP_TRY(hipGetLastError());
+    for (uint32_t done = 0; done < n; done += kMaxBatch) {
+        const uint32_t m = std::min<uint32_t>(kMaxBatch, n - done);
+        PlanesOut out{};
+        PackedBatch in{};
+        out.ys = i420_out->stride[0]; out.us = i420_out->stride[1]; out.vs = i420_out->stride[2];
+        uint64_t a8 = out.ys, a4 = out.us | out.vs, ain = rgba_in->stride;
+        for (uint32_t i = 0; i < m; i++) {
+            out.y[i] = static_cast<uint8_t *>(outs[done + i].data[0]);
+            out.u[i] = static_cast<uint8_t *>(outs[done + i].data[1]);
+            out.v[i] = static_cast<uint8_t *>(outs[done + i].data[2]);
+            in.base[i] = static_cast<uint8_t *>(ins[done + i].data);
+            a8 |= reinterpret_cast<uintptr_t>(out.y[i]);
+            a4 |= reinterpret_cast<uintptr_t>(out.u[i]) | reinterpret_cast<uintptr_t>(out.v[i]);
+            ain |= reinterpret_cast<uintptr_t>(in.base[i]);
+        }
+        const bool dword_ok = (ain & 3) == 0;
+        const bool aligned = (a8 & 7) == 0 && (a4 & 3) == 0 && (ain & 15) == 0;
+        const dim3 grid(((w + 7) / 8 + kCvtBlock - 1) / kCvtBlock, h / 2, m);
+        if (aligned)
+            hipLaunchKernelGGL(rgba_to_i420_kernel<true>, grid, dim3(kCvtBlock), 0, st, in, (uint64_t)rgba_in->stride, w, h, k, out, dword_ok);
+        else
+            hipLaunchKernelGGL(rgba_to_i420_kernel<false>, grid, dim3(kCvtBlock), 0, st, in, (uint64_t)rgba_in->stride, w, h, k, out, dword_ok);
+        MVFX_HIP_TRY(hipGetLastError());
+    }
     return MVFX_OK;
+}
+
+extern "C" {
+
+int mvfx_convert_i420_to_rgba(const mvfx_planar_frame *i420_in, const mvfx_frame *rgba_out, int32_t yuv_standard, mvfx_stream stream)
+{
+    return i420_to_rgba_impl(i420_in, rgba_out, 1, yuv_standard, as_stream(stream));
+}
+
+int mvfx_convert_i420_to_rgba_frames(const mvfx_planar_frame *i420_in, const mvfx_frame *rgba_out, uint32_t n_frames,
+                                     int32_t yuv_standard, mvfx_stream stream)
+{
+    return i420_to_rgba_impl(i420_in, rgba_out, n_frames, yuv_standard, as_stream(stream));
+}
+
+int mvfx_convert_rgba_to_i420(const mvfx_frame *rgba_in, const mvfx_planar_frame *i420_out, int32_t yuv_standard, mvfx_stream stream)
+{
+    return rgba_to_i420_impl(rgba_in, i420_out, 1, yuv_standard, as_stream(stream));
+}
+
+int mvfx_convert_rgba_to_i420_frames(const mvfx_frame *rgba_in, const mvfx_planar_frame *i420_out, uint32_t n_frames,
+                                     int32_t yuv_standard, mvfx_stream stream)
+{
+    return rgba_to_i420_impl(rgba_in, i420_out, n_frames, yuv_standard, as_stream(stream));
 }
 
 } // extern "C"

@@ -364,6 +364,11 @@ int mvfx_convert_i420_to_rgba(const mvfx_planar_frame *i420_in, const mvfx_frame
                               int32_t yuv_standard, mvfx_stream stream);
 int mvfx_convert_rgba_to_i420(const mvfx_frame *rgba_in, const mvfx_planar_frame *i420_out,
                               int32_t yuv_standard, mvfx_stream stream);
+/* n frame pairs sharing geometry and strides (one frame from each of n streams) in ONE launch */
+int mvfx_convert_i420_to_rgba_frames(const mvfx_planar_frame *i420_in, const mvfx_frame *rgba_out,
+                                     uint32_t n_frames, int32_t yuv_standard, mvfx_stream stream);
+int mvfx_convert_rgba_to_i420_frames(const mvfx_frame *rgba_in, const mvfx_planar_frame *i420_out,
+                                     uint32_t n_frames, int32_t yuv_standard, mvfx_stream stream);
 /* `videoconvert ! colorlut ! videoconvert` on a device-resident I420 frame (colorlut/imp.rs:17-19): I420 -> RGBA,
  * the LUT (colorlut/imp.rs:226-294), RGBA -> I420 -- fused into ONE kernel when the frame allows it (width % 8 == 0,
  * even height, planes aligned to 8 / 4 bytes, finite LUT domain), the same three steps through scratch frames

@@ -203,3 +203,34 @@ def test_hsvfilter_i420_matches_three_oracles(gpu, settings, geom):
     assert np.array_equal(V, Vw), np.argwhere(V != Vw)[:5]
     # aliasing input and output is refused
     assert gpu.lib().mvfx_hsvfilter_transform_i420(ctypes.byref(fin), ctypes.byref(fin), ctypes.byref(st), 0, None) == gpu.ERR_INVALID_ARGUMENT
+
+
+def test_batched_converters_match_single_frame_calls(gpu):
+    """one frame from each of n streams per launch (blockIdx.z): same bytes as n single-frame calls; batches must share geometry"""
+    w, h, n = 64, 34, 5
+    ys, cs, yr, cr, uo, vo, size = orc.i420_layout(w, h)
+    raws = [frames.splitmix64_bytes(0x5EED1100 + i, size) for i in range(n)]
+    dins = [gpu.DeviceBuffer(size).upload(r) for r in raws]
+    douts = [gpu.DeviceBuffer(w * 4 * h) for _ in range(n)]
+    fin = (gpu.PlanarFrame * n)(*[gpu.make_i420(d.ptr, w, h, ys, cs, uo, vo) for d in dins])
+    fout = (gpu.Frame * n)(*[gpu.make_frame(d.ptr, w, h, w * 4, "RGBA") for d in douts])
+    gpu.check(gpu.lib().mvfx_convert_i420_to_rgba_frames(fin, fout, n, 0, None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    rgbas = []
+    for i in range(n):
+        rc, want = orc.convert_i420_to_rgba(raws[i], w, h, 0)
+        got = douts[i].download(w * 4 * h).reshape(h, w * 4)
+        assert np.array_equal(got, want)
+        rgbas.append(want)
+    back = [gpu.DeviceBuffer(size) for _ in range(n)]
+    fback = (gpu.PlanarFrame * n)(*[gpu.make_i420(d.ptr, w, h, ys, cs, uo, vo) for d in back])
+    gpu.check(gpu.lib().mvfx_convert_rgba_to_i420_frames(fout, fback, n, 0, None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    for i in range(n):
+        rc, Yw, Uw, Vw = orc.convert_rgba_to_i420(rgbas[i], w, h, w * 4, 0)
+        d = back[i].download(size)
+        assert np.array_equal(d[: ys * yr].reshape(yr, ys)[:h, :w], Yw)
+        assert np.array_equal(d[uo: uo + cs * cr].reshape(cr, cs)[: h // 2, : w // 2], Uw)
+        assert np.array_equal(d[vo: vo + cs * cr].reshape(cr, cs)[: h // 2, : w // 2], Vw)
+    fout[2].stride = w * 4 + 16
+    assert gpu.lib().mvfx_convert_i420_to_rgba_frames(fin, fout, n, 0, None) == gpu.ERR_INVALID_ARGUMENT

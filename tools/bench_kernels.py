@@ -249,6 +249,13 @@ def main():
         fr = [vfx.make_frame(src[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
         ms = timeit(lambda i=0: vfx.check(lib.mvfx_convert_rgba_to_i420(ctypes.byref(fr[i % POOL]), ctypes.byref(fi[i % POOL]), 0, sptr)), iters=300)
         report("convert RGBA->I420 4K (videoconvert-equivalent, BT.2020 h-cosited)", ms, W * H * 11 // 2, 1)
+        fia = (vfx.PlanarFrame * POOL)(*fi)
+        foa = (vfx.Frame * POOL)(*fo)
+        fra = (vfx.Frame * POOL)(*fr)
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_convert_i420_to_rgba_frames(fia, foa, POOL, 0, sptr)), iters=60)
+        report(f"convert I420->RGBA 4K batch{POOL} (one launch)", ms, POOL * W * H * 11 // 2, POOL)
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_convert_rgba_to_i420_frames(fra, fia, POOL, 0, sptr)), iters=60)
+        report(f"convert RGBA->I420 4K batch{POOL} (one launch)", ms, POOL * W * H * 11 // 2, POOL)
 
     if want("lut420"):
         from tests import cubes as _c
