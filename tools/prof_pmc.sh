@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/prof_pmc.sh <tag> <kernel-name-substring> <bench_kernels selector...> -- on the GPU box: separate rocprofv3 PMC
-# passes (FETCH_SIZE, WRITE_SIZE; no tracing domains alongside) of tools/bench_kernels.py; prints per-dispatch averages
+# passes (FETCH_SIZE, WRITE_SIZE, VALUBusy+MemUnitBusy; no tracing domains alongside) of tools/bench_kernels.py; prints per-dispatch averages
 # of the kernels whose name contains the substring.
 set -u
 TAG=$1; MATCH=$2; shift 2
@@ -8,8 +8,9 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --pmc $C -f csv -d "$OUT/$C" -o pmc -- python3 "$REPO/tools/bench_kernels.py" "$@" > /dev/null 2> "$OUT/$C.err"
+for C in FETCH_SIZE WRITE_SIZE "VALUBusy MemUnitBusy"; do
+    D=$(echo $C | tr " " "_")
+    timeout 300 rocprofv3 --pmc $C -f csv -d "$OUT/$D" -o pmc -- python3 "$REPO/tools/bench_kernels.py" "$@" > /dev/null 2> "$OUT/$D.err"
 done
 cd "$REPO"
 python3 - "$OUT" "$MATCH" <<'PY' | tee "$OUT/summary.txt"
