@@ -136,7 +136,16 @@ def videocompare_main(args):
         bands = [(vfx.Frame * 2)(*[vfx.make_frame(pairs[k, p].data_ptr(), W, rows, W * 4, "RGBA") for p in range(2)])
                  for k in range(pool)]
 
+        dist_out = ctypes.c_double()
+
         def step(i):
+            if world == 1:
+                # one GPU holds both whole frames: HasherEngine::hash_image x2 + compare in the C ABI (one launch for both
+                # pads, one 512-byte D2H, host bit derivation), exactly what the element does per aggregate
+                vfx.check(lib.mvfx_videocompare_distance(ctypes.byref(bands[i % pool][0]), ctypes.byref(bands[i % pool][1]),
+                                                         ctypes.byref(dist_out), sptr))
+                return [dist_out.value]
+
             def partial():  # both pads' bands in one launch
                 vfx.check(lib.mvfx_blockhash_sums_pads(bands[i % pool], 2, H, r0, ctypes.c_void_p(sums.data_ptr()), sptr))
                 return sums
@@ -173,7 +182,7 @@ def videocompare_main(args):
                        "parallelism": f"{world} row bands, RCCL all-reduce per pair", "last_distance": d[0]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
-                         "note": "end-to-end per pair incl. all-reduce, D2H of 64 sums and host bit derivation"}}), flush=True)
+                         "note": "end-to-end per pair incl. all-reduce (N > 1), D2H of the block sums, the synchronisation and host bit derivation"}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
