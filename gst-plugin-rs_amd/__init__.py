@@ -148,6 +148,7 @@ SIGNATURES = {
     "mvfx_hsvfilter_transform_i420": (c_int, [POINTER(PlanarFrame), POINTER(PlanarFrame), POINTER(HsvFilterSettings), ctypes.c_int32, c_void_p]),
     "mvfx_convert_i420_to_rgba_frames": (c_int, [POINTER(PlanarFrame), POINTER(Frame), c_uint32, ctypes.c_int32, c_void_p]),
     "mvfx_convert_rgba_to_i420_frames": (c_int, [POINTER(Frame), POINTER(PlanarFrame), c_uint32, ctypes.c_int32, c_void_p]),
+    "mvfx_hsvdetector_transform_i420": (c_int, [POINTER(PlanarFrame), POINTER(Frame), POINTER(HsvDetectorSettings), ctypes.c_int32, c_void_p]),
     "mvfx_colorlut_transform_i420": (c_int, [c_void_p, POINTER(PlanarFrame), POINTER(PlanarFrame), ctypes.c_int32, c_void_p]),
     "mvfx_roundedcorners_compose_a420": (c_int, [POINTER(PlanarFrame), c_void_p, c_uint32, POINTER(PlanarFrame), c_void_p]),
 }

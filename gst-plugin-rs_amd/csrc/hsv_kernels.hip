@@ -693,6 +693,67 @@ void launch_detect(int bpp, int off, bool ibgr, bool a0, bool obgr, dim3 grid, h
 #undef MVFX_ARGS
 }
 
+
+// ---- hsvdetector on an I420 frame: `videoconvert ! hsvdetector` in one kernel ------------------------------------
+// I420 (decoder output) -> RGB in registers (convert_math.hpp) -> hsv_detect -> the detector's 4-byte output format:
+// 1.5 B/px read + 4 B/px written instead of 5.5 + 8.  One lane = 8 x 2 pixels (4 chroma samples), as in the converters.
+template <bool OUT_A0, bool OUT_BGR, int VARIANT, bool ALIGNED>
+__global__ __launch_bounds__(kBlock) void hsvdetector_i420_kernel(const uint8_t *yp, const uint8_t *up, const uint8_t *vp, uint64_t ys,
+                                                                  uint64_t us, uint64_t vs, uint32_t width, uint32_t height,
+                                                                  YuvToRgbCoef k, HsvDetectorParams p, uint8_t *out, uint64_t out_stride)
+{
+    const uint32_t x0 = (blockIdx.x * kBlock + threadIdx.x) * 8;
+    const uint32_t y0 = blockIdx.y * 2;
+    if (x0 >= width) return;
+    const bool row1 = y0 + 1 < height;
+    const uint8_t *yr0 = yp + (uint64_t)y0 * ys, *yr1 = yr0 + ys;
+    const uint8_t *ur = up + (uint64_t)blockIdx.y * us, *vr = vp + (uint64_t)blockIdx.y * vs;
+    uint8_t *o0 = out + (uint64_t)y0 * out_stride, *o1 = o0 + out_stride;
+    auto detect = [&](uint32_t rgba) -> uint32_t { // rgba: R,G,B in bytes 0..2 (what videoconvert hands to the detector as RGBx)
+        if constexpr (VARIANT == kDetFast)
+            return detect_px4_fast<0, false, OUT_A0, OUT_BGR>(rgba, p);
+        else
+            return detect_px<4, 0, false, OUT_A0, OUT_BGR, VARIANT>(rgba & 0xffu, (rgba >> 8) & 0xffu, (rgba >> 16) & 0xffu, p);
+    };
+    // (the literal variant -- fmodf loops -- keeps the per-pixel path: sixteen inlined copies of it crash the register
+    // allocator of this compiler, and it only runs for settings outside the strength-reduced domain)
+    if constexpr (ALIGNED && VARIANT != kGeneral) if (x0 + 8 <= width) {
+        const uint2 ya = *reinterpret_cast<const uint2 *>(yr0 + x0);
+        const uint2 yb = row1 ? *reinterpret_cast<const uint2 *>(yr1 + x0) : make_uint2(0, 0);
+        const uint32_t u4 = *reinterpret_cast<const uint32_t *>(ur + x0 / 2), v4 = *reinterpret_cast<const uint32_t *>(vr + x0 / 2);
+        uint32_t pa[8], pb[8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const ChromaTerms c = chroma_terms((u4 >> (8 * j)) & 0xffu, (v4 >> (8 * j)) & 0xffu, k);
+            const uint32_t wa = j < 2 ? ya.x : ya.y, wb = j < 2 ? yb.x : yb.y;
+            const int sh = (2 * j & 3) * 8;
+            pa[2 * j] = detect(yuv_pixel((wa >> sh) & 0xffu, c, k));
+            pa[2 * j + 1] = detect(yuv_pixel((wa >> (sh + 8)) & 0xffu, c, k));
+            pb[2 * j] = detect(yuv_pixel((wb >> sh) & 0xffu, c, k));
+            pb[2 * j + 1] = detect(yuv_pixel((wb >> (sh + 8)) & 0xffu, c, k));
+        }
+        uint4 *d0 = reinterpret_cast<uint4 *>(o0 + (uint64_t)x0 * 4);
+        d0[0] = make_uint4(pa[0], pa[1], pa[2], pa[3]);
+        d0[1] = make_uint4(pa[4], pa[5], pa[6], pa[7]);
+        if (row1) {
+            uint4 *d1 = reinterpret_cast<uint4 *>(o1 + (uint64_t)x0 * 4);
+            d1[0] = make_uint4(pb[0], pb[1], pb[2], pb[3]);
+            d1[1] = make_uint4(pb[4], pb[5], pb[6], pb[7]);
+        }
+        return;
+    }
+#pragma unroll 1
+    for (uint32_t x = x0; x < min(x0 + 8, width); x++) {
+        const ChromaTerms c = chroma_terms(ur[x / 2], vr[x / 2], k);
+#pragma unroll 1
+        for (int r = 0; r < (row1 ? 2 : 1); r++) {
+            const uint32_t q = detect(yuv_pixel((r ? yr1 : yr0)[x], c, k));
+            uint8_t *d = (r ? o1 : o0) + (uint64_t)x * 4;
+            d[0] = (uint8_t)q; d[1] = (uint8_t)(q >> 8); d[2] = (uint8_t)(q >> 16); d[3] = (uint8_t)(q >> 24);
+        }
+    }
+}
+
 // One frame pair of a batch: formats, sizes, the reference's asserts.
 int check_detect_pair(const mvfx_frame *in, const mvfx_frame *out, int *bpp, int *off, bool *ibgr, bool *a0, bool *obgr)
 {
@@ -783,12 +844,75 @@ int hsvdetector_impl(const mvfx_frame *ins, const mvfx_frame *outs, uint32_t n,
     return MVFX_OK;
 }
 
+
+int hsvdetector_i420_impl(const mvfx_planar_frame *in, const mvfx_frame *out, const mvfx_hsvdetector_settings *s, int yuv_standard,
+                          hipStream_t stream)
+{
+    if (!in || !out || !s)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvdetector_i420: NULL frame or settings");
+    if (in->format != MVFX_FORMAT_I420)
+        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "hsvdetector_i420: input must be I420");
+    bool a0, obgr;
+    if (detect_out_layout(out->format, &a0, &obgr) != 0)
+        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "hsvdetector: output format %d not in RGBA ARGB BGRA ABGR (hsvdetector/imp.rs:89-96)", out->format);
+    if (int rc = check_packed_frame(out, "hsvdetector output"); rc != MVFX_OK) return rc;
+    if (in->width != out->width || in->height != out->height)
+        return fail(MVFX_ERR_NOT_NEGOTIATED, "hsvdetector: input %ux%u and output %ux%u differ (assert_eq! hsvdetector/imp.rs:121)",
+                    in->width, in->height, out->width, out->height);
+    if (yuv_standard < 0 || yuv_standard > 3)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvdetector_i420: yuv_standard %d is not 0..3", yuv_standard);
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    const uint32_t w = in->width, h = in->height, cw = (w + 1) / 2;
+    if (w == 0 || h == 0) return MVFX_OK;
+    for (int pidx = 0; pidx < 3; pidx++)
+        if (!in->data[pidx] || in->stride[pidx] < (pidx == 0 ? w : cw))
+            return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvdetector_i420: bad plane %d", pidx);
+    if ((h + 1) / 2 > 65535u)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvdetector_i420: height %u too large", h);
+    const auto pz = [](float v) { return v == 0.0f ? 0.0f : v; };
+    const HsvDetectorParams p{180.0f - s->hue_ref, pz(s->hue_var), s->saturation_ref, pz(s->saturation_var),
+                              s->value_ref, pz(s->value_var), 180.0f, make_consts(nullptr)};
+    const float dv[6] = {s->hue_ref, s->hue_var, s->saturation_ref, s->saturation_var, s->value_ref, s->value_var};
+    bool det_fast_ok = std::fabs(p.ref_hue_offset) <= 360.0f;
+    for (float f : dv) det_fast_ok = det_fast_ok && std::isfinite(f);
+    if (g_variant == 2 && !det_fast_ok)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvdetector: settings are outside the proven domain of the strength-reduced hue test");
+    const int variant = g_variant == 1 ? kGeneral : (det_fast_ok ? kDetFast : kFast);
+    const YuvToRgbCoef k = yuv_to_rgb_coef(pick_yuv_standard(h, yuv_standard));
+    const uint8_t *yp = static_cast<const uint8_t *>(in->data[0]), *up = static_cast<const uint8_t *>(in->data[1]), *vp = static_cast<const uint8_t *>(in->data[2]);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(yp) | in->stride[0]) & 7) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(up) | in->stride[1] | reinterpret_cast<uintptr_t>(vp) | in->stride[2]) & 3) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(out->data) | out->stride) & 15) == 0;
+    const dim3 grid(((w + 7) / 8 + kBlock - 1) / kBlock, (h + 1) / 2);
+    uint8_t *o = static_cast<uint8_t *>(out->data);
+#define MVFX_DI(A, B, V, AL) \
+    hipLaunchKernelGGL((hsvdetector_i420_kernel<A, B, V, AL>), grid, dim3(kBlock), 0, stream, yp, up, vp, (uint64_t)in->stride[0], \
+                       (uint64_t)in->stride[1], (uint64_t)in->stride[2], w, h, k, p, o, (uint64_t)out->stride)
+#define MVFX_DI_V(A, B, AL) \
+    do { if (variant == kDetFast) MVFX_DI(A, B, kDetFast, AL); else if (variant == kFast) MVFX_DI(A, B, kFast, AL); else MVFX_DI(A, B, kGeneral, AL); } while (0)
+#define MVFX_DI_AL(A, B) \
+    do { if (aligned) MVFX_DI_V(A, B, true); else MVFX_DI_V(A, B, false); } while (0)
+    if (a0) { if (obgr) MVFX_DI_AL(true, true); else MVFX_DI_AL(true, false); }
+    else { if (obgr) MVFX_DI_AL(false, true); else MVFX_DI_AL(false, false); }
+#undef MVFX_DI_AL
+#undef MVFX_DI_V
+#undef MVFX_DI
+    MVFX_HIP_TRY(hipGetLastError());
+    return MVFX_OK;
+}
+
 } // namespace
 } // namespace mvfx
 
 using namespace mvfx;
 
 extern "C" {
+
+int mvfx_hsvdetector_transform_i420(const mvfx_planar_frame *i420_in, const mvfx_frame *out_frame,
+                                    const mvfx_hsvdetector_settings *settings, int32_t yuv_standard, mvfx_stream stream)
+{
+    return hsvdetector_i420_impl(i420_in, out_frame, settings, yuv_standard, as_stream(stream));
+}
 
 int mvfx_hsvfilter_set_variant(int variant)
 {

@@ -381,6 +381,11 @@ int mvfx_colorlut_transform_i420(mvfx_cube_lut *lut, const mvfx_planar_frame *i4
 int mvfx_hsvfilter_transform_i420(const mvfx_planar_frame *i420_in, const mvfx_planar_frame *i420_out,
                                   const mvfx_hsvfilter_settings *settings, int32_t yuv_standard,
                                   mvfx_stream stream);
+/* `videoconvert ! hsvdetector` on a device-resident I420 frame: I420 -> RGB in registers -> hsv_detect
+ * (hsvdetector/imp.rs:100-160) -> RGBA / ARGB / BGRA / ABGR.  Any frame size. */
+int mvfx_hsvdetector_transform_i420(const mvfx_planar_frame *i420_in, const mvfx_frame *out_frame,
+                                    const mvfx_hsvdetector_settings *settings, int32_t yuv_standard,
+                                    mvfx_stream stream);
 
 #ifdef __cplusplus
 }

@@ -234,3 +234,27 @@ def test_batched_converters_match_single_frame_calls(gpu):
         assert np.array_equal(d[vo: vo + cs * cr].reshape(cr, cs)[: h // 2, : w // 2], Vw)
     fout[2].stride = w * 4 + 16
     assert gpu.lib().mvfx_convert_i420_to_rgba_frames(fin, fout, n, 0, None) == gpu.ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("out_fmt", ["RGBA", "ARGB", "BGRA", "ABGR"])
+@pytest.mark.parametrize("settings", [(120.0, 40.0, 0.6, 0.4, 0.6, 0.4), (0.0, 10.0, 0.0, 0.15, 0.0, 0.3), (400.0, 180.0, 0.5, 1.0, 0.5, 1.0)],
+                         ids=["bench", "defaults", "literal-huge-ref"])
+def test_hsvdetector_i420_matches_two_oracles(gpu, out_fmt, settings):
+    """videoconvert ! hsvdetector fused: oracle(i420->rgba) -> oracle(hsvdetector RGBx -> out_fmt); odd sizes, misaligned planes"""
+    for (w, h, shift) in [(64, 32, 0), (65, 33, 0), (24, 578, 0), (1920, 1080, 0), (40, 10, 1)]:
+        ys, cs, yr, cr, uo, vo, size = orc.i420_layout(w, h)
+        raw = frames.splitmix64_bytes(0x5EED1200 + w + h, size)
+        rc, rgba = orc.convert_i420_to_rgba(raw, w, h, 0)
+        assert rc == 0
+        want = np.zeros((h, w * 4), np.uint8)
+        assert orc.hsvdetector(rgba, w * 4, "RGBx", want, w * 4, out_fmt, w, settings) == 0
+        din = gpu.DeviceBuffer(size + 64)
+        gpu.check(gpu.lib().mvfx_copy_to_device(ctypes.c_void_p(din.ptr + shift), raw.ctypes.data_as(ctypes.c_void_p), size, None))
+        dout = gpu.DeviceBuffer(w * 4 * h)
+        fin = gpu.make_i420(din.ptr + shift, w, h, ys, cs, uo, vo)
+        fout = gpu.make_frame(dout.ptr, w, h, w * 4, out_fmt)
+        st = gpu.HsvDetectorSettings(*settings)
+        gpu.check(gpu.lib().mvfx_hsvdetector_transform_i420(ctypes.byref(fin), ctypes.byref(fout), ctypes.byref(st), 0, None))
+        gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+        got = dout.download(w * 4 * h).reshape(h, w * 4)
+        assert np.array_equal(got, want), (w, h, np.argwhere(got != want)[:5])
