@@ -178,12 +178,17 @@ int colordetect_hist_impl(const mvfx_frame *frame, uint32_t quality, uint64_t fi
     if ((reinterpret_cast<uintptr_t>(hist_dev) & 15) != 0)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "colordetect: the histogram buffer must be 16-byte aligned");
     hipLaunchKernelGGL(colordetect_init_kernel, dim3(kHistBins / (256 * 4)), dim3(256), 0, st, hist_dev, minmax_dev);
-    int dev = 0, cus = 256;
+    int dev = 0;
     (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     constexpr size_t kHistLds = (kHistWords + 8) * sizeof(uint32_t);
-    MVFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(colordetect_hist_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHistLds));
+    // per device, once per thread (not per frame): the CU count and the opt-in to > 64 KiB of dynamic LDS
+    static thread_local int attr_device = -1, cus = 256;
+    if (attr_device != dev) {
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        MVFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(colordetect_hist_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHistLds));
+        attr_device = dev;
+    }
     uint64_t done = 0;
     while (done < n_samples) {
         const uint64_t chunk = std::min<uint64_t>(n_samples - done, (uint64_t)kMaxGroupsPerLaunch * kMaxSamplesPerGroup);
