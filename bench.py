@@ -347,6 +347,8 @@ def main():
                     help="colorlut workload: frame content. The LUT gathers are content dependent: smooth gradients with +-3 "
                          "codes of noise (default), uniform-random colours (worst case: every pixel another LUT cell), or flat "
                          "videotestsrc-smpte-like bars (best case)")
+    ap.add_argument("--typed-loads", type=int, default=1, choices=[0, 1],
+                    help="hsvfilter: u8/255 by typed buffer loads (texture-unit UNORM conversion) instead of VALU")
     ap.add_argument("--hash-algo", default="blockhash", choices=["blockhash", "dssim"],
                     help="videocompare workload: blockhash (the element's default) or the SSIM-family distance")
     ap.add_argument("--workload", default="hsvfilter",
@@ -386,6 +388,7 @@ def main():
     vfx.check(lib.mvfx_set_device(local_rank))
     vfx.check(lib.mvfx_hsvfilter_set_variant(args.variant))
     vfx.check(lib.mvfx_hsvfilter_set_streaming(args.streaming))
+    vfx.check(lib.mvfx_hsvfilter_set_typed_loads(args.typed_loads))
 
     # ---- resident frame pool: pool x batch distinct uniform-random 4K RGBA frames -------------
     pool = max(1, args.pool)
@@ -469,10 +472,11 @@ def main():
                    "settle_seconds_before_warmup": args.settle_seconds, "settle_steps": settle_steps,
                    "parallelism": f"{world} independent stream shards, no data-path collective",
                    "kernel_variant": {0: "auto", 1: "literal", 2: "strength-reduced"}[args.variant],
-                   "cache_policy": "non-temporal (mvfx_hsvfilter_set_streaming(1))" if args.streaming else "default"},
+                   "cache_policy": "non-temporal (mvfx_hsvfilter_set_streaming(1))" if args.streaming else "default",
+                   "u8_to_unit_float": "typed buffer loads (texture-unit UNORM8, exact)" if args.typed_loads else "VALU (cvt + mul + fmac)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "hsvfilter4_kernel<RGBA, vec4>", "bytes_per_launch": bytes_per_launch,
+                     "kernel": "hsvfilter4_typed_kernel" if args.typed_loads else "hsvfilter4_kernel<RGBA, vec4>", "bytes_per_launch": bytes_per_launch,
                      "avg_launch_ms": kernel_ms, "read_side_GBs": achieved / 2},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

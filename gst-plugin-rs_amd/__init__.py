@@ -101,6 +101,7 @@ SIGNATURES = {
     "mvfx_hsvfilter_transform_frames_ip": (c_int, [POINTER(Frame), c_uint32, POINTER(HsvFilterSettings), c_void_p]),
     "mvfx_hsvfilter_transform_frame_ip_host": (c_int, [POINTER(Frame), POINTER(HsvFilterSettings)]),
     "mvfx_hsvfilter_set_variant": (c_int, [c_int]),
+    "mvfx_hsvfilter_set_typed_loads": (c_int, [c_int]),
     "mvfx_hsvfilter_set_streaming": (c_int, [c_int]),
     "mvfx_hsvdetector_transform_frame": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(HsvDetectorSettings), c_void_p]),
     "mvfx_hsvdetector_transform_frames": (c_int, [POINTER(Frame), POINTER(Frame), c_uint32, POINTER(HsvDetectorSettings), c_void_p]),

@@ -142,6 +142,10 @@ int mvfx_hsvfilter_set_variant(int variant);
  * on device memory: +4 % for the pair); 1 = non-temporal loads and stores, for frames that leave the
  * GPU or are not touched again before ~256 MB of other traffic (+3 % on a standalone stream). */
 int mvfx_hsvfilter_set_streaming(int on);
+/* 1 (default): the three `byte / 255.0` divisions of every pixel are done by typed buffer loads (texture-unit UNORM conversion,
+ * exact for all 256 byte values: tools/probe_unorm.hip) instead of 9 VALU instructions; 4-byte formats, aligned frames,
+ * strength-reduced settings; other frames keep the VALU kernels.  Same bytes either way. */
+int mvfx_hsvfilter_set_typed_loads(int on);
 
 /* ---- hsvdetector : video/hsv/src/hsvdetector/imp.rs ----
  * Settings == `struct Settings` hsvdetector/imp.rs:34-42 (defaults :26-31). */

@@ -353,3 +353,25 @@ def test_hsvdetector_size_mismatch(gpu):
     rc = gpu.lib().mvfx_hsvdetector_transform_frame_host(ctypes.byref(fi), ctypes.byref(fo),
                                                          ctypes.byref(gpu.HsvDetectorSettings.default()))
     assert rc == gpu.ERR_UNSUPPORTED_FORMAT
+
+
+def test_typed_loads_and_valu_paths_agree_on_all_triples(gpu):
+    """hsvfilter's u8/255 through typed buffer loads (texture-unit UNORM8 conversion, the default) and through the VALU
+    kernels: both bit-exact against the oracle on all 2^24 (R,G,B) triples, every 4-byte layout, both hue-shift signs"""
+    ex = frames.exhaustive_rgbx()
+    try:
+        for fmt in ("RGBA", "xBGR", "BGRx", "ARGB"):
+            for st in ((90.0, 1.25, -0.05, 0.9, 0.02), (-45.0, 0.8, 0.1, 1.1, -0.03)):
+                want = ex.copy()
+                assert orc.hsvfilter(want, 4096, 4096 * 4, fmt, st) == 0
+                for typed in (1, 0):
+                    gpu.check(gpu.lib().mvfx_hsvfilter_set_typed_loads(typed))
+                    buf = gpu.DeviceBuffer(ex.nbytes).upload(ex)
+                    f = gpu.make_frame(buf.ptr, 4096, 4096, 4096 * 4, fmt)
+                    s = gpu.HsvFilterSettings(*st)
+                    gpu.check(gpu.lib().mvfx_hsvfilter_transform_frame_ip(ctypes.byref(f), ctypes.byref(s), None))
+                    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+                    got = buf.download().reshape(want.shape)
+                    assert np.array_equal(got, want), (fmt, st, typed, int(np.count_nonzero(got != want)))
+    finally:
+        gpu.check(gpu.lib().mvfx_hsvfilter_set_typed_loads(1))

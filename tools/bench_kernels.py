@@ -20,6 +20,8 @@ lib = vfx.lib()
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 vfx.check(lib.mvfx_set_device(0))
+if os.environ.get("MVFX_TYPED_LOADS"):
+    vfx.check(lib.mvfx_hsvfilter_set_typed_loads(int(os.environ["MVFX_TYPED_LOADS"])))
 stream = torch.cuda.current_stream(dev)
 sptr = ctypes.c_void_p(stream.cuda_stream)
 PEAK = 8000.0
