@@ -373,6 +373,52 @@ __device__ __forceinline__ uint32_t detect_px4_fast(uint32_t px, const HsvDetect
     return __builtin_amdgcn_perm(hit, px, sel);
 }
 
+
+// hsvdetector with u8/255 by typed buffer loads (see hsvfilter4_typed_kernel): 4-byte inputs, strength-reduced hue
+// test.  The descriptor's DST_SEL delivers (R, G, B); the v_perm selector that builds the output pixel from the raw
+// input dword and the hit mask is a kernel argument (it depends on the two layouts only), so one instantiation serves
+// all 16 format pairs.
+__global__ __launch_bounds__(kBlock) void hsvdetector_typed_kernel(FrameBatch in_fb, FrameBatch out_fb, uint64_t width, uint32_t rows,
+                                                                   uint64_t in_stride, uint64_t out_stride, HsvDetectorParams p,
+                                                                   uint32_t word3, uint32_t frame_bytes, uint32_t perm_sel)
+{
+    const uint64_t a = reinterpret_cast<uint64_t>(in_fb.base[blockIdx.z]);
+    uint8_t *out = out_fb.base[blockIdx.z];
+    i32x4 rs;
+    rs.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    rs.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));
+    rs.z = __builtin_amdgcn_readfirstlane((int)frame_bytes);
+    rs.w = __builtin_amdgcn_readfirstlane((int)word3);
+    const uint32_t sel = __builtin_amdgcn_readfirstlane(perm_sel);
+    for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        uint8_t *oline = out + (uint64_t)row * out_stride;
+        const uint32_t line_off = (uint32_t)((uint64_t)row * in_stride);
+        const uint64_t groups = width >> 2; // the launcher guarantees width % 4 == 0
+        for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (uint64_t)gridDim.x * kBlock) {
+            u32x4 raw;
+            f32x3 c[4];
+            const uint32_t voff = line_off + (uint32_t)(g << 4);
+            asm volatile("buffer_load_dwordx4 %0, %5, %6, 0 offen\n\t"
+                         "buffer_load_format_xyz %1, %5, %6, 0 offen\n\t"
+                         "buffer_load_format_xyz %2, %5, %6, 0 offen offset:4\n\t"
+                         "buffer_load_format_xyz %3, %5, %6, 0 offen offset:8\n\t"
+                         "buffer_load_format_xyz %4, %5, %6, 0 offen offset:12\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(raw), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+                         : "v"(voff), "s"(rs)
+                         : "memory");
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+            uint32_t r[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const HsvN hsv = from_unit_rgb_fast_n(c[j].x, c[j].y, c[j].z, p.consts);
+                r[j] = __builtin_amdgcn_perm(~detect_miss_mask_fast(hsv, p), w[j], sel); // selector byte 4 = the hit mask
+            }
+            *reinterpret_cast<uint4 *>(oline + (g << 4)) = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+    }
+}
+
 template <int IN_BPP, int IN_OFF, bool IN_BGR, bool OUT_A0, bool OUT_BGR, int VARIANT, int MODE>
 __global__ __launch_bounds__(kBlock) void hsvdetector_kernel(FrameBatch in_fb, FrameBatch out_fb,
                                                              uint64_t width, uint32_t rows,
@@ -936,6 +982,16 @@ int hsvdetector_impl(const mvfx_frame *ins, const mvfx_frame *outs, uint32_t n,
         uint64_t bx = (work + kBlock - 1) / kBlock;
         if (bx > 65535u * 16u) bx = 65535u * 16u;
         const dim3 grid((uint32_t)bx, rows < 65535u ? rows : 65535u, m);
+        const uint64_t in_bytes = (uint64_t)in->stride * in->height;
+        if (g_typed && vec && variant == kDetFast && bpp == 4 && (width & 3) == 0 && in_bytes < (1ull << 32)) {
+            const uint32_t iR = off + (ibgr ? 2 : 0), iG = off + 1, iB = off + (ibgr ? 0 : 2);
+            const uint32_t word3 = (4 + iR) | ((4 + iG) << 3) | ((4 + iB) << 6) | (10u << 15); // see hsvfilter_impl
+            const uint32_t o0 = obgr ? iB : iR, o2 = obgr ? iR : iB; // detect_px4_fast's selector, formed at run time
+            const uint32_t sel = a0 ? (4u | (o0 << 8) | (iG << 16) | (o2 << 24)) : (o0 | (iG << 8) | (o2 << 16) | (4u << 24));
+            hipLaunchKernelGGL(hsvdetector_typed_kernel, grid, dim3(kBlock), 0, stream, ifb, ofb, width, rows, is, os, p, word3, (uint32_t)in_bytes, sel);
+            MVFX_HIP_TRY(hipGetLastError());
+            continue;
+        }
         if (vec) {
             if (variant == kDetFast) launch_detect<kDetFast, kModeVec4>(bpp, off, ibgr, a0, obgr, grid, stream, ifb, ofb, width, rows, is, os, p);
             else if (variant == kFast) launch_detect<kFast, kModeVec4>(bpp, off, ibgr, a0, obgr, grid, stream, ifb, ofb, width, rows, is, os, p);

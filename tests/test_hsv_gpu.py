@@ -375,3 +375,26 @@ def test_typed_loads_and_valu_paths_agree_on_all_triples(gpu):
                     assert np.array_equal(got, want), (fmt, st, typed, int(np.count_nonzero(got != want)))
     finally:
         gpu.check(gpu.lib().mvfx_hsvfilter_set_typed_loads(1))
+
+
+def test_typed_loads_hsvdetector_all_triples(gpu):
+    """the detector's typed-load path (default) and its VALU path against the oracle on all 2^24 triples, 4 input x 2 output layouts"""
+    ex = frames.exhaustive_rgbx()
+    st = (120.0, 40.0, 0.6, 0.4, 0.6, 0.4)
+    try:
+        for in_fmt, out_fmt in (("RGBx", "RGBA"), ("xBGR", "ARGB"), ("BGRx", "BGRA"), ("xRGB", "ABGR")):
+            want = np.empty_like(ex)
+            assert orc.hsvdetector(ex, 4096 * 4, in_fmt, want, 4096 * 4, out_fmt, 4096, st) == 0
+            for typed in (1, 0):
+                gpu.check(gpu.lib().mvfx_hsvfilter_set_typed_loads(typed))
+                src = gpu.DeviceBuffer(ex.nbytes).upload(ex)
+                dst = gpu.DeviceBuffer(ex.nbytes)
+                fi = gpu.make_frame(src.ptr, 4096, 4096, 4096 * 4, in_fmt)
+                fo = gpu.make_frame(dst.ptr, 4096, 4096, 4096 * 4, out_fmt)
+                s = gpu.HsvDetectorSettings(*st)
+                gpu.check(gpu.lib().mvfx_hsvdetector_transform_frame(ctypes.byref(fi), ctypes.byref(fo), ctypes.byref(s), None))
+                gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+                got = dst.download().reshape(want.shape)
+                assert np.array_equal(got, want), (in_fmt, out_fmt, typed, int(np.count_nonzero(got != want)))
+    finally:
+        gpu.check(gpu.lib().mvfx_hsvfilter_set_typed_loads(1))
