@@ -1,0 +1,32 @@
+// Shared by hsv_kernels.hip and hsv_typed_kernels.hip: the LDS selector table of the strength-reduced hsvfilter kernels
+// and the launcher of the typed-load kernel.
+#pragma once
+
+#include "hsv_math.hpp"
+#include "mvfx_internal.h"
+
+namespace mvfx {
+
+constexpr int kHsvBlock = 256;
+
+// LDS tables of one workgroup of the FAST hsvfilter kernels
+struct FilterLds {
+    uint32_t sextant[8]; // v_perm_b32 selectors, see sextant_selector()
+};
+
+// Fills the LDS tables of this workgroup (no-op for the literal variant). blockDim.x == 256.
+template <int VARIANT>
+__device__ __forceinline__ void init_filter_lds(FilterLds &lds, int off, bool bgr)
+{
+    if constexpr (VARIANT != kGeneral) {
+        if (threadIdx.x < 8)
+            lds.sextant[threadIdx.x] = sextant_selector(threadIdx.x, off, bgr);
+        __syncthreads();
+    }
+}
+
+// hsv_typed_kernels.hip: hsvfilter4_typed_kernel<neg ? kFastNeg : kFast, tile (1 | 2), streaming>
+void launch_hsvfilter_typed(bool neg_shift, int tile, bool streaming, dim3 grid, hipStream_t stream, const FrameBatch &fb, uint64_t width,
+                            uint32_t rows, uint64_t stride, const FastConsts &p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr);
+
+} // namespace mvfx

@@ -21,6 +21,7 @@
 //   This file is compiled with the ILP-driven scheduling strategy (Makefile): the pixel function is one long
 //   dependent chain and the four pixels of a group have to be interleaved by the scheduler (+3.8 %).
 #include "hsv_math.hpp"
+#include "hsv_filter_lds.hpp"
 #include "convert_math.hpp"
 #include "mvfx_internal.h"
 
@@ -61,11 +62,6 @@ __device__ __forceinline__ uint32_t repack4(uint32_t px, uint32_t R, uint32_t G,
     return (px & keep) | (c0 << (8 * OFF)) | (G << (8 * OFF + 8)) | (c2 << (8 * OFF + 16));
 }
 
-// LDS tables of one workgroup of the FAST hsvfilter kernels
-struct FilterLds {
-    uint32_t sextant[8]; // v_perm_b32 selectors, see sextant_selector()
-};
-
 template <int OFF, bool BGR, int VARIANT>
 __device__ __forceinline__ uint32_t filter_px4(uint32_t px, const FastConsts &k, const FilterLds &lds)
 {
@@ -84,17 +80,6 @@ __device__ __forceinline__ uint32_t filter_px4(uint32_t px, const FastConsts &k,
         uint32_t T;
         const uint32_t sel_off = hsvfilter_fast_unit<VARIANT == kFastNeg>(BGR ? c2 : c0, c1, BGR ? c0 : c2, k, T);
         return __builtin_amdgcn_perm(T, px, sextant_at(lds.sextant, sel_off));
-    }
-}
-
-// Fills the LDS tables of this workgroup (no-op for the literal variant). blockDim.x == 256.
-template <int VARIANT>
-__device__ __forceinline__ void init_filter_lds(FilterLds &lds, int off, bool bgr)
-{
-    if constexpr (VARIANT != kGeneral) {
-        if (threadIdx.x < 8)
-            lds.sextant[threadIdx.x] = sextant_selector(threadIdx.x, off, bgr);
-        __syncthreads();
     }
 }
 
@@ -178,94 +163,10 @@ __global__ __launch_bounds__(kBlock) void hsvfilter4_kernel(FrameBatch fb, uint6
 }
 
 
-// ---- hsvfilter, 4-byte formats, u8/255 by the texture unit ------------------------------------------------------
-// A typed buffer load (buffer_load_format_xyz, DATA_FORMAT 8_8_8_8, NUM_FORMAT UNORM) returns RN(byte / 255.0f) for
-// every byte value in every channel (tools/probe_unorm.hip: 256 x 4 values, all exact), and the descriptor's DST_SEL
-// hands the channels over as (R, G, B) whatever the byte order: the three exact divisions of a pixel -- 9 of its 63
-// VALU instructions (v_cvt_f32_ubyteN + v_mul + v_fmac each) -- are done by the memory pipeline on the way in.
-// The raw dwords (4th byte, v_perm source) come from an untyped buffer_load_dwordx4 through the same descriptor; the
-// typed loads of the same 16 bytes follow immediately and merge into its cache lines.  All loads of a lane and their
-// wait are ONE asm statement: the compiler does not track asm loads, so nothing may touch their registers in between.
+// ---- hsvfilter, 4-byte formats, u8/255 by the texture unit: hsv_typed_kernels.hip (its own translation unit: LLVM's
+// default scheduler suits it, the ILP strategy this file is built with suits everything here) ----
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-template <int VARIANT, int TILE, bool NT>
-__global__ __launch_bounds__(kBlock) void hsvfilter4_typed_kernel(FrameBatch fb, uint64_t width, uint32_t rows, uint64_t stride,
-                                                                  FastConsts p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr)
-{
-    static_assert(VARIANT == kFast || VARIANT == kFastNeg, "strength-reduced variants only");
-    __shared__ FilterLds lds;
-    init_filter_lds<VARIANT>(lds, off, bgr);
-    uint8_t *frame = fb.base[blockIdx.z];
-    const uint64_t a = reinterpret_cast<uint64_t>(frame);
-    i32x4 rs;
-    rs.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
-    rs.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu)); // stride 0: raw byte offsets
-    rs.z = __builtin_amdgcn_readfirstlane((int)frame_bytes);
-    rs.w = __builtin_amdgcn_readfirstlane((int)word3);
-    for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
-        uint8_t *line = frame + (uint64_t)row * stride;
-        const uint32_t line_off = (uint32_t)((uint64_t)row * stride);
-        const uint64_t groups = width >> 2; // the launcher guarantees width % 4 == 0
-        for (uint64_t t0 = (uint64_t)blockIdx.x * (kBlock * TILE); t0 < groups; t0 += (uint64_t)gridDim.x * (kBlock * TILE)) {
-            u32x4 raw[TILE];
-            f32x3 c[TILE][4];
-            uint32_t voff[TILE];
-#pragma unroll
-            for (int u = 0; u < TILE; u++) // groups past the end: the buffer bounds check returns zeros, nothing is stored
-                voff[u] = line_off + (uint32_t)((t0 + (uint64_t)u * kBlock + threadIdx.x) << 4);
-#define MVFX_TYPED_LOADS2(NTS)                                                                 \
-    asm volatile("buffer_load_dwordx4 %0, %10, %12, 0 offen" NTS "\n\t"                          \
-                 "buffer_load_dwordx4 %1, %11, %12, 0 offen" NTS "\n\t"                          \
-                 "buffer_load_format_xyz %2, %10, %12, 0 offen\n\t"                              \
-                 "buffer_load_format_xyz %3, %10, %12, 0 offen offset:4\n\t"                     \
-                 "buffer_load_format_xyz %4, %10, %12, 0 offen offset:8\n\t"                     \
-                 "buffer_load_format_xyz %5, %10, %12, 0 offen offset:12\n\t"                    \
-                 "buffer_load_format_xyz %6, %11, %12, 0 offen\n\t"                              \
-                 "buffer_load_format_xyz %7, %11, %12, 0 offen offset:4\n\t"                     \
-                 "buffer_load_format_xyz %8, %11, %12, 0 offen offset:8\n\t"                     \
-                 "buffer_load_format_xyz %9, %11, %12, 0 offen offset:12\n\t"                    \
-                 "s_waitcnt vmcnt(0)"                                                             \
-                 : "=&v"(raw[0]), "=&v"(raw[1]), "=&v"(c[0][0]), "=&v"(c[0][1]), "=&v"(c[0][2]), "=&v"(c[0][3]), \
-                   "=&v"(c[1][0]), "=&v"(c[1][1]), "=&v"(c[1][2]), "=&v"(c[1][3])                 \
-                 : "v"(voff[0]), "v"(voff[1]), "s"(rs)                                            \
-                 : "memory")
-#define MVFX_TYPED_LOADS1(NTS)                                                                 \
-    asm volatile("buffer_load_dwordx4 %0, %5, %6, 0 offen" NTS "\n\t"                            \
-                 "buffer_load_format_xyz %1, %5, %6, 0 offen\n\t"                                \
-                 "buffer_load_format_xyz %2, %5, %6, 0 offen offset:4\n\t"                       \
-                 "buffer_load_format_xyz %3, %5, %6, 0 offen offset:8\n\t"                       \
-                 "buffer_load_format_xyz %4, %5, %6, 0 offen offset:12\n\t"                      \
-                 "s_waitcnt vmcnt(0)"                                                             \
-                 : "=&v"(raw[0]), "=&v"(c[0][0]), "=&v"(c[0][1]), "=&v"(c[0][2]), "=&v"(c[0][3])  \
-                 : "v"(voff[0]), "s"(rs)                                                          \
-                 : "memory")
-            if constexpr (TILE == 2) {
-                if constexpr (NT) MVFX_TYPED_LOADS2(" nt"); else MVFX_TYPED_LOADS2("");
-            } else {
-                if constexpr (NT) MVFX_TYPED_LOADS1(" nt"); else MVFX_TYPED_LOADS1("");
-            }
-#undef MVFX_TYPED_LOADS2
-#undef MVFX_TYPED_LOADS1
-#pragma unroll
-            for (int u = 0; u < TILE; u++) {
-                const uint64_t g = t0 + (uint64_t)u * kBlock + threadIdx.x;
-                if (g < groups) {
-                    uint32_t w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        uint32_t T;
-                        const uint32_t sel_off = hsvfilter_fast_unit<VARIANT == kFastNeg>(c[u][j].x, c[u][j].y, c[u][j].z, p, T);
-                        w[j] = __builtin_amdgcn_perm(T, w[j], sextant_at(lds.sextant, sel_off));
-                    }
-                    const u32x4 t = {w[0], w[1], w[2], w[3]};
-                    if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(line + (g << 4)));
-                    else *reinterpret_cast<u32x4 *>(line + (g << 4)) = t;
-                }
-            }
-        }
-    }
-}
 
 // ---- hsvfilter, 3-byte formats (RGB / BGR) ---------------------------------------------------
 struct __attribute__((aligned(4))) U3 {
@@ -717,11 +618,8 @@ int hsvfilter_impl(const mvfx_frame *frames, uint32_t n, const mvfx_hsvfilter_se
             const uint32_t iR = off + (bgr ? 2 : 0), iG = off + 1, iB = off + (bgr ? 0 : 2);
             const uint32_t word3 = (4 + iR) | ((4 + iG) << 3) | ((4 + iB) << 6) | (10u << 15);
             const bool neg = std::signbit(s->hue_shift) && s->hue_shift != 0.0f;
-#define MVFX_LT(V, T_) if (g_streaming) hipLaunchKernelGGL((hsvfilter4_typed_kernel<V, T_, true>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p, word3, (uint32_t)frame_bytes, off, bgr); \
-                       else hipLaunchKernelGGL((hsvfilter4_typed_kernel<V, T_, false>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p, word3, (uint32_t)frame_bytes, off, bgr)
-            if (g.tile == kTile) { if (neg) MVFX_LT(kFastNeg, kTile); else MVFX_LT(kFast, kTile); }
-            else { if (neg) MVFX_LT(kFastNeg, 1); else MVFX_LT(kFast, 1); }
-#undef MVFX_LT
+            launch_hsvfilter_typed(neg, g.tile == kTile ? kTile : 1, g_streaming != 0, g.grid, stream, fb, g.width, g.rows, g.stride, p, word3,
+                                   (uint32_t)frame_bytes, off, bgr);
             MVFX_HIP_TRY(hipGetLastError());
             continue;
         }
