@@ -232,6 +232,8 @@ static void gst_hsv_detector_get_property(GObject *obj, guint id, GValue *value,
 
 static const gchar *const kDetectorIn[] = {"RGBx", "xRGB", "BGRx", "xBGR", "RGB", "BGR", NULL};  // hsvdetector/imp.rs:78-87
 static const gchar *const kDetectorOut[] = {"RGBA", "ARGB", "BGRA", "ABGR", NULL};              // :89-96
+// memory:HIPMemory sink caps additionally take I420 (decoder output): `videoconvert ! hsvdetector` as one kernel
+static const gchar *const kDetectorInHip[] = {"RGBx", "xRGB", "BGRx", "xBGR", "RGB", "BGR", "I420", NULL};
 
 // BaseTransformImpl::transform_caps (hsvdetector/imp.rs:386-419): replace the `format` field of
 // every structure with the list of the other side, then intersect with the filter (First mode)
@@ -240,10 +242,16 @@ static GstCaps *gst_hsv_detector_transform_caps(GstBaseTransform *trans, GstPadD
 {
     GstCaps *other = gst_caps_copy(caps);
     GstCaps *tmpl = mvfx_video_caps(direction == GST_PAD_SRC ? kDetectorIn : kDetectorOut);
+    GstCaps *tmpl_hip = mvfx_video_caps(direction == GST_PAD_SRC ? kDetectorInHip : kDetectorOut);
     const GValue *formats = gst_structure_get_value(gst_caps_get_structure(tmpl, 0), "format");
-    for (guint i = 0; i < gst_caps_get_size(other); i++)
-        gst_structure_set_value(gst_caps_get_structure(other, i), "format", formats);
+    const GValue *formats_hip = gst_structure_get_value(gst_caps_get_structure(tmpl_hip, 0), "format");
+    for (guint i = 0; i < gst_caps_get_size(other); i++) {
+        GstCapsFeatures *f = gst_caps_get_features(other, i);
+        const gboolean hip = f && gst_caps_features_contains(f, MVFX_CAPS_FEATURE_MEMORY_HIP);
+        gst_structure_set_value(gst_caps_get_structure(other, i), "format", hip ? formats_hip : formats);
+    }
     gst_caps_unref(tmpl);
+    gst_caps_unref(tmpl_hip);
     GST_CAT_DEBUG_OBJECT(hsvdetector_debug, trans, "Transformed caps from %" GST_PTR_FORMAT " to %" GST_PTR_FORMAT " in direction %d",
                          caps, other, (int)direction);
     if (filter) {
@@ -292,14 +300,16 @@ static GstFlowReturn gst_hsv_detector_bt_transform(GstBaseTransform *bt, GstBuff
     }
     GstMapInfo imap, omap;
     mvfx_frame fi, fo;
-    if (!mvfx_hip_map_frame(inbuf, &vf->in_info, GST_MAP_READ, &imap, &fi))
+    mvfx_planar_frame pi;
+    const gboolean i420 = GST_VIDEO_INFO_FORMAT(&vf->in_info) == GST_VIDEO_FORMAT_I420;
+    if (i420 ? !mvfx_hip_map_i420(inbuf, &vf->in_info, GST_MAP_READ, &imap, &pi) : !mvfx_hip_map_frame(inbuf, &vf->in_info, GST_MAP_READ, &imap, &fi))
         return GST_FLOW_ERROR;
     if (!mvfx_hip_map_frame(outbuf, &vf->out_info, GST_MAP_WRITE, &omap, &fo)) {
         gst_buffer_unmap(inbuf, &imap);
         return GST_FLOW_ERROR;
     }
     mvfx_stream st = mvfx_thread_stream();
-    int rc = mvfx_hsvdetector_transform_frame(&fi, &fo, &s, st);
+    int rc = i420 ? mvfx_hsvdetector_transform_i420(&pi, &fo, &s, 0, st) : mvfx_hsvdetector_transform_frame(&fi, &fo, &s, st);
     if (rc == MVFX_OK)
         rc = mvfx_stream_synchronize(st);
     gst_buffer_unmap(outbuf, &omap);
@@ -339,7 +349,13 @@ static void gst_hsv_detector_class_init(GstHsvDetectorClass *klass)
                            0.0f, 1.0f, 0.3f, flags));
     gst_element_class_set_static_metadata(element, "HSV detector", "Filter/Effect/Converter/Video",
         "Works within the HSV colorspace to mark positive pixels", "Julien Bardagi <julien.bardagi@gmail.com>");
-    mvfx_add_pad_templates(element, mvfx_caps_plus_hip(mvfx_video_caps(kDetectorIn)), mvfx_caps_plus_hip(mvfx_video_caps(kDetectorOut)));
+    GstCaps *sink_tmpl = mvfx_video_caps(kDetectorIn); // the reference's caps, then the HIP twin incl. I420
+    {
+        GstCaps *hip_in = mvfx_video_caps(kDetectorInHip);
+        gst_caps_append(sink_tmpl, mvfx_caps_with_hip_feature(hip_in));
+        gst_caps_unref(hip_in);
+    }
+    mvfx_add_pad_templates(element, sink_tmpl, mvfx_caps_plus_hip(mvfx_video_caps(kDetectorOut)));
     GST_BASE_TRANSFORM_CLASS(klass)->transform_caps = gst_hsv_detector_transform_caps;
     GST_BASE_TRANSFORM_CLASS(klass)->prepare_output_buffer = gst_hsv_detector_prepare_output_buffer;
     GST_BASE_TRANSFORM_CLASS(klass)->propose_allocation = gst_hsv_detector_propose_allocation;

@@ -320,3 +320,20 @@ def test_hsvfilter_on_hipmemory_i420_equals_the_videoconvert_sandwich(gpu, tmp_p
     fused = np.fromfile(f"{tmp_path}/dev.raw", dtype=np.uint8)
     assert fused.size == sandwich.size == 2 * w * h * 3 // 2
     assert np.array_equal(fused, sandwich), np.argwhere(fused != sandwich)[:8]
+
+
+def test_hsvdetector_on_hipmemory_i420_equals_videoconvert_then_detector(gpu, tmp_path):
+    """`videoconvert ! hsvdetector` with the image's real videoconvert against `hipupload ! hsvdetector ! hipdownload` fed
+    with I420 buffers in HBM (fused kernel): identical RGBA bytes."""
+    w, h = 320, 240
+    props = "hue-ref=120 hue-var=60 saturation-ref=0.6 saturation-var=0.4 value-ref=0.6 value-var=0.4"
+    src = f"videotestsrc num-buffers=2 pattern=smpte ! video/x-raw,format=I420,width={w},height={h}"
+    ref = _capture(tmp_path, src + f" ! videoconvert ! video/x-raw,format=RGBx ! hsvdetector {props} ! video/x-raw,format=RGBA", "ref.raw")
+    r = gst_env.run([LAUNCH, "-v"] + (src + f" ! hipupload ! hsvdetector name=d {props} ! video/x-raw(memory:HIPMemory),format=RGBA ! hipdownload "
+                                      f"! filesink location={tmp_path}/dev.raw").split(), tmp_path)
+    assert r.returncode == 0, r.stdout
+    assert re.search(r"d\.GstPad:sink: caps = video/x-raw\(memory:HIPMemory\).*format=\(string\)I420", r.stdout), r.stdout[-1500:]
+    fused = np.fromfile(f"{tmp_path}/dev.raw", dtype=np.uint8)
+    assert fused.size == ref.size == 2 * w * h * 4
+    assert np.array_equal(fused, ref), np.argwhere(fused != ref)[:8]
+    assert 0 < np.count_nonzero(fused[3::4]) < fused.size // 4
