@@ -258,3 +258,30 @@ def test_hsvdetector_i420_matches_two_oracles(gpu, out_fmt, settings):
         gpu.check(gpu.lib().mvfx_stream_synchronize(None))
         got = dout.download(w * 4 * h).reshape(h, w * 4)
         assert np.array_equal(got, want), (w, h, np.argwhere(got != want)[:5])
+
+
+def test_fused_entry_points_reject_bad_arguments(gpu):
+    from tests import cubes
+    w, h = 64, 32
+    ys, cs, yr, cr, uo, vo, size = orc.i420_layout(w, h)
+    a = gpu.DeviceBuffer(size)
+    b = gpu.DeviceBuffer(size)
+    fa = gpu.make_i420(a.ptr, w, h, ys, cs, uo, vo)
+    fb = gpu.make_i420(b.ptr, w, h, ys, cs, uo, vo)
+    lut = gpu.CubeLut(cubes.analytic_3d(9))
+    L = gpu.lib()
+    assert L.mvfx_colorlut_transform_i420(lut.h, ctypes.byref(fa), ctypes.byref(fa), 0, None) == gpu.ERR_INVALID_ARGUMENT  # aliasing
+    assert L.mvfx_colorlut_transform_i420(None, ctypes.byref(fa), ctypes.byref(fb), 0, None) == gpu.ERR_NO_LUT
+    assert L.mvfx_colorlut_transform_i420(lut.h, ctypes.byref(fa), ctypes.byref(fb), 9, None) == gpu.ERR_INVALID_ARGUMENT
+    small = gpu.make_i420(b.ptr, w, h // 2, ys, cs, uo, vo)
+    assert L.mvfx_colorlut_transform_i420(lut.h, ctypes.byref(fa), ctypes.byref(small), 0, None) == gpu.ERR_NOT_NEGOTIATED
+    st = gpu.HsvFilterSettings.default()
+    odd = gpu.make_i420(a.ptr, w - 1, h, ys, cs, uo, vo)
+    odd_out = gpu.make_i420(b.ptr, w - 1, h, ys, cs, uo, vo)
+    assert L.mvfx_hsvfilter_transform_i420(ctypes.byref(odd), ctypes.byref(odd_out), ctypes.byref(st), 0, None) == gpu.ERR_INVALID_ARGUMENT
+    ds = gpu.HsvDetectorSettings.default()
+    out = gpu.DeviceBuffer(w * h * 4)
+    rgbx = gpu.make_frame(out.ptr, w, h, w * 4, "RGBx")  # not an output format of the detector
+    assert L.mvfx_hsvdetector_transform_i420(ctypes.byref(fa), ctypes.byref(rgbx), ctypes.byref(ds), 0, None) == gpu.ERR_UNSUPPORTED_FORMAT
+    rgba = gpu.make_frame(out.ptr, w, h, w * 4, "RGBA")
+    assert L.mvfx_convert_i420_to_rgba_frames(ctypes.byref(fa), ctypes.byref(rgba), 0, 0, None) == gpu.ERR_INVALID_ARGUMENT  # empty batch
