@@ -144,6 +144,7 @@ SIGNATURES = {
     "mvfx_ssim_distance_host": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(ctypes.c_double)]),
     "mvfx_roundedcorners_mask": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_void_p]),
     "mvfx_roundedcorners_mask_host": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_uint32]),
+    "mvfx_roundedcorners_cairo_version": (c_char_p, []),
     "mvfx_convert_i420_to_rgba": (c_int, [POINTER(PlanarFrame), POINTER(Frame), ctypes.c_int32, c_void_p]),
     "mvfx_convert_rgba_to_i420": (c_int, [POINTER(Frame), POINTER(PlanarFrame), ctypes.c_int32, c_void_p]),
     "mvfx_hsvfilter_transform_i420": (c_int, [POINTER(PlanarFrame), POINTER(PlanarFrame), POINTER(HsvFilterSettings), ctypes.c_int32, c_void_p]),

@@ -16,14 +16,14 @@
 //     workgroup, then a 64-wave launch that adds the partials (no same-address atomics, no memset);
 //     every pad of an aggregate in one launch (blockIdx.z).
 //     A row range can be given so that 8 ranks each reduce one block-row and all-reduce 64 u32.
-//  roundedcorners (video/videofx/src/border/imp.rs:57-180)
-//     A8 mask of a rounded rectangle (fill + 1 px stroke, anti-aliased).  cairo's scan converter
-//     is not restated; the kernel computes area coverage on a 16x16 sub-sample grid, validated
-//     against libcairo 1.16 goldens with a documented tolerance (tests/test_videofx_gpu.py).
-//     radius 0 => 0xFF everywhere (exact, border/imp.rs:123-128).
-//     Optional I420 -> A420 compose for device-resident pipelines (plane copies + mask).
+//  roundedcorners (video/videofx/src/border/imp.rs:57-180, 482-559)
+//     The A8 mask is rendered ONCE per caps / radius change by libcairo, exactly as the reference
+//     does (host/cairo_mask.cpp replays border/imp.rs:64-103 through the system library), and
+//     uploaded; the per-frame device work is the I420 -> A420 compose (plane copies + mask) for
+//     device-resident pipelines.  radius 0 => 0xFF everywhere (border/imp.rs:123-128).
 #include "mvfx_internal.h"
 
+#include "cairo_mask.h"
 #include "mmcq.h"
 
 #include <algorithm>
@@ -409,58 +409,6 @@ uint64_t blockhash_bits(const uint32_t sums[64], uint32_t width, uint32_t height
 
 // ------------------------------------------------------------------ roundedcorners
 
-constexpr int kSub = 16; // sub-samples per axis for partially covered pixels
-
-// Coverage of pixel (px,py) by the rounded rectangle [0,w]x[0,h] with corner radius r (fill) and
-// by the 1 px stroke along its outline, on a kSub x kSub grid of sample centres.
-__device__ __forceinline__ uint32_t rounded_alpha(uint32_t px, uint32_t py, float w, float h, float r)
-{
-    // distance of the pixel's nearest / farthest point to the relevant corner centre decides
-    // quickly whether the pixel is trivially inside or outside
-    const bool left = px + 0.5f < w * 0.5f, top = py + 0.5f < h * 0.5f;
-    const float cx = left ? r : w - r;
-    const float cy = top ? r : h - r;
-    const bool in_corner_x = left ? (float)px < r : (float)(px + 1) > w - r;
-    const bool in_corner_y = top ? (float)py < r : (float)(py + 1) > h - r;
-    if (!(in_corner_x && in_corner_y))
-        return 255u; // straight edges lie on the frame border: fill covers the pixel completely
-    uint32_t fill = 0, stroke = 0;
-    for (int sy = 0; sy < kSub; sy++) {
-        const float y = py + (sy + 0.5f) / kSub;
-        for (int sx = 0; sx < kSub; sx++) {
-            const float x = px + (sx + 0.5f) / kSub;
-            // only the quadrant beyond the arc centre is rounded
-            const bool beyond_x = left ? (x < cx) : (x > cx);
-            const bool beyond_y = top ? (y < cy) : (y > cy);
-            if (beyond_x && beyond_y) {
-                const float d = sqrtf((x - cx) * (x - cx) + (y - cy) * (y - cy));
-                fill += d <= r;
-                stroke += fabsf(d - r) <= 0.5f;
-            } else {
-                fill += 1; // inside the straight part (stroke there is hidden under the fill)
-            }
-        }
-    }
-    const uint32_t n = kSub * kSub;
-    const uint32_t F = (fill * 255u + n / 2) / n, S = (stroke * 255u + n / 2) / n;
-    // OVER: stroke composited on top of the fill, 8-bit arithmetic
-    const uint32_t t = S * (255u - F) + 128u;
-    return min(255u, F + ((t + (t >> 8)) >> 8));
-}
-
-__global__ __launch_bounds__(256) void rounded_mask_kernel(uint8_t *mask, uint32_t width, uint32_t height,
-                                                           uint32_t stride, uint32_t mask_rows, uint32_t radius)
-{
-    const uint32_t x = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t y = blockIdx.y;
-    if (x >= stride || y >= mask_rows) return;
-    uint8_t v;
-    if (radius == 0) v = 0xff;                         // border/imp.rs:123-128: whole memory 0xff
-    else if (x >= width || y >= height) v = 0;         // alpha_mem.fill(0) outside the surface
-    else v = (uint8_t)rounded_alpha(x, y, (float)width, (float)height, (float)radius);
-    mask[(uint64_t)y * stride + x] = v;
-}
-
 // The four plane copies of the A420 compose in ONE launch (grid z = plane): four back-to-back launches of
 // 2-8 MB each were launch-bound (20 us for 33 MB).  A plane whose rows are contiguous in both buffers is
 // described as a single long row.
@@ -711,41 +659,31 @@ int mvfx_videocompare_distance(const mvfx_frame *reference_frame, const mvfx_fra
     return MVFX_OK;
 }
 
+int mvfx_roundedcorners_mask_host(uint8_t *mask_host, uint32_t width, uint32_t height, uint32_t stride,
+                                  uint32_t border_radius_px)
+{
+    if (!mask_host || stride < width || width == 0 || height == 0)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "roundedcorners: bad mask geometry %ux%u stride %u", width, height, stride);
+    return cairo_render_rounded_mask(mask_host, width, height, stride, border_radius_px);
+}
+
 int mvfx_roundedcorners_mask(uint8_t *mask_device, uint32_t width, uint32_t height, uint32_t stride,
                              uint32_t border_radius_px, mvfx_stream stream)
 {
     if (!mask_device || stride < width || width == 0 || height == 0)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "roundedcorners: bad mask geometry %ux%u stride %u", width, height, stride);
-    if ((uint64_t)border_radius_px * 2 > width || (uint64_t)border_radius_px * 2 > height)
-        return fail(MVFX_ERR_INVALID_ARGUMENT,
-                    "roundedcorners: border-radius-px %u exceeds half of %ux%u; cairo's self-intersecting path for that "
-                    "case is not modelled by the HIP mask kernel", border_radius_px, width, height);
     if (int rc = require_device(); rc != MVFX_OK) return rc;
-    const uint32_t rows = (height + 1) & ~1u; // border/imp.rs:469-470 round_up_2(height)
-    const dim3 grid((stride + 255) / 256, rows, 1);
-    if (rows > 65535u)
-        return fail(MVFX_ERR_INVALID_ARGUMENT, "roundedcorners: height %u too large", height);
-    hipLaunchKernelGGL(rounded_mask_kernel, grid, dim3(256), 0, as_stream(stream), mask_device, width, height, stride, rows, border_radius_px);
-    MVFX_HIP_TRY(hipGetLastError());
+    // once per caps / border-radius change (border/imp.rs:491-519): render with cairo, move to HBM
+    const size_t bytes = (size_t)stride * ((height + 1) & ~1u);
+    std::vector<uint8_t> host(bytes);
+    if (int rc = cairo_render_rounded_mask(host.data(), width, height, stride, border_radius_px); rc != MVFX_OK) return rc;
+    hipStream_t st = as_stream(stream);
+    MVFX_HIP_TRY(hipMemcpyAsync(mask_device, host.data(), bytes, hipMemcpyHostToDevice, st));
+    MVFX_HIP_TRY(hipStreamSynchronize(st)); // `host` dies with this call
     return MVFX_OK;
 }
 
-int mvfx_roundedcorners_mask_host(uint8_t *mask_host, uint32_t width, uint32_t height, uint32_t stride,
-                                  uint32_t border_radius_px)
-{
-    if (!mask_host)
-        return fail(MVFX_ERR_INVALID_ARGUMENT, "roundedcorners: NULL mask");
-    if (int rc = require_device(); rc != MVFX_OK) return rc;
-    const size_t bytes = (size_t)stride * ((height + 1) & ~1u);
-    void *dev = nullptr;
-    if (int rc = host_scratch(bytes ? bytes : 16, 0, &dev); rc != MVFX_OK) return rc;
-    hipStream_t st = host_stream();
-    if (int rc = mvfx_roundedcorners_mask(static_cast<uint8_t *>(dev), width, height, stride, border_radius_px, st); rc != MVFX_OK)
-        return rc;
-    MVFX_HIP_TRY(hipMemcpyAsync(mask_host, dev, bytes, hipMemcpyDeviceToHost, st));
-    MVFX_HIP_TRY(hipStreamSynchronize(st));
-    return MVFX_OK;
-}
+const char *mvfx_roundedcorners_cairo_version(void) { return cairo_mask_library_version(); }
 
 int mvfx_roundedcorners_compose_a420(const mvfx_planar_frame *i420_in, const uint8_t *mask_device,
                                      uint32_t mask_stride, const mvfx_planar_frame *a420_out, mvfx_stream stream)

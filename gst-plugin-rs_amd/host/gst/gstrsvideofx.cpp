@@ -339,8 +339,9 @@ static gboolean gst_rounded_corners_set_caps(GstBaseTransform *trans, GstCaps *i
     return TRUE;
 }
 
-// generate_alpha_mask (:108-180): the mask is rendered by the HIP kernel and copied into the
-// shared alpha GstMemory
+// generate_alpha_mask (:108-180): the mask is rendered by libcairo with the reference's call sequence
+// (mvfx_roundedcorners_mask*, host/cairo_mask.cpp) into the shared alpha GstMemory -- system memory on the
+// reference's path, HBM on the memory:HIPMemory path
 static gboolean rounded_corners_generate_mask(GstRoundedCorners *self, guint radius)
 {
     // make_mut(): the memory may be shared with in-flight buffers -> copy on write
@@ -357,9 +358,8 @@ static gboolean rounded_corners_generate_mask(GstRoundedCorners *self, guint rad
     const uint32_t mw = (uint32_t)GST_VIDEO_INFO_WIDTH(&self->out_info), mh = (uint32_t)GST_VIDEO_INFO_HEIGHT(&self->out_info),
                    ms = (uint32_t)GST_VIDEO_INFO_PLANE_STRIDE(&self->out_info, 3);
     int rc;
-    if (self->hip) { // rendered where it will be read
+    if (self->hip) { // uploaded once to where the compose kernel reads it (synchronous)
         rc = mvfx_roundedcorners_mask(map.data, mw, mh, ms, radius, mvfx_thread_stream());
-        if (rc == MVFX_OK) rc = mvfx_stream_synchronize(mvfx_thread_stream());
     } else {
         rc = mvfx_roundedcorners_mask_host(map.data, mw, mh, ms, radius);
     }
@@ -409,9 +409,18 @@ static GstFlowReturn gst_rounded_corners_prepare_output_buffer(GstBaseTransform 
         if (fr != GST_FLOW_OK)
             return fr;
         GstMapInfo imap, omap, amap;
-        if (!gst_buffer_map(inbuf, &imap, (GstMapFlags)(GST_MAP_READ | MVFX_MAP_HIP)) ||
-            !gst_buffer_map(out, &omap, (GstMapFlags)(GST_MAP_WRITE | MVFX_MAP_HIP)) ||
-            !gst_memory_map(self->alpha_mem, &amap, (GstMapFlags)(GST_MAP_READ | MVFX_MAP_HIP))) {
+        if (!gst_buffer_map(inbuf, &imap, (GstMapFlags)(GST_MAP_READ | MVFX_MAP_HIP))) {
+            gst_buffer_unref(out);
+            return GST_FLOW_ERROR;
+        }
+        if (!gst_buffer_map(out, &omap, (GstMapFlags)(GST_MAP_WRITE | MVFX_MAP_HIP))) {
+            gst_buffer_unmap(inbuf, &imap);
+            gst_buffer_unref(out);
+            return GST_FLOW_ERROR;
+        }
+        if (!gst_memory_map(self->alpha_mem, &amap, (GstMapFlags)(GST_MAP_READ | MVFX_MAP_HIP))) {
+            gst_buffer_unmap(out, &omap);
+            gst_buffer_unmap(inbuf, &imap);
             gst_buffer_unref(out);
             return GST_FLOW_ERROR;
         }
@@ -462,7 +471,16 @@ static GstFlowReturn gst_rounded_corners_prepare_output_buffer(GstBaseTransform 
             offsets[p] = meta->offset[p];
             strides[p] = meta->stride[p];
         }
-        gst_buffer_remove_meta(buf, GST_META_CAST(meta));
+        if (GST_META_FLAG_IS_SET(GST_META_CAST(meta), GST_META_FLAG_LOCKED)) {
+            // border/imp.rs:202-224: a locked (pool-owned) meta cannot be removed -> new buffer with the memories,
+            // flags and timestamps of this one and none of its metas
+            GstBuffer *fresh = gst_buffer_copy_region(
+                buf, (GstBufferCopyFlags)(GST_BUFFER_COPY_FLAGS | GST_BUFFER_COPY_TIMESTAMPS | GST_BUFFER_COPY_MEMORY), 0, -1);
+            if (buf != inbuf) gst_buffer_unref(buf);
+            buf = fresh;
+        } else {
+            gst_buffer_remove_meta(buf, GST_META_CAST(meta));
+        }
     } else {
         for (guint p = 0; p < 3; p++) {
             offsets[p] = GST_VIDEO_INFO_PLANE_OFFSET(&self->out_info, p);

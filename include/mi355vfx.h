@@ -339,15 +339,21 @@ typedef struct mvfx_planar_frame {
 } mvfx_planar_frame;
 
 /* Replaces generate_alpha_mask + draw_rounded_corners (border/imp.rs:57-180): writes the A8
- * plane (stride x round_up_2(height) bytes): 0xFF everywhere when border_radius_px == 0, else 0
- * outside / 255 inside the rounded rectangle with anti-aliased corner arcs (fill + 1 px stroke).
- * Anti-aliased values follow area coverage, not cairo's scan converter bit for bit (tolerance in
- * DESIGN.md); everything that is not on a corner arc is exact. */
+ * plane (stride x round_up_2(height) bytes): 0xFF everywhere when border_radius_px == 0
+ * (border/imp.rs:123-128), else the rounded rectangle drawn by libcairo with the reference's exact
+ * call sequence (new_sub_path, four arcs, close_path, fill_preserve, 1 px stroke) -- the same C
+ * library the reference calls through cairo-rs, loaded at run time (dlopen "libcairo.so.2";
+ * MVFX_CAIRO_LIBRARY overrides the path; MVFX_ERR_IO if absent), so the bytes equal the
+ * reference's for every radius, including 2*radius > min(width, height).  Runs once per caps /
+ * radius change (border/imp.rs:491-519); the per-frame device work is the compose below.
+ * The device flavour renders on the host and uploads (synchronous on `stream`). */
 int mvfx_roundedcorners_mask(uint8_t *mask_device, uint32_t width, uint32_t height,
                              uint32_t stride, uint32_t border_radius_px, mvfx_stream stream);
-/* same, into host memory (the shared alpha GstMemory of the element); synchronous */
+/* same, into host memory (the shared alpha GstMemory of the element); synchronous, touches no device */
 int mvfx_roundedcorners_mask_host(uint8_t *mask_host, uint32_t width, uint32_t height,
                                   uint32_t stride, uint32_t border_radius_px);
+/* cairo_version_string() of the libcairo in use, NULL when none can be loaded */
+const char *mvfx_roundedcorners_cairo_version(void);
 /* I420 -> A420 into one device buffer: copies Y, U, V and the mask as plane 3 (what
  * prepare_output_buffer does by appending the shared alpha GstMemory, border/imp.rs:482-559). */
 int mvfx_roundedcorners_compose_a420(const mvfx_planar_frame *i420_in, const uint8_t *mask_device,

@@ -17,7 +17,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = [(32, 24, 8), (64, 48, 10), (641, 481, 33), (640, 480, 0), (33, 17, 40), (1920, 1080, 1),
-         (1920, 1080, 50), (1920, 1080, 540), (3840, 2160, 100)]
+         (1920, 1080, 50), (1920, 1080, 540), (3840, 2160, 100),
+         # 2*radius > min(width, height): cairo draws the self-overlapping path; the element must not refuse it
+         (64, 48, 30), (1920, 1080, 700), (100, 101, 4000)]
 
 
 def load_cairo():

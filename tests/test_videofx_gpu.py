@@ -235,7 +235,8 @@ def test_blockhash_8k_pair(gpu):
 
 # ---------------------------------------------------------------- roundedcorners
 
-MASK_TOLERANCE = 32  # max |HIP - cairo| on anti-aliased arc pixels (documented in DESIGN.md)
+MASK_CASES = ["w32_h24_r8", "w64_h48_r10", "w641_h481_r33", "w640_h480_r0", "w33_h17_r40", "w1920_h1080_r1",
+              "w1920_h1080_r50", "w1920_h1080_r540", "w3840_h2160_r100", "w64_h48_r30", "w1920_h1080_r700", "w100_h101_r4000"]
 
 
 @pytest.fixture(scope="module")
@@ -243,9 +244,10 @@ def cairo_masks():
     return np.load(os.path.join(GOLDEN, "roundedcorners_masks.npz"))
 
 
-@pytest.mark.parametrize("case", ["w32_h24_r8", "w64_h48_r10", "w641_h481_r33", "w640_h480_r0", "w1920_h1080_r1",
-                                  "w1920_h1080_r50", "w1920_h1080_r540", "w3840_h2160_r100"])
+@pytest.mark.parametrize("case", MASK_CASES)
 def test_roundedcorners_mask_vs_cairo_golden(gpu, cairo_masks, case):
+    """The A8 plane in HBM is byte-identical to libcairo's rendering of border/imp.rs:57-106 for every radius,
+    2*radius > min(width, height) included (no tolerance: the mask is produced by the reference's own rasteriser)."""
     gold = cairo_masks[case]
     w, h, r = (int(t[1:]) for t in case.split("_"))
     rows, stride = gold.shape
@@ -254,18 +256,48 @@ def test_roundedcorners_mask_vs_cairo_golden(gpu, cairo_masks, case):
     gpu.check(gpu.lib().mvfx_roundedcorners_mask(ctypes.c_void_p(buf.ptr), w, h, stride, r, None))
     gpu.check(gpu.lib().mvfx_stream_synchronize(None))
     got = buf.download().reshape(rows, stride)
-    if r == 0:
-        assert np.array_equal(got, gold)  # exact: 0xFF everywhere (border/imp.rs:123-128)
-        return
-    # fully covered / fully empty pixels are exact
-    solid = (gold == 0) | (gold == 255)
-    diff = np.abs(got.astype(np.int32) - gold.astype(np.int32))
-    assert diff.max() <= MASK_TOLERANCE, f"max |diff| {diff.max()}"
-    frac_exact_solid = np.count_nonzero(diff[solid] == 0) / np.count_nonzero(solid)
-    assert frac_exact_solid > 0.9999
-    # padding columns / the extra row of an odd height stay 0
-    assert not got[:, w:].any() and not got[h:].any()
-    print(case, "max diff", diff.max(), "mean diff on partial px", diff[~solid].mean() if (~solid).any() else 0)
+    assert np.array_equal(got, gold)
+
+
+@pytest.mark.parametrize("w,h,r", [(64, 48, 10), (3840, 2160, 100), (641, 481, 33)])
+def test_roundedcorners_compose_a420_sizes(gpu, cairo_masks, w, h, r):
+    """BASELINE config 4 shape (3840x2160) and an odd size: Y/U/V copied bit-exactly into the A420 buffer with
+    GStreamer's plane layout, plane 3 == the cairo mask (prepare_output_buffer, border/imp.rs:482-559)."""
+    gold = cairo_masks[f"w{w}_h{h}_r{r}"]
+    ys, cs = (w + 3) & ~3, (((w + 1) // 2) + 3) & ~3      # GstVideoInfo strides of I420 / A420
+    hh, ch = (h + 1) & ~1, ((h + 1) & ~1) // 2            # round_up_2(height) rows of Y, half of that of chroma
+    offs = [0, ys * hh, ys * hh + cs * ch, ys * hh + 2 * cs * ch]
+    i420 = frames.splitmix64_bytes(0x5EED0100 + w, offs[3])
+    src = gpu.DeviceBuffer(i420.nbytes).upload(i420)
+    mask = gpu.DeviceBuffer(gold.nbytes)
+    gpu.check(gpu.lib().mvfx_roundedcorners_mask(ctypes.c_void_p(mask.ptr), w, h, ys, r, None))
+    out_size = offs[3] + ys * hh
+    dst = gpu.DeviceBuffer(out_size).upload(np.full(out_size, 0x5A, np.uint8))
+    fi, fo = gpu.PlanarFrame(), gpu.PlanarFrame()
+    for p in range(3):
+        fi.data[p] = src.ptr + offs[p]
+        fo.data[p] = dst.ptr + offs[p]
+        fi.stride[p] = fo.stride[p] = ys if p == 0 else cs
+    fo.data[3] = dst.ptr + offs[3]
+    fo.stride[3] = ys
+    fi.width = fo.width = w
+    fi.height = fo.height = h
+    fi.format, fo.format = gpu.FORMATS["I420"], gpu.FORMATS["A420"]
+    gpu.check(gpu.lib().mvfx_roundedcorners_compose_a420(ctypes.byref(fi), ctypes.c_void_p(mask.ptr), ys, ctypes.byref(fo), None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    out = dst.download()
+    cw, chh = (w + 1) // 2, (h + 1) // 2
+    y_in, y_out = i420[:ys * hh].reshape(hh, ys), out[:ys * hh].reshape(hh, ys)
+    assert np.array_equal(y_out[:h, :w], y_in[:h, :w])
+    for p in (1, 2):
+        c_in = i420[offs[p]:offs[p] + cs * ch].reshape(ch, cs)
+        c_out = out[offs[p]:offs[p] + cs * ch].reshape(ch, cs)
+        assert np.array_equal(c_out[:chh, :cw], c_in[:chh, :cw])
+    a_out = out[offs[3]:].reshape(hh, ys)
+    assert np.array_equal(a_out[:h, :w], gold[:h, :w])
+    # row padding of the destination is not written
+    if ys > w:
+        assert (y_out[:h, w:] == 0x5A).all() and (a_out[:h, w:] == 0x5A).all()
 
 
 def test_roundedcorners_compose_a420(gpu, cairo_masks):
