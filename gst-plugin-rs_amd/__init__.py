@@ -41,6 +41,34 @@ ERR_NO_LUT = -9
 ERR_OUT_OF_MEMORY = -10
 
 
+# mvfx_thread_set_options bits
+OPT_NONTEMPORAL = 0x01
+OPT_HSV_LITERAL = 0x02
+OPT_HSV_FORCE_FAST = 0x04
+OPT_HSV_VALU_UNORM = 0x08
+OPT_LUT_PLACEMENT_SHIFT = 4
+
+
+class options:
+    """``with vfx.options(variant=1, typed=False): ...`` -- sets the calling thread's kernel options
+    (mvfx_thread_set_options) for the block and restores the previous word.  variant: 0 auto, 1 literal,
+    2 force strength-reduced; placement: colorlut LUT placement 0..4."""
+
+    def __init__(self, variant=0, nontemporal=False, typed=True, placement=0):
+        self.word = ((OPT_NONTEMPORAL if nontemporal else 0) | (OPT_HSV_LITERAL if variant == 1 else 0) |
+                     (OPT_HSV_FORCE_FAST if variant == 2 else 0) | (0 if typed else OPT_HSV_VALU_UNORM) |
+                     (placement << OPT_LUT_PLACEMENT_SHIFT))
+
+    def __enter__(self):
+        self.prev = lib().mvfx_thread_options()
+        check(lib().mvfx_thread_set_options(self.word))
+        return self
+
+    def __exit__(self, *exc):
+        lib().mvfx_thread_set_options(self.prev)
+        return False
+
+
 class Frame(Structure):
     """struct mvfx_frame"""
     _fields_ = [("data", c_void_p), ("width", c_uint32), ("height", c_uint32),
@@ -97,12 +125,11 @@ SIGNATURES = {
     "mvfx_copy_to_host": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mvfx_copy_device_to_device": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mvfx_thread_stream": (c_void_p, []),
+    "mvfx_thread_set_options": (c_int, [c_uint32]),
+    "mvfx_thread_options": (c_uint32, []),
     "mvfx_hsvfilter_transform_frame_ip": (c_int, [POINTER(Frame), POINTER(HsvFilterSettings), c_void_p]),
     "mvfx_hsvfilter_transform_frames_ip": (c_int, [POINTER(Frame), c_uint32, POINTER(HsvFilterSettings), c_void_p]),
     "mvfx_hsvfilter_transform_frame_ip_host": (c_int, [POINTER(Frame), POINTER(HsvFilterSettings)]),
-    "mvfx_hsvfilter_set_variant": (c_int, [c_int]),
-    "mvfx_hsvfilter_set_typed_loads": (c_int, [c_int]),
-    "mvfx_hsvfilter_set_streaming": (c_int, [c_int]),
     "mvfx_hsvdetector_transform_frame": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(HsvDetectorSettings), c_void_p]),
     "mvfx_hsvdetector_transform_frames": (c_int, [POINTER(Frame), POINTER(Frame), c_uint32, POINTER(HsvDetectorSettings), c_void_p]),
     "mvfx_hsvdetector_transform_frame_host": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(HsvDetectorSettings)]),
@@ -118,7 +145,6 @@ SIGNATURES = {
     "mvfx_colorlut_transform_frame": (c_int, [c_void_p, POINTER(Frame), POINTER(Frame), c_void_p]),
     "mvfx_colorlut_transform_frames": (c_int, [c_void_p, POINTER(Frame), POINTER(Frame), c_uint32, c_void_p]),
     "mvfx_colorlut_transform_frame_host": (c_int, [c_void_p, POINTER(Frame), POINTER(Frame)]),
-    "mvfx_colorlut_set_placement": (c_int, [c_int]),
     "mvfx_colordetect_histogram": (c_int, [POINTER(Frame), c_uint32, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     "mvfx_mmcq_palette_from_histogram": (c_int, [c_void_p, POINTER(c_uint32), c_uint32, POINTER(c_uint32), POINTER(c_uint32)]),
     "mvfx_colordetect_palette": (c_int, [POINTER(Frame), c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_uint32), c_void_p]),

@@ -4,12 +4,14 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 
 namespace mvfx {
 
 namespace {
 thread_local char t_last_error[512] = "";
+thread_local uint32_t t_options = 0; // mvfx_thread_set_options
 
 struct Scratch {
     void *ptr = nullptr;
@@ -17,17 +19,29 @@ struct Scratch {
 };
 constexpr int kScratchSlots = 4;
 
-// Per-thread staging state of the *_host entry points; released when the thread (e.g. a GStreamer
-// streaming thread) exits so pipelines that come and go do not leak device memory.
-struct ThreadState {
+// Per-thread, per-device staging state of the *_host entry points (a thread that switches devices with
+// mvfx_set_device gets a separate stream and scratch set for each ordinal); released when the thread (e.g. a
+// GStreamer streaming thread) exits so pipelines that come and go do not leak device memory.
+struct DeviceState {
     Scratch scratch[kScratchSlots];
     hipStream_t stream = nullptr;
-    int stream_device = -1;
+    bool stream_tried = false;
+};
+struct ThreadState {
+    std::map<int, DeviceState> per_device;
+    DeviceState &current()
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        return per_device[dev];
+    }
     ~ThreadState()
     {
-        for (Scratch &s : scratch)
-            if (s.ptr) (void)hipFree(s.ptr);
-        if (stream) (void)hipStreamDestroy(stream);
+        for (auto &kv : per_device) {
+            for (Scratch &s : kv.second.scratch)
+                if (s.ptr) (void)hipFree(s.ptr);
+            if (kv.second.stream) (void)hipStreamDestroy(kv.second.stream);
+        }
     }
 };
 thread_local ThreadState t_state;
@@ -41,6 +55,8 @@ int fail(int status, const char *fmt, ...)
     va_end(ap);
     return status;
 }
+
+uint32_t thread_options() { return t_options; }
 
 int require_device()
 {
@@ -78,7 +94,7 @@ int host_scratch(size_t bytes, int slot, void **out)
 {
     if (slot < 0 || slot >= kScratchSlots)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "bad scratch slot %d", slot);
-    Scratch &s = t_state.scratch[slot];
+    Scratch &s = t_state.current().scratch[slot];
     if (s.cap < bytes) {
         if (s.ptr) {
             MVFX_HIP_TRY(hipFree(s.ptr));
@@ -97,15 +113,15 @@ int host_scratch(size_t bytes, int slot, void **out)
 
 hipStream_t host_stream()
 {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (t_state.stream == nullptr || t_state.stream_device != dev) {
-        if (t_state.stream) (void)hipStreamDestroy(t_state.stream);
-        if (hipStreamCreateWithFlags(&t_state.stream, hipStreamNonBlocking) != hipSuccess)
-            t_state.stream = nullptr; // fall back to the null stream
-        t_state.stream_device = dev;
+    DeviceState &d = t_state.current();
+    if (!d.stream_tried) {
+        d.stream_tried = true;
+        if (hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            d.stream = nullptr; // the null stream
+        }
     }
-    return t_state.stream;
+    return d.stream;
 }
 
 } // namespace mvfx
@@ -213,5 +229,21 @@ int mvfx_copy_device_to_device(void *dst_device, const void *src_device, size_t 
 }
 
 mvfx_stream mvfx_thread_stream(void) { return reinterpret_cast<mvfx_stream>(host_stream()); }
+
+int mvfx_thread_set_options(uint32_t options)
+{
+    const uint32_t known = MVFX_OPT_NONTEMPORAL | MVFX_OPT_HSV_LITERAL | MVFX_OPT_HSV_FORCE_FAST | MVFX_OPT_HSV_VALU_UNORM |
+                           MVFX_OPT_LUT_PLACEMENT_MASK;
+    if (options & ~known)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options 0x%x: unknown bits 0x%x", options, options & ~known);
+    if ((options & MVFX_OPT_HSV_LITERAL) && (options & MVFX_OPT_HSV_FORCE_FAST))
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options: MVFX_OPT_HSV_LITERAL and MVFX_OPT_HSV_FORCE_FAST exclude each other");
+    if (((options & MVFX_OPT_LUT_PLACEMENT_MASK) >> MVFX_OPT_LUT_PLACEMENT_SHIFT) > 4)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options: colorlut placement must be 0 (auto) .. 4 (literal kernels)");
+    t_options = options;
+    return MVFX_OK;
+}
+
+uint32_t mvfx_thread_options(void) { return t_options; }
 
 } // extern "C"

@@ -568,7 +568,6 @@ __global__ __launch_bounds__(kLdsBlock) void colorlut_fast_lds_kernel(FrameBatch
     }
 }
 
-int g_lut_placement = 0; // 0 auto, 1 global node layout, 2 LDS, 3 global cell-packed, 4 literal kernels
 
 int ensure_uploaded(mvfx_cube_lut *h)
 {
@@ -703,7 +702,7 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
         finite = finite && std::isfinite(l.domain_scale[c]) && std::isfinite(l.domain_offset[c]);
     // 0 auto | 1 node layout in global/L2 | 2 LDS | 3 cell-packed global | 4 literal kernels
     bool use_lds = fits_lds, use_cells = false, use_fast = finite && vec;
-    switch (g_lut_placement) {
+    switch (opt_lut_placement()) {
     case 1: use_lds = false; break;
     case 2:
         if (!fits_lds) return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: LUT of size %u does not fit in LDS", l.size);
@@ -825,7 +824,7 @@ int colorlut_i420_impl(mvfx_cube_lut *h, const mvfx_planar_frame *in, const mvfx
         const uint64_t v = (uint64_t)(uintptr_t)in->data[pidx] | in->stride[pidx] | (uint64_t)(uintptr_t)out->data[pidx] | out->stride[pidx];
         bits |= pidx == 0 ? (v & 7) : (v & 3);
     }
-    const bool fused = finite && bits == 0 && (w % 8) == 0 && hgt / 2 <= 65535u && g_lut_placement != 4;
+    const bool fused = finite && bits == 0 && (w % 8) == 0 && hgt / 2 <= 65535u && opt_lut_placement() != 4;
     if (fused) {
         LutParams p{};
         p.cube = reinterpret_cast<const float4 *>(h->d_rgba);
@@ -936,14 +935,6 @@ const float *mvfx_cube_lut_table_1d(const mvfx_cube_lut *lut, int channel)
 {
     if (!lut || lut->lut.is_3d || channel < 0 || channel > 2) return nullptr;
     return lut->lut.table[channel].data();
-}
-
-int mvfx_colorlut_set_placement(int placement)
-{
-    if (placement < 0 || placement > 4)
-        return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut placement must be 0 (auto), 1 (global node layout), 2 (LDS), 3 (global cell-packed) or 4 (literal kernels)");
-    g_lut_placement = placement;
-    return MVFX_OK;
 }
 
 int mvfx_colorlut_transform_frame(mvfx_cube_lut *lut, const mvfx_frame *in_frame, const mvfx_frame *out_frame,

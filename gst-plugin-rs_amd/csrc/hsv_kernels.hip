@@ -411,9 +411,8 @@ __global__ __launch_bounds__(kBlock) void hsv_from_frame_kernel(const uint8_t *i
 
 // ---- host side ------------------------------------------------------------------------------
 
-int g_variant = 0;   // mvfx_hsvfilter_set_variant
-int g_streaming = 0; // mvfx_hsvfilter_set_streaming
-int g_typed = 1;     // mvfx_hsvfilter_set_typed_loads: u8/255 by typed buffer loads (hsvfilter4_typed_kernel)
+// Kernel choices come from the calling thread's options (mvfx_thread_set_options, capi_common.hip): no process globals,
+// so two elements on two streaming threads never see each other's choice.
 
 // Domain of the FAST kernels (hsv_math.hpp): finite settings, |shift| <= 360, shift not in
 // (0,1e-30) in magnitude.
@@ -516,6 +515,7 @@ template <int VARIANT>
 void launch_filter(int bpp, int off, bool bgr, const Geometry &g, const FrameBatch &fb,
                    const FastConsts &p, hipStream_t stream)
 {
+    const bool nontemporal = opt_nontemporal();
 
 #define MVFX_L4(O, B, M) \
     hipLaunchKernelGGL((hsvfilter4_kernel<O, B, VARIANT, M>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p)
@@ -528,7 +528,7 @@ void launch_filter(int bpp, int off, bool bgr, const Geometry &g, const FrameBat
         const int key = (off ? 2 : 0) | (bgr ? 1 : 0);
         switch (g.mode) {
         case kModeVec4:
-            if (g_streaming && VARIANT != kGeneral)
+            if (nontemporal && VARIANT != kGeneral)
                 switch (key) { case 0: MVFX_L4V(0, false, true); break; case 1: MVFX_L4V(0, true, true); break;
                                case 2: MVFX_L4V(1, false, true); break; default: MVFX_L4V(1, true, true); break; }
             else
@@ -597,6 +597,7 @@ int hsvfilter_impl(const mvfx_frame *frames, uint32_t n, const mvfx_hsvfilter_se
         return rc;
 
     const bool fast_ok = fast_domain_ok(*s);
+    const int g_variant = opt_hsv_variant();
     if (g_variant == 2 && !fast_ok)
         return fail(MVFX_ERR_INVALID_ARGUMENT,
                     "hsvfilter: settings are outside the proven domain of the strength-reduced kernel");
@@ -612,13 +613,13 @@ int hsvfilter_impl(const mvfx_frame *frames, uint32_t n, const mvfx_hsvfilter_se
             fb.base[i] = static_cast<uint8_t *>(frames[done + i].data);
         const Geometry g = plan(frames + done, m, bpp, m, bpp == 4 ? kTile : 1);
         const uint64_t frame_bytes = (uint64_t)frames[0].stride * frames[0].height;
-        if (g_typed && use_fast && bpp == 4 && g.mode == kModeVec4 && (g.width & 3) == 0 && frame_bytes < (1ull << 32)) {
+        if (opt_typed_loads() && use_fast && bpp == 4 && g.mode == kModeVec4 && (g.width & 3) == 0 && frame_bytes < (1ull << 32)) {
             // descriptor word 3: DST_SEL x/y/z = the bytes holding R, G, B (4 + byte index), w = 0; NUM_FORMAT UNORM (0);
             // DATA_FORMAT 8_8_8_8 (10)
             const uint32_t iR = off + (bgr ? 2 : 0), iG = off + 1, iB = off + (bgr ? 0 : 2);
             const uint32_t word3 = (4 + iR) | ((4 + iG) << 3) | ((4 + iB) << 6) | (10u << 15);
             const bool neg = std::signbit(s->hue_shift) && s->hue_shift != 0.0f;
-            launch_hsvfilter_typed(neg, g.tile == kTile ? kTile : 1, g_streaming != 0, g.grid, stream, fb, g.width, g.rows, g.stride, p, word3,
+            launch_hsvfilter_typed(neg, g.tile == kTile ? kTile : 1, opt_nontemporal(), g.grid, stream, fb, g.width, g.rows, g.stride, p, word3,
                                    (uint32_t)frame_bytes, off, bgr);
             MVFX_HIP_TRY(hipGetLastError());
             continue;
@@ -662,6 +663,7 @@ int hsvfilter_i420_impl(const mvfx_planar_frame *in, const mvfx_planar_frame *ou
         bits |= pidx == 0 ? (v & 7) : (v & 3);
     }
     const bool fast_ok = fast_domain_ok(*s);
+    const int g_variant = opt_hsv_variant();
     if (g_variant == 2 && !fast_ok)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvfilter: settings are outside the proven domain of the strength-reduced kernel");
     const bool use_fast = g_variant == 2 || (g_variant == 0 && fast_ok);
@@ -851,7 +853,8 @@ int hsvdetector_impl(const mvfx_frame *ins, const mvfx_frame *outs, uint32_t n,
     bool det_fast_ok = std::fabs(p.ref_hue_offset) <= 360.0f;
     for (float f : dv) det_fast_ok = det_fast_ok && std::isfinite(f);
     // from_rgb's FAST form is settings-independent, so it is always valid here; the hue test has
-    // its own domain (det_fast_ok).  g_variant: 0 auto, 1 everything literal, 2 force both fast.
+    // its own domain (det_fast_ok).  variant option: 0 auto, 1 everything literal, 2 force both fast.
+    const int g_variant = opt_hsv_variant();
     if (g_variant == 2 && !det_fast_ok)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvdetector: settings are outside the proven domain of the strength-reduced hue test");
     const int variant = g_variant == 1 ? kGeneral : (det_fast_ok ? kDetFast : kFast);
@@ -881,7 +884,7 @@ int hsvdetector_impl(const mvfx_frame *ins, const mvfx_frame *outs, uint32_t n,
         if (bx > 65535u * 16u) bx = 65535u * 16u;
         const dim3 grid((uint32_t)bx, rows < 65535u ? rows : 65535u, m);
         const uint64_t in_bytes = (uint64_t)in->stride * in->height;
-        if (g_typed && vec && variant == kDetFast && bpp == 4 && (width & 3) == 0 && in_bytes < (1ull << 32)) {
+        if (opt_typed_loads() && vec && variant == kDetFast && bpp == 4 && (width & 3) == 0 && in_bytes < (1ull << 32)) {
             const uint32_t iR = off + (ibgr ? 2 : 0), iG = off + 1, iB = off + (ibgr ? 0 : 2);
             const uint32_t word3 = (4 + iR) | ((4 + iG) << 3) | ((4 + iB) << 6) | (10u << 15); // see hsvfilter_impl
             const uint32_t o0 = obgr ? iB : iR, o2 = obgr ? iR : iB; // detect_px4_fast's selector, formed at run time
@@ -935,6 +938,7 @@ int hsvdetector_i420_impl(const mvfx_planar_frame *in, const mvfx_frame *out, co
     const float dv[6] = {s->hue_ref, s->hue_var, s->saturation_ref, s->saturation_var, s->value_ref, s->value_var};
     bool det_fast_ok = std::fabs(p.ref_hue_offset) <= 360.0f;
     for (float f : dv) det_fast_ok = det_fast_ok && std::isfinite(f);
+    const int g_variant = opt_hsv_variant();
     if (g_variant == 2 && !det_fast_ok)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvdetector: settings are outside the proven domain of the strength-reduced hue test");
     const int variant = g_variant == 1 ? kGeneral : (det_fast_ok ? kDetFast : kFast);
@@ -972,26 +976,6 @@ int mvfx_hsvdetector_transform_i420(const mvfx_planar_frame *i420_in, const mvfx
                                     const mvfx_hsvdetector_settings *settings, int32_t yuv_standard, mvfx_stream stream)
 {
     return hsvdetector_i420_impl(i420_in, out_frame, settings, yuv_standard, as_stream(stream));
-}
-
-int mvfx_hsvfilter_set_variant(int variant)
-{
-    if (variant < 0 || variant > 2)
-        return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvfilter variant must be 0 (auto), 1 (general) or 2 (fast)");
-    g_variant = variant;
-    return MVFX_OK;
-}
-
-int mvfx_hsvfilter_set_streaming(int on)
-{
-    g_streaming = on ? 1 : 0;
-    return MVFX_OK;
-}
-
-int mvfx_hsvfilter_set_typed_loads(int on)
-{
-    g_typed = on ? 1 : 0;
-    return MVFX_OK;
 }
 
 int mvfx_hsvfilter_transform_frame_ip(const mvfx_frame *frame, const mvfx_hsvfilter_settings *settings,
@@ -1089,7 +1073,7 @@ int mvfx_hsv_from_frame(const mvfx_frame *frame, float *hsv_out_device, mvfx_str
     const dim3 grid((frame->width + kBlock - 1) / kBlock, frame->height < 65535u ? frame->height : 65535u, 1);
     const uint8_t *in = static_cast<const uint8_t *>(frame->data);
     hipStream_t st = as_stream(stream);
-    const bool fast = g_variant != 1;
+    const bool fast = opt_hsv_variant() != 1;
     const FastConsts kc = make_consts(nullptr);
 #define MVFX_LH(O, B) \
     do { if (fast) hipLaunchKernelGGL((hsv_from_frame_kernel<O, B, kFast>), grid, dim3(kBlock), 0, st, in, hsv_out_device, frame->width, frame->height, (uint64_t)frame->stride, kc); \

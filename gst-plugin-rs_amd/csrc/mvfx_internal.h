@@ -47,7 +47,14 @@ inline int bytes_per_pixel(int format)
 // Basic validation shared by every packed-frame entry point.
 int check_packed_frame(const mvfx_frame *f, const char *what);
 
-// Grow-only device scratch used by the *_host entry points (one per thread).
+// Kernel options of the calling thread (mvfx_thread_set_options); the thread is the library's context.
+uint32_t thread_options();
+inline int opt_hsv_variant() { const uint32_t o = thread_options(); return (o & MVFX_OPT_HSV_LITERAL) ? 1 : ((o & MVFX_OPT_HSV_FORCE_FAST) ? 2 : 0); }
+inline bool opt_nontemporal() { return (thread_options() & MVFX_OPT_NONTEMPORAL) != 0; }
+inline bool opt_typed_loads() { return (thread_options() & MVFX_OPT_HSV_VALU_UNORM) == 0; }
+inline int opt_lut_placement() { return (int)((thread_options() & MVFX_OPT_LUT_PLACEMENT_MASK) >> MVFX_OPT_LUT_PLACEMENT_SHIFT); }
+
+// Grow-only device scratch used by the *_host entry points (one per thread and device).
 int host_scratch(size_t bytes, int slot, void **out);
 hipStream_t host_stream();
 

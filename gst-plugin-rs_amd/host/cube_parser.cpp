@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <locale.h>
 
 namespace mvfx {
 namespace {
@@ -96,7 +97,7 @@ bool iequals(std::string_view a, const char *b)
 }
 
 // Rust `str::parse::<f32>()`: [+-]? (inf|infinity|nan | digits* [. digits*] ([eE][+-]?digits+)?)
-// with at least one mantissa digit; correctly rounded (glibc strtof is, too).
+// with at least one mantissa digit; correctly rounded, locale-independent.
 bool rust_f32(std::string_view tok, float &out)
 {
     if (tok.empty() || tok.size() > 4096)
@@ -127,9 +128,13 @@ bool rust_f32(std::string_view tok, float &out)
         if (j != tok.size())
             return false;
     }
+    // strtof_l in the "C" locale: correctly rounded like Rust's dec2flt (overflow -> inf, underflow -> 0/denormal)
+    // and -- unlike plain strtof -- independent of the process locale (gst-launch and GTK applications call
+    // setlocale(LC_ALL, ""); under a comma-decimal LC_NUMERIC strtof stops at the '.').
+    static const locale_t c_locale = newlocale(LC_ALL_MASK, "C", static_cast<locale_t>(nullptr));
     const std::string z(tok);
     char *end = nullptr;
-    out = std::strtof(z.c_str(), &end);
+    out = c_locale ? strtof_l(z.c_str(), &end, c_locale) : std::strtof(z.c_str(), &end);
     return end == z.c_str() + z.size();
 }
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVFX_ABI_VERSION 1
+#define MVFX_ABI_VERSION 2
 
 /* Pixel formats on the path (GstVideoFormat names).  hsvfilter: the first ten
  * (hsvfilter/imp.rs:278-289); hsvdetector sink RGBx..BGR, src RGBA..ABGR
@@ -101,6 +101,24 @@ int mvfx_copy_device_to_device(void *dst_device, const void *src_device, size_t 
  * element layer issue the device entry points of one streaming thread in order. */
 mvfx_stream mvfx_thread_stream(void);
 
+/* ---- per-thread kernel options ----
+ * The calling thread is the library's implicit context: its private stream (mvfx_thread_stream), its staging scratch
+ * and these options are thread-local, so elements on different streaming threads never see each other's choice and
+ * an element that shares a thread with others sets its word before its call (one TLS store).  Every combination
+ * produces the same bytes; the options pick cache policy and kernel variant.  0 (default) = automatic. */
+#define MVFX_OPT_NONTEMPORAL 0x01u     /* hsvfilter: non-temporal loads/stores -- the frame leaves the GPU or is not re-read
+                                          before ~256 MB of other traffic (+3 % on a standalone stream); leave clear when
+                                          the next element reads it on the GPU (hsvfilter ! hsvdetector: +4 % for the pair) */
+#define MVFX_OPT_HSV_LITERAL 0x02u     /* hsvfilter/hsvdetector: force the literal transcription (IEEE divides, fmodf) */
+#define MVFX_OPT_HSV_FORCE_FAST 0x04u  /* force the strength-reduced kernels; MVFX_ERR_INVALID_ARGUMENT when the settings
+                                          are outside their proven domain instead of silently running the literal ones */
+#define MVFX_OPT_HSV_VALU_UNORM 0x08u  /* `byte / 255.0` on the VALU instead of typed buffer loads (texture-unit UNORM8
+                                          conversion, exact for all 256 byte values: tools/probe_unorm.hip) */
+#define MVFX_OPT_LUT_PLACEMENT_SHIFT 4 /* colorlut LUT placement: 0 auto | 1 node layout in global/L2 | 2 LDS |         */
+#define MVFX_OPT_LUT_PLACEMENT_MASK 0x70u /* 3 cell-packed global | 4 literal kernels; (placement << SHIFT) & MASK       */
+int mvfx_thread_set_options(uint32_t options);
+uint32_t mvfx_thread_options(void);
+
 /* ---- hsvfilter : video/hsv/src/hsvfilter/imp.rs ----
  * Settings == `struct Settings` hsvfilter/imp.rs:32-39 (defaults :25-29: 0,1,0,1,0). */
 typedef struct mvfx_hsvfilter_settings {
@@ -130,22 +148,6 @@ int mvfx_hsvfilter_transform_frames_ip(const mvfx_frame *frames, uint32_t n_fram
  * H2D -> kernel -> D2H on an internal stream, returns when `frame->data` holds the result. */
 int mvfx_hsvfilter_transform_frame_ip_host(const mvfx_frame *frame,
                                            const mvfx_hsvfilter_settings *settings);
-
-/* Selects the kernel variant used by the three calls above (per process, for A/B and
- * parity tests): 0 = automatic (default), 1 = force the literal transcription (IEEE divides,
- * fmodf), 2 = force the strength-reduced kernel (fails with MVFX_ERR_INVALID_ARGUMENT when
- * the settings are outside its proven domain instead of silently falling back). */
-int mvfx_hsvfilter_set_variant(int variant);
-
-/* Cache policy of the hsvfilter kernels on 16-byte aligned 4-byte frames (per process): 0 (default)
- * = normal caching, right when the next element reads the frame on the GPU (hsvfilter ! hsvdetector
- * on device memory: +4 % for the pair); 1 = non-temporal loads and stores, for frames that leave the
- * GPU or are not touched again before ~256 MB of other traffic (+3 % on a standalone stream). */
-int mvfx_hsvfilter_set_streaming(int on);
-/* 1 (default): the three `byte / 255.0` divisions of every pixel are done by typed buffer loads (texture-unit UNORM conversion,
- * exact for all 256 byte values: tools/probe_unorm.hip) instead of 9 VALU instructions; 4-byte formats, aligned frames,
- * strength-reduced settings; other frames keep the VALU kernels.  Same bytes either way. */
-int mvfx_hsvfilter_set_typed_loads(int on);
 
 /* ---- hsvdetector : video/hsv/src/hsvdetector/imp.rs ----
  * Settings == `struct Settings` hsvdetector/imp.rs:34-42 (defaults :26-31). */
@@ -210,13 +212,12 @@ int mvfx_colorlut_transform_frames(mvfx_cube_lut *lut, const mvfx_frame *in_fram
                                    mvfx_stream stream);
 int mvfx_colorlut_transform_frame_host(mvfx_cube_lut *lut, const mvfx_frame *in_frame,
                                        const mvfx_frame *out_frame);
-/* Where the LUT is read from / which kernel runs (per process, for A/B and parity tests):
- * 0 = automatic (LDS when the table fits: 3-D size <= 21, 1-D size <= 4096; else the cell-packed
+/* Where the LUT is read from / which kernel runs is a thread option (MVFX_OPT_LUT_PLACEMENT_*, see
+ * mvfx_thread_set_options): 0 = automatic (LDS when the table fits: 3-D size <= 21, 1-D size <= 4096; else the cell-packed
  * copy for 3-D size <= 65; else the node layout in global/L2), 1 = node layout in global/L2,
  * 2 = LDS (MVFX_ERR_INVALID_ARGUMENT if it does not fit), 3 = cell-packed global copy,
  * 4 = the literal-transcription kernels (also used automatically when the LUT's domain
  * scale/offset are not finite). */
-int mvfx_colorlut_set_placement(int placement);
 
 /* ---- colordetect : video/videofx/src/colordetect/imp.rs ----
  * The reference calls color_thief::get_palette(plane, format, quality, max_colors) (crate

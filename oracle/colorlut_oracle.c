@@ -3,7 +3,7 @@
  *
  * Follows /root/reference/video/colorlut/src/parser.rs (Adobe .cube parser) and
  * /root/reference/video/colorlut/src/colorlut/imp.rs:226-543 (1-D linear and 3-D trilinear
- * LUT on RGBA8 and RGBA64 LE/BE).  Build: gcc -O2 -ffp-contract=off.
+ * LUT on RGBA8 and RGBA64 LE/BE).  Build: gcc -O3 -ffp-contract=off.
  *
  * Rust semantics reproduced:
  *   str::lines()            -> split on '\n', a trailing '\r' is stripped
@@ -17,6 +17,7 @@
 #include "oracle.h"
 
 #include <errno.h>
+#include <locale.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -102,7 +103,11 @@ static int rust_parse_f32(const char *s, size_t n, float *out)
     memcpy(buf, s, n);
     buf[n] = 0;
     char *endp = NULL;
-    float v = strtof(buf, &endp); /* glibc strtof is correctly rounded, like dec2flt */
+    /* glibc strtof is correctly rounded, like dec2flt; the _l form in the "C" locale keeps it independent of the
+     * process LC_NUMERIC (Rust's str::parse is locale-free) */
+    static locale_t c_locale;
+    if (!c_locale) c_locale = newlocale(LC_ALL_MASK, "C", (locale_t)0);
+    float v = c_locale ? strtof_l(buf, &endp, c_locale) : strtof(buf, &endp);
     if (endp != buf + n)
         return -1;
     *out = v;

@@ -2,7 +2,7 @@
  * oracle/hsv_oracle.c -- CPU restatement of video/hsv (TEST INFRASTRUCTURE ONLY).
  *
  * Follows /root/reference/video/hsv/src/hsvutils.rs, hsvfilter/imp.rs and
- * hsvdetector/imp.rs statement by statement.  Build: gcc -O2 -ffp-contract=off.
+ * hsvdetector/imp.rs statement by statement.  Build: gcc -O3 -ffp-contract=off.
  *
  * Rust semantics reproduced here:
  *   f32 `%`            -> fmodf (exact, sign of dividend)

@@ -8,7 +8,7 @@
  * The reference (sdroege/gst-plugin-rs) is Rust and cannot be built in this image
  * (no rustc/cargo), so this is a "port" oracle: plain C that follows the reference
  * loops statement by statement.  Each function cites the file:line it restates.
- * Built with `gcc -O2 -ffp-contract=off` (no fast-math) so that every f32 operation
+ * Built with `gcc -O3 -ffp-contract=off` (no fast-math) so that every f32 operation
  * rounds exactly once, as rustc emits it.
  *
  * Pinning status (see DESIGN.md "Oracle"):

@@ -49,7 +49,7 @@ def test_format_enum_matches_oracle_and_header(vfx):
 
 def test_status_strings(vfx):
     lib = vfx.lib()
-    assert lib.mvfx_abi_version() == 1
+    assert lib.mvfx_abi_version() == 2
     assert lib.mvfx_status_string(0) == b"ok"
     for code in range(-10, 0):
         assert lib.mvfx_status_string(code) not in (b"ok", b"unknown status")
@@ -87,4 +87,27 @@ def test_argument_validation_needs_no_device(vfx):
     a = np.zeros(64, np.uint8)
     f = vfx.make_frame(a.ctypes.data, 4, 4, 16, "I420")
     assert lib.mvfx_hsvfilter_transform_frame_ip_host(ctypes.byref(f), ctypes.byref(s)) == vfx.ERR_UNSUPPORTED_FORMAT
-    assert lib.mvfx_hsvfilter_set_variant(7) == vfx.ERR_INVALID_ARGUMENT
+    assert lib.mvfx_thread_set_options(0x1000) == vfx.ERR_INVALID_ARGUMENT                       # unknown bit
+    assert lib.mvfx_thread_set_options(vfx.OPT_HSV_LITERAL | vfx.OPT_HSV_FORCE_FAST) == vfx.ERR_INVALID_ARGUMENT
+    assert lib.mvfx_thread_set_options(5 << vfx.OPT_LUT_PLACEMENT_SHIFT) == vfx.ERR_INVALID_ARGUMENT  # placement 0..4
+    assert lib.mvfx_thread_options() == 0
+
+
+def test_kernel_options_are_thread_local(vfx):
+    """The calling thread is the context: an element on another streaming thread never sees this thread's word."""
+    import threading
+    lib = vfx.lib()
+    seen = {}
+    with vfx.options(nontemporal=True, typed=False, placement=3):
+        assert lib.mvfx_thread_options() == (vfx.OPT_NONTEMPORAL | vfx.OPT_HSV_VALU_UNORM | (3 << vfx.OPT_LUT_PLACEMENT_SHIFT))
+
+        def other():
+            seen["before"] = lib.mvfx_thread_options()
+            lib.mvfx_thread_set_options(vfx.OPT_HSV_LITERAL)
+            seen["after"] = lib.mvfx_thread_options()
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert seen == {"before": 0, "after": vfx.OPT_HSV_LITERAL}
+        assert lib.mvfx_thread_options() & vfx.OPT_NONTEMPORAL
+    assert lib.mvfx_thread_options() == 0

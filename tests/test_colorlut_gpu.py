@@ -44,7 +44,7 @@ def test_colorlut_random_frames(gpu, luts, name, fmt, placement):
     dev, o = luts[name]
     if placement == 3 and not dev.is_3d:
         pytest.skip("cell-packed layout is 3-D only")
-    gpu.check(gpu.lib().mvfx_colorlut_set_placement(placement))
+    gpu.check(gpu.lib().mvfx_thread_set_options(gpu.options(placement=placement).word))
     try:
         for (w, h, pad) in ((257, 9, 16), (64, 8, 0), (1, 1, 0), (1023, 3, 0)):
             bpp = 8 if fmt != "RGBA" else 4
@@ -57,7 +57,7 @@ def test_colorlut_random_frames(gpu, luts, name, fmt, placement):
             bad = np.count_nonzero(got != exp)
             assert bad == 0, f"{name} {fmt} {w}x{h}: {bad} bytes differ"
     finally:
-        gpu.lib().mvfx_colorlut_set_placement(0)
+        gpu.lib().mvfx_thread_set_options(gpu.options(placement=0).word)
 
 
 @pytest.mark.parametrize("name", ["analytic33", "analytic21", "identity17", "curve1d_256", "nan_nodes", "nan_domain"])
@@ -146,8 +146,8 @@ def test_colorlut_errors(gpu, luts):
     f2 = gpu.make_frame(a.ctypes.data, 4, 2, 16, "RGBA")
     assert gpu.lib().mvfx_colorlut_transform_frame_host(dev.h, ctypes.byref(fi), ctypes.byref(f2)) == gpu.ERR_NOT_NEGOTIATED
     big, _o = luts["analytic33"]
-    gpu.lib().mvfx_colorlut_set_placement(2)
+    gpu.lib().mvfx_thread_set_options(gpu.options(placement=2).word)
     try:
         assert gpu.lib().mvfx_colorlut_transform_frame_host(big.h, ctypes.byref(fi), ctypes.byref(fo)) == gpu.ERR_INVALID_ARGUMENT
     finally:
-        gpu.lib().mvfx_colorlut_set_placement(0)
+        gpu.lib().mvfx_thread_set_options(gpu.options(placement=0).word)

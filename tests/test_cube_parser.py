@@ -2,6 +2,7 @@
 C ABI) and the oracle's parser, both against the reference's own known-answer tests
 (video/colorlut/src/parser.rs:377-474) and against each other on edge syntax."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -213,3 +214,32 @@ def test_parse_file_errors(vfx, tmp_path):
     with pytest.raises(vfx.MvfxError) as e:
         vfx.CubeLut(path=str(worse))
     assert e.value.status == vfx.ERR_PARSE and "worse.cube" in e.value.message
+
+
+def test_float_parsing_is_locale_independent(vfx):
+    """Rust's str::parse::<f32> knows no locale; gst-launch / GTK apps call setlocale(LC_ALL, "").  Neither parser may
+    bind plain strtof (which follows LC_NUMERIC and stops at '.' under a comma-decimal locale): both use strtof_l with
+    a "C" locale object.  Where a comma-decimal locale is installed the parse is also exercised under it."""
+    import locale
+    import subprocess
+    for so in (vfx.LIB_PATH, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "liboracle.so")):
+        syms = subprocess.run(["nm", "-D", "--undefined-only", so], stdout=subprocess.PIPE, text=True, check=True).stdout
+        names = {line.split()[-1].split("@")[0] for line in syms.splitlines() if line.strip()}
+        assert "strtof_l" in names and "newlocale" in names, so
+    text = "LUT_1D_SIZE 2\nDOMAIN_MAX 1.5 1.5 1.5\n0.0 0.25 0.5\n1.0 0.75 1e-1\n"
+    saved = locale.setlocale(locale.LC_NUMERIC)
+    switched = False
+    for cand in ("de_DE.UTF-8", "fr_FR.UTF-8", "ru_RU.UTF-8", "de_DE", "fr_FR"):
+        try:
+            locale.setlocale(locale.LC_NUMERIC, cand)
+            switched = True
+            break
+        except locale.Error:
+            continue
+    try:
+        lut = vfx.CubeLut(text)
+        assert lut.size == 2 and not lut.is_3d
+        assert [lut.table(c)[1] for c in range(3)] == [1.0, 0.75, np.float32(0.1)]
+    finally:
+        locale.setlocale(locale.LC_NUMERIC, saved)
+    print("comma-decimal locale exercised:", switched)

@@ -35,7 +35,7 @@ GENERAL_ONLY_SETTINGS = [               # outside the strength-reduced kernel's 
 
 def _device_filter(vfx, host_frame, w, h, stride, fmt, settings, variant=0, batch=False):
     buf = vfx.DeviceBuffer(host_frame.nbytes).upload(host_frame)
-    vfx.check(vfx.lib().mvfx_hsvfilter_set_variant(variant))
+    vfx.check(vfx.lib().mvfx_thread_set_options(vfx.options(variant=variant).word))
     try:
         s = vfx.HsvFilterSettings(*settings)
         if batch:
@@ -44,7 +44,7 @@ def _device_filter(vfx, host_frame, w, h, stride, fmt, settings, variant=0, batc
             vfx.hsvfilter_device(buf.ptr, w, h, stride, fmt, s)
         vfx.check(vfx.lib().mvfx_stream_synchronize(None))
     finally:
-        vfx.lib().mvfx_hsvfilter_set_variant(0)
+        vfx.lib().mvfx_thread_set_options(vfx.options(variant=0).word)
     return buf.download().reshape(host_frame.shape)
 
 
@@ -73,13 +73,13 @@ def test_hsvfilter_exhaustive_general_domain(gpu, exhaustive, settings):
     assert np.array_equal(got, expect)
     # and the fast kernel must refuse rather than silently produce something
     buf = gpu.DeviceBuffer(16)
-    gpu.lib().mvfx_hsvfilter_set_variant(2)
+    gpu.lib().mvfx_thread_set_options(gpu.options(variant=2).word)
     try:
         f = gpu.make_frame(buf.ptr, 2, 2, 8, "RGBA")
         rc = gpu.lib().mvfx_hsvfilter_transform_frame_ip(ctypes.byref(f), ctypes.byref(gpu.HsvFilterSettings(*settings)), None)
         assert rc == gpu.ERR_INVALID_ARGUMENT
     finally:
-        gpu.lib().mvfx_hsvfilter_set_variant(0)
+        gpu.lib().mvfx_thread_set_options(gpu.options(variant=0).word)
 
 
 @pytest.mark.parametrize("variant", [2, 1], ids=["fast", "general"])
@@ -88,13 +88,13 @@ def test_from_rgb_f32_exhaustive(gpu, exhaustive, variant):
     vfx = gpu
     src = vfx.DeviceBuffer(exhaustive.nbytes).upload(exhaustive)
     out = vfx.DeviceBuffer((1 << 24) * 3 * 4)
-    vfx.lib().mvfx_hsvfilter_set_variant(variant)
+    vfx.lib().mvfx_thread_set_options(vfx.options(variant=variant).word)
     try:
         f = vfx.make_frame(src.ptr, 4096, 4096, 4096 * 4, "RGBx")
         vfx.check(vfx.lib().mvfx_hsv_from_frame(ctypes.byref(f), ctypes.c_void_p(out.ptr), None))
         vfx.check(vfx.lib().mvfx_stream_synchronize(None))
     finally:
-        vfx.lib().mvfx_hsvfilter_set_variant(0)
+        vfx.lib().mvfx_thread_set_options(vfx.options(variant=0).word)
     got = out.download(dtype=np.float32).reshape(-1, 3)
     expect = orc.hsv_from_rgbx(exhaustive)
     diff = got.view(np.uint32) != expect.view(np.uint32)
@@ -188,16 +188,16 @@ def test_hsvfilter_batch_matches_single(gpu):
 
 @pytest.mark.parametrize("w,h", [(3840, 2160), (1021, 7), (8, 1), (2047, 3)])
 def test_hsvfilter_streaming_policy_same_bytes(gpu, w, h):
-    """mvfx_hsvfilter_set_streaming(1) (non-temporal loads/stores, 2 pixel groups per lane) changes no byte;
+    """MVFX_OPT_NONTEMPORAL (non-temporal loads/stores, 2 pixel groups per lane) changes no byte;
     sizes with partial tiles / 1-3 pixel tails included."""
     frame = frames.random_frame(0x5EED0400 + w, w, h)
     expect = frame.copy()
     assert orc.hsvfilter(expect, w, w * 4, "RGBA", BENCH_SETTINGS) == 0
     try:
-        gpu.check(gpu.lib().mvfx_hsvfilter_set_streaming(1))
+        gpu.check(gpu.lib().mvfx_thread_set_options(gpu.options(nontemporal=bool(1)).word))
         got = _device_filter(gpu, frame, w, h, w * 4, "RGBA", BENCH_SETTINGS, 0)
     finally:
-        gpu.check(gpu.lib().mvfx_hsvfilter_set_streaming(0))
+        gpu.check(gpu.lib().mvfx_thread_set_options(gpu.options(nontemporal=bool(0)).word))
     assert np.array_equal(got, expect)
 
 
@@ -283,13 +283,13 @@ def test_hsvdetector_exhaustive(gpu, exhaustive, settings, variant):
     dst = gpu.DeviceBuffer(exhaustive.nbytes)
     fi = gpu.make_frame(src.ptr, 4096, 4096, 4096 * 4, "RGBx")
     fo = gpu.make_frame(dst.ptr, 4096, 4096, 4096 * 4, "RGBA")
-    gpu.lib().mvfx_hsvfilter_set_variant(variant)
+    gpu.lib().mvfx_thread_set_options(gpu.options(variant=variant).word)
     try:
         gpu.check(gpu.lib().mvfx_hsvdetector_transform_frame(ctypes.byref(fi), ctypes.byref(fo),
                                                              ctypes.byref(gpu.HsvDetectorSettings(*settings)), None))
         gpu.check(gpu.lib().mvfx_stream_synchronize(None))
     finally:
-        gpu.lib().mvfx_hsvfilter_set_variant(0)
+        gpu.lib().mvfx_thread_set_options(gpu.options(variant=0).word)
     got = dst.download().reshape(exhaustive.shape)
     assert np.array_equal(got, expect)
     if not np.isnan(settings[0]) and settings[1] > 0 and settings[3] > 0:
@@ -365,7 +365,7 @@ def test_typed_loads_and_valu_paths_agree_on_all_triples(gpu):
                 want = ex.copy()
                 assert orc.hsvfilter(want, 4096, 4096 * 4, fmt, st) == 0
                 for typed in (1, 0):
-                    gpu.check(gpu.lib().mvfx_hsvfilter_set_typed_loads(typed))
+                    gpu.check(gpu.lib().mvfx_thread_set_options(gpu.options(typed=bool(typed)).word))
                     buf = gpu.DeviceBuffer(ex.nbytes).upload(ex)
                     f = gpu.make_frame(buf.ptr, 4096, 4096, 4096 * 4, fmt)
                     s = gpu.HsvFilterSettings(*st)
@@ -374,7 +374,7 @@ def test_typed_loads_and_valu_paths_agree_on_all_triples(gpu):
                     got = buf.download().reshape(want.shape)
                     assert np.array_equal(got, want), (fmt, st, typed, int(np.count_nonzero(got != want)))
     finally:
-        gpu.check(gpu.lib().mvfx_hsvfilter_set_typed_loads(1))
+        gpu.check(gpu.lib().mvfx_thread_set_options(gpu.options(typed=bool(1)).word))
 
 
 def test_typed_loads_hsvdetector_all_triples(gpu):
@@ -386,7 +386,7 @@ def test_typed_loads_hsvdetector_all_triples(gpu):
             want = np.empty_like(ex)
             assert orc.hsvdetector(ex, 4096 * 4, in_fmt, want, 4096 * 4, out_fmt, 4096, st) == 0
             for typed in (1, 0):
-                gpu.check(gpu.lib().mvfx_hsvfilter_set_typed_loads(typed))
+                gpu.check(gpu.lib().mvfx_thread_set_options(gpu.options(typed=bool(typed)).word))
                 src = gpu.DeviceBuffer(ex.nbytes).upload(ex)
                 dst = gpu.DeviceBuffer(ex.nbytes)
                 fi = gpu.make_frame(src.ptr, 4096, 4096, 4096 * 4, in_fmt)
@@ -397,4 +397,4 @@ def test_typed_loads_hsvdetector_all_triples(gpu):
                 got = dst.download().reshape(want.shape)
                 assert np.array_equal(got, want), (in_fmt, out_fmt, typed, int(np.count_nonzero(got != want)))
     finally:
-        gpu.check(gpu.lib().mvfx_hsvfilter_set_typed_loads(1))
+        gpu.check(gpu.lib().mvfx_thread_set_options(gpu.options(typed=bool(1)).word))

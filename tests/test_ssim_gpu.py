@@ -115,3 +115,38 @@ def test_4k_pair_identical_and_perturbed(gpu):
     b[500:1500, 2000:8000] ^= 0x40
     d2 = gpu.ssim_distance_host(a.reshape(-1), b.reshape(-1), w, h, w * 4, w * 4, "RGBA")
     assert 0.0 < d1 < d2
+
+
+def test_8k_pair_matches_f64_oracle_whole_and_banded(gpu):
+    """BASELINE config 5 shape: 7680x4320 RGBA pair, `hash-algo=dssim` (hashed_image.rs:49-59,72-75).
+    Whole-frame distance against the f64 oracle to 1e-9, and the 3-band partial path (what
+    distributed.ssim_sharded runs per rank) reduced by hand equals the whole-frame result."""
+    w, h = 7680, 4320
+    a, b = _pair(0xD558, w, h, 4, 9, every=101)
+    b[1000:1400, 4000:9000] ^= 0x20  # a structured region besides the sparse +9 perturbation
+    da = gpu.DeviceBuffer(a.nbytes).upload(a)
+    db = gpu.DeviceBuffer(b.nbytes).upload(b)
+    fa, fb = gpu.make_frame(da.ptr, w, h, w * 4, "RGBA"), gpu.make_frame(db.ptr, w, h, w * 4, "RGBA")
+    d = ctypes.c_double()
+    gpu.check(gpu.lib().mvfx_ssim_distance(ctypes.byref(fa), ctypes.byref(fb), ctypes.byref(d), None))
+    rc, want, _ = orc.ssim_distance(a, b, w, h, w * 4, w * 4, "RGBA")
+    assert rc == 0 and want > 0.0
+    assert d.value == pytest.approx(want, rel=1e-9, abs=1e-12)
+    # identical 8K frames: exactly 0.0 (tests/videocompare.rs:141-182 property at the config-5 size)
+    gpu.check(gpu.lib().mvfx_ssim_distance(ctypes.byref(fa), ctypes.byref(fa), ctypes.byref(d), None))
+    assert d.value == 0.0
+    gpu.check(gpu.lib().mvfx_ssim_distance(ctypes.byref(fa), ctypes.byref(fb), ctypes.byref(d), None))
+    bands = ((0, 1440), (1440, 2896), (2896, h))  # 16-row aligned: every pyramid level partitions exactly
+    firsts = [gpu.ssim_partial_sums(fa, fb, r0, r1) for r0, r1 in bands]
+    n = firsts[0][2]
+    tot_s = [sum(f[0][s] for f in firsts) for s in range(5)]
+    tot_c = [sum(f[1][s] for f in firsts) for s in range(5)]
+    mean = [tot_s[s] / tot_c[s] if tot_c[s] else 0.0 for s in range(5)]
+    dev = [0.0] * 5
+    for r0, r1 in bands:
+        gpu.ssim_partial_sums(fa, fb, r0, r1)
+        part = gpu.ssim_partial_deviation(mean)
+        dev = [dev[s] + part[s] for s in range(5)]
+    mad = [dev[s] / tot_c[s] if tot_c[s] else 0.0 for s in range(5)]
+    assert gpu.ssim_combine(mean, mad, n) == pytest.approx(want, rel=1e-9, abs=1e-12)
+    assert gpu.ssim_combine(mean, mad, n) == pytest.approx(d.value, rel=1e-11, abs=1e-13)

@@ -21,7 +21,7 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 vfx.check(lib.mvfx_set_device(0))
 if os.environ.get("MVFX_TYPED_LOADS"):
-    vfx.check(lib.mvfx_hsvfilter_set_typed_loads(int(os.environ["MVFX_TYPED_LOADS"])))
+    vfx.check(lib.mvfx_thread_set_options(vfx.options(typed=bool(int(os.environ["MVFX_TYPED_LOADS"])).word)))
 stream = torch.cuda.current_stream(dev)
 sptr = ctypes.c_void_p(stream.cuda_stream)
 PEAK = 8000.0
@@ -137,10 +137,10 @@ def main():
                 fi = [vfx.make_frame(src[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
                 fo = [vfx.make_frame(dst[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
                 for placement in ((0, 1) if size <= 21 else (0,)):
-                    vfx.check(lib.mvfx_colorlut_set_placement(placement))
+                    vfx.check(lib.mvfx_thread_set_options(vfx.options(placement=placement).word))
                     ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fi[i % POOL]), ctypes.byref(fo[i % POOL]), sptr)), iters=300)
                     report(f"colorlut 3D {size}^3 RGBA 4K {data} placement={'auto' if placement == 0 else 'global'}", ms, 2 * NB, 1)
-                vfx.check(lib.mvfx_colorlut_set_placement(0))
+                vfx.check(lib.mvfx_thread_set_options(vfx.options(placement=0).word))
         lut = vfx.CubeLut(cubes.analytic_3d(33))
         src = natural_like_gpu(POOL, W, H, 11)
         dst = torch.empty_like(src)
