@@ -1,33 +1,41 @@
 #!/usr/bin/env python3
 """bench.py -- hsvfilter on 3840x2160 RGBA frames, device-resident, on N MI355X of one node.
 
-    python bench.py --gpus 1 --steps 2000 --warmup 200
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8 --steps 20 --warmup 5          # spawns 8 worker processes itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path (mvfx_hsvfilter_transform_frames_ip, in place) over one
-batch of `--batch` synthetic 4K RGBA frames (one frame from each of `--batch` independent
-streams) in ONE launch.  Frames are independent, so ranks shard streams with no data-path
-collective ("weak" scaling: every GPU gets its own `--batch` streams); the only collectives
-are the timing barrier and the max-over-ranks reduction.
+A "step" = one pass of the hot path over one batch of `--batch` synthetic 4K RGBA frames (one frame from each of
+`--batch` independent streams), in place.  Two launch models are measured in the same run:
 
-Before the W warmup steps the same step runs untimed for --settle-seconds (0.6 s): the MI355X
-clock governor starts every process in a low-power state and needs ~0.2 s of sustained load to
-reach its steady clocks (305 us/launch for the first 100 launches, 199 us afterwards); a video
-stream runs in the steady state, so that is what the K timed steps measure.
+  * "batch"   -- mvfx_hsvfilter_transform_frames_ip: the `--batch` frames in ONE launch (blockIdx.z = stream);
+  * "streams" -- what the GStreamer element does: `--batch` host threads (one streaming thread per stream), each
+                 with its own HIP stream, each calling the SINGLE-frame mvfx_hsvfilter_transform_frame_ip once per
+                 buffer (hsvfilter/imp.rs:322-326), no synchronisation between launches (libmvfxbench.so).
 
-Inputs are resident in HBM before the timed region.  The frame pool is much larger than the
-256 MiB Infinity Cache and every step touches a different batch, so reads come from HBM.
+`value` is the model named by `config.launch_model` (--launch-model, default "batch"); the other model's number
+travels in `config.other_launch_model`.  Frames are independent, so ranks shard streams with no data-path
+collective ("weak" scaling: every GPU gets its own `--batch` streams); the only collectives are the timing barrier,
+the max-over-ranks reduction and the gather of the per-rank rates.
 
-The JSON line carries `roofline` (algorithmic bytes per launch / average launch duration
-measured with HIP events on the launch stream) and, at N=1, `cpu_baseline` (the oracle's
-single-threaded loop -- what the reference does on its one streaming thread -- on a bounded
-sample of the same frames).
+Before the W warmup steps the same step runs untimed for --settle-seconds (0.6 s): the MI355X clock governor starts
+every process in a low-power state and needs ~0.2 s of sustained load to reach its steady clocks.  Settle and warm-up
+run on scratch batches; the K timed steps start on frames NO kernel has touched (fresh uniform-random bytes), so the
+`data` field is literally true for the first `resident_batches` steps (K beyond that re-filters filtered frames).
+
+Inputs are resident in HBM before the timed region.  The frame pool is much larger than the 256 MiB Infinity Cache
+and every step touches a different batch, so reads come from HBM.
+
+The JSON line carries `roofline` (algorithmic bytes per launch / average launch duration from HIP events on the
+launch stream, plus the d2d-copy ceiling measured in the same run) and, at N=1, `cpu_baseline` (the oracle's loop on
+one host thread -- what the reference does on its one streaming thread -- and on nproc threads, bounded sample).
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -38,6 +46,114 @@ W4K, H4K = 3840, 2160
 FRAME_BYTES = W4K * H4K * 4
 SETTINGS = (90.0, 1.25, -0.05, 0.9, 0.02)  # SURVEY.md 8d hsvfilter settings
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+# ------------------------------------------------------------------------------------------------ launching
+
+def spawn_workers(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N worker processes (one per GPU) BEFORE anything in this
+    process touches the GPU.  The parent never initialises HIP and never exec()s; it relays rank 0's JSON line and
+    exits non-zero if any worker failed."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                    "MVFX_BENCH_WORKER": "1"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write(f"bench.py: worker(s) failed (rank, exit code): {bad}\n")
+        sys.exit(1)
+
+
+class Worker:
+    """One rank: device, torch.distributed over RCCL when WORLD_SIZE > 1, the C ABI."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        import _pkg
+        self.torch, self.dist = torch, dist
+        self.vfx = _pkg.vfx
+        self.lib = self.vfx.lib()  # raises if libmi355vfx.so is missing: no fallback
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus and self.rank == 0:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}; using WORLD_SIZE\n")
+        if not torch.cuda.is_available():
+            sys.stderr.write("bench.py: no GPU visible; the HIP path has no CPU fallback\n")
+            sys.exit(3)
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.rccl_ranks = 1
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl", device_id=self.dev)  # "nccl" IS RCCL on ROCm
+            one = torch.ones(1, dtype=torch.int32, device=self.dev)
+            dist.all_reduce(one)  # an actual collective: how many ranks RCCL sees
+            self.rccl_ranks = int(one[0])
+        self.vfx.check(self.lib.mvfx_set_device(self.local_rank))
+        self.stream = torch.cuda.current_stream(self.dev)
+        self.sptr = ctypes.c_void_p(self.stream.cuda_stream)
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.dev)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_over_ranks(self, *vals):
+        if self.world == 1:
+            return vals
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return tuple(float(x) for x in t)
+
+    def gather(self, val):
+        if self.world == 1:
+            return [val]
+        t = self.torch.tensor([val], dtype=self.torch.float64, device=self.dev)
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(x[0]) for x in out]
+
+    def timed(self, step, steps, first_index=0, events=False):
+        """barrier + synchronize on both sides; returns (wall seconds, average ms between the two HIP events)."""
+        torch = self.torch
+        self.sync()
+        self.barrier()
+        self.sync()
+        ev0 = ev1 = None
+        if events:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        if events:
+            ev0.record(self.stream)
+        for i in range(steps):
+            step(first_index + i)
+        if events:
+            ev1.record(self.stream)
+        self.sync()
+        self.barrier()
+        self.sync()
+        elapsed = time.perf_counter() - t0
+        return elapsed, (ev0.elapsed_time(ev1) / max(steps, 1) if events else None)
+
+    def finish(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
 
 
 def settle(step, seconds, sync, fixed_steps=None):
@@ -59,46 +175,87 @@ def settle(step, seconds, sync, fixed_steps=None):
     return n
 
 
+def measured_copy_ceiling(w):
+    """Device-to-device copy of 1 GiB (2 GiB of HBM traffic) with torch, same run, same clocks: the practical HBM ceiling
+    SURVEY 8d asks to quote beside the 8 TB/s spec."""
+    torch = w.torch
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=w.dev)
+    b = torch.empty(n, dtype=torch.uint8, device=w.dev)
+    a.random_(0, 256)
+    for _ in range(5):
+        b.copy_(a)
+    w.sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    ev0.record(w.stream)
+    for _ in range(reps):
+        b.copy_(a)
+    ev1.record(w.stream)
+    w.sync()
+    return 2.0 * n * reps / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+
 def cpu_baseline(seconds: float):
-    """Oracle (port of hsvfilter/imp.rs:76-120) on one host core, bounded sample."""
+    """Oracle (port of hsvfilter/imp.rs:76-120, gcc -O3 -ffp-contract=off like profile.release) on the GPU box's host cores:
+    one thread -- what the reference does, its transform_frame_ip runs on ONE streaming thread per element -- and
+    nproc threads each filtering its own stream.  8 distinct frames rotate so the 33 MB input is not cache
+    resident.  Bounded: ~seconds per leg."""
+    import threading
     import numpy as np
     from tests import frames
     from tests import oracle_binding as orc
-    frame = frames.random_frame(0x5EED0001, W4K, H4K)
-    work = frame.copy()
-    orc.hsvfilter(work, W4K, W4K * 4, "RGBA", SETTINGS)  # warm
-    n = 0
-    dt = 0.0
-    while dt < seconds:
-        np.copyto(work, frame)  # fresh input each time; the copy is not timed
-        t1 = time.perf_counter()
-        orc.hsvfilter(work, W4K, W4K * 4, "RGBA", SETTINGS)
-        dt += time.perf_counter() - t1
-        n += 1
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} frames of 3840x2160 RGBA (uniform random, seed 0x5EED0001), "
-                      f"oracle/hsv_oracle.c gcc -O2 -ffp-contract=off, 1 thread, {dt:.1f} s"}
+    nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    distinct = 8
+    src = [frames.random_frame(0x5EED0001 + k, W4K, H4K) for k in range(distinct)]
 
+    def run(n_threads, budget):
+        counts = [0] * n_threads
+        spans = [0.0] * n_threads
+        go = threading.Event()
+
+        def body(t):
+            work = [s.copy() for s in src[:2]]  # this thread's private pair of destination buffers
+            orc.hsvfilter(work[0], W4K, W4K * 4, "RGBA", SETTINGS)  # warm (page faults, code)
+            go.wait()
+            n, dt = 0, 0.0
+            while dt < budget:
+                buf = work[n & 1]
+                np.copyto(buf, src[(t + n) % distinct])  # fresh input each time; the copy is not timed
+                t1 = time.perf_counter()
+                orc.hsvfilter(buf, W4K, W4K * 4, "RGBA", SETTINGS)  # ctypes releases the GIL for the call
+                dt += time.perf_counter() - t1
+                n += 1
+            counts[t], spans[t] = n, dt
+
+        ths = [threading.Thread(target=body, args=(t,)) for t in range(n_threads)]
+        for th in ths:
+            th.start()
+        go.set()
+        for th in ths:
+            th.join()
+        return sum(c / s for c, s in zip(counts, spans)), sum(counts), max(spans)
+
+    one_fps, one_n, one_dt = run(1, seconds)
+    all_fps, all_n, all_dt = run(nproc, seconds) if nproc > 1 else (one_fps, one_n, one_dt)
+    return {"value": one_fps, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{one_n} frames of 3840x2160 RGBA (uniform random, 8 distinct frames rotating, seeds 0x5EED0001..8), "
+                      f"oracle/hsv_oracle.c gcc -O3 -ffp-contract=off, 1 thread, {one_dt:.1f} s",
+            "all_cores": {"value": all_fps, "unit": "frames/s", "cores": nproc, "nproc": nproc,
+                          "sample": f"{all_n} frames, {nproc} threads x own stream of frames, {all_dt:.1f} s per thread"}}
+
+
+# ------------------------------------------------------------------------------------------------ config 5
 
 def videocompare_main(args):
     """BASELINE config 5: blockhash distance of 7680x4320 RGBA frame pairs.  Inputs are pre-sharded:
     rank r holds block-row band r of both frames; one all-reduce of 2x64 sums."""
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    import _pkg
-    vfx = _pkg.vfx
-    lib = vfx.lib()
+    w = Worker(args)
+    torch, vfx, lib, dev, sptr, stream = w.torch, w.vfx, w.lib, w.dev, w.sptr, w.stream
     from gst_plugin_rs_amd import distributed as D
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
-    vfx.check(lib.mvfx_set_device(local_rank))
+    rank, world = w.rank, w.world
     W, H = 7680, 4320
     r0, r1 = D.band_rows(H, rank, world)
     rows = r1 - r0
@@ -107,13 +264,11 @@ def videocompare_main(args):
     gen.manual_seed(0x5EED0001)  # same seed on every rank: band r of the same virtual frames
     pairs = torch.randint(0, 256, (pool, 2, rows * W * 4), dtype=torch.uint8, device=dev, generator=gen)
     sums = torch.zeros((2, 64), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    sptr = ctypes.c_void_p(stream.cuda_stream)
 
-    def bits(s, w, h):
+    def bits(s, w_, h_):
         arr = (ctypes.c_uint32 * 64)(*[int(x) for x in s])
         out = ctypes.c_uint64()
-        vfx.check(lib.mvfx_blockhash_bits(arr, w, h, ctypes.byref(out)))
+        vfx.check(lib.mvfx_blockhash_bits(arr, w_, h_, ctypes.byref(out)))
         return out.value
 
     if args.hash_algo == "dssim":
@@ -175,73 +330,61 @@ def videocompare_main(args):
                 return sums
             return D.videocompare_sharded(partial, 2, W, H, bits, dev, all_pads=True)
 
-    settle(step, args.settle_seconds, lambda: torch.cuda.synchronize(dev), fixed_steps=400 if args.hash_algo == "blockhash" else 20)  # all-reduce inside the step
+    settle(step, args.settle_seconds, w.sync, fixed_steps=400 if args.hash_algo == "blockhash" else 20)  # all-reduce inside the step
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        d = step(i)
-    if args.hash_algo == "blockhash" and world == 1 and args.pairs_in_flight > 1:
-        for slot in range(len(ring_busy)):  # drain the pairs still in flight (inside the timed region)
-            if ring_busy[slot]:
-                finish(slot)
-        d = [last[0]]
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    result = [None]
+
+    def timed_step(i):
+        result[0] = step(i)
+
+    def whole(i):  # the K steps + the drain of the pairs still in flight, all inside the timed region
+        for k in range(args.steps):
+            timed_step(k)
+        if args.hash_algo == "blockhash" and world == 1 and args.pairs_in_flight > 1:
+            for slot in range(len(ring_busy)):
+                if ring_busy[slot]:
+                    finish(slot)
+            result[0] = [last[0]]
+
+    elapsed, _ = w.timed(whole, 1)
+    (elapsed,) = w.max_over_ranks(elapsed)
+    d = result[0]
+    per_rank = w.gather(args.steps / elapsed)
     bytes_per_pair = 2 * W * H * 4
     achieved = bytes_per_pair * args.steps / elapsed / 1e9
     if rank == 0:
         print(json.dumps({
             "metric": "videocompare_8k_rgba_pairs_per_sec", "value": args.steps / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32" if args.hash_algo == "blockhash" else "f64",
             "data": "synthetic uniform-random u8 RGBA, device-resident, rows pre-sharded by block-row band",
             "config": {"workload": "videocompare blockhash 7680x4320 RGBA pair, band-sharded + all-reduce(2x64 u32)" if args.hash_algo == "blockhash"
                        else "videocompare dssim (multi-scale SSIM, f64) 7680x4320 RGBA pair, row bands + 2 all-reduces of 10 f64",
                        "parallelism": f"{world} row bands, RCCL all-reduce per pair" if world > 1 else
-                                      f"one GPU, whole frames, {args.pairs_in_flight} pair(s) in flight", "last_distance": d[0]},
+                                      f"one GPU, whole frames, {args.pairs_in_flight} pair(s) in flight", "last_distance": d[0],
+                       "rccl_ranks": w.rccl_ranks, "per_rank_pairs_per_sec": per_rank},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
                          "note": "end-to-end per pair incl. all-reduce (N > 1), D2H of the block sums, the synchronisation and host bit derivation"}}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    w.finish()
 
+
+# ------------------------------------------------------------------------------------------------ configs 2-4
 
 def config_main(args):
     """BASELINE configs 2-4 as device-resident per-GPU stream workloads (no data-path collective)."""
-    import torch
-    import torch.distributed as dist
-    import _pkg
     from tests import cubes
-    vfx = _pkg.vfx
-    lib = vfx.lib()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
-    vfx.check(lib.mvfx_set_device(local_rank))
-    stream = torch.cuda.current_stream(dev)
-    sptr = ctypes.c_void_p(stream.cuda_stream)
+    w = Worker(args)
+    torch, vfx, lib, dev, sptr = w.torch, w.vfx, w.lib, w.dev, w.sptr
+    rank, world = w.rank, w.world
     gen = torch.Generator(device=dev)
     gen.manual_seed(0x5EED0100 + rank)
 
     def rnd(n, nbytes):
         return torch.randint(0, 256, (n, nbytes), dtype=torch.uint8, device=dev, generator=gen)
 
+    data = "synthetic uniform-random u8, device-resident"
     if args.workload == "hsv1080p":
         # args.batch independent 1080p streams per step: one frame of each through hsvfilter then hsvdetector,
         # two launches per step (a single 1080p frame is ~3 + ~6 us of GPU work: launch-bound one at a time)
@@ -270,7 +413,9 @@ def config_main(args):
             from tests import frames as _frames
             one = torch.from_numpy(_frames.smpte_like(W, H).reshape(-1)).to(dev)
             src = one.unsqueeze(0).repeat(pool * nb, 1).contiguous()
+            data = "synthetic videotestsrc-smpte-like bars, device-resident"
         else:  # smooth 2-D colour gradients (different phase per frame) + sensor-like noise of +-3 codes
+            data = "synthetic smooth colour gradients + uniform noise of +-3 codes (natural-like), device-resident"
             x = torch.linspace(0, 1, W, device=dev).view(1, 1, W)
             y = torch.linspace(0, 1, H, device=dev).view(1, H, 1)
             src = torch.empty((pool * nb, FRAME_BYTES), dtype=torch.uint8, device=dev)
@@ -325,53 +470,175 @@ def config_main(args):
         frames_per_step = 1
         bytes_per_step, name = W * H * 4 + FRAME_BYTES, "roundedcorners I420->A420 compose (r=100) + colordetect histogram (quality=10), one 3840x2160 stream per GPU"
 
-    settle(step, args.settle_seconds, lambda: torch.cuda.synchronize(dev))
+    settle(step, args.settle_seconds, w.sync)
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    elapsed, _ = w.timed(step, args.steps, first_index=args.warmup)
+    (elapsed,) = w.max_over_ranks(elapsed)
+    per_rank = w.gather(args.steps * frames_per_step / elapsed)
     achieved = bytes_per_step * args.steps / elapsed / 1e9
     if rank == 0:
         print(json.dumps({
             "metric": f"{args.workload}_frames_per_sec", "value": args.steps * frames_per_step * world / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.workload != "videofx" else "u8",
-            "data": "synthetic uniform-random u8, device-resident", "config": {"workload": name, "parallelism": f"{world} independent streams"},
+            "data": data, "config": {"workload": name, "parallelism": f"{world} independent streams", "rccl_ranks": w.rccl_ranks,
+                                     "per_rank_frames_per_sec": per_rank},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "note": "wall clock over the launches of a step (per GPU)"}}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    w.finish()
+
+
+# ------------------------------------------------------------------------------------------------ headline
+
+def hsvfilter_main(args):
+    w = Worker(args)
+    torch, vfx, lib, dev, sptr = w.torch, w.vfx, w.lib, w.dev, w.sptr
+    rank, world = w.rank, w.world
+    opts = vfx.options(variant=args.variant, nontemporal=bool(args.streaming), typed=bool(args.typed_loads)).word
+    vfx.check(lib.mvfx_thread_set_options(opts))
+
+    # ---- resident frame pool: (pool + 2 scratch) x batch distinct uniform-random 4K RGBA frames --------------
+    pool = max(1, args.pool)
+    n_scratch = 2
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0100 + rank)
+    frames = torch.randint(0, 256, (pool + n_scratch, args.batch, FRAME_BYTES), dtype=torch.uint8, device=dev, generator=gen)
+    settings = vfx.HsvFilterSettings(*SETTINGS)
+    frame_arrays = []
+    for b in range(pool + n_scratch):
+        arr = (vfx.Frame * args.batch)(*[
+            vfx.make_frame(frames[b, i].data_ptr(), W4K, H4K, W4K * 4, "RGBA") for i in range(args.batch)])
+        frame_arrays.append(arr)
+
+    def launch(batch_index):
+        rc = lib.mvfx_hsvfilter_transform_frames_ip(frame_arrays[batch_index], args.batch, ctypes.byref(settings), sptr)
+        if rc != 0:
+            raise RuntimeError(f"mvfx status {rc}: {vfx.last_error()}")
+
+    def scratch_step(i):   # settle + warm-up: only the scratch batches are filtered (2 x batch x 33 MB >> Infinity Cache)
+        launch(pool + (i % n_scratch))
+
+    def step(i):           # timed: batch i of the untouched pool
+        launch(i % pool)
+
+    settle_steps = settle(scratch_step, args.settle_seconds, w.sync)
+    ceiling = measured_copy_ceiling(w) if rank == 0 or world > 1 else None
+    # the copy ceiling kept the clocks up; W warm-up steps of the real kernel straight after it
+    for i in range(args.warmup):
+        scratch_step(i)
+    elapsed, kernel_ms = w.timed(step, args.steps, events=True)
+    elapsed, kernel_ms = w.max_over_ranks(elapsed, kernel_ms)
+    batch_fps_rank = w.gather(args.steps * args.batch / elapsed)
+    batch_fps = args.steps * args.batch * world / elapsed
+
+    # ---- the element's launch model: --batch host threads x own HIP stream x single-frame calls -----------
+    streams = None
+    bench_so = os.path.join(ROOT, "gst-plugin-rs_amd", "libmvfxbench.so")
+    if args.stream_threads > 0:
+        hb = ctypes.CDLL(bench_so)  # raises when the harness was not built (build() builds it)
+        nthr = args.stream_threads
+        fpt = max(2, (pool * args.batch) // nthr)          # frames per thread, all from the resident pool
+        flat = (vfx.Frame * (nthr * fpt))(*[
+            vfx.make_frame(frames[(k // args.batch) % pool, k % args.batch].data_ptr(), W4K, H4K, W4K * 4, "RGBA")
+            for k in range(nthr * fpt)])
+        # at least 200 launches per thread: the K x batch frames of the batch leg (320 at the driver's K=20) would be ~20
+        # launches per thread = 5 ms, dominated by thread wake-up skew
+        launches = max(200, args.steps * args.batch // nthr)
+        # the threads create their streams first (GPU idle for several ms -> clocks drop): own ~0.4 s warm-up on the threads
+        stream_warmup = max(20, args.warmup, int(args.settle_seconds / 0.6 * 28000) // nthr)
+        secs = ctypes.c_double()
+        per = (ctypes.c_double * nthr)()
+        w.sync()
+        w.barrier()
+        rc = hb.mvfxbench_hsvfilter_streams(w.local_rank, nthr, stream_warmup, launches, flat, fpt, ctypes.byref(settings),
+                                            opts, ctypes.byref(secs), per)
+        if rc != 0:
+            raise RuntimeError(f"mvfxbench status {rc}: {vfx.last_error()}")
+        w.barrier()
+        (s_elapsed,) = w.max_over_ranks(secs.value)
+        s_fps = nthr * launches * world / s_elapsed
+        streams = {"launch_model": f"{nthr} threads x 1 frame (own HIP stream each, single-frame mvfx_hsvfilter_transform_frame_ip, "
+                                   "no sync between launches)",
+                   "value": s_fps, "unit": "frames/s", "frames": nthr * launches, "launches_per_thread": launches,
+                   "warmup_launches_per_thread": stream_warmup, "seconds": s_elapsed,
+                   "achieved_GBs": s_fps / world * 2 * FRAME_BYTES / 1e9, "frac": s_fps / world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS,
+                   "per_rank_frames_per_sec": w.gather(nthr * launches / secs.value)}
+
+    # HBM traffic per launch from the committed rocprofv3 PMC passes (cannot be collected live)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "hsvfilter_traffic.json")) as f:
+            t = json.load(f)
+        traffic = t["hbm_bytes_per_launch"] * args.batch / t["frames_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    bytes_per_launch = args.batch * 2 * FRAME_BYTES  # 4 B read + 4 B written per pixel (SURVEY 8d)
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    batch_model = {"launch_model": f"1 launch x {args.batch} frames (mvfx_hsvfilter_transform_frames_ip, blockIdx.z = stream)",
+                   "value": batch_fps, "unit": "frames/s", "per_rank_frames_per_sec": batch_fps_rank}
+    use_streams = args.launch_model == "streams" and streams is not None
+    head, other = (streams, batch_model) if use_streams else (batch_model, streams)
+    total_frames = args.steps * args.batch * world
+    out = {
+        "metric": "hsvfilter_4k_rgba_frames_per_sec",
+        "value": head["value"],
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": (total_frames / head["value"]) / max(args.steps, 1) * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic uniform-random u8 RGBA (torch.randint, seed 0x5EED0100+rank), device-resident; the timed steps start "
+                "on frames no kernel has touched (settle + warm-up run on scratch batches)",
+        "config": {"workload": "hsvfilter 3840x2160 RGBA in place, hue-shift=90 saturation-mul=1.25 "
+                               "saturation-off=-0.05 value-mul=0.9 value-off=0.02",
+                   "launch_model": head["launch_model"], "other_launch_model": other,
+                   "frames_per_step_per_gpu": args.batch, "resident_batches": pool,
+                   "settle_seconds_before_warmup": args.settle_seconds, "settle_steps": settle_steps,
+                   "parallelism": f"{world} independent stream shards, no data-path collective",
+                   "rccl_ranks": w.rccl_ranks, "per_rank_frames_per_sec": head["per_rank_frames_per_sec"],
+                   "kernel_variant": {0: "auto", 1: "literal", 2: "strength-reduced"}[args.variant],
+                   "cache_policy": "non-temporal (MVFX_OPT_NONTEMPORAL)" if args.streaming else "default",
+                   "u8_to_unit_float": "typed buffer loads (texture-unit UNORM8, exact)" if args.typed_loads else "VALU (cvt + mul + fmac)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "hsvfilter4_typed_kernel" if args.typed_loads else "hsvfilter4_kernel<RGBA, vec4>", "bytes_per_launch": bytes_per_launch,
+                     "avg_launch_ms": kernel_ms, "read_side_GBs": achieved / 2,
+                     "ceiling_measured_GBs": ceiling, "frac_of_measured_ceiling": achieved / ceiling if ceiling else None,
+                     "ceiling_note": "torch device-to-device copy of 1 GiB (read + write bytes) timed with HIP events in this run",
+                     "launch_model": batch_model["launch_model"]},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    w.finish()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--settle-seconds", type=float, default=0.6,
                     help="untimed run of the same step before the W warmup steps: the clock governor of the MI355X needs "
                          "~0.2 s of sustained load to leave its low-power state (profiles/r1/exp_ramp_launch_series.txt: "
                          "305 us/launch for the first 100 launches, 199 us after 0.2 s); 0 disables")
     ap.add_argument("--batch", type=int, default=16, help="4K frames (streams) per step per GPU")
-    ap.add_argument("--pool", type=int, default=24, help="distinct batches resident in HBM")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--pool", type=int, default=24, help="distinct batches resident in HBM (timed steps beyond it re-filter frames)")
+    ap.add_argument("--launch-model", default="batch", choices=["batch", "streams"],
+                    help="which launch model `value` reports: batch = --batch frames in one launch; streams = --stream-threads host "
+                         "threads x own HIP stream x single-frame calls (the element's model); the other one is reported in config")
+    ap.add_argument("--stream-threads", type=int, default=16, help="host threads of the streams model (0 = skip that leg)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget per leg (1 thread, then nproc threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 literal kernel, 2 strength-reduced")
     ap.add_argument("--streaming", type=int, default=1,
-                    help="mvfx_hsvfilter_set_streaming: 1 = non-temporal loads/stores (the frames of this workload are not "
+                    help="MVFX_OPT_NONTEMPORAL: 1 = non-temporal loads/stores (the frames of this workload are not "
                          "read again on the GPU: standalone filter), 0 = normal caching (element chains)")
     ap.add_argument("--content", default="natural", choices=["natural", "random", "smpte"],
                     help="colorlut workload: frame content. The LUT gathers are content dependent: smooth gradients with +-3 "
@@ -390,134 +657,13 @@ def main():
                          "(hsvfilter + hsvdetector 1920x1080); colorlut = config 3 (33^3 cube, 4K); videofx = config 4 "
                          "(roundedcorners compose + colordetect, one 4K stream per GPU); videocompare = config 5")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_workers(args, sys.argv[1:])  # the parent never touches the GPU
     if args.workload == "videocompare":
         return videocompare_main(args)
     if args.workload != "hsvfilter":
         return config_main(args)
-
-    import torch
-    import torch.distributed as dist
-    import _pkg
-    vfx = _pkg.vfx
-    lib = vfx.lib()  # raises if libmi355vfx.so is missing: no fallback
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
-                             "torch.distributed.run --nproc-per-node N\n")
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
-    if not torch.cuda.is_available():
-        sys.stderr.write("bench.py: no GPU visible; the HIP path has no CPU fallback\n")
-        sys.exit(3)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
-    vfx.check(lib.mvfx_set_device(local_rank))
-    vfx.check(lib.mvfx_hsvfilter_set_variant(args.variant))
-    vfx.check(lib.mvfx_hsvfilter_set_streaming(args.streaming))
-    vfx.check(lib.mvfx_hsvfilter_set_typed_loads(args.typed_loads))
-
-    # ---- resident frame pool: pool x batch distinct uniform-random 4K RGBA frames -------------
-    pool = max(1, args.pool)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0x5EED0100 + rank)
-    frames = torch.randint(0, 256, (pool, args.batch, FRAME_BYTES), dtype=torch.uint8, device=dev,
-                           generator=gen)
-    settings = vfx.HsvFilterSettings(*SETTINGS)
-    frame_arrays = []
-    for b in range(pool):
-        arr = (vfx.Frame * args.batch)(*[
-            vfx.make_frame(frames[b, i].data_ptr(), W4K, H4K, W4K * 4, "RGBA") for i in range(args.batch)])
-        frame_arrays.append(arr)
-    stream = torch.cuda.current_stream(dev)
-    sptr = ctypes.c_void_p(stream.cuda_stream)
-
-    def step(i):
-        rc = lib.mvfx_hsvfilter_transform_frames_ip(frame_arrays[i % pool], args.batch,
-                                                    ctypes.byref(settings), sptr)
-        if rc != 0:
-            raise RuntimeError(f"mvfx status {rc}: {vfx.last_error()}")
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    # clock ramp, see --settle-seconds; not part of the W warmup / K timed steps
-    settle_steps = settle(step, args.settle_seconds, lambda: torch.cuda.synchronize(dev))
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for i in range(args.steps):
-        step(args.warmup + i)
-    ev1.record(stream)
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)  # average launch duration on the stream
-
-    if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
-
-    # HBM traffic per launch from the committed rocprofv3 PMC passes (cannot be collected live)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "hsvfilter_traffic.json")) as f:
-            t = json.load(f)
-        traffic = t["hbm_bytes_per_launch"] * args.batch / t["frames_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    total_frames = args.steps * args.batch * world
-    fps = total_frames / elapsed
-    bytes_per_launch = args.batch * 2 * FRAME_BYTES  # 4 B read + 4 B written per pixel (SURVEY 8d)
-    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    out = {
-        "metric": "hsvfilter_4k_rgba_frames_per_sec",
-        "value": fps,
-        "unit": "frames/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic uniform-random u8 RGBA (torch.randint, seed 0x5EED0100+rank), device-resident",
-        "config": {"workload": "hsvfilter 3840x2160 RGBA in place, hue-shift=90 saturation-mul=1.25 "
-                               "saturation-off=-0.05 value-mul=0.9 value-off=0.02",
-                   "frames_per_step_per_gpu": args.batch, "resident_batches": pool,
-                   "settle_seconds_before_warmup": args.settle_seconds, "settle_steps": settle_steps,
-                   "parallelism": f"{world} independent stream shards, no data-path collective",
-                   "kernel_variant": {0: "auto", 1: "literal", 2: "strength-reduced"}[args.variant],
-                   "cache_policy": "non-temporal (mvfx_hsvfilter_set_streaming(1))" if args.streaming else "default",
-                   "u8_to_unit_float": "typed buffer loads (texture-unit UNORM8, exact)" if args.typed_loads else "VALU (cvt + mul + fmac)"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "hsvfilter4_typed_kernel" if args.typed_loads else "hsvfilter4_kernel<RGBA, vec4>", "bytes_per_launch": bytes_per_launch,
-                     "avg_launch_ms": kernel_ms, "read_side_GBs": achieved / 2},
-    }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    return hsvfilter_main(args)
 
 
 if __name__ == "__main__":

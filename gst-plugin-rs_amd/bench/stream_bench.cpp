@@ -1,0 +1,90 @@
+// libmvfxbench.so -- measurement harness for the launch model the elements really use: every
+// stream has its own host thread (GStreamer: one streaming thread per stream) with its own HIP
+// stream (mvfx_thread_stream) and calls the SINGLE-frame C-ABI entry point once per buffer
+// (hsvfilter/imp.rs:322-326: one transform_frame_ip per buffer).  Python threads would put the
+// GIL between the launches, so the threads live here; bench.py only starts the run and reads the
+// clock values back.  Nothing in here computes pixels and the product library does not link it.
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <thread>
+#include <vector>
+
+#include "mi355vfx.h"
+
+namespace {
+
+struct SpinBarrier {
+    std::atomic<uint32_t> arrived{0};
+    std::atomic<uint32_t> generation{0};
+    uint32_t n;
+    explicit SpinBarrier(uint32_t n_) : n(n_) {}
+    void wait()
+    {
+        const uint32_t gen = generation.load(std::memory_order_acquire);
+        if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+            arrived.store(0, std::memory_order_relaxed);
+            generation.fetch_add(1, std::memory_order_release);
+        } else {
+            while (generation.load(std::memory_order_acquire) == gen) std::this_thread::yield();
+        }
+    }
+};
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+} // namespace
+
+extern "C" {
+
+// n_threads host threads; thread t filters frames[t*frames_per_thread + (i % frames_per_thread)] for
+// i in [0, warmup + launches), one mvfx_hsvfilter_transform_frame_ip per frame on its own stream, no
+// synchronisation between launches (the device-memory element hands the buffer on with an event).
+// Timed region: all threads released together after their warm-up has drained; ends when the last
+// thread's stream has drained.  seconds_out = that wall time; thread_seconds[t] = thread t's own span.
+int mvfxbench_hsvfilter_streams(int device, uint32_t n_threads, uint32_t warmup, uint32_t launches, const mvfx_frame *frames,
+                                uint32_t frames_per_thread, const mvfx_hsvfilter_settings *settings, uint32_t options,
+                                double *seconds_out, double *thread_seconds)
+{
+    if (!frames || !settings || !seconds_out || n_threads == 0 || frames_per_thread == 0) return MVFX_ERR_INVALID_ARGUMENT;
+    SpinBarrier ready(n_threads + 1), go(n_threads + 1), done(n_threads + 1);
+    std::vector<int> status(n_threads, MVFX_OK);
+    std::vector<double> span(n_threads, 0.0);
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < n_threads; t++) {
+        pool.emplace_back([&, t] {
+            int rc = mvfx_set_device(device);
+            if (rc == MVFX_OK) rc = mvfx_thread_set_options(options);
+            mvfx_stream st = mvfx_thread_stream();
+            const mvfx_frame *mine = frames + (size_t)t * frames_per_thread;
+            for (uint32_t i = 0; i < warmup && rc == MVFX_OK; i++)
+                rc = mvfx_hsvfilter_transform_frame_ip(&mine[i % frames_per_thread], settings, st);
+            if (rc == MVFX_OK) rc = mvfx_stream_synchronize(st);
+            ready.wait();
+            go.wait();
+            const double t0 = now_s();
+            for (uint32_t i = 0; i < launches && rc == MVFX_OK; i++)
+                rc = mvfx_hsvfilter_transform_frame_ip(&mine[(warmup + i) % frames_per_thread], settings, st);
+            if (rc == MVFX_OK) rc = mvfx_stream_synchronize(st);
+            span[t] = now_s() - t0;
+            status[t] = rc;
+            done.wait();
+        });
+    }
+    ready.wait();
+    const double t0 = now_s();
+    go.wait();
+    done.wait();
+    *seconds_out = now_s() - t0;
+    for (std::thread &th : pool) th.join();
+    for (uint32_t t = 0; t < n_threads; t++) {
+        if (thread_seconds) thread_seconds[t] = span[t];
+        if (status[t] != MVFX_OK) return status[t];
+    }
+    return MVFX_OK;
+}
+
+} // extern "C"

@@ -32,11 +32,15 @@ namespace mvfx {
 namespace {
 
 constexpr int kBlock = 256; // 128 / 512 / 1024 measured slower (profiles/r1/ab_steady_block_nt.txt)
-constexpr int kTile = 2;    // 16-byte pixel groups per lane in hsvfilter4_kernel (vec4 mode) for multi-frame launches: both loads are
-                            // issued first; launches of fewer than kTileMinGroups groups (one or two 4K frames) keep one group
-                            // per lane (twice the workgroups: 16.8 vs 18.4 us for a single 4K frame)
-constexpr uint64_t kTileMinGroups = 3ull * 3840 * 2160 / 4;
-                            // (1: -8 %, 3: -0.4 %, 4: -2 % under the ILP scheduling strategy, ab_steady_sched_strategy.txt)
+constexpr int kTile = 2;    // 16-byte pixel groups per lane in hsvfilter4_kernel (vec4 mode): both loads are issued first
+                            // (1: -8 %, 3: -0.4 %, 4: -2 % under the ILP scheduling strategy, ab_steady_sched_strategy.txt).
+                            // Launches smaller than one 4K frame keep one group per lane (more workgroups to balance).
+                            // Round 1 kept one group per lane up to two 4K frames because an ISOLATED launch followed by a
+                            // synchronisation finishes sooner that way (16.8 vs 18.4 us); what an element on device memory
+                            // needs is throughput with launches of several streams in flight, and there two groups per lane
+                            // win: 16 threads x single-frame launches 72.3 k -> 78.2 k frames/s, one thread 62.7 k -> 64.2 k
+                            // (profiles/r2/streams_sweep_tile1.txt / _tile2.txt, same box, batch-16 launches 78.8 k).
+constexpr uint64_t kTileMinGroups = 1ull * 3840 * 2160 / 4;
 
 enum : int { kModeBytes = 0, kModeVec4 = 1, kModeDword = 2 };
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

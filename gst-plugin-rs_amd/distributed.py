@@ -47,7 +47,9 @@ def videocompare_sharded(partial_sums: Callable[[int], torch.Tensor], n_pads: in
     (pad 0 = the reference pad, videocompare/imp.rs:210-233); with all_pads=True, partial_sums()
     -> [n_pads, 64] from ONE launch over every pad (mvfx_blockhash_sums_pads).
     Returns the distances of pads 1.. to the reference pad (videocompare/imp.rs:349-353)."""
-    sharded = dist.is_initialized() and dist.get_world_size(group) > 1
+    # whenever a process group exists the sums go through the collective, also with one rank (the world-1 RCCL test on
+    # the single-GPU box runs the very same code path as 8 ranks); without a group (plain single-GPU use) nothing is reduced
+    sharded = dist.is_initialized()
     if all_pads:
         parts = partial_sums()
         if sharded:  # u32 block sums travel as int64 so that the all-reduce cannot wrap a signed 32-bit lane
@@ -79,7 +81,7 @@ def ssim_sharded(partial_sums: Callable[[], Tuple[Sequence[float], Sequence[floa
     same distance (videocompare/hashed_image.rs:72-75)."""
     sums, counts, n_scales = partial_sums()
     t = torch.tensor([list(sums), list(counts)], dtype=torch.float64, device=device)
-    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = dist.is_initialized()
     if multi:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     tot = t.cpu().tolist()
@@ -101,7 +103,7 @@ def colordetect_sharded(partial_hist: Callable[[], Tuple[torch.Tensor, torch.Ten
     hist = hist.to(torch.int64).to(device)
     lo = mm[0::2].to(torch.int64).to(device)
     hi = mm[1::2].to(torch.int64).to(device)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():
         dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
