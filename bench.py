@@ -50,11 +50,18 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 
 # ------------------------------------------------------------------------------------------------ launching
 
-def spawn_workers(args, argv):
+def spawn_workers(args, argv, script=None, device_count=None):
     """`python bench.py --gpus N` without a launcher: start N worker processes (one per GPU) BEFORE anything in this
     process touches the GPU.  The parent never initialises HIP and never exec()s; it relays rank 0's JSON line and
     exits non-zero if any worker failed."""
     import socket
+    if device_count is None:
+        import torch  # device_count() does not initialise the GPU on this image (unlike is_available())
+        device_count = torch.cuda.device_count()
+    have = device_count
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible\n")
+        sys.exit(2)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -64,11 +71,34 @@ def spawn_workers(args, argv):
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
                     "MVFX_BENCH_WORKER": "1"})
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
+    # one worker failing (e.g. no such device) must not leave the others waiting in the rendezvous: poll, and end the
+    # rest -- exactly the PIDs started here -- as soon as one has exited non-zero
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()))
+    reader.start()
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[r] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join()
+    sys.stdout.write("".join(chunks))
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
