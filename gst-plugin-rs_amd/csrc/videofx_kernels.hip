@@ -27,6 +27,7 @@
 #include "mmcq.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -320,6 +321,140 @@ __global__ __launch_bounds__(64) void blockhash_reduce_kernel(const uint32_t *pa
     if (threadIdx.x == 0) sums[blockIdx.x] = a;
 }
 
+// ---- image_hasher's `blockhash_slow` (frames whose width or height is not a multiple of 8) ------------------------
+// f32 block sums accumulated in RASTER ORDER, up to four `+=` per pixel (see oracle/videofx_oracle.c for the crate's
+// statements incl. its `x + 1. % block_width` precedence).  Every pixel lands in exactly one block (right == left and
+// bottom == top always), so the 64 blocks are 64 independent ordered chains: one wave per (block, pad).
+//   UNIT weights (width > 8 and height > 8: fmod(1, block) == 1, weights exactly 0 / 1): a pixel adds its integer value
+//   once (+0.0 three times: no-ops).  While the running total is certainly < 2^24 every f32 addition is exact and the
+//   order cannot matter: the first kExactPixels pixels of a block (raster order) are summed in parallel; after that the
+//   chain is followed literally, one v_add_f32 per pixel in raster order (lane values through v_readlane).
+//   Other frames (a dimension <= 8): fractional weights, four literal additions per pixel, one lane per block.
+struct SlowBounds {
+    uint32_t xs[9], ys[9]; // block b covers columns [xs[b], xs[b+1]) / rows [ys[b], ys[b+1]): floor(x / block_width) in f32, host
+    float mx, my;          // fmodf(1, block_width), fmodf(1, block_height)
+};
+constexpr uint32_t kExactPixels = (1u << 24) / 765u - 64u; // 21,867 pixels x 765 < 2^24
+
+template <int BPP>
+__device__ __forceinline__ uint32_t slow_pixel_value(const uint8_t *p)
+{
+    if constexpr (BPP == 4) return p[3] == 0 ? 765u : (uint32_t)p[0] + p[1] + p[2];
+    else return (uint32_t)p[0] + p[1] + p[2];
+}
+
+template <int BPP>
+__global__ __launch_bounds__(64) void blockhash_slow_unit_kernel(SumPads pads, SlowBounds b, uint32_t *sums)
+{
+    const uint32_t block = blockIdx.x, bx = block & 7, by = block >> 3, lane = threadIdx.x;
+    const uint8_t *plane = pads.plane[blockIdx.y];
+    const uint64_t stride = pads.stride[blockIdx.y];
+    const uint32_t x0 = b.xs[bx], x1 = b.xs[bx + 1], y0 = b.ys[by], y1 = b.ys[by + 1];
+    uint32_t consumed = 0, acc = 0; // exact phase: private integer partials, `consumed` is wave-uniform
+    float fsum = 0.0f;
+    bool exact = true;
+    for (uint32_t y = y0; y < y1; y++) {
+        const uint8_t *row = plane + (uint64_t)y * stride;
+        for (uint32_t xc = x0; xc < x1; xc += 64) {
+            const uint32_t x = xc + lane;
+            const uint32_t v = x < x1 ? slow_pixel_value<BPP>(row + (uint64_t)x * BPP) : 0u;
+            const uint32_t n = x1 - xc < 64u ? x1 - xc : 64u;
+            if (exact && consumed + n <= kExactPixels) {
+                acc += v;
+                consumed += n;
+                continue;
+            }
+            if (exact) { // leave the exact phase: total of the prefix, < 2^24, exactly representable
+                exact = false;
+                uint32_t t = acc;
+                for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+                fsum = (float)t;
+            }
+            const float fv = (float)v; // lanes past the block's last column hold +0.0: adding it changes nothing
+#pragma unroll
+            for (int i = 0; i < 64; i++)
+                fsum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fv), i));
+        }
+    }
+    if (exact) {
+        uint32_t t = acc;
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+        fsum = (float)t;
+    }
+    if (lane == 0) sums[blockIdx.y * 64 + block] = __builtin_bit_cast(uint32_t, fsum);
+}
+
+// fractional weights (a dimension <= 8 pixels): literal transcription, thread = block
+template <int BPP>
+__global__ __launch_bounds__(64) void blockhash_slow_weighted_kernel(SumPads pads, SlowBounds b, uint32_t *sums)
+{
+    const uint32_t block = threadIdx.x, bx = block & 7, by = block >> 3;
+    const uint8_t *plane = pads.plane[blockIdx.x];
+    const uint64_t stride = pads.stride[blockIdx.x];
+    float sum = 0.0f;
+    for (uint32_t yi = b.ys[by]; yi < b.ys[by + 1]; yi++) {
+        const float y_mod = (float)yi + b.my;
+        const float weight_top = y_mod - truncf(y_mod), weight_bottom = 1.0f - weight_top;
+        for (uint32_t xi = b.xs[bx]; xi < b.xs[bx + 1]; xi++) {
+            const float x_mod = (float)xi + b.mx;
+            const float weight_left = x_mod - truncf(x_mod), weight_right = 1.0f - weight_left;
+            const float px_sum = (float)slow_pixel_value<BPP>(plane + (uint64_t)yi * stride + (uint64_t)xi * BPP);
+            sum += px_sum * weight_left * weight_top;
+            sum += px_sum * weight_left * weight_bottom;
+            sum += px_sum * weight_right * weight_top;
+            sum += px_sum * weight_right * weight_bottom;
+        }
+    }
+    sums[blockIdx.x * 64 + block] = __builtin_bit_cast(uint32_t, sum);
+}
+
+// Host side of the slow path: block boundaries with the crate's f32 arithmetic (`(x as f32 / block_width).floor()`),
+// then one wave per (block, pad).  Not shardable by rows: a block sum is ONE ordered f32 chain over all of its rows.
+int blockhash_slow_impl(const mvfx_frame *frames, uint32_t n_pads, uint32_t *sums_dev, hipStream_t st)
+{
+    const mvfx_frame *f0 = &frames[0];
+    const uint32_t w = f0->width, h = f0->height;
+    SlowBounds b{};
+    const float block_width = (float)w / 8.0f, block_height = (float)h / 8.0f;
+    b.mx = std::fmod(1.0f, block_width);
+    b.my = std::fmod(1.0f, block_height);
+    auto bounds = [](uint32_t n, float block, uint32_t out[9]) -> bool {
+        uint32_t prev = 0;
+        out[0] = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            const float q = std::floor((float)i / block);
+            if (!(q >= 0.0f && q <= 7.0f)) return false; // the crate would index out of bounds
+            const uint32_t blk = (uint32_t)q;
+            if (blk < prev) return false;
+            for (; prev < blk; prev++) out[prev + 1] = i;
+        }
+        for (; prev < 8; prev++) out[prev + 1] = n;
+        return true;
+    };
+    if (!bounds(w, block_width, b.xs) || !bounds(h, block_height, b.ys))
+        return fail(MVFX_ERR_REFERENCE_PANIC, "blockhash: block index out of range for %ux%u (image_hasher would panic)", w, h);
+    const bool unit = b.mx == 1.0f && b.my == 1.0f;
+    const int bpp = f0->format == MVFX_FORMAT_RGBA ? 4 : 3;
+    for (uint32_t first = 0; first < n_pads; first += kSumMaxPads) {
+        const uint32_t n = std::min<uint32_t>(kSumMaxPads, n_pads - first);
+        SumPads pads{};
+        for (uint32_t p = 0; p < n; p++) {
+            pads.plane[p] = static_cast<const uint8_t *>(frames[first + p].data);
+            pads.stride[p] = frames[first + p].stride;
+        }
+        uint32_t *out = sums_dev + (size_t)first * 64;
+        if (unit) {
+            if (bpp == 4) hipLaunchKernelGGL(blockhash_slow_unit_kernel<4>, dim3(64, n), dim3(64), 0, st, pads, b, out);
+            else hipLaunchKernelGGL(blockhash_slow_unit_kernel<3>, dim3(64, n), dim3(64), 0, st, pads, b, out);
+        } else {
+            if (bpp == 4) hipLaunchKernelGGL(blockhash_slow_weighted_kernel<4>, dim3(n), dim3(64), 0, st, pads, b, out);
+            else hipLaunchKernelGGL(blockhash_slow_weighted_kernel<3>, dim3(n), dim3(64), 0, st, pads, b, out);
+        }
+        MVFX_HIP_TRY(hipGetLastError());
+    }
+    return MVFX_OK;
+}
+
 // Block sums of rows [row_begin,row_end) of n_pads frames of one size and format -> sums_dev[n_pads][64]
 int blockhash_sums_impl(const mvfx_frame *frames, uint32_t n_pads, uint32_t row_begin, uint32_t row_end,
                         uint32_t *sums_dev, hipStream_t st)
@@ -337,12 +472,18 @@ int blockhash_sums_impl(const mvfx_frame *frames, uint32_t n_pads, uint32_t row_
         if (frame->format != f0->format)
             return fail(MVFX_ERR_INVALID_ARGUMENT, "blockhash: the frames of one multi-pad call must share one format");
     }
-    if (f0->width == 0 || f0->height == 0 || f0->width % 8 != 0 || f0->height % 8 != 0)
-        return fail(MVFX_ERR_INVALID_ARGUMENT,
-                    "blockhash: %ux%u is not a multiple of 8 in both dimensions; only the integer fast path of the "
-                    "blockhash algorithm is implemented", f0->width, f0->height);
+    if (f0->width == 0 || f0->height == 0)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "blockhash: empty frame");
     if (int rc = require_device(); rc != MVFX_OK) return rc;
     if (row_end > f0->height) row_end = f0->height;
+    if (f0->width % 8 != 0 || f0->height % 8 != 0) {
+        // image_hasher's f32 path: a block sum is one ordered chain over all of the block's rows -> whole frames only
+        if (row_begin != 0 || row_end != f0->height)
+            return fail(MVFX_ERR_INVALID_ARGUMENT,
+                        "blockhash: %ux%u is not a multiple of 8 in both dimensions: the f32 block sums of that path are "
+                        "order-dependent chains and cannot be split into row bands", f0->width, f0->height);
+        return blockhash_slow_impl(frames, n_pads, sums_dev, st);
+    }
     if (row_begin >= row_end) {
         MVFX_HIP_TRY(hipMemsetAsync(sums_dev, 0, (size_t)n_pads * 64 * sizeof(uint32_t), st));
         return MVFX_OK;
@@ -388,11 +529,31 @@ int blockhash_sums_impl(const mvfx_frame *frames, uint32_t n_pads, uint32_t row_
     return MVFX_OK;
 }
 
-// bits from the 64 sums: 4 bands of 16 blocks, upper median, `> median` or equal-and-bright
+// bits from the 64 sums (gen_hash!): 4 groups of 16 blocks, upper median, `> median` or equal-and-bright.
+// Multiples of 8: u32 sums, equality exact.  Other sizes: the words are f32 bit patterns, |v - median| < 0.001
+// (FLOAT_EQ_MARGIN) and the brightness bound 765.0 * (block_width * block_height) / 2.0 in f32.
 uint64_t blockhash_bits(const uint32_t sums[64], uint32_t width, uint32_t height)
 {
-    const uint64_t half_block_value = (uint64_t)765 * (width / 8) * (height / 8) / 2;
     uint64_t hash = 0;
+    if (width % 8 != 0 || height % 8 != 0) {
+        float blocks[64];
+        std::memcpy(blocks, sums, sizeof(blocks));
+        const float block_area = ((float)width / 8.0f) * ((float)height / 8.0f);
+        const float cmp_factor = 765.0f * block_area / 2.0f;
+        for (int band = 0; band < 4; band++) {
+            float sorted[16];
+            std::memcpy(sorted, blocks + 16 * band, sizeof(sorted));
+            std::nth_element(sorted, sorted + 8, sorted + 16);
+            const float median = sorted[8];
+            for (int i = 0; i < 16; i++) {
+                const float v = blocks[16 * band + i];
+                if (v > median || (std::fabs(v - median) < 0.001f && median > cmp_factor))
+                    hash |= 1ull << (16 * band + i);
+            }
+        }
+        return hash;
+    }
+    const uint64_t half_block_value = (uint64_t)765 * (width / 8) * (height / 8) / 2;
     for (int band = 0; band < 4; band++) {
         uint32_t sorted[16];
         std::memcpy(sorted, sums + 16 * band, sizeof(sorted));
@@ -586,8 +747,8 @@ int mvfx_blockhash_bits(const uint32_t sums_host[64], uint32_t width, uint32_t h
 {
     if (!sums_host || !hash_out)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "blockhash_bits: NULL argument");
-    if (width == 0 || height == 0 || width % 8 || height % 8)
-        return fail(MVFX_ERR_INVALID_ARGUMENT, "blockhash_bits: %ux%u is not a multiple of 8", width, height);
+    if (width == 0 || height == 0)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "blockhash_bits: empty frame");
     *hash_out = blockhash_bits(sums_host, width, height);
     return MVFX_OK;
 }

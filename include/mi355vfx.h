@@ -248,13 +248,18 @@ const char *mvfx_css_color_similar(uint8_t r, uint8_t g, uint8_t b);
 /* ---- videocompare : video/videofx/src/videocompare/{imp,hashed_image}.rs ----
  * Default hash-algo Blockhash (image_hasher 3.1.1, 8x8 bits, hashed_image.rs:37-45,104):
  * 64 block sums of r+g+b (765 when alpha == 0) over an 8x8 grid, bits against the band
- * median, distance = Hamming distance as f64 (hashed_image.rs:70).  Width and height must be
- * multiples of 8 (true for every BASELINE shape); row padding never counts (the reference
- * packs the frame first, hashed_image.rs:110-130). */
+ * median, distance = Hamming distance as f64 (hashed_image.rs:70); row padding never counts (the
+ * reference packs the frame first, hashed_image.rs:110-130).  Any RGB / RGBA size is accepted, as by the
+ * reference (videocompare/imp.rs:158-163):
+ *   width and height multiples of 8 (every BASELINE shape): the crate's integer path, u32 sums;
+ *   any other size: the crate's f32 path -- every block sum is ONE chain of f32 additions in raster order
+ *   (64 independent ordered chains, one wave per block on the device); the 64 words are then f32 BIT
+ *   PATTERNS, mvfx_blockhash_bits compares them with the crate's 0.001 margin.  That path cannot be split
+ *   into row bands (MVFX_ERR_INVALID_ARGUMENT for a partial row range). */
 
 /* Partial block sums of image rows [row_begin,row_end) -> sums_device[64] (overwritten).
  * Ranks that each own a row band all-reduce(sum) the 64 u32 and then call
- * mvfx_blockhash_bits on the total. */
+ * mvfx_blockhash_bits on the total (sizes that are multiples of 8 only). */
 int mvfx_blockhash_sums(const mvfx_frame *frame, uint32_t row_begin, uint32_t row_end,
                         uint32_t *sums_device, mvfx_stream stream);
 /* Same for a rank that holds ONLY its row band in memory: `band` describes rows

@@ -7,7 +7,7 @@
  *   color-name  1.2.0 (Cargo.lock:2045-2048)  call site colordetect/imp.rs:77-79
  *   image_hasher 3.1.1 (Cargo.lock:7459-7468) call sites videocompare/hashed_image.rs:37-45,70
  * This file restates their published algorithms (MMCQ modified median cut from Leptonica ->
- * quantize.js -> color-thief; the "blockhash" perceptual hash, integer fast path).
+ * quantize.js -> color-thief; the "blockhash" perceptual hash, integer fast path and f32 slow path).
  * PARITY UNPINNED beyond what the reference's own pipeline tests pin:
  *   video/videofx/tests/colordetect.rs:21-68   solid red  => dominant-color "red"
  *   video/videofx/tests/videocompare.rs:57-139 red vs red => distance 0; snow vs red => > 0
@@ -343,8 +343,23 @@ const char *orc_css_color_similar(uint8_t r, uint8_t g, uint8_t b)
 
 /* ------------------------------------------------------------------ videocompare */
 
-/* blockhash integer fast path (W%8==0 && H%8==0); pixel value r+g+b, RGBA: 765 if a==0.
- * The frame is first tightly packed (hashed_image.rs:110-130): row padding never counts. */
+/* image_hasher 3.1.1 `blockhash(img, 8, 8)` (src/alg/blockhash.rs; crate not under /root/reference: PARITY UNPINNED,
+ * restated from the crate's published source).  Pixel value r+g+b, RGBA: 765 if a==0 (`sum_px`).  The frame is first
+ * tightly packed (hashed_image.rs:110-130): row padding never counts.
+ *
+ *   W%8==0 && H%8==0  -> `blockhash_fast`: u32 block sums over W/8 x H/8 blocks.
+ *   otherwise         -> `blockhash_slow`: f32 block sums, every pixel visited in raster order:
+ *        block_width = W as f32 / 8.0; block_x = x / block_width; x_mod = x + 1. % block_width   (sic: `%` binds tighter
+ *        than `+`, so x_mod = x + fmod(1, block_width), which is x + 1 whenever W > 8);
+ *        weight_left = fract(x_mod), weight_right = 1 - weight_left; block_left = floor(block_x);
+ *        block_right = trunc(x_mod) == 0 ? ceil(block_x) : block_left   (same in y with top/bottom);
+ *        blocks[top][left] += p*wl*wt; blocks[bottom][left] += p*wl*wb; blocks[top][right] += p*wr*wt;
+ *        blocks[bottom][right] += p*wr*wb       -- four f32 `+=` per pixel, in this order.
+ *      (trunc(x_mod) == 0 only for x == 0, where ceil(block_x) == 0 == block_left, so right == left and bottom == top
+ *      always; for W > 8 and H > 8 the weights are exactly 0/1 and a pixel adds `p` once and +0.0 three times.)
+ * The 64 sums are returned as 32-bit words: u32 values on the fast path, f32 BIT PATTERNS on the slow path. */
+static int blockhash_is_fast(uint32_t width, uint32_t height) { return width % 8 == 0 && height % 8 == 0; }
+
 int orc_blockhash_sums(const uint8_t *data, uint32_t width, uint32_t height, uint32_t stride,
                        int format, uint32_t sums[64])
 {
@@ -352,20 +367,59 @@ int orc_blockhash_sums(const uint8_t *data, uint32_t width, uint32_t height, uin
     if (format == ORC_FORMAT_RGB) bpp = 3;
     else if (format == ORC_FORMAT_RGBA) bpp = 4;
     else return ORC_ERR_FORMAT; /* videocompare caps: RGB, RGBA only (imp.rs:160-162) */
-    if (width == 0 || height == 0 || width % 8 != 0 || height % 8 != 0)
-        return ORC_ERR_PANIC; /* float-weighted slow path not restated */
+    if (width == 0 || height == 0)
+        return ORC_ERR_PANIC;
     memset(sums, 0, 64 * sizeof(uint32_t));
-    uint32_t bw = width / 8, bh = height / 8;
-    for (uint32_t y = 0; y < height; y++) {
-        const uint8_t *row = data + (size_t)y * stride;
-        for (uint32_t x = 0; x < width; x++) {
-            const uint8_t *p = row + (size_t)x * (size_t)bpp;
+    if (blockhash_is_fast(width, height)) { /* blockhash_fast */
+        uint32_t bw = width / 8, bh = height / 8;
+        for (uint32_t y = 0; y < height; y++) {
+            const uint8_t *row = data + (size_t)y * stride;
+            for (uint32_t x = 0; x < width; x++) {
+                const uint8_t *p = row + (size_t)x * (size_t)bpp;
+                uint32_t v = (uint32_t)p[0] + p[1] + p[2];
+                if (bpp == 4 && p[3] == 0)
+                    v = 765;
+                sums[(y / bh) * 8 + x / bw] += v;
+            }
+        }
+        return ORC_OK;
+    }
+    /* blockhash_slow */
+    float blocks[64];
+    for (int i = 0; i < 64; i++) blocks[i] = 0.0f;
+    const float block_width = (float)width / 8.0f, block_height = (float)height / 8.0f;
+    const float mx = fmodf(1.0f, block_width), my = fmodf(1.0f, block_height);
+    for (uint32_t yi = 0; yi < height; yi++) {
+        const uint8_t *row = data + (size_t)yi * stride;
+        const float y = (float)yi;
+        const float block_y = y / block_height;
+        const float y_mod = y + my;
+        const float weight_top = y_mod - truncf(y_mod);
+        const float weight_bottom = 1.0f - weight_top;
+        const uint32_t block_top = (uint32_t)floorf(block_y);
+        const uint32_t block_bottom = truncf(y_mod) == 0.0f ? (uint32_t)ceilf(block_y) : block_top;
+        for (uint32_t xi = 0; xi < width; xi++) {
+            const uint8_t *p = row + (size_t)xi * (size_t)bpp;
             uint32_t v = (uint32_t)p[0] + p[1] + p[2];
             if (bpp == 4 && p[3] == 0)
                 v = 765;
-            sums[(y / bh) * 8 + x / bw] += v;
+            const float px_sum = (float)v;
+            const float x = (float)xi;
+            const float block_x = x / block_width;
+            const float x_mod = x + mx;
+            const float weight_left = x_mod - truncf(x_mod);
+            const float weight_right = 1.0f - weight_left;
+            const uint32_t block_left = (uint32_t)floorf(block_x);
+            const uint32_t block_right = truncf(x_mod) == 0.0f ? (uint32_t)ceilf(block_x) : block_left;
+            if (block_left > 7 || block_right > 7 || block_top > 7 || block_bottom > 7)
+                return ORC_ERR_PANIC; /* slice index out of bounds in the crate */
+            blocks[block_top * 8 + block_left] += px_sum * weight_left * weight_top;
+            blocks[block_bottom * 8 + block_left] += px_sum * weight_left * weight_bottom;
+            blocks[block_top * 8 + block_right] += px_sum * weight_right * weight_top;
+            blocks[block_bottom * 8 + block_right] += px_sum * weight_right * weight_bottom;
         }
     }
+    memcpy(sums, blocks, sizeof(blocks));
     return ORC_OK;
 }
 
@@ -375,11 +429,37 @@ static int cmp_u32(const void *a, const void *b)
     return (x > y) - (x < y);
 }
 
-/* 4 horizontal bands of 2 block-rows; median = sorted[len/2] (upper median);
- * bit = v > median || (|v - median| < 1 && median > half) */
+static int cmp_f32(const void *a, const void *b)
+{
+    float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
+/* gen_hash!: 4 groups of 16 blocks (2 block-rows); median = sorted[len/2] (upper median);
+ * fast: bit = v > median || (v == median && median > 765*bw*bh/2)                       (u32)
+ * slow: bit = v > median || (|v - median| < 0.001 && median > 765.0*(bw*bh)/2.0)         (f32, FLOAT_EQ_MARGIN) */
 uint64_t orc_blockhash_bits(const uint32_t sums[64], uint32_t width, uint32_t height)
 {
     uint64_t hash = 0;
+    if (!blockhash_is_fast(width, height)) {
+        float blocks[64];
+        memcpy(blocks, sums, sizeof(blocks));
+        const float block_width = (float)width / 8.0f, block_height = (float)height / 8.0f;
+        const float block_area = block_width * block_height;
+        const float cmp_factor = 765.0f * block_area / 2.0f;
+        for (int band = 0; band < 4; band++) {
+            float sorted[16];
+            memcpy(sorted, blocks + band * 16, sizeof(sorted));
+            qsort(sorted, 16, sizeof(float), cmp_f32);
+            const float median = sorted[8];
+            for (int i = 0; i < 16; i++) {
+                const float v = blocks[band * 16 + i];
+                if (v > median || (fabsf(v - median) < 0.001f && median > cmp_factor))
+                    hash |= (uint64_t)1 << (band * 16 + i);
+            }
+        }
+        return hash;
+    }
     uint64_t half = (uint64_t)765 * (width / 8) * (height / 8) / 2;
     for (int band = 0; band < 4; band++) {
         uint32_t sorted[16];

@@ -250,3 +250,54 @@ def image_hash_bits(px, algo):
 
 
 HASH_RESIZE = {"mean": (8, 8), "gradient": (9, 8), "vertgradient": (8, 9), "doublegradient": (5, 5)}
+
+
+# ---- image_hasher 3.1.1 blockhash, f32 slow path (sizes not divisible by 8) -------------------------------------
+def blockhash_slow_sums(frame, width, height, bpp):
+    """Second restatement of `blockhash_slow` (see oracle/videofx_oracle.c for the algorithm): returns float32[64].
+    Written differently from the C loop on purpose: pixels are bucketed per block first and every block's chain of f32
+    additions is one np.cumsum (sequential float32 accumulation); the four weighted terms of a pixel are interleaved in
+    the crate's order.  Terms that are exactly +0.0 are kept (adding them is what the crate does)."""
+    px = frame[:height, :width * bpp].reshape(height, width, bpp).astype(np.uint32)
+    v = px[..., 0] + px[..., 1] + px[..., 2]
+    if bpp == 4:
+        v = np.where(px[..., 3] == 0, np.uint32(765), v)
+    p = v.astype(np.float32)
+    bw, bh = F(width) / F(8), F(height) / F(8)
+    xs, ys = np.arange(width, dtype=np.float32), np.arange(height, dtype=np.float32)
+    mx, my = np.fmod(F(1), bw), np.fmod(F(1), bh)
+    xm, ym = xs + mx, ys + my
+    wl, wt = xm - np.trunc(xm), ym - np.trunc(ym)
+    wr, wb = F(1) - wl, F(1) - wt
+    left, top = np.floor(xs / bw).astype(np.int64), np.floor(ys / bh).astype(np.int64)
+    right = np.where(np.trunc(xm) == 0, np.ceil(xs / bw).astype(np.int64), left)
+    bottom = np.where(np.trunc(ym) == 0, np.ceil(ys / bh).astype(np.int64), top)
+    assert right.max() < 8 and bottom.max() < 8
+    # term k of pixel (y, x): (block index, value), k = 0..3 in the crate's order
+    terms = [(top[:, None] * 8 + left[None, :], (p * wl[None, :]) * wt[:, None]),
+             (bottom[:, None] * 8 + left[None, :], (p * wl[None, :]) * wb[:, None]),
+             (top[:, None] * 8 + right[None, :], (p * wr[None, :]) * wt[:, None]),
+             (bottom[:, None] * 8 + right[None, :], (p * wr[None, :]) * wb[:, None])]
+    blk = np.stack([t[0] for t in terms], axis=-1).reshape(-1)       # raster order, 4 terms per pixel
+    val = np.stack([t[1] for t in terms], axis=-1).astype(np.float32).reshape(-1)
+    out = np.zeros(64, dtype=np.float32)
+    for b in range(64):
+        chain = val[blk == b]
+        if chain.size:
+            out[b] = np.cumsum(chain, dtype=np.float32)[-1]
+    return out
+
+
+def blockhash_slow_bits(blocks, width, height):
+    """gen_hash! for the f32 path: upper median of each group of 16, FLOAT_EQ_MARGIN 0.001."""
+    blocks = np.asarray(blocks, dtype=np.float32)
+    area = (F(width) / F(8)) * (F(height) / F(8))
+    cmp_factor = F(765) * area / F(2)
+    h = 0
+    for band in range(4):
+        g = blocks[16 * band:16 * band + 16]
+        median = np.sort(g)[8]
+        for i in range(16):
+            if g[i] > median or (abs(F(g[i] - median)) < F(0.001) and median > cmp_factor):
+                h |= 1 << (16 * band + i)
+    return h

@@ -104,9 +104,9 @@ def test_roundedcorners_i420_to_a420(gpu, tmp_path):
     assert np.array_equal(same, raw)
 
 
-def _videocompare(tmp_path, pattern_a, pattern_b, extra=""):
+def _videocompare(tmp_path, pattern_a, pattern_b, extra="", size=(320, 240)):
     """tests/videocompare.rs setup_pipeline: two videotestsrc -> videocompare -> fakesink"""
-    caps = "video/x-raw,format=RGBA,width=320,height=240"
+    caps = f"video/x-raw,format=RGBA,width={size[0]},height={size[1]}"
     pipeline = (f"videocompare name=compare {extra} ! fakesink "
                 f"videotestsrc pattern={pattern_a} num-buffers=2 ! {caps} ! compare.sink_0 "
                 f"videotestsrc pattern={pattern_b} num-buffers=2 ! {caps} ! compare.sink_1")
@@ -132,6 +132,20 @@ def test_videocompare_snow_vs_red_is_silent(gpu, tmp_path):
     out = _videocompare(tmp_path, "red", "snow", "max-dist-threshold=64")
     m = re.search(r"distance\\=\\\(double\\\)(\d+)", out)
     assert m and int(m.group(1)) > 0
+
+
+@pytest.mark.parametrize("size", [(854, 480), (1366, 768), (7, 5)])
+def test_videocompare_sizes_that_are_not_multiples_of_8(gpu, tmp_path, size):
+    """The reference accepts any RGB/RGBA size (videocompare/imp.rs:158-163) and image_hasher then takes its f32 path
+    (854 % 8 == 6, 1366 % 8 == 6): the element must hash such streams, not error."""
+    out = _videocompare(tmp_path, "red", "red", size=size)
+    msgs = re.findall(r"videocompare, running-time=\(guint64\)(\d+), pad-distances=\(structure\)<([^>]*)>", out)
+    assert len(msgs) >= 1, out
+    assert re.search(r"distance\\=\\\(double\\\)0", msgs[0][1]), msgs[0][1]
+    if size[0] > 8:
+        out = _videocompare(tmp_path, "red", "snow", "max-dist-threshold=64", size=size)
+        m = re.search(r"distance\\=\\\(double\\\)(\d+)", out)
+        assert m and int(m.group(1)) > 0, out
 
 
 @pytest.mark.parametrize("algo", ["mean", "gradient", "vertgradient", "doublegradient"])

@@ -92,3 +92,38 @@ def test_self_golden_vectors():
         for algo in ALGOS:
             rc, hv, n = orc.image_hash(f, case["width"], case["height"], case["stride"], case["format"], algo)
             assert rc == 0 and f"{hv:016x}" == case["hash"][algo], (case, algo)
+
+
+# ---- blockhash on sizes that are not multiples of 8 (image_hasher's f32 `blockhash_slow`) ------------------------
+@pytest.mark.parametrize("w,h,bpp", [(1366, 768, 4), (854, 480, 3), (641, 481, 4), (7, 5, 4), (9, 9, 3), (8, 9, 4), (5, 300, 3),
+                                     (300, 3, 4), (1, 1, 4), (2001, 1501, 4)])
+def test_blockhash_slow_path_oracle_equals_numpy_twin(w, h, bpp):
+    """Two separately written restatements agree bit for bit on the f32 sums and on the hash.  2001x1501 pushes every
+    block sum past 2^24, where f32 additions round and the ORDER of the chain matters."""
+    from tests import np_twin
+    fmt = "RGBA" if bpp == 4 else "RGB"
+    stride = w * bpp + (5 if bpp == 3 else 8)
+    a = frames.random_frame(0xB10C + w, w, h, bpp, stride)
+    if bpp == 4:
+        a[::3, 3::16] = 0  # some fully transparent pixels count 765
+    rc, s = orc.blockhash_sums(a, w, h, stride, fmt)
+    assert rc == 0
+    got = np.array(s, dtype=np.uint32).view(np.float32)
+    want = np_twin.blockhash_slow_sums(a, w, h, bpp)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    if w == 2001:
+        assert got.min() > 2 ** 24  # the order-dependent regime is really exercised
+    rc, hh = orc.blockhash(a, w, h, stride, fmt)
+    assert rc == 0 and hh == np_twin.blockhash_slow_bits(want, w, h)
+
+
+def test_blockhash_slow_path_reference_pins():
+    """tests/videocompare.rs:57-139 pattern at a non-multiple-of-8 size: identical -> 0, red vs snow -> > 0."""
+    w, h = 854, 480
+    red = np.zeros((h, w * 4), np.uint8)
+    red[:, 0::4] = 255
+    red[:, 3::4] = 255
+    snow = frames.random_frame(0x5EED, w, h, 4)
+    hr = orc.blockhash(red, w, h, w * 4, "RGBA")[1]
+    assert orc.hamming(hr, orc.blockhash(red.copy(), w, h, w * 4, "RGBA")[1]) == 0
+    assert orc.hamming(hr, orc.blockhash(snow, w, h, w * 4, "RGBA")[1]) > 0

@@ -327,3 +327,52 @@ def test_roundedcorners_compose_a420(gpu, cairo_masks):
     out = dst.download()
     assert np.array_equal(out[:offs[3]], i420)
     assert np.array_equal(out[offs[3]:], mask.download())
+
+
+# ---------------------------------------------------------------- blockhash, sizes that are not multiples of 8
+# image_hasher's f32 `blockhash_slow` (hashed_image.rs:24-45 accepts any size): 64 ordered f32 chains on the device.
+
+@pytest.mark.parametrize("w,h,fmt,bpp", [(1366, 768, "RGBA", 4), (854, 480, "RGB", 3), (641, 481, "RGBA", 4), (1921, 1081, "RGBA", 4),
+                                         (2001, 1501, "RGB", 3), (7, 5, "RGBA", 4), (9, 9, "RGB", 3), (8, 9, "RGBA", 4), (5, 300, "RGB", 3),
+                                         (300, 3, "RGBA", 4), (1, 1, "RGBA", 4), (1366, 5, "RGBA", 4)])
+def test_blockhash_slow_path_sums_and_hash_match_oracle(gpu, w, h, fmt, bpp):
+    stride = w * bpp + (5 if bpp == 3 else 12)   # padded, unaligned rows
+    a = frames.random_frame(0xB10C + w, w, h, bpp, stride)
+    if bpp == 4:
+        a[::3, 3::16] = 0
+    rc, want = orc.blockhash_sums(a, w, h, stride, fmt)
+    assert rc == 0
+    d = gpu.DeviceBuffer(a.nbytes).upload(a)
+    sums = gpu.DeviceBuffer(64 * 4)
+    f = gpu.make_frame(d.ptr, w, h, stride, fmt)
+    gpu.check(gpu.lib().mvfx_blockhash_sums(ctypes.byref(f), 0, h, ctypes.c_void_p(sums.ptr), None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    got = sums.download(dtype=np.uint32)
+    assert np.array_equal(got, np.array(want, dtype=np.uint32)), "f32 block sums differ in their bit patterns"
+    if (w, h) in ((1921, 1081), (2001, 1501)):
+        assert got.view(np.float32).min() > 2 ** 24  # past the exact regime: the order of the additions matters
+    rc, hh = orc.blockhash(a, w, h, stride, fmt)
+    assert gpu.blockhash_host(a.reshape(-1), w, h, stride, fmt) == hh
+    out = ctypes.c_uint64()
+    gpu.check(gpu.lib().mvfx_blockhash_bits((ctypes.c_uint32 * 64)(*[int(x) for x in got]), w, h, ctypes.byref(out)))
+    assert out.value == hh
+
+
+def test_blockhash_slow_path_pair_distance_and_errors(gpu):
+    """mvfx_videocompare_distance on 854x480 (854 % 8 == 6): what the element calls per aggregate; a partial row range is
+    refused (an f32 block sum is one ordered chain over all of its rows)."""
+    w, h = 854, 480
+    a = frames.random_frame(0xB10D, w, h, 4)
+    b = a.copy()
+    b[100:300, 400:2000] ^= 0x55
+    da, db = gpu.DeviceBuffer(a.nbytes).upload(a), gpu.DeviceBuffer(b.nbytes).upload(b)
+    fa, fb = gpu.make_frame(da.ptr, w, h, w * 4, "RGBA"), gpu.make_frame(db.ptr, w, h, w * 4, "RGBA")
+    d = ctypes.c_double(-1)
+    gpu.check(gpu.lib().mvfx_videocompare_distance(ctypes.byref(fa), ctypes.byref(fa), ctypes.byref(d), None))
+    assert d.value == 0.0
+    gpu.check(gpu.lib().mvfx_videocompare_distance(ctypes.byref(fa), ctypes.byref(fb), ctypes.byref(d), None))
+    ha, hb = orc.blockhash(a, w, h, w * 4, "RGBA")[1], orc.blockhash(b, w, h, w * 4, "RGBA")[1]
+    assert d.value == float(orc.hamming(ha, hb)) and d.value > 0
+    sums = gpu.DeviceBuffer(64 * 4)
+    assert gpu.lib().mvfx_blockhash_sums(ctypes.byref(fa), 0, 240, ctypes.c_void_p(sums.ptr), None) == gpu.ERR_INVALID_ARGUMENT
+    assert "row bands" in gpu.last_error()
