@@ -5,7 +5,8 @@ import shutil
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PLUGIN_DIR = os.path.join(ROOT, "gst-plugin-rs_amd", "gst-plugins")
+# MVFX_GST_PLUGIN_DIR / MVFX_GST_LD_PRELOAD: `make asan-test` points the same tests at the sanitizer build of the plugins
+PLUGIN_DIR = os.environ.get("MVFX_GST_PLUGIN_DIR") or os.path.join(ROOT, "gst-plugin-rs_amd", "gst-plugins")
 PLUGINS = ["libgsthsv.so", "libgstcolorlut.so", "libgstrsvideofx.so", "libgstmi355hip.so"]
 
 
@@ -29,11 +30,17 @@ def env(tmpdir):
     e["GST_REGISTRY"] = os.path.join(str(tmpdir), "registry.bin")
     e["GST_REGISTRY_FORK"] = "no"
     e.pop("LD_PRELOAD", None)
+    if os.environ.get("MVFX_GST_LD_PRELOAD"):
+        e["LD_PRELOAD"] = os.environ["MVFX_GST_LD_PRELOAD"]
     return e
 
 
 def run(args, tmpdir, timeout=120, extra_env=None):
     e = env(tmpdir)
+    if os.environ.get("MVFX_GST_LD_PRELOAD") and shutil.which("setarch"):
+        # gcc 11's libasan cannot place its shadow memory under 32-bit mmap randomisation: run the tool without ASLR
+        import platform
+        args = ["setarch", platform.machine(), "-R"] + list(args)
     if extra_env:
         e.update(extra_env)
     return subprocess.run(args, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
