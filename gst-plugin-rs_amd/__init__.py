@@ -118,6 +118,7 @@ SIGNATURES = {
     "mvfx_status_string": (c_char_p, [c_int]),
     "mvfx_device_count": (c_int, []),
     "mvfx_set_device": (c_int, [c_int]),
+    "mvfx_current_device": (c_int, []),
     "mvfx_stream_synchronize": (c_int, [c_void_p]),
     "mvfx_device_alloc": (c_int, [POINTER(c_void_p), c_size_t]),
     "mvfx_device_free": (c_int, [c_void_p]),
@@ -125,6 +126,15 @@ SIGNATURES = {
     "mvfx_copy_to_host": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mvfx_copy_device_to_device": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mvfx_thread_stream": (c_void_p, []),
+    "mvfx_event_create": (c_int, [POINTER(c_void_p)]),
+    "mvfx_event_destroy": (c_int, [c_void_p]),
+    "mvfx_event_record": (c_int, [c_void_p, c_void_p]),
+    "mvfx_stream_wait_event": (c_int, [c_void_p, c_void_p]),
+    "mvfx_event_synchronize": (c_int, [c_void_p]),
+    "mvfx_host_alloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "mvfx_host_free": (c_int, [c_void_p]),
+    "mvfx_copy_to_device_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mvfx_copy_to_host_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mvfx_thread_set_options": (c_int, [c_uint32]),
     "mvfx_thread_options": (c_uint32, []),
     "mvfx_hsvfilter_transform_frame_ip": (c_int, [POINTER(Frame), POINTER(HsvFilterSettings), c_void_p]),

@@ -169,6 +169,16 @@ int mvfx_set_device(int ordinal)
     return MVFX_OK;
 }
 
+int mvfx_current_device(void)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return dev;
+}
+
 int mvfx_stream_synchronize(mvfx_stream stream)
 {
     if (int rc = require_device(); rc != MVFX_OK) return rc;
@@ -229,6 +239,88 @@ int mvfx_copy_device_to_device(void *dst_device, const void *src_device, size_t 
 }
 
 mvfx_stream mvfx_thread_stream(void) { return reinterpret_cast<mvfx_stream>(host_stream()); }
+
+int mvfx_event_create(mvfx_event *out)
+{
+    if (!out)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "event_create: NULL out pointer");
+    *out = nullptr;
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    hipEvent_t e = nullptr;
+    MVFX_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); // ordering only: the cheap kind
+    *out = reinterpret_cast<mvfx_event>(e);
+    return MVFX_OK;
+}
+
+int mvfx_event_destroy(mvfx_event event)
+{
+    if (!event) return MVFX_OK;
+    MVFX_HIP_TRY(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+    return MVFX_OK;
+}
+
+int mvfx_event_record(mvfx_event event, mvfx_stream stream)
+{
+    if (!event)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "event_record: NULL event");
+    MVFX_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(event), as_stream(stream)));
+    return MVFX_OK;
+}
+
+int mvfx_stream_wait_event(mvfx_stream stream, mvfx_event event)
+{
+    if (!event)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "stream_wait_event: NULL event");
+    MVFX_HIP_TRY(hipStreamWaitEvent(as_stream(stream), reinterpret_cast<hipEvent_t>(event), 0));
+    return MVFX_OK;
+}
+
+int mvfx_event_synchronize(mvfx_event event)
+{
+    if (!event)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "event_synchronize: NULL event");
+    MVFX_HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)));
+    return MVFX_OK;
+}
+
+int mvfx_host_alloc(void **out_ptr, size_t bytes)
+{
+    if (!out_ptr)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "host_alloc: NULL out pointer");
+    *out_ptr = nullptr;
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    hipError_t e = hipHostMalloc(out_ptr, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess)
+        return fail(MVFX_ERR_OUT_OF_MEMORY, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return MVFX_OK;
+}
+
+int mvfx_host_free(void *ptr)
+{
+    if (!ptr) return MVFX_OK;
+    MVFX_HIP_TRY(hipHostFree(ptr));
+    return MVFX_OK;
+}
+
+int mvfx_copy_to_device_async(void *dst_device, const void *src_host, size_t bytes, mvfx_stream stream)
+{
+    if (bytes == 0) return MVFX_OK;
+    if (!dst_device || !src_host)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "copy_to_device_async: NULL pointer");
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    MVFX_HIP_TRY(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return MVFX_OK;
+}
+
+int mvfx_copy_to_host_async(void *dst_host, const void *src_device, size_t bytes, mvfx_stream stream)
+{
+    if (bytes == 0) return MVFX_OK;
+    if (!dst_host || !src_device)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "copy_to_host_async: NULL pointer");
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    MVFX_HIP_TRY(hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    return MVFX_OK;
+}
 
 int mvfx_thread_set_options(uint32_t options)
 {

@@ -125,9 +125,11 @@ static GstFlowReturn gst_color_lut_bt_transform(GstBaseTransform *bt, GstBuffer 
             return GST_FLOW_ERROR;
         }
         mvfx_stream st = mvfx_thread_stream();
+        mvfx_hip_buffer_acquire(inbuf, st);
+        mvfx_hip_buffer_acquire(outbuf, st);
         int rc = mvfx_colorlut_transform_i420(self->lut, &pi, &po, 0, st);
-        if (rc == MVFX_OK)
-            rc = mvfx_stream_synchronize(st);
+        mvfx_hip_buffer_release(inbuf, st);
+        mvfx_hip_buffer_release(outbuf, st);
         gst_buffer_unmap(outbuf, &omap);
         gst_buffer_unmap(inbuf, &imap);
         return MVFX_GST_FLOW(self, rc);
@@ -139,10 +141,13 @@ static GstFlowReturn gst_color_lut_bt_transform(GstBaseTransform *bt, GstBuffer 
         gst_buffer_unmap(inbuf, &imap);
         return GST_FLOW_ERROR;
     }
+    // fences instead of a host wait per buffer (d3d12colorlut/imp.rs:695-714)
     mvfx_stream st = mvfx_thread_stream();
+    mvfx_hip_buffer_acquire(inbuf, st);
+    mvfx_hip_buffer_acquire(outbuf, st);
     int rc = mvfx_colorlut_transform_frame(self->lut, &fi, &fo, st);
-    if (rc == MVFX_OK)
-        rc = mvfx_stream_synchronize(st);
+    mvfx_hip_buffer_release(inbuf, st);
+    mvfx_hip_buffer_release(outbuf, st);
     gst_buffer_unmap(outbuf, &omap);
     gst_buffer_unmap(inbuf, &imap);
     return MVFX_GST_FLOW(self, rc);

@@ -107,6 +107,7 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
             for (guint p = 0; p < 3; p++)
                 pout.data[p] = (guint8 *)scratch + GST_VIDEO_INFO_PLANE_OFFSET(&vf->in_info, p);
             mvfx_stream st = mvfx_thread_stream();
+            mvfx_hip_buffer_acquire(buf, st);
             rc = mvfx_hsvfilter_transform_i420(&pin, &pout, &s, 0, st);
             if (rc == MVFX_OK)
                 rc = mvfx_copy_device_to_device(map.data, scratch, size, st); // synchronises the stream
@@ -117,10 +118,14 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
     mvfx_frame f;
     if (!mvfx_hip_map_frame(buf, &vf->in_info, GST_MAP_READWRITE, &map, &f))
         return GST_FLOW_ERROR;
+    // no host wait per buffer: the stream first waits (on the device) for whoever touched the block last, and the block's
+    // fence is recorded behind the kernel -- the next element, possibly on another streaming thread and stream, waits for
+    // it the same way, a CPU map waits on the host (d3d12colorlut/imp.rs:695-714 does this with an ID3D12Fence)
     mvfx_stream st = mvfx_thread_stream();
+    mvfx_hip_buffer_acquire(buf, st);
+    // default cache policy (thread option word 0): the next element reads this frame on the GPU
     int rc = mvfx_hsvfilter_transform_frame_ip(&f, &s, st);
-    if (rc == MVFX_OK)
-        rc = mvfx_stream_synchronize(st); // the buffer may be consumed on another streaming thread
+    mvfx_hip_buffer_release(buf, st);
     gst_buffer_unmap(buf, &map);
     return MVFX_GST_FLOW(self, rc);
 }
@@ -309,9 +314,11 @@ static GstFlowReturn gst_hsv_detector_bt_transform(GstBaseTransform *bt, GstBuff
         return GST_FLOW_ERROR;
     }
     mvfx_stream st = mvfx_thread_stream();
+    mvfx_hip_buffer_acquire(inbuf, st);
+    mvfx_hip_buffer_acquire(outbuf, st);
     int rc = i420 ? mvfx_hsvdetector_transform_i420(&pi, &fo, &s, 0, st) : mvfx_hsvdetector_transform_frame(&fi, &fo, &s, st);
-    if (rc == MVFX_OK)
-        rc = mvfx_stream_synchronize(st);
+    mvfx_hip_buffer_release(inbuf, st);  // the reader's fence too: the block may be recycled and overwritten next
+    mvfx_hip_buffer_release(outbuf, st);
     gst_buffer_unmap(outbuf, &omap);
     gst_buffer_unmap(inbuf, &imap);
     return MVFX_GST_FLOW(self, rc);

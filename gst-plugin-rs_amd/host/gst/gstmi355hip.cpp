@@ -5,12 +5,15 @@
 #include "mvfx_gst_common.h"
 #include "mvfxhipmemory.h"
 
+#include <gst/base/gstpushsrc.h>
+
 GST_DEBUG_CATEGORY_STATIC(mi355hip_debug);
 
 struct GstMi355HipCopy {
     GstBaseTransform parent;
     GstVideoInfo info;
     gboolean have_info;
+    GstBufferPool *pinned; // hipdownload: page-locked system-memory output buffers (D2H is then a plain DMA)
 };
 struct GstMi355HipCopyClass {
     GstBaseTransformClass parent_class;
@@ -37,6 +40,11 @@ static gboolean hipcopy_set_caps(GstBaseTransform *trans, GstCaps *incaps, GstCa
 {
     GstMi355HipCopy *self = (GstMi355HipCopy *)trans;
     self->have_info = gst_video_info_from_caps(&self->info, incaps);
+    if (self->pinned) {
+        gst_buffer_pool_set_active(self->pinned, FALSE);
+        gst_object_unref(self->pinned);
+        self->pinned = NULL;
+    }
     return self->have_info;
 }
 
@@ -58,6 +66,19 @@ static GstFlowReturn hipcopy_prepare_output_buffer(GstBaseTransform *trans, GstB
             }
             gst_object_unref(pool);
         }
+    }
+    if (!upload) { // page-locked system memory of our own pool; MVFX_HIP_PAGEABLE=1 keeps malloc'ed buffers (A/B measurements)
+        if (!self->pinned && !g_getenv("MVFX_HIP_PAGEABLE")) {
+            GstCaps *caps = gst_video_info_to_caps(&self->info);
+            self->pinned = mvfx_pinned_buffer_pool_new_configured(caps, (guint)GST_VIDEO_INFO_SIZE(&self->info), 0);
+            gst_caps_unref(caps);
+            if (self->pinned && !gst_buffer_pool_set_active(self->pinned, TRUE)) {
+                gst_object_unref(self->pinned);
+                self->pinned = NULL;
+            }
+        }
+        if (self->pinned && gst_buffer_pool_acquire_buffer(self->pinned, outbuf, NULL) != GST_FLOW_OK)
+            *outbuf = NULL;
     }
     if (!*outbuf) {
         GstAllocator *alloc = upload ? mvfx_hip_allocator_get() : NULL;
@@ -83,7 +104,21 @@ static gboolean hipcopy_propose_allocation(GstBaseTransform *trans, GstQuery *de
 {
     if (!GST_BASE_TRANSFORM_CLASS(hipcopy_parent_class)->propose_allocation(trans, decide_query, query))
         return FALSE;
-    mvfx_hip_propose_allocation(query); // no-op unless the sink caps carry memory:HIPMemory
+    if (mvfx_hip_propose_allocation(query)) // hipdownload: the sink caps carry memory:HIPMemory
+        return TRUE;
+    // hipupload: offer upstream a pool of page-locked system memory -- a source that fills our buffers makes the H2D copy a
+    // plain DMA at PCIe speed instead of the runtime's chunked staging of pageable memory
+    GstCaps *caps = NULL;
+    gboolean need_pool = FALSE;
+    gst_query_parse_allocation(query, &caps, &need_pool);
+    GstVideoInfo info;
+    if (caps && gst_video_info_from_caps(&info, caps) && !g_getenv("MVFX_HIP_PAGEABLE")) {
+        const guint size = (guint)GST_VIDEO_INFO_SIZE(&info);
+        GstBufferPool *pool = need_pool ? mvfx_pinned_buffer_pool_new_configured(caps, size, 2) : NULL;
+        gst_query_add_allocation_pool(query, pool, size, 2, 0);
+        if (pool) gst_object_unref(pool);
+        gst_query_add_allocation_meta(query, GST_VIDEO_META_API_TYPE, NULL);
+    }
     return TRUE;
 }
 
@@ -102,6 +137,10 @@ static GstFlowReturn hipcopy_transform(GstBaseTransform *trans, GstBuffer *inbuf
         return GST_FLOW_NOT_NEGOTIATED;
     }
     int rc = MVFX_OK;
+    // the copies run on this thread's stream behind the fence of the device block (its producer, or the last reader of a
+    // recycled block); the system-memory side is only borrowed, so the call returns when the copy has landed
+    mvfx_stream st = mvfx_thread_stream();
+    mvfx_hip_buffer_acquire(dev, st);
     // device buffers always use the default GstVideoInfo layout (offsets / strides of `info`)
     for (guint p = 0; p < GST_VIDEO_INFO_N_PLANES(&self->info) && rc == MVFX_OK; p++) {
         guint8 *d = dmap.data + GST_VIDEO_INFO_PLANE_OFFSET(&self->info, p);
@@ -109,17 +148,29 @@ static GstFlowReturn hipcopy_transform(GstBaseTransform *trans, GstBuffer *inbuf
         const gint dstride = GST_VIDEO_INFO_PLANE_STRIDE(&self->info, p), sstride = GST_VIDEO_FRAME_PLANE_STRIDE(&frame, p);
         const guint rows = GST_VIDEO_FRAME_COMP_HEIGHT(&frame, p == 3 ? 3 : p);
         if (dstride == sstride) {
-            rc = upload ? mvfx_copy_to_device(d, s, (size_t)dstride * rows, NULL) : mvfx_copy_to_host(s, d, (size_t)dstride * rows, NULL);
+            rc = upload ? mvfx_copy_to_device_async(d, s, (size_t)dstride * rows, st) : mvfx_copy_to_host_async(s, d, (size_t)dstride * rows, st);
         } else {
             const size_t row = (size_t)MIN(dstride, sstride);
             for (guint y = 0; y < rows && rc == MVFX_OK; y++)
-                rc = upload ? mvfx_copy_to_device(d + (size_t)y * dstride, s + (size_t)y * sstride, row, NULL)
-                            : mvfx_copy_to_host(s + (size_t)y * sstride, d + (size_t)y * dstride, row, NULL);
+                rc = upload ? mvfx_copy_to_device_async(d + (size_t)y * dstride, s + (size_t)y * sstride, row, st)
+                            : mvfx_copy_to_host_async(s + (size_t)y * sstride, d + (size_t)y * dstride, row, st);
         }
     }
+    if (rc == MVFX_OK) rc = mvfx_stream_synchronize(st);
     gst_buffer_unmap(dev, &dmap);
     gst_video_frame_unmap(&frame);
     return MVFX_GST_FLOW(trans, rc);
+}
+
+static gboolean hipcopy_stop(GstBaseTransform *trans)
+{
+    GstMi355HipCopy *self = (GstMi355HipCopy *)trans;
+    if (self->pinned) {
+        gst_buffer_pool_set_active(self->pinned, FALSE);
+        gst_object_unref(self->pinned);
+        self->pinned = NULL;
+    }
+    return TRUE;
 }
 
 static void hipcopy_class_init_common(GstMi355HipCopyClass *klass, gboolean upload)
@@ -144,12 +195,17 @@ static void hipcopy_class_init_common(GstMi355HipCopyClass *klass, gboolean uplo
     bt->decide_allocation = hipcopy_decide_allocation;
     bt->propose_allocation = hipcopy_propose_allocation;
     bt->transform = hipcopy_transform;
+    bt->stop = hipcopy_stop;
     bt->passthrough_on_same_caps = FALSE;
 }
 
 static void hipupload_class_init(gpointer klass, gpointer) { hipcopy_class_init_common((GstMi355HipCopyClass *)klass, TRUE); }
 static void hipdownload_class_init(gpointer klass, gpointer) { hipcopy_class_init_common((GstMi355HipCopyClass *)klass, FALSE); }
-static void hipcopy_init(GTypeInstance *inst, gpointer) { ((GstMi355HipCopy *)inst)->have_info = FALSE; }
+static void hipcopy_init(GTypeInstance *inst, gpointer)
+{
+    ((GstMi355HipCopy *)inst)->have_info = FALSE;
+    ((GstMi355HipCopy *)inst)->pinned = NULL;
+}
 
 static GType hipcopy_register(const gchar *name, GClassInitFunc class_init)
 {
@@ -162,11 +218,139 @@ static GType hipcopy_register(const gchar *name, GClassInitFunc class_init)
     return g_type_register_static(GST_TYPE_BASE_TRANSFORM, name, &info, (GTypeFlags)0);
 }
 
+
+// ------------------------------------------------------------------------------------ hiptestsrc
+// A generator-free frame source for throughput measurements (tools/bench_gst_pipeline.py): videotestsrc spends more time
+// painting a 4K frame than the whole filter chain needs.  Every buffer of the negotiated pool is filled ONCE with a
+// pseudo-random frame (system memory: a memcpy; memory:HIPMemory: one H2D copy) and then handed out again as it comes
+// back from downstream, whatever it then contains -- in the steady state create() costs nothing on either path.
+struct GstMi355HipTestSrc {
+    GstPushSrc parent;
+    GstVideoInfo info;
+    gboolean have_info, hip;
+    guint8 *pattern;
+    gsize pattern_size;
+    guint64 n;
+};
+struct GstMi355HipTestSrcClass { GstPushSrcClass parent_class; };
+G_DEFINE_TYPE(GstMi355HipTestSrc, gst_mi355_hip_test_src, GST_TYPE_PUSH_SRC)
+
+static GQuark hiptestsrc_filled_quark(void) { return g_quark_from_static_string("mvfx-hiptestsrc-filled"); }
+
+static GstCaps *hiptestsrc_fixate(GstBaseSrc *src, GstCaps *caps)
+{
+    caps = gst_caps_make_writable(caps);
+    GstStructure *s = gst_caps_get_structure(caps, 0);
+    gst_structure_fixate_field_string(s, "format", "RGBA");
+    gst_structure_fixate_field_nearest_int(s, "width", 320);
+    gst_structure_fixate_field_nearest_int(s, "height", 240);
+    gst_structure_fixate_field_nearest_fraction(s, "framerate", 30, 1);
+    return GST_BASE_SRC_CLASS(gst_mi355_hip_test_src_parent_class)->fixate(src, caps);
+}
+
+static gboolean hiptestsrc_set_caps(GstBaseSrc *src, GstCaps *caps)
+{
+    GstMi355HipTestSrc *self = (GstMi355HipTestSrc *)src;
+    self->have_info = gst_video_info_from_caps(&self->info, caps);
+    if (!self->have_info) return FALSE;
+    self->hip = mvfx_caps_has_hip_feature(caps);
+    g_free(self->pattern);
+    self->pattern_size = GST_VIDEO_INFO_SIZE(&self->info);
+    self->pattern = (guint8 *)g_malloc(self->pattern_size);
+    guint64 x = 0x5EED0001ull; // splitmix64 bytes
+    for (gsize i = 0; i < self->pattern_size; i += 8) {
+        x += 0x9E3779B97F4A7C15ull;
+        guint64 z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        memcpy(self->pattern + i, &z, MIN((gsize)8, self->pattern_size - i));
+    }
+    gst_base_src_set_blocksize(src, (guint)self->pattern_size);
+    return TRUE;
+}
+
+static gboolean hiptestsrc_decide_allocation(GstBaseSrc *src, GstQuery *query)
+{
+    mvfx_hip_decide_allocation(query); // HIP pool when the caps carry memory:HIPMemory; otherwise downstream's (pinned) pool or the default
+    return GST_BASE_SRC_CLASS(gst_mi355_hip_test_src_parent_class)->decide_allocation(src, query);
+}
+
+static GstFlowReturn hiptestsrc_fill(GstPushSrc *psrc, GstBuffer *buf)
+{
+    GstMi355HipTestSrc *self = (GstMi355HipTestSrc *)psrc;
+    if (!self->have_info) return GST_FLOW_NOT_NEGOTIATED;
+    GstMemory *mem = gst_buffer_peek_memory(buf, 0);
+    if (!gst_mini_object_get_qdata(GST_MINI_OBJECT_CAST(mem), hiptestsrc_filled_quark())) {
+        GstMapInfo map;
+        if (self->hip && mvfx_buffer_is_hip(buf)) {
+            if (!gst_buffer_map(buf, &map, (GstMapFlags)(MVFX_MAP_HIP | GST_MAP_WRITE))) return GST_FLOW_ERROR;
+            mvfx_hip_memory_wait(mem);
+            const int rc = mvfx_copy_to_device(map.data, self->pattern, MIN(self->pattern_size, map.size), NULL);
+            gst_buffer_unmap(buf, &map);
+            if (rc != MVFX_OK) return MVFX_GST_FLOW(self, rc);
+        } else {
+            if (!gst_buffer_map(buf, &map, GST_MAP_WRITE)) return GST_FLOW_ERROR;
+            memcpy(map.data, self->pattern, MIN(self->pattern_size, map.size));
+            gst_buffer_unmap(buf, &map);
+        }
+        gst_mini_object_set_qdata(GST_MINI_OBJECT_CAST(mem), hiptestsrc_filled_quark(), GINT_TO_POINTER(1), NULL);
+    }
+    const GstClockTime dur = GST_VIDEO_INFO_FPS_N(&self->info) > 0
+        ? gst_util_uint64_scale_int(GST_SECOND, GST_VIDEO_INFO_FPS_D(&self->info), GST_VIDEO_INFO_FPS_N(&self->info)) : GST_CLOCK_TIME_NONE;
+    GST_BUFFER_PTS(buf) = GST_CLOCK_TIME_IS_VALID(dur) ? self->n * dur : GST_CLOCK_TIME_NONE;
+    GST_BUFFER_DTS(buf) = GST_CLOCK_TIME_NONE;
+    GST_BUFFER_DURATION(buf) = dur;
+    GST_BUFFER_OFFSET(buf) = self->n++;
+    return GST_FLOW_OK;
+}
+
+static gboolean hiptestsrc_start(GstBaseSrc *src)
+{
+    ((GstMi355HipTestSrc *)src)->n = 0;
+    return TRUE;
+}
+
+static void gst_mi355_hip_test_src_finalize(GObject *obj)
+{
+    g_free(((GstMi355HipTestSrc *)obj)->pattern);
+    G_OBJECT_CLASS(gst_mi355_hip_test_src_parent_class)->finalize(obj);
+}
+
+static void gst_mi355_hip_test_src_class_init(GstMi355HipTestSrcClass *klass)
+{
+    GstElementClass *element = GST_ELEMENT_CLASS(klass);
+    GstBaseSrcClass *bs = GST_BASE_SRC_CLASS(klass);
+    G_OBJECT_CLASS(klass)->finalize = gst_mi355_hip_test_src_finalize;
+    GstCaps *sys = gst_caps_new_empty_simple("video/x-raw");
+    GstCaps *both = mvfx_caps_plus_hip(sys);
+    gst_element_class_add_pad_template(element, gst_pad_template_new("src", GST_PAD_SRC, GST_PAD_ALWAYS, both));
+    gst_caps_unref(both);
+    gst_element_class_set_static_metadata(element, "HIP test source", "Source/Video",
+                                          "Pre-generated pseudo-random video frames in system or memory:HIPMemory buffers (no per-frame generator cost)",
+                                          "mi355-vfx");
+    bs->fixate = hiptestsrc_fixate;
+    bs->set_caps = hiptestsrc_set_caps;
+    bs->decide_allocation = hiptestsrc_decide_allocation;
+    bs->start = hiptestsrc_start;
+    GST_PUSH_SRC_CLASS(klass)->fill = hiptestsrc_fill;
+}
+
+static void gst_mi355_hip_test_src_init(GstMi355HipTestSrc *self)
+{
+    self->have_info = self->hip = FALSE;
+    self->pattern = NULL;
+    self->pattern_size = 0;
+    self->n = 0;
+    gst_base_src_set_format(GST_BASE_SRC(self), GST_FORMAT_TIME);
+}
+
 static gboolean plugin_init(GstPlugin *plugin)
 {
     GST_DEBUG_CATEGORY_INIT(mi355hip_debug, "mi355hip", 0, "MI355X HIP memory upload/download");
     return gst_element_register(plugin, "hipupload", GST_RANK_NONE, hipcopy_register("GstMi355HipUpload", hipupload_class_init)) &&
-           gst_element_register(plugin, "hipdownload", GST_RANK_NONE, hipcopy_register("GstMi355HipDownload", hipdownload_class_init));
+           gst_element_register(plugin, "hipdownload", GST_RANK_NONE, hipcopy_register("GstMi355HipDownload", hipdownload_class_init)) &&
+           gst_element_register(plugin, "hiptestsrc", GST_RANK_NONE, gst_mi355_hip_test_src_get_type());
 }
 
 GST_PLUGIN_DEFINE(GST_VERSION_MAJOR, GST_VERSION_MINOR, mi355hip, "MI355X HIP device-memory bridge elements", plugin_init,

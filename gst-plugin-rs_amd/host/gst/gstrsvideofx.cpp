@@ -149,6 +149,7 @@ static GstFlowReturn gst_color_detect_bt_transform_ip(GstBaseTransform *bt, GstB
         return GST_FLOW_ERROR;
     uint32_t palette[256];
     uint32_t n = 0;
+    mvfx_hip_buffer_acquire(buf, mvfx_thread_stream()); // the producer's fence; the call itself returns the palette (sync)
     const int rc = mvfx_colordetect_palette(&f, quality, max_colors, palette, &n, mvfx_thread_stream());
     gst_buffer_unmap(buf, &map);
     if (rc != MVFX_OK) {
@@ -439,9 +440,12 @@ static GstFlowReturn gst_rounded_corners_prepare_output_buffer(GstBaseTransform 
         pi.height = po.height = (uint32_t)GST_VIDEO_INFO_HEIGHT(&self->out_info);
         pi.format = MVFX_FORMAT_I420;
         po.format = MVFX_FORMAT_A420;
+        mvfx_hip_buffer_acquire(inbuf, mvfx_thread_stream());
+        mvfx_hip_buffer_acquire(out, mvfx_thread_stream());
         int rc = mvfx_roundedcorners_compose_a420(&pi, amap.data, (uint32_t)GST_VIDEO_INFO_PLANE_STRIDE(&self->out_info, 3), &po,
                                                   mvfx_thread_stream());
-        if (rc == MVFX_OK) rc = mvfx_stream_synchronize(mvfx_thread_stream());
+        mvfx_hip_buffer_release(inbuf, mvfx_thread_stream());
+        mvfx_hip_buffer_release(out, mvfx_thread_stream());
         gst_memory_unmap(self->alpha_mem, &amap);
         gst_buffer_unmap(out, &omap);
         gst_buffer_unmap(inbuf, &imap);
@@ -690,6 +694,7 @@ static int compare_view_open(GstPad *pad, GstBuffer *buf, CompareView *v)
         if (!mvfx_hip_map_frame(buf, &info, GST_MAP_READ, &v->map, &v->f))
             return MVFX_ERR_INVALID_ARGUMENT;
         v->device = v->mapped_hip = TRUE;
+        mvfx_hip_buffer_acquire(buf, mvfx_thread_stream()); // the producer's fence; the hash / distance calls below synchronise
         GST_CAT_LOG_OBJECT(videocompare_debug, pad, "frame of %" GST_PTR_FORMAT " stays in device memory", pad);
         return MVFX_OK;
     }

@@ -8,10 +8,15 @@
 typedef struct {
     GstMemory mem;
     void *dptr;       // hipMalloc'ed
+    int device;       // ordinal the block lives on
     guint8 *shadow;   // host copy while CPU-mapped
     GstMapFlags shadow_flags;
     gint cpu_maps;
     GMutex lock;
+    // the fence of the buffer (d3d12colorlut/imp.rs:695-714 keeps an ID3D12Fence value on the output memory): recorded by
+    // the last stream that enqueued work on the block; the next user makes its stream wait for it, a CPU map waits on the host
+    mvfx_event last_use;
+    gboolean pending;
 } MvfxHipMemory;
 
 typedef struct { GstAllocator parent; } MvfxHipAllocator;
@@ -19,42 +24,81 @@ typedef struct { GstAllocatorClass parent_class; } MvfxHipAllocatorClass;
 
 G_DEFINE_TYPE(MvfxHipAllocator, mvfx_hip_allocator, GST_TYPE_ALLOCATOR)
 
-// Small free list keyed by size: video buffers of one stream all have the same size, so a freed
-// block is handed to the next allocation instead of paying hipFree + hipMalloc per frame.
+// Small free list keyed by (device, size): video buffers of one stream all have the same size, so a freed
+// block is handed to the next allocation instead of paying hipFree + hipMalloc per frame.  The block keeps its
+// fence: work still in flight on it when the buffer was dropped orders before the next owner's first kernel.
 #define MVFX_FREELIST_MAX 16
 static GMutex freelist_lock;
-static struct { void *dptr; gsize size; } freelist[MVFX_FREELIST_MAX];
+static struct { void *dptr; gsize size; int device; mvfx_event last_use; gboolean pending; } freelist[MVFX_FREELIST_MAX];
 
-static void *freelist_take(gsize size)
+static int current_device(void)
 {
-    void *p = NULL;
-    g_mutex_lock(&freelist_lock);
-    for (int i = 0; i < MVFX_FREELIST_MAX; i++)
-        if (freelist[i].dptr && freelist[i].size == size) { p = freelist[i].dptr; freelist[i].dptr = NULL; break; }
-    g_mutex_unlock(&freelist_lock);
-    return p;
+    return mvfx_current_device();
 }
 
-static gboolean freelist_give(void *dptr, gsize size)
+static gboolean freelist_take(gsize size, int device, void **dptr, mvfx_event *ev, gboolean *pending)
+{
+    gboolean found = FALSE;
+    g_mutex_lock(&freelist_lock);
+    for (int i = 0; i < MVFX_FREELIST_MAX && !found; i++)
+        if (freelist[i].dptr && freelist[i].size == size && freelist[i].device == device) {
+            *dptr = freelist[i].dptr;
+            *ev = freelist[i].last_use;
+            *pending = freelist[i].pending;
+            freelist[i].dptr = NULL;
+            found = TRUE;
+        }
+    g_mutex_unlock(&freelist_lock);
+    return found;
+}
+
+static gboolean freelist_give(void *dptr, gsize size, int device, mvfx_event ev, gboolean pending)
 {
     gboolean kept = FALSE;
     g_mutex_lock(&freelist_lock);
     for (int i = 0; i < MVFX_FREELIST_MAX && !kept; i++)
-        if (!freelist[i].dptr) { freelist[i].dptr = dptr; freelist[i].size = size; kept = TRUE; }
+        if (!freelist[i].dptr) {
+            freelist[i].dptr = dptr; freelist[i].size = size; freelist[i].device = device;
+            freelist[i].last_use = ev; freelist[i].pending = pending;
+            kept = TRUE;
+        }
     g_mutex_unlock(&freelist_lock);
     return kept;
 }
 
+void mvfx_hip_allocator_trim(void)
+{
+    g_mutex_lock(&freelist_lock);
+    for (int i = 0; i < MVFX_FREELIST_MAX; i++)
+        if (freelist[i].dptr) {
+            if (freelist[i].pending) mvfx_event_synchronize(freelist[i].last_use);
+            mvfx_device_free(freelist[i].dptr);
+            mvfx_event_destroy(freelist[i].last_use);
+            freelist[i].dptr = NULL;
+        }
+    g_mutex_unlock(&freelist_lock);
+}
+
 static GstMemory *mvfx_hip_alloc(GstAllocator *allocator, gsize size, GstAllocationParams *params)
 {
-    void *dptr = freelist_take(size);
-    if (!dptr && mvfx_device_alloc(&dptr, size) != MVFX_OK) {
-        GST_ERROR("HIP allocation of %" G_GSIZE_FORMAT " bytes failed: %s", size, mvfx_last_error());
-        return NULL;
+    void *dptr = NULL;
+    mvfx_event ev = NULL;
+    gboolean pending = FALSE;
+    const int device = current_device();
+    if (!freelist_take(size, device, &dptr, &ev, &pending)) {
+        if (mvfx_device_alloc(&dptr, size) != MVFX_OK) {
+            GST_ERROR("HIP allocation of %" G_GSIZE_FORMAT " bytes failed: %s", size, mvfx_last_error());
+            return NULL;
+        }
     }
     MvfxHipMemory *m = g_new0(MvfxHipMemory, 1);
-    gst_memory_init(GST_MEMORY_CAST(m), (GstMemoryFlags)0, allocator, NULL, size, 255, 0, size);
+    // NO_SHARE: there is no mem_share (sub-range views of device blocks are not needed by these elements);
+    // gst_buffer_copy_region / gst_buffer_resize then copy instead of calling a NULL vfunc
+    gst_memory_init(GST_MEMORY_CAST(m), GST_MEMORY_FLAG_NO_SHARE, allocator, NULL, size, 255, 0, size);
     m->dptr = dptr;
+    m->device = device;
+    m->last_use = ev;
+    m->pending = pending;
     g_mutex_init(&m->lock);
     return GST_MEMORY_CAST(m);
 }
@@ -62,18 +106,70 @@ static GstMemory *mvfx_hip_alloc(GstAllocator *allocator, gsize size, GstAllocat
 static void mvfx_hip_free(GstAllocator *, GstMemory *mem)
 {
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
-    if (!freelist_give(m->dptr, mem->maxsize))
+    if (!freelist_give(m->dptr, mem->maxsize, m->device, m->last_use, m->pending)) {
+        if (m->pending) mvfx_event_synchronize(m->last_use);
         mvfx_device_free(m->dptr);
+        mvfx_event_destroy(m->last_use);
+    }
     g_free(m->shadow);
     g_mutex_clear(&m->lock);
     g_free(m);
+}
+
+void mvfx_hip_memory_acquire(GstMemory *mem, mvfx_stream stream)
+{
+    if (!mvfx_is_hip_memory(mem)) return;
+    MvfxHipMemory *m = (MvfxHipMemory *)mem;
+    g_mutex_lock(&m->lock);
+    if (m->pending && m->last_use)
+        mvfx_stream_wait_event(stream, m->last_use); // device-side wait; the host goes on
+    g_mutex_unlock(&m->lock);
+}
+
+void mvfx_hip_memory_release(GstMemory *mem, mvfx_stream stream)
+{
+    if (!mvfx_is_hip_memory(mem)) return;
+    MvfxHipMemory *m = (MvfxHipMemory *)mem;
+    g_mutex_lock(&m->lock);
+    if (!m->last_use && mvfx_event_create(&m->last_use) != MVFX_OK)
+        m->last_use = NULL;
+    if (m->last_use && mvfx_event_record(m->last_use, stream) == MVFX_OK)
+        m->pending = TRUE;
+    else
+        mvfx_stream_synchronize(stream); // no event: fall back to a blocking hand-off
+    g_mutex_unlock(&m->lock);
+}
+
+void mvfx_hip_memory_wait(GstMemory *mem)
+{
+    if (!mvfx_is_hip_memory(mem)) return;
+    MvfxHipMemory *m = (MvfxHipMemory *)mem;
+    g_mutex_lock(&m->lock);
+    if (m->pending && m->last_use) {
+        mvfx_event_synchronize(m->last_use);
+        m->pending = FALSE;
+    }
+    g_mutex_unlock(&m->lock);
+}
+
+void mvfx_hip_buffer_acquire(GstBuffer *buf, mvfx_stream stream)
+{
+    for (guint i = 0; buf && i < gst_buffer_n_memory(buf); i++)
+        mvfx_hip_memory_acquire(gst_buffer_peek_memory(buf, i), stream);
+}
+
+void mvfx_hip_buffer_release(GstBuffer *buf, mvfx_stream stream)
+{
+    for (guint i = 0; buf && i < gst_buffer_n_memory(buf); i++)
+        mvfx_hip_memory_release(gst_buffer_peek_memory(buf, i), stream);
 }
 
 static gpointer mvfx_hip_map_full(GstMemory *mem, GstMapInfo *info, gsize maxsize)
 {
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
     if (info->flags & MVFX_MAP_HIP)
-        return m->dptr; // device pointer, zero copy
+        return m->dptr; // device pointer, zero copy; the caller orders its work with mvfx_hip_memory_acquire / _release
+    mvfx_hip_memory_wait(mem); // a CPU reader / writer needs the enqueued work finished
     g_mutex_lock(&m->lock);
     if (m->cpu_maps == 0) {
         m->shadow = (guint8 *)g_malloc(mem->maxsize);
@@ -112,9 +208,11 @@ static GstMemory *mvfx_hip_copy(GstMemory *mem, gssize offset, gssize size)
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
     if (size == -1)
         size = mem->size > (gsize)offset ? mem->size - offset : 0;
+    mvfx_hip_memory_wait(mem);
     GstMemory *copy = mvfx_hip_alloc(mem->allocator, size, NULL);
     if (!copy)
         return NULL;
+    mvfx_hip_memory_wait(copy); // a recycled block may still have a reader in flight
     if (mvfx_copy_device_to_device(((MvfxHipMemory *)copy)->dptr, (guint8 *)m->dptr + mem->offset + offset, size, NULL) != MVFX_OK) {
         gst_memory_unref(copy);
         return NULL;
@@ -136,7 +234,7 @@ static void mvfx_hip_allocator_init(MvfxHipAllocator *self)
     a->mem_map_full = mvfx_hip_map_full;
     a->mem_unmap_full = mvfx_hip_unmap_full;
     a->mem_copy = mvfx_hip_copy;
-    // no mem_share: sub-buffers of device memory are not needed by these elements
+    // no mem_share: memories are created GST_MEMORY_FLAG_NO_SHARE
     GST_OBJECT_FLAG_SET(a, GST_ALLOCATOR_FLAG_CUSTOM_ALLOC);
 }
 
@@ -284,6 +382,96 @@ static GstBufferPool *new_configured_pool(GstCaps *caps, guint size)
     GstBufferPool *pool = mvfx_hip_buffer_pool_new();
     GstStructure *config = gst_buffer_pool_get_config(pool);
     gst_buffer_pool_config_set_params(config, caps, size, 0, 0);
+    gst_buffer_pool_config_add_option(config, GST_BUFFER_POOL_OPTION_VIDEO_META);
+    if (!gst_buffer_pool_set_config(pool, config)) {
+        gst_object_unref(pool);
+        return NULL;
+    }
+    return pool;
+}
+
+// ------------------------------------------------------------------------------------ pinned host pool
+
+typedef struct {
+    GstBufferPool parent;
+    GstVideoInfo info;
+    gboolean have_info;
+    gsize size;
+} MvfxPinnedBufferPool;
+typedef struct { GstBufferPoolClass parent_class; } MvfxPinnedBufferPoolClass;
+
+G_DEFINE_TYPE(MvfxPinnedBufferPool, mvfx_pinned_buffer_pool, GST_TYPE_BUFFER_POOL)
+
+static const gchar **mvfx_pinned_pool_get_options(GstBufferPool *)
+{
+    static const gchar *options[] = {GST_BUFFER_POOL_OPTION_VIDEO_META, NULL};
+    return options;
+}
+
+static gboolean mvfx_pinned_pool_set_config(GstBufferPool *pool, GstStructure *config)
+{
+    MvfxPinnedBufferPool *self = (MvfxPinnedBufferPool *)pool;
+    GstCaps *caps = NULL;
+    guint size = 0, min = 0, max = 0;
+    if (!gst_buffer_pool_config_get_params(config, &caps, &size, &min, &max) || !caps)
+        return FALSE;
+    self->have_info = gst_video_info_from_caps(&self->info, caps);
+    if (self->have_info && GST_VIDEO_INFO_SIZE(&self->info) > size) {
+        size = (guint)GST_VIDEO_INFO_SIZE(&self->info);
+        gst_buffer_pool_config_set_params(config, caps, size, min, max);
+    }
+    self->size = size;
+    return GST_BUFFER_POOL_CLASS(mvfx_pinned_buffer_pool_parent_class)->set_config(pool, config);
+}
+
+static void pinned_block_free(gpointer block) { mvfx_host_free(block); }
+
+static GstFlowReturn mvfx_pinned_pool_alloc_buffer(GstBufferPool *pool, GstBuffer **buffer, GstBufferPoolAcquireParams *)
+{
+    MvfxPinnedBufferPool *self = (MvfxPinnedBufferPool *)pool;
+    void *block = NULL;
+    GstBuffer *buf;
+    if (mvfx_host_alloc(&block, self->size) == MVFX_OK) {
+        buf = gst_buffer_new_wrapped_full((GstMemoryFlags)0, block, self->size, 0, self->size, block, pinned_block_free);
+    } else { // still system memory, only slower to copy from / to
+        GST_WARNING("pinned host allocation of %" G_GSIZE_FORMAT " bytes failed (%s): pageable buffer instead", self->size, mvfx_last_error());
+        buf = gst_buffer_new_allocate(NULL, self->size, NULL);
+        if (!buf) return GST_FLOW_ERROR;
+    }
+    if (self->have_info)
+        gst_buffer_add_video_meta_full(buf, GST_VIDEO_FRAME_FLAG_NONE, GST_VIDEO_INFO_FORMAT(&self->info),
+                                       GST_VIDEO_INFO_WIDTH(&self->info), GST_VIDEO_INFO_HEIGHT(&self->info),
+                                       GST_VIDEO_INFO_N_PLANES(&self->info), self->info.offset, self->info.stride);
+    *buffer = buf;
+    return GST_FLOW_OK;
+}
+
+static void mvfx_pinned_buffer_pool_class_init(MvfxPinnedBufferPoolClass *klass)
+{
+    GstBufferPoolClass *pc = GST_BUFFER_POOL_CLASS(klass);
+    pc->get_options = mvfx_pinned_pool_get_options;
+    pc->set_config = mvfx_pinned_pool_set_config;
+    pc->alloc_buffer = mvfx_pinned_pool_alloc_buffer;
+}
+
+static void mvfx_pinned_buffer_pool_init(MvfxPinnedBufferPool *self)
+{
+    self->have_info = FALSE;
+    self->size = 0;
+}
+
+GstBufferPool *mvfx_pinned_buffer_pool_new(void)
+{
+    GstBufferPool *pool = (GstBufferPool *)g_object_new(mvfx_pinned_buffer_pool_get_type(), NULL);
+    gst_object_ref_sink(pool);
+    return pool;
+}
+
+GstBufferPool *mvfx_pinned_buffer_pool_new_configured(GstCaps *caps, guint size, guint min_buffers)
+{
+    GstBufferPool *pool = mvfx_pinned_buffer_pool_new();
+    GstStructure *config = gst_buffer_pool_get_config(pool);
+    gst_buffer_pool_config_set_params(config, caps, size, min_buffers, 0);
     gst_buffer_pool_config_add_option(config, GST_BUFFER_POOL_OPTION_VIDEO_META);
     if (!gst_buffer_pool_set_config(pool, config)) {
         gst_object_unref(pool);

@@ -18,6 +18,19 @@ G_BEGIN_DECLS
 #define MVFX_MAP_HIP ((GstMapFlags)(GST_MAP_FLAG_LAST << 1))
 
 GstAllocator *mvfx_hip_allocator_get(void);           // singleton, new reference
+void mvfx_hip_allocator_trim(void);                   // returns the cached device blocks of the free list to HIP
+
+// ---- fences instead of per-buffer stream synchronisation (d3d12colorlut/imp.rs:695-714 sets a fence on the output
+// memory and returns).  An element brackets the kernels it enqueues on `stream` for a device buffer:
+//     mvfx_hip_buffer_acquire(buf, stream);   // stream waits (on the device) for whoever used the block last
+//     ... launch ...
+//     mvfx_hip_buffer_release(buf, stream);   // record the block's fence on the stream; no host wait
+// A CPU map of the memory (and hipdownload) waits for the fence on the host.
+void mvfx_hip_memory_acquire(GstMemory *mem, void *stream);
+void mvfx_hip_memory_release(GstMemory *mem, void *stream);
+void mvfx_hip_memory_wait(GstMemory *mem);
+void mvfx_hip_buffer_acquire(GstBuffer *buf, void *stream);
+void mvfx_hip_buffer_release(GstBuffer *buf, void *stream);
 gboolean mvfx_is_hip_memory(GstMemory *mem);
 gboolean mvfx_buffer_is_hip(GstBuffer *buf);          // single HIP memory holding the whole frame
 gboolean mvfx_caps_has_hip_feature(const GstCaps *caps);
@@ -37,6 +50,10 @@ gboolean mvfx_hip_propose_allocation(GstQuery *query);
 // decide_allocation of an element whose SRC caps carry memory:HIPMemory: makes sure pool 0 of the query is a
 // HIP pool (the one downstream proposed, or a new one).  Call before chaining up to the base class.
 gboolean mvfx_hip_decide_allocation(GstQuery *query);
+// System-memory buffers backed by page-locked host memory (hipHostMalloc): what hipupload offers upstream and what
+// hipdownload hands downstream, so that the PCIe copies are plain DMA instead of the runtime's pageable staging.
+GstBufferPool *mvfx_pinned_buffer_pool_new(void);
+GstBufferPool *mvfx_pinned_buffer_pool_new_configured(GstCaps *caps, guint size, guint min_buffers);
 guint64 mvfx_hip_pool_buffers_allocated(void);        // process-wide counters for tests / debugging
 guint64 mvfx_hip_pool_buffers_acquired(void);
 

@@ -88,6 +88,7 @@ const char *mvfx_last_error(void);        /* thread-local, never NULL */
 const char *mvfx_status_string(int status);
 int mvfx_device_count(void);              /* 0 when no HIP device is visible */
 int mvfx_set_device(int ordinal);
+int mvfx_current_device(void);            /* ordinal of the calling thread's current device, -1 without a device */
 int mvfx_stream_synchronize(mvfx_stream stream);
 
 /* Device buffers for callers that do not bring their own allocator (tests, the element
@@ -100,6 +101,26 @@ int mvfx_copy_device_to_device(void *dst_device, const void *src_device, size_t 
 /* The calling thread's private non-blocking stream (the one the *_host entry points use); lets an
  * element layer issue the device entry points of one streaming thread in order. */
 mvfx_stream mvfx_thread_stream(void);
+
+/* ---- events: the fence a device-memory element leaves on its output instead of blocking ----
+ * What the reference's d3d12colorlut does with ID3D12Fence (set a fence value on the output memory and return,
+ * d3d12colorlut/imp.rs:695-714): the producer records an event on its stream after the last kernel that touches a
+ * buffer, the next user makes ITS stream wait for it (device-side wait, the host never blocks) and a CPU map waits on
+ * the host.  hipEvent_t passed through as an opaque pointer. */
+typedef void *mvfx_event;
+int mvfx_event_create(mvfx_event *out);
+int mvfx_event_destroy(mvfx_event event);
+int mvfx_event_record(mvfx_event event, mvfx_stream stream);
+int mvfx_stream_wait_event(mvfx_stream stream, mvfx_event event);
+int mvfx_event_synchronize(mvfx_event event);
+
+/* Page-locked host memory (hipHostMalloc) for upload / download staging: a copy from or to it is a real DMA at PCIe
+ * speed instead of the runtime's chunked staging of pageable memory; and copies that do NOT synchronise (the caller
+ * orders them with the stream / an event; the host block must stay valid until then). */
+int mvfx_host_alloc(void **out_ptr, size_t bytes);
+int mvfx_host_free(void *ptr);
+int mvfx_copy_to_device_async(void *dst_device, const void *src_host, size_t bytes, mvfx_stream stream);
+int mvfx_copy_to_host_async(void *dst_host, const void *src_device, size_t bytes, mvfx_stream stream);
 
 /* ---- per-thread kernel options ----
  * The calling thread is the library's implicit context: its private stream (mvfx_thread_stream), its staging scratch

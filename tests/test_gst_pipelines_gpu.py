@@ -354,3 +354,40 @@ def test_hsvdetector_on_hipmemory_i420_equals_videoconvert_then_detector(gpu, tm
     assert fused.size == ref.size == 2 * w * h * 4
     assert np.array_equal(fused, ref), np.argwhere(fused != ref)[:8]
     assert 0 < np.count_nonzero(fused[3::4]) < fused.size // 4
+
+
+def test_hipmemory_chain_with_fences_across_streaming_threads(gpu, tmp_path):
+    """Every element only records / waits for the fence of the device block (no host wait per buffer,
+    d3d12colorlut/imp.rs:695-714).  `queue`s put the three filters on three streaming threads = three HIP streams, 1080p
+    frames keep several kernels in flight, pools recycle blocks whose last reader may still be running: all 12 frames must
+    still be bit-exact.  Source: hiptestsrc (pre-filled pinned pool buffers offered by hipupload)."""
+    cube = tmp_path / "look.cube"
+    cube.write_text(cubes.analytic_3d(17))
+    w, h, n = 1920, 1080, 12
+    src = f"hiptestsrc num-buffers={{n}} ! video/x-raw,format=RGBx,width={w},height={h},framerate=30/1"
+    raw = _capture(tmp_path, src.format(n=1), "in.raw")
+    assert raw.size == w * h * 4 and len(np.unique(raw[:4096])) > 100
+    r = gst_env.run([LAUNCH, "-q"] + (src.format(n=n) + " ! hipupload ! queue ! hsvfilter hue-shift=45 ! queue ! hsvdetector hue-ref=120 "
+                    "hue-var=60 saturation-ref=0.6 saturation-var=0.4 value-ref=0.6 value-var=0.4 ! video/x-raw(memory:HIPMemory),format=RGBA "
+                    f"! queue ! colorlut location={cube} ! queue ! hipdownload ! filesink location={tmp_path}/out.raw").split(), tmp_path)
+    assert r.returncode == 0, r.stdout
+    got = np.fromfile(f"{tmp_path}/out.raw", dtype=np.uint8).reshape(n, h, w * 4)
+    mid = raw.copy().reshape(h, w * 4)
+    orc.hsvfilter(mid, w, w * 4, "RGBx", (45.0, 1.0, 0.0, 1.0, 0.0))
+    det = np.empty_like(mid)
+    orc.hsvdetector(mid, w * 4, "RGBx", det, w * 4, "RGBA", w, (120.0, 60.0, 0.6, 0.4, 0.6, 0.4))
+    exp = np.empty_like(det)
+    assert orc.CubeLut(cube.read_text()).apply(det, w * 4, exp, w * 4, w, h, "RGBA") == 0
+    for k in range(n):
+        assert np.array_equal(got[k], exp), f"frame {k} differs"
+
+
+def test_hiptestsrc_device_memory_source(gpu, tmp_path):
+    """hiptestsrc negotiates memory:HIPMemory directly (frames born in HBM): first pass of every pool buffer is the pattern"""
+    w, h = 320, 240
+    raw = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBA,width={w},height={h}", "in.raw")
+    got = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw(memory:HIPMemory),format=RGBA,width={w},height={h} ! hsvfilter hue-shift=90 "
+                   "! hipdownload", "out.raw")
+    exp = raw.copy().reshape(h, w * 4)
+    orc.hsvfilter(exp, w, w * 4, "RGBA", (90.0, 1.0, 0.0, 1.0, 0.0))
+    assert np.array_equal(got.reshape(exp.shape), exp)

@@ -1,9 +1,20 @@
 #!/usr/bin/env python3
-"""tools/bench_gst_pipeline.py -- pipeline-level frames/s of the real GStreamer elements, host path
-(system-memory buffers: H2D + kernel + D2H inside every element) vs device path
-(`memory:HIPMemory`: one hipupload, N elements in HBM, one hipdownload).  The source is a looped
-raw frame from RAM (multifilesrc-free: videotestsrc pattern=black is the cheapest generator in the
-image), so the numbers bound the element chain, not the generator.  Run on the GPU box."""
+"""tools/bench_gst_pipeline.py -- pipeline-level frames/s of the real GStreamer elements at 3840x2160:
+
+  host chain:  hiptestsrc ! hsvfilter ! hsvdetector ! colorlut ! fakesink               (system-memory buffers: every element
+                                                                                         does H2D + kernel + D2H, as a drop-in
+                                                                                         for the reference's CPU elements must)
+  HIP chain:   hiptestsrc ! hipupload ! hsvfilter ! hsvdetector ! colorlut ! hipdownload ! fakesink
+                                                                                        (memory:HIPMemory between the elements:
+                                                                                         one upload, three kernels ordered by
+                                                                                         fences, one download)
+  device only: hiptestsrc(memory:HIPMemory) ! hsvfilter ! hsvdetector ! colorlut ! fakesink   (no PCIe at all)
+
+`hiptestsrc` hands out pre-filled pool buffers (no per-frame generator cost; videotestsrc needs longer to paint a 4K
+frame than the whole chain needs to filter it).  Every pipeline runs twice, with N1 and N2 buffers; frames/s =
+(N2 - N1) / (t2 - t1), which removes process start-up, plugin loading, LUT parsing and the first-frame allocations.
+Run on the GPU box:  python tools/bench_gst_pipeline.py [--width 3840 --height 2160]"""
+import argparse
 import json
 import os
 import sys
@@ -17,30 +28,57 @@ from tests import cubes, gst_env  # noqa: E402
 LAUNCH = gst_env.tool("gst-launch-1.0")
 
 
-def run(pipeline, tmp):
+def run(pipeline, tmp, extra_env=None):
     t0 = time.perf_counter()
-    r = gst_env.run([LAUNCH, "-q"] + pipeline.split(), tmp, timeout=600)
+    r = gst_env.run([LAUNCH, "-q"] + pipeline.split(), tmp, timeout=900, extra_env=extra_env)
     dt = time.perf_counter() - t0
     if r.returncode != 0:
-        raise RuntimeError(r.stdout)
+        raise RuntimeError(r.stdout[-3000:])
     return dt
 
 
+def fps(template, tmp, n1, n2, extra_env=None):
+    run(template.format(n=n1), tmp, extra_env)  # page cache, registry
+    t1 = min(run(template.format(n=n1), tmp, extra_env) for _ in range(2))
+    t2 = min(run(template.format(n=n2), tmp, extra_env) for _ in range(2))
+    return (n2 - n1) / (t2 - t1), t1, t2
+
+
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--n1", type=int, default=60)
+    ap.add_argument("--n2", type=int, default=460)
+    ap.add_argument("--lut", type=int, default=33)
+    args = ap.parse_args()
     tmp = tempfile.mkdtemp()
     cube = os.path.join(tmp, "look.cube")
     with open(cube, "w") as f:
-        f.write(cubes.analytic_3d(17))
-    for (w, h, n) in ((1920, 1080, 300), (3840, 2160, 120)):
-        src = f"videotestsrc pattern=black num-buffers={n} ! video/x-raw,format=RGBx,width={w},height={h}"
-        chain = ("hsvfilter hue-shift=45 ! hsvdetector hue-ref=120 hue-var=60 saturation-ref=0.6 saturation-var=0.4 "
-                 f"value-ref=0.6 value-var=0.4 ! {{caps}} ! colorlut location={cube}")
-        base = run(f"{src} ! fakesink", tmp)
-        host = run(f"{src} ! {chain.format(caps='video/x-raw,format=RGBA')} ! fakesink", tmp)
-        hip = run(f"{src} ! hipupload ! {chain.format(caps='video/x-raw(memory:HIPMemory),format=RGBA')} ! hipdownload ! fakesink", tmp)
-        print(json.dumps({"frame": f"{w}x{h}", "buffers": n, "source_only_fps": round(n / base, 1),
-                          "host_path_fps": round(n / host, 1), "hipmemory_path_fps": round(n / hip, 1),
-                          "chain": "hsvfilter ! hsvdetector ! colorlut(17^3)"}), flush=True)
+        f.write(cubes.analytic_3d(args.lut))
+    w, h = args.width, args.height
+    size = f"width={w},height={h},framerate=30/1"
+    chain = ("hsvfilter hue-shift=45 ! hsvdetector hue-ref=120 hue-var=60 saturation-ref=0.6 saturation-var=0.4 "
+             f"value-ref=0.6 value-var=0.4 ! {{rgba}} ! colorlut location={cube}")
+    sys_rgbx, hip_rgbx = f"video/x-raw,format=RGBx,{size}", f"video/x-raw(memory:HIPMemory),format=RGBx,{size}"
+    pipes = {
+        "source_only_system": f"hiptestsrc num-buffers={{n}} ! {sys_rgbx} ! fakesink sync=false",
+        "host_chain": f"hiptestsrc num-buffers={{n}} ! {sys_rgbx} ! {chain.format(rgba='video/x-raw,format=RGBA')} ! fakesink sync=false",
+        "hip_chain": (f"hiptestsrc num-buffers={{n}} ! {sys_rgbx} ! hipupload ! "
+                      f"{chain.format(rgba='video/x-raw(memory:HIPMemory),format=RGBA')} ! hipdownload ! fakesink sync=false"),
+        "device_only_chain": (f"hiptestsrc num-buffers={{n}} ! {hip_rgbx} ! "
+                              f"{chain.format(rgba='video/x-raw(memory:HIPMemory),format=RGBA')} ! fakesink sync=false"),
+    }
+    out = {"frame": f"{w}x{h}", "chain": f"hsvfilter ! hsvdetector ! colorlut({args.lut}^3)", "n1": args.n1, "n2": args.n2}
+    for name, tpl in pipes.items():
+        v, t1, t2 = fps(tpl, tmp, args.n1, args.n2)
+        out[name + "_fps"] = round(v, 1)
+        out[name + "_seconds"] = [round(t1, 3), round(t2, 3)]
+    # the same HIP chain with pageable staging (what round 1 shipped): upload source and download target malloc'ed
+    v, t1, t2 = fps(pipes["hip_chain"], tmp, args.n1, args.n2, {"MVFX_HIP_PAGEABLE": "1"})
+    out["hip_chain_pageable_staging_fps"] = round(v, 1)
+    out["hip_over_host"] = round(out["hip_chain_fps"] / out["host_chain_fps"], 2)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
