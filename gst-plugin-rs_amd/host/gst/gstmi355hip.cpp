@@ -272,7 +272,21 @@ static gboolean hiptestsrc_set_caps(GstBaseSrc *src, GstCaps *caps)
 
 static gboolean hiptestsrc_decide_allocation(GstBaseSrc *src, GstQuery *query)
 {
-    mvfx_hip_decide_allocation(query); // HIP pool when the caps carry memory:HIPMemory; otherwise downstream's (pinned) pool or the default
+    // HIP pool when the caps carry memory:HIPMemory; otherwise downstream's pool (hipupload offers page-locked buffers) or,
+    // when nobody proposed one, a plain video buffer pool of our own -- buffers must be RECYCLED for the fill-once scheme
+    if (!mvfx_hip_decide_allocation(query) && gst_query_get_n_allocation_pools(query) == 0) {
+        GstCaps *caps = NULL;
+        gst_query_parse_allocation(query, &caps, NULL);
+        GstVideoInfo info;
+        if (caps && gst_video_info_from_caps(&info, caps)) {
+            GstBufferPool *pool = gst_video_buffer_pool_new();
+            GstStructure *config = gst_buffer_pool_get_config(pool);
+            gst_buffer_pool_config_set_params(config, caps, (guint)GST_VIDEO_INFO_SIZE(&info), 2, 0);
+            if (gst_buffer_pool_set_config(pool, config))
+                gst_query_add_allocation_pool(query, pool, (guint)GST_VIDEO_INFO_SIZE(&info), 2, 0);
+            gst_object_unref(pool);
+        }
+    }
     return GST_BASE_SRC_CLASS(gst_mi355_hip_test_src_parent_class)->decide_allocation(src, query);
 }
 
