@@ -330,8 +330,8 @@ int mvfx_thread_set_options(uint32_t options)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options 0x%x: unknown bits 0x%x", options, options & ~known);
     if ((options & MVFX_OPT_HSV_LITERAL) && (options & MVFX_OPT_HSV_FORCE_FAST))
         return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options: MVFX_OPT_HSV_LITERAL and MVFX_OPT_HSV_FORCE_FAST exclude each other");
-    if (((options & MVFX_OPT_LUT_PLACEMENT_MASK) >> MVFX_OPT_LUT_PLACEMENT_SHIFT) > 4)
-        return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options: colorlut placement must be 0 (auto) .. 4 (literal kernels)");
+    if (((options & MVFX_OPT_LUT_PLACEMENT_MASK) >> MVFX_OPT_LUT_PLACEMENT_SHIFT) > 5)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options: colorlut placement must be 0 (auto) .. 5 (tile kernel)");
     t_options = options;
     return MVFX_OK;
 }

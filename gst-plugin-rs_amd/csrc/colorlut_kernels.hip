@@ -34,6 +34,7 @@ struct mvfx_cube_lut {
     std::mutex mu;
     int device = -1;       // device the copies below live on
     float *d_rgba = nullptr;
+    uint32_t *d_tile_tables = nullptr; // tile kernel: 3 x 256 x (cell index, fraction) per byte value + 192 neighbourhood piece offsets
     float *d_cells = nullptr; // cell-packed copy: size^3 cells x 8 corners x (r,g,b) f32 = 96 B (3-D, size <= kCellMaxSize)
     float *d_table[3] = {nullptr, nullptr, nullptr};
 };
@@ -46,6 +47,10 @@ constexpr uint32_t kLds3dMaxSize = 21;   // 21^3 * 16 B = 148,176 B
 constexpr uint32_t kLds1dMaxSize = 4096; // 3 * 4096 * 4 B = 48 KB
 constexpr int kLdsBlock = 1024;
 constexpr uint32_t kCellMaxSize = 65;    // 65^3 * 96 B = 26 MB; larger cubes keep the node layout only
+constexpr uint32_t kCellF4 = 6;          // float4 per cell of the cell-packed table (96 bytes).  Padding cells to one 128-byte line was tried for
+                                         // uniform-random colours and buys nothing: L1 fetches 64-byte blocks from L2 and a 96-byte cell always
+                                         // covers exactly two of them (TCP_TCC_READ_REQ 2.36 -> 2.1 per pixel, the 4.6 MB table no longer fits
+                                         // one XCD's 4 MiB L2: 11.3 k vs 12.0 k frames/s; profiles/r2/colorlut_random_floor.txt)
 
 // Constants of the FAST kernels, passed as kernel arguments so they sit in SGPRs (32-bit VOP2
 // encodings; see hsv_math.hpp for the instruction-class measurements).
@@ -58,6 +63,7 @@ struct LutFast {
 struct LutParams {
     LutFast fast;
     const float4 *cells;  // 3-D cell-packed copy (8 corners per cell) or nullptr
+    const uint32_t *tile_tables; // colorlut_tile_kernel: coordinate tables + neighbourhood piece offsets
     const float4 *cube;   // 3-D nodes
     const float *t[3];    // 1-D tables
     uint32_t size;
@@ -383,7 +389,7 @@ __device__ __forceinline__ void lf_sample_3d(CUBE cube, const float4 *cells, uin
         // 96-byte cell: 8 corners x (r,g,b) f32, 3.45 MB for 33^3 (fits one XCD's 4 MiB L2)
         const uint32_t index = x0 + size * (y0 + size * z0);
         if (index != cache.index) {
-            const float4 *cell = cells + (size_t)index * 6;
+            const float4 *cell = cells + (size_t)index * kCellF4;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
                 const float4 v = cell[i];
@@ -510,6 +516,112 @@ __device__ __forceinline__ void lf_rows(const uint8_t *in, uint8_t *out, uint64_
 }
 
 
+// ---------------------------------------------------------------- RGBA8 through a 3-D LUT, wave-local cell neighbourhood in LDS
+//
+// What bounds the per-lane gather kernel above is the vector L1's tag look-up rate, on natural content as much as on random
+// content (rocprofv3, profiles/r2/colorlut_counters_*_before.txt: TCP busy 97 %, 3.2 / 6.1 look-ups per pixel at ~1.2 per
+// clock per CU; VALUBusy 64 % / 28 %): every lane that needs a cell pays 6 look-ups for its 96 bytes, whoever else in the
+// wave wants the same bytes.  Pictures are locally coherent in colour: this kernel gives a wave a 16 x 16 pixel TILE
+// (spatially compact, unlike 256 consecutive pixels of a row), takes the LUT cell of the tile's centre pixel as anchor and
+// loads the 3 x 3 x 3 cells around it -- nine runs of 288 contiguous bytes, 162 coalesced 16-byte pieces in three wave
+// loads, ~54 look-ups -- into the wave's 2.6 KB of LDS.  A pixel whose cell lies in that neighbourhood (a cell of a 33^3
+// cube spans 8 code values per axis, the window 24) reads its 24 floats with six ds_read_b128 (lanes on one cell
+// broadcast); the others gather from the cell table in global memory/L2 exactly as before.  Same arithmetic (lf_coord,
+// lf_trilinear<true>): bit-identical results.
+constexpr int kTileNbCells = 27;                       // 3 x 3 x 3 cells
+constexpr int kTileNbPieces = kTileNbCells * 6;        // 16-byte pieces
+constexpr int kTileWaveLdsFloat4 = kTileNbPieces + 2;  // +32 bytes: de-phases the four waves' regions over the banks
+
+// The lattice coordinate of a channel depends on its byte value only: (cell index, fraction) come from a 3 x 256 entry
+// table in LDS (built on the host with the same f32 steps, ensure_uploaded) instead of 7 VALU instructions per channel --
+// the kernel is VALU-bound once the gathers are gone (rocprofv3: VALUBusy 100 %, profiles/r2/colorlut_tile_counters.txt).
+// (Typed buffer loads for u8/255 and several tiles per wave were tried and measured slower here: -4 % and -7 %.)
+constexpr uint32_t kCoordEntries = 3 * 256;
+
+__global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb, FrameBatch out_fb, uint32_t width, uint32_t height,
+                                                               uint32_t in_stride, uint32_t out_stride, LutParams p)
+{
+    __shared__ float4 nbr[kBlock / 64][kTileWaveLdsFloat4];
+    __shared__ uint2 coord[kCoordEntries]; // {cell index, fraction bits} per channel and byte value
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    {
+        const uint2 *src = reinterpret_cast<const uint2 *>(p.tile_tables);
+#pragma unroll
+        for (uint32_t i = 0; i < kCoordEntries / kBlock; i++) coord[i * kBlock + threadIdx.x] = src[i * kBlock + threadIdx.x];
+    }
+    // workgroup = four horizontally adjacent tiles (grid x), one tile row per grid y
+    const uint32_t x = (blockIdx.x * (kBlock / 64) + wave) * 16 + (lane & 3) * 4, y = blockIdx.y * 16 + (lane >> 2);
+    const bool valid = x < width && y < height; // width % 4 == 0 (launcher): a lane's four pixels are all inside or all outside
+    const uint8_t *in = in_fb.base[blockIdx.z];
+    uint8_t *out = out_fb.base[blockIdx.z];
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (valid) v = *reinterpret_cast<const uint4 *>(in + (y * in_stride + x * 4));
+    // offsets of this lane's three pieces of the neighbourhood relative to the anchor cell (float4 units)
+    const uint32_t rel0 = p.tile_tables[2 * kCoordEntries + lane], rel1 = p.tile_tables[2 * kCoordEntries + 64 + lane],
+                   rel2 = p.tile_tables[2 * kCoordEntries + 128 + lane];
+    __syncthreads(); // coordinate table complete
+    uint32_t px[4] = {v.x, v.y, v.z, v.w};
+    uint32_t ix[4], iy[4], iz[4];
+    float fx[4], fy[4], fz[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint2 er = coord[px[j] & 0xffu], eg = coord[256 + ((px[j] >> 8) & 0xffu)], eb = coord[512 + ((px[j] >> 16) & 0xffu)];
+        ix[j] = er.x; fx[j] = __uint_as_float(er.y);
+        iy[j] = eg.x; fy[j] = __uint_as_float(eg.y);
+        iz[j] = eb.x; fz[j] = __uint_as_float(eb.y);
+    }
+    // anchor: the cell of the tile's centre pixel (lane 34 = row 8, columns 8..11), window = anchor-1 .. anchor+1 per axis,
+    // shifted to stay inside the table (cell indices run 0 .. size-1; the launcher guarantees size >= 3)
+    const uint32_t hi = p.size - 3;
+    const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)ix[0], 34), cy = (uint32_t)__builtin_amdgcn_readlane((int)iy[0], 34),
+                   cz = (uint32_t)__builtin_amdgcn_readlane((int)iz[0], 34);
+    const uint32_t ax = min(cx > 0 ? cx - 1 : 0u, hi), ay = min(cy > 0 ? cy - 1 : 0u, hi), az = min(cz > 0 ? cz - 1 : 0u, hi);
+    const uint32_t anchor = (ax + p.size * (ay + p.size * az)) * kCellF4; // float4 units; wave-uniform
+    float4 *mine = nbr[wave];
+    mine[lane] = p.cells[anchor + rel0];
+    mine[64 + lane] = p.cells[anchor + rel1];
+    if (lane < (uint32_t)kTileNbPieces - 128u) mine[128 + lane] = p.cells[anchor + rel2];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t dx = ix[j] - ax, dy = iy[j] - ay, dz = iz[j] - az; // unsigned: below the anchor wraps to a huge value
+        float4 c6[6];
+        if (dx < 3u && dy < 3u && dz < 3u) {
+            const float4 *cell = mine + (dx + 3u * (dy + 3u * dz)) * 6u;
+#pragma unroll
+            for (int i = 0; i < 6; i++) c6[i] = cell[i];
+        } else {
+            // outside the window (an edge crossing the tile, heavy noise, synthetic random frames): this lane's own gather
+            // from the cell table in global memory / L2, six 16-byte loads.  A quad-cooperative form (the four lanes of a quad
+            // fetch one cell with two coalesced loads and hand it over through LDS: 2.8 instead of 6.1 L1 look-ups per pixel)
+            // was built and measured: no faster on uniform-random colours -- there the L1's miss path is the floor (a cell is
+            // two 64-byte L2 requests, ~0.39 requests per clock per CU) -- and slower when only a few pixels of a tile fall
+            // outside (profiles/r2/colorlut_random_floor.txt)
+            const float4 *cell = p.cells + (ix[j] + p.size * (iy[j] + p.size * iz[j])) * kCellF4;
+#pragma unroll
+            for (int i = 0; i < 6; i++) c6[i] = cell[i];
+        }
+        const float f[24] = {c6[0].x, c6[0].y, c6[0].z, c6[0].w, c6[1].x, c6[1].y, c6[1].z, c6[1].w, c6[2].x, c6[2].y, c6[2].z, c6[2].w,
+                             c6[3].x, c6[3].y, c6[3].z, c6[3].w, c6[4].x, c6[4].y, c6[4].z, c6[4].w, c6[5].x, c6[5].y, c6[5].z, c6[5].w};
+        float4 c[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) c[i] = make_float4(f[3 * i], f[3 * i + 1], f[3 * i + 2], 0.0f);
+        float r, g, b;
+        lf_trilinear<true>(c, fx[j], fy[j], fz[j], r, g, b);
+        const float yr = r * p.fast.out_scale + p.fast.pred_half, yg = g * p.fast.out_scale + p.fast.pred_half,
+                    yb = b * p.fast.out_scale + p.fast.pred_half;
+        uint32_t w = px[j];
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yr));
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yg));
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
+        px[j] = w;
+    }
+    if (valid)
+        *reinterpret_cast<uint4 *>(out + (y * out_stride + x * 4)) = make_uint4(px[0], px[1], px[2], px[3]);
+}
+
 // ---------------------------------------------------------------- colorlut on I420 frames, fused
 //
 // `videoconvert ! colorlut ! videoconvert` of the reference's example pipeline (colorlut/imp.rs:17-19) in ONE kernel:
@@ -579,6 +691,7 @@ int ensure_uploaded(mvfx_cube_lut *h)
     // (re)upload for this device
     if (h->d_rgba) { (void)hipFree(h->d_rgba); h->d_rgba = nullptr; }
     if (h->d_cells) { (void)hipFree(h->d_cells); h->d_cells = nullptr; }
+    if (h->d_tile_tables) { (void)hipFree(h->d_tile_tables); h->d_tile_tables = nullptr; }
     for (auto &t : h->d_table) if (t) { (void)hipFree(t); t = nullptr; }
     const CubeLut &l = h->lut;
     if (l.is_3d) {
@@ -587,23 +700,49 @@ int ensure_uploaded(mvfx_cube_lut *h)
         MVFX_HIP_TRY(hipMemcpy(h->d_rgba, l.rgba.data(), bytes, hipMemcpyHostToDevice));
         if (l.size <= kCellMaxSize) { // cell-packed copy: corner (i,j,k) of cell (x,y,z) = node(min(x+i,m), ...)
             const size_t n = (size_t)l.size, m = n - 1;
-            std::vector<float> cells(n * n * n * 24);
+            std::vector<float> cells(n * n * n * kCellF4 * 4, 0.0f);
             for (size_t z = 0; z < n; z++)
                 for (size_t y = 0; y < n; y++)
                     for (size_t x = 0; x < n; x++)
                         for (size_t c = 0; c < 8; c++) {
                             const size_t xx = std::min(x + (c & 1), m), yy = std::min(y + ((c >> 1) & 1), m), zz = std::min(z + (c >> 2), m);
-                            std::memcpy(&cells[((x + n * (y + n * z)) * 8 + c) * 3], &l.rgba[(xx + n * (yy + n * zz)) * 4], 12);
+                            std::memcpy(&cells[(x + n * (y + n * z)) * (kCellF4 * 4) + c * 3], &l.rgba[(xx + n * (yy + n * zz)) * 4], 12);
                         }
             // odd corners (x+1) become the x-differences RN(c_odd - c_even): what `a + (b - a) * t` subtracts per pixel
             for (size_t cell = 0; cell < n * n * n; cell++)
                 for (size_t pair = 0; pair < 4; pair++)
                     for (size_t ch = 0; ch < 3; ch++) {
-                        float *even = &cells[(cell * 8 + 2 * pair) * 3 + ch], *odd = even + 3;
+                        float *even = &cells[cell * (kCellF4 * 4) + 2 * pair * 3 + ch], *odd = even + 3;
                         *odd = *odd - *even;
                     }
             MVFX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_cells), cells.size() * sizeof(float)));
             MVFX_HIP_TRY(hipMemcpy(h->d_cells, cells.data(), cells.size() * sizeof(float), hipMemcpyHostToDevice));
+            // tables of colorlut_tile_kernel: per channel and byte value the lattice cell index and fraction -- norm_comp *
+            // (size - 1), floor, t = x - x0 (imp.rs:471-474, 496-506) evaluated here in the same f32 steps the FAST device
+            // functions take (this file is built with -ffp-contract=off; the domain is finite on that path) -- and the
+            // offsets of the 162 sixteen-byte pieces of a 3 x 3 x 3 cell neighbourhood relative to its anchor cell
+            if (l.size >= 3) {
+                std::vector<uint32_t> tt(3 * 256 * 2 + 192, 0u);
+                const float size_m1 = (float)l.size - 1.0f;
+                for (int c = 0; c < 3; c++)
+                    for (int b = 0; b < 256; b++) {
+                        const float v = (float)b / 255.0f;                       // RN(b / 255) == the device's mul + fmac form (P8)
+                        float n = v * l.domain_scale[c];
+                        n = n + l.domain_offset[c];
+                        n = n < 0.0f ? 0.0f : (n > 1.0f ? 1.0f : n);             // v_add_f32 clamp on finite values
+                        const float x = n * size_m1;
+                        const uint32_t i0 = (uint32_t)x;                         // floor (x >= 0)
+                        const float t = x - (float)i0;
+                        tt[(c * 256 + b) * 2] = i0;
+                        std::memcpy(&tt[(c * 256 + b) * 2 + 1], &t, 4);
+                    }
+                for (uint32_t q = 0; q < 162; q++) {
+                    const uint32_t run = q / 18u, piece = q - run * 18u, dz = run / 3u, dy = run - dz * 3u;
+                    tt[1536 + q] = (l.size * (dy + l.size * dz) + piece / 6u) * kCellF4 + piece % 6u; // float4 units; run = dy + 3 dz: three x-adjacent cells
+                }
+                MVFX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_tile_tables), tt.size() * sizeof(uint32_t)));
+                MVFX_HIP_TRY(hipMemcpy(h->d_tile_tables, tt.data(), tt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            }
         }
     } else {
         for (int c = 0; c < 3; c++) {
@@ -700,8 +839,12 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
     bool finite = true;
     for (int c = 0; c < 3; c++)
         finite = finite && std::isfinite(l.domain_scale[c]) && std::isfinite(l.domain_offset[c]);
-    // 0 auto | 1 node layout in global/L2 | 2 LDS | 3 cell-packed global | 4 literal kernels
-    bool use_lds = fits_lds, use_cells = false, use_fast = finite && vec;
+    // 0 auto | 1 node layout in global/L2 | 2 LDS | 3 cell-packed global, per-lane gathers | 4 literal kernels |
+    // 5 cell-packed global + wave-local 3x3x3 cell neighbourhood in LDS (16 x 16 pixel tiles)
+    bool use_lds = fits_lds, use_cells = false, use_fast = finite && vec, use_tiles = false;
+    const bool tiles_ok = l.is_3d && !wide && h->d_cells != nullptr && h->d_tile_tables != nullptr && finite && (in->width & 3) == 0 &&
+                          ((align_or | in->stride | out->stride) & 15) == 0 && (uint64_t)in->stride * in->height < (1ull << 32) &&
+                          (uint64_t)out->stride * out->height < (1ull << 32) && (in->height + 15) / 16 <= 65535u;
     switch (opt_lut_placement()) {
     case 1: use_lds = false; break;
     case 2:
@@ -711,13 +854,18 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
         if (!h->d_cells) return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: no cell-packed copy for this LUT (1-D or size > %u)", kCellMaxSize);
         use_lds = false; use_cells = true; break;
     case 4: use_fast = false; break;
+    case 5:
+        if (!tiles_ok) return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: the tile kernel needs a 3-D LUT of size 3..%u, RGBA, width %% 4 == 0 and 16-byte aligned rows", kCellMaxSize);
+        use_lds = false; use_cells = true; use_tiles = true; break;
     default:
         use_cells = !use_lds && h->d_cells != nullptr;
+        use_tiles = use_cells && tiles_ok;
         break;
     }
     if (!use_fast) use_cells = false; // the literal kernels read the node layout
     const size_t lds_bytes = l.is_3d ? (size_t)l.size * l.size * l.size * 16 : (size_t)l.size * 12;
     p.cells = reinterpret_cast<const float4 *>(h->d_cells);
+    p.tile_tables = h->d_tile_tables;
     p.fast.c_hi = wide ? 1.0f / 65535.0f : 1.0f / 255.0f;
     p.fast.c_lo = (float)((wide ? 1.0 / 65535.0 : 1.0 / 255.0) - (double)p.fast.c_hi);
     p.fast.out_scale = wide ? 65535.0f : 255.0f;
@@ -748,6 +896,13 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
     }
     const FrameBatch &ip = ifb, &op = ofb;
 
+    if (use_fast && use_tiles) {
+        const uint32_t tiles_x = (in->width + 15) / 16, tiles_y = (in->height + 15) / 16;
+        const dim3 tgrid((tiles_x + kBlock / 64 - 1) / (kBlock / 64), tiles_y, n);
+        hipLaunchKernelGGL(colorlut_tile_kernel, tgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p);
+        MVFX_HIP_TRY(hipGetLastError());
+        return MVFX_OK;
+    }
     if (use_fast) {
 #define MVFX_FG(IS3D, CELLS, WIDE, LE) \
     do { hipLaunchKernelGGL((colorlut_fast_global_kernel<IS3D, CELLS, WIDE, LE>), grid, dim3(kBlock), 0, st, ip, op, width, rows, is, os, p); \
@@ -910,6 +1065,7 @@ void mvfx_cube_lut_free(mvfx_cube_lut *lut)
     if (!lut) return;
     if (lut->d_rgba) (void)hipFree(lut->d_rgba);
     if (lut->d_cells) (void)hipFree(lut->d_cells);
+    if (lut->d_tile_tables) (void)hipFree(lut->d_tile_tables);
     for (auto &t : lut->d_table) if (t) (void)hipFree(t);
     delete lut;
 }
