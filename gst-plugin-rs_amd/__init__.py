@@ -22,10 +22,10 @@ LIB_PATH = os.environ.get("MVFX_LIB") or os.path.join(_HERE, "libmi355vfx.so")
 # mvfx_format (include/mi355vfx.h)
 FORMATS = {
     "RGBx": 0, "xRGB": 1, "BGRx": 2, "xBGR": 3, "RGBA": 4, "ARGB": 5, "BGRA": 6, "ABGR": 7,
-    "RGB": 8, "BGR": 9, "RGBA64_LE": 10, "RGBA64_BE": 11, "I420": 12, "A420": 13,
+    "RGB": 8, "BGR": 9, "RGBA64_LE": 10, "RGBA64_BE": 11, "I420": 12, "A420": 13, "RGB10A2_LE": 14,
 }
 FORMAT_NAMES = {v: k for k, v in FORMATS.items()}
-BYTES_PER_PIXEL = {0: 4, 1: 4, 2: 4, 3: 4, 4: 4, 5: 4, 6: 4, 7: 4, 8: 3, 9: 3, 10: 8, 11: 8}
+BYTES_PER_PIXEL = {0: 4, 1: 4, 2: 4, 3: 4, 4: 4, 5: 4, 6: 4, 7: 4, 8: 3, 9: 3, 10: 8, 11: 8, 14: 4}
 
 # mvfx_status
 OK = 0
@@ -155,6 +155,10 @@ SIGNATURES = {
     "mvfx_colorlut_transform_frame": (c_int, [c_void_p, POINTER(Frame), POINTER(Frame), c_void_p]),
     "mvfx_colorlut_transform_frames": (c_int, [c_void_p, POINTER(Frame), POINTER(Frame), c_uint32, c_void_p]),
     "mvfx_colorlut_transform_frame_host": (c_int, [c_void_p, POINTER(Frame), POINTER(Frame)]),
+    "mvfx_cube_lut_write": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]),
+    "mvfx_free_text": (None, [c_void_p]),
+    "mvfx_overlay_blend": (c_int, [POINTER(Frame), POINTER(Frame), c_int32, c_int32, c_float, c_void_p]),
+    "mvfx_overlay_blend_host": (c_int, [POINTER(Frame), POINTER(Frame), c_int32, c_int32, c_float]),
     "mvfx_colordetect_histogram": (c_int, [POINTER(Frame), c_uint32, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     "mvfx_mmcq_palette_from_histogram": (c_int, [c_void_p, POINTER(c_uint32), c_uint32, POINTER(c_uint32), POINTER(c_uint32)]),
     "mvfx_colordetect_palette": (c_int, [POINTER(Frame), c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_uint32), c_void_p]),
@@ -335,6 +339,16 @@ class CubeLut:
         fi = make_frame(src_ptr, width, height, src_stride, fmt)
         fo = make_frame(dst_ptr, width, height, dst_stride, fmt)
         check(lib().mvfx_colorlut_transform_frame(self.h, ctypes.byref(fi), ctypes.byref(fo), stream))
+
+    def write(self) -> str:
+        """mvfx_cube_lut_write: the LUT as .cube text (round-trips bit for bit through the parser)"""
+        text = c_void_p()
+        n = c_size_t()
+        check(lib().mvfx_cube_lut_write(self.h, ctypes.byref(text), ctypes.byref(n)))
+        try:
+            return ctypes.string_at(text.value, n.value).decode("utf-8")
+        finally:
+            lib().mvfx_free_text(text)
 
     def free(self):
         if getattr(self, "h", None):

@@ -312,6 +312,42 @@ __global__ __launch_bounds__(kLdsBlock) void colorlut_lds_kernel(FrameBatch in_f
 }
 
 
+// ---------------------------------------------------------------- RGB10A2_LE (d3d12colorlut's third format)
+// d3d12colorlut accepts RGBA64_LE, RGB10A2_LE and RGBA on D3D12 memory (d3d12colorlut/imp.rs:236-244) and samples the LUT in
+// an HLSL shader -- hardware filtering, not bit-defined.  Here the CPU element's arithmetic is extended the way its 8- and
+// 16-bit paths are written (imp.rs:471-479, 537-543): v / 1023.0, the same clamp / lattice / trilinear steps,
+// (clamp(v, 0, 1) * 1023.0).round(), the two alpha bits copied.  Little-endian dword: R bits 0-9, G 10-19, B 20-29, A 30-31.
+template <bool IS3D>
+__global__ __launch_bounds__(kBlock) void colorlut_rgb10a2_kernel(FrameBatch in_fb, FrameBatch out_fb, uint32_t width, uint32_t rows,
+                                                                  uint64_t in_stride, uint64_t out_stride, LutParams p)
+{
+    const uint8_t *in = in_fb.base[blockIdx.z];
+    uint8_t *out = out_fb.base[blockIdx.z];
+    for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y)
+        for (uint32_t x = blockIdx.x * kBlock + threadIdx.x; x < width; x += gridDim.x * kBlock) {
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(in + (uint64_t)row * in_stride + (uint64_t)x * 4);
+            float v[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                v[c] = std_clamp01((float)((w >> (10 * c)) & 1023u) / 1023.0f * p.scale[c] + p.offset[c]) * p.size_m1;
+            float o[3];
+            if constexpr (IS3D) {
+                sample_3d(p.cube, p.size, v[0], v[1], v[2], o[0], o[1], o[2]);
+            } else {
+                o[0] = sample_1d(p.t[0], p.size - 1, v[0]);
+                o[1] = sample_1d(p.t[1], p.size - 1, v[1]);
+                o[2] = sample_1d(p.t[2], p.size - 1, v[2]);
+            }
+            uint32_t res = w & 0xC0000000u;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float r = round_half_away(std_clamp01(o[c]) * 1023.0f);
+                res |= ((r == r) ? (uint32_t)__float2uint_rz(r) : 0u) << (10 * c);
+            }
+            *reinterpret_cast<uint32_t *>(out + (uint64_t)row * out_stride + (uint64_t)x * 4) = res;
+        }
+}
+
 // ---------------------------------------------------------------- FAST path (finite domain)
 //
 // Same values as the literal functions above through exact reductions: u8/255 and u16/65535 as
@@ -794,8 +830,10 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
         if (int rc = check_packed_frame(&ins[i], "colorlut input"); rc != MVFX_OK) return rc;
         if (int rc = check_packed_frame(&outs[i], "colorlut output"); rc != MVFX_OK) return rc;
     }
-    if (in->format != MVFX_FORMAT_RGBA && in->format != MVFX_FORMAT_RGBA64_LE && in->format != MVFX_FORMAT_RGBA64_BE)
-        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "colorlut: format %d is not RGBA / RGBA64_LE / RGBA64_BE (colorlut/imp.rs:122-134)", in->format);
+    if (in->format != MVFX_FORMAT_RGBA && in->format != MVFX_FORMAT_RGBA64_LE && in->format != MVFX_FORMAT_RGBA64_BE &&
+        in->format != MVFX_FORMAT_RGB10A2_LE)
+        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "colorlut: format %d is not RGBA / RGBA64_LE / RGBA64_BE (colorlut/imp.rs:122-134) or RGB10A2_LE "
+                    "(d3d12colorlut/imp.rs:236-244)", in->format);
     if (out->format != in->format)
         return fail(MVFX_ERR_NOT_NEGOTIATED, "colorlut: input and output formats differ");
     if (int rc = check_packed_frame(in, "colorlut input"); rc != MVFX_OK) return rc;
@@ -817,6 +855,27 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
     }
     p.size = l.size;
     p.size_m1 = (float)l.size - 1.0f;
+
+    if (in->format == MVFX_FORMAT_RGB10A2_LE) {
+        FrameBatch ifb10{}, ofb10{};
+        uint64_t bits = (uint64_t)in->stride | out->stride;
+        for (uint32_t i = 0; i < n; i++) {
+            ifb10.base[i] = static_cast<uint8_t *>(ins[i].data);
+            ofb10.base[i] = static_cast<uint8_t *>(outs[i].data);
+            bits |= (uint64_t)(uintptr_t)ins[i].data | (uint64_t)(uintptr_t)outs[i].data;
+        }
+        if (bits & 3)
+            return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: RGB10A2_LE frames must be 4-byte aligned");
+        const dim3 g10((in->width + kBlock - 1) / kBlock, in->height < 65535u ? in->height : 65535u, n);
+        if (l.is_3d)
+            hipLaunchKernelGGL(colorlut_rgb10a2_kernel<true>, g10, dim3(kBlock), 0, st, ifb10, ofb10, in->width, in->height, (uint64_t)in->stride,
+                               (uint64_t)out->stride, p);
+        else
+            hipLaunchKernelGGL(colorlut_rgb10a2_kernel<false>, g10, dim3(kBlock), 0, st, ifb10, ofb10, in->width, in->height, (uint64_t)in->stride,
+                               (uint64_t)out->stride, p);
+        MVFX_HIP_TRY(hipGetLastError());
+        return MVFX_OK;
+    }
 
     const bool wide = in->format != MVFX_FORMAT_RGBA;
     const bool le = in->format != MVFX_FORMAT_RGBA64_BE;
@@ -1069,6 +1128,22 @@ void mvfx_cube_lut_free(mvfx_cube_lut *lut)
     for (auto &t : lut->d_table) if (t) (void)hipFree(t);
     delete lut;
 }
+
+int mvfx_cube_lut_write(const mvfx_cube_lut *lut, char **text_out, size_t *len_out)
+{
+    if (!lut || !text_out)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "cube_lut_write: NULL argument");
+    const std::string text = write_cube(lut->lut);
+    char *buf = static_cast<char *>(malloc(text.size() + 1));
+    if (!buf)
+        return fail(MVFX_ERR_OUT_OF_MEMORY, "cube_lut_write: %zu bytes", text.size() + 1);
+    std::memcpy(buf, text.c_str(), text.size() + 1);
+    *text_out = buf;
+    if (len_out) *len_out = text.size();
+    return MVFX_OK;
+}
+
+void mvfx_free_text(char *text) { free(text); }
 
 int mvfx_cube_lut_is_3d(const mvfx_cube_lut *lut) { return lut && lut->lut.is_3d ? 1 : 0; }
 uint32_t mvfx_cube_lut_size(const mvfx_cube_lut *lut) { return lut ? lut->lut.size : 0; }

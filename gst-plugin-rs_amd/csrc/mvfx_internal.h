@@ -34,6 +34,7 @@ inline int bytes_per_pixel(int format)
     switch (format) {
     case MVFX_FORMAT_RGBX: case MVFX_FORMAT_XRGB: case MVFX_FORMAT_BGRX: case MVFX_FORMAT_XBGR:
     case MVFX_FORMAT_RGBA: case MVFX_FORMAT_ARGB: case MVFX_FORMAT_BGRA: case MVFX_FORMAT_ABGR:
+    case MVFX_FORMAT_RGB10A2_LE:
         return 4;
     case MVFX_FORMAT_RGB: case MVFX_FORMAT_BGR:
         return 3;

@@ -287,6 +287,8 @@ bool parse_cube(std::string_view text, CubeLut &out, std::string &error)
         }
     }
     for (int c = 0; c < 3; c++) { // :264-274
+        lut.domain_min[c] = dmin[c];
+        lut.domain_max[c] = dmax[c];
         lut.domain_scale[c] = 1.0f / (dmax[c] - dmin[c]);
         lut.domain_offset[c] = -dmin[c] * lut.domain_scale[c];
     }
@@ -317,6 +319,35 @@ bool valid_utf8(const std::string &s)
     return true;
 }
 } // namespace
+
+std::string write_cube(const CubeLut &lut)
+{
+    static const locale_t c_locale = newlocale(LC_ALL_MASK, "C", static_cast<locale_t>(nullptr));
+    const locale_t old = c_locale ? uselocale(c_locale) : static_cast<locale_t>(nullptr); // '.' decimal point whatever LC_NUMERIC says
+    std::string out;
+    char line[128];
+    const auto f3 = [&](const char *key, float a, float b, float c) {
+        snprintf(line, sizeof(line), "%s%.9g %.9g %.9g\n", key, (double)a, (double)b, (double)c);
+        out += line;
+    };
+    snprintf(line, sizeof(line), "%s %u\n", lut.is_3d ? "LUT_3D_SIZE" : "LUT_1D_SIZE", lut.size);
+    out += line;
+    const bool default_domain = lut.domain_min[0] == 0.0f && lut.domain_min[1] == 0.0f && lut.domain_min[2] == 0.0f &&
+                                lut.domain_max[0] == 1.0f && lut.domain_max[1] == 1.0f && lut.domain_max[2] == 1.0f;
+    if (!default_domain) {
+        f3("DOMAIN_MIN ", lut.domain_min[0], lut.domain_min[1], lut.domain_min[2]);
+        f3("DOMAIN_MAX ", lut.domain_max[0], lut.domain_max[1], lut.domain_max[2]);
+    }
+    if (lut.is_3d) {
+        const size_t n = (size_t)lut.size * lut.size * lut.size;
+        out.reserve(out.size() + n * 36);
+        for (size_t i = 0; i < n; i++) f3("", lut.rgba[4 * i], lut.rgba[4 * i + 1], lut.rgba[4 * i + 2]); // R fastest (parser.rs:43-53)
+    } else {
+        for (size_t i = 0; i < lut.size; i++) f3("", lut.table[0][i], lut.table[1][i], lut.table[2][i]);
+    }
+    if (old) uselocale(old);
+    return out;
+}
 
 bool parse_cube_file(const char *path, CubeLut &out, std::string &error, bool &io_error)
 {

@@ -36,6 +36,7 @@ extern "C" {
  * (hsvfilter/imp.rs:278-289); hsvdetector sink RGBx..BGR, src RGBA..ABGR
  * (hsvdetector/imp.rs:78-96); colorlut RGBA, RGBA64_LE/BE (colorlut/imp.rs:122-134);
  * colordetect RGB,RGBA,ARGB,BGR,BGRA (colordetect/imp.rs:214-221); videocompare RGB,RGBA;
+ * colorlut additionally RGB10A2_LE on device memory (the D3D12 variant's third format, d3d12colorlut/imp.rs:236-244);
  * roundedcorners I420 -> A420 (border/imp.rs:345-365). */
 typedef enum mvfx_format {
     MVFX_FORMAT_RGBX = 0,
@@ -51,7 +52,8 @@ typedef enum mvfx_format {
     MVFX_FORMAT_RGBA64_LE = 10,
     MVFX_FORMAT_RGBA64_BE = 11,
     MVFX_FORMAT_I420 = 12,
-    MVFX_FORMAT_A420 = 13
+    MVFX_FORMAT_A420 = 13,
+    MVFX_FORMAT_RGB10A2_LE = 14 /* colorlut only: third format of d3d12colorlut's caps (d3d12colorlut/imp.rs:236-244) */
 } mvfx_format;
 
 typedef enum mvfx_status {
@@ -239,6 +241,28 @@ int mvfx_colorlut_transform_frame_host(mvfx_cube_lut *lut, const mvfx_frame *in_
  * 2 = LDS (MVFX_ERR_INVALID_ARGUMENT if it does not fit), 3 = cell-packed global copy,
  * 4 = the literal-transcription kernels (also used automatically when the LUT's domain
  * scale/offset are not finite). */
+
+/* Writes the LUT as Adobe .cube text: LUT_1D_SIZE / LUT_3D_SIZE, DOMAIN_MIN / DOMAIN_MAX when they are not
+ * 0 / 1, then the rows, floats with 9 significant digits -- mvfx_cube_lut_parse of the text yields the same LUT bit for
+ * bit (parser.rs:110-282 accepts exactly this grammar).  *text_out is malloc'ed (NUL-terminated); release with
+ * mvfx_free_text. */
+int mvfx_cube_lut_write(const mvfx_cube_lut *lut, char **text_out, size_t *len_out);
+void mvfx_free_text(char *text);
+
+/* ---- imagersoverlay blending : video/image/src/overlay/imp.rs:703-727 ----
+ * The element's per-frame work when downstream does not take the overlay-composition meta: `composition.blend(frame)` ==
+ * libgstvideo's gst_video_overlay_composition_blend.  One unscaled BGRA rectangle (non-premultiplied: what load_image
+ * builds, imp.rs:241-283) at (x, y) -- any position, clipped against the frame -- with the rectangle's global alpha
+ * (`alpha` property, imp.rs:183-185) onto a packed RGB frame, in place.  Arithmetic = libgstvideo 1.14.0's (pinned with
+ * vectors made by the image's own library, tests/golden/make_overlay_blend_golden.py):
+ *   a_s = overlay alpha (x (int)(global_alpha * 255) / 255 when global_alpha != 1); a_s == 0 leaves the pixel untouched;
+ *   a_o = a_s + a_d (255 - a_s) / 255;  c_o = (c_s a_s + c_d a_d (255 - a_s) / 255) / max(a_o, 1), truncating divisions;
+ *   a_d = 255 for RGB / BGR; the x byte of RGBx / BGRx / xRGB / xBGR is treated as alpha, as 1.14.0 does.
+ * Destination formats: the ten packed RGB formats of mvfx_format.  `overlay` must be MVFX_FORMAT_BGRA. */
+int mvfx_overlay_blend(const mvfx_frame *frame, const mvfx_frame *overlay, int32_t x, int32_t y, float global_alpha,
+                       mvfx_stream stream);
+/* host memory for both (a mapped GstBuffer and the decoded image): only the clipped rectangle crosses PCIe */
+int mvfx_overlay_blend_host(const mvfx_frame *frame, const mvfx_frame *overlay, int32_t x, int32_t y, float global_alpha);
 
 /* ---- colordetect : video/videofx/src/colordetect/imp.rs ----
  * The reference calls color_thief::get_palette(plane, format, quality, max_colors) (crate

@@ -424,6 +424,45 @@ int orc_colorlut_transform_frame(const orc_cube_lut *lut, const uint8_t *src, si
     if (!lut)
         return ORC_ERR_PARSE; /* "No LUT configured" :209-213 */
     int wide, le = 1;
+    if (format == ORC_FORMAT_RGB10A2_LE) {
+        /* RGB10A2_LE: the format d3d12colorlut accepts beside RGBA / RGBA64_LE (d3d12colorlut/imp.rs:236-244).  That element
+         * samples the LUT in an HLSL shader (hardware filtering, not bit-defined); the CPU element's arithmetic is extended here
+         * the way its 8- and 16-bit paths are written (imp.rs:471-479, 537-543): norm = v / 1023.0, same clamp / lattice /
+         * trilinear steps, float_to_u10 = (clamp(v, 0, 1) * 1023.0).round() as u16, the 2 alpha bits copied.  Little-endian
+         * dword: R bits 0-9, G 10-19, B 20-29, A 30-31.  Self-defined extension: PARITY UNPINNED by construction. */
+        if (src_stride == 0 || dst_stride == 0) return ORC_ERR_PANIC;
+        const float sm1 = (float)lut->size - 1.0f;
+        for (size_t y = 0; y < height; y++) {
+            if (y * (size_t)src_stride + (size_t)width * 4 > src_len || y * (size_t)dst_stride + (size_t)width * 4 > dst_len)
+                return ORC_ERR_PANIC; /* &row[..width_in_bytes] out of range */
+            const uint8_t *s = src + y * (size_t)src_stride;
+            uint8_t *d = dst + y * (size_t)dst_stride;
+            for (size_t x = 0; x < width; x++, s += 4, d += 4) {
+                const uint32_t w = (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16) | ((uint32_t)s[3] << 24);
+                float v[3], out[4];
+                for (int c = 0; c < 3; c++) {
+                    float n = (float)((w >> (10 * c)) & 1023u) / 1023.0f;
+                    n = n * lut->domain_scale[c] + lut->domain_offset[c];
+                    n = n < 0.0f ? 0.0f : n; /* f32::clamp: NaN stays NaN */
+                    n = n > 1.0f ? 1.0f : n;
+                    v[c] = n * sm1;
+                }
+                if (lut->is_3d) sample_3d(lut, v[0], v[1], v[2], out);
+                else for (int c = 0; c < 3; c++) out[c] = sample_1d(lut->table[c], lut->size, v[c]);
+                uint32_t o = w & 0xC0000000u;
+                for (int c = 0; c < 3; c++) {
+                    float f = out[c];
+                    f = f < 0.0f ? 0.0f : f;
+                    f = f > 1.0f ? 1.0f : f;
+                    f = roundf(f * 1023.0f);
+                    const uint32_t q = (f == f) ? (uint32_t)f : 0u; /* NaN as u16 == 0 */
+                    o |= (q & 1023u) << (10 * c);
+                }
+                d[0] = (uint8_t)o; d[1] = (uint8_t)(o >> 8); d[2] = (uint8_t)(o >> 16); d[3] = (uint8_t)(o >> 24);
+            }
+        }
+        return ORC_OK;
+    }
     switch (format) {
     case ORC_FORMAT_RGBA: wide = 0; break;
     case ORC_FORMAT_RGBA64_LE: wide = 1; le = 1; break;

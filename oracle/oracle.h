@@ -47,7 +47,8 @@ enum {
     ORC_FORMAT_RGBA64_LE = 10,
     ORC_FORMAT_RGBA64_BE = 11,
     ORC_FORMAT_I420 = 12,
-    ORC_FORMAT_A420 = 13
+    ORC_FORMAT_A420 = 13,
+    ORC_FORMAT_RGB10A2_LE = 14 /* colorlut only: the third format of d3d12colorlut's caps (d3d12colorlut/imp.rs:236-244) */
 };
 
 /* Error codes of the oracle (negative).  ORC_ERR_PANIC marks inputs on which the
@@ -122,6 +123,15 @@ uint64_t orc_blockhash_bits(const uint32_t sums[64], uint32_t width, uint32_t he
 int orc_blockhash(const uint8_t *data, uint32_t width, uint32_t height, uint32_t stride,
                   int format, uint64_t *hash);
 uint32_t orc_hamming64(uint64_t a, uint64_t b);
+
+/* imagersoverlay's per-frame work: `composition.blend(frame)` (video/image/src/overlay/imp.rs:703-727) ==
+ * gst_video_overlay_composition_blend -> gst_video_blend of libgstvideo (NOT under /root/reference).  One unscaled
+ * BGRA rectangle (non-premultiplied, what load_image builds: imp.rs:241-283) at (x, y) with the rectangle's global alpha
+ * onto a packed RGB frame.  Restated from and pinned against the image's own libgstvideo 1.14.0 (tests/golden/
+ * make_overlay_blend_golden.py), like the videoconvert restatement. */
+int orc_overlay_blend(uint8_t *data, uint32_t width, uint32_t height, uint32_t stride, int format,
+                      const uint8_t *overlay_bgra, uint32_t overlay_width, uint32_t overlay_height, uint32_t overlay_stride,
+                      int32_t x, int32_t y, float global_alpha);
 /* image_hasher 3.1.1 Mean / Gradient / VertGradient / DoubleGradient on image 0.25.10's grayscale +
  * Lanczos3 resize (hashed_image.rs:89-107); algo = GstVideoCompareHashAlgorithm value 0..3.
  * PARITY UNPINNED (crates not under /root/reference). */

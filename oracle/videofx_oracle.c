@@ -632,3 +632,57 @@ int orc_image_hash(const uint8_t *data, uint32_t width, uint32_t height, uint32_
     *n_bits = k;
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------------ imagersoverlay: gst_video_blend (libgstvideo 1.14.0)
+ *
+ * Behaviour of the library in the image, established by probing gst_video_overlay_composition_blend through ctypes on all
+ * 65536 (source alpha, destination alpha) pairs, 1.5 M random colour samples, eight destination formats and seven global
+ * alphas (0 mismatches; generator and fixtures: tests/golden/make_overlay_blend_golden.py):
+ *   a_s  = overlay alpha;  with a rectangle global alpha g != 1:  a_s = a_s * (int)(g * 255) / 255      (integer division)
+ *   a_s == 0  -> the destination pixel is left untouched
+ *   a_d  = destination alpha byte; 255 for RGB / BGR.  The x byte of RGBx / BGRx / xRGB / xBGR IS treated as alpha by
+ *          1.14.0 (read as a_d and overwritten with the result alpha) -- a quirk of that version, reproduced here.
+ *   a_o  = a_s + a_d * (255 - a_s) / 255
+ *   c_o  = (c_s * a_s + c_d * a_d * (255 - a_s) / 255) / max(a_o, 1)      per colour channel, all divisions truncating
+ * The rectangle is clipped against the frame; overlay rows/columns that fall outside are skipped. */
+int orc_overlay_blend(uint8_t *data, uint32_t width, uint32_t height, uint32_t stride, int format,
+                      const uint8_t *overlay_bgra, uint32_t overlay_width, uint32_t overlay_height, uint32_t overlay_stride,
+                      int32_t x, int32_t y, float global_alpha)
+{
+    int bpp, ir, ig, ib, ia; /* byte index of R, G, B and alpha (-1: none) in a destination pixel */
+    switch (format) {
+    case ORC_FORMAT_RGBA: case ORC_FORMAT_RGBX: bpp = 4; ir = 0; ig = 1; ib = 2; ia = 3; break;
+    case ORC_FORMAT_BGRA: case ORC_FORMAT_BGRX: bpp = 4; ir = 2; ig = 1; ib = 0; ia = 3; break;
+    case ORC_FORMAT_ARGB: case ORC_FORMAT_XRGB: bpp = 4; ir = 1; ig = 2; ib = 3; ia = 0; break;
+    case ORC_FORMAT_ABGR: case ORC_FORMAT_XBGR: bpp = 4; ir = 3; ig = 2; ib = 1; ia = 0; break;
+    case ORC_FORMAT_RGB: bpp = 3; ir = 0; ig = 1; ib = 2; ia = -1; break;
+    case ORC_FORMAT_BGR: bpp = 3; ir = 2; ig = 1; ib = 0; ia = -1; break;
+    default: return ORC_ERR_FORMAT;
+    }
+    const int have_g = global_alpha != 1.0f;
+    const uint32_t g = (uint32_t)(int)(global_alpha * 255.0f);
+    for (uint32_t oy = 0; oy < overlay_height; oy++) {
+        const int64_t dy = (int64_t)y + oy;
+        if (dy < 0 || dy >= (int64_t)height) continue;
+        for (uint32_t ox = 0; ox < overlay_width; ox++) {
+            const int64_t dx = (int64_t)x + ox;
+            if (dx < 0 || dx >= (int64_t)width) continue;
+            const uint8_t *s = overlay_bgra + (size_t)oy * overlay_stride + (size_t)ox * 4;
+            uint8_t *d = data + (size_t)dy * stride + (size_t)dx * (size_t)bpp;
+            uint32_t a_s = s[3];
+            if (have_g) a_s = a_s * g / 255u;
+            if (a_s == 0) continue;
+            const uint32_t a_d = ia >= 0 ? d[ia] : 255u;
+            const uint32_t a_o = a_s + a_d * (255u - a_s) / 255u;
+            const uint32_t div = a_o ? a_o : 1u;
+            const uint32_t cs[3] = {s[2], s[1], s[0]}; /* overlay is BGRA */
+            const int idx[3] = {ir, ig, ib};
+            for (int c = 0; c < 3; c++) {
+                uint32_t v = (cs[c] * a_s + d[idx[c]] * a_d * (255u - a_s) / 255u) / div;
+                d[idx[c]] = (uint8_t)(v > 255u ? 255u : v);
+            }
+            if (ia >= 0) d[ia] = (uint8_t)a_o;
+        }
+    }
+    return ORC_OK;
+}

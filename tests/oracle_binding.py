@@ -12,7 +12,7 @@ SO = os.path.join(ROOT, "oracle", "liboracle.so")
 
 FORMATS = {
     "RGBx": 0, "xRGB": 1, "BGRx": 2, "xBGR": 3, "RGBA": 4, "ARGB": 5, "BGRA": 6, "ABGR": 7,
-    "RGB": 8, "BGR": 9, "RGBA64_LE": 10, "RGBA64_BE": 11, "I420": 12, "A420": 13,
+    "RGB": 8, "BGR": 9, "RGBA64_LE": 10, "RGBA64_BE": 11, "I420": 12, "A420": 13, "RGB10A2_LE": 14,
 }
 
 _lib = None
@@ -288,3 +288,12 @@ def ssim_band(a: np.ndarray, b: np.ndarray, width, height, stride_a, stride_b, f
 
 def ssim_combine(mean, mad, n_scales):
     return lib().orc_ssim_combine((ctypes.c_double * 5)(*mean), (ctypes.c_double * 5)(*mad), n_scales)
+
+
+def overlay_blend(dest: np.ndarray, width, height, stride, fmt, overlay: np.ndarray, ow, oh, x, y, global_alpha=1.0):
+    """In place on `dest`; overlay is BGRA with stride ow*4.  Returns the status."""
+    L = lib()
+    L.orc_overlay_blend.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_int, c_void_p, c_uint32, c_uint32, c_uint32,
+                                    ctypes.c_int32, ctypes.c_int32, ctypes.c_float]
+    L.orc_overlay_blend.restype = c_int
+    return L.orc_overlay_blend(dest.ctypes.data, width, height, stride, _fmt(fmt), overlay.ctypes.data, ow, oh, ow * 4, x, y, global_alpha)

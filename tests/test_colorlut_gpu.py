@@ -151,3 +151,27 @@ def test_colorlut_errors(gpu, luts):
         assert gpu.lib().mvfx_colorlut_transform_frame_host(big.h, ctypes.byref(fi), ctypes.byref(fo)) == gpu.ERR_INVALID_ARGUMENT
     finally:
         gpu.lib().mvfx_thread_set_options(gpu.options(placement=0).word)
+
+
+# ---- RGB10A2_LE: the third format of d3d12colorlut's caps (d3d12colorlut/imp.rs:236-244), device memory only
+@pytest.mark.parametrize("which", ["3d33", "3d9", "1d"])
+def test_colorlut_rgb10a2_le_matches_oracle(gpu, which):
+    text = {"3d33": cubes.analytic_3d(33), "3d9": cubes.analytic_3d(9),
+            "1d": "LUT_1D_SIZE 3\nDOMAIN_MIN 0 0.1 0\nDOMAIN_MAX 1 0.9 2\n0 0 0\n0.25 0.9 0.5\n1 1 0.75\n"}[which]
+    w, h = 1021, 67
+    stride = w * 4 + 12
+    rng = np.random.default_rng(0x10A2)
+    src = rng.integers(0, 256, (h, stride), dtype=np.uint8)
+    # one row holding every 10-bit value in every channel
+    v = np.arange(1024, dtype=np.uint32)[:w]
+    src[0, :w * 4] = (v | (v[::-1] << 10) | (((v * 7) % 1024) << 20) | ((v % 4) << 30)).astype("<u4").view(np.uint8)
+    want = np.zeros_like(src)
+    o = orc.CubeLut(text)
+    assert o.apply(src, stride, want, stride, w, h, "RGB10A2_LE") == 0
+    lut = gpu.CubeLut(text)
+    di, do = gpu.DeviceBuffer(src.nbytes).upload(src), gpu.DeviceBuffer(src.nbytes).upload(np.zeros_like(src))
+    lut.apply_device(di.ptr, stride, do.ptr, stride, w, h, "RGB10A2_LE")
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    got = do.download().reshape(h, stride)
+    assert np.array_equal(got[:, :w * 4], want[:, :w * 4])
+    assert not got[:, w * 4:].any()  # row padding untouched

@@ -243,3 +243,33 @@ def test_float_parsing_is_locale_independent(vfx):
     finally:
         locale.setlocale(locale.LC_NUMERIC, saved)
     print("comma-decimal locale exercised:", switched)
+
+
+# ---- .cube writer: parse(write(lut)) == lut bit for bit, for the product parser AND the oracle parser
+WRITER_CASES = {
+    "analytic9": lambda: cubes.analytic_3d(9),
+    "1d_domain_nan_inf": lambda: "LUT_1D_SIZE 4\nDOMAIN_MIN -0.25 0 0.125\nDOMAIN_MAX 1.5 2 1\n0 0 0\n0.1 0.33333334 1e-7\n0.7 nan -inf\n1 1.00000012 3.4028235e38\n",
+    "3d_denormal": lambda: "LUT_3D_SIZE 2\n0 0 0\n1 0 0\n0 1 0\n1 1 0\n0 0 1\n1 0 1\n0 1 1\n0.99999994 1 1e-45\n",
+}
+
+
+@pytest.mark.parametrize("which", list(WRITER_CASES))
+def test_cube_writer_round_trips_bit_for_bit(vfx, which):
+    text = WRITER_CASES[which]()
+    a = vfx.CubeLut(text)
+    written = a.write()
+    assert written.startswith("LUT_3D_SIZE" if a.is_3d else "LUT_1D_SIZE")
+    b = vfx.CubeLut(written)
+    assert (a.is_3d, a.size) == (b.is_3d, b.size)
+    for u, v in zip(a.domain(), b.domain()):
+        assert np.array_equal(u.view(np.uint32), v.view(np.uint32))
+    if a.is_3d:
+        assert np.array_equal(a.rgba().view(np.uint32), b.rgba().view(np.uint32))
+    else:
+        for c in range(3):
+            ta, tb = a.table(c), b.table(c)
+            assert np.array_equal(np.isnan(ta), np.isnan(tb))
+            assert np.array_equal(ta[~np.isnan(ta)].view(np.uint32), tb[~np.isnan(tb)].view(np.uint32))
+    o = orc.CubeLut(written)  # the independent parser accepts the writer's text too
+    assert o.ok, o.error
+    assert o.apply is not None and written.count("\n") == (a.size ** 3 if a.is_3d else a.size) + (3 if "DOMAIN_MIN" in written else 1)
