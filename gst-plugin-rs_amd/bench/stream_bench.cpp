@@ -43,13 +43,14 @@ extern "C" {
 // n_threads host threads; thread t filters frames[t*frames_per_thread + (i % frames_per_thread)] for
 // i in [0, warmup + launches), one mvfx_hsvfilter_transform_frame_ip per frame on its own stream, no
 // synchronisation between launches (the device-memory element hands the buffer on with an event).
-// Timed region: all threads released together after their warm-up has drained; ends when the last
-// thread's stream has drained.  seconds_out = that wall time; thread_seconds[t] = thread t's own span.
-int mvfxbench_hsvfilter_streams(int device, uint32_t n_threads, uint32_t warmup, uint32_t launches, const mvfx_frame *frames,
+// Timed region (repeated `reps` times back to back, each bracketed by barriers): all threads released together after the
+// previous work has drained; ends when the last thread's stream has drained.  seconds_out[r] = wall time of repetition r;
+// thread_seconds[t] = thread t's own span in the last repetition.
+int mvfxbench_hsvfilter_streams(int device, uint32_t n_threads, uint32_t warmup, uint32_t launches, uint32_t reps, const mvfx_frame *frames,
                                 uint32_t frames_per_thread, const mvfx_hsvfilter_settings *settings, uint32_t options,
                                 double *seconds_out, double *thread_seconds)
 {
-    if (!frames || !settings || !seconds_out || n_threads == 0 || frames_per_thread == 0) return MVFX_ERR_INVALID_ARGUMENT;
+    if (!frames || !settings || !seconds_out || n_threads == 0 || frames_per_thread == 0 || reps == 0) return MVFX_ERR_INVALID_ARGUMENT;
     SpinBarrier ready(n_threads + 1), go(n_threads + 1), done(n_threads + 1);
     std::vector<int> status(n_threads, MVFX_OK);
     std::vector<double> span(n_threads, 0.0);
@@ -64,21 +65,25 @@ int mvfxbench_hsvfilter_streams(int device, uint32_t n_threads, uint32_t warmup,
                 rc = mvfx_hsvfilter_transform_frame_ip(&mine[i % frames_per_thread], settings, st);
             if (rc == MVFX_OK) rc = mvfx_stream_synchronize(st);
             ready.wait();
-            go.wait();
-            const double t0 = now_s();
-            for (uint32_t i = 0; i < launches && rc == MVFX_OK; i++)
-                rc = mvfx_hsvfilter_transform_frame_ip(&mine[(warmup + i) % frames_per_thread], settings, st);
-            if (rc == MVFX_OK) rc = mvfx_stream_synchronize(st);
-            span[t] = now_s() - t0;
+            for (uint32_t r = 0; r < reps; r++) {
+                go.wait();
+                const double t0 = now_s();
+                for (uint32_t i = 0; i < launches && rc == MVFX_OK; i++)
+                    rc = mvfx_hsvfilter_transform_frame_ip(&mine[(warmup + i) % frames_per_thread], settings, st);
+                if (rc == MVFX_OK) rc = mvfx_stream_synchronize(st);
+                span[t] = now_s() - t0;
+                done.wait();
+            }
             status[t] = rc;
-            done.wait();
         });
     }
     ready.wait();
-    const double t0 = now_s();
-    go.wait();
-    done.wait();
-    *seconds_out = now_s() - t0;
+    for (uint32_t r = 0; r < reps; r++) {
+        const double t0 = now_s();
+        go.wait();
+        done.wait();
+        seconds_out[r] = now_s() - t0;
+    }
     for (std::thread &th : pool) th.join();
     for (uint32_t t = 0; t < n_threads; t++) {
         if (thread_seconds) thread_seconds[t] = span[t];
