@@ -614,6 +614,7 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
     const uint32_t ax = min(cx > 0 ? cx - 1 : 0u, hi), ay = min(cy > 0 ? cy - 1 : 0u, hi), az = min(cz > 0 ? cz - 1 : 0u, hi);
     const uint32_t anchor = (ax + p.size * (ay + p.size * az)) * kCellF4; // float4 units; wave-uniform
     float4 *mine = nbr[wave];
+    const uint32_t wave_lds_bytes = wave * (uint32_t)(kTileWaveLdsFloat4 * sizeof(float4));
     mine[lane] = p.cells[anchor + rel0];
     mine[64 + lane] = p.cells[anchor + rel1];
     if (lane < (uint32_t)kTileNbPieces - 128u) mine[128 + lane] = p.cells[anchor + rel2];
@@ -625,7 +626,12 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
         const uint32_t dx = ix[j] - ax, dy = iy[j] - ay, dz = iz[j] - az; // unsigned: below the anchor wraps to a huge value
         float4 c6[6];
         if (dx < 3u && dy < 3u && dz < 3u) {
-            const float4 *cell = mine + (dx + 3u * (dy + 3u * dz)) * 6u;
+            // 24-bit multiply-adds, the last one spelled out: plain `mine + index * 6` compiles to three quarter-rate
+            // v_mad_u64_u32 per pixel
+            const uint32_t nbi = __umul24(dz, 9u) + __umul24(dy, 3u) + dx;
+            uint32_t off;
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(nbi), "s"(96u), "v"(wave_lds_bytes));
+            const float4 *cell = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(&nbr[0][0]) + off);
 #pragma unroll
             for (int i = 0; i < 6; i++) c6[i] = cell[i];
         } else {
@@ -635,7 +641,7 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
             // was built and measured: no faster on uniform-random colours -- there the L1's miss path is the floor (a cell is
             // two 64-byte L2 requests, ~0.39 requests per clock per CU) -- and slower when only a few pixels of a tile fall
             // outside (profiles/r2/colorlut_random_floor.txt)
-            const float4 *cell = p.cells + (ix[j] + p.size * (iy[j] + p.size * iz[j])) * kCellF4;
+            const float4 *cell = p.cells + __umul24(__umul24(__umul24(iz[j], p.size) + iy[j], p.size) + ix[j], kCellF4); // < 2^24 (size <= 65)
 #pragma unroll
             for (int i = 0; i < 6; i++) c6[i] = cell[i];
         }
