@@ -17,7 +17,7 @@ struct Scratch {
     void *ptr = nullptr;
     size_t cap = 0;
 };
-constexpr int kScratchSlots = 4;
+constexpr int kScratchSlots = 6; // 0-3: staging of the *_host entry points and small results; 5: colordetect's per-XCD tables (fixed size, never regrown)
 
 // Per-thread, per-device staging state of the *_host entry points (a thread that switches devices with
 // mvfx_set_device gets a separate stream and scratch set for each ordinal); released when the thread (e.g. a

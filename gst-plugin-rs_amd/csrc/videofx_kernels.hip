@@ -41,6 +41,7 @@ constexpr uint32_t kHistWords = kHistBins / 2;         // packed u16 pairs
 constexpr uint32_t kMaxSamplesPerGroup = 65535;        // 16-bit bins cannot overflow
 constexpr uint32_t kMaxGroupsPerLaunch = 2048;
 constexpr int kHistInFlight = 8;                       // sample loads a lane issues before binning
+constexpr uint32_t kXcdTableWords = kHistBins + 8;     // one private table per XCD: 32768 counters + 6 bounds (+2 pad: 16-byte rows)
 
 struct HistLayout {
     int bpp, ir, ig, ib, ia; // ia < 0: no alpha (255)
@@ -48,7 +49,7 @@ struct HistLayout {
 
 __global__ __launch_bounds__(kHistBlock) void colordetect_hist_kernel(
     const uint8_t *plane, uint64_t first_sample, uint64_t n_samples, uint32_t samples_per_group,
-    uint32_t quality, HistLayout lay, uint32_t *hist, uint32_t *minmax)
+    uint32_t quality, HistLayout lay, uint32_t *xcd_tables)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist_lds[]; // kHistWords + 8 words (> 64 KiB: dynamic)
     uint32_t *bins = hist_lds;
@@ -120,29 +121,51 @@ __global__ __launch_bounds__(kHistBlock) void colordetect_hist_kernel(
         }
     }
     __syncthreads();
-    // flush: only the non-empty LDS words, ONE 64-bit device-scope atomic per word = two neighbouring bins (their u32
-    // counters sit side by side in the 8-byte aligned global table and a bin cannot reach 2^32 samples, so the low half
-    // never carries into the high one).  Device-scope atomics run at ~55 G/s on this part, which is what bounds
-    // uniform-random colours (every sample its own bin): 32.2 us with one 32-bit atomic per bin, 24.6 us packed;
-    // natural video touches a few thousand bins per group and spends ~1.5 us here.
+    // flush: only the non-empty LDS words, one 64-bit atomic per word = two neighbouring bins (their u32 counters sit side
+    // by side in the 8-byte aligned table and a bin cannot reach 2^32 samples, so the low half never carries into the high one).
+    // Round 1 flushed into ONE table with device-scope atomics (~55 G/s on this part: 15 us for the 0.8 M non-empty words of a
+    // uniform-random 4K frame).  The XCDs' L2s are not coherent with each other, but each is the point of coherence of its own
+    // CUs: every workgroup now adds into the private table of the XCD IT RUNS ON (HW_REG_XCC_ID, read from the hardware --
+    // nothing is assumed about the block -> XCD mapping) with workgroup-scope atomics, which execute in that XCD's L2; the
+    // kernel boundary writes the L2s back and colordetect_reduce_kernel adds the eight tables.
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 7u;
+    uint32_t *hist = xcd_tables + (size_t)xcc * kXcdTableWords;
     for (uint32_t i = threadIdx.x; i < kHistWords; i += kHistBlock) {
         const uint32_t v = bins[i];
         if (v)
-            atomicAdd(reinterpret_cast<unsigned long long *>(hist) + i,
-                      (unsigned long long)(v & 0xffffu) | ((unsigned long long)(v >> 16) << 32));
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(hist) + i,
+                                   (unsigned long long)(v & 0xffffu) | ((unsigned long long)(v >> 16) << 32), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (threadIdx.x < 3) {
-        atomicMin(&minmax[2 * threadIdx.x], s_min[threadIdx.x]);
-        atomicMax(&minmax[2 * threadIdx.x + 1], s_max[threadIdx.x]);
+        __hip_atomic_fetch_min(&hist[kHistBins + 2 * threadIdx.x], s_min[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(&hist[kHistBins + 2 * threadIdx.x + 1], s_max[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
-// zeroes the 32768 global bins and seeds the six bounds: one launch instead of a kernel + a memset node
-__global__ __launch_bounds__(256) void colordetect_init_kernel(uint32_t *hist, uint32_t *minmax)
+// Second launch: bin b of the result = sum of the eight XCD tables; the tables are left in their idle state (zero counts,
+// bounds 255 / 0) for the next frame, so no separate clearing launch or memset exists.  4 bins per lane.
+__global__ __launch_bounds__(256) void colordetect_reduce_kernel(uint32_t *xcd_tables, uint32_t *hist, uint32_t *minmax)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    reinterpret_cast<uint4 *>(hist)[i] = make_uint4(0, 0, 0, 0);
-    if (i < 6) minmax[i] = (i & 1) ? 0u : 255u;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x; // uint4 index, kHistBins / 4 of them
+    uint4 acc = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+        uint4 *t = reinterpret_cast<uint4 *>(xcd_tables + (size_t)k * kXcdTableWords) + i;
+        const uint4 v = *t;
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        *t = make_uint4(0, 0, 0, 0);
+    }
+    reinterpret_cast<uint4 *>(hist)[i] = acc;
+    if (i < 6) {
+        uint32_t m = (i & 1) ? 0u : 255u;
+        for (uint32_t k = 0; k < 8; k++) {
+            uint32_t *b = xcd_tables + (size_t)k * kXcdTableWords + kHistBins + i;
+            m = (i & 1) ? max(m, *b) : min(m, *b);
+            *b = (i & 1) ? 0u : 255u;
+        }
+        minmax[i] = m;
+    }
 }
 
 int colordetect_layout(int format, HistLayout *lay)
@@ -175,19 +198,28 @@ int colordetect_hist_impl(const mvfx_frame *frame, uint32_t quality, uint64_t fi
     if (first_sample > total_samples) first_sample = total_samples;
     if (n_samples > total_samples - first_sample) n_samples = total_samples - first_sample;
 
-    static_assert(kHistBins % (256 * 4) == 0, "init kernel writes uint4 per lane");
+    static_assert(kHistBins % (256 * 4) == 0, "the reduce kernel handles uint4 per lane");
     if ((reinterpret_cast<uintptr_t>(hist_dev) & 15) != 0)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "colordetect: the histogram buffer must be 16-byte aligned");
-    hipLaunchKernelGGL(colordetect_init_kernel, dim3(kHistBins / (256 * 4)), dim3(256), 0, st, hist_dev, minmax_dev);
     int dev = 0;
     (void)hipGetDevice(&dev);
     constexpr size_t kHistLds = (kHistWords + 8) * sizeof(uint32_t);
-    // per device, once per thread (not per frame): the CU count and the opt-in to > 64 KiB of dynamic LDS
+    // per device, once per thread (not per frame): the CU count, the opt-in to > 64 KiB of dynamic LDS, and the eight
+    // per-XCD tables (1 MiB) in their idle state (the reduce kernel restores it after every frame)
     static thread_local int attr_device = -1, cus = 256;
+    static thread_local uint32_t *xcd_tables = nullptr;
     if (attr_device != dev) {
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         MVFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(colordetect_hist_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHistLds));
+        void *tables = nullptr;
+        if (int rc = host_scratch(8 * kXcdTableWords * sizeof(uint32_t), 5, &tables); rc != MVFX_OK) return rc;
+        std::vector<uint32_t> idle(8 * kXcdTableWords, 0u);
+        for (uint32_t k = 0; k < 8; k++)
+            for (uint32_t c = 0; c < 3; c++) idle[(size_t)k * kXcdTableWords + kHistBins + 2 * c] = 255u;
+        MVFX_HIP_TRY(hipMemcpyAsync(tables, idle.data(), idle.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        MVFX_HIP_TRY(hipStreamSynchronize(st));
+        xcd_tables = static_cast<uint32_t *>(tables);
         attr_device = dev;
     }
     uint64_t done = 0;
@@ -201,10 +233,12 @@ int colordetect_hist_impl(const mvfx_frame *frame, uint32_t quality, uint64_t fi
         const uint32_t groups = (uint32_t)((chunk + per_group - 1) / per_group);
         hipLaunchKernelGGL(colordetect_hist_kernel, dim3(groups), dim3(kHistBlock), kHistLds, st,
                            static_cast<const uint8_t *>(frame->data), first_sample + done, chunk, per_group, quality,
-                           lay, hist_dev, minmax_dev);
+                           lay, xcd_tables);
         MVFX_HIP_TRY(hipGetLastError());
         done += chunk;
     }
+    hipLaunchKernelGGL(colordetect_reduce_kernel, dim3(kHistBins / (256 * 4)), dim3(256), 0, st, xcd_tables, hist_dev, minmax_dev);
+    MVFX_HIP_TRY(hipGetLastError());
     return MVFX_OK;
 }
 
