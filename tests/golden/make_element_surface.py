@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Extracts the element surface (the drop-in contract of SURVEY.md 8b) of the six elements on
-the path from the reference's machine-readable docs cache
+the path (plus imagersoverlay) from the reference's machine-readable docs cache
 (/root/reference/docs/plugins/gst_plugins_cache.json) into a small JSON fixture:
 plugin name/license/description, element long-name/klass/description/author/hierarchy,
 pad-template formats and every property's type/default/range/mutability.
@@ -14,7 +14,7 @@ import re
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = "/root/reference/docs/plugins/gst_plugins_cache.json"
 WANT = {"hsv": ["hsvfilter", "hsvdetector"], "colorlut": ["colorlut"],
-        "rsvideofx": ["colordetect", "roundedcorners", "videocompare"]}
+        "rsvideofx": ["colordetect", "roundedcorners", "videocompare"], "imagers": ["imagersoverlay"]}
 
 
 def formats_of(caps: str):

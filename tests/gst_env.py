@@ -7,7 +7,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # MVFX_GST_PLUGIN_DIR / MVFX_GST_LD_PRELOAD: `make asan-test` points the same tests at the sanitizer build of the plugins
 PLUGIN_DIR = os.environ.get("MVFX_GST_PLUGIN_DIR") or os.path.join(ROOT, "gst-plugin-rs_amd", "gst-plugins")
-PLUGINS = ["libgsthsv.so", "libgstcolorlut.so", "libgstrsvideofx.so", "libgstmi355hip.so"]
+PLUGINS = ["libgsthsv.so", "libgstcolorlut.so", "libgstrsvideofx.so", "libgstmi355hip.so", "libgstimagers.so"]
 
 
 def tool(name):

