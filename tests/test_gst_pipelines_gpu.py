@@ -437,9 +437,9 @@ def test_imagersoverlay_on_hipmemory_and_scaled(gpu, tmp_path):
     raw = _capture(tmp_path, src, "in.raw").reshape(3, h, w * 4)
     dev = _capture(tmp_path, src + f" ! hipupload ! imagersoverlay location={logo} offset-x=100 offset-y=50 alpha=0.5 ! "
                    "video/x-raw(memory:HIPMemory),format=RGBA ! hipdownload", "dev.raw").reshape(3, h, w * 4)
-    want = raw[0].copy()
-    assert orc.overlay_blend(want, w, h, w * 4, "RGBA", bgra, 48, 32, 100, 50, 0.5) == 0
-    for k in range(3):
+    for k in range(3):  # the smpte pattern's snow strip differs from frame to frame
+        want = raw[k].copy()
+        assert orc.overlay_blend(want, w, h, w * 4, "RGBA", bgra, 48, 32, 100, 50, 0.5) == 0
         assert np.array_equal(dev[k], want)
     # render size != image size: libgstvideo scales the rectangle (once per composition); host and device paths agree
     args = f"imagersoverlay location={logo} offset-x=10 offset-y=10 overlay-width=96 overlay-height=40"
