@@ -228,18 +228,82 @@ def measured_copy_ceiling(w):
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
 
-def cpu_baseline(seconds: float):
+# ------------------------------------------------------------------------------------------------ frame contents
+
+FRAME_CONTENTS = ("videotestsrc", "natural", "random")
+CONTENT_TEXT = {
+    "videotestsrc": "videotestsrc pattern=smpte RGBA frames (colour bars + LCG snow, byte-identical to GStreamer's generator: "
+                    "tests/test_videotestsrc_frames_cpu.py; consecutive frames of the stream, i.e. distinct snow in each)",
+    "natural": "smooth colour gradients (another phase per frame) + uniform noise of +-3 codes (natural-like)",
+    "random": "uniform-random u8 RGBA (torch.randint)",
+}
+
+
+def natural_frame(torch, dev, gen, k, W, H):
+    """One natural-like RGBA frame as a flat u8 tensor: smooth 2-D colour gradients (phase k) + noise of +-3 codes."""
+    x = torch.linspace(0, 1, W, device=dev).view(1, W)
+    y = torch.linspace(0, 1, H, device=dev).view(H, 1)
+    ph = 0.37 * k
+    img = torch.stack([(0.5 + 0.45 * torch.sin(3.0 * x + 2.0 * y + ph)).expand(H, W),
+                       (0.5 + 0.45 * torch.sin(5.0 * y - 1.5 * x + 2 * ph)).expand(H, W),
+                       (0.5 + 0.45 * torch.cos(4.0 * x * y + ph)).expand(H, W),
+                       torch.ones((H, W), device=dev)], dim=-1) * 255.0
+    noise = torch.randint(-3, 4, img.shape, device=dev, generator=gen).float()
+    noise[..., 3] = 0
+    return (img + noise).clamp(0, 255).to(torch.uint8).view(-1)
+
+
+def fill_frames(torch, dev, gen, flat, kind, W, H, first_frame=0):
+    """Fill flat[n, W*H*4] (device, u8) with `kind` frames; frame j is frame first_frame + j of its stream."""
+    n = flat.shape[0]
+    if kind == "random":
+        flat.random_(0, 256, generator=gen)
+    elif kind == "natural":
+        for j in range(n):
+            flat[j] = natural_frame(torch, dev, gen, first_frame + j, W, H)
+    elif kind == "videotestsrc":
+        import numpy as np
+        from tests import frames as _frames
+        base, _ = _frames.videotestsrc_smpte(W, H, 1)
+        flat[:] = torch.from_numpy(base.reshape(-1)).to(dev).unsqueeze(0)
+        x0, y0 = _frames.vts_snow_geometry(W, H)
+        per_frame = (W - x0) * (H - y0)
+        a_np, c_np = _frames.vts_lcg_affine(per_frame)
+        a_full, c_full = int(a_np[-1]), int(c_np[-1])           # the per_frame-step map: state at the start of the next frame
+        a = torch.from_numpy(a_np.astype(np.int64)).to(dev)
+        c = torch.from_numpy(c_np.astype(np.int64)).to(dev)
+        state = 0
+        for _ in range(first_frame):
+            state = (a_full * state + c_full) & 0xFFFFFFFF
+        for j in range(n):
+            st = (a * state + c) & 0xFFFFFFFF                   # int64 products wrap mod 2^64: the low 32 bits are exact
+            grey = ((st >> 16) & 0xFF).to(torch.uint8).view(H - y0, W - x0, 1)
+            flat[j].view(H, W, 4)[y0:, x0:, :3] = grey
+            state = (a_full * state + c_full) & 0xFFFFFFFF
+    else:
+        raise ValueError(kind)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+
+def cpu_baseline(seconds: float, content: str = "videotestsrc"):
     """Oracle (port of hsvfilter/imp.rs:76-120, gcc -O3 -ffp-contract=off like profile.release) on the GPU box's host cores:
     one thread -- what the reference does, its transform_frame_ip runs on ONE streaming thread per element -- and
-    nproc threads each filtering its own stream.  8 distinct frames rotate so the 33 MB input is not cache
-    resident.  Bounded: ~seconds per leg."""
+    nproc threads each filtering its own stream.  8 distinct frames of the same content as the GPU legs rotate so
+    the 33 MB input is not cache resident.  Bounded: ~seconds per leg."""
     import threading
     import numpy as np
     from tests import frames
     from tests import oracle_binding as orc
     nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     distinct = 8
-    src = [frames.random_frame(0x5EED0001 + k, W4K, H4K) for k in range(distinct)]
+    if content == "videotestsrc":
+        vts, _ = frames.videotestsrc_smpte(W4K, H4K, distinct)
+        src = [vts[k] for k in range(distinct)]
+        what = "videotestsrc pattern=smpte, 8 consecutive frames rotating"
+    else:
+        src = [frames.random_frame(0x5EED0001 + k, W4K, H4K) for k in range(distinct)]
+        what = "uniform random, 8 distinct frames rotating, seeds 0x5EED0001..8"
 
     def run(n_threads, budget):
         counts = [0] * n_threads
@@ -271,7 +335,7 @@ def cpu_baseline(seconds: float):
     one_fps, one_n, one_dt = run(1, seconds)
     all_fps, all_n, all_dt = run(nproc, seconds) if nproc > 1 else (one_fps, one_n, one_dt)
     return {"value": one_fps, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{one_n} frames of 3840x2160 RGBA (uniform random, 8 distinct frames rotating, seeds 0x5EED0001..8), "
+            "sample": f"{one_n} frames of 3840x2160 RGBA ({what}), "
                       f"oracle/hsv_oracle.c gcc -O3 -ffp-contract=off, 1 thread, {one_dt:.1f} s",
             "all_cores": {"value": all_fps, "unit": "frames/s", "cores": nproc, "nproc": nproc,
                           "sample": f"{all_n} frames, {nproc} threads x own stream of frames, {all_dt:.1f} s per thread"}}
@@ -446,18 +510,9 @@ def config_main(args):
             data = "synthetic videotestsrc-smpte-like bars, device-resident"
         else:  # smooth 2-D colour gradients (different phase per frame) + sensor-like noise of +-3 codes
             data = "synthetic smooth colour gradients + uniform noise of +-3 codes (natural-like), device-resident"
-            x = torch.linspace(0, 1, W, device=dev).view(1, 1, W)
-            y = torch.linspace(0, 1, H, device=dev).view(1, H, 1)
             src = torch.empty((pool * nb, FRAME_BYTES), dtype=torch.uint8, device=dev)
             for k in range(pool * nb):
-                ph = 0.37 * k
-                img = torch.stack([(0.5 + 0.45 * torch.sin(3.0 * x + 2.0 * y + ph)).expand(1, H, W),
-                                   (0.5 + 0.45 * torch.sin(5.0 * y - 1.5 * x + 2 * ph)).expand(1, H, W),
-                                   (0.5 + 0.45 * torch.cos(4.0 * x * y + ph)).expand(1, H, W),
-                                   torch.ones((1, H, W), device=dev)], dim=-1) * 255.0
-                noise = torch.randint(-3, 4, img.shape, device=dev, generator=gen).float()
-                noise[..., 3] = 0
-                src[k] = (img + noise).clamp(0, 255).to(torch.uint8).view(-1)
+                src[k] = natural_frame(torch, dev, gen, k, W, H)
         dst = torch.empty((pool * nb, FRAME_BYTES), dtype=torch.uint8, device=dev)
         fi = [(vfx.Frame * nb)(*[vfx.make_frame(src[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
         fo = [(vfx.Frame * nb)(*[vfx.make_frame(dst[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
@@ -528,12 +583,15 @@ def hsvfilter_main(args):
     opts = vfx.options(variant=args.variant, nontemporal=bool(args.streaming), typed=bool(args.typed_loads)).word
     vfx.check(lib.mvfx_thread_set_options(opts))
 
-    # ---- resident frame pool: (pool + 2 scratch) x batch distinct uniform-random 4K RGBA frames --------------
+    # ---- resident frame pool: (pool + 2 scratch) x batch distinct 4K RGBA frames of --frame-content ---------
     pool = max(1, args.pool)
     n_scratch = 2
     gen = torch.Generator(device=dev)
     gen.manual_seed(0x5EED0100 + rank)
-    frames = torch.randint(0, 256, (pool + n_scratch, args.batch, FRAME_BYTES), dtype=torch.uint8, device=dev, generator=gen)
+    frames = torch.empty((pool + n_scratch, args.batch, FRAME_BYTES), dtype=torch.uint8, device=dev)
+    flat_frames = frames.view(-1, FRAME_BYTES)
+    # rank r's shard = its own streams: with videotestsrc content every rank starts further down the snow sequence
+    fill_frames(torch, dev, gen, flat_frames, args.frame_content, W4K, H4K, first_frame=rank * flat_frames.shape[0])
     settings = vfx.HsvFilterSettings(*SETTINGS)
     frame_arrays = []
     for b in range(pool + n_scratch):
@@ -552,16 +610,21 @@ def hsvfilter_main(args):
     def step(i):           # timed: batch i of the untouched pool
         launch(i % pool)
 
-    settle_steps = settle(scratch_step, args.settle_seconds, w.sync)
-    if args.converged_data:  # A/B only: filter the timed pool a few times first (what round 1 timed without saying so)
-        for k in range(args.converged_data):
-            for b in range(pool):
-                launch(b)
-        w.sync()
-    for i in range(args.warmup):
-        scratch_step(i)
-    elapsed, kernel_ms = w.timed(step, args.steps, events=True)
-    elapsed, kernel_ms = w.max_over_ranks(elapsed, kernel_ms)
+    def batch_leg():
+        """settle + W warm-up launches on the scratch batches, then K timed launches on untouched pool batches."""
+        n_settle = settle(scratch_step, args.settle_seconds, w.sync)
+        if args.converged_data:  # A/B only: filter the timed pool a few times first (what round 1 timed without saying so)
+            for k in range(args.converged_data):
+                for b in range(pool):
+                    launch(b)
+            w.sync()
+        for i in range(args.warmup):
+            scratch_step(i)
+        secs, k_ms = w.timed(step, args.steps, events=True)
+        secs, k_ms = w.max_over_ranks(secs, k_ms)
+        return n_settle, secs, k_ms
+
+    settle_steps, elapsed, kernel_ms = batch_leg()
     batch_fps_rank = w.gather(args.steps * args.batch / elapsed)
     batch_fps = args.steps * args.batch * world / elapsed
 
@@ -604,6 +667,17 @@ def hsvfilter_main(args):
     # measured after the timed legs: a burst of plain copies between settle and the timed steps leaves the governor in another
     # power state (the timed kernels then ran 3-4 % slower: profiles/r2/ab_fresh_vs_converged_data.txt)
     ceiling = measured_copy_ceiling(w)
+    # ---- the same batch leg on the other frame contents: the kernel has no data-dependent branch, but the chip is power
+    # limited on this kernel and the bytes decide how much the data paths toggle (tools/exp_content_power.py) -------------
+    sweep = {}
+    if args.content_sweep:
+        for kind in FRAME_CONTENTS:
+            if kind == args.frame_content:
+                continue
+            fill_frames(torch, dev, gen, flat_frames, kind, W4K, H4K, first_frame=rank * flat_frames.shape[0])
+            _, sw_secs, sw_ms = batch_leg()
+            sweep[kind] = {"value": args.steps * args.batch * world / sw_secs, "unit": "frames/s", "avg_launch_ms": sw_ms,
+                           "frac": args.batch * 2 * FRAME_BYTES / (sw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "data": CONTENT_TEXT[kind]}
     # HBM traffic per launch from the committed rocprofv3 PMC passes (cannot be collected live)
     traffic = None
     try:
@@ -631,11 +705,12 @@ def hsvfilter_main(args):
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": ("synthetic uniform-random u8 RGBA (torch.randint, seed 0x5EED0100+rank), device-resident; the timed steps start "
-                 "on frames no kernel has touched (settle + warm-up run on scratch batches)") if not args.converged_data else
-                f"A/B: uniform-random frames filtered {args.converged_data}x before the timed steps (converged, low-entropy)",
+        "data": (f"synthetic {CONTENT_TEXT[args.frame_content]}, device-resident; the timed steps start on frames no kernel has "
+                 "touched (settle + warm-up run on scratch batches)") if not args.converged_data else
+                f"A/B: {args.frame_content} frames filtered {args.converged_data}x before the timed steps (converged, low-entropy)",
         "config": {"workload": "hsvfilter 3840x2160 RGBA in place, hue-shift=90 saturation-mul=1.25 "
                                "saturation-off=-0.05 value-mul=0.9 value-off=0.02",
+                   "frame_content": args.frame_content, "other_frame_contents": sweep,
                    "launch_model": head["launch_model"], "other_launch_model": other,
                    "frames_per_step_per_gpu": args.batch, "resident_batches": pool,
                    "settle_seconds_before_warmup": args.settle_seconds, "settle_steps": settle_steps,
@@ -653,7 +728,7 @@ def hsvfilter_main(args):
                      "launch_model": batch_model["launch_model"]},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.frame_content)
     if rank == 0:
         print(json.dumps(out), flush=True)
     w.finish()
@@ -684,6 +759,12 @@ def main():
     ap.add_argument("--streaming", type=int, default=1,
                     help="MVFX_OPT_NONTEMPORAL: 1 = non-temporal loads/stores (the frames of this workload are not "
                          "read again on the GPU: standalone filter), 0 = normal caching (element chains)")
+    ap.add_argument("--frame-content", default="videotestsrc", choices=list(FRAME_CONTENTS),
+                    help="hsvfilter workload: what the frames hold. videotestsrc = pattern=smpte frames exactly as GStreamer's "
+                         "videotestsrc renders them (the buffers BASELINE.json's workload names); natural = smooth gradients + "
+                         "noise; random = uniform-random bytes (the most power-hungry input: the chip clocks ~8 %% lower on it)")
+    ap.add_argument("--content-sweep", type=int, default=1, choices=[0, 1],
+                    help="hsvfilter workload: also time the batch leg on the other two frame contents (reported in config)")
     ap.add_argument("--content", default="natural", choices=["natural", "random", "smpte"],
                     help="colorlut workload: frame content. The LUT gathers are content dependent: smooth gradients with +-3 "
                          "codes of noise (default), uniform-random colours (worst case: every pixel another LUT cell), or flat "

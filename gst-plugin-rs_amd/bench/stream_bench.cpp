@@ -46,11 +46,23 @@ extern "C" {
 // Timed region (repeated `reps` times back to back, each bracketed by barriers): all threads released together after the
 // previous work has drained; ends when the last thread's stream has drained.  seconds_out[r] = wall time of repetition r;
 // thread_seconds[t] = thread t's own span in the last repetition.
-int mvfxbench_hsvfilter_streams(int device, uint32_t n_threads, uint32_t warmup, uint32_t launches, uint32_t reps, const mvfx_frame *frames,
-                                uint32_t frames_per_thread, const mvfx_hsvfilter_settings *settings, uint32_t options,
-                                double *seconds_out, double *thread_seconds)
+//
+// `batch` frames per launch (mvfx_hsvfilter_transform_frames_ip; 1 = the single-frame entry point): thread t walks its
+// frames in groups of `batch` (frames_per_thread must be a multiple of it) -- the "few threads, each batching the streams it
+// owns" model between the two extremes bench.py reports.
+int mvfxbench_hsvfilter_streams_batched(int device, uint32_t n_threads, uint32_t warmup, uint32_t launches, uint32_t reps,
+                                        const mvfx_frame *frames, uint32_t frames_per_thread, uint32_t batch,
+                                        const mvfx_hsvfilter_settings *settings, uint32_t options, double *seconds_out,
+                                        double *thread_seconds)
 {
-    if (!frames || !settings || !seconds_out || n_threads == 0 || frames_per_thread == 0 || reps == 0) return MVFX_ERR_INVALID_ARGUMENT;
+    if (!frames || !settings || !seconds_out || n_threads == 0 || frames_per_thread == 0 || reps == 0 || batch == 0 ||
+        frames_per_thread % batch != 0)
+        return MVFX_ERR_INVALID_ARGUMENT;
+    const uint32_t groups = frames_per_thread / batch;
+    auto launch = [&](const mvfx_frame *mine, uint32_t i, mvfx_stream st) {
+        const mvfx_frame *f = mine + (size_t)(i % groups) * batch;
+        return batch == 1 ? mvfx_hsvfilter_transform_frame_ip(f, settings, st) : mvfx_hsvfilter_transform_frames_ip(f, batch, settings, st);
+    };
     SpinBarrier ready(n_threads + 1), go(n_threads + 1), done(n_threads + 1);
     std::vector<int> status(n_threads, MVFX_OK);
     std::vector<double> span(n_threads, 0.0);
@@ -62,14 +74,14 @@ int mvfxbench_hsvfilter_streams(int device, uint32_t n_threads, uint32_t warmup,
             mvfx_stream st = mvfx_thread_stream();
             const mvfx_frame *mine = frames + (size_t)t * frames_per_thread;
             for (uint32_t i = 0; i < warmup && rc == MVFX_OK; i++)
-                rc = mvfx_hsvfilter_transform_frame_ip(&mine[i % frames_per_thread], settings, st);
+                rc = launch(mine, i, st);
             if (rc == MVFX_OK) rc = mvfx_stream_synchronize(st);
             ready.wait();
             for (uint32_t r = 0; r < reps; r++) {
                 go.wait();
                 const double t0 = now_s();
                 for (uint32_t i = 0; i < launches && rc == MVFX_OK; i++)
-                    rc = mvfx_hsvfilter_transform_frame_ip(&mine[(warmup + i) % frames_per_thread], settings, st);
+                    rc = launch(mine, warmup + i, st);
                 if (rc == MVFX_OK) rc = mvfx_stream_synchronize(st);
                 span[t] = now_s() - t0;
                 done.wait();
@@ -90,6 +102,14 @@ int mvfxbench_hsvfilter_streams(int device, uint32_t n_threads, uint32_t warmup,
         if (status[t] != MVFX_OK) return status[t];
     }
     return MVFX_OK;
+}
+
+int mvfxbench_hsvfilter_streams(int device, uint32_t n_threads, uint32_t warmup, uint32_t launches, uint32_t reps, const mvfx_frame *frames,
+                                uint32_t frames_per_thread, const mvfx_hsvfilter_settings *settings, uint32_t options,
+                                double *seconds_out, double *thread_seconds)
+{
+    return mvfxbench_hsvfilter_streams_batched(device, n_threads, warmup, launches, reps, frames, frames_per_thread, 1, settings, options,
+                                               seconds_out, thread_seconds);
 }
 
 } // extern "C"

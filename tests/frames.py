@@ -52,3 +52,64 @@ def smpte_like(width: int, height: int, seed: int = 0x5EED0003) -> np.ndarray:
     f[y1:, :, 1] = snow
     f[y1:, :, 2] = snow
     return f.reshape(height, width * 4)
+
+
+# ---------------------------------------------------------------- videotestsrc pattern=smpte, RGBA
+# The frames BASELINE.json's workload names ("synthetic videotestsrc buffers").  Restated from the observable output of
+# GStreamer 1.14's videotestsrc (checked byte for byte against the element itself in tests/test_videotestsrc_frames_cpu.py,
+# several sizes, several consecutive frames): seven 100 % bars over the top 2/3, the reversed blue/black/magenta/black/cyan/
+# black/white strip down to 3/4, then -I / white / +Q in sixths, super-black / black / dark grey in twelfths and, in the last
+# quarter of the width, "snow": grey = bits 16..23 of the C library style LCG  s <- s * 1103515245 + 12345 (mod 2^32), whose
+# state starts at 0 and runs on from frame to frame.
+
+VTS_LCG_A, VTS_LCG_C = 1103515245, 12345
+_VTS_BARS = np.array([[255, 255, 255], [255, 255, 0], [0, 255, 255], [0, 255, 0], [255, 0, 255], [255, 0, 0], [0, 0, 255]], dtype=np.uint8)
+_VTS_BLACK = np.array([0, 0, 0], dtype=np.uint8)
+
+
+def vts_lcg_affine(n: int):
+    """(A_i, C_i) for i = 1..n with  s_{k+i} = A_i * s_k + C_i  (mod 2^32), as uint64 arrays (built by doubling)."""
+    a = np.empty(max(n, 1), dtype=np.uint64)
+    c = np.empty(max(n, 1), dtype=np.uint64)
+    m = np.uint64(0xFFFFFFFF)
+    a[0], c[0] = VTS_LCG_A, VTS_LCG_C
+    have = 1
+    while have < n:
+        take = min(have, n - have)
+        ah, ch = a[have - 1], c[have - 1]  # the `have`-step map
+        a[have:have + take] = (a[:take] * ah) & m
+        c[have:have + take] = (a[:take] * ch + c[:take]) & m
+        have += take
+    return a[:n], c[:n]
+
+
+def vts_snow_geometry(width: int, height: int):
+    """(x0, y0): the snow rectangle is columns x0..width of rows y0..height."""
+    return width * 3 // 4, height * 3 // 4
+
+
+def videotestsrc_smpte(width: int, height: int, n_frames: int = 1, state: int = 0):
+    """(frames[n, height, width*4] uint8 RGBA, LCG state after the last frame)."""
+    base = np.empty((height, width, 4), dtype=np.uint8)
+    base[..., 3] = 255
+    y1, y2 = 2 * height // 3, 3 * height // 4
+    for i in range(7):
+        xa, xb = i * width // 7, (i + 1) * width // 7
+        base[:y1, xa:xb, :3] = _VTS_BARS[i]
+        base[y1:y2, xa:xb, :3] = _VTS_BLACK if i & 1 else _VTS_BARS[6 - i]
+    for i, col in enumerate(([0, 0, 128], [255, 255, 255], [0, 128, 255])):
+        base[y2:, i * width // 6:(i + 1) * width // 6, :3] = col
+    for i, g in enumerate((0, 0, 19)):
+        base[y2:, width // 2 + i * width // 12:width // 2 + (i + 1) * width // 12, :3] = g
+    x0, y0 = vts_snow_geometry(width, height)
+    per_frame = (width - x0) * (height - y0)
+    a, c = vts_lcg_affine(per_frame)
+    out = np.empty((n_frames, height, width, 4), dtype=np.uint8)
+    for f in range(n_frames):
+        out[f] = base
+        if per_frame:
+            s = (a * np.uint64(state) + c) & np.uint64(0xFFFFFFFF)
+            grey = ((s >> np.uint64(16)) & np.uint64(0xFF)).astype(np.uint8).reshape(height - y0, width - x0)
+            out[f, y0:, x0:, :3] = grey[..., None]
+            state = int(s[-1])
+    return out.reshape(n_frames, height, width * 4), state
