@@ -4,12 +4,11 @@
 //  colordetect  (video/videofx/src/colordetect/imp.rs:57-86 -> color_thief::get_palette)
 //     The O(pixels) part of MMCQ is the 5-5-5 histogram over every `quality`-th pixel of the
 //     flat plane (padding included, colordetect/imp.rs:69).  Kernel: 1024-thread workgroups,
-//     LDS-privatised 32768-bin histogram packed as 16-bit pairs (64 KiB, two workgroups per CU;
-//     each workgroup is given < 65536 samples so a 16-bit bin cannot overflow), per-wave
-//     min/max folded through LDS, then one 64-bit device-scope atomic per NON-EMPTY pair of bins into
-//     the 128 KiB global table (dense partial histograms + a reduce kernel were 3x slower: 47 us vs
-//     the frame's 6.6 us read time).  The serial median cut runs on the host (host/mmcq.cpp), as it
-//     does in the reference.
+//     LDS-privatised 32768-bin histogram packed as 16-bit pairs (64 KiB; each workgroup is given
+//     < 65536 samples so a 16-bit bin cannot overflow), per-wave min/max folded through LDS, the
+//     packed histogram of every workgroup written out densely (no global atomics: content
+//     independent timing) and a second launch that adds the partials.  The serial median cut runs
+//     on the host (host/mmcq.cpp), as it does in the reference.
 //  videocompare (video/videofx/src/videocompare/hashed_image.rs:24-79 -> image_hasher Blockhash)
 //     64 block sums (u32) of r+g+b (765 when alpha==0) over an 8x8 grid of W/8 x H/8 blocks:
 //     16-byte non-temporal reads (4 rows in flight per lane), wave shuffle reduction, one plain store per
@@ -36,12 +35,14 @@ namespace {
 
 // ------------------------------------------------------------------ colordetect
 
+typedef uint32_t sum_u32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int kHistBlock = 1024;
 constexpr uint32_t kHistWords = kHistBins / 2;         // packed u16 pairs
 constexpr uint32_t kMaxSamplesPerGroup = 65535;        // 16-bit bins cannot overflow
-constexpr uint32_t kMaxGroupsPerLaunch = 2048;
+constexpr uint32_t kMaxGroupsPerLaunch = 1024;          // 64 MiB of partials
 constexpr int kHistInFlight = 8;                       // sample loads a lane issues before binning
-constexpr uint32_t kXcdTableWords = kHistBins + 8;     // one private table per XCD: 32768 counters + 6 bounds (+2 pad: 16-byte rows)
+constexpr uint32_t kPartialWords = kHistWords + 8;     // scratch per group: 16384 packed pairs + 6 bounds (+2 pad)
 
 struct HistLayout {
     int bpp, ir, ig, ib, ia; // ia < 0: no alpha (255)
@@ -49,7 +50,7 @@ struct HistLayout {
 
 __global__ __launch_bounds__(kHistBlock) void colordetect_hist_kernel(
     const uint8_t *plane, uint64_t first_sample, uint64_t n_samples, uint32_t samples_per_group,
-    uint32_t quality, HistLayout lay, uint32_t *xcd_tables)
+    uint32_t quality, HistLayout lay, uint32_t *partials)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist_lds[]; // kHistWords + 8 words (> 64 KiB: dynamic)
     uint32_t *bins = hist_lds;
@@ -121,52 +122,103 @@ __global__ __launch_bounds__(kHistBlock) void colordetect_hist_kernel(
         }
     }
     __syncthreads();
-    // flush: only the non-empty LDS words, one 64-bit atomic per word = two neighbouring bins (their u32 counters sit side
-    // by side in the 8-byte aligned table and a bin cannot reach 2^32 samples, so the low half never carries into the high one).
-    // Round 1 flushed into ONE table with device-scope atomics (~55 G/s on this part: 15 us for the 0.8 M non-empty words of a
-    // uniform-random 4K frame).  The XCDs' L2s are not coherent with each other, but each is the point of coherence of its own
-    // CUs: every workgroup now adds into the private table of the XCD IT RUNS ON (HW_REG_XCC_ID, read from the hardware --
-    // nothing is assumed about the block -> XCD mapping) with workgroup-scope atomics, which execute in that XCD's L2; the
-    // kernel boundary writes the L2s back and colordetect_reduce_kernel adds the eight tables.  (Measured, 4K: q=1 56 -> 43.6 us,
-    // q=10 uniform-random 24.2 us unchanged, natural 14.3 -> 13.5 us.  Also tried in round 2: every group storing its packed
-    // histogram densely (64 KiB, no atomics) + a summing launch: 37 us whatever the content -- rejected again.)
-    const uint32_t xcc = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 7u;
-    uint32_t *hist = xcd_tables + (size_t)xcc * kXcdTableWords;
-    for (uint32_t i = threadIdx.x; i < kHistWords; i += kHistBlock) {
-        const uint32_t v = bins[i];
-        if (v)
-            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(hist) + i,
-                                   (unsigned long long)(v & 0xffffu) | ((unsigned long long)(v >> 16) << 32), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+    // flush: the group's packed histogram goes out DENSE (64 KiB of coalesced 16-byte stores, no atomics) and
+    // colordetect_reduce_kernel adds the groups' partials.  History: round 1 flushed the non-empty words with device-scope
+    // 64-bit atomics into one table (~55 G atomics/s: 15 us for the 0.8 M non-empty words of a uniform-random 4K frame at
+    // quality 10); round 2 first moved them into per-XCD tables with workgroup-scope atomics (they execute in the XCD's own
+    // L2; q=1 56 -> 43.6 us, q=10 random unchanged at 24 us: ~85 G atomics/s is still ~10 us for 0.8 M of them), then
+    // dropped the atomics: the partials are G x 64 KiB = 12 MiB at 4K, written (non-temporal) and read once.  4K quality 10,
+    // both launches: 26.5 us (uniform-random colours) / 13.9 us (smooth content) with atomics -> 15.8 us whatever the
+    // content; quality 1: 48.5 -> 27.3 us.  (An earlier dense attempt -- row-major partials, a 32-workgroup summing launch --
+    // took 37 us: the layout below and a full-width second launch are what make it pay.)
+    // layout: [block of 16 uint4 columns][group][16 uint4]: the reduce kernel's workgroup (one column block) reads the
+    // groups' 256-byte pieces as ONE contiguous run; the six bounds of every group follow the histograms.
+    const uint32_t n_groups = gridDim.x;
+    uint4 *dst = reinterpret_cast<uint4 *>(partials);
+    const uint4 *src = reinterpret_cast<const uint4 *>(bins);
+#pragma unroll
+    for (uint32_t i = threadIdx.x; i < kHistWords / 4; i += kHistBlock) {
+        const uint4 v = src[i];
+        __builtin_nontemporal_store((sum_u32x4){v.x, v.y, v.z, v.w},
+                                    reinterpret_cast<sum_u32x4 *>(dst) + ((size_t)(i >> 4) * n_groups + blockIdx.x) * 16 + (i & 15));
     }
     if (threadIdx.x < 3) {
-        __hip_atomic_fetch_min(&hist[kHistBins + 2 * threadIdx.x], s_min[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_max(&hist[kHistBins + 2 * threadIdx.x + 1], s_max[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t *bounds = partials + (size_t)n_groups * kHistWords + (size_t)blockIdx.x * 8;
+        bounds[2 * threadIdx.x] = s_min[threadIdx.x];
+        bounds[2 * threadIdx.x + 1] = s_max[threadIdx.x];
     }
 }
 
-// Second launch: bin b of the result = sum of the eight XCD tables; the tables are left in their idle state (zero counts,
-// bounds 255 / 0) for the next frame, so no separate clearing launch or memset exists.  4 bins per lane.
-__global__ __launch_bounds__(256) void colordetect_reduce_kernel(uint32_t *xcd_tables, uint32_t *hist, uint32_t *minmax)
+// Second launch: bin b = sum over the groups' partials (16-bit pairs widened to u32), bounds = min / max over the groups.
+// 256 workgroups x 1024 lanes: workgroup w owns 16 uint4 columns (= 128 bins); lane (c, s) adds column c of the partials
+// s, s+64, ... (all of a 4K frame's 8 MiB in flight at once: with 256 lanes per workgroup and 8 loads per lane the launch was
+// latency bound, 5.9 us at 128 groups and +2 us per 64 more); the four slices of a wave meet by shuffles, the 16 waves in LDS.
+// `accumulate`: add to what hist / minmax already hold (frames of more than kMaxGroupsPerLaunch x 65535 samples take several
+// launches).
+constexpr int kReduceBlock = 1024;
+constexpr uint32_t kReduceGroups = kHistWords / 4 / 16;
+
+__global__ __launch_bounds__(kReduceBlock) void colordetect_reduce_kernel(const uint32_t *partials, uint32_t n_groups, uint32_t *hist,
+                                                                          uint32_t *minmax, int accumulate)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x; // uint4 index, kHistBins / 4 of them
-    uint4 acc = make_uint4(0, 0, 0, 0);
+    __shared__ uint32_t part[16][16 * 8];
+    __shared__ uint32_t mm[32][8];
+    const uint32_t c = threadIdx.x & 15, s = threadIdx.x >> 4; // 64 slices
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t g0 = s; g0 < n_groups; g0 += 64 * 4) { // four loads in flight per lane
+        sum_u32x4 v[4];
 #pragma unroll
-    for (uint32_t k = 0; k < 8; k++) {
-        uint4 *t = reinterpret_cast<uint4 *>(xcd_tables + (size_t)k * kXcdTableWords) + i;
-        const uint4 v = *t;
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        *t = make_uint4(0, 0, 0, 0);
-    }
-    reinterpret_cast<uint4 *>(hist)[i] = acc;
-    if (i < 6) {
-        uint32_t m = (i & 1) ? 0u : 255u;
-        for (uint32_t k = 0; k < 8; k++) {
-            uint32_t *b = xcd_tables + (size_t)k * kXcdTableWords + kHistBins + i;
-            m = (i & 1) ? max(m, *b) : min(m, *b);
-            *b = (i & 1) ? 0u : 255u;
+        for (int j = 0; j < 4; j++) {
+            const uint32_t g = min(g0 + 64u * j, n_groups - 1);
+            v[j] = __builtin_nontemporal_load(reinterpret_cast<const sum_u32x4 *>(partials) + ((size_t)blockIdx.x * n_groups + g) * 16 + c);
         }
-        minmax[i] = m;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (g0 + 64u * j >= n_groups) v[j] = (sum_u32x4){0, 0, 0, 0};
+            acc[0] += v[j].x & 0xffffu; acc[1] += v[j].x >> 16;
+            acc[2] += v[j].y & 0xffffu; acc[3] += v[j].y >> 16;
+            acc[4] += v[j].z & 0xffffu; acc[5] += v[j].z >> 16;
+            acc[6] += v[j].w & 0xffffu; acc[7] += v[j].w >> 16;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { // lanes c, c+16, c+32, c+48 of a wave hold the same column
+        acc[k] += (uint32_t)__shfl_xor((int)acc[k], 16);
+        acc[k] += (uint32_t)__shfl_xor((int)acc[k], 32);
+    }
+    if ((threadIdx.x & 63) < 16) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            part[threadIdx.x >> 6][c * 8 + k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            sum += part[k][threadIdx.x];
+        uint32_t *out = hist + (size_t)blockIdx.x * 128 + threadIdx.x;
+        *out = accumulate ? *out + sum : sum;
+    }
+    if (blockIdx.x == 0) { // bounds: value i of every group's six (min r, max r, min g, max g, min b, max b)
+        const uint32_t i = threadIdx.x & 7, slice = (threadIdx.x >> 3) & 31;
+        uint32_t m = (i & 1) ? 0u : 255u;
+        if (i < 6 && threadIdx.x < 256)
+            for (uint32_t g = slice; g < n_groups; g += 32) {
+                const uint32_t v = partials[(size_t)n_groups * kHistWords + (size_t)g * 8 + i];
+                m = (i & 1) ? max(m, v) : min(m, v);
+            }
+        if (threadIdx.x < 256)
+            mm[slice][i] = m;
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            uint32_t r = (i & 1) ? 0u : 255u;
+            for (int k = 0; k < 32; k++)
+                r = (i & 1) ? max(r, mm[k][i]) : min(r, mm[k][i]);
+            if (accumulate)
+                r = (i & 1) ? max(r, minmax[i]) : min(r, minmax[i]);
+            minmax[i] = r;
+        }
     }
 }
 
@@ -200,53 +252,50 @@ int colordetect_hist_impl(const mvfx_frame *frame, uint32_t quality, uint64_t fi
     if (first_sample > total_samples) first_sample = total_samples;
     if (n_samples > total_samples - first_sample) n_samples = total_samples - first_sample;
 
-    static_assert(kHistBins % (256 * 4) == 0, "the reduce kernel handles uint4 per lane");
+    static_assert(kReduceGroups * 128 == kHistBins, "the reduce kernel's workgroups own 128 bins each");
     if ((reinterpret_cast<uintptr_t>(hist_dev) & 15) != 0)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "colordetect: the histogram buffer must be 16-byte aligned");
     int dev = 0;
     (void)hipGetDevice(&dev);
     constexpr size_t kHistLds = (kHistWords + 8) * sizeof(uint32_t);
-    // per device, once per thread (not per frame): the CU count, the opt-in to > 64 KiB of dynamic LDS, and the eight
-    // per-XCD tables (1 MiB) in their idle state (the reduce kernel restores it after every frame)
+    // per device, once per thread (not per frame): the CU count and the opt-in to > 64 KiB of dynamic LDS
     static thread_local int attr_device = -1, cus = 256;
-    static thread_local uint32_t *xcd_tables = nullptr;
     if (attr_device != dev) {
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         MVFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(colordetect_hist_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHistLds));
-        void *tables = nullptr;
-        if (int rc = host_scratch(8 * kXcdTableWords * sizeof(uint32_t), 5, &tables); rc != MVFX_OK) return rc;
-        std::vector<uint32_t> idle(8 * kXcdTableWords, 0u);
-        for (uint32_t k = 0; k < 8; k++)
-            for (uint32_t c = 0; c < 3; c++) idle[(size_t)k * kXcdTableWords + kHistBins + 2 * c] = 255u;
-        MVFX_HIP_TRY(hipMemcpyAsync(tables, idle.data(), idle.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        MVFX_HIP_TRY(hipStreamSynchronize(st));
-        xcd_tables = static_cast<uint32_t *>(tables);
         attr_device = dev;
     }
     uint64_t done = 0;
-    while (done < n_samples) {
+    int launches = 0;
+    do {
         const uint64_t chunk = std::min<uint64_t>(n_samples - done, (uint64_t)kMaxGroupsPerLaunch * kMaxSamplesPerGroup);
-        // one 1024-thread group per two CUs: every group pays a 64 KiB LDS clear and a 32768-bin flush scan, so few
-        // groups with many samples each win (cus/2: 14.8 us on smooth content, q=1 73.9 us; 2*cus: 22.2 / 110 us);
-        // each group < 65536 samples (16-bit bins)
-        const uint64_t want_groups = std::max<uint64_t>((uint64_t)cus / 2, 1);
+        // 3/4 of a 1024-thread group per CU: every group pays a 64 KiB LDS clear and a 64 KiB partial that the second launch
+        // has to read back, so few groups with many samples each win (4K, hist + reduce: 128 groups 11.4 + 4.8 us at quality 10
+        // and 27.5 + 5.0 at quality 1; 192: 10.7 + 5.1 / 22.0 + 5.3; 256: 11.1 + 6.3 / 18.0 + 6.3); each group < 65536 samples
+        // (16-bit bins)
+        const uint64_t want_groups = std::max<uint64_t>((uint64_t)cus * 3 / 4, 1);
         uint32_t per_group = (uint32_t)std::min<uint64_t>(kMaxSamplesPerGroup, std::max<uint64_t>((chunk + want_groups - 1) / want_groups, 1024));
         const uint32_t groups = (uint32_t)((chunk + per_group - 1) / per_group);
-        hipLaunchKernelGGL(colordetect_hist_kernel, dim3(groups), dim3(kHistBlock), kHistLds, st,
-                           static_cast<const uint8_t *>(frame->data), first_sample + done, chunk, per_group, quality,
-                           lay, xcd_tables);
+        void *partials = nullptr;
+        if (groups) {
+            if (int rc = host_scratch((size_t)groups * kPartialWords * sizeof(uint32_t), 5, &partials); rc != MVFX_OK) return rc;
+            hipLaunchKernelGGL(colordetect_hist_kernel, dim3(groups), dim3(kHistBlock), kHistLds, st,
+                               static_cast<const uint8_t *>(frame->data), first_sample + done, chunk, per_group, quality,
+                               lay, static_cast<uint32_t *>(partials));
+            MVFX_HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(colordetect_reduce_kernel, dim3(kReduceGroups), dim3(kReduceBlock), 0, st,
+                           static_cast<const uint32_t *>(partials), groups, hist_dev, minmax_dev, launches > 0 ? 1 : 0);
         MVFX_HIP_TRY(hipGetLastError());
         done += chunk;
-    }
-    hipLaunchKernelGGL(colordetect_reduce_kernel, dim3(kHistBins / (256 * 4)), dim3(256), 0, st, xcd_tables, hist_dev, minmax_dev);
-    MVFX_HIP_TRY(hipGetLastError());
+        launches++;
+    } while (done < n_samples);
     return MVFX_OK;
 }
 
 // ------------------------------------------------------------------ videocompare / blockhash
 
-typedef uint32_t sum_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kSumBlock = 256;
 constexpr int kSumMaxPads = 16;      // frames per launch (blockIdx.z); more pads take more launches
 constexpr int kSumRowsPerLane = 4;   // loads a lane has in flight (one unrolled batch), then the tail
