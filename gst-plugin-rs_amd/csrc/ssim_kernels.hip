@@ -43,53 +43,89 @@ struct Planes {
 // Full-resolution linear RGB is never stored: scale 0 goes straight from the bytes to the Lab planes, scale 1
 // averages the four source pixels itself, and every coarser level writes its linear planes (for the next
 // level) and its Lab planes (for the map) in one pass -- 1.8 GB instead of 4.3 GB of f64 traffic per 8K image.
+// cbrt(t) for t in (216/24389, ~1]: t^(-1/3) from the f32 log2 / exp2 units (relative error < 1e-6), two division-free
+// Newton steps r <- r (4 - t r^3) / 3 in f64 (1e-6 -> 2e-12 -> < 1e-20), cbrt = t r^2: ~15 instructions against the ~70 of the
+// library routine, within 2 ulp of it (the conversion kernels were VALU bound: 243 instructions per pixel, 75 % VALU busy,
+// three cube roots and five divisions by constants per pixel; round 2).
+__device__ __forceinline__ double cbrt_unit(double t)
+{
+    double r = (double)__builtin_amdgcn_exp2f(-0.33333334f * __builtin_amdgcn_logf((float)t));
+    const double t3 = t * (1.0 / 3.0);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const double r3 = r * r * r;
+        r = r * (4.0 / 3.0 - t3 * r3);
+    }
+    return t * (r * r);
+}
+
 __device__ __forceinline__ double lab_f(double t)
 {
     const double eps = 216.0 / 24389.0, kappa = 24389.0 / 27.0;
-    return t > eps ? cbrt(t) : (kappa * t + 16.0) / 116.0;
+    return t > eps ? cbrt_unit(t) : (kappa * t + 16.0) * (1.0 / 116.0);
 }
 
 __device__ __forceinline__ void store_lab(const Planes &lab, size_t i, double r, double g, double b)
 {
-    const double X = (0.4124 * r + 0.3576 * g + 0.1805 * b) / 0.9505;
+    // the oracle divides by 0.9505, 1.089, 100 and 220; multiplying by the reciprocals differs by <= 1 ulp per operation
+    const double X = (0.4124 * r + 0.3576 * g + 0.1805 * b) * (1.0 / 0.9505);
     const double Y = 0.2126 * r + 0.7152 * g + 0.0722 * b;
-    const double Z = (0.0193 * r + 0.1192 * g + 0.9505 * b) / 1.089;
+    const double Z = (0.0193 * r + 0.1192 * g + 0.9505 * b) * (1.0 / 1.089);
     const double fx = lab_f(X), fy = lab_f(Y), fz = lab_f(Z);
-    lab.p[0][i] = (116.0 * fy - 16.0) / 100.0;
-    lab.p[1][i] = (86.2 + 500.0 * (fx - fy)) / 220.0;
-    lab.p[2][i] = (107.9 + 200.0 * (fy - fz)) / 220.0;
+    lab.p[0][i] = (116.0 * fy - 16.0) * (1.0 / 100.0);
+    lab.p[1][i] = (86.2 + 500.0 * (fx - fy)) * (1.0 / 220.0);
+    lab.p[2][i] = (107.9 + 200.0 * (fy - fz)) * (1.0 / 220.0);
 }
 
-// linear RGB of one source pixel, alpha premultiplied
-__device__ __forceinline__ void linear_px(const uint8_t *p, int bpp, const double *lut, double &r, double &g, double &b)
+// linear RGB of one source pixel, alpha premultiplied.  `lut` (sRGB byte -> linear f64) is the workgroup's LDS copy; WIDE:
+// 4-byte pixels in 4-byte aligned rows are fetched as one dword.  (Round 2: with four byte loads and three table loads from
+// global memory per pixel the two conversion kernels were bound by the vector L1's tag rate -- 1.4e8 accesses per 8K launch,
+// 0.55 M per CU at ~1 per clock = 0.23 of the 0.28 ms.)
+template <int BPP, bool WIDE>
+__device__ __forceinline__ void linear_px(const uint8_t *p, const double *lut, double &r, double &g, double &b)
 {
-    const double a = bpp == 4 ? p[3] / 255.0 : 1.0;
-    r = lut[p[0]] * a; g = lut[p[1]] * a; b = lut[p[2]] * a;
+    uint32_t c0, c1, c2, c3 = 255;
+    if (WIDE) {
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+        c0 = v & 0xffu; c1 = (v >> 8) & 0xffu; c2 = (v >> 16) & 0xffu; c3 = v >> 24;
+    } else {
+        c0 = p[0]; c1 = p[1]; c2 = p[2];
+        if (BPP == 4) c3 = p[3];
+    }
+    const double a = BPP == 4 ? c3 * (1.0 / 255.0) : 1.0; // 255 * (1/255) == 1 exactly
+    r = lut[c0] * a; g = lut[c1] * a; b = lut[c2] * a;
 }
 
 // scale 0: bytes -> Lab
-__global__ __launch_bounds__(kBlock) void ssim_lab0_kernel(const uint8_t *frame, int y0, uint64_t stride, int bpp,
-                                                           const double *lut, Planes lab)
+template <int BPP, bool WIDE>
+__global__ __launch_bounds__(kBlock) void ssim_lab0_kernel(const uint8_t *frame, int y0, uint64_t stride, const double *lut, Planes lab)
 {
+    __shared__ double s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
     const int x = blockIdx.x * kBlock + threadIdx.x, y = y0 + blockIdx.y;
     if (x >= lab.w) return;
     double r, g, b;
-    linear_px(frame + (uint64_t)y * stride + (uint64_t)x * bpp, bpp, lut, r, g, b);
+    linear_px<BPP, WIDE>(frame + (uint64_t)y * stride + (uint64_t)x * BPP, s_lut, r, g, b);
     store_lab(lab, (size_t)y * lab.w + x, r, g, b);
 }
 
 // scale 1: 2x2 box of the linearised source pixels -> linear planes + Lab planes of the half-size image
-__global__ __launch_bounds__(kBlock) void ssim_down1_kernel(const uint8_t *frame, int y0, uint64_t stride, int bpp,
-                                                            const double *lut, Planes lin, Planes lab)
+template <int BPP, bool WIDE>
+__global__ __launch_bounds__(kBlock) void ssim_down1_kernel(const uint8_t *frame, int y0, uint64_t stride, const double *lut, Planes lin,
+                                                            Planes lab)
 {
+    __shared__ double s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
     const int x = blockIdx.x * kBlock + threadIdx.x, y = y0 + blockIdx.y;
     if (x >= lin.w) return;
-    const uint8_t *r0 = frame + (uint64_t)(2 * y) * stride + (uint64_t)(2 * x) * bpp, *r1 = r0 + stride;
+    const uint8_t *r0 = frame + (uint64_t)(2 * y) * stride + (uint64_t)(2 * x) * BPP, *r1 = r0 + stride;
     double v[4][3];
-    linear_px(r0, bpp, lut, v[0][0], v[0][1], v[0][2]);
-    linear_px(r0 + bpp, bpp, lut, v[1][0], v[1][1], v[1][2]);
-    linear_px(r1, bpp, lut, v[2][0], v[2][1], v[2][2]);
-    linear_px(r1 + bpp, bpp, lut, v[3][0], v[3][1], v[3][2]);
+    linear_px<BPP, WIDE>(r0, s_lut, v[0][0], v[0][1], v[0][2]);
+    linear_px<BPP, WIDE>(r0 + BPP, s_lut, v[1][0], v[1][1], v[1][2]);
+    linear_px<BPP, WIDE>(r1, s_lut, v[2][0], v[2][1], v[2][2]);
+    linear_px<BPP, WIDE>(r1 + BPP, s_lut, v[3][0], v[3][1], v[3][2]);
     double o[3];
 #pragma unroll
     for (int c = 0; c < 3; c++)
@@ -129,45 +165,88 @@ __device__ __forceinline__ double block_sum(double v)
 }
 
 // SSIM map of rows [y0,y1) of one scale + its sum.  The 5x5 binomial window is separable: a workgroup owns a
-// 64 x kSeg tile; pass A computes the five horizontally blurred moments of the tile's kSeg + 4 rows (every
-// (row, column) entry is an independent 5 + 5 load job, so the loads of a tile are all in flight together) into
-// LDS, pass B runs the vertical blur down each column from LDS (8 rows x 5 moments per 4 outputs) and the
-// SSIM term.  First version (25-tap window per pixel from global memory): 1.7 ms for the 8K scale-0 map.
-constexpr int kSeg = 16;
-constexpr int kTileW = 64;
-
+// kTileW x kSeg tile.  Per channel: the raw values of both images for the tile + 2-pixel halo go into LDS ONCE (R);
+// pass A forms the five products per pixel and their horizontal blur for two neighbouring columns per job (six raw values of
+// each image = three 16-byte LDS reads) into H; pass B runs the vertical blur down each column from H and the SSIM term, while
+// the next channel's raw values are already on their way from memory (registers -> R after the pass).
+// History: 25-tap window per pixel from global memory 1.7 ms for the 8K scale-0 map; separable with pass A reading its ten
+// taps per entry from global memory 0.95 ms -- that version made 5e8 vector-L1 accesses per 8K pair (2 M per CU at ~1 per
+// clock = 0.8 of its 1.28 ms, VALU 27 % busy; profiles/r2/ssim_counters_before.txt): the L1 tag rate was the bound.
+template <int kSeg, int kTileW>
 __global__ __launch_bounds__(kBlock) void ssim_map_kernel(Planes a, Planes b, int y0, int y1, double *map, double *sum)
 {
-    __shared__ double H[5][kSeg + 4][kTileW]; // 51 KB
+    constexpr int kRowsPerLane = kSeg * kTileW / kBlock;
+    static_assert(kRowsPerLane * kBlock == kSeg * kTileW && kBlock % kTileW == 0 && kTileW % 2 == 0, "tile shape");
+    constexpr int kRows = kSeg + 4, kRawCols = kTileW + 4, kRawStride = kTileW + 6; // stride: even (16-byte pairs), not a multiple of 32
+    constexpr int kRawN = kRows * kRawCols;
+    constexpr int kRawPerLane = (2 * kRawN + kBlock - 1) / kBlock;
+    constexpr int kPairs = kRows * (kTileW / 2);
+    __shared__ __attribute__((aligned(16))) double R[2][kRows][kRawStride];
+    __shared__ __attribute__((aligned(16))) double H[5][kRows][kTileW];
     const int w = a.w, h = a.h;
     const int tx0 = blockIdx.x * kTileW, ty0 = y0 + blockIdx.y * kSeg;
     const double B0 = 1.0 / 16, B1 = 4.0 / 16, B2 = 6.0 / 16;
-    const int col = threadIdx.x % kTileW, rg = threadIdx.x / kTileW; // pass B: column, group of 4 rows
-    double acc[4] = {0, 0, 0, 0};
+    const int col = threadIdx.x % kTileW, rg = threadIdx.x / kTileW; // pass B: column, group of rows
+    double acc[kRowsPerLane] = {};
+
+    // raw job j -> (image, row, column) of the haloed tile and its clamped source index (the same for every channel)
+    int raw_lds[kRawPerLane];
+    size_t raw_src[kRawPerLane];
+#pragma unroll
+    for (int k = 0; k < kRawPerLane; k++) {
+        const int j = min((int)threadIdx.x + k * kBlock, 2 * kRawN - 1);
+        const int img = j / kRawN, rem = j % kRawN, row = rem / kRawCols, rc = rem % kRawCols;
+        const int yy = min(max(ty0 - 2 + row, 0), h - 1), xx = min(max(tx0 - 2 + rc, 0), w - 1);
+        raw_lds[k] = (img * kRows + row) * kRawStride + rc;
+        raw_src[k] = (size_t)yy * w + xx;
+    }
+    double nxt[kRawPerLane];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < kRawPerLane; k++) {
+            const bool second = (int)threadIdx.x + k * kBlock >= kRawN;
+            nxt[k] = (second ? b.p[c] : a.p[c])[raw_src[k]];
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int k = 0; k < kRawPerLane; k++)
+            if ((int)threadIdx.x + k * kBlock < 2 * kRawN) (&R[0][0][0])[raw_lds[k]] = nxt[k];
+    };
+    fetch(0);
+    stage();
+    __syncthreads();
 #pragma unroll 1
     for (int c = 0; c < 3; c++) {
-        const double *pa = a.p[c], *pb = b.p[c];
-        for (int e = threadIdx.x; e < (kSeg + 4) * kTileW; e += kBlock) {
-            const int row = e / kTileW, cc = e % kTileW;
-            const int yy = min(max(ty0 - 2 + row, 0), h - 1);
-            const size_t base = (size_t)yy * w;
-            const int x = tx0 + cc;
-            double hm[5] = {0, 0, 0, 0, 0};
+        for (int p = threadIdx.x; p < kPairs; p += kBlock) {
+            const int row = p / (kTileW / 2), cc = (p % (kTileW / 2)) * 2;
+            double v1[6], v2[6];
 #pragma unroll
-            for (int d = 0; d < 5; d++) {
-                const int xx = min(max(x + d - 2, 0), w - 1);
-                const double v1 = pa[base + xx], v2 = pb[base + xx];
-                const double wgt = d == 2 ? B2 : ((d == 1 || d == 3) ? B1 : B0);
-                hm[0] += wgt * v1; hm[1] += wgt * v2;
-                hm[2] += wgt * v1 * v1; hm[3] += wgt * v2 * v2; hm[4] += wgt * v1 * v2;
+            for (int k = 0; k < 3; k++) {
+                const double2 t1 = *reinterpret_cast<const double2 *>(&R[0][row][cc + 2 * k]);
+                const double2 t2 = *reinterpret_cast<const double2 *>(&R[1][row][cc + 2 * k]);
+                v1[2 * k] = t1.x; v1[2 * k + 1] = t1.y;
+                v2[2 * k] = t2.x; v2[2 * k + 1] = t2.y;
+            }
+            double q[5][6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                q[0][k] = v1[k]; q[1][k] = v2[k];
+                q[2][k] = v1[k] * v1[k]; q[3][k] = v2[k] * v2[k]; q[4][k] = v1[k] * v2[k];
             }
 #pragma unroll
-            for (int q = 0; q < 5; q++) H[q][row][cc] = hm[q];
+            for (int m = 0; m < 5; m++) {
+                double2 o;
+                o.x = B0 * (q[m][0] + q[m][4]) + B1 * (q[m][1] + q[m][3]) + B2 * q[m][2];
+                o.y = B0 * (q[m][1] + q[m][5]) + B1 * (q[m][2] + q[m][4]) + B2 * q[m][3];
+                *reinterpret_cast<double2 *>(&H[m][row][cc]) = o;
+            }
         }
         __syncthreads();
+        if (c < 2) fetch(c + 1); // R is free from here on; the loads fly during pass B
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int tr = rg * 4 + r; // output row of the tile; window rows tr .. tr + 4 of H
+        for (int r = 0; r < kRowsPerLane; r++) {
+            const int tr = rg * kRowsPerLane + r; // output row of the tile; window rows tr .. tr + 4 of H
             double m[5];
 #pragma unroll
             for (int q = 0; q < 5; q++)
@@ -176,13 +255,14 @@ __global__ __launch_bounds__(kBlock) void ssim_map_kernel(Planes a, Planes b, in
             const double s11 = m[2] - m1 * m1, s22 = m[3] - m2 * m2, s12 = m[4] - m1 * m2;
             acc[r] += ((2.0 * m1 * m2 + kC1) * (2.0 * s12 + kC2)) / ((m1 * m1 + m2 * m2 + kC1) * (s11 + s22 + kC2));
         }
+        if (c < 2) stage();
         __syncthreads();
     }
     double total = 0.0;
     const int x = tx0 + col;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int y = ty0 + rg * 4 + r;
+    for (int r = 0; r < kRowsPerLane; r++) {
+        const int y = ty0 + rg * kRowsPerLane + r;
         if (x < w && y < y1) {
             const double val = acc[r] / 3.0;
             map[(size_t)y * w + x] = val;
@@ -279,6 +359,19 @@ int ensure_scratch(SsimState &S, int w0, int h0, hipStream_t st)
     return MVFX_OK;
 }
 
+template <int kSeg, int kTileW>
+void launch_map_t(int w, int y0, int y1, hipStream_t st, const Planes &a, const Planes &b, double *map, double *sum)
+{
+    hipLaunchKernelGGL((ssim_map_kernel<kSeg, kTileW>), dim3((w + kTileW - 1) / kTileW, (y1 - y0 + kSeg - 1) / kSeg), dim3(kBlock), 0, st,
+                       a, b, y0, y1, map, sum);
+}
+
+// Tile shape, 8K pair end to end: 64x16 2.24 ms, 32x16 2.16 ms (38 KB of LDS: four workgroups per CU), 32x32 2.24 ms, 64x32 2.49 ms.
+void launch_map(int w, int y0, int y1, hipStream_t st, const Planes &a, const Planes &b, double *map, double *sum)
+{
+    launch_map_t<16, 32>(w, y0, y1, st, a, b, map, sum);
+}
+
 dim3 grid2d(int w, int rows) { return dim3((w + kBlock - 1) / kBlock, rows > 0 ? rows : 1, 1); }
 
 } // namespace
@@ -353,10 +446,16 @@ int mvfx_ssim_partial_sums(const mvfx_frame *reference_frame, const mvfx_frame *
                 Planes out = (s & 1) ? S.half[i] : S.quarter[i]; // scale 1, 3 -> half-size buffer; 2, 4 -> quarter-size buffer
                 out.w = w; out.h = h;
                 const dim3 grid = grid2d(w, b[s] - a[s]);
+                const uint64_t stride = fr[i]->stride;
+                const bool wide = bpp == 4 && ((reinterpret_cast<uintptr_t>(src) | stride) & 3) == 0;
                 if (s == 0) {
-                    hipLaunchKernelGGL(ssim_lab0_kernel, grid, dim3(kBlock), 0, st, src, a[0], (uint64_t)fr[i]->stride, bpp, S.d_lut, lab[i]);
+                    if (wide) hipLaunchKernelGGL((ssim_lab0_kernel<4, true>), grid, dim3(kBlock), 0, st, src, a[0], stride, S.d_lut, lab[i]);
+                    else if (bpp == 4) hipLaunchKernelGGL((ssim_lab0_kernel<4, false>), grid, dim3(kBlock), 0, st, src, a[0], stride, S.d_lut, lab[i]);
+                    else hipLaunchKernelGGL((ssim_lab0_kernel<3, false>), grid, dim3(kBlock), 0, st, src, a[0], stride, S.d_lut, lab[i]);
                 } else if (s == 1) {
-                    hipLaunchKernelGGL(ssim_down1_kernel, grid, dim3(kBlock), 0, st, src, a[1], (uint64_t)fr[i]->stride, bpp, S.d_lut, out, lab[i]);
+                    if (wide) hipLaunchKernelGGL((ssim_down1_kernel<4, true>), grid, dim3(kBlock), 0, st, src, a[1], stride, S.d_lut, out, lab[i]);
+                    else if (bpp == 4) hipLaunchKernelGGL((ssim_down1_kernel<4, false>), grid, dim3(kBlock), 0, st, src, a[1], stride, S.d_lut, out, lab[i]);
+                    else hipLaunchKernelGGL((ssim_down1_kernel<3, false>), grid, dim3(kBlock), 0, st, src, a[1], stride, S.d_lut, out, lab[i]);
                 } else {
                     Planes in = (s & 1) ? S.quarter[i] : S.half[i];
                     in.w = ws[s - 1]; in.h = hs[s - 1];
@@ -364,8 +463,7 @@ int mvfx_ssim_partial_sums(const mvfx_frame *reference_frame, const mvfx_frame *
                 }
             }
         if (S.y1[s] > S.y0[s])
-            hipLaunchKernelGGL(ssim_map_kernel, dim3((w + kTileW - 1) / kTileW, (S.y1[s] - S.y0[s] + kSeg - 1) / kSeg), dim3(kBlock), 0, st, lab[0], lab[1], S.y0[s], S.y1[s],
-                               S.map[s], S.d_sums + s * kSlots);
+            launch_map(w, S.y0[s], S.y1[s], st, lab[0], lab[1], S.map[s], S.d_sums + (size_t)s * kSlots);
     }
     S.scales = n_scales;
     MVFX_HIP_TRY(hipGetLastError());
