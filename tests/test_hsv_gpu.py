@@ -211,6 +211,17 @@ def test_hsvfilter_4k_full_size(gpu):
         assert np.array_equal(got, expect)
 
 
+def test_hsvfilter_4k_videotestsrc_frames(gpu):
+    """The frames bench.py times (videotestsrc pattern=smpte, consecutive frames = different snow): full-frame compare."""
+    w, h = 3840, 2160
+    vts, _ = frames.videotestsrc_smpte(w, h, 2)
+    for frame in vts:
+        expect = frame.copy()
+        assert orc.hsvfilter(expect, w, w * 4, "RGBA", BENCH_SETTINGS) == 0
+        got = _device_filter(gpu, frame, w, h, w * 4, "RGBA", BENCH_SETTINGS, 0, batch=True)
+        assert np.array_equal(got, expect)
+
+
 def test_reference_panic_sizes(gpu):
     """642x481 RGB: stride 1928 * 481 % 3 == 2 -> the reference's assert_eq! fires."""
     w, h, stride = 642, 481, 1928
