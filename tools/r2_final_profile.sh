@@ -12,7 +12,7 @@ for wl in hsv1080p videofx videocompare; do python bench.py --workload $wl --ste
 python bench.py --workload videocompare --hash-algo dssim --steps 20 --warmup 3 2>/dev/null >> $O/bench_configs.jsonl
 for c in natural random smpte; do python bench.py --workload colorlut --content $c --steps 40 --warmup 10 2>/dev/null >> $O/bench_configs.jsonl; done
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 300 --warmup 50 --no-cpu-baseline --stream-threads 0"
+ARGS="--steps 300 --warmup 50 --no-cpu-baseline --stream-threads 0 --content-sweep 0"
 rocprofv3 --kernel-trace --stats -f csv -d $O/trace -o trace -- python3 $REPO/bench.py $ARGS > $O/bench_under_trace.json 2> $O/trace.err
 rocprofv3 --pmc FETCH_SIZE -f csv -d $O/pmc_fetch -o pmc -- python3 $REPO/bench.py $ARGS > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE -f csv -d $O/pmc_write -o pmc -- python3 $REPO/bench.py $ARGS > /dev/null 2> $O/pmc_write.err
