@@ -571,7 +571,10 @@ constexpr int kTileWaveLdsFloat4 = kTileNbPieces + 2;  // +32 bytes: de-phases t
 // The lattice coordinate of a channel depends on its byte value only: (cell index, fraction) come from a 3 x 256 entry
 // table in LDS (built on the host with the same f32 steps, ensure_uploaded) instead of 7 VALU instructions per channel --
 // the kernel is VALU-bound once the gathers are gone (rocprofv3: VALUBusy 100 %, profiles/r2/colorlut_tile_counters.txt).
-// (Typed buffer loads for u8/255 and several tiles per wave were tried and measured slower here: -4 % and -7 %.)
+// (Typed buffer loads for u8/255 and several tiles per wave were tried and measured slower here: -4 % and -7 %.  A 5 x 5 x 5
+// window for big cubes -- a cell of a 65^3 cube spans only 4 code values, natural-like 4K frame 37.7 us against 24.0 us with
+// 33^3 -- costs more than its hits save: 12 KB of cells per tile in twelve wave loads, 48 KB of LDS per workgroup; 65^3
+// natural 54.4 us, flat bars 57 us against 30 us, and 33^3 natural 52 us.)
 constexpr uint32_t kCoordEntries = 3 * 256;
 
 __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb, FrameBatch out_fb, uint32_t width, uint32_t height,

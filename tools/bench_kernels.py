@@ -129,7 +129,7 @@ def main():
         report("hsvdetector RGBx->RGBA 4K", ms, 2 * NB, 1)
 
     if want("colorlut"):
-        for size in (33, 17, 9):
+        for size in (33, 65, 17, 9):
             lut = vfx.CubeLut(cubes.analytic_3d(size))
             for data in ("random", "smpte", "natural"):
                 src = rand_frames(POOL, NB, 5) if data == "random" else (smpte_like_gpu(POOL, W, H) if data == "smpte" else natural_like_gpu(POOL, W, H, 11))
