@@ -926,8 +926,14 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
         if (!tiles_ok) return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: the tile kernel needs a 3-D LUT of size 3..%u, RGBA, width %% 4 == 0 and 16-byte aligned rows", kCellMaxSize);
         use_lds = false; use_cells = true; use_tiles = true; break;
     default:
+        // the tile kernel also beats the whole-cube-in-LDS kernel on cubes that fit LDS (17^3, 4K natural-like frame: 23.9 vs
+        // 31.2 us per single-frame launch, 49.3 k vs 39.8 k fps with 16 frames per launch; flat bars 28.2 vs 30.5 us); only
+        // on uniform-random colours is the LDS cube faster (44.7 vs 79.5 us) -- pictures are not that, and 33^3 has no LDS
+        // alternative anyway.  The LDS cube stays for frames the tile kernel does not take (odd widths, unaligned rows,
+        // RGBA64) and behind MVFX_OPT_LUT_PLACEMENT = 2.
+        use_tiles = tiles_ok;
+        if (use_tiles) use_lds = false;
         use_cells = !use_lds && h->d_cells != nullptr;
-        use_tiles = use_cells && tiles_ok;
         break;
     }
     if (!use_fast) use_cells = false; // the literal kernels read the node layout

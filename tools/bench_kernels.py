@@ -148,6 +148,12 @@ def main():
         fo = (vfx.Frame * POOL)(*[vfx.make_frame(dst[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)])
         ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frames(lut.h, fi, fo, POOL, sptr)), iters=40)
         report(f"colorlut 3D 33^3 RGBA 4K natural batch{POOL} (one launch)", ms, 2 * NB * POOL, POOL)
+        lut17 = vfx.CubeLut(cubes.analytic_3d(17))
+        for placement in (2, 5):
+            vfx.check(lib.mvfx_thread_set_options(vfx.options(placement=placement).word))
+            ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frames(lut17.h, fi, fo, POOL, sptr)), iters=40)
+            report(f"colorlut 3D 17^3 RGBA 4K natural batch{POOL} (one launch) placement={ {2: 'LDS cube', 5: 'tile kernel'}[placement]}", ms, 2 * NB * POOL, POOL)
+        vfx.check(lib.mvfx_thread_set_options(vfx.options(placement=0).word))
         lut = vfx.CubeLut(cubes.curve_1d(1024))
         src = rand_frames(POOL, NB, 6)
         dst = torch.empty_like(src)
