@@ -127,6 +127,9 @@ def main():
         fo = [vfx.make_frame(dst[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
         ms = timeit(lambda i=0: vfx.check(lib.mvfx_hsvdetector_transform_frame(ctypes.byref(fi[i % POOL]), ctypes.byref(fo[i % POOL]), ctypes.byref(s), sptr)), iters=300)
         report("hsvdetector RGBx->RGBA 4K", ms, 2 * NB, 1)
+        fia, foa = (vfx.Frame * POOL)(*fi), (vfx.Frame * POOL)(*fo)
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_hsvdetector_transform_frames(fia, foa, POOL, ctypes.byref(s), sptr)), iters=60)
+        report(f"hsvdetector RGBx->RGBA 4K batch{POOL} (one launch)", ms, 2 * NB * POOL, POOL)
 
     if want("colorlut"):
         for size in (33, 65, 17, 9):
