@@ -1,0 +1,30 @@
+"""Application-style use of the real elements in one process (PyGObject): property changes while PLAYING, caps changes in
+mid-stream on system and device memory, and repeated NULL <-> PLAYING cycles of the device-memory chain."""
+import pytest
+
+from tests import gst_inprocess
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not gst_inprocess.available(), reason="no PyGObject + GStreamer in this environment")]
+
+
+@pytest.mark.parametrize("chain", ["", "hip"])
+def test_hsvfilter_properties_changed_while_playing(chain):
+    r = gst_inprocess.run("hsvfilter_property_change", chain)
+    assert r["frames"] == 8
+    assert r["mismatches"] == []
+
+
+@pytest.mark.parametrize("chain", ["hsv", "hsv-hip"])
+def test_size_change_in_mid_stream(chain):
+    r = gst_inprocess.run("renegotiate", chain)
+    assert r["frames"] == 8
+    assert r["sizes"] == [[96, 64], [160, 120]]
+    assert r["mismatches"] == []
+
+
+def test_device_memory_chain_survives_state_cycles_without_accumulating_device_memory():
+    r = gst_inprocess.run("state_cycles", 24, timeout=600)
+    assert r["results"] == ["eos"]
+    free = r["free_mb"]
+    # after the first cycles (code objects, streams, the allocator's first blocks) free memory must stay flat
+    assert min(free[6:]) > free[5] - 64.0, free
