@@ -160,6 +160,122 @@ def a420_layout(w, h):
     return 0, w * h, w * h + (w // 2) * (h // 2), w * h + 2 * (w // 2) * (h // 2)
 
 
+def rounded_radius_change(_arg):
+    """border-radius-px changed while PLAYING (mutable in PLAYING, border/imp.rs:299-310): the mask follows, and 0 turns the
+    element into an I420 passthrough (the src caps are reconfigured)."""
+    w, h, n = 96, 64, 9
+    radii = {0: 10, 3: 30, 6: 0}          # buffer index at which the probe sets the radius
+    pipe = Gst.parse_launch(f"videotestsrc num-buffers={n} ! video/x-raw,format=I420,width={w},height={h} ! "
+                            "roundedcorners name=r border-radius-px=10 ! appsink name=sink sync=false")
+    r, sink = pipe.get_by_name("r"), pipe.get_by_name("sink")
+    seen = [0]
+
+    def probe(pad, info):
+        if seen[0] in radii:
+            r.set_property("border-radius-px", radii[seen[0]])
+        seen[0] += 1
+        return Gst.PadProbeReturn.OK
+
+    r.get_static_pad("sink").add_probe(Gst.PadProbeType.BUFFER, probe)
+    pipe.set_state(Gst.State.PLAYING)
+    got = pull_all(sink)
+    pipe.set_state(Gst.State.NULL)
+    import _pkg
+    vfx = _pkg.vfx
+    formats, bad = [], []
+    for i, (caps, data) in enumerate(got):
+        fmt = Gst.Caps.from_string(caps).get_structure(0).get_value("format")
+        formats.append(fmt)
+        radius = 10 if i < 3 else (30 if i < 6 else 0)
+        arr = np.frombuffer(data, dtype=np.uint8)
+        if radius == 0:
+            if fmt != "I420" or arr.size != w * h * 3 // 2:
+                bad.append(i)
+            continue
+        mask = np.zeros((h, w), dtype=np.uint8)
+        assert vfx.lib().mvfx_roundedcorners_mask_host(mask.ctypes.data, w, h, w, radius) == 0
+        off = a420_layout(w, h)[3]
+        if fmt != "A420" or not np.array_equal(arr[off:off + w * h].reshape(h, w), mask):
+            bad.append(i)
+    return {"frames": len(got), "formats": formats, "mismatches": bad}
+
+
+def hsvdetector_property_change(chain):
+    """All six hsvdetector properties changed from a pad probe while PLAYING (hsvdetector/imp.rs:254-320)."""
+    w, h, n, switch = 160, 120, 8, 3
+    a = (0.0, 10.0, 0.0, 0.15, 0.0, 0.3)          # the defaults
+    b = (120.0, 60.0, 0.6, 0.5, 0.5, 0.6)
+    pre, post = ("hipupload ! ", "hipdownload ! ") if chain == "hip" else ("", "")
+    pipe = Gst.parse_launch(f"videotestsrc num-buffers={n} ! video/x-raw,format=RGBx,width={w},height={h} ! {pre}"
+                            f"hsvdetector name=d ! {post}video/x-raw,format=RGBA ! appsink name=sink sync=false")
+    d, sink = pipe.get_by_name("d"), pipe.get_by_name("sink")
+    seen = [0]
+
+    def probe(pad, info):
+        if seen[0] == switch:
+            for name, v in zip(("hue-ref", "hue-var", "saturation-ref", "saturation-var", "value-ref", "value-var"), b):
+                d.set_property(name, v)
+        seen[0] += 1
+        return Gst.PadProbeReturn.OK
+
+    d.get_static_pad("sink").add_probe(Gst.PadProbeType.BUFFER, probe)
+    pipe.set_state(Gst.State.PLAYING)
+    got = pull_all(sink)
+    pipe.set_state(Gst.State.NULL)
+    src, _ = frames.videotestsrc_smpte(w, h, n)   # RGBx from videotestsrc carries x = 255, like RGBA's alpha
+    bad, opaque = [], []
+    for i, (_, data) in enumerate(got):
+        want = np.zeros((h, w * 4), dtype=np.uint8)
+        assert orc.hsvdetector(src[i], w * 4, "RGBx", want, w * 4, "RGBA", w, a if i < switch else b) == 0
+        out = np.frombuffer(data, dtype=np.uint8).reshape(h, w * 4)
+        if not np.array_equal(out, want):
+            bad.append(i)
+        opaque.append(int(np.count_nonzero(out[:, 3::4])))
+    return {"frames": len(got), "mismatches": bad, "opaque_pixels": opaque}
+
+
+def overlay_property_change(chain):
+    """imagersoverlay: alpha and offsets changed while PLAYING (mutable in PLAYING, overlay/imp.rs:317-420): every frame is
+    blended with the values in force when it passes."""
+    from PIL import Image
+    w, h, n, switch = 320, 240, 6, 3
+    tmp = os.environ.get("MVFX_WORKER_TMP", "/tmp")
+    logo = os.path.join(tmp, "logo.png")
+    rng = np.random.default_rng(7)
+    rgba = rng.integers(0, 256, (32, 48, 4), dtype=np.uint8)
+    rgba[..., 3] = np.linspace(0, 255, 48, dtype=np.uint8)[None, :]
+    Image.fromarray(rgba, "RGBA").save(logo)
+    bgra = np.ascontiguousarray(rgba[..., [2, 1, 0, 3]]).reshape(32, 48 * 4)
+    pre, post = ("hipupload ! ", "hipdownload ! ") if chain == "hip" else ("", "")
+    pipe = Gst.parse_launch(f"videotestsrc num-buffers={n} ! video/x-raw,format=RGBA,width={w},height={h} ! {pre}"
+                            f"imagersoverlay name=o location={logo} offset-x=10 offset-y=20 alpha=1.0 ! {post}video/x-raw,format=RGBA ! "
+                            "appsink name=sink sync=false")
+    o, sink = pipe.get_by_name("o"), pipe.get_by_name("sink")
+    seen = [0]
+
+    def probe(pad, info):
+        if seen[0] == switch:
+            o.set_property("alpha", 0.4)
+            o.set_property("offset-x", 100)
+            o.set_property("offset-y", -30)      # from the bottom edge
+        seen[0] += 1
+        return Gst.PadProbeReturn.OK
+
+    o.get_static_pad("sink").add_probe(Gst.PadProbeType.BUFFER, probe)
+    pipe.set_state(Gst.State.PLAYING)
+    got = pull_all(sink)
+    pipe.set_state(Gst.State.NULL)
+    src, _ = frames.videotestsrc_smpte(w, h, n)
+    bad = []
+    for i, (_, data) in enumerate(got):
+        want = src[i].copy()
+        x, y, alpha = (10, 20, 1.0) if i < switch else (100, h - 30 - 32, 0.4)
+        assert orc.overlay_blend(want, w, h, w * 4, "RGBA", bgra, 48, 32, x, y, alpha) == 0
+        if not np.array_equal(np.frombuffer(data, dtype=np.uint8).reshape(h, w * 4), want):
+            bad.append(i)
+    return {"frames": len(got), "mismatches": bad}
+
+
 def state_cycles(n_cycles):
     """NULL -> PLAYING -> EOS -> NULL over and over on the device-memory chain: nothing may accumulate on the device (pools and
     allocator freelists are released in stop() / trimmed)."""
@@ -188,6 +304,8 @@ def state_cycles(n_cycles):
 
 
 SCENARIOS = {"hsvfilter_property_change": hsvfilter_property_change, "renegotiate": renegotiate,
+             "rounded_radius_change": rounded_radius_change, "hsvdetector_property_change": hsvdetector_property_change,
+             "overlay_property_change": overlay_property_change,
              "state_cycles": lambda n: state_cycles(int(n))}
 
 if __name__ == "__main__":

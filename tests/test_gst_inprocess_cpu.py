@@ -12,3 +12,10 @@ def test_roundedcorners_rerenders_its_mask_when_the_size_changes_in_mid_stream()
     assert r["frames"] == 8
     assert r["sizes"] == [[96, 64], [160, 120]]
     assert r["mismatches"] == []
+
+
+def test_roundedcorners_radius_changed_while_playing_including_back_to_passthrough():
+    r = gst_inprocess.run("rounded_radius_change")
+    assert r["frames"] == 9
+    assert r["formats"] == ["A420"] * 6 + ["I420"] * 3
+    assert r["mismatches"] == []

@@ -22,6 +22,21 @@ def test_size_change_in_mid_stream(chain):
     assert r["mismatches"] == []
 
 
+@pytest.mark.parametrize("chain", ["", "hip"])
+def test_hsvdetector_properties_changed_while_playing(chain):
+    r = gst_inprocess.run("hsvdetector_property_change", chain)
+    assert r["frames"] == 8
+    assert r["mismatches"] == []
+    assert r["opaque_pixels"][0] != r["opaque_pixels"][-1]   # the second set of ranges selects other pixels
+
+
+@pytest.mark.parametrize("chain", ["", "hip"])
+def test_imagersoverlay_properties_changed_while_playing(chain):
+    r = gst_inprocess.run("overlay_property_change", chain)
+    assert r["frames"] == 6
+    assert r["mismatches"] == []
+
+
 def test_device_memory_chain_survives_state_cycles_without_accumulating_device_memory():
     r = gst_inprocess.run("state_cycles", 24, timeout=600)
     assert r["results"] == ["eos"]
