@@ -276,6 +276,69 @@ def overlay_property_change(chain):
     return {"frames": len(got), "mismatches": bad}
 
 
+def videocompare_three_pads(_arg):
+    """The aggregator the way an application builds it (videocompare/imp.rs:188-256, 283-377): request pads sink_0..2 by
+    template, sink_0 is the reference; red vs red vs smpte at max-dist-threshold 0 -> every aggregate posts ONE element message
+    that lists BOTH other pads (distance 0 for the red one, > 0 for the colour bars; a solid blue frame would hash like the red one:
+    blockhash of a constant image is constant); then release a pad and run again."""
+    import re
+
+    def build(patterns, n=4):
+        pipe = Gst.Pipeline.new(None)
+        vc = Gst.ElementFactory.make("videocompare", "compare")
+        sink = Gst.ElementFactory.make("fakesink", None)
+        pipe.add(vc)
+        pipe.add(sink)
+        assert vc.link(sink)
+        pads = []
+        for k, pat in enumerate(patterns):
+            src = Gst.ElementFactory.make("videotestsrc", None)
+            src.set_property("num-buffers", n)
+            Gst.util_set_object_arg(src, "pattern", pat)
+            cf = Gst.ElementFactory.make("capsfilter", None)
+            cf.set_property("caps", Gst.Caps.from_string("video/x-raw,format=RGBA,width=320,height=240,framerate=30/1"))
+            pipe.add(src)
+            pipe.add(cf)
+            assert src.link(cf)
+            pad = vc.get_request_pad("sink_%u")
+            assert pad is not None and pad.get_name() == f"sink_{k}", pad.get_name() if pad else None
+            assert cf.get_static_pad("src").link(pad) == Gst.PadLinkReturn.OK
+            pads.append(pad)
+        return pipe, vc, pads
+
+    def run(pipe):
+        pipe.set_state(Gst.State.PLAYING)
+        bus, msgs = pipe.get_bus(), []
+        while True:
+            m = bus.timed_pop_filtered(30 * Gst.SECOND, Gst.MessageType.EOS | Gst.MessageType.ERROR | Gst.MessageType.ELEMENT)
+            if m is None or m.type == Gst.MessageType.EOS:
+                break
+            if m.type == Gst.MessageType.ERROR:
+                msgs.append("ERROR " + m.parse_error()[0].message)
+                break
+            st = m.get_structure()
+            if st is not None and st.get_name() == "videocompare":
+                text = st.to_string()
+                found = {name: float(d) for name, d in re.findall(r"\b(sink_\d+).*?distance\W+double\W+([0-9.e+-]+)", text)}
+                msgs.append(found if found else "UNPARSED " + text)
+        pipe.set_state(Gst.State.NULL)
+        return msgs
+
+    pipe, vc, pads = build(["red", "red", "smpte"])
+    first = run(pipe)
+    # second pipeline: the same three branches, then the third pad released before PLAYING -> two-pad aggregates
+    pipe2, vc2, pads2 = build(["red", "red", "smpte"])
+    peer = pads2[2].get_peer()
+    peer.unlink(pads2[2])
+    vc2.release_request_pad(pads2[2])
+    # the unlinked third branch would stop the pipeline with not-linked: give it a sink of its own
+    fs = Gst.ElementFactory.make("fakesink", None)
+    pipe2.add(fs)
+    assert peer.link(fs.get_static_pad("sink")) == Gst.PadLinkReturn.OK
+    second = run(pipe2)
+    return {"first": first, "second": second, "sink_pads_after_release": sorted(p.get_name() for p in vc2.sinkpads)}
+
+
 def state_cycles(n_cycles):
     """NULL -> PLAYING -> EOS -> NULL over and over on the device-memory chain: nothing may accumulate on the device (pools and
     allocator freelists are released in stop() / trimmed)."""
@@ -305,7 +368,7 @@ def state_cycles(n_cycles):
 
 SCENARIOS = {"hsvfilter_property_change": hsvfilter_property_change, "renegotiate": renegotiate,
              "rounded_radius_change": rounded_radius_change, "hsvdetector_property_change": hsvdetector_property_change,
-             "overlay_property_change": overlay_property_change,
+             "overlay_property_change": overlay_property_change, "videocompare_three_pads": videocompare_three_pads,
              "state_cycles": lambda n: state_cycles(int(n))}
 
 if __name__ == "__main__":

@@ -37,6 +37,19 @@ def test_imagersoverlay_properties_changed_while_playing(chain):
     assert r["mismatches"] == []
 
 
+def test_videocompare_built_with_request_pads_reports_every_other_pad():
+    r = gst_inprocess.run("videocompare_three_pads")
+    first = [m for m in r["first"] if isinstance(m, dict)]
+    assert len(first) == len(r["first"]) >= 1, r["first"]
+    for m in first:
+        assert sorted(m) == ["sink_1", "sink_2"], m      # never the reference pad itself (imp.rs:326-329)
+        assert m["sink_1"] == 0.0 and m["sink_2"] > 0.0
+    second = [m for m in r["second"] if isinstance(m, dict)]
+    assert len(second) == len(r["second"]) >= 1, r["second"]
+    assert all(sorted(m) == ["sink_1"] and m["sink_1"] == 0.0 for m in second)
+    assert r["sink_pads_after_release"] == ["sink_0", "sink_1"]
+
+
 def test_device_memory_chain_survives_state_cycles_without_accumulating_device_memory():
     r = gst_inprocess.run("state_cycles", 24, timeout=600)
     assert r["results"] == ["eos"]
