@@ -32,8 +32,14 @@ def run(scenario, arg="", timeout=300):
     e["LD_PRELOAD"] = STDCXX
     e["MVFX_WORKER_TMP"] = tmp
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gst_worker.py")
-    r = subprocess.run([sys.executable, worker, scenario, str(arg)], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
-                       timeout=timeout)
+    cmd = [sys.executable, worker, scenario, str(arg)]
+    if os.environ.get("MVFX_GST_LD_PRELOAD"):  # `make asan-test`: the sanitizer runtime first, and no ASLR (see gst_env.run)
+        import platform
+        import shutil
+        e["LD_PRELOAD"] = os.environ["MVFX_GST_LD_PRELOAD"] + " " + STDCXX
+        if shutil.which("setarch"):
+            cmd = ["setarch", platform.machine(), "-R"] + cmd
+    r = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
     for line in r.stdout.splitlines():
         if line.startswith("RESULT "):
             return json.loads(line[7:])
