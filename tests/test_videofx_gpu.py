@@ -79,6 +79,23 @@ def test_colordetect_8k_quality1_i32_sums_wrap(gpu):
     assert gpal == pal
 
 
+def test_colordetect_histogram_more_samples_than_one_launch_takes(gpu):
+    """> 1024 groups x 65535 samples (16-bit bins per group): the second launch must ADD to the histogram and combine the
+    bounds.  The top 40 % of the frame is mid-grey-ish (channels 64..191), so the extreme bins and bounds come only from rows
+    that fall into the second launch."""
+    w, h = 16384, 4200                      # 68.8 M samples at quality 1 > 67.1 M
+    f = frames.random_frame(0x5EED0777, w, h)
+    top = f[: h * 2 // 5]
+    top[:] = 64 + (top >> 1)
+    f[:, 3::4] = 255
+    rc, hist, mm, n = orc.colordetect_histogram(f, "RGBA", 1)
+    assert rc == 0 and n > 1024 * 65535
+    ghist, gmm = _gpu_hist(gpu, f, w, h, w * 4, "RGBA", 1)
+    assert np.array_equal(ghist, hist.astype(np.uint32))
+    assert gmm.tolist() == mm
+    assert mm[0] == 0 and mm[1] == 31       # bounds only the bottom rows can produce
+
+
 def test_colordetect_reference_pin_red(gpu):
     """tests/colordetect.rs:21-68: solid red => dominant-color 'red' (palette[0] = 252,4,4)"""
     w, h = 320, 240
