@@ -150,3 +150,24 @@ def test_8k_pair_matches_f64_oracle_whole_and_banded(gpu):
     mad = [dev[s] / tot_c[s] if tot_c[s] else 0.0 for s in range(5)]
     assert gpu.ssim_combine(mean, mad, n) == pytest.approx(want, rel=1e-9, abs=1e-12)
     assert gpu.ssim_combine(mean, mad, n) == pytest.approx(d.value, rel=1e-11, abs=1e-13)
+
+
+def test_rgba_frames_at_odd_addresses_take_the_byte_path(gpu):
+    """4-byte pixels whose rows are not 4-byte aligned (a frame at an odd offset inside a larger device block, stride % 4 != 0):
+    the conversion kernels must not fetch pixels as dwords there.  Same distance as the aligned copy of the same pixels."""
+    w, h = 96, 64
+    stride = w * 4 + 2
+    a, b = _pair(0xD5A1, w, h, 4, 40, every=7, stride=stride)
+    rc, want, _ = orc.ssim_distance(a, b, w, h, stride, stride, "RGBA")
+    assert rc == 0
+    blocks = []
+    frames_ = []
+    for img in (a, b):
+        raw = np.zeros(img.nbytes + 8, dtype=np.uint8)
+        raw[1:1 + img.nbytes] = img.reshape(-1)          # the frame starts one byte into the block
+        blk = gpu.DeviceBuffer(raw.nbytes).upload(raw)
+        blocks.append(blk)
+        frames_.append(gpu.make_frame(blk.ptr + 1, w, h, stride, "RGBA"))
+    d = ctypes.c_double()
+    gpu.check(gpu.lib().mvfx_ssim_distance(ctypes.byref(frames_[0]), ctypes.byref(frames_[1]), ctypes.byref(d), None))
+    assert d.value == pytest.approx(want, rel=1e-9, abs=1e-12)
