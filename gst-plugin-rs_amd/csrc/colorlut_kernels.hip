@@ -577,13 +577,18 @@ constexpr int kTileWaveLdsFloat4 = kTileNbPieces + 2;  // +32 bytes: de-phases t
 // natural 54.4 us, flat bars 57 us against 30 us, and 33^3 natural 52 us.)
 constexpr uint32_t kCoordEntries = 3 * 256;
 
+// WIDE: RGBA64 (LE: little endian) -- a lane's four pixels are 32 bytes (two 16-byte loads), the lattice coordinates come from
+// lf_coord on the 16-bit values (the byte-indexed LDS table does not exist for 65536 values; same arithmetic as the gather
+// kernel's lf_px16), the output is lf_px16's.  Round 2: 4K natural-like RGBA64 frame 43.4 us with the per-lane gathers.
+template <bool WIDE, bool LE>
 __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb, FrameBatch out_fb, uint32_t width, uint32_t height,
                                                                uint32_t in_stride, uint32_t out_stride, LutParams p)
 {
+    constexpr uint32_t kBpp = WIDE ? 8 : 4;
     __shared__ float4 nbr[kBlock / 64][kTileWaveLdsFloat4];
-    __shared__ uint2 coord[kCoordEntries]; // {cell index, fraction bits} per channel and byte value
+    __shared__ uint2 coord[WIDE ? 1 : kCoordEntries]; // {cell index, fraction bits} per channel and byte value
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    {
+    if constexpr (!WIDE) {
         const uint2 *src = reinterpret_cast<const uint2 *>(p.tile_tables);
 #pragma unroll
         for (uint32_t i = 0; i < kCoordEntries / kBlock; i++) coord[i * kBlock + threadIdx.x] = src[i * kBlock + threadIdx.x];
@@ -593,21 +598,34 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
     const bool valid = x < width && y < height; // width % 4 == 0 (launcher): a lane's four pixels are all inside or all outside
     const uint8_t *in = in_fb.base[blockIdx.z];
     uint8_t *out = out_fb.base[blockIdx.z];
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (valid) v = *reinterpret_cast<const uint4 *>(in + (y * in_stride + x * 4));
+    uint4 v = make_uint4(0, 0, 0, 0), v2 = make_uint4(0, 0, 0, 0);
+    if (valid) {
+        v = *reinterpret_cast<const uint4 *>(in + (y * in_stride + x * kBpp));
+        if constexpr (WIDE) v2 = *reinterpret_cast<const uint4 *>(in + (y * in_stride + x * kBpp + 16));
+    }
     // offsets of this lane's three pieces of the neighbourhood relative to the anchor cell (float4 units)
     const uint32_t rel0 = p.tile_tables[2 * kCoordEntries + lane], rel1 = p.tile_tables[2 * kCoordEntries + 64 + lane],
                    rel2 = p.tile_tables[2 * kCoordEntries + 128 + lane];
-    __syncthreads(); // coordinate table complete
-    uint32_t px[4] = {v.x, v.y, v.z, v.w};
+    if constexpr (!WIDE) __syncthreads(); // coordinate table complete
+    uint32_t px[4] = {v.x, v.y, v.z, v.w};      // RGBA8: the pixels; RGBA64: low words (r | g << 16) of the pixels
+    uint32_t px_hi[4] = {0, 0, 0, 0};           // RGBA64: high words (b | a << 16)
+    if constexpr (WIDE) { px[0] = v.x; px_hi[0] = v.y; px[1] = v.z; px_hi[1] = v.w; px[2] = v2.x; px_hi[2] = v2.y; px[3] = v2.z; px_hi[3] = v2.w; }
     uint32_t ix[4], iy[4], iz[4];
     float fx[4], fy[4], fz[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const uint2 er = coord[px[j] & 0xffu], eg = coord[256 + ((px[j] >> 8) & 0xffu)], eb = coord[512 + ((px[j] >> 16) & 0xffu)];
-        ix[j] = er.x; fx[j] = __uint_as_float(er.y);
-        iy[j] = eg.x; fy[j] = __uint_as_float(eg.y);
-        iz[j] = eb.x; fz[j] = __uint_as_float(eb.y);
+        if constexpr (WIDE) {
+            uint32_t rv = px[j] & 0xffffu, gv = px[j] >> 16, bv = px_hi[j] & 0xffffu;
+            if constexpr (!LE) { rv = bswap16(rv); gv = bswap16(gv); bv = bswap16(bv); }
+            lf_coord((float)rv, p.fast, p.scale[0], p.offset[0], p.size_m1, ix[j], fx[j]);
+            lf_coord((float)gv, p.fast, p.scale[1], p.offset[1], p.size_m1, iy[j], fy[j]);
+            lf_coord((float)bv, p.fast, p.scale[2], p.offset[2], p.size_m1, iz[j], fz[j]);
+        } else {
+            const uint2 er = coord[px[j] & 0xffu], eg = coord[256 + ((px[j] >> 8) & 0xffu)], eb = coord[512 + ((px[j] >> 16) & 0xffu)];
+            ix[j] = er.x; fx[j] = __uint_as_float(er.y);
+            iy[j] = eg.x; fy[j] = __uint_as_float(eg.y);
+            iz[j] = eb.x; fz[j] = __uint_as_float(eb.y);
+        }
     }
     // anchor: the cell of the tile's centre pixel (lane 34 = row 8, columns 8..11), window = anchor-1 .. anchor+1 per axis,
     // shifted to stay inside the table (cell indices run 0 .. size-1; the launcher guarantees size >= 3)
@@ -657,14 +675,27 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
         lf_trilinear<true>(c, fx[j], fy[j], fz[j], r, g, b);
         const float yr = r * p.fast.out_scale + p.fast.pred_half, yg = g * p.fast.out_scale + p.fast.pred_half,
                     yb = b * p.fast.out_scale + p.fast.pred_half;
-        uint32_t w = px[j];
-        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yr));
-        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yg));
-        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
-        px[j] = w;
+        if constexpr (WIDE) {
+            uint32_t ro = (uint32_t)__float2uint_rz(yr), go = (uint32_t)__float2uint_rz(yg), bo = (uint32_t)__float2uint_rz(yb);
+            if constexpr (!LE) { ro = bswap16(ro); go = bswap16(go); bo = bswap16(bo); }
+            px[j] = ro | (go << 16);
+            px_hi[j] = bo | (px_hi[j] & 0xffff0000u);
+        } else {
+            uint32_t w = px[j];
+            asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yr));
+            asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yg));
+            asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
+            px[j] = w;
+        }
     }
-    if (valid)
-        *reinterpret_cast<uint4 *>(out + (y * out_stride + x * 4)) = make_uint4(px[0], px[1], px[2], px[3]);
+    if (valid) {
+        if constexpr (WIDE) {
+            *reinterpret_cast<uint4 *>(out + (y * out_stride + x * kBpp)) = make_uint4(px[0], px_hi[0], px[1], px_hi[1]);
+            *reinterpret_cast<uint4 *>(out + (y * out_stride + x * kBpp + 16)) = make_uint4(px[2], px_hi[2], px[3], px_hi[3]);
+        } else {
+            *reinterpret_cast<uint4 *>(out + (y * out_stride + x * 4)) = make_uint4(px[0], px[1], px[2], px[3]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- colorlut on I420 frames, fused
@@ -910,7 +941,7 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
     // 0 auto | 1 node layout in global/L2 | 2 LDS | 3 cell-packed global, per-lane gathers | 4 literal kernels |
     // 5 cell-packed global + wave-local 3x3x3 cell neighbourhood in LDS (16 x 16 pixel tiles)
     bool use_lds = fits_lds, use_cells = false, use_fast = finite && vec, use_tiles = false;
-    const bool tiles_ok = l.is_3d && !wide && h->d_cells != nullptr && h->d_tile_tables != nullptr && finite && (in->width & 3) == 0 &&
+    const bool tiles_ok = l.is_3d && h->d_cells != nullptr && h->d_tile_tables != nullptr && finite && (in->width & 3) == 0 &&
                           ((align_or | in->stride | out->stride) & 15) == 0 && (uint64_t)in->stride * in->height < (1ull << 32) &&
                           (uint64_t)out->stride * out->height < (1ull << 32) && (in->height + 15) / 16 <= 65535u;
     switch (opt_lut_placement()) {
@@ -923,7 +954,7 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
         use_lds = false; use_cells = true; break;
     case 4: use_fast = false; break;
     case 5:
-        if (!tiles_ok) return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: the tile kernel needs a 3-D LUT of size 3..%u, RGBA, width %% 4 == 0 and 16-byte aligned rows", kCellMaxSize);
+        if (!tiles_ok) return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: the tile kernel needs a 3-D LUT of size 3..%u, width %% 4 == 0 and 16-byte aligned rows", kCellMaxSize);
         use_lds = false; use_cells = true; use_tiles = true; break;
     default:
         // the tile kernel also beats the whole-cube-in-LDS kernel on cubes that fit LDS (17^3, 4K natural-like frame: 23.9 vs
@@ -973,7 +1004,12 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
     if (use_fast && use_tiles) {
         const uint32_t tiles_x = (in->width + 15) / 16, tiles_y = (in->height + 15) / 16;
         const dim3 tgrid((tiles_x + kBlock / 64 - 1) / (kBlock / 64), tiles_y, n);
-        hipLaunchKernelGGL(colorlut_tile_kernel, tgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p);
+        if (!wide)
+            hipLaunchKernelGGL((colorlut_tile_kernel<false, true>), tgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p);
+        else if (le)
+            hipLaunchKernelGGL((colorlut_tile_kernel<true, true>), tgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p);
+        else
+            hipLaunchKernelGGL((colorlut_tile_kernel<true, false>), tgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p);
         MVFX_HIP_TRY(hipGetLastError());
         return MVFX_OK;
     }

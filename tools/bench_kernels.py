@@ -171,6 +171,15 @@ def main():
         fo = [vfx.make_frame(dst[i].data_ptr(), W, H, W * 8, "RGBA64_LE") for i in range(8)]
         ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fi[i % 8]), ctypes.byref(fo[i % 8]), sptr)), iters=300)
         report("colorlut 3D 33^3 RGBA64_LE 4K random", ms, 4 * NB, 1)
+        # natural-like 16-bit frames: the 8-bit picture scaled by 257 plus noise in the low byte (+-3 codes of 8-bit worth)
+        nat8 = natural_like_gpu(8, W, H, 21).view(8, H * W * 4).to(torch.int32)
+        nat16 = (nat8 * 257 + torch.randint(-128, 129, nat8.shape, device=dev, dtype=torch.int32)).clamp(0, 65535).to(torch.int16)
+        src64 = nat16.view(torch.uint8).view(8, -1).contiguous()
+        dst64 = torch.empty_like(src64)
+        fi = [vfx.make_frame(src64[i].data_ptr(), W, H, W * 8, "RGBA64_LE") for i in range(8)]
+        fo = [vfx.make_frame(dst64[i].data_ptr(), W, H, W * 8, "RGBA64_LE") for i in range(8)]
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fi[i % 8]), ctypes.byref(fo[i % 8]), sptr)), iters=300)
+        report("colorlut 3D 33^3 RGBA64_LE 4K natural", ms, 4 * NB, 1)
 
     if want("colordetect"):
         src = rand_frames(POOL, NB, 9)
