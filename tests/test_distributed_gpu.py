@@ -54,3 +54,68 @@ def test_ssim_and_colordetect_sharded_over_rccl(worker_result):
     assert rc == 0 and worker_result["ssim"] == pytest.approx(want, rel=1e-9, abs=1e-12)
     rc, want_pal = orc.colordetect_palette(a, "RGBA", 10, 5)
     assert rc >= 0 and worker_result["palette"] == [int(x) for x in want_pal]
+
+
+# ---------------------------------------------------------------------------------------------------------------- world 2
+# Two ranks on the box's ONE GPU (own process and HIP context each), every rank holding only its share of the inputs, HIP
+# kernels for the per-rank compute, gloo for the collectives (RCCL refuses two ranks on one device): the N > 1 orchestration
+# with the real kernels, which the CPU tests (oracle compute) and the world-1 RCCL test (one rank) each cover only half of.
+
+@pytest.fixture(scope="module")
+def world2_results(gpu):
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ)
+        env.update({"RANK": str(rank), "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "hip_world2_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    results = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, out[-3000:]
+        line = [ln for ln in out.splitlines() if ln.startswith("RESULT ")]
+        assert line, out[-3000:]
+        results.append(json.loads(line[-1][len("RESULT "):]))
+    return sorted(results, key=lambda r: r["rank"])
+
+
+def test_world2_every_rank_holds_a_different_share(world2_results):
+    r0, r1 = world2_results
+    assert (r0["world"], r1["world"]) == (2, 2)
+    assert r0["band"] == [0, 540] and r1["band"] == [540, 1080]
+    assert r0["ssim_band"][1] == r1["ssim_band"][0] and r0["ssim_band"][0] == 0 and r1["ssim_band"][1] == 240
+    assert r0["samples"][0] + r0["samples"][1] == r1["samples"][0] and sum(r["samples"][1] for r in world2_results) == 7680
+
+
+def test_world2_videocompare_hip_bands(world2_results):
+    w, h = 1920, 1080
+    a = frames.random_frame(0x5EED0001, w, h)
+    b = a.copy()
+    b[::3, 0:w * 4:16] ^= 0x3C
+    hs = [orc.blockhash(f, w, h, w * 4, "RGBA")[1] for f in (a, b, 255 - a, a)]
+    want = [float(orc.hamming(hs[0], x)) for x in hs[1:]]
+    assert world2_results[0]["videocompare"] == want and world2_results[1]["videocompare"] == want
+
+
+def test_world2_ssim_and_colordetect(world2_results):
+    w, h = 320, 240
+    a = frames.random_frame(0x5EED0002, w, h)
+    b = a.copy()
+    b[5::7, 3:w * 4:11] ^= 0x15
+    rc, want, _ = orc.ssim_distance(a, b, w, h, w * 4, w * 4, "RGBA")
+    rc2, want_pal = orc.colordetect_palette(a, "RGBA", 10, 5)
+    assert rc == 0 and rc2 >= 0
+    for r in world2_results:
+        assert r["ssim"] == pytest.approx(want, rel=1e-9, abs=1e-12)
+        assert r["palette"] == [int(x) for x in want_pal]
+    assert world2_results[0]["ssim"] == world2_results[1]["ssim"]      # every rank derives the same value
