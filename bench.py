@@ -460,7 +460,15 @@ def videocompare_main(args):
                        "rccl_ranks": w.rccl_ranks, "per_rank_pairs_per_sec": per_rank},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
-                         "note": "end-to-end per pair incl. all-reduce (N > 1), D2H of the block sums, the synchronisation and host bit derivation"}}), flush=True)
+                         "note": "end-to-end per pair incl. all-reduce (N > 1), D2H of the block sums, the synchronisation and host bit derivation"
+                                 if args.hash_algo == "blockhash" else
+                                 "the compulsory input bytes against HBM peak (SURVEY 8d); this path is f64 arithmetic: its five kernels issue "
+                                 "4.74e8 wave64 VALU instructions per 8K pair (rocprofv3 SQ_INSTS_VALU, profiles/r2/ssim_counters_after.txt), see "
+                                 "valu_issue_frac",
+                         **({} if args.hash_algo == "blockhash" else
+                            {"valu_issue_frac": 4.74e8 * 64 * (args.steps / elapsed) / world / (256 * 64 * 2.4e9),
+                             "valu_issue_note": "wave64 VALU instructions per second / (256 CUs x 64 lanes x 2.4 GHz), single GPU whole frames"})}}),
+              flush=True)
     w.finish()
 
 
