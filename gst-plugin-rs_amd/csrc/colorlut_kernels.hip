@@ -577,6 +577,71 @@ constexpr int kTileWaveLdsFloat4 = kTileNbPieces + 2;  // +32 bytes: de-phases t
 // natural 54.4 us, flat bars 57 us against 30 us, and 33^3 natural 52 us.)
 constexpr uint32_t kCoordEntries = 3 * 256;
 
+// The 24 floats of the cell (ix, iy, iz): from the wave's LDS window when the cell lies in it, otherwise this lane's own gather
+// from the cell table in global memory / L2 (six 16-byte loads).  A quad-cooperative form of the gather (the four lanes of a
+// quad fetch one cell with two coalesced loads and hand it over through LDS: 2.8 instead of 6.1 L1 look-ups per pixel) was
+// built and measured: no faster on uniform-random colours -- there the L1's miss path is the floor (a cell is two 64-byte L2
+// requests, ~0.39 requests per clock per CU) -- and slower when only a few pixels of a tile fall outside
+// (profiles/r2/colorlut_random_floor.txt).
+// `nbr_base` is an LDS-address-space pointer on purpose: through a generic pointer the six reads become flat loads (the
+// kernel then runs at 60 % of its speed).
+typedef const __attribute__((address_space(3))) char *lds_bytes_t;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) f32x4_t *lds_float4_t;
+
+__device__ __forceinline__ void tile_cell(lds_bytes_t nbr_base, uint32_t wave_lds_bytes, const LutParams &p, uint32_t ix, uint32_t iy,
+                                          uint32_t iz, uint32_t ax, uint32_t ay, uint32_t az, float4 (&c)[8])
+{
+    const uint32_t dx = ix - ax, dy = iy - ay, dz = iz - az; // unsigned: below the anchor wraps to a huge value
+    float4 c6[6];
+    if (dx < 3u && dy < 3u && dz < 3u) {
+        // 24-bit multiply-adds, the last one spelled out: plain `mine + index * 6` compiles to three quarter-rate v_mad_u64_u32
+        const uint32_t nbi = __umul24(dz, 9u) + __umul24(dy, 3u) + dx;
+        uint32_t off;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(nbi), "s"(96u), "v"(wave_lds_bytes));
+        lds_float4_t cell = (lds_float4_t)(nbr_base + off);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const f32x4_t v = cell[i];
+            c6[i] = make_float4(v.x, v.y, v.z, v.w);
+        }
+    } else {
+        const float4 *cell = p.cells + __umul24(__umul24(__umul24(iz, p.size) + iy, p.size) + ix, kCellF4); // < 2^24 (size <= 65)
+#pragma unroll
+        for (int i = 0; i < 6; i++) c6[i] = cell[i];
+    }
+    const float f[24] = {c6[0].x, c6[0].y, c6[0].z, c6[0].w, c6[1].x, c6[1].y, c6[1].z, c6[1].w, c6[2].x, c6[2].y, c6[2].z, c6[2].w,
+                         c6[3].x, c6[3].y, c6[3].z, c6[3].w, c6[4].x, c6[4].y, c6[4].z, c6[4].w, c6[5].x, c6[5].y, c6[5].z, c6[5].w};
+#pragma unroll
+    for (int i = 0; i < 8; i++) c[i] = make_float4(f[3 * i], f[3 * i + 1], f[3 * i + 2], 0.0f);
+}
+
+// The wave's 3 x 3 x 3 window: anchor = the cell (cx, cy, cz) of the wave's centre pixel minus one per axis, shifted to stay
+// inside the table (cell indices run 0 .. size-1; the launchers guarantee size >= 3); three coalesced wave loads into `mine`.
+struct TileRel {
+    uint32_t r0, r1, r2; // offsets of this lane's three pieces of the window relative to the anchor cell (float4 units)
+};
+
+__device__ __forceinline__ TileRel tile_rel(uint32_t lane, const LutParams &p) // issue early: the values are needed after the coordinates
+{
+    return {p.tile_tables[2 * kCoordEntries + lane], p.tile_tables[2 * kCoordEntries + 64 + lane], p.tile_tables[2 * kCoordEntries + 128 + lane]};
+}
+
+__device__ __forceinline__ void tile_load_window(float4 *mine, uint32_t lane, const LutParams &p, const TileRel &rel, uint32_t cx, uint32_t cy,
+                                                 uint32_t cz, uint32_t &ax, uint32_t &ay, uint32_t &az)
+{
+    const uint32_t rel0 = rel.r0, rel1 = rel.r1, rel2 = rel.r2;
+    const uint32_t hi = p.size - 3;
+    ax = min(cx > 0 ? cx - 1 : 0u, hi); ay = min(cy > 0 ? cy - 1 : 0u, hi); az = min(cz > 0 ? cz - 1 : 0u, hi);
+    const uint32_t anchor = (ax + p.size * (ay + p.size * az)) * kCellF4; // float4 units; wave-uniform
+    mine[lane] = p.cells[anchor + rel0];
+    mine[64 + lane] = p.cells[anchor + rel1];
+    if (lane < (uint32_t)kTileNbPieces - 128u) mine[128 + lane] = p.cells[anchor + rel2];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // WIDE: RGBA64 (LE: little endian) -- a lane's four pixels are 32 bytes (two 16-byte loads), the lattice coordinates come from
 // lf_coord on the 16-bit values (the byte-indexed LDS table does not exist for 65536 values; same arithmetic as the gather
 // kernel's lf_px16), the output is lf_px16's.  Round 2: 4K natural-like RGBA64 frame 43.4 us with the per-lane gathers.
@@ -603,9 +668,7 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
         v = *reinterpret_cast<const uint4 *>(in + (y * in_stride + x * kBpp));
         if constexpr (WIDE) v2 = *reinterpret_cast<const uint4 *>(in + (y * in_stride + x * kBpp + 16));
     }
-    // offsets of this lane's three pieces of the neighbourhood relative to the anchor cell (float4 units)
-    const uint32_t rel0 = p.tile_tables[2 * kCoordEntries + lane], rel1 = p.tile_tables[2 * kCoordEntries + 64 + lane],
-                   rel2 = p.tile_tables[2 * kCoordEntries + 128 + lane];
+    const TileRel rel = tile_rel(lane, p);
     if constexpr (!WIDE) __syncthreads(); // coordinate table complete
     uint32_t px[4] = {v.x, v.y, v.z, v.w};      // RGBA8: the pixels; RGBA64: low words (r | g << 16) of the pixels
     uint32_t px_hi[4] = {0, 0, 0, 0};           // RGBA64: high words (b | a << 16)
@@ -627,50 +690,16 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
             iz[j] = eb.x; fz[j] = __uint_as_float(eb.y);
         }
     }
-    // anchor: the cell of the tile's centre pixel (lane 34 = row 8, columns 8..11), window = anchor-1 .. anchor+1 per axis,
-    // shifted to stay inside the table (cell indices run 0 .. size-1; the launcher guarantees size >= 3)
-    const uint32_t hi = p.size - 3;
+    // anchor: the cell of the tile's centre pixel (lane 34 = row 8, columns 8..11)
     const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)ix[0], 34), cy = (uint32_t)__builtin_amdgcn_readlane((int)iy[0], 34),
                    cz = (uint32_t)__builtin_amdgcn_readlane((int)iz[0], 34);
-    const uint32_t ax = min(cx > 0 ? cx - 1 : 0u, hi), ay = min(cy > 0 ? cy - 1 : 0u, hi), az = min(cz > 0 ? cz - 1 : 0u, hi);
-    const uint32_t anchor = (ax + p.size * (ay + p.size * az)) * kCellF4; // float4 units; wave-uniform
-    float4 *mine = nbr[wave];
+    uint32_t ax, ay, az;
+    tile_load_window(nbr[wave], lane, p, rel, cx, cy, cz, ax, ay, az);
     const uint32_t wave_lds_bytes = wave * (uint32_t)(kTileWaveLdsFloat4 * sizeof(float4));
-    mine[lane] = p.cells[anchor + rel0];
-    mine[64 + lane] = p.cells[anchor + rel1];
-    if (lane < (uint32_t)kTileNbPieces - 128u) mine[128 + lane] = p.cells[anchor + rel2];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const uint32_t dx = ix[j] - ax, dy = iy[j] - ay, dz = iz[j] - az; // unsigned: below the anchor wraps to a huge value
-        float4 c6[6];
-        if (dx < 3u && dy < 3u && dz < 3u) {
-            // 24-bit multiply-adds, the last one spelled out: plain `mine + index * 6` compiles to three quarter-rate
-            // v_mad_u64_u32 per pixel
-            const uint32_t nbi = __umul24(dz, 9u) + __umul24(dy, 3u) + dx;
-            uint32_t off;
-            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(nbi), "s"(96u), "v"(wave_lds_bytes));
-            const float4 *cell = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(&nbr[0][0]) + off);
-#pragma unroll
-            for (int i = 0; i < 6; i++) c6[i] = cell[i];
-        } else {
-            // outside the window (an edge crossing the tile, heavy noise, synthetic random frames): this lane's own gather
-            // from the cell table in global memory / L2, six 16-byte loads.  A quad-cooperative form (the four lanes of a quad
-            // fetch one cell with two coalesced loads and hand it over through LDS: 2.8 instead of 6.1 L1 look-ups per pixel)
-            // was built and measured: no faster on uniform-random colours -- there the L1's miss path is the floor (a cell is
-            // two 64-byte L2 requests, ~0.39 requests per clock per CU) -- and slower when only a few pixels of a tile fall
-            // outside (profiles/r2/colorlut_random_floor.txt)
-            const float4 *cell = p.cells + __umul24(__umul24(__umul24(iz[j], p.size) + iy[j], p.size) + ix[j], kCellF4); // < 2^24 (size <= 65)
-#pragma unroll
-            for (int i = 0; i < 6; i++) c6[i] = cell[i];
-        }
-        const float f[24] = {c6[0].x, c6[0].y, c6[0].z, c6[0].w, c6[1].x, c6[1].y, c6[1].z, c6[1].w, c6[2].x, c6[2].y, c6[2].z, c6[2].w,
-                             c6[3].x, c6[3].y, c6[3].z, c6[3].w, c6[4].x, c6[4].y, c6[4].z, c6[4].w, c6[5].x, c6[5].y, c6[5].z, c6[5].w};
         float4 c[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) c[i] = make_float4(f[3 * i], f[3 * i + 1], f[3 * i + 2], 0.0f);
+        tile_cell((lds_bytes_t)&nbr[0][0], wave_lds_bytes, p, ix[j], iy[j], iz[j], ax, ay, az, c);
         float r, g, b;
         lf_trilinear<true>(c, fx[j], fy[j], fz[j], r, g, b);
         const float yr = r * p.fast.out_scale + p.fast.pred_half, yg = g * p.fast.out_scale + p.fast.pred_half,
@@ -712,6 +741,56 @@ __global__ __launch_bounds__(kI420Block) void colorlut_i420_kernel(I420Planes pl
     CellCache cache;
     i420_fused_tile(pl, width, height, kin, kout, edge,
                     [&](uint32_t px) { return lf_px8<IS3D, CELLS>(px, p, p.cube, p.t[0], p.t[1], p.t[2], cache); });
+}
+
+// The fused I420 kernel with the wave-local window: the compact walk of convert_math.hpp (a wave = 64 x 16 pixels, each lane an
+// 8 x 2 strip of it), the window anchored at the cell of the wave's centre pixel (the first pixel of lane 36 = column 32, row 8 of the
+// block; lane 0's when the centre lies outside the frame), coordinates from the byte table.  On natural-like content the per-lane
+// gathers of colorlut_i420_kernel were the bound: 38.7 us per 4K frame against 31.7 us on one flat colour (no gathers at all;
+// 27.7 us with the coordinates from the byte table).  This kernel: 30.5 us natural-like, 29.4 us flat.
+__global__ __launch_bounds__(kI420Block) void colorlut_i420_tile_kernel(I420Planes pl, uint32_t width, uint32_t height, LutParams p,
+                                                                        YuvToRgbCoef kin, RgbToYuvCoef kout)
+{
+    __shared__ int2 edge[kI420Block];
+    __shared__ uint2 coord[kCoordEntries];
+    __shared__ float4 nbr[kI420Block / 64][kTileWaveLdsFloat4];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    {
+        const uint2 *src = reinterpret_cast<const uint2 *>(p.tile_tables);
+#pragma unroll
+        for (uint32_t i = 0; i < kCoordEntries / kI420Block; i++) coord[i * kI420Block + threadIdx.x] = src[i * kI420Block + threadIdx.x];
+    }
+    uint32_t x0, y0, edge_index;
+    bool has_left;
+    i420_lane_origin<true>(x0, y0, edge_index, has_left);
+    const bool active = x0 < width && y0 < height;
+    uint32_t first = 0xff000000u;
+    if (active) {
+        const uint32_t crow = y0 / 2;
+        const ChromaTerms c = chroma_terms(pl.iu[(uint64_t)crow * pl.ius + x0 / 2], pl.iv[(uint64_t)crow * pl.ivs + x0 / 2], kin);
+        first = yuv_pixel(pl.iy[(uint64_t)y0 * pl.iys + x0], c, kin);
+    }
+    const TileRel rel = tile_rel(lane, p);
+    __syncthreads(); // coordinate table complete
+    const uint32_t centre = __builtin_amdgcn_readlane((int)active, 36) ? 36u : 0u;
+    const uint32_t fpx = (uint32_t)__builtin_amdgcn_readlane((int)first, centre);
+    const uint32_t cx = coord[fpx & 0xffu].x, cy = coord[256 + ((fpx >> 8) & 0xffu)].x, cz = coord[512 + ((fpx >> 16) & 0xffu)].x;
+    uint32_t ax, ay, az;
+    tile_load_window(nbr[wave], lane, p, rel, cx, cy, cz, ax, ay, az);
+    const uint32_t wave_lds_bytes = wave * (uint32_t)(kTileWaveLdsFloat4 * sizeof(float4));
+    i420_fused_tile<true>(pl, width, height, kin, kout, edge, [&](uint32_t px) {
+        const uint2 er = coord[px & 0xffu], eg = coord[256 + ((px >> 8) & 0xffu)], eb = coord[512 + ((px >> 16) & 0xffu)];
+        float4 c[8];
+        tile_cell((lds_bytes_t)&nbr[0][0], wave_lds_bytes, p, er.x, eg.x, eb.x, ax, ay, az, c);
+        float r, g, b;
+        lf_trilinear<true>(c, __uint_as_float(er.y), __uint_as_float(eg.y), __uint_as_float(eb.y), r, g, b);
+        const float yr = r * p.fast.out_scale + p.fast.pred_half, yg = g * p.fast.out_scale + p.fast.pred_half,
+                    yb = b * p.fast.out_scale + p.fast.pred_half;
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(yr));
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(yg));
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(yb));
+        return px;
+    });
 }
 
 template <bool IS3D, bool CELLS, bool WIDE, bool LE>
@@ -1108,7 +1187,11 @@ int colorlut_i420_impl(mvfx_cube_lut *h, const mvfx_planar_frame *in, const mvfx
         const YuvToRgbCoef kin = yuv_to_rgb_coef(std_);
         const RgbToYuvCoef kout = rgb_to_yuv_coef(std_);
         const dim3 grid((w / 8 + kI420Block - 1) / kI420Block, hgt / 2);
-        if (l.is_3d && h->d_cells)
+        p.tile_tables = h->d_tile_tables;
+        if (l.is_3d && h->d_cells && h->d_tile_tables && hgt / 16 + 1 <= 65535u) {
+            const dim3 tgrid((w + 255) / 256, (hgt + 15) / 16);
+            hipLaunchKernelGGL(colorlut_i420_tile_kernel, tgrid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);
+        } else if (l.is_3d && h->d_cells)
             hipLaunchKernelGGL((colorlut_i420_kernel<true, true>), grid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);
         else if (l.is_3d)
             hipLaunchKernelGGL((colorlut_i420_kernel<true, false>), grid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);

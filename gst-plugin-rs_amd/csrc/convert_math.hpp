@@ -122,19 +122,41 @@ struct I420Planes {
     uint64_t iys, ius, ivs, oys, ous, ovs;
 };
 
-template <typename F>
+// COMPACT = false: a workgroup is a 2048 x 2 pixel strip (lane after lane along the row), grid = (ceil(width / 2048), height / 2).
+// COMPACT = true:  a wave is a 64 x 16 pixel block (8 lanes across, 8 down), a workgroup four of them side by side (256 x 16),
+//                  grid = (ceil(width / 256), ceil(height / 16)): the pixels of a wave are close to each other in the picture, which
+//                  the wave-local LUT window of colorlut needs.
+template <bool COMPACT>
+__device__ __forceinline__ void i420_lane_origin(uint32_t &x0, uint32_t &y0, uint32_t &edge_index, bool &has_left_in_group)
+{
+    if constexpr (COMPACT) {
+        const uint32_t wave = threadIdx.x >> 6, lx = threadIdx.x & 7, ly = (threadIdx.x >> 3) & 7;
+        x0 = (blockIdx.x * 4 + wave) * 64 + lx * 8;
+        y0 = blockIdx.y * 16 + ly * 2;
+        edge_index = ly * 32 + wave * 8 + lx;
+        has_left_in_group = (wave * 8 + lx) > 0;
+    } else {
+        x0 = (blockIdx.x * kI420Block + threadIdx.x) * 8;
+        y0 = blockIdx.y * 2;
+        edge_index = threadIdx.x;
+        has_left_in_group = threadIdx.x > 0;
+    }
+}
+
+template <bool COMPACT = false, typename F>
 __device__ __forceinline__ void i420_fused_tile(const I420Planes &pl, uint32_t width, uint32_t height, const YuvToRgbCoef &kin,
                                                 const RgbToYuvCoef &kout, int2 *edge, F &&px_fn)
 {
-    const uint32_t x0 = (blockIdx.x * kI420Block + threadIdx.x) * 8;
-    const uint32_t y0 = blockIdx.y * 2;
-    const bool active = x0 < width;
+    uint32_t x0, y0, edge_index;
+    bool has_left;
+    i420_lane_origin<COMPACT>(x0, y0, edge_index, has_left);
+    const uint32_t crow = y0 / 2;
+    const bool active = x0 < width && y0 < height;
     const bool cosited = kout.cosited != 0;
     int32_t cu[8], cv[8];
     uint32_t ya0 = 0, ya1 = 0, yb0 = 0, yb1 = 0;
     const uint8_t *yr0 = pl.iy + (uint64_t)y0 * pl.iys, *yr1 = yr0 + pl.iys;
-    const uint8_t *ur = pl.iu + (uint64_t)blockIdx.y * pl.ius, *vr = pl.iv + (uint64_t)blockIdx.y * pl.ivs;
-    (void)height;
+    const uint8_t *ur = pl.iu + (uint64_t)crow * pl.ius, *vr = pl.iv + (uint64_t)crow * pl.ivs;
     if (active) {
         const uint2 ya = *reinterpret_cast<const uint2 *>(yr0 + x0), yb = *reinterpret_cast<const uint2 *>(yr1 + x0);
         const uint32_t u4 = *reinterpret_cast<const uint32_t *>(ur + x0 / 2), v4 = *reinterpret_cast<const uint32_t *>(vr + x0 / 2);
@@ -160,12 +182,12 @@ __device__ __forceinline__ void i420_fused_tile(const I420Planes &pl, uint32_t w
     }
     int32_t lu = 0, lv = 0;
     if (cosited) { // uniform branch
-        edge[threadIdx.x] = active ? make_int2(cu[7], cv[7]) : make_int2(0, 0);
+        edge[edge_index] = active ? make_int2(cu[7], cv[7]) : make_int2(0, 0);
         __syncthreads();
         if (active && x0 > 0) {
-            if (threadIdx.x > 0) {
-                lu = edge[threadIdx.x - 1].x;
-                lv = edge[threadIdx.x - 1].y;
+            if (has_left) {
+                lu = edge[edge_index - 1].x;
+                lv = edge[edge_index - 1].y;
             } else { // left neighbour lives in another workgroup: evaluate column x0 - 1 here
                 const ChromaTerms c = chroma_terms(ur[(x0 - 1) / 2], vr[(x0 - 1) / 2], kin);
                 const uint32_t qa = px_fn(yuv_pixel(yr0[x0 - 1], c, kin)), qb = px_fn(yuv_pixel(yr1[x0 - 1], c, kin));
@@ -189,8 +211,8 @@ __device__ __forceinline__ void i420_fused_tile(const I420Planes &pl, uint32_t w
         u4o |= ru << (8 * i);
         v4o |= rv << (8 * i);
     }
-    *reinterpret_cast<uint32_t *>(pl.ou + (uint64_t)blockIdx.y * pl.ous + x0 / 2) = u4o;
-    *reinterpret_cast<uint32_t *>(pl.ov + (uint64_t)blockIdx.y * pl.ovs + x0 / 2) = v4o;
+    *reinterpret_cast<uint32_t *>(pl.ou + (uint64_t)crow * pl.ous + x0 / 2) = u4o;
+    *reinterpret_cast<uint32_t *>(pl.ov + (uint64_t)crow * pl.ovs + x0 / 2) = v4o;
 }
 
 } // namespace mvfx

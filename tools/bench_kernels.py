@@ -293,6 +293,11 @@ def main():
         torch.cuda.synchronize()
         ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_i420(lut.h, ctypes.byref(fi[i % POOL]), ctypes.byref(fo[i % POOL]), 0, sptr)), iters=200)
         report("colorlut 33^3 on I420 4K natural, fused videoconvert!colorlut!videoconvert (one kernel)", ms, W * H * 3, 1)
+        # one flat colour: every pixel repeats its lane's previous LUT cell -> no gathers at all: the floor of the fused kernel
+        flat = torch.full((POOL, isz), 0x6B, dtype=torch.uint8, device=dev)
+        ff = [vfx.make_i420(flat[i].data_ptr(), W, H, W, W // 2, W * H, W * H * 5 // 4) for i in range(POOL)]
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_i420(lut.h, ctypes.byref(ff[i % POOL]), ctypes.byref(fo[i % POOL]), 0, sptr)), iters=200)
+        report("colorlut 33^3 on I420 4K one flat colour (no LUT gathers), fused kernel", ms, W * H * 3, 1)
         tmp_a = torch.empty((POOL, NB), dtype=torch.uint8, device=dev)
         tmp_b = torch.empty((POOL, NB), dtype=torch.uint8, device=dev)
         fa = [vfx.make_frame(tmp_a[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
