@@ -557,7 +557,7 @@ __device__ __forceinline__ void lf_rows(const uint8_t *in, uint8_t *out, uint64_
 // What bounds the per-lane gather kernel above is the vector L1's tag look-up rate, on natural content as much as on random
 // content (rocprofv3, profiles/r2/colorlut_counters_*_before.txt: TCP busy 97 %, 3.2 / 6.1 look-ups per pixel at ~1.2 per
 // clock per CU; VALUBusy 64 % / 28 %): every lane that needs a cell pays 6 look-ups for its 96 bytes, whoever else in the
-// wave wants the same bytes.  Pictures are locally coherent in colour: this kernel gives a wave a 16 x 16 pixel TILE
+// wave wants the same bytes.  Pictures are locally coherent in colour: this kernel gives a wave a compact pixel BLOCK (64 x 16 or 32 x 16)
 // (spatially compact, unlike 256 consecutive pixels of a row), takes the LUT cell of the tile's centre pixel as anchor and
 // loads the 3 x 3 x 3 cells around it -- nine runs of 288 contiguous bytes, 162 coalesced 16-byte pieces in three wave
 // loads, ~54 look-ups -- into the wave's 2.6 KB of LDS.  A pixel whose cell lies in that neighbourhood (a cell of a 33^3
@@ -645,11 +645,17 @@ __device__ __forceinline__ void tile_load_window(float4 *mine, uint32_t lane, co
 // WIDE: RGBA64 (LE: little endian) -- a lane's four pixels are 32 bytes (two 16-byte loads), the lattice coordinates come from
 // lf_coord on the 16-bit values (the byte-indexed LDS table does not exist for 65536 values; same arithmetic as the gather
 // kernel's lf_px16), the output is lf_px16's.  Round 2: 4K natural-like RGBA64 frame 43.4 us with the per-lane gathers.
-template <bool WIDE, bool LE>
+// A wave's block: ACROSS lanes x (64 / ACROSS) lanes, every lane ROWS rows of four pixels: 4 ACROSS x (64 / ACROSS) ROWS pixels.
+// <16, 4> = 64 x 16 and <8, 2> = 32 x 16 are built (the launcher explains the choice): the coordinate table and the window are set
+// up once per 1024 / 512 pixels; the first version's 16 x 16 tile (<4, 1>) paid that set-up every 256 pixels and reached 47.0 k fps
+// where 64 x 16 reaches 61.6 k.
+template <bool WIDE, bool LE, int ACROSS, int ROWS>
 __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb, FrameBatch out_fb, uint32_t width, uint32_t height,
                                                                uint32_t in_stride, uint32_t out_stride, LutParams p)
 {
     constexpr uint32_t kBpp = WIDE ? 8 : 4;
+    constexpr uint32_t kAcross = ACROSS, kTileW = 4 * ACROSS, kDown = 64 / ACROSS, kTileH = kDown * ROWS,
+                       kCentreLane = (kDown / 2) * ACROSS + ACROSS / 2;
     __shared__ float4 nbr[kBlock / 64][kTileWaveLdsFloat4];
     __shared__ uint2 coord[WIDE ? 1 : kCoordEntries]; // {cell index, fraction bits} per channel and byte value
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -659,70 +665,79 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
         for (uint32_t i = 0; i < kCoordEntries / kBlock; i++) coord[i * kBlock + threadIdx.x] = src[i * kBlock + threadIdx.x];
     }
     // workgroup = four horizontally adjacent tiles (grid x), one tile row per grid y
-    const uint32_t x = (blockIdx.x * (kBlock / 64) + wave) * 16 + (lane & 3) * 4, y = blockIdx.y * 16 + (lane >> 2);
-    const bool valid = x < width && y < height; // width % 4 == 0 (launcher): a lane's four pixels are all inside or all outside
+    const uint32_t x = (blockIdx.x * (kBlock / 64) + wave) * kTileW + (lane % kAcross) * 4, y0 = blockIdx.y * kTileH + (lane / kAcross) * ROWS;
     const uint8_t *in = in_fb.base[blockIdx.z];
     uint8_t *out = out_fb.base[blockIdx.z];
-    uint4 v = make_uint4(0, 0, 0, 0), v2 = make_uint4(0, 0, 0, 0);
-    if (valid) {
-        v = *reinterpret_cast<const uint4 *>(in + (y * in_stride + x * kBpp));
-        if constexpr (WIDE) v2 = *reinterpret_cast<const uint4 *>(in + (y * in_stride + x * kBpp + 16));
-    }
     const TileRel rel = tile_rel(lane, p);
-    if constexpr (!WIDE) __syncthreads(); // coordinate table complete
-    uint32_t px[4] = {v.x, v.y, v.z, v.w};      // RGBA8: the pixels; RGBA64: low words (r | g << 16) of the pixels
-    uint32_t px_hi[4] = {0, 0, 0, 0};           // RGBA64: high words (b | a << 16)
-    if constexpr (WIDE) { px[0] = v.x; px_hi[0] = v.y; px[1] = v.z; px_hi[1] = v.w; px[2] = v2.x; px_hi[2] = v2.y; px[3] = v2.z; px_hi[3] = v2.w; }
-    uint32_t ix[4], iy[4], iz[4];
-    float fx[4], fy[4], fz[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if constexpr (WIDE) {
-            uint32_t rv = px[j] & 0xffffu, gv = px[j] >> 16, bv = px_hi[j] & 0xffffu;
-            if constexpr (!LE) { rv = bswap16(rv); gv = bswap16(gv); bv = bswap16(bv); }
-            lf_coord((float)rv, p.fast, p.scale[0], p.offset[0], p.size_m1, ix[j], fx[j]);
-            lf_coord((float)gv, p.fast, p.scale[1], p.offset[1], p.size_m1, iy[j], fy[j]);
-            lf_coord((float)bv, p.fast, p.scale[2], p.offset[2], p.size_m1, iz[j], fz[j]);
-        } else {
-            const uint2 er = coord[px[j] & 0xffu], eg = coord[256 + ((px[j] >> 8) & 0xffu)], eb = coord[512 + ((px[j] >> 16) & 0xffu)];
-            ix[j] = er.x; fx[j] = __uint_as_float(er.y);
-            iy[j] = eg.x; fy[j] = __uint_as_float(eg.y);
-            iz[j] = eb.x; fz[j] = __uint_as_float(eb.y);
-        }
-    }
-    // anchor: the cell of the tile's centre pixel (lane 34 = row 8, columns 8..11)
-    const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)ix[0], 34), cy = (uint32_t)__builtin_amdgcn_readlane((int)iy[0], 34),
-                   cz = (uint32_t)__builtin_amdgcn_readlane((int)iz[0], 34);
-    uint32_t ax, ay, az;
-    tile_load_window(nbr[wave], lane, p, rel, cx, cy, cz, ax, ay, az);
+    uint32_t ax = 0, ay = 0, az = 0;
     const uint32_t wave_lds_bytes = wave * (uint32_t)(kTileWaveLdsFloat4 * sizeof(float4));
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        float4 c[8];
-        tile_cell((lds_bytes_t)&nbr[0][0], wave_lds_bytes, p, ix[j], iy[j], iz[j], ax, ay, az, c);
-        float r, g, b;
-        lf_trilinear<true>(c, fx[j], fy[j], fz[j], r, g, b);
-        const float yr = r * p.fast.out_scale + p.fast.pred_half, yg = g * p.fast.out_scale + p.fast.pred_half,
-                    yb = b * p.fast.out_scale + p.fast.pred_half;
-        if constexpr (WIDE) {
-            uint32_t ro = (uint32_t)__float2uint_rz(yr), go = (uint32_t)__float2uint_rz(yg), bo = (uint32_t)__float2uint_rz(yb);
-            if constexpr (!LE) { ro = bswap16(ro); go = bswap16(go); bo = bswap16(bo); }
-            px[j] = ro | (go << 16);
-            px_hi[j] = bo | (px_hi[j] & 0xffff0000u);
-        } else {
-            uint32_t w = px[j];
-            asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yr));
-            asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yg));
-            asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
-            px[j] = w;
+    for (int row = 0; row < ROWS; row++) {
+        const uint32_t y = y0 + row;
+        const bool valid = x < width && y < height; // width % 4 == 0 (launcher): a lane's four pixels are all inside or all outside
+        uint4 v = make_uint4(0, 0, 0, 0), v2 = make_uint4(0, 0, 0, 0);
+        if (valid) {
+            v = *reinterpret_cast<const uint4 *>(in + (y * in_stride + x * kBpp));
+            if constexpr (WIDE) v2 = *reinterpret_cast<const uint4 *>(in + (y * in_stride + x * kBpp + 16));
         }
-    }
-    if (valid) {
-        if constexpr (WIDE) {
-            *reinterpret_cast<uint4 *>(out + (y * out_stride + x * kBpp)) = make_uint4(px[0], px_hi[0], px[1], px_hi[1]);
-            *reinterpret_cast<uint4 *>(out + (y * out_stride + x * kBpp + 16)) = make_uint4(px[2], px_hi[2], px[3], px_hi[3]);
-        } else {
-            *reinterpret_cast<uint4 *>(out + (y * out_stride + x * 4)) = make_uint4(px[0], px[1], px[2], px[3]);
+        if (row == 0) {
+            if constexpr (!WIDE) __syncthreads(); // coordinate table complete
+        }
+        uint32_t px[4] = {v.x, v.y, v.z, v.w};      // RGBA8: the pixels; RGBA64: low words (r | g << 16) of the pixels
+        uint32_t px_hi[4] = {0, 0, 0, 0};           // RGBA64: high words (b | a << 16)
+        if constexpr (WIDE) { px[0] = v.x; px_hi[0] = v.y; px[1] = v.z; px_hi[1] = v.w; px[2] = v2.x; px_hi[2] = v2.y; px[3] = v2.z; px_hi[3] = v2.w; }
+        uint32_t ix[4], iy[4], iz[4];
+        float fx[4], fy[4], fz[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if constexpr (WIDE) {
+                uint32_t rv = px[j] & 0xffffu, gv = px[j] >> 16, bv = px_hi[j] & 0xffffu;
+                if constexpr (!LE) { rv = bswap16(rv); gv = bswap16(gv); bv = bswap16(bv); }
+                lf_coord((float)rv, p.fast, p.scale[0], p.offset[0], p.size_m1, ix[j], fx[j]);
+                lf_coord((float)gv, p.fast, p.scale[1], p.offset[1], p.size_m1, iy[j], fy[j]);
+                lf_coord((float)bv, p.fast, p.scale[2], p.offset[2], p.size_m1, iz[j], fz[j]);
+            } else {
+                const uint2 er = coord[px[j] & 0xffu], eg = coord[256 + ((px[j] >> 8) & 0xffu)], eb = coord[512 + ((px[j] >> 16) & 0xffu)];
+                ix[j] = er.x; fx[j] = __uint_as_float(er.y);
+                iy[j] = eg.x; fy[j] = __uint_as_float(eg.y);
+                iz[j] = eb.x; fz[j] = __uint_as_float(eb.y);
+            }
+        }
+        if (row == 0) {
+            // anchor: the cell of the block's centre pixel (64 x 16: lane 40 = rows 8..11, columns 32..35, its first row)
+            const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)ix[0], kCentreLane),
+                           cy = (uint32_t)__builtin_amdgcn_readlane((int)iy[0], kCentreLane),
+                           cz = (uint32_t)__builtin_amdgcn_readlane((int)iz[0], kCentreLane);
+            tile_load_window(nbr[wave], lane, p, rel, cx, cy, cz, ax, ay, az);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float4 c[8];
+            tile_cell((lds_bytes_t)&nbr[0][0], wave_lds_bytes, p, ix[j], iy[j], iz[j], ax, ay, az, c);
+            float r, g, b;
+            lf_trilinear<true>(c, fx[j], fy[j], fz[j], r, g, b);
+            const float yr = r * p.fast.out_scale + p.fast.pred_half, yg = g * p.fast.out_scale + p.fast.pred_half,
+                        yb = b * p.fast.out_scale + p.fast.pred_half;
+            if constexpr (WIDE) {
+                uint32_t ro = (uint32_t)__float2uint_rz(yr), go = (uint32_t)__float2uint_rz(yg), bo = (uint32_t)__float2uint_rz(yb);
+                if constexpr (!LE) { ro = bswap16(ro); go = bswap16(go); bo = bswap16(bo); }
+                px[j] = ro | (go << 16);
+                px_hi[j] = bo | (px_hi[j] & 0xffff0000u);
+            } else {
+                uint32_t w = px[j];
+                asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yr));
+                asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yg));
+                asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
+                px[j] = w;
+            }
+        }
+        if (valid) {
+            if constexpr (WIDE) {
+                *reinterpret_cast<uint4 *>(out + (y * out_stride + x * kBpp)) = make_uint4(px[0], px_hi[0], px[1], px_hi[1]);
+                *reinterpret_cast<uint4 *>(out + (y * out_stride + x * kBpp + 16)) = make_uint4(px[2], px_hi[2], px[3], px_hi[3]);
+            } else {
+                *reinterpret_cast<uint4 *>(out + (y * out_stride + x * 4)) = make_uint4(px[0], px[1], px[2], px[3]);
+            }
         }
     }
 }
@@ -1081,14 +1096,23 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
     const FrameBatch &ip = ifb, &op = ofb;
 
     if (use_fast && use_tiles) {
-        const uint32_t tiles_x = (in->width + 15) / 16, tiles_y = (in->height + 15) / 16;
+        // wave block: 64 x 16 pixels for RGBA8 on cubes up to 48 points per axis, 32 x 16 for bigger cubes (finer cells: the colours of a
+        // smaller block stay in the window more often) and for RGBA64.  4K, 33^3 natural-like, 16 frames per launch / one frame / flat
+        // bars one frame / 65^3 one frame / RGBA64 one frame:
+        //   16 x 16 (lanes 4 x 16, 1 row each)  47.0 k fps  24.9 us  29.5 us  38.1 us  33.2 us      (round 2's first version)
+        //   64 x 16 (16 x 4, 4 rows)            61.6 k      22.5     24.3     39.4     34.2
+        //   32 x 16 (8 x 8, 2 rows)             57.0 k      21.5     28.1     37.8     32.4
+        //   64 x 32 (16 x 4, 8 rows) 60.2 k / 31.0 us;  32 x 32 59.1 k / 23.9;  64 x 8 56.3 k / 22.4;  32 x 64 47.4 k / 34.3
+        const bool wide_block = !wide && l.size < 49;
+        const uint32_t tile_w = wide_block ? 64 : 32, tile_h = 16;
+        const uint32_t tiles_x = (in->width + tile_w - 1) / tile_w, tiles_y = (in->height + tile_h - 1) / tile_h;
         const dim3 tgrid((tiles_x + kBlock / 64 - 1) / (kBlock / 64), tiles_y, n);
-        if (!wide)
-            hipLaunchKernelGGL((colorlut_tile_kernel<false, true>), tgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p);
-        else if (le)
-            hipLaunchKernelGGL((colorlut_tile_kernel<true, true>), tgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p);
-        else
-            hipLaunchKernelGGL((colorlut_tile_kernel<true, false>), tgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p);
+#define MVFX_TK(WIDE, LE, A, R) hipLaunchKernelGGL((colorlut_tile_kernel<WIDE, LE, A, R>), tgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p)
+        if (wide_block) MVFX_TK(false, true, 16, 4);
+        else if (!wide) MVFX_TK(false, true, 8, 2);
+        else if (le) MVFX_TK(true, true, 8, 2);
+        else MVFX_TK(true, false, 8, 2);
+#undef MVFX_TK
         MVFX_HIP_TRY(hipGetLastError());
         return MVFX_OK;
     }
