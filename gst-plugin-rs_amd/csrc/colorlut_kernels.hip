@@ -621,7 +621,8 @@ __device__ __forceinline__ void tile_cell(lds_bytes_t nbr_base, uint32_t wave_ld
 // (A 4 x 4 x 4 window with the three cell indices packed into one word -- one subtraction, one mask test and one v_dot4 for the
 // LDS offset instead of nine instructions -- was built on top of the 64 x 16 blocks and measured: 33^3 natural-like 61.6 k -> 52.6 k
 // fps, flat bars 24.3 -> 33.6 us per 4K frame, 65^3 unchanged: the three extra wave loads per block and the 6 KB of LDS per wave cost
-// more than the simpler test and the wider window return.)
+// more than the simpler test and the wider window return.  A 2 x 2 x 2 window anchored by the centre pixel's position in its cell
+// (one wave load): flat bars unchanged, natural-like 61.6 k -> 37.2 k fps -- too many pixels fall outside.)
 struct TileRel {
     uint32_t r0, r1, r2; // offsets of this lane's three pieces of the window relative to the anchor cell (float4 units)
 };
