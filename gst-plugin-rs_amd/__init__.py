@@ -135,6 +135,7 @@ SIGNATURES = {
     "mvfx_host_free": (c_int, [c_void_p]),
     "mvfx_copy_to_device_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mvfx_copy_to_host_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mvfx_copy_device_to_device_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mvfx_thread_set_options": (c_int, [c_uint32]),
     "mvfx_thread_options": (c_uint32, []),
     "mvfx_hsvfilter_transform_frame_ip": (c_int, [POINTER(Frame), POINTER(HsvFilterSettings), c_void_p]),

@@ -322,6 +322,16 @@ int mvfx_copy_to_host_async(void *dst_host, const void *src_device, size_t bytes
     return MVFX_OK;
 }
 
+int mvfx_copy_device_to_device_async(void *dst_device, const void *src_device, size_t bytes, mvfx_stream stream)
+{
+    if (bytes == 0) return MVFX_OK;
+    if (!dst_device || !src_device)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "copy_device_to_device_async: NULL pointer");
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    MVFX_HIP_TRY(hipMemcpyAsync(dst_device, src_device, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return MVFX_OK;
+}
+
 int mvfx_thread_set_options(uint32_t options)
 {
     const uint32_t known = MVFX_OPT_NONTEMPORAL | MVFX_OPT_HSV_LITERAL | MVFX_OPT_HSV_FORCE_FAST | MVFX_OPT_HSV_VALU_UNORM |

@@ -221,15 +221,22 @@ static GType hipcopy_register(const gchar *name, GClassInitFunc class_init)
 
 // ------------------------------------------------------------------------------------ hiptestsrc
 // A generator-free frame source for throughput measurements (tools/bench_gst_pipeline.py): videotestsrc spends more time
-// painting a 4K frame than the whole filter chain needs.  Every buffer of the negotiated pool is filled ONCE with a
-// pseudo-random frame (system memory: a memcpy; memory:HIPMemory: one H2D copy) and then handed out again as it comes
-// back from downstream, whatever it then contains -- in the steady state create() costs nothing on either path.
+// painting a 4K frame than the whole filter chain needs.  The frame is painted ONCE in set_caps -- for the packed RGB formats
+// what `videotestsrc pattern=smpte` paints (bars, -I / white / +Q, super-black / black / grey, LCG snow: tests/frames.py has the
+// same restatement, checked against the element), pseudo-random bytes for every other format.
+//   system memory: every pool buffer is filled once (a 33 MB memcpy per 4K frame would cap the source at ~350 fps) and handed out
+//                  again as it comes back -- fine for elements that leave system buffers untouched (hipupload, out-of-place
+//                  filters); an in-place filter on system memory sees its own output again next time round;
+//   HIP memory:    every frame is refreshed from a device-resident master with one asynchronous device-to-device copy on the
+//                  streaming thread's stream, ordered by the block's fence (13 us of GPU time per 4K frame): in-place filters
+//                  downstream (hsvfilter) always get the same input.
 struct GstMi355HipTestSrc {
     GstPushSrc parent;
     GstVideoInfo info;
     gboolean have_info, hip;
     guint8 *pattern;
     gsize pattern_size;
+    void *master;        // device copy of `pattern` (memory:HIPMemory caps)
     guint64 n;
 };
 struct GstMi355HipTestSrcClass { GstPushSrcClass parent_class; };
@@ -248,6 +255,51 @@ static GstCaps *hiptestsrc_fixate(GstBaseSrc *src, GstCaps *caps)
     return GST_BASE_SRC_CLASS(gst_mi355_hip_test_src_parent_class)->fixate(src, caps);
 }
 
+// videotestsrc pattern=smpte, frame 0, for packed 8-bit RGB formats (3 or 4 bytes per pixel); FALSE for anything else
+static gboolean hiptestsrc_paint_smpte(const GstVideoInfo *info, guint8 *dst)
+{
+    const GstVideoFormatInfo *f = info->finfo;
+    if (!GST_VIDEO_FORMAT_INFO_IS_RGB(f) || GST_VIDEO_INFO_N_PLANES(info) != 1 || GST_VIDEO_FORMAT_INFO_DEPTH(f, 0) != 8)
+        return FALSE;
+    const gint bpp = GST_VIDEO_FORMAT_INFO_PSTRIDE(f, 0);
+    if (bpp != 3 && bpp != 4) return FALSE;
+    const gint w = GST_VIDEO_INFO_WIDTH(info), h = GST_VIDEO_INFO_HEIGHT(info), stride = GST_VIDEO_INFO_PLANE_STRIDE(info, 0);
+    const gint ro = GST_VIDEO_FORMAT_INFO_POFFSET(f, 0), go = GST_VIDEO_FORMAT_INFO_POFFSET(f, 1), bo = GST_VIDEO_FORMAT_INFO_POFFSET(f, 2);
+    static const guint8 bars[7][3] = {{255, 255, 255}, {255, 255, 0}, {0, 255, 255}, {0, 255, 0}, {255, 0, 255}, {255, 0, 0}, {0, 0, 255}};
+    static const guint8 low[3][3] = {{0, 0, 128}, {255, 255, 255}, {0, 128, 255}};
+    static const guint8 greys[3] = {0, 0, 19};
+    const gint y1 = 2 * h / 3, y2 = 3 * h / 4, x_snow = w * 3 / 4;
+    guint32 lcg = 0;
+    memset(dst, 255, GST_VIDEO_INFO_SIZE(info)); // alpha / padding byte of the 4-byte formats
+    for (gint y = 0; y < h; y++) {
+        guint8 *row = dst + (gsize)y * stride;
+        for (gint x = 0; x < w; x++) {
+            guint8 r, g, b;
+            if (y < y2) {
+                gint i = 0;
+                while (i < 6 && x >= (i + 1) * w / 7) i++;
+                const guint8 *c = bars[y < y1 ? i : 6 - i];
+                if (y >= y1 && (i & 1)) r = g = b = 0;
+                else { r = c[0]; g = c[1]; b = c[2]; }
+            } else if (x < w / 2) {
+                gint i = 0;
+                while (i < 2 && x >= (i + 1) * w / 6) i++;
+                r = low[i][0]; g = low[i][1]; b = low[i][2];
+            } else if (x < x_snow) {
+                gint i = 0;
+                while (i < 2 && x >= w / 2 + (i + 1) * w / 12) i++;
+                r = g = b = greys[i];
+            } else {
+                lcg = lcg * 1103515245u + 12345u;
+                r = g = b = (guint8)(lcg >> 16);
+            }
+            guint8 *px = row + (gsize)x * bpp;
+            px[ro] = r; px[go] = g; px[bo] = b;
+        }
+    }
+    return TRUE;
+}
+
 static gboolean hiptestsrc_set_caps(GstBaseSrc *src, GstCaps *caps)
 {
     GstMi355HipTestSrc *self = (GstMi355HipTestSrc *)src;
@@ -257,14 +309,27 @@ static gboolean hiptestsrc_set_caps(GstBaseSrc *src, GstCaps *caps)
     g_free(self->pattern);
     self->pattern_size = GST_VIDEO_INFO_SIZE(&self->info);
     self->pattern = (guint8 *)g_malloc(self->pattern_size);
-    guint64 x = 0x5EED0001ull; // splitmix64 bytes
-    for (gsize i = 0; i < self->pattern_size; i += 8) {
-        x += 0x9E3779B97F4A7C15ull;
-        guint64 z = x;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        z ^= z >> 31;
-        memcpy(self->pattern + i, &z, MIN((gsize)8, self->pattern_size - i));
+    if (!hiptestsrc_paint_smpte(&self->info, self->pattern)) {
+        guint64 x = 0x5EED0001ull; // splitmix64 bytes
+        for (gsize i = 0; i < self->pattern_size; i += 8) {
+            x += 0x9E3779B97F4A7C15ull;
+            guint64 z = x;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            memcpy(self->pattern + i, &z, MIN((gsize)8, self->pattern_size - i));
+        }
+    }
+    if (self->master) {
+        mvfx_device_free(self->master);
+        self->master = NULL;
+    }
+    if (self->hip) {
+        if (mvfx_device_alloc(&self->master, self->pattern_size) != MVFX_OK ||
+            mvfx_copy_to_device(self->master, self->pattern, self->pattern_size, NULL) != MVFX_OK) {
+            GST_ELEMENT_ERROR(self, RESOURCE, FAILED, ("hiptestsrc: %s", mvfx_last_error()), (NULL));
+            return FALSE;
+        }
     }
     gst_base_src_set_blocksize(src, (guint)self->pattern_size);
     return TRUE;
@@ -295,19 +360,20 @@ static GstFlowReturn hiptestsrc_fill(GstPushSrc *psrc, GstBuffer *buf)
     GstMi355HipTestSrc *self = (GstMi355HipTestSrc *)psrc;
     if (!self->have_info) return GST_FLOW_NOT_NEGOTIATED;
     GstMemory *mem = gst_buffer_peek_memory(buf, 0);
-    if (!gst_mini_object_get_qdata(GST_MINI_OBJECT_CAST(mem), hiptestsrc_filled_quark())) {
+    if (self->hip && self->master && mvfx_buffer_is_hip(buf)) {
         GstMapInfo map;
-        if (self->hip && mvfx_buffer_is_hip(buf)) {
-            if (!gst_buffer_map(buf, &map, (GstMapFlags)(MVFX_MAP_HIP | GST_MAP_WRITE))) return GST_FLOW_ERROR;
-            mvfx_hip_memory_wait(mem);
-            const int rc = mvfx_copy_to_device(map.data, self->pattern, MIN(self->pattern_size, map.size), NULL);
-            gst_buffer_unmap(buf, &map);
-            if (rc != MVFX_OK) return MVFX_GST_FLOW(self, rc);
-        } else {
-            if (!gst_buffer_map(buf, &map, GST_MAP_WRITE)) return GST_FLOW_ERROR;
-            memcpy(map.data, self->pattern, MIN(self->pattern_size, map.size));
-            gst_buffer_unmap(buf, &map);
-        }
+        if (!gst_buffer_map(buf, &map, (GstMapFlags)(MVFX_MAP_HIP | GST_MAP_WRITE))) return GST_FLOW_ERROR;
+        mvfx_stream st = mvfx_thread_stream();
+        mvfx_hip_buffer_acquire(buf, st);
+        const int rc = mvfx_copy_device_to_device_async(map.data, self->master, MIN(self->pattern_size, map.size), st);
+        mvfx_hip_buffer_release(buf, st);
+        gst_buffer_unmap(buf, &map);
+        if (rc != MVFX_OK) return MVFX_GST_FLOW(self, rc);
+    } else if (!gst_mini_object_get_qdata(GST_MINI_OBJECT_CAST(mem), hiptestsrc_filled_quark())) {
+        GstMapInfo map;
+        if (!gst_buffer_map(buf, &map, GST_MAP_WRITE)) return GST_FLOW_ERROR;
+        memcpy(map.data, self->pattern, MIN(self->pattern_size, map.size));
+        gst_buffer_unmap(buf, &map);
         gst_mini_object_set_qdata(GST_MINI_OBJECT_CAST(mem), hiptestsrc_filled_quark(), GINT_TO_POINTER(1), NULL);
     }
     const GstClockTime dur = GST_VIDEO_INFO_FPS_N(&self->info) > 0
@@ -327,7 +393,9 @@ static gboolean hiptestsrc_start(GstBaseSrc *src)
 
 static void gst_mi355_hip_test_src_finalize(GObject *obj)
 {
-    g_free(((GstMi355HipTestSrc *)obj)->pattern);
+    GstMi355HipTestSrc *self = (GstMi355HipTestSrc *)obj;
+    g_free(self->pattern);
+    if (self->master) mvfx_device_free(self->master);
     G_OBJECT_CLASS(gst_mi355_hip_test_src_parent_class)->finalize(obj);
 }
 
@@ -341,7 +409,7 @@ static void gst_mi355_hip_test_src_class_init(GstMi355HipTestSrcClass *klass)
     gst_element_class_add_pad_template(element, gst_pad_template_new("src", GST_PAD_SRC, GST_PAD_ALWAYS, both));
     gst_caps_unref(both);
     gst_element_class_set_static_metadata(element, "HIP test source", "Source/Video",
-                                          "Pre-generated pseudo-random video frames in system or memory:HIPMemory buffers (no per-frame generator cost)",
+                                          "Pre-painted videotestsrc-smpte frames in system or memory:HIPMemory buffers (no per-frame generator cost)",
                                           "mi355-vfx");
     bs->fixate = hiptestsrc_fixate;
     bs->set_caps = hiptestsrc_set_caps;
@@ -355,6 +423,7 @@ static void gst_mi355_hip_test_src_init(GstMi355HipTestSrc *self)
     self->have_info = self->hip = FALSE;
     self->pattern = NULL;
     self->pattern_size = 0;
+    self->master = NULL;
     self->n = 0;
     gst_base_src_set_format(GST_BASE_SRC(self), GST_FORMAT_TIME);
 }

@@ -123,6 +123,7 @@ int mvfx_host_alloc(void **out_ptr, size_t bytes);
 int mvfx_host_free(void *ptr);
 int mvfx_copy_to_device_async(void *dst_device, const void *src_host, size_t bytes, mvfx_stream stream);
 int mvfx_copy_to_host_async(void *dst_host, const void *src_device, size_t bytes, mvfx_stream stream);
+int mvfx_copy_device_to_device_async(void *dst_device, const void *src_device, size_t bytes, mvfx_stream stream);
 
 /* ---- per-thread kernel options ----
  * The calling thread is the library's implicit context: its private stream (mvfx_thread_stream), its staging scratch

@@ -360,13 +360,13 @@ def test_hipmemory_chain_with_fences_across_streaming_threads(gpu, tmp_path):
     """Every element only records / waits for the fence of the device block (no host wait per buffer,
     d3d12colorlut/imp.rs:695-714).  `queue`s put the three filters on three streaming threads = three HIP streams, 1080p
     frames keep several kernels in flight, pools recycle blocks whose last reader may still be running: all 12 frames must
-    still be bit-exact.  Source: hiptestsrc (pre-filled pinned pool buffers offered by hipupload)."""
+    still be bit-exact.  Source: hiptestsrc (pre-painted videotestsrc-smpte frames in the pinned pool buffers offered by hipupload)."""
     cube = tmp_path / "look.cube"
     cube.write_text(cubes.analytic_3d(17))
     w, h, n = 1920, 1080, 12
     src = f"hiptestsrc num-buffers={{n}} ! video/x-raw,format=RGBx,width={w},height={h},framerate=30/1"
     raw = _capture(tmp_path, src.format(n=1), "in.raw")
-    assert raw.size == w * h * 4 and len(np.unique(raw[:4096])) > 100
+    assert raw.size == w * h * 4 and len(np.unique(raw[-4096:])) > 100   # the snow corner of the smpte frame
     r = gst_env.run([LAUNCH, "-q"] + (src.format(n=n) + " ! hipupload ! queue ! hsvfilter hue-shift=45 ! queue ! hsvdetector hue-ref=120 "
                     "hue-var=60 saturation-ref=0.6 saturation-var=0.4 value-ref=0.6 value-var=0.4 ! video/x-raw(memory:HIPMemory),format=RGBA "
                     f"! queue ! colorlut location={cube} ! queue ! hipdownload ! filesink location={tmp_path}/out.raw").split(), tmp_path)

@@ -53,3 +53,23 @@ def test_bench_pool_filler_equals_the_generator():
     bench.fill_frames(torch, torch.device("cpu"), None, flat, "videotestsrc", W, H, first_frame=first)
     want, _ = frames.videotestsrc_smpte(W, H, first + n)
     assert np.array_equal(flat.numpy().reshape(n, H, W * 4), want[first:])
+
+
+@pytest.mark.parametrize("fmt,width,height", [("RGBA", 320, 240), ("RGBx", 641, 481), ("BGRx", 64, 48), ("xRGB", 96, 64), ("RGB", 100, 50),
+                                              ("BGR", 66, 34), ("ARGB", 1920, 1080)])
+def test_hiptestsrc_paints_the_first_videotestsrc_frame(fmt, width, height):
+    """hiptestsrc (the generator-free source of tools/bench_gst_pipeline.py) on system memory: byte-identical to the first frame
+    of `videotestsrc pattern=smpte` in every packed RGB format."""
+    tmp = tempfile.mkdtemp()
+    outs = []
+    for src in ("videotestsrc", "hiptestsrc"):
+        out = os.path.join(tmp, src + ".raw")
+        r = gst_env.run([gst_env.tool("gst-launch-1.0"), "-q", src, "num-buffers=1", "!",
+                         f"video/x-raw,format={fmt},width={width},height={height}", "!", "filesink", f"location={out}"], tmp, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:]
+        outs.append(np.fromfile(out, dtype=np.uint8))
+    assert outs[0].size == outs[1].size
+    bpp = 3 if fmt in ("RGB", "BGR") else 4
+    stride = (width * bpp + 3) // 4 * 4            # row padding (3-byte formats) is not picture content
+    rows = [o.reshape(height, stride)[:, :width * bpp] for o in outs]
+    assert np.array_equal(rows[0], rows[1])
