@@ -248,10 +248,15 @@ static GstCaps *hiptestsrc_fixate(GstBaseSrc *src, GstCaps *caps)
 {
     caps = gst_caps_make_writable(caps);
     GstStructure *s = gst_caps_get_structure(caps, 0);
-    gst_structure_fixate_field_string(s, "format", "RGBA");
-    gst_structure_fixate_field_nearest_int(s, "width", 320);
-    gst_structure_fixate_field_nearest_int(s, "height", 240);
-    gst_structure_fixate_field_nearest_fraction(s, "framerate", 30, 1);
+    // fields a downstream capsfilter left out are set, the others fixated to the nearest value (videotestsrc's defaults)
+    if (gst_structure_has_field(s, "format")) gst_structure_fixate_field_string(s, "format", "RGBA");
+    else gst_structure_set(s, "format", G_TYPE_STRING, "RGBA", NULL);
+    if (gst_structure_has_field(s, "width")) gst_structure_fixate_field_nearest_int(s, "width", 320);
+    else gst_structure_set(s, "width", G_TYPE_INT, 320, NULL);
+    if (gst_structure_has_field(s, "height")) gst_structure_fixate_field_nearest_int(s, "height", 240);
+    else gst_structure_set(s, "height", G_TYPE_INT, 240, NULL);
+    if (gst_structure_has_field(s, "framerate")) gst_structure_fixate_field_nearest_fraction(s, "framerate", 30, 1);
+    else gst_structure_set(s, "framerate", GST_TYPE_FRACTION, 30, 1, NULL);
     return GST_BASE_SRC_CLASS(gst_mi355_hip_test_src_parent_class)->fixate(src, caps);
 }
 
