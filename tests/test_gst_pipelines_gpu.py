@@ -393,6 +393,31 @@ def test_hiptestsrc_device_memory_source(gpu, tmp_path):
     assert np.array_equal(got.reshape(exp.shape), exp)
 
 
+def test_hiptestsrc_device_frames_are_refreshed_although_hsvfilter_works_in_place(gpu, tmp_path):
+    """Frames born in HBM: the source refreshes every recycled block from its device master (async device-to-device copy ordered
+    by the block's fence) while downstream elements on other streaming threads may still be reading the block's previous life;
+    hsvfilter then overwrites it in place.  40 frames at 1080p through three streaming threads: every one equals the oracle's
+    answer for THE pattern (a block handed out un-refreshed would come out filtered twice)."""
+    cube = tmp_path / "look.cube"
+    cube.write_text(cubes.analytic_3d(17))
+    w, h, n = 1920, 1080, 40
+    raw = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBx,width={w},height={h}", "in.raw")
+    r = gst_env.run([LAUNCH, "-q"] + (f"hiptestsrc num-buffers={n} ! video/x-raw(memory:HIPMemory),format=RGBx,width={w},height={h},framerate=30/1 ! "
+                    "hsvfilter hue-shift=45 ! queue max-size-buffers=2 ! hsvdetector hue-ref=120 hue-var=60 saturation-ref=0.6 saturation-var=0.4 "
+                    "value-ref=0.6 value-var=0.4 ! video/x-raw(memory:HIPMemory),format=RGBA ! queue max-size-buffers=2 ! "
+                    f"colorlut location={cube} ! hipdownload ! filesink location={tmp_path}/out.raw").split(), tmp_path)
+    assert r.returncode == 0, r.stdout
+    got = np.fromfile(f"{tmp_path}/out.raw", dtype=np.uint8).reshape(n, h, w * 4)
+    mid = raw.copy().reshape(h, w * 4)
+    orc.hsvfilter(mid, w, w * 4, "RGBx", (45.0, 1.0, 0.0, 1.0, 0.0))
+    det = np.empty_like(mid)
+    orc.hsvdetector(mid, w * 4, "RGBx", det, w * 4, "RGBA", w, (120.0, 60.0, 0.6, 0.4, 0.6, 0.4))
+    exp = np.empty_like(det)
+    assert orc.CubeLut(cube.read_text()).apply(det, w * 4, exp, w * 4, w, h, "RGBA") == 0
+    bad = [k for k in range(n) if not np.array_equal(got[k], exp)]
+    assert bad == []
+
+
 # ---- imagersoverlay (SURVEY 8f-4): PNG logo blended by the HIP kernel, positions per overlay/imp.rs:84-191
 def _logo_png(path, w=48, h=32):
     from PIL import Image
