@@ -16,6 +16,10 @@ def _cases():
         "analytic9": cubes.analytic_3d(9),
         "analytic21": cubes.analytic_3d(21),   # largest cube that is staged in LDS
         "analytic33": cubes.analytic_3d(33),   # BASELINE config 3 (L2-resident)
+        "analytic65": cubes.analytic_3d(65),   # largest cell-packed cube: the 32 x 16 block shape of the window kernel
+        "analytic3": cubes.analytic_3d(3),     # smallest cube the window kernel takes (window = the whole cube)
+        # 3-D with a DOMAIN: scaled / offset coordinates, channels that never reach the upper / lower cells
+        "domain33": cubes.analytic_3d(33).replace("DOMAIN_MIN 0.0 0.0 0.0", "DOMAIN_MIN -0.25 0.0 0.1").replace("DOMAIN_MAX 1.0 1.0 1.0", "DOMAIN_MAX 1.5 1.0 0.9"),
         "curve1d_256": cubes.curve_1d(256),
         "curve1d_2": cubes.curve_1d(2),
         "curve1d_4096": cubes.curve_1d(4096),
@@ -60,7 +64,8 @@ def test_colorlut_random_frames(gpu, luts, name, fmt, placement):
         gpu.lib().mvfx_thread_set_options(gpu.options(placement=0).word)
 
 
-@pytest.mark.parametrize("name", ["analytic33", "analytic21", "identity17", "curve1d_256", "nan_nodes", "nan_domain"])
+@pytest.mark.parametrize("name", ["analytic33", "analytic21", "identity17", "curve1d_256", "nan_nodes", "nan_domain", "analytic65", "analytic9",
+                                  "analytic3", "domain33"])
 def test_colorlut_exhaustive_rgba8(gpu, luts, name):
     """all 2^24 RGB triples through the LUT (RGBA8), device entry point, automatic kernel choice"""
     dev, o = luts[name]
