@@ -29,7 +29,7 @@ def pull_all(sink):
     """[(caps string, bytes)] of every sample until EOS."""
     out = []
     while True:
-        s = sink.emit("pull-sample")
+        s = sink.emit("try-pull-sample", 20 * Gst.SECOND)   # None at EOS -- and after 20 s without a sample instead of hanging
         if s is None:
             return out
         b = s.get_buffer()
@@ -339,6 +339,54 @@ def videocompare_three_pads(_arg):
     return {"first": first, "second": second, "sink_pads_after_release": sorted(p.get_name() for p in vc2.sinkpads)}
 
 
+def colorlut_relocation(chain):
+    """`location` is mutable in READY (colorlut/imp.rs:118-140): a pipeline taken to READY with one file configured, then given another
+    file (another size: every device table differs) and played -- it must grade with the second LUT; a control run keeps the first."""
+    from tests import cubes
+    w, h, n = 160, 120, 3
+    tmp = os.environ.get("MVFX_WORKER_TMP", "/tmp")
+    texts = [cubes.analytic_3d(17), cubes.identity_3d(33).replace("LUT_3D_SIZE 33", "LUT_3D_SIZE 33\nDOMAIN_MIN 0 0 0\nDOMAIN_MAX 1 1 1")]
+    paths = []
+    for k, t in enumerate(texts):
+        paths.append(os.path.join(tmp, f"lut{k}.cube"))
+        with open(paths[-1], "w") as f:
+            f.write(t)
+    pre, post = ("hipupload ! ", "hipdownload ! ") if chain == "hip" else ("", "")
+    desc = (f"videotestsrc num-buffers={n} ! video/x-raw,format=RGBA,width={w},height={h} ! {pre}colorlut name=l location={paths[0]} ! "
+            f"{post}video/x-raw,format=RGBA ! appsink name=sink sync=false")
+    src, _ = frames.videotestsrc_smpte(w, h, 1)      # the bars; the snow differs from frame to frame: left out of the comparison
+    runs = []
+    for k in range(2):
+        pipe = Gst.parse_launch(desc)
+        lut, sink = pipe.get_by_name("l"), pipe.get_by_name("sink")
+        if k == 1:   # READY with the first file configured, then the other one
+            pipe.set_state(Gst.State.READY)
+            pipe.get_state(5 * Gst.SECOND)
+            lut.set_property("location", paths[1])
+        pipe.set_state(Gst.State.PLAYING)
+        got = pull_all(sink)
+        pipe.set_state(Gst.State.NULL)
+        o = orc.CubeLut(texts[k])
+        x0, y0 = frames.vts_snow_geometry(w, h)
+        bad = []
+        for i, (_, data) in enumerate(got):
+            out = np.frombuffer(data, dtype=np.uint8).reshape(h, w * 4)
+            want = np.empty_like(src[0])
+            assert o.apply(src[0], w * 4, want, w * 4, w, h, "RGBA") == 0
+            a = out.reshape(h, w, 4).copy()
+            b = want.reshape(h, w, 4).copy()
+            a[y0:, x0:] = 0
+            b[y0:, x0:] = 0
+            if not np.array_equal(a, b):
+                bad.append(i)
+        runs.append({"frames": len(got), "mismatches": bad})
+    # the two LUTs must actually differ on the bars, or the test proves nothing
+    w0, w1 = np.empty_like(src[0]), np.empty_like(src[0])
+    orc.CubeLut(texts[0]).apply(src[0], w * 4, w0, w * 4, w, h, "RGBA")
+    orc.CubeLut(texts[1]).apply(src[0], w * 4, w1, w * 4, w, h, "RGBA")
+    return {"runs": runs, "luts_differ": bool(np.count_nonzero(w0 != w1) > 1000)}
+
+
 def state_cycles(n_cycles):
     """NULL -> PLAYING -> EOS -> NULL over and over on the device-memory chain: nothing may accumulate on the device (pools and
     allocator freelists are released in stop() / trimmed)."""
@@ -369,6 +417,7 @@ def state_cycles(n_cycles):
 SCENARIOS = {"hsvfilter_property_change": hsvfilter_property_change, "renegotiate": renegotiate,
              "rounded_radius_change": rounded_radius_change, "hsvdetector_property_change": hsvdetector_property_change,
              "overlay_property_change": overlay_property_change, "videocompare_three_pads": videocompare_three_pads,
+             "colorlut_relocation": colorlut_relocation,
              "state_cycles": lambda n: state_cycles(int(n))}
 
 if __name__ == "__main__":

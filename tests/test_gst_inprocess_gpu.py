@@ -37,6 +37,14 @@ def test_imagersoverlay_properties_changed_while_playing(chain):
     assert r["mismatches"] == []
 
 
+@pytest.mark.parametrize("chain", ["", "hip"])
+def test_colorlut_location_changed_in_ready_between_two_runs(chain):
+    r = gst_inprocess.run("colorlut_relocation", chain, timeout=90)
+    assert r["luts_differ"]
+    assert [x["frames"] for x in r["runs"]] == [3, 3]
+    assert [x["mismatches"] for x in r["runs"]] == [[], []]
+
+
 def test_videocompare_built_with_request_pads_reports_every_other_pad():
     r = gst_inprocess.run("videocompare_three_pads")
     first = [m for m in r["first"] if isinstance(m, dict)]
