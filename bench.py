@@ -554,14 +554,22 @@ def config_main(args):
             planes.append((a, b))
         fr = [vfx.make_frame(rgba[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(pool)]
 
+        # --element-streams 2: the two elements on their own HIP streams, as with a `queue` between them (two streaming threads:
+        # frame k's colordetect overlaps frame k+1's compose); 1: both on one stream, one after the other (one streaming thread)
+        second = torch.cuda.Stream(device=dev) if args.element_streams == 2 else None
+        sptr2 = ctypes.c_void_p(second.cuda_stream) if second is not None else sptr
+
         def step(i):
             k = i % pool
             vfx.check(lib.mvfx_roundedcorners_compose_a420(ctypes.byref(planes[k][0]), ctypes.c_void_p(mask.data_ptr()), W,
                                                            ctypes.byref(planes[k][1]), sptr))
             vfx.check(lib.mvfx_colordetect_histogram(ctypes.byref(fr[k]), 10, 0, vfx.ALL_SAMPLES, ctypes.c_void_p(hist.data_ptr()),
-                                                     ctypes.c_void_p(hist.data_ptr() + 32768 * 4), sptr))
+                                                     ctypes.c_void_p(hist.data_ptr() + 32768 * 4), sptr2))
         frames_per_step = 1
-        bytes_per_step, name = W * H * 4 + FRAME_BYTES, "roundedcorners I420->A420 compose (r=100) + colordetect histogram (quality=10), one 3840x2160 stream per GPU"
+        bytes_per_step = W * H * 4 + FRAME_BYTES
+        name = ("roundedcorners I420->A420 compose (r=100) + colordetect histogram (quality=10), one 3840x2160 stream per GPU, "
+                + ("both elements on one HIP stream (one streaming thread)" if second is None else
+                   "the two elements on their own HIP streams (a queue between them: two streaming threads)"))
 
     settle(step, args.settle_seconds, w.sync)
     for i in range(args.warmup):
@@ -779,6 +787,9 @@ def main():
                          "videotestsrc-smpte-like bars (best case)")
     ap.add_argument("--typed-loads", type=int, default=1, choices=[0, 1],
                     help="hsvfilter: u8/255 by typed buffer loads (texture-unit UNORM conversion) instead of VALU")
+    ap.add_argument("--element-streams", type=int, default=1, choices=[1, 2],
+                    help="videofx workload: 1 = roundedcorners and colordetect on one HIP stream (one streaming thread), 2 = on their "
+                         "own streams (a queue between the elements)")
     ap.add_argument("--pairs-in-flight", type=int, default=2,
                     help="videocompare blockhash on one GPU: pairs whose host round trip overlaps the next pair's kernel (1 = the "
                          "synchronous mvfx_videocompare_distance call the element makes per aggregate)")

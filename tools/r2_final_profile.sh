@@ -9,6 +9,7 @@ cd $REPO
 python bench.py --steps 20 --warmup 5 > $O/bench_headline.json 2> $O/bench_headline.err
 python bench.py --steps 20 --warmup 5 --launch-model streams --no-cpu-baseline > $O/bench_headline_streams.json 2>> $O/bench_headline.err
 for wl in hsv1080p videofx videocompare; do python bench.py --workload $wl --steps 200 --warmup 20 2>/dev/null >> $O/bench_configs.jsonl; done
+python bench.py --workload videofx --element-streams 2 --steps 200 --warmup 20 2>/dev/null >> $O/bench_configs.jsonl
 python bench.py --workload videocompare --hash-algo dssim --steps 20 --warmup 3 2>/dev/null >> $O/bench_configs.jsonl
 for c in natural random smpte; do python bench.py --workload colorlut --content $c --steps 40 --warmup 10 2>/dev/null >> $O/bench_configs.jsonl; done
 cd /tmp && export TMPDIR=/tmp
