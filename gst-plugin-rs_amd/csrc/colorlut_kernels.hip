@@ -710,9 +710,11 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
         }
         if (row == 0) {
             // anchor: the cell of the block's centre pixel (64 x 16: lane 40 = rows 8..11, columns 32..35, its first row)
-            const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)ix[0], kCentreLane),
-                           cy = (uint32_t)__builtin_amdgcn_readlane((int)iy[0], kCentreLane),
-                           cz = (uint32_t)__builtin_amdgcn_readlane((int)iz[0], kCentreLane);
+            // (a block that sticks out of the frame on the right or at the bottom may have its centre outside: lane 0 then)
+            const uint32_t centre = __builtin_amdgcn_readlane((int)valid, kCentreLane) ? kCentreLane : 0u;
+            const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)ix[0], centre),
+                           cy = (uint32_t)__builtin_amdgcn_readlane((int)iy[0], centre),
+                           cz = (uint32_t)__builtin_amdgcn_readlane((int)iz[0], centre);
             tile_load_window(nbr[wave], lane, p, rel, cx, cy, cz, ax, ay, az);
         }
 #pragma unroll
