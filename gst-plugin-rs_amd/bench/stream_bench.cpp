@@ -112,4 +112,53 @@ int mvfxbench_hsvfilter_streams(int device, uint32_t n_threads, uint32_t warmup,
                                                seconds_out, thread_seconds);
 }
 
+// The same launch model for colorlut: thread t grades in_frames[t*frames_per_thread + i] into out_frames[...] with the shared LUT
+// handle, one mvfx_colorlut_transform_frame per frame on its own stream.
+int mvfxbench_colorlut_streams(int device, uint32_t n_threads, uint32_t warmup, uint32_t launches, uint32_t reps, mvfx_cube_lut *lut,
+                               const mvfx_frame *in_frames, const mvfx_frame *out_frames, uint32_t frames_per_thread, uint32_t options,
+                               double *seconds_out, double *thread_seconds)
+{
+    if (!lut || !in_frames || !out_frames || !seconds_out || n_threads == 0 || frames_per_thread == 0 || reps == 0)
+        return MVFX_ERR_INVALID_ARGUMENT;
+    SpinBarrier ready(n_threads + 1), go(n_threads + 1), done(n_threads + 1);
+    std::vector<int> status(n_threads, MVFX_OK);
+    std::vector<double> span(n_threads, 0.0);
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < n_threads; t++) {
+        pool.emplace_back([&, t] {
+            int rc = mvfx_set_device(device);
+            if (rc == MVFX_OK) rc = mvfx_thread_set_options(options);
+            mvfx_stream st = mvfx_thread_stream();
+            const mvfx_frame *in = in_frames + (size_t)t * frames_per_thread, *out = out_frames + (size_t)t * frames_per_thread;
+            for (uint32_t i = 0; i < warmup && rc == MVFX_OK; i++)
+                rc = mvfx_colorlut_transform_frame(lut, &in[i % frames_per_thread], &out[i % frames_per_thread], st);
+            if (rc == MVFX_OK) rc = mvfx_stream_synchronize(st);
+            ready.wait();
+            for (uint32_t r = 0; r < reps; r++) {
+                go.wait();
+                const double t0 = now_s();
+                for (uint32_t i = 0; i < launches && rc == MVFX_OK; i++)
+                    rc = mvfx_colorlut_transform_frame(lut, &in[(warmup + i) % frames_per_thread], &out[(warmup + i) % frames_per_thread], st);
+                if (rc == MVFX_OK) rc = mvfx_stream_synchronize(st);
+                span[t] = now_s() - t0;
+                done.wait();
+            }
+            status[t] = rc;
+        });
+    }
+    ready.wait();
+    for (uint32_t r = 0; r < reps; r++) {
+        const double t0 = now_s();
+        go.wait();
+        done.wait();
+        seconds_out[r] = now_s() - t0;
+    }
+    for (std::thread &th : pool) th.join();
+    for (uint32_t t = 0; t < n_threads; t++) {
+        if (thread_seconds) thread_seconds[t] = span[t];
+        if (status[t] != MVFX_OK) return status[t];
+    }
+    return MVFX_OK;
+}
+
 } // extern "C"
