@@ -659,7 +659,10 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
                                                                uint32_t in_stride, uint32_t out_stride, LutParams p)
 {
     constexpr uint32_t kBpp = WIDE ? 8 : 4;
-    constexpr uint32_t kAcross = ACROSS, kTileW = 4 * ACROSS, kDown = 64 / ACROSS, kTileH = kDown * ROWS,
+    // pixels per lane and row: one 16-byte load / store per lane, contiguous over the lanes (RGBA64: two pixels; with four -- two
+    // instructions whose lanes sit 32 bytes apart -- a 4K natural-like RGBA64 frame took 32.4 us instead of 30.0 us)
+    constexpr int PX = WIDE ? 2 : 4;
+    constexpr uint32_t kAcross = ACROSS, kTileW = PX * ACROSS, kDown = 64 / ACROSS, kTileH = kDown * ROWS,
                        kCentreLane = (kDown / 2) * ACROSS + ACROSS / 2;
     __shared__ float4 nbr[kBlock / 64][kTileWaveLdsFloat4];
     __shared__ uint2 coord[WIDE ? 1 : kCoordEntries]; // {cell index, fraction bits} per channel and byte value
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
         for (uint32_t i = 0; i < kCoordEntries / kBlock; i++) coord[i * kBlock + threadIdx.x] = src[i * kBlock + threadIdx.x];
     }
     // workgroup = four horizontally adjacent tiles (grid x), one tile row per grid y
-    const uint32_t x = (blockIdx.x * (kBlock / 64) + wave) * kTileW + (lane % kAcross) * 4, y0 = blockIdx.y * kTileH + (lane / kAcross) * ROWS;
+    const uint32_t x = (blockIdx.x * (kBlock / 64) + wave) * kTileW + (lane % kAcross) * PX, y0 = blockIdx.y * kTileH + (lane / kAcross) * ROWS;
     const uint8_t *in = in_fb.base[blockIdx.z];
     uint8_t *out = out_fb.base[blockIdx.z];
     const TileRel rel = tile_rel(lane, p);
@@ -679,22 +682,19 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
 #pragma unroll
     for (int row = 0; row < ROWS; row++) {
         const uint32_t y = y0 + row;
-        const bool valid = x < width && y < height; // width % 4 == 0 (launcher): a lane's four pixels are all inside or all outside
-        uint4 v = make_uint4(0, 0, 0, 0), v2 = make_uint4(0, 0, 0, 0);
-        if (valid) {
-            v = *reinterpret_cast<const uint4 *>(in + (y * in_stride + x * kBpp));
-            if constexpr (WIDE) v2 = *reinterpret_cast<const uint4 *>(in + (y * in_stride + x * kBpp + 16));
-        }
+        const bool valid = x < width && y < height; // width % 4 == 0 (launcher): a lane's pixels are all inside or all outside
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (valid) v = *reinterpret_cast<const uint4 *>(in + (y * in_stride + x * kBpp));
         if (row == 0) {
             if constexpr (!WIDE) __syncthreads(); // coordinate table complete
         }
-        uint32_t px[4] = {v.x, v.y, v.z, v.w};      // RGBA8: the pixels; RGBA64: low words (r | g << 16) of the pixels
+        uint32_t px[4] = {v.x, v.y, v.z, v.w};      // RGBA8: the four pixels; RGBA64: low words (r | g << 16) of the two pixels
         uint32_t px_hi[4] = {0, 0, 0, 0};           // RGBA64: high words (b | a << 16)
-        if constexpr (WIDE) { px[0] = v.x; px_hi[0] = v.y; px[1] = v.z; px_hi[1] = v.w; px[2] = v2.x; px_hi[2] = v2.y; px[3] = v2.z; px_hi[3] = v2.w; }
+        if constexpr (WIDE) { px[0] = v.x; px_hi[0] = v.y; px[1] = v.z; px_hi[1] = v.w; }
         uint32_t ix[4], iy[4], iz[4];
         float fx[4], fy[4], fz[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < PX; j++) {
             if constexpr (WIDE) {
                 uint32_t rv = px[j] & 0xffffu, gv = px[j] >> 16, bv = px_hi[j] & 0xffffu;
                 if constexpr (!LE) { rv = bswap16(rv); gv = bswap16(gv); bv = bswap16(bv); }
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
             tile_load_window(nbr[wave], lane, p, rel, cx, cy, cz, ax, ay, az);
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < PX; j++) {
             float4 c[8];
             tile_cell((lds_bytes_t)&nbr[0][0], wave_lds_bytes, p, ix[j], iy[j], iz[j], ax, ay, az, c);
             float r, g, b;
@@ -741,7 +741,6 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
         if (valid) {
             if constexpr (WIDE) {
                 *reinterpret_cast<uint4 *>(out + (y * out_stride + x * kBpp)) = make_uint4(px[0], px_hi[0], px[1], px_hi[1]);
-                *reinterpret_cast<uint4 *>(out + (y * out_stride + x * kBpp + 16)) = make_uint4(px[2], px_hi[2], px[3], px_hi[3]);
             } else {
                 *reinterpret_cast<uint4 *>(out + (y * out_stride + x * 4)) = make_uint4(px[0], px[1], px[2], px[3]);
             }
@@ -1117,8 +1116,8 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
 #define MVFX_TK(WIDE, LE, A, R) hipLaunchKernelGGL((colorlut_tile_kernel<WIDE, LE, A, R>), tgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p)
         if (wide_block) MVFX_TK(false, true, 16, 4);
         else if (!wide) MVFX_TK(false, true, 8, 2);
-        else if (le) MVFX_TK(true, true, 8, 2);
-        else MVFX_TK(true, false, 8, 2);
+        else if (le) MVFX_TK(true, true, 16, 4);   // RGBA64: 16 lanes x 2 pixels = the same 32 x 16 block
+        else MVFX_TK(true, false, 16, 4);
 #undef MVFX_TK
         MVFX_HIP_TRY(hipGetLastError());
         return MVFX_OK;
