@@ -323,6 +323,9 @@ def main():
             vfx.check(lib.mvfx_convert_rgba_to_i420(ctypes.byref(fa[k]), ctypes.byref(fo[k]), 0, sptr))
         ms = timeit(three_h, iters=300)
         report("hsvfilter on I420 4K random, three launches through an RGBA frame", ms, W * H * 3, 1)
+        ds = vfx.HsvDetectorSettings(120.0, 40.0, 0.6, 0.4, 0.6, 0.4)
+        ms = timeit(lambda i=0: vfx.check(lib.mvfx_hsvdetector_transform_i420(ctypes.byref(fri[i % POOL]), ctypes.byref(fa[i % POOL]), ctypes.byref(ds), 0, sptr)), iters=300)
+        report("hsvdetector on I420 4K random -> RGBA, fused videoconvert!hsvdetector (one kernel)", ms, W * H * 11 // 2, 1)
 
     # d2d copy ceiling measured on this box (SURVEY 8d asks for it next to the 8 TB/s spec)
     if want("copy"):
