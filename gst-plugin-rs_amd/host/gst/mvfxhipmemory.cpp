@@ -245,6 +245,8 @@ GstAllocator *mvfx_hip_allocator_get(void)
     if (g_once_init_enter(&once)) {
         singleton = (GstAllocator *)g_object_new(mvfx_hip_allocator_get_type(), NULL);
         gst_object_ref_sink(singleton);
+        // one allocator for the life of the process, like GStreamer's own system-memory allocator: tell the leaks tracer
+        GST_OBJECT_FLAG_SET(singleton, GST_OBJECT_FLAG_MAY_BE_LEAKED);
         g_once_init_leave(&once, 1);
     }
     return (GstAllocator *)gst_object_ref(singleton);
