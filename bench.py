@@ -28,8 +28,15 @@ Inputs are resident in HBM before the timed region.  The frame pool is much larg
 and every step touches a different batch, so reads come from HBM.
 
 The JSON line carries `roofline` (algorithmic bytes per launch / average launch duration from HIP events on the
-launch stream, plus the d2d-copy ceiling measured in the same run) and, at N=1, `cpu_baseline` (the oracle's loop on
-one host thread -- what the reference does on its one streaming thread -- and on nproc threads, bounded sample).
+launch stream = `frac` / `frac_kernel`; the same bytes over the wall clock `value` is made of = `frac_wall`; p10/p50/p90 of
+the per-launch time; HBM traffic per launch from the committed rocprofv3 PMC passes; the RMW-probe ceiling measured in the
+same run) and, at N=1, `cpu_baseline` (the oracle's loop on one host thread -- what the reference does on its one streaming
+thread -- and on nproc threads, bounded sample).
+
+At N=1 the same run then measures BASELINE configs 2-5 (`config.other_configs`: hsv1080p, colorlut 33^3 on natural-like and
+uniform-random frames, videofx, videocompare blockhash and dssim), each with its own roofline fractions, per-step
+percentiles, committed PMC traffic and a bounded CPU-port baseline; at N>1 the band-sharded videocompare leg with its RCCL
+all-reduce.  `--workload <name>` prints one of them as its own line (what tools/r3_traffic.sh profiles).
 """
 import argparse
 import ctypes
@@ -181,6 +188,19 @@ class Worker:
         elapsed = time.perf_counter() - t0
         return elapsed, (ev0.elapsed_time(ev1) / max(steps, 1) if events else None)
 
+    def event_times(self, step, steps, first_index=0):
+        """`steps` steps with a HIP event on the launch stream between every two: per-step microseconds (launch + whatever
+        the step leaves between two launches), for the p10 / p50 / p90 of the line."""
+        torch = self.torch
+        self.sync()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        evs[0].record(self.stream)
+        for i in range(steps):
+            step(first_index + i)
+            evs[i + 1].record(self.stream)
+        self.sync()
+        return [evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(steps)]
+
     def finish(self):
         if self.world > 1:
             self.dist.destroy_process_group()
@@ -205,28 +225,40 @@ def settle(step, seconds, sync, fixed_steps=None):
     return n
 
 
-def measured_copy_ceiling(w):
-    """Device-to-device copy of 1 GiB (2 GiB of HBM traffic) with torch, same run, same clocks: the practical HBM ceiling
-    SURVEY 8d asks to quote beside the 8 TB/s spec."""
-    torch = w.torch
-    n = 1 << 30
-    a = torch.empty(n, dtype=torch.uint8, device=w.dev)
-    b = torch.empty(n, dtype=torch.uint8, device=w.dev)
-    a.random_(0, 256)
-    for _ in range(5):
-        b.copy_(a)
-    w.sync()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
-    ev0.record(w.stream)
-    for _ in range(reps):
-        b.copy_(a)
-    ev1.record(w.stream)
-    w.sync()
-    return 2.0 * n * reps / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+def percentiles(us):
+    """p10 / p50 / p90 / mean of a list of per-step microseconds (median and p10/p90 over >= 200 iterations)."""
+    v = sorted(us)
+    n = len(v)
+    if n == 0:
+        return None
+    pick = lambda q: v[min(n - 1, max(0, int(round(q * (n - 1)))))]
+    return {"n": n, "p10": pick(0.10), "p50": pick(0.50), "p90": pick(0.90), "mean": sum(v) / n, "unit": "us"}
 
 
-# ------------------------------------------------------------------------------------------------ CPU baseline
+def bench_harness():
+    """libmvfxbench.so (measurement only: host threads of the per-stream launch model, the RMW ceiling probe)."""
+    hb = ctypes.CDLL(os.path.join(ROOT, "gst-plugin-rs_amd", "libmvfxbench.so"))  # raises when build() has not run
+    hb.mvfxbench_rmw_ceiling.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                         ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    return hb
+
+
+def measured_rmw_ceiling(w, base_ptr, bytes_per_launch, regions):
+    """The practical HBM ceiling SURVEY 8d asks to quote beside the 8 TB/s spec, measured in THIS run on the same resident
+    pool: the memory shape of the headline kernel with trivial arithmetic (gst-plugin-rs_amd/bench/probe_rmw.hip: one
+    16-byte non-temporal load + store per lane, in place; the out-of-place twin for the filters that write another frame)."""
+    hb = bench_harness()
+    out = {}
+    for mode, key in ((0, "in_place_nt"), (1, "in_place_cached"), (2, "out_of_place_nt")):
+        gbs, us = ctypes.c_double(), ctypes.c_double()
+        n = 4 * regions  # every region XOR-ed an even number of times: the pool is left as it was
+        rc = hb.mvfxbench_rmw_ceiling(ctypes.c_void_p(base_ptr), bytes_per_launch, regions, n, n, mode, w.sptr,
+                                      ctypes.byref(gbs), ctypes.byref(us))
+        if rc != 0:
+            raise RuntimeError(f"mvfxbench_rmw_ceiling status {rc}")
+        out[key] = {"GBs": gbs.value, "us_per_launch": us.value}
+    return out
+
 
 # ------------------------------------------------------------------------------------------------ frame contents
 
@@ -286,89 +318,546 @@ def fill_frames(torch, dev, gen, flat, kind, W, H, first_frame=0):
         torch.cuda.synchronize()
 
 
-def cpu_baseline(seconds: float, content: str = "videotestsrc"):
-    """Oracle (port of hsvfilter/imp.rs:76-120, gcc -O3 -ffp-contract=off like profile.release) on the GPU box's host cores:
-    one thread -- what the reference does, its transform_frame_ip runs on ONE streaming thread per element -- and
-    nproc threads each filtering its own stream.  8 distinct frames of the same content as the GPU legs rotate so
-    the 33 MB input is not cache resident.  Bounded: ~seconds per leg."""
+# ------------------------------------------------------------------------------------------------ CPU baselines
+# The reference is Rust and cannot be built here or on the GPU box (no rustc): the timed CPU path is oracle/*.c, the
+# statement-by-statement port of the reference loops (gcc -O3 -ffp-contract=off like its profile.release), "kind": "port".
+# Only this leg of bench.py touches oracle/.  One thread = what the reference does (its transform_frame runs on ONE streaming
+# thread per element); nproc threads = that many independent streams.  Bounded: ~`seconds` per leg.
+
+def _nproc():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+def cpu_rate(make_unit, seconds, n_threads):
+    """make_unit(t) -> (prepare, unit): prepare() is untimed (fresh input for in-place loops), unit() is one unit of work,
+    timed; ctypes releases the GIL for the oracle calls.  Returns (units/s summed over the threads, units, longest span)."""
     import threading
+    counts = [0] * n_threads
+    spans = [0.0] * n_threads
+    go = threading.Event()
+
+    def body(t):
+        prepare, unit = make_unit(t)
+        prepare()
+        unit()  # warm: page faults, code
+        go.wait()
+        n, dt = 0, 0.0
+        while dt < seconds:
+            prepare()
+            t1 = time.perf_counter()
+            unit()
+            dt += time.perf_counter() - t1
+            n += 1
+        counts[t], spans[t] = n, dt
+
+    ths = [threading.Thread(target=body, args=(t,)) for t in range(n_threads)]
+    for th in ths:
+        th.start()
+    go.set()
+    for th in ths:
+        th.join()
+    return sum(c / s for c, s in zip(counts, spans) if s > 0), sum(counts), max(spans)
+
+
+def cpu_baseline_of(make_unit, seconds, unit, what, scale=1.0, scale_note=None):
+    nproc = _nproc()
+    one, one_n, one_dt = cpu_rate(make_unit, seconds, 1)
+    if nproc > 1:
+        allr, all_n, all_dt = cpu_rate(make_unit, seconds, nproc)
+    else:
+        allr, all_n, all_dt = one, one_n, one_dt
+    out = {"value": one * scale, "unit": unit, "cores": 1, "kind": "port",
+           "sample": f"{one_n} x {what}, 1 thread, {one_dt:.1f} s" + (f"; {scale_note}" if scale_note else ""),
+           "all_cores": {"value": allr * scale, "unit": unit, "cores": nproc, "nproc": nproc,
+                         "sample": f"{all_n} x the same unit on {nproc} threads (independent streams), {all_dt:.1f} s per thread"}}
+    return out
+
+
+def cpu_baseline_hsvfilter(seconds, content="videotestsrc"):
+    """hsvfilter/imp.rs:76-120 on 3840x2160 RGBA: 8 distinct frames of the same content as the GPU legs rotate so the 33 MB
+    input is not cache resident; every thread filters a fresh copy (in-place loop), the copy is not timed."""
     import numpy as np
     from tests import frames
     from tests import oracle_binding as orc
-    nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     distinct = 8
     if content == "videotestsrc":
         vts, _ = frames.videotestsrc_smpte(W4K, H4K, distinct)
         src = [vts[k] for k in range(distinct)]
-        what = "videotestsrc pattern=smpte, 8 consecutive frames rotating"
+        what = "3840x2160 RGBA frame (videotestsrc pattern=smpte, 8 consecutive frames rotating)"
     else:
         src = [frames.random_frame(0x5EED0001 + k, W4K, H4K) for k in range(distinct)]
-        what = "uniform random, 8 distinct frames rotating, seeds 0x5EED0001..8"
+        what = "3840x2160 RGBA frame (uniform random, 8 distinct frames rotating, seeds 0x5EED0001..8)"
 
-    def run(n_threads, budget):
-        counts = [0] * n_threads
-        spans = [0.0] * n_threads
-        go = threading.Event()
+    def make_unit(t):
+        work = src[0].copy()
+        k = [t]
 
-        def body(t):
-            work = [s.copy() for s in src[:2]]  # this thread's private pair of destination buffers
-            orc.hsvfilter(work[0], W4K, W4K * 4, "RGBA", SETTINGS)  # warm (page faults, code)
-            go.wait()
-            n, dt = 0, 0.0
-            while dt < budget:
-                buf = work[n & 1]
-                np.copyto(buf, src[(t + n) % distinct])  # fresh input each time; the copy is not timed
-                t1 = time.perf_counter()
-                orc.hsvfilter(buf, W4K, W4K * 4, "RGBA", SETTINGS)  # ctypes releases the GIL for the call
-                dt += time.perf_counter() - t1
-                n += 1
-            counts[t], spans[t] = n, dt
-
-        ths = [threading.Thread(target=body, args=(t,)) for t in range(n_threads)]
-        for th in ths:
-            th.start()
-        go.set()
-        for th in ths:
-            th.join()
-        return sum(c / s for c, s in zip(counts, spans)), sum(counts), max(spans)
-
-    one_fps, one_n, one_dt = run(1, seconds)
-    all_fps, all_n, all_dt = run(nproc, seconds) if nproc > 1 else (one_fps, one_n, one_dt)
-    return {"value": one_fps, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{one_n} frames of 3840x2160 RGBA ({what}), "
-                      f"oracle/hsv_oracle.c gcc -O3 -ffp-contract=off, 1 thread, {one_dt:.1f} s",
-            "all_cores": {"value": all_fps, "unit": "frames/s", "cores": nproc, "nproc": nproc,
-                          "sample": f"{all_n} frames, {nproc} threads x own stream of frames, {all_dt:.1f} s per thread"}}
+        def prepare():
+            np.copyto(work, src[k[0] % distinct])
+            k[0] += 1
+        return prepare, lambda: orc.hsvfilter(work, W4K, W4K * 4, "RGBA", SETTINGS)
+    return cpu_baseline_of(make_unit, seconds, "frames/s", what + ", oracle/hsv_oracle.c orc_hsvfilter_transform_frame_ip, gcc -O3 -ffp-contract=off")
 
 
-# ------------------------------------------------------------------------------------------------ config 5
+def cpu_baseline_hsv1080p(seconds, host_frames):
+    """config 2: hsvfilter in place (hsvfilter/imp.rs:76-120) then hsvdetector RGBx -> RGBA (hsvdetector/imp.rs:100-160)
+    on one 1920x1080 frame = one unit."""
+    import numpy as np
+    from tests import oracle_binding as orc
+    W, H = 1920, 1080
+
+    def make_unit(t):
+        work = host_frames[0].copy()
+        out = np.empty_like(work)
+        k = [t]
+
+        def prepare():
+            np.copyto(work, host_frames[k[0] % len(host_frames)])
+            k[0] += 1
+
+        def unit():
+            orc.hsvfilter(work, W, W * 4, "RGBx", SETTINGS)
+            orc.hsvdetector(work, W * 4, "RGBx", out, W * 4, "RGBA", W, DETECT_SETTINGS)
+        return prepare, unit
+    return cpu_baseline_of(make_unit, seconds, "frames/s", "1920x1080 RGBx frame through orc_hsvfilter_transform_frame_ip + "
+                           "orc_hsvdetector_transform_frame (oracle/hsv_oracle.c)")
+
+
+def cpu_baseline_colorlut(seconds, host_frames, cube_text, content):
+    """config 3: transform_rgba_3d (colorlut/imp.rs:267-294, 431-535) on one 3840x2160 RGBA frame = one unit."""
+    import numpy as np
+    from tests import oracle_binding as orc
+    lut = orc.CubeLut(cube_text)
+
+    def make_unit(t):
+        out = np.empty_like(host_frames[0])
+        k = [t]
+
+        def unit():
+            src = host_frames[k[0] % len(host_frames)]
+            k[0] += 1
+            lut.apply(src, W4K * 4, out, W4K * 4, W4K, H4K, "RGBA")
+        return (lambda: None), unit
+    return cpu_baseline_of(make_unit, seconds, "frames/s", f"3840x2160 RGBA frame ({content}) through orc_colorlut_transform_frame, "
+                           "33^3 cube (oracle/colorlut_oracle.c)")
+
+
+def cpu_baseline_videofx(seconds, host_rgba):
+    """config 4 per frame in the reference: roundedcorners appends the shared alpha GstMemory (border/imp.rs:527-557, O(1), no
+    pixel work) and colordetect runs color_thief::get_palette on the whole plane (colordetect/imp.rs:57-86) = one unit."""
+    from tests import oracle_binding as orc
+
+    def make_unit(t):
+        k = [t]
+
+        def unit():
+            f = host_rgba[k[0] % len(host_rgba)]
+            k[0] += 1
+            orc.colordetect_palette(f, "RGBA", 10, 2)
+        return (lambda: None), unit
+    return cpu_baseline_of(make_unit, seconds, "frames/s", "3840x2160 RGBA frame through orc_colordetect_palette quality=10 max-colors=2 "
+                           "(histogram + median cut, oracle/videofx_oracle.c); the reference's roundedcorners does no per-frame pixel work")
+
+
+def cpu_baseline_blockhash(seconds, host_pair):
+    """config 5, hash-algo=blockhash: HasherEngine::hash_image x2 + compare (hashed_image.rs:24-79) on one 7680x4320 pair."""
+    from tests import oracle_binding as orc
+    W, H = 7680, 4320
+
+    def make_unit(t):
+        def unit():
+            _, ha = orc.blockhash(host_pair[0], W, H, W * 4, "RGBA")
+            _, hb = orc.blockhash(host_pair[1], W, H, W * 4, "RGBA")
+            orc.hamming(ha, hb)
+        return (lambda: None), unit
+    return cpu_baseline_of(make_unit, seconds, "pairs/s", "7680x4320 RGBA pair through orc_blockhash x2 + orc_hamming64 (oracle/videofx_oracle.c)")
+
+
+def cpu_baseline_dssim(seconds, host_pair_crop, cw, ch):
+    """config 5, hash-algo=dssim: one 8K pair is ~18 s of one host thread, so the bounded sample is a cw x ch crop of the same
+    pair; the cost of every pyramid level is linear in the pixel count, so pairs/s is scaled by the pixel ratio."""
+    from tests import oracle_binding as orc
+    scale = (cw * ch) / (7680.0 * 4320.0)
+
+    def make_unit(t):
+        def unit():
+            orc.ssim_distance(host_pair_crop[0], host_pair_crop[1], cw, ch, cw * 4, cw * 4, "RGBA")
+        return (lambda: None), unit
+    return cpu_baseline_of(make_unit, seconds, "pairs/s", f"{cw}x{ch} RGBA crop pair through orc_ssim_distance (oracle/ssim_oracle.c, f64)",
+                           scale=scale, scale_note=f"scaled to 7680x4320 pairs by the pixel ratio {scale:.5f}")
+
+
+# ------------------------------------------------------------------------------------------------ HBM traffic (committed PMC passes)
+
+def committed_traffic(key, units_per_step):
+    """HBM bytes per step from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot be collected live inside
+    a timed run): profiles/traffic.json, written by tools/r3_traffic.py from `rocprofv3 --pmc` runs of `bench.py --workload
+    <key>`.  Returns (bytes per step scaled to this run's units per step, source text) or (None, reason)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)[key]
+        return t["hbm_bytes_per_step"] * units_per_step / t["units_per_step"], t["source"]
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        pass
+    if key == "hsvfilter":
+        try:
+            with open(os.path.join(ROOT, "profiles", "hsvfilter_traffic.json")) as f:
+                t = json.load(f)
+            return t["hbm_bytes_per_launch"] * units_per_step / t["frames_per_launch"], "committed rocprofv3 pass: " + t["source"]
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, "no committed rocprofv3 PMC pass for this workload"
+
+
+# ------------------------------------------------------------------------------------------------ the legs (configs 2-5)
+
+DETECT_SETTINGS = (120.0, 40.0, 0.6, 0.4, 0.6, 0.4)  # SURVEY.md 8d hsvdetector settings
+
+
+class Leg:
+    """One workload on this rank: `step(i)` enqueues one pass of the path over one batch on w.stream."""
+
+    def __init__(self, key, metric, unit, units_per_step, bytes_per_step, dtype, data, workload, step, kernels, cpu=None,
+                 fixed_settle=None, extra=None, note=None, scaling="weak", total_units=None):
+        self.key, self.metric, self.unit = key, metric, unit
+        self.units_per_step, self.bytes_per_step = units_per_step, bytes_per_step
+        self.dtype, self.data, self.workload, self.step, self.kernels = dtype, data, workload, step, kernels
+        self.cpu, self.fixed_settle, self.extra, self.note, self.scaling = cpu, fixed_settle, extra or {}, note, scaling
+
+
+def measure_leg(w, leg, steps, warmup, settle_seconds, pct_steps, cpu_seconds):
+    """settle -> W warm-up -> K steps between barriers (wall clock + one pair of HIP events on the launch stream) -> pct_steps
+    steps with a HIP event between every two (p10 / p50 / p90 of the per-step time) -> the CPU port on the host cores."""
+    executed = [0]
+
+    def counted(i):
+        executed[0] += 1
+        return leg.step(i)
+
+    settle(counted, settle_seconds, w.sync, fixed_steps=leg.fixed_settle)
+    for i in range(warmup):
+        counted(i)
+    secs, ev_ms = w.timed(counted, steps, first_index=warmup, events=True)
+    secs, ev_ms = w.max_over_ranks(secs, ev_ms)
+    per_rank = w.gather(steps * leg.units_per_step / secs)
+    pct = percentiles(w.event_times(counted, pct_steps, first_index=warmup + steps)) if pct_steps > 0 else None
+    world = w.world
+    per_gpu_bytes = leg.bytes_per_step  # per rank and step
+    achieved_kernel = per_gpu_bytes / (ev_ms * 1e-3) / 1e9
+    achieved_wall = per_gpu_bytes * steps / secs / 1e9
+    traffic, traffic_source = committed_traffic(leg.key, leg.units_per_step)
+    value = steps * leg.units_per_step * (world if leg.scaling == "weak" else 1) / secs
+    out = {
+        "metric": leg.metric, "value": value, "unit": leg.unit, "steps": steps, "warmup": warmup,
+        "ms_per_step": secs / steps * 1e3, "scaling": leg.scaling, "dtype": leg.dtype, "data": leg.data,
+        "config": {"workload": leg.workload, "units_per_step_per_gpu": leg.units_per_step, "per_rank_units_per_sec": per_rank,
+                   "steps_executed": executed[0], **leg.extra},
+        "roofline": {"bound": "hbm", "achieved": achieved_kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved_kernel / HBM_PEAK_GBS, "frac_kernel": achieved_kernel / HBM_PEAK_GBS,
+                     "frac_wall": achieved_wall / HBM_PEAK_GBS, "achieved_wall": achieved_wall,
+                     "bytes_per_step": per_gpu_bytes, "avg_step_ms": ev_ms, "step_us": pct, "kernels": leg.kernels,
+                     "traffic": traffic, "traffic_source": traffic_source,
+                     "traffic_over_algorithmic": (traffic / per_gpu_bytes) if traffic else None,
+                     "note": ("frac / frac_kernel: algorithmic bytes of SURVEY 8d per step / average step time between two HIP events on "
+                              "the launch stream; frac_wall: the same bytes / wall clock between the barriers (what `value` is made of)"
+                              + ("; " + leg.note if leg.note else ""))},
+    }
+    if leg.cpu is not None and w.rank == 0 and world == 1 and cpu_seconds > 0:
+        out["cpu_baseline"] = leg.cpu(cpu_seconds)
+    return out
+
+
+def make_leg_hsv1080p(w, args):
+    """config 2: args.batch independent 1080p streams per step: one frame of each through hsvfilter (in place, RGBx) then
+    hsvdetector (RGBx -> RGBA): two launches per step (a single 1080p frame is ~3 + ~6 us of GPU work: launch-bound alone)."""
+    torch, vfx, lib, dev, sptr = w.torch, w.vfx, w.lib, w.dev, w.sptr
+    W, H, nb = 1920, 1080, args.batch
+    pool = max(2, 96 // nb)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0200 + w.rank)
+    src = torch.empty((pool * nb, W * H * 4), dtype=torch.uint8, device=dev)
+    fill_frames(torch, dev, gen, src, "videotestsrc", W, H, first_frame=w.rank * pool * nb)
+    dst = torch.empty((pool * nb, W * H * 4), dtype=torch.uint8, device=dev)
+    fs = vfx.HsvFilterSettings(*SETTINGS)
+    ds = vfx.HsvDetectorSettings(*DETECT_SETTINGS)
+    fi = [(vfx.Frame * nb)(*[vfx.make_frame(src[b * nb + i].data_ptr(), W, H, W * 4, "RGBx") for i in range(nb)]) for b in range(pool)]
+    fo = [(vfx.Frame * nb)(*[vfx.make_frame(dst[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
+    host = [src[k].cpu().numpy().reshape(H, W * 4).copy() for k in range(4)] if w.rank == 0 and w.world == 1 else None
+
+    def step(i):
+        k = i % pool
+        vfx.check(lib.mvfx_hsvfilter_transform_frames_ip(fi[k], nb, ctypes.byref(fs), sptr))
+        vfx.check(lib.mvfx_hsvdetector_transform_frames(fi[k], fo[k], nb, ctypes.byref(ds), sptr))
+    leg = Leg("hsv1080p", "hsv1080p_frames_per_sec", "frames/s", nb, nb * 4 * W * H * 4, "f32",
+              "synthetic videotestsrc pattern=smpte 1920x1080 RGBx frames, device-resident",
+              f"hsvfilter (RGBx, in place) + hsvdetector RGBx->RGBA, {nb} streams of 1920x1080 per launch; 8 + 8 algorithmic B/px",
+              step, ["hsvfilter4_typed_kernel", "hsvdetector_typed_kernel"],
+              cpu=(lambda s: cpu_baseline_hsv1080p(s, host)) if host else None)
+    leg.keep = (src, dst, fi, fo)
+    return leg
+
+
+def make_leg_colorlut(w, args, content):
+    """config 3: args.batch streams graded with the same 33^3 LUT, one 4K frame of each per launch."""
+    from tests import cubes
+    torch, vfx, lib, dev, sptr = w.torch, w.vfx, w.lib, w.dev, w.sptr
+    W, H, nb = W4K, H4K, args.batch
+    pool = max(2, 32 // nb)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0300 + w.rank)
+    cube_text = cubes.analytic_3d(33)
+    lut = vfx.CubeLut(cube_text)
+    src = torch.empty((pool * nb, FRAME_BYTES), dtype=torch.uint8, device=dev)
+    if content == "random":
+        src.random_(0, 256, generator=gen)
+        data = "synthetic uniform-random u8 RGBA (every pixel another LUT cell: the gather worst case), device-resident"
+    elif content == "smpte":
+        fill_frames(torch, dev, gen, src, "videotestsrc", W, H, first_frame=w.rank * pool * nb)
+        data = "synthetic " + CONTENT_TEXT["videotestsrc"] + ", device-resident"
+    else:
+        fill_frames(torch, dev, gen, src, "natural", W, H, first_frame=w.rank * pool * nb)
+        data = "synthetic " + CONTENT_TEXT["natural"] + ", device-resident"
+    dst = torch.empty((pool * nb, FRAME_BYTES), dtype=torch.uint8, device=dev)
+    fi = [(vfx.Frame * nb)(*[vfx.make_frame(src[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
+    fo = [(vfx.Frame * nb)(*[vfx.make_frame(dst[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
+    host = [src[k].cpu().numpy().reshape(H, W * 4).copy() for k in range(3)] if w.rank == 0 and w.world == 1 else None
+
+    def step(i):
+        k = i % pool
+        vfx.check(lib.mvfx_colorlut_transform_frames(lut.h, fi[k], fo[k], nb, sptr))
+
+    def streams_leg():
+        """the element's launch model: --stream-threads host threads x own HIP stream x single-frame mvfx_colorlut_transform_frame"""
+        hb = bench_harness()
+        nthr = args.stream_threads
+        fpt = max(1, (pool * nb) // nthr)
+        fin = (vfx.Frame * (nthr * fpt))(*[vfx.make_frame(src[k].data_ptr(), W, H, W * 4, "RGBA") for k in range(nthr * fpt)])
+        fout = (vfx.Frame * (nthr * fpt))(*[vfx.make_frame(dst[k].data_ptr(), W, H, W * 4, "RGBA") for k in range(nthr * fpt)])
+        launches, reps = 100, 5
+        secs, per = (ctypes.c_double * reps)(), (ctypes.c_double * nthr)()
+        w.sync()
+        w.barrier()
+        rc = hb.mvfxbench_colorlut_streams(w.local_rank, nthr, 200, launches, reps, lut.h, fin, fout, fpt, 0, secs, per)
+        if rc != 0:
+            raise RuntimeError(f"mvfxbench status {rc}: {vfx.last_error()}")
+        w.barrier()
+        (med,) = w.max_over_ranks(sorted(secs)[reps // 2])
+        fps = nthr * launches * w.world / med
+        return {"launch_model": f"{nthr} threads x 1 frame (own HIP stream each, single-frame mvfx_colorlut_transform_frame)",
+                "value": fps, "unit": "frames/s", "launches_per_thread": launches, "statistic": "median of 5 repetitions",
+                "frac_wall": fps / w.world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS}
+    leg = Leg("colorlut_" + content, "colorlut_frames_per_sec", "frames/s", nb, nb * 2 * FRAME_BYTES, "f32", data,
+              f"colorlut 33^3 .cube (575 KB of nodes), {nb} streams of 3840x2160 RGBA per launch, content={content}; 4 + 4 algorithmic B/px "
+              "(the LUT gathers are content dependent: random colours are the worst case, flat bars the best)",
+              step, ["colorlut_tile_kernel"],
+              cpu=(lambda s: cpu_baseline_colorlut(s, host, cube_text, content)) if host else None)
+    leg.keep = (src, dst, fi, fo, lut)
+    leg.streams_leg = streams_leg
+    return leg
+
+
+def make_leg_videofx(w, args):
+    """config 4: one 4K stream per GPU: roundedcorners I420 -> A420 compose with the r=100 mask + colordetect on the RGBA twin."""
+    torch, vfx, lib, dev, sptr = w.torch, w.vfx, w.lib, w.dev, w.sptr
+    W, H, pool = W4K, H4K, 16
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0400 + w.rank)
+    i420 = torch.randint(0, 256, (pool, W * H * 3 // 2), dtype=torch.uint8, device=dev, generator=gen)
+    a420 = torch.empty((pool, W * H * 5 // 2), dtype=torch.uint8, device=dev)
+    rgba = torch.empty((pool, FRAME_BYTES), dtype=torch.uint8, device=dev)
+    fill_frames(torch, dev, gen, rgba, "natural", W, H, first_frame=w.rank * pool)
+    mask = torch.empty(W * H, dtype=torch.uint8, device=dev)
+    vfx.check(lib.mvfx_roundedcorners_mask(ctypes.c_void_p(mask.data_ptr()), W, H, W, 100, sptr))
+    hist = torch.zeros(32768 + 8, dtype=torch.int32, device=dev)
+    offs = [0, W * H, W * H * 5 // 4, W * H * 3 // 2]
+    planes = []
+    for k in range(pool):
+        a, b = vfx.PlanarFrame(), vfx.PlanarFrame()
+        for p_ in range(3):
+            a.data[p_] = i420[k].data_ptr() + offs[p_]
+            b.data[p_] = a420[k].data_ptr() + offs[p_]
+            a.stride[p_] = b.stride[p_] = W if p_ == 0 else W // 2
+        b.data[3] = a420[k].data_ptr() + offs[3]
+        b.stride[3] = W
+        a.width = b.width = W
+        a.height = b.height = H
+        a.format, b.format = vfx.FORMATS["I420"], vfx.FORMATS["A420"]
+        planes.append((a, b))
+    fr = [vfx.make_frame(rgba[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(pool)]
+    host = [rgba[k].cpu().numpy().copy() for k in range(4)] if w.rank == 0 and w.world == 1 else None
+    # --element-streams 2: the two elements on their own HIP streams, as with a `queue` between them (two streaming threads:
+    # frame k's colordetect overlaps frame k+1's compose); 1: both on one stream, one after the other (one streaming thread)
+    second = torch.cuda.Stream(device=dev) if args.element_streams == 2 else None
+    sptr2 = ctypes.c_void_p(second.cuda_stream) if second is not None else sptr
+
+    def step(i):
+        k = i % pool
+        vfx.check(lib.mvfx_roundedcorners_compose_a420(ctypes.byref(planes[k][0]), ctypes.c_void_p(mask.data_ptr()), W,
+                                                       ctypes.byref(planes[k][1]), sptr))
+        vfx.check(lib.mvfx_colordetect_histogram(ctypes.byref(fr[k]), 10, 0, vfx.ALL_SAMPLES, ctypes.c_void_p(hist.data_ptr()),
+                                                 ctypes.c_void_p(hist.data_ptr() + 32768 * 4), sptr2))
+    leg = Leg("videofx", "videofx_frames_per_sec", "frames/s", 1, W * H * 4 + FRAME_BYTES, "u8",
+              "synthetic: uniform-random I420 planes (compose), natural-like RGBA frames (colordetect), device-resident",
+              "roundedcorners I420->A420 compose (r=100; 1.5 R + 2.5 W B/px) + colordetect histogram (quality=10; 4 touched B/px), one "
+              "3840x2160 stream per GPU, " + ("both elements on one HIP stream (one streaming thread)" if second is None else
+                                               "the two elements on their own HIP streams (a queue between them: two streaming threads)"),
+              step, ["copy_planes_kernel", "colordetect_hist_kernel"],
+              cpu=(lambda s: cpu_baseline_videofx(s, host)) if host else None)
+    leg.keep = (i420, a420, rgba, mask, hist, planes, fr, second)
+    return leg
+
+
+def make_leg_videocompare(w, args, algo):
+    """config 5 on one GPU holding both whole 7680x4320 RGBA frames of every pair."""
+    torch, vfx, lib, dev, sptr, stream = w.torch, w.vfx, w.lib, w.dev, w.sptr, w.stream
+    W, H = 7680, 4320
+    pool = 4 if algo == "blockhash" else 2
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0500)
+    full = torch.empty((pool, 2, H * W * 4), dtype=torch.uint8, device=dev)
+    for k in range(pool):
+        full[k, 0].random_(0, 256, generator=gen)
+    full[:, 1] = full[:, 0]
+    full[:, 1, ::97] ^= 0x10          # B = A with ~1 % of the bytes perturbed (SURVEY 8d iv)
+    fr = [(vfx.Frame * 2)(*[vfx.make_frame(full[k, p].data_ptr(), W, H, W * 4, "RGBA") for p in range(2)]) for k in range(pool)]
+    dist_out = ctypes.c_double()
+    last = [0.0]
+    host_pair = None
+    if w.rank == 0 and w.world == 1:
+        if algo == "blockhash":
+            host_pair = [full[0, p].cpu().numpy().reshape(H, W * 4).copy() for p in range(2)]
+        else:
+            cw, ch = 1920, 1080
+            host_pair = [full[0, p].view(H, W * 4)[:ch, :cw * 4].contiguous().cpu().numpy().copy() for p in range(2)]
+    bytes_per_pair = 2 * W * H * 4
+    if algo == "dssim":
+        def step(i):
+            vfx.check(lib.mvfx_ssim_distance(ctypes.byref(fr[i % pool][0]), ctypes.byref(fr[i % pool][1]), ctypes.byref(dist_out), sptr))
+            last[0] = dist_out.value
+        leg = Leg("videocompare_dssim", "videocompare_dssim_8k_rgba_pairs_per_sec", "pairs/s", 1, bytes_per_pair, "f32",
+                  "synthetic uniform-random u8 RGBA 8K pairs (B = A with 1 % of the bytes perturbed), device-resident",
+                  "videocompare hash-algo=dssim (multi-scale SSIM) on 7680x4320 RGBA pairs, one GPU, synchronous mvfx_ssim_distance per pair; "
+                  "4 + 4 compulsory B/px-pair (the planes of the pyramid are implementation traffic)",
+                  step, ["ssim_*"], cpu=(lambda s: cpu_baseline_dssim(s, host_pair, 1920, 1080)) if host_pair else None,
+                  fixed_settle=20, extra={"last_distance": last},
+                  note="compulsory input bytes against HBM peak; the pyramid planes are extra traffic, see traffic_over_algorithmic")
+    else:
+        depth = max(1, args.pairs_in_flight)
+        ring_dev = torch.zeros((depth, 2, 64), dtype=torch.int32, device=dev)
+        ring_host = torch.zeros((depth, 2, 64), dtype=torch.int32).pin_memory()
+        ring_evt = [torch.cuda.Event() for _ in range(depth)]
+        ring_busy = [False] * depth
+
+        def bits(s):
+            arr = (ctypes.c_uint32 * 64)(*[int(x) for x in s])
+            out = ctypes.c_uint64()
+            vfx.check(lib.mvfx_blockhash_bits(arr, W, H, ctypes.byref(out)))
+            return out.value
+
+        def finish(slot):
+            ring_evt[slot].synchronize()
+            h = [bits([int(v) & 0xFFFFFFFF for v in ring_host[slot, p].tolist()]) for p in range(2)]
+            ring_busy[slot] = False
+            last[0] = float(bin(h[0] ^ h[1]).count("1"))
+
+        def step(i):
+            if depth == 1:
+                # HasherEngine::hash_image x2 + compare in the C ABI (one launch for both pads, one 512-byte D2H, host bit
+                # derivation), exactly what the element does per aggregate
+                vfx.check(lib.mvfx_videocompare_distance(ctypes.byref(fr[i % pool][0]), ctypes.byref(fr[i % pool][1]),
+                                                         ctypes.byref(dist_out), sptr))
+                last[0] = dist_out.value
+                return
+            # `depth` pairs in flight: the block sums of pair i travel to pinned host memory asynchronously and become hashes
+            # / the distance while the kernel of pair i+1 .. i+depth-1 runs
+            slot = i % depth
+            if ring_busy[slot]:
+                finish(slot)
+            vfx.check(lib.mvfx_blockhash_sums_pads(fr[i % pool], 2, H, 0, ctypes.c_void_p(ring_dev[slot].data_ptr()), sptr))
+            ring_host[slot].copy_(ring_dev[slot], non_blocking=True)
+            ring_evt[slot].record(stream)
+            ring_busy[slot] = True
+        leg = Leg("videocompare_blockhash", "videocompare_blockhash_8k_rgba_pairs_per_sec", "pairs/s", 1, bytes_per_pair, "u32",
+                  "synthetic uniform-random u8 RGBA 8K pairs (B = A with 1 % of the bytes perturbed), device-resident",
+                  f"videocompare hash-algo=blockhash on 7680x4320 RGBA pairs, one GPU, whole frames, {depth} pair(s) in flight "
+                  "(1 = the synchronous mvfx_videocompare_distance the element calls per aggregate); 4 + 4 B/px-pair",
+                  step, ["blockhash_sums_kernel", "blockhash_reduce_kernel"],
+                  cpu=(lambda s: cpu_baseline_blockhash(s, host_pair)) if host_pair else None, fixed_settle=400,
+                  extra={"last_distance": last, "pairs_in_flight": depth},
+                  note="per pair incl. the D2H of the 128 block sums and the host bit derivation")
+        leg.drain = lambda: [finish(s) for s in range(depth) if ring_busy[s]]
+    leg.keep = (full, fr)
+    return leg
+
+
+def other_config_legs(w, args):
+    """BASELINE configs 2-5 measured in the same run as the headline (`config.other_configs` of the driver's line): each with
+    value, roofline fractions from HIP events and wall clock, p10/p50/p90 per step, committed PMC traffic and a CPU-port baseline."""
+    torch = w.torch
+    out = {}
+    makers = [("hsv1080p", lambda: make_leg_hsv1080p(w, args)),
+              ("colorlut_natural", lambda: make_leg_colorlut(w, args, "natural")),
+              ("colorlut_random", lambda: make_leg_colorlut(w, args, "random")),
+              ("videofx", lambda: make_leg_videofx(w, args)),
+              ("videocompare_blockhash", lambda: make_leg_videocompare(w, args, "blockhash")),
+              ("videocompare_dssim", lambda: make_leg_videocompare(w, args, "dssim"))]
+    steps = {"hsv1080p": 200, "colorlut_natural": 100, "colorlut_random": 40, "videofx": 400, "videocompare_blockhash": 400,
+             "videocompare_dssim": 30}
+    for key, make in makers:
+        try:
+            leg = make()
+            k = steps[key]
+            r = measure_leg(w, leg, k, max(5, k // 10), args.other_settle_seconds, 200 if key != "videocompare_dssim" else 40,
+                            args.other_cpu_seconds)
+            if hasattr(leg, "drain"):
+                leg.drain()
+            if key == "colorlut_natural" and args.stream_threads > 0:
+                r["config"]["other_launch_model"] = leg.streams_leg()
+            if "last_distance" in r["config"]:
+                r["config"]["last_distance"] = r["config"]["last_distance"][0]
+            out[key] = r
+            del leg
+        except Exception as e:  # a failing side leg must not cost the headline line
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ config 5, sharded (N > 1)
 
 def videocompare_main(args):
-    """BASELINE config 5: blockhash distance of 7680x4320 RGBA frame pairs.  Inputs are pre-sharded:
-    rank r holds block-row band r of both frames; one all-reduce of 2x64 sums."""
+    """BASELINE config 5: distance of 7680x4320 RGBA frame pairs.  N == 1: whole frames on the one GPU.  N > 1: inputs are
+    pre-sharded, rank r holds block-row band r of both frames; one all-reduce of 2x64 sums per pair."""
     w = Worker(args)
-    torch, vfx, lib, dev, sptr, stream = w.torch, w.vfx, w.lib, w.dev, w.sptr, w.stream
+    if w.world == 1:
+        leg = make_leg_videocompare(w, args, args.hash_algo)
+        r = measure_leg(w, leg, args.steps, args.warmup, args.settle_seconds, args.pct_steps, 0 if args.no_cpu_baseline else args.other_cpu_seconds)
+        if hasattr(leg, "drain"):
+            leg.drain()
+        r["config"]["last_distance"] = r["config"]["last_distance"][0]
+        r.update({"n_gpus": 1, "higher_is_better": True, "vs_baseline": None})
+        r["config"].update({"parallelism": "one GPU, whole frames", "rccl_ranks": w.rccl_ranks})
+        print(json.dumps(r), flush=True)
+        w.finish()
+        return
+    out = videocompare_sharded_leg(w, args, args.hash_algo, args.steps, args.warmup)
+    if w.rank == 0:
+        print(json.dumps(out), flush=True)
+    w.finish()
+
+
+def videocompare_sharded_leg(w, args, algo, steps, warmup):
+    torch, vfx, lib, dev, sptr = w.torch, w.vfx, w.lib, w.dev, w.sptr
     from gst_plugin_rs_amd import distributed as D
     rank, world = w.rank, w.world
     W, H = 7680, 4320
     r0, r1 = D.band_rows(H, rank, world)
     rows = r1 - r0
-    pool = 4
     gen = torch.Generator(device=dev)
-    gen.manual_seed(0x5EED0001)  # same seed on every rank: band r of the same virtual frames
-    pairs = torch.randint(0, 256, (pool, 2, rows * W * 4), dtype=torch.uint8, device=dev, generator=gen)
-    sums = torch.zeros((2, 64), dtype=torch.int32, device=dev)
-
-    def bits(s, w_, h_):
-        arr = (ctypes.c_uint32 * 64)(*[int(x) for x in s])
-        out = ctypes.c_uint64()
-        vfx.check(lib.mvfx_blockhash_bits(arr, w_, h_, ctypes.byref(out)))
-        return out.value
-
-    if args.hash_algo == "dssim":
+    if algo == "dssim":
         # every rank holds both full frames (a band's 5-level pyramid needs a halo of up to 64 rows) and maps only its band;
         # two all-reduces of 10 f64 per pair (distributed.ssim_sharded)
-        del pairs
         pool = 2
         gen.manual_seed(0x5EED0002)
         full = torch.randint(0, 256, (pool, 2, H * W * 4), dtype=torch.uint8, device=dev, generator=gen)
@@ -382,233 +871,75 @@ def videocompare_main(args):
             return [D.ssim_sharded(lambda: vfx.ssim_partial_sums(fr[k][0], fr[k][1], y0, y1, sptr),
                                    lambda mean: vfx.ssim_partial_deviation(mean, sptr), vfx.ssim_combine, dev)]
     else:
+        pool = 4
+        gen.manual_seed(0x5EED0001)  # same seed on every rank: band r of the same virtual frames
+        pairs = torch.randint(0, 256, (pool, 2, rows * W * 4), dtype=torch.uint8, device=dev, generator=gen)
+        sums = torch.zeros((2, 64), dtype=torch.int32, device=dev)
         bands = [(vfx.Frame * 2)(*[vfx.make_frame(pairs[k, p].data_ptr(), W, rows, W * 4, "RGBA") for p in range(2)])
                  for k in range(pool)]
 
-        dist_out = ctypes.c_double()
-        depth = max(1, args.pairs_in_flight)
-        ring_dev = torch.zeros((depth, 2, 64), dtype=torch.int32, device=dev)
-        ring_host = torch.zeros((depth, 2, 64), dtype=torch.int32).pin_memory()
-        ring_evt = [torch.cuda.Event() for _ in range(depth)]
-        ring_busy = [False] * depth
-        last = [0.0]
-
-        def finish(slot):
-            ring_evt[slot].synchronize()
-            h = [bits([int(v) & 0xFFFFFFFF for v in ring_host[slot, p].tolist()], W, H) for p in range(2)]
-            ring_busy[slot] = False
-            last[0] = float(bin(h[0] ^ h[1]).count("1"))
+        def bits(s, w_, h_):
+            arr = (ctypes.c_uint32 * 64)(*[int(x) for x in s])
+            out = ctypes.c_uint64()
+            vfx.check(lib.mvfx_blockhash_bits(arr, w_, h_, ctypes.byref(out)))
+            return out.value
 
         def step(i):
-            if world == 1 and depth == 1:
-                # one GPU holds both whole frames: HasherEngine::hash_image x2 + compare in the C ABI (one launch for both
-                # pads, one 512-byte D2H, host bit derivation), exactly what the element does per aggregate
-                vfx.check(lib.mvfx_videocompare_distance(ctypes.byref(bands[i % pool][0]), ctypes.byref(bands[i % pool][1]),
-                                                         ctypes.byref(dist_out), sptr))
-                return [dist_out.value]
-            if world == 1:
-                # `depth` pairs in flight: the block sums of pair i are copied to pinned host memory asynchronously and
-                # turned into hashes / the distance while the kernel of pair i+1 .. i+depth-1 runs (the host round trip of
-                # a pair, ~25 us, no longer sits between two 42 us kernels)
-                slot = i % depth
-                if ring_busy[slot]:
-                    finish(slot)
-                vfx.check(lib.mvfx_blockhash_sums_pads(bands[i % pool], 2, H, 0, ctypes.c_void_p(ring_dev[slot].data_ptr()), sptr))
-                ring_host[slot].copy_(ring_dev[slot], non_blocking=True)
-                ring_evt[slot].record(stream)
-                ring_busy[slot] = True
-                return [last[0]]
-
             def partial():  # both pads' bands in one launch
                 vfx.check(lib.mvfx_blockhash_sums_pads(bands[i % pool], 2, H, r0, ctypes.c_void_p(sums.data_ptr()), sptr))
                 return sums
             return D.videocompare_sharded(partial, 2, W, H, bits, dev, all_pads=True)
 
-    settle(step, args.settle_seconds, w.sync, fixed_steps=400 if args.hash_algo == "blockhash" else 20)  # all-reduce inside the step
-    for i in range(args.warmup):
+    settle(step, args.settle_seconds, w.sync, fixed_steps=200 if algo == "blockhash" else 10)  # all-reduce inside the step
+    for i in range(warmup):
         step(i)
     result = [None]
 
     def timed_step(i):
         result[0] = step(i)
-
-    def whole(i):  # the K steps + the drain of the pairs still in flight, all inside the timed region
-        for k in range(args.steps):
-            timed_step(k)
-        if args.hash_algo == "blockhash" and world == 1 and args.pairs_in_flight > 1:
-            for slot in range(len(ring_busy)):
-                if ring_busy[slot]:
-                    finish(slot)
-            result[0] = [last[0]]
-
-    elapsed, _ = w.timed(whole, 1)
+    elapsed, _ = w.timed(timed_step, steps)
     (elapsed,) = w.max_over_ranks(elapsed)
-    d = result[0]
-    per_rank = w.gather(args.steps / elapsed)
+    # the collective alone: the same 2x64 all-reduce with nothing around it (latency-bound on xGMI)
+    t = torch.zeros((2, 64), dtype=torch.int64, device=dev)
+    for _ in range(20):
+        w.dist.all_reduce(t)
+    ar_s, _ = w.timed(lambda i: w.dist.all_reduce(t), 200)
+    (ar_s,) = w.max_over_ranks(ar_s)
     bytes_per_pair = 2 * W * H * 4
-    achieved = bytes_per_pair * args.steps / elapsed / 1e9
-    if rank == 0:
-        print(json.dumps({
-            "metric": "videocompare_8k_rgba_pairs_per_sec", "value": args.steps / elapsed, "unit": "pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32" if args.hash_algo == "blockhash" else "f64",
-            "data": "synthetic uniform-random u8 RGBA, device-resident, rows pre-sharded by block-row band",
-            "config": {"workload": "videocompare blockhash 7680x4320 RGBA pair, band-sharded + all-reduce(2x64 u32)" if args.hash_algo == "blockhash"
-                       else "videocompare dssim (multi-scale SSIM, f64) 7680x4320 RGBA pair, row bands + 2 all-reduces of 10 f64",
-                       "parallelism": f"{world} row bands, RCCL all-reduce per pair" if world > 1 else
-                                      f"one GPU, whole frames, {args.pairs_in_flight} pair(s) in flight", "last_distance": d[0],
-                       "rccl_ranks": w.rccl_ranks, "per_rank_pairs_per_sec": per_rank},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                         "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
-                         "note": "end-to-end per pair incl. all-reduce (N > 1), D2H of the block sums, the synchronisation and host bit derivation"
-                                 if args.hash_algo == "blockhash" else
-                                 "the compulsory input bytes against HBM peak (SURVEY 8d); this path is f64 arithmetic: its five kernels issue "
-                                 "4.74e8 wave64 VALU instructions per 8K pair (rocprofv3 SQ_INSTS_VALU, profiles/r2/ssim_counters_after.txt), see "
-                                 "valu_issue_frac",
-                         **({} if args.hash_algo == "blockhash" else
-                            {"valu_issue_frac": 4.74e8 * 64 * (args.steps / elapsed) / world / (256 * 64 * 2.4e9),
-                             "valu_issue_note": "wave64 VALU instructions per second / (256 CUs x 64 lanes x 2.4 GHz), single GPU whole frames"})}}),
-              flush=True)
-    w.finish()
+    achieved = bytes_per_pair * steps / elapsed / 1e9
+    return {
+        "metric": "videocompare_8k_rgba_pairs_per_sec", "value": steps / elapsed, "unit": "pairs/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32" if algo == "blockhash" else "f32",
+        "data": "synthetic uniform-random u8 RGBA, device-resident, rows pre-sharded by block-row band",
+        "config": {"workload": "videocompare blockhash 7680x4320 RGBA pair, band-sharded + all-reduce(2x64 u32)" if algo == "blockhash"
+                   else "videocompare dssim (multi-scale SSIM) 7680x4320 RGBA pair, row bands + 2 all-reduces of 10 f64",
+                   "parallelism": f"{world} row bands, RCCL all-reduce per pair", "last_distance": result[0][0],
+                   "rccl_ranks": w.rccl_ranks, "allreduce_us": ar_s / 200 * 1e6,
+                   "allreduce_note": "RCCL all-reduce(sum) of 2x64 int64 alone, back to back on the launch stream, wall clock / 200"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                     "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
+                     "note": "end-to-end per pair incl. the all-reduce, the D2H of the block sums, the synchronisation and host bit derivation"}}
 
 
 # ------------------------------------------------------------------------------------------------ configs 2-4
 
 def config_main(args):
-    """BASELINE configs 2-4 as device-resident per-GPU stream workloads (no data-path collective)."""
-    from tests import cubes
+    """One of BASELINE configs 2-4 as its own line (device-resident per-GPU stream workloads, no data-path collective)."""
     w = Worker(args)
-    torch, vfx, lib, dev, sptr = w.torch, w.vfx, w.lib, w.dev, w.sptr
-    rank, world = w.rank, w.world
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0x5EED0100 + rank)
-
-    def rnd(n, nbytes):
-        return torch.randint(0, 256, (n, nbytes), dtype=torch.uint8, device=dev, generator=gen)
-
-    data = "synthetic uniform-random u8, device-resident"
     if args.workload == "hsv1080p":
-        # args.batch independent 1080p streams per step: one frame of each through hsvfilter then hsvdetector,
-        # two launches per step (a single 1080p frame is ~3 + ~6 us of GPU work: launch-bound one at a time)
-        W, H, nb = 1920, 1080, args.batch
-        pool = max(2, 96 // nb)
-        src, dst = rnd(pool * nb, W * H * 4), torch.empty((pool * nb, W * H * 4), dtype=torch.uint8, device=dev)
-        fs = vfx.HsvFilterSettings(*SETTINGS)
-        ds = vfx.HsvDetectorSettings(120.0, 40.0, 0.6, 0.4, 0.6, 0.4)
-        fi = [(vfx.Frame * nb)(*[vfx.make_frame(src[b * nb + i].data_ptr(), W, H, W * 4, "RGBx") for i in range(nb)]) for b in range(pool)]
-        fo = [(vfx.Frame * nb)(*[vfx.make_frame(dst[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
-
-        def step(i):
-            k = i % pool
-            vfx.check(lib.mvfx_hsvfilter_transform_frames_ip(fi[k], nb, ctypes.byref(fs), sptr))
-            vfx.check(lib.mvfx_hsvdetector_transform_frames(fi[k], fo[k], nb, ctypes.byref(ds), sptr))
-        frames_per_step = nb
-        bytes_per_step, name = nb * 4 * W * H * 4, f"hsvfilter (RGBx, in place) + hsvdetector RGBx->RGBA, {nb} streams of 1920x1080 per launch"
+        leg = make_leg_hsv1080p(w, args)
     elif args.workload == "colorlut":
-        # args.batch streams graded with the same 33^3 LUT, one frame of each per launch
-        W, H, nb = W4K, H4K, args.batch
-        pool = max(2, 32 // nb)
-        lut = vfx.CubeLut(cubes.analytic_3d(33))
-        if args.content == "random":
-            src = rnd(pool * nb, FRAME_BYTES)
-        elif args.content == "smpte":
-            from tests import frames as _frames
-            one = torch.from_numpy(_frames.smpte_like(W, H).reshape(-1)).to(dev)
-            src = one.unsqueeze(0).repeat(pool * nb, 1).contiguous()
-            data = "synthetic videotestsrc-smpte-like bars, device-resident"
-        else:  # smooth 2-D colour gradients (different phase per frame) + sensor-like noise of +-3 codes
-            data = "synthetic smooth colour gradients + uniform noise of +-3 codes (natural-like), device-resident"
-            src = torch.empty((pool * nb, FRAME_BYTES), dtype=torch.uint8, device=dev)
-            for k in range(pool * nb):
-                src[k] = natural_frame(torch, dev, gen, k, W, H)
-        dst = torch.empty((pool * nb, FRAME_BYTES), dtype=torch.uint8, device=dev)
-        fi = [(vfx.Frame * nb)(*[vfx.make_frame(src[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
-        fo = [(vfx.Frame * nb)(*[vfx.make_frame(dst[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
-
-        def step(i):
-            k = i % pool
-            vfx.check(lib.mvfx_colorlut_transform_frames(lut.h, fi[k], fo[k], nb, sptr))
-        frames_per_step = nb
-        bytes_per_step, name = nb * 2 * FRAME_BYTES, (f"colorlut 33^3 .cube, {nb} streams of 3840x2160 RGBA per launch, content={args.content} "
-                                                      "(the LUT gathers are content dependent: random colours are the worst case, flat bars the best)")
-
-        def streams_leg():
-            """the element's launch model: --stream-threads host threads x own HIP stream x single-frame mvfx_colorlut_transform_frame"""
-            hb = ctypes.CDLL(os.path.join(ROOT, "gst-plugin-rs_amd", "libmvfxbench.so"))
-            nthr = args.stream_threads
-            fpt = max(1, (pool * nb) // nthr)
-            fin = (vfx.Frame * (nthr * fpt))(*[vfx.make_frame(src[k].data_ptr(), W, H, W * 4, "RGBA") for k in range(nthr * fpt)])
-            fout = (vfx.Frame * (nthr * fpt))(*[vfx.make_frame(dst[k].data_ptr(), W, H, W * 4, "RGBA") for k in range(nthr * fpt)])
-            launches, reps = max(100, args.steps * nb // nthr), 5
-            secs, per = (ctypes.c_double * reps)(), (ctypes.c_double * nthr)()
-            w.sync()
-            w.barrier()
-            rc = hb.mvfxbench_colorlut_streams(w.local_rank, nthr, 400, launches, reps, lut.h, fin, fout, fpt, 0, secs, per)
-            if rc != 0:
-                raise RuntimeError(f"mvfxbench status {rc}: {vfx.last_error()}")
-            w.barrier()
-            (med,) = w.max_over_ranks(sorted(secs)[reps // 2])
-            fps = nthr * launches * world / med
-            return {"launch_model": f"{nthr} threads x 1 frame (own HIP stream each, single-frame mvfx_colorlut_transform_frame)",
-                    "value": fps, "unit": "frames/s", "launches_per_thread": launches, "statistic": "median of 5 repetitions",
-                    "frac": fps / world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS}
-    else:  # videofx: one 4K stream per GPU: I420 -> A420 compose with the r=100 mask + colordetect on the RGBA twin
-        W, H, pool = W4K, H4K, 16
-        i420, a420 = rnd(pool, W * H * 3 // 2), torch.empty((pool, W * H * 5 // 2), dtype=torch.uint8, device=dev)
-        rgba = rnd(pool, FRAME_BYTES)
-        mask = torch.empty(W * H, dtype=torch.uint8, device=dev)
-        vfx.check(lib.mvfx_roundedcorners_mask(ctypes.c_void_p(mask.data_ptr()), W, H, W, 100, sptr))
-        hist = torch.zeros(32768 + 8, dtype=torch.int32, device=dev)
-        offs = [0, W * H, W * H * 5 // 4, W * H * 3 // 2]
-        planes = []
-        for k in range(pool):
-            a, b = vfx.PlanarFrame(), vfx.PlanarFrame()
-            for p_ in range(3):
-                a.data[p_] = i420[k].data_ptr() + offs[p_]
-                b.data[p_] = a420[k].data_ptr() + offs[p_]
-                a.stride[p_] = b.stride[p_] = W if p_ == 0 else W // 2
-            b.data[3] = a420[k].data_ptr() + offs[3]
-            b.stride[3] = W
-            a.width = b.width = W
-            a.height = b.height = H
-            a.format, b.format = vfx.FORMATS["I420"], vfx.FORMATS["A420"]
-            planes.append((a, b))
-        fr = [vfx.make_frame(rgba[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(pool)]
-
-        # --element-streams 2: the two elements on their own HIP streams, as with a `queue` between them (two streaming threads:
-        # frame k's colordetect overlaps frame k+1's compose); 1: both on one stream, one after the other (one streaming thread)
-        second = torch.cuda.Stream(device=dev) if args.element_streams == 2 else None
-        sptr2 = ctypes.c_void_p(second.cuda_stream) if second is not None else sptr
-
-        def step(i):
-            k = i % pool
-            vfx.check(lib.mvfx_roundedcorners_compose_a420(ctypes.byref(planes[k][0]), ctypes.c_void_p(mask.data_ptr()), W,
-                                                           ctypes.byref(planes[k][1]), sptr))
-            vfx.check(lib.mvfx_colordetect_histogram(ctypes.byref(fr[k]), 10, 0, vfx.ALL_SAMPLES, ctypes.c_void_p(hist.data_ptr()),
-                                                     ctypes.c_void_p(hist.data_ptr() + 32768 * 4), sptr2))
-        frames_per_step = 1
-        bytes_per_step = W * H * 4 + FRAME_BYTES
-        name = ("roundedcorners I420->A420 compose (r=100) + colordetect histogram (quality=10), one 3840x2160 stream per GPU, "
-                + ("both elements on one HIP stream (one streaming thread)" if second is None else
-                   "the two elements on their own HIP streams (a queue between them: two streaming threads)"))
-
-    settle(step, args.settle_seconds, w.sync)
-    for i in range(args.warmup):
-        step(i)
-    elapsed, _ = w.timed(step, args.steps, first_index=args.warmup)
-    (elapsed,) = w.max_over_ranks(elapsed)
-    per_rank = w.gather(args.steps * frames_per_step / elapsed)
-    achieved = bytes_per_step * args.steps / elapsed / 1e9
-    other_model = streams_leg() if args.workload == "colorlut" and args.stream_threads > 0 else None
-    if rank == 0:
-        print(json.dumps({
-            "metric": f"{args.workload}_frames_per_sec", "value": args.steps * frames_per_step * world / elapsed, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.workload != "videofx" else "u8",
-            "data": data, "config": {"workload": name, "parallelism": f"{world} independent streams", "rccl_ranks": w.rccl_ranks,
-                                     "per_rank_frames_per_sec": per_rank, **({"other_launch_model": other_model} if other_model else {})},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "note": "wall clock over the launches of a step (per GPU)"}}), flush=True)
+        leg = make_leg_colorlut(w, args, args.content)
+    else:
+        leg = make_leg_videofx(w, args)
+    r = measure_leg(w, leg, args.steps, args.warmup, args.settle_seconds, args.pct_steps, 0 if args.no_cpu_baseline else args.other_cpu_seconds)
+    if args.workload == "colorlut" and args.stream_threads > 0:
+        r["config"]["other_launch_model"] = leg.streams_leg()
+    r.update({"n_gpus": w.world, "higher_is_better": True, "vs_baseline": None})
+    r["config"].update({"parallelism": f"{w.world} independent streams", "rccl_ranks": w.rccl_ranks})
+    if w.rank == 0:
+        print(json.dumps(r), flush=True)
     w.finish()
 
 
@@ -637,7 +968,10 @@ def hsvfilter_main(args):
             vfx.make_frame(frames[b, i].data_ptr(), W4K, H4K, W4K * 4, "RGBA") for i in range(args.batch)])
         frame_arrays.append(arr)
 
+    n_launches = [0]
+
     def launch(batch_index):
+        n_launches[0] += 1
         rc = lib.mvfx_hsvfilter_transform_frames_ip(frame_arrays[batch_index], args.batch, ctypes.byref(settings), sptr)
         if rc != 0:
             raise RuntimeError(f"mvfx status {rc}: {vfx.last_error()}")
@@ -665,17 +999,25 @@ def hsvfilter_main(args):
     settle_steps, elapsed, kernel_ms = batch_leg()
     batch_fps_rank = w.gather(args.steps * args.batch / elapsed)
     batch_fps = args.steps * args.batch * world / elapsed
+    # per-launch spread (median + p10/p90 over >= 200 iterations): the launches continue through the pool with a HIP
+    # event between every two; launches beyond the first `pool` re-filter frames (videotestsrc bars stay bars)
+    launch_pct = percentiles(w.event_times(step, args.pct_steps, first_index=args.steps)) if args.pct_steps > 0 else None
 
     # ---- the element's launch model: --batch host threads x own HIP stream x single-frame calls -----------
     streams = None
-    bench_so = os.path.join(ROOT, "gst-plugin-rs_amd", "libmvfxbench.so")
     if args.stream_threads > 0:
-        hb = ctypes.CDLL(bench_so)  # raises when the harness was not built (build() builds it)
+        hb = bench_harness()
         nthr = args.stream_threads
         fpt = max(2, (pool * args.batch) // nthr)          # frames per thread, all from the resident pool
         flat = (vfx.Frame * (nthr * fpt))(*[
             vfx.make_frame(frames[(k // args.batch) % pool, k % args.batch].data_ptr(), W4K, H4K, W4K * 4, "RGBA")
             for k in range(nthr * fpt)])
+        # warm-up on the scratch batches (as the batch leg): the timed launches start on pool frames that have been through the
+        # filter as often as the batch leg left them, not ~70 more times
+        wfpt = max(1, (n_scratch * args.batch) // nthr)
+        warm = (vfx.Frame * (nthr * wfpt))(*[
+            vfx.make_frame(frames[pool + (k // args.batch) % n_scratch, k % args.batch].data_ptr(), W4K, H4K, W4K * 4, "RGBA")
+            for k in range(nthr * wfpt)])
         # at least 200 launches per thread: the K x batch frames of the batch leg (320 at the driver's K=20) would be ~20
         # launches per thread = 5 ms, dominated by thread wake-up skew
         launches = max(200, args.steps * args.batch // nthr)
@@ -686,8 +1028,8 @@ def hsvfilter_main(args):
         per = (ctypes.c_double * nthr)()
         w.sync()
         w.barrier()
-        rc = hb.mvfxbench_hsvfilter_streams(w.local_rank, nthr, stream_warmup, launches, reps, flat, fpt, ctypes.byref(settings),
-                                            opts, secs, per)
+        rc = hb.mvfxbench_hsvfilter_streams_warm(w.local_rank, nthr, stream_warmup, launches, reps, flat, fpt, 1, warm, wfpt,
+                                                 ctypes.byref(settings), opts, secs, per)
         if rc != 0:
             raise RuntimeError(f"mvfxbench status {rc}: {vfx.last_error()}")
         w.barrier()
@@ -695,16 +1037,13 @@ def hsvfilter_main(args):
         (s_elapsed,) = w.max_over_ranks(rep_secs[reps // 2])
         s_fps = nthr * launches * world / s_elapsed
         streams = {"launch_model": f"{nthr} threads x 1 frame (own HIP stream each, single-frame mvfx_hsvfilter_transform_frame_ip, "
-                                   "no sync between launches)",
+                                   "no sync between launches; warm-up on scratch frames)",
                    "value": s_fps, "unit": "frames/s", "frames": nthr * launches, "launches_per_thread": launches,
                    "warmup_launches_per_thread": stream_warmup, "seconds": s_elapsed, "statistic": "median of 5 repetitions",
-                   "achieved_GBs": s_fps / world * 2 * FRAME_BYTES / 1e9, "frac": s_fps / world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS,
+                   "achieved_GBs": s_fps / world * 2 * FRAME_BYTES / 1e9, "frac_wall": s_fps / world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS,
                    "repetitions_frames_per_sec": [round(nthr * launches / t) for t in secs],
                    "per_rank_frames_per_sec": w.gather(nthr * launches / rep_secs[reps // 2])}
 
-    # measured after the timed legs: a burst of plain copies between settle and the timed steps leaves the governor in another
-    # power state (the timed kernels then ran 3-4 % slower: profiles/r2/ab_fresh_vs_converged_data.txt)
-    ceiling = measured_copy_ceiling(w)
     # ---- the same batch leg on the other frame contents: the kernel has no data-dependent branch, but the chip is power
     # limited on this kernel and the bytes decide how much the data paths toggle (tools/exp_content_power.py) -------------
     sweep = {}
@@ -715,22 +1054,22 @@ def hsvfilter_main(args):
             fill_frames(torch, dev, gen, flat_frames, kind, W4K, H4K, first_frame=rank * flat_frames.shape[0])
             _, sw_secs, sw_ms = batch_leg()
             sweep[kind] = {"value": args.steps * args.batch * world / sw_secs, "unit": "frames/s", "avg_launch_ms": sw_ms,
-                           "frac": args.batch * 2 * FRAME_BYTES / (sw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "data": CONTENT_TEXT[kind]}
-    # HBM traffic per launch from the committed rocprofv3 PMC passes (cannot be collected live)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "hsvfilter_traffic.json")) as f:
-            t = json.load(f)
-        traffic = t["hbm_bytes_per_launch"] * args.batch / t["frames_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+                           "frac_kernel": args.batch * 2 * FRAME_BYTES / (sw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "frac_wall": args.steps * args.batch * 2 * FRAME_BYTES / sw_secs / 1e9 / HBM_PEAK_GBS, "data": CONTENT_TEXT[kind]}
+    # measured after the timed legs: a burst of other kernels between settle and the timed steps leaves the governor in another
+    # power state (the timed kernels then ran 3-4 % slower: profiles/r2/ab_fresh_vs_converged_data.txt)
+    settle(scratch_step, min(args.settle_seconds, 0.3), w.sync)
+    ceiling = measured_rmw_ceiling(w, frames.data_ptr(), args.batch * FRAME_BYTES, pool + n_scratch)
+    traffic, traffic_source = committed_traffic("hsvfilter", args.batch)
     bytes_per_launch = args.batch * 2 * FRAME_BYTES  # 4 B read + 4 B written per pixel
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    achieved_wall = batch_fps / world * 2 * FRAME_BYTES / 1e9
     batch_model = {"launch_model": f"1 launch x {args.batch} frames (mvfx_hsvfilter_transform_frames_ip, blockIdx.z = stream)",
                    "value": batch_fps, "unit": "frames/s", "per_rank_frames_per_sec": batch_fps_rank}
     use_streams = args.launch_model == "streams" and streams is not None
     head, other = (streams, batch_model) if use_streams else (batch_model, streams)
     total_frames = args.steps * args.batch * world
+    ceil_gbs = ceiling["in_place_nt"]["GBs"]
     out = {
         "metric": "hsvfilter_4k_rgba_frames_per_sec",
         "value": head["value"],
@@ -750,7 +1089,7 @@ def hsvfilter_main(args):
                                "saturation-off=-0.05 value-mul=0.9 value-off=0.02",
                    "frame_content": args.frame_content, "other_frame_contents": sweep,
                    "launch_model": head["launch_model"], "other_launch_model": other,
-                   "frames_per_step_per_gpu": args.batch, "resident_batches": pool,
+                   "frames_per_step_per_gpu": args.batch, "resident_batches": pool, "steps_executed": n_launches[0],
                    "settle_seconds_before_warmup": args.settle_seconds, "settle_steps": settle_steps,
                    "parallelism": f"{world} independent stream shards, no data-path collective",
                    "rccl_ranks": w.rccl_ranks, "per_rank_frames_per_sec": head["per_rank_frames_per_sec"],
@@ -758,15 +1097,35 @@ def hsvfilter_main(args):
                    "cache_policy": "non-temporal (MVFX_OPT_NONTEMPORAL)" if args.streaming else "default",
                    "u8_to_unit_float": "typed buffer loads (texture-unit UNORM8, exact)" if args.typed_loads else "VALU (cvt + mul + fmac)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "frac_kernel": achieved / HBM_PEAK_GBS,
+                     "frac_wall": achieved_wall / HBM_PEAK_GBS, "achieved_wall": achieved_wall,
+                     "frac_note": "frac = frac_kernel: algorithmic bytes per launch / average launch duration between two HIP events on "
+                                  "the launch stream over the K timed launches; frac_wall: the same bytes / the wall clock `value` is made of",
+                     "traffic": traffic, "traffic_source": traffic_source,
+                     "traffic_over_algorithmic": traffic / bytes_per_launch if traffic else None,
                      "kernel": "hsvfilter4_typed_kernel" if args.typed_loads else "hsvfilter4_kernel<RGBA, vec4>", "bytes_per_launch": bytes_per_launch,
-                     "avg_launch_ms": kernel_ms, "read_side_GBs": achieved / 2,
-                     "ceiling_measured_GBs": ceiling, "frac_of_measured_ceiling": achieved / ceiling if ceiling else None,
-                     "ceiling_note": "torch device-to-device copy of 1 GiB (read + write bytes) timed with HIP events in this run",
+                     "avg_launch_ms": kernel_ms, "launch_us": launch_pct, "read_side_GBs": achieved / 2,
+                     "ceiling_measured_GBs": ceil_gbs, "frac_of_measured_ceiling": achieved / ceil_gbs if ceil_gbs else None,
+                     "ceilings": ceiling,
+                     "ceiling_note": "in-tree RMW probe (gst-plugin-rs_amd/bench/probe_rmw.hip): the kernel's own memory shape -- one 16-byte "
+                                     "non-temporal load + store per lane, in place, trivial arithmetic -- over the same resident pool, timed with "
+                                     "HIP events in this run after the timed legs; in_place_cached / out_of_place_nt are the shapes of the other filters",
                      "launch_model": batch_model["launch_model"]},
     }
+    del frames, flat_frames, frame_arrays
+    torch.cuda.empty_cache()
+    if args.other_configs and world == 1:
+        vfx.check(lib.mvfx_thread_set_options(0))
+        out["config"]["other_configs"] = other_config_legs(w, args)
+    elif args.other_configs and world > 1:
+        # the one workload with a data-path collective, on the real xGMI fabric: 8K pairs band-sharded over the ranks
+        vfx.check(lib.mvfx_thread_set_options(0))
+        try:
+            out["config"]["other_configs"] = {"videocompare_blockhash_sharded": videocompare_sharded_leg(w, args, "blockhash", 200, 20)}
+        except Exception as e:
+            out["config"]["other_configs"] = {"videocompare_blockhash_sharded": {"error": f"{type(e).__name__}: {e}"}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.frame_content)
+        out["cpu_baseline"] = cpu_baseline_hsvfilter(args.cpu_seconds, args.frame_content)
     if rank == 0:
         print(json.dumps(out), flush=True)
     w.finish()
@@ -793,6 +1152,13 @@ def main():
                          "clocks higher: profiles/r2/ab_fresh_vs_converged_data.txt). Default 0 = fresh uniform-random frames")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget per leg (1 thread, then nproc threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--other-configs", type=int, default=1, choices=[0, 1],
+                    help="hsvfilter workload: after the headline legs also measure BASELINE configs 2-5 in this run "
+                         "(config.other_configs); N > 1: the band-sharded videocompare leg with its RCCL all-reduce")
+    ap.add_argument("--other-cpu-seconds", type=float, default=2.5, help="CPU baseline budget per leg of configs 2-5")
+    ap.add_argument("--other-settle-seconds", type=float, default=0.3, help="untimed run before each leg of configs 2-5")
+    ap.add_argument("--pct-steps", type=int, default=200,
+                    help="extra steps with a HIP event between every two, for the p10/p50/p90 of the per-step time (0 = skip)")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 literal kernel, 2 strength-reduced")
     ap.add_argument("--streaming", type=int, default=1,
                     help="MVFX_OPT_NONTEMPORAL: 1 = non-temporal loads/stores (the frames of this workload are not "
@@ -823,6 +1189,8 @@ def main():
                          "(hsvfilter + hsvdetector 1920x1080); colorlut = config 3 (33^3 cube, 4K); videofx = config 4 "
                          "(roundedcorners compose + colordetect, one 4K stream per GPU); videocompare = config 5")
     args = ap.parse_args()
+    if args.no_cpu_baseline:
+        args.other_cpu_seconds = 0.0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_workers(args, sys.argv[1:])  # the parent never touches the GPU
     if args.workload == "videocompare":

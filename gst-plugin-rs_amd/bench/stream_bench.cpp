@@ -50,19 +50,25 @@ extern "C" {
 // `batch` frames per launch (mvfx_hsvfilter_transform_frames_ip; 1 = the single-frame entry point): thread t walks its
 // frames in groups of `batch` (frames_per_thread must be a multiple of it) -- the "few threads, each batching the streams it
 // owns" model between the two extremes bench.py reports.
-int mvfxbench_hsvfilter_streams_batched(int device, uint32_t n_threads, uint32_t warmup, uint32_t launches, uint32_t reps,
-                                        const mvfx_frame *frames, uint32_t frames_per_thread, uint32_t batch,
-                                        const mvfx_hsvfilter_settings *settings, uint32_t options, double *seconds_out,
-                                        double *thread_seconds)
+//
+// `warm_frames` (may be NULL): warm_frames_per_thread scratch frames per thread for the warm-up launches, so that the timed
+// launches start on frames no kernel has touched (frames that went through the filter many times are low-entropy, the chip
+// draws less power on them and clocks higher: profiles/r2/exp_content_power.txt).  NULL = warm up on the timed frames.
+int mvfxbench_hsvfilter_streams_warm(int device, uint32_t n_threads, uint32_t warmup, uint32_t launches, uint32_t reps,
+                                     const mvfx_frame *frames, uint32_t frames_per_thread, uint32_t batch,
+                                     const mvfx_frame *warm_frames, uint32_t warm_frames_per_thread,
+                                     const mvfx_hsvfilter_settings *settings, uint32_t options, double *seconds_out,
+                                     double *thread_seconds)
 {
     if (!frames || !settings || !seconds_out || n_threads == 0 || frames_per_thread == 0 || reps == 0 || batch == 0 ||
-        frames_per_thread % batch != 0)
+        frames_per_thread % batch != 0 || (warm_frames && (warm_frames_per_thread == 0 || warm_frames_per_thread % batch != 0)))
         return MVFX_ERR_INVALID_ARGUMENT;
     const uint32_t groups = frames_per_thread / batch;
-    auto launch = [&](const mvfx_frame *mine, uint32_t i, mvfx_stream st) {
-        const mvfx_frame *f = mine + (size_t)(i % groups) * batch;
+    auto launch_in = [&](const mvfx_frame *mine, uint32_t n_groups, uint32_t i, mvfx_stream st) {
+        const mvfx_frame *f = mine + (size_t)(i % n_groups) * batch;
         return batch == 1 ? mvfx_hsvfilter_transform_frame_ip(f, settings, st) : mvfx_hsvfilter_transform_frames_ip(f, batch, settings, st);
     };
+    auto launch = [&](const mvfx_frame *mine, uint32_t i, mvfx_stream st) { return launch_in(mine, groups, i, st); };
     SpinBarrier ready(n_threads + 1), go(n_threads + 1), done(n_threads + 1);
     std::vector<int> status(n_threads, MVFX_OK);
     std::vector<double> span(n_threads, 0.0);
@@ -73,15 +79,17 @@ int mvfxbench_hsvfilter_streams_batched(int device, uint32_t n_threads, uint32_t
             if (rc == MVFX_OK) rc = mvfx_thread_set_options(options);
             mvfx_stream st = mvfx_thread_stream();
             const mvfx_frame *mine = frames + (size_t)t * frames_per_thread;
+            const mvfx_frame *warm = warm_frames ? warm_frames + (size_t)t * warm_frames_per_thread : mine;
+            const uint32_t warm_groups = warm_frames ? warm_frames_per_thread / batch : groups;
             for (uint32_t i = 0; i < warmup && rc == MVFX_OK; i++)
-                rc = launch(mine, i, st);
+                rc = launch_in(warm, warm_groups, i, st);
             if (rc == MVFX_OK) rc = mvfx_stream_synchronize(st);
             ready.wait();
             for (uint32_t r = 0; r < reps; r++) {
                 go.wait();
                 const double t0 = now_s();
                 for (uint32_t i = 0; i < launches && rc == MVFX_OK; i++)
-                    rc = launch(mine, warmup + i, st);
+                    rc = launch(mine, r * launches + i, st);
                 if (rc == MVFX_OK) rc = mvfx_stream_synchronize(st);
                 span[t] = now_s() - t0;
                 done.wait();
@@ -102,6 +110,15 @@ int mvfxbench_hsvfilter_streams_batched(int device, uint32_t n_threads, uint32_t
         if (status[t] != MVFX_OK) return status[t];
     }
     return MVFX_OK;
+}
+
+int mvfxbench_hsvfilter_streams_batched(int device, uint32_t n_threads, uint32_t warmup, uint32_t launches, uint32_t reps,
+                                        const mvfx_frame *frames, uint32_t frames_per_thread, uint32_t batch,
+                                        const mvfx_hsvfilter_settings *settings, uint32_t options, double *seconds_out,
+                                        double *thread_seconds)
+{
+    return mvfxbench_hsvfilter_streams_warm(device, n_threads, warmup, launches, reps, frames, frames_per_thread, batch, nullptr, 0,
+                                            settings, options, seconds_out, thread_seconds);
 }
 
 int mvfxbench_hsvfilter_streams(int device, uint32_t n_threads, uint32_t warmup, uint32_t launches, uint32_t reps, const mvfx_frame *frames,

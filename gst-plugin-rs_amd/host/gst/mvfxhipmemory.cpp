@@ -14,7 +14,10 @@ typedef struct {
     gint cpu_maps;
     GMutex lock;
     // the fence of the buffer (d3d12colorlut/imp.rs:695-714 keeps an ID3D12Fence value on the output memory): recorded by
-    // the last stream that enqueued work on the block; the next user makes its stream wait for it, a CPU map waits on the host
+    // the last stream that enqueued work on the block; the next user makes its stream wait for it, a CPU map waits on the host.
+    // Releases CHAIN: a stream that records while another stream's record is still pending first waits for that one (device
+    // side), so that the single event always covers every user so far -- two readers of one buffer behind a `tee` on two
+    // streaming threads must both have finished before a recycled block is written again.
     mvfx_event last_use;
     gboolean pending;
 } MvfxHipMemory;
@@ -52,18 +55,33 @@ static gboolean freelist_take(gsize size, int device, void **dptr, mvfx_event *e
     return found;
 }
 
-static gboolean freelist_give(void *dptr, gsize size, int device, mvfx_event ev, gboolean pending)
+static void release_block(void *dptr, mvfx_event ev, gboolean pending)
 {
-    gboolean kept = FALSE;
+    if (pending && ev) mvfx_event_synchronize(ev);
+    mvfx_device_free(dptr);
+    if (ev) mvfx_event_destroy(ev);
+}
+
+// Always keeps the block: when the list is full the OLDEST entry is evicted and freed (sizes of a previous negotiation would
+// otherwise occupy the slots for the rest of the process and send every later free down the device-synchronising hipFree path).
+static void freelist_give(void *dptr, gsize size, int device, mvfx_event ev, gboolean pending)
+{
+    static guint next_victim = 0;
+    void *old_dptr = NULL;
+    mvfx_event old_ev = NULL;
+    gboolean old_pending = FALSE;
     g_mutex_lock(&freelist_lock);
-    for (int i = 0; i < MVFX_FREELIST_MAX && !kept; i++)
-        if (!freelist[i].dptr) {
-            freelist[i].dptr = dptr; freelist[i].size = size; freelist[i].device = device;
-            freelist[i].last_use = ev; freelist[i].pending = pending;
-            kept = TRUE;
-        }
+    int slot = -1;
+    for (int i = 0; i < MVFX_FREELIST_MAX && slot < 0; i++)
+        if (!freelist[i].dptr) slot = i;
+    if (slot < 0) {
+        slot = (int)(next_victim++ % MVFX_FREELIST_MAX);
+        old_dptr = freelist[slot].dptr; old_ev = freelist[slot].last_use; old_pending = freelist[slot].pending;
+    }
+    freelist[slot].dptr = dptr; freelist[slot].size = size; freelist[slot].device = device;
+    freelist[slot].last_use = ev; freelist[slot].pending = pending;
     g_mutex_unlock(&freelist_lock);
-    return kept;
+    if (old_dptr) release_block(old_dptr, old_ev, old_pending);
 }
 
 void mvfx_hip_allocator_trim(void)
@@ -71,9 +89,7 @@ void mvfx_hip_allocator_trim(void)
     g_mutex_lock(&freelist_lock);
     for (int i = 0; i < MVFX_FREELIST_MAX; i++)
         if (freelist[i].dptr) {
-            if (freelist[i].pending) mvfx_event_synchronize(freelist[i].last_use);
-            mvfx_device_free(freelist[i].dptr);
-            mvfx_event_destroy(freelist[i].last_use);
+            release_block(freelist[i].dptr, freelist[i].last_use, freelist[i].pending);
             freelist[i].dptr = NULL;
         }
     g_mutex_unlock(&freelist_lock);
@@ -106,11 +122,7 @@ static GstMemory *mvfx_hip_alloc(GstAllocator *allocator, gsize size, GstAllocat
 static void mvfx_hip_free(GstAllocator *, GstMemory *mem)
 {
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
-    if (!freelist_give(m->dptr, mem->maxsize, m->device, m->last_use, m->pending)) {
-        if (m->pending) mvfx_event_synchronize(m->last_use);
-        mvfx_device_free(m->dptr);
-        mvfx_event_destroy(m->last_use);
-    }
+    freelist_give(m->dptr, mem->maxsize, m->device, m->last_use, m->pending);
     g_free(m->shadow);
     g_mutex_clear(&m->lock);
     g_free(m);
@@ -133,6 +145,10 @@ void mvfx_hip_memory_release(GstMemory *mem, mvfx_stream stream)
     g_mutex_lock(&m->lock);
     if (!m->last_use && mvfx_event_create(&m->last_use) != MVFX_OK)
         m->last_use = NULL;
+    // chain onto the fence another user may have left since our acquire (a second reader behind a tee): this stream waits
+    // for it on the device, so the record below covers that user too; a no-op when the pending record is this stream's own
+    if (m->last_use && m->pending)
+        mvfx_stream_wait_event(stream, m->last_use);
     if (m->last_use && mvfx_event_record(m->last_use, stream) == MVFX_OK)
         m->pending = TRUE;
     else
@@ -348,9 +364,19 @@ static GstFlowReturn mvfx_hip_pool_acquire_buffer(GstBufferPool *pool, GstBuffer
     return ret;
 }
 
+// The pool's buffers go back to the allocator (its free list) when the pool stops; nothing of that size may be asked for again
+// (caps change, READY -> NULL): give the blocks back to the device.
+static gboolean mvfx_hip_pool_stop(GstBufferPool *pool)
+{
+    const gboolean ok = GST_BUFFER_POOL_CLASS(mvfx_hip_buffer_pool_parent_class)->stop(pool);
+    mvfx_hip_allocator_trim();
+    return ok;
+}
+
 static void mvfx_hip_buffer_pool_class_init(MvfxHipBufferPoolClass *klass)
 {
     GstBufferPoolClass *pc = GST_BUFFER_POOL_CLASS(klass);
+    pc->stop = mvfx_hip_pool_stop;
     pc->get_options = mvfx_hip_pool_get_options;
     pc->set_config = mvfx_hip_pool_set_config;
     pc->alloc_buffer = mvfx_hip_pool_alloc_buffer;

@@ -418,6 +418,31 @@ def test_hiptestsrc_device_frames_are_refreshed_although_hsvfilter_works_in_plac
     assert bad == []
 
 
+def test_hipmemory_tee_two_device_readers_on_recycled_blocks(gpu, tmp_path):
+    """One device buffer read by TWO elements on two streaming threads (tee ! queue ! hsvdetector, twice): both readers release
+    the block's fence; the release of the second chains onto the first's, so the source's next refresh + the in-place hsvfilter
+    of the recycled block wait for BOTH kernels (a fence that only remembered the later reader let the block be overwritten
+    under the other one).  40 frames at 1080p from a small pool; both branches must equal the oracle on every frame."""
+    w, h, n = 1920, 1080, 40
+    raw = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBx,width={w},height={h}", "in.raw")
+    det = [(120.0, 60.0, 0.6, 0.4, 0.6, 0.4), (300.0, 80.0, 0.5, 0.5, 0.5, 0.5)]
+    branch = ("t. ! queue max-size-buffers=3 ! hsvdetector hue-ref={0} hue-var={1} saturation-ref={2} saturation-var={3} value-ref={4} "
+              "value-var={5} ! video/x-raw(memory:HIPMemory),format=RGBA ! hipdownload ! filesink location={6}")
+    r = gst_env.run([LAUNCH, "-q"] + (f"hiptestsrc num-buffers={n} ! video/x-raw(memory:HIPMemory),format=RGBx,width={w},height={h},framerate=30/1 ! "
+                    "hsvfilter hue-shift=45 ! tee name=t " + branch.format(*det[0], f"{tmp_path}/a.raw") + " " +
+                    branch.format(*det[1], f"{tmp_path}/b.raw")).split(), tmp_path)
+    assert r.returncode == 0, r.stdout
+    mid = raw.copy().reshape(h, w * 4)
+    orc.hsvfilter(mid, w, w * 4, "RGBx", (45.0, 1.0, 0.0, 1.0, 0.0))
+    for name, settings in zip(("a.raw", "b.raw"), det):
+        got = np.fromfile(f"{tmp_path}/{name}", dtype=np.uint8).reshape(n, h, w * 4)
+        exp = np.empty_like(mid)
+        orc.hsvdetector(mid, w * 4, "RGBx", exp, w * 4, "RGBA", w, settings)
+        assert 0 < np.count_nonzero(exp[:, 3::4]) < exp[:, 3::4].size
+        bad = [k for k in range(n) if not np.array_equal(got[k], exp)]
+        assert bad == [], f"{name}: frames {bad} differ"
+
+
 # ---- imagersoverlay (SURVEY 8f-4): PNG logo blended by the HIP kernel, positions per overlay/imp.rs:84-191
 def _logo_png(path, w=48, h=32):
     from PIL import Image
