@@ -47,15 +47,17 @@ OPT_HSV_LITERAL = 0x02
 OPT_HSV_FORCE_FAST = 0x04
 OPT_HSV_VALU_UNORM = 0x08
 OPT_LUT_PLACEMENT_SHIFT = 4
+OPT_SSIM_F64 = 0x80
 
 
 class options:
     """``with vfx.options(variant=1, typed=False): ...`` -- sets the calling thread's kernel options
     (mvfx_thread_set_options) for the block and restores the previous word.  variant: 0 auto, 1 literal,
-    2 force strength-reduced; placement: colorlut LUT placement 0..4."""
+    2 force strength-reduced; placement: colorlut LUT placement 0..5 (include/mi355vfx.h: 0 auto, 1 node layout in global/L2,
+    2 LDS, 3 cell-packed global, 4 literal kernels, 5 tile kernel)."""
 
-    def __init__(self, variant=0, nontemporal=False, typed=True, placement=0):
-        self.word = ((OPT_NONTEMPORAL if nontemporal else 0) | (OPT_HSV_LITERAL if variant == 1 else 0) |
+    def __init__(self, variant=0, nontemporal=False, typed=True, placement=0, ssim_f64=False):
+        self.word = ((OPT_SSIM_F64 if ssim_f64 else 0) | (OPT_NONTEMPORAL if nontemporal else 0) | (OPT_HSV_LITERAL if variant == 1 else 0) |
                      (OPT_HSV_FORCE_FAST if variant == 2 else 0) | (0 if typed else OPT_HSV_VALU_UNORM) |
                      (placement << OPT_LUT_PLACEMENT_SHIFT))
 
@@ -161,6 +163,7 @@ SIGNATURES = {
     "mvfx_overlay_blend": (c_int, [POINTER(Frame), POINTER(Frame), c_int32, c_int32, c_float, c_void_p]),
     "mvfx_overlay_blend_host": (c_int, [POINTER(Frame), POINTER(Frame), c_int32, c_int32, c_float]),
     "mvfx_colordetect_histogram": (c_int, [POINTER(Frame), c_uint32, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
+    "mvfx_colordetect_histogram_frames": (c_int, [POINTER(Frame), c_uint32, c_uint32, c_void_p, c_void_p]),
     "mvfx_mmcq_palette_from_histogram": (c_int, [c_void_p, POINTER(c_uint32), c_uint32, POINTER(c_uint32), POINTER(c_uint32)]),
     "mvfx_colordetect_palette": (c_int, [POINTER(Frame), c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_uint32), c_void_p]),
     "mvfx_colordetect_palette_host": (c_int, [POINTER(Frame), c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_uint32)]),
@@ -173,6 +176,14 @@ SIGNATURES = {
     "mvfx_blockhash": (c_int, [POINTER(Frame), POINTER(c_uint64), c_void_p]),
     "mvfx_blockhash_host": (c_int, [POINTER(Frame), POINTER(c_uint64)]),
     "mvfx_videocompare_distance": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(ctypes.c_double), c_void_p]),
+    "mvfx_comm_unique_id": (c_int, [c_void_p]),
+    "mvfx_comm_create": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "mvfx_comm_destroy": (c_int, [c_void_p]),
+    "mvfx_comm_rank": (c_int, [c_void_p]),
+    "mvfx_comm_world": (c_int, [c_void_p]),
+    "mvfx_comm_allreduce": (c_int, [c_void_p, c_void_p, c_size_t, c_int32, c_int32, c_void_p]),
+    "mvfx_videocompare_sharded_distances": (c_int, [c_void_p, POINTER(Frame), c_uint32, c_uint32, c_uint32, POINTER(ctypes.c_double),
+                                                    POINTER(c_uint64), c_void_p]),
     "mvfx_image_hash": (c_int, [POINTER(Frame), ctypes.c_int32, POINTER(c_uint64), POINTER(c_uint32), c_void_p]),
     "mvfx_image_hash_host": (c_int, [POINTER(Frame), ctypes.c_int32, POINTER(c_uint64), POINTER(c_uint32)]),
     "mvfx_image_gray_resize_lanczos3": (c_int, [POINTER(Frame), c_uint32, c_uint32, c_void_p, c_void_p]),
@@ -364,6 +375,7 @@ class CubeLut:
 
 
 ALL_SAMPLES = (1 << 64) - 1
+COLORDETECT_RECORD_WORDS = 32768 + 8
 
 
 def colordetect_palette_host(frame_bytes, width, height, stride, fmt, quality=10, max_colors=2):
@@ -392,6 +404,45 @@ def make_i420(base_ptr: int, width: int, height: int, y_stride: int, c_stride: i
     f.stride[0], f.stride[1], f.stride[2] = y_stride, c_stride, c_stride
     f.width, f.height, f.format = width, height, FORMATS["I420"]
     return f
+
+
+DTYPE_U32, DTYPE_U64, DTYPE_F64 = 0, 1, 2
+REDUCE_SUM, REDUCE_MIN, REDUCE_MAX = 0, 1, 2
+
+
+class Comm:
+    """mvfx_comm: the library's own RCCL communicator (one process per GPU).  `broadcast_id(id_bytes_or_None) -> bytes` hands rank 0's
+    128-byte id to every rank (torch.distributed.broadcast_object_list in the bench, a file in the tests)."""
+
+    def __init__(self, rank: int, world: int, broadcast_id):
+        ident = None
+        if rank == 0:
+            buf = (ctypes.c_uint8 * 128)()
+            check(lib().mvfx_comm_unique_id(buf))
+            ident = bytes(buf)
+        ident = broadcast_id(ident)
+        h = c_void_p()
+        check(lib().mvfx_comm_create((ctypes.c_uint8 * 128).from_buffer_copy(ident), rank, world, ctypes.byref(h)))
+        self.h, self.rank, self.world = h, rank, world
+
+    def allreduce(self, ptr: int, count: int, dtype=DTYPE_U32, op=REDUCE_SUM, stream=None):
+        check(lib().mvfx_comm_allreduce(self.h, c_void_p(ptr), count, dtype, op, stream))
+
+    def destroy(self):
+        if getattr(self, "h", None):
+            lib().mvfx_comm_destroy(self.h)
+            self.h = None
+
+
+def videocompare_sharded_distances(comm, bands, full_height, band_first_row, stream=None, want_hashes=False):
+    """bands: ctypes array of Frame, this rank's rows of every pad's frame -> distances of pads 1.. to pad 0 (and the hashes)"""
+    n = len(bands)
+    out = (ctypes.c_double * max(n - 1, 1))()
+    hashes = (c_uint64 * n)() if want_hashes else None
+    check(lib().mvfx_videocompare_sharded_distances(comm.h if comm is not None else None, bands, n, full_height, band_first_row, out,
+                                                    hashes, stream))
+    d = [out[i] for i in range(n - 1)]
+    return (d, [hashes[i] for i in range(n)]) if want_hashes else d
 
 
 HASH_ALGOS = {"mean": 0, "gradient": 1, "vertgradient": 2, "doublegradient": 3, "blockhash": 4, "dssim": 5}

@@ -17,13 +17,22 @@ struct Scratch {
     void *ptr = nullptr;
     size_t cap = 0;
 };
-constexpr int kScratchSlots = 6; // 0-3: staging of the *_host entry points and small results; 5: colordetect's per-XCD tables (fixed size, never regrown)
+constexpr int kScratchSlots = 6; // 0-3: staging of the *_host entry points and small results (4, 5: free)
+constexpr int kStreamScratch = 8; // scratch blocks keyed by the stream the work is enqueued on (stream_scratch)
 
 // Per-thread, per-device staging state of the *_host entry points (a thread that switches devices with
 // mvfx_set_device gets a separate stream and scratch set for each ordinal); released when the thread (e.g. a
 // GStreamer streaming thread) exits so pipelines that come and go do not leak device memory.
+struct StreamScratch {
+    hipStream_t stream = nullptr;
+    Scratch block;
+    uint64_t last_use = 0;
+    bool used = false;
+};
 struct DeviceState {
     Scratch scratch[kScratchSlots];
+    StreamScratch by_stream[kStreamScratch];
+    uint64_t tick = 0;
     hipStream_t stream = nullptr;
     bool stream_tried = false;
 };
@@ -40,6 +49,8 @@ struct ThreadState {
         for (auto &kv : per_device) {
             for (Scratch &s : kv.second.scratch)
                 if (s.ptr) (void)hipFree(s.ptr);
+            for (StreamScratch &s : kv.second.by_stream)
+                if (s.block.ptr) (void)hipFree(s.block.ptr);
             if (kv.second.stream) (void)hipStreamDestroy(kv.second.stream);
         }
     }
@@ -102,6 +113,41 @@ int host_scratch(size_t bytes, int slot, void **out)
             s.cap = 0;
         }
         const size_t want = bytes + (bytes >> 2); // head-room for the next, slightly larger, frame
+        hipError_t e = hipMalloc(&s.ptr, want);
+        if (e != hipSuccess)
+            return fail(MVFX_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        s.cap = want;
+    }
+    *out = s.ptr;
+    return MVFX_OK;
+}
+
+// Scratch for kernels that hand intermediate results from one launch to the next on `stream` (colordetect's partial
+// histograms): one block per (thread, device, stream), so two asynchronous calls of one thread on different streams never
+// share a block; a block only grows (hipFree synchronises the device, so work in flight on the old block is over before it goes).
+int stream_scratch(hipStream_t stream, size_t bytes, void **out)
+{
+    DeviceState &d = t_state.current();
+    StreamScratch *slot = nullptr, *free_slot = nullptr, *lru = nullptr;
+    for (StreamScratch &s : d.by_stream) {
+        if (s.used && s.stream == stream) { slot = &s; break; }
+        if (!s.used) { if (!free_slot) free_slot = &s; }
+        else if (!lru || s.last_use < lru->last_use) lru = &s;
+    }
+    if (!slot) { // an unused block, else the least recently used one takes over (its memory is kept if large enough)
+        slot = free_slot ? free_slot : lru;
+        slot->stream = stream;
+        slot->used = true;
+    }
+    slot->last_use = ++d.tick;
+    Scratch &s = slot->block;
+    if (s.cap < bytes) {
+        if (s.ptr) {
+            MVFX_HIP_TRY(hipFree(s.ptr));
+            s.ptr = nullptr;
+            s.cap = 0;
+        }
+        const size_t want = bytes + (bytes >> 2);
         hipError_t e = hipMalloc(&s.ptr, want);
         if (e != hipSuccess)
             return fail(MVFX_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
@@ -335,7 +381,7 @@ int mvfx_copy_device_to_device_async(void *dst_device, const void *src_device, s
 int mvfx_thread_set_options(uint32_t options)
 {
     const uint32_t known = MVFX_OPT_NONTEMPORAL | MVFX_OPT_HSV_LITERAL | MVFX_OPT_HSV_FORCE_FAST | MVFX_OPT_HSV_VALU_UNORM |
-                           MVFX_OPT_LUT_PLACEMENT_MASK;
+                           MVFX_OPT_LUT_PLACEMENT_MASK | MVFX_OPT_SSIM_F64;
     if (options & ~known)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options 0x%x: unknown bits 0x%x", options, options & ~known);
     if ((options & MVFX_OPT_HSV_LITERAL) && (options & MVFX_OPT_HSV_FORCE_FAST))

@@ -9,7 +9,7 @@
 //   global_store_dwordx4, so a wave64 touches 1 KiB contiguous per instruction; in launches of several frames a
 //   lane owns two such groups one workgroup-width apart and issues both loads before the arithmetic.  A frame
 //   whose stride equals width*4 is treated as ONE row of width*height pixels (no per-row tail).
-//   mvfx_hsvfilter_set_streaming(1) adds the non-temporal hint to those loads/stores.
+//   mvfx_thread_set_options(MVFX_OPT_NONTEMPORAL) adds the non-temporal hint to those loads/stores.
 //   3-byte formats: one lane owns 4 pixels = 12 bytes = global_load_dwordx3, rows stay
 //   dword-coalesced; the <4-pixel row tail is done bytewise by the owning lane.
 //   Frames that are not 16-byte (4-byte formats) / 4-byte (3-byte formats) aligned fall back to

@@ -58,6 +58,8 @@ inline int opt_lut_placement() { return (int)((thread_options() & MVFX_OPT_LUT_P
 // Grow-only device scratch used by the *_host entry points (one per thread and device).
 int host_scratch(size_t bytes, int slot, void **out);
 hipStream_t host_stream();
+// Grow-only device scratch keyed by (thread, device, stream): intermediate results handed from one launch to the next on `stream`.
+int stream_scratch(hipStream_t stream, size_t bytes, void **out);
 
 constexpr int kMaxBatch = 32; // frames per launch of the batched entry points
 

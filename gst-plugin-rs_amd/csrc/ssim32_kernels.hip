@@ -1,0 +1,481 @@
+// f32 pipeline of the SSIM-family distance behind videocompare's `hash-algo=dssim` (round 3).
+//
+// dssim-core (the crate the reference calls, videocompare/hashed_image.rs:49-59,72-75) is an f32 library; round 2's
+// device path carried f64 planes through five kernel types: 8.7 GB of HBM traffic per 8K pair against 265 MB of compulsory
+// input (profiles/r3/traffic_summary.txt), 1.83 ms per pair.  This file keeps everything per pixel in f32 and in LDS /
+// registers, f64 only in the reductions:
+//
+//   one kernel per pyramid level (ssim32_level_kernel): a workgroup owns a 60 x 28 tile, fetches the 64 x 32 haloed source
+//   pixels of BOTH images (level 0: the frame bytes; level >= 1: the previous level's linear-RGB f32 planes), converts them
+//   to the Lab-like planes the metric runs on -- as (image A, image B) pairs, so the arithmetic is packed f32 on aligned
+//   VGPR pairs and the pairs go to LDS with one 8-byte store -- writes the 2x2 box average of the linear values as the
+//   next level's planes (the pyramid comes out of the same pass), then runs the separable 5x5 binomial window as a sliding
+//   window down each column: per row five 8-byte LDS reads and the horizontal sums of v1, v2 (packed), v1^2, v2^2 (packed)
+//   and v1 v2 in registers, a ring of five rows for the vertical sums; the SSIM term of the three channels is summed in
+//   registers and the map value written once (f32).  No Lab plane, no window sum ever goes to memory.
+//   HBM traffic per 8K pair: 2 x 133 MB of bytes (x1.2 halo re-reads, mostly L2 hits) + 2 x 100 MB of level-1 planes written
+//   and read + the f32 maps (133 + 33 + ... MB written, read once by the deviation pass).
+//
+//   Cancellation: var = E[x^2] - E[x]^2 loses digits in f32 when the window is flat and bright; every tile therefore
+//   subtracts a per-tile, per-channel constant (image A's value at the tile centre) before squaring -- the variance and
+//   covariance are invariant, the means get it added back.
+//
+//   Identical frames give exactly 0: both lanes of every packed operation see the same bits, v1 v2 is computed with the
+//   same operations in the same order as v1^2, numerator and denominator of the SSIM term are then bit-identical, and the
+//   quotient is a Newton-corrected reciprocal product that returns exactly 1 for n == d; map values of exactly 1.0f sum
+//   exactly in f64, so mean = 1, deviation = 0, distance = 0 (tests/videocompare.rs:141-182).
+//
+// PARITY UNPINNED against the crate: the checker is oracle/ssim_oracle.c (f64); the f32 device value agrees with
+// it to ~1e-6 relative (tests/test_ssim_gpu.py states the tolerance per case).  No FMA contraction in this file: the fused
+// operations are written out, so the packed and the scalar lanes round alike.
+#include "mvfx_internal.h"
+#include "ssim32.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace mvfx {
+namespace ssim32 {
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int kTW = 60, kTH = 28;          // interior of a tile (outputs)
+constexpr int kRW = kTW + 4, kRH = kTH + 4; // haloed tile: 64 x 32
+constexpr int kThreads = 256;
+constexpr int kSegRows = 7, kSegs = kTH / kSegRows; // blur tasks: (column, segment of 7 rows), 240 of the 256 threads
+constexpr int kBlocksX = kRW / 2, kBlocksY = kRH / 2; // 2x2 pixel blocks of the haloed tile: 32 x 16 = 512, two per thread
+static_assert(kSegs * kSegRows == kTH && kTW * kSegs <= kThreads && kBlocksX * kBlocksY == 2 * kThreads, "tile shape");
+constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
+
+__device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// cbrt(t) for t in (216/24389, ~1.1]: exp2(log2(t) / 3) from the hardware transcendentals (relative error ~3e-7), one Newton step
+// r <- r - (r^3 - t) / (3 r^2) written division-free with y = t^(-1/3): y' = y (4 - t y^3) / 3, cbrt = t y'^2
+__device__ __forceinline__ float cbrt_unit(float t)
+{
+    float y = __builtin_amdgcn_exp2f(-0.33333334f * __builtin_amdgcn_logf(t)); // t^(-1/3)
+    const float y3 = y * y * y;
+    y = y * __builtin_fmaf(-0.33333334f * t, y3, 1.3333334f);
+    return t * (y * y);
+}
+
+__device__ __forceinline__ float lab_f(float t)
+{
+    const float eps = 216.0f / 24389.0f, kappa = 24389.0f / 27.0f;
+    const float lin = __builtin_fmaf(kappa, t, 16.0f) * (1.0f / 116.0f);
+    return t > eps ? cbrt_unit(t) : lin;
+}
+
+// linear RGB (premultiplied) of the same pixel of both images -> the three planes of both, as pairs (oracle: to_lab)
+__device__ __forceinline__ void to_lab2(f2 r, f2 g, f2 b, f2 out[3])
+{
+    const f2 X = fma2(splat(0.1805f), b, fma2(splat(0.3576f), g, splat(0.4124f) * r)) * splat(1.0f / 0.9505f);
+    const f2 Y = fma2(splat(0.0722f), b, fma2(splat(0.7152f), g, splat(0.2126f) * r));
+    const f2 Z = fma2(splat(0.9505f), b, fma2(splat(0.1192f), g, splat(0.0193f) * r)) * splat(1.0f / 1.089f);
+    const f2 fx = {lab_f(X.x), lab_f(X.y)}, fy = {lab_f(Y.x), lab_f(Y.y)}, fz = {lab_f(Z.x), lab_f(Z.y)};
+    out[0] = fma2(splat(1.16f), fy, splat(-0.16f));
+    out[1] = fma2(splat(500.0f / 220.0f), fx - fy, splat(86.2f / 220.0f));
+    out[2] = fma2(splat(200.0f / 220.0f), fy - fz, splat(107.9f / 220.0f));
+}
+
+struct LevelArgs {
+    // source of both images: MODE 0 / 1 frame bytes, MODE 2 the three linear planes of this level (pitch = w)
+    const uint8_t *bytes[2];
+    uint64_t stride[2];
+    const float *lin[2][3];
+    const float *lut;       // sRGB byte -> linear f32 (256 entries)
+    int w, h;               // size of this level
+    int cover_lo;           // first row of the tile grid (even)
+    int rd_lo, rd_hi;       // rows of the source that exist for this launch (a band: the rows the previous level produced)
+    int y0, y1;             // rows of the map this launch produces (the band)
+    float *map;             // w x h, absolutely indexed
+    double *sum;            // kSlots accumulators of the map sum
+    float *nxt[2][3];       // next level's linear planes ((w/2) x (h/2)), NULL at the last level
+    int nw, nh, ny_lo, ny_hi; // next level's size and the rows of it this launch must produce
+};
+
+// One pixel pair -> linear premultiplied RGB of image A (x lanes) and image B (y lanes).
+template <int MODE, int BPP>
+__device__ __forceinline__ void load_linear(const LevelArgs &A, const float *s_lut, int x, int y, f2 &r, f2 &g, f2 &b)
+{
+    if (MODE == 2) {
+        const size_t i = (size_t)y * A.w + x;
+        r = (f2){A.lin[0][0][i], A.lin[1][0][i]};
+        g = (f2){A.lin[0][1][i], A.lin[1][1][i]};
+        b = (f2){A.lin[0][2][i], A.lin[1][2][i]};
+        return;
+    }
+    uint32_t c[2][4];
+#pragma unroll
+    for (int im = 0; im < 2; im++) {
+        const uint8_t *p = A.bytes[im] + (uint64_t)y * A.stride[im] + (uint64_t)x * BPP;
+        if (MODE == 0) {
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(p);
+            c[im][0] = v & 0xffu; c[im][1] = (v >> 8) & 0xffu; c[im][2] = (v >> 16) & 0xffu; c[im][3] = v >> 24;
+        } else {
+            c[im][0] = p[0]; c[im][1] = p[1]; c[im][2] = p[2];
+            c[im][3] = BPP == 4 ? p[3] : 255u;
+        }
+    }
+    const f2 a = (f2){(float)c[0][3], (float)c[1][3]} * splat(1.0f / 255.0f); // 255 * (1/255) rounds to exactly 1
+    r = (f2){s_lut[c[0][0]], s_lut[c[1][0]]} * a;
+    g = (f2){s_lut[c[0][1]], s_lut[c[1][1]]} * a;
+    b = (f2){s_lut[c[0][2]], s_lut[c[1][2]]} * a;
+}
+
+// weighted sum with the binomial row (1, 4, 6, 4, 1); the 1/16 per direction is applied once at the end (1/256, exact)
+__device__ __forceinline__ f2 binom5(f2 a, f2 b, f2 c, f2 d, f2 e)
+{
+    return fma2(splat(6.0f), c, fma2(splat(4.0f), b + d, a + e));
+}
+__device__ __forceinline__ float binom5(float a, float b, float c, float d, float e)
+{
+    return __builtin_fmaf(6.0f, c, __builtin_fmaf(4.0f, b + d, a + e));
+}
+
+// n / d, correctly rounded for the operands that occur here (finite, d > 0, quotient O(1)); exactly 1 for n == d
+__device__ __forceinline__ float quotient(float n, float d)
+{
+    const float rc = __builtin_amdgcn_rcpf(d);
+    const float q = n * rc;
+    const float rem = __builtin_fmaf(-q, d, n);
+    return __builtin_fmaf(rem, rc, q);
+}
+
+template <int MODE, int BPP>
+__global__ __launch_bounds__(kThreads) void ssim32_level_kernel(LevelArgs A)
+{
+    __shared__ __attribute__((aligned(16))) f2 raw[3][kRH][kRW]; // 48 KiB: (A, B) pairs of the centred planes
+    __shared__ float s_lut[256];
+    __shared__ f2 s_centre[3];
+    __shared__ double s_part[kThreads / 64];
+    const int tx0 = blockIdx.x * kTW, ty0 = A.cover_lo + blockIdx.y * kTH;
+    if (MODE != 2) {
+        s_lut[threadIdx.x] = A.lut[threadIdx.x];
+        __syncthreads();
+    }
+
+    // ---- fetch + convert: thread t owns the 2x2 blocks t and t + 256 of the haloed tile ---------------------------------
+    f2 lab[2][4][3]; // [block][pixel of the block][channel]
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int blk = threadIdx.x + k * kThreads, bx = blk % kBlocksX, by = blk / kBlocksX;
+        f2 box[3] = {splat(0.0f), splat(0.0f), splat(0.0f)};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // edge replication (oracle: clampi); rows are clamped to the rows that exist for this launch, which is the frame for a
+            // whole-frame call and differs from it only in rows whose outputs are discarded for a band
+            const int x = min(max(tx0 - 2 + 2 * bx + (j & 1), 0), A.w - 1), y = min(max(ty0 - 2 + 2 * by + (j >> 1), A.rd_lo), A.rd_hi - 1);
+            f2 r, g, b;
+            load_linear<MODE, BPP>(A, s_lut, x, y, r, g, b);
+            box[0] += r; box[1] += g; box[2] += b;
+            to_lab2(r, g, b, lab[k][j]);
+        }
+        // the pyramid: 2x2 box of the LINEAR values of the interior blocks -> next level's planes (oracle: downsample)
+        if (A.nxt[0][0] != nullptr && bx >= 1 && bx <= kTW / 2 && by >= 1 && by <= kTH / 2) {
+            const int X = tx0 / 2 - 1 + bx, Y = (ty0 - 2) / 2 + by;
+            if (X < A.nw && Y >= A.ny_lo && Y < A.ny_hi) {
+                const size_t o = (size_t)Y * A.nw + X;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const f2 v = box[c] * splat(0.25f);
+                    A.nxt[0][c][o] = v.x;
+                    A.nxt[1][c][o] = v.y;
+                }
+            }
+        }
+    }
+    // the tile's centring constants: image A's planes at the haloed tile's centre pixel (block (16, 8), its first pixel)
+    if (threadIdx.x == (kBlocksY / 2) * kBlocksX + kBlocksX / 2 - kThreads) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) s_centre[c] = splat(lab[1][0][c].x);
+    }
+    __syncthreads();
+    f2 centre[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) centre[c] = s_centre[c];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int blk = threadIdx.x + k * kThreads, bx = blk % kBlocksX, by = blk / kBlocksX;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            // two pixels of a row = 16 contiguous bytes of LDS
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f2 p0 = lab[k][0][c] - centre[c], p1 = lab[k][1][c] - centre[c], p2 = lab[k][2][c] - centre[c], p3 = lab[k][3][c] - centre[c];
+            *reinterpret_cast<f4 *>(&raw[c][2 * by][2 * bx]) = (f4){p0.x, p0.y, p1.x, p1.y};
+            *reinterpret_cast<f4 *>(&raw[c][2 * by + 1][2 * bx]) = (f4){p2.x, p2.y, p3.x, p3.y};
+        }
+    }
+    __syncthreads();
+
+    // ---- separable 5x5 binomial window, sliding down the column; SSIM term of the three channels ----------------------------
+    float acc[kSegRows];
+#pragma unroll
+    for (int r = 0; r < kSegRows; r++) acc[r] = 0.0f;
+    const int col = threadIdx.x % kTW, seg = threadIdx.x / kTW;
+    if (seg < kSegs) {
+#pragma unroll 1
+        for (int c = 0; c < 3; c++) {
+            f2 hs[5], hq[5]; // ring of the horizontal sums of (v1, v2) and (v1^2, v2^2)
+            float hx[5];     // ... and of v1 v2
+#pragma unroll
+            for (int j = 0; j < kSegRows + 4; j++) {
+                const f2 *row = &raw[c][seg * kSegRows + j][col];
+                const f2 p0 = row[0], p1 = row[1], p2 = row[2], p3 = row[3], p4 = row[4];
+                hs[j % 5] = binom5(p0, p1, p2, p3, p4);
+                hq[j % 5] = binom5(p0 * p0, p1 * p1, p2 * p2, p3 * p3, p4 * p4);
+                hx[j % 5] = binom5(p0.x * p0.y, p1.x * p1.y, p2.x * p2.y, p3.x * p3.y, p4.x * p4.y);
+                if (j >= 4) {
+                    // window rows j-4 .. j (ring order is irrelevant to the symmetric weights except for the centre: row j-2)
+                    const int a = (j - 4) % 5, b = (j - 3) % 5, m = (j - 2) % 5, d = (j - 1) % 5, e = j % 5;
+                    const f2 mc = binom5(hs[a], hs[b], hs[m], hs[d], hs[e]) * splat(1.0f / 256.0f);       // centred means
+                    const f2 ex = binom5(hq[a], hq[b], hq[m], hq[d], hq[e]) * splat(1.0f / 256.0f);       // E[x'^2]
+                    const float e12 = binom5(hx[a], hx[b], hx[m], hx[d], hx[e]) * (1.0f / 256.0f);         // E[x1' x2']
+                    const f2 var = ex - mc * mc;                                                          // s11, s22
+                    const float s12 = e12 - mc.x * mc.y;
+                    const f2 mean = mc + centre[c];
+                    const f2 mm = mean * mean;
+                    const float lum_n = __builtin_fmaf(2.0f, mean.x * mean.y, kC1), lum_d = (mm.x + mm.y) + kC1;
+                    const float str_n = __builtin_fmaf(2.0f, s12, kC2), str_d = (var.x + var.y) + kC2;
+                    acc[j - 4] += quotient(lum_n * str_n, lum_d * str_d);
+                }
+            }
+        }
+    }
+    double total = 0.0;
+    if (seg < kSegs) {
+        const int x = tx0 + col;
+        float part = 0.0f;
+#pragma unroll
+        for (int r = 0; r < kSegRows; r++) {
+            const int y = ty0 + seg * kSegRows + r;
+            if (x < A.w && y >= A.y0 && y < A.y1) {
+                const float val = acc[r] * (1.0f / 3.0f); // 3 * fl(1/3) rounds to exactly 1
+                A.map[(size_t)y * A.w + x] = val;
+                part += val; // <= 7 values of O(1)
+            }
+        }
+        total = (double)part;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        total += __shfl_down(total, off);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < kThreads / 64; i++) t += s_part[i];
+        atomicAdd(A.sum + ((blockIdx.x + blockIdx.y * gridDim.x) % kSlots), t);
+    }
+}
+
+// second pass: sum of |map - mean| over the band (the map is f32; the difference and the sum are f64)
+__global__ __launch_bounds__(kThreads) void ssim32_dev_kernel(const float *map, int w, int y0, int y1, double avg, double *sum)
+{
+    __shared__ double s_part[kThreads / 64];
+    const size_t n = (size_t)w * (size_t)(y1 - y0), base = (size_t)y0 * w;
+    double t = 0.0;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads)
+        t += fabs((double)map[base + i] - avg);
+    for (int off = 32; off > 0; off >>= 1)
+        t += __shfl_down(t, off);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < kThreads / 64; i++) s += s_part[i];
+        atomicAdd(sum + (blockIdx.x % kSlots), s);
+    }
+}
+
+// Per-thread scratch, kept while the frame size stays the same: linear planes of levels 1..4 (both images), the five maps.
+struct State {
+    std::vector<void *> allocations;
+    int w0 = 0, h0 = 0, device = -1;
+    float *lin[kScales][2][3] = {};
+    float *map[kScales] = {};
+    int w[kScales] = {}, h[kScales] = {}, y0[kScales] = {}, y1[kScales] = {};
+    int scales = 0;
+    double *d_sums = nullptr; // [2 passes][kScales][kSlots]
+    float *d_lut = nullptr;
+    void release()
+    {
+        for (void *p : allocations) (void)hipFree(p);
+        allocations.clear();
+        scales = 0;
+        w0 = h0 = 0;
+    }
+    ~State() { release(); }
+};
+thread_local State t_state;
+
+int dalloc(State &S, size_t bytes, void **out)
+{
+    hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+    if (e != hipSuccess)
+        return fail(MVFX_ERR_OUT_OF_MEMORY, "ssim: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    S.allocations.push_back(*out);
+    return MVFX_OK;
+}
+
+int ensure_scratch(State &S, int w0, int h0, hipStream_t st)
+{
+    int dev = 0;
+    MVFX_HIP_TRY(hipGetDevice(&dev));
+    if (S.w0 == w0 && S.h0 == h0 && S.device == dev && !S.allocations.empty())
+        return MVFX_OK;
+    S.release();
+    S.device = dev;
+    if (int rc = dalloc(S, sizeof(double) * 2 * kScales * kSlots, reinterpret_cast<void **>(&S.d_sums)); rc != MVFX_OK) return rc;
+    if (int rc = dalloc(S, sizeof(float) * 256, reinterpret_cast<void **>(&S.d_lut)); rc != MVFX_OK) return rc;
+    float lut[256];
+    for (int i = 0; i < 256; i++) { // oracle: srgb_to_linear, rounded once to f32
+        const double x = i / 255.0;
+        lut[i] = (float)(x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4));
+    }
+    MVFX_HIP_TRY(hipMemcpyAsync(S.d_lut, lut, sizeof(lut), hipMemcpyHostToDevice, st));
+    MVFX_HIP_TRY(hipStreamSynchronize(st)); // `lut` is a stack buffer
+    int w = w0, h = h0;
+    for (int s = 0; s < kScales; s++) {
+        if (s > 0) {
+            if (w / 2 < 8 || h / 2 < 8) break;
+            w /= 2; h /= 2;
+            for (int i = 0; i < 2; i++)
+                for (int c = 0; c < 3; c++)
+                    if (int rc = dalloc(S, sizeof(float) * (size_t)w * h, reinterpret_cast<void **>(&S.lin[s][i][c])); rc != MVFX_OK) return rc;
+        }
+        if (int rc = dalloc(S, sizeof(float) * (size_t)w * h, reinterpret_cast<void **>(&S.map[s])); rc != MVFX_OK) return rc;
+    }
+    S.w0 = w0; S.h0 = h0;
+    return MVFX_OK;
+}
+
+template <int MODE, int BPP>
+void launch_level(const LevelArgs &A, int cover_hi, hipStream_t st)
+{
+    const dim3 grid((A.w + kTW - 1) / kTW, (cover_hi - A.cover_lo + kTH - 1) / kTH);
+    hipLaunchKernelGGL((ssim32_level_kernel<MODE, BPP>), grid, dim3(kThreads), 0, st, A);
+}
+
+int read_slots(const double *d_slots, double out[kScales], hipStream_t st)
+{
+    std::vector<double> slots((size_t)kScales * kSlots);
+    MVFX_HIP_TRY(hipMemcpyAsync(slots.data(), d_slots, slots.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    MVFX_HIP_TRY(hipStreamSynchronize(st));
+    for (int s = 0; s < kScales; s++) {
+        out[s] = 0.0;
+        for (int k = 0; k < kSlots; k++) out[s] += slots[(size_t)s * kSlots + k];
+    }
+    return MVFX_OK;
+}
+
+} // namespace
+
+int partial_sums(const mvfx_frame *const fr[2], uint32_t row_begin, uint32_t row_end, double sums_out[5], double counts_out[5],
+                 uint32_t *n_scales_out, hipStream_t st)
+{
+    const int w0 = (int)fr[0]->width, h0 = (int)fr[0]->height;
+    State &S = t_state;
+    if (int rc = ensure_scratch(S, w0, h0, st); rc != MVFX_OK) return rc;
+    MVFX_HIP_TRY(hipMemsetAsync(S.d_sums, 0, sizeof(double) * 2 * kScales * kSlots, st));
+
+    // geometry: size of every level, the band's map rows [y0, y1) there, and the rows [lo, hi) its tile grid has to cover: the
+    // band itself and twice what the next coarser level READS (its cover +- 2 rows of window halo)
+    int n_scales = 0, lo[kScales], hi[kScales];
+    for (int s = 0, w = w0, h = h0; s < kScales; s++) {
+        if (s > 0) {
+            if (w / 2 < 8 || h / 2 < 8) break;
+            w /= 2; h /= 2;
+        }
+        S.w[s] = w; S.h[s] = h;
+        S.y0[s] = std::min((int)(row_begin >> s), h);
+        S.y1[s] = row_end == (uint32_t)h0 ? h : std::min((int)(row_end >> s), h);
+        n_scales = s + 1;
+    }
+    int read_lo = 0, read_hi = 0; // rows of level s + 1 that level s + 1 reads (empty at the start)
+    for (int s = n_scales - 1; s >= 0; s--) {
+        lo[s] = S.y0[s]; hi[s] = S.y1[s];
+        if (hi[s] <= lo[s]) { lo[s] = 0; hi[s] = 0; }
+        if (read_hi > read_lo) {
+            const int need_lo = 2 * read_lo, need_hi = std::min(2 * read_hi, S.h[s]);
+            if (hi[s] > lo[s]) { lo[s] = std::min(lo[s], need_lo); hi[s] = std::max(hi[s], need_hi); }
+            else { lo[s] = need_lo; hi[s] = need_hi; }
+        }
+        lo[s] &= ~1; // the tile grid starts on an even row (2x2 boxes)
+        read_lo = std::max(lo[s] - 2, 0);
+        read_hi = hi[s] > lo[s] ? std::min(hi[s] + 2, S.h[s]) : read_lo;
+    }
+
+    for (int s = 0; s < n_scales; s++) {
+        if (hi[s] <= lo[s]) continue;
+        LevelArgs A = {};
+        A.w = S.w[s]; A.h = S.h[s];
+        A.cover_lo = lo[s];
+        A.rd_lo = std::max(lo[s] - 2, 0);
+        A.rd_hi = std::min(hi[s] + 2, S.h[s]);
+        A.y0 = S.y0[s]; A.y1 = S.y1[s];
+        A.map = S.map[s];
+        A.sum = S.d_sums + (size_t)s * kSlots;
+        A.lut = S.d_lut;
+        if (s + 1 < n_scales) {
+            for (int i = 0; i < 2; i++)
+                for (int c = 0; c < 3; c++) A.nxt[i][c] = S.lin[s + 1][i][c];
+            A.nw = S.w[s + 1]; A.nh = S.h[s + 1];
+            // rows of level s + 1 its own launch reads: its cover +- 2
+            A.ny_lo = hi[s + 1] > lo[s + 1] ? std::max(lo[s + 1] - 2, 0) : 0;
+            A.ny_hi = hi[s + 1] > lo[s + 1] ? std::min(hi[s + 1] + 2, S.h[s + 1]) : 0;
+        }
+        if (s == 0) {
+            const int bpp = fr[0]->format == MVFX_FORMAT_RGBA ? 4 : 3;
+            bool wide = bpp == 4;
+            for (int i = 0; i < 2; i++) {
+                A.bytes[i] = static_cast<const uint8_t *>(fr[i]->data);
+                A.stride[i] = fr[i]->stride;
+                wide = wide && ((reinterpret_cast<uintptr_t>(fr[i]->data) | fr[i]->stride) & 3) == 0;
+            }
+            if (wide) launch_level<0, 4>(A, hi[s], st);
+            else if (bpp == 4) launch_level<1, 4>(A, hi[s], st);
+            else launch_level<1, 3>(A, hi[s], st);
+        } else {
+            for (int i = 0; i < 2; i++)
+                for (int c = 0; c < 3; c++) A.lin[i][c] = S.lin[s][i][c];
+            launch_level<2, 4>(A, hi[s], st);
+        }
+    }
+    S.scales = n_scales;
+    MVFX_HIP_TRY(hipGetLastError());
+    double sums[kScales];
+    if (int rc = read_slots(S.d_sums, sums, st); rc != MVFX_OK) return rc;
+    for (int s = 0; s < kScales; s++) {
+        sums_out[s] = s < S.scales ? sums[s] : 0.0;
+        counts_out[s] = s < S.scales ? (double)S.w[s] * (double)std::max(S.y1[s] - S.y0[s], 0) : 0.0;
+    }
+    *n_scales_out = (uint32_t)S.scales;
+    return MVFX_OK;
+}
+
+bool pending() { return t_state.scales != 0; }
+
+int partial_deviation(const double mean[5], double deviation_sums_out[5], hipStream_t st)
+{
+    State &S = t_state;
+    for (int s = 0; s < S.scales; s++)
+        if (S.y1[s] > S.y0[s]) {
+            const size_t n = (size_t)S.w[s] * (size_t)(S.y1[s] - S.y0[s]);
+            const unsigned grid = (unsigned)std::min<size_t>((n + kThreads * 8 - 1) / (kThreads * 8), 2048);
+            hipLaunchKernelGGL(ssim32_dev_kernel, dim3(grid ? grid : 1), dim3(kThreads), 0, st, S.map[s], S.w[s], S.y0[s], S.y1[s], mean[s],
+                               S.d_sums + (size_t)(kScales + s) * kSlots);
+        }
+    MVFX_HIP_TRY(hipGetLastError());
+    double sums[kScales];
+    if (int rc = read_slots(S.d_sums + (size_t)kScales * kSlots, sums, st); rc != MVFX_OK) return rc;
+    for (int s = 0; s < kScales; s++)
+        deviation_sums_out[s] = s < S.scales ? sums[s] : 0.0;
+    S.scales = 0;
+    return MVFX_OK;
+}
+
+} // namespace ssim32
+} // namespace mvfx

@@ -9,12 +9,14 @@
 // repository's own f64 restatement (oracle/ssim_oracle.c) and against the one property the
 // reference's test pins (identical frames => 0, tests/videocompare.rs:141-182).
 //
-// Everything is f64 on the device (planes, window sums, reductions): this path is a quality
-// metric, not a bandwidth race, and f64 keeps the GPU within 1e-9 of the oracle.  The map of each
+// Round 3: the DEFAULT path is the f32 pipeline of ssim32_kernels.hip (dssim-core is an f32 library; one fused kernel per
+// pyramid level).  The kernels in THIS file are the f64 twin of round 2, selected per thread with MVFX_OPT_SSIM_F64:
+// everything is f64 on the device (planes, window sums, reductions), within 1e-9 of the oracle -- the checker's twin.  The map of each
 // scale is kept in device scratch between the two reduction passes (mean, then mean absolute
 // deviation), so a multi-GPU caller can all-reduce the five partial sums in between
 // (row bands with a 2-row halo per scale are read from the full frames resident on each GPU).
 #include "mvfx_internal.h"
+#include "ssim32.h"
 
 #include <cmath>
 #include <cstring>
@@ -405,6 +407,8 @@ int mvfx_ssim_partial_sums(const mvfx_frame *reference_frame, const mvfx_frame *
     if (int rc = require_device(); rc != MVFX_OK) return rc;
 
     hipStream_t st = as_stream(stream);
+    if ((thread_options() & MVFX_OPT_SSIM_F64) == 0) // default: the f32 pipeline (what dssim-core computes in); f64 planes on request
+        return ssim32::partial_sums(fr, row_begin, row_end, sums_out, counts_out, n_scales_out, st);
     SsimState &S = t_ssim;
     if (int rc = ensure_scratch(S, w0, h0, st); rc != MVFX_OK) return rc;
     MVFX_HIP_TRY(hipMemsetAsync(S.d_sums, 0, sizeof(double) * 2 * kScales * kSlots, st));
@@ -487,6 +491,8 @@ int mvfx_ssim_partial_deviation(const double mean[5], double deviation_sums_out[
 {
     if (!mean || !deviation_sums_out)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "ssim: NULL argument");
+    if (ssim32::pending())
+        return ssim32::partial_deviation(mean, deviation_sums_out, as_stream(stream));
     SsimState &S = t_ssim;
     if (S.scales == 0)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "ssim: mvfx_ssim_partial_sums must be called first on this thread");

@@ -162,9 +162,14 @@ __global__ __launch_bounds__(kHistBlock) void colordetect_hist_kernel(
 constexpr int kReduceBlock = 1024;
 constexpr uint32_t kReduceGroups = kHistWords / 4 / 16;
 
-__global__ __launch_bounds__(kReduceBlock) void colordetect_reduce_kernel(const uint32_t *partials, uint32_t n_groups, uint32_t *hist,
-                                                                          uint32_t *minmax, int accumulate)
+__global__ __launch_bounds__(kReduceBlock) void colordetect_reduce_kernel(const uint32_t *partials_all, uint32_t n_groups, uint32_t *hist_all,
+                                                                          uint32_t *minmax_all, int accumulate)
 {
+    // blockIdx.y = frame (1 for the single-frame entry point): its partials, its 32768 + 8 output words
+    const uint32_t *partials = partials_all + (size_t)blockIdx.y * n_groups * kHistWords;
+    const uint32_t *bounds_in = partials_all + (size_t)gridDim.y * n_groups * kHistWords + (size_t)blockIdx.y * n_groups * 8;
+    uint32_t *hist = hist_all + (size_t)blockIdx.y * (kHistBins + 8);
+    uint32_t *minmax = minmax_all + (size_t)blockIdx.y * (kHistBins + 8);
     __shared__ uint32_t part[16][16 * 8];
     __shared__ uint32_t mm[32][8];
     const uint32_t c = threadIdx.x & 15, s = threadIdx.x >> 4; // 64 slices
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(kReduceBlock) void colordetect_reduce_kernel(const 
         uint32_t m = (i & 1) ? 0u : 255u;
         if (i < 6 && threadIdx.x < 256)
             for (uint32_t g = slice; g < n_groups; g += 32) {
-                const uint32_t v = partials[(size_t)n_groups * kHistWords + (size_t)g * 8 + i];
+                const uint32_t v = bounds_in[(size_t)g * 8 + i];
                 m = (i & 1) ? max(m, v) : min(m, v);
             }
         if (threadIdx.x < 256)
@@ -226,6 +231,117 @@ __global__ __launch_bounds__(kReduceBlock) void colordetect_reduce_kernel(const 
     }
 }
 
+
+// ---- round 3: the 4-byte formats on 16-byte aligned planes -------------------------------------------------------------------
+// Every 64-byte line of the frame holds a sample at quality <= 10 (a sample every 40 bytes at most), so the kernel reads the
+// WHOLE plane as a coalesced stream of 16-byte loads per lane (the blockhash shape, ~6 TB/s) and picks the samples out of the
+// registers: pixel P is sample P / quality iff P % quality == 0.  A lane's unit is 4 pixels; remainder of its first pixel is
+// kept incrementally (no division in the loop).  blockIdx.y = frame: the batched entry point bins one frame from each of n
+// streams in one launch with few groups per frame (a group may take up to 65535 samples), so the dense partials stay small
+// against the frames (n = 16 at 4K: 32 MiB of partials beside 531 MB of pixels).
+constexpr int kHistMaxFrames = 32;
+
+struct HistPlanes {
+    const uint8_t *plane[kHistMaxFrames];
+};
+
+// kHist4InFlight: 16-byte loads a lane issues before it bins
+template <bool MULTI, int kHist4InFlight> // MULTI: quality < 4, a 4-pixel unit can hold more than one sample
+__global__ __launch_bounds__(kHistBlock) void colordetect_hist4_kernel(
+    HistPlanes planes, uint64_t unit_begin, uint64_t unit_end, uint64_t px_begin, uint64_t px_end, uint32_t units_per_group,
+    uint32_t quality, uint32_t step_mod_q, HistLayout lay, uint32_t *partials)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist_lds[];
+    uint32_t *bins = hist_lds;
+    uint32_t *s_min = hist_lds + kHistWords, *s_max = hist_lds + kHistWords + 4;
+    for (uint32_t i = threadIdx.x; i < kHistWords; i += kHistBlock)
+        bins[i] = 0;
+    if (threadIdx.x < 3) { s_min[threadIdx.x] = 255; s_max[threadIdx.x] = 0; }
+    __syncthreads();
+
+    const sum_u32x4 *src = reinterpret_cast<const sum_u32x4 *>(planes.plane[blockIdx.y]);
+    const uint64_t g_begin = unit_begin + (uint64_t)blockIdx.x * units_per_group;
+    const uint64_t g_end = min(g_begin + units_per_group, unit_end);
+    uint32_t mn[3] = {255, 255, 255}, mx[3] = {0, 0, 0};
+    const uint32_t sh_r = 8 * lay.ir, sh_g = 8 * lay.ig, sh_b = 8 * lay.ib, sh_a = 8 * lay.ia;
+    uint64_t u0 = g_begin + threadIdx.x;
+    uint32_t rem = (uint32_t)((u0 * 4ull) % quality); // (first pixel of the lane's unit) % quality, then incrementally
+    // one pixel: skip test of color_thief (alpha < 125 or near white), 5-5-5 bin, LDS atomic on the packed pair
+    auto bin_px = [&](uint32_t v) {
+        uint32_t r = (v >> sh_r) & 0xff, g = (v >> sh_g) & 0xff, b = (v >> sh_b) & 0xff;
+        const uint32_t a = (v >> sh_a) & 0xff;
+        if (a < 125 || (r > 250 && g > 250 && b > 250))
+            return;
+        r >>= 3; g >>= 3; b >>= 3;
+        mn[0] = min(mn[0], r); mx[0] = max(mx[0], r);
+        mn[1] = min(mn[1], g); mx[1] = max(mx[1], g);
+        mn[2] = min(mn[2], b); mx[2] = max(mx[2], b);
+        const uint32_t bin = (r << 10) | (g << 5) | b;
+        atomicAdd(&bins[bin >> 1], 1u << ((bin & 1) * 16));
+    };
+    for (; u0 < g_end; u0 += (uint64_t)kHistBlock * kHist4InFlight) {
+        sum_u32x4 v[kHist4InFlight];
+#pragma unroll
+        for (int j = 0; j < kHist4InFlight; j++) { // unconditional loads from clamped units (no per-load s_waitcnt)
+            const uint64_t u = min(u0 + (uint64_t)j * kHistBlock, g_end - 1);
+            v[j] = __builtin_nontemporal_load(src + u);
+        }
+#pragma unroll
+        for (int j = 0; j < kHist4InFlight; j++) {
+            const uint64_t u = u0 + (uint64_t)j * kHistBlock;
+            const bool in_group = u < g_end;
+            const uint32_t rj = (rem + (uint32_t)j * ((kHistBlock * 4u) % quality)) % quality;
+            const uint64_t p0 = u * 4ull;
+            const uint32_t px[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            if (MULTI) {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t t = rj + k; // < quality + 3 <= 3 * quality + ... : a sample iff t is a multiple of quality
+                    const bool is_sample = (t == 0) | (t == quality) | (t == 2 * quality) | (t == 3 * quality);
+                    if (in_group && is_sample && p0 + k >= px_begin && p0 + k < px_end)
+                        bin_px(px[k]);
+                }
+            } else {
+                // quality >= 4: at most one sample per unit, the pixel k = (quality - rj) % quality when that is < 4
+                const uint32_t k = rj == 0 ? 0u : quality - rj;
+                if (in_group && k < 4 && p0 + k >= px_begin && p0 + k < px_end) {
+                    const uint32_t sel = k == 0 ? px[0] : k == 1 ? px[1] : k == 2 ? px[2] : px[3];
+                    bin_px(sel);
+                }
+            }
+        }
+        rem = (rem + step_mod_q) % quality;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[c] = min(mn[c], (uint32_t)__shfl_down((int)mn[c], off));
+            mx[c] = max(mx[c], (uint32_t)__shfl_down((int)mx[c], off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&s_min[c], mn[c]);
+            atomicMax(&s_max[c], mx[c]);
+        }
+    }
+    __syncthreads();
+    // dense flush, same layout as colordetect_hist_kernel, one region per frame: [frame][column block][group][16 uint4], then
+    // the bounds of every group of every frame
+    const uint32_t n_groups = gridDim.x;
+    uint32_t *mine = partials + (size_t)blockIdx.y * n_groups * kHistWords;
+    const uint4 *lds = reinterpret_cast<const uint4 *>(bins);
+#pragma unroll
+    for (uint32_t i = threadIdx.x; i < kHistWords / 4; i += kHistBlock) {
+        const uint4 w = lds[i];
+        __builtin_nontemporal_store((sum_u32x4){w.x, w.y, w.z, w.w},
+                                    reinterpret_cast<sum_u32x4 *>(mine) + ((size_t)(i >> 4) * n_groups + blockIdx.x) * 16 + (i & 15));
+    }
+    if (threadIdx.x < 3) {
+        uint32_t *bounds = partials + (size_t)gridDim.y * n_groups * kHistWords + ((size_t)blockIdx.y * n_groups + blockIdx.x) * 8;
+        bounds[2 * threadIdx.x] = s_min[threadIdx.x];
+        bounds[2 * threadIdx.x + 1] = s_max[threadIdx.x];
+    }
+}
+
 int colordetect_layout(int format, HistLayout *lay)
 {
     switch (format) { // colordetect/imp.rs:274-281 -> color_thief::ColorFormat
@@ -238,17 +354,30 @@ int colordetect_layout(int format, HistLayout *lay)
     }
 }
 
-int colordetect_hist_impl(const mvfx_frame *frame, uint32_t quality, uint64_t first_sample, uint64_t n_samples,
+// One or several frames (same geometry, stride and format).  hist_dev / minmax_dev of frame f: hist_dev + f * hist_stride_words,
+// minmax_dev + f * hist_stride_words (the frames entry point lays them out as n x (32768 + 8) words; the single-frame one passes
+// its two pointers and n = 1).
+int colordetect_hist_impl(const mvfx_frame *frames, uint32_t n_frames, uint32_t quality, uint64_t first_sample, uint64_t n_samples,
                           uint32_t *hist_dev, uint32_t *minmax_dev, hipStream_t st)
 {
-    if (!frame || !hist_dev || !minmax_dev)
+    if (!frames || !hist_dev || !minmax_dev || n_frames == 0)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "colordetect: NULL argument");
+    const mvfx_frame *frame = &frames[0];
     HistLayout lay;
     if (colordetect_layout(frame->format, &lay) != 0)
         return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "colordetect: format %d is not RGB RGBA ARGB BGR BGRA (colordetect/imp.rs:214-221)", frame->format);
     if (quality < 1 || quality > 10) // color-thief asserts quality in 1..=10
         return fail(MVFX_ERR_REFERENCE_PANIC, "colordetect: quality %u is outside 1..=10; color_thief::get_palette asserts on it", quality);
-    if (int rc = check_packed_frame(frame, "colordetect"); rc != MVFX_OK) return rc;
+    bool aligned16 = true;
+    for (uint32_t f = 0; f < n_frames; f++) {
+        if (int rc = check_packed_frame(&frames[f], "colordetect"); rc != MVFX_OK) return rc;
+        if (frames[f].width != frame->width || frames[f].height != frame->height || frames[f].stride != frame->stride ||
+            frames[f].format != frame->format)
+            return fail(MVFX_ERR_INVALID_ARGUMENT, "colordetect: the frames of one launch must share size, stride and format");
+        aligned16 = aligned16 && (reinterpret_cast<uintptr_t>(frames[f].data) & 15) == 0;
+    }
+    if (n_frames > 1 && minmax_dev != hist_dev + kHistBins)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "colordetect: batched output must be n x (32768 + 8) words");
     if (int rc = require_device(); rc != MVFX_OK) return rc;
     // every quality-th pixel of the flat plane, padding included (colordetect/imp.rs:69)
     const uint64_t pixel_count = (uint64_t)frame->stride * frame->height / (uint64_t)lay.bpp;
@@ -268,33 +397,99 @@ int colordetect_hist_impl(const mvfx_frame *frame, uint32_t quality, uint64_t fi
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         MVFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(colordetect_hist_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHistLds));
+        const void *k4[] = {reinterpret_cast<const void *>(colordetect_hist4_kernel<false, 4>), reinterpret_cast<const void *>(colordetect_hist4_kernel<true, 4>)};
+        for (const void *k : k4)
+            MVFX_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHistLds));
         attr_device = dev;
     }
-    uint64_t done = 0;
     int launches = 0;
-    do {
-        const uint64_t chunk = std::min<uint64_t>(n_samples - done, (uint64_t)kMaxGroupsPerLaunch * kMaxSamplesPerGroup);
-        // 3/4 of a 1024-thread group per CU: every group pays a 64 KiB LDS clear and a 64 KiB partial that the second launch
-        // has to read back, so few groups with many samples each win (4K, hist + reduce: 128 groups 11.4 + 4.8 us at quality 10
-        // and 27.5 + 5.0 at quality 1; 192: 10.7 + 5.1 / 22.0 + 5.3; 256: 11.1 + 6.3 / 18.0 + 6.3); each group < 65536 samples
-        // (16-bit bins)
-        const uint64_t want_groups = std::max<uint64_t>((uint64_t)cus * 3 / 4, 1);
-        uint32_t per_group = (uint32_t)std::min<uint64_t>(kMaxSamplesPerGroup, std::max<uint64_t>((chunk + want_groups - 1) / want_groups, 1024));
-        const uint32_t groups = (uint32_t)((chunk + per_group - 1) / per_group);
-        void *partials = nullptr;
-        if (groups) {
-            if (int rc = host_scratch((size_t)groups * kPartialWords * sizeof(uint32_t), 5, &partials); rc != MVFX_OK) return rc;
-            hipLaunchKernelGGL(colordetect_hist_kernel, dim3(groups), dim3(kHistBlock), kHistLds, st,
-                               static_cast<const uint8_t *>(frame->data), first_sample + done, chunk, per_group, quality,
-                               lay, static_cast<uint32_t *>(partials));
-            MVFX_HIP_TRY(hipGetLastError());
+    uint64_t byte_path_first = first_sample, byte_path_n = n_samples; // what is left for the per-sample kernel
+
+    // ---- streaming path: 4-byte pixels, 16-byte aligned planes; covers the whole 4-pixel units of the sample range --------------
+    // Measured on 4K RGBA (profiles/r3/colordetect_sweep.txt): one frame per launch, quality 10: per-sample kernel 10.7 + 5.1 us,
+    // streaming kernel 13.0 + 6.0 us at its best (192 groups, 4 loads in flight; 96...256 groups x 4 / 8 / 12 in flight: 17.6-22.2 us
+    // for the pair) -- a single frame is bound by the fixed cost of two launches and one memory round trip, which the sparse
+    // 4-byte loads make as well; quality 1: 25.8 against 27.3 us.  16 frames per launch: 113.5 us = 7.1 us per frame = 0.58 of the
+    // HBM peak (hist 95.7 us = 5.55 TB/s of frame reads, reduce 17.7 us), 16...64 groups per frame within 6 % of each other.
+    const bool streaming = lay.bpp == 4 && aligned16 && n_samples > 0 && pixel_count >= 4 && (n_frames > 1 || quality < 4);
+    if (streaming) {
+        const uint64_t px_begin = first_sample * quality, px_end = (first_sample + n_samples - 1) * quality + 1; // sample pixels in [begin, end)
+        const uint64_t unit_begin = px_begin / 4, unit_end = std::min<uint64_t>((px_end + 3) / 4, pixel_count / 4);
+        // samples beyond the last whole unit (a plane whose pixel count is not a multiple of 4) go to the per-sample kernel below
+        const uint64_t covered_end_px = std::min<uint64_t>(px_end, unit_end * 4);
+        const uint64_t covered_samples = covered_end_px > px_begin ? (covered_end_px - 1 - px_begin) / quality + 1 : 0;
+        byte_path_first = first_sample + covered_samples;
+        byte_path_n = n_samples - covered_samples;
+        // 16-bit bins: a group of U consecutive units (4U pixels) holds at most ceil(4U / quality) + 1 samples <= 65535
+        const uint64_t cap_units = std::max<uint64_t>((uint64_t)(kMaxSamplesPerGroup - 1) * quality / 4 - 1, 1);
+        uint64_t done = unit_begin;
+        while (done < unit_end) {
+            const uint64_t units = unit_end - done;
+            // single frame: 3/4 of a 1024-lane group per CU (each group pays a 64 KiB LDS clear + a 64 KiB partial the second launch
+            // reads back); several frames: ~2 groups per CU in total, few per frame, so the partials stay small beside the pixels
+            uint64_t want_groups = n_frames == 1 ? std::max<uint64_t>((uint64_t)cus * 3 / 4, 1)
+                                                 : std::max<uint64_t>((uint64_t)cus * 2 / n_frames, 8);
+            uint64_t per_group = std::max<uint64_t>((units + want_groups - 1) / want_groups, (uint64_t)kHistBlock * 4);
+            per_group = std::min<uint64_t>(per_group, cap_units);
+            uint64_t groups = (units + per_group - 1) / per_group;
+            uint64_t chunk_units = units;
+            if (groups > kMaxGroupsPerLaunch) { groups = kMaxGroupsPerLaunch; chunk_units = groups * per_group; }
+            void *partials = nullptr;
+            if (int rc = stream_scratch(st, (size_t)n_frames * groups * kPartialWords * sizeof(uint32_t), &partials); rc != MVFX_OK) return rc;
+            for (uint32_t f0 = 0; f0 < n_frames; f0 += kHistMaxFrames) { // <= 32 plane pointers travel in the kernel arguments
+                const uint32_t nf = std::min<uint32_t>(n_frames - f0, kHistMaxFrames);
+                HistPlanes planes;
+                for (uint32_t f = 0; f < nf; f++) planes.plane[f] = static_cast<const uint8_t *>(frames[f0 + f].data);
+                uint32_t *part_f = static_cast<uint32_t *>(partials) + (size_t)f0 * groups * kPartialWords;
+                const int in_flight = 4; // 16-byte loads in flight per lane (8 and 12 measured: never faster)
+                const uint32_t step_mod = (uint32_t)(((uint64_t)kHistBlock * in_flight * 4) % quality);
+                if (quality < 4)
+                    hipLaunchKernelGGL((colordetect_hist4_kernel<true, 4>), dim3((uint32_t)groups, nf), dim3(kHistBlock), kHistLds, st, planes, done,
+                                       done + chunk_units, px_begin, px_end, (uint32_t)per_group, quality, step_mod, lay, part_f);
+                else
+                    hipLaunchKernelGGL((colordetect_hist4_kernel<false, 4>), dim3((uint32_t)groups, nf), dim3(kHistBlock), kHistLds, st, planes, done,
+                                       done + chunk_units, px_begin, px_end, (uint32_t)per_group, quality, step_mod, lay, part_f);
+                MVFX_HIP_TRY(hipGetLastError());
+                hipLaunchKernelGGL(colordetect_reduce_kernel, dim3(kReduceGroups, nf), dim3(kReduceBlock), 0, st, part_f, (uint32_t)groups,
+                                   hist_dev + (size_t)f0 * (kHistBins + 8), minmax_dev + (size_t)f0 * (kHistBins + 8), launches > 0 ? 1 : 0);
+                MVFX_HIP_TRY(hipGetLastError());
+            }
+            done += chunk_units;
+            launches++;
         }
-        hipLaunchKernelGGL(colordetect_reduce_kernel, dim3(kReduceGroups), dim3(kReduceBlock), 0, st,
-                           static_cast<const uint32_t *>(partials), groups, hist_dev, minmax_dev, launches > 0 ? 1 : 0);
-        MVFX_HIP_TRY(hipGetLastError());
-        done += chunk;
-        launches++;
-    } while (done < n_samples);
+        if (byte_path_n == 0)
+            return MVFX_OK;
+    }
+
+    // ---- per-sample path: 3-byte pixels, unaligned planes, and the samples of a trailing partial unit ---------------------------
+    for (uint32_t f = 0; f < n_frames; f++) {
+        uint64_t done = 0;
+        int frame_launches = launches;
+        do {
+            const uint64_t chunk = std::min<uint64_t>(byte_path_n - done, (uint64_t)kMaxGroupsPerLaunch * kMaxSamplesPerGroup);
+            // 3/4 of a 1024-thread group per CU: every group pays a 64 KiB LDS clear and a 64 KiB partial that the second launch
+            // has to read back, so few groups with many samples each win (4K, hist + reduce: 128 groups 11.4 + 4.8 us at quality 10
+            // and 27.5 + 5.0 at quality 1; 192: 10.7 + 5.1 / 22.0 + 5.3; 256: 11.1 + 6.3 / 18.0 + 6.3); each group < 65536 samples
+            // (16-bit bins)
+            const uint64_t want_groups = std::max<uint64_t>((uint64_t)cus * 3 / 4, 1);
+            uint32_t per_group = (uint32_t)std::min<uint64_t>(kMaxSamplesPerGroup, std::max<uint64_t>((chunk + want_groups - 1) / want_groups, 1024));
+            const uint32_t groups = (uint32_t)((chunk + per_group - 1) / per_group);
+            void *partials = nullptr;
+            if (int rc = stream_scratch(st, (size_t)std::max<uint32_t>(groups, 1) * kPartialWords * sizeof(uint32_t), &partials); rc != MVFX_OK) return rc;
+            if (groups) {
+                hipLaunchKernelGGL(colordetect_hist_kernel, dim3(groups), dim3(kHistBlock), kHistLds, st,
+                                   static_cast<const uint8_t *>(frames[f].data), byte_path_first + done, chunk, per_group, quality,
+                                   lay, static_cast<uint32_t *>(partials));
+                MVFX_HIP_TRY(hipGetLastError());
+            }
+            hipLaunchKernelGGL(colordetect_reduce_kernel, dim3(kReduceGroups, 1), dim3(kReduceBlock), 0, st,
+                               static_cast<const uint32_t *>(partials), groups, hist_dev + (size_t)f * (kHistBins + 8),
+                               minmax_dev + (size_t)f * (kHistBins + 8), frame_launches > 0 ? 1 : 0);
+            MVFX_HIP_TRY(hipGetLastError());
+            done += chunk;
+            frame_launches++;
+        } while (done < byte_path_n);
+    }
     return MVFX_OK;
 }
 
@@ -726,7 +921,15 @@ extern "C" {
 int mvfx_colordetect_histogram(const mvfx_frame *frame, uint32_t quality, uint64_t first_sample, uint64_t n_samples,
                                uint32_t *hist_device, uint32_t *minmax_device, mvfx_stream stream)
 {
-    return colordetect_hist_impl(frame, quality, first_sample, n_samples, hist_device, minmax_device, as_stream(stream));
+    return colordetect_hist_impl(frame, 1, quality, first_sample, n_samples, hist_device, minmax_device, as_stream(stream));
+}
+
+int mvfx_colordetect_histogram_frames(const mvfx_frame *frames, uint32_t n_frames, uint32_t quality, uint32_t *hist_device,
+                                      mvfx_stream stream)
+{
+    if (!hist_device)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "colordetect: NULL output");
+    return colordetect_hist_impl(frames, n_frames, quality, 0, ~0ull, hist_device, hist_device + kHistBins, as_stream(stream));
 }
 
 int mvfx_mmcq_palette_from_histogram(const uint32_t *hist_host, const uint32_t minmax[6], uint32_t max_colors,
@@ -757,7 +960,7 @@ static int palette_common(const mvfx_frame *dev_frame, uint32_t quality, uint32_
     void *scratch = nullptr;
     if (int rc = host_scratch((kHistBins + 8) * sizeof(uint32_t), 3, &scratch); rc != MVFX_OK) return rc;
     uint32_t *hist_dev = static_cast<uint32_t *>(scratch), *mm_dev = hist_dev + kHistBins;
-    if (int rc = colordetect_hist_impl(dev_frame, quality, 0, ~0ull, hist_dev, mm_dev, st); rc != MVFX_OK) return rc;
+    if (int rc = colordetect_hist_impl(dev_frame, 1, quality, 0, ~0ull, hist_dev, mm_dev, st); rc != MVFX_OK) return rc;
     std::vector<uint32_t> host(kHistBins + 8);
     MVFX_HIP_TRY(hipMemcpyAsync(host.data(), hist_dev, (kHistBins + 6) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     MVFX_HIP_TRY(hipStreamSynchronize(st));
@@ -794,8 +997,11 @@ int mvfx_blockhash_sums(const mvfx_frame *frame, uint32_t row_begin, uint32_t ro
     return blockhash_sums_impl(frame, 1, row_begin, row_end, sums_device, as_stream(stream));
 }
 
-// views of whole frames whose rows outside the band are never touched
-static int blockhash_bands_impl(const mvfx_frame *bands, uint32_t n_pads, uint32_t full_height, uint32_t band_first_row,
+} // extern "C"
+
+namespace mvfx {
+// views of whole frames whose rows outside the band are never touched (also called by comm_rccl.hip)
+int blockhash_bands_impl(const mvfx_frame *bands, uint32_t n_pads, uint32_t full_height, uint32_t band_first_row,
                                 uint32_t *sums_device, hipStream_t st)
 {
     if (!bands || !sums_device || n_pads == 0)
@@ -819,6 +1025,9 @@ static int blockhash_bands_impl(const mvfx_frame *bands, uint32_t n_pads, uint32
     }
     return blockhash_sums_impl(whole.data(), n_pads, band_first_row, band_first_row + bands[0].height, sums_device, st);
 }
+} // namespace mvfx
+
+extern "C" {
 
 int mvfx_blockhash_sums_band(const mvfx_frame *band, uint32_t full_height, uint32_t band_first_row,
                              uint32_t *sums_device, mvfx_stream stream)

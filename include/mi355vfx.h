@@ -139,7 +139,10 @@ int mvfx_copy_device_to_device_async(void *dst_device, const void *src_device, s
 #define MVFX_OPT_HSV_VALU_UNORM 0x08u  /* `byte / 255.0` on the VALU instead of typed buffer loads (texture-unit UNORM8
                                           conversion, exact for all 256 byte values: tools/probe_unorm.hip) */
 #define MVFX_OPT_LUT_PLACEMENT_SHIFT 4 /* colorlut LUT placement: 0 auto | 1 node layout in global/L2 | 2 LDS |         */
-#define MVFX_OPT_LUT_PLACEMENT_MASK 0x70u /* 3 cell-packed global | 4 literal kernels; (placement << SHIFT) & MASK       */
+#define MVFX_OPT_LUT_PLACEMENT_MASK 0x70u /* 3 cell-packed global | 4 literal kernels | 5 tile kernel (wave-local LUT     */
+                                          /* window in LDS, the automatic choice for 3-D cubes); (placement << SHIFT) & MASK */
+#define MVFX_OPT_SSIM_F64 0x80u        /* hash-algo=dssim: f64 planes and window sums (round 2's pipeline, within 1e-9 of the f64
+                                          checker) instead of the default f32 pipeline (what dssim-core computes in) */
 int mvfx_thread_set_options(uint32_t options);
 uint32_t mvfx_thread_options(void);
 
@@ -237,11 +240,14 @@ int mvfx_colorlut_transform_frames(mvfx_cube_lut *lut, const mvfx_frame *in_fram
 int mvfx_colorlut_transform_frame_host(mvfx_cube_lut *lut, const mvfx_frame *in_frame,
                                        const mvfx_frame *out_frame);
 /* Where the LUT is read from / which kernel runs is a thread option (MVFX_OPT_LUT_PLACEMENT_*, see
- * mvfx_thread_set_options): 0 = automatic (LDS when the table fits: 3-D size <= 21, 1-D size <= 4096; else the cell-packed
+ * mvfx_thread_set_options): 0 = automatic (3-D cubes of 3..65 points on 16-byte aligned frames whose width is a multiple of
+ * 4: the tile kernel, placement 5; otherwise LDS when the table fits: 3-D size <= 21, 1-D size <= 4096; else the cell-packed
  * copy for 3-D size <= 65; else the node layout in global/L2), 1 = node layout in global/L2,
  * 2 = LDS (MVFX_ERR_INVALID_ARGUMENT if it does not fit), 3 = cell-packed global copy,
  * 4 = the literal-transcription kernels (also used automatically when the LUT's domain
- * scale/offset are not finite). */
+ * scale/offset are not finite), 5 = the tile kernel: a wave owns a compact block of pixels and keeps the 3x3x3 LUT cells
+ * around the colour of the block's centre pixel in wave-private LDS (MVFX_ERR_INVALID_ARGUMENT when the frame or cube does
+ * not allow it). */
 
 /* Writes the LUT as Adobe .cube text: LUT_1D_SIZE / LUT_3D_SIZE, DOMAIN_MIN / DOMAIN_MAX when they are not
  * 0 / 1, then the rows, floats with 9 significant digits -- mvfx_cube_lut_parse of the text yields the same LUT bit for
@@ -279,6 +285,13 @@ int mvfx_overlay_blend_host(const mvfx_frame *frame, const mvfx_frame *overlay, 
 int mvfx_colordetect_histogram(const mvfx_frame *frame, uint32_t quality, uint64_t first_sample,
                                uint64_t n_samples, uint32_t *hist_device,
                                uint32_t *minmax_device, mvfx_stream stream);
+/* The same for one frame of each of n_frames streams (same size, stride and format) in ONE pair of launches (blockIdx.y =
+ * stream): hist_device holds n_frames records of MVFX_COLORDETECT_RECORD_WORDS u32 -- 32768 bins, the six bounds
+ * {rmin,rmax,gmin,gmax,bmin,bmax}, two words of padding -- record f for frames[f].  A single 4K frame at quality 10 is ~10 us of
+ * GPU work of which half is the fixed cost of two launches; 16 streams per launch run at the HBM rate of reading the frames. */
+#define MVFX_COLORDETECT_RECORD_WORDS (32768u + 8u)
+int mvfx_colordetect_histogram_frames(const mvfx_frame *frames, uint32_t n_frames, uint32_t quality,
+                                      uint32_t *hist_device, mvfx_stream stream);
 /* Host-only median cut over a (possibly all-reduced) histogram.  palette_out: max_colors
  * entries packed 0x00RRGGBB, most dominant first (colordetect/imp.rs:95-99). */
 int mvfx_mmcq_palette_from_histogram(const uint32_t *hist_host, const uint32_t minmax[6],
@@ -329,6 +342,35 @@ int mvfx_blockhash_host(const mvfx_frame *frame, uint64_t *hash_out);
 int mvfx_videocompare_distance(const mvfx_frame *reference_frame, const mvfx_frame *other_frame,
                                double *distance_out, mvfx_stream stream);
 
+/* ---- the collective of the path, inside the library (videocompare/imp.rs:259-389 on row-distributed frames) ----
+ * RCCL is loaded at run time (dlopen "librccl.so.1", MVFX_RCCL_LIBRARY overrides; MVFX_ERR_IO if absent): only multi-GPU users
+ * need it.  One process per GPU: rank 0 makes a 128-byte id (mvfx_comm_unique_id), the host layer hands it to the other ranks by
+ * whatever it has, every rank calls mvfx_comm_create on its own device (ncclCommInitRank).  A NULL communicator means one GPU. */
+typedef struct mvfx_comm mvfx_comm;
+#define MVFX_COMM_ID_BYTES 128
+int mvfx_comm_unique_id(uint8_t id_out[MVFX_COMM_ID_BYTES]);
+int mvfx_comm_create(const uint8_t id[MVFX_COMM_ID_BYTES], int rank, int world, mvfx_comm **out);
+int mvfx_comm_destroy(mvfx_comm *comm);
+int mvfx_comm_rank(const mvfx_comm *comm);
+int mvfx_comm_world(const mvfx_comm *comm);
+/* In-place all-reduce of `count` elements in device memory on `stream` (asynchronous): the SSIM partial sums (10 f64) and the
+ * colordetect histogram (32768 u32 + bounds) of a distributed frame go through the same communicator. */
+#define MVFX_DTYPE_U32 0
+#define MVFX_DTYPE_U64 1
+#define MVFX_DTYPE_F64 2
+#define MVFX_REDUCE_SUM 0
+#define MVFX_REDUCE_MIN 1
+#define MVFX_REDUCE_MAX 2
+int mvfx_comm_allreduce(mvfx_comm *comm, void *buffer_device, size_t count, int32_t dtype, int32_t op, mvfx_stream stream);
+/* One aggregate of videocompare (hash-algo=blockhash) over pads whose frames are distributed by rows: `bands` = this rank's rows
+ * [band_first_row, band_first_row + bands[p].height) of every pad's frame of `full_height` rows (pad 0 = the reference pad,
+ * imp.rs:210-233).  Band kernel -> ncclAllReduce(sum) of n_pads x 64 u32 on `stream` -> hash bits and Hamming distances on the
+ * device -> one D2H of n_pads - 1 words; every rank returns the same distances_out[n_pads - 1] (distance of pad p + 1 to the
+ * reference, hashed_image.rs:70) and, when hashes_out != NULL, the n_pads 64-bit hashes.  Sizes must be multiples of 8 (the
+ * crate's f32 path for other sizes cannot be split by rows); n_pads <= 16.  Synchronous. */
+int mvfx_videocompare_sharded_distances(mvfx_comm *comm, const mvfx_frame *bands, uint32_t n_pads, uint32_t full_height,
+                                        uint32_t band_first_row, double *distances_out, uint64_t *hashes_out, mvfx_stream stream);
+
 /* GstVideoCompareHashAlgorithm values (videocompare/mod.rs:57-92) */
 typedef enum mvfx_hash_algo {
     MVFX_HASH_MEAN = 0,
@@ -361,6 +403,9 @@ int mvfx_videocompare_distance_algo(const mvfx_frame *reference_frame,
  * `dssim`, NOT in the default build).  dssim-core 3.4.0 is not vendored under the reference:
  * this is the published multi-scale SSIM structure, PARITY UNPINNED against the
  * crate; identical frames give exactly 0.0 (tests/videocompare.rs:141-182).  RGB / RGBA only.
+ *
+ * Arithmetic: f32 per pixel (dssim-core is an f32 library) with f64 reductions; a per-tile centring constant keeps the f32
+ * variances free of cancellation; agreement with the f64 checker ~1e-6 relative.  MVFX_OPT_SSIM_F64 selects f64 throughout.
  *
  * Two-pass, shardable by row bands (boundaries multiples of 16, or the frame height):
  *   1. mvfx_ssim_partial_sums: per-scale sum of the SSIM map over the band + pixel counts;

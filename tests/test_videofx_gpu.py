@@ -96,6 +96,96 @@ def test_colordetect_histogram_more_samples_than_one_launch_takes(gpu):
     assert mm[0] == 0 and mm[1] == 31       # bounds only the bottom rows can produce
 
 
+@pytest.mark.parametrize("quality", list(range(1, 11)))
+def test_colordetect_histogram_every_quality_streaming_and_per_sample_paths(gpu, quality):
+    """4-byte formats on a 16-byte aligned plane take the streaming kernel (the whole plane as 16-byte loads, samples picked
+    out of the registers: pixel P is a sample iff P % quality == 0); the same plane at an address that is only 4-byte aligned
+    takes the per-sample kernel.  Both must equal the oracle for every quality, on a plane whose pixel count is not a multiple
+    of 4 (the last partial unit goes to the per-sample kernel in accumulate mode)."""
+    w, h, stride = 333, 71, 333 * 4 + 4          # 23927 pixels incl. the padding: % 4 == 3
+    f = frames.random_frame(0x5EED0710 + quality, w, h, 4, stride)
+    f[5:9] = 253
+    rc, hist, mm, n = orc.colordetect_histogram(f, "BGRA", quality)
+    assert rc == 0
+    ghist, gmm = _gpu_hist(gpu, f, w, h, stride, "BGRA", quality)   # one frame: streaming kernel for quality < 4, per-sample above
+    assert np.array_equal(ghist, hist.astype(np.uint32)) and gmm.tolist() == mm
+    # two frames per launch: always the streaming kernel (the second frame: the first with another alpha pattern)
+    f2 = f.copy()
+    f2[:, 3::4] = np.where(f2[:, 3::4] < 40, 200, f2[:, 3::4])
+    rc, hist2, mm2, _ = orc.colordetect_histogram(f2, "BGRA", quality)
+    b1, b2 = gpu.DeviceBuffer(f.nbytes).upload(f), gpu.DeviceBuffer(f2.nbytes).upload(f2)
+    arr = (gpu.Frame * 2)(gpu.make_frame(b1.ptr, w, h, stride, "BGRA"), gpu.make_frame(b2.ptr, w, h, stride, "BGRA"))
+    rec2 = gpu.DeviceBuffer(2 * gpu.COLORDETECT_RECORD_WORDS * 4)
+    gpu.check(gpu.lib().mvfx_colordetect_histogram_frames(arr, 2, quality, ctypes.c_void_p(rec2.ptr), None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    r2 = rec2.download(dtype=np.uint32).reshape(2, gpu.COLORDETECT_RECORD_WORDS)
+    assert np.array_equal(r2[0, :32768], hist.astype(np.uint32)) and r2[0, 32768:32774].tolist() == mm
+    assert np.array_equal(r2[1, :32768], hist2.astype(np.uint32)) and r2[1, 32768:32774].tolist() == mm2
+    # the same bytes 4 bytes into a device buffer
+    buf = gpu.DeviceBuffer(f.nbytes + 16)
+    shifted = np.zeros(f.nbytes + 16, np.uint8)
+    shifted[4:4 + f.nbytes] = f.reshape(-1)
+    buf.upload(shifted)
+    out = gpu.DeviceBuffer(gpu.COLORDETECT_RECORD_WORDS * 4)
+    fr = gpu.make_frame(buf.ptr + 4, w, h, stride, "BGRA")
+    gpu.check(gpu.lib().mvfx_colordetect_histogram(ctypes.byref(fr), quality, 0, gpu.ALL_SAMPLES, ctypes.c_void_p(out.ptr),
+                                                   ctypes.c_void_p(out.ptr + 32768 * 4), None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    rec = out.download(dtype=np.uint32)
+    assert np.array_equal(rec[:32768], hist.astype(np.uint32)) and rec[32768:32774].tolist() == mm
+
+
+@pytest.mark.parametrize("n_frames,quality,size", [(5, 10, (640, 480)), (34, 3, (320, 180)), (16, 10, (1920, 1080)), (3, 1, (641, 481))])
+def test_colordetect_histogram_frames_equals_single_frame_calls(gpu, n_frames, quality, size):
+    """mvfx_colordetect_histogram_frames: one frame of each of n streams in one pair of launches (blockIdx.y = stream; > 32
+    frames are split) = the oracle's histogram and bounds of every frame, record by record."""
+    w, h = size
+    fr_host = [frames.random_frame(0x5EED0720 + k, w, h) for k in range(n_frames)]
+    for k, f in enumerate(fr_host):
+        f[:, 3::4] |= 0x40 * (k & 3)                      # different alpha statistics per frame
+        f[: (k % 5) * h // 10] >>= (k % 3)                  # different colour ranges per frame (bounds differ)
+    bufs = [gpu.DeviceBuffer(f.nbytes).upload(f) for f in fr_host]
+    arr = (gpu.Frame * n_frames)(*[gpu.make_frame(b.ptr, w, h, w * 4, "RGBA") for b in bufs])
+    out = gpu.DeviceBuffer(n_frames * gpu.COLORDETECT_RECORD_WORDS * 4)
+    gpu.check(gpu.lib().mvfx_colordetect_histogram_frames(arr, n_frames, quality, ctypes.c_void_p(out.ptr), None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    rec = out.download(dtype=np.uint32).reshape(n_frames, gpu.COLORDETECT_RECORD_WORDS)
+    for k, f in enumerate(fr_host):
+        rc, hist, mm, n = orc.colordetect_histogram(f, "RGBA", quality)
+        assert rc == 0
+        assert np.array_equal(rec[k, :32768], hist.astype(np.uint32)), f"frame {k}"
+        assert rec[k, 32768:32774].tolist() == mm, f"frame {k}"
+
+
+def test_colordetect_histogram_frames_rejects_mixed_geometry(gpu):
+    b = gpu.DeviceBuffer(64 * 64 * 4)
+    arr = (gpu.Frame * 2)(gpu.make_frame(b.ptr, 64, 64, 256, "RGBA"), gpu.make_frame(b.ptr, 32, 64, 256, "RGBA"))
+    out = gpu.DeviceBuffer(2 * gpu.COLORDETECT_RECORD_WORDS * 4)
+    assert gpu.lib().mvfx_colordetect_histogram_frames(arr, 2, 10, ctypes.c_void_p(out.ptr), None) == gpu.ERR_INVALID_ARGUMENT
+
+
+def test_colordetect_two_streams_of_one_thread_do_not_share_partials(gpu):
+    """The partial histograms live in scratch keyed by the stream: two asynchronous calls of ONE thread on two streams, no
+    synchronisation in between, each produce their own frame's histogram."""
+    w, h = 1920, 1080
+    fa, fb = frames.random_frame(0x5EED0730, w, h), frames.smpte_like(w, h)
+    ba, bb = gpu.DeviceBuffer(fa.nbytes).upload(fa), gpu.DeviceBuffer(fb.nbytes).upload(fb)
+    oa, ob = gpu.DeviceBuffer(gpu.COLORDETECT_RECORD_WORDS * 4), gpu.DeviceBuffer(gpu.COLORDETECT_RECORD_WORDS * 4)
+    s1, s2 = gpu.lib().mvfx_thread_stream(), None    # the thread's non-blocking stream and the null stream
+    fra, frb = gpu.make_frame(ba.ptr, w, h, w * 4, "RGBA"), gpu.make_frame(bb.ptr, w, h, w * 4, "RGBA")
+    for _ in range(8):
+        gpu.check(gpu.lib().mvfx_colordetect_histogram(ctypes.byref(fra), 10, 0, gpu.ALL_SAMPLES, ctypes.c_void_p(oa.ptr),
+                                                       ctypes.c_void_p(oa.ptr + 32768 * 4), ctypes.c_void_p(s1)))
+        gpu.check(gpu.lib().mvfx_colordetect_histogram(ctypes.byref(frb), 10, 0, gpu.ALL_SAMPLES, ctypes.c_void_p(ob.ptr),
+                                                       ctypes.c_void_p(ob.ptr + 32768 * 4), s2))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(ctypes.c_void_p(s1)))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    for f, o in ((fa, oa), (fb, ob)):
+        rc, hist, mm, n = orc.colordetect_histogram(f, "RGBA", 10)
+        rec = o.download(dtype=np.uint32)
+        assert np.array_equal(rec[:32768], hist.astype(np.uint32)) and rec[32768:32774].tolist() == mm
+
+
 def test_colordetect_reference_pin_red(gpu):
     """tests/colordetect.rs:21-68: solid red => dominant-color 'red' (palette[0] = 252,4,4)"""
     w, h = 320, 240

@@ -194,6 +194,14 @@ def main():
         ms = timeit(lambda i=0: vfx.check(lib.mvfx_colordetect_histogram(ctypes.byref(frn[i % POOL]), 10, 0, vfx.ALL_SAMPLES,
                     ctypes.c_void_p(hist.data_ptr()), ctypes.c_void_p(hist.data_ptr() + 32768 * 4), sptr)), iters=300)
         report("colordetect histogram 4K RGBA quality=10 natural content", ms, NB, 1)
+        # one frame of each of 16 streams per pair of launches (mvfx_colordetect_histogram_frames), two rotating batches
+        big = rand_frames(2 * POOL, NB, 19)
+        recs = torch.zeros(POOL * vfx.COLORDETECT_RECORD_WORDS, dtype=torch.int32, device=dev)
+        arrs = [(vfx.Frame * POOL)(*[vfx.make_frame(big[b * POOL + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]) for b in range(2)]
+        for q in (10, 1):
+            ms = timeit(lambda i=0: vfx.check(lib.mvfx_colordetect_histogram_frames(arrs[i & 1], POOL, q, ctypes.c_void_p(recs.data_ptr()), sptr)),
+                        iters=100)
+            report(f"colordetect histogram 4K RGBA quality={q}, 16 frames per launch", ms, POOL * NB, POOL)
 
     if want("blockhash"):
         W8, H8 = 7680, 4320
