@@ -874,21 +874,13 @@ def videocompare_sharded_leg(w, args, algo, steps, warmup):
         pool = 4
         gen.manual_seed(0x5EED0001)  # same seed on every rank: band r of the same virtual frames
         pairs = torch.randint(0, 256, (pool, 2, rows * W * 4), dtype=torch.uint8, device=dev, generator=gen)
-        sums = torch.zeros((2, 64), dtype=torch.int32, device=dev)
         bands = [(vfx.Frame * 2)(*[vfx.make_frame(pairs[k, p].data_ptr(), W, rows, W * 4, "RGBA") for p in range(2)])
                  for k in range(pool)]
-
-        def bits(s, w_, h_):
-            arr = (ctypes.c_uint32 * 64)(*[int(x) for x in s])
-            out = ctypes.c_uint64()
-            vfx.check(lib.mvfx_blockhash_bits(arr, w_, h_, ctypes.byref(out)))
-            return out.value
+        comm = D.make_comm(vfx, rank, world)  # the library's own RCCL communicator (its id travels over the torch group)
 
         def step(i):
-            def partial():  # both pads' bands in one launch
-                vfx.check(lib.mvfx_blockhash_sums_pads(bands[i % pool], 2, H, r0, ctypes.c_void_p(sums.data_ptr()), sptr))
-                return sums
-            return D.videocompare_sharded(partial, 2, W, H, bits, dev, all_pads=True)
+            # band kernel -> ncclAllReduce(2 x 64 u32) -> bits + Hamming on the device -> 4-byte D2H, all inside the C entry
+            return vfx.videocompare_sharded_distances(comm, bands[i % pool], H, r0, sptr)
 
     settle(step, args.settle_seconds, w.sync, fixed_steps=200 if algo == "blockhash" else 10)  # all-reduce inside the step
     for i in range(warmup):
@@ -899,12 +891,19 @@ def videocompare_sharded_leg(w, args, algo, steps, warmup):
         result[0] = step(i)
     elapsed, _ = w.timed(timed_step, steps)
     (elapsed,) = w.max_over_ranks(elapsed)
-    # the collective alone: the same 2x64 all-reduce with nothing around it (latency-bound on xGMI)
-    t = torch.zeros((2, 64), dtype=torch.int64, device=dev)
-    for _ in range(20):
-        w.dist.all_reduce(t)
-    ar_s, _ = w.timed(lambda i: w.dist.all_reduce(t), 200)
+    # the collective alone: the same 2x64 u32 all-reduce with nothing around it (latency-bound on xGMI), through the library
+    t = torch.zeros((2, 64), dtype=torch.int32, device=dev)
+    if algo == "blockhash":
+        one_ar = lambda i: comm.allreduce(t.data_ptr(), 128, vfx.DTYPE_U32, vfx.REDUCE_SUM, sptr)
+    else:
+        one_ar = lambda i: w.dist.all_reduce(t)
+    for i in range(20):
+        one_ar(i)
+    ar_s, _ = w.timed(one_ar, 200)
     (ar_s,) = w.max_over_ranks(ar_s)
+    if algo == "blockhash":
+        w.sync()
+        comm.destroy()
     bytes_per_pair = 2 * W * H * 4
     achieved = bytes_per_pair * steps / elapsed / 1e9
     return {
@@ -916,7 +915,10 @@ def videocompare_sharded_leg(w, args, algo, steps, warmup):
                    else "videocompare dssim (multi-scale SSIM) 7680x4320 RGBA pair, row bands + 2 all-reduces of 10 f64",
                    "parallelism": f"{world} row bands, RCCL all-reduce per pair", "last_distance": result[0][0],
                    "rccl_ranks": w.rccl_ranks, "allreduce_us": ar_s / 200 * 1e6,
-                   "allreduce_note": "RCCL all-reduce(sum) of 2x64 int64 alone, back to back on the launch stream, wall clock / 200"},
+                   "allreduce_note": "RCCL all-reduce(sum) of 2x64 u32 alone (mvfx_comm_allreduce: ncclAllReduce inside libmi355vfx), back to "
+                                     "back on the launch stream, wall clock / 200",
+                   "collective": "ncclAllReduce inside mvfx_videocompare_sharded_distances (library-owned communicator), hash bits + Hamming "
+                                 "distance on the device, one 4-byte D2H per pair" if algo == "blockhash" else "torch.distributed all_reduce x2"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                      "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
                      "note": "end-to-end per pair incl. the all-reduce, the D2H of the block sums, the synchronisation and host bit derivation"}}

@@ -566,7 +566,16 @@ __device__ __forceinline__ void lf_rows(const uint8_t *in, uint8_t *out, uint64_
 // lf_trilinear<true>): bit-identical results.
 constexpr int kTileNbCells = 27;                       // 3 x 3 x 3 cells
 constexpr int kTileNbPieces = kTileNbCells * 6;        // 16-byte pieces
-constexpr int kTileWaveLdsFloat4 = kTileNbPieces + 2;  // +32 bytes: de-phases the four waves' regions over the banks
+// LDS pitch of a window cell in 16-byte pieces.  Round 3: 7 (112 bytes), not 6: a ds_read_b128 serves 16 lanes at a time, a
+// 16-byte piece covers 4 of the 64 banks, so piece i of cell n sits on bank group (pitch * n + i) mod 16 -- with pitch 6 the cells n
+// and n + 8 of the 27 (e.g. the x-neighbour and the z-neighbour of the centre cell, dx - 1 against dz - 1) share their banks and
+// lanes of one group that want both serialise (profiles/r2/colorlut_block_counters.txt: SQ_LDS_BANK_CONFLICT 2.6e7 of 9.3e7 LDS
+// cycles per 16-frame launch, the LDS busy 56 % of the launch); with pitch 7 only cells 16 apart collide, which are never neighbours.
+#ifndef MVFX_TILE_CELL_PITCH
+#define MVFX_TILE_CELL_PITCH 7
+#endif
+constexpr int kTileCellPitch = MVFX_TILE_CELL_PITCH;
+constexpr int kTileWaveLdsFloat4 = kTileNbCells * kTileCellPitch + 2;  // +32 bytes: de-phases the four waves' regions over the banks
 
 // The lattice coordinate of a channel depends on its byte value only: (cell index, fraction) come from a 3 x 256 entry
 // table in LDS (built on the host with the same f32 steps, ensure_uploaded) instead of 7 VALU instructions per channel --
@@ -598,7 +607,7 @@ __device__ __forceinline__ void tile_cell(lds_bytes_t nbr_base, uint32_t wave_ld
         // 24-bit multiply-adds, the last one spelled out: plain `mine + index * 6` compiles to three quarter-rate v_mad_u64_u32
         const uint32_t nbi = __umul24(dz, 9u) + __umul24(dy, 3u) + dx;
         uint32_t off;
-        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(nbi), "s"(96u), "v"(wave_lds_bytes));
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(nbi), "s"((uint32_t)(kTileCellPitch * 16)), "v"(wave_lds_bytes));
         lds_float4_t cell = (lds_float4_t)(nbr_base + off);
 #pragma unroll
         for (int i = 0; i < 6; i++) {
@@ -639,9 +648,11 @@ __device__ __forceinline__ void tile_load_window(float4 *mine, uint32_t lane, co
     const uint32_t hi = p.size - 3;
     ax = min(cx > 0 ? cx - 1 : 0u, hi); ay = min(cy > 0 ? cy - 1 : 0u, hi); az = min(cz > 0 ? cz - 1 : 0u, hi);
     const uint32_t anchor = (ax + p.size * (ay + p.size * az)) * kCellF4; // float4 units; wave-uniform
-    mine[lane] = p.cells[anchor + rel0];
-    mine[64 + lane] = p.cells[anchor + rel1];
-    if (lane < (uint32_t)kTileNbPieces - 128u) mine[128 + lane] = p.cells[anchor + rel2];
+    // piece q = 6 n + i of the window goes to pitch * n + i (lane-constant indices: q / 6 by multiplication, q < 192)
+    auto slot = [](uint32_t q) { const uint32_t n = (q * 171u) >> 10; return n * (uint32_t)kTileCellPitch + (q - n * 6u); };
+    mine[slot(lane)] = p.cells[anchor + rel0];
+    mine[slot(64 + lane)] = p.cells[anchor + rel1];
+    if (lane < (uint32_t)kTileNbPieces - 128u) mine[slot(128 + lane)] = p.cells[anchor + rel2];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

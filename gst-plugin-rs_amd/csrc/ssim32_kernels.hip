@@ -11,7 +11,7 @@
 //   VGPR pairs and the pairs go to LDS with one 8-byte store -- writes the 2x2 box average of the linear values as the
 //   next level's planes (the pyramid comes out of the same pass), then runs the separable 5x5 binomial window as a sliding
 //   window down each column: per row five 8-byte LDS reads and the horizontal sums of v1, v2 (packed), v1^2, v2^2 (packed)
-//   and v1 v2 in registers, a ring of five rows for the vertical sums; the SSIM term of the three channels is summed in
+//   and (v1 - v2)^2 in registers, a ring of five rows for the vertical sums; the SSIM terms of the three channels are summed in
 //   registers and the map value written once (f32).  No Lab plane, no window sum ever goes to memory.
 //   HBM traffic per 8K pair: 2 x 133 MB of bytes (x1.2 halo re-reads, mostly L2 hits) + 2 x 100 MB of level-1 planes written
 //   and read + the f32 maps (133 + 33 + ... MB written, read once by the deviation pass).
@@ -20,14 +20,17 @@
 //   subtracts a per-tile, per-channel constant (image A's value at the tile centre) before squaring -- the variance and
 //   covariance are invariant, the means get it added back.
 //
-//   Identical frames give exactly 0: both lanes of every packed operation see the same bits, v1 v2 is computed with the
-//   same operations in the same order as v1^2, numerator and denominator of the SSIM term are then bit-identical, and the
-//   quotient is a Newton-corrected reciprocal product that returns exactly 1 for n == d; map values of exactly 1.0f sum
-//   exactly in f64, so mean = 1, deviation = 0, distance = 0 (tests/videocompare.rs:141-182).
+//   Near-identical frames: 1 - ssim is tiny, and an f32 quotient next to 1.0 cannot hold it (6e-8 absolute).  The kernel therefore
+//   computes the DEFICIT of every term directly.  With a = (m1 - m2)^2 and b = Var(x1 - x2) over the window (the fifth window sum
+//   is that of (x1 - x2)^2 instead of x1 x2):  2 m1 m2 + C1 = (m1^2 + m2^2 + C1) - a  and  2 s12 + C2 = (s11 + s22 + C2) - b, so
+//   1 - term = (a sd + b (ld - a)) / (ld sd)  with ld, sd the two denominators -- every factor is formed from small quantities
+//   without cancellation, the deficit has f32 RELATIVE accuracy, and the map in memory is the deficit map (mean and mean absolute
+//   deviation are the same numbers either way).  Identical frames: x1 - x2 = 0 everywhere, a = b = 0, deficit exactly 0,
+//   distance exactly 0 (tests/videocompare.rs:141-182).
 //
 // PARITY UNPINNED against the crate: the checker is oracle/ssim_oracle.c (f64); the f32 device value agrees with
-// it to ~1e-6 relative (tests/test_ssim_gpu.py states the tolerance per case).  No FMA contraction in this file: the fused
-// operations are written out, so the packed and the scalar lanes round alike.
+// it to ~1e-6 relative (tests/test_ssim_gpu.py states the tolerance).  No FMA contraction in this file: the fused operations are
+// written out.
 #include "mvfx_internal.h"
 #include "ssim32.h"
 
@@ -95,6 +98,7 @@ struct LevelArgs {
     double *sum;            // kSlots accumulators of the map sum
     float *nxt[2][3];       // next level's linear planes ((w/2) x (h/2)), NULL at the last level
     int nw, nh, ny_lo, ny_hi; // next level's size and the rows of it this launch must produce
+    int vec8;               // two horizontally adjacent source pixels (x even) may be fetched with one 8-byte load
 };
 
 // One pixel pair -> linear premultiplied RGB of image A (x lanes) and image B (y lanes).
@@ -126,6 +130,45 @@ __device__ __forceinline__ void load_linear(const LevelArgs &A, const float *s_l
     b = (f2){s_lut[c[0][2]], s_lut[c[1][2]]} * a;
 }
 
+// The two pixels (x, y), (x + 1, y) of a 2x2 block's row (x even, may lie outside the frame: edge replication) of both images.
+template <int MODE, int BPP>
+__device__ __forceinline__ void load_linear_pair(const LevelArgs &A, const float *s_lut, int x, int y, f2 r[2], f2 g[2], f2 b[2])
+{
+    if (A.vec8 && x >= 0 && x + 1 < A.w) {
+        if (MODE == 2) {
+            const size_t i = (size_t)y * A.w + x;
+            f2 v[2][3];
+#pragma unroll
+            for (int im = 0; im < 2; im++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) v[im][c] = *reinterpret_cast<const f2 *>(A.lin[im][c] + i);
+            r[0] = (f2){v[0][0].x, v[1][0].x}; r[1] = (f2){v[0][0].y, v[1][0].y};
+            g[0] = (f2){v[0][1].x, v[1][1].x}; g[1] = (f2){v[0][1].y, v[1][1].y};
+            b[0] = (f2){v[0][2].x, v[1][2].x}; b[1] = (f2){v[0][2].y, v[1][2].y};
+            return;
+        }
+        if (MODE == 0) {
+            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+            u2 px[2];
+#pragma unroll
+            for (int im = 0; im < 2; im++)
+                px[im] = *reinterpret_cast<const u2 *>(A.bytes[im] + (uint64_t)y * A.stride[im] + (uint64_t)x * 4);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint32_t va = k ? px[0].y : px[0].x, vb = k ? px[1].y : px[1].x;
+                const f2 al = (f2){(float)(va >> 24), (float)(vb >> 24)} * splat(1.0f / 255.0f);
+                r[k] = (f2){s_lut[va & 0xffu], s_lut[vb & 0xffu]} * al;
+                g[k] = (f2){s_lut[(va >> 8) & 0xffu], s_lut[(vb >> 8) & 0xffu]} * al;
+                b[k] = (f2){s_lut[(va >> 16) & 0xffu], s_lut[(vb >> 16) & 0xffu]} * al;
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+        load_linear<MODE, BPP>(A, s_lut, min(max(x + k, 0), A.w - 1), y, r[k], g[k], b[k]);
+}
+
 // weighted sum with the binomial row (1, 4, 6, 4, 1); the 1/16 per direction is applied once at the end (1/256, exact)
 __device__ __forceinline__ f2 binom5(f2 a, f2 b, f2 c, f2 d, f2 e)
 {
@@ -136,7 +179,7 @@ __device__ __forceinline__ float binom5(float a, float b, float c, float d, floa
     return __builtin_fmaf(6.0f, c, __builtin_fmaf(4.0f, b + d, a + e));
 }
 
-// n / d, correctly rounded for the operands that occur here (finite, d > 0, quotient O(1)); exactly 1 for n == d
+// n / d to ~1 ulp for the operands that occur here (finite, d > 0): reciprocal, one residual correction
 __device__ __forceinline__ float quotient(float n, float d)
 {
     const float rc = __builtin_amdgcn_rcpf(d);
@@ -161,18 +204,21 @@ __global__ __launch_bounds__(kThreads) void ssim32_level_kernel(LevelArgs A)
     // ---- fetch + convert: thread t owns the 2x2 blocks t and t + 256 of the haloed tile ---------------------------------
     f2 lab[2][4][3]; // [block][pixel of the block][channel]
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int blk = threadIdx.x + k * kThreads, bx = blk % kBlocksX, by = blk / kBlocksX;
+    for (int k2 = 0; k2 < 2; k2++) {
+        const int blk = threadIdx.x + k2 * kThreads, bx = blk % kBlocksX, by = blk / kBlocksX;
         f2 box[3] = {splat(0.0f), splat(0.0f), splat(0.0f)};
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < 2; j++) { // the two rows of the block
             // edge replication (oracle: clampi); rows are clamped to the rows that exist for this launch, which is the frame for a
             // whole-frame call and differs from it only in rows whose outputs are discarded for a band
-            const int x = min(max(tx0 - 2 + 2 * bx + (j & 1), 0), A.w - 1), y = min(max(ty0 - 2 + 2 * by + (j >> 1), A.rd_lo), A.rd_hi - 1);
-            f2 r, g, b;
-            load_linear<MODE, BPP>(A, s_lut, x, y, r, g, b);
-            box[0] += r; box[1] += g; box[2] += b;
-            to_lab2(r, g, b, lab[k][j]);
+            const int x = tx0 - 2 + 2 * bx, y = min(max(ty0 - 2 + 2 * by + j, A.rd_lo), A.rd_hi - 1);
+            f2 r[2], g[2], b[2];
+            load_linear_pair<MODE, BPP>(A, s_lut, x, y, r, g, b);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                box[0] += r[k]; box[1] += g[k]; box[2] += b[k];
+                to_lab2(r[k], g[k], b[k], lab[k2][2 * j + k]);
+            }
         }
         // the pyramid: 2x2 box of the LINEAR values of the interior blocks -> next level's planes (oracle: downsample)
         if (A.nxt[0][0] != nullptr && bx >= 1 && bx <= kTW / 2 && by >= 1 && by <= kTH / 2) {
@@ -220,27 +266,32 @@ __global__ __launch_bounds__(kThreads) void ssim32_level_kernel(LevelArgs A)
 #pragma unroll 1
         for (int c = 0; c < 3; c++) {
             f2 hs[5], hq[5]; // ring of the horizontal sums of (v1, v2) and (v1^2, v2^2)
-            float hx[5];     // ... and of v1 v2
+            float hd[5];     // ... and of (v1 - v2)^2
 #pragma unroll
             for (int j = 0; j < kSegRows + 4; j++) {
                 const f2 *row = &raw[c][seg * kSegRows + j][col];
                 const f2 p0 = row[0], p1 = row[1], p2 = row[2], p3 = row[3], p4 = row[4];
+                const float d0 = p0.x - p0.y, d1 = p1.x - p1.y, d2 = p2.x - p2.y, d3 = p3.x - p3.y, d4 = p4.x - p4.y;
                 hs[j % 5] = binom5(p0, p1, p2, p3, p4);
                 hq[j % 5] = binom5(p0 * p0, p1 * p1, p2 * p2, p3 * p3, p4 * p4);
-                hx[j % 5] = binom5(p0.x * p0.y, p1.x * p1.y, p2.x * p2.y, p3.x * p3.y, p4.x * p4.y);
+                hd[j % 5] = binom5(d0 * d0, d1 * d1, d2 * d2, d3 * d3, d4 * d4);
                 if (j >= 4) {
                     // window rows j-4 .. j (ring order is irrelevant to the symmetric weights except for the centre: row j-2)
-                    const int a = (j - 4) % 5, b = (j - 3) % 5, m = (j - 2) % 5, d = (j - 1) % 5, e = j % 5;
-                    const f2 mc = binom5(hs[a], hs[b], hs[m], hs[d], hs[e]) * splat(1.0f / 256.0f);       // centred means
-                    const f2 ex = binom5(hq[a], hq[b], hq[m], hq[d], hq[e]) * splat(1.0f / 256.0f);       // E[x'^2]
-                    const float e12 = binom5(hx[a], hx[b], hx[m], hx[d], hx[e]) * (1.0f / 256.0f);         // E[x1' x2']
-                    const f2 var = ex - mc * mc;                                                          // s11, s22
-                    const float s12 = e12 - mc.x * mc.y;
-                    const f2 mean = mc + centre[c];
+                    const int ra = (j - 4) % 5, rb = (j - 3) % 5, rm = (j - 2) % 5, rd = (j - 1) % 5, re = j % 5;
+                    // the window sums carry the weight 256 = 16 x 16 un-normalised (every factor below scales with it alike, the
+                    // quotient is homogeneous): M = 256 m', Q = 256 E[x'^2], QD = 256 E[(x1 - x2)^2]
+                    const f2 M = binom5(hs[ra], hs[rb], hs[rm], hs[rd], hs[re]);
+                    const f2 Q = binom5(hq[ra], hq[rb], hq[rm], hq[rd], hq[re]);
+                    const float QD = binom5(hd[ra], hd[rb], hd[rm], hd[rd], hd[re]);
+                    const f2 var = fma2(splat(256.0f), Q, -(M * M));             // 65536 (s11, s22)
+                    const float dm = M.x - M.y;
+                    const float a = dm * dm;                                      // 65536 (m1 - m2)^2
+                    const float b = __builtin_fmaf(256.0f, QD, -a);               // 65536 Var(x1 - x2) = 65536 (s11 + s22 - 2 s12)
+                    const f2 mean = fma2(splat(256.0f), centre[c], M);            // 256 (m1, m2)
                     const f2 mm = mean * mean;
-                    const float lum_n = __builtin_fmaf(2.0f, mean.x * mean.y, kC1), lum_d = (mm.x + mm.y) + kC1;
-                    const float str_n = __builtin_fmaf(2.0f, s12, kC2), str_d = (var.x + var.y) + kC2;
-                    acc[j - 4] += quotient(lum_n * str_n, lum_d * str_d);
+                    const float ld = (mm.x + mm.y) + 65536.0f * kC1, sd = (var.x + var.y) + 65536.0f * kC2;
+                    // 1 - (ld - a)(sd - b) / (ld sd) = (a sd + b (ld - a)) / (ld sd)
+                    acc[j - 4] += quotient(__builtin_fmaf(a, sd, b * (ld - a)), ld * sd);
                 }
             }
         }
@@ -253,9 +304,9 @@ __global__ __launch_bounds__(kThreads) void ssim32_level_kernel(LevelArgs A)
         for (int r = 0; r < kSegRows; r++) {
             const int y = ty0 + seg * kSegRows + r;
             if (x < A.w && y >= A.y0 && y < A.y1) {
-                const float val = acc[r] * (1.0f / 3.0f); // 3 * fl(1/3) rounds to exactly 1
+                const float val = acc[r] * (1.0f / 3.0f); // the DEFICIT 1 - ssim of this pixel (mean of the three channels)
                 A.map[(size_t)y * A.w + x] = val;
-                part += val; // <= 7 values of O(1)
+                part += val; // <= 7 values
             }
         }
         total = (double)part;
@@ -271,22 +322,33 @@ __global__ __launch_bounds__(kThreads) void ssim32_level_kernel(LevelArgs A)
     }
 }
 
-// second pass: sum of |map - mean| over the band (the map is f32; the difference and the sum are f64)
-__global__ __launch_bounds__(kThreads) void ssim32_dev_kernel(const float *map, int w, int y0, int y1, double avg, double *sum)
+// second pass: sum of |map - mean| over the band = sum of |deficit - (1 - mean)| (the deficits are f32; difference and sum f64);
+// all levels in one launch (blockIdx.y = level): five launches of 5...40 us of work each were launch-bound
+struct DevArgs {
+    const float *map[kScales];
+    size_t first[kScales], count[kScales]; // the band's elements of every level's map
+    double avg_deficit[kScales];
+    double *sum; // [kScales][kSlots]
+};
+
+__global__ __launch_bounds__(kThreads) void ssim32_dev_kernel(DevArgs D)
 {
     __shared__ double s_part[kThreads / 64];
-    const size_t n = (size_t)w * (size_t)(y1 - y0), base = (size_t)y0 * w;
+    const int s = blockIdx.y;
+    const float *map = D.map[s] + D.first[s];
+    const size_t n = D.count[s];
+    const double avg = D.avg_deficit[s];
     double t = 0.0;
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads)
-        t += fabs((double)map[base + i] - avg);
+        t += fabs((double)map[i] - avg);
     for (int off = 32; off > 0; off >>= 1)
         t += __shfl_down(t, off);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = t;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < kThreads / 64; i++) s += s_part[i];
-        atomicAdd(sum + (blockIdx.x % kSlots), s);
+    if (threadIdx.x == 0 && n) {
+        double sum = 0.0;
+        for (int i = 0; i < kThreads / 64; i++) sum += s_part[i];
+        atomicAdd(D.sum + (size_t)s * kSlots + (blockIdx.x % kSlots), sum);
     }
 }
 
@@ -435,12 +497,16 @@ int partial_sums(const mvfx_frame *const fr[2], uint32_t row_begin, uint32_t row
                 A.stride[i] = fr[i]->stride;
                 wide = wide && ((reinterpret_cast<uintptr_t>(fr[i]->data) | fr[i]->stride) & 3) == 0;
             }
+            bool vec8 = wide;
+            for (int i = 0; i < 2; i++) vec8 = vec8 && ((reinterpret_cast<uintptr_t>(fr[i]->data) | fr[i]->stride) & 7) == 0;
+            A.vec8 = vec8 ? 1 : 0;
             if (wide) launch_level<0, 4>(A, hi[s], st);
             else if (bpp == 4) launch_level<1, 4>(A, hi[s], st);
             else launch_level<1, 3>(A, hi[s], st);
         } else {
             for (int i = 0; i < 2; i++)
                 for (int c = 0; c < 3; c++) A.lin[i][c] = S.lin[s][i][c];
+            A.vec8 = (A.w & 1) == 0 ? 1 : 0; // hipMalloc'ed planes with an even pitch: (y w + x) even for even x
             launch_level<2, 4>(A, hi[s], st);
         }
     }
@@ -448,9 +514,9 @@ int partial_sums(const mvfx_frame *const fr[2], uint32_t row_begin, uint32_t row
     MVFX_HIP_TRY(hipGetLastError());
     double sums[kScales];
     if (int rc = read_slots(S.d_sums, sums, st); rc != MVFX_OK) return rc;
-    for (int s = 0; s < kScales; s++) {
-        sums_out[s] = s < S.scales ? sums[s] : 0.0;
+    for (int s = 0; s < kScales; s++) { // the device sums are those of the deficit 1 - ssim; the interface speaks of the map
         counts_out[s] = s < S.scales ? (double)S.w[s] * (double)std::max(S.y1[s] - S.y0[s], 0) : 0.0;
+        sums_out[s] = s < S.scales ? counts_out[s] - sums[s] : 0.0;
     }
     *n_scales_out = (uint32_t)S.scales;
     return MVFX_OK;
@@ -461,13 +527,20 @@ bool pending() { return t_state.scales != 0; }
 int partial_deviation(const double mean[5], double deviation_sums_out[5], hipStream_t st)
 {
     State &S = t_state;
-    for (int s = 0; s < S.scales; s++)
-        if (S.y1[s] > S.y0[s]) {
-            const size_t n = (size_t)S.w[s] * (size_t)(S.y1[s] - S.y0[s]);
-            const unsigned grid = (unsigned)std::min<size_t>((n + kThreads * 8 - 1) / (kThreads * 8), 2048);
-            hipLaunchKernelGGL(ssim32_dev_kernel, dim3(grid ? grid : 1), dim3(kThreads), 0, st, S.map[s], S.w[s], S.y0[s], S.y1[s], mean[s],
-                               S.d_sums + (size_t)(kScales + s) * kSlots);
-        }
+    DevArgs D = {};
+    D.sum = S.d_sums + (size_t)kScales * kSlots;
+    size_t most = 0;
+    for (int s = 0; s < S.scales; s++) {
+        D.map[s] = S.map[s];
+        D.first[s] = (size_t)S.y0[s] * S.w[s];
+        D.count[s] = S.y1[s] > S.y0[s] ? (size_t)S.w[s] * (size_t)(S.y1[s] - S.y0[s]) : 0;
+        D.avg_deficit[s] = 1.0 - mean[s];
+        most = std::max(most, D.count[s]);
+    }
+    if (most && S.scales) {
+        const unsigned grid = (unsigned)std::min<size_t>((most + kThreads * 8 - 1) / (kThreads * 8), 2048);
+        hipLaunchKernelGGL(ssim32_dev_kernel, dim3(grid ? grid : 1, S.scales), dim3(kThreads), 0, st, D);
+    }
     MVFX_HIP_TRY(hipGetLastError());
     double sums[kScales];
     if (int rc = read_slots(S.d_sums + (size_t)kScales * kSlots, sums, st); rc != MVFX_OK) return rc;

@@ -63,6 +63,24 @@ def videocompare_sharded(partial_sums: Callable[[int], torch.Tensor], n_pads: in
     return [float(bin(hashes[0] ^ h).count("1")) for h in hashes[1:]]
 
 
+def videocompare_sharded_device(vfx, comm, bands, full_height: int, band_first_row: int, stream=None) -> List[float]:
+    """The same aggregate through the library's own collective (round 3): band kernel -> ncclAllReduce of n_pads x 64 u32 on the
+    launch stream -> hash bits + Hamming distances on the device -> one D2H of n_pads - 1 words
+    (mvfx_videocompare_sharded_distances; `comm` is a vfx.Comm or None for one GPU).  No host round trip of the sums, no Python bit
+    derivation; `videocompare_sharded` above stays as the torch.distributed shim the gloo CPU tests drive."""
+    return vfx.videocompare_sharded_distances(comm, bands, full_height, band_first_row, stream)
+
+
+def make_comm(vfx, rank: int, world: int, group=None):
+    """The library's RCCL communicator for this rank, its 128-byte id travelling from rank 0 over the torch.distributed group
+    that already exists (any backend)."""
+    def bcast(ident):
+        box = [ident]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return box[0]
+    return vfx.Comm(rank, world, bcast if world > 1 else (lambda ident: ident))
+
+
 def ssim_band_rows(height: int, rank: int, world: int) -> Tuple[int, int]:
     """Row band for the SSIM distance: boundaries are multiples of 16 rows so that every one of the
     five pyramid levels partitions exactly (the last rank takes the remainder)."""

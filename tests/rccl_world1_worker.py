@@ -55,6 +55,14 @@ def main():
         return o.value
 
     out["videocompare"] = D.videocompare_sharded(partial, len(pads), w, h, bits, dev, all_pads=True)
+    # the same aggregate through the library's own RCCL communicator (world 1): all-reduce + bits + Hamming on the device
+    comm = D.make_comm(gpu, 0, 1)
+    out["videocompare_c_entry"], out["hashes_c_entry"] = gpu.videocompare_sharded_distances(comm, fr, h, 0, sptr, want_hashes=True)
+    buf = torch.arange(10, dtype=torch.float64, device=dev)
+    comm.allreduce(buf.data_ptr(), 10, gpu.DTYPE_F64, gpu.REDUCE_SUM, sptr)
+    torch.cuda.synchronize(dev)
+    out["allreduce_f64_world1"] = buf.cpu().tolist()
+    comm.destroy()
 
     # dssim: two all-reduces of 10 f64 around the two map passes
     sw, sh = 320, 240

@@ -43,6 +43,10 @@ def test_videocompare_sharded_hip_bands_over_rccl(worker_result):
     hs = [orc.blockhash(f, w, h, w * 4, "RGBA")[1] for f in pads]
     want = [float(orc.hamming(hs[0], x)) for x in hs[1:]]
     assert worker_result["videocompare"] == want and want[2] == 0.0
+    # mvfx_videocompare_sharded_distances over the library's own communicator: ncclAllReduce inside the C entry, bits on the device
+    assert worker_result["videocompare_c_entry"] == want
+    assert worker_result["hashes_c_entry"] == hs
+    assert worker_result["allreduce_f64_world1"] == [float(i) for i in range(10)]
 
 
 def test_ssim_and_colordetect_sharded_over_rccl(worker_result):
@@ -51,7 +55,7 @@ def test_ssim_and_colordetect_sharded_over_rccl(worker_result):
     b = a.copy()
     b[5::7, 3:w * 4:11] ^= 0x15
     rc, want, _ = orc.ssim_distance(a, b, w, h, w * 4, w * 4, "RGBA")
-    assert rc == 0 and worker_result["ssim"] == pytest.approx(want, rel=1e-9, abs=1e-12)
+    assert rc == 0 and worker_result["ssim"] == pytest.approx(want, rel=1e-5, abs=2e-9)  # the default f32 pipeline
     rc, want_pal = orc.colordetect_palette(a, "RGBA", 10, 5)
     assert rc >= 0 and worker_result["palette"] == [int(x) for x in want_pal]
 
@@ -116,6 +120,6 @@ def test_world2_ssim_and_colordetect(world2_results):
     rc2, want_pal = orc.colordetect_palette(a, "RGBA", 10, 5)
     assert rc == 0 and rc2 >= 0
     for r in world2_results:
-        assert r["ssim"] == pytest.approx(want, rel=1e-9, abs=1e-12)
+        assert r["ssim"] == pytest.approx(want, rel=1e-5, abs=2e-9)  # the default f32 pipeline
         assert r["palette"] == [int(x) for x in want_pal]
     assert world2_results[0]["ssim"] == world2_results[1]["ssim"]      # every rank derives the same value

@@ -1,7 +1,13 @@
-"""videocompare hash-algo=dssim on the GPU (gst-plugin-rs_amd/csrc/ssim_kernels.hip) against the f64
-restatement oracle/ssim_oracle.c.  PARITY UNPINNED against dssim-core itself (see the oracle's
-header); pinned here: the reference test's property (identical -> 0.0, tests/videocompare.rs:141-182),
-agreement with the oracle to 1e-9 relative, band partials == whole frame."""
+"""videocompare hash-algo=dssim on the GPU against the f64 restatement oracle/ssim_oracle.c.  PARITY UNPINNED against
+dssim-core itself (see the oracle's header); pinned here: the reference test's property (identical -> 0.0,
+tests/videocompare.rs:141-182), agreement with the oracle, band partials == whole frame.
+
+Two device pipelines, every test runs on both (fixture `prec`):
+  f32 (default, gst-plugin-rs_amd/csrc/ssim32_kernels.hip): f32 per pixel like dssim-core, f64 reductions, the deficit 1 - ssim
+      computed without cancellation -> 1e-5 relative to the oracle (SURVEY A.3's tolerance; measured 1e-8 ... 4e-6,
+      profiles/r3/ssim32_error_vs_f64_oracle.txt) plus 2e-9 absolute for distances below ~1e-4 (the Lab planes themselves are
+      rounded to f32: two colours 1 code apart differ by 1e-3 with 3e-8 of rounding on each);
+  f64 (MVFX_OPT_SSIM_F64, ssim_kernels.hip): the checker's twin, 1e-9 relative."""
 import ctypes
 
 import numpy as np
@@ -11,6 +17,13 @@ from tests import frames
 from tests import oracle_binding as orc
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["f32", "f64"])
+def prec(request, gpu):
+    """(relative, absolute) tolerance of the selected device pipeline against the f64 oracle; selects it for the test's thread"""
+    with gpu.options(ssim_f64=request.param == "f64"):
+        yield (1e-9, 1e-12) if request.param == "f64" else (1e-5, 2e-9)
 
 
 def _pair(seed, w, h, bpp, amp, every=97, stride=None):
@@ -23,7 +36,7 @@ def _pair(seed, w, h, bpp, amp, every=97, stride=None):
 
 
 @pytest.mark.parametrize("fmt,bpp,w,h", [("RGBA", 4, 320, 240), ("RGB", 3, 131, 77), ("RGBA", 4, 8, 8), ("RGB", 3, 1920, 1080)])
-def test_identical_frames_distance_is_exactly_zero(gpu, fmt, bpp, w, h):
+def test_identical_frames_distance_is_exactly_zero(gpu, prec, fmt, bpp, w, h):
     a = frames.random_frame(0xD5510 + w, w, h, bpp)
     assert gpu.ssim_distance_host(a.reshape(-1), a.reshape(-1), w, h, w * bpp, w * bpp, fmt) == 0.0
 
@@ -31,18 +44,18 @@ def test_identical_frames_distance_is_exactly_zero(gpu, fmt, bpp, w, h):
 @pytest.mark.parametrize("fmt,bpp,w,h,stride", [
     ("RGBA", 4, 64, 48, None), ("RGB", 3, 131, 77, 131 * 3 + 5), ("RGBA", 4, 320, 240, 320 * 4 + 64),
     ("RGB", 3, 17, 9, None), ("RGBA", 4, 640, 360, None)])
-def test_matches_f64_oracle(gpu, fmt, bpp, w, h, stride):
+def test_matches_f64_oracle(gpu, prec, fmt, bpp, w, h, stride):
     stride = stride or w * bpp
     for amp, every in ((1, 97), (25, 13), (120, 5)):
         a, b = _pair(0xD5520 + w + amp, w, h, bpp, amp, every, stride)
         rc, want, _ = orc.ssim_distance(a, b, w, h, stride, stride, fmt)
         assert rc == 0
         got = gpu.ssim_distance_host(a.reshape(-1), b.reshape(-1), w, h, stride, stride, fmt)
-        assert got == pytest.approx(want, rel=1e-9, abs=1e-12)  # distance = 1/ssim - 1: 1e-12 absolute on ssim ~ 1
+        assert got == pytest.approx(want, rel=prec[0], abs=prec[1])
         assert got > 0.0
 
 
-def test_monotone_ladder_and_inverted(gpu):
+def test_monotone_ladder_and_inverted(gpu, prec):
     w, h = 256, 192
     last = 0.0
     for amp in (1, 3, 10, 40, 120):
@@ -56,7 +69,7 @@ def test_monotone_ladder_and_inverted(gpu):
     assert gpu.ssim_distance_host(a.reshape(-1), inv.reshape(-1), w, h, w * 4, w * 4, "RGBA") > last
 
 
-def test_band_partials_equal_whole_frame(gpu):
+def test_band_partials_equal_whole_frame(gpu, prec):
     """The sharded path (distributed.ssim_sharded) on one GPU: 3 bands, reduced by hand."""
     w, h = 200, 150
     a, b = _pair(0xD555, w, h, 4, 30, every=11)
@@ -74,7 +87,7 @@ def test_band_partials_equal_whole_frame(gpu):
     tot_c = [sum(f[1][s] for f in firsts) for s in range(5)]
     o_s, o_c, o_n = orc.ssim_band(a, b, w, h, w * 4, w * 4, "RGBA", 0, h)
     assert n == o_n and tot_c == o_c
-    assert tot_s == pytest.approx(o_s, rel=1e-12)
+    assert tot_s == pytest.approx(o_s, rel=1e-12 if prec[0] < 1e-8 else 1e-7)
     mean = [tot_s[s] / tot_c[s] if tot_c[s] else 0.0 for s in range(5)]
     dev = [0.0] * 5
     for r0, r1 in bands:
@@ -82,9 +95,10 @@ def test_band_partials_equal_whole_frame(gpu):
         part = gpu.ssim_partial_deviation(mean)
         dev = [dev[s] + part[s] for s in range(5)]
     mad = [dev[s] / tot_c[s] if tot_c[s] else 0.0 for s in range(5)]
-    assert gpu.ssim_combine(mean, mad, n) == pytest.approx(d.value, rel=1e-9, abs=1e-12)
+    # bands and the whole frame tile the rows differently (another centring constant per tile in the f32 pipeline)
+    assert gpu.ssim_combine(mean, mad, n) == pytest.approx(d.value, rel=max(prec[0] * 0.1, 1e-9), abs=prec[1])
     rc, want, _ = orc.ssim_distance(a, b, w, h, w * 4, w * 4, "RGBA")
-    assert d.value == pytest.approx(want, rel=1e-9, abs=1e-12)
+    assert d.value == pytest.approx(want, rel=prec[0], abs=prec[1])
 
 
 def test_argument_errors(gpu):
@@ -105,7 +119,7 @@ def test_argument_errors(gpu):
     assert gpu.lib().mvfx_ssim_partial_deviation(sums, sums, None) in (gpu.ERR_INVALID_ARGUMENT, 0)
 
 
-def test_4k_pair_identical_and_perturbed(gpu):
+def test_4k_pair_identical_and_perturbed(gpu, prec):
     w, h = 3840, 2160
     a = frames.random_frame(0xD556, w, h)
     assert gpu.ssim_distance_host(a.reshape(-1), a.reshape(-1), w, h, w * 4, w * 4, "RGBA") == 0.0
@@ -117,7 +131,7 @@ def test_4k_pair_identical_and_perturbed(gpu):
     assert 0.0 < d1 < d2
 
 
-def test_8k_pair_matches_f64_oracle_whole_and_banded(gpu):
+def test_8k_pair_matches_f64_oracle_whole_and_banded(gpu, prec):
     """BASELINE config 5 shape: 7680x4320 RGBA pair, `hash-algo=dssim` (hashed_image.rs:49-59,72-75).
     Whole-frame distance against the f64 oracle to 1e-9, and the 3-band partial path (what
     distributed.ssim_sharded runs per rank) reduced by hand equals the whole-frame result."""
@@ -131,7 +145,7 @@ def test_8k_pair_matches_f64_oracle_whole_and_banded(gpu):
     gpu.check(gpu.lib().mvfx_ssim_distance(ctypes.byref(fa), ctypes.byref(fb), ctypes.byref(d), None))
     rc, want, _ = orc.ssim_distance(a, b, w, h, w * 4, w * 4, "RGBA")
     assert rc == 0 and want > 0.0
-    assert d.value == pytest.approx(want, rel=1e-9, abs=1e-12)
+    assert d.value == pytest.approx(want, rel=prec[0], abs=prec[1])
     # identical 8K frames: exactly 0.0 (tests/videocompare.rs:141-182 property at the config-5 size)
     gpu.check(gpu.lib().mvfx_ssim_distance(ctypes.byref(fa), ctypes.byref(fa), ctypes.byref(d), None))
     assert d.value == 0.0
@@ -148,11 +162,11 @@ def test_8k_pair_matches_f64_oracle_whole_and_banded(gpu):
         part = gpu.ssim_partial_deviation(mean)
         dev = [dev[s] + part[s] for s in range(5)]
     mad = [dev[s] / tot_c[s] if tot_c[s] else 0.0 for s in range(5)]
-    assert gpu.ssim_combine(mean, mad, n) == pytest.approx(want, rel=1e-9, abs=1e-12)
-    assert gpu.ssim_combine(mean, mad, n) == pytest.approx(d.value, rel=1e-11, abs=1e-13)
+    assert gpu.ssim_combine(mean, mad, n) == pytest.approx(want, rel=prec[0], abs=prec[1])
+    assert gpu.ssim_combine(mean, mad, n) == pytest.approx(d.value, rel=1e-11 if prec[0] < 1e-8 else 1e-6, abs=1e-13 if prec[0] < 1e-8 else prec[1])
 
 
-def test_rgba_frames_at_odd_addresses_take_the_byte_path(gpu):
+def test_rgba_frames_at_odd_addresses_take_the_byte_path(gpu, prec):
     """4-byte pixels whose rows are not 4-byte aligned (a frame at an odd offset inside a larger device block, stride % 4 != 0):
     the conversion kernels must not fetch pixels as dwords there.  Same distance as the aligned copy of the same pixels."""
     w, h = 96, 64
@@ -170,4 +184,28 @@ def test_rgba_frames_at_odd_addresses_take_the_byte_path(gpu):
         frames_.append(gpu.make_frame(blk.ptr + 1, w, h, stride, "RGBA"))
     d = ctypes.c_double()
     gpu.check(gpu.lib().mvfx_ssim_distance(ctypes.byref(frames_[0]), ctypes.byref(frames_[1]), ctypes.byref(d), None))
-    assert d.value == pytest.approx(want, rel=1e-9, abs=1e-12)
+    assert d.value == pytest.approx(want, rel=prec[0], abs=prec[1])
+
+
+def test_tiny_distances_keep_relative_accuracy(gpu, prec):
+    """Near-identical frames: 1 - ssim ~ 1e-6.  The f32 pipeline computes the deficit of every SSIM term directly
+    ((m1 - m2)^2 and Var(x1 - x2) from the difference image), so the distance keeps its relative accuracy where a quotient next
+    to 1.0f would hold 6e-8 absolute; flat bright content (variance by cancellation) and two colours one code apart included."""
+    w, h = 640, 360
+    a = frames.random_frame(0xD5B0, w, h)
+    b = a.copy()
+    b.reshape(-1)[::97] ^= 1                                  # +-1 on every 97th byte
+    flat = np.full((h, w * 4), 200, np.uint8)
+    flat2 = flat.copy()
+    flat2[:, ::8] = 201                                       # every other pixel's red one code up
+    x = np.linspace(0, 1, w)[None, :]
+    y = np.linspace(0, 1, h)[:, None]
+    smooth = np.stack([(0.5 + 0.45 * np.sin(3 * x + 2 * y)) * 255, (0.5 + 0.45 * np.sin(5 * y - 1.5 * x)) * 255 + 0 * x,
+                       (0.5 + 0.45 * np.cos(4 * x * y)) * 255, np.full((h, w), 255.0)], axis=-1).astype(np.uint8).reshape(h, w * 4)
+    smooth2 = smooth.copy()
+    smooth2[100:140, 400:1200] ^= 1
+    for p, q in ((a, b), (flat, flat2), (smooth, smooth2)):
+        rc, want, _ = orc.ssim_distance(p, q, w, h, w * 4, w * 4, "RGBA")
+        assert rc == 0 and 0.0 < want < 1e-3
+        got = gpu.ssim_distance_host(p.reshape(-1), q.reshape(-1), w, h, w * 4, w * 4, "RGBA")
+        assert got == pytest.approx(want, rel=prec[0], abs=prec[1])

@@ -483,3 +483,52 @@ def test_blockhash_slow_path_pair_distance_and_errors(gpu):
     sums = gpu.DeviceBuffer(64 * 4)
     assert gpu.lib().mvfx_blockhash_sums(ctypes.byref(fa), 0, 240, ctypes.c_void_p(sums.ptr), None) == gpu.ERR_INVALID_ARGUMENT
     assert "row bands" in gpu.last_error()
+
+
+@pytest.mark.parametrize("size,n_pads", [((320, 240), 2), ((1920, 1080), 5), ((64, 8), 3), ((7680, 4320), 2), ((1024, 1024), 16)])
+def test_videocompare_device_bits_and_distances_match_oracle(gpu, size, n_pads):
+    """mvfx_videocompare_sharded_distances without a communicator (one GPU, whole frames and bands): block sums -> hash bits (4 bands
+    of 16, upper median, equal-and-bright rule) and Hamming distances derived ON THE DEVICE equal the oracle's hashes / distances;
+    ties (flat frames: every block sum equal) included."""
+    w, h = size
+    base = frames.random_frame(0x5EED0800 + w, w, h)
+    pads = [base]
+    for k in range(1, n_pads):
+        f = base.copy()
+        if k % 4 == 1:
+            f[:: k + 1, :: 16 * k] ^= 0x3C
+        elif k % 4 == 2:
+            f[:] = 255 - f
+            f[:, 3::4] = base[:, 3::4]
+        elif k % 4 == 3:
+            f[:] = 200                     # flat: all 64 sums equal -> the `v == median && median > half` branch decides every bit
+        pads.append(f)
+    hs = [orc.blockhash(f, w, h, w * 4, "RGBA")[1] for f in pads]
+    want = [float(orc.hamming(hs[0], x)) for x in hs[1:]]
+    bufs = [gpu.DeviceBuffer(f.nbytes).upload(f) for f in pads]
+    arr = (gpu.Frame * n_pads)(*[gpu.make_frame(b.ptr, w, h, w * 4, "RGBA") for b in bufs])
+    got, hashes = gpu.videocompare_sharded_distances(None, arr, h, 0, None, want_hashes=True)
+    assert hashes == hs and got == want
+    if h % 16 == 0:   # a band alone: the totals are the band's partial sums -> the oracle's bits of those partial sums
+        rows = h // 2
+        band = (gpu.Frame * n_pads)(*[gpu.make_frame(b.ptr + rows * w * 4, w, rows, w * 4, "RGBA") for b in bufs])
+        got_b, hashes_b = gpu.videocompare_sharded_distances(None, band, h, rows, None, want_hashes=True)
+        sums = [orc.blockhash_sums(np.ascontiguousarray(f[rows:]), w, rows, w * 4, "RGBA") for f in pads]
+        # the lower half of an 8 x 8 grid of (h / 8)-row blocks = block rows 4..7; orc sums of the half frame use (rows / 8)-row blocks,
+        # so compare through the device's own band sums instead: they must reproduce the hashes
+        dsum = gpu.DeviceBuffer(n_pads * 64 * 4)
+        gpu.check(gpu.lib().mvfx_blockhash_sums_pads(band, n_pads, h, rows, ctypes.c_void_p(dsum.ptr), None))
+        gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+        ds = dsum.download(dtype=np.uint32).reshape(n_pads, 64)
+        assert hashes_b == [orc.blockhash_bits(ds[p], w, h) for p in range(n_pads)]
+        assert got_b == [float(orc.hamming(hashes_b[0], x)) for x in hashes_b[1:]]
+
+
+def test_videocompare_sharded_entry_rejects_what_cannot_shard(gpu):
+    b = gpu.DeviceBuffer(100 * 100 * 4)
+    arr = (gpu.Frame * 2)(gpu.make_frame(b.ptr, 100, 100, 400, "RGBA"), gpu.make_frame(b.ptr, 100, 100, 400, "RGBA"))
+    out = (ctypes.c_double * 1)()
+    L = gpu.lib()
+    assert L.mvfx_videocompare_sharded_distances(None, arr, 2, 100, 0, out, None, None) == gpu.ERR_INVALID_ARGUMENT   # 100 % 8 != 0
+    one = (gpu.Frame * 1)(gpu.make_frame(b.ptr, 96, 96, 400, "RGBA"))
+    assert L.mvfx_videocompare_sharded_distances(None, one, 1, 96, 0, out, None, None) == gpu.ERR_INVALID_ARGUMENT    # no other pad

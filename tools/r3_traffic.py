@@ -15,12 +15,12 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-PRODUCT = ("hsvfilter", "hsvdetector", "hsv_from_frame", "colorlut", "copy_planes", "colordetect", "blockhash", "ssim_", "vsample",
+PRODUCT = ("hsvfilter", "hsvdetector", "hsv_from_frame", "colorlut", "copy_planes", "colordetect", "blockhash", "ssim", "vsample",
            "hsample", "gray_kernel", "i420", "overlay_blend")
 # read pattern of each product kernel (which calibration row applies)
 READ_PATTERN = [("hsvfilter4_typed", "read16_nt"), ("hsvfilter", "read16_nt"), ("hsvdetector", "read16"), ("colorlut", "read16"),
                 ("copy_planes", "read16"), ("colordetect_hist", "read4_stride40"), ("colordetect", "read16"), ("blockhash", "read16"),
-                ("ssim_", "read16"), ("", "read16")]
+                ("ssim", "read16"), ("", "read16")]
 WRITE_PATTERN = [("hsvfilter", "write16_nt"), ("", "write16")]
 
 
