@@ -1006,7 +1006,7 @@ def hsvfilter_main(args):
     launch_pct = percentiles(w.event_times(step, args.pct_steps, first_index=args.steps)) if args.pct_steps > 0 else None
 
     # ---- the element's launch model: --batch host threads x own HIP stream x single-frame calls -----------
-    streams = None
+    streams = combined = None
     if args.stream_threads > 0:
         hb = bench_harness()
         nthr = args.stream_threads
@@ -1026,25 +1026,36 @@ def hsvfilter_main(args):
         # the threads create their streams first (GPU idle for several ms -> clocks drop): own ~0.4 s warm-up on the threads
         stream_warmup = max(20, args.warmup, int(args.settle_seconds / 0.6 * 28000) // nthr)
         reps = 5  # the median of five back-to-back repetitions: a single 40 ms window is at the mercy of one descheduled thread
-        secs = (ctypes.c_double * reps)()
-        per = (ctypes.c_double * nthr)()
-        w.sync()
-        w.barrier()
-        rc = hb.mvfxbench_hsvfilter_streams_warm(w.local_rank, nthr, stream_warmup, launches, reps, flat, fpt, 1, warm, wfpt,
-                                                 ctypes.byref(settings), opts, secs, per)
-        if rc != 0:
-            raise RuntimeError(f"mvfxbench status {rc}: {vfx.last_error()}")
-        w.barrier()
-        rep_secs = sorted(secs)
-        (s_elapsed,) = w.max_over_ranks(rep_secs[reps // 2])
-        s_fps = nthr * launches * world / s_elapsed
-        streams = {"launch_model": f"{nthr} threads x 1 frame (own HIP stream each, single-frame mvfx_hsvfilter_transform_frame_ip, "
-                                   "no sync between launches; warm-up on scratch frames)",
-                   "value": s_fps, "unit": "frames/s", "frames": nthr * launches, "launches_per_thread": launches,
-                   "warmup_launches_per_thread": stream_warmup, "seconds": s_elapsed, "statistic": "median of 5 repetitions",
-                   "achieved_GBs": s_fps / world * 2 * FRAME_BYTES / 1e9, "frac_wall": s_fps / world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS,
-                   "repetitions_frames_per_sec": [round(nthr * launches / t) for t in secs],
-                   "per_rank_frames_per_sec": w.gather(nthr * launches / rep_secs[reps // 2])}
+
+        def threads_leg(batch_arg, what):
+            secs = (ctypes.c_double * reps)()
+            per = (ctypes.c_double * nthr)()
+            w.sync()
+            w.barrier()
+            rc = hb.mvfxbench_hsvfilter_streams_warm(w.local_rank, nthr, stream_warmup, launches, reps, flat, fpt, batch_arg, warm, wfpt,
+                                                     ctypes.byref(settings), opts, secs, per)
+            if rc != 0:
+                raise RuntimeError(f"mvfxbench status {rc}: {vfx.last_error()}")
+            w.barrier()
+            rep_secs = sorted(secs)
+            (s_elapsed,) = w.max_over_ranks(rep_secs[reps // 2])
+            s_fps = nthr * launches * world / s_elapsed
+            return {"launch_model": what, "value": s_fps, "unit": "frames/s", "frames": nthr * launches, "launches_per_thread": launches,
+                    "warmup_launches_per_thread": stream_warmup, "seconds": s_elapsed, "statistic": "median of 5 repetitions",
+                    "achieved_GBs": s_fps / world * 2 * FRAME_BYTES / 1e9, "frac_wall": s_fps / world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS,
+                    "repetitions_frames_per_sec": [round(nthr * launches / t) for t in secs],
+                    "per_rank_frames_per_sec": w.gather(nthr * launches / rep_secs[reps // 2])}
+
+        streams = threads_leg(1, f"{nthr} threads x 1 frame (own HIP stream each, single-frame mvfx_hsvfilter_transform_frame_ip, "
+                                 "no sync between launches; warm-up on scratch frames)")
+        # the launch combiner: the same threads make the same single-frame calls, the library coalesces them into batched launches
+        nb, nf = ctypes.c_uint64(), ctypes.c_uint64()
+        lib.mvfx_combiner_stats(w.local_rank, ctypes.byref(nb), ctypes.byref(nf))
+        combined = threads_leg(0, f"{nthr} threads x 1 frame through the launch combiner (mvfx_hsvfilter_transform_frame_ip_combined: one call "
+                                  "per buffer, frames of all threads coalesced into batched launches by the library)")
+        nb2, nf2 = ctypes.c_uint64(), ctypes.c_uint64()
+        lib.mvfx_combiner_stats(w.local_rank, ctypes.byref(nb2), ctypes.byref(nf2))
+        combined["frames_per_combined_launch"] = (nf2.value - nf.value) / max(nb2.value - nb.value, 1)
 
     # ---- the same batch leg on the other frame contents: the kernel has no data-dependent branch, but the chip is power
     # limited on this kernel and the bytes decide how much the data paths toggle (tools/exp_content_power.py) -------------
@@ -1090,7 +1101,7 @@ def hsvfilter_main(args):
         "config": {"workload": "hsvfilter 3840x2160 RGBA in place, hue-shift=90 saturation-mul=1.25 "
                                "saturation-off=-0.05 value-mul=0.9 value-off=0.02",
                    "frame_content": args.frame_content, "other_frame_contents": sweep,
-                   "launch_model": head["launch_model"], "other_launch_model": other,
+                   "launch_model": head["launch_model"], "other_launch_model": other, "combined_launch_model": combined,
                    "frames_per_step_per_gpu": args.batch, "resident_batches": pool, "steps_executed": n_launches[0],
                    "settle_seconds_before_warmup": args.settle_seconds, "settle_steps": settle_steps,
                    "parallelism": f"{world} independent stream shards, no data-path collective",

@@ -142,6 +142,10 @@ SIGNATURES = {
     "mvfx_thread_options": (c_uint32, []),
     "mvfx_hsvfilter_transform_frame_ip": (c_int, [POINTER(Frame), POINTER(HsvFilterSettings), c_void_p]),
     "mvfx_hsvfilter_transform_frames_ip": (c_int, [POINTER(Frame), c_uint32, POINTER(HsvFilterSettings), c_void_p]),
+    "mvfx_hsvfilter_transform_frames_ip_settings": (c_int, [POINTER(Frame), c_uint32, POINTER(HsvFilterSettings), c_void_p]),
+    "mvfx_hsvfilter_transform_frame_ip_combined": (c_int, [POINTER(Frame), POINTER(HsvFilterSettings), c_void_p]),
+    "mvfx_combiner_stats": (c_int, [c_int, POINTER(c_uint64), POINTER(c_uint64)]),
+    "mvfx_combiner_average_wait_us": (ctypes.c_double, [c_int]),
     "mvfx_hsvfilter_transform_frame_ip_host": (c_int, [POINTER(Frame), POINTER(HsvFilterSettings)]),
     "mvfx_hsvdetector_transform_frame": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(HsvDetectorSettings), c_void_p]),
     "mvfx_hsvdetector_transform_frames": (c_int, [POINTER(Frame), POINTER(Frame), c_uint32, POINTER(HsvDetectorSettings), c_void_p]),

@@ -54,18 +54,24 @@ extern "C" {
 // `warm_frames` (may be NULL): warm_frames_per_thread scratch frames per thread for the warm-up launches, so that the timed
 // launches start on frames no kernel has touched (frames that went through the filter many times are low-entropy, the chip
 // draws less power on them and clocks higher: profiles/r2/exp_content_power.txt).  NULL = warm up on the timed frames.
+//
+// batch == 0: the launch combiner -- every thread calls the single-frame mvfx_hsvfilter_transform_frame_ip_combined and the
+// library's submitter thread coalesces the frames of all threads into batched launches.
 int mvfxbench_hsvfilter_streams_warm(int device, uint32_t n_threads, uint32_t warmup, uint32_t launches, uint32_t reps,
                                      const mvfx_frame *frames, uint32_t frames_per_thread, uint32_t batch,
                                      const mvfx_frame *warm_frames, uint32_t warm_frames_per_thread,
                                      const mvfx_hsvfilter_settings *settings, uint32_t options, double *seconds_out,
                                      double *thread_seconds)
 {
-    if (!frames || !settings || !seconds_out || n_threads == 0 || frames_per_thread == 0 || reps == 0 || batch == 0 ||
+    const bool combined = batch == 0;
+    if (combined) batch = 1;
+    if (!frames || !settings || !seconds_out || n_threads == 0 || frames_per_thread == 0 || reps == 0 ||
         frames_per_thread % batch != 0 || (warm_frames && (warm_frames_per_thread == 0 || warm_frames_per_thread % batch != 0)))
         return MVFX_ERR_INVALID_ARGUMENT;
     const uint32_t groups = frames_per_thread / batch;
     auto launch_in = [&](const mvfx_frame *mine, uint32_t n_groups, uint32_t i, mvfx_stream st) {
         const mvfx_frame *f = mine + (size_t)(i % n_groups) * batch;
+        if (combined) return mvfx_hsvfilter_transform_frame_ip_combined(f, settings, st);
         return batch == 1 ? mvfx_hsvfilter_transform_frame_ip(f, settings, st) : mvfx_hsvfilter_transform_frames_ip(f, batch, settings, st);
     };
     auto launch = [&](const mvfx_frame *mine, uint32_t i, mvfx_stream st) { return launch_in(mine, groups, i, st); };

@@ -25,8 +25,21 @@ __device__ __forceinline__ void init_filter_lds(FilterLds &lds, int off, bool bg
     }
 }
 
+// The settings-dependent part of FastConsts, one per frame of a launch whose frames come from different elements
+struct FrameSettings {
+    float hue_shift, saturation_mul, saturation_off, value_mul, value_off, neg_saturation_mul;
+};
+struct FrameSettingsBatch {
+    FrameSettings s[kMaxBatch];
+};
+
 // hsv_typed_kernels.hip: hsvfilter4_typed_kernel<neg ? kFastNeg : kFast, tile (1 | 2), streaming>
 void launch_hsvfilter_typed(bool neg_shift, int tile, bool streaming, dim3 grid, hipStream_t stream, const FrameBatch &fb, uint64_t width,
                             uint32_t rows, uint64_t stride, const FastConsts &p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr);
+
+// the same with per-frame settings in the kernel arguments (all frames: hue_shift of one sign)
+void launch_hsvfilter_typed_frames(bool neg_shift, int tile, bool streaming, dim3 grid, hipStream_t stream, const FrameBatch &fb, uint64_t width,
+                                   uint32_t rows, uint64_t stride, const FastConsts &p, const FrameSettingsBatch &fs, uint32_t word3,
+                                   uint32_t frame_bytes, int off, bool bgr);
 
 } // namespace mvfx

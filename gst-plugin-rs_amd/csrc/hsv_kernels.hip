@@ -25,8 +25,10 @@
 #include "convert_math.hpp"
 #include "mvfx_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 namespace mvfx {
 namespace {
@@ -640,6 +642,67 @@ int hsvfilter_impl(const mvfx_frame *frames, uint32_t n, const mvfx_hsvfilter_se
 }
 
 
+// n frames of one geometry and format, every frame with ITS OWN settings (frames of different hsvfilter elements that the launch
+// combiner put together).  Frames whose settings allow the typed strength-reduced kernel share launches (one per sign of
+// hue-shift: the wrap of the shifted hue is compiled in); the others go through hsvfilter_impl one by one.  Same bytes as n calls of
+// hsvfilter_impl.
+int hsvfilter_frames_impl(const mvfx_frame *frames, uint32_t n, const mvfx_hsvfilter_settings *settings, hipStream_t stream)
+{
+    if (!frames || !settings || n == 0)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvfilter: NULL frame/settings or empty batch");
+    int bpp, off;
+    bool bgr;
+    if (filter_layout(frames[0].format, &bpp, &off, &bgr) != 0)
+        return fail(MVFX_ERR_UNSUPPORTED_FORMAT, "hsvfilter: format %d is not a packed RGB format (hsvfilter/imp.rs:372)", frames[0].format);
+    bool same = true;
+    for (uint32_t i = 1; i < n; i++)
+        same = same && frames[i].width == frames[0].width && frames[i].height == frames[0].height && frames[i].stride == frames[0].stride &&
+               frames[i].format == frames[0].format;
+    const uint64_t frame_bytes = (uint64_t)frames[0].stride * frames[0].height;
+    const bool typed_ok = same && opt_typed_loads() && opt_hsv_variant() != 1 && bpp == 4 && frame_bytes < (1ull << 32) && frame_bytes % 4 == 0 &&
+                          frames[0].width != 0 && frames[0].height != 0;
+    std::vector<uint32_t> group[2]; // [hue_shift negative]
+    for (uint32_t i = 0; i < n; i++) {
+        const mvfx_hsvfilter_settings &s = settings[i];
+        if (typed_ok && fast_domain_ok(s) && check_packed_frame(&frames[i], "hsvfilter") == MVFX_OK)
+            group[std::signbit(s.hue_shift) && s.hue_shift != 0.0f ? 1 : 0].push_back(i);
+        else if (int rc = hsvfilter_impl(&frames[i], 1, &s, stream); rc != MVFX_OK)
+            return rc;
+    }
+    if (group[0].empty() && group[1].empty()) return MVFX_OK;
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    const uint32_t iR = off + (bgr ? 2 : 0), iG = off + 1, iB = off + (bgr ? 0 : 2);
+    const uint32_t word3 = (4 + iR) | ((4 + iG) << 3) | ((4 + iB) << 6) | (10u << 15);
+    for (int neg = 0; neg < 2; neg++) {
+        const std::vector<uint32_t> &idx = group[neg];
+        for (size_t done = 0; done < idx.size(); done += kMaxBatch) {
+            const uint32_t m = (uint32_t)std::min<size_t>(idx.size() - done, kMaxBatch);
+            FrameBatch fb{};
+            FrameSettingsBatch fs{};
+            std::vector<mvfx_frame> sel(m);
+            for (uint32_t k = 0; k < m; k++) {
+                const uint32_t i = idx[done + k];
+                sel[k] = frames[i];
+                fb.base[k] = static_cast<uint8_t *>(frames[i].data);
+                const FastConsts c = make_consts(&settings[i]);
+                fs.s[k] = {c.hue_shift, c.saturation_mul, c.saturation_off, c.value_mul, c.value_off, c.neg_saturation_mul};
+            }
+            const Geometry g = plan(sel.data(), m, bpp, m, kTile);
+            if (g.mode != kModeVec4 || (g.width & 3) != 0) { // unaligned frames: the per-frame path
+                for (uint32_t k = 0; k < m; k++)
+                    if (int rc = hsvfilter_impl(&sel[k], 1, &settings[idx[done + k]], stream); rc != MVFX_OK) return rc;
+                continue;
+            }
+            const FastConsts p = make_consts(&settings[idx[done]]);
+            launch_hsvfilter_typed_frames(neg != 0, g.tile == kTile ? kTile : 1, opt_nontemporal(), g.grid, stream, fb, g.width, g.rows, g.stride, p, fs,
+                                          word3, (uint32_t)frame_bytes, off, bgr);
+            MVFX_HIP_TRY(hipGetLastError());
+        }
+    }
+    return MVFX_OK;
+}
+
+
 int hsvfilter_i420_impl(const mvfx_planar_frame *in, const mvfx_planar_frame *out, const mvfx_hsvfilter_settings *s, int yuv_standard,
                         hipStream_t stream)
 {
@@ -1006,6 +1069,12 @@ int mvfx_hsvfilter_transform_frames_ip(const mvfx_frame *frames, uint32_t n_fram
                                        const mvfx_hsvfilter_settings *settings, mvfx_stream stream)
 {
     return hsvfilter_impl(frames, n_frames, settings, as_stream(stream));
+}
+
+int mvfx_hsvfilter_transform_frames_ip_settings(const mvfx_frame *frames, uint32_t n_frames,
+                                                const mvfx_hsvfilter_settings *settings, mvfx_stream stream)
+{
+    return hsvfilter_frames_impl(frames, n_frames, settings, as_stream(stream));
 }
 
 int mvfx_hsvfilter_transform_i420(const mvfx_planar_frame *i420_in, const mvfx_planar_frame *i420_out,

@@ -21,8 +21,8 @@ typedef float f32x3 __attribute__((ext_vector_type(3)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 template <int VARIANT, int TILE, bool NT>
-__global__ __launch_bounds__(kBlock) void hsvfilter4_typed_kernel(FrameBatch fb, uint64_t width, uint32_t rows, uint64_t stride,
-                                                                  FastConsts p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr)
+__device__ __forceinline__ void hsvfilter4_typed_body(const FrameBatch &fb, uint64_t width, uint32_t rows, uint64_t stride,
+                                                      const FastConsts &p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr)
 {
     static_assert(VARIANT == kFast || VARIANT == kFastNeg, "strength-reduced variants only");
     __shared__ FilterLds lds;
@@ -98,6 +98,31 @@ __global__ __launch_bounds__(kBlock) void hsvfilter4_typed_kernel(FrameBatch fb,
     }
 }
 
+template <int VARIANT, int TILE, bool NT>
+__global__ __launch_bounds__(kBlock) void hsvfilter4_typed_kernel(FrameBatch fb, uint64_t width, uint32_t rows, uint64_t stride,
+                                                                  FastConsts p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr)
+{
+    hsvfilter4_typed_body<VARIANT, TILE, NT>(fb, width, rows, stride, p, word3, frame_bytes, off, bgr);
+}
+
+// The same kernel with the settings of every frame of the launch in the argument block (blockIdx.z = frame = stream): what the
+// launch combiner needs -- the elements of a process each keep their own `hue-shift` ... properties (hsvfilter/imp.rs:32-39), yet
+// their frames share one launch.  The per-frame values are wave-uniform scalar loads from the kernel arguments.
+template <int VARIANT, int TILE, bool NT>
+__global__ __launch_bounds__(kBlock) void hsvfilter4_typed_frames_kernel(FrameBatch fb, uint64_t width, uint32_t rows, uint64_t stride,
+                                                                         FastConsts p, FrameSettingsBatch fs, uint32_t word3,
+                                                                         uint32_t frame_bytes, int off, bool bgr)
+{
+    const FrameSettings &f = fs.s[blockIdx.z];
+    p.hue_shift = f.hue_shift;
+    p.saturation_mul = f.saturation_mul;
+    p.saturation_off = f.saturation_off;
+    p.value_mul = f.value_mul;
+    p.value_off = f.value_off;
+    p.neg_saturation_mul = f.neg_saturation_mul;
+    hsvfilter4_typed_body<VARIANT, TILE, NT>(fb, width, rows, stride, p, word3, frame_bytes, off, bgr);
+}
+
 
 } // namespace
 
@@ -111,6 +136,19 @@ void launch_hsvfilter_typed(bool neg_shift, int tile, bool streaming, dim3 grid,
     else { if (neg_shift) MVFX_LT_NT(kFastNeg, 1); else MVFX_LT_NT(kFast, 1); }
 #undef MVFX_LT_NT
 #undef MVFX_LT
+}
+
+void launch_hsvfilter_typed_frames(bool neg_shift, int tile, bool streaming, dim3 grid, hipStream_t stream, const FrameBatch &fb, uint64_t width,
+                                   uint32_t rows, uint64_t stride, const FastConsts &p, const FrameSettingsBatch &fs, uint32_t word3,
+                                   uint32_t frame_bytes, int off, bool bgr)
+{
+#define MVFX_LF(V, T_, NT_) \
+    hipLaunchKernelGGL((hsvfilter4_typed_frames_kernel<V, T_, NT_>), grid, dim3(kBlock), 0, stream, fb, width, rows, stride, p, fs, word3, frame_bytes, off, bgr)
+#define MVFX_LF_NT(V, T_) do { if (streaming) MVFX_LF(V, T_, true); else MVFX_LF(V, T_, false); } while (0)
+    if (tile == 2) { if (neg_shift) MVFX_LF_NT(kFastNeg, 2); else MVFX_LF_NT(kFast, 2); }
+    else { if (neg_shift) MVFX_LF_NT(kFastNeg, 1); else MVFX_LF_NT(kFast, 1); }
+#undef MVFX_LF_NT
+#undef MVFX_LF
 }
 
 } // namespace mvfx

@@ -123,8 +123,11 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
     // it the same way, a CPU map waits on the host (d3d12colorlut/imp.rs:695-714 does this with an ID3D12Fence)
     mvfx_stream st = mvfx_thread_stream();
     mvfx_hip_buffer_acquire(buf, st);
-    // default cache policy (thread option word 0): the next element reads this frame on the GPU
-    int rc = mvfx_hsvfilter_transform_frame_ip(&f, &s, st);
+    // default cache policy (thread option word 0): the next element reads this frame on the GPU.
+    // MVFX_COMBINE=1 (environment, read once): the launch combiner -- still one call per buffer, but the frames the hsvfilter
+    // elements of this process hand in at about the same time leave as one batched launch with per-frame settings
+    static const bool combine = g_getenv("MVFX_COMBINE") && atoi(g_getenv("MVFX_COMBINE")) != 0;
+    int rc = combine ? mvfx_hsvfilter_transform_frame_ip_combined(&f, &s, st) : mvfx_hsvfilter_transform_frame_ip(&f, &s, st);
     mvfx_hip_buffer_release(buf, st);
     gst_buffer_unmap(buf, &map);
     return MVFX_GST_FLOW(self, rc);

@@ -234,6 +234,7 @@ struct GstMi355HipTestSrc {
     GstPushSrc parent;
     GstVideoInfo info;
     gboolean have_info, hip;
+    gboolean refresh;    // property: re-copy the master into every recycled device block (default); FALSE: fill each block once
     guint8 *pattern;
     gsize pattern_size;
     void *master;        // device copy of `pattern` (memory:HIPMemory caps)
@@ -368,10 +369,16 @@ static GstFlowReturn hiptestsrc_fill(GstPushSrc *psrc, GstBuffer *buf)
     if (self->hip && self->master && mvfx_buffer_is_hip(buf)) {
         GstMapInfo map;
         if (!gst_buffer_map(buf, &map, (GstMapFlags)(MVFX_MAP_HIP | GST_MAP_WRITE))) return GST_FLOW_ERROR;
-        mvfx_stream st = mvfx_thread_stream();
-        mvfx_hip_buffer_acquire(buf, st);
-        const int rc = mvfx_copy_device_to_device_async(map.data, self->master, MIN(self->pattern_size, map.size), st);
-        mvfx_hip_buffer_release(buf, st);
+        int rc = MVFX_OK;
+        // refresh=false (throughput measurements of a filter alone): a block is filled on its first trip only -- an in-place filter
+        // downstream then works on its own output from the second trip on, and the source costs no HBM traffic
+        if (self->refresh || !gst_mini_object_get_qdata(GST_MINI_OBJECT_CAST(mem), hiptestsrc_filled_quark())) {
+            mvfx_stream st = mvfx_thread_stream();
+            mvfx_hip_buffer_acquire(buf, st);
+            rc = mvfx_copy_device_to_device_async(map.data, self->master, MIN(self->pattern_size, map.size), st);
+            mvfx_hip_buffer_release(buf, st);
+            gst_mini_object_set_qdata(GST_MINI_OBJECT_CAST(mem), hiptestsrc_filled_quark(), GINT_TO_POINTER(1), NULL);
+        }
         gst_buffer_unmap(buf, &map);
         if (rc != MVFX_OK) return MVFX_GST_FLOW(self, rc);
     } else if (!gst_mini_object_get_qdata(GST_MINI_OBJECT_CAST(mem), hiptestsrc_filled_quark())) {
@@ -404,11 +411,31 @@ static void gst_mi355_hip_test_src_finalize(GObject *obj)
     G_OBJECT_CLASS(gst_mi355_hip_test_src_parent_class)->finalize(obj);
 }
 
+enum { PROP_TS_0, PROP_TS_REFRESH };
+
+static void hiptestsrc_set_property(GObject *obj, guint id, const GValue *value, GParamSpec *pspec)
+{
+    if (id == PROP_TS_REFRESH) ((GstMi355HipTestSrc *)obj)->refresh = g_value_get_boolean(value);
+    else G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec);
+}
+
+static void hiptestsrc_get_property(GObject *obj, guint id, GValue *value, GParamSpec *pspec)
+{
+    if (id == PROP_TS_REFRESH) g_value_set_boolean(value, ((GstMi355HipTestSrc *)obj)->refresh);
+    else G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec);
+}
+
 static void gst_mi355_hip_test_src_class_init(GstMi355HipTestSrcClass *klass)
 {
     GstElementClass *element = GST_ELEMENT_CLASS(klass);
     GstBaseSrcClass *bs = GST_BASE_SRC_CLASS(klass);
     G_OBJECT_CLASS(klass)->finalize = gst_mi355_hip_test_src_finalize;
+    G_OBJECT_CLASS(klass)->set_property = hiptestsrc_set_property;
+    G_OBJECT_CLASS(klass)->get_property = hiptestsrc_get_property;
+    g_object_class_install_property(G_OBJECT_CLASS(klass), PROP_TS_REFRESH,
+        g_param_spec_boolean("refresh", "Refresh", "memory:HIPMemory: copy the pattern into every recycled buffer (FALSE: fill each buffer once; "
+                             "in-place filters downstream then see their own output again)", TRUE,
+                             (GParamFlags)(G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS)));
     GstCaps *sys = gst_caps_new_empty_simple("video/x-raw");
     GstCaps *both = mvfx_caps_plus_hip(sys);
     gst_element_class_add_pad_template(element, gst_pad_template_new("src", GST_PAD_SRC, GST_PAD_ALWAYS, both));
@@ -426,6 +453,7 @@ static void gst_mi355_hip_test_src_class_init(GstMi355HipTestSrcClass *klass)
 static void gst_mi355_hip_test_src_init(GstMi355HipTestSrc *self)
 {
     self->have_info = self->hip = FALSE;
+    self->refresh = TRUE;
     self->pattern = NULL;
     self->pattern_size = 0;
     self->master = NULL;

@@ -1,0 +1,127 @@
+"""The launch combiner (gst-plugin-rs_amd/csrc/combiner.hip): one call per buffer stays the element's contract
+(hsvfilter/imp.rs:322-326), frames that the streaming threads of a process submit at about the same time share one batched launch
+with per-frame settings.  Checked: the bytes equal the oracle's for every stream's own settings (both signs of hue-shift, settings
+outside the strength-reduced kernel's domain, a stream with another frame size), calls are ordered with the caller's stream, and
+launches really are shared."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+from tests import frames
+from tests import oracle_binding as orc
+
+pytestmark = pytest.mark.gpu
+
+SETTINGS = [(90.0, 1.25, -0.05, 0.9, 0.02), (-45.0, 0.8, 0.1, 1.1, -0.03), (0.0, 1.0, 0.0, 1.0, 0.0), (359.5, 2.0, -0.5, 0.5, 0.25),
+            (-360.0, 1.0, 0.0, 1.0, 0.0), (500.0, 1.0, 0.0, 1.0, 0.0), (12.5, 0.0, 0.5, 1.0, 0.0), (-0.0, 1.5, 0.0, 0.75, 0.1)]
+
+
+def test_frames_with_their_own_settings_in_one_call(gpu):
+    """mvfx_hsvfilter_transform_frames_ip_settings: settings[i] for frames[i]; frames of one sign of hue-shift share a launch, settings
+    outside the proven domain (|shift| > 360) take the literal kernel -- same bytes as the oracle frame by frame."""
+    w, h, n = 640, 360, len(SETTINGS)
+    host = [frames.random_frame(0xC0B0 + k, w, h) for k in range(n)]
+    bufs = [gpu.DeviceBuffer(f.nbytes).upload(f) for f in host]
+    arr = (gpu.Frame * n)(*[gpu.make_frame(b.ptr, w, h, w * 4, "BGRx") for b in bufs])
+    st = (gpu.HsvFilterSettings * n)(*[gpu.HsvFilterSettings(*s) for s in SETTINGS])
+    gpu.check(gpu.lib().mvfx_hsvfilter_transform_frames_ip_settings(arr, n, st, None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    for k in range(n):
+        exp = host[k].copy()
+        assert orc.hsvfilter(exp, w, w * 4, "BGRx", SETTINGS[k]) == 0
+        assert np.array_equal(bufs[k].download().reshape(h, w * 4), exp), f"frame {k} settings {SETTINGS[k]}"
+
+
+def test_sixteen_threads_through_the_combiner(gpu):
+    """16 host threads (GStreamer: one streaming thread per stream), each with its own HIP stream, frames and settings, each making
+    single-frame calls through the combiner; thread 15 works on another frame size (never shares a launch).  Every frame equals the
+    oracle's answer for its stream's settings; the combiner needed fewer launches than frames."""
+    L = gpu.lib()
+    n_threads, per_thread = 16, 12
+    w, h = 960, 540
+    nb0, nf0 = ctypes.c_uint64(), ctypes.c_uint64()
+    gpu.check(L.mvfx_combiner_stats(0, ctypes.byref(nb0), ctypes.byref(nf0)))
+    errors, results = [], {}
+    start = threading.Barrier(n_threads)
+
+    def body(t):
+        try:
+            gpu.check(L.mvfx_set_device(0))
+            tw, th = (w, h) if t != 15 else (320, 200)
+            s = SETTINGS[t % len(SETTINGS)]
+            st = gpu.HsvFilterSettings(*s)
+            stream = L.mvfx_thread_stream()
+            host = [frames.random_frame(0xC100 + 97 * t + k, tw, th) for k in range(per_thread)]
+            bufs = [gpu.DeviceBuffer(f.nbytes) for f in host]
+            start.wait()
+            for k in range(per_thread):
+                # upload on the caller's stream, filter through the combiner, download on the caller's stream: the combined call must
+                # order behind the copy before it and ahead of the copy after it
+                gpu.check(L.mvfx_copy_to_device_async(ctypes.c_void_p(bufs[k].ptr), host[k].ctypes.data_as(ctypes.c_void_p), host[k].nbytes,
+                                                      ctypes.c_void_p(stream)))
+                f = gpu.make_frame(bufs[k].ptr, tw, th, tw * 4, "RGBA")
+                gpu.check(L.mvfx_hsvfilter_transform_frame_ip_combined(ctypes.byref(f), ctypes.byref(st), ctypes.c_void_p(stream)))
+            out = [np.empty_like(f) for f in host]
+            for k in range(per_thread):
+                gpu.check(L.mvfx_copy_to_host_async(out[k].ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(bufs[k].ptr), out[k].nbytes,
+                                                    ctypes.c_void_p(stream)))
+            gpu.check(L.mvfx_stream_synchronize(ctypes.c_void_p(stream)))
+            results[t] = (host, out, s, tw)
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    ths = [threading.Thread(target=body, args=(t,)) for t in range(n_threads)]
+    for th_ in ths:
+        th_.start()
+    for th_ in ths:
+        th_.join()
+    assert errors == []
+    for t, (host, out, s, tw) in results.items():
+        for k in range(per_thread):
+            exp = host[k].copy()
+            assert orc.hsvfilter(exp, tw, tw * 4, "RGBA", s) == 0
+            assert np.array_equal(out[k], exp), f"thread {t} frame {k}"
+    nb1, nf1 = ctypes.c_uint64(), ctypes.c_uint64()
+    gpu.check(L.mvfx_combiner_stats(0, ctypes.byref(nb1), ctypes.byref(nf1)))
+    assert nf1.value - nf0.value == n_threads * per_thread
+    assert nb1.value - nb0.value < nf1.value - nf0.value, "no launch was shared"
+
+
+LONE = r"""
+import ctypes, sys, time
+sys.path.insert(0, {root!r})
+import _pkg
+from tests import frames
+gpu = _pkg.vfx
+L = gpu.lib()
+gpu.check(L.mvfx_set_device(0))
+w, h = 320, 240
+f0 = frames.random_frame(0xC200, w, h)
+buf = gpu.DeviceBuffer(f0.nbytes).upload(f0)
+f = gpu.make_frame(buf.ptr, w, h, w * 4, "RGBA")
+st = gpu.HsvFilterSettings(90.0, 1.25, -0.05, 0.9, 0.02)
+for _ in range(5):
+    gpu.check(L.mvfx_hsvfilter_transform_frame_ip_combined(ctypes.byref(f), ctypes.byref(st), None))
+gpu.check(L.mvfx_stream_synchronize(None))
+t = time.perf_counter()
+for _ in range(50):
+    gpu.check(L.mvfx_hsvfilter_transform_frame_ip_combined(ctypes.byref(f), ctypes.byref(st), None))
+gpu.check(L.mvfx_stream_synchronize(None))
+print("PER_CALL_US", (time.perf_counter() - t) / 50 * 1e6)
+"""
+
+
+def test_a_lone_stream_is_not_held_back(gpu):
+    """One caller is the only recently active stream: every call is launched at once, however long the collection window is
+    (here 20 ms: 50 calls would take a second if each waited for it)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MVFX_COMBINE_WINDOW_US="20000")
+    r = subprocess.run([sys.executable, "-c", LONE.format(root=root)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-2000:]
+    us = float([ln for ln in r.stdout.splitlines() if ln.startswith("PER_CALL_US")][-1].split()[1])
+    assert us < 2000.0, f"{us:.0f} us per call: the lone stream waited for the window"

@@ -443,6 +443,29 @@ def test_hipmemory_tee_two_device_readers_on_recycled_blocks(gpu, tmp_path):
         assert bad == [], f"{name}: frames {bad} differ"
 
 
+def test_sixteen_hsvfilter_branches_through_the_launch_combiner(gpu, tmp_path):
+    """16 `hiptestsrc ! hsvfilter ! hipdownload ! filesink` streams in one process with MVFX_COMBINE=1: every hsvfilter still makes
+    one call per buffer (hsvfilter/imp.rs:322-326), the library coalesces the frames of the 16 streaming threads into batched
+    launches with per-frame settings.  Every branch has its own hue-shift (both signs) / saturation-mul; every frame of every branch
+    equals the oracle's answer for that branch; and launches were shared."""
+    w, h, n, branches = 640, 360, 10, 16
+    raw = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBA,width={w},height={h}", "in.raw")
+    settings = [((23 * k) % 360 - 150.0, 1.0 + 0.05 * k, 0.0, 1.0, 0.0) for k in range(branches)]
+    caps = f"video/x-raw(memory:HIPMemory),format=RGBA,width={w},height={h},framerate=30/1"
+    pipe = " ".join(f"hiptestsrc num-buffers={n} ! {caps} ! hsvfilter hue-shift={s[0]} saturation-mul={s[1]} ! hipdownload ! "
+                    f"filesink location={tmp_path}/b{k}.raw" for k, s in enumerate(settings))
+    r = gst_env.run([LAUNCH, "-q"] + pipe.split(), tmp_path, extra_env={"MVFX_COMBINE": "1", "MVFX_COMBINE_STATS": "1"})
+    assert r.returncode == 0, r.stdout
+    for k, s in enumerate(settings):
+        got = np.fromfile(f"{tmp_path}/b{k}.raw", dtype=np.uint8).reshape(n, h, w * 4)
+        exp = raw.copy().reshape(h, w * 4)
+        assert orc.hsvfilter(exp, w, w * 4, "RGBA", s) == 0
+        bad = [i for i in range(n) if not np.array_equal(got[i], exp)]
+        assert bad == [], f"branch {k} (hue-shift {s[0]}): frames {bad} differ"
+    m = re.search(r"mvfx combiner device 0: (\d+) launches for (\d+) frames", r.stdout)
+    assert m and int(m.group(2)) == branches * n and int(m.group(1)) < int(m.group(2)), r.stdout[-500:]
+
+
 # ---- imagersoverlay (SURVEY 8f-4): PNG logo blended by the HIP kernel, positions per overlay/imp.rs:84-191
 def _logo_png(path, w=48, h=32):
     from PIL import Image

@@ -45,14 +45,45 @@ def fps(template, tmp, n1, n2, extra_env=None):
     return (n2 - n1) / (t2 - t1), t1, t2
 
 
+def branches_main(args):
+    """--branches N: N independent `hiptestsrc ! hsvfilter ! fakesink` streams in ONE process (each its own streaming thread and
+    HIP stream, each hsvfilter with its own hue-shift), frames born in HBM.  Launch model of the elements: a launch per buffer
+    (MVFX_COMBINE unset) against the launch combiner (MVFX_COMBINE=1: the frames of the N threads leave as batched launches with
+    per-frame settings).  refresh=false: the source fills every pool block once, so the only HBM traffic is the filter's 8 B/px."""
+    import re
+    tmp = tempfile.mkdtemp()
+    w, h, n = args.width, args.height, args.branches
+    caps = f"video/x-raw(memory:HIPMemory),format=RGBA,width={w},height={h},framerate=30/1"
+    out = {"frame": f"{w}x{h}", "branches": n, "n1": args.n1, "n2": args.n2, "bytes_per_frame": 2 * w * h * 4}
+    for refresh in ("false", "true"):
+        tpl = " ".join(f"hiptestsrc num-buffers={{n}} refresh={refresh} ! {caps} ! hsvfilter hue-shift={(17 * k) % 360 - 120} saturation-mul={1 + 0.02 * k} "
+                       "! fakesink sync=false" for k in range(n))
+        for combine in ("0", "1"):
+            env = {"MVFX_COMBINE": combine, "MVFX_COMBINE_STATS": "1"}
+            v, t1, t2 = fps(tpl, tmp, args.n1, args.n2, env)
+            key = f"refresh_{refresh}_combine_{combine}"
+            out[key + "_fps"] = round(v * n, 1)
+            out[key + "_frac_of_8TBs"] = round(v * n * 2 * w * h * 4 / 8e12, 4)
+            if combine == "1":
+                r = gst_env.run([LAUNCH, "-q"] + tpl.format(n=args.n2).split(), tmp, timeout=900, extra_env=env)
+                m = re.search(r"mvfx combiner device 0: (\d+) launches for (\d+) frames \(([0-9.]+) frames per launch\), ([0-9.]+) us", r.stdout)
+                if m:
+                    out[key + "_frames_per_launch"] = float(m.group(3))
+                    out[key + "_submit_to_launch_us"] = float(m.group(4))
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--branches", type=int, default=0, help="N parallel hiptestsrc ! hsvfilter ! fakesink streams in one process (launch combiner A/B)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--n1", type=int, default=60)
     ap.add_argument("--n2", type=int, default=460)
     ap.add_argument("--lut", type=int, default=33)
     args = ap.parse_args()
+    if args.branches > 0:
+        return branches_main(args)
     tmp = tempfile.mkdtemp()
     cube = os.path.join(tmp, "look.cube")
     with open(cube, "w") as f:
