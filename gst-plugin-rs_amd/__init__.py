@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("MVFX_LIB") or os.path.join(_HERE, "libmi355vfx.so")
 # mvfx_format (include/mi355vfx.h)
 FORMATS = {
     "RGBx": 0, "xRGB": 1, "BGRx": 2, "xBGR": 3, "RGBA": 4, "ARGB": 5, "BGRA": 6, "ABGR": 7,
-    "RGB": 8, "BGR": 9, "RGBA64_LE": 10, "RGBA64_BE": 11, "I420": 12, "A420": 13, "RGB10A2_LE": 14,
+    "RGB": 8, "BGR": 9, "RGBA64_LE": 10, "RGBA64_BE": 11, "I420": 12, "A420": 13, "RGB10A2_LE": 14, "NV12": 15,
 }
 FORMAT_NAMES = {v: k for k, v in FORMATS.items()}
 BYTES_PER_PIXEL = {0: 4, 1: 4, 2: 4, 3: 4, 4: 4, 5: 4, 6: 4, 7: 4, 8: 3, 9: 3, 10: 8, 11: 8, 14: 4}
@@ -203,6 +203,8 @@ SIGNATURES = {
     "mvfx_roundedcorners_cairo_version": (c_char_p, []),
     "mvfx_convert_i420_to_rgba": (c_int, [POINTER(PlanarFrame), POINTER(Frame), ctypes.c_int32, c_void_p]),
     "mvfx_convert_rgba_to_i420": (c_int, [POINTER(Frame), POINTER(PlanarFrame), ctypes.c_int32, c_void_p]),
+    "mvfx_convert_nv12_to_rgba": (c_int, [POINTER(PlanarFrame), POINTER(Frame), ctypes.c_int32, c_void_p]),
+    "mvfx_convert_rgba_to_nv12": (c_int, [POINTER(Frame), POINTER(PlanarFrame), ctypes.c_int32, c_void_p]),
     "mvfx_hsvfilter_transform_i420": (c_int, [POINTER(PlanarFrame), POINTER(PlanarFrame), POINTER(HsvFilterSettings), ctypes.c_int32, c_void_p]),
     "mvfx_convert_i420_to_rgba_frames": (c_int, [POINTER(PlanarFrame), POINTER(Frame), c_uint32, ctypes.c_int32, c_void_p]),
     "mvfx_convert_rgba_to_i420_frames": (c_int, [POINTER(Frame), POINTER(PlanarFrame), c_uint32, ctypes.c_int32, c_void_p]),

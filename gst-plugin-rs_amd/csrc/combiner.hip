@@ -1,28 +1,27 @@
 // Launch combiner: the elements keep their contract -- one call per buffer (hsvfilter/imp.rs:322-326) -- yet the frames that the
 // streaming threads of one process hand in at about the same time leave as ONE batched launch (blockIdx.z = frame, the settings
 // of every frame in the kernel arguments).  A 4K frame is ~11.5 us of GPU work inside a 16-frame launch and ~16 us as a launch of
-// its own; 16 threads x own stream x single-frame launches reach 0.66 of the HBM peak where the batched launch reaches 0.72
-// (profiles/r3/bench_driver_command.json: every kernel boundary costs ~1-2 us of whole-chip time).
+// its own; 16 threads x own stream x single-frame launches reach 0.66 of the HBM peak where the batched launch reaches 0.72: every
+// kernel boundary costs ~1-2 us of whole-chip time.
 //
-//   caller (a streaming thread, its own HIP stream S):
-//       record event R on S                      -- everything the caller enqueued before (the fence wait of the buffer) orders first
-//       enqueue {frame, settings, R}, wake the submitter, sleep until the frame's batch has been launched
-//       make S wait for the batch's event D      -- whatever the caller enqueues next on S (its fence record, the next element's
-//                                                   kernel) orders behind the batch: same ordering as the single-frame call
-//   submitter (one thread per device, its own stream C):
-//       wait for the first request; then until 16 requests are there, one of every stream that submitted in the last 2 ms, or the
-//       window (MVFX_COMBINE_WINDOW_US, default 40) is over;  C waits for every R;  one launch for the frames that share geometry and format
-//       (others: the next round);  record D on C;  wake the callers.
-//
-// The host never waits for the GPU in here.  Latency added per buffer: at most the window, in a busy process the time the other
-// streams take to hand in their frames (microseconds).
+// No extra thread.  The first caller that finds no open batch becomes its LEADER; callers that arrive while it collects join as
+// followers:
+//   follower (its own stream S): record event R on S unless S is idle (everything the caller enqueued before orders first), put
+//       {frame, settings, R} into the open batch, spin until the leader has launched, then make S wait for the batch's event D
+//       (whatever the caller enqueues next on S -- its fence record, the next element's kernel -- orders behind the batch);
+//   leader (its own stream L): spins until 16 frames are in, every stream that submitted in the last 2 ms has one in, or the
+//       window (MVFX_COMBINE_WINDOW_US, default 30) is over; closes the batch; L waits for every follower's R; ONE launch on L
+//       for all frames (frames that do not share the first one's geometry / format / cache policy are not admitted: they open the
+//       next batch); records D on L; releases the followers.
+// The host never waits for the GPU in here, and a lone stream is never held back (it is the only recent caller: its batch closes at
+// once).  Round 3 history: the first version handed the frames to a submitter thread through a condition variable -- two thread
+// hand-offs and a mutex convoy of 16 woken callers per batch: 46.6 k fps where plain per-stream launches do 79.6 k
+// (profiles/r3/combiner_first_version.txt); leader / follower with short spins removed the hand-offs.
 #include "mvfx_internal.h"
 
 #include <atomic>
 #include <chrono>
-#include <condition_variable>
 #include <cstdlib>
-#include <deque>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -31,78 +30,141 @@
 namespace mvfx {
 namespace {
 
-struct DoneSlot {
-    hipEvent_t event = nullptr;
-    int waiters = 0; // callers that still have to make their stream wait for `event` (guarded by Combiner::m)
-};
+constexpr int kMaxCombine = 16;
+using Clock = std::chrono::steady_clock;
 
 struct Request {
     mvfx_frame frame;
     mvfx_hsvfilter_settings settings;
-    hipEvent_t ready;
-    uint32_t options;       // the caller's thread options (cache policy)
-    bool launched = false;
+    hipEvent_t ready; // nullptr: the caller's stream was idle
+};
+
+struct Batch {
+    Request *req[kMaxCombine];
+    std::atomic<int> n{0};
+    std::atomic<int> launched{0}; // release-stored by the leader after the launch has been enqueued
+    int waiters = 0;              // followers that still have to take `done` (guarded by Combiner::m)
+    bool open = false;
+    uint32_t options = 0;
+    hipEvent_t done = nullptr;
     int status = MVFX_OK;
     char error[256] = "";
-    DoneSlot *done = nullptr;
 };
+
+inline void cpu_relax()
+{
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
 
 class Combiner {
 public:
-    explicit Combiner(int device) : device_(device)
+    explicit Combiner(int device) : device_(device), ring_(64)
     {
         if (const char *e = getenv("MVFX_COMBINE_WINDOW_US")) window_us_ = std::max(atoi(e), 0);
-        worker_ = std::thread([this] { run(); });
-    }
-    ~Combiner()
-    {
-        {
-            std::lock_guard<std::mutex> g(m_);
-            stop_ = true;
-        }
-        cv_work_.notify_all();
-        if (worker_.joinable()) worker_.join();
     }
 
-    int submit(const mvfx_frame *frame, const mvfx_hsvfilter_settings *settings, hipStream_t caller_stream)
+    int submit(const mvfx_frame *frame, const mvfx_hsvfilter_settings *settings, hipStream_t stream)
     {
-        // the caller's ordering point: one event per calling thread and device, re-recorded per call (a record replaces the
-        // previous one only after its batch has been launched, i.e. after the submitter's stream took its wait)
-        struct ReadyEvents { // destroyed with the calling thread (GStreamer streaming threads come and go)
-            std::map<int, hipEvent_t> by_device;
-            ~ReadyEvents() { for (auto &kv : by_device) if (kv.second) (void)hipEventDestroy(kv.second); }
-        };
-        thread_local ReadyEvents t_ready;
-        hipEvent_t &ready = t_ready.by_device[device_];
-        if (!ready)
-            MVFX_HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-        MVFX_HIP_TRY(hipEventRecord(ready, caller_stream));
-        Request req;
-        req.frame = *frame;
-        req.settings = *settings;
-        req.ready = ready;
-        req.options = thread_options();
-        DoneSlot *done = nullptr;
-        const auto t_in = std::chrono::steady_clock::now();
+        const auto t_in = Clock::now();
+        Request req{*frame, *settings, nullptr};
+        const uint32_t options = thread_options();
+        Batch *b = nullptr;
+        bool leader = false;
+        size_t expected = 1;
         {
             std::unique_lock<std::mutex> lk(m_);
-            queue_.push_back(&req);
-            seen_[std::this_thread::get_id()] = std::chrono::steady_clock::now();
-            cv_work_.notify_one();
-            cv_done_.wait(lk, [&] { return req.launched; });
-            done = req.done;
+            seen_[std::this_thread::get_id()] = t_in;
+            Batch *o = open_;
+            if (o && o->open && o->n.load(std::memory_order_relaxed) < kMaxCombine && o->options == options &&
+                same_geometry(o->req[0]->frame, *frame)) {
+                // follower: the ordering point of this stream, unless nothing is pending on it
+                lk.unlock();
+                if (hipStreamQuery(stream) != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (int rc = ready_event(&req.ready); rc != MVFX_OK) return rc;
+                    MVFX_HIP_TRY(hipEventRecord(req.ready, stream));
+                }
+                lk.lock();
+                o = open_; // the batch may have closed while the event was recorded
+                if (o && o->open && o->n.load(std::memory_order_relaxed) < kMaxCombine && o->options == options &&
+                    same_geometry(o->req[0]->frame, *frame)) {
+                    b = o;
+                    b->req[b->n.load(std::memory_order_relaxed)] = &req;
+                    b->waiters++;
+                    b->n.fetch_add(1, std::memory_order_release);
+                }
+            }
+            if (!b) { // leader of a new batch (an open batch this frame cannot join stays open for its own leader)
+                leader = true;
+                for (Batch &s : ring_)
+                    if (!s.open && s.waiters == 0 && (s.n.load(std::memory_order_relaxed) == 0 || s.launched.load(std::memory_order_relaxed))) { b = &s; break; }
+                // (64 slots; a slot is busy only while one of at most 16 followers still has to take its event)
+                if (!b) return fail(MVFX_ERR_DEVICE, "launch combiner: no free batch slot");
+                b->n.store(0, std::memory_order_relaxed);
+                b->launched.store(0, std::memory_order_relaxed);
+                b->options = options;
+                b->status = MVFX_OK;
+                b->req[0] = &req;
+                b->n.store(1, std::memory_order_release);
+                b->open = true;
+                if (!open_ || !open_->open) open_ = b; // else: another geometry is collecting, this one goes alone
+                const bool alone = open_ != b;
+                for (auto it = seen_.begin(); it != seen_.end();) { // streams that handed in a frame in the last 2 ms
+                    if (t_in - it->second > std::chrono::milliseconds(2)) it = seen_.erase(it);
+                    else { ++expected; ++it; }
+                }
+                expected = alone ? 1 : std::min<size_t>(std::max<size_t>(expected - 1, 1), kMaxCombine);
+            }
         }
-        wait_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_in).count();
-        int rc = req.status;
-        if (rc != MVFX_OK) fail(rc, "%s", req.error);
-        if (done) {
-            const hipError_t e = hipStreamWaitEvent(caller_stream, done->event, 0);
+        int rc = MVFX_OK;
+        if (leader) {
+            // collect: spin (the other streams are microseconds away), yield when the window is long
+            const auto deadline = t_in + std::chrono::microseconds(window_us_);
+            while ((size_t)b->n.load(std::memory_order_acquire) < expected && Clock::now() < deadline) cpu_relax();
+            int n;
             {
                 std::lock_guard<std::mutex> g(m_);
-                done->waiters--;
+                b->open = false;
+                if (open_ == b) open_ = nullptr;
+                n = b->n.load(std::memory_order_acquire);
+            }
+            if (!b->done && hipEventCreateWithFlags(&b->done, hipEventDisableTiming) != hipSuccess) rc = MVFX_ERR_DEVICE;
+            mvfx_frame frames[kMaxCombine];
+            mvfx_hsvfilter_settings settings_all[kMaxCombine];
+            for (int i = 0; i < n; i++) {
+                frames[i] = b->req[i]->frame;
+                settings_all[i] = b->req[i]->settings;
+                if (i > 0 && b->req[i]->ready && rc == MVFX_OK && hipStreamWaitEvent(stream, b->req[i]->ready, 0) != hipSuccess) rc = MVFX_ERR_DEVICE;
+            }
+            if (rc == MVFX_OK)
+                rc = mvfx_hsvfilter_transform_frames_ip_settings(frames, (uint32_t)n, settings_all, stream);
+            else
+                fail(rc, "launch combiner: a HIP event call failed: %s", hipGetErrorString(hipGetLastError()));
+            if (rc != MVFX_OK) snprintf(b->error, sizeof(b->error), "%s", mvfx_last_error());
+            if (n > 1 && b->done && hipEventRecord(b->done, stream) != hipSuccess && rc == MVFX_OK) rc = MVFX_ERR_DEVICE;
+            b->status = rc;
+            batches_++;
+            frames_ += (uint64_t)n;
+            b->launched.store(1, std::memory_order_release);
+        } else {
+            // follower: the leader is busy launching; spin, then yield
+            int spins = 0;
+            while (!b->launched.load(std::memory_order_acquire)) {
+                if (++spins < 4000) cpu_relax();
+                else std::this_thread::yield();
+            }
+            rc = b->status;
+            if (rc != MVFX_OK) fail(rc, "%s", b->error);
+            const hipError_t e = b->done ? hipStreamWaitEvent(stream, b->done, 0) : hipErrorInvalidValue;
+            {
+                std::lock_guard<std::mutex> g(m_);
+                b->waiters--;
             }
             if (e != hipSuccess && rc == MVFX_OK) rc = fail(MVFX_ERR_DEVICE, "hipStreamWaitEvent failed: %s", hipGetErrorString(e));
         }
+        wait_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - t_in).count();
         return rc;
     }
 
@@ -114,100 +176,38 @@ public:
     }
 
 private:
-    void run()
+    static bool same_geometry(const mvfx_frame &a, const mvfx_frame &b)
     {
-        (void)hipSetDevice(device_);
-        hipStream_t stream = nullptr;
-        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) stream = nullptr;
-        std::vector<DoneSlot> ring(64);
-        std::unique_lock<std::mutex> lk(m_);
-        for (;;) {
-            cv_work_.wait(lk, [&] { return stop_ || !queue_.empty(); });
-            if (stop_ && queue_.empty()) break;
-            // collect: until the batch is full, every stream that has been handing in frames lately (the last 2 ms) has one in the
-            // queue, or the window is over.  A lone stream -- or a 30 fps live one -- never waits: it is the only recent caller.
-            const auto now = std::chrono::steady_clock::now();
-            size_t expected = 0;
-            for (auto it = seen_.begin(); it != seen_.end();) {
-                if (now - it->second > std::chrono::milliseconds(2)) it = seen_.erase(it);
-                else { ++expected; ++it; }
-            }
-            expected = std::min<size_t>(std::max<size_t>(expected, 1), kMaxCombine);
-            const auto deadline = now + std::chrono::microseconds(window_us_);
-            cv_work_.wait_until(lk, deadline, [&] { return stop_ || queue_.size() >= expected; });
-            // frames that can share the first one's launch
-            std::vector<Request *> batch;
-            const Request *first = queue_.front();
-            for (auto it = queue_.begin(); it != queue_.end() && batch.size() < (size_t)kMaxCombine;) {
-                Request *r = *it;
-                if (r->frame.width == first->frame.width && r->frame.height == first->frame.height && r->frame.stride == first->frame.stride &&
-                    r->frame.format == first->frame.format && r->options == first->options) {
-                    batch.push_back(r);
-                    it = queue_.erase(it);
-                } else {
-                    ++it;
-                }
-            }
-            DoneSlot *slot = nullptr;
-            for (DoneSlot &s : ring)
-                if (s.waiters == 0) { slot = &s; break; }
-            // (64 slots, at most kMaxCombine callers hold one each: a free one always exists)
-            slot->waiters = (int)batch.size();
-            lk.unlock();
-
-            int rc = MVFX_OK;
-            char error[256] = "";
-            if (!slot->event && hipEventCreateWithFlags(&slot->event, hipEventDisableTiming) != hipSuccess) rc = MVFX_ERR_DEVICE;
-            std::vector<mvfx_frame> frames(batch.size());
-            std::vector<mvfx_hsvfilter_settings> settings(batch.size());
-            for (size_t i = 0; i < batch.size() && rc == MVFX_OK; i++) {
-                frames[i] = batch[i]->frame;
-                settings[i] = batch[i]->settings;
-                if (hipStreamWaitEvent(stream, batch[i]->ready, 0) != hipSuccess) rc = MVFX_ERR_DEVICE;
-            }
-            if (rc == MVFX_OK) {
-                (void)mvfx_thread_set_options(batch[0]->options);
-                rc = mvfx_hsvfilter_transform_frames_ip_settings(frames.data(), (uint32_t)frames.size(), settings.data(), stream);
-                if (rc != MVFX_OK) snprintf(error, sizeof(error), "%s", mvfx_last_error());
-            } else {
-                snprintf(error, sizeof(error), "launch combiner: a HIP event call failed: %s", hipGetErrorString(hipGetLastError()));
-            }
-            if (slot->event && hipEventRecord(slot->event, stream) != hipSuccess && rc == MVFX_OK) rc = MVFX_ERR_DEVICE;
-            batches_++;
-            frames_ += batch.size();
-
-            lk.lock();
-            for (Request *r : batch) {
-                r->status = rc;
-                if (rc != MVFX_OK) snprintf(r->error, sizeof(r->error), "%s", error);
-                r->done = slot;
-                r->launched = true;
-            }
-            cv_done_.notify_all();
-        }
-        lk.unlock();
-        if (stream) {
-            (void)hipStreamSynchronize(stream);
-            (void)hipStreamDestroy(stream);
-        }
-        for (DoneSlot &s : ring)
-            if (s.event) (void)hipEventDestroy(s.event);
+        return a.width == b.width && a.height == b.height && a.stride == b.stride && a.format == b.format;
     }
 
-    static constexpr int kMaxCombine = 16;
+    // one event per calling thread and device, re-recorded per call (the previous record has been waited for by then: the caller
+    // returned from that submit only after its batch was launched)
+    int ready_event(hipEvent_t *out)
+    {
+        struct ReadyEvents { // destroyed with the calling thread (GStreamer streaming threads come and go)
+            std::map<int, hipEvent_t> by_device;
+            ~ReadyEvents() { for (auto &kv : by_device) if (kv.second) (void)hipEventDestroy(kv.second); }
+        };
+        thread_local ReadyEvents t_ready;
+        hipEvent_t &ready = t_ready.by_device[device_];
+        if (!ready)
+            MVFX_HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+        *out = ready;
+        return MVFX_OK;
+    }
+
     const int device_;
-    int window_us_ = 40;
+    int window_us_ = 30;
     std::mutex m_;
-    std::condition_variable cv_work_, cv_done_;
-    std::deque<Request *> queue_;
-    std::map<std::thread::id, std::chrono::steady_clock::time_point> seen_; // callers and when they last submitted
-    bool stop_ = false;
-    std::thread worker_;
-    std::atomic<uint64_t> batches_{0}, frames_{0}, wait_ns_{0}; // wait: submit -> launch enqueued, summed over the frames
+    std::vector<Batch> ring_;
+    Batch *open_ = nullptr;
+    std::map<std::thread::id, Clock::time_point> seen_; // callers and when they last submitted
+    std::atomic<uint64_t> batches_{0}, frames_{0}, wait_ns_{0}; // wait: time inside submit, summed over the frames
 };
 
 std::mutex g_combiners_lock;
-std::map<int, Combiner *> g_combiners; // one per device, for the life of the process (the worker thread parks on its condition variable)
+std::map<int, Combiner *> g_combiners; // one per device, for the life of the process
 
 Combiner *combiner_for(int device)
 {
@@ -223,7 +223,7 @@ Combiner *combiner_for(int device)
                     uint64_t b = 0, f = 0;
                     double wait = 0.0;
                     kv.second->stats(&b, &f, &wait);
-                    fprintf(stderr, "mvfx combiner device %d: %llu launches for %llu frames (%.2f frames per launch), %.1f us from submit to launch per frame\n",
+                    fprintf(stderr, "mvfx combiner device %d: %llu launches for %llu frames (%.2f frames per launch), %.1f us per call\n",
                             kv.first, (unsigned long long)b, (unsigned long long)f, b ? (double)f / (double)b : 0.0, wait);
                 }
             });

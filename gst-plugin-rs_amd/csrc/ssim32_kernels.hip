@@ -10,8 +10,8 @@
 //   to the Lab-like planes the metric runs on -- as (image A, image B) pairs, so the arithmetic is packed f32 on aligned
 //   VGPR pairs and the pairs go to LDS with one 8-byte store -- writes the 2x2 box average of the linear values as the
 //   next level's planes (the pyramid comes out of the same pass), then runs the separable 5x5 binomial window as a sliding
-//   window down each column: per row five 8-byte LDS reads and the horizontal sums of v1, v2 (packed), v1^2, v2^2 (packed)
-//   and (v1 - v2)^2 in registers, a ring of five rows for the vertical sums; the SSIM terms of the three channels are summed in
+//   window down each column: per row five 8-byte LDS reads and the horizontal sums of (s, d) and (s^2, d^2) -- s, d the sum and
+//   difference of the two images' values -- in registers, two packed operations each, a ring of five rows for the vertical sums; the SSIM terms of the three channels are summed in
 //   registers and the map value written once (f32).  No Lab plane, no window sum ever goes to memory.
 //   HBM traffic per 8K pair: 2 x 133 MB of bytes (x1.2 halo re-reads, mostly L2 hits) + 2 x 100 MB of level-1 planes written
 //   and read + the f32 maps (133 + 33 + ... MB written, read once by the deviation pass).
@@ -21,8 +21,8 @@
 //   covariance are invariant, the means get it added back.
 //
 //   Near-identical frames: 1 - ssim is tiny, and an f32 quotient next to 1.0 cannot hold it (6e-8 absolute).  The kernel therefore
-//   computes the DEFICIT of every term directly.  With a = (m1 - m2)^2 and b = Var(x1 - x2) over the window (the fifth window sum
-//   is that of (x1 - x2)^2 instead of x1 x2):  2 m1 m2 + C1 = (m1^2 + m2^2 + C1) - a  and  2 s12 + C2 = (s11 + s22 + C2) - b, so
+//   computes the DEFICIT of every term directly.  With a = (m1 - m2)^2 and b = Var(x1 - x2) over the window (LDS holds the sum
+//   and the difference of the two images' values, the window sums are those of s, d, s^2, d^2 -- all packed):  2 m1 m2 + C1 = (m1^2 + m2^2 + C1) - a  and  2 s12 + C2 = (s11 + s22 + C2) - b, so
 //   1 - term = (a sd + b (ld - a)) / (ld sd)  with ld, sd the two denominators -- every factor is formed from small quantities
 //   without cancellation, the deficit has f32 RELATIVE accuracy, and the map in memory is the deficit map (mean and mean absolute
 //   deviation are the same numbers either way).  Identical frames: x1 - x2 = 0 everywhere, a = b = 0, deficit exactly 0,
@@ -69,7 +69,12 @@ __device__ __forceinline__ float lab_f(float t)
 {
     const float eps = 216.0f / 24389.0f, kappa = 24389.0f / 27.0f;
     const float lin = __builtin_fmaf(kappa, t, 16.0f) * (1.0f / 116.0f);
-    return t > eps ? cbrt_unit(t) : lin;
+    // both sides are always computed and the result is a select: as a branch (what the compiler makes of `t > eps ? cbrt : lin`
+    // when it may sink the transcendentals) every one of the 48 cube roots of a lane became its own basic block with a serial
+    // log -> exp -> Newton chain and nothing to overlap it with (round 3: 470 -> ... us for the 8K level-0 launch)
+    float cb = cbrt_unit(fmaxf(t, eps));
+    asm volatile("" : "+v"(cb));
+    return t > eps ? cb : lin;
 }
 
 // linear RGB (premultiplied) of the same pixel of both images -> the three planes of both, as pairs (oracle: to_lab)
@@ -174,11 +179,6 @@ __device__ __forceinline__ f2 binom5(f2 a, f2 b, f2 c, f2 d, f2 e)
 {
     return fma2(splat(6.0f), c, fma2(splat(4.0f), b + d, a + e));
 }
-__device__ __forceinline__ float binom5(float a, float b, float c, float d, float e)
-{
-    return __builtin_fmaf(6.0f, c, __builtin_fmaf(4.0f, b + d, a + e));
-}
-
 // n / d to ~1 ulp for the operands that occur here (finite, d > 0): reciprocal, one residual correction
 __device__ __forceinline__ float quotient(float n, float d)
 {
@@ -191,7 +191,7 @@ __device__ __forceinline__ float quotient(float n, float d)
 template <int MODE, int BPP>
 __global__ __launch_bounds__(kThreads) void ssim32_level_kernel(LevelArgs A)
 {
-    __shared__ __attribute__((aligned(16))) f2 raw[3][kRH][kRW]; // 48 KiB: (A, B) pairs of the centred planes
+    __shared__ __attribute__((aligned(16))) f2 raw[3][kRH][kRW]; // 48 KiB: per pixel and plane (x1' + x2', x1 - x2), x' = x - centre
     __shared__ float s_lut[256];
     __shared__ f2 s_centre[3];
     __shared__ double s_part[kThreads / 64];
@@ -248,11 +248,18 @@ __global__ __launch_bounds__(kThreads) void ssim32_level_kernel(LevelArgs A)
         const int blk = threadIdx.x + k * kThreads, bx = blk % kBlocksX, by = blk / kBlocksX;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
+            // LDS holds, per pixel, the pair (s, d) = (x1' + x2', x1 - x2) of the centred values: everything the SSIM term needs is a
+            // window sum of s, d, s^2 or d^2 (see below), so the whole window arithmetic is packed f32 on these pairs.
             // two pixels of a row = 16 contiguous bytes of LDS
             typedef float f4 __attribute__((ext_vector_type(4)));
-            const f2 p0 = lab[k][0][c] - centre[c], p1 = lab[k][1][c] - centre[c], p2 = lab[k][2][c] - centre[c], p3 = lab[k][3][c] - centre[c];
-            *reinterpret_cast<f4 *>(&raw[c][2 * by][2 * bx]) = (f4){p0.x, p0.y, p1.x, p1.y};
-            *reinterpret_cast<f4 *>(&raw[c][2 * by + 1][2 * bx]) = (f4){p2.x, p2.y, p3.x, p3.y};
+            f2 q[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f2 v = lab[k][j][c], vc = v - centre[c];
+                q[j] = (f2){vc.x + vc.y, v.x - v.y};
+            }
+            *reinterpret_cast<f4 *>(&raw[c][2 * by][2 * bx]) = (f4){q[0].x, q[0].y, q[1].x, q[1].y};
+            *reinterpret_cast<f4 *>(&raw[c][2 * by + 1][2 * bx]) = (f4){q[2].x, q[2].y, q[3].x, q[3].y};
         }
     }
     __syncthreads();
@@ -265,31 +272,30 @@ __global__ __launch_bounds__(kThreads) void ssim32_level_kernel(LevelArgs A)
     if (seg < kSegs) {
 #pragma unroll 1
         for (int c = 0; c < 3; c++) {
-            f2 hs[5], hq[5]; // ring of the horizontal sums of (v1, v2) and (v1^2, v2^2)
-            float hd[5];     // ... and of (v1 - v2)^2
+            // With s = x1' + x2' and d = x1 - x2 (x' = x - centre):   m1 - m2 = E[d],   m1' + m2' = E[s],
+            //   m1^2 + m2^2 = ((m1 + m2)^2 + (m1 - m2)^2) / 2,   E[x1'^2] + E[x2'^2] = (E[s^2] + E[d^2]) / 2,
+            //   s11 + s22 = E[x1'^2] + E[x2'^2] - (m1'^2 + m2'^2),   Var(x1 - x2) = E[d^2] - E[d]^2
+            // -- the term never needs s11, s22 or the means separately.  Window sums carry the weight 256 un-normalised.
+            f2 hp[5], hq[5]; // ring of the horizontal sums of (s, d) and (s^2, d^2)
+            const float c512 = 512.0f * centre[c].x; // 256 (m1 + m2) = MS + 512 centre
 #pragma unroll
             for (int j = 0; j < kSegRows + 4; j++) {
                 const f2 *row = &raw[c][seg * kSegRows + j][col];
                 const f2 p0 = row[0], p1 = row[1], p2 = row[2], p3 = row[3], p4 = row[4];
-                const float d0 = p0.x - p0.y, d1 = p1.x - p1.y, d2 = p2.x - p2.y, d3 = p3.x - p3.y, d4 = p4.x - p4.y;
-                hs[j % 5] = binom5(p0, p1, p2, p3, p4);
+                hp[j % 5] = binom5(p0, p1, p2, p3, p4);
                 hq[j % 5] = binom5(p0 * p0, p1 * p1, p2 * p2, p3 * p3, p4 * p4);
-                hd[j % 5] = binom5(d0 * d0, d1 * d1, d2 * d2, d3 * d3, d4 * d4);
                 if (j >= 4) {
                     // window rows j-4 .. j (ring order is irrelevant to the symmetric weights except for the centre: row j-2)
                     const int ra = (j - 4) % 5, rb = (j - 3) % 5, rm = (j - 2) % 5, rd = (j - 1) % 5, re = j % 5;
-                    // the window sums carry the weight 256 = 16 x 16 un-normalised (every factor below scales with it alike, the
-                    // quotient is homogeneous): M = 256 m', Q = 256 E[x'^2], QD = 256 E[(x1 - x2)^2]
-                    const f2 M = binom5(hs[ra], hs[rb], hs[rm], hs[rd], hs[re]);
-                    const f2 Q = binom5(hq[ra], hq[rb], hq[rm], hq[rd], hq[re]);
-                    const float QD = binom5(hd[ra], hd[rb], hd[rm], hd[rd], hd[re]);
-                    const f2 var = fma2(splat(256.0f), Q, -(M * M));             // 65536 (s11, s22)
-                    const float dm = M.x - M.y;
-                    const float a = dm * dm;                                      // 65536 (m1 - m2)^2
-                    const float b = __builtin_fmaf(256.0f, QD, -a);               // 65536 Var(x1 - x2) = 65536 (s11 + s22 - 2 s12)
-                    const f2 mean = fma2(splat(256.0f), centre[c], M);            // 256 (m1, m2)
-                    const f2 mm = mean * mean;
-                    const float ld = (mm.x + mm.y) + 65536.0f * kC1, sd = (var.x + var.y) + 65536.0f * kC2;
+                    const f2 M = binom5(hp[ra], hp[rb], hp[rm], hp[rd], hp[re]);   // 256 (m1' + m2', m1 - m2)
+                    const f2 Q = binom5(hq[ra], hq[rb], hq[rm], hq[rd], hq[re]);   // 256 (E[s^2], E[d^2])
+                    const f2 M2 = M * M;
+                    const float a = M2.y;                                          // 65536 (m1 - m2)^2
+                    const float b = __builtin_fmaf(256.0f, Q.y, -a);               // 65536 Var(x1 - x2)
+                    const float var = __builtin_fmaf(128.0f, Q.x + Q.y, -0.5f * (M2.x + M2.y)); // 65536 (s11 + s22)
+                    const float ms = M.x + c512;                                   // 256 (m1 + m2)
+                    const float ld = __builtin_fmaf(0.5f, __builtin_fmaf(ms, ms, a), 65536.0f * kC1); // 65536 (m1^2 + m2^2 + C1)
+                    const float sd = var + 65536.0f * kC2;
                     // 1 - (ld - a)(sd - b) / (ld sd) = (a sd + b (ld - a)) / (ld sd)
                     acc[j - 4] += quotient(__builtin_fmaf(a, sd, b * (ld - a)), ld * sd);
                 }

@@ -53,7 +53,8 @@ typedef enum mvfx_format {
     MVFX_FORMAT_RGBA64_BE = 11,
     MVFX_FORMAT_I420 = 12,
     MVFX_FORMAT_A420 = 13,
-    MVFX_FORMAT_RGB10A2_LE = 14 /* colorlut only: third format of d3d12colorlut's caps (d3d12colorlut/imp.rs:236-244) */
+    MVFX_FORMAT_RGB10A2_LE = 14, /* colorlut only: third format of d3d12colorlut's caps (d3d12colorlut/imp.rs:236-244) */
+    MVFX_FORMAT_NV12 = 15        /* converters only: Y plane + one plane of interleaved (U, V) pairs */
 } mvfx_format;
 
 typedef enum mvfx_status {
@@ -179,14 +180,15 @@ int mvfx_hsvfilter_transform_frames_ip_settings(const mvfx_frame *frames, uint32
 /* Launch combiner: same contract as mvfx_hsvfilter_transform_frame_ip -- one call per buffer (hsvfilter/imp.rs:322-326),
  * asynchronous, ordered behind what the caller enqueued on `stream` before and ahead of what it enqueues afterwards -- but
  * the frames that the threads of one process submit at about the same time leave as ONE batched launch (per device; up to 16
- * frames, each with its own settings).  A call returns as soon as its frame's launch has been enqueued, after at most
- * MVFX_COMBINE_WINDOW_US (environment, default 40) microseconds of waiting for other streams' frames; the host never waits for
- * the GPU.  What it buys: 16 streams reach the batched kernel's rate (0.72 of the HBM peak) instead of 0.66 with a launch per frame. */
+ * frames, each with its own settings).  No extra thread: the first caller of a batch leads it -- it waits at most
+ * MVFX_COMBINE_WINDOW_US (environment, default 30) microseconds for the other recently active streams' frames and launches all of
+ * them on its own stream -- the others follow (their streams wait for the batch's event).  A call returns as soon as its frame's
+ * launch has been enqueued; the host never waits for the GPU; a lone stream is never held back.  Measured numbers: DESIGN.md. */
 int mvfx_hsvfilter_transform_frame_ip_combined(const mvfx_frame *frame, const mvfx_hsvfilter_settings *settings,
                                                mvfx_stream stream);
 /* batches launched and frames carried by the combiner of `device` so far (frames / batches = the average batch) */
 int mvfx_combiner_stats(int device, uint64_t *batches_out, uint64_t *frames_out);
-/* average time a call spent between handing its frame in and its launch being enqueued (the latency the combiner adds), in us;
+/* average time a combined call took on the host (collection wait + launch or event hand-over), in us;
  * MVFX_COMBINE_STATS=1 in the environment prints all three numbers to stderr at process exit (gst-launch runs) */
 double mvfx_combiner_average_wait_us(int device);
 
@@ -451,7 +453,7 @@ typedef struct mvfx_planar_frame {
     void *data[4];
     uint32_t stride[4];
     uint32_t width, height;
-    int32_t format; /* MVFX_FORMAT_I420 or MVFX_FORMAT_A420 */
+    int32_t format; /* MVFX_FORMAT_I420, MVFX_FORMAT_A420 or MVFX_FORMAT_NV12 */
 } mvfx_planar_frame;
 
 /* Replaces generate_alpha_mask + draw_rounded_corners (border/imp.rs:57-180): writes the A8
@@ -485,11 +487,21 @@ int mvfx_roundedcorners_compose_a420(const mvfx_planar_frame *i420_in, const uin
  * (tests/golden/make_videoconvert_golden.py).
  * yuv_standard: 0 = GStreamer 1.14's default for the frame height (<= 576 lines BT.601 + chroma-site none, < 2160
  * BT.709 + h-cosited, else BT.2020 + h-cosited), 1 / 2 / 3 force BT.601 / BT.709 / BT.2020.
- * RGBA -> I420 needs even width and height.  Device pointers; asynchronous on `stream`. */
+ * RGBA -> I420 takes any size: an odd-sized frame is converted as the next even size with its last column / row replicated,
+ * which is what the element does (chroma planes of RU2(w)/2 x RU2(h)/2 samples).  Device pointers; asynchronous on `stream`. */
 int mvfx_convert_i420_to_rgba(const mvfx_planar_frame *i420_in, const mvfx_frame *rgba_out,
                               int32_t yuv_standard, mvfx_stream stream);
 int mvfx_convert_rgba_to_i420(const mvfx_frame *rgba_in, const mvfx_planar_frame *i420_out,
                               int32_t yuv_standard, mvfx_stream stream);
+/* RGBA -> NV12 (what encoders and display engines take): the same Y, U and V as RGBA -> I420, data[0] = Y plane, data[1] = plane
+ * of interleaved (U, V) pairs, stride[1] >= 2 * RU2(w)/2; any size. */
+int mvfx_convert_rgba_to_nv12(const mvfx_frame *rgba_in, const mvfx_planar_frame *nv12_out, int32_t yuv_standard,
+                              mvfx_stream stream);
+/* NV12 -> RGBA (what hardware decoders emit): GStreamer 1.14.0 has no fast path for it -- unlike I420 -> RGBA, which duplicates the
+ * chroma -- and interpolates the chroma, horizontally then vertically (video-chroma.c; chroma-site none <= 576 lines, h-cosited
+ * above), before the same matrix; reproduced bit for bit (goldens from the element, incl. odd sizes and 3840x2160).  Any size. */
+int mvfx_convert_nv12_to_rgba(const mvfx_planar_frame *nv12_in, const mvfx_frame *rgba_out, int32_t yuv_standard,
+                              mvfx_stream stream);
 /* n frame pairs sharing geometry and strides (one frame from each of n streams) in ONE launch */
 int mvfx_convert_i420_to_rgba_frames(const mvfx_planar_frame *i420_in, const mvfx_frame *rgba_out,
                                      uint32_t n_frames, int32_t yuv_standard, mvfx_stream stream);

@@ -48,7 +48,8 @@ enum {
     ORC_FORMAT_RGBA64_BE = 11,
     ORC_FORMAT_I420 = 12,
     ORC_FORMAT_A420 = 13,
-    ORC_FORMAT_RGB10A2_LE = 14 /* colorlut only: the third format of d3d12colorlut's caps (d3d12colorlut/imp.rs:236-244) */
+    ORC_FORMAT_RGB10A2_LE = 14, /* colorlut only: the third format of d3d12colorlut's caps (d3d12colorlut/imp.rs:236-244) */
+    ORC_FORMAT_NV12 = 15        /* converter output only */
 };
 
 /* Error codes of the oracle (negative).  ORC_ERR_PANIC marks inputs on which the
@@ -149,6 +150,10 @@ int orc_convert_i420_to_rgba(const uint8_t *y_plane, const uint8_t *u_plane, con
 int orc_convert_rgba_to_i420(const uint8_t *rgba, uint32_t rgba_stride, uint32_t width, uint32_t height, int standard,
                              uint8_t *y_plane, uint8_t *u_plane, uint8_t *v_plane, uint32_t y_stride, uint32_t u_stride,
                              uint32_t v_stride);
+int orc_convert_rgba_to_nv12(const uint8_t *rgba, uint32_t rgba_stride, uint32_t width, uint32_t height, int standard,
+                             uint8_t *y_plane, uint8_t *uv_plane, uint32_t y_stride, uint32_t uv_stride);
+int orc_convert_nv12_to_rgba(const uint8_t *y_plane, const uint8_t *uv_plane, uint32_t y_stride, uint32_t uv_stride, uint32_t width,
+                             uint32_t height, int standard, uint8_t *rgba, uint32_t rgba_stride);
 
 /* SSIM-family distance behind hash-algo=dssim (dssim-core 3.4.0, non-default feature; PARITY
  * UNPINNED, see ssim_oracle.c): f64, formats RGB / RGBA. */

@@ -12,7 +12,7 @@ SO = os.path.join(ROOT, "oracle", "liboracle.so")
 
 FORMATS = {
     "RGBx": 0, "xRGB": 1, "BGRx": 2, "xBGR": 3, "RGBA": 4, "ARGB": 5, "BGRA": 6, "ABGR": 7,
-    "RGB": 8, "BGR": 9, "RGBA64_LE": 10, "RGBA64_BE": 11, "I420": 12, "A420": 13, "RGB10A2_LE": 14,
+    "RGB": 8, "BGR": 9, "RGBA64_LE": 10, "RGBA64_BE": 11, "I420": 12, "A420": 13, "RGB10A2_LE": 14, "NV12": 15,
 }
 
 _lib = None
@@ -72,6 +72,10 @@ def lib():
         L.orc_convert_i420_to_rgba.restype = c_int
         L.orc_convert_rgba_to_i420.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_int, c_void_p, c_void_p, c_void_p, c_uint32, c_uint32, c_uint32]
         L.orc_convert_rgba_to_i420.restype = c_int
+        L.orc_convert_rgba_to_nv12.argtypes = [c_void_p, c_uint32, c_uint32, c_uint32, c_int, c_void_p, c_void_p, c_uint32, c_uint32]
+        L.orc_convert_rgba_to_nv12.restype = c_int
+        L.orc_convert_nv12_to_rgba.argtypes = [c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_int, c_void_p, c_uint32]
+        L.orc_convert_nv12_to_rgba.restype = c_int
         L.orc_hamming64.argtypes = [c_uint64, c_uint64]
         L.orc_hamming64.restype = c_uint32
         L.orc_ssim_distance.argtypes = [c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_int,
@@ -255,13 +259,39 @@ def convert_i420_to_rgba(raw: np.ndarray, w, h, standard=0):
 
 
 def convert_rgba_to_i420(px: np.ndarray, w, h, stride, standard=0):
-    """-> (rc, Y[h,w], U[h/2,w/2], V[h/2,w/2]) tightly packed"""
+    """-> (rc, Y[h,w], U[RU2(h)/2, RU2(w)/2], V[...]) tightly packed"""
+    cw, ch = (w + 1) // 2, (h + 1) // 2
     Y = np.zeros((h, w), np.uint8)
-    U = np.zeros((h // 2, max(w // 2, 1)), np.uint8)
-    V = np.zeros((h // 2, max(w // 2, 1)), np.uint8)
-    rc = lib().orc_convert_rgba_to_i420(px.ctypes.data, stride, w, h, standard, Y.ctypes.data, U.ctypes.data, V.ctypes.data,
-                                        w, max(w // 2, 1), max(w // 2, 1))
+    U = np.zeros((ch, cw), np.uint8)
+    V = np.zeros((ch, cw), np.uint8)
+    rc = lib().orc_convert_rgba_to_i420(px.ctypes.data, stride, w, h, standard, Y.ctypes.data, U.ctypes.data, V.ctypes.data, w, cw, cw)
     return rc, Y, U, V
+
+
+def convert_rgba_to_nv12(px: np.ndarray, w, h, stride, standard=0):
+    """-> (rc, Y[h,w], UV[RU2(h)/2, 2 * RU2(w)/2]) tightly packed"""
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    Y = np.zeros((h, w), np.uint8)
+    UV = np.zeros((ch, 2 * cw), np.uint8)
+    rc = lib().orc_convert_rgba_to_nv12(px.ctypes.data, stride, w, h, standard, Y.ctypes.data, UV.ctypes.data, w, 2 * cw)
+    return rc, Y, UV
+
+
+def nv12_layout(w, h):
+    """GstVideoInfo layout of NV12: (y stride, uv stride, y rows, uv rows, uv offset, size)"""
+    ru = lambda v, a: (v + a - 1) // a * a
+    ys, uvs, yr = ru(w, 4), ru(ru(w, 2), 4), ru(h, 2)
+    return ys, uvs, yr, yr // 2, ys * yr, ys * yr + uvs * (yr // 2)
+
+
+def convert_nv12_to_rgba(raw: np.ndarray, w, h, standard=0):
+    """raw: one NV12 frame in the GstVideoInfo layout -> (rc, h x w*4 RGBA)"""
+    ys, uvs, yr, cr, uvo, size = nv12_layout(w, h)
+    assert raw.size >= size
+    out = np.zeros((h, w * 4), np.uint8)
+    base = raw.ctypes.data
+    rc = lib().orc_convert_nv12_to_rgba(base, base + uvo, ys, uvs, w, h, standard, out.ctypes.data, w * 4)
+    return rc, out
 
 
 def hamming(a, b):

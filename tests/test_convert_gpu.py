@@ -41,9 +41,91 @@ def _to_i420(gpu, px, w, h, stride, standard=0, shift=0):
     gpu.check(gpu.lib().mvfx_stream_synchronize(None))
     d = dout.download(size)
     Y = d[: ys * yr].reshape(yr, ys)[:h, :w]
-    U = d[uo: uo + cs * cr].reshape(cr, cs)[: h // 2, : w // 2]
-    V = d[vo: vo + cs * cr].reshape(cr, cs)[: h // 2, : w // 2]
+    U = d[uo: uo + cs * cr].reshape(cr, cs)[: (h + 1) // 2, : (w + 1) // 2]
+    V = d[vo: vo + cs * cr].reshape(cr, cs)[: (h + 1) // 2, : (w + 1) // 2]
     return Y, U, V
+
+
+def _to_nv12(gpu, px, w, h, stride, standard=0, shift=0):
+    """GstVideoInfo layout of NV12: Y stride RU4(w) x RU2(h) rows, UV stride RU4(RU2(w)) x RU2(h)/2 rows"""
+    ru = lambda v, a: (v + a - 1) // a * a
+    ys, uvs, yr, cr = ru(w, 4), ru(ru(w, 2), 4), ru(h, 2), ru(h, 2) // 2
+    din = gpu.DeviceBuffer(px.nbytes + 64)
+    gpu.check(gpu.lib().mvfx_copy_to_device(ctypes.c_void_p(din.ptr + shift), px.ctypes.data_as(ctypes.c_void_p), px.nbytes, None))
+    fin = gpu.make_frame(din.ptr + shift, w, h, stride, "RGBA")
+    dout = gpu.DeviceBuffer(ys * yr + uvs * cr + 64)
+    fout = gpu.PlanarFrame()
+    fout.data[0], fout.data[1] = dout.ptr, dout.ptr + ys * yr
+    fout.stride[0], fout.stride[1] = ys, uvs
+    fout.width, fout.height, fout.format = w, h, gpu.FORMATS["NV12"]
+    gpu.check(gpu.lib().mvfx_convert_rgba_to_nv12(ctypes.byref(fin), ctypes.byref(fout), standard, None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    d = dout.download(ys * yr + uvs * cr)
+    return d[: ys * yr].reshape(yr, ys)[:h, :w], d[ys * yr:].reshape(cr, uvs)[: (h + 1) // 2, : 2 * ((w + 1) // 2)]
+
+
+def _nv12_to_rgba(gpu, raw, w, h, standard=0, shift=0, out_pad=0):
+    ys, uvs, yr, cr, uvo, size = orc.nv12_layout(w, h)
+    din = gpu.DeviceBuffer(size + 64)
+    gpu.check(gpu.lib().mvfx_copy_to_device(ctypes.c_void_p(din.ptr + shift), raw.ctypes.data_as(ctypes.c_void_p), size, None))
+    fin = gpu.PlanarFrame()
+    fin.data[0], fin.data[1] = din.ptr + shift, din.ptr + shift + uvo
+    fin.stride[0], fin.stride[1] = ys, uvs
+    fin.width, fin.height, fin.format = w, h, gpu.FORMATS["NV12"]
+    ostride = w * 4 + out_pad
+    dout = gpu.DeviceBuffer(ostride * h + 64)
+    fout = gpu.make_frame(dout.ptr + shift, w, h, ostride, "RGBA")
+    gpu.check(gpu.lib().mvfx_convert_nv12_to_rgba(ctypes.byref(fin), ctypes.byref(fout), standard, None))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    return dout.download(ostride * h + shift)[shift:].reshape(h, ostride)[:, : w * 4]
+
+
+@pytest.mark.parametrize("meta", [m for m in META if m[0].startswith("nv12_to_rgba")], ids=lambda m: m[0])
+def test_nv12_to_rgba_matches_gstreamer_goldens(gpu, meta):
+    key, seed, w, h, digest = meta[0], int(meta[1]), int(meta[2]), int(meta[3]), meta[4]
+    raw = frames.splitmix64_bytes(seed, orc.nv12_layout(w, h)[5])
+    got = _nv12_to_rgba(gpu, raw, w, h)
+    assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == digest
+
+
+@pytest.mark.parametrize("geom", [(64, 32), (65, 33), (1, 1), (2, 2), (3, 5), (9, 3), (24, 578), (8, 2160), (1920, 1080), (1919, 1079)])
+@pytest.mark.parametrize("standard", [0, 1, 2, 3])
+def test_nv12_to_rgba_matches_oracle(gpu, geom, standard):
+    """chroma interpolated horizontally, then vertically (the element's generic path), every colorimetry default, odd sizes, an
+    unaligned frame with a padded output stride"""
+    w, h = geom
+    raw = frames.splitmix64_bytes(0x5EED1000 + w * 13 + h, orc.nv12_layout(w, h)[5])
+    rc, want = orc.convert_nv12_to_rgba(raw, w, h, standard)
+    assert rc == 0
+    assert np.array_equal(_nv12_to_rgba(gpu, raw, w, h, standard), want)
+    if standard in (0, 2):
+        assert np.array_equal(_nv12_to_rgba(gpu, raw, w, h, standard, shift=1, out_pad=4), want)
+
+
+@pytest.mark.parametrize("meta", [m for m in META if m[0].startswith("rgba_to_nv12")], ids=lambda m: m[0])
+def test_rgba_to_nv12_matches_gstreamer_goldens(gpu, meta):
+    key, seed, w, h, digest = meta[0], int(meta[1]), int(meta[2]), int(meta[3]), meta[4]
+    px = frames.random_frame(seed, w, h)
+    Y, UV = _to_nv12(gpu, px, w, h, w * 4)
+    packed = np.concatenate([Y.reshape(-1), UV.reshape(-1)])
+    assert hashlib.sha256(packed.tobytes()).hexdigest() == digest
+
+
+@pytest.mark.parametrize("geom", [(65, 33), (1, 1), (3, 3), (5, 7), (7, 601), (66, 33), (65, 34), (641, 481), (1919, 1079), (9, 2161)])
+@pytest.mark.parametrize("standard", [0, 1, 2, 3])
+def test_rgba_to_i420_and_nv12_odd_sizes_match_oracle(gpu, geom, standard):
+    """odd-sized frames: the last column / row replicated to the next even size (what the element does); I420 and NV12 carry the
+    same samples; 4-byte aligned and unaligned input"""
+    w, h = geom
+    stride = w * 4 + 4
+    px = frames.random_frame(0x5EED0F00 + w * 13 + h, w, h, 4, stride)
+    rc, Yw, Uw, Vw = orc.convert_rgba_to_i420(px, w, h, stride, standard)
+    assert rc == 0
+    for shift in (0, 1):
+        Y, U, V = _to_i420(gpu, px, w, h, stride, standard, shift=shift)
+        assert np.array_equal(Y, Yw) and np.array_equal(U, Uw) and np.array_equal(V, Vw)
+        Y, UV = _to_nv12(gpu, px, w, h, stride, standard, shift=shift)
+        assert np.array_equal(Y, Yw) and np.array_equal(UV[:, 0::2], Uw) and np.array_equal(UV[:, 1::2], Vw)
 
 
 @pytest.mark.parametrize("meta", [m for m in META if m[0].startswith("i420_to_rgba")], ids=lambda m: m[0])
@@ -121,7 +203,7 @@ def test_errors(gpu):
     assert L.mvfx_convert_i420_to_rgba(ctypes.byref(i420), ctypes.byref(small), 0, None) == gpu.ERR_NOT_NEGOTIATED
     odd_i = gpu.make_i420(buf.ptr, 15, 7, 16, 8, 128, 192)
     odd = gpu.make_frame(buf.ptr + 1024, 15, 7, 64, "RGBA")
-    assert L.mvfx_convert_rgba_to_i420(ctypes.byref(odd), ctypes.byref(odd_i), 0, None) == gpu.ERR_INVALID_ARGUMENT
+    assert L.mvfx_convert_rgba_to_i420(ctypes.byref(odd), ctypes.byref(odd_i), 0, None) == gpu.OK   # odd sizes: edge replication (round 3)
 
 
 # ---------------------------------------------------------------- colorlut on I420 frames (fused videoconvert ! colorlut ! videoconvert)

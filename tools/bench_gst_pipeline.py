@@ -60,12 +60,14 @@ def branches_main(args):
                        "! fakesink sync=false" for k in range(n))
         for combine in ("0", "1"):
             env = {"MVFX_COMBINE": combine, "MVFX_COMBINE_STATS": "1"}
-            v, t1, t2 = fps(tpl, tmp, args.n1, args.n2, env)
+            # ten times the buffers of the single-chain runs: 16 branches at tens of thousands of frames per second finish 500 buffers each
+            # inside the noise of a process start
+            v, t1, t2 = fps(tpl, tmp, args.n1 * 10, args.n2 * 10, env)
             key = f"refresh_{refresh}_combine_{combine}"
             out[key + "_fps"] = round(v * n, 1)
             out[key + "_frac_of_8TBs"] = round(v * n * 2 * w * h * 4 / 8e12, 4)
             if combine == "1":
-                r = gst_env.run([LAUNCH, "-q"] + tpl.format(n=args.n2).split(), tmp, timeout=900, extra_env=env)
+                r = gst_env.run([LAUNCH, "-q"] + tpl.format(n=args.n2 * 10).split(), tmp, timeout=900, extra_env=env)
                 m = re.search(r"mvfx combiner device 0: (\d+) launches for (\d+) frames \(([0-9.]+) frames per launch\), ([0-9.]+) us", r.stdout)
                 if m:
                     out[key + "_frames_per_launch"] = float(m.group(3))
