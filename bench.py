@@ -166,7 +166,7 @@ class Worker:
         self.dist.all_gather(out, t)
         return [float(x[0]) for x in out]
 
-    def timed(self, step, steps, first_index=0, events=False):
+    def timed(self, step, steps, first_index=0, events=False, join=None):
         """barrier + synchronize on both sides; returns (wall seconds, average ms between the two HIP events)."""
         torch = self.torch
         self.sync()
@@ -181,6 +181,8 @@ class Worker:
         for i in range(steps):
             step(first_index + i)
         if events:
+            if join is not None:
+                join()  # a leg that uses a second stream: the launch stream waits for it, so the closing event covers both
             ev1.record(self.stream)
         self.sync()
         self.barrier()
@@ -188,7 +190,7 @@ class Worker:
         elapsed = time.perf_counter() - t0
         return elapsed, (ev0.elapsed_time(ev1) / max(steps, 1) if events else None)
 
-    def event_times(self, step, steps, first_index=0):
+    def event_times(self, step, steps, first_index=0, join=None):
         """`steps` steps with a HIP event on the launch stream between every two: per-step microseconds (launch + whatever
         the step leaves between two launches), for the p10 / p50 / p90 of the line."""
         torch = self.torch
@@ -197,6 +199,8 @@ class Worker:
         evs[0].record(self.stream)
         for i in range(steps):
             step(first_index + i)
+            if join is not None:
+                join()
             evs[i + 1].record(self.stream)
         self.sync()
         return [evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(steps)]
@@ -537,10 +541,11 @@ def measure_leg(w, leg, steps, warmup, settle_seconds, pct_steps, cpu_seconds):
     settle(counted, settle_seconds, w.sync, fixed_steps=leg.fixed_settle)
     for i in range(warmup):
         counted(i)
-    secs, ev_ms = w.timed(counted, steps, first_index=warmup, events=True)
+    join = getattr(leg, "join", None)
+    secs, ev_ms = w.timed(counted, steps, first_index=warmup, events=True, join=join)
     secs, ev_ms = w.max_over_ranks(secs, ev_ms)
     per_rank = w.gather(steps * leg.units_per_step / secs)
-    pct = percentiles(w.event_times(counted, pct_steps, first_index=warmup + steps)) if pct_steps > 0 else None
+    pct = percentiles(w.event_times(counted, pct_steps, first_index=warmup + steps, join=join)) if pct_steps > 0 else None
     world = w.world
     per_gpu_bytes = leg.bytes_per_step  # per rank and step
     achieved_kernel = per_gpu_bytes / (ev_ms * 1e-3) / 1e9
@@ -704,6 +709,15 @@ def make_leg_videofx(w, args):
               step, ["copy_planes_kernel", "colordetect_hist_kernel"],
               cpu=(lambda s: cpu_baseline_videofx(s, host)) if host else None)
     leg.keep = (i420, a420, rgba, mask, hist, planes, fr, second)
+    if second is not None:
+        join_ev = torch.cuda.Event()
+
+        def join():  # the launch stream waits for what the second stream has been given so far
+            join_ev.record(second)
+            w.stream.wait_event(join_ev)
+        leg.join = join
+        leg.note = ("two HIP streams: avg_step_ms spans K steps with ONE join of the two streams at the end (throughput); step_us joins them after "
+                    "every step (latency of one frame through both elements, no overlap between frames)")
     return leg
 
 
@@ -795,10 +809,13 @@ def other_config_legs(w, args):
     value, roofline fractions from HIP events and wall clock, p10/p50/p90 per step, committed PMC traffic and a CPU-port baseline."""
     torch = w.torch
     out = {}
+    import copy
+    args_vfx = copy.copy(args)
+    args_vfx.element_streams = 2  # config 4 in the driver's line: the two elements on their own streaming threads (HIP streams)
     makers = [("hsv1080p", lambda: make_leg_hsv1080p(w, args)),
               ("colorlut_natural", lambda: make_leg_colorlut(w, args, "natural")),
               ("colorlut_random", lambda: make_leg_colorlut(w, args, "random")),
-              ("videofx", lambda: make_leg_videofx(w, args)),
+              ("videofx", lambda: make_leg_videofx(w, args_vfx)),
               ("videocompare_blockhash", lambda: make_leg_videocompare(w, args, "blockhash")),
               ("videocompare_dssim", lambda: make_leg_videocompare(w, args, "dssim"))]
     steps = {"hsv1080p": 200, "colorlut_natural": 100, "colorlut_random": 40, "videofx": 400, "videocompare_blockhash": 400,
@@ -1056,6 +1073,14 @@ def hsvfilter_main(args):
         nb2, nf2 = ctypes.c_uint64(), ctypes.c_uint64()
         lib.mvfx_combiner_stats(w.local_rank, ctypes.byref(nb2), ctypes.byref(nf2))
         combined["frames_per_combined_launch"] = (nf2.value - nf.value) / max(nb2.value - nb.value, 1)
+        # ... and its fenced entry (what the element uses with MVFX_COMBINE=2): no caller streams, the frames' fences in and out, all
+        # combined launches on one library-owned stream
+        fenced = threads_leg(0xFFFFFFFF, f"{nthr} threads x 1 frame through the launch combiner's fenced entry (mvfx_hsvfilter_transform_frame_ip_fenced: one "
+                                          "call per buffer, the buffer's fence in and out, batched launches on one library-owned stream)")
+        nb3, nf3 = ctypes.c_uint64(), ctypes.c_uint64()
+        lib.mvfx_combiner_stats(w.local_rank, ctypes.byref(nb3), ctypes.byref(nf3))
+        fenced["frames_per_combined_launch"] = (nf3.value - nf2.value) / max(nb3.value - nb2.value, 1)
+        combined["fenced_entry"] = fenced
 
     # ---- the same batch leg on the other frame contents: the kernel has no data-dependent branch, but the chip is power
     # limited on this kernel and the bytes decide how much the data paths toggle (tools/exp_content_power.py) -------------
@@ -1131,12 +1156,30 @@ def hsvfilter_main(args):
         vfx.check(lib.mvfx_thread_set_options(0))
         out["config"]["other_configs"] = other_config_legs(w, args)
     elif args.other_configs and world > 1:
-        # the one workload with a data-path collective, on the real xGMI fabric: 8K pairs band-sharded over the ranks
+        # the one workload with a data-path collective, on the real xGMI fabric: 8K pairs band-sharded over the ranks, the all-reduce
+        # inside libmi355vfx (its own RCCL communicator).  It runs under a watchdog: this leg has never seen more than one GPU before
+        # the driver's scaling run, and a rank stuck in a rendezvous must not cost the headline line.
         vfx.check(lib.mvfx_thread_set_options(0))
-        try:
-            out["config"]["other_configs"] = {"videocompare_blockhash_sharded": videocompare_sharded_leg(w, args, "blockhash", 200, 20)}
-        except Exception as e:
-            out["config"]["other_configs"] = {"videocompare_blockhash_sharded": {"error": f"{type(e).__name__}: {e}"}}
+        import threading
+        box = {}
+
+        def side_leg():
+            try:
+                torch.cuda.set_device(w.local_rank)
+                vfx.check(lib.mvfx_set_device(w.local_rank))
+                box["r"] = videocompare_sharded_leg(w, args, "blockhash", 200, 20)
+            except Exception as e:  # noqa: BLE001
+                box["r"] = {"error": f"{type(e).__name__}: {e}"}
+
+        th = threading.Thread(target=side_leg, daemon=True)
+        th.start()
+        th.join(timeout=args.side_leg_timeout)
+        if th.is_alive():
+            out["config"]["other_configs"] = {"videocompare_blockhash_sharded": {"error": f"no result within {args.side_leg_timeout} s (watchdog)"}}
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            os._exit(0)  # the stuck thread holds the communicator: no orderly teardown
+        out["config"]["other_configs"] = {"videocompare_blockhash_sharded": box["r"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_hsvfilter(args.cpu_seconds, args.frame_content)
     if rank == 0:
@@ -1168,6 +1211,7 @@ def main():
     ap.add_argument("--other-configs", type=int, default=1, choices=[0, 1],
                     help="hsvfilter workload: after the headline legs also measure BASELINE configs 2-5 in this run "
                          "(config.other_configs); N > 1: the band-sharded videocompare leg with its RCCL all-reduce")
+    ap.add_argument("--side-leg-timeout", type=float, default=180.0, help="N > 1: watchdog of the band-sharded videocompare leg, seconds")
     ap.add_argument("--other-cpu-seconds", type=float, default=2.5, help="CPU baseline budget per leg of configs 2-5")
     ap.add_argument("--other-settle-seconds", type=float, default=0.3, help="untimed run before each leg of configs 2-5")
     ap.add_argument("--pct-steps", type=int, default=200,

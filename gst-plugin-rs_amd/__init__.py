@@ -128,6 +128,7 @@ SIGNATURES = {
     "mvfx_copy_to_host": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mvfx_copy_device_to_device": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mvfx_thread_stream": (c_void_p, []),
+    "mvfx_thread_stream_n": (c_void_p, [c_uint32]),
     "mvfx_event_create": (c_int, [POINTER(c_void_p)]),
     "mvfx_event_destroy": (c_int, [c_void_p]),
     "mvfx_event_record": (c_int, [c_void_p, c_void_p]),
@@ -144,6 +145,7 @@ SIGNATURES = {
     "mvfx_hsvfilter_transform_frames_ip": (c_int, [POINTER(Frame), c_uint32, POINTER(HsvFilterSettings), c_void_p]),
     "mvfx_hsvfilter_transform_frames_ip_settings": (c_int, [POINTER(Frame), c_uint32, POINTER(HsvFilterSettings), c_void_p]),
     "mvfx_hsvfilter_transform_frame_ip_combined": (c_int, [POINTER(Frame), POINTER(HsvFilterSettings), c_void_p]),
+    "mvfx_hsvfilter_transform_frame_ip_fenced": (c_int, [POINTER(Frame), POINTER(HsvFilterSettings), c_void_p, POINTER(c_void_p)]),
     "mvfx_combiner_stats": (c_int, [c_int, POINTER(c_uint64), POINTER(c_uint64)]),
     "mvfx_combiner_average_wait_us": (ctypes.c_double, [c_int]),
     "mvfx_hsvfilter_transform_frame_ip_host": (c_int, [POINTER(Frame), POINTER(HsvFilterSettings)]),

@@ -57,14 +57,22 @@ extern "C" {
 //
 // batch == 0: the launch combiner -- every thread calls the single-frame mvfx_hsvfilter_transform_frame_ip_combined and the
 // library's submitter thread coalesces the frames of all threads into batched launches.
+//
+// streams_per_thread (mvfxbench_hsvfilter_streams_rot): every thread rotates its launches over that many private HIP streams
+// (mvfx_thread_stream_n): consecutive frames of one video stream are independent, so the kernels of one thread may overlap.
+static uint32_t g_streams_per_thread = 1;
+
 int mvfxbench_hsvfilter_streams_warm(int device, uint32_t n_threads, uint32_t warmup, uint32_t launches, uint32_t reps,
                                      const mvfx_frame *frames, uint32_t frames_per_thread, uint32_t batch,
                                      const mvfx_frame *warm_frames, uint32_t warm_frames_per_thread,
                                      const mvfx_hsvfilter_settings *settings, uint32_t options, double *seconds_out,
                                      double *thread_seconds)
 {
+    const uint32_t rot = g_streams_per_thread ? g_streams_per_thread : 1;
+    // batch == 0xFFFFFFFF: the combiner's fenced entry (no caller stream: the frame's previous launch's event in, a new event out)
+    const bool fenced = batch == 0xFFFFFFFFu;
     const bool combined = batch == 0;
-    if (combined) batch = 1;
+    if (combined || fenced) batch = 1;
     if (!frames || !settings || !seconds_out || n_threads == 0 || frames_per_thread == 0 || reps == 0 ||
         frames_per_thread % batch != 0 || (warm_frames && (warm_frames_per_thread == 0 || warm_frames_per_thread % batch != 0)))
         return MVFX_ERR_INVALID_ARGUMENT;
@@ -83,20 +91,29 @@ int mvfxbench_hsvfilter_streams_warm(int device, uint32_t n_threads, uint32_t wa
         pool.emplace_back([&, t] {
             int rc = mvfx_set_device(device);
             if (rc == MVFX_OK) rc = mvfx_thread_set_options(options);
-            mvfx_stream st = mvfx_thread_stream();
+            mvfx_stream sts[4];
+            for (uint32_t k = 0; k < 4; k++) sts[k] = mvfx_thread_stream_n(k % rot);
             const mvfx_frame *mine = frames + (size_t)t * frames_per_thread;
             const mvfx_frame *warm = warm_frames ? warm_frames + (size_t)t * warm_frames_per_thread : mine;
             const uint32_t warm_groups = warm_frames ? warm_frames_per_thread / batch : groups;
+            auto sync_all = [&]() { int e = MVFX_OK; for (uint32_t k = 0; k < rot && k < 4 && e == MVFX_OK; k++) e = mvfx_stream_synchronize(sts[k]); return e; };
+            std::vector<mvfx_event> fence(frames_per_thread + (warm_frames ? warm_frames_per_thread : 0), nullptr); // per frame: its last launch
+            auto launch_fenced = [&](const mvfx_frame *set, uint32_t n_frames, uint32_t base, uint32_t i) {
+                const uint32_t k = i % n_frames;
+                return mvfx_hsvfilter_transform_frame_ip_fenced(set + k, settings, fence[base + k], &fence[base + k]);
+            };
+            auto sync_fences = [&]() { int e = MVFX_OK; for (mvfx_event ev : fence) if (ev && e == MVFX_OK) e = mvfx_event_synchronize(ev); return e; };
             for (uint32_t i = 0; i < warmup && rc == MVFX_OK; i++)
-                rc = launch_in(warm, warm_groups, i, st);
-            if (rc == MVFX_OK) rc = mvfx_stream_synchronize(st);
+                rc = fenced ? launch_fenced(warm, warm_frames ? warm_frames_per_thread : frames_per_thread, warm_frames ? frames_per_thread : 0, i)
+                            : launch_in(warm, warm_groups, i, sts[i % rot % 4]);
+            if (rc == MVFX_OK) rc = fenced ? sync_fences() : sync_all();
             ready.wait();
             for (uint32_t r = 0; r < reps; r++) {
                 go.wait();
                 const double t0 = now_s();
                 for (uint32_t i = 0; i < launches && rc == MVFX_OK; i++)
-                    rc = launch(mine, r * launches + i, st);
-                if (rc == MVFX_OK) rc = mvfx_stream_synchronize(st);
+                    rc = fenced ? launch_fenced(mine, frames_per_thread, 0, r * launches + i) : launch(mine, r * launches + i, sts[i % rot % 4]);
+                if (rc == MVFX_OK) rc = fenced ? sync_fences() : sync_all();
                 span[t] = now_s() - t0;
                 done.wait();
             }
@@ -116,6 +133,18 @@ int mvfxbench_hsvfilter_streams_warm(int device, uint32_t n_threads, uint32_t wa
         if (status[t] != MVFX_OK) return status[t];
     }
     return MVFX_OK;
+}
+
+int mvfxbench_hsvfilter_streams_rot(int device, uint32_t n_threads, uint32_t streams_per_thread, uint32_t warmup, uint32_t launches, uint32_t reps,
+                                    const mvfx_frame *frames, uint32_t frames_per_thread, const mvfx_frame *warm_frames,
+                                    uint32_t warm_frames_per_thread, const mvfx_hsvfilter_settings *settings, uint32_t options,
+                                    double *seconds_out, double *thread_seconds)
+{
+    g_streams_per_thread = streams_per_thread < 1 ? 1 : (streams_per_thread > 4 ? 4 : streams_per_thread);
+    const int rc = mvfxbench_hsvfilter_streams_warm(device, n_threads, warmup, launches, reps, frames, frames_per_thread, 1, warm_frames,
+                                                    warm_frames_per_thread, settings, options, seconds_out, thread_seconds);
+    g_streams_per_thread = 1;
+    return rc;
 }
 
 int mvfxbench_hsvfilter_streams_batched(int device, uint32_t n_threads, uint32_t warmup, uint32_t launches, uint32_t reps,

@@ -33,6 +33,8 @@ struct DeviceState {
     Scratch scratch[kScratchSlots];
     StreamScratch by_stream[kStreamScratch];
     uint64_t tick = 0;
+    hipStream_t extra[3] = {nullptr, nullptr, nullptr}; // mvfx_thread_stream_n(1..3)
+    bool extra_tried[3] = {false, false, false};
     hipStream_t stream = nullptr;
     bool stream_tried = false;
 };
@@ -52,6 +54,8 @@ struct ThreadState {
             for (StreamScratch &s : kv.second.by_stream)
                 if (s.block.ptr) (void)hipFree(s.block.ptr);
             if (kv.second.stream) (void)hipStreamDestroy(kv.second.stream);
+            for (hipStream_t e : kv.second.extra)
+                if (e) (void)hipStreamDestroy(e);
         }
     }
 };
@@ -170,6 +174,21 @@ hipStream_t host_stream()
     return d.stream;
 }
 
+hipStream_t host_stream_n(uint32_t index)
+{
+    if (index == 0) return host_stream();
+    DeviceState &d = t_state.current();
+    const uint32_t k = (index - 1) % 3;
+    if (!d.extra_tried[k]) {
+        d.extra_tried[k] = true;
+        if (hipStreamCreateWithFlags(&d.extra[k], hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            d.extra[k] = nullptr;
+        }
+    }
+    return d.extra[k] ? d.extra[k] : host_stream();
+}
+
 } // namespace mvfx
 
 using namespace mvfx;
@@ -285,6 +304,7 @@ int mvfx_copy_device_to_device(void *dst_device, const void *src_device, size_t 
 }
 
 mvfx_stream mvfx_thread_stream(void) { return reinterpret_cast<mvfx_stream>(host_stream()); }
+mvfx_stream mvfx_thread_stream_n(uint32_t index) { return reinterpret_cast<mvfx_stream>(host_stream_n(index)); }
 
 int mvfx_event_create(mvfx_event *out)
 {

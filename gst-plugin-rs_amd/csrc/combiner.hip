@@ -36,7 +36,7 @@ using Clock = std::chrono::steady_clock;
 struct Request {
     mvfx_frame frame;
     mvfx_hsvfilter_settings settings;
-    hipEvent_t ready; // nullptr: the caller's stream was idle
+    hipEvent_t ready; // stream mode: the caller's ordering point (nullptr: its stream was idle); fenced mode: the frame's fence (nullptr: none)
 };
 
 struct Batch {
@@ -60,16 +60,28 @@ inline void cpu_relax()
 
 class Combiner {
 public:
-    explicit Combiner(int device) : device_(device), ring_(64)
+    explicit Combiner(int device) : device_(device), ring_(256)
     {
         if (const char *e = getenv("MVFX_COMBINE_WINDOW_US")) window_us_ = std::max(atoi(e), 0);
     }
 
-    int submit(const mvfx_frame *frame, const mvfx_hsvfilter_settings *settings, hipStream_t stream)
+    // fenced == false: `stream` is the caller's stream (ordering through it, see the file comment).
+    // fenced == true:  no caller stream at all.  `wait_for` is the frame's fence (an event its previous user recorded, or NULL), the
+    //   launch runs on the combiner's OWN stream of this device -- every fenced launch of the device, in submission order -- and
+    //   *done_out is the event behind it: the frame's new fence.  Nothing is enqueued on any other stream, so consecutive batches are
+    //   separated by one kernel boundary only, like the batched entry point called from one thread.
+    int submit(const mvfx_frame *frame, const mvfx_hsvfilter_settings *settings, hipStream_t stream, bool fenced = false,
+               hipEvent_t wait_for = nullptr, hipEvent_t *done_out = nullptr)
     {
         const auto t_in = Clock::now();
-        Request req{*frame, *settings, nullptr};
-        const uint32_t options = thread_options();
+        Request req{*frame, *settings, fenced ? wait_for : nullptr};
+        const uint32_t options = thread_options() | (fenced ? 0x80000000u : 0u); // the two modes never share a batch
+        if (fenced) {
+            std::lock_guard<std::mutex> g(m_);
+            if (!own_stream_ && hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking) != hipSuccess)
+                return fail(MVFX_ERR_DEVICE, "launch combiner: no stream: %s", hipGetErrorString(hipGetLastError()));
+            stream = own_stream_;
+        }
         Batch *b = nullptr;
         bool leader = false;
         size_t expected = 1;
@@ -81,7 +93,7 @@ public:
                 same_geometry(o->req[0]->frame, *frame)) {
                 // follower: the ordering point of this stream, unless nothing is pending on it
                 lk.unlock();
-                if (hipStreamQuery(stream) != hipSuccess) {
+                if (!fenced && hipStreamQuery(stream) != hipSuccess) {
                     (void)hipGetLastError();
                     if (int rc = ready_event(&req.ready); rc != MVFX_OK) return rc;
                     MVFX_HIP_TRY(hipEventRecord(req.ready, stream));
@@ -136,14 +148,20 @@ public:
             for (int i = 0; i < n; i++) {
                 frames[i] = b->req[i]->frame;
                 settings_all[i] = b->req[i]->settings;
-                if (i > 0 && b->req[i]->ready && rc == MVFX_OK && hipStreamWaitEvent(stream, b->req[i]->ready, 0) != hipSuccess) rc = MVFX_ERR_DEVICE;
+                if ((i > 0 || fenced) && b->req[i]->ready && rc == MVFX_OK && hipStreamWaitEvent(stream, b->req[i]->ready, 0) != hipSuccess)
+                    rc = MVFX_ERR_DEVICE;
             }
-            if (rc == MVFX_OK)
+            if (rc == MVFX_OK) {
+                const uint32_t mine = thread_options();
+                if (fenced) (void)mvfx_thread_set_options(b->options & 0x7fffffffu);
                 rc = mvfx_hsvfilter_transform_frames_ip_settings(frames, (uint32_t)n, settings_all, stream);
+                if (fenced) (void)mvfx_thread_set_options(mine);
+            }
             else
                 fail(rc, "launch combiner: a HIP event call failed: %s", hipGetErrorString(hipGetLastError()));
             if (rc != MVFX_OK) snprintf(b->error, sizeof(b->error), "%s", mvfx_last_error());
-            if (n > 1 && b->done && hipEventRecord(b->done, stream) != hipSuccess && rc == MVFX_OK) rc = MVFX_ERR_DEVICE;
+            if ((n > 1 || fenced) && b->done && hipEventRecord(b->done, stream) != hipSuccess && rc == MVFX_OK) rc = MVFX_ERR_DEVICE;
+            if (fenced && done_out) *done_out = b->done;
             b->status = rc;
             batches_++;
             frames_ += (uint64_t)n;
@@ -157,7 +175,8 @@ public:
             }
             rc = b->status;
             if (rc != MVFX_OK) fail(rc, "%s", b->error);
-            const hipError_t e = b->done ? hipStreamWaitEvent(stream, b->done, 0) : hipErrorInvalidValue;
+            if (fenced && done_out) *done_out = b->done;
+            const hipError_t e = fenced ? hipSuccess : (b->done ? hipStreamWaitEvent(stream, b->done, 0) : hipErrorInvalidValue);
             {
                 std::lock_guard<std::mutex> g(m_);
                 b->waiters--;
@@ -202,6 +221,7 @@ private:
     std::mutex m_;
     std::vector<Batch> ring_;
     Batch *open_ = nullptr;
+    hipStream_t own_stream_ = nullptr; // fenced mode: every launch of this device, in submission order
     std::map<std::thread::id, Clock::time_point> seen_; // callers and when they last submitted
     std::atomic<uint64_t> batches_{0}, frames_{0}, wait_ns_{0}; // wait: time inside submit, summed over the frames
 };
@@ -248,6 +268,22 @@ int mvfx_hsvfilter_transform_frame_ip_combined(const mvfx_frame *frame, const mv
     int device = 0;
     MVFX_HIP_TRY(hipGetDevice(&device));
     return combiner_for(device)->submit(frame, settings, as_stream(stream));
+}
+
+int mvfx_hsvfilter_transform_frame_ip_fenced(const mvfx_frame *frame, const mvfx_hsvfilter_settings *settings, mvfx_event wait_for,
+                                             mvfx_event *done_out)
+{
+    if (!frame || !settings || !done_out)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "hsvfilter: NULL frame, settings or event output");
+    *done_out = nullptr;
+    if (int rc = check_packed_frame(frame, "hsvfilter"); rc != MVFX_OK) return rc;
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    int device = 0;
+    MVFX_HIP_TRY(hipGetDevice(&device));
+    hipEvent_t done = nullptr;
+    const int rc = combiner_for(device)->submit(frame, settings, nullptr, true, reinterpret_cast<hipEvent_t>(wait_for), &done);
+    *done_out = reinterpret_cast<mvfx_event>(done);
+    return rc;
 }
 
 int mvfx_combiner_stats(int device, uint64_t *batches_out, uint64_t *frames_out)

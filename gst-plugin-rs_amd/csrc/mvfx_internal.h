@@ -58,6 +58,7 @@ inline int opt_lut_placement() { return (int)((thread_options() & MVFX_OPT_LUT_P
 // Grow-only device scratch used by the *_host entry points (one per thread and device).
 int host_scratch(size_t bytes, int slot, void **out);
 hipStream_t host_stream();
+hipStream_t host_stream_n(uint32_t index); // 0 = host_stream(), 1..3 = further private streams of the calling thread
 // Grow-only device scratch keyed by (thread, device, stream): intermediate results handed from one launch to the next on `stream`.
 int stream_scratch(hipStream_t stream, size_t bytes, void **out);
 

@@ -121,13 +121,24 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
     // no host wait per buffer: the stream first waits (on the device) for whoever touched the block last, and the block's
     // fence is recorded behind the kernel -- the next element, possibly on another streaming thread and stream, waits for
     // it the same way, a CPU map waits on the host (d3d12colorlut/imp.rs:695-714 does this with an ID3D12Fence)
-    mvfx_stream st = mvfx_thread_stream();
-    mvfx_hip_buffer_acquire(buf, st);
     // default cache policy (thread option word 0): the next element reads this frame on the GPU.
-    // MVFX_COMBINE=1 (environment, read once): the launch combiner -- still one call per buffer, but the frames the hsvfilter
-    // elements of this process hand in at about the same time leave as one batched launch with per-frame settings
-    static const bool combine = g_getenv("MVFX_COMBINE") && atoi(g_getenv("MVFX_COMBINE")) != 0;
-    int rc = combine ? mvfx_hsvfilter_transform_frame_ip_combined(&f, &s, st) : mvfx_hsvfilter_transform_frame_ip(&f, &s, st);
+    // MVFX_COMBINE (environment, read once): the launch combiner -- still one call per buffer, but the frames the hsvfilter elements
+    // of this process hand in at about the same time leave as one batched launch with per-frame settings.  1: ordered through this
+    // thread's stream; 2: the fenced entry -- the buffer's fence goes in as an event, the batch's event comes back as its new fence,
+    // nothing is enqueued on a stream of this thread ("the launch combiner")
+    static const int combine = g_getenv("MVFX_COMBINE") ? atoi(g_getenv("MVFX_COMBINE")) : 0;
+    int rc;
+    if (combine == 2 && gst_buffer_n_memory(buf) == 1) {
+        GstMemory *mem = gst_buffer_peek_memory(buf, 0);
+        mvfx_event done = NULL;
+        rc = mvfx_hsvfilter_transform_frame_ip_fenced(&f, &s, mvfx_hip_memory_pending_fence(mem), &done);
+        if (rc == MVFX_OK && done) mvfx_hip_memory_set_borrowed_fence(mem, done);
+        gst_buffer_unmap(buf, &map);
+        return MVFX_GST_FLOW(self, rc);
+    }
+    mvfx_stream st = mvfx_element_stream();
+    mvfx_hip_buffer_acquire(buf, st);
+    rc = combine == 1 ? mvfx_hsvfilter_transform_frame_ip_combined(&f, &s, st) : mvfx_hsvfilter_transform_frame_ip(&f, &s, st);
     mvfx_hip_buffer_release(buf, st);
     gst_buffer_unmap(buf, &map);
     return MVFX_GST_FLOW(self, rc);
@@ -316,7 +327,7 @@ static GstFlowReturn gst_hsv_detector_bt_transform(GstBaseTransform *bt, GstBuff
         gst_buffer_unmap(inbuf, &imap);
         return GST_FLOW_ERROR;
     }
-    mvfx_stream st = mvfx_thread_stream();
+    mvfx_stream st = mvfx_element_stream();
     mvfx_hip_buffer_acquire(inbuf, st);
     mvfx_hip_buffer_acquire(outbuf, st);
     int rc = i420 ? mvfx_hsvdetector_transform_i420(&pi, &fo, &s, 0, st) : mvfx_hsvdetector_transform_frame(&fi, &fo, &s, st);

@@ -180,6 +180,24 @@ static inline GstFlowReturn mvfx_hip_new_output(GstBaseTransform *trans, GstBuff
         return GST_BASE_TRANSFORM_CLASS(parent_class_ptr)->decide_allocation(trans, query);                           \
     }
 
+// The HIP stream a device-memory filter enqueues THIS buffer on.  Consecutive buffers of a video stream are independent frames and every
+// buffer carries its own fence, so a streaming thread may rotate over several private streams (mvfx_thread_stream_n): the tail of one
+// frame's kernel then overlaps the head of the next one's instead of running back to back on one stream (4K hsvfilter, one streaming
+// thread: profiles/r3/stream_rotation.txt).  MVFX_ELEMENT_STREAMS = 1..4 (environment, read once).
+#ifndef MVFX_ELEMENT_STREAMS_DEFAULT
+#define MVFX_ELEMENT_STREAMS_DEFAULT 1
+#endif
+static inline mvfx_stream mvfx_element_stream(void)
+{
+    static const guint n = [] {
+        const gchar *e = g_getenv("MVFX_ELEMENT_STREAMS");
+        const int v = e ? atoi(e) : MVFX_ELEMENT_STREAMS_DEFAULT;
+        return (guint)CLAMP(v, 1, 4);
+    }();
+    static thread_local guint counter = 0;
+    return mvfx_thread_stream_n(n > 1 ? counter++ % n : 0);
+}
+
 static inline void mvfx_add_pad_templates(GstElementClass *klass, GstCaps *sink_caps, GstCaps *src_caps)
 {
     gst_element_class_add_pad_template(klass, gst_pad_template_new("sink", GST_PAD_SINK, GST_PAD_ALWAYS, sink_caps));

@@ -20,6 +20,9 @@ typedef struct {
     // streaming threads must both have finished before a recycled block is written again.
     mvfx_event last_use;
     gboolean pending;
+    // a fence recorded by somebody else on a stream of theirs (the launch combiner's batch event): not owned, never re-recorded
+    // here; while set it is what the next user waits for, and the next release chains onto it like onto a pending own record
+    mvfx_event borrowed;
 } MvfxHipMemory;
 
 typedef struct { GstAllocator parent; } MvfxHipAllocator;
@@ -122,6 +125,10 @@ static GstMemory *mvfx_hip_alloc(GstAllocator *allocator, gsize size, GstAllocat
 static void mvfx_hip_free(GstAllocator *, GstMemory *mem)
 {
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
+    if (m->borrowed) { // the free list carries owned events only: finish the borrowed one here (rare: a buffer dropped right behind the combiner)
+        mvfx_event_synchronize(m->borrowed);
+        m->borrowed = NULL;
+    }
     freelist_give(m->dptr, mem->maxsize, m->device, m->last_use, m->pending);
     g_free(m->shadow);
     g_mutex_clear(&m->lock);
@@ -133,8 +140,30 @@ void mvfx_hip_memory_acquire(GstMemory *mem, mvfx_stream stream)
     if (!mvfx_is_hip_memory(mem)) return;
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
     g_mutex_lock(&m->lock);
+    if (m->borrowed)
+        mvfx_stream_wait_event(stream, m->borrowed);
     if (m->pending && m->last_use)
         mvfx_stream_wait_event(stream, m->last_use); // device-side wait; the host goes on
+    g_mutex_unlock(&m->lock);
+}
+
+void *mvfx_hip_memory_pending_fence(GstMemory *mem)
+{
+    if (!mvfx_is_hip_memory(mem)) return NULL;
+    MvfxHipMemory *m = (MvfxHipMemory *)mem;
+    g_mutex_lock(&m->lock);
+    // the borrowed fence is always younger than the own record it was set behind (the combiner's launch waited for that one)
+    void *ev = m->borrowed ? m->borrowed : (m->pending ? m->last_use : NULL);
+    g_mutex_unlock(&m->lock);
+    return ev;
+}
+
+void mvfx_hip_memory_set_borrowed_fence(GstMemory *mem, void *event)
+{
+    if (!mvfx_is_hip_memory(mem)) return;
+    MvfxHipMemory *m = (MvfxHipMemory *)mem;
+    g_mutex_lock(&m->lock);
+    m->borrowed = event;
     g_mutex_unlock(&m->lock);
 }
 
@@ -149,6 +178,10 @@ void mvfx_hip_memory_release(GstMemory *mem, mvfx_stream stream)
     // for it on the device, so the record below covers that user too; a no-op when the pending record is this stream's own
     if (m->last_use && m->pending)
         mvfx_stream_wait_event(stream, m->last_use);
+    if (m->borrowed) { // same chaining for a fence somebody else recorded; the own record below then covers it
+        mvfx_stream_wait_event(stream, m->borrowed);
+        m->borrowed = NULL;
+    }
     if (m->last_use && mvfx_event_record(m->last_use, stream) == MVFX_OK)
         m->pending = TRUE;
     else
@@ -161,6 +194,10 @@ void mvfx_hip_memory_wait(GstMemory *mem)
     if (!mvfx_is_hip_memory(mem)) return;
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
     g_mutex_lock(&m->lock);
+    if (m->borrowed) {
+        mvfx_event_synchronize(m->borrowed);
+        m->borrowed = NULL;
+    }
     if (m->pending && m->last_use) {
         mvfx_event_synchronize(m->last_use);
         m->pending = FALSE;

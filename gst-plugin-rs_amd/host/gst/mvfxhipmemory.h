@@ -29,6 +29,11 @@ void mvfx_hip_allocator_trim(void);                   // returns the cached devi
 void mvfx_hip_memory_acquire(GstMemory *mem, void *stream);
 void mvfx_hip_memory_release(GstMemory *mem, void *stream);
 void mvfx_hip_memory_wait(GstMemory *mem);
+// Fences as plain events, for work that is not enqueued on a stream of the element's (the launch combiner's fenced entry):
+// the event a new user of the block has to wait for (NULL: none pending), and a borrowed event -- owned by somebody else, valid for
+// the life of the process -- as the block's new fence (it stands in front of the block's own event until the next release).
+void *mvfx_hip_memory_pending_fence(GstMemory *mem);
+void mvfx_hip_memory_set_borrowed_fence(GstMemory *mem, void *event);
 void mvfx_hip_buffer_acquire(GstBuffer *buf, void *stream);
 void mvfx_hip_buffer_release(GstBuffer *buf, void *stream);
 gboolean mvfx_is_hip_memory(GstMemory *mem);

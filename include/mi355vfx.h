@@ -104,6 +104,11 @@ int mvfx_copy_device_to_device(void *dst_device, const void *src_device, size_t 
 /* The calling thread's private non-blocking stream (the one the *_host entry points use); lets an
  * element layer issue the device entry points of one streaming thread in order. */
 mvfx_stream mvfx_thread_stream(void);
+/* Further private streams of the calling thread (index 0 = mvfx_thread_stream(), 1..3 more, index taken modulo 4).  Consecutive
+ * buffers of one video stream are independent frames: an element that alternates between two of these per buffer lets the tail of
+ * one frame's kernel overlap the head of the next one's (a launch per 4K frame: 16.2 us back to back on ONE stream); the buffers'
+ * fences keep every consumer correct. */
+mvfx_stream mvfx_thread_stream_n(uint32_t index);
 
 /* ---- events: the fence a device-memory element leaves on its output instead of blocking ----
  * What the reference's d3d12colorlut does with ID3D12Fence (set a fence value on the output memory and return,
@@ -186,6 +191,14 @@ int mvfx_hsvfilter_transform_frames_ip_settings(const mvfx_frame *frames, uint32
  * launch has been enqueued; the host never waits for the GPU; a lone stream is never held back.  Measured numbers: DESIGN.md. */
 int mvfx_hsvfilter_transform_frame_ip_combined(const mvfx_frame *frame, const mvfx_hsvfilter_settings *settings,
                                                mvfx_stream stream);
+/* The combiner without caller streams: the frame's ordering is given as events.  `wait_for` (may be NULL) is the fence its previous
+ * user left on the frame; `*done_out` receives the event behind the launch that filters it -- the frame's new fence, owned by the
+ * library, valid for the life of the process (it may come to stand for a LATER launch of the same in-order stream: waiting for it
+ * is then conservative, never wrong).  All fenced launches of a device run on one library-owned stream in submission order, so
+ * consecutive batches are separated by a kernel boundary only -- no cross-stream waits on either side, which is what made the
+ * stream-ordered variant above slower than per-stream launches.  This is the entry the element uses with MVFX_COMBINE=2. */
+int mvfx_hsvfilter_transform_frame_ip_fenced(const mvfx_frame *frame, const mvfx_hsvfilter_settings *settings,
+                                             mvfx_event wait_for, mvfx_event *done_out);
 /* batches launched and frames carried by the combiner of `device` so far (frames / batches = the average batch) */
 int mvfx_combiner_stats(int device, uint64_t *batches_out, uint64_t *frames_out);
 /* average time a combined call took on the host (collection wait + launch or event hand-over), in us;

@@ -34,7 +34,8 @@ def test_frames_with_their_own_settings_in_one_call(gpu):
         assert np.array_equal(bufs[k].download().reshape(h, w * 4), exp), f"frame {k} settings {SETTINGS[k]}"
 
 
-def test_sixteen_threads_through_the_combiner(gpu):
+@pytest.mark.parametrize("fenced", [False, True], ids=["stream-ordered", "fenced"])
+def test_sixteen_threads_through_the_combiner(gpu, fenced):
     """16 host threads (GStreamer: one streaming thread per stream), each with its own HIP stream, frames and settings, each making
     single-frame calls through the combiner; thread 15 works on another frame size (never shares a launch).  Every frame equals the
     oracle's answer for its stream's settings; the combiner needed fewer launches than frames."""
@@ -55,6 +56,8 @@ def test_sixteen_threads_through_the_combiner(gpu):
             stream = L.mvfx_thread_stream()
             host = [frames.random_frame(0xC100 + 97 * t + k, tw, th) for k in range(per_thread)]
             bufs = [gpu.DeviceBuffer(f.nbytes) for f in host]
+            ev_in = ctypes.c_void_p()
+            gpu.check(L.mvfx_event_create(ctypes.byref(ev_in)))
             start.wait()
             for k in range(per_thread):
                 # upload on the caller's stream, filter through the combiner, download on the caller's stream: the combined call must
@@ -62,7 +65,15 @@ def test_sixteen_threads_through_the_combiner(gpu):
                 gpu.check(L.mvfx_copy_to_device_async(ctypes.c_void_p(bufs[k].ptr), host[k].ctypes.data_as(ctypes.c_void_p), host[k].nbytes,
                                                       ctypes.c_void_p(stream)))
                 f = gpu.make_frame(bufs[k].ptr, tw, th, tw * 4, "RGBA")
-                gpu.check(L.mvfx_hsvfilter_transform_frame_ip_combined(ctypes.byref(f), ctypes.byref(st), ctypes.c_void_p(stream)))
+                if fenced:
+                    # the frame's fence in (the upload's event), the batch's event out; this thread's stream then waits for it
+                    gpu.check(L.mvfx_event_record(ev_in, ctypes.c_void_p(stream)))
+                    done = ctypes.c_void_p()
+                    gpu.check(L.mvfx_hsvfilter_transform_frame_ip_fenced(ctypes.byref(f), ctypes.byref(st), ev_in, ctypes.byref(done)))
+                    assert done.value
+                    gpu.check(L.mvfx_stream_wait_event(ctypes.c_void_p(stream), done))
+                else:
+                    gpu.check(L.mvfx_hsvfilter_transform_frame_ip_combined(ctypes.byref(f), ctypes.byref(st), ctypes.c_void_p(stream)))
             out = [np.empty_like(f) for f in host]
             for k in range(per_thread):
                 gpu.check(L.mvfx_copy_to_host_async(out[k].ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(bufs[k].ptr), out[k].nbytes,

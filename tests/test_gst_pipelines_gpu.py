@@ -443,7 +443,8 @@ def test_hipmemory_tee_two_device_readers_on_recycled_blocks(gpu, tmp_path):
         assert bad == [], f"{name}: frames {bad} differ"
 
 
-def test_sixteen_hsvfilter_branches_through_the_launch_combiner(gpu, tmp_path):
+@pytest.mark.parametrize("mode", ["1", "2"], ids=["stream-ordered", "fenced"])
+def test_sixteen_hsvfilter_branches_through_the_launch_combiner(gpu, tmp_path, mode):
     """16 `hiptestsrc ! hsvfilter ! hipdownload ! filesink` streams in one process with MVFX_COMBINE=1: every hsvfilter still makes
     one call per buffer (hsvfilter/imp.rs:322-326), the library coalesces the frames of the 16 streaming threads into batched
     launches with per-frame settings.  Every branch has its own hue-shift (both signs) / saturation-mul; every frame of every branch
@@ -454,7 +455,7 @@ def test_sixteen_hsvfilter_branches_through_the_launch_combiner(gpu, tmp_path):
     caps = f"video/x-raw(memory:HIPMemory),format=RGBA,width={w},height={h},framerate=30/1"
     pipe = " ".join(f"hiptestsrc num-buffers={n} ! {caps} ! hsvfilter hue-shift={s[0]} saturation-mul={s[1]} ! hipdownload ! "
                     f"filesink location={tmp_path}/b{k}.raw" for k, s in enumerate(settings))
-    r = gst_env.run([LAUNCH, "-q"] + pipe.split(), tmp_path, extra_env={"MVFX_COMBINE": "1", "MVFX_COMBINE_STATS": "1"})
+    r = gst_env.run([LAUNCH, "-q"] + pipe.split(), tmp_path, extra_env={"MVFX_COMBINE": mode, "MVFX_COMBINE_STATS": "1"})
     assert r.returncode == 0, r.stdout
     for k, s in enumerate(settings):
         got = np.fromfile(f"{tmp_path}/b{k}.raw", dtype=np.uint8).reshape(n, h, w * 4)

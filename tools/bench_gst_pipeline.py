@@ -58,7 +58,7 @@ def branches_main(args):
     for refresh in ("false", "true"):
         tpl = " ".join(f"hiptestsrc num-buffers={{n}} refresh={refresh} ! {caps} ! hsvfilter hue-shift={(17 * k) % 360 - 120} saturation-mul={1 + 0.02 * k} "
                        "! fakesink sync=false" for k in range(n))
-        for combine in ("0", "1"):
+        for combine in ("0", "1", "2"):
             env = {"MVFX_COMBINE": combine, "MVFX_COMBINE_STATS": "1"}
             # ten times the buffers of the single-chain runs: 16 branches at tens of thousands of frames per second finish 500 buffers each
             # inside the noise of a process start
@@ -66,7 +66,7 @@ def branches_main(args):
             key = f"refresh_{refresh}_combine_{combine}"
             out[key + "_fps"] = round(v * n, 1)
             out[key + "_frac_of_8TBs"] = round(v * n * 2 * w * h * 4 / 8e12, 4)
-            if combine == "1":
+            if combine != "0":
                 r = gst_env.run([LAUNCH, "-q"] + tpl.format(n=args.n2 * 10).split(), tmp, timeout=900, extra_env=env)
                 m = re.search(r"mvfx combiner device 0: (\d+) launches for (\d+) frames \(([0-9.]+) frames per launch\), ([0-9.]+) us", r.stdout)
                 if m:
