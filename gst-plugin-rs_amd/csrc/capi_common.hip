@@ -6,6 +6,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <vector>
 
 namespace mvfx {
 
@@ -37,14 +38,59 @@ struct DeviceState {
     bool extra_tried[3] = {false, false, false};
     hipStream_t stream = nullptr;
     bool stream_tried = false;
+    int device = 0;
 };
+// The private streams of threads that have exited, per device, for the next thread that asks for one.  Streams are never destroyed:
+// sixteen GStreamer streaming threads leaving at end-of-stream called hipStreamDestroy concurrently and the runtime (ROCm 7.2) crashed
+// inside it about two runs in three with two streams per thread (tools/exp_rot2_crash.py, backtrace via tools/segv_trace.c: two threads
+// in ~ThreadState -> hipStreamDestroy at once).  A recycled stream may still have its previous owner's work queued: that only orders
+// ahead of the new owner's.  The pool is bounded by the largest number of threads alive at the same time; it is leaked on purpose
+// (threads may exit after the static destructors ran).
+struct IdleStreams {
+    std::mutex lock;
+    std::map<int, std::vector<hipStream_t>> by_device;
+};
+IdleStreams &idle_streams()
+{
+    static IdleStreams *pool = new IdleStreams;
+    return *pool;
+}
+hipStream_t take_stream(int device)
+{
+    {
+        IdleStreams &pool = idle_streams();
+        std::lock_guard<std::mutex> g(pool.lock);
+        std::vector<hipStream_t> &v = pool.by_device[device];
+        if (!v.empty()) {
+            hipStream_t s = v.back();
+            v.pop_back();
+            return s;
+        }
+    }
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        s = nullptr; // the null stream
+    }
+    return s;
+}
+void give_back_stream(int device, hipStream_t s)
+{
+    if (!s) return;
+    IdleStreams &pool = idle_streams();
+    std::lock_guard<std::mutex> g(pool.lock);
+    pool.by_device[device].push_back(s);
+}
+
 struct ThreadState {
     std::map<int, DeviceState> per_device;
     DeviceState &current()
     {
         int dev = 0;
         (void)hipGetDevice(&dev);
-        return per_device[dev];
+        DeviceState &d = per_device[dev];
+        d.device = dev;
+        return d;
     }
     ~ThreadState()
     {
@@ -53,9 +99,8 @@ struct ThreadState {
                 if (s.ptr) (void)hipFree(s.ptr);
             for (StreamScratch &s : kv.second.by_stream)
                 if (s.block.ptr) (void)hipFree(s.block.ptr);
-            if (kv.second.stream) (void)hipStreamDestroy(kv.second.stream);
-            for (hipStream_t e : kv.second.extra)
-                if (e) (void)hipStreamDestroy(e);
+            give_back_stream(kv.first, kv.second.stream);
+            for (hipStream_t e : kv.second.extra) give_back_stream(kv.first, e);
         }
     }
 };
@@ -166,10 +211,7 @@ hipStream_t host_stream()
     DeviceState &d = t_state.current();
     if (!d.stream_tried) {
         d.stream_tried = true;
-        if (hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess) {
-            (void)hipGetLastError();
-            d.stream = nullptr; // the null stream
-        }
+        d.stream = take_stream(d.device); // nullptr (the null stream) when none can be created
     }
     return d.stream;
 }
@@ -181,10 +223,7 @@ hipStream_t host_stream_n(uint32_t index)
     const uint32_t k = (index - 1) % 3;
     if (!d.extra_tried[k]) {
         d.extra_tried[k] = true;
-        if (hipStreamCreateWithFlags(&d.extra[k], hipStreamNonBlocking) != hipSuccess) {
-            (void)hipGetLastError();
-            d.extra[k] = nullptr;
-        }
+        d.extra[k] = take_stream(d.device);
     }
     return d.extra[k] ? d.extra[k] : host_stream();
 }
@@ -406,8 +445,8 @@ int mvfx_thread_set_options(uint32_t options)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options 0x%x: unknown bits 0x%x", options, options & ~known);
     if ((options & MVFX_OPT_HSV_LITERAL) && (options & MVFX_OPT_HSV_FORCE_FAST))
         return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options: MVFX_OPT_HSV_LITERAL and MVFX_OPT_HSV_FORCE_FAST exclude each other");
-    if (((options & MVFX_OPT_LUT_PLACEMENT_MASK) >> MVFX_OPT_LUT_PLACEMENT_SHIFT) > 5)
-        return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options: colorlut placement must be 0 (auto) .. 5 (tile kernel)");
+    if (((options & MVFX_OPT_LUT_PLACEMENT_MASK) >> MVFX_OPT_LUT_PLACEMENT_SHIFT) > 6)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options: colorlut placement must be 0 (auto) .. 6 (baked table)");
     t_options = options;
     return MVFX_OK;
 }

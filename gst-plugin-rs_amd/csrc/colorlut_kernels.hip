@@ -37,6 +37,11 @@ struct mvfx_cube_lut {
     uint32_t *d_tile_tables = nullptr; // tile kernel: 3 x 256 x (cell index, fraction) per byte value + 192 neighbourhood piece offsets
     float *d_cells = nullptr; // cell-packed copy: size^3 cells x 8 corners x (r,g,b) f32 = 96 B (3-D, size <= kCellMaxSize)
     float *d_table[3] = {nullptr, nullptr, nullptr};
+    // baked table (placement 6): the LUT applied to every one of the 2^24 RGB byte triples, 64 MiB, entry = output R | G << 8 | B << 16
+    // at index r | g << 8 | b << 16 -- produced by running this file's own interpolating kernels once over a 4096 x 4096 frame that
+    // holds every colour, so its bytes are theirs by construction
+    std::mutex bake_mu;
+    uint32_t *d_baked = nullptr;
 };
 
 namespace mvfx {
@@ -879,6 +884,7 @@ int ensure_uploaded(mvfx_cube_lut *h)
     if (h->d_rgba) { (void)hipFree(h->d_rgba); h->d_rgba = nullptr; }
     if (h->d_cells) { (void)hipFree(h->d_cells); h->d_cells = nullptr; }
     if (h->d_tile_tables) { (void)hipFree(h->d_tile_tables); h->d_tile_tables = nullptr; }
+    if (h->d_baked) { (void)hipFree(h->d_baked); h->d_baked = nullptr; }
     for (auto &t : h->d_table) if (t) { (void)hipFree(t); t = nullptr; }
     const CubeLut &l = h->lut;
     if (l.is_3d) {
@@ -959,8 +965,87 @@ int launch_one(bool use_lds, dim3 grid, size_t lds_bytes, hipStream_t st, const 
     return MVFX_OK;
 }
 
+// ---- baked table (placement 6) --------------------------------------------------------------------------------------------
+// An RGBA8 pixel is a pure function of its three colour bytes, so the whole LUT fits a table of 2^24 dwords: 64 MiB, a quarter of the
+// 256 MiB Infinity Cache, nothing beside 288 GB of HBM.  Per pixel: one 4-byte gather instead of six 16-byte LDS reads and 57 f32
+// operations; the interpolating kernels are VALU-bound, this one is bound by the L1 tag rate and by how many table lines
+// a frame's colours touch.
+constexpr uint32_t kBakedSide = 4096; // the all-colours frame: 4096 x 4096 pixels, pixel i holds colour i
+
+__global__ __launch_bounds__(256) void colorlut_all_colours_kernel(uint32_t *frame)
+{
+    const uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    *reinterpret_cast<uint4 *>(frame + i) = make_uint4(i, i + 1, i + 2, i + 3); // alpha byte 0
+}
+
+// PER_LANE 16-byte groups per lane, all loads issued before the first gather (memory-level parallelism for the table misses)
+template <int PER_LANE>
+__global__ __launch_bounds__(256) void colorlut_baked_kernel(FrameBatch in, FrameBatch out, uint64_t vecs_per_row, uint32_t rows, uint64_t is,
+                                                             uint64_t os, const uint32_t *__restrict__ table)
+{
+    const uint8_t *src = in.base[blockIdx.z];
+    uint8_t *dst = out.base[blockIdx.z];
+    const uint64_t x0 = ((uint64_t)blockIdx.x * PER_LANE) * 256u + threadIdx.x;
+    for (uint32_t y = blockIdx.y; y < rows; y += gridDim.y) {
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t *srow = reinterpret_cast<const u32x4_t *>(src + (uint64_t)y * is);
+        u32x4_t *drow = reinterpret_cast<u32x4_t *>(dst + (uint64_t)y * os);
+        u32x4_t v[PER_LANE];
+#pragma unroll
+        for (int k = 0; k < PER_LANE; k++) {
+            const uint64_t x = x0 + (uint64_t)k * 256u;
+            if (x < vecs_per_row) v[k] = __builtin_nontemporal_load(srow + x);
+        }
+#pragma unroll
+        for (int k = 0; k < PER_LANE; k++) {
+            const uint64_t x = x0 + (uint64_t)k * 256u;
+            if (x < vecs_per_row) {
+                u32x4_t o;
+                o.x = table[v[k].x & 0xffffffu] | (v[k].x & 0xff000000u); // alpha byte copied (imp.rs:262, :291)
+                o.y = table[v[k].y & 0xffffffu] | (v[k].y & 0xff000000u);
+                o.z = table[v[k].z & 0xffffffu] | (v[k].z & 0xff000000u);
+                o.w = table[v[k].w & 0xffffffu] | (v[k].w & 0xff000000u);
+                __builtin_nontemporal_store(o, drow + x);
+            }
+        }
+    }
+}
+
+int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *outs, uint32_t n, hipStream_t st, bool baking);
+
+// Builds the table on first use (per LUT and device): all 2^24 colours through the interpolating kernels, then the host waits once.
+int ensure_baked(mvfx_cube_lut *h, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(h->bake_mu);
+    {
+        std::lock_guard<std::mutex> l2(h->mu);
+        if (h->d_baked) return MVFX_OK;
+    }
+    const size_t bytes = (size_t)kBakedSide * kBakedSide * 4;
+    uint32_t *all = nullptr, *table = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&all), bytes) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&table), bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        if (all) (void)hipFree(all);
+        return fail(MVFX_ERR_OUT_OF_MEMORY, "colorlut: no memory for the baked table (2 x 64 MiB)");
+    }
+    hipLaunchKernelGGL(colorlut_all_colours_kernel, dim3(kBakedSide * kBakedSide / 1024), dim3(256), 0, st, all);
+    mvfx_frame fi{}, fo{};
+    fi.data = all; fo.data = table;
+    fi.width = fo.width = kBakedSide; fi.height = fo.height = kBakedSide;
+    fi.stride = fo.stride = kBakedSide * 4;
+    fi.format = fo.format = MVFX_FORMAT_RGBA;
+    int rc = colorlut_impl(h, &fi, &fo, 1, st, true);
+    const hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(all);
+    if (rc == MVFX_OK && e != hipSuccess) rc = fail(MVFX_ERR_DEVICE, "colorlut: building the baked table failed: %s", hipGetErrorString(e));
+    if (rc != MVFX_OK) { (void)hipFree(table); return rc; }
+    std::lock_guard<std::mutex> l2(h->mu);
+    h->d_baked = table;
+    return MVFX_OK;
+}
+
 // n frame pairs sharing geometry and format through one LUT (n == 1: the reference's transform_frame)
-int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *outs, uint32_t n, hipStream_t st)
+int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *outs, uint32_t n, hipStream_t st, bool baking = false)
 {
     if (!h)
         return fail(MVFX_ERR_NO_LUT, "colorlut: No LUT configured (colorlut/imp.rs:209-213)");
@@ -969,7 +1054,7 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
     if (n > (uint32_t)kMaxBatch) { // split into launches of <= kMaxBatch pairs
         for (uint32_t done = 0; done < n; done += kMaxBatch) {
             const uint32_t m = (n - done) < (uint32_t)kMaxBatch ? (n - done) : (uint32_t)kMaxBatch;
-            if (int rc = colorlut_impl(h, ins + done, outs + done, m, st); rc != MVFX_OK) return rc;
+            if (int rc = colorlut_impl(h, ins + done, outs + done, m, st, baking); rc != MVFX_OK) return rc;
         }
         return MVFX_OK;
     }
@@ -1044,6 +1129,20 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
     if (flat) { width = (uint64_t)in->width * in->height; rows = 1; is = os = 0; }
     else align_or |= is | os;
     const bool vec = (align_or & 15) == 0;
+
+    if (!baking && !wide && opt_lut_placement() == 6) {
+        if (!vec || (!flat && (in->width & 3) != 0) || (flat && (width & 3) != 0))
+            return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: the baked table kernel needs 16-byte aligned rows and a width that is a multiple of 4");
+        if (int rc = ensure_baked(h, st); rc != MVFX_OK) return rc;
+        const uint64_t vecs = width / 4;
+        constexpr int kPerLane = 2;
+        const uint64_t bx = (vecs + 256u * kPerLane - 1) / (256u * kPerLane);
+        if (bx > 0x7fffffffull) return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: frame too large");
+        hipLaunchKernelGGL(colorlut_baked_kernel<kPerLane>, dim3((uint32_t)bx, rows < 65535u ? rows : 65535u, n), dim3(256), 0, st, ifb, ofb, vecs, rows,
+                           is, os, h->d_baked);
+        MVFX_HIP_TRY(hipGetLastError());
+        return MVFX_OK;
+    }
 
     const bool fits_lds = l.is_3d ? l.size <= kLds3dMaxSize : l.size <= kLds1dMaxSize;
     bool finite = true;
@@ -1300,6 +1399,7 @@ void mvfx_cube_lut_free(mvfx_cube_lut *lut)
     if (lut->d_rgba) (void)hipFree(lut->d_rgba);
     if (lut->d_cells) (void)hipFree(lut->d_cells);
     if (lut->d_tile_tables) (void)hipFree(lut->d_tile_tables);
+    if (lut->d_baked) (void)hipFree(lut->d_baked);
     for (auto &t : lut->d_table) if (t) (void)hipFree(t);
     delete lut;
 }

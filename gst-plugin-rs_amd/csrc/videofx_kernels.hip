@@ -427,9 +427,11 @@ int colordetect_hist_impl(const mvfx_frame *frames, uint32_t n_frames, uint32_t 
         while (done < unit_end) {
             const uint64_t units = unit_end - done;
             // single frame: 3/4 of a 1024-lane group per CU (each group pays a 64 KiB LDS clear + a 64 KiB partial the second launch
-            // reads back); several frames: ~2 groups per CU in total, few per frame, so the partials stay small beside the pixels
-            uint64_t want_groups = n_frames == 1 ? std::max<uint64_t>((uint64_t)cus * 3 / 4, 1)
-                                                 : std::max<uint64_t>((uint64_t)cus * 2 / n_frames, 8);
+            // reads back); several frames: ~1 group per CU in total, few per frame, so the partials stay small beside the pixels
+            // (16 x 4K per launch pair, 8 / 12 / 16 / 24 / 32 groups per frame: 113.0 / 113.0 / 104.7 / 122.5 / 115.0 us,
+            // profiles/r3/colordetect_groups.txt; an earlier box: 16 / 24 / 32 / 48 / 64: 105.2 / 120.9 / 113.6 / 115.3 / 120.9)
+            const uint64_t want_groups = n_frames == 1 ? std::max<uint64_t>((uint64_t)cus * 3 / 4, 1)
+                                                       : std::max<uint64_t>((uint64_t)cus / n_frames, 8);
             uint64_t per_group = std::max<uint64_t>((units + want_groups - 1) / want_groups, (uint64_t)kHistBlock * 4);
             per_group = std::min<uint64_t>(per_group, cap_units);
             uint64_t groups = (units + per_group - 1) / per_group;

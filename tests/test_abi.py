@@ -89,7 +89,7 @@ def test_argument_validation_needs_no_device(vfx):
     assert lib.mvfx_hsvfilter_transform_frame_ip_host(ctypes.byref(f), ctypes.byref(s)) == vfx.ERR_UNSUPPORTED_FORMAT
     assert lib.mvfx_thread_set_options(0x1000) == vfx.ERR_INVALID_ARGUMENT                       # unknown bit
     assert lib.mvfx_thread_set_options(vfx.OPT_HSV_LITERAL | vfx.OPT_HSV_FORCE_FAST) == vfx.ERR_INVALID_ARGUMENT
-    assert lib.mvfx_thread_set_options(6 << vfx.OPT_LUT_PLACEMENT_SHIFT) == vfx.ERR_INVALID_ARGUMENT  # placement 0..5
+    assert lib.mvfx_thread_set_options(7 << vfx.OPT_LUT_PLACEMENT_SHIFT) == vfx.ERR_INVALID_ARGUMENT  # placement 0..6
     assert lib.mvfx_thread_options() == 0
 
 

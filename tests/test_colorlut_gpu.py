@@ -80,6 +80,52 @@ def test_colorlut_exhaustive_rgba8(gpu, luts, name):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("name", ["analytic33", "domain33", "analytic65", "curve1d_256", "nan_nodes", "nan_domain"])
+def test_colorlut_baked_table(gpu, luts, name):
+    """placement 6: the LUT baked into a table of all 2^24 colours (built on first use by the interpolating kernels) and applied with one
+    gather per pixel.  All 2^24 triples with a non-zero alpha byte, then a batch of padded frames: the oracle's bytes, alpha copied,
+    padding untouched; frames the kernel does not take (unaligned rows) are refused, RGBA64 falls through to the automatic choice."""
+    dev, o = luts[name]
+    L = gpu.lib()
+    gpu.check(L.mvfx_thread_set_options(gpu.options(placement=6).word))
+    try:
+        ex = frames.exhaustive_rgbx()  # byte 3 is a hash of the pixel index: it must come through untouched
+        exp = np.empty_like(ex)
+        assert o.apply(ex, 4096 * 4, exp, 4096 * 4, 4096, 4096, "RGBA") == 0
+        src = gpu.DeviceBuffer(ex.nbytes).upload(ex)
+        dst = gpu.DeviceBuffer(ex.nbytes)
+        dev.apply_device(src.ptr, 4096 * 4, dst.ptr, 4096 * 4, 4096, 4096, "RGBA")
+        gpu.check(L.mvfx_stream_synchronize(None))
+        assert np.array_equal(dst.download().reshape(ex.shape), exp)
+        # a batch of frames with row padding (stride a multiple of 16, width a multiple of 4)
+        n, w, h, stride = 5, 252, 31, 252 * 4 + 16
+        ins = [frames.random_frame(0x5EED0B00 + k, w, h, 4, stride) for k in range(n)]
+        din = [gpu.DeviceBuffer(f.nbytes).upload(f) for f in ins]
+        fill = np.full((h, stride), 0x5A, np.uint8)
+        dout = [gpu.DeviceBuffer(fill.nbytes).upload(fill) for _ in range(n)]
+        fi = (gpu.Frame * n)(*[gpu.make_frame(b.ptr, w, h, stride, "RGBA") for b in din])
+        fo = (gpu.Frame * n)(*[gpu.make_frame(b.ptr, w, h, stride, "RGBA") for b in dout])
+        gpu.check(L.mvfx_colorlut_transform_frames(dev.h, fi, fo, n, None))
+        gpu.check(L.mvfx_stream_synchronize(None))
+        for k in range(n):
+            e = fill.copy()
+            assert o.apply(ins[k], stride, e, stride, w, h, "RGBA") == 0
+            assert np.array_equal(dout[k].download().reshape(h, stride), e), f"frame {k}"
+        # unaligned rows: refused, not silently routed elsewhere
+        odd = (gpu.Frame * 1)(gpu.make_frame(din[0].ptr + 4, 8, 2, stride, "RGBA"))
+        assert L.mvfx_colorlut_transform_frames(dev.h, odd, fo, 1, None) == gpu.ERR_INVALID_ARGUMENT
+        # RGBA64 has no table (2^48 colours): the automatic choice runs
+        w16 = frames.random_frame(0x5EED0B10, 16, 4, 8, 16 * 8)
+        e16 = np.empty_like(w16)
+        assert o.apply(w16, 16 * 8, e16, 16 * 8, 16, 4, "RGBA64_LE") == 0
+        s16, d16 = gpu.DeviceBuffer(w16.nbytes).upload(w16), gpu.DeviceBuffer(w16.nbytes)
+        dev.apply_device(s16.ptr, 16 * 8, d16.ptr, 16 * 8, 16, 4, "RGBA64_LE")
+        gpu.check(L.mvfx_stream_synchronize(None))
+        assert np.array_equal(d16.download().reshape(w16.shape), e16)
+    finally:
+        L.mvfx_thread_set_options(gpu.options(placement=0).word)
+
+
 @pytest.mark.parametrize("name,fmt,w,h,pad", [("analytic33", "RGBA", 256, 33, 0), ("analytic21", "RGBA", 127, 9, 8),
                                                ("curve1d_4096", "RGBA64_LE", 64, 17, 0), ("analytic9", "RGBA64_BE", 33, 5, 16)])
 def test_colorlut_batch_matches_single(gpu, luts, name, fmt, w, h, pad):

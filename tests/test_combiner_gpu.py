@@ -136,3 +136,54 @@ def test_a_lone_stream_is_not_held_back(gpu):
     assert r.returncode == 0, r.stdout[-2000:]
     us = float([ln for ln in r.stdout.splitlines() if ln.startswith("PER_CALL_US")][-1].split()[1])
     assert us < 2000.0, f"{us:.0f} us per call: the lone stream waited for the window"
+
+
+def test_threads_that_come_and_go_recycle_their_streams(gpu):
+    """Sixteen threads per generation, each rotating single-frame hsvfilter launches over its four private streams
+    (mvfx_thread_stream_n) and exiting with work still queued -- GStreamer streaming threads at end-of-stream.  The streams of an
+    exiting thread go back to a per-device pool (destroying them concurrently crashed inside the HIP runtime: capi_common.hip,
+    IdleStreams): later generations get the same handles again, and the bytes are the oracle's."""
+    L = gpu.lib()
+    L.mvfx_thread_stream_n.restype = ctypes.c_void_p
+    L.mvfx_thread_stream_n.argtypes = [ctypes.c_uint32]
+    n_threads, generations, w, h = 16, 6, 640, 360
+    s = SETTINGS[0]
+    host = frames.random_frame(0xC200, w, h)
+    exp = host.copy()
+    assert orc.hsvfilter(exp, w, w * 4, "RGBA", s) == 0
+    seen, errors = [], []
+    for g in range(generations):
+        handles, bufs = {}, {}
+        start = threading.Barrier(n_threads)
+
+        def body(t):
+            try:
+                gpu.check(L.mvfx_set_device(0))
+                st = gpu.HsvFilterSettings(*s)
+                streams = [L.mvfx_thread_stream_n(i) for i in range(4)]
+                assert all(streams) and len(set(streams)) == 4
+                handles[t] = streams
+                mine = [gpu.DeviceBuffer(host.nbytes).upload(host) for _ in range(4)]
+                start.wait()
+                for k in range(4):
+                    f = gpu.make_frame(mine[k].ptr, w, h, w * 4, "RGBA")
+                    gpu.check(L.mvfx_hsvfilter_transform_frame_ip(ctypes.byref(f), ctypes.byref(st), ctypes.c_void_p(streams[k])))
+                bufs[t] = mine  # the thread exits with its launches still in flight
+            except Exception as e:  # noqa: BLE001
+                errors.append((g, t, repr(e)))
+
+        ths = [threading.Thread(target=body, args=(t,)) for t in range(n_threads)]
+        for th_ in ths:
+            th_.start()
+        for th_ in ths:
+            th_.join()
+        assert errors == []
+        for t in range(n_threads):
+            for k in range(4):
+                gpu.check(L.mvfx_stream_synchronize(ctypes.c_void_p(handles[t][k])))
+                assert np.array_equal(bufs[t][k].download().reshape(h, w * 4), exp), f"generation {g} thread {t} stream {k}"
+        seen.append({x for v in handles.values() for x in v})
+    assert all(len(x) == n_threads * 4 for x in seen)
+    # generation 0 may draw on streams that threads of earlier tests left in the pool; from then on nothing new is created
+    # (without the pool: 6 x 64 distinct handles)
+    assert len(set().union(*seen)) <= 2 * n_threads * 4, "later generations of threads did not get pooled streams back"

@@ -131,6 +131,35 @@ def main():
         ms = timeit(lambda i=0: vfx.check(lib.mvfx_hsvdetector_transform_frames(fia, foa, POOL, ctypes.byref(s), sptr)), iters=60)
         report(f"hsvdetector RGBx->RGBA 4K batch{POOL} (one launch)", ms, 2 * NB * POOL, POOL)
 
+    if want("baked"):
+        # placement 6 (the LUT baked into a 64 MiB table of all 2^24 colours, one gather per pixel) against the automatic choice
+        # (the interpolating tile kernel), same frames, single-frame launches and 16 frames per launch
+        lut = vfx.CubeLut(cubes.analytic_3d(33))
+        for data in ("natural", "smpte", "random"):
+            src = rand_frames(POOL, NB, 5) if data == "random" else (smpte_like_gpu(POOL, W, H) if data == "smpte" else natural_like_gpu(POOL, W, H, 11))
+            dst = torch.empty_like(src)
+            fi = (vfx.Frame * POOL)(*[vfx.make_frame(src[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)])
+            fo = (vfx.Frame * POOL)(*[vfx.make_frame(dst[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)])
+            for placement in (0, 6):
+                vfx.check(lib.mvfx_thread_set_options(vfx.options(placement=placement).word))
+                what = {0: "auto (tile kernel)", 6: "baked table"}[placement]
+                ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fi[i % POOL]), ctypes.byref(fo[i % POOL]), sptr)), iters=300)
+                report(f"colorlut 3D 33^3 RGBA 4K {data} placement={what}", ms, 2 * NB, 1)
+                ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frames(lut.h, fi, fo, POOL, sptr)), iters=40 if data != "random" else 10)
+                report(f"colorlut 3D 33^3 RGBA 4K {data} batch{POOL} (one launch) placement={what}", ms, 2 * NB * POOL, POOL)
+            vfx.check(lib.mvfx_thread_set_options(vfx.options(placement=0).word))
+        import time as _t
+        for size in (33, 65):
+            l2 = vfx.CubeLut(cubes.analytic_3d(size))
+            vfx.check(lib.mvfx_thread_set_options(vfx.options(placement=6).word))
+            torch.cuda.synchronize()
+            t0 = _t.perf_counter()
+            vfx.check(lib.mvfx_colorlut_transform_frame(l2.h, ctypes.byref(fi[0]), ctypes.byref(fo[0]), sptr))
+            torch.cuda.synchronize()
+            print(json.dumps({"kernel": f"colorlut baked table: first call with a new {size}^3 LUT (upload + bake 2^24 colours + one 4K frame)",
+                              "ms": round((_t.perf_counter() - t0) * 1e3, 3)}), flush=True)
+            vfx.check(lib.mvfx_thread_set_options(vfx.options(placement=0).word))
+
     if want("colorlut"):
         for size in (33, 65, 17, 9):
             lut = vfx.CubeLut(cubes.analytic_3d(size))
