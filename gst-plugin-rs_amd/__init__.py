@@ -53,8 +53,8 @@ OPT_SSIM_F64 = 0x80
 class options:
     """``with vfx.options(variant=1, typed=False): ...`` -- sets the calling thread's kernel options
     (mvfx_thread_set_options) for the block and restores the previous word.  variant: 0 auto, 1 literal,
-    2 force strength-reduced; placement: colorlut LUT placement 0..5 (include/mi355vfx.h: 0 auto, 1 node layout in global/L2,
-    2 LDS, 3 cell-packed global, 4 literal kernels, 5 tile kernel)."""
+    2 force strength-reduced; placement: colorlut LUT placement 0..6 (include/mi355vfx.h: 0 auto, 1 node layout in global/L2,
+    2 LDS, 3 cell-packed global, 4 literal kernels, 5 tile kernel, 6 baked table of all 2^24 colours)."""
 
     def __init__(self, variant=0, nontemporal=False, typed=True, placement=0, ssim_f64=False):
         self.word = ((OPT_SSIM_F64 if ssim_f64 else 0) | (OPT_NONTEMPORAL if nontemporal else 0) | (OPT_HSV_LITERAL if variant == 1 else 0) |

@@ -146,7 +146,8 @@ int mvfx_copy_device_to_device_async(void *dst_device, const void *src_device, s
                                           conversion, exact for all 256 byte values: tools/probe_unorm.hip) */
 #define MVFX_OPT_LUT_PLACEMENT_SHIFT 4 /* colorlut LUT placement: 0 auto | 1 node layout in global/L2 | 2 LDS |         */
 #define MVFX_OPT_LUT_PLACEMENT_MASK 0x70u /* 3 cell-packed global | 4 literal kernels | 5 tile kernel (wave-local LUT     */
-                                          /* window in LDS, the automatic choice for 3-D cubes); (placement << SHIFT) & MASK */
+                                          /* window in LDS, the automatic choice for 3-D cubes) | 6 baked table (RGBA8 only); */
+                                          /* (placement << SHIFT) & MASK */
 #define MVFX_OPT_SSIM_F64 0x80u        /* hash-algo=dssim: f64 planes and window sums (round 2's pipeline, within 1e-9 of the f64
                                           checker) instead of the default f32 pipeline (what dssim-core computes in) */
 int mvfx_thread_set_options(uint32_t options);
@@ -281,7 +282,12 @@ int mvfx_colorlut_transform_frame_host(mvfx_cube_lut *lut, const mvfx_frame *in_
  * 4 = the literal-transcription kernels (also used automatically when the LUT's domain
  * scale/offset are not finite), 5 = the tile kernel: a wave owns a compact block of pixels and keeps the 3x3x3 LUT cells
  * around the colour of the block's centre pixel in wave-private LDS (MVFX_ERR_INVALID_ARGUMENT when the frame or cube does
- * not allow it). */
+ * not allow it), 6 = RGBA8 frames only (other formats take the automatic choice): the LUT baked into a table of all 2^24
+ * colours (64 MiB of device memory per LUT, built on the first call by running the interpolating kernels over a frame that
+ * holds every colour -- ~5 ms, the host waits once) and applied with one 4-byte gather per pixel; needs 16-byte aligned rows
+ * and a width that is a multiple of 4 (MVFX_ERR_INVALID_ARGUMENT otherwise).  Faster than the tile kernel on flat content
+ * (bars, animation: 0.69 against 0.47 of the HBM peak), slower on noisy content (0.29 against 0.51) -- never chosen
+ * automatically (profiles/r3/colorlut_baked_table.txt). */
 
 /* Writes the LUT as Adobe .cube text: LUT_1D_SIZE / LUT_3D_SIZE, DOMAIN_MIN / DOMAIN_MAX when they are not
  * 0 / 1, then the rows, floats with 9 significant digits -- mvfx_cube_lut_parse of the text yields the same LUT bit for

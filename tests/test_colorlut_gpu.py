@@ -112,8 +112,9 @@ def test_colorlut_baked_table(gpu, luts, name):
             assert o.apply(ins[k], stride, e, stride, w, h, "RGBA") == 0
             assert np.array_equal(dout[k].download().reshape(h, stride), e), f"frame {k}"
         # unaligned rows: refused, not silently routed elsewhere
-        odd = (gpu.Frame * 1)(gpu.make_frame(din[0].ptr + 4, 8, 2, stride, "RGBA"))
-        assert L.mvfx_colorlut_transform_frames(dev.h, odd, fo, 1, None) == gpu.ERR_INVALID_ARGUMENT
+        odd_in = (gpu.Frame * 1)(gpu.make_frame(din[0].ptr + 4, 8, 2, stride, "RGBA"))
+        odd_out = (gpu.Frame * 1)(gpu.make_frame(dout[0].ptr, 8, 2, stride, "RGBA"))
+        assert L.mvfx_colorlut_transform_frames(dev.h, odd_in, odd_out, 1, None) == gpu.ERR_INVALID_ARGUMENT
         # RGBA64 has no table (2^48 colours): the automatic choice runs
         w16 = frames.random_frame(0x5EED0B10, 16, 4, 8, 16 * 8)
         e16 = np.empty_like(w16)
