@@ -131,16 +131,26 @@ class Worker:
         if not torch.cuda.is_available():
             sys.stderr.write("bench.py: no GPU visible; the HIP path has no CPU fallback\n")
             sys.exit(3)
-        torch.cuda.set_device(self.local_rank)
-        self.dev = torch.device("cuda", self.local_rank)
+        # MVFX_BENCH_TEST_SHARED_GPU=1 (tests/test_distributed_gpu.py only): every rank on GPU local_rank % device_count and the
+        # rendezvous over gloo, so that the N > 1 control flow of this file runs on the one-GPU box (RCCL refuses two ranks on one GPU;
+        # the line then says backend "gloo" and is not a measurement)
+        shared = os.environ.get("MVFX_BENCH_TEST_SHARED_GPU") == "1"
+        self.backend = "gloo" if shared else "nccl"
+        self.device_index = self.local_rank % max(torch.cuda.device_count(), 1) if shared else self.local_rank
+        torch.cuda.set_device(self.device_index)
+        self.dev = torch.device("cuda", self.device_index)
+        self.coll_dev = torch.device("cpu") if shared else self.dev  # where the small tensors of the timing collectives live
         self.rccl_ranks = 1
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="nccl", device_id=self.dev)  # "nccl" IS RCCL on ROCm
-            one = torch.ones(1, dtype=torch.int32, device=self.dev)
+            if shared:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=self.dev)  # "nccl" IS RCCL on ROCm
+            one = torch.ones(1, dtype=torch.int32, device=self.coll_dev)
             dist.all_reduce(one)  # an actual collective: how many ranks RCCL sees
             self.rccl_ranks = int(one[0])
-        self.vfx.check(self.lib.mvfx_set_device(self.local_rank))
+        self.vfx.check(self.lib.mvfx_set_device(self.device_index))
         self.stream = torch.cuda.current_stream(self.dev)
         self.sptr = ctypes.c_void_p(self.stream.cuda_stream)
 
@@ -154,14 +164,14 @@ class Worker:
     def max_over_ranks(self, *vals):
         if self.world == 1:
             return vals
-        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self.dev)
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self.coll_dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return tuple(float(x) for x in t)
 
     def gather(self, val):
         if self.world == 1:
             return [val]
-        t = self.torch.tensor([val], dtype=self.torch.float64, device=self.dev)
+        t = self.torch.tensor([val], dtype=self.torch.float64, device=self.coll_dev)
         out = [self.torch.zeros_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t)
         return [float(x[0]) for x in out]
@@ -642,7 +652,7 @@ def make_leg_colorlut(w, args, content):
         secs, per = (ctypes.c_double * reps)(), (ctypes.c_double * nthr)()
         w.sync()
         w.barrier()
-        rc = hb.mvfxbench_colorlut_streams(w.local_rank, nthr, 200, launches, reps, lut.h, fin, fout, fpt, 0, secs, per)
+        rc = hb.mvfxbench_colorlut_streams(w.device_index, nthr, 200, launches, reps, lut.h, fin, fout, fpt, 0, secs, per)
         if rc != 0:
             raise RuntimeError(f"mvfxbench status {rc}: {vfx.last_error()}")
         w.barrier()
@@ -1049,7 +1059,7 @@ def hsvfilter_main(args):
             per = (ctypes.c_double * nthr)()
             w.sync()
             w.barrier()
-            rc = hb.mvfxbench_hsvfilter_streams_warm(w.local_rank, nthr, stream_warmup, launches, reps, flat, fpt, batch_arg, warm, wfpt,
+            rc = hb.mvfxbench_hsvfilter_streams_warm(w.device_index, nthr, stream_warmup, launches, reps, flat, fpt, batch_arg, warm, wfpt,
                                                      ctypes.byref(settings), opts, secs, per)
             if rc != 0:
                 raise RuntimeError(f"mvfxbench status {rc}: {vfx.last_error()}")
@@ -1067,18 +1077,18 @@ def hsvfilter_main(args):
                                  "no sync between launches; warm-up on scratch frames)")
         # the launch combiner: the same threads make the same single-frame calls, the library coalesces them into batched launches
         nb, nf = ctypes.c_uint64(), ctypes.c_uint64()
-        lib.mvfx_combiner_stats(w.local_rank, ctypes.byref(nb), ctypes.byref(nf))
+        lib.mvfx_combiner_stats(w.device_index, ctypes.byref(nb), ctypes.byref(nf))
         combined = threads_leg(0, f"{nthr} threads x 1 frame through the launch combiner (mvfx_hsvfilter_transform_frame_ip_combined: one call "
                                   "per buffer, frames of all threads coalesced into batched launches by the library)")
         nb2, nf2 = ctypes.c_uint64(), ctypes.c_uint64()
-        lib.mvfx_combiner_stats(w.local_rank, ctypes.byref(nb2), ctypes.byref(nf2))
+        lib.mvfx_combiner_stats(w.device_index, ctypes.byref(nb2), ctypes.byref(nf2))
         combined["frames_per_combined_launch"] = (nf2.value - nf.value) / max(nb2.value - nb.value, 1)
         # ... and its fenced entry (what the element uses with MVFX_COMBINE=2): no caller streams, the frames' fences in and out, all
         # combined launches on one library-owned stream
         fenced = threads_leg(0xFFFFFFFF, f"{nthr} threads x 1 frame through the launch combiner's fenced entry (mvfx_hsvfilter_transform_frame_ip_fenced: one "
                                           "call per buffer, the buffer's fence in and out, batched launches on one library-owned stream)")
         nb3, nf3 = ctypes.c_uint64(), ctypes.c_uint64()
-        lib.mvfx_combiner_stats(w.local_rank, ctypes.byref(nb3), ctypes.byref(nf3))
+        lib.mvfx_combiner_stats(w.device_index, ctypes.byref(nb3), ctypes.byref(nf3))
         fenced["frames_per_combined_launch"] = (nf3.value - nf2.value) / max(nb3.value - nb2.value, 1)
         combined["fenced_entry"] = fenced
 
@@ -1130,7 +1140,8 @@ def hsvfilter_main(args):
                    "frames_per_step_per_gpu": args.batch, "resident_batches": pool, "steps_executed": n_launches[0],
                    "settle_seconds_before_warmup": args.settle_seconds, "settle_steps": settle_steps,
                    "parallelism": f"{world} independent stream shards, no data-path collective",
-                   "rccl_ranks": w.rccl_ranks, "per_rank_frames_per_sec": head["per_rank_frames_per_sec"],
+                   "rccl_ranks": w.rccl_ranks, "rendezvous_backend": w.backend if world > 1 else None,
+                   "per_rank_frames_per_sec": head["per_rank_frames_per_sec"],
                    "kernel_variant": {0: "auto", 1: "literal", 2: "strength-reduced"}[args.variant],
                    "cache_policy": "non-temporal (MVFX_OPT_NONTEMPORAL)" if args.streaming else "default",
                    "u8_to_unit_float": "typed buffer loads (texture-unit UNORM8, exact)" if args.typed_loads else "VALU (cvt + mul + fmac)"},
@@ -1165,8 +1176,8 @@ def hsvfilter_main(args):
 
         def side_leg():
             try:
-                torch.cuda.set_device(w.local_rank)
-                vfx.check(lib.mvfx_set_device(w.local_rank))
+                torch.cuda.set_device(w.device_index)
+                vfx.check(lib.mvfx_set_device(w.device_index))
                 box["r"] = videocompare_sharded_leg(w, args, "blockhash", 200, 20)
             except Exception as e:  # noqa: BLE001
                 box["r"] = {"error": f"{type(e).__name__}: {e}"}

@@ -35,6 +35,8 @@ struct mvfx_cube_lut {
     int device = -1;       // device the copies below live on
     float *d_rgba = nullptr;
     uint32_t *d_tile_tables = nullptr; // tile kernel: 3 x 256 x (cell index, fraction) per byte value + 192 neighbourhood piece offsets
+    uint32_t *d_xcoord = nullptr; // colorlut_xtile_kernel: per byte value of g and b {cell index x LDS row pitch, fraction bits}
+    float *d_xtable = nullptr; // x-prelerped table of colorlut_xtile_kernel: [y][z][r byte] x (X.rgb, D.rgb) f32 = 24 B (3-D, 4 <= size <= kCellMaxSize)
     float *d_cells = nullptr; // cell-packed copy: size^3 cells x 8 corners x (r,g,b) f32 = 96 B (3-D, size <= kCellMaxSize)
     float *d_table[3] = {nullptr, nullptr, nullptr};
     // baked table (placement 6): the LUT applied to every one of the 2^24 RGB byte triples, 64 MiB, entry = output R | G << 8 | B << 16
@@ -69,6 +71,8 @@ struct LutParams {
     LutFast fast;
     const float4 *cells;  // 3-D cell-packed copy (8 corners per cell) or nullptr
     const uint32_t *tile_tables; // colorlut_tile_kernel: coordinate tables + neighbourhood piece offsets
+    const float4 *xtable; // colorlut_xtile_kernel: the x-prelerped table, addressed in 16-byte pieces (or nullptr)
+    const uint2 *xcoord;  // colorlut_xtile_kernel: 512 x {cell index x row pitch, fraction bits} (g, then b)
     const float4 *cube;   // 3-D nodes
     const float *t[3];    // 1-D tables
     uint32_t size;
@@ -580,6 +584,9 @@ constexpr int kTileNbPieces = kTileNbCells * 6;        // 16-byte pieces
 #define MVFX_TILE_CELL_PITCH 7
 #endif
 constexpr int kTileCellPitch = MVFX_TILE_CELL_PITCH;
+#ifndef MVFX_XTILE_RW
+#define MVFX_XTILE_RW 24 // r bytes per window row of colorlut_xtile_kernel
+#endif
 constexpr int kTileWaveLdsFloat4 = kTileNbCells * kTileCellPitch + 2;  // +32 bytes: de-phases the four waves' regions over the banks
 
 // The lattice coordinate of a channel depends on its byte value only: (cell index, fraction) come from a 3 x 256 entry
@@ -764,6 +771,163 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
     }
 }
 
+// ---------------------------------------------------------------- the x-prelerped tile kernel (round 3)
+//
+// An RGBA8 pixel's r byte fixes (x0, tx), so the four x-lerps of sample_3d (imp.rs:515-518) depend on (r byte, y node, z node) only:
+//   X[y][z][r] = c(x0,y,z) + (c(x1,y,z) - c(x0,y,z)) * tx          (the reference's own three roundings, done once per LUT)
+// and the difference the y-lerp subtracts, D[y][z][r] = RN(X[min(y+1,max)][z][r] - X[y][z][r]), is fixed with it.  Per pixel that
+// leaves  c0 = X[y0][z0][r] + D[y0][z0][r] * ty,  c1 = X[y0][z1][r] + D[y0][z1][r] * ty,  out = c0 + (c1 - c0) * tz -- 21 f32
+// operations instead of 51, two 24-byte LDS reads instead of six 16-byte ones, same bits (every operation that remains is one the
+// reference performs, on the same operands).  Table: [y][z][r] with z running to size inclusive -- row `size` repeats row size - 1,
+// which is what z1 = min(z0 + 1, max) selects there, so the second entry is ALWAYS the next z row -- 256 x size x (size + 1) entries
+// of 24 bytes (33^3: 6.9 MB), built on the device by colorlut_xtable_build_kernel from the node layout and the r channel's
+// coordinate table.
+// A wave owns a 64 x 16 block of pixels (as colorlut_tile_kernel) and keeps in wave-private LDS the entries of RW consecutive r
+// bytes x 3 y cells x 4 z rows around the block's centre pixel: 12 rows of RW x 24 contiguous bytes; pixels outside the window read
+// their two entries from the table in global memory.  The per-byte coordinate entries of g and b hold the cell index already
+// multiplied by the window's LDS pitch of that axis, so the in-window test and the LDS address are three subtractions, three
+// compares, one add3 and one mad.
+constexpr uint32_t kXRows = 12;          // 3 y cells x 4 z rows
+constexpr uint32_t kXRowPieces = 384;    // 16-byte pieces per (y, z) row of the table: 256 entries x 24 B
+constexpr uint32_t kXPitchZ = MVFX_XTILE_RW * 24, kXPitchY = 4 * kXPitchZ; // LDS bytes between z rows / y cells of a window
+
+__global__ __launch_bounds__(256) void colorlut_xtable_build_kernel(const float4 *__restrict__ cube, const uint32_t *__restrict__ tile_tables,
+                                                                    uint32_t size, float *__restrict__ xtable)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x; // = (y * (size + 1) + zrow) * 256 + r
+    if (i >= size * (size + 1) * 256u) return;
+    const uint32_t r = i & 255u, yz = i >> 8, zrow = yz % (size + 1), y = yz / (size + 1), m = size - 1, s2 = size * size;
+    const uint32_t z = min(zrow, m);
+    const uint32_t x0 = tile_tables[2 * r], x1 = min(x0 + 1, m), y1 = min(y + 1, m);
+    const float tx = __uint_as_float(tile_tables[2 * r + 1]);
+    const float4 a0 = cube[x0 + y * size + z * s2], b0 = cube[x1 + y * size + z * s2];
+    const float4 a1 = cube[x0 + y1 * size + z * s2], b1 = cube[x1 + y1 * size + z * s2];
+    const float X0[3] = {lf_lerp(a0.x, b0.x, tx), lf_lerp(a0.y, b0.y, tx), lf_lerp(a0.z, b0.z, tx)};
+    const float X1[3] = {lf_lerp(a1.x, b1.x, tx), lf_lerp(a1.y, b1.y, tx), lf_lerp(a1.z, b1.z, tx)};
+    float *e = xtable + (uint64_t)i * 6;
+    e[0] = X0[0]; e[1] = X0[1]; e[2] = X0[2];
+    e[3] = X1[0] - X0[0]; e[4] = X1[1] - X0[1]; e[5] = X1[2] - X0[2];
+}
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) f32x2_t *lds_float2_t;
+
+template <int RW>
+__global__ __launch_bounds__(kBlock) void colorlut_xtile_kernel(FrameBatch in_fb, FrameBatch out_fb, uint32_t width, uint32_t height,
+                                                                uint32_t in_stride, uint32_t out_stride, LutParams p)
+{
+    static_assert(RW % 2 == 0 && RW <= 64, "window rows start and end on 16-byte pieces");
+    static_assert(RW * 24 == kXPitchZ, "the coordinate table is built for this window width");
+    constexpr uint32_t kAcross = 16, kRows = 4, kTileW = 64, kTileH = 16;
+    constexpr uint32_t kRowP = RW * 3 / 2;            // 16-byte pieces per window row
+    constexpr uint32_t kPieces = kXRows * kRowP;      // per wave
+    constexpr uint32_t kWaveBytes = kPieces * 16 + 32; // +32 bytes: de-phases the four waves' regions over the banks
+    __shared__ __attribute__((aligned(16))) uint8_t win[(kBlock / 64) * kWaveBytes];
+    __shared__ uint2 coord[512]; // {cell index x LDS pitch, fraction bits} per byte value of the g and b channels
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint8_t *in = in_fb.base[blockIdx.z];
+    uint8_t *out = out_fb.base[blockIdx.z];
+    const uint32_t bx = (blockIdx.x * (kBlock / 64) + wave) * kTileW, by = blockIdx.y * kTileH; // the wave's block
+    const uint32_t x = bx + (lane % kAcross) * 4, y0 = by + (lane / kAcross) * kRows;
+    // 1. every pixel of the lane, up front (four 16-byte loads in flight while the window is being fetched)
+    uint4 v[kRows];
+#pragma unroll
+    for (uint32_t row = 0; row < kRows; row++) {
+        v[row] = make_uint4(0, 0, 0, 0);
+        if (x < width && y0 + row < height) v[row] = *reinterpret_cast<const uint4 *>(in + ((y0 + row) * in_stride + x * 4));
+    }
+    // 2. the window, anchored at the block's centre pixel (its top-left pixel when the centre lies outside the frame): the pixel and
+    // its two coordinate entries come through the scalar cache, so this chain does not wait for the vector loads above
+    uint32_t ar, ayp, azp; // anchor: first r byte, y cell x kXPitchY, z row x kXPitchZ
+    {
+        // (a wave of the last workgroup of a row may lie wholly right of the frame: it reads pixel (0, 0) and stores nothing)
+        const uint32_t cxp = bx + kTileW / 2 < width ? bx + kTileW / 2 : bx, cyp = by + kTileH / 2 < height ? by + kTileH / 2 : by;
+        const uint32_t coff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(bx < width ? cyp * in_stride + cxp * 4 : 0u));
+        const uint32_t cpx = *reinterpret_cast<const uint32_t *>(in + coff);
+        const uint32_t cr = cpx & 0xffu;
+        const uint32_t cy = p.tile_tables[2 * (256 + ((cpx >> 8) & 0xffu))], cz = p.tile_tables[2 * (512 + ((cpx >> 16) & 0xffu))];
+        ar = min((cr > RW / 2 ? cr - RW / 2 : 0u) & ~1u, 256u - RW); // even: a window row starts on a 16-byte piece
+        const uint32_t ay = min(cy > 0 ? cy - 1 : 0u, p.size - 3), az = min(cz > 0 ? cz - 1 : 0u, p.size - 3); // z rows run 0 .. size
+        ayp = ay * kXPitchY;
+        azp = az * kXPitchZ;
+        const uint32_t base = (ay * (p.size + 1) + az) * kXRowPieces + ar * 3 / 2; // wave-uniform
+        // global -> LDS directly (global_load_lds_dwordx4: LDS address = wave-uniform base + lane x 16, which is exactly the window's
+        // piece order): no staging registers, no ds_write pass
+        typedef __attribute__((address_space(3))) void *lds_void_t;
+        typedef const __attribute__((address_space(1))) void *global_void_t;
+#pragma unroll
+        for (uint32_t q0 = 0; q0 < kPieces; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            if (q0 + 64 <= kPieces || q < kPieces) {
+                const uint32_t wr = q / kRowP, k = q - wr * kRowP; // window row = dy * 4 + dz
+                __builtin_amdgcn_global_load_lds((global_void_t)(p.xtable + (base + ((wr >> 2) * (p.size + 1) + (wr & 3u)) * kXRowPieces + k)),
+                                                 (lds_void_t)(win + wave * kWaveBytes + q0 * 16), 16, 0, 0);
+            }
+        }
+    }
+    coord[threadIdx.x] = p.xcoord[threadIdx.x];
+    coord[kBlock + threadIdx.x] = p.xcoord[kBlock + threadIdx.x];
+    __syncthreads(); // coordinate table and (a fortiori) this wave's window complete
+    // LDS byte address of entry (y cell, z row, r) = yp + zp + 24 r + lds_k, with the anchor folded into the wave-uniform lds_k
+    const uint32_t lds_k = wave * kWaveBytes - ayp - azp - ar * 24u, ar24 = ar * 24u, wave_lds = wave * kWaveBytes;
+#pragma unroll
+    for (uint32_t row = 0; row < kRows; row++) {
+        const uint32_t y = y0 + row;
+        const bool valid = x < width && y < height; // width % 4 == 0 (launcher)
+        uint32_t px[4] = {v[row].x, v[row].y, v[row].z, v[row].w};
+        // the four pixels' entries from the window; a pixel outside it reads the window's first entry and is patched below (one
+        // branch per four pixels instead of one per pixel: the scalar side of an if / else costs about five instructions)
+        f32x2_t e0[4][3], e1[4][3];
+        float ty[4], tz[4];
+        uint32_t gy[4], gz[4];
+        bool miss[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint2 eg = coord[(px[j] >> 8) & 0xffu], eb = coord[256 + ((px[j] >> 16) & 0xffu)];
+            ty[j] = __uint_as_float(eg.y);
+            tz[j] = __uint_as_float(eb.y);
+            gy[j] = eg.x;
+            gz[j] = eb.x;
+            uint32_t r24;
+            asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r24) : "v"(px[j]), "v"(24u));
+            const uint32_t dr24 = r24 - ar24, dyp = eg.x - ayp, dzp = eb.x - azp; // unsigned: below the anchor wraps to a huge value
+            // (bitwise |: with || the compiler turns the second and third test into branches behind the LDS wait)
+            miss[j] = (dr24 >= (uint32_t)RW * 24u) | (dyp >= 3u * kXPitchY) | (dzp >= 3u * kXPitchZ);
+            const uint32_t off = miss[j] ? wave_lds : eg.x + eb.x + (r24 + lds_k);
+            const lds_float2_t q0 = (lds_float2_t)((lds_bytes_t)&win[0] + off), q1 = (lds_float2_t)((lds_bytes_t)&win[0] + off + kXPitchZ);
+            e0[j][0] = q0[0]; e0[j][1] = q0[1]; e0[j][2] = q0[2];
+            e1[j][0] = q1[0]; e1[j][1] = q1[1]; e1[j][2] = q1[2];
+        }
+        if (miss[0] | miss[1] | miss[2] | miss[3]) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (miss[j]) {
+                    const uint32_t iy = gy[j] / kXPitchY, iz = gz[j] / kXPitchZ, r = px[j] & 0xffu;
+                    const f32x2_t *g0 = reinterpret_cast<const f32x2_t *>(p.xtable) + (uint64_t)((iy * (p.size + 1) + iz) * 256u + r) * 3, *g1 = g0 + 256 * 3;
+                    e0[j][0] = g0[0]; e0[j][1] = g0[1]; e0[j][2] = g0[2];
+                    e1[j][0] = g1[0]; e1[j][1] = g1[1]; e1[j][2] = g1[2];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // entry = (X.r, X.g) (X.b, D.r) (D.g, D.b)
+            const float c0r = e0[j][0].x + e0[j][1].y * ty[j], c0g = e0[j][0].y + e0[j][2].x * ty[j], c0b = e0[j][1].x + e0[j][2].y * ty[j];
+            const float c1r = e1[j][0].x + e1[j][1].y * ty[j], c1g = e1[j][0].y + e1[j][2].x * ty[j], c1b = e1[j][1].x + e1[j][2].y * ty[j];
+            const float rr = lf_add_clamp(c0r, (c1r - c0r) * tz[j]), gg = lf_add_clamp(c0g, (c1g - c0g) * tz[j]),
+                        bb = lf_add_clamp(c0b, (c1b - c0b) * tz[j]);
+            const float yr = rr * p.fast.out_scale + p.fast.pred_half, yg = gg * p.fast.out_scale + p.fast.pred_half,
+                        yb = bb * p.fast.out_scale + p.fast.pred_half;
+            uint32_t w = px[j];
+            asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yr));
+            asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yg));
+            asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
+            px[j] = w;
+        }
+        if (valid) *reinterpret_cast<uint4 *>(out + (y * out_stride + x * 4)) = make_uint4(px[0], px[1], px[2], px[3]);
+    }
+}
+
 // ---------------------------------------------------------------- colorlut on I420 frames, fused
 //
 // `videoconvert ! colorlut ! videoconvert` of the reference's example pipeline (colorlut/imp.rs:17-19) in ONE kernel:
@@ -883,6 +1047,8 @@ int ensure_uploaded(mvfx_cube_lut *h)
     // (re)upload for this device
     if (h->d_rgba) { (void)hipFree(h->d_rgba); h->d_rgba = nullptr; }
     if (h->d_cells) { (void)hipFree(h->d_cells); h->d_cells = nullptr; }
+    if (h->d_xtable) { (void)hipFree(h->d_xtable); h->d_xtable = nullptr; }
+    if (h->d_xcoord) { (void)hipFree(h->d_xcoord); h->d_xcoord = nullptr; }
     if (h->d_tile_tables) { (void)hipFree(h->d_tile_tables); h->d_tile_tables = nullptr; }
     if (h->d_baked) { (void)hipFree(h->d_baked); h->d_baked = nullptr; }
     for (auto &t : h->d_table) if (t) { (void)hipFree(t); t = nullptr; }
@@ -935,6 +1101,21 @@ int ensure_uploaded(mvfx_cube_lut *h)
                 }
                 MVFX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_tile_tables), tt.size() * sizeof(uint32_t)));
                 MVFX_HIP_TRY(hipMemcpy(h->d_tile_tables, tt.data(), tt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                if (l.size >= 4) { // the x-prelerped table of colorlut_xtile_kernel, computed on the device from the two copies above
+                    const size_t entries = (size_t)l.size * (l.size + 1) * 256;
+                    MVFX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_xtable), entries * 6 * sizeof(float)));
+                    hipLaunchKernelGGL(colorlut_xtable_build_kernel, dim3((uint32_t)((entries + 255) / 256)), dim3(256), 0, nullptr,
+                                       reinterpret_cast<const float4 *>(h->d_rgba), h->d_tile_tables, l.size, h->d_xtable);
+                    MVFX_HIP_TRY(hipGetLastError());
+                    std::vector<uint32_t> xc(512 * 2);
+                    for (int b = 0; b < 256; b++) {
+                        xc[2 * b] = tt[(256 + b) * 2] * kXPitchY;          xc[2 * b + 1] = tt[(256 + b) * 2 + 1];
+                        xc[2 * (256 + b)] = tt[(512 + b) * 2] * kXPitchZ;  xc[2 * (256 + b) + 1] = tt[(512 + b) * 2 + 1];
+                    }
+                    MVFX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_xcoord), xc.size() * sizeof(uint32_t)));
+                    MVFX_HIP_TRY(hipMemcpy(h->d_xcoord, xc.data(), xc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                    MVFX_HIP_TRY(hipStreamSynchronize(nullptr));
+                }
             }
         }
     } else {
@@ -1181,6 +1362,8 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
     const size_t lds_bytes = l.is_3d ? (size_t)l.size * l.size * l.size * 16 : (size_t)l.size * 12;
     p.cells = reinterpret_cast<const float4 *>(h->d_cells);
     p.tile_tables = h->d_tile_tables;
+    p.xtable = reinterpret_cast<const float4 *>(h->d_xtable);
+    p.xcoord = reinterpret_cast<const uint2 *>(h->d_xcoord);
     p.fast.c_hi = wide ? 1.0f / 65535.0f : 1.0f / 255.0f;
     p.fast.c_lo = (float)((wide ? 1.0 / 65535.0 : 1.0 / 255.0) - (double)p.fast.c_hi);
     p.fast.out_scale = wide ? 65535.0f : 255.0f;
@@ -1219,6 +1402,14 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
         //   64 x 16 (16 x 4, 4 rows)            61.6 k      22.5     24.3     39.4     34.2
         //   32 x 16 (8 x 8, 2 rows)             57.0 k      21.5     28.1     37.8     32.4
         //   64 x 32 (16 x 4, 8 rows) 60.2 k / 31.0 us;  32 x 32 59.1 k / 23.9;  64 x 8 56.3 k / 22.4;  32 x 64 47.4 k / 34.3
+        // RGBA8 on cubes of 4+ points: the x-prelerped kernel (placement 5 keeps the kernel below for A/B runs)
+        if (!wide && h->d_xtable && opt_lut_placement() != 5) {
+            const uint32_t tx_ = (in->width + 63) / 64, ty_ = (in->height + 15) / 16;
+            const dim3 xgrid((tx_ + kBlock / 64 - 1) / (kBlock / 64), ty_, n);
+            hipLaunchKernelGGL(colorlut_xtile_kernel<MVFX_XTILE_RW>, xgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p);
+            MVFX_HIP_TRY(hipGetLastError());
+            return MVFX_OK;
+        }
         const bool wide_block = !wide && l.size < 49;
         const uint32_t tile_w = wide_block ? 64 : 32, tile_h = 16;
         const uint32_t tiles_x = (in->width + tile_w - 1) / tile_w, tiles_y = (in->height + tile_h - 1) / tile_h;
@@ -1398,6 +1589,8 @@ void mvfx_cube_lut_free(mvfx_cube_lut *lut)
     if (!lut) return;
     if (lut->d_rgba) (void)hipFree(lut->d_rgba);
     if (lut->d_cells) (void)hipFree(lut->d_cells);
+    if (lut->d_xtable) (void)hipFree(lut->d_xtable);
+    if (lut->d_xcoord) (void)hipFree(lut->d_xcoord);
     if (lut->d_tile_tables) (void)hipFree(lut->d_tile_tables);
     if (lut->d_baked) (void)hipFree(lut->d_baked);
     for (auto &t : lut->d_table) if (t) (void)hipFree(t);

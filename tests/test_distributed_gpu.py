@@ -123,3 +123,35 @@ def test_world2_ssim_and_colordetect(world2_results):
         assert r["ssim"] == pytest.approx(want, rel=1e-5, abs=2e-9)  # the default f32 pipeline
         assert r["palette"] == [int(x) for x in want_pal]
     assert world2_results[0]["ssim"] == world2_results[1]["ssim"]      # every rank derives the same value
+
+
+def test_bench_two_ranks_control_flow_on_one_gpu(gpu, tmp_path):
+    """The N > 1 branch of bench.py has only ever been read, never run: the driver's scaling run is its first execution on real
+    hardware.  Here the launcher's exact command (`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`) runs with both ranks
+    on the one GPU and the rendezvous over gloo (MVFX_BENCH_TEST_SHARED_GPU=1; RCCL refuses two ranks on one device): barriers, the
+    max-over-ranks timing, the whole-job aggregate and the watchdog around the band-sharded leg (whose RCCL communicator cannot
+    come up here: it must report an error, not cost the line).  Not a measurement."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["MVFX_BENCH_TEST_SHARED_GPU"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--pool", "6",
+           "--settle-seconds", "0.1", "--content-sweep", "0", "--side-leg-timeout", "60"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    c = d["config"]
+    assert c["rccl_ranks"] == 2 and c["rendezvous_backend"] == "gloo"
+    assert len(c["per_rank_frames_per_sec"]) == 2
+    # whole-job value = frames of both ranks / the slowest rank's time: never more than the sum of the per-rank rates
+    assert d["value"] <= sum(c["per_rank_frames_per_sec"]) * 1.0001
+    side = c["other_configs"]["videocompare_blockhash_sharded"]
+    assert "error" in side or side["n_gpus"] == 2
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only

@@ -140,9 +140,9 @@ def main():
             dst = torch.empty_like(src)
             fi = (vfx.Frame * POOL)(*[vfx.make_frame(src[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)])
             fo = (vfx.Frame * POOL)(*[vfx.make_frame(dst[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)])
-            for placement in (0, 6):
+            for placement in (0, 5, 6):
                 vfx.check(lib.mvfx_thread_set_options(vfx.options(placement=placement).word))
-                what = {0: "auto (tile kernel)", 6: "baked table"}[placement]
+                what = {0: "auto (x-prelerped tile kernel)", 5: "tile kernel of round 2", 6: "baked table"}[placement]
                 ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fi[i % POOL]), ctypes.byref(fo[i % POOL]), sptr)), iters=300)
                 report(f"colorlut 3D 33^3 RGBA 4K {data} placement={what}", ms, 2 * NB, 1)
                 ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frames(lut.h, fi, fo, POOL, sptr)), iters=40 if data != "random" else 10)
