@@ -812,29 +812,45 @@ __global__ __launch_bounds__(256) void colorlut_xtable_build_kernel(const float4
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) f32x2_t *lds_float2_t;
 
+#ifndef MVFX_XTILE_ROWS
+#define MVFX_XTILE_ROWS 4 // rows of four pixels per lane: the wave's block is 64 x (4 x rows) pixels
+#endif
+#ifndef MVFX_XTILE_NT
+#define MVFX_XTILE_NT 1   // 1: non-temporal pixel loads and stores (16 x 4K natural-like 70.7 k -> 73.1 k fps, one frame 21.8 -> 19.1 us:
+                          // the pixels stream through once, the table stays in L2)
+#endif
 template <int RW>
 __global__ __launch_bounds__(kBlock) void colorlut_xtile_kernel(FrameBatch in_fb, FrameBatch out_fb, uint32_t width, uint32_t height,
                                                                 uint32_t in_stride, uint32_t out_stride, LutParams p)
 {
     static_assert(RW % 2 == 0 && RW <= 64, "window rows start and end on 16-byte pieces");
     static_assert(RW * 24 == kXPitchZ, "the coordinate table is built for this window width");
-    constexpr uint32_t kAcross = 16, kRows = 4, kTileW = 64, kTileH = 16;
+    constexpr uint32_t kAcross = 16, kRows = MVFX_XTILE_ROWS, kTileW = 64, kTileH = 4 * kRows;
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
     constexpr uint32_t kRowP = RW * 3 / 2;            // 16-byte pieces per window row
     constexpr uint32_t kPieces = kXRows * kRowP;      // per wave
     constexpr uint32_t kWaveBytes = kPieces * 16 + 32; // +32 bytes: de-phases the four waves' regions over the banks
     __shared__ __attribute__((aligned(16))) uint8_t win[(kBlock / 64) * kWaveBytes];
     __shared__ uint2 coord[512]; // {cell index x LDS pitch, fraction bits} per byte value of the g and b channels
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint8_t *in = in_fb.base[blockIdx.z];
-    uint8_t *out = out_fb.base[blockIdx.z];
-    const uint32_t bx = (blockIdx.x * (kBlock / 64) + wave) * kTileW, by = blockIdx.y * kTileH; // the wave's block
+    // (giving every XCD a contiguous run of the workgroup order -- whole frames of a batch, a band of a single frame -- so that its L2
+    // holds a smaller part of the table: 71.6 k vs 72.3 k fps, one frame 20.8 vs 19.1 us; with non-temporal pixel accesses the table
+    // misses are 8 % of the pixel bytes already, FETCH_SIZE 572 MB vs 540 MB per 16 frames)
+    const uint32_t gx = blockIdx.x, gy = blockIdx.y, gz = blockIdx.z;
+    const uint8_t *in = in_fb.base[gz];
+    uint8_t *out = out_fb.base[gz];
+    const uint32_t bx = (gx * (kBlock / 64) + wave) * kTileW, by = gy * kTileH; // the wave's block
     const uint32_t x = bx + (lane % kAcross) * 4, y0 = by + (lane / kAcross) * kRows;
     // 1. every pixel of the lane, up front (four 16-byte loads in flight while the window is being fetched)
     uint4 v[kRows];
 #pragma unroll
     for (uint32_t row = 0; row < kRows; row++) {
         v[row] = make_uint4(0, 0, 0, 0);
-        if (x < width && y0 + row < height) v[row] = *reinterpret_cast<const uint4 *>(in + ((y0 + row) * in_stride + x * 4));
+        if (x < width && y0 + row < height) {
+            const u32x4_t *src = reinterpret_cast<const u32x4_t *>(in + ((y0 + row) * in_stride + x * 4));
+            const u32x4_t t = MVFX_XTILE_NT ? __builtin_nontemporal_load(src) : *src;
+            v[row] = make_uint4(t.x, t.y, t.z, t.w);
+        }
     }
     // 2. the window, anchored at the block's centre pixel (its top-left pixel when the centre lies outside the frame): the pixel and
     // its two coordinate entries come through the scalar cache, so this chain does not wait for the vector loads above
@@ -916,15 +932,22 @@ __global__ __launch_bounds__(kBlock) void colorlut_xtile_kernel(FrameBatch in_fb
             const float c1r = e1[j][0].x + e1[j][1].y * ty[j], c1g = e1[j][0].y + e1[j][2].x * ty[j], c1b = e1[j][1].x + e1[j][2].y * ty[j];
             const float rr = lf_add_clamp(c0r, (c1r - c0r) * tz[j]), gg = lf_add_clamp(c0g, (c1g - c0g) * tz[j]),
                         bb = lf_add_clamp(c0b, (c1b - c0b) * tz[j]);
-            const float yr = rr * p.fast.out_scale + p.fast.pred_half, yg = gg * p.fast.out_scale + p.fast.pred_half,
-                        yb = bb * p.fast.out_scale + p.fast.pred_half;
+            // float_to_u8 (imp.rs:537-539) as ONE fused multiply-add + truncation: trunc(fma(v, 255, pred(0.5))) == round(v * 255) for
+            // every float v in [0, 1] (tools/prove_exact.c P15, exhaustive); the other kernels of this file use mul + add (P10)
+            const float yr = __builtin_fmaf(rr, p.fast.out_scale, p.fast.pred_half), yg = __builtin_fmaf(gg, p.fast.out_scale, p.fast.pred_half),
+                        yb = __builtin_fmaf(bb, p.fast.out_scale, p.fast.pred_half);
             uint32_t w = px[j];
             asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yr));
             asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yg));
             asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
             px[j] = w;
         }
-        if (valid) *reinterpret_cast<uint4 *>(out + (y * out_stride + x * 4)) = make_uint4(px[0], px[1], px[2], px[3]);
+        if (valid) {
+            u32x4_t *dst = reinterpret_cast<u32x4_t *>(out + (y * out_stride + x * 4));
+            const u32x4_t t = {px[0], px[1], px[2], px[3]};
+            if (MVFX_XTILE_NT) __builtin_nontemporal_store(t, dst);
+            else *dst = t;
+        }
     }
 }
 
@@ -1404,7 +1427,7 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
         //   64 x 32 (16 x 4, 8 rows) 60.2 k / 31.0 us;  32 x 32 59.1 k / 23.9;  64 x 8 56.3 k / 22.4;  32 x 64 47.4 k / 34.3
         // RGBA8 on cubes of 4+ points: the x-prelerped kernel (placement 5 keeps the kernel below for A/B runs)
         if (!wide && h->d_xtable && opt_lut_placement() != 5) {
-            const uint32_t tx_ = (in->width + 63) / 64, ty_ = (in->height + 15) / 16;
+            const uint32_t tx_ = (in->width + 63) / 64, ty_ = (in->height + 4 * MVFX_XTILE_ROWS - 1) / (4 * MVFX_XTILE_ROWS);
             const dim3 xgrid((tx_ + kBlock / 64 - 1) / (kBlock / 64), ty_, n);
             hipLaunchKernelGGL(colorlut_xtile_kernel<MVFX_XTILE_RW>, xgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p);
             MVFX_HIP_TRY(hipGetLastError());

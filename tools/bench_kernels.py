@@ -168,10 +168,10 @@ def main():
                 dst = torch.empty_like(src)
                 fi = [vfx.make_frame(src[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
                 fo = [vfx.make_frame(dst[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(POOL)]
-                for placement in ((0, 1, 2, 5) if size <= 21 else (0,)):
+                for placement in ((0, 1, 2, 5) if size <= 21 else (0, 5)):
                     vfx.check(lib.mvfx_thread_set_options(vfx.options(placement=placement).word))
                     ms = timeit(lambda i=0: vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, ctypes.byref(fi[i % POOL]), ctypes.byref(fo[i % POOL]), sptr)), iters=300)
-                    report(f"colorlut 3D {size}^3 RGBA 4K {data} placement={ {0: 'auto', 1: 'global nodes', 2: 'LDS cube', 5: 'tile kernel'}[placement]}", ms, 2 * NB, 1)
+                    report(f"colorlut 3D {size}^3 RGBA 4K {data} placement={ {0: 'auto', 1: 'global nodes', 2: 'LDS cube', 5: 'tile kernel (round 2)'}[placement]}", ms, 2 * NB, 1)
                 vfx.check(lib.mvfx_thread_set_options(vfx.options(placement=0).word))
         lut = vfx.CubeLut(cubes.analytic_3d(33))
         src = natural_like_gpu(POOL, W, H, 11)

@@ -26,6 +26,8 @@
  *  P14 1 - |fma(f,2,-1)| == fma(-2, |f-0.5|, 1) for every float f in [0,1)
  *  P10 f32::round (half away from zero) of v in [0,65535.5] == truncf(v + PRED_HALF), PRED_HALF = 0.49999997
  *      (largest float below 0.5); used by colorlut's float_to_u8 / float_to_u16
+ *  P15 float_to_u8 with ONE fused operation: for every float v in [0,1], roundf(v * 255.0f) == truncf(fmaf(v, 255.0f, PRED_HALF))
+ *      (colorlut_xtile_kernel; the same with 65535 fails on 2 floats -- there fmaf(v, 65535.0f, 0.5f) is the exact one)
  *  P7  fmodf(x,360) followed by `if <0 {+=360}` == conditional +-360 for every float x in
  *      [-360,720) (results compared as floats, +0 == -0)
  *  P4  from_rgb hue is in [0,360) for all 2^24 (R,G,B) => `hue % 360` is the identity
@@ -253,6 +255,18 @@ int main(void)
         }
         printf("P14 1-|2f-1| == fma(-2,|f-0.5|,1) on [0,1): %s (%llu mismatches)\n", bad ? "FAIL" : "PASS", (unsigned long long)bad);
         ok_all &= !bad;
+    }
+    { /* P15 */
+        const float h = nextafterf(0.5f, 0.0f);
+        uint64_t bad8 = 0, bad16 = 0;
+        for (uint32_t u = 0; u <= f2u(1.0f); u++) {
+            const float v = u2f(u);
+            if (truncf(fmaf(v, 255.0f, h)) != roundf(v * 255.0f)) bad8++;
+            if (truncf(fmaf(v, 65535.0f, 0.5f)) != roundf(v * 65535.0f)) bad16++;
+        }
+        printf("P15 fused float_to_u8 trunc(fma(v,255,pred(0.5))): %s (%llu); float_to_u16 trunc(fma(v,65535,0.5)): %s (%llu)\n",
+               bad8 ? "FAIL" : "PASS", (unsigned long long)bad8, bad16 ? "FAIL" : "PASS", (unsigned long long)bad16);
+        ok_all &= !bad8 && !bad16;
     }
     printf("%s\n", ok_all ? "ALL PASS" : "SOME FAILED");
     return ok_all ? 0 : 1;
