@@ -663,8 +663,9 @@ def make_leg_colorlut(w, args, content):
                 "frac_wall": fps / w.world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS}
     leg = Leg("colorlut_" + content, "colorlut_frames_per_sec", "frames/s", nb, nb * 2 * FRAME_BYTES, "f32", data,
               f"colorlut 33^3 .cube (575 KB of nodes), {nb} streams of 3840x2160 RGBA per launch, content={content}; 4 + 4 algorithmic B/px "
-              "(the LUT gathers are content dependent: random colours are the worst case, flat bars the best)",
-              step, ["colorlut_tile_kernel"],
+              "(the LUT gathers are content dependent: random colours are the worst case, flat bars the best); kernel: the x-prelerped tile "
+              "kernel (6.9 MB table of the four x-lerps + the y-difference per r byte, built once per LUT; window staged in LDS)",
+              step, ["colorlut_xtile_kernel"],
               cpu=(lambda s: cpu_baseline_colorlut(s, host, cube_text, content)) if host else None)
     leg.keep = (src, dst, fi, fo, lut)
     leg.streams_leg = streams_leg

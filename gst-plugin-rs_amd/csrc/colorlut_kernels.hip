@@ -1017,6 +1017,78 @@ __global__ __launch_bounds__(kI420Block) void colorlut_i420_tile_kernel(I420Plan
     });
 }
 
+// The fused I420 kernel on the x-prelerped table (round 3): the compact walk of convert_math.hpp as above, the LUT step of
+// colorlut_xtile_kernel -- window of MVFX_XTILE_RW r bytes x 3 y cells x 4 z rows around the first pixel of lane 36 (lane 0's when
+// the block's centre lies outside the frame), filled by global_load_lds, premultiplied coordinate entries for g and b.
+__global__ __launch_bounds__(kI420Block) void colorlut_i420_xtile_kernel(I420Planes pl, uint32_t width, uint32_t height, LutParams p,
+                                                                         YuvToRgbCoef kin, RgbToYuvCoef kout)
+{
+    constexpr uint32_t RW = MVFX_XTILE_RW, kRowP = RW * 3 / 2, kPieces = kXRows * kRowP, kWaveBytes = kPieces * 16 + 32;
+    __shared__ int2 edge[kI420Block];
+    __shared__ uint2 coord[512];
+    __shared__ __attribute__((aligned(16))) uint8_t win[(kI420Block / 64) * kWaveBytes];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t i = threadIdx.x; i < 512; i += kI420Block) coord[i] = p.xcoord[i];
+    uint32_t x0, y0, edge_index;
+    bool has_left;
+    i420_lane_origin<true>(x0, y0, edge_index, has_left);
+    const bool active = x0 < width && y0 < height;
+    uint32_t first = 0xff000000u;
+    if (active) {
+        const uint32_t crow = y0 / 2;
+        const ChromaTerms c = chroma_terms(pl.iu[(uint64_t)crow * pl.ius + x0 / 2], pl.iv[(uint64_t)crow * pl.ivs + x0 / 2], kin);
+        first = yuv_pixel(pl.iy[(uint64_t)y0 * pl.iys + x0], c, kin);
+    }
+    const uint32_t centre = __builtin_amdgcn_readlane((int)active, 36) ? 36u : 0u;
+    const uint32_t fpx = (uint32_t)__builtin_amdgcn_readlane((int)first, centre);
+    const uint32_t cr = fpx & 0xffu, cy = p.tile_tables[2 * (256 + ((fpx >> 8) & 0xffu))], cz = p.tile_tables[2 * (512 + ((fpx >> 16) & 0xffu))];
+    const uint32_t ar = min((cr > RW / 2 ? cr - RW / 2 : 0u) & ~1u, 256u - RW);
+    const uint32_t ay = min(cy > 0 ? cy - 1 : 0u, p.size - 3), az = min(cz > 0 ? cz - 1 : 0u, p.size - 3);
+    const uint32_t ayp = ay * kXPitchY, azp = az * kXPitchZ, ar24 = ar * 24u;
+    {
+        const uint32_t base = (ay * (p.size + 1) + az) * kXRowPieces + ar * 3 / 2;
+        typedef __attribute__((address_space(3))) void *lds_void_t;
+        typedef const __attribute__((address_space(1))) void *global_void_t;
+#pragma unroll
+        for (uint32_t q0 = 0; q0 < kPieces; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            if (q0 + 64 <= kPieces || q < kPieces) {
+                const uint32_t wr = q / kRowP, k = q - wr * kRowP;
+                __builtin_amdgcn_global_load_lds((global_void_t)(p.xtable + (base + ((wr >> 2) * (p.size + 1) + (wr & 3u)) * kXRowPieces + k)),
+                                                 (lds_void_t)(win + wave * kWaveBytes + q0 * 16), 16, 0, 0);
+            }
+        }
+    }
+    __syncthreads(); // coordinate table and window complete
+    const uint32_t wave_lds = wave * kWaveBytes, lds_k = wave_lds - ayp - azp - ar24;
+    i420_fused_tile<true>(pl, width, height, kin, kout, edge, [&](uint32_t px) {
+        const uint2 eg = coord[(px >> 8) & 0xffu], eb = coord[256 + ((px >> 16) & 0xffu)];
+        const float ty = __uint_as_float(eg.y), tz = __uint_as_float(eb.y);
+        uint32_t r24;
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r24) : "v"(px), "v"(24u));
+        const uint32_t dr24 = r24 - ar24, dyp = eg.x - ayp, dzp = eb.x - azp;
+        const bool miss = (dr24 >= RW * 24u) | (dyp >= 3u * kXPitchY) | (dzp >= 3u * kXPitchZ);
+        const uint32_t off = miss ? wave_lds : eg.x + eb.x + (r24 + lds_k);
+        const lds_float2_t q0 = (lds_float2_t)((lds_bytes_t)&win[0] + off), q1 = (lds_float2_t)((lds_bytes_t)&win[0] + off + kXPitchZ);
+        f32x2_t e0[3] = {q0[0], q0[1], q0[2]}, e1[3] = {q1[0], q1[1], q1[2]};
+        if (miss) {
+            const uint32_t iy = eg.x / kXPitchY, iz = eb.x / kXPitchZ, r = px & 0xffu;
+            const f32x2_t *g0 = reinterpret_cast<const f32x2_t *>(p.xtable) + (uint64_t)((iy * (p.size + 1) + iz) * 256u + r) * 3, *g1 = g0 + 256 * 3;
+            e0[0] = g0[0]; e0[1] = g0[1]; e0[2] = g0[2];
+            e1[0] = g1[0]; e1[1] = g1[1]; e1[2] = g1[2];
+        }
+        const float c0r = e0[0].x + e0[1].y * ty, c0g = e0[0].y + e0[2].x * ty, c0b = e0[1].x + e0[2].y * ty;
+        const float c1r = e1[0].x + e1[1].y * ty, c1g = e1[0].y + e1[2].x * ty, c1b = e1[1].x + e1[2].y * ty;
+        const float rr = lf_add_clamp(c0r, (c1r - c0r) * tz), gg = lf_add_clamp(c0g, (c1g - c0g) * tz), bb = lf_add_clamp(c0b, (c1b - c0b) * tz);
+        const float yr = __builtin_fmaf(rr, p.fast.out_scale, p.fast.pred_half), yg = __builtin_fmaf(gg, p.fast.out_scale, p.fast.pred_half),
+                    yb = __builtin_fmaf(bb, p.fast.out_scale, p.fast.pred_half); // P15
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(yr));
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(yg));
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(yb));
+        return px;
+    });
+}
+
 template <bool IS3D, bool CELLS, bool WIDE, bool LE>
 __global__ __launch_bounds__(kBlock) void colorlut_fast_global_kernel(FrameBatch in_fb, FrameBatch out_fb, uint64_t width,
                                                                       uint32_t rows, uint64_t in_stride,
@@ -1542,9 +1614,14 @@ int colorlut_i420_impl(mvfx_cube_lut *h, const mvfx_planar_frame *in, const mvfx
         const RgbToYuvCoef kout = rgb_to_yuv_coef(std_);
         const dim3 grid((w / 8 + kI420Block - 1) / kI420Block, hgt / 2);
         p.tile_tables = h->d_tile_tables;
+        p.xtable = reinterpret_cast<const float4 *>(h->d_xtable);
+        p.xcoord = reinterpret_cast<const uint2 *>(h->d_xcoord);
         if (l.is_3d && h->d_cells && h->d_tile_tables && hgt / 16 + 1 <= 65535u) {
             const dim3 tgrid((w + 255) / 256, (hgt + 15) / 16);
-            hipLaunchKernelGGL(colorlut_i420_tile_kernel, tgrid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);
+            if (h->d_xtable && opt_lut_placement() != 5)
+                hipLaunchKernelGGL(colorlut_i420_xtile_kernel, tgrid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);
+            else
+                hipLaunchKernelGGL(colorlut_i420_tile_kernel, tgrid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);
         } else if (l.is_3d && h->d_cells)
             hipLaunchKernelGGL((colorlut_i420_kernel<true, true>), grid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);
         else if (l.is_3d)
