@@ -815,6 +815,11 @@ typedef const __attribute__((address_space(3))) f32x2_t *lds_float2_t;
 #ifndef MVFX_XTILE_ROWS
 #define MVFX_XTILE_ROWS 4 // rows of four pixels per lane: the wave's block is 64 x (4 x rows) pixels
 #endif
+#ifndef MVFX_XTILE_MISS_CELLS
+#define MVFX_XTILE_MISS_CELLS 0 // pixels outside the window: 0 = two entries of the x table, 1 = the 96-byte cell of the cell-packed table
+                                // (uniform-random colours 2.22 -> 1.59 ms per 16 frames, but 104 instead of 92 VGPRs: natural-like 0.635 ->
+                                // 0.585 of the HBM peak, flat bars 0.56 -> 0.47 on the same box -- not taken)
+#endif
 #ifndef MVFX_XTILE_NT
 #define MVFX_XTILE_NT 1   // 1: non-temporal pixel loads and stores (16 x 4K natural-like 70.7 k -> 73.1 k fps, one frame 21.8 -> 19.1 us:
                           // the pixels stream through once, the table stays in L2)
@@ -918,10 +923,35 @@ __global__ __launch_bounds__(kBlock) void colorlut_xtile_kernel(FrameBatch in_fb
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (miss[j]) {
+#if MVFX_XTILE_MISS_CELLS
+                    // outside the window: the 96-byte cell of the cell-packed table (3.45 MB, L2 resident; the x-prelerped table is twice
+                    // that and a frame of uniform-random colours, where every pixel takes this path, ran at 7.2 k instead of 12.1 k fps
+                    // on it), x-lerped here into the same (X, D) pair the table would have delivered
+                    const uint32_t iy = gy[j] / kXPitchY, iz = gz[j] / kXPitchZ;
+                    const uint2 er = reinterpret_cast<const uint2 *>(p.tile_tables)[px[j] & 0xffu];
+                    const float tx = __uint_as_float(er.y);
+                    const float4 *cell = p.cells + __umul24(__umul24(__umul24(iz, p.size) + iy, p.size) + er.x, kCellF4);
+                    float4 c6[6];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) c6[i] = cell[i];
+                    const float f[24] = {c6[0].x, c6[0].y, c6[0].z, c6[0].w, c6[1].x, c6[1].y, c6[1].z, c6[1].w, c6[2].x, c6[2].y, c6[2].z, c6[2].w,
+                                         c6[3].x, c6[3].y, c6[3].z, c6[3].w, c6[4].x, c6[4].y, c6[4].z, c6[4].w, c6[5].x, c6[5].y, c6[5].z, c6[5].w};
+                    // corner i = 3 floats at f[3 i]: c000, d100, c010, d110, c001, d101, c011, d111 (odd corners hold the x-differences)
+                    float X[4][3];
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) X[q][ch] = f[6 * q + ch] + f[6 * q + 3 + ch] * tx;
+                    e0[j][0] = f32x2_t{X[0][0], X[0][1]}; e0[j][1] = f32x2_t{X[0][2], X[1][0] - X[0][0]};
+                    e0[j][2] = f32x2_t{X[1][1] - X[0][1], X[1][2] - X[0][2]};
+                    e1[j][0] = f32x2_t{X[2][0], X[2][1]}; e1[j][1] = f32x2_t{X[2][2], X[3][0] - X[2][0]};
+                    e1[j][2] = f32x2_t{X[3][1] - X[2][1], X[3][2] - X[2][2]};
+#else
                     const uint32_t iy = gy[j] / kXPitchY, iz = gz[j] / kXPitchZ, r = px[j] & 0xffu;
                     const f32x2_t *g0 = reinterpret_cast<const f32x2_t *>(p.xtable) + (uint64_t)((iy * (p.size + 1) + iz) * 256u + r) * 3, *g1 = g0 + 256 * 3;
                     e0[j][0] = g0[0]; e0[j][1] = g0[1]; e0[j][2] = g0[2];
                     e1[j][0] = g1[0]; e1[j][1] = g1[1]; e1[j][2] = g1[2];
+#endif
                 }
             }
         }
