@@ -21,6 +21,22 @@ def random_frame(seed: int, width: int, height: int, bpp: int = 4, stride: int |
     return splitmix64_bytes(seed, stride * height).reshape(height, stride)
 
 
+def natural_like(width: int, height: int, seed: int = 0x5EED0004) -> np.ndarray:
+    """RGBA frame of smooth 2-D colour gradients + seeded noise of +-3 codes per channel (what bench.py calls "natural-like": neighbouring
+    pixels fall into the same or adjacent LUT cells, never into exactly the same colour), alpha = a hash of the position."""
+    x = np.linspace(0.0, 1.0, width, dtype=np.float64)[None, :]
+    y = np.linspace(0.0, 1.0, height, dtype=np.float64)[:, None]
+    ph = 0.37 * (seed & 15)
+    f = np.empty((height, width, 4), dtype=np.uint8)
+    chans = (0.5 + 0.45 * np.sin(3.0 * x + 2.0 * y + ph), 0.5 + 0.45 * np.sin(5.0 * y - 1.5 * x + 2 * ph), 0.5 + 0.45 * np.cos(4.0 * x * y + ph))
+    noise = splitmix64_bytes(seed, width * height * 4).reshape(height, width, 4)
+    for c in range(3):
+        v = np.broadcast_to(chans[c], (height, width)) * 255.0 + (noise[..., c] % 7).astype(np.float64) - 3.0
+        f[..., c] = np.clip(v, 0, 255).astype(np.uint8)
+    f[..., 3] = noise[..., 3]
+    return f.reshape(height, width * 4)
+
+
 def exhaustive_rgbx() -> np.ndarray:
     """4096x4096 4-byte frame holding all 2^24 (c0,c1,c2) triples; byte 3 =
     (i*2654435761 mod 2^32)>>24 must come through untouched (SURVEY.md 8d iii)."""

@@ -168,6 +168,46 @@ def test_colorlut_4k_rgba_33(gpu, luts):
         assert np.array_equal(dst.download().reshape(h, w * 4), exp)
 
 
+@pytest.mark.parametrize("name", ["analytic33", "domain33", "analytic65", "analytic9", "nan_nodes4"])
+@pytest.mark.parametrize("placement", [0, 5], ids=["x-prelerped", "tile-round2"])
+def test_colorlut_window_kernels(gpu, luts, name, placement):
+    """The two window kernels on the frames that exercise their windows: smooth gradients + noise (most pixels inside the wave's window,
+    some outside), flat bars (everything inside), uniform-random (everything outside: the per-lane global path), at sizes that are not
+    multiples of the 64 x 16 wave block (partial blocks, a last workgroup whose trailing waves lie outside the frame), batched.
+    placement 0 = colorlut_xtile_kernel (x-prelerped table), 5 = colorlut_tile_kernel (3 x 3 x 3 cell window): the oracle's bytes."""
+    if name == "nan_nodes4":
+        text = "LUT_3D_SIZE 4\n" + "".join(("nan 0.5 inf\n" if (i * 7) % 5 == 0 else ("0.25 -inf 2\n" if i % 3 == 0 else f"{i / 64:.6f} {1 - i / 64:.6f} 0.5\n"))
+                                            for i in range(64))
+        o = orc.CubeLut(text)
+        assert o.ok, o.error
+        dev = gpu.CubeLut(text)
+    else:
+        dev, o = luts[name]
+    L = gpu.lib()
+    gpu.check(L.mvfx_thread_set_options(gpu.options(placement=placement).word))
+    try:
+        for (w, h) in ((3840, 2160), (1000, 250), (68, 20)):
+            n = 2 if w > 2000 else 3
+            srcs = []
+            for k in range(n):
+                kind = (k + (w // 4)) % 3
+                f = frames.natural_like(w, h, 0x5EED0C00 + k) if kind == 0 else (frames.smpte_like(w, h) if kind == 1 else frames.random_frame(0x5EED0C10 + k, w, h))
+                srcs.append(np.ascontiguousarray(f).reshape(h, w * 4))
+            din = [gpu.DeviceBuffer(f.nbytes).upload(f) for f in srcs]
+            dout = [gpu.DeviceBuffer(f.nbytes) for f in srcs]
+            fi = (gpu.Frame * n)(*[gpu.make_frame(b.ptr, w, h, w * 4, "RGBA") for b in din])
+            fo = (gpu.Frame * n)(*[gpu.make_frame(b.ptr, w, h, w * 4, "RGBA") for b in dout])
+            gpu.check(L.mvfx_colorlut_transform_frames(dev.h, fi, fo, n, None))
+            gpu.check(L.mvfx_stream_synchronize(None))
+            for k in range(n):
+                exp = np.empty_like(srcs[k])
+                assert o.apply(srcs[k], w * 4, exp, w * 4, w, h, "RGBA") == 0
+                got = dout[k].download().reshape(h, w * 4)
+                assert np.array_equal(got, exp), f"{name} {w}x{h} frame {k}: {np.count_nonzero(got != exp)} bytes differ"
+    finally:
+        L.mvfx_thread_set_options(gpu.options(placement=0).word)
+
+
 def test_colorlut_rgba64_wide_values(gpu, luts):
     """RGBA64: every 16-bit value on each channel at least once (65536 px ramp + random)"""
     dev, o = luts["analytic33"]
