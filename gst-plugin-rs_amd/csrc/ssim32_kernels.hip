@@ -68,11 +68,13 @@ __device__ __forceinline__ float cbrt_unit(float t)
 __device__ __forceinline__ float lab_f(float t)
 {
     const float eps = 216.0f / 24389.0f, kappa = 24389.0f / 27.0f;
-    const float lin = __builtin_fmaf(kappa, t, 16.0f) * (1.0f / 116.0f);
+    const float lin = __builtin_fmaf(kappa / 116.0f, t, 16.0f / 116.0f); // (kappa t + 16) / 116 in one operation
     // both sides are always computed and the result is a select: as a branch (what the compiler makes of `t > eps ? cbrt : lin`
     // when it may sink the transcendentals) every one of the 48 cube roots of a lane became its own basic block with a serial
     // log -> exp -> Newton chain and nothing to overlap it with (round 3: 470 -> ... us for the 8K level-0 launch)
-    float cb = cbrt_unit(fmaxf(t, eps));
+    // (no guard on t: for t <= eps -- including 0, where the logarithm is -inf and the Newton step makes a NaN -- the select below
+    // takes `lin` and never looks at the other operand)
+    float cb = cbrt_unit(t);
     asm volatile("" : "+v"(cb));
     return t > eps ? cb : lin;
 }
@@ -80,9 +82,11 @@ __device__ __forceinline__ float lab_f(float t)
 // linear RGB (premultiplied) of the same pixel of both images -> the three planes of both, as pairs (oracle: to_lab)
 __device__ __forceinline__ void to_lab2(f2 r, f2 g, f2 b, f2 out[3])
 {
-    const f2 X = fma2(splat(0.1805f), b, fma2(splat(0.3576f), g, splat(0.4124f) * r)) * splat(1.0f / 0.9505f);
+    // the white-point divisions are folded into the matrix rows (X / 0.9505, Z / 1.089): one rounding less per value than the oracle's
+    // two steps, inside the tolerance of this pipeline (tests/test_ssim_gpu.py)
+    const f2 X = fma2(splat(0.1805f / 0.9505f), b, fma2(splat(0.3576f / 0.9505f), g, splat(0.4124f / 0.9505f) * r));
     const f2 Y = fma2(splat(0.0722f), b, fma2(splat(0.7152f), g, splat(0.2126f) * r));
-    const f2 Z = fma2(splat(0.9505f), b, fma2(splat(0.1192f), g, splat(0.0193f) * r)) * splat(1.0f / 1.089f);
+    const f2 Z = fma2(splat(0.9505f / 1.089f), b, fma2(splat(0.1192f / 1.089f), g, splat(0.0193f / 1.089f) * r));
     const f2 fx = {lab_f(X.x), lab_f(X.y)}, fy = {lab_f(Y.x), lab_f(Y.y)}, fz = {lab_f(Z.x), lab_f(Z.y)};
     out[0] = fma2(splat(1.16f), fy, splat(-0.16f));
     out[1] = fma2(splat(500.0f / 220.0f), fx - fy, splat(86.2f / 220.0f));
