@@ -820,12 +820,15 @@ typedef const __attribute__((address_space(3))) f32x2_t *lds_float2_t;
                                 // (uniform-random colours 2.22 -> 1.59 ms per 16 frames, but 104 instead of 92 VGPRs: natural-like 0.635 ->
                                 // 0.585 of the HBM peak, flat bars 0.56 -> 0.47 on the same box -- not taken)
 #endif
+#ifndef MVFX_XTILE_MIN_BLOCKS
+#define MVFX_XTILE_MIN_BLOCKS 1
+#endif
 #ifndef MVFX_XTILE_NT
 #define MVFX_XTILE_NT 1   // 1: non-temporal pixel loads and stores (16 x 4K natural-like 70.7 k -> 73.1 k fps, one frame 21.8 -> 19.1 us:
                           // the pixels stream through once, the table stays in L2)
 #endif
 template <int RW>
-__global__ __launch_bounds__(kBlock) void colorlut_xtile_kernel(FrameBatch in_fb, FrameBatch out_fb, uint32_t width, uint32_t height,
+__global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_kernel(FrameBatch in_fb, FrameBatch out_fb, uint32_t width, uint32_t height,
                                                                 uint32_t in_stride, uint32_t out_stride, LutParams p)
 {
     static_assert(RW % 2 == 0 && RW <= 64, "window rows start and end on 16-byte pieces");
