@@ -820,6 +820,9 @@ typedef const __attribute__((address_space(3))) f32x2_t *lds_float2_t;
                                 // (uniform-random colours 2.22 -> 1.59 ms per 16 frames, but 104 instead of 92 VGPRs: natural-like 0.635 ->
                                 // 0.585 of the HBM peak, flat bars 0.56 -> 0.47 on the same box -- not taken)
 #endif
+#ifndef MVFX_XTILE_GROUP
+#define MVFX_XTILE_GROUP 4 // pixels per window look-up / miss branch group (1, 2 or 4)
+#endif
 #ifndef MVFX_XTILE_MIN_BLOCKS
 #define MVFX_XTILE_MIN_BLOCKS 1
 #endif
@@ -899,39 +902,46 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
         const uint32_t y = y0 + row;
         const bool valid = x < width && y < height; // width % 4 == 0 (launcher)
         uint32_t px[4] = {v[row].x, v[row].y, v[row].z, v[row].w};
-        // the four pixels' entries from the window; a pixel outside it reads the window's first entry and is patched below (one
-        // branch per four pixels instead of one per pixel: the scalar side of an if / else costs about five instructions)
-        f32x2_t e0[4][3], e1[4][3];
-        float ty[4], tz[4];
-        uint32_t gy[4], gz[4];
-        bool miss[4];
+        // kGroup pixels at a time: their entries from the window; a pixel outside it reads the window's first entry and is patched in ONE
+        // branch per group (the scalar side of an if / else costs about five instructions)
+        constexpr int kGroup = MVFX_XTILE_GROUP;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint2 eg = coord[(px[j] >> 8) & 0xffu], eb = coord[256 + ((px[j] >> 16) & 0xffu)];
+        for (int g0 = 0; g0 < 4; g0 += kGroup) {
+        f32x2_t e0[kGroup][3], e1[kGroup][3];
+        float ty[kGroup], tz[kGroup];
+        uint32_t gy[kGroup], gz[kGroup];
+        bool miss[kGroup];
+        bool any_miss = false;
+#pragma unroll
+        for (int j = 0; j < kGroup; j++) {
+            const uint32_t pxj = px[g0 + j];
+            const uint2 eg = coord[(pxj >> 8) & 0xffu], eb = coord[256 + ((pxj >> 16) & 0xffu)];
             ty[j] = __uint_as_float(eg.y);
             tz[j] = __uint_as_float(eb.y);
             gy[j] = eg.x;
             gz[j] = eb.x;
             uint32_t r24;
-            asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r24) : "v"(px[j]), "v"(24u));
+            asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r24) : "v"(pxj), "v"(24u));
             const uint32_t dr24 = r24 - ar24, dyp = eg.x - ayp, dzp = eb.x - azp; // unsigned: below the anchor wraps to a huge value
             // (bitwise |: with || the compiler turns the second and third test into branches behind the LDS wait)
             miss[j] = (dr24 >= (uint32_t)RW * 24u) | (dyp >= 3u * kXPitchY) | (dzp >= 3u * kXPitchZ);
+            any_miss = any_miss | miss[j];
             const uint32_t off = miss[j] ? wave_lds : eg.x + eb.x + (r24 + lds_k);
             const lds_float2_t q0 = (lds_float2_t)((lds_bytes_t)&win[0] + off), q1 = (lds_float2_t)((lds_bytes_t)&win[0] + off + kXPitchZ);
             e0[j][0] = q0[0]; e0[j][1] = q0[1]; e0[j][2] = q0[2];
             e1[j][0] = q1[0]; e1[j][1] = q1[1]; e1[j][2] = q1[2];
         }
-        if (miss[0] | miss[1] | miss[2] | miss[3]) {
+        if (any_miss) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < kGroup; j++) {
                 if (miss[j]) {
+                    const uint32_t pxj = px[g0 + j];
 #if MVFX_XTILE_MISS_CELLS
-                    // outside the window: the 96-byte cell of the cell-packed table (3.45 MB, L2 resident; the x-prelerped table is twice
-                    // that and a frame of uniform-random colours, where every pixel takes this path, ran at 7.2 k instead of 12.1 k fps
-                    // on it), x-lerped here into the same (X, D) pair the table would have delivered
+                    // outside the window: the 96-byte cell of the cell-packed table (3.45 MB, L2 resident -- the x-prelerped table is twice
+                    // that, and its two entries of a pixel lie 6 KB apart: a frame of uniform-random colours, where every pixel takes this
+                    // path, read 14.9 GB per 16 frames from it, 14 x the pixels), x-lerped here into the (X, D) pairs the table holds
                     const uint32_t iy = gy[j] / kXPitchY, iz = gz[j] / kXPitchZ;
-                    const uint2 er = reinterpret_cast<const uint2 *>(p.tile_tables)[px[j] & 0xffu];
+                    const uint2 er = reinterpret_cast<const uint2 *>(p.tile_tables)[pxj & 0xffu];
                     const float tx = __uint_as_float(er.y);
                     const float4 *cell = p.cells + __umul24(__umul24(__umul24(iz, p.size) + iy, p.size) + er.x, kCellF4);
                     float4 c6[6];
@@ -950,16 +960,16 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
                     e1[j][0] = f32x2_t{X[2][0], X[2][1]}; e1[j][1] = f32x2_t{X[2][2], X[3][0] - X[2][0]};
                     e1[j][2] = f32x2_t{X[3][1] - X[2][1], X[3][2] - X[2][2]};
 #else
-                    const uint32_t iy = gy[j] / kXPitchY, iz = gz[j] / kXPitchZ, r = px[j] & 0xffu;
-                    const f32x2_t *g0 = reinterpret_cast<const f32x2_t *>(p.xtable) + (uint64_t)((iy * (p.size + 1) + iz) * 256u + r) * 3, *g1 = g0 + 256 * 3;
-                    e0[j][0] = g0[0]; e0[j][1] = g0[1]; e0[j][2] = g0[2];
-                    e1[j][0] = g1[0]; e1[j][1] = g1[1]; e1[j][2] = g1[2];
+                    const uint32_t iy = gy[j] / kXPitchY, iz = gz[j] / kXPitchZ, r = pxj & 0xffu;
+                    const f32x2_t *g0p = reinterpret_cast<const f32x2_t *>(p.xtable) + (uint64_t)((iy * (p.size + 1) + iz) * 256u + r) * 3, *g1p = g0p + 256 * 3;
+                    e0[j][0] = g0p[0]; e0[j][1] = g0p[1]; e0[j][2] = g0p[2];
+                    e1[j][0] = g1p[0]; e1[j][1] = g1p[1]; e1[j][2] = g1p[2];
 #endif
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < kGroup; j++) {
             // entry = (X.r, X.g) (X.b, D.r) (D.g, D.b)
             const float c0r = e0[j][0].x + e0[j][1].y * ty[j], c0g = e0[j][0].y + e0[j][2].x * ty[j], c0b = e0[j][1].x + e0[j][2].y * ty[j];
             const float c1r = e1[j][0].x + e1[j][1].y * ty[j], c1g = e1[j][0].y + e1[j][2].x * ty[j], c1b = e1[j][1].x + e1[j][2].y * ty[j];
@@ -969,11 +979,12 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
             // every float v in [0, 1] (tools/prove_exact.c P15, exhaustive); the other kernels of this file use mul + add (P10)
             const float yr = __builtin_fmaf(rr, p.fast.out_scale, p.fast.pred_half), yg = __builtin_fmaf(gg, p.fast.out_scale, p.fast.pred_half),
                         yb = __builtin_fmaf(bb, p.fast.out_scale, p.fast.pred_half);
-            uint32_t w = px[j];
+            uint32_t w = px[g0 + j];
             asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yr));
             asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yg));
             asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
-            px[j] = w;
+            px[g0 + j] = w;
+        }
         }
         if (valid) {
             u32x4_t *dst = reinterpret_cast<u32x4_t *>(out + (y * out_stride + x * 4));
