@@ -268,7 +268,7 @@ def main():
             fb = vfx.make_frame(src[1].data_ptr(), w, h, w * 4, "RGBA")
             d = ctypes.c_double()
             ms = timeit(lambda i=0: vfx.check(lib.mvfx_ssim_distance(ctypes.byref(fa), ctypes.byref(fb), ctypes.byref(d), sptr)), iters=10, settle_s=0.5)
-            report(f"videocompare dssim {tag} RGBA pair (5 scales, f64)", ms, 2 * w * h * 4, 1, {"distance": d.value})
+            report(f"videocompare dssim {tag} RGBA pair (5 scales, f32 pipeline)", ms, 2 * w * h * 4, 1, {"distance": d.value})
 
     if want("roundedcorners"):
         mask = torch.empty(W * H, dtype=torch.uint8, device=dev)
