@@ -79,15 +79,57 @@ __device__ __forceinline__ float lab_f(float t)
     return t > eps ? cb : lin;
 }
 
+#ifndef MVFX_SSIM_CBRT_TABLE
+#define MVFX_SSIM_CBRT_TABLE 0 // 1: cube roots from an LDS seed table + two Newton steps instead of log2 / exp2 + one step.  Measured: SLOWER,
+                               // 8K pair 0.660 -> 0.739 ms (1515 -> 1353 pairs/s): six more random LDS reads per pixel pair and a longer
+                               // dependent chain cost more than the two quarter-rate instructions they replace (profiles/r3/ssim32_cbrt_table_ab.txt)
+#endif
+// The seed table: t^(-1/3) at the centre of every bin of the top 15 bits of a float (sign, exponent, 6 mantissa bits) between
+// eps = 216/24389 and 1.1 -- 447 bins, relative width 1/64, seed error <= 0.27 %.  Two Newton steps y <- y (4 - t y^3) / 3 square that
+// to 1.5e-5 and then below the rounding of an f32; log2 / exp2 (quarter rate) are gone from the pixel path.
+constexpr uint32_t kCbrtLo = 0x3C111A6Cu >> 17; // bits(216 / 24389 = 0.008856452) >> 17
+constexpr uint32_t kCbrtBins = 448;
+
+__device__ __forceinline__ void cbrt_table_fill(float *table, uint32_t tid, uint32_t nthreads)
+{
+    for (uint32_t i = tid; i < kCbrtBins; i += nthreads) {
+        const float centre = __uint_as_float(((kCbrtLo + i) << 17) | (1u << 16));
+        table[i] = __builtin_amdgcn_exp2f(-0.33333334f * __builtin_amdgcn_logf(centre));
+    }
+}
+
+__device__ __forceinline__ float cbrt_seeded(float t, const float *table)
+{
+    const uint32_t bin = min((__float_as_uint(t) >> 17) - kCbrtLo, kCbrtBins - 1); // below eps: wraps, clamped; the caller's select drops it
+    float y = table[bin];
+    const float a = -0.33333334f * t;
+    y = y * __builtin_fmaf(a, y * y * y, 1.3333334f);
+    y = y * __builtin_fmaf(a, y * y * y, 1.3333334f);
+    return t * (y * y);
+}
+
+__device__ __forceinline__ float lab_f(float t, const float *cbrt_table)
+{
+#if MVFX_SSIM_CBRT_TABLE
+    const float eps = 216.0f / 24389.0f, kappa = 24389.0f / 27.0f;
+    const float lin = __builtin_fmaf(kappa / 116.0f, t, 16.0f / 116.0f);
+    float cb = cbrt_seeded(t, cbrt_table);
+    asm volatile("" : "+v"(cb));
+    return t > eps ? cb : lin;
+#else
+    return lab_f(t);
+#endif
+}
+
 // linear RGB (premultiplied) of the same pixel of both images -> the three planes of both, as pairs (oracle: to_lab)
-__device__ __forceinline__ void to_lab2(f2 r, f2 g, f2 b, f2 out[3])
+__device__ __forceinline__ void to_lab2(f2 r, f2 g, f2 b, f2 out[3], const float *ct)
 {
     // the white-point divisions are folded into the matrix rows (X / 0.9505, Z / 1.089): one rounding less per value than the oracle's
     // two steps, inside the tolerance of this pipeline (tests/test_ssim_gpu.py)
     const f2 X = fma2(splat(0.1805f / 0.9505f), b, fma2(splat(0.3576f / 0.9505f), g, splat(0.4124f / 0.9505f) * r));
     const f2 Y = fma2(splat(0.0722f), b, fma2(splat(0.7152f), g, splat(0.2126f) * r));
     const f2 Z = fma2(splat(0.9505f / 1.089f), b, fma2(splat(0.1192f / 1.089f), g, splat(0.0193f / 1.089f) * r));
-    const f2 fx = {lab_f(X.x), lab_f(X.y)}, fy = {lab_f(Y.x), lab_f(Y.y)}, fz = {lab_f(Z.x), lab_f(Z.y)};
+    const f2 fx = {lab_f(X.x, ct), lab_f(X.y, ct)}, fy = {lab_f(Y.x, ct), lab_f(Y.y, ct)}, fz = {lab_f(Z.x, ct), lab_f(Z.y, ct)};
     out[0] = fma2(splat(1.16f), fy, splat(-0.16f));
     out[1] = fma2(splat(500.0f / 220.0f), fx - fy, splat(86.2f / 220.0f));
     out[2] = fma2(splat(200.0f / 220.0f), fy - fz, splat(107.9f / 220.0f));
@@ -200,10 +242,10 @@ __global__ __launch_bounds__(kThreads) void ssim32_level_kernel(LevelArgs A)
     __shared__ f2 s_centre[3];
     __shared__ double s_part[kThreads / 64];
     const int tx0 = blockIdx.x * kTW, ty0 = A.cover_lo + blockIdx.y * kTH;
-    if (MODE != 2) {
-        s_lut[threadIdx.x] = A.lut[threadIdx.x];
-        __syncthreads();
-    }
+    __shared__ float s_cbrt[MVFX_SSIM_CBRT_TABLE ? kCbrtBins : 1];
+    if (MVFX_SSIM_CBRT_TABLE) cbrt_table_fill(s_cbrt, threadIdx.x, kThreads);
+    if (MODE != 2) s_lut[threadIdx.x] = A.lut[threadIdx.x];
+    if (MVFX_SSIM_CBRT_TABLE || MODE != 2) __syncthreads();
 
     // ---- fetch + convert: thread t owns the 2x2 blocks t and t + 256 of the haloed tile ---------------------------------
     f2 lab[2][4][3]; // [block][pixel of the block][channel]
@@ -221,7 +263,7 @@ __global__ __launch_bounds__(kThreads) void ssim32_level_kernel(LevelArgs A)
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 box[0] += r[k]; box[1] += g[k]; box[2] += b[k];
-                to_lab2(r[k], g[k], b[k], lab[k2][2 * j + k]);
+                to_lab2(r[k], g[k], b[k], lab[k2][2 * j + k], s_cbrt);
             }
         }
         // the pyramid: 2x2 box of the LINEAR values of the interior blocks -> next level's planes (oracle: downsample)
