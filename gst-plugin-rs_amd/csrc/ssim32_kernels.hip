@@ -84,6 +84,7 @@ __device__ __forceinline__ float lab_f(float t)
                                // 8K pair 0.660 -> 0.739 ms (1515 -> 1353 pairs/s): six more random LDS reads per pixel pair and a longer
                                // dependent chain cost more than the two quarter-rate instructions they replace (profiles/r3/ssim32_cbrt_table_ab.txt)
 #endif
+#if MVFX_SSIM_CBRT_TABLE
 // The seed table: t^(-1/3) at the centre of every bin of the top 15 bits of a float (sign, exponent, 6 mantissa bits) between
 // eps = 216/24389 and 1.1 -- 447 bins, relative width 1/64, seed error <= 0.27 %.  Two Newton steps y <- y (4 - t y^3) / 3 square that
 // to 1.5e-5 and then below the rounding of an f32; log2 / exp2 (quarter rate) are gone from the pixel path.
@@ -107,6 +108,8 @@ __device__ __forceinline__ float cbrt_seeded(float t, const float *table)
     y = y * __builtin_fmaf(a, y * y * y, 1.3333334f);
     return t * (y * y);
 }
+
+#endif
 
 __device__ __forceinline__ float lab_f(float t, const float *cbrt_table)
 {
@@ -242,8 +245,10 @@ __global__ __launch_bounds__(kThreads) void ssim32_level_kernel(LevelArgs A)
     __shared__ f2 s_centre[3];
     __shared__ double s_part[kThreads / 64];
     const int tx0 = blockIdx.x * kTW, ty0 = A.cover_lo + blockIdx.y * kTH;
-    __shared__ float s_cbrt[MVFX_SSIM_CBRT_TABLE ? kCbrtBins : 1];
-    if (MVFX_SSIM_CBRT_TABLE) cbrt_table_fill(s_cbrt, threadIdx.x, kThreads);
+    __shared__ float s_cbrt[MVFX_SSIM_CBRT_TABLE ? 448 : 1];
+#if MVFX_SSIM_CBRT_TABLE
+    cbrt_table_fill(s_cbrt, threadIdx.x, kThreads);
+#endif
     if (MODE != 2) s_lut[threadIdx.x] = A.lut[threadIdx.x];
     if (MVFX_SSIM_CBRT_TABLE || MODE != 2) __syncthreads();
 
