@@ -707,7 +707,14 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
         const uint32_t y = y0 + row;
         const bool valid = x < width && y < height; // width % 4 == 0 (launcher): a lane's pixels are all inside or all outside
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (valid) v = *reinterpret_cast<const uint4 *>(in + (y * in_stride + x * kBpp));
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        if (valid) {
+            if constexpr (WIDE) { // streamed once: non-temporal, the cell table keeps the L2 (as in colorlut_xtile_kernel)
+                const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(in + (y * in_stride + x * kBpp)));
+                v = make_uint4(t.x, t.y, t.z, t.w);
+            } else
+                v = *reinterpret_cast<const uint4 *>(in + (y * in_stride + x * kBpp));
+        }
         if (row == 0) {
             if constexpr (!WIDE) __syncthreads(); // coordinate table complete
         }
@@ -746,8 +753,12 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
             tile_cell((lds_bytes_t)&nbr[0][0], wave_lds_bytes, p, ix[j], iy[j], iz[j], ax, ay, az, c);
             float r, g, b;
             lf_trilinear<true>(c, fx[j], fy[j], fz[j], r, g, b);
-            const float yr = r * p.fast.out_scale + p.fast.pred_half, yg = g * p.fast.out_scale + p.fast.pred_half,
-                        yb = b * p.fast.out_scale + p.fast.pred_half;
+            // RGBA64: float_to_u16 as one fused multiply-add, trunc(fma(v, 65535, 0.5)) == round(v * 65535) for every float v in [0, 1]
+            // (tools/prove_exact.c P15; with pred(0.5) two floats fail for 65535, with 0.5 none); RGBA8 keeps mul + add (P10) here --
+            // this kernel is the round-2 reference of the A/B runs
+            const float yr = WIDE ? __builtin_fmaf(r, p.fast.out_scale, 0.5f) : r * p.fast.out_scale + p.fast.pred_half,
+                        yg = WIDE ? __builtin_fmaf(g, p.fast.out_scale, 0.5f) : g * p.fast.out_scale + p.fast.pred_half,
+                        yb = WIDE ? __builtin_fmaf(b, p.fast.out_scale, 0.5f) : b * p.fast.out_scale + p.fast.pred_half;
             if constexpr (WIDE) {
                 uint32_t ro = (uint32_t)__float2uint_rz(yr), go = (uint32_t)__float2uint_rz(yg), bo = (uint32_t)__float2uint_rz(yb);
                 if constexpr (!LE) { ro = bswap16(ro); go = bswap16(go); bo = bswap16(bo); }
@@ -763,7 +774,8 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
         }
         if (valid) {
             if constexpr (WIDE) {
-                *reinterpret_cast<uint4 *>(out + (y * out_stride + x * kBpp)) = make_uint4(px[0], px_hi[0], px[1], px_hi[1]);
+                const u32x4_t t = {px[0], px_hi[0], px[1], px_hi[1]};
+                __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t *>(out + (y * out_stride + x * kBpp)));
             } else {
                 *reinterpret_cast<uint4 *>(out + (y * out_stride + x * 4)) = make_uint4(px[0], px[1], px[2], px[3]);
             }
