@@ -124,7 +124,7 @@ static GstFlowReturn gst_color_lut_bt_transform(GstBaseTransform *bt, GstBuffer 
             gst_buffer_unmap(inbuf, &imap);
             return GST_FLOW_ERROR;
         }
-        mvfx_stream st = mvfx_element_stream();
+        mvfx_stream st = mvfx_element_stream(inbuf);
         mvfx_hip_buffer_acquire(inbuf, st);
         mvfx_hip_buffer_acquire(outbuf, st);
         int rc = mvfx_colorlut_transform_i420(self->lut, &pi, &po, 0, st);
@@ -142,7 +142,7 @@ static GstFlowReturn gst_color_lut_bt_transform(GstBaseTransform *bt, GstBuffer 
         return GST_FLOW_ERROR;
     }
     // fences instead of a host wait per buffer (d3d12colorlut/imp.rs:695-714)
-    mvfx_stream st = mvfx_element_stream();
+    mvfx_stream st = mvfx_element_stream(inbuf);
     mvfx_hip_buffer_acquire(inbuf, st);
     mvfx_hip_buffer_acquire(outbuf, st);
     int rc = mvfx_colorlut_transform_frame(self->lut, &fi, &fo, st);

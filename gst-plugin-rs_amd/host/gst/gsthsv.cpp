@@ -136,7 +136,7 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
         gst_buffer_unmap(buf, &map);
         return MVFX_GST_FLOW(self, rc);
     }
-    mvfx_stream st = mvfx_element_stream();
+    mvfx_stream st = mvfx_element_stream(buf);
     mvfx_hip_buffer_acquire(buf, st);
     rc = combine == 1 ? mvfx_hsvfilter_transform_frame_ip_combined(&f, &s, st) : mvfx_hsvfilter_transform_frame_ip(&f, &s, st);
     mvfx_hip_buffer_release(buf, st);
@@ -327,7 +327,7 @@ static GstFlowReturn gst_hsv_detector_bt_transform(GstBaseTransform *bt, GstBuff
         gst_buffer_unmap(inbuf, &imap);
         return GST_FLOW_ERROR;
     }
-    mvfx_stream st = mvfx_element_stream();
+    mvfx_stream st = mvfx_element_stream(inbuf);
     mvfx_hip_buffer_acquire(inbuf, st);
     mvfx_hip_buffer_acquire(outbuf, st);
     int rc = i420 ? mvfx_hsvdetector_transform_i420(&pi, &fo, &s, 0, st) : mvfx_hsvdetector_transform_frame(&fi, &fo, &s, st);

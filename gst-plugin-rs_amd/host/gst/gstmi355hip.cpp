@@ -365,6 +365,13 @@ static GstFlowReturn hiptestsrc_fill(GstPushSrc *psrc, GstBuffer *buf)
 {
     GstMi355HipTestSrc *self = (GstMi355HipTestSrc *)psrc;
     if (!self->have_info) return GST_FLOW_NOT_NEGOTIATED;
+    // timestamps first: the stream the device copy below runs on is picked from the buffer's frame number (mvfx_element_stream)
+    const GstClockTime dur = GST_VIDEO_INFO_FPS_N(&self->info) > 0
+        ? gst_util_uint64_scale_int(GST_SECOND, GST_VIDEO_INFO_FPS_D(&self->info), GST_VIDEO_INFO_FPS_N(&self->info)) : GST_CLOCK_TIME_NONE;
+    GST_BUFFER_PTS(buf) = GST_CLOCK_TIME_IS_VALID(dur) ? self->n * dur : GST_CLOCK_TIME_NONE;
+    GST_BUFFER_DTS(buf) = GST_CLOCK_TIME_NONE;
+    GST_BUFFER_DURATION(buf) = dur;
+    GST_BUFFER_OFFSET(buf) = self->n++;
     GstMemory *mem = gst_buffer_peek_memory(buf, 0);
     if (self->hip && self->master && mvfx_buffer_is_hip(buf)) {
         GstMapInfo map;
@@ -373,7 +380,7 @@ static GstFlowReturn hiptestsrc_fill(GstPushSrc *psrc, GstBuffer *buf)
         // refresh=false (throughput measurements of a filter alone): a block is filled on its first trip only -- an in-place filter
         // downstream then works on its own output from the second trip on, and the source costs no HBM traffic
         if (self->refresh || !gst_mini_object_get_qdata(GST_MINI_OBJECT_CAST(mem), hiptestsrc_filled_quark())) {
-            mvfx_stream st = mvfx_thread_stream();
+            mvfx_stream st = mvfx_element_stream(buf); // the stream the filters downstream will pick for this frame
             mvfx_hip_buffer_acquire(buf, st);
             rc = mvfx_copy_device_to_device_async(map.data, self->master, MIN(self->pattern_size, map.size), st);
             mvfx_hip_buffer_release(buf, st);
@@ -388,12 +395,6 @@ static GstFlowReturn hiptestsrc_fill(GstPushSrc *psrc, GstBuffer *buf)
         gst_buffer_unmap(buf, &map);
         gst_mini_object_set_qdata(GST_MINI_OBJECT_CAST(mem), hiptestsrc_filled_quark(), GINT_TO_POINTER(1), NULL);
     }
-    const GstClockTime dur = GST_VIDEO_INFO_FPS_N(&self->info) > 0
-        ? gst_util_uint64_scale_int(GST_SECOND, GST_VIDEO_INFO_FPS_D(&self->info), GST_VIDEO_INFO_FPS_N(&self->info)) : GST_CLOCK_TIME_NONE;
-    GST_BUFFER_PTS(buf) = GST_CLOCK_TIME_IS_VALID(dur) ? self->n * dur : GST_CLOCK_TIME_NONE;
-    GST_BUFFER_DTS(buf) = GST_CLOCK_TIME_NONE;
-    GST_BUFFER_DURATION(buf) = dur;
-    GST_BUFFER_OFFSET(buf) = self->n++;
     return GST_FLOW_OK;
 }
 

@@ -180,22 +180,34 @@ static inline GstFlowReturn mvfx_hip_new_output(GstBaseTransform *trans, GstBuff
         return GST_BASE_TRANSFORM_CLASS(parent_class_ptr)->decide_allocation(trans, query);                           \
     }
 
-// The HIP stream a device-memory filter enqueues THIS buffer on.  Consecutive buffers of a video stream are independent frames and every
-// buffer carries its own fence, so a streaming thread may rotate over several private streams (mvfx_thread_stream_n): the tail of one
-// frame's kernel then overlaps the head of the next one's instead of running back to back on one stream (4K hsvfilter, one streaming
-// thread: profiles/r3/stream_rotation.txt).  MVFX_ELEMENT_STREAMS = 1..4 (environment, read once).
+// The HIP stream a device-memory element enqueues THIS buffer on.  Consecutive buffers of a video stream are independent frames and
+// every buffer carries its own fence, so a streaming thread may alternate between private streams (mvfx_thread_stream_n): the tail
+// of one frame's kernel then overlaps the head of the next one's instead of running back to back on one stream (4K hsvfilter, one
+// streaming thread: 0.52 -> 0.67 of the HBM peak, profiles/r3/stream_rotation.txt).  The index comes from the BUFFER -- its frame
+// number pts / duration, else its offset -- not from a counter of the element: every element of a chain then puts the same frame on the
+// same stream (no cross-stream fence wait inside a frame's chain; a per-element counter cost the three-filter chain 20 %), and
+// consecutive frames alternate.  MVFX_ELEMENT_STREAMS = 1..4 (environment, read once).
 #ifndef MVFX_ELEMENT_STREAMS_DEFAULT
-#define MVFX_ELEMENT_STREAMS_DEFAULT 1
+#define MVFX_ELEMENT_STREAMS_DEFAULT 2
 #endif
-static inline mvfx_stream mvfx_element_stream(void)
+static inline mvfx_stream mvfx_element_stream(GstBuffer *buf)
 {
     static const guint n = [] {
         const gchar *e = g_getenv("MVFX_ELEMENT_STREAMS");
         const int v = e ? atoi(e) : MVFX_ELEMENT_STREAMS_DEFAULT;
         return (guint)CLAMP(v, 1, 4);
     }();
-    static thread_local guint counter = 0;
-    return mvfx_thread_stream_n(n > 1 ? counter++ % n : 0);
+    if (n == 1) return mvfx_thread_stream();
+    guint64 frame;
+    if (buf && GST_BUFFER_PTS_IS_VALID(buf) && GST_BUFFER_DURATION_IS_VALID(buf) && GST_BUFFER_DURATION(buf) > 0)
+        frame = (GST_BUFFER_PTS(buf) + GST_BUFFER_DURATION(buf) / 2) / GST_BUFFER_DURATION(buf);
+    else if (buf && GST_BUFFER_OFFSET_IS_VALID(buf))
+        frame = GST_BUFFER_OFFSET(buf);
+    else {
+        static thread_local guint64 counter = 0;
+        frame = counter++;
+    }
+    return mvfx_thread_stream_n((guint)(frame % n));
 }
 
 static inline void mvfx_add_pad_templates(GstElementClass *klass, GstCaps *sink_caps, GstCaps *src_caps)

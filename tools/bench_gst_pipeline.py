@@ -77,6 +77,7 @@ def branches_main(args):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="comma-separated pipeline names of the chain mode (default: all)")
     ap.add_argument("--branches", type=int, default=0, help="N parallel hiptestsrc ! hsvfilter ! fakesink streams in one process (launch combiner A/B)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -112,12 +113,18 @@ def main():
                               f"{chain.format(rgba='video/x-raw(memory:HIPMemory),format=RGBA')} ! fakesink sync=false"),
     }
     out = {"frame": f"{w}x{h}", "chain": f"hsvfilter ! hsvdetector ! colorlut({args.lut}^3)", "n1": args.n1, "n2": args.n2}
+    only = [x for x in args.only.split(",") if x]
     for name, tpl in pipes.items():
+        if only and name not in only:
+            continue
         # the device-only chain runs ~10 k frames/s: 400 frames are 40 ms, inside the noise of a process start -- 10x the frames there
         n1, n2 = (args.n1 * 10, args.n2 * 10) if name == "device_only_chain" else (args.n1, args.n2)
         v, t1, t2 = fps(tpl, tmp, n1, n2)
         out[name + "_fps"] = round(v, 1)
         out[name + "_seconds"] = [round(t1, 3), round(t2, 3)]
+    if only:
+        print(json.dumps(out), flush=True)
+        return
     # the same HIP chain with pageable staging (what round 1 shipped): upload source and download target malloc'ed
     v, t1, t2 = fps(pipes["hip_chain"], tmp, args.n1, args.n2, {"MVFX_HIP_PAGEABLE": "1"})
     out["hip_chain_pageable_staging_fps"] = round(v, 1)
