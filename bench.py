@@ -1034,7 +1034,7 @@ def hsvfilter_main(args):
     launch_pct = percentiles(w.event_times(step, args.pct_steps, first_index=args.steps)) if args.pct_steps > 0 else None
 
     # ---- the element's launch model: --batch host threads x own HIP stream x single-frame calls -----------
-    streams = combined = None
+    streams = combined = single_stream = None
     if args.stream_threads > 0:
         hb = bench_harness()
         nthr = args.stream_threads
@@ -1076,6 +1076,27 @@ def hsvfilter_main(args):
 
         streams = threads_leg(1, f"{nthr} threads x 1 frame (own HIP stream each, single-frame mvfx_hsvfilter_transform_frame_ip, "
                                  "no sync between launches; warm-up on scratch frames)")
+        # ONE video stream: one host thread making single-frame calls, on one private HIP stream and alternating between two (what the
+        # GStreamer elements do per buffer since round 3, MVFX_ELEMENT_STREAMS = 2: the next frame's head overlaps the previous one's tail).
+        # It runs AFTER the 16-thread leg on purpose: its thread then gets a pair of streams that an exited thread left in the library's pool,
+        # and a pair that shares a hardware queue would not overlap (capi_common.hip, StreamBundle)
+        def one_thread_leg(streams_per_thread):
+            n1 = 2000
+            secs = (ctypes.c_double * reps)()
+            per = (ctypes.c_double * 1)()
+            w.sync()
+            w.barrier()
+            rc = hb.mvfxbench_hsvfilter_streams_rot(w.device_index, 1, streams_per_thread, 200, n1, reps, flat, nthr * fpt, warm, nthr * wfpt,
+                                                    ctypes.byref(settings), opts, secs, per)
+            if rc != 0:
+                raise RuntimeError(f"mvfxbench status {rc}: {vfx.last_error()}")
+            w.barrier()
+            (med,) = w.max_over_ranks(sorted(secs)[reps // 2])
+            fps1 = n1 * world / med
+            return {"launch_model": f"1 thread x single-frame calls alternating between {streams_per_thread} private HIP stream(s)", "value": fps1,
+                    "unit": "frames/s", "launches": n1, "statistic": "median of 5 repetitions",
+                    "frac_wall": fps1 / world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS}
+        single_stream = {"one_stream": one_thread_leg(1), "two_streams": one_thread_leg(2)}
         # the launch combiner: the same threads make the same single-frame calls, the library coalesces them into batched launches
         nb, nf = ctypes.c_uint64(), ctypes.c_uint64()
         lib.mvfx_combiner_stats(w.device_index, ctypes.byref(nb), ctypes.byref(nf))
@@ -1138,6 +1159,7 @@ def hsvfilter_main(args):
                                "saturation-off=-0.05 value-mul=0.9 value-off=0.02",
                    "frame_content": args.frame_content, "other_frame_contents": sweep,
                    "launch_model": head["launch_model"], "other_launch_model": other, "combined_launch_model": combined,
+                   "one_video_stream_launch_models": single_stream,
                    "frames_per_step_per_gpu": args.batch, "resident_batches": pool, "steps_executed": n_launches[0],
                    "settle_seconds_before_warmup": args.settle_seconds, "settle_steps": settle_steps,
                    "parallelism": f"{world} independent stream shards, no data-path collective",

@@ -38,35 +38,36 @@ struct DeviceState {
     bool extra_tried[3] = {false, false, false};
     hipStream_t stream = nullptr;
     bool stream_tried = false;
+    bool bundle_tried = false; // the pool of exited threads' streams has been asked once
     int device = 0;
 };
-// The private streams of threads that have exited, per device, for the next thread that asks for one.  Streams are never destroyed:
+// The private streams of threads that have exited, per device, for the next thread that asks.  Streams are never destroyed:
 // sixteen GStreamer streaming threads leaving at end-of-stream called hipStreamDestroy concurrently and the runtime (ROCm 7.2) crashed
 // inside it about two runs in three with two streams per thread (tools/exp_rot2_crash.py, backtrace via tools/segv_trace.c: two threads
 // in ~ThreadState -> hipStreamDestroy at once).  A recycled stream may still have its previous owner's work queued: that only orders
-// ahead of the new owner's.  The pool is bounded by the largest number of threads alive at the same time; it is leaked on purpose
-// (threads may exit after the static destructors ran).
+// ahead of the new owner's.
+// A thread's streams are pooled and handed out as ONE BUNDLE: the runtime binds a stream to one of its few hardware queues when the
+// stream is created (the least loaded one: a thread that creates its streams one after the other gets them on different queues), and
+// kernels of two streams that share a hardware queue do not overlap.  Handing out single streams in any order gave a thread two
+// streams of one queue and the gain of alternating between them was gone (one thread, 4K hsvfilter: 64.9 k fps on such a pair, 80.9 k
+// on a pair created together -- bench.py config.one_video_stream_launch_models).  The pool is bounded by the largest number of threads
+// alive at the same time; it is leaked on purpose (threads may exit after the static destructors ran).
+struct StreamBundle {
+    hipStream_t stream = nullptr;                         // mvfx_thread_stream() = mvfx_thread_stream_n(0)
+    hipStream_t extra[3] = {nullptr, nullptr, nullptr};   // mvfx_thread_stream_n(1..3)
+    bool any() const { return stream || extra[0] || extra[1] || extra[2]; }
+};
 struct IdleStreams {
     std::mutex lock;
-    std::map<int, std::vector<hipStream_t>> by_device;
+    std::map<int, std::vector<StreamBundle>> by_device;
 };
 IdleStreams &idle_streams()
 {
     static IdleStreams *pool = new IdleStreams;
     return *pool;
 }
-hipStream_t take_stream(int device)
+hipStream_t new_stream()
 {
-    {
-        IdleStreams &pool = idle_streams();
-        std::lock_guard<std::mutex> g(pool.lock);
-        std::vector<hipStream_t> &v = pool.by_device[device];
-        if (!v.empty()) {
-            hipStream_t s = v.back();
-            v.pop_back();
-            return s;
-        }
-    }
     hipStream_t s = nullptr;
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
         (void)hipGetLastError();
@@ -74,12 +75,37 @@ hipStream_t take_stream(int device)
     }
     return s;
 }
-void give_back_stream(int device, hipStream_t s)
+// the bundle of an exited thread (the one with the most streams in it first), or an empty one
+void adopt_bundle(DeviceState &d)
 {
-    if (!s) return;
+    if (d.bundle_tried) return;
+    d.bundle_tried = true;
     IdleStreams &pool = idle_streams();
     std::lock_guard<std::mutex> g(pool.lock);
-    pool.by_device[device].push_back(s);
+    std::vector<StreamBundle> &v = pool.by_device[d.device];
+    if (v.empty()) return;
+    size_t best = 0;
+    auto count = [](const StreamBundle &b) { return (b.stream != nullptr) + (b.extra[0] != nullptr) + (b.extra[1] != nullptr) + (b.extra[2] != nullptr); };
+    for (size_t i = 1; i < v.size(); i++)
+        if (count(v[i]) > count(v[best])) best = i;
+    const StreamBundle b = v[best];
+    v.erase(v.begin() + (long)best);
+    d.stream = b.stream;
+    d.stream_tried = b.stream != nullptr;
+    for (int k = 0; k < 3; k++) {
+        d.extra[k] = b.extra[k];
+        d.extra_tried[k] = b.extra[k] != nullptr;
+    }
+}
+void give_back_bundle(int device, const DeviceState &d)
+{
+    StreamBundle b;
+    b.stream = d.stream;
+    for (int k = 0; k < 3; k++) b.extra[k] = d.extra[k];
+    if (!b.any()) return;
+    IdleStreams &pool = idle_streams();
+    std::lock_guard<std::mutex> g(pool.lock);
+    pool.by_device[device].push_back(b);
 }
 
 struct ThreadState {
@@ -99,8 +125,7 @@ struct ThreadState {
                 if (s.ptr) (void)hipFree(s.ptr);
             for (StreamScratch &s : kv.second.by_stream)
                 if (s.block.ptr) (void)hipFree(s.block.ptr);
-            give_back_stream(kv.first, kv.second.stream);
-            for (hipStream_t e : kv.second.extra) give_back_stream(kv.first, e);
+            give_back_bundle(kv.first, kv.second);
         }
     }
 };
@@ -209,9 +234,14 @@ int stream_scratch(hipStream_t stream, size_t bytes, void **out)
 hipStream_t host_stream()
 {
     DeviceState &d = t_state.current();
+    adopt_bundle(d);
     if (!d.stream_tried) {
         d.stream_tried = true;
-        d.stream = take_stream(d.device); // nullptr (the null stream) when none can be created
+        d.stream = new_stream(); // nullptr (the null stream) when none can be created
+        if (!d.extra_tried[0]) { // its partner right behind it (a different hardware queue: see StreamBundle), whether or not it is used
+            d.extra_tried[0] = true;
+            d.extra[0] = new_stream();
+        }
     }
     return d.stream;
 }
@@ -221,9 +251,10 @@ hipStream_t host_stream_n(uint32_t index)
     if (index == 0) return host_stream();
     DeviceState &d = t_state.current();
     const uint32_t k = (index - 1) % 3;
+    (void)host_stream(); // adopts a pooled bundle or creates stream 0 and its partner first
     if (!d.extra_tried[k]) {
         d.extra_tried[k] = true;
-        d.extra[k] = take_stream(d.device);
+        d.extra[k] = new_stream();
     }
     return d.extra[k] ? d.extra[k] : host_stream();
 }
