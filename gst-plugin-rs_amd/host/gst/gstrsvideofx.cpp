@@ -440,12 +440,12 @@ static GstFlowReturn gst_rounded_corners_prepare_output_buffer(GstBaseTransform 
         pi.height = po.height = (uint32_t)GST_VIDEO_INFO_HEIGHT(&self->out_info);
         pi.format = MVFX_FORMAT_I420;
         po.format = MVFX_FORMAT_A420;
-        mvfx_hip_buffer_acquire(inbuf, mvfx_thread_stream());
-        mvfx_hip_buffer_acquire(out, mvfx_thread_stream());
-        int rc = mvfx_roundedcorners_compose_a420(&pi, amap.data, (uint32_t)GST_VIDEO_INFO_PLANE_STRIDE(&self->out_info, 3), &po,
-                                                  mvfx_thread_stream());
-        mvfx_hip_buffer_release(inbuf, mvfx_thread_stream());
-        mvfx_hip_buffer_release(out, mvfx_thread_stream());
+        const mvfx_stream st = mvfx_element_stream(inbuf); // per frame, as the hsv / colorlut elements pick it (the mask was uploaded synchronously)
+        mvfx_hip_buffer_acquire(inbuf, st);
+        mvfx_hip_buffer_acquire(out, st);
+        int rc = mvfx_roundedcorners_compose_a420(&pi, amap.data, (uint32_t)GST_VIDEO_INFO_PLANE_STRIDE(&self->out_info, 3), &po, st);
+        mvfx_hip_buffer_release(inbuf, st);
+        mvfx_hip_buffer_release(out, st);
         gst_memory_unmap(self->alpha_mem, &amap);
         gst_buffer_unmap(out, &omap);
         gst_buffer_unmap(inbuf, &imap);
