@@ -190,6 +190,7 @@ SIGNATURES = {
     "mvfx_comm_allreduce": (c_int, [c_void_p, c_void_p, c_size_t, c_int32, c_int32, c_void_p]),
     "mvfx_videocompare_sharded_distances": (c_int, [c_void_p, POINTER(Frame), c_uint32, c_uint32, c_uint32, POINTER(ctypes.c_double),
                                                     POINTER(c_uint64), c_void_p]),
+    "mvfx_videocompare_sharded_dssim": (c_int, [c_void_p, POINTER(Frame), POINTER(Frame), c_uint32, c_uint32, POINTER(ctypes.c_double), c_void_p]),
     "mvfx_image_hash": (c_int, [POINTER(Frame), ctypes.c_int32, POINTER(c_uint64), POINTER(c_uint32), c_void_p]),
     "mvfx_image_hash_host": (c_int, [POINTER(Frame), ctypes.c_int32, POINTER(c_uint64), POINTER(c_uint32)]),
     "mvfx_image_gray_resize_lanczos3": (c_int, [POINTER(Frame), c_uint32, c_uint32, c_void_p, c_void_p]),
@@ -451,6 +452,15 @@ def videocompare_sharded_distances(comm, bands, full_height, band_first_row, str
                                                     hashes, stream))
     d = [out[i] for i in range(n - 1)]
     return (d, [hashes[i] for i in range(n)]) if want_hashes else d
+
+
+def videocompare_sharded_dssim(comm, frame_a, frame_b, row_begin, row_end, stream=None):
+    """hash-algo=dssim of a pair whose rows are shared out over the ranks of `comm` (None: one GPU): this rank maps rows
+    [row_begin, row_end) of the whole frames it holds; both all-reduces happen inside the library (RCCL)."""
+    out = ctypes.c_double()
+    check(lib().mvfx_videocompare_sharded_dssim(comm.h if comm is not None else None, ctypes.byref(frame_a), ctypes.byref(frame_b), row_begin,
+                                                row_end, ctypes.byref(out), stream))
+    return out.value
 
 
 HASH_ALGOS = {"mean": 0, "gradient": 1, "vertgradient": 2, "doublegradient": 3, "blockhash": 4, "dssim": 5}

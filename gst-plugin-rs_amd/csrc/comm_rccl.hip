@@ -234,4 +234,38 @@ int mvfx_videocompare_sharded_distances(mvfx_comm *comm, const mvfx_frame *bands
     return MVFX_OK;
 }
 
+int mvfx_videocompare_sharded_dssim(mvfx_comm *comm, const mvfx_frame *reference_frame, const mvfx_frame *other_frame,
+                                    uint32_t row_begin, uint32_t row_end, double *distance_out, mvfx_stream stream)
+{
+    if (!reference_frame || !other_frame || !distance_out)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "videocompare dssim: NULL frame or output");
+    hipStream_t st = as_stream(stream);
+    double sums[5] = {}, counts[5] = {};
+    uint32_t n_scales = 0;
+    if (int rc = mvfx_ssim_partial_sums(reference_frame, other_frame, row_begin, row_end, sums, counts, &n_scales, stream); rc != MVFX_OK) return rc;
+    double tot[10];
+    for (int i = 0; i < 5; i++) { tot[i] = sums[i]; tot[5 + i] = counts[i]; }
+    void *scratch = nullptr;
+    if (comm) { // 80 + 40 bytes through the collective; with one rank the band's sums are the totals
+        if (int rc = stream_scratch(st, 16 * sizeof(double), &scratch); rc != MVFX_OK) return rc;
+        MVFX_HIP_TRY(hipMemcpyAsync(scratch, tot, sizeof(tot), hipMemcpyHostToDevice, st));
+        if (int rc = mvfx_comm_allreduce(comm, scratch, 10, MVFX_DTYPE_F64, MVFX_REDUCE_SUM, stream); rc != MVFX_OK) return rc;
+        MVFX_HIP_TRY(hipMemcpyAsync(tot, scratch, sizeof(tot), hipMemcpyDeviceToHost, st));
+        MVFX_HIP_TRY(hipStreamSynchronize(st));
+    }
+    double mean[5], dev[5] = {};
+    for (int i = 0; i < 5; i++) mean[i] = tot[5 + i] != 0.0 ? tot[i] / tot[5 + i] : 0.0;
+    if (int rc = mvfx_ssim_partial_deviation(mean, dev, stream); rc != MVFX_OK) return rc;
+    if (comm) {
+        MVFX_HIP_TRY(hipMemcpyAsync(scratch, dev, sizeof(dev), hipMemcpyHostToDevice, st));
+        if (int rc = mvfx_comm_allreduce(comm, scratch, 5, MVFX_DTYPE_F64, MVFX_REDUCE_SUM, stream); rc != MVFX_OK) return rc;
+        MVFX_HIP_TRY(hipMemcpyAsync(dev, scratch, sizeof(dev), hipMemcpyDeviceToHost, st));
+        MVFX_HIP_TRY(hipStreamSynchronize(st));
+    }
+    double mad[5];
+    for (int i = 0; i < 5; i++) mad[i] = tot[5 + i] != 0.0 ? dev[i] / tot[5 + i] : 0.0;
+    *distance_out = mvfx_ssim_combine(mean, mad, n_scales);
+    return MVFX_OK;
+}
+
 } // extern "C"

@@ -411,6 +411,15 @@ int mvfx_comm_allreduce(mvfx_comm *comm, void *buffer_device, size_t count, int3
 int mvfx_videocompare_sharded_distances(mvfx_comm *comm, const mvfx_frame *bands, uint32_t n_pads, uint32_t full_height,
                                         uint32_t band_first_row, double *distances_out, uint64_t *hashes_out, mvfx_stream stream);
 
+/* The same aggregate for hash-algo=dssim (BASELINE config 5: "videocompare SSIM ... tile-sharded across 8 GPUs with RCCL all-reduce";
+ * hashed_image.rs:49-59,72-75): every rank holds both WHOLE frames (a band's five-level pyramid needs a halo of its neighbours' rows)
+ * and maps rows [row_begin, row_end) only -- band boundaries multiples of 16 or the frame height, the bands of all ranks a partition
+ * of the rows.  mvfx_ssim_partial_sums on the band -> ncclAllReduce(sum) of 10 f64 (per-scale sums and pixel counts) ->
+ * mvfx_ssim_partial_deviation against the global means -> ncclAllReduce(sum) of 5 f64 -> mvfx_ssim_combine: every rank returns the
+ * same distance.  comm == NULL: one GPU (then identical to mvfx_ssim_distance when the band is the whole frame).  Synchronous. */
+int mvfx_videocompare_sharded_dssim(mvfx_comm *comm, const mvfx_frame *reference_frame, const mvfx_frame *other_frame,
+                                    uint32_t row_begin, uint32_t row_end, double *distance_out, mvfx_stream stream);
+
 /* GstVideoCompareHashAlgorithm values (videocompare/mod.rs:57-92) */
 typedef enum mvfx_hash_algo {
     MVFX_HASH_MEAN = 0,

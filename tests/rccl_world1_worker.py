@@ -75,6 +75,12 @@ def main():
     out["ssim"] = D.ssim_sharded(lambda: gpu.ssim_partial_sums(fa, fb, y0, y1, sptr), lambda mean: gpu.ssim_partial_deviation(mean, sptr),
                                  gpu.ssim_combine, dev)
 
+    # the same distance through the library's own communicator (world 1): both all-reduces inside mvfx_videocompare_sharded_dssim
+    comm2 = D.make_comm(gpu, 0, 1)
+    out["ssim_c_entry"] = gpu.videocompare_sharded_dssim(comm2, fa, fb, y0, y1, sptr)
+    out["ssim_c_entry_no_comm"] = gpu.videocompare_sharded_dssim(None, fa, fb, y0, y1, sptr)
+    comm2.destroy()
+
     # colordetect: device histogram -> all-reduce(sum) + min/max -> host median cut
     hist = torch.zeros(32768 + 8, dtype=torch.int32, device=dev)
 

@@ -56,6 +56,8 @@ def test_ssim_and_colordetect_sharded_over_rccl(worker_result):
     b[5::7, 3:w * 4:11] ^= 0x15
     rc, want, _ = orc.ssim_distance(a, b, w, h, w * 4, w * 4, "RGBA")
     assert rc == 0 and worker_result["ssim"] == pytest.approx(want, rel=1e-5, abs=2e-9)  # the default f32 pipeline
+    # mvfx_videocompare_sharded_dssim: the two all-reduces inside the library (RCCL, world 1) and without a communicator -- same bits
+    assert worker_result["ssim_c_entry"] == worker_result["ssim"] == worker_result["ssim_c_entry_no_comm"]
     rc, want_pal = orc.colordetect_palette(a, "RGBA", 10, 5)
     assert rc >= 0 and worker_result["palette"] == [int(x) for x in want_pal]
 
@@ -152,6 +154,7 @@ def test_bench_two_ranks_control_flow_on_one_gpu(gpu, tmp_path):
     assert len(c["per_rank_frames_per_sec"]) == 2
     # whole-job value = frames of both ranks / the slowest rank's time: never more than the sum of the per-rank rates
     assert d["value"] <= sum(c["per_rank_frames_per_sec"]) * 1.0001
-    side = c["other_configs"]["videocompare_blockhash_sharded"]
-    assert "error" in side or side["n_gpus"] == 2
+    for key in ("videocompare_blockhash_sharded", "videocompare_dssim_sharded"):
+        side = c["other_configs"][key]
+        assert "error" in side or side["n_gpus"] == 2, key
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
