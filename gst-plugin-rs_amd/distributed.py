@@ -8,8 +8,9 @@ What shards and how (DESIGN.md "Multi-GPU"):
     every pad's frame): each rank reduces its band to 64 partial block sums per frame, then ONE
     all-reduce(sum) of n_pads x 64 u32 (512 B for a pair) makes the totals visible everywhere and
     every rank derives the hash bits and Hamming distances redundantly (`videocompare_sharded`).
-  * videocompare `hash-algo=dssim`: two all-reduces of 10 f64 each (per-scale sums + counts, then
-    per-scale absolute deviations) around the two map passes (`ssim_sharded`).
+  * videocompare `hash-algo=dssim`: two all-reduces (10 f64: per-scale sums + counts, then 5 f64:
+    per-scale absolute deviations) around the two map passes (`ssim_sharded`; inside the library:
+    `ssim_sharded_device` = mvfx_videocompare_sharded_dssim).
   * colordetect on one distributed frame: all-reduce(sum) of the 32768-bin histogram plus
     min/max of the six channel bounds, then the host median cut on every rank
     (`colordetect_sharded`).
@@ -69,6 +70,13 @@ def videocompare_sharded_device(vfx, comm, bands, full_height: int, band_first_r
     (mvfx_videocompare_sharded_distances; `comm` is a vfx.Comm or None for one GPU).  No host round trip of the sums, no Python bit
     derivation; `videocompare_sharded` above stays as the torch.distributed shim the gloo CPU tests drive."""
     return vfx.videocompare_sharded_distances(comm, bands, full_height, band_first_row, stream)
+
+
+def ssim_sharded_device(vfx, comm, frame_a, frame_b, row_begin: int, row_end: int, stream=None) -> float:
+    """hash-algo=dssim through the library's own collective (round 3): band maps -> ncclAllReduce of 10 f64 -> band deviations ->
+    ncclAllReduce of 5 f64 -> combine, inside mvfx_videocompare_sharded_dssim (`comm` is a vfx.Comm or None for one GPU); `ssim_sharded`
+    below stays as the torch.distributed shim the gloo CPU tests drive."""
+    return vfx.videocompare_sharded_dssim(comm, frame_a, frame_b, row_begin, row_end, stream)
 
 
 def make_comm(vfx, rank: int, world: int, group=None):
