@@ -713,29 +713,37 @@ def make_leg_videofx(w, args):
     host = [rgba[k].cpu().numpy().copy() for k in range(4)] if w.rank == 0 and w.world == 1 else None
     # --element-streams 2: the two elements on their own HIP streams, as with a `queue` between them (two streaming threads:
     # frame k's colordetect overlaps frame k+1's compose); 1: both on one stream, one after the other (one streaming thread)
-    second = torch.cuda.Stream(device=dev) if args.element_streams == 2 else None
-    sptr2 = ctypes.c_void_p(second.cuda_stream) if second is not None else sptr
+    # The two streams are the library's (mvfx_thread_stream_n(0 / 1): created one behind the other, so the runtime binds them to different
+    # hardware queues) -- what two streaming threads get.  Round 3 found that the torch stream used here before shared a hardware queue
+    # with the launch stream: the two elements' kernels never overlapped and the leg measured their SUM instead of the slower one.
+    second = args.element_streams == 2
+    s_a = ctypes.c_void_p(lib.mvfx_thread_stream_n(0)) if second else sptr
+    s_b = ctypes.c_void_p(lib.mvfx_thread_stream_n(1)) if second else sptr
 
     def step(i):
         k = i % pool
         vfx.check(lib.mvfx_roundedcorners_compose_a420(ctypes.byref(planes[k][0]), ctypes.c_void_p(mask.data_ptr()), W,
-                                                       ctypes.byref(planes[k][1]), sptr))
+                                                       ctypes.byref(planes[k][1]), s_a))
         vfx.check(lib.mvfx_colordetect_histogram(ctypes.byref(fr[k]), 10, 0, vfx.ALL_SAMPLES, ctypes.c_void_p(hist.data_ptr()),
-                                                 ctypes.c_void_p(hist.data_ptr() + 32768 * 4), sptr2))
+                                                 ctypes.c_void_p(hist.data_ptr() + 32768 * 4), s_b))
     leg = Leg("videofx", "videofx_frames_per_sec", "frames/s", 1, W * H * 4 + FRAME_BYTES, "u8",
               "synthetic: uniform-random I420 planes (compose), natural-like RGBA frames (colordetect), device-resident",
               "roundedcorners I420->A420 compose (r=100; 1.5 R + 2.5 W B/px) + colordetect histogram (quality=10; 4 touched B/px), one "
-              "3840x2160 stream per GPU, " + ("both elements on one HIP stream (one streaming thread)" if second is None else
+              "3840x2160 stream per GPU, " + ("both elements on one HIP stream (one streaming thread)" if not second else
                                                "the two elements on their own HIP streams (a queue between them: two streaming threads)"),
               step, ["copy_planes_kernel", "colordetect_hist_kernel"],
               cpu=(lambda s: cpu_baseline_videofx(s, host)) if host else None)
-    leg.keep = (i420, a420, rgba, mask, hist, planes, fr, second)
-    if second is not None:
-        join_ev = torch.cuda.Event()
+    leg.keep = (i420, a420, rgba, mask, hist, planes, fr)
+    if second:
+        ev_a, ev_b = ctypes.c_void_p(), ctypes.c_void_p()
+        vfx.check(lib.mvfx_event_create(ctypes.byref(ev_a)))
+        vfx.check(lib.mvfx_event_create(ctypes.byref(ev_b)))
 
-        def join():  # the launch stream waits for what the second stream has been given so far
-            join_ev.record(second)
-            w.stream.wait_event(join_ev)
+        def join():  # the launch stream waits for what the two element streams have been given so far
+            vfx.check(lib.mvfx_event_record(ev_a, s_a))
+            vfx.check(lib.mvfx_event_record(ev_b, s_b))
+            vfx.check(lib.mvfx_stream_wait_event(sptr, ev_a))
+            vfx.check(lib.mvfx_stream_wait_event(sptr, ev_b))
         leg.join = join
         leg.note = ("two HIP streams: avg_step_ms spans K steps with ONE join of the two streams at the end (throughput); step_us joins them after "
                     "every step (latency of one frame through both elements, no overlap between frames)")
