@@ -1120,22 +1120,23 @@ def hsvfilter_main(args):
                     "unit": "frames/s", "launches": n1, "statistic": "median of 5 repetitions",
                     "frac_wall": fps1 / world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS}
         single_stream = {"one_stream": one_thread_leg(1), "two_streams": one_thread_leg(2)}
-        # the launch combiner: the same threads make the same single-frame calls, the library coalesces them into batched launches
-        nb, nf = ctypes.c_uint64(), ctypes.c_uint64()
-        lib.mvfx_combiner_stats(w.device_index, ctypes.byref(nb), ctypes.byref(nf))
-        combined = threads_leg(0, f"{nthr} threads x 1 frame through the launch combiner (mvfx_hsvfilter_transform_frame_ip_combined: one call "
-                                  "per buffer, frames of all threads coalesced into batched launches by the library)")
-        nb2, nf2 = ctypes.c_uint64(), ctypes.c_uint64()
-        lib.mvfx_combiner_stats(w.device_index, ctypes.byref(nb2), ctypes.byref(nf2))
-        combined["frames_per_combined_launch"] = (nf2.value - nf.value) / max(nb2.value - nb.value, 1)
-        # ... and its fenced entry (what the element uses with MVFX_COMBINE=2): no caller streams, the frames' fences in and out, all
-        # combined launches on one library-owned stream
-        fenced = threads_leg(0xFFFFFFFF, f"{nthr} threads x 1 frame through the launch combiner's fenced entry (mvfx_hsvfilter_transform_frame_ip_fenced: one "
-                                          "call per buffer, the buffer's fence in and out, batched launches on one library-owned stream)")
-        nb3, nf3 = ctypes.c_uint64(), ctypes.c_uint64()
-        lib.mvfx_combiner_stats(w.device_index, ctypes.byref(nb3), ctypes.byref(nf3))
-        fenced["frames_per_combined_launch"] = (nf3.value - nf2.value) / max(nb3.value - nb2.value, 1)
-        combined["fenced_entry"] = fenced
+        if args.combiner_legs:  # (0: a profiling run -- rocprofv3's queue interceptor crashes on this leg's cross-stream event waits)
+            # the launch combiner: the same threads make the same single-frame calls, the library coalesces them into batched launches
+            nb, nf = ctypes.c_uint64(), ctypes.c_uint64()
+            lib.mvfx_combiner_stats(w.device_index, ctypes.byref(nb), ctypes.byref(nf))
+            combined = threads_leg(0, f"{nthr} threads x 1 frame through the launch combiner (mvfx_hsvfilter_transform_frame_ip_combined: one call "
+                                      "per buffer, frames of all threads coalesced into batched launches by the library)")
+            nb2, nf2 = ctypes.c_uint64(), ctypes.c_uint64()
+            lib.mvfx_combiner_stats(w.device_index, ctypes.byref(nb2), ctypes.byref(nf2))
+            combined["frames_per_combined_launch"] = (nf2.value - nf.value) / max(nb2.value - nb.value, 1)
+            # ... and its fenced entry (what the element uses with MVFX_COMBINE=2): no caller streams, the frames' fences in and out, all
+            # combined launches on one library-owned stream
+            fenced = threads_leg(0xFFFFFFFF, f"{nthr} threads x 1 frame through the launch combiner's fenced entry (mvfx_hsvfilter_transform_frame_ip_fenced: one "
+                                              "call per buffer, the buffer's fence in and out, batched launches on one library-owned stream)")
+            nb3, nf3 = ctypes.c_uint64(), ctypes.c_uint64()
+            lib.mvfx_combiner_stats(w.device_index, ctypes.byref(nb3), ctypes.byref(nf3))
+            fenced["frames_per_combined_launch"] = (nf3.value - nf2.value) / max(nb3.value - nb2.value, 1)
+            combined["fenced_entry"] = fenced
 
     # ---- the same batch leg on the other frame contents: the kernel has no data-dependent branch, but the chip is power
     # limited on this kernel and the bytes decide how much the data paths toggle (tools/exp_content_power.py) -------------
@@ -1280,6 +1281,9 @@ def main():
     ap.add_argument("--other-configs", type=int, default=1, choices=[0, 1],
                     help="hsvfilter workload: after the headline legs also measure BASELINE configs 2-5 in this run "
                          "(config.other_configs); N > 1: the band-sharded videocompare leg with its RCCL all-reduce")
+    ap.add_argument("--combiner-legs", type=int, default=1, choices=[0, 1],
+                    help="0 skips the two launch-combiner legs: rocprofiler-sdk 7.2 (rocprofv3 --kernel-trace / --pmc) crashes inside its HSA queue "
+                         "interceptor on the cross-stream hipStreamWaitEvent traffic they generate (profiles/r3/rocprofv3_crash_in_queue_interceptor.txt)")
     ap.add_argument("--side-leg-timeout", type=float, default=180.0, help="N > 1: watchdog of the band-sharded videocompare leg, seconds")
     ap.add_argument("--other-cpu-seconds", type=float, default=2.5, help="CPU baseline budget per leg of configs 2-5")
     ap.add_argument("--other-settle-seconds", type=float, default=0.3, help="untimed run before each leg of configs 2-5")
