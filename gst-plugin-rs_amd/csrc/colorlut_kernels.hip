@@ -832,6 +832,12 @@ typedef const __attribute__((address_space(3))) f32x2_t *lds_float2_t;
                                 // (uniform-random colours 2.22 -> 1.59 ms per 16 frames, but 104 instead of 92 VGPRs: natural-like 0.635 ->
                                 // 0.585 of the HBM peak, flat bars 0.56 -> 0.47 on the same box -- not taken)
 #endif
+#ifndef MVFX_XTILE_ANCHOR4
+#define MVFX_XTILE_ANCHOR4 0 // 1: the window is anchored at the mean of four pixels of the block instead of its centre pixel.  Measured
+                             // (profiles/r3/colorlut_anchor4.txt): gradients +- 8 codes of noise 39.3 k -> 47.3 k fps, +- 5: 59.0 k -> 61.9 k, but
+                             // +- 3 unchanged, one clean frame per launch 18.8 -> 20.2 us (a longer scalar chain in front of the window fill) and
+                             // flat bars 0.550 -> 0.531 (a block across an edge gets an anchor that fits neither side): off
+#endif
 #ifndef MVFX_XTILE_GROUP
 #define MVFX_XTILE_GROUP 4 // pixels per window look-up / miss branch group (1, 2 or 4)
 #endif
@@ -882,7 +888,23 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
         // (a wave of the last workgroup of a row may lie wholly right of the frame: it reads pixel (0, 0) and stores nothing)
         const uint32_t cxp = bx + kTileW / 2 < width ? bx + kTileW / 2 : bx, cyp = by + kTileH / 2 < height ? by + kTileH / 2 : by;
         const uint32_t coff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(bx < width ? cyp * in_stride + cxp * 4 : 0u));
-        const uint32_t cpx = *reinterpret_cast<const uint32_t *>(in + coff);
+        uint32_t cpx = *reinterpret_cast<const uint32_t *>(in + coff);
+#if MVFX_XTILE_ANCHOR4
+        // a block that lies wholly inside the frame is anchored at the MEAN of four of its pixels (the centres of its quadrants): one pixel
+        // carries the full noise of the picture, and every code the anchor is off shrinks the part of the window the other pixels can use
+        // (gradients +- 5 codes of noise: profiles/r3/colorlut_anchor4.txt)
+        if (bx + kTileW <= width && by + kTileH <= height) {
+            const uint32_t o0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)((by + kTileH / 4) * in_stride + (bx + kTileW / 4) * 4));
+            const uint32_t dxq = (kTileW / 2) * 4, dyq = (kTileH / 2) * in_stride;
+            const uint32_t q0 = *reinterpret_cast<const uint32_t *>(in + o0), q1 = *reinterpret_cast<const uint32_t *>(in + o0 + dxq),
+                           q2 = *reinterpret_cast<const uint32_t *>(in + o0 + dyq), q3 = *reinterpret_cast<const uint32_t *>(in + o0 + dyq + dxq);
+            // per-byte sums of four bytes fit ten bits: even and odd bytes in separate words
+            const uint32_t ev = (q0 & 0x00ff00ffu) + (q1 & 0x00ff00ffu) + (q2 & 0x00ff00ffu) + (q3 & 0x00ff00ffu) + 0x00020002u;
+            const uint32_t od = ((q0 >> 8) & 0x00ff00ffu) + ((q1 >> 8) & 0x00ff00ffu) + ((q2 >> 8) & 0x00ff00ffu) + ((q3 >> 8) & 0x00ff00ffu) + 0x00020002u;
+            cpx = ((ev >> 2) & 0x00ff00ffu) | (((od >> 2) & 0x00ff00ffu) << 8);
+        }
+        cpx = (uint32_t)__builtin_amdgcn_readfirstlane((int)cpx); // wave-uniform by construction: keeps the two table look-ups below scalar
+#endif
         const uint32_t cr = cpx & 0xffu;
         const uint32_t cy = p.tile_tables[2 * (256 + ((cpx >> 8) & 0xffu))], cz = p.tile_tables[2 * (512 + ((cpx >> 16) & 0xffu))];
         ar = min((cr > RW / 2 ? cr - RW / 2 : 0u) & ~1u, 256u - RW); // even: a window row starts on a 16-byte piece
