@@ -112,7 +112,7 @@ public:
                 leader = true;
                 for (Batch &s : ring_)
                     if (!s.open && s.waiters == 0 && (s.n.load(std::memory_order_relaxed) == 0 || s.launched.load(std::memory_order_relaxed))) { b = &s; break; }
-                // (64 slots; a slot is busy only while one of at most 16 followers still has to take its event)
+                // (256 slots; a slot is busy only while one of at most 16 followers still has to take its event)
                 if (!b) return fail(MVFX_ERR_DEVICE, "launch combiner: no free batch slot");
                 b->n.store(0, std::memory_order_relaxed);
                 b->launched.store(0, std::memory_order_relaxed);

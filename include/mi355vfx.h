@@ -276,8 +276,10 @@ int mvfx_colorlut_transform_frame_host(mvfx_cube_lut *lut, const mvfx_frame *in_
                                        const mvfx_frame *out_frame);
 /* Where the LUT is read from / which kernel runs is a thread option (MVFX_OPT_LUT_PLACEMENT_*, see
  * mvfx_thread_set_options): 0 = automatic (3-D cubes of 3..65 points on 16-byte aligned frames whose width is a multiple of
- * 4: the tile kernel, placement 5; otherwise LDS when the table fits: 3-D size <= 21, 1-D size <= 4096; else the cell-packed
- * copy for 3-D size <= 65; else the node layout in global/L2), 1 = node layout in global/L2,
+ * 4: RGBA8 on cubes of 4+ points the x-prelerped window kernel -- a table of the trilinear sample's four x-lerps and its
+ * y-difference per (r byte, y node, z node), 6.9 MB for 33^3, built on the device when the LUT is first used there --, RGBA64 and
+ * 3-point cubes the tile kernel of placement 5; otherwise LDS when the table fits: 3-D size <= 21, 1-D size <= 4096; else
+ * the cell-packed copy for 3-D size <= 65; else the node layout in global/L2), 1 = node layout in global/L2,
  * 2 = LDS (MVFX_ERR_INVALID_ARGUMENT if it does not fit), 3 = cell-packed global copy,
  * 4 = the literal-transcription kernels (also used automatically when the LUT's domain
  * scale/offset are not finite), 5 = the tile kernel: a wave owns a compact block of pixels and keeps the 3x3x3 LUT cells
