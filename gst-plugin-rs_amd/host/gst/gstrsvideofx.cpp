@@ -440,10 +440,10 @@ static GstFlowReturn gst_rounded_corners_prepare_output_buffer(GstBaseTransform 
         pi.height = po.height = (uint32_t)GST_VIDEO_INFO_HEIGHT(&self->out_info);
         pi.format = MVFX_FORMAT_I420;
         po.format = MVFX_FORMAT_A420;
-        // this thread's one stream: alternating between two per buffer, as the hsv / colorlut elements do, costs this element a third of
-        // its rate (4K: 42-55 k fps on one stream, 30-35 k alternating -- every frame also takes a recycled output block whose fence lives on
-        // the other stream)
-        const mvfx_stream st = mvfx_thread_stream();
+        // per frame, as the hsv / colorlut elements pick it (the mask was uploaded synchronously).  It pays only with a few output blocks in
+        // rotation (mvfx_hip_decide_allocation's pool minimum): 4K, one stream 39-45 k fps, alternating 50-64 k; with a pool that recycled
+        // one block the alternation LOST a third
+        const mvfx_stream st = mvfx_element_stream(inbuf);
         mvfx_hip_buffer_acquire(inbuf, st);
         mvfx_hip_buffer_acquire(out, st);
         int rc = mvfx_roundedcorners_compose_a420(&pi, amap.data, (uint32_t)GST_VIDEO_INFO_PLANE_STRIDE(&self->out_info, 3), &po, st);

@@ -589,6 +589,13 @@ gboolean mvfx_hip_decide_allocation(GstQuery *query)
         pool = new_configured_pool(caps, size);
     if (!pool)
         return FALSE;
+    // A few blocks in rotation (the pool's queue is first in, first out): behind a sink that drops its buffers at once a pool without a
+    // minimum recycles ONE block, every frame then writes where the previous frame's kernel may still be writing, and consecutive
+    // frames can never overlap -- with the elements alternating between two streams that wait even crosses streams
+    // (MVFX_HIP_POOL_MIN, default 4; profiles/r3/gst_pool_min_buffers.txt).
+    static const guint pool_min = [] { const gchar *e = g_getenv("MVFX_HIP_POOL_MIN"); return (guint)CLAMP(e ? atoi(e) : 4, 0, 64); }();
+    if (min < pool_min) min = pool_min;
+    if (max != 0 && max < min) max = min;
     if (have)
         gst_query_set_nth_allocation_pool(query, 0, pool, size, min, max);
     else
