@@ -531,3 +531,34 @@ def test_imagersoverlay_without_location_is_passthrough_and_missing_file_errors(
     assert np.array_equal(same, raw)
     r = gst_env.run([LAUNCH] + (src + f" ! imagersoverlay location={tmp_path}/nope.png ! fakesink").split(), tmp_path)
     assert r.returncode != 0 and "Could not load overlay image" in r.stdout
+
+
+@pytest.mark.parametrize("queues", [True, False], ids=["queues", "one-thread"])
+def test_device_chain_on_frames_that_all_differ(gpu, tmp_path, queues):
+    """videotestsrc pattern=snow: every frame is different, so an ordering mistake between the elements' alternating HIP streams, the
+    pool blocks kept in rotation and the upload / download copies shows as a wrong frame (constant test frames hide it).  Upload, three
+    device filters (with and without queues between them), download; every output frame against the oracle applied to ITS input."""
+    w, h, n = 320, 240, 240
+    cube = os.path.join(str(tmp_path), "look.cube")
+    open(cube, "w").write(cubes.analytic_3d(17))
+    q = " ! queue max-size-buffers=3" if queues else ""
+    fin, fout = os.path.join(str(tmp_path), "in.raw"), os.path.join(str(tmp_path), "out.raw")
+    pipe = (f"videotestsrc pattern=snow num-buffers={n} ! video/x-raw,format=RGBx,width={w},height={h},framerate=30/1 ! tee name=t "
+            f"t. ! queue ! filesink location={fin} "
+            f"t. ! queue ! hipupload{q} ! hsvfilter hue-shift=45{q} ! hsvdetector hue-ref=120 hue-var=60 saturation-ref=0.6 saturation-var=0.4 "
+            f"value-ref=0.6 value-var=0.4 ! video/x-raw(memory:HIPMemory),format=RGBA{q} ! colorlut location={cube}{q} ! hipdownload ! "
+            f"filesink location={fout}")
+    r = gst_env.run([LAUNCH, "-q"] + pipe.split(), tmp_path, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:]
+    a = np.fromfile(fin, np.uint8).reshape(n, h, w * 4)
+    b = np.fromfile(fout, np.uint8).reshape(n, h, w * 4)
+    assert not np.array_equal(a[0], a[1]), "the source frames do not differ"
+    lut = orc.CubeLut(open(cube).read())
+    for k in range(n):
+        mid = a[k].copy()
+        assert orc.hsvfilter(mid, w, w * 4, "RGBx", (45.0, 1.0, 0.0, 1.0, 0.0)) == 0
+        det = np.empty_like(mid)
+        assert orc.hsvdetector(mid, w * 4, "RGBx", det, w * 4, "RGBA", w, (120.0, 60.0, 0.6, 0.4, 0.6, 0.4)) == 0
+        exp = np.empty_like(det)
+        assert lut.apply(det, w * 4, exp, w * 4, w, h, "RGBA") == 0
+        assert np.array_equal(b[k], exp), f"frame {k}"
