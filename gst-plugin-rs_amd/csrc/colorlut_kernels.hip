@@ -837,6 +837,9 @@ typedef const __attribute__((address_space(3))) f32x2_t *lds_float2_t;
                              // (profiles/r3/colorlut_anchor4.txt): gradients +- 8 codes of noise 39.3 k -> 47.3 k fps, +- 5: 59.0 k -> 61.9 k, but
                              // +- 3 unchanged, one clean frame per launch 18.8 -> 20.2 us (a longer scalar chain in front of the window fill) and
                              // flat bars 0.550 -> 0.531 (a block across an edge gets an anchor that fits neither side): off
+                             // 2: the same four samples through one vector load of lanes 0..3 ahead of the pixel loads, the mean only where they
+                             // agree: +- 5 / 8 / 12 codes of noise +6 / +18 / +10 %, clean and +- 3 frames -1...2 %, one frame per launch 19.0 -> 20.2 us:
+                             // the anchor chain then waits behind a vector load.  Also off; a build for noisy footage may want it
 #endif
 #ifndef MVFX_XTILE_GROUP
 #define MVFX_XTILE_GROUP 4 // pixels per window look-up / miss branch group (1, 2 or 4)
@@ -870,6 +873,13 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
     uint8_t *out = out_fb.base[gz];
     const uint32_t bx = (gx * (kBlock / 64) + wave) * kTileW, by = gy * kTileH; // the wave's block
     const uint32_t x = bx + (lane % kAcross) * 4, y0 = by + (lane / kAcross) * kRows;
+#if MVFX_XTILE_ANCHOR4 == 2
+    // four samples of the block (the centres of its quadrants) through ONE vector load of lanes 0..3, issued ahead of the pixel loads
+    uint32_t smp = 0;
+    const bool whole_block = bx + kTileW <= width && by + kTileH <= height;
+    if (whole_block && lane < 4)
+        smp = *reinterpret_cast<const uint32_t *>(in + ((by + kTileH / 4 + (lane >> 1) * (kTileH / 2)) * in_stride + (bx + kTileW / 4 + (lane & 1) * (kTileW / 2)) * 4));
+#endif
     // 1. every pixel of the lane, up front (four 16-byte loads in flight while the window is being fetched)
     uint4 v[kRows];
 #pragma unroll
@@ -889,7 +899,20 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
         const uint32_t cxp = bx + kTileW / 2 < width ? bx + kTileW / 2 : bx, cyp = by + kTileH / 2 < height ? by + kTileH / 2 : by;
         const uint32_t coff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(bx < width ? cyp * in_stride + cxp * 4 : 0u));
         uint32_t cpx = *reinterpret_cast<const uint32_t *>(in + coff);
-#if MVFX_XTILE_ANCHOR4
+#if MVFX_XTILE_ANCHOR4 == 2
+        if (__builtin_amdgcn_readfirstlane((int)whole_block)) {
+            const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)smp, 0) & 0xffffffu, q1 = (uint32_t)__builtin_amdgcn_readlane((int)smp, 1) & 0xffffffu,
+                           q2 = (uint32_t)__builtin_amdgcn_readlane((int)smp, 2) & 0xffffffu, q3 = (uint32_t)__builtin_amdgcn_readlane((int)smp, 3) & 0xffffffu;
+            // the mean only where the four agree (sum of absolute byte differences along the two diagonals): across an edge the mean
+            // would fit neither side, there the first sample stands
+            const uint32_t spread = __builtin_amdgcn_sad_u8(q0, q3, 0u) + __builtin_amdgcn_sad_u8(q1, q2, 0u);
+            const uint32_t ev = (q0 & 0x00ff00ffu) + (q1 & 0x00ff00ffu) + (q2 & 0x00ff00ffu) + (q3 & 0x00ff00ffu) + 0x00020002u;
+            const uint32_t od = ((q0 >> 8) & 0x00ff00ffu) + ((q1 >> 8) & 0x00ff00ffu) + ((q2 >> 8) & 0x00ff00ffu) + ((q3 >> 8) & 0x00ff00ffu) + 0x00020002u;
+            const uint32_t mean = ((ev >> 2) & 0x00ff00ffu) | (((od >> 2) & 0x00ff00ffu) << 8);
+            cpx = spread <= 72u ? mean : q0;
+        }
+        cpx = (uint32_t)__builtin_amdgcn_readfirstlane((int)cpx);
+#elif MVFX_XTILE_ANCHOR4
         // a block that lies wholly inside the frame is anchored at the MEAN of four of its pixels (the centres of its quadrants): one pixel
         // carries the full noise of the picture, and every code the anchor is off shrinks the part of the window the other pixels can use
         // (gradients +- 5 codes of noise: profiles/r3/colorlut_anchor4.txt)
