@@ -113,14 +113,117 @@ def spawn_workers(args, argv, script=None, device_count=None):
         sys.exit(1)
 
 
-def emit(line):
-    """The ONE JSON line, last on stdout: native libraries (RCCL's version banner) write to C stdio, which is block-buffered on a pipe and
-    would otherwise be flushed at exit, after the line."""
+FINAL_LINE_LIMIT = 3000   # bytes: the driver keeps only a tail of stdout, so the LAST line must be small (round 3's 20 KB line arrived beheaded)
+SUB_LINE_LIMIT = 1000
+FULL_DOC = os.path.join(ROOT, "bench_out", "last_run.json")
+
+
+def _r(x, digits=6):
+    """floats to `digits` significant digits: the compact lines carry numbers, not float64 noise"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _flush_c_stdio():
+    """native libraries (RCCL's version banner) write to C stdio, which is block-buffered on a pipe and would otherwise be
+    flushed at exit, after the line"""
     try:
         ctypes.CDLL(None).fflush(None)
     except OSError:
         pass
-    print(json.dumps(line), flush=True)
+
+
+def compact_cpu(cpu):
+    if not cpu:
+        return None
+    out = {"value": _r(cpu["value"]), "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"], "sample": cpu["sample"][:200]}
+    if "all_cores" in cpu:
+        out["all_cores"] = {"value": _r(cpu["all_cores"]["value"]), "cores": cpu["all_cores"]["cores"]}
+    return out
+
+
+def compact_roofline(r):
+    """scalars only.  `frac` = `achieved` / `peak` with `achieved` the algorithmic bytes over the WALL clock `value` is made of;
+    `frac_kernel` the same bytes over the average launch duration between two HIP events on the launch stream; `frac_valu` the
+    committed SQ_INSTS_VALU of the step x 4 cycles over what 1024 SIMDs issue at 2.4 GHz in the measured step time."""
+    keys = ("bound", "achieved", "peak", "unit", "frac", "frac_kernel", "achieved_kernel", "frac_valu", "traffic", "traffic_committed",
+            "traffic_over_algorithmic", "kernel", "bytes_per_step", "avg_step_us", "p50_step_us", "frac_of_measured_ceiling", "ceiling_measured_GBs")
+    return {k: _r(r[k]) for k in keys if k in r}
+
+
+def compact_headline(out):
+    """The driver's line: what the bench contract names and nothing else (the whole document is FULL_DOC)."""
+    c = out.get("config", {})
+    cfg = {k: c[k] for k in ("workload", "launch_model", "frame_content", "frames_per_step_per_gpu", "parallelism", "rccl_ranks",
+                             "rendezvous_backend", "collective") if c.get(k) is not None}
+    for k in ("per_rank_frames_per_sec", "per_rank_units_per_sec"):
+        if k in c:
+            cfg[k] = [_r(v, 5) for v in c[k]]
+    for k in ("element_path", "value_p50", "last_distance", "allreduce_us", "side_legs"):
+        if c.get(k) is not None:
+            cfg[k] = _r(c[k]) if not isinstance(c[k], dict) else c[k]
+    cfg["full_document"] = os.path.relpath(FULL_DOC, ROOT)
+    line = {k: _r(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                     "vs_baseline", "dtype") if k in out}
+    line["data"] = out.get("data", "synthetic")[:160]
+    line["config"] = cfg
+    line["roofline"] = compact_roofline(out.get("roofline", {}))
+    if out.get("cpu_baseline"):
+        line["cpu_baseline"] = compact_cpu(out["cpu_baseline"])
+    if "wall_s" in out:
+        line["wall_s"] = _r(out["wall_s"], 4)
+    return line
+
+
+def compact_sub(key, r):
+    """one of configs 2-5 (or a side measurement) as its own small line, printed BEFORE the final line"""
+    if "error" in r:
+        return {"sub": key, "error": str(r["error"])[:300]}
+    rf = r.get("roofline", {})
+    out = {"sub": key, "metric": r.get("metric"), "value": _r(r.get("value")), "unit": r.get("unit"), "ms_per_step": _r(r.get("ms_per_step")),
+           "bound": rf.get("bound"), "frac_wall": _r(rf.get("frac")), "frac_kernel": _r(rf.get("frac_kernel")), "frac_valu": _r(rf.get("frac_valu")),
+           "traffic_ratio": _r(rf.get("traffic_over_algorithmic"), 4)}
+    cpu = r.get("cpu_baseline")
+    if cpu:
+        out["cpu_value"] = _r(cpu["value"])
+        out["cpu_all_cores"] = _r(cpu.get("all_cores", {}).get("value"))
+        out["cpu_cores"] = cpu.get("all_cores", {}).get("cores")
+    for k in ("element_model", "last_distance", "n_gpus", "allreduce_us"):
+        v = r.get("config", {}).get(k, r.get(k))
+        if v is not None and not isinstance(v, (list, dict)):
+            out[k] = _r(v)
+    out.update(r.get("sub_extra", {}))
+    return {k: v for k, v in out.items() if v is not None}
+
+
+def emit(doc, subs=(), full=False):
+    """Side lines first (one small JSON line each), then the ONE final line, last on stdout; the whole document goes to
+    bench_out/last_run.json.  full=True (--full 1, the profiling tools): the final line is the whole document."""
+    _flush_c_stdio()
+    try:
+        os.makedirs(os.path.dirname(FULL_DOC), exist_ok=True)
+        with open(FULL_DOC, "w") as f:
+            json.dump(doc, f, indent=1, default=str)
+    except OSError as e:  # a read-only tree must not cost the line
+        sys.stderr.write(f"bench.py: could not write {FULL_DOC}: {e}\n")
+    for key, r in subs:
+        s = json.dumps(compact_sub(key, r))
+        if len(s) > SUB_LINE_LIMIT:
+            s = json.dumps({"sub": key, "error": f"sub-line of {len(s)} bytes dropped (limit {SUB_LINE_LIMIT}); see the full document"})
+        print(s, flush=True)
+    if full:
+        print(json.dumps(doc, default=str), flush=True)
+        return
+    line = compact_headline(doc)
+    s = json.dumps(line)
+    if len(s) > FINAL_LINE_LIMIT:  # never hand the driver a line it will cut: shed the optional parts
+        for k in ("side_legs", "element_path", "per_rank_frames_per_sec", "per_rank_units_per_sec"):
+            line["config"].pop(k, None)
+        line["data"] = line["data"][:60]
+        s = json.dumps(line)
+    assert len(s) <= FINAL_LINE_LIMIT, len(s)
+    print(s, flush=True)
 
 
 class Worker:
@@ -295,8 +398,8 @@ CONTENT_TEXT = {
 }
 
 
-def natural_frame(torch, dev, gen, k, W, H):
-    """One natural-like RGBA frame as a flat u8 tensor: smooth 2-D colour gradients (phase k) + noise of +-3 codes."""
+def natural_frame(torch, dev, gen, k, W, H, noise=3):
+    """One natural-like RGBA frame as a flat u8 tensor: smooth 2-D colour gradients (phase k) + uniform noise of +-`noise` codes."""
     x = torch.linspace(0, 1, W, device=dev).view(1, W)
     y = torch.linspace(0, 1, H, device=dev).view(H, 1)
     ph = 0.37 * k
@@ -304,19 +407,21 @@ def natural_frame(torch, dev, gen, k, W, H):
                        (0.5 + 0.45 * torch.sin(5.0 * y - 1.5 * x + 2 * ph)).expand(H, W),
                        (0.5 + 0.45 * torch.cos(4.0 * x * y + ph)).expand(H, W),
                        torch.ones((H, W), device=dev)], dim=-1) * 255.0
-    noise = torch.randint(-3, 4, img.shape, device=dev, generator=gen).float()
-    noise[..., 3] = 0
-    return (img + noise).clamp(0, 255).to(torch.uint8).view(-1)
+    if noise > 0:
+        nz = torch.randint(-noise, noise + 1, img.shape, device=dev, generator=gen).float()
+        nz[..., 3] = 0
+        img = img + nz
+    return img.clamp(0, 255).to(torch.uint8).view(-1)
 
 
-def fill_frames(torch, dev, gen, flat, kind, W, H, first_frame=0):
+def fill_frames(torch, dev, gen, flat, kind, W, H, first_frame=0, noise=3):
     """Fill flat[n, W*H*4] (device, u8) with `kind` frames; frame j is frame first_frame + j of its stream."""
     n = flat.shape[0]
     if kind == "random":
         flat.random_(0, 256, generator=gen)
     elif kind == "natural":
         for j in range(n):
-            flat[j] = natural_frame(torch, dev, gen, first_frame + j, W, H)
+            flat[j] = natural_frame(torch, dev, gen, first_frame + j, W, H, noise)
     elif kind == "videotestsrc":
         import numpy as np
         from tests import frames as _frames
@@ -383,34 +488,36 @@ def cpu_rate(make_unit, seconds, n_threads):
     return sum(c / s for c, s in zip(counts, spans) if s > 0), sum(counts), max(spans)
 
 
+ALL_CORES_SECONDS = [None]  # budget of the nproc-thread leg (None: same as the 1-thread leg; 0: skip it) -- set from the command line
+
+
 def cpu_baseline_of(make_unit, seconds, unit, what, scale=1.0, scale_note=None):
     nproc = _nproc()
     one, one_n, one_dt = cpu_rate(make_unit, seconds, 1)
-    if nproc > 1:
-        allr, all_n, all_dt = cpu_rate(make_unit, seconds, nproc)
-    else:
-        allr, all_n, all_dt = one, one_n, one_dt
     out = {"value": one * scale, "unit": unit, "cores": 1, "kind": "port",
-           "sample": f"{one_n} x {what}, 1 thread, {one_dt:.1f} s" + (f"; {scale_note}" if scale_note else ""),
-           "all_cores": {"value": allr * scale, "unit": unit, "cores": nproc, "nproc": nproc,
-                         "sample": f"{all_n} x the same unit on {nproc} threads (independent streams), {all_dt:.1f} s per thread"}}
+           "sample": f"{one_n} x {what}, 1 thread, {one_dt:.1f} s" + (f"; {scale_note}" if scale_note else "")}
+    all_s = seconds if ALL_CORES_SECONDS[0] is None else ALL_CORES_SECONDS[0]
+    if all_s > 0:
+        allr, all_n, all_dt = cpu_rate(make_unit, all_s, nproc) if nproc > 1 else (one, one_n, one_dt)
+        out["all_cores"] = {"value": allr * scale, "unit": unit, "cores": nproc, "nproc": nproc,
+                            "sample": f"{all_n} x the same unit on {nproc} threads (independent streams), {all_dt:.1f} s per thread"}
     return out
 
 
 def cpu_baseline_hsvfilter(seconds, content="videotestsrc"):
-    """hsvfilter/imp.rs:76-120 on 3840x2160 RGBA: 8 distinct frames of the same content as the GPU legs rotate so the 33 MB
+    """hsvfilter/imp.rs:76-120 on 3840x2160 RGBA: 4 distinct frames of the same content as the GPU legs rotate so the 33 MB
     input is not cache resident; every thread filters a fresh copy (in-place loop), the copy is not timed."""
     import numpy as np
     from tests import frames
     from tests import oracle_binding as orc
-    distinct = 8
+    distinct = 4
     if content == "videotestsrc":
         vts, _ = frames.videotestsrc_smpte(W4K, H4K, distinct)
         src = [vts[k] for k in range(distinct)]
-        what = "3840x2160 RGBA frame (videotestsrc pattern=smpte, 8 consecutive frames rotating)"
+        what = "3840x2160 RGBA frame (videotestsrc pattern=smpte, 4 consecutive frames rotating)"
     else:
         src = [frames.random_frame(0x5EED0001 + k, W4K, H4K) for k in range(distinct)]
-        what = "3840x2160 RGBA frame (uniform random, 8 distinct frames rotating, seeds 0x5EED0001..8)"
+        what = "3840x2160 RGBA frame (uniform random, 4 distinct frames rotating, seeds 0x5EED0001..4)"
 
     def make_unit(t):
         work = src[0].copy()
@@ -533,6 +640,57 @@ def committed_traffic(key, units_per_step):
     return None, "no committed rocprofv3 PMC pass for this workload"
 
 
+VALU_CLOCK_HZ = 2.4e9      # MI355X_MICROARCH.md: max clock 2400 MHz
+VALU_SIMDS = 256 * 4       # 256 CUs x 4 SIMDs; a wave64 non-packed VALU instruction occupies its SIMD for 4 cycles (157.3 TF fp32 vector peak)
+# which ceiling binds, from the committed rocprofv3 counters (VALUBusy / MemUnitBusy / SQ_INSTS_VALU passes under profiles/); the
+# committed profiles/traffic.json overrides this table per workload when it carries a "bound" field
+BOUND_FROM_COUNTERS = {"hsvfilter": "valu", "hsv1080p": "valu", "hsvfilter_rgb": "valu", "hsvdetector_rgb": "valu",
+                       "colorlut_natural": "valu", "colorlut_random": "hbm", "colorlut_smpte": "valu",
+                       "videofx": "hbm", "videocompare_blockhash": "hbm", "videocompare_dssim": "valu"}
+
+
+def committed_counters(key, units_per_step):
+    """{"bound", "valu_insts" (SQ_INSTS_VALU wave-instructions per step, or None)} from the committed PMC passes"""
+    bound, valu = BOUND_FROM_COUNTERS.get(key, "hbm"), None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)[key]
+        bound = t.get("bound", bound)
+        if t.get("valu_insts_per_step"):
+            valu = t["valu_insts_per_step"] * units_per_step / t["units_per_step"]
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        pass
+    return {"bound": bound, "valu_insts": valu}
+
+
+def frac_valu(valu_insts, step_seconds):
+    """fraction of the VALU issue ceiling: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x step time).  Quarter-rate instructions
+    (v_rcp, v_sqrt ...) count as one, so this is a lower bound of the VALU pipes' occupancy."""
+    if not valu_insts or not step_seconds:
+        return None
+    return valu_insts * 4.0 / (VALU_SIMDS * VALU_CLOCK_HZ * step_seconds)
+
+
+def roofline_of(key, units_per_step, bytes_per_step, wall_s_per_step, event_s_per_step, kernel, pct=None):
+    """The `roofline` object of a line: `achieved` / `frac` over the wall clock `value` is made of, `*_kernel` over the HIP-event
+    average on the launch stream, `bound` + `frac_valu` and the HBM `traffic_committed` from the committed PMC passes."""
+    traffic, traffic_source = committed_traffic(key, units_per_step)
+    ctr = committed_counters(key, units_per_step)
+    achieved_wall = bytes_per_step / wall_s_per_step / 1e9
+    achieved_kernel = bytes_per_step / event_s_per_step / 1e9 if event_s_per_step else None
+    out = {"bound": ctr["bound"], "achieved": achieved_wall, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_wall / HBM_PEAK_GBS,
+           "achieved_kernel": achieved_kernel, "frac_kernel": achieved_kernel / HBM_PEAK_GBS if achieved_kernel else None,
+           "frac_valu": frac_valu(ctr["valu_insts"], event_s_per_step or wall_s_per_step),
+           "traffic": None, "traffic_committed": traffic, "traffic_source": traffic_source,
+           "traffic_over_algorithmic": (traffic / bytes_per_step) if traffic else None,
+           "kernel": kernel, "bytes_per_step": bytes_per_step,
+           "avg_step_us": event_s_per_step * 1e6 if event_s_per_step else None, "step_us": pct,
+           "p50_step_us": pct["p50"] if pct else None,
+           "note": "traffic: null because FETCH_SIZE / WRITE_SIZE cannot be collected inside a timed run; traffic_committed = the committed "
+                   "rocprofv3 --pmc passes of this workload (profiles/traffic.json), scaled to this run's units per step"}
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ the legs (configs 2-5)
 
 DETECT_SETTINGS = (120.0, 40.0, 0.6, 0.4, 0.6, 0.4)  # SURVEY.md 8d hsvdetector settings
@@ -553,6 +711,7 @@ def measure_leg(w, leg, steps, warmup, settle_seconds, pct_steps, cpu_seconds):
     """settle -> W warm-up -> K steps between barriers (wall clock + one pair of HIP events on the launch stream) -> pct_steps
     steps with a HIP event between every two (p10 / p50 / p90 of the per-step time) -> the CPU port on the host cores."""
     executed = [0]
+    t_measure = time.perf_counter()
 
     def counted(i):
         executed[0] += 1
@@ -568,27 +727,24 @@ def measure_leg(w, leg, steps, warmup, settle_seconds, pct_steps, cpu_seconds):
     pct = percentiles(w.event_times(counted, pct_steps, first_index=warmup + steps, join=join)) if pct_steps > 0 else None
     world = w.world
     per_gpu_bytes = leg.bytes_per_step  # per rank and step
-    achieved_kernel = per_gpu_bytes / (ev_ms * 1e-3) / 1e9
-    achieved_wall = per_gpu_bytes * steps / secs / 1e9
-    traffic, traffic_source = committed_traffic(leg.key, leg.units_per_step)
     value = steps * leg.units_per_step * (world if leg.scaling == "weak" else 1) / secs
+    roof = roofline_of(leg.key, leg.units_per_step, per_gpu_bytes, secs / steps, ev_ms * 1e-3, ", ".join(leg.kernels), pct)
+    roof["avg_step_ms"] = ev_ms
+    if leg.note:
+        roof["leg_note"] = leg.note
     out = {
         "metric": leg.metric, "value": value, "unit": leg.unit, "steps": steps, "warmup": warmup,
         "ms_per_step": secs / steps * 1e3, "scaling": leg.scaling, "dtype": leg.dtype, "data": leg.data,
         "config": {"workload": leg.workload, "units_per_step_per_gpu": leg.units_per_step, "per_rank_units_per_sec": per_rank,
                    "steps_executed": executed[0], **leg.extra},
-        "roofline": {"bound": "hbm", "achieved": achieved_kernel, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_kernel / HBM_PEAK_GBS, "frac_kernel": achieved_kernel / HBM_PEAK_GBS,
-                     "frac_wall": achieved_wall / HBM_PEAK_GBS, "achieved_wall": achieved_wall,
-                     "bytes_per_step": per_gpu_bytes, "avg_step_ms": ev_ms, "step_us": pct, "kernels": leg.kernels,
-                     "traffic": traffic, "traffic_source": traffic_source,
-                     "traffic_over_algorithmic": (traffic / per_gpu_bytes) if traffic else None,
-                     "note": ("frac / frac_kernel: algorithmic bytes of SURVEY 8d per step / average step time between two HIP events on "
-                              "the launch stream; frac_wall: the same bytes / wall clock between the barriers (what `value` is made of)"
-                              + ("; " + leg.note if leg.note else ""))},
+        "roofline": roof,
     }
+    if pct:
+        out["config"]["value_p50"] = leg.units_per_step * (world if leg.scaling == "weak" else 1) / (pct["p50"] * 1e-6)
+    t_gpu = time.perf_counter()
     if leg.cpu is not None and w.rank == 0 and world == 1 and cpu_seconds > 0:
         out["cpu_baseline"] = leg.cpu(cpu_seconds)
+    out["measure_seconds"] = {"gpu": t_gpu - t_measure, "cpu": time.perf_counter() - t_gpu}
     return out
 
 
@@ -677,8 +833,88 @@ def make_leg_colorlut(w, args, content):
               "kernel (6.9 MB table of the four x-lerps + the y-difference per r byte, built once per LUT; window staged in LDS)",
               step, ["colorlut_xtile_kernel"],
               cpu=(lambda s: cpu_baseline_colorlut(s, host, cube_text, content)) if host else None)
+    def noise_sweep():
+        """frames/s of the same batched launch on natural-like frames with +-0 / 3 / 5 / 8 / 16 codes of noise (camera footage is
+        noisy: the more codes of noise, the more LUT cells a tile of pixels touches): HIP events around 30 launches each."""
+        res = {}
+        for amp in (0, 3, 5, 8, 16):
+            fill_frames(torch, dev, gen, src, "natural", W, H, first_frame=w.rank * pool * nb, noise=amp)
+            for i in range(6):
+                step(i)
+            secs_, ev_ms_ = w.timed(step, 30, events=True)
+            res[str(amp)] = round(nb * w.world / (ev_ms_ * 1e-3))
+        return res
     leg.keep = (src, dst, fi, fo, lut)
     leg.streams_leg = streams_leg
+    leg.noise_sweep = noise_sweep
+    return leg
+
+
+def make_leg_hsv3(w, args, which):
+    """The 3-byte formats the headline ignores (hsvfilter/imp.rs:328-371, hsvdetector/imp.rs:422-707): args.batch streams of
+    3840x2160 per launch; which = "filter": hsvfilter RGB in place (3 R + 3 W B/px); "detector": hsvdetector RGB -> RGBA (3 R + 4 W)."""
+    torch, vfx, lib, dev, sptr = w.torch, w.vfx, w.lib, w.dev, w.sptr
+    W, H, nb = W4K, H4K, args.batch
+    stride3 = (W * 3 + 3) & ~3
+    pool = max(2, 48 // nb)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED0600 + w.rank)
+    rgba = torch.empty((pool * nb, FRAME_BYTES), dtype=torch.uint8, device=dev)
+    fill_frames(torch, dev, gen, rgba, "videotestsrc", W, H, first_frame=w.rank * pool * nb)
+    src = rgba.view(pool * nb, H, W, 4)[..., :3].contiguous().view(pool * nb, H * stride3)  # the same smpte frames, packed RGB
+    del rgba
+    fi = [(vfx.Frame * nb)(*[vfx.make_frame(src[b * nb + i].data_ptr(), W, H, stride3, "RGB") for i in range(nb)]) for b in range(pool)]
+    host = [src[k].cpu().numpy().reshape(H, stride3).copy() for k in range(3)] if w.rank == 0 and w.world == 1 else None
+    fs = vfx.HsvFilterSettings(*SETTINGS)
+    ds = vfx.HsvDetectorSettings(*DETECT_SETTINGS)
+    if which == "filter":
+        def step(i):
+            vfx.check(lib.mvfx_hsvfilter_transform_frames_ip(fi[i % pool], nb, ctypes.byref(fs), sptr))
+
+        def cpu(seconds):
+            import numpy as np
+            from tests import oracle_binding as orc
+
+            def make_unit(t):
+                work = host[0].copy()
+                k = [t]
+
+                def prepare():
+                    np.copyto(work, host[k[0] % len(host)])
+                    k[0] += 1
+                return prepare, lambda: orc.hsvfilter(work, W, stride3, "RGB", SETTINGS)
+            return cpu_baseline_of(make_unit, seconds, "frames/s", "3840x2160 RGB frame through orc_hsvfilter_transform_frame_ip (oracle/hsv_oracle.c)")
+        leg = Leg("hsvfilter_rgb", "hsvfilter_4k_rgb_frames_per_sec", "frames/s", nb, nb * 2 * W * H * 3, "f32",
+                  "synthetic videotestsrc pattern=smpte frames packed to RGB, device-resident",
+                  f"hsvfilter 3840x2160 RGB (3 B/px) in place, {nb} streams per launch; 3 + 3 algorithmic B/px", step, ["hsvfilter3_kernel"],
+                  cpu=cpu if host else None)
+        leg.keep = (src, fi)
+        return leg
+    dst = torch.empty((pool * nb, FRAME_BYTES), dtype=torch.uint8, device=dev)
+    fo = [(vfx.Frame * nb)(*[vfx.make_frame(dst[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
+
+    def step(i):
+        vfx.check(lib.mvfx_hsvdetector_transform_frames(fi[i % pool], fo[i % pool], nb, ctypes.byref(ds), sptr))
+
+    def cpu(seconds):
+        import numpy as np
+        from tests import oracle_binding as orc
+
+        def make_unit(t):
+            out = np.empty((H, W * 4), dtype=np.uint8)
+            k = [t]
+
+            def unit():
+                f = host[k[0] % len(host)]
+                k[0] += 1
+                orc.hsvdetector(f, stride3, "RGB", out, W * 4, "RGBA", W, DETECT_SETTINGS)
+            return (lambda: None), unit
+        return cpu_baseline_of(make_unit, seconds, "frames/s", "3840x2160 RGB frame through orc_hsvdetector_transform_frame (oracle/hsv_oracle.c)")
+    leg = Leg("hsvdetector_rgb", "hsvdetector_4k_rgb_in_frames_per_sec", "frames/s", nb, nb * W * H * 7, "f32",
+              "synthetic videotestsrc pattern=smpte frames packed to RGB, device-resident",
+              f"hsvdetector 3840x2160 RGB -> RGBA, {nb} streams per launch; 3 + 4 algorithmic B/px", step, ["hsvdetector_kernel"],
+              cpu=cpu if host else None)
+    leg.keep = (src, dst, fi, fo)
     return leg
 
 
@@ -770,7 +1006,7 @@ def make_leg_videocompare(w, args, algo):
         if algo == "blockhash":
             host_pair = [full[0, p].cpu().numpy().reshape(H, W * 4).copy() for p in range(2)]
         else:
-            cw, ch = 1920, 1080
+            cw, ch = 960, 540
             host_pair = [full[0, p].view(H, W * 4)[:ch, :cw * 4].contiguous().cpu().numpy().copy() for p in range(2)]
     bytes_per_pair = 2 * W * H * 4
     if algo == "dssim":
@@ -781,7 +1017,7 @@ def make_leg_videocompare(w, args, algo):
                   "synthetic uniform-random u8 RGBA 8K pairs (B = A with 1 % of the bytes perturbed), device-resident",
                   "videocompare hash-algo=dssim (multi-scale SSIM) on 7680x4320 RGBA pairs, one GPU, synchronous mvfx_ssim_distance per pair; "
                   "4 + 4 compulsory B/px-pair (the planes of the pyramid are implementation traffic)",
-                  step, ["ssim_*"], cpu=(lambda s: cpu_baseline_dssim(s, host_pair, 1920, 1080)) if host_pair else None,
+                  step, ["ssim_*"], cpu=(lambda s: cpu_baseline_dssim(s, host_pair, 960, 540)) if host_pair else None,
                   fixed_settle=20, extra={"last_distance": last},
                   note="compulsory input bytes against HBM peak; the pyramid planes are extra traffic, see traffic_over_algorithmic")
     else:
@@ -834,24 +1070,32 @@ def make_leg_videocompare(w, args, algo):
 
 
 def other_config_legs(w, args):
-    """BASELINE configs 2-5 measured in the same run as the headline (`config.other_configs` of the driver's line): each with
-    value, roofline fractions from HIP events and wall clock, p10/p50/p90 per step, committed PMC traffic and a CPU-port baseline."""
+    """BASELINE configs 2-5 measured in the same run as the headline: each becomes its own small JSON line printed before the final
+    line (compact_sub) and a full entry of bench_out/last_run.json: value, roofline fractions over the wall clock and over HIP events,
+    p10/p50/p90 per step, committed PMC traffic / bound and a bounded CPU-port baseline."""
     torch = w.torch
     out = {}
     import copy
     args_vfx = copy.copy(args)
-    args_vfx.element_streams = 2  # config 4 in the driver's line: the two elements on their own streaming threads (HIP streams)
+    args_vfx.element_streams = 2  # config 4 in the driver's run: the two elements on their own streaming threads (HIP streams)
     makers = [("hsv1080p", lambda: make_leg_hsv1080p(w, args)),
               ("colorlut_natural", lambda: make_leg_colorlut(w, args, "natural")),
               ("colorlut_random", lambda: make_leg_colorlut(w, args, "random")),
               ("videofx", lambda: make_leg_videofx(w, args_vfx)),
               ("videocompare_blockhash", lambda: make_leg_videocompare(w, args, "blockhash")),
-              ("videocompare_dssim", lambda: make_leg_videocompare(w, args, "dssim"))]
+              ("videocompare_dssim", lambda: make_leg_videocompare(w, args, "dssim")),
+              ("hsvfilter_rgb", lambda: make_leg_hsv3(w, args, "filter")),
+              ("hsvdetector_rgb", lambda: make_leg_hsv3(w, args, "detector"))]
     steps = {"hsv1080p": 200, "colorlut_natural": 100, "colorlut_random": 40, "videofx": 400, "videocompare_blockhash": 400,
-             "videocompare_dssim": 30}
+             "videocompare_dssim": 30, "hsvfilter_rgb": 60, "hsvdetector_rgb": 60}
+    only = [k for k in args.only_configs.split(",") if k]
     for key, make in makers:
+        if only and key not in only:
+            continue
+        t0 = time.perf_counter()
         try:
             leg = make()
+            t_made = time.perf_counter() - t0
             k = steps[key]
             r = measure_leg(w, leg, k, max(5, k // 10), args.other_settle_seconds, 200 if key != "videocompare_dssim" else 40,
                             args.other_cpu_seconds)
@@ -859,14 +1103,19 @@ def other_config_legs(w, args):
                 leg.drain()
             if key == "colorlut_natural" and args.stream_threads > 0:
                 r["config"]["other_launch_model"] = leg.streams_leg()
+                r["config"]["element_model"] = r["config"]["other_launch_model"]["value"]
+            if key == "colorlut_natural" and args.noise_sweep:
+                r["sub_extra"] = {"noise_fps": leg.noise_sweep()}
             if "last_distance" in r["config"]:
                 r["config"]["last_distance"] = r["config"]["last_distance"][0]
+            r["measure_seconds"]["make"] = t_made
             out[key] = r
             del leg
         except Exception as e:  # a failing side leg must not cost the headline line
             out[key] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
+        out[key]["leg_seconds"] = time.perf_counter() - t0
     return out
 
 
@@ -886,12 +1135,12 @@ def videocompare_main(args):
         r["config"]["last_distance"] = r["config"]["last_distance"][0]
         r.update({"n_gpus": 1, "higher_is_better": True, "vs_baseline": None})
         r["config"].update({"parallelism": "one GPU, whole frames", "rccl_ranks": w.rccl_ranks})
-        emit(r)
+        emit(r, full=bool(args.full))
         w.finish()
         return
     out = videocompare_sharded_leg(w, args, args.hash_algo, args.steps, args.warmup)
     if w.rank == 0:
-        emit(out)
+        emit(out, full=bool(args.full))
     w.finish()
 
 
@@ -970,7 +1219,7 @@ def videocompare_sharded_leg(w, args, algo, steps, warmup):
                    "collective": "ncclAllReduce inside mvfx_videocompare_sharded_distances (library-owned communicator), hash bits + Hamming "
                                  "distance on the device, one 4-byte D2H per pair" if algo == "blockhash" else
                                  "two ncclAllReduce (10 + 5 f64) inside mvfx_videocompare_sharded_dssim (library-owned communicator)"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+        "roofline": {"bound": "hbm" if algo == "blockhash" else "valu", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                      "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
                      "note": "end-to-end per pair incl. the all-reduce, the D2H of the block sums, the synchronisation and host bit derivation"}}
 
@@ -992,14 +1241,17 @@ def config_main(args):
     r.update({"n_gpus": w.world, "higher_is_better": True, "vs_baseline": None})
     r["config"].update({"parallelism": f"{w.world} independent streams", "rccl_ranks": w.rccl_ranks})
     if w.rank == 0:
-        emit(r)
+        emit(r, full=bool(args.full))
     w.finish()
 
 
 # ------------------------------------------------------------------------------------------------ headline
 
 def hsvfilter_main(args):
+    t_start = time.perf_counter()
+    timing = {}
     w = Worker(args)
+    timing["worker_init"] = time.perf_counter() - t_start
     torch, vfx, lib, dev, sptr = w.torch, w.vfx, w.lib, w.dev, w.sptr
     rank, world = w.rank, w.world
     opts = vfx.options(variant=args.variant, nontemporal=bool(args.streaming), typed=bool(args.typed_loads)).word
@@ -1154,16 +1406,31 @@ def hsvfilter_main(args):
     # power state (the timed kernels then ran 3-4 % slower: profiles/r2/ab_fresh_vs_converged_data.txt)
     settle(scratch_step, min(args.settle_seconds, 0.3), w.sync)
     ceiling = measured_rmw_ceiling(w, frames.data_ptr(), args.batch * FRAME_BYTES, pool + n_scratch)
-    traffic, traffic_source = committed_traffic("hsvfilter", args.batch)
     bytes_per_launch = args.batch * 2 * FRAME_BYTES  # 4 B read + 4 B written per pixel
-    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-    achieved_wall = batch_fps / world * 2 * FRAME_BYTES / 1e9
     batch_model = {"launch_model": f"1 launch x {args.batch} frames (mvfx_hsvfilter_transform_frames_ip, blockIdx.z = stream)",
                    "value": batch_fps, "unit": "frames/s", "per_rank_frames_per_sec": batch_fps_rank}
     use_streams = args.launch_model == "streams" and streams is not None
     head, other = (streams, batch_model) if use_streams else (batch_model, streams)
     total_frames = args.steps * args.batch * world
     ceil_gbs = ceiling["in_place_nt"]["GBs"]
+    kernel_name = "hsvfilter4_typed_kernel" if args.typed_loads else "hsvfilter4_kernel<RGBA, vec4>"
+    # wall seconds per launch of the model `value` reports (per GPU: every rank runs its own launches)
+    wall_per_launch = args.batch * world / head["value"]
+    roof = roofline_of("hsvfilter", args.batch, bytes_per_launch, wall_per_launch, kernel_ms * 1e-3, kernel_name, launch_pct)
+    roof.update({"avg_launch_ms": kernel_ms, "launch_us": launch_pct, "bytes_per_launch": bytes_per_launch,
+                 "read_side_GBs": roof["achieved_kernel"] / 2, "ceiling_measured_GBs": ceil_gbs,
+                 "frac_of_measured_ceiling": roof["achieved_kernel"] / ceil_gbs if ceil_gbs else None, "ceilings": ceiling,
+                 "ceiling_note": "in-tree RMW probe (gst-plugin-rs_amd/bench/probe_rmw.hip): the kernel's own memory shape -- one 16-byte "
+                                 "non-temporal load + store per lane, in place, trivial arithmetic -- over the same resident pool, timed with "
+                                 "HIP events in this run after the timed legs; in_place_cached / out_of_place_nt are the shapes of the other filters",
+                 "launch_model": batch_model["launch_model"]})
+    # what ONE drop-in hsvfilter element does (one call per buffer, hsvfilter/imp.rs:322-326), beside the batched entry `value` reports
+    element_path = None
+    if streams is not None:
+        element_path = {"threads16_fps": _r(streams["value"], 5), "threads16_frac": _r(streams["frac_wall"], 4)}
+        if single_stream:
+            element_path.update({"one_thread_fps": _r(single_stream["two_streams"]["value"], 5),
+                                 "one_thread_frac": _r(single_stream["two_streams"]["frac_wall"], 4)})
     out = {
         "metric": "hsvfilter_4k_rgba_frames_per_sec",
         "value": head["value"],
@@ -1176,14 +1443,16 @@ def hsvfilter_main(args):
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": (f"synthetic {CONTENT_TEXT[args.frame_content]}, device-resident; the timed steps start on frames no kernel has "
-                 "touched (settle + warm-up run on scratch batches)") if not args.converged_data else
-                f"A/B: {args.frame_content} frames filtered {args.converged_data}x before the timed steps (converged, low-entropy)",
+        "data": (f"synthetic {args.frame_content} 4K RGBA frames, device-resident; timed steps start on frames no kernel has touched"
+                 if not args.converged_data else
+                 f"A/B: {args.frame_content} frames filtered {args.converged_data}x before the timed steps (converged, low-entropy)"),
+        "data_detail": CONTENT_TEXT[args.frame_content],
         "config": {"workload": "hsvfilter 3840x2160 RGBA in place, hue-shift=90 saturation-mul=1.25 "
                                "saturation-off=-0.05 value-mul=0.9 value-off=0.02",
                    "frame_content": args.frame_content, "other_frame_contents": sweep,
                    "launch_model": head["launch_model"], "other_launch_model": other, "combined_launch_model": combined,
-                   "one_video_stream_launch_models": single_stream,
+                   "one_video_stream_launch_models": single_stream, "element_path": element_path,
+                   "value_p50": args.batch * world / (launch_pct["p50"] * 1e-6) if launch_pct else None,
                    "frames_per_step_per_gpu": args.batch, "resident_batches": pool, "steps_executed": n_launches[0],
                    "settle_seconds_before_warmup": args.settle_seconds, "settle_steps": settle_steps,
                    "parallelism": f"{world} independent stream shards, no data-path collective",
@@ -1192,27 +1461,25 @@ def hsvfilter_main(args):
                    "kernel_variant": {0: "auto", 1: "literal", 2: "strength-reduced"}[args.variant],
                    "cache_policy": "non-temporal (MVFX_OPT_NONTEMPORAL)" if args.streaming else "default",
                    "u8_to_unit_float": "typed buffer loads (texture-unit UNORM8, exact)" if args.typed_loads else "VALU (cvt + mul + fmac)"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "frac_kernel": achieved / HBM_PEAK_GBS,
-                     "frac_wall": achieved_wall / HBM_PEAK_GBS, "achieved_wall": achieved_wall,
-                     "frac_note": "frac = frac_kernel: algorithmic bytes per launch / average launch duration between two HIP events on "
-                                  "the launch stream over the K timed launches; frac_wall: the same bytes / the wall clock `value` is made of",
-                     "traffic": traffic, "traffic_source": traffic_source,
-                     "traffic_over_algorithmic": traffic / bytes_per_launch if traffic else None,
-                     "kernel": "hsvfilter4_typed_kernel" if args.typed_loads else "hsvfilter4_kernel<RGBA, vec4>", "bytes_per_launch": bytes_per_launch,
-                     "avg_launch_ms": kernel_ms, "launch_us": launch_pct, "read_side_GBs": achieved / 2,
-                     "ceiling_measured_GBs": ceil_gbs, "frac_of_measured_ceiling": achieved / ceil_gbs if ceil_gbs else None,
-                     "ceilings": ceiling,
-                     "ceiling_note": "in-tree RMW probe (gst-plugin-rs_amd/bench/probe_rmw.hip): the kernel's own memory shape -- one 16-byte "
-                                     "non-temporal load + store per lane, in place, trivial arithmetic -- over the same resident pool, timed with "
-                                     "HIP events in this run after the timed legs; in_place_cached / out_of_place_nt are the shapes of the other filters",
-                     "launch_model": batch_model["launch_model"]},
+        "roofline": roof,
     }
+    timing["headline_gpu_legs"] = time.perf_counter() - t_start
     del frames, flat_frames, frame_arrays
     torch.cuda.empty_cache()
+    subs = []
     if args.other_configs and world == 1:
         vfx.check(lib.mvfx_thread_set_options(0))
-        out["config"]["other_configs"] = other_config_legs(w, args)
+        t1 = time.perf_counter()
+        ALL_CORES_SECONDS[0] = args.other_cpu_all_seconds
+        others = other_config_legs(w, args)
+        out["config"]["other_configs"] = others
+        subs = list(others.items())
+        timing["other_configs"] = time.perf_counter() - t1
+        if args.gst_pipeline:
+            t1 = time.perf_counter()
+            subs.append(("gst_element_pipeline", gst_pipeline_leg(args)))
+            out["config"]["gst_element_pipeline"] = subs[-1][1]
+            timing["gst_pipeline"] = time.perf_counter() - t1
     elif args.other_configs and world > 1:
         # the one workload with a data-path collective, on the real xGMI fabric: 8K pairs band-sharded over the ranks, the all-reduce
         # inside libmi355vfx (its own RCCL communicator).  It runs under a watchdog: this leg has never seen more than one GPU before
@@ -1236,25 +1503,54 @@ def hsvfilter_main(args):
         th = threading.Thread(target=side_leg, daemon=True)
         th.start()
         th.join(timeout=args.side_leg_timeout)
-        if th.is_alive():
-            late = {"error": f"no result within {args.side_leg_timeout} s (watchdog)"}
-            out["config"]["other_configs"] = {"videocompare_blockhash_sharded": box.get("r", late), "videocompare_dssim_sharded": box.get("d", late)}
+        late = {"error": f"no result within {args.side_leg_timeout} s (watchdog)"}
+        stuck = th.is_alive()
+        sides = {"videocompare_blockhash_sharded": box.get("r", late), "videocompare_dssim_sharded": box.get("d", late)}
+        out["config"]["other_configs"] = sides
+        subs = list(sides.items())
+        if stuck:
             if rank == 0:
-                emit(out)
+                out["wall_s"] = time.perf_counter() - t_start
+                emit(out, subs, full=bool(args.full))
             os._exit(0)  # the stuck thread holds the communicator: no orderly teardown
-        out["config"]["other_configs"] = {"videocompare_blockhash_sharded": box["r"], "videocompare_dssim_sharded": box.get("d")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        t1 = time.perf_counter()
+        ALL_CORES_SECONDS[0] = args.cpu_all_seconds
         out["cpu_baseline"] = cpu_baseline_hsvfilter(args.cpu_seconds, args.frame_content)
+        timing["cpu_baseline"] = time.perf_counter() - t1
     if world > 1:  # every rank empties its C stdio first (RCCL's banner), so that rank 0's line is the last thing on the launcher's stdout
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
+        _flush_c_stdio()
         sys.stdout.flush()
         w.barrier()
     if rank == 0:
-        emit(out)
+        out["wall_s"] = time.perf_counter() - t_start
+        out["timing_s"] = timing
+        emit(out, subs, full=bool(args.full))
     w.finish()
+
+
+def gst_pipeline_leg(args):
+    """The real element: `gst-launch-1.0 hiptestsrc ! video/x-raw(memory:HIPMemory),RGBA,3840x2160 ! hsvfilter ! fakesink` in child
+    processes (tools/bench_gst_pipeline.py --branches 1: two runs with N1 and N2 buffers, frames/s = (N2 - N1) / (t2 - t1))."""
+    gst_dir = os.path.join(ROOT, "gst-plugin-rs_amd", "gst-plugins")
+    if not os.path.isdir(gst_dir) or not os.path.exists("/opt/conda/bin/gst-launch-1.0"):
+        return {"error": "no GStreamer on this box (the element layer is an optional build target)"}
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_gst_pipeline.py"), "--branches", "1", "--quick", "1",
+           "--n1", str(args.gst_n1), "--n2", str(args.gst_n2)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=args.gst_timeout)
+        if r.returncode != 0:
+            return {"error": f"bench_gst_pipeline rc {r.returncode}: {r.stderr[-200:]}"}
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+    fps = d.get("refresh_false_combine_0_fps")
+    return {"metric": "gst_hsvfilter_element_4k_rgba_frames_per_sec", "value": fps, "unit": "frames/s",
+            "ms_per_step": 1e3 / fps if fps else None,
+            "roofline": {"bound": "valu", "frac": fps * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS if fps else None},
+            "sub_extra": {"pipeline": "gst-launch-1.0 hiptestsrc refresh=false ! video/x-raw(memory:HIPMemory),format=RGBA,3840x2160 ! hsvfilter ! fakesink",
+                          "buffers": [d.get("n1"), d.get("n2")]},
+            "detail": d}
 
 
 def main():
@@ -1276,16 +1572,30 @@ def main():
                     help="A/B only: filter every frame of the timed pool this many times BEFORE the timed steps (frames that have "
                          "been through hsvfilter repeatedly converge to low-entropy colours; the chip then draws less power and "
                          "clocks higher: profiles/r2/ab_fresh_vs_converged_data.txt). Default 0 = fresh uniform-random frames")
-    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU baseline budget per leg (1 thread, then nproc threads)")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU baseline budget per leg (1 thread, then nproc threads)")
+    ap.add_argument("--cpu-all-seconds", type=float, default=3.0, help="headline CPU baseline on nproc threads (0 = skip)")
+    ap.add_argument("--other-cpu-all-seconds", type=float, default=0.0,
+                    help="configs 2-5: CPU baseline on nproc threads (0 = skip: the driver's command has to fit in a minute; the sub-lines quote the "
+                         "one-thread rate, which is what the reference's one streaming thread does)")
+    ap.add_argument("--full", type=int, default=0, choices=[0, 1],
+                    help="1: the final line is the whole document (profiling tools); 0: the compact line (<= 3000 bytes) -- the whole document "
+                         "is always written to bench_out/last_run.json")
+    ap.add_argument("--only-configs", default="", help="comma-separated subset of the configs 2-5 legs (default: all)")
+    ap.add_argument("--noise-sweep", type=int, default=1, choices=[0, 1], help="colorlut: frames/s at +-0/3/5/8/16 codes of noise (sub-line field)")
+    ap.add_argument("--gst-pipeline", type=int, default=1, choices=[0, 1],
+                    help="N = 1: also time the real GStreamer element (gst-launch-1.0 hiptestsrc ! hsvfilter ! fakesink, 4K, child processes)")
+    ap.add_argument("--gst-n1", type=int, default=2000)
+    ap.add_argument("--gst-n2", type=int, default=62000)
+    ap.add_argument("--gst-timeout", type=float, default=60.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--other-configs", type=int, default=1, choices=[0, 1],
                     help="hsvfilter workload: after the headline legs also measure BASELINE configs 2-5 in this run "
                          "(config.other_configs); N > 1: the band-sharded videocompare leg with its RCCL all-reduce")
-    ap.add_argument("--combiner-legs", type=int, default=1, choices=[0, 1],
+    ap.add_argument("--combiner-legs", type=int, default=0, choices=[0, 1],
                     help="0 skips the two launch-combiner legs: rocprofiler-sdk 7.2 (rocprofv3 --kernel-trace / --pmc) crashes inside its HSA queue "
                          "interceptor on the cross-stream hipStreamWaitEvent traffic they generate (profiles/r3/rocprofv3_crash_in_queue_interceptor.txt)")
     ap.add_argument("--side-leg-timeout", type=float, default=180.0, help="N > 1: watchdog of the band-sharded videocompare leg, seconds")
-    ap.add_argument("--other-cpu-seconds", type=float, default=2.5, help="CPU baseline budget per leg of configs 2-5")
+    ap.add_argument("--other-cpu-seconds", type=float, default=1.0, help="CPU baseline budget per leg of configs 2-5 (1 thread, then nproc threads)")
     ap.add_argument("--other-settle-seconds", type=float, default=0.3, help="untimed run before each leg of configs 2-5")
     ap.add_argument("--pct-steps", type=int, default=200,
                     help="extra steps with a HIP event between every two, for the p10/p50/p90 of the per-step time (0 = skip)")

@@ -44,3 +44,69 @@ def test_plain_command_on_a_box_without_gpus_exits_with_a_message():
     import torch
     if torch.cuda.device_count() < 2:
         assert r.returncode == 2 and "GPU(s) visible" in r.stderr
+
+
+def _fat_document():
+    """a document as large as round 3's 20 KB line: prose notes, nested legs, per-rank lists"""
+    prose = "x" * 1500
+    roof = {"bound": "valu", "achieved": 5731.123456789, "peak": 8000.0, "unit": "GB/s", "frac": 0.716390432, "frac_kernel": 0.7237,
+            "achieved_kernel": 5790.1, "frac_valu": 0.98, "traffic": None, "traffic_committed": 1063442837.92, "traffic_source": prose,
+            "traffic_over_algorithmic": 1.0016574, "kernel": "hsvfilter4_typed_kernel", "bytes_per_step": 1061683200, "avg_step_us": 183.3,
+            "p50_step_us": 185.3, "note": prose, "ceiling_note": prose, "ceilings": {"a": {"GBs": 6000.0, "us_per_launch": 100.0}},
+            "step_us": {"n": 200, "p10": 183.3, "p50": 185.3, "p90": 188.2, "mean": 185.5, "unit": "us"}}
+    cpu = {"value": 3.21, "unit": "frames/s", "cores": 1, "kind": "port", "sample": prose,
+           "all_cores": {"value": 400.2, "unit": "frames/s", "cores": 256, "nproc": 256, "sample": prose}}
+    leg = {"metric": "colorlut_frames_per_sec", "value": 72107.9, "unit": "frames/s", "ms_per_step": 0.22, "data": prose,
+           "config": {"workload": prose, "per_rank_units_per_sec": [72107.9]}, "roofline": dict(roof), "cpu_baseline": dict(cpu),
+           "sub_extra": {"noise_fps": {"0": 80000, "3": 70000, "5": 60000, "8": 55000, "16": 30000}}}
+    doc = {"metric": "hsvfilter_4k_rgba_frames_per_sec", "value": 86640.5123, "unit": "frames/s", "n_gpus": 8, "steps": 20, "warmup": 5,
+           "ms_per_step": 0.1847, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": prose,
+           "config": {"workload": "hsvfilter 3840x2160 RGBA in place, hue-shift=90 saturation-mul=1.25 saturation-off=-0.05 value-mul=0.9 value-off=0.02",
+                      "launch_model": "1 launch x 16 frames (mvfx_hsvfilter_transform_frames_ip, blockIdx.z = stream)", "frames_per_step_per_gpu": 16,
+                      "parallelism": "8 independent stream shards, no data-path collective", "rccl_ranks": 8,
+                      "per_rank_frames_per_sec": [86640.5123] * 8, "other_launch_model": {"note": prose},
+                      "element_path": {"threads16_fps": 80000.0, "threads16_frac": 0.66, "one_thread_fps": 81000.0, "one_thread_frac": 0.67},
+                      "other_configs": {k: dict(leg) for k in ("hsv1080p", "colorlut_natural", "colorlut_random", "videofx", "videocompare_blockhash",
+                                                                "videocompare_dssim", "hsvfilter_rgb", "hsvdetector_rgb")}},
+           "roofline": roof, "cpu_baseline": cpu}
+    return doc
+
+
+def test_final_line_is_small_and_carries_roofline_and_cpu_baseline(tmp_path, capsys, monkeypatch):
+    """the driver keeps a tail of stdout; a 20 KB final line arrived beheaded and nothing was parsed.  The LAST line must stay
+    below 3000 bytes for any document, carry `roofline` and `cpu_baseline`, and every earlier line must be a small JSON line of its own."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "FULL_DOC", str(tmp_path / "bench_out" / "last_run.json"))
+    doc = _fat_document()
+    assert len(json.dumps(doc)) > 20000
+    bench.emit(doc, list(doc["config"]["other_configs"].items()))
+    lines = capsys.readouterr().out.strip().splitlines()
+    assert len(lines) == 9
+    last = json.loads(lines[-1])
+    assert len(lines[-1]) < 3000
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in last, k
+    assert last["config"]["workload"].startswith("hsvfilter 3840x2160 RGBA") and "model" not in last["config"]
+    r = last["roofline"]
+    assert r["bound"] == "valu" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "traffic" in r and r["traffic"] is None and r["traffic_committed"] > 0 and "frac_kernel" in r and "frac_valu" in r
+    c = last["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["all_cores"]["cores"] == 256 and len(c["sample"]) <= 200
+    for ln in lines[:-1]:
+        assert len(ln) <= 1000
+        s = json.loads(ln)
+        assert s["sub"] and s["value"] > 0 and "frac_wall" in s and "cpu_value" in s
+    # the whole document travels in the file
+    full = json.loads((tmp_path / "bench_out" / "last_run.json").read_text())
+    assert full["config"]["other_configs"]["colorlut_natural"]["data"] == doc["config"]["other_configs"]["colorlut_natural"]["data"]
+
+
+def test_a_failed_side_leg_is_a_small_error_line(tmp_path, capsys, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "FULL_DOC", str(tmp_path / "last_run.json"))
+    doc = _fat_document()
+    bench.emit(doc, [("videofx", {"error": "RuntimeError: " + "y" * 5000})])
+    lines = capsys.readouterr().out.strip().splitlines()
+    assert len(lines) == 2 and len(lines[0]) < 1000 and json.loads(lines[0])["sub"] == "videofx" and len(lines[1]) < 3000

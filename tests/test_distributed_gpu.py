@@ -146,15 +146,18 @@ def test_bench_two_ranks_control_flow_on_one_gpu(gpu, tmp_path):
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(tmp_path))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE line
-    d = json.loads(lines[0])
+    assert len(lines) == 3, r.stdout[-2000:]  # rank 0 prints the two sharded side legs as their own small lines, then THE line
+    assert all(len(ln) < 3000 for ln in lines)
+    d = json.loads(lines[-1])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     c = d["config"]
     assert c["rccl_ranks"] == 2 and c["rendezvous_backend"] == "gloo"
     assert len(c["per_rank_frames_per_sec"]) == 2
     # whole-job value = frames of both ranks / the slowest rank's time: never more than the sum of the per-rank rates
     assert d["value"] <= sum(c["per_rank_frames_per_sec"]) * 1.0001
+    assert d["roofline"]["bound"] in ("valu", "hbm") and d["roofline"]["frac"] > 0
+    subs = {json.loads(ln)["sub"]: json.loads(ln) for ln in lines[:-1]}
     for key in ("videocompare_blockhash_sharded", "videocompare_dssim_sharded"):
-        side = c["other_configs"][key]
+        side = subs[key]
         assert "error" in side or side["n_gpus"] == 2, key
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only

@@ -55,14 +55,15 @@ def branches_main(args):
     w, h, n = args.width, args.height, args.branches
     caps = f"video/x-raw(memory:HIPMemory),format=RGBA,width={w},height={h},framerate=30/1"
     out = {"frame": f"{w}x{h}", "branches": n, "n1": args.n1, "n2": args.n2, "bytes_per_frame": 2 * w * h * 4}
-    for refresh in ("false", "true"):
+    for refresh in (("false",) if args.quick else ("false", "true")):
         tpl = " ".join(f"hiptestsrc num-buffers={{n}} refresh={refresh} ! {caps} ! hsvfilter hue-shift={(17 * k) % 360 - 120} saturation-mul={1 + 0.02 * k} "
                        "! fakesink sync=false" for k in range(n))
-        for combine in ("0", "1", "2"):
+        for combine in (("0",) if args.quick else ("0", "1", "2")):
             env = {"MVFX_COMBINE": combine, "MVFX_COMBINE_STATS": "1"}
             # ten times the buffers of the single-chain runs: 16 branches at tens of thousands of frames per second finish 500 buffers each
             # inside the noise of a process start
-            v, t1, t2 = fps(tpl, tmp, args.n1 * 10, args.n2 * 10, env)
+            mul = 1 if args.quick else 10
+            v, t1, t2 = fps(tpl, tmp, args.n1 * mul, args.n2 * mul, env)
             key = f"refresh_{refresh}_combine_{combine}"
             out[key + "_fps"] = round(v * n, 1)
             out[key + "_frac_of_8TBs"] = round(v * n * 2 * w * h * 4 / 8e12, 4)
@@ -79,6 +80,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="", help="comma-separated pipeline names of the chain mode (default: all)")
     ap.add_argument("--branches", type=int, default=0, help="N parallel hiptestsrc ! hsvfilter ! fakesink streams in one process (launch combiner A/B)")
+    ap.add_argument("--quick", type=int, default=0, help="--branches: only refresh=false, no combiner, n1 / n2 taken literally (bench.py's sub-line)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--n1", type=int, default=60)
