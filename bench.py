@@ -796,8 +796,8 @@ def make_leg_colorlut(w, args, content):
         fill_frames(torch, dev, gen, src, "videotestsrc", W, H, first_frame=w.rank * pool * nb)
         data = "synthetic " + CONTENT_TEXT["videotestsrc"] + ", device-resident"
     else:
-        fill_frames(torch, dev, gen, src, "natural", W, H, first_frame=w.rank * pool * nb)
-        data = "synthetic " + CONTENT_TEXT["natural"] + ", device-resident"
+        fill_frames(torch, dev, gen, src, "natural", W, H, first_frame=w.rank * pool * nb, noise=args.noise)
+        data = "synthetic " + CONTENT_TEXT["natural"].replace("+-3", f"+-{args.noise}") + ", device-resident"
     dst = torch.empty((pool * nb, FRAME_BYTES), dtype=torch.uint8, device=dev)
     fi = [(vfx.Frame * nb)(*[vfx.make_frame(src[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
     fo = [(vfx.Frame * nb)(*[vfx.make_frame(dst[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
@@ -1613,6 +1613,7 @@ def main():
                     help="colorlut workload: frame content. The LUT gathers are content dependent: smooth gradients with +-3 "
                          "codes of noise (default), uniform-random colours (worst case: every pixel another LUT cell), or flat "
                          "videotestsrc-smpte-like bars (best case)")
+    ap.add_argument("--noise", type=int, default=3, help="colorlut workload, content natural: uniform noise of +-N codes on the gradients")
     ap.add_argument("--typed-loads", type=int, default=1, choices=[0, 1],
                     help="hsvfilter: u8/255 by typed buffer loads (texture-unit UNORM conversion) instead of VALU")
     ap.add_argument("--element-streams", type=int, default=1, choices=[1, 2],

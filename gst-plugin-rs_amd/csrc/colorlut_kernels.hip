@@ -27,6 +27,7 @@
 #include <new>
 #include <algorithm>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 struct mvfx_cube_lut {
@@ -799,9 +800,49 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
 // their two entries from the table in global memory.  The per-byte coordinate entries of g and b hold the cell index already
 // multiplied by the window's LDS pitch of that axis, so the in-window test and the LDS address are three subtractions, three
 // compares, one add3 and one mad.
-constexpr uint32_t kXRows = 12;          // 3 y cells x 4 z rows
 constexpr uint32_t kXRowPieces = 384;    // 16-byte pieces per (y, z) row of the table: 256 entries x 24 B
-constexpr uint32_t kXPitchZ = MVFX_XTILE_RW * 24, kXPitchY = 4 * kXPitchZ; // LDS bytes between z rows / y cells of a window
+#ifndef MVFX_XTILE_YPAD
+#define MVFX_XTILE_YPAD 0 // bytes between the y slabs of a window in LDS.  Without it a slab is 4 x 576 = 2304 bytes = 9 x 256: the entries
+                          // (r, y, z) and (r, y + 1, z) sit on the SAME banks, and lanes of one ds_read whose g bytes fall into neighbouring
+                          // cells -- every block of a noisy picture -- serialise
+#endif
+constexpr uint32_t kXPitchZ = MVFX_XTILE_RW * 24, kXPitchY = 4 * kXPitchZ + MVFX_XTILE_YPAD; // LDS bytes between z rows / y cells of a window
+constexpr uint32_t kXWaveBytes = 3 * kXPitchY + 32; // +32 bytes: de-phases the four waves' regions over the banks
+
+// The wave's window: 3 y slabs x 4 z rows x RW entries of the x table, global -> LDS directly (global_load_lds_dwordx4: LDS address =
+// wave-uniform base + lane x 16, which is the window's piece order inside a slab): no staging registers, no ds_write pass.
+// `base` = the table piece of (ay, az, ar), wave-uniform.
+__device__ __forceinline__ void xtile_fill_window(const float4 *xtable, uint32_t base, uint32_t size, uint8_t *lds_region, uint32_t lane)
+{
+    typedef __attribute__((address_space(3))) void *lds_void_t;
+    typedef const __attribute__((address_space(1))) void *global_void_t;
+    constexpr uint32_t kRowP = MVFX_XTILE_RW * 3 / 2, kSlabP = 4 * kRowP;
+    if constexpr (MVFX_XTILE_YPAD == 0) {
+        constexpr uint32_t kPieces = 3 * kSlabP;
+#pragma unroll
+        for (uint32_t q0 = 0; q0 < kPieces; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            if (q0 + 64 <= kPieces || q < kPieces) {
+                const uint32_t wr = q / kRowP, k = q - wr * kRowP; // window row = dy * 4 + dz
+                __builtin_amdgcn_global_load_lds((global_void_t)(xtable + (base + ((wr >> 2) * (size + 1) + (wr & 3u)) * kXRowPieces + k)),
+                                                 (lds_void_t)(lds_region + q0 * 16), 16, 0, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (uint32_t dy = 0; dy < 3; dy++) {
+#pragma unroll
+            for (uint32_t q0 = 0; q0 < kSlabP; q0 += 64) {
+                const uint32_t q = q0 + lane;
+                if (q0 + 64 <= kSlabP || q < kSlabP) {
+                    const uint32_t dz = q / kRowP, k = q - dz * kRowP;
+                    __builtin_amdgcn_global_load_lds((global_void_t)(xtable + (base + (dy * (size + 1) + dz) * kXRowPieces + k)),
+                                                     (lds_void_t)(lds_region + dy * kXPitchY + q0 * 16), 16, 0, 0);
+                }
+            }
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void colorlut_xtable_build_kernel(const float4 *__restrict__ cube, const uint32_t *__restrict__ tile_tables,
                                                                     uint32_t size, float *__restrict__ xtable)
@@ -827,11 +868,6 @@ typedef const __attribute__((address_space(3))) f32x2_t *lds_float2_t;
 #ifndef MVFX_XTILE_ROWS
 #define MVFX_XTILE_ROWS 4 // rows of four pixels per lane: the wave's block is 64 x (4 x rows) pixels
 #endif
-#ifndef MVFX_XTILE_MISS_CELLS
-#define MVFX_XTILE_MISS_CELLS 0 // pixels outside the window: 0 = two entries of the x table, 1 = the 96-byte cell of the cell-packed table
-                                // (uniform-random colours 2.22 -> 1.59 ms per 16 frames, but 104 instead of 92 VGPRs: natural-like 0.635 ->
-                                // 0.585 of the HBM peak, flat bars 0.56 -> 0.47 on the same box -- not taken)
-#endif
 #ifndef MVFX_XTILE_ANCHOR4
 #define MVFX_XTILE_ANCHOR4 0 // 1: the window is anchored at the mean of four pixels of the block instead of its centre pixel.  Measured
                              // (profiles/r3/colorlut_anchor4.txt): gradients +- 8 codes of noise 39.3 k -> 47.3 k fps, +- 5: 59.0 k -> 61.9 k, but
@@ -841,11 +877,19 @@ typedef const __attribute__((address_space(3))) f32x2_t *lds_float2_t;
                              // agree: +- 5 / 8 / 12 codes of noise +6 / +18 / +10 %, clean and +- 3 frames -1...2 %, one frame per launch 19.0 -> 20.2 us:
                              // the anchor chain then waits behind a vector load.  Also off; a build for noisy footage may want it
 #endif
-#ifndef MVFX_XTILE_GROUP
-#define MVFX_XTILE_GROUP 4 // pixels per window look-up / miss branch group (1, 2 or 4)
-#endif
 #ifndef MVFX_XTILE_MIN_BLOCKS
-#define MVFX_XTILE_MIN_BLOCKS 1
+#define MVFX_XTILE_MIN_BLOCKS 5 // workgroups per CU the register allocation must leave room for (the LDS admits five): without it the dense pass
+                                // of round 4 -- rare blocks -- raises the kernel to 102 VGPRs and every block loses a wave per SIMD
+#endif
+#ifndef MVFX_XTILE_DENSE
+#define MVFX_XTILE_DENSE 1 // 1 (round 4): pixels outside the window are listed per wave and served densely after the block's rows (see the kernel)
+#endif
+#define MVFX_XTILE_DENSE_NEEDS_INPUT 0 // (a first version re-read outside pixels from the input frame: overlapping frames had to be kept away)
+#ifndef MVFX_XTILE_DENSE_MIN
+#define MVFX_XTILE_DENSE_MIN 48 // of the 256 pixels of a block's first row of four per lane: more outside the window => the other rows through the dense pass
+#endif
+#ifndef MVFX_XTILE_HEAVY
+#define MVFX_XTILE_HEAVY 128 // of the 256 pixels of a block's first row of four per lane: more outside the window => the whole block through the dense pass
 #endif
 #ifndef MVFX_XTILE_NT
 #define MVFX_XTILE_NT 1   // 1: non-temporal pixel loads and stores (16 x 4K natural-like 70.7 k -> 73.1 k fps, one frame 21.8 -> 19.1 us:
@@ -859,9 +903,7 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
     static_assert(RW * 24 == kXPitchZ, "the coordinate table is built for this window width");
     constexpr uint32_t kAcross = 16, kRows = MVFX_XTILE_ROWS, kTileW = 64, kTileH = 4 * kRows;
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    constexpr uint32_t kRowP = RW * 3 / 2;            // 16-byte pieces per window row
-    constexpr uint32_t kPieces = kXRows * kRowP;      // per wave
-    constexpr uint32_t kWaveBytes = kPieces * 16 + 32; // +32 bytes: de-phases the four waves' regions over the banks
+    constexpr uint32_t kWaveBytes = kXWaveBytes;
     __shared__ __attribute__((aligned(16))) uint8_t win[(kBlock / 64) * kWaveBytes];
     __shared__ uint2 coord[512]; // {cell index x LDS pitch, fraction bits} per byte value of the g and b channels
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -881,12 +923,14 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
         smp = *reinterpret_cast<const uint32_t *>(in + ((by + kTileH / 4 + (lane >> 1) * (kTileH / 2)) * in_stride + (bx + kTileW / 4 + (lane & 1) * (kTileW / 2)) * 4));
 #endif
     // 1. every pixel of the lane, up front (four 16-byte loads in flight while the window is being fetched)
+    uint32_t voff_in = y0 * in_stride + x * 4, voff_out = y0 * out_stride + x * 4; // the lane's byte offsets into rows y0 .. of the frames
+    asm volatile("" : "+v"(voff_in), "+v"(voff_out)); // both formed HERE (left alone the compiler re-forms the second one late from a 64-bit x * 4 that it spills)
     uint4 v[kRows];
 #pragma unroll
     for (uint32_t row = 0; row < kRows; row++) {
         v[row] = make_uint4(0, 0, 0, 0);
         if (x < width && y0 + row < height) {
-            const u32x4_t *src = reinterpret_cast<const u32x4_t *>(in + ((y0 + row) * in_stride + x * 4));
+            const u32x4_t *src = reinterpret_cast<const u32x4_t *>(in + (size_t)row * in_stride + voff_in); // uniform row base + one 32-bit lane offset
             const u32x4_t t = MVFX_XTILE_NT ? __builtin_nontemporal_load(src) : *src;
             v[row] = make_uint4(t.x, t.y, t.z, t.w);
         }
@@ -894,6 +938,7 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
     // 2. the window, anchored at the block's centre pixel (its top-left pixel when the centre lies outside the frame): the pixel and
     // its two coordinate entries come through the scalar cache, so this chain does not wait for the vector loads above
     uint32_t ar, ayp, azp; // anchor: first r byte, y cell x kXPitchY, z row x kXPitchZ
+    uint32_t ccy, ccz; // the centre pixel's LUT cell in g and b (scalar)
     {
         // (a wave of the last workgroup of a row may lie wholly right of the frame: it reads pixel (0, 0) and stores nothing)
         const uint32_t cxp = bx + kTileW / 2 < width ? bx + kTileW / 2 : bx, cyp = by + kTileH / 2 < height ? by + kTileH / 2 : by;
@@ -930,103 +975,101 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
 #endif
         const uint32_t cr = cpx & 0xffu;
         const uint32_t cy = p.tile_tables[2 * (256 + ((cpx >> 8) & 0xffu))], cz = p.tile_tables[2 * (512 + ((cpx >> 16) & 0xffu))];
+        ccy = cy; ccz = cz;
         ar = min((cr > RW / 2 ? cr - RW / 2 : 0u) & ~1u, 256u - RW); // even: a window row starts on a 16-byte piece
         const uint32_t ay = min(cy > 0 ? cy - 1 : 0u, p.size - 3), az = min(cz > 0 ? cz - 1 : 0u, p.size - 3); // z rows run 0 .. size
         ayp = ay * kXPitchY;
         azp = az * kXPitchZ;
         const uint32_t base = (ay * (p.size + 1) + az) * kXRowPieces + ar * 3 / 2; // wave-uniform
-        // global -> LDS directly (global_load_lds_dwordx4: LDS address = wave-uniform base + lane x 16, which is exactly the window's
-        // piece order): no staging registers, no ds_write pass
-        typedef __attribute__((address_space(3))) void *lds_void_t;
-        typedef const __attribute__((address_space(1))) void *global_void_t;
-#pragma unroll
-        for (uint32_t q0 = 0; q0 < kPieces; q0 += 64) {
-            const uint32_t q = q0 + lane;
-            if (q0 + 64 <= kPieces || q < kPieces) {
-                const uint32_t wr = q / kRowP, k = q - wr * kRowP; // window row = dy * 4 + dz
-                __builtin_amdgcn_global_load_lds((global_void_t)(p.xtable + (base + ((wr >> 2) * (p.size + 1) + (wr & 3u)) * kXRowPieces + k)),
-                                                 (lds_void_t)(win + wave * kWaveBytes + q0 * 16), 16, 0, 0);
-            }
-        }
+        xtile_fill_window(p.xtable, base, p.size, win + wave * kWaveBytes, lane);
     }
     coord[threadIdx.x] = p.xcoord[threadIdx.x];
     coord[kBlock + threadIdx.x] = p.xcoord[kBlock + threadIdx.x];
     __syncthreads(); // coordinate table and (a fortiori) this wave's window complete
     // LDS byte address of entry (y cell, z row, r) = yp + zp + 24 r + lds_k, with the anchor folded into the wave-uniform lds_k
     const uint32_t lds_k = wave * kWaveBytes - ayp - azp - ar * 24u, ar24 = ar * 24u, wave_lds = wave * kWaveBytes;
-#pragma unroll
-    for (uint32_t row = 0; row < kRows; row++) {
-        const uint32_t y = y0 + row;
-        const bool valid = x < width && y < height; // width % 4 == 0 (launcher)
+    // One row of four pixels per lane.  INLINE (rounds 3 and 4, the common case): pixels outside the window are served where they are
+    // found -- ONE branch per row that patches their two entries in from the x table in global memory -- and the row is stored.
+    // !INLINE (round 4, blocks with many outside pixels, see below): an outside pixel keeps its input value, `mm` records which of the
+    // lane's pixels they were (bit 15 - (4 row + j): shifted in by an add-with-carry whose carry-in is the pixel's outside mask), the
+    // row stays in v[row] for the dense pass.  Row 0 returns the wave's number of outside pixels; when that is more than
+    // MVFX_XTILE_DENSE_MIN it returns early: nothing served, nothing stored, the block goes the other way.
+    uint32_t mm = 0;
+    auto do_row = [&](auto inline_tag, const uint32_t row) -> uint32_t {
+        constexpr bool INLINE = decltype(inline_tag)::value;
+        const bool valid = x < width && y0 + row < height; // width % 4 == 0 (launcher)
         uint32_t px[4] = {v[row].x, v[row].y, v[row].z, v[row].w};
-        // kGroup pixels at a time: their entries from the window; a pixel outside it reads the window's first entry and is patched in ONE
-        // branch per group (the scalar side of an if / else costs about five instructions)
-        constexpr int kGroup = MVFX_XTILE_GROUP;
+        uint32_t outside = 0;
+        constexpr int G = 4; // pixels at a time
 #pragma unroll
-        for (int g0 = 0; g0 < 4; g0 += kGroup) {
-        f32x2_t e0[kGroup][3], e1[kGroup][3];
-        float ty[kGroup], tz[kGroup];
-        uint32_t gy[kGroup], gz[kGroup];
-        bool miss[kGroup];
+        for (int g0 = 0; g0 < 4; g0 += G) {
+        f32x2_t e0[G][3], e1[G][3];
+        float ty[G], tz[G];
+        bool miss[G];
         bool any_miss = false;
 #pragma unroll
-        for (int j = 0; j < kGroup; j++) {
+        for (int j = 0; j < G; j++) {
             const uint32_t pxj = px[g0 + j];
             const uint2 eg = coord[(pxj >> 8) & 0xffu], eb = coord[256 + ((pxj >> 16) & 0xffu)];
             ty[j] = __uint_as_float(eg.y);
             tz[j] = __uint_as_float(eb.y);
-            gy[j] = eg.x;
-            gz[j] = eb.x;
             uint32_t r24;
             asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r24) : "v"(pxj), "v"(24u));
             const uint32_t dr24 = r24 - ar24, dyp = eg.x - ayp, dzp = eb.x - azp; // unsigned: below the anchor wraps to a huge value
             // (bitwise |: with || the compiler turns the second and third test into branches behind the LDS wait)
             miss[j] = (dr24 >= (uint32_t)RW * 24u) | (dyp >= 3u * kXPitchY) | (dzp >= 3u * kXPitchZ);
             any_miss = any_miss | miss[j];
+            if constexpr (INLINE) {
+                if (MVFX_XTILE_DENSE && row == 0) outside += (uint32_t)__popcll(__ballot(miss[j] & valid)); // (row 0 decides how the block is served)
+            } else {
+                const uint64_t mb = __ballot(miss[j] & valid);
+                uint64_t carry_out;
+                asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(mm), "=s"(carry_out) : "v"(mm), "s"(mb)); // mm = 2 mm + outside
+            }
             const uint32_t off = miss[j] ? wave_lds : eg.x + eb.x + (r24 + lds_k);
             const lds_float2_t q0 = (lds_float2_t)((lds_bytes_t)&win[0] + off), q1 = (lds_float2_t)((lds_bytes_t)&win[0] + off + kXPitchZ);
             e0[j][0] = q0[0]; e0[j][1] = q0[1]; e0[j][2] = q0[2];
             e1[j][0] = q1[0]; e1[j][1] = q1[1]; e1[j][2] = q1[2];
         }
-        if (any_miss) {
+        if constexpr (INLINE) {
+            if (MVFX_XTILE_DENSE && row == 0 && outside > MVFX_XTILE_DENSE_MIN) { // wave-uniform
+                // many outside pixels -- but when they all want the same entries (a block across an edge between two flat colours) the
+                // branch below serves them at broadcast speed and the dense pass has nothing to add: count those whose g and b lie in
+                // the first outside pixel's bucket of 16 codes
+                uint32_t fpx = 0;
+                bool found = false;
 #pragma unroll
-            for (int j = 0; j < kGroup; j++) {
-                if (miss[j]) {
-                    const uint32_t pxj = px[g0 + j];
-#if MVFX_XTILE_MISS_CELLS
-                    // outside the window: the 96-byte cell of the cell-packed table (3.45 MB, L2 resident -- the x-prelerped table is twice
-                    // that, and its two entries of a pixel lie 6 KB apart: a frame of uniform-random colours, where every pixel takes this
-                    // path, read 14.9 GB per 16 frames from it, 14 x the pixels), x-lerped here into the (X, D) pairs the table holds
-                    const uint32_t iy = gy[j] / kXPitchY, iz = gz[j] / kXPitchZ;
-                    const uint2 er = reinterpret_cast<const uint2 *>(p.tile_tables)[pxj & 0xffu];
-                    const float tx = __uint_as_float(er.y);
-                    const float4 *cell = p.cells + __umul24(__umul24(__umul24(iz, p.size) + iy, p.size) + er.x, kCellF4);
-                    float4 c6[6];
+                for (int j = 0; j < G; j++) {
+                    const uint64_t b = __ballot(miss[j] & valid);
+                    if (b != 0 && !found) {
+                        fpx = (uint32_t)__builtin_amdgcn_readlane((int)px[g0 + j], __builtin_ctzll(b));
+                        found = true;
+                    }
+                }
+                uint32_t alike = 0;
 #pragma unroll
-                    for (int i = 0; i < 6; i++) c6[i] = cell[i];
-                    const float f[24] = {c6[0].x, c6[0].y, c6[0].z, c6[0].w, c6[1].x, c6[1].y, c6[1].z, c6[1].w, c6[2].x, c6[2].y, c6[2].z, c6[2].w,
-                                         c6[3].x, c6[3].y, c6[3].z, c6[3].w, c6[4].x, c6[4].y, c6[4].z, c6[4].w, c6[5].x, c6[5].y, c6[5].z, c6[5].w};
-                    // corner i = 3 floats at f[3 i]: c000, d100, c010, d110, c001, d101, c011, d111 (odd corners hold the x-differences)
-                    float X[4][3];
+                for (int j = 0; j < G; j++)
+                    alike += (uint32_t)__popcll(__ballot(miss[j] & valid & (((px[g0 + j] ^ fpx) & 0x00f0f000u) == 0u)));
+                if (alike * 4u < outside * 3u) return outside; // nothing served, nothing stored: the block goes the other way
+                outside = 0;
+            }
+            if (any_miss) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++)
-#pragma unroll
-                        for (int ch = 0; ch < 3; ch++) X[q][ch] = f[6 * q + ch] + f[6 * q + 3 + ch] * tx;
-                    e0[j][0] = f32x2_t{X[0][0], X[0][1]}; e0[j][1] = f32x2_t{X[0][2], X[1][0] - X[0][0]};
-                    e0[j][2] = f32x2_t{X[1][1] - X[0][1], X[1][2] - X[0][2]};
-                    e1[j][0] = f32x2_t{X[2][0], X[2][1]}; e1[j][1] = f32x2_t{X[2][2], X[3][0] - X[2][0]};
-                    e1[j][2] = f32x2_t{X[3][1] - X[2][1], X[3][2] - X[2][2]};
-#else
-                    const uint32_t iy = gy[j] / kXPitchY, iz = gz[j] / kXPitchZ, r = pxj & 0xffu;
-                    const f32x2_t *g0p = reinterpret_cast<const f32x2_t *>(p.xtable) + (uint64_t)((iy * (p.size + 1) + iz) * 256u + r) * 3, *g1p = g0p + 256 * 3;
-                    e0[j][0] = g0p[0]; e0[j][1] = g0p[1]; e0[j][2] = g0p[2];
-                    e1[j][0] = g1p[0]; e1[j][1] = g1p[1]; e1[j][2] = g1p[2];
-#endif
+                for (int j = 0; j < G; j++) {
+                    if (miss[j]) {
+                        // (the premultiplied cell indices are read again here rather than kept from above: eight VGPRs less on the path
+                        // every block takes)
+                        const uint32_t pxj = px[g0 + j];
+                        const uint32_t iy = coord[(pxj >> 8) & 0xffu].x / kXPitchY, iz = coord[256 + ((pxj >> 16) & 0xffu)].x / kXPitchZ, r = pxj & 0xffu;
+                        const f32x2_t *g0p = reinterpret_cast<const f32x2_t *>(p.xtable) + (uint64_t)((iy * (p.size + 1) + iz) * 256u + r) * 3, *g1p = g0p + 256 * 3;
+                        e0[j][0] = g0p[0]; e0[j][1] = g0p[1]; e0[j][2] = g0p[2];
+                        e1[j][0] = g1p[0]; e1[j][1] = g1p[1]; e1[j][2] = g1p[2];
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < kGroup; j++) {
+        for (int j = 0; j < G; j++) {
             // entry = (X.r, X.g) (X.b, D.r) (D.g, D.b)
             const float c0r = e0[j][0].x + e0[j][1].y * ty[j], c0g = e0[j][0].y + e0[j][2].x * ty[j], c0b = e0[j][1].x + e0[j][2].y * ty[j];
             const float c1r = e1[j][0].x + e1[j][1].y * ty[j], c1g = e1[j][0].y + e1[j][2].x * ty[j], c1b = e1[j][1].x + e1[j][2].y * ty[j];
@@ -1043,12 +1086,183 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
             px[g0 + j] = w;
         }
         }
+        // (!INLINE: the row is stored too -- an outside pixel as a placeholder that the dense pass overwrites with a 4-byte store; keeping
+        // the rows in registers until then cost the kernel a wave per SIMD)
         if (valid) {
-            u32x4_t *dst = reinterpret_cast<u32x4_t *>(out + (y * out_stride + x * 4));
+            u32x4_t *dst = reinterpret_cast<u32x4_t *>(out + (size_t)row * out_stride + voff_out);
             const u32x4_t t = {px[0], px[1], px[2], px[3]};
             if (MVFX_XTILE_NT) __builtin_nontemporal_store(t, dst);
             else *dst = t;
         }
+        return outside;
+    };
+    const uint32_t row0_outside = do_row(std::true_type{}, 0);
+    if (!MVFX_XTILE_DENSE || row0_outside <= MVFX_XTILE_DENSE_MIN) { // wave-uniform: the common case
+#pragma unroll
+        for (uint32_t row = 1; row < kRows; row++) do_row(std::true_type{}, row);
+        return;
+    }
+    // ---- blocks with many pixels outside the window (noisy footage, a block across several edges, random colours): round 4.
+    // The branch per row above is walked by the whole wave as soon as ONE of its 256 pixels is outside, and every pixel it serves waits
+    // for its own two entries from global memory.  Here the rows run WITHOUT it (heavy: more than MVFX_XTILE_HEAVY of row 0's 256
+    // pixels outside -- no row runs at all), the wave lists its outside pixels in the LDS of its -- then dead -- window and serves
+    // them DENSELY, entry i on lane i mod 64, from a second, wider window in the node layout.
+    constexpr uint32_t kNodeSide = 6;
+    const bool heavy = row0_outside > MVFX_XTILE_HEAVY;
+    if (heavy) {
+        // which way: the node window covers five cells per axis; when the block's pixels mostly lie further than that from its centre
+        // colour in g or b (uniform-random colours), every lane gathers its own pixels' 96-byte cells the way
+        // colorlut_fast_global_kernel does (a cell the lane used last is kept) -- no list, 16-byte stores
+        uint32_t far = 0;
+        const uint32_t hi2 = p.size > kNodeSide ? p.size - kNodeSide : 0u;
+        const uint32_t f2y = min(ccy > 2 ? ccy - 2 : 0u, hi2) * kXPitchY, f2z = min(ccz > 2 ? ccz - 2 : 0u, hi2) * kXPitchZ;
+        const uint32_t s4[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint2 eg = coord[(s4[j] >> 8) & 0xffu], eb = coord[256 + ((s4[j] >> 16) & 0xffu)];
+            far += (uint32_t)__popcll(__ballot(((eg.x - f2y >= (kNodeSide - 1) * kXPitchY) | (eb.x - f2z >= (kNodeSide - 1) * kXPitchZ)) && x < width && y0 < height));
+        }
+        if (far > 128u) { // wave-uniform
+            CellCache cache;
+#pragma unroll
+            for (uint32_t hr = 0; hr < kRows; hr++) {
+                uint4 q = v[hr];
+                q.x = lf_px8<true, true>(q.x, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
+                q.y = lf_px8<true, true>(q.y, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
+                q.z = lf_px8<true, true>(q.z, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
+                q.w = lf_px8<true, true>(q.w, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
+                if (x < width && y0 + hr < height) {
+                    u32x4_t *dst = reinterpret_cast<u32x4_t *>(out + (size_t)hr * out_stride + voff_out);
+                    const u32x4_t t = {q.x, q.y, q.z, q.w};
+                    if (MVFX_XTILE_NT) __builtin_nontemporal_store(t, dst);
+                    else *dst = t;
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (uint32_t row = 0; row < kRows; row++) mm = (mm << 4) | ((x < width && y0 + row < height) ? 15u : 0u);
+    } else {
+#pragma unroll
+        for (uint32_t row = 0; row < kRows; row++) do_row(std::false_type{}, row);
+    }
+    if (__ballot(mm != 0) == 0) return;
+    // The wave's window is dead; its LDS now holds (a) the block's outside pixels, compacted (ballot + mbcnt), two rows of four per lane
+    // at a time: input value (4 bytes) and (4 row + j) << 6 | lane (2 bytes), and (b) a SECOND window in the node layout: 6 x 6 x 6 LUT
+    // nodes (16 bytes each, 3.4 KB) around the cell of the FIRST listed pixel (an outside pixel: across an edge that is the other
+    // colour, in a noisy block the side of the first window the block's colours spill over) -- five cells = 40 code values per axis
+    // for a 33^3 cube, where the first window has 24 -- filled with the reference's own index clamp (min(i + 1, size - 1),
+    // imp.rs:498-503) so that a cell on the cube's upper faces reads the node twice, as sample_3d does.  Entry i goes to lane i mod 64,
+    // every lane busy: its cell's eight nodes come from the second window (ds_read_b128 at constant offsets) or, outside that too, from
+    // the 96-byte cell of the cell-packed table in global memory / L2; x lerps, y lerp, z lerp in the reference's order and operations;
+    // a 4-byte store over the placeholder.
+    // The rows above are in L2 before such a store lands on one of them (other lanes of this wave wrote them):
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    typedef __attribute__((address_space(3))) uint32_t *lds_u32_t;
+    typedef __attribute__((address_space(3))) uint16_t *lds_u16_t;
+    const uint32_t swave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t slane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t sbx = (gx * (kBlock / 64) + swave) * kTileW;
+    constexpr uint32_t kNodePieces = kNodeSide * kNodeSide * kNodeSide, kRound = 64 * 2 * kRows; // entries per round: two rows
+    static_assert(kNodePieces * 16 + kRound * 6 <= kWaveBytes - 32, "node window + one round's list fit the wave's region");
+    const lds_bytes_t region = (lds_bytes_t)&win[0] + swave * kWaveBytes;
+    typedef __attribute__((address_space(3))) f32x4_t *lds_float4_w;
+    const lds_float4_w nodes = (lds_float4_w)region;
+    const lds_u32_t pxl = (lds_u32_t)(region + kNodePieces * 16);
+    const lds_u16_t idl = (lds_u16_t)(region + kNodePieces * 16 + kRound * 4);
+    uint32_t a2x = 0, a2y = 0, a2z = 0;
+    bool have_nodes = false;
+#pragma unroll
+    for (uint32_t round = 0; round < 2; round++) {
+    const uint32_t pxs[2 * kRows] = {v[2 * round].x, v[2 * round].y, v[2 * round].z, v[2 * round].w,
+                                     v[2 * round + 1].x, v[2 * round + 1].y, v[2 * round + 1].z, v[2 * round + 1].w};
+    static_assert(kRows == 4, "pxs[] spells two rows out");
+    uint32_t n = 0;
+#pragma unroll
+    for (uint32_t k = round * 2 * kRows; k < (round + 1) * 2 * kRows; k++) {
+        const bool mine = (mm >> (kRows * 4 - 1 - k)) & 1u;
+        const uint64_t b = __ballot(mine);
+        if (b != 0) { // wave-uniform
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+            if (mine) {
+                pxl[n + below] = pxs[k - round * 2 * kRows];
+                idl[n + below] = (uint16_t)(k * 64u + slane);
+            }
+            n += (uint32_t)__popcll(b);
+        }
+    }
+    if (n == 0) continue;
+    if (!have_nodes) { // wave-uniform: once per block
+        have_nodes = true;
+        const uint32_t fpx = (uint32_t)__builtin_amdgcn_readfirstlane((int)pxl[0]);
+        uint32_t c0, c1, c2;
+        float unused;
+        lf_coord((float)(fpx & 0xffu), p.fast, p.scale[0], p.offset[0], p.size_m1, c0, unused);
+        lf_coord((float)((fpx >> 8) & 0xffu), p.fast, p.scale[1], p.offset[1], p.size_m1, c1, unused);
+        lf_coord((float)((fpx >> 16) & 0xffu), p.fast, p.scale[2], p.offset[2], p.size_m1, c2, unused);
+        const uint32_t hi2 = p.size > kNodeSide ? p.size - kNodeSide : 0u, m = p.size - 1;
+        a2x = min(c0 > 2 ? c0 - 2 : 0u, hi2); a2y = min(c1 > 2 ? c1 - 2 : 0u, hi2); a2z = min(c2 > 2 ? c2 - 2 : 0u, hi2);
+#pragma unroll
+        for (uint32_t q0 = 0; q0 < kNodePieces; q0 += 64) {
+            const uint32_t q = q0 + slane;
+            if (q0 + 64 <= kNodePieces || q < kNodePieces) {
+                const uint32_t dz = q / (kNodeSide * kNodeSide), rem = q - dz * (kNodeSide * kNodeSide), dy = rem / kNodeSide, dx = rem - dy * kNodeSide;
+                const float4 nv = p.cube[min(a2x + dx, m) + p.size * (min(a2y + dy, m) + p.size * min(a2z + dz, m))];
+                nodes[q] = f32x4_t{nv.x, nv.y, nv.z, nv.w};
+            }
+        }
+    }
+    // (same wave, LDS operations complete in order: no barrier between the writes above and the reads below)
+    for (uint32_t i = slane; i < n; i += 64) {
+        const uint32_t pxj = pxl[i], ent = idl[i];
+        uint32_t ix, iy, iz;
+        float tx, ty, tz;
+        lf_coord((float)(pxj & 0xffu), p.fast, p.scale[0], p.offset[0], p.size_m1, ix, tx);
+        lf_coord((float)((pxj >> 8) & 0xffu), p.fast, p.scale[1], p.offset[1], p.size_m1, iy, ty);
+        lf_coord((float)((pxj >> 16) & 0xffu), p.fast, p.scale[2], p.offset[2], p.size_m1, iz, tz);
+        const uint32_t dx = ix - a2x, dy = iy - a2y, dz = iz - a2z; // unsigned: below the anchor wraps to a huge value
+        // one z plane at a time (four nodes in registers instead of eight): x lerps, y lerp -- the reference's order and operations
+        // (a + (b - a) * t each, imp.rs:515-523) -- then the z lerp of the two planes' results
+        float c0[3], c1[3];
+        auto plane = [&](const float (&a00)[3], const float (&d10)[3], const float (&a01)[3], const float (&d11)[3], float (&o)[3]) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float c00 = a00[ch] + d10[ch] * tx, c10 = a01[ch] + d11[ch] * tx;
+                o[ch] = lf_lerp(c00, c10, ty);
+            }
+        };
+        if ((dx < kNodeSide - 1) & (dy < kNodeSide - 1) & (dz < kNodeSide - 1)) {
+            const lds_float4_w q = nodes + ((dz * kNodeSide + dy) * kNodeSide + dx);
+#pragma unroll
+            for (int zp = 0; zp < 2; zp++) {
+                const f32x4_t n00 = q[zp * kNodeSide * kNodeSide], n10 = q[zp * kNodeSide * kNodeSide + 1], n01 = q[zp * kNodeSide * kNodeSide + kNodeSide],
+                              n11 = q[zp * kNodeSide * kNodeSide + kNodeSide + 1];
+                const float a00[3] = {n00.x, n00.y, n00.z}, d10[3] = {n10.x - n00.x, n10.y - n00.y, n10.z - n00.z};
+                const float a01[3] = {n01.x, n01.y, n01.z}, d11[3] = {n11.x - n01.x, n11.y - n01.y, n11.z - n01.z};
+                plane(a00, d10, a01, d11, zp ? c1 : c0);
+            }
+        } else {
+            // the 96-byte cell: c000, d100, c010, d110 | c001, d101, c011, d111 (the odd corners hold the x differences RN(b - a))
+            const float4 *cell = p.cells + __umul24(__umul24(__umul24(iz, p.size) + iy, p.size) + ix, kCellF4);
+#pragma unroll
+            for (int zp = 0; zp < 2; zp++) {
+                const float4 u0 = cell[3 * zp], u1 = cell[3 * zp + 1], u2 = cell[3 * zp + 2];
+                const float a00[3] = {u0.x, u0.y, u0.z}, d10[3] = {u0.w, u1.x, u1.y}, a01[3] = {u1.z, u1.w, u2.x}, d11[3] = {u2.y, u2.z, u2.w};
+                plane(a00, d10, a01, d11, zp ? c1 : c0);
+            }
+        }
+        const float rr = lf_add_clamp(c0[0], (c1[0] - c0[0]) * tz), gg = lf_add_clamp(c0[1], (c1[1] - c0[1]) * tz),
+                    bb = lf_add_clamp(c0[2], (c1[2] - c0[2]) * tz);
+        const float yr = __builtin_fmaf(rr, p.fast.out_scale, p.fast.pred_half), yg = __builtin_fmaf(gg, p.fast.out_scale, p.fast.pred_half),
+                    yb = __builtin_fmaf(bb, p.fast.out_scale, p.fast.pred_half);
+        uint32_t w = pxj;
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yr));
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yg));
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
+        const uint32_t l = ent & 63u, k = ent >> 6;
+        const uint32_t xx = sbx + (l % kAcross) * 4 + (k & 3u), yy = by + (l / kAcross) * kRows + (k >> 2);
+        *reinterpret_cast<uint32_t *>(out + (yy * out_stride + xx * 4)) = w;
+    }
     }
 }
 
@@ -1124,7 +1338,7 @@ __global__ __launch_bounds__(kI420Block) void colorlut_i420_tile_kernel(I420Plan
 __global__ __launch_bounds__(kI420Block) void colorlut_i420_xtile_kernel(I420Planes pl, uint32_t width, uint32_t height, LutParams p,
                                                                          YuvToRgbCoef kin, RgbToYuvCoef kout)
 {
-    constexpr uint32_t RW = MVFX_XTILE_RW, kRowP = RW * 3 / 2, kPieces = kXRows * kRowP, kWaveBytes = kPieces * 16 + 32;
+    constexpr uint32_t RW = MVFX_XTILE_RW, kWaveBytes = kXWaveBytes;
     __shared__ int2 edge[kI420Block];
     __shared__ uint2 coord[512];
     __shared__ __attribute__((aligned(16))) uint8_t win[(kI420Block / 64) * kWaveBytes];
@@ -1148,17 +1362,7 @@ __global__ __launch_bounds__(kI420Block) void colorlut_i420_xtile_kernel(I420Pla
     const uint32_t ayp = ay * kXPitchY, azp = az * kXPitchZ, ar24 = ar * 24u;
     {
         const uint32_t base = (ay * (p.size + 1) + az) * kXRowPieces + ar * 3 / 2;
-        typedef __attribute__((address_space(3))) void *lds_void_t;
-        typedef const __attribute__((address_space(1))) void *global_void_t;
-#pragma unroll
-        for (uint32_t q0 = 0; q0 < kPieces; q0 += 64) {
-            const uint32_t q = q0 + lane;
-            if (q0 + 64 <= kPieces || q < kPieces) {
-                const uint32_t wr = q / kRowP, k = q - wr * kRowP;
-                __builtin_amdgcn_global_load_lds((global_void_t)(p.xtable + (base + ((wr >> 2) * (p.size + 1) + (wr & 3u)) * kXRowPieces + k)),
-                                                 (lds_void_t)(win + wave * kWaveBytes + q0 * 16), 16, 0, 0);
-            }
-        }
+        xtile_fill_window(p.xtable, base, p.size, win + wave * kWaveBytes, lane);
     }
     __syncthreads(); // coordinate table and window complete
     const uint32_t wave_lds = wave * kWaveBytes, lds_k = wave_lds - ayp - azp - ar24;
@@ -1599,7 +1803,14 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
         //   32 x 16 (8 x 8, 2 rows)             57.0 k      21.5     28.1     37.8     32.4
         //   64 x 32 (16 x 4, 8 rows) 60.2 k / 31.0 us;  32 x 32 59.1 k / 23.9;  64 x 8 56.3 k / 22.4;  32 x 64 47.4 k / 34.3
         // RGBA8 on cubes of 4+ points: the x-prelerped kernel (placement 5 keeps the kernel below for A/B runs)
-        if (!wide && h->d_xtable && opt_lut_placement() != 5) {
+        // (its dense pass reads a pixel outside the window from the INPUT frame after the block's rows are stored: frames that share
+        // memory with their output go to the kernel below)
+        bool overlap = false;
+        for (uint32_t i = 0; MVFX_XTILE_DENSE_NEEDS_INPUT && i < n; i++) {
+            const uint8_t *a = static_cast<const uint8_t *>(ins[i].data), *b = static_cast<const uint8_t *>(outs[i].data);
+            overlap = overlap || (a < b + (size_t)outs[i].stride * outs[i].height && b < a + (size_t)ins[i].stride * ins[i].height);
+        }
+        if (!wide && h->d_xtable && opt_lut_placement() != 5 && !overlap) {
             const uint32_t tx_ = (in->width + 63) / 64, ty_ = (in->height + 4 * MVFX_XTILE_ROWS - 1) / (4 * MVFX_XTILE_ROWS);
             const dim3 xgrid((tx_ + kBlock / 64 - 1) / (kBlock / 64), ty_, n);
             hipLaunchKernelGGL(colorlut_xtile_kernel<MVFX_XTILE_RW>, xgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p);
