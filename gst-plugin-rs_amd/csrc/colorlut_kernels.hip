@@ -878,18 +878,13 @@ typedef const __attribute__((address_space(3))) f32x2_t *lds_float2_t;
                              // the anchor chain then waits behind a vector load.  Also off; a build for noisy footage may want it
 #endif
 #ifndef MVFX_XTILE_MIN_BLOCKS
-#define MVFX_XTILE_MIN_BLOCKS 5 // workgroups per CU the register allocation must leave room for (the LDS admits five): without it the dense pass
-                                // of round 4 -- rare blocks -- raises the kernel to 102 VGPRs and every block loses a wave per SIMD
+#define MVFX_XTILE_MIN_BLOCKS 1
 #endif
-#ifndef MVFX_XTILE_DENSE
-#define MVFX_XTILE_DENSE 1 // 1 (round 4): pixels outside the window are listed per wave and served densely after the block's rows (see the kernel)
+#ifndef MVFX_XTILE_FAR_GATHER
+#define MVFX_XTILE_FAR_GATHER 1 // 1 (round 4): blocks of far-apart colours skip the window (see the kernel)
 #endif
-#define MVFX_XTILE_DENSE_NEEDS_INPUT 0 // (a first version re-read outside pixels from the input frame: overlapping frames had to be kept away)
-#ifndef MVFX_XTILE_DENSE_MIN
-#define MVFX_XTILE_DENSE_MIN 48 // of the 256 pixels of a block's first row of four per lane: more outside the window => the other rows through the dense pass
-#endif
-#ifndef MVFX_XTILE_HEAVY
-#define MVFX_XTILE_HEAVY 128 // of the 256 pixels of a block's first row of four per lane: more outside the window => the whole block through the dense pass
+#ifndef MVFX_XTILE_FAR
+#define MVFX_XTILE_FAR 64 // |g - centre g| + |b - centre b| above which an outside pixel counts as far
 #endif
 #ifndef MVFX_XTILE_NT
 #define MVFX_XTILE_NT 1   // 1: non-temporal pixel loads and stores (16 x 4K natural-like 70.7 k -> 73.1 k fps, one frame 21.8 -> 19.1 us:
@@ -938,7 +933,7 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
     // 2. the window, anchored at the block's centre pixel (its top-left pixel when the centre lies outside the frame): the pixel and
     // its two coordinate entries come through the scalar cache, so this chain does not wait for the vector loads above
     uint32_t ar, ayp, azp; // anchor: first r byte, y cell x kXPitchY, z row x kXPitchZ
-    uint32_t ccy, ccz; // the centre pixel's LUT cell in g and b (scalar)
+    uint32_t ccpx; // the block's centre pixel (scalar)
     {
         // (a wave of the last workgroup of a row may lie wholly right of the frame: it reads pixel (0, 0) and stores nothing)
         const uint32_t cxp = bx + kTileW / 2 < width ? bx + kTileW / 2 : bx, cyp = by + kTileH / 2 < height ? by + kTileH / 2 : by;
@@ -975,7 +970,7 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
 #endif
         const uint32_t cr = cpx & 0xffu;
         const uint32_t cy = p.tile_tables[2 * (256 + ((cpx >> 8) & 0xffu))], cz = p.tile_tables[2 * (512 + ((cpx >> 16) & 0xffu))];
-        ccy = cy; ccz = cz;
+        ccpx = cpx;
         ar = min((cr > RW / 2 ? cr - RW / 2 : 0u) & ~1u, 256u - RW); // even: a window row starts on a 16-byte piece
         const uint32_t ay = min(cy > 0 ? cy - 1 : 0u, p.size - 3), az = min(cz > 0 ? cz - 1 : 0u, p.size - 3); // z rows run 0 .. size
         ayp = ay * kXPitchY;
@@ -988,28 +983,33 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
     __syncthreads(); // coordinate table and (a fortiori) this wave's window complete
     // LDS byte address of entry (y cell, z row, r) = yp + zp + 24 r + lds_k, with the anchor folded into the wave-uniform lds_k
     const uint32_t lds_k = wave * kWaveBytes - ayp - azp - ar * 24u, ar24 = ar * 24u, wave_lds = wave * kWaveBytes;
-    // One row of four pixels per lane.  INLINE (rounds 3 and 4, the common case): pixels outside the window are served where they are
-    // found -- ONE branch per row that patches their two entries in from the x table in global memory -- and the row is stored.
-    // !INLINE (round 4, blocks with many outside pixels, see below): an outside pixel keeps its input value, `mm` records which of the
-    // lane's pixels they were (bit 15 - (4 row + j): shifted in by an add-with-carry whose carry-in is the pixel's outside mask), the
-    // row stays in v[row] for the dense pass.  Row 0 returns the wave's number of outside pixels; when that is more than
-    // MVFX_XTILE_DENSE_MIN it returns early: nothing served, nothing stored, the block goes the other way.
-    uint32_t mm = 0;
-    auto do_row = [&](auto inline_tag, const uint32_t row) -> uint32_t {
-        constexpr bool INLINE = decltype(inline_tag)::value;
+    // One row of four pixels per lane: their entries from the window; a pixel outside it reads the window's first entry and is patched
+    // in ONE branch per row (the scalar side of an if / else costs about five instructions) with its two entries of the x table from
+    // global memory.
+    // Round 4, row 0 only: when nearly all (> 248) of the wave's 256 pixels of that row are outside the window (videotestsrc's grey snow
+    // -- r = g = b, uniform-random -- leaves 233 +- 5 outside and is served faster by the branch: its entries all lie on the table's
+    // diagonal) AND most of those are far
+    // from the block's centre colour (more than MVFX_XTILE_FAR codes in g and b together: not a noisy picture) AND less than a quarter
+    // of them resemble the first one (not the other side of an edge between two flat colours -- there the branch serves whole groups of
+    // lanes from the same few lines): uniform-random colours.  Such a block is not worth a
+    // window at all: every lane gathers its own pixels' 96-byte cells of the cell-packed table (3.45 MB for 33^3: it stays in the XCD's
+    // L2, where the 6.9 MB x table does not) the way colorlut_fast_global_kernel does -- lf_px8, the full trilinear form, a cell the lane
+    // used last is kept.  Uniform-random 4K frames: 7.2 k -> 12 k fps, HBM traffic 14.5 x -> see profiles/r4.
+    // (Also built and measured in round 4, bit-exact, not shipped: listing the outside pixels per wave (ballot + mbcnt) in the LDS of the
+    // dead window and serving them densely from a second 6 x 6 x 6 node window: +8 % at +- 8 codes of noise, +7 % at +- 16, -3 % at
+    // +- 5, -7 % on flat bars, and 98 VGPRs -- a wave per SIMD less for every block; profiles/r4/colorlut_dense_pass.txt and the
+    // commit before this one.)
+    auto do_row = [&](const uint32_t row) -> bool { // true: row 0 found the block "far" -- nothing served, nothing stored
         const bool valid = x < width && y0 + row < height; // width % 4 == 0 (launcher)
         uint32_t px[4] = {v[row].x, v[row].y, v[row].z, v[row].w};
-        uint32_t outside = 0;
-        constexpr int G = 4; // pixels at a time
-#pragma unroll
-        for (int g0 = 0; g0 < 4; g0 += G) {
-        f32x2_t e0[G][3], e1[G][3];
-        float ty[G], tz[G];
-        bool miss[G];
+        f32x2_t e0[4][3], e1[4][3];
+        float ty[4], tz[4];
+        bool miss[4];
         bool any_miss = false;
+        uint32_t outside = 0;
 #pragma unroll
-        for (int j = 0; j < G; j++) {
-            const uint32_t pxj = px[g0 + j];
+        for (int j = 0; j < 4; j++) {
+            const uint32_t pxj = px[j];
             const uint2 eg = coord[(pxj >> 8) & 0xffu], eb = coord[256 + ((pxj >> 16) & 0xffu)];
             ty[j] = __uint_as_float(eg.y);
             tz[j] = __uint_as_float(eb.y);
@@ -1019,57 +1019,46 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
             // (bitwise |: with || the compiler turns the second and third test into branches behind the LDS wait)
             miss[j] = (dr24 >= (uint32_t)RW * 24u) | (dyp >= 3u * kXPitchY) | (dzp >= 3u * kXPitchZ);
             any_miss = any_miss | miss[j];
-            if constexpr (INLINE) {
-                if (MVFX_XTILE_DENSE && row == 0) outside += (uint32_t)__popcll(__ballot(miss[j] & valid)); // (row 0 decides how the block is served)
-            } else {
-                const uint64_t mb = __ballot(miss[j] & valid);
-                uint64_t carry_out;
-                asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(mm), "=s"(carry_out) : "v"(mm), "s"(mb)); // mm = 2 mm + outside
-            }
+            if (MVFX_XTILE_FAR_GATHER && row == 0) outside += (uint32_t)__popcll(__ballot(miss[j] & valid));
             const uint32_t off = miss[j] ? wave_lds : eg.x + eb.x + (r24 + lds_k);
             const lds_float2_t q0 = (lds_float2_t)((lds_bytes_t)&win[0] + off), q1 = (lds_float2_t)((lds_bytes_t)&win[0] + off + kXPitchZ);
             e0[j][0] = q0[0]; e0[j][1] = q0[1]; e0[j][2] = q0[2];
             e1[j][0] = q1[0]; e1[j][1] = q1[1]; e1[j][2] = q1[2];
         }
-        if constexpr (INLINE) {
-            if (MVFX_XTILE_DENSE && row == 0 && outside > MVFX_XTILE_DENSE_MIN) { // wave-uniform
-                // many outside pixels -- but when they all want the same entries (a block across an edge between two flat colours) the
-                // branch below serves them at broadcast speed and the dense pass has nothing to add: count those whose g and b lie in
-                // the first outside pixel's bucket of 16 codes
-                uint32_t fpx = 0;
-                bool found = false;
+        if (MVFX_XTILE_FAR_GATHER && row == 0 && outside > 248u) { // wave-uniform, rare
+            uint32_t far = 0, alike = 0, fpx = 0;
+            bool found = false;
 #pragma unroll
-                for (int j = 0; j < G; j++) {
-                    const uint64_t b = __ballot(miss[j] & valid);
-                    if (b != 0 && !found) {
-                        fpx = (uint32_t)__builtin_amdgcn_readlane((int)px[g0 + j], __builtin_ctzll(b));
-                        found = true;
-                    }
+            for (int j = 0; j < 4; j++) {
+                const uint64_t b = __ballot(miss[j] & valid);
+                if (b != 0 && !found) {
+                    fpx = (uint32_t)__builtin_amdgcn_readlane((int)px[j], __builtin_ctzll(b)); // the first outside pixel
+                    found = true;
                 }
-                uint32_t alike = 0;
-#pragma unroll
-                for (int j = 0; j < G; j++)
-                    alike += (uint32_t)__popcll(__ballot(miss[j] & valid & (((px[g0 + j] ^ fpx) & 0x00f0f000u) == 0u)));
-                if (alike * 4u < outside * 3u) return outside; // nothing served, nothing stored: the block goes the other way
-                outside = 0;
             }
-            if (any_miss) {
 #pragma unroll
-                for (int j = 0; j < G; j++) {
-                    if (miss[j]) {
-                        // (the premultiplied cell indices are read again here rather than kept from above: eight VGPRs less on the path
-                        // every block takes)
-                        const uint32_t pxj = px[g0 + j];
-                        const uint32_t iy = coord[(pxj >> 8) & 0xffu].x / kXPitchY, iz = coord[256 + ((pxj >> 16) & 0xffu)].x / kXPitchZ, r = pxj & 0xffu;
-                        const f32x2_t *g0p = reinterpret_cast<const f32x2_t *>(p.xtable) + (uint64_t)((iy * (p.size + 1) + iz) * 256u + r) * 3, *g1p = g0p + 256 * 3;
-                        e0[j][0] = g0p[0]; e0[j][1] = g0p[1]; e0[j][2] = g0p[2];
-                        e1[j][0] = g1p[0]; e1[j][1] = g1p[1]; e1[j][2] = g1p[2];
-                    }
+            for (int j = 0; j < 4; j++) {
+                // |g - centre g| + |b - centre b| in one v_sad_u8; "alike": g and b in the first outside pixel's buckets of 16 codes
+                far += (uint32_t)__popcll(__ballot(miss[j] & valid & (__builtin_amdgcn_sad_u8(px[j] & 0x00ffff00u, ccpx & 0x00ffff00u, 0u) > (uint32_t)MVFX_XTILE_FAR)));
+                alike += (uint32_t)__popcll(__ballot(miss[j] & valid & (((px[j] ^ fpx) & 0x00f0f000u) == 0u)));
+            }
+            if (far * 4u > outside * 3u && alike * 4u < outside) return true;
+        }
+        if (any_miss) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (miss[j]) {
+                    // (the premultiplied cell indices are read again here rather than kept from above: fewer VGPRs on the path every block takes)
+                    const uint32_t pxj = px[j];
+                    const uint32_t iy = coord[(pxj >> 8) & 0xffu].x / kXPitchY, iz = coord[256 + ((pxj >> 16) & 0xffu)].x / kXPitchZ, r = pxj & 0xffu;
+                    const f32x2_t *g0p = reinterpret_cast<const f32x2_t *>(p.xtable) + (uint64_t)((iy * (p.size + 1) + iz) * 256u + r) * 3, *g1p = g0p + 256 * 3;
+                    e0[j][0] = g0p[0]; e0[j][1] = g0p[1]; e0[j][2] = g0p[2];
+                    e1[j][0] = g1p[0]; e1[j][1] = g1p[1]; e1[j][2] = g1p[2];
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < G; j++) {
+        for (int j = 0; j < 4; j++) {
             // entry = (X.r, X.g) (X.b, D.r) (D.g, D.b)
             const float c0r = e0[j][0].x + e0[j][1].y * ty[j], c0g = e0[j][0].y + e0[j][2].x * ty[j], c0b = e0[j][1].x + e0[j][2].y * ty[j];
             const float c1r = e1[j][0].x + e1[j][1].y * ty[j], c1g = e1[j][0].y + e1[j][2].x * ty[j], c1b = e1[j][1].x + e1[j][2].y * ty[j];
@@ -1079,191 +1068,40 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
             // every float v in [0, 1] (tools/prove_exact.c P15, exhaustive); the other kernels of this file use mul + add (P10)
             const float yr = __builtin_fmaf(rr, p.fast.out_scale, p.fast.pred_half), yg = __builtin_fmaf(gg, p.fast.out_scale, p.fast.pred_half),
                         yb = __builtin_fmaf(bb, p.fast.out_scale, p.fast.pred_half);
-            uint32_t w = px[g0 + j];
+            uint32_t w = px[j];
             asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yr));
             asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yg));
             asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
-            px[g0 + j] = w;
+            px[j] = w;
         }
-        }
-        // (!INLINE: the row is stored too -- an outside pixel as a placeholder that the dense pass overwrites with a 4-byte store; keeping
-        // the rows in registers until then cost the kernel a wave per SIMD)
         if (valid) {
             u32x4_t *dst = reinterpret_cast<u32x4_t *>(out + (size_t)row * out_stride + voff_out);
             const u32x4_t t = {px[0], px[1], px[2], px[3]};
             if (MVFX_XTILE_NT) __builtin_nontemporal_store(t, dst);
             else *dst = t;
         }
-        return outside;
+        return false;
     };
-    const uint32_t row0_outside = do_row(std::true_type{}, 0);
-    if (!MVFX_XTILE_DENSE || row0_outside <= MVFX_XTILE_DENSE_MIN) { // wave-uniform: the common case
+    if (do_row(0)) { // wave-uniform, rare
+        CellCache cache;
 #pragma unroll
-        for (uint32_t row = 1; row < kRows; row++) do_row(std::true_type{}, row);
+        for (uint32_t hr = 0; hr < kRows; hr++) {
+            uint4 q = v[hr];
+            q.x = lf_px8<true, true>(q.x, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
+            q.y = lf_px8<true, true>(q.y, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
+            q.z = lf_px8<true, true>(q.z, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
+            q.w = lf_px8<true, true>(q.w, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
+            if (x < width && y0 + hr < height) {
+                u32x4_t *dst = reinterpret_cast<u32x4_t *>(out + (size_t)hr * out_stride + voff_out);
+                const u32x4_t t = {q.x, q.y, q.z, q.w};
+                if (MVFX_XTILE_NT) __builtin_nontemporal_store(t, dst);
+                else *dst = t;
+            }
+        }
         return;
     }
-    // ---- blocks with many pixels outside the window (noisy footage, a block across several edges, random colours): round 4.
-    // The branch per row above is walked by the whole wave as soon as ONE of its 256 pixels is outside, and every pixel it serves waits
-    // for its own two entries from global memory.  Here the rows run WITHOUT it (heavy: more than MVFX_XTILE_HEAVY of row 0's 256
-    // pixels outside -- no row runs at all), the wave lists its outside pixels in the LDS of its -- then dead -- window and serves
-    // them DENSELY, entry i on lane i mod 64, from a second, wider window in the node layout.
-    constexpr uint32_t kNodeSide = 6;
-    const bool heavy = row0_outside > MVFX_XTILE_HEAVY;
-    if (heavy) {
-        // which way: the node window covers five cells per axis; when the block's pixels mostly lie further than that from its centre
-        // colour in g or b (uniform-random colours), every lane gathers its own pixels' 96-byte cells the way
-        // colorlut_fast_global_kernel does (a cell the lane used last is kept) -- no list, 16-byte stores
-        uint32_t far = 0;
-        const uint32_t hi2 = p.size > kNodeSide ? p.size - kNodeSide : 0u;
-        const uint32_t f2y = min(ccy > 2 ? ccy - 2 : 0u, hi2) * kXPitchY, f2z = min(ccz > 2 ? ccz - 2 : 0u, hi2) * kXPitchZ;
-        const uint32_t s4[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint2 eg = coord[(s4[j] >> 8) & 0xffu], eb = coord[256 + ((s4[j] >> 16) & 0xffu)];
-            far += (uint32_t)__popcll(__ballot(((eg.x - f2y >= (kNodeSide - 1) * kXPitchY) | (eb.x - f2z >= (kNodeSide - 1) * kXPitchZ)) && x < width && y0 < height));
-        }
-        if (far > 128u) { // wave-uniform
-            CellCache cache;
-#pragma unroll
-            for (uint32_t hr = 0; hr < kRows; hr++) {
-                uint4 q = v[hr];
-                q.x = lf_px8<true, true>(q.x, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
-                q.y = lf_px8<true, true>(q.y, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
-                q.z = lf_px8<true, true>(q.z, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
-                q.w = lf_px8<true, true>(q.w, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
-                if (x < width && y0 + hr < height) {
-                    u32x4_t *dst = reinterpret_cast<u32x4_t *>(out + (size_t)hr * out_stride + voff_out);
-                    const u32x4_t t = {q.x, q.y, q.z, q.w};
-                    if (MVFX_XTILE_NT) __builtin_nontemporal_store(t, dst);
-                    else *dst = t;
-                }
-            }
-            return;
-        }
-#pragma unroll
-        for (uint32_t row = 0; row < kRows; row++) mm = (mm << 4) | ((x < width && y0 + row < height) ? 15u : 0u);
-    } else {
-#pragma unroll
-        for (uint32_t row = 0; row < kRows; row++) do_row(std::false_type{}, row);
-    }
-    if (__ballot(mm != 0) == 0) return;
-    // The wave's window is dead; its LDS now holds (a) the block's outside pixels, compacted (ballot + mbcnt), two rows of four per lane
-    // at a time: input value (4 bytes) and (4 row + j) << 6 | lane (2 bytes), and (b) a SECOND window in the node layout: 6 x 6 x 6 LUT
-    // nodes (16 bytes each, 3.4 KB) around the cell of the FIRST listed pixel (an outside pixel: across an edge that is the other
-    // colour, in a noisy block the side of the first window the block's colours spill over) -- five cells = 40 code values per axis
-    // for a 33^3 cube, where the first window has 24 -- filled with the reference's own index clamp (min(i + 1, size - 1),
-    // imp.rs:498-503) so that a cell on the cube's upper faces reads the node twice, as sample_3d does.  Entry i goes to lane i mod 64,
-    // every lane busy: its cell's eight nodes come from the second window (ds_read_b128 at constant offsets) or, outside that too, from
-    // the 96-byte cell of the cell-packed table in global memory / L2; x lerps, y lerp, z lerp in the reference's order and operations;
-    // a 4-byte store over the placeholder.
-    // The rows above are in L2 before such a store lands on one of them (other lanes of this wave wrote them):
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    typedef __attribute__((address_space(3))) uint32_t *lds_u32_t;
-    typedef __attribute__((address_space(3))) uint16_t *lds_u16_t;
-    const uint32_t swave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t slane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const uint32_t sbx = (gx * (kBlock / 64) + swave) * kTileW;
-    constexpr uint32_t kNodePieces = kNodeSide * kNodeSide * kNodeSide, kRound = 64 * 2 * kRows; // entries per round: two rows
-    static_assert(kNodePieces * 16 + kRound * 6 <= kWaveBytes - 32, "node window + one round's list fit the wave's region");
-    const lds_bytes_t region = (lds_bytes_t)&win[0] + swave * kWaveBytes;
-    typedef __attribute__((address_space(3))) f32x4_t *lds_float4_w;
-    const lds_float4_w nodes = (lds_float4_w)region;
-    const lds_u32_t pxl = (lds_u32_t)(region + kNodePieces * 16);
-    const lds_u16_t idl = (lds_u16_t)(region + kNodePieces * 16 + kRound * 4);
-    uint32_t a2x = 0, a2y = 0, a2z = 0;
-    bool have_nodes = false;
-#pragma unroll
-    for (uint32_t round = 0; round < 2; round++) {
-    const uint32_t pxs[2 * kRows] = {v[2 * round].x, v[2 * round].y, v[2 * round].z, v[2 * round].w,
-                                     v[2 * round + 1].x, v[2 * round + 1].y, v[2 * round + 1].z, v[2 * round + 1].w};
-    static_assert(kRows == 4, "pxs[] spells two rows out");
-    uint32_t n = 0;
-#pragma unroll
-    for (uint32_t k = round * 2 * kRows; k < (round + 1) * 2 * kRows; k++) {
-        const bool mine = (mm >> (kRows * 4 - 1 - k)) & 1u;
-        const uint64_t b = __ballot(mine);
-        if (b != 0) { // wave-uniform
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-            if (mine) {
-                pxl[n + below] = pxs[k - round * 2 * kRows];
-                idl[n + below] = (uint16_t)(k * 64u + slane);
-            }
-            n += (uint32_t)__popcll(b);
-        }
-    }
-    if (n == 0) continue;
-    if (!have_nodes) { // wave-uniform: once per block
-        have_nodes = true;
-        const uint32_t fpx = (uint32_t)__builtin_amdgcn_readfirstlane((int)pxl[0]);
-        uint32_t c0, c1, c2;
-        float unused;
-        lf_coord((float)(fpx & 0xffu), p.fast, p.scale[0], p.offset[0], p.size_m1, c0, unused);
-        lf_coord((float)((fpx >> 8) & 0xffu), p.fast, p.scale[1], p.offset[1], p.size_m1, c1, unused);
-        lf_coord((float)((fpx >> 16) & 0xffu), p.fast, p.scale[2], p.offset[2], p.size_m1, c2, unused);
-        const uint32_t hi2 = p.size > kNodeSide ? p.size - kNodeSide : 0u, m = p.size - 1;
-        a2x = min(c0 > 2 ? c0 - 2 : 0u, hi2); a2y = min(c1 > 2 ? c1 - 2 : 0u, hi2); a2z = min(c2 > 2 ? c2 - 2 : 0u, hi2);
-#pragma unroll
-        for (uint32_t q0 = 0; q0 < kNodePieces; q0 += 64) {
-            const uint32_t q = q0 + slane;
-            if (q0 + 64 <= kNodePieces || q < kNodePieces) {
-                const uint32_t dz = q / (kNodeSide * kNodeSide), rem = q - dz * (kNodeSide * kNodeSide), dy = rem / kNodeSide, dx = rem - dy * kNodeSide;
-                const float4 nv = p.cube[min(a2x + dx, m) + p.size * (min(a2y + dy, m) + p.size * min(a2z + dz, m))];
-                nodes[q] = f32x4_t{nv.x, nv.y, nv.z, nv.w};
-            }
-        }
-    }
-    // (same wave, LDS operations complete in order: no barrier between the writes above and the reads below)
-    for (uint32_t i = slane; i < n; i += 64) {
-        const uint32_t pxj = pxl[i], ent = idl[i];
-        uint32_t ix, iy, iz;
-        float tx, ty, tz;
-        lf_coord((float)(pxj & 0xffu), p.fast, p.scale[0], p.offset[0], p.size_m1, ix, tx);
-        lf_coord((float)((pxj >> 8) & 0xffu), p.fast, p.scale[1], p.offset[1], p.size_m1, iy, ty);
-        lf_coord((float)((pxj >> 16) & 0xffu), p.fast, p.scale[2], p.offset[2], p.size_m1, iz, tz);
-        const uint32_t dx = ix - a2x, dy = iy - a2y, dz = iz - a2z; // unsigned: below the anchor wraps to a huge value
-        // one z plane at a time (four nodes in registers instead of eight): x lerps, y lerp -- the reference's order and operations
-        // (a + (b - a) * t each, imp.rs:515-523) -- then the z lerp of the two planes' results
-        float c0[3], c1[3];
-        auto plane = [&](const float (&a00)[3], const float (&d10)[3], const float (&a01)[3], const float (&d11)[3], float (&o)[3]) {
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const float c00 = a00[ch] + d10[ch] * tx, c10 = a01[ch] + d11[ch] * tx;
-                o[ch] = lf_lerp(c00, c10, ty);
-            }
-        };
-        if ((dx < kNodeSide - 1) & (dy < kNodeSide - 1) & (dz < kNodeSide - 1)) {
-            const lds_float4_w q = nodes + ((dz * kNodeSide + dy) * kNodeSide + dx);
-#pragma unroll
-            for (int zp = 0; zp < 2; zp++) {
-                const f32x4_t n00 = q[zp * kNodeSide * kNodeSide], n10 = q[zp * kNodeSide * kNodeSide + 1], n01 = q[zp * kNodeSide * kNodeSide + kNodeSide],
-                              n11 = q[zp * kNodeSide * kNodeSide + kNodeSide + 1];
-                const float a00[3] = {n00.x, n00.y, n00.z}, d10[3] = {n10.x - n00.x, n10.y - n00.y, n10.z - n00.z};
-                const float a01[3] = {n01.x, n01.y, n01.z}, d11[3] = {n11.x - n01.x, n11.y - n01.y, n11.z - n01.z};
-                plane(a00, d10, a01, d11, zp ? c1 : c0);
-            }
-        } else {
-            // the 96-byte cell: c000, d100, c010, d110 | c001, d101, c011, d111 (the odd corners hold the x differences RN(b - a))
-            const float4 *cell = p.cells + __umul24(__umul24(__umul24(iz, p.size) + iy, p.size) + ix, kCellF4);
-#pragma unroll
-            for (int zp = 0; zp < 2; zp++) {
-                const float4 u0 = cell[3 * zp], u1 = cell[3 * zp + 1], u2 = cell[3 * zp + 2];
-                const float a00[3] = {u0.x, u0.y, u0.z}, d10[3] = {u0.w, u1.x, u1.y}, a01[3] = {u1.z, u1.w, u2.x}, d11[3] = {u2.y, u2.z, u2.w};
-                plane(a00, d10, a01, d11, zp ? c1 : c0);
-            }
-        }
-        const float rr = lf_add_clamp(c0[0], (c1[0] - c0[0]) * tz), gg = lf_add_clamp(c0[1], (c1[1] - c0[1]) * tz),
-                    bb = lf_add_clamp(c0[2], (c1[2] - c0[2]) * tz);
-        const float yr = __builtin_fmaf(rr, p.fast.out_scale, p.fast.pred_half), yg = __builtin_fmaf(gg, p.fast.out_scale, p.fast.pred_half),
-                    yb = __builtin_fmaf(bb, p.fast.out_scale, p.fast.pred_half);
-        uint32_t w = pxj;
-        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yr));
-        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yg));
-        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
-        const uint32_t l = ent & 63u, k = ent >> 6;
-        const uint32_t xx = sbx + (l % kAcross) * 4 + (k & 3u), yy = by + (l / kAcross) * kRows + (k >> 2);
-        *reinterpret_cast<uint32_t *>(out + (yy * out_stride + xx * 4)) = w;
-    }
-    }
+    for (uint32_t row = 1; row < kRows; row++) do_row(row);
 }
 
 // ---------------------------------------------------------------- colorlut on I420 frames, fused
@@ -1803,14 +1641,7 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
         //   32 x 16 (8 x 8, 2 rows)             57.0 k      21.5     28.1     37.8     32.4
         //   64 x 32 (16 x 4, 8 rows) 60.2 k / 31.0 us;  32 x 32 59.1 k / 23.9;  64 x 8 56.3 k / 22.4;  32 x 64 47.4 k / 34.3
         // RGBA8 on cubes of 4+ points: the x-prelerped kernel (placement 5 keeps the kernel below for A/B runs)
-        // (its dense pass reads a pixel outside the window from the INPUT frame after the block's rows are stored: frames that share
-        // memory with their output go to the kernel below)
-        bool overlap = false;
-        for (uint32_t i = 0; MVFX_XTILE_DENSE_NEEDS_INPUT && i < n; i++) {
-            const uint8_t *a = static_cast<const uint8_t *>(ins[i].data), *b = static_cast<const uint8_t *>(outs[i].data);
-            overlap = overlap || (a < b + (size_t)outs[i].stride * outs[i].height && b < a + (size_t)ins[i].stride * ins[i].height);
-        }
-        if (!wide && h->d_xtable && opt_lut_placement() != 5 && !overlap) {
+        if (!wide && h->d_xtable && opt_lut_placement() != 5) {
             const uint32_t tx_ = (in->width + 63) / 64, ty_ = (in->height + 4 * MVFX_XTILE_ROWS - 1) / (4 * MVFX_XTILE_ROWS);
             const dim3 xgrid((tx_ + kBlock / 64 - 1) / (kBlock / 64), ty_, n);
             hipLaunchKernelGGL(colorlut_xtile_kernel<MVFX_XTILE_RW>, xgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p);
