@@ -199,7 +199,7 @@ int host_scratch(size_t bytes, int slot, void **out)
 // Scratch for kernels that hand intermediate results from one launch to the next on `stream` (colordetect's partial
 // histograms): one block per (thread, device, stream), so two asynchronous calls of one thread on different streams never
 // share a block; a block only grows (hipFree synchronises the device, so work in flight on the old block is over before it goes).
-int stream_scratch(hipStream_t stream, size_t bytes, void **out)
+static int stream_scratch_slot(hipStream_t stream, StreamScratch **out)
 {
     DeviceState &d = t_state.current();
     StreamScratch *slot = nullptr, *free_slot = nullptr, *lru = nullptr;
@@ -208,12 +208,28 @@ int stream_scratch(hipStream_t stream, size_t bytes, void **out)
         if (!s.used) { if (!free_slot) free_slot = &s; }
         else if (!lru || s.last_use < lru->last_use) lru = &s;
     }
-    if (!slot) { // an unused block, else the least recently used one takes over (its memory is kept if large enough)
+    if (!slot) {
         slot = free_slot ? free_slot : lru;
+        if (!free_slot) {
+            // the least recently used stream's block changes owner: work that stream still has in flight may be reading or writing
+            // it (colordetect's launches are asynchronous), so it is given back -- hipFree waits for the device -- and the new
+            // owner allocates its own (a thread that works on more than kStreamScratch streams pays this; none of the elements does)
+            if (slot->block.ptr) MVFX_HIP_TRY(hipFree(slot->block.ptr));
+            slot->block.ptr = nullptr;
+            slot->block.cap = 0;
+        }
         slot->stream = stream;
         slot->used = true;
     }
     slot->last_use = ++d.tick;
+    *out = slot;
+    return MVFX_OK;
+}
+
+int stream_scratch(hipStream_t stream, size_t bytes, void **out)
+{
+    StreamScratch *slot = nullptr;
+    if (int rc = stream_scratch_slot(stream, &slot); rc != MVFX_OK) return rc;
     Scratch &s = slot->block;
     if (s.cap < bytes) {
         if (s.ptr) {
