@@ -264,9 +264,10 @@ hipStream_t host_stream()
 
 hipStream_t host_stream_n(uint32_t index)
 {
+    index %= 4; // documented: the index is taken modulo 4 (4 is stream 0 again)
     if (index == 0) return host_stream();
     DeviceState &d = t_state.current();
-    const uint32_t k = (index - 1) % 3;
+    const uint32_t k = index - 1;
     (void)host_stream(); // adopts a pooled bundle or creates stream 0 and its partner first
     if (!d.extra_tried[k]) {
         d.extra_tried[k] = true;

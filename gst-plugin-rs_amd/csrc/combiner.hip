@@ -113,7 +113,23 @@ public:
                 for (Batch &s : ring_)
                     if (!s.open && s.waiters == 0 && (s.n.load(std::memory_order_relaxed) == 0 || s.launched.load(std::memory_order_relaxed))) { b = &s; break; }
                 // (256 slots; a slot is busy only while one of at most 16 followers still has to take its event)
-                if (!b) return fail(MVFX_ERR_DEVICE, "launch combiner: no free batch slot");
+                if (!b) {
+                    // every slot still has a follower that has not taken its event (256 slots: it has not been seen): the frame
+                    // goes out on its own instead of failing the buffer -- a plain launch on the caller's stream; in fenced mode on
+                    // the combiner's stream behind the frame's fence, with a fresh event as the new fence
+                    lk.unlock();
+                    if (!fenced) return mvfx_hsvfilter_transform_frame_ip(frame, settings, stream);
+                    if (wait_for && hipStreamWaitEvent(stream, wait_for, 0) != hipSuccess)
+                        return fail(MVFX_ERR_DEVICE, "launch combiner: hipStreamWaitEvent failed: %s", hipGetErrorString(hipGetLastError()));
+                    if (int rc1 = mvfx_hsvfilter_transform_frame_ip(frame, settings, stream); rc1 != MVFX_OK) return rc1;
+                    if (done_out) {
+                        hipEvent_t ev = nullptr;
+                        if (int rc1 = ready_event(&ev); rc1 != MVFX_OK) return rc1;
+                        MVFX_HIP_TRY(hipEventRecord(ev, stream));
+                        *done_out = ev;
+                    }
+                    return MVFX_OK;
+                }
                 b->n.store(0, std::memory_order_relaxed);
                 b->launched.store(0, std::memory_order_relaxed);
                 b->options = options;
@@ -204,12 +220,34 @@ private:
     // returned from that submit only after its batch was launched)
     int ready_event(hipEvent_t *out)
     {
-        struct ReadyEvents { // destroyed with the calling thread (GStreamer streaming threads come and go)
+        // The events of exited threads are POOLED, never destroyed: GStreamer streaming threads come and go, sixteen of them leave at
+        // end-of-stream at once, and concurrent teardown of HIP objects from exiting threads is what crashed the runtime with streams
+        // (profiles/r3/stream_destroy_crash_backtrace.txt; capi_common.hip pools streams for the same reason).  The pool is leaked on
+        // purpose (threads may exit after the static destructors ran).
+        struct EventPool {
+            std::mutex lock;
+            std::map<int, std::vector<hipEvent_t>> idle;
+        };
+        static EventPool *pool = new EventPool;
+        struct ReadyEvents {
             std::map<int, hipEvent_t> by_device;
-            ~ReadyEvents() { for (auto &kv : by_device) if (kv.second) (void)hipEventDestroy(kv.second); }
+            ~ReadyEvents()
+            {
+                std::lock_guard<std::mutex> g(pool->lock);
+                for (auto &kv : by_device)
+                    if (kv.second) pool->idle[kv.first].push_back(kv.second);
+            }
         };
         thread_local ReadyEvents t_ready;
         hipEvent_t &ready = t_ready.by_device[device_];
+        if (!ready) {
+            std::lock_guard<std::mutex> g(pool->lock);
+            std::vector<hipEvent_t> &idle = pool->idle[device_];
+            if (!idle.empty()) {
+                ready = idle.back();
+                idle.pop_back();
+            }
+        }
         if (!ready)
             MVFX_HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
         *out = ready;

@@ -18,6 +18,7 @@ constexpr int kSlots = 256; // accumulators per (pass, scale): one f64 atomic pe
 int partial_sums(const mvfx_frame *const fr[2], uint32_t row_begin, uint32_t row_end, double sums_out[5], double counts_out[5],
                  uint32_t *n_scales_out, hipStream_t st);
 bool pending(); // a partial_sums of this thread is waiting for its partial_deviation
+void abandon(); // forget it (the caller starts a pair on the f64 pipeline: the last partial_sums decides which pass 2 runs)
 int partial_deviation(const double mean[5], double deviation_sums_out[5], hipStream_t st);
 
 } // namespace ssim32

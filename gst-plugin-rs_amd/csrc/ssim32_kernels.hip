@@ -567,10 +567,11 @@ int partial_sums(const mvfx_frame *const fr[2], uint32_t row_begin, uint32_t row
             launch_level<2, 4>(A, hi[s], st);
         }
     }
-    S.scales = n_scales;
+    S.scales = 0; // a pass 1 that fails below leaves nothing pending
     MVFX_HIP_TRY(hipGetLastError());
     double sums[kScales];
     if (int rc = read_slots(S.d_sums, sums, st); rc != MVFX_OK) return rc;
+    S.scales = n_scales; // pass 2 of THIS pipeline is what mvfx_ssim_partial_deviation runs next on this thread
     for (int s = 0; s < kScales; s++) { // the device sums are those of the deficit 1 - ssim; the interface speaks of the map
         counts_out[s] = s < S.scales ? (double)S.w[s] * (double)std::max(S.y1[s] - S.y0[s], 0) : 0.0;
         sums_out[s] = s < S.scales ? counts_out[s] - sums[s] : 0.0;
@@ -580,6 +581,7 @@ int partial_sums(const mvfx_frame *const fr[2], uint32_t row_begin, uint32_t row
 }
 
 bool pending() { return t_state.scales != 0; }
+void abandon() { t_state.scales = 0; }
 
 int partial_deviation(const double mean[5], double deviation_sums_out[5], hipStream_t st)
 {

@@ -407,9 +407,15 @@ int mvfx_ssim_partial_sums(const mvfx_frame *reference_frame, const mvfx_frame *
     if (int rc = require_device(); rc != MVFX_OK) return rc;
 
     hipStream_t st = as_stream(stream);
-    if ((thread_options() & MVFX_OPT_SSIM_F64) == 0) // default: the f32 pipeline (what dssim-core computes in); f64 planes on request
+    // whichever pipeline runs THIS pass 1 is the one mvfx_ssim_partial_deviation continues: a pass 1 of the other pipeline that never
+    // got its pass 2 (a failed read, a caller that gave the pair up) must not be picked up later with stale maps
+    if ((thread_options() & MVFX_OPT_SSIM_F64) == 0) { // default: the f32 pipeline (what dssim-core computes in); f64 planes on request
+        t_ssim.scales = 0;
         return ssim32::partial_sums(fr, row_begin, row_end, sums_out, counts_out, n_scales_out, st);
+    }
+    ssim32::abandon();
     SsimState &S = t_ssim;
+    S.scales = 0;
     if (int rc = ensure_scratch(S, w0, h0, st); rc != MVFX_OK) return rc;
     MVFX_HIP_TRY(hipMemsetAsync(S.d_sums, 0, sizeof(double) * 2 * kScales * kSlots, st));
 

@@ -87,15 +87,28 @@ static void freelist_give(void *dptr, gsize size, int device, mvfx_event ev, gbo
     if (old_dptr) release_block(old_dptr, old_ev, old_pending);
 }
 
-void mvfx_hip_allocator_trim(void)
+// Gives cached blocks back to the device: those of `size` bytes (0: every size) on the calling thread's device.  The victims are
+// collected under the lock and released outside it (release_block waits for the block's fence and hipFree synchronises the device:
+// another pipeline's alloc / free must not queue behind that on freelist_lock).
+static void freelist_trim(gsize size)
 {
+    struct { void *dptr; mvfx_event ev; gboolean pending; } victims[MVFX_FREELIST_MAX];
+    int n = 0;
+    const int device = current_device();
     g_mutex_lock(&freelist_lock);
     for (int i = 0; i < MVFX_FREELIST_MAX; i++)
-        if (freelist[i].dptr) {
-            release_block(freelist[i].dptr, freelist[i].last_use, freelist[i].pending);
+        if (freelist[i].dptr && (size == 0 || (freelist[i].size == size && freelist[i].device == device))) {
+            victims[n].dptr = freelist[i].dptr; victims[n].ev = freelist[i].last_use; victims[n].pending = freelist[i].pending;
+            n++;
             freelist[i].dptr = NULL;
         }
     g_mutex_unlock(&freelist_lock);
+    for (int i = 0; i < n; i++) release_block(victims[i].dptr, victims[i].ev, victims[i].pending);
+}
+
+void mvfx_hip_allocator_trim(void)
+{
+    freelist_trim(0);
 }
 
 static GstMemory *mvfx_hip_alloc(GstAllocator *allocator, gsize size, GstAllocationParams *params)
@@ -402,11 +415,13 @@ static GstFlowReturn mvfx_hip_pool_acquire_buffer(GstBufferPool *pool, GstBuffer
 }
 
 // The pool's buffers go back to the allocator (its free list) when the pool stops; nothing of that size may be asked for again
-// (caps change, READY -> NULL): give the blocks back to the device.
+// (caps change, READY -> NULL): give THIS pool's blocks back to the device -- the cached blocks of other sizes belong to other
+// pipelines of the process, which keep them.
 static gboolean mvfx_hip_pool_stop(GstBufferPool *pool)
 {
+    MvfxHipBufferPool *self = (MvfxHipBufferPool *)pool;
     const gboolean ok = GST_BUFFER_POOL_CLASS(mvfx_hip_buffer_pool_parent_class)->stop(pool);
-    mvfx_hip_allocator_trim();
+    if (self->size > 0) freelist_trim(self->size);
     return ok;
 }
 

@@ -456,7 +456,11 @@ int mvfx_videocompare_distance_algo(const mvfx_frame *reference_frame,
  * crate; identical frames give exactly 0.0 (tests/videocompare.rs:141-182).  RGB / RGBA only.
  *
  * Arithmetic: f32 per pixel (dssim-core is an f32 library) with f64 reductions; a per-tile centring constant keeps the f32
- * variances free of cancellation; agreement with the f64 checker ~1e-6 relative.  MVFX_OPT_SSIM_F64 selects f64 throughout.
+ * variances free of cancellation; measured against the f64 checker (profiles/r3/ssim32_error_vs_f64_oracle.txt): ~1e-10 absolute,
+ * up to ~7e-5 relative for distances around 1e-6 (near-identical frames), ~1e-6 relative for ordinary pairs.
+ * MVFX_OPT_SSIM_F64 selects f64 throughout.
+ * A pass 1 (mvfx_ssim_partial_sums) decides which pipeline its pass 2 runs on; a pass 1 that failed or was abandoned is forgotten
+ * by the next pass 1 of either pipeline.
  *
  * Two-pass, shardable by row bands (boundaries multiples of 16, or the frame height):
  *   1. mvfx_ssim_partial_sums: per-scale sum of the SSIM map over the band + pixel counts;
