@@ -655,7 +655,7 @@ def committed_counters(key, units_per_step):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)[key]
-        bound = t.get("bound", bound)
+        bound = t.get("bound") or bound
         if t.get("valu_insts_per_step"):
             valu = t["valu_insts_per_step"] * units_per_step / t["units_per_step"]
     except (OSError, KeyError, ValueError, ZeroDivisionError):
@@ -1231,6 +1231,8 @@ def config_main(args):
     w = Worker(args)
     if args.workload == "hsv1080p":
         leg = make_leg_hsv1080p(w, args)
+    elif args.workload in ("hsvfilter_rgb", "hsvdetector_rgb"):
+        leg = make_leg_hsv3(w, args, "filter" if args.workload == "hsvfilter_rgb" else "detector")
     elif args.workload == "colorlut":
         leg = make_leg_colorlut(w, args, args.content)
     else:
@@ -1625,7 +1627,7 @@ def main():
     ap.add_argument("--hash-algo", default="blockhash", choices=["blockhash", "dssim"],
                     help="videocompare workload: blockhash (the element's default) or the SSIM-family distance")
     ap.add_argument("--workload", default="hsvfilter",
-                    choices=["hsvfilter", "hsv1080p", "colorlut", "videofx", "videocompare"],
+                    choices=["hsvfilter", "hsv1080p", "colorlut", "videofx", "videocompare", "hsvfilter_rgb", "hsvdetector_rgb"],
                     help="hsvfilter = the headline metric (default, BASELINE metric); hsv1080p = config 2 "
                          "(hsvfilter + hsvdetector 1920x1080); colorlut = config 3 (33^3 cube, 4K); videofx = config 4 "
                          "(roundedcorners compose + colordetect, one 4K stream per GPU); videocompare = config 5")

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -61,6 +62,14 @@ extern "C" {
 // streams_per_thread (mvfxbench_hsvfilter_streams_rot): every thread rotates its launches over that many private HIP streams
 // (mvfx_thread_stream_n): consecutive frames of one video stream are independent, so the kernels of one thread may overlap.
 static uint32_t g_streams_per_thread = 1;
+// MVFXBENCH_SPLIT=n (round 4 experiment): every single-frame call becomes n calls on n horizontal bands of the frame, band p of call i
+// on stream (i * n + p) % streams_per_thread -- what an element could do per buffer to shorten the fill and drain of a one-frame launch
+static uint32_t split_bands()
+{
+    const char *e = getenv("MVFXBENCH_SPLIT");
+    const int n = e ? atoi(e) : 1;
+    return n < 1 ? 1u : (n > 8 ? 8u : (uint32_t)n);
+}
 
 int mvfxbench_hsvfilter_streams_warm(int device, uint32_t n_threads, uint32_t warmup, uint32_t launches, uint32_t reps,
                                      const mvfx_frame *frames, uint32_t frames_per_thread, uint32_t batch,
@@ -77,9 +86,21 @@ int mvfxbench_hsvfilter_streams_warm(int device, uint32_t n_threads, uint32_t wa
         frames_per_thread % batch != 0 || (warm_frames && (warm_frames_per_thread == 0 || warm_frames_per_thread % batch != 0)))
         return MVFX_ERR_INVALID_ARGUMENT;
     const uint32_t groups = frames_per_thread / batch;
+    const uint32_t split = split_bands();
     auto launch_in = [&](const mvfx_frame *mine, uint32_t n_groups, uint32_t i, mvfx_stream st) {
         const mvfx_frame *f = mine + (size_t)(i % n_groups) * batch;
         if (combined) return mvfx_hsvfilter_transform_frame_ip_combined(f, settings, st);
+        if (split > 1 && batch == 1) {
+            int rc = MVFX_OK;
+            for (uint32_t p = 0; p < split && rc == MVFX_OK; p++) {
+                mvfx_frame band = *f;
+                const uint32_t r0 = (uint32_t)((uint64_t)f->height * p / split), r1 = (uint32_t)((uint64_t)f->height * (p + 1) / split);
+                band.data = static_cast<uint8_t *>(f->data) + (size_t)r0 * f->stride;
+                band.height = r1 - r0;
+                rc = mvfx_hsvfilter_transform_frame_ip(&band, settings, mvfx_thread_stream_n((i * split + p) % rot));
+            }
+            return rc;
+        }
         return batch == 1 ? mvfx_hsvfilter_transform_frame_ip(f, settings, st) : mvfx_hsvfilter_transform_frames_ip(f, batch, settings, st);
     };
     auto launch = [&](const mvfx_frame *mine, uint32_t i, mvfx_stream st) { return launch_in(mine, groups, i, st); };
