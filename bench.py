@@ -1586,8 +1586,9 @@ def main():
     ap.add_argument("--noise-sweep", type=int, default=1, choices=[0, 1], help="colorlut: frames/s at +-0/3/5/8/16 codes of noise (sub-line field)")
     ap.add_argument("--gst-pipeline", type=int, default=1, choices=[0, 1],
                     help="N = 1: also time the real GStreamer element (gst-launch-1.0 hiptestsrc ! hsvfilter ! fakesink, 4K, child processes)")
-    ap.add_argument("--gst-n1", type=int, default=2000)
-    ap.add_argument("--gst-n2", type=int, default=62000)
+    ap.add_argument("--gst-n1", type=int, default=10000)
+    ap.add_argument("--gst-n2", type=int, default=130000,
+                    help="buffers of the two timed gst-launch runs (frames/s = (n2 - n1) / (t2 - t1)); 2000 / 62000 understated the rate by 5-15 %%: the difference of two process run times needs seconds, not tenths")
     ap.add_argument("--gst-timeout", type=float, default=60.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--other-configs", type=int, default=1, choices=[0, 1],
