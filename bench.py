@@ -1539,11 +1539,17 @@ def gst_pipeline_leg(args):
         return {"error": "no GStreamer on this box (the element layer is an optional build target)"}
     cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_gst_pipeline.py"), "--branches", "1", "--quick", "1",
            "--n1", str(args.gst_n1), "--n2", str(args.gst_n2)]
-    try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=args.gst_timeout)
+
+    def one(pair):
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=args.gst_timeout,
+                           env=dict(os.environ, MVFX_ELEMENT_PAIR=pair))
         if r.returncode != 0:
-            return {"error": f"bench_gst_pipeline rc {r.returncode}: {r.stderr[-200:]}"}
-        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            raise RuntimeError(f"bench_gst_pipeline rc {r.returncode}: {r.stderr[-200:]}")
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    try:
+        d = one("1")  # the element as shipped: two consecutive frames per launch (gsthsv.cpp)
+        # one launch per buffer (rounds 2-3), on request: the A/B of the round is profiles/r4/element_path.txt
+        single = one("0").get("refresh_false_combine_0_fps") if args.gst_ab else None
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"[:300]}
     fps = d.get("refresh_false_combine_0_fps")
@@ -1551,7 +1557,8 @@ def gst_pipeline_leg(args):
             "ms_per_step": 1e3 / fps if fps else None,
             "roofline": {"bound": "valu", "frac": fps * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS if fps else None},
             "sub_extra": {"pipeline": "gst-launch-1.0 hiptestsrc refresh=false ! video/x-raw(memory:HIPMemory),format=RGBA,3840x2160 ! hsvfilter ! fakesink",
-                          "buffers": [d.get("n1"), d.get("n2")]},
+                          "buffers": [d.get("n1"), d.get("n2")], "one_launch_per_buffer_fps": single,
+                          "note": "the pool's blocks are re-filtered (converged content clocks higher than fresh frames)"},
             "detail": d}
 
 
@@ -1586,8 +1593,9 @@ def main():
     ap.add_argument("--noise-sweep", type=int, default=1, choices=[0, 1], help="colorlut: frames/s at +-0/3/5/8/16 codes of noise (sub-line field)")
     ap.add_argument("--gst-pipeline", type=int, default=1, choices=[0, 1],
                     help="N = 1: also time the real GStreamer element (gst-launch-1.0 hiptestsrc ! hsvfilter ! fakesink, 4K, child processes)")
+    ap.add_argument("--gst-ab", type=int, default=0, choices=[0, 1], help="also time the element with MVFX_ELEMENT_PAIR=0 (one launch per buffer)")
     ap.add_argument("--gst-n1", type=int, default=10000)
-    ap.add_argument("--gst-n2", type=int, default=130000,
+    ap.add_argument("--gst-n2", type=int, default=160000,
                     help="buffers of the two timed gst-launch runs (frames/s = (n2 - n1) / (t2 - t1)); 2000 / 62000 understated the rate by 5-15 %%: the difference of two process run times needs seconds, not tenths")
     ap.add_argument("--gst-timeout", type=float, default=60.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -168,6 +168,19 @@ int mvfxbench_hsvfilter_streams_rot(int device, uint32_t n_threads, uint32_t str
     return rc;
 }
 
+// `batch` frames per launch AND the launches rotated over `streams_per_thread` private streams (round 4: what an element could reach by
+// holding a few buffers back and launching them together)
+int mvfxbench_hsvfilter_streams_rot_batched(int device, uint32_t n_threads, uint32_t streams_per_thread, uint32_t warmup, uint32_t launches,
+                                            uint32_t reps, const mvfx_frame *frames, uint32_t frames_per_thread, uint32_t batch,
+                                            const mvfx_hsvfilter_settings *settings, uint32_t options, double *seconds_out, double *thread_seconds)
+{
+    g_streams_per_thread = streams_per_thread < 1 ? 1 : (streams_per_thread > 4 ? 4 : streams_per_thread);
+    const int rc = mvfxbench_hsvfilter_streams_warm(device, n_threads, warmup, launches, reps, frames, frames_per_thread, batch, nullptr, 0,
+                                                    settings, options, seconds_out, thread_seconds);
+    g_streams_per_thread = 1;
+    return rc;
+}
+
 int mvfxbench_hsvfilter_streams_batched(int device, uint32_t n_threads, uint32_t warmup, uint32_t launches, uint32_t reps,
                                         const mvfx_frame *frames, uint32_t frames_per_thread, uint32_t batch,
                                         const mvfx_hsvfilter_settings *settings, uint32_t options, double *seconds_out,

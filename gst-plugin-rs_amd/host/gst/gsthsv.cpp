@@ -16,6 +16,15 @@ struct GstHsvFilter {
     mvfx_hsvfilter_settings settings;
     void *i420_scratch;               // device frame for the fused I420 path (streaming thread only)
     gsize i420_scratch_size;
+    // Round 4, device memory: ONE buffer's kernel is held back so that two consecutive frames leave as one launch (see
+    // gst_hsv_filter_bt_transform_ip).  Guarded by pend_lock; `pend_mem` is referenced while set and carries this element's deferred mark.
+    std::mutex *pend_lock;
+    GstMemory *pend_mem;
+    mvfx_frame pend_frame;
+    mvfx_hsvfilter_settings pend_settings;
+    mvfx_stream pend_stream;          // the stream a lone launch of the held-back frame goes on (the frame's own: mvfx_element_stream)
+    guint pair_no;
+    guint64 n_buffers, n_pairs, n_singles; // MVFX_ELEMENT_PAIR_STATS=1 prints them in stop()
 };
 struct GstHsvFilterClass {
     GstVideoFilterClass parent_class;
@@ -71,6 +80,29 @@ static GstFlowReturn gst_hsv_filter_transform_frame_ip(GstVideoFilter *filter, G
 
 // Device-resident path: a `video/x-raw(memory:HIPMemory)` buffer is filtered in HBM, no PCIe copy.
 MVFX_DEFINE_HIP_ALLOCATION_VFUNCS(gst_hsv_filter, gst_hsv_filter_parent_class)
+
+// The held-back frame leaves alone (pend_lock held).  A failure cannot be the flow return of its buffer any more: it is posted.
+static void gst_hsv_filter_flush_locked(GstHsvFilter *self)
+{
+    GstMemory *mem = self->pend_mem;
+    if (!mem) return;
+    self->pend_mem = NULL;
+    mvfx_hip_memory_clear_deferred(mem, GST_OBJECT(self)); // before the acquire below: that would call back into this flush
+    mvfx_hip_memory_acquire(mem, self->pend_stream);
+    const int rc = mvfx_hsvfilter_transform_frame_ip(&self->pend_frame, &self->pend_settings, self->pend_stream);
+    mvfx_hip_memory_release(mem, self->pend_stream);
+    gst_memory_unref(mem);
+    self->n_singles++;
+    if (rc != MVFX_OK)
+        GST_ELEMENT_ERROR(self, LIBRARY, FAILED, ("%s", mvfx_last_error()), ("held-back frame"));
+}
+
+static void gst_hsv_filter_flush_cb(GstObject *owner)
+{
+    GstHsvFilter *self = reinterpret_cast<GstHsvFilter *>(owner);
+    std::lock_guard<std::mutex> g(*self->pend_lock);
+    gst_hsv_filter_flush_locked(self);
+}
 
 static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuffer *buf)
 {
@@ -137,6 +169,48 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
         return MVFX_GST_FLOW(self, rc);
     }
     mvfx_stream st = mvfx_element_stream(buf);
+    // Pair launches (default; MVFX_ELEMENT_PAIR=0 turns them off).  One 4K frame per launch fills and drains the chip for 33 MB: 0.67 of
+    // the HBM peak from one streaming thread however the streams are rotated; TWO frames per launch on two alternating streams reach
+    // 0.71 (profiles/r4/element_path.txt).  The contract stays one call per buffer (hsvfilter/imp.rs:322-326): the call returns at
+    // once, the frame's kernel is HELD BACK, the block says so (mvfx_hip_memory_set_deferred), and it leaves together with the next
+    // buffer's frame -- or alone, the moment anybody looks at the block's fence (the next element's acquire, a CPU map, hipdownload, a
+    // recycled block coming round again), at EOS, on flush-start and in stop().  Settings are the ones in force when the buffer came.
+    static const bool pair = !(g_getenv("MVFX_ELEMENT_PAIR") && atoi(g_getenv("MVFX_ELEMENT_PAIR")) == 0);
+    if (pair && combine == 0 && gst_buffer_n_memory(buf) == 1) {
+        GstMemory *mem = gst_buffer_peek_memory(buf, 0);
+        gst_buffer_unmap(buf, &map); // (a MVFX_MAP_HIP map is the device pointer: it stays valid while the memory lives)
+        std::unique_lock<std::mutex> g(*self->pend_lock);
+        self->n_buffers++;
+        if (self->pend_mem && (self->pend_mem == mem || self->pend_frame.width != f.width || self->pend_frame.height != f.height ||
+                               self->pend_frame.stride != f.stride || self->pend_frame.format != f.format))
+            gst_hsv_filter_flush_locked(self); // the same block again, or another geometry: the held-back frame goes first, alone
+        if (!self->pend_mem) {
+            self->pend_mem = gst_memory_ref(mem);
+            self->pend_frame = f;
+            self->pend_settings = s;
+            self->pend_stream = st;
+            g.unlock();
+            mvfx_hip_memory_set_deferred(mem, gst_hsv_filter_flush_cb, GST_OBJECT(self));
+            return GST_FLOW_OK;
+        }
+        GstMemory *first = self->pend_mem;
+        const mvfx_frame frames[2] = {self->pend_frame, f};
+        const mvfx_hsvfilter_settings settings[2] = {self->pend_settings, s};
+        self->pend_mem = NULL;
+        mvfx_hip_memory_clear_deferred(first, GST_OBJECT(self));
+        // consecutive PAIRS alternate between two streams of this thread (the frame-number rule of mvfx_element_stream would put
+        // every pair on the stream of its odd frame)
+        st = mvfx_thread_stream_n(self->pair_no++ & 1u);
+        mvfx_hip_memory_acquire(first, st);
+        mvfx_hip_buffer_acquire(buf, st);
+        rc = mvfx_hsvfilter_transform_frames_ip_settings(frames, 2, settings, st);
+        mvfx_hip_memory_release(first, st);
+        mvfx_hip_buffer_release(buf, st);
+        self->n_pairs++;
+        g.unlock();
+        gst_memory_unref(first);
+        return MVFX_GST_FLOW(self, rc);
+    }
     mvfx_hip_buffer_acquire(buf, st);
     rc = combine == 1 ? mvfx_hsvfilter_transform_frame_ip_combined(&f, &s, st) : mvfx_hsvfilter_transform_frame_ip(&f, &s, st);
     mvfx_hip_buffer_release(buf, st);
@@ -144,10 +218,29 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
     return MVFX_GST_FLOW(self, rc);
 }
 
+// EOS, flush-start: nothing stays held back across them
+static gboolean gst_hsv_filter_sink_event(GstBaseTransform *bt, GstEvent *event)
+{
+    if (GST_EVENT_TYPE(event) == GST_EVENT_EOS || GST_EVENT_TYPE(event) == GST_EVENT_FLUSH_START)
+        gst_hsv_filter_flush_cb(GST_OBJECT(bt));
+    return GST_BASE_TRANSFORM_CLASS(gst_hsv_filter_parent_class)->sink_event(bt, event);
+}
+
+static gboolean gst_hsv_filter_stop(GstBaseTransform *bt)
+{
+    gst_hsv_filter_flush_cb(GST_OBJECT(bt));
+    GstHsvFilter *self = reinterpret_cast<GstHsvFilter *>(bt);
+    if (g_getenv("MVFX_ELEMENT_PAIR_STATS") && self->n_buffers)
+        g_printerr("hsvfilter %s: %" G_GUINT64_FORMAT " device buffers = 2 x %" G_GUINT64_FORMAT " pair launches + %" G_GUINT64_FORMAT
+                   " single launches\n", GST_OBJECT_NAME(bt), self->n_buffers, self->n_pairs, self->n_singles);
+    return TRUE;
+}
+
 static void gst_hsv_filter_finalize(GObject *obj)
 {
     mvfx_device_free(reinterpret_cast<GstHsvFilter *>(obj)->i420_scratch);
     delete reinterpret_cast<GstHsvFilter *>(obj)->lock;
+    delete reinterpret_cast<GstHsvFilter *>(obj)->pend_lock;
     G_OBJECT_CLASS(gst_hsv_filter_parent_class)->finalize(obj);
 }
 
@@ -191,6 +284,8 @@ static void gst_hsv_filter_class_init(GstHsvFilterClass *klass)
     mvfx_add_pad_templates(element, tmpl[0], tmpl[1]);
     vfilter->transform_frame_ip = gst_hsv_filter_transform_frame_ip; // AlwaysInPlace (:315-320)
     GST_BASE_TRANSFORM_CLASS(klass)->transform_ip = gst_hsv_filter_bt_transform_ip;
+    GST_BASE_TRANSFORM_CLASS(klass)->sink_event = gst_hsv_filter_sink_event;
+    GST_BASE_TRANSFORM_CLASS(klass)->stop = gst_hsv_filter_stop;
     GST_BASE_TRANSFORM_CLASS(klass)->propose_allocation = gst_hsv_filter_propose_allocation; // d3d12colorlut/imp.rs:385-492
     GST_BASE_TRANSFORM_CLASS(klass)->decide_allocation = gst_hsv_filter_decide_allocation;
 }
@@ -198,6 +293,10 @@ static void gst_hsv_filter_class_init(GstHsvFilterClass *klass)
 static void gst_hsv_filter_init(GstHsvFilter *self)
 {
     self->lock = new std::mutex();
+    self->pend_lock = new std::mutex();
+    self->pend_mem = NULL;
+    self->pair_no = 0;
+    self->n_buffers = self->n_pairs = self->n_singles = 0;
     self->settings = mvfx_hsvfilter_settings{0.0f, 1.0f, 0.0f, 1.0f, 0.0f};
     self->i420_scratch = NULL;
     self->i420_scratch_size = 0;

@@ -23,6 +23,9 @@ typedef struct {
     // a fence recorded by somebody else on a stream of theirs (the launch combiner's batch event): not owned, never re-recorded
     // here; while set it is what the next user waits for, and the next release chains onto it like onto a pending own record
     mvfx_event borrowed;
+    // work an element holds back on this block (mvfx_hip_memory_set_deferred): flushed by the next user before it looks at the fence
+    MvfxDeferredFlush deferred_flush;
+    GstObject *deferred_owner; // referenced while set
 } MvfxHipMemory;
 
 typedef struct { GstAllocator parent; } MvfxHipAllocator;
@@ -148,10 +151,51 @@ static void mvfx_hip_free(GstAllocator *, GstMemory *mem)
     g_free(m);
 }
 
+// Runs the block's deferred work, if any: the owner is referenced across the call, the memory's lock is NOT held (the flush releases
+// the block, which takes it).  The flush clears the mark (mvfx_hip_memory_clear_deferred); a flush that forgets to is unmarked here.
+static void run_deferred(MvfxHipMemory *m)
+{
+    g_mutex_lock(&m->lock);
+    MvfxDeferredFlush fn = m->deferred_flush;
+    GstObject *owner = fn ? GST_OBJECT(gst_object_ref(m->deferred_owner)) : NULL;
+    g_mutex_unlock(&m->lock);
+    if (!fn) return;
+    fn(owner);
+    mvfx_hip_memory_clear_deferred(GST_MEMORY_CAST(m), owner);
+    gst_object_unref(owner);
+}
+
+void mvfx_hip_memory_set_deferred(GstMemory *mem, MvfxDeferredFlush flush, GstObject *owner)
+{
+    if (!mvfx_is_hip_memory(mem) || !flush || !owner) return;
+    MvfxHipMemory *m = (MvfxHipMemory *)mem;
+    run_deferred(m); // somebody else's held-back work on this block comes first
+    g_mutex_lock(&m->lock);
+    m->deferred_flush = flush;
+    m->deferred_owner = GST_OBJECT(gst_object_ref(owner));
+    g_mutex_unlock(&m->lock);
+}
+
+void mvfx_hip_memory_clear_deferred(GstMemory *mem, GstObject *owner)
+{
+    if (!mvfx_is_hip_memory(mem)) return;
+    MvfxHipMemory *m = (MvfxHipMemory *)mem;
+    GstObject *drop = NULL;
+    g_mutex_lock(&m->lock);
+    if (m->deferred_flush && m->deferred_owner == owner) {
+        drop = m->deferred_owner;
+        m->deferred_flush = NULL;
+        m->deferred_owner = NULL;
+    }
+    g_mutex_unlock(&m->lock);
+    if (drop) gst_object_unref(drop);
+}
+
 void mvfx_hip_memory_acquire(GstMemory *mem, mvfx_stream stream)
 {
     if (!mvfx_is_hip_memory(mem)) return;
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
+    run_deferred(m);
     g_mutex_lock(&m->lock);
     if (m->borrowed)
         mvfx_stream_wait_event(stream, m->borrowed);
@@ -164,6 +208,7 @@ void *mvfx_hip_memory_pending_fence(GstMemory *mem)
 {
     if (!mvfx_is_hip_memory(mem)) return NULL;
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
+    run_deferred(m);
     g_mutex_lock(&m->lock);
     // the borrowed fence is always younger than the own record it was set behind (the combiner's launch waited for that one)
     void *ev = m->borrowed ? m->borrowed : (m->pending ? m->last_use : NULL);
@@ -184,6 +229,7 @@ void mvfx_hip_memory_release(GstMemory *mem, mvfx_stream stream)
 {
     if (!mvfx_is_hip_memory(mem)) return;
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
+    run_deferred(m); // (a user that released without acquiring: the held-back work still comes first)
     g_mutex_lock(&m->lock);
     if (!m->last_use && mvfx_event_create(&m->last_use) != MVFX_OK)
         m->last_use = NULL;
@@ -206,6 +252,7 @@ void mvfx_hip_memory_wait(GstMemory *mem)
 {
     if (!mvfx_is_hip_memory(mem)) return;
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
+    run_deferred(m);
     g_mutex_lock(&m->lock);
     if (m->borrowed) {
         mvfx_event_synchronize(m->borrowed);

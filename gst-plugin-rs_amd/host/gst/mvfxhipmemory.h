@@ -32,6 +32,13 @@ void mvfx_hip_memory_wait(GstMemory *mem);
 // Fences as plain events, for work that is not enqueued on a stream of the element's (the launch combiner's fenced entry):
 // the event a new user of the block has to wait for (NULL: none pending), and a borrowed event -- owned by somebody else, valid for
 // the life of the process -- as the block's new fence (it stands in front of the block's own event until the next release).
+// Deferred work (round 4): an element may hold a buffer's kernel back (hsvfilter launches two consecutive frames together) and say so on
+// the block: `flush(owner)` is called -- with no lock of the memory held -- by the NEXT user of the block before it looks at the fence
+// (mvfx_hip_memory_acquire / _wait / _pending_fence / _release, a CPU map); it must launch the work and mvfx_hip_memory_release the
+// block (after mvfx_hip_memory_clear_deferred).  The mark holds a reference on `owner` (a GstObject); the owner keeps one on the memory.
+typedef void (*MvfxDeferredFlush)(GstObject *owner);
+void mvfx_hip_memory_set_deferred(GstMemory *mem, MvfxDeferredFlush flush, GstObject *owner);
+void mvfx_hip_memory_clear_deferred(GstMemory *mem, GstObject *owner); // no-op unless the mark is this owner's
 void *mvfx_hip_memory_pending_fence(GstMemory *mem);
 void mvfx_hip_memory_set_borrowed_fence(GstMemory *mem, void *event);
 void mvfx_hip_buffer_acquire(GstBuffer *buf, void *stream);

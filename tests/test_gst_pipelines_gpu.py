@@ -562,3 +562,47 @@ def test_device_chain_on_frames_that_all_differ(gpu, tmp_path, queues):
         exp = np.empty_like(det)
         assert lut.apply(det, w * 4, exp, w * 4, w, h, "RGBA") == 0
         assert np.array_equal(b[k], exp), f"frame {k}"
+
+
+def _pair_stats(text):
+    import re
+    m = re.search(r"hsvfilter \S+: (\d+) device buffers = 2 x (\d+) pair launches \+ (\d+) single launches", text)
+    assert m, text[-2000:]
+    return tuple(int(x) for x in m.groups())
+
+
+def test_hsvfilter_pair_launches_every_buffer_exactly_once(gpu, tmp_path):
+    """Round 4: on device memory hsvfilter holds ONE buffer's kernel back and launches two consecutive frames together (one call per
+    buffer stays the contract, hsvfilter/imp.rs:322-326).  (a) nobody looks at the blocks (fakesink): 21 buffers = 10 pairs + the last
+    one flushed at EOS; (b) a consumer on ANOTHER streaming thread (queue ! hipdownload) flushes held-back frames itself or finds them
+    paired: all 41 frames come out filtered exactly once, byte for byte."""
+    w, h = 640, 360
+    caps = f"video/x-raw(memory:HIPMemory),format=RGBA,width={w},height={h},framerate=30/1"
+    r = gst_env.run([LAUNCH, "-q"] + f"hiptestsrc num-buffers=21 refresh=false ! {caps} ! hsvfilter hue-shift=45 ! fakesink sync=false".split(),
+                    tmp_path, extra_env={"MVFX_ELEMENT_PAIR_STATS": "1"})
+    assert r.returncode == 0, r.stdout
+    assert _pair_stats(r.stdout) == (21, 10, 1)
+    n = 41
+    raw = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBA,width={w},height={h}", "in.raw")
+    r = gst_env.run([LAUNCH, "-q"] + (f"hiptestsrc num-buffers={n} ! {caps} ! hsvfilter hue-shift=45 saturation-mul=1.2 ! queue max-size-buffers=3 ! "
+                                      f"hipdownload ! filesink location={tmp_path}/out.raw").split(), tmp_path, extra_env={"MVFX_ELEMENT_PAIR_STATS": "1"})
+    assert r.returncode == 0, r.stdout
+    buffers, pairs, singles = _pair_stats(r.stdout)
+    assert buffers == n and 2 * pairs + singles == n
+    exp = raw.copy().reshape(h, w * 4)
+    orc.hsvfilter(exp, w, w * 4, "RGBA", (45.0, 1.2, 0.0, 1.0, 0.0))
+    got = np.fromfile(f"{tmp_path}/out.raw", dtype=np.uint8).reshape(n, h, w * 4)
+    assert [k for k in range(n) if not np.array_equal(got[k], exp)] == []
+
+
+def test_hsvfilter_pair_launches_can_be_turned_off(gpu, tmp_path):
+    w, h = 320, 240
+    caps = f"video/x-raw(memory:HIPMemory),format=RGBA,width={w},height={h},framerate=30/1"
+    raw = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBA,width={w},height={h}", "in.raw")
+    r = gst_env.run([LAUNCH, "-q"] + (f"hiptestsrc num-buffers=5 ! {caps} ! hsvfilter hue-shift=90 ! hipdownload ! filesink location={tmp_path}/out.raw").split(),
+                    tmp_path, extra_env={"MVFX_ELEMENT_PAIR": "0", "MVFX_ELEMENT_PAIR_STATS": "1"})
+    assert r.returncode == 0 and "pair launches" not in r.stdout, r.stdout
+    exp = raw.copy().reshape(h, w * 4)
+    orc.hsvfilter(exp, w, w * 4, "RGBA", (90.0, 1.0, 0.0, 1.0, 0.0))
+    got = np.fromfile(f"{tmp_path}/out.raw", dtype=np.uint8).reshape(5, h, w * 4)
+    assert all(np.array_equal(got[k], exp) for k in range(5))
