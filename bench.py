@@ -1374,6 +1374,26 @@ def hsvfilter_main(args):
                     "unit": "frames/s", "launches": n1, "statistic": "median of 5 repetitions",
                     "frac_wall": fps1 / world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS}
         single_stream = {"one_stream": one_thread_leg(1), "two_streams": one_thread_leg(2)}
+
+        def pairs_leg():
+            """what the hsvfilter ELEMENT does since round 4: one thread, two consecutive frames per launch, pairs alternating between
+            two streams (the call per buffer returns at once; host/gst/gsthsv.cpp)"""
+            n1 = 2000
+            secs = (ctypes.c_double * reps)()
+            per = (ctypes.c_double * 1)()
+            w.sync()
+            w.barrier()
+            rc = hb.mvfxbench_hsvfilter_streams_rot_batched(w.device_index, 1, 2, 100, n1 // 2, reps, flat, (nthr * fpt) // 2 * 2, 2,
+                                                            ctypes.byref(settings), opts, secs, per)
+            if rc != 0:
+                raise RuntimeError(f"mvfxbench status {rc}: {vfx.last_error()}")
+            w.barrier()
+            (med,) = w.max_over_ranks(sorted(secs)[reps // 2])
+            fps1 = n1 * world / med
+            return {"launch_model": "1 thread x 2 frames per launch, launches alternating between 2 private HIP streams (the element's model)",
+                    "value": fps1, "unit": "frames/s", "frames": n1, "statistic": "median of 5 repetitions",
+                    "frac_wall": fps1 / world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS}
+        single_stream["pairs_two_streams"] = pairs_leg()
         if args.combiner_legs:  # (0: a profiling run -- rocprofv3's queue interceptor crashes on this leg's cross-stream event waits)
             # the launch combiner: the same threads make the same single-frame calls, the library coalesces them into batched launches
             nb, nf = ctypes.c_uint64(), ctypes.c_uint64()
@@ -1433,6 +1453,9 @@ def hsvfilter_main(args):
         if single_stream:
             element_path.update({"one_thread_fps": _r(single_stream["two_streams"]["value"], 5),
                                  "one_thread_frac": _r(single_stream["two_streams"]["frac_wall"], 4)})
+            if "pairs_two_streams" in single_stream:
+                element_path.update({"one_thread_pairs_fps": _r(single_stream["pairs_two_streams"]["value"], 5),
+                                     "one_thread_pairs_frac": _r(single_stream["pairs_two_streams"]["frac_wall"], 4)})
     out = {
         "metric": "hsvfilter_4k_rgba_frames_per_sec",
         "value": head["value"],
