@@ -307,6 +307,10 @@ class Worker:
             if join is not None:
                 join()  # a leg that uses a second stream: the launch stream waits for it, so the closing event covers both
             ev1.record(self.stream)
+            # poll the closing event before the synchronize below: a sleeping hipDeviceSynchronize wakes up 40-100 us late, which is
+            # 1-3 % of a 3.7 ms timed region (20 launches); the region stays bracketed by barrier + synchronize on both sides
+            while not ev1.query():
+                pass
         self.sync()
         self.barrier()
         self.sync()
