@@ -1398,6 +1398,25 @@ def hsvfilter_main(args):
                     "value": fps1, "unit": "frames/s", "frames": n1, "statistic": "median of 5 repetitions",
                     "frac_wall": fps1 / world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS}
         single_stream["pairs_two_streams"] = pairs_leg()
+
+        def threads_pairs_leg():
+            """the same model on all streams at once: --stream-threads elements, each launching pairs on its two streams"""
+            n1 = max(200, args.steps * args.batch // nthr) // 2 * 2
+            secs = (ctypes.c_double * reps)()
+            per = (ctypes.c_double * nthr)()
+            w.sync()
+            w.barrier()
+            rc = hb.mvfxbench_hsvfilter_streams_rot_batched(w.device_index, nthr, 2, 100, n1 // 2, reps, flat, fpt // 2 * 2, 2,
+                                                            ctypes.byref(settings), opts, secs, per)
+            if rc != 0:
+                raise RuntimeError(f"mvfxbench status {rc}: {vfx.last_error()}")
+            w.barrier()
+            (med,) = w.max_over_ranks(sorted(secs)[reps // 2])
+            fpsn = nthr * n1 * world / med
+            return {"launch_model": f"{nthr} threads x 2 frames per launch, each alternating between 2 private HIP streams", "value": fpsn,
+                    "unit": "frames/s", "statistic": "median of 5 repetitions", "frac_wall": fpsn / world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS}
+        if fpt >= 2:
+            single_stream["threads_pairs"] = threads_pairs_leg()
         if args.combiner_legs:  # (0: a profiling run -- rocprofv3's queue interceptor crashes on this leg's cross-stream event waits)
             # the launch combiner: the same threads make the same single-frame calls, the library coalesces them into batched launches
             nb, nf = ctypes.c_uint64(), ctypes.c_uint64()
@@ -1460,6 +1479,9 @@ def hsvfilter_main(args):
             if "pairs_two_streams" in single_stream:
                 element_path.update({"one_thread_pairs_fps": _r(single_stream["pairs_two_streams"]["value"], 5),
                                      "one_thread_pairs_frac": _r(single_stream["pairs_two_streams"]["frac_wall"], 4)})
+            if "threads_pairs" in single_stream:
+                element_path.update({"threads16_pairs_fps": _r(single_stream["threads_pairs"]["value"], 5),
+                                     "threads16_pairs_frac": _r(single_stream["threads_pairs"]["frac_wall"], 4)})
     out = {
         "metric": "hsvfilter_4k_rgba_frames_per_sec",
         "value": head["value"],

@@ -87,10 +87,11 @@ static void gst_hsv_filter_flush_locked(GstHsvFilter *self)
     GstMemory *mem = self->pend_mem;
     if (!mem) return;
     self->pend_mem = NULL;
-    mvfx_hip_memory_clear_deferred(mem, GST_OBJECT(self)); // before the acquire below: that would call back into this flush
-    mvfx_hip_memory_acquire(mem, self->pend_stream);
+    // the mark stays on the block until its fence is recorded (release_as_owner): a consumer on another streaming thread that looks at
+    // the block meanwhile runs into this element's lock, not past an unrecorded fence
+    mvfx_hip_memory_acquire_as_owner(mem, self->pend_stream, GST_OBJECT(self));
     const int rc = mvfx_hsvfilter_transform_frame_ip(&self->pend_frame, &self->pend_settings, self->pend_stream);
-    mvfx_hip_memory_release(mem, self->pend_stream);
+    mvfx_hip_memory_release_as_owner(mem, self->pend_stream, GST_OBJECT(self));
     gst_memory_unref(mem);
     self->n_singles++;
     if (rc != MVFX_OK)
@@ -197,14 +198,13 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
         const mvfx_frame frames[2] = {self->pend_frame, f};
         const mvfx_hsvfilter_settings settings[2] = {self->pend_settings, s};
         self->pend_mem = NULL;
-        mvfx_hip_memory_clear_deferred(first, GST_OBJECT(self));
         // consecutive PAIRS alternate between two streams of this thread (the frame-number rule of mvfx_element_stream would put
         // every pair on the stream of its odd frame)
         st = mvfx_thread_stream_n(self->pair_no++ & 1u);
-        mvfx_hip_memory_acquire(first, st);
+        mvfx_hip_memory_acquire_as_owner(first, st, GST_OBJECT(self)); // (the mark stays until the fence is recorded: see the flush)
         mvfx_hip_buffer_acquire(buf, st);
         rc = mvfx_hsvfilter_transform_frames_ip_settings(frames, 2, settings, st);
-        mvfx_hip_memory_release(first, st);
+        mvfx_hip_memory_release_as_owner(first, st, GST_OBJECT(self));
         mvfx_hip_buffer_release(buf, st);
         self->n_pairs++;
         g.unlock();

@@ -138,9 +138,14 @@ static GstMemory *mvfx_hip_alloc(GstAllocator *allocator, gsize size, GstAllocat
     return GST_MEMORY_CAST(m);
 }
 
+static void run_deferred(MvfxHipMemory *m);
+
 static void mvfx_hip_free(GstAllocator *, GstMemory *mem)
 {
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
+    // a mark can only be stale here (an owner with work held back on the block keeps a reference on it): this drops the mark's
+    // reference on its owner
+    run_deferred(m);
     if (m->borrowed) { // the free list carries owned events only: finish the borrowed one here (rare: a buffer dropped right behind the combiner)
         mvfx_event_synchronize(m->borrowed);
         m->borrowed = NULL;
@@ -191,11 +196,22 @@ void mvfx_hip_memory_clear_deferred(GstMemory *mem, GstObject *owner)
     if (drop) gst_object_unref(drop);
 }
 
-void mvfx_hip_memory_acquire(GstMemory *mem, mvfx_stream stream)
+static gboolean deferred_is_owners(MvfxHipMemory *m, GstObject *owner)
+{
+    if (!owner) return FALSE;
+    g_mutex_lock(&m->lock);
+    const gboolean mine = m->deferred_flush != NULL && m->deferred_owner == owner;
+    g_mutex_unlock(&m->lock);
+    return mine;
+}
+
+void mvfx_hip_memory_acquire(GstMemory *mem, mvfx_stream stream) { mvfx_hip_memory_acquire_as_owner(mem, stream, NULL); }
+
+void mvfx_hip_memory_acquire_as_owner(GstMemory *mem, mvfx_stream stream, GstObject *owner)
 {
     if (!mvfx_is_hip_memory(mem)) return;
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
-    run_deferred(m);
+    if (!deferred_is_owners(m, owner)) run_deferred(m); // the owner launching its own held-back work does not flush itself
     g_mutex_lock(&m->lock);
     if (m->borrowed)
         mvfx_stream_wait_event(stream, m->borrowed);
@@ -225,11 +241,17 @@ void mvfx_hip_memory_set_borrowed_fence(GstMemory *mem, void *event)
     g_mutex_unlock(&m->lock);
 }
 
-void mvfx_hip_memory_release(GstMemory *mem, mvfx_stream stream)
+void mvfx_hip_memory_release(GstMemory *mem, mvfx_stream stream) { mvfx_hip_memory_release_as_owner(mem, stream, NULL); }
+
+// `owner` != NULL: the owner of the block's held-back work has just enqueued it on `stream`: the fence is recorded and the mark
+// goes away in ONE critical section of the block -- a consumer on another thread either still sees the mark (its flush then waits
+// for the owner's lock and finds the work launched) or already sees the fence, never neither.
+void mvfx_hip_memory_release_as_owner(GstMemory *mem, mvfx_stream stream, GstObject *owner)
 {
     if (!mvfx_is_hip_memory(mem)) return;
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
-    run_deferred(m); // (a user that released without acquiring: the held-back work still comes first)
+    if (!deferred_is_owners(m, owner)) run_deferred(m); // (a user that released without acquiring: the held-back work still comes first)
+    GstObject *drop = NULL;
     g_mutex_lock(&m->lock);
     if (!m->last_use && mvfx_event_create(&m->last_use) != MVFX_OK)
         m->last_use = NULL;
@@ -245,7 +267,13 @@ void mvfx_hip_memory_release(GstMemory *mem, mvfx_stream stream)
         m->pending = TRUE;
     else
         mvfx_stream_synchronize(stream); // no event: fall back to a blocking hand-off
+    if (owner && m->deferred_flush && m->deferred_owner == owner) {
+        drop = m->deferred_owner;
+        m->deferred_flush = NULL;
+        m->deferred_owner = NULL;
+    }
     g_mutex_unlock(&m->lock);
+    if (drop) gst_object_unref(drop);
 }
 
 void mvfx_hip_memory_wait(GstMemory *mem)

@@ -39,6 +39,10 @@ void mvfx_hip_memory_wait(GstMemory *mem);
 typedef void (*MvfxDeferredFlush)(GstObject *owner);
 void mvfx_hip_memory_set_deferred(GstMemory *mem, MvfxDeferredFlush flush, GstObject *owner);
 void mvfx_hip_memory_clear_deferred(GstMemory *mem, GstObject *owner); // no-op unless the mark is this owner's
+// The owner launching its held-back work: acquire WITHOUT flushing its own mark, release that records the fence and drops the mark in one
+// critical section (a consumer on another thread must never see "no mark, no fence yet").
+void mvfx_hip_memory_acquire_as_owner(GstMemory *mem, void *stream, GstObject *owner);
+void mvfx_hip_memory_release_as_owner(GstMemory *mem, void *stream, GstObject *owner);
 void *mvfx_hip_memory_pending_fence(GstMemory *mem);
 void mvfx_hip_memory_set_borrowed_fence(GstMemory *mem, void *event);
 void mvfx_hip_buffer_acquire(GstBuffer *buf, void *stream);
