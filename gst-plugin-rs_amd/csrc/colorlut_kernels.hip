@@ -883,13 +883,16 @@ typedef const volatile __attribute__((address_space(3))) f32x2_t *lds_float2_t;
 #define MVFX_XTILE_ROWS 4 // rows of four pixels per lane: the wave's block is 64 x (4 x rows) pixels
 #endif
 #ifndef MVFX_XTILE_ANCHOR4
-#define MVFX_XTILE_ANCHOR4 0 // 1: the window is anchored at the mean of four pixels of the block instead of its centre pixel.  Measured
-                             // (profiles/r3/colorlut_anchor4.txt): gradients +- 8 codes of noise 39.3 k -> 47.3 k fps, +- 5: 59.0 k -> 61.9 k, but
-                             // +- 3 unchanged, one clean frame per launch 18.8 -> 20.2 us (a longer scalar chain in front of the window fill) and
-                             // flat bars 0.550 -> 0.531 (a block across an edge gets an anchor that fits neither side): off
-                             // 2: the same four samples through one vector load of lanes 0..3 ahead of the pixel loads, the mean only where they
-                             // agree: +- 5 / 8 / 12 codes of noise +6 / +18 / +10 %, clean and +- 3 frames -1...2 %, one frame per launch 19.0 -> 20.2 us:
-                             // the anchor chain then waits behind a vector load.  Also off; a build for noisy footage may want it
+#define MVFX_XTILE_ANCHOR4 2 // where the window is anchored.  0: at the block's centre pixel (rounds 3 and 4 until its last day): one pixel carries the
+                             // full noise of the picture, and every code the anchor is off shrinks the part of the window the other pixels can use.
+                             // 1: at the mean of four pixels of the block (the centres of its quadrants) through scalar loads.
+                             // 2 (shipped): the same four samples through ONE vector load of lanes 0..3 ahead of the pixel loads, the mean only
+                             // where they agree (across an edge the mean fits neither side: the first sample stands).
+                             // Round 4, after the window reads became ds_read_b64 (profiles/r4/colorlut_anchor.txt, same box, 16 x 4K per launch):
+                             //   noise +-0 / 3 / 5 / 8 / 16 / flat bars:  0: 76.4 / 73.2 / 59.9 / 39.2 / 23.9 / 64.5 k fps
+                             //                                            1: 73.7 / 72.0 / 66.7 / 44.9 / 25.4 / 61.9 k
+                             //                                            2: 76.6 / 74.0 / 68.1 / 46.3 / 25.0 / 63.7 k   one frame per launch 18.5 us (0: 19.0)
+                             // (round 3, with ds_read2_b64 window reads, 2 cost the clean frames 1-2 % and a single frame 1 us: it stayed off)
 #endif
 #ifndef MVFX_XTILE_MIN_BLOCKS
 #define MVFX_XTILE_MIN_BLOCKS 1
