@@ -146,7 +146,7 @@ def compact_cpu(cpu):
 def compact_roofline(r):
     """scalars only.  `frac` = `achieved` / `peak` with `achieved` the algorithmic bytes over the WALL clock `value` is made of;
     `frac_kernel` the same bytes over the average launch duration between two HIP events on the launch stream; `frac_valu` the
-    committed SQ_INSTS_VALU of the step x 4 cycles over what 1024 SIMDs issue at 2.4 GHz in the measured step time."""
+    committed SQ_INSTS_VALU of the step x the measured 1.07 ns issue interval over 1024 SIMDs x the measured step time (a lower bound)."""
     keys = ("bound", "achieved", "peak", "unit", "frac", "frac_kernel", "achieved_kernel", "frac_valu", "traffic", "traffic_committed",
             "traffic_over_algorithmic", "kernel", "bytes_per_step", "avg_step_us", "p50_step_us", "frac_of_measured_ceiling", "ceiling_measured_GBs")
     return {k: _r(r[k]) for k in keys if k in r}
@@ -644,8 +644,12 @@ def committed_traffic(key, units_per_step):
     return None, "no committed rocprofv3 PMC pass for this workload"
 
 
-VALU_CLOCK_HZ = 2.4e9      # MI355X_MICROARCH.md: max clock 2400 MHz
-VALU_SIMDS = 256 * 4       # 256 CUs x 4 SIMDs; a wave64 non-packed VALU instruction occupies its SIMD for 4 cycles (157.3 TF fp32 vector peak)
+VALU_SIMDS = 256 * 4       # 256 CUs x 4 SIMDs
+# one wave64 VALU instruction per 1.07 ns per SIMD is the fastest a SIMD issues them (v_fma/add/mul_f32, v_add_u32, v_and ...: 2 cycles
+# at the ~2.1 GHz the chip holds under an all-VALU load); min/max/cvt/perm/cmp/SDWA and any operation with an SGPR source take 1.75 ns
+# on a second pipe that overlaps with the first, v_rcp_f32 3.46 ns overlapping with nothing: tools/probes/valu_issue.hip,
+# profiles/r4/valu_issue_probe.txt.  (SQ_ACTIVE_INST_VALU / the VALUBusy metric count a flat 4 cycles per instruction and pass 100 %.)
+VALU_ISSUE_NS = 1.07
 # which ceiling binds, from the committed rocprofv3 counters (VALUBusy / MemUnitBusy / SQ_INSTS_VALU passes under profiles/); the
 # committed profiles/traffic.json overrides this table per workload when it carries a "bound" field
 BOUND_FROM_COUNTERS = {"hsvfilter": "valu", "hsv1080p": "valu", "hsvfilter_rgb": "valu", "hsvdetector_rgb": "valu",
@@ -668,11 +672,11 @@ def committed_counters(key, units_per_step):
 
 
 def frac_valu(valu_insts, step_seconds):
-    """fraction of the VALU issue ceiling: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x step time).  Quarter-rate instructions
-    (v_rcp, v_sqrt ...) count as one, so this is a lower bound of the VALU pipes' occupancy."""
+    """fraction of the VALU issue ceiling: SQ_INSTS_VALU x 1.07 ns / (1024 SIMDs x step time).  Every instruction is priced as the
+    fastest class, so this is a lower bound of the time the step's VALU work needs (tools/valu_cost.py prices a kernel's static mix)."""
     if not valu_insts or not step_seconds:
         return None
-    return valu_insts * 4.0 / (VALU_SIMDS * VALU_CLOCK_HZ * step_seconds)
+    return valu_insts * VALU_ISSUE_NS * 1e-9 / (VALU_SIMDS * step_seconds)
 
 
 def roofline_of(key, units_per_step, bytes_per_step, wall_s_per_step, event_s_per_step, kernel, pct=None):
