@@ -436,6 +436,19 @@ int mvfx_event_synchronize(mvfx_event event)
     return MVFX_OK;
 }
 
+int mvfx_event_query(mvfx_event event)
+{
+    if (!event)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "event_query: NULL event");
+    const hipError_t e = hipEventQuery(reinterpret_cast<hipEvent_t>(event));
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError(); // not an error: do not leave it for the next call's check
+        return 0;
+    }
+    return fail(MVFX_ERR_DEVICE, "event_query: %s", hipGetErrorString(e));
+}
+
 int mvfx_host_alloc(void **out_ptr, size_t bytes)
 {
     if (!out_ptr)

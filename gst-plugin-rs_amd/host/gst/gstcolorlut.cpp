@@ -2,6 +2,7 @@
 // Same surface as video/colorlut/src/{lib.rs,colorlut/imp.rs}; LUT application runs in the HIP
 // kernels behind include/mi355vfx.h, .cube parsing in host/cube_parser.cpp.
 #include "mvfx_gst_common.h"
+#include "mvfx_pair_hold.h"
 
 #include <mutex>
 #include <string>
@@ -14,6 +15,7 @@ struct GstColorLut {
     std::string *location; // Settings { location: Option<String> } (:45-48); empty + !has_location = None
     gboolean has_location;
     mvfx_cube_lut *lut;    // State { lut: Option<CubeLut> } (:50-53)
+    MvfxPairHold *hold;    // pair launches on device buffers (mvfx_pair_hold.h); the LUT lives from start() to stop(), which flushes first
 };
 struct GstColorLutClass {
     GstVideoFilterClass parent_class;
@@ -66,10 +68,36 @@ static gboolean gst_color_lut_start(GstBaseTransform *trans)
     return TRUE;
 }
 
+static int gst_color_lut_pair_launch(GstObject *element, const mvfx_frame *in, const mvfx_frame *out, uint32_t n, mvfx_stream st)
+{
+    GstColorLut *self = reinterpret_cast<GstColorLut *>(element);
+    return n == 1 ? mvfx_colorlut_transform_frame(self->lut, in, out, st) : mvfx_colorlut_transform_frames(self->lut, in, out, n, st);
+}
+
+static void gst_color_lut_flush_cb(GstObject *owner) // EOS, flush-start, stop
+{
+    mvfx_pair_flush(reinterpret_cast<GstColorLut *>(owner)->hold, owner, gst_color_lut_pair_launch);
+}
+
+static void gst_color_lut_looked_at_cb(GstObject *owner) // registered on the held-back frame's blocks
+{
+    mvfx_pair_flush_foreign(reinterpret_cast<GstColorLut *>(owner)->hold, owner, gst_color_lut_pair_launch);
+}
+
+// EOS, flush-start: nothing stays held back across them
+static gboolean gst_color_lut_sink_event(GstBaseTransform *bt, GstEvent *event)
+{
+    if (GST_EVENT_TYPE(event) == GST_EVENT_EOS || GST_EVENT_TYPE(event) == GST_EVENT_FLUSH_START)
+        gst_color_lut_flush_cb(GST_OBJECT(bt));
+    return GST_BASE_TRANSFORM_CLASS(gst_color_lut_parent_class)->sink_event(bt, event);
+}
+
 // BaseTransformImpl::stop (:196-199)
 static gboolean gst_color_lut_stop(GstBaseTransform *trans)
 {
     GstColorLut *self = reinterpret_cast<GstColorLut *>(trans);
+    gst_color_lut_flush_cb(GST_OBJECT(trans)); // the held-back frame still needs the LUT
+    mvfx_pair_print_stats(self->hold, GST_OBJECT(trans), "colorlut");
     std::lock_guard<std::mutex> g(*self->lock);
     if (self->lut) mvfx_cube_lut_free(self->lut);
     self->lut = nullptr;
@@ -143,6 +171,19 @@ static GstFlowReturn gst_color_lut_bt_transform(GstBaseTransform *bt, GstBuffer 
     }
     // fences instead of a host wait per buffer (d3d12colorlut/imp.rs:695-714)
     mvfx_stream st = mvfx_element_stream(inbuf);
+    if (mvfx_pair_enabled() && gst_buffer_n_memory(inbuf) == 1 && gst_buffer_n_memory(outbuf) == 1) {
+        gst_buffer_unmap(outbuf, &omap); // (a MVFX_MAP_HIP map is the device pointer: it stays valid while the memory lives)
+        gst_buffer_unmap(inbuf, &imap);
+        const int prc = mvfx_pair_submit(self->hold, GST_OBJECT(self), gst_color_lut_pair_launch, gst_color_lut_looked_at_cb, inbuf, outbuf, fi, fo,
+                                         st, TRUE, [] {});
+        if (prc != MVFX_PAIR_NOT_TAKEN) return MVFX_GST_FLOW(self, prc);
+        mvfx_hip_buffer_acquire(inbuf, st);
+        mvfx_hip_buffer_acquire(outbuf, st);
+        const int drc = mvfx_colorlut_transform_frame(self->lut, &fi, &fo, st);
+        mvfx_hip_memory_release_tagged(gst_buffer_peek_memory(inbuf, 0), st, GST_OBJECT(self));
+        mvfx_hip_memory_release_tagged(gst_buffer_peek_memory(outbuf, 0), st, GST_OBJECT(self));
+        return MVFX_GST_FLOW(self, drc);
+    }
     mvfx_hip_buffer_acquire(inbuf, st);
     mvfx_hip_buffer_acquire(outbuf, st);
     int rc = mvfx_colorlut_transform_frame(self->lut, &fi, &fo, st);
@@ -158,6 +199,7 @@ static void gst_color_lut_finalize(GObject *obj)
     GstColorLut *self = reinterpret_cast<GstColorLut *>(obj);
     if (self->lut) mvfx_cube_lut_free(self->lut);
     delete self->location;
+    delete self->hold;
     delete self->lock;
     G_OBJECT_CLASS(gst_color_lut_parent_class)->finalize(obj);
 }
@@ -193,6 +235,7 @@ static void gst_color_lut_class_init(GstColorLutClass *klass)
     GST_BASE_TRANSFORM_CLASS(klass)->propose_allocation = gst_color_lut_propose_allocation; // d3d12colorlut/imp.rs:385-492
     GST_BASE_TRANSFORM_CLASS(klass)->decide_allocation = gst_color_lut_decide_allocation;
     GST_BASE_TRANSFORM_CLASS(klass)->transform = gst_color_lut_bt_transform;
+    GST_BASE_TRANSFORM_CLASS(klass)->sink_event = gst_color_lut_sink_event;
     GST_BASE_TRANSFORM_CLASS(klass)->start = gst_color_lut_start;
     GST_BASE_TRANSFORM_CLASS(klass)->stop = gst_color_lut_stop;
     GST_VIDEO_FILTER_CLASS(klass)->transform_frame = gst_color_lut_transform_frame; // NeverInPlace (:162-166)
@@ -201,6 +244,7 @@ static void gst_color_lut_class_init(GstColorLutClass *klass)
 static void gst_color_lut_init(GstColorLut *self)
 {
     self->lock = new std::mutex();
+    self->hold = new MvfxPairHold();
     self->location = new std::string();
     self->has_location = FALSE;
     self->lut = nullptr;

@@ -2,6 +2,7 @@
 // Same surface as video/hsv/src/{lib.rs,hsvfilter,hsvdetector} of the reference; the per-pixel
 // work is done by the HIP kernels behind include/mi355vfx.h.
 #include "mvfx_gst_common.h"
+#include "mvfx_pair_hold.h"
 
 #include <mutex>
 
@@ -24,7 +25,8 @@ struct GstHsvFilter {
     mvfx_hsvfilter_settings pend_settings;
     mvfx_stream pend_stream;          // the stream a lone launch of the held-back frame goes on (the frame's own: mvfx_element_stream)
     guint pair_no;
-    guint64 n_buffers, n_pairs, n_singles; // MVFX_ELEMENT_PAIR_STATS=1 prints them in stop()
+    guint foreign_streak, direct_left;     // held-back frames that somebody's look flushed, in a row; plain launches left (mvfx_pair_hold.h)
+    guint64 n_buffers, n_pairs, n_singles, n_direct; // MVFX_ELEMENT_PAIR_STATS=1 prints them in stop()
 };
 struct GstHsvFilterClass {
     GstVideoFilterClass parent_class;
@@ -82,7 +84,7 @@ static GstFlowReturn gst_hsv_filter_transform_frame_ip(GstVideoFilter *filter, G
 MVFX_DEFINE_HIP_ALLOCATION_VFUNCS(gst_hsv_filter, gst_hsv_filter_parent_class)
 
 // The held-back frame leaves alone (pend_lock held).  A failure cannot be the flow return of its buffer any more: it is posted.
-static void gst_hsv_filter_flush_locked(GstHsvFilter *self)
+static void gst_hsv_filter_flush_locked(GstHsvFilter *self, MvfxUnrefLater *later)
 {
     GstMemory *mem = self->pend_mem;
     if (!mem) return;
@@ -92,17 +94,32 @@ static void gst_hsv_filter_flush_locked(GstHsvFilter *self)
     mvfx_hip_memory_acquire_as_owner(mem, self->pend_stream, GST_OBJECT(self));
     const int rc = mvfx_hsvfilter_transform_frame_ip(&self->pend_frame, &self->pend_settings, self->pend_stream);
     mvfx_hip_memory_release_as_owner(mem, self->pend_stream, GST_OBJECT(self));
-    gst_memory_unref(mem);
+    later->add(mem); // dropped after pend_lock is released (mvfx_pair_hold.h)
     self->n_singles++;
     if (rc != MVFX_OK)
         GST_ELEMENT_ERROR(self, LIBRARY, FAILED, ("%s", mvfx_last_error()), ("held-back frame"));
 }
 
-static void gst_hsv_filter_flush_cb(GstObject *owner)
+static void gst_hsv_filter_flush_cb(GstObject *owner) // EOS, flush-start, stop
 {
     GstHsvFilter *self = reinterpret_cast<GstHsvFilter *>(owner);
+    MvfxUnrefLater later;
     std::lock_guard<std::mutex> g(*self->pend_lock);
-    gst_hsv_filter_flush_locked(self);
+    gst_hsv_filter_flush_locked(self, &later);
+}
+
+// Registered on the held-back frame's block: somebody looked.  Behind another device element that happens to EVERY frame, and holding
+// back then only costs (mvfx_pair_hold.h): after kMvfxPairStreak in a row the element launches per buffer for kMvfxPairDirect buffers.
+static void gst_hsv_filter_looked_at_cb(GstObject *owner)
+{
+    GstHsvFilter *self = reinterpret_cast<GstHsvFilter *>(owner);
+    MvfxUnrefLater later;
+    std::lock_guard<std::mutex> g(*self->pend_lock);
+    if (self->pend_mem && mvfx_pair_mode() == 1 && ++self->foreign_streak >= kMvfxPairStreak) {
+        self->foreign_streak = 0;
+        self->direct_left = kMvfxPairDirect;
+    }
+    gst_hsv_filter_flush_locked(self, &later);
 }
 
 static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuffer *buf)
@@ -176,22 +193,38 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
     // once, the frame's kernel is HELD BACK, the block says so (mvfx_hip_memory_set_deferred), and it leaves together with the next
     // buffer's frame -- or alone, the moment anybody looks at the block's fence (the next element's acquire, a CPU map, hipdownload, a
     // recycled block coming round again), at EOS, on flush-start and in stop().  Settings are the ones in force when the buffer came.
-    static const bool pair = !(g_getenv("MVFX_ELEMENT_PAIR") && atoi(g_getenv("MVFX_ELEMENT_PAIR")) == 0);
+    const bool pair = mvfx_pair_enabled();
     if (pair && combine == 0 && gst_buffer_n_memory(buf) == 1) {
         GstMemory *mem = gst_buffer_peek_memory(buf, 0);
         gst_buffer_unmap(buf, &map); // (a MVFX_MAP_HIP map is the device pointer: it stays valid while the memory lives)
+        // the block still being written (the source's copy, an upstream kernel: in flight or held back): a stage of a dependent chain
+        // does not hold back (mvfx_pair_hold.h)
+        const gboolean chained = mvfx_pair_mode() == 1 && mvfx_hip_memory_busy(mem, GST_OBJECT(self));
+        // somebody else's held-back work on the block leaves before our lock is taken; under the lock no foreign flush runs
+        mvfx_hip_memory_flush_foreign(mem, GST_OBJECT(self));
+        MvfxUnrefLater later;
         std::unique_lock<std::mutex> g(*self->pend_lock);
         self->n_buffers++;
+        if (chained || self->direct_left) { // ... or every held-back frame was flushed by somebody's look lately
+            if (self->direct_left) self->direct_left--;
+            self->n_direct++;
+            gst_hsv_filter_flush_locked(self, &later);
+            g.unlock();
+            mvfx_hip_buffer_acquire(buf, st);
+            rc = mvfx_hsvfilter_transform_frame_ip(&f, &s, st);
+            mvfx_hip_memory_release_tagged(mem, st, GST_OBJECT(self));
+            return MVFX_GST_FLOW(self, rc);
+        }
         if (self->pend_mem && (self->pend_mem == mem || self->pend_frame.width != f.width || self->pend_frame.height != f.height ||
                                self->pend_frame.stride != f.stride || self->pend_frame.format != f.format))
-            gst_hsv_filter_flush_locked(self); // the same block again, or another geometry: the held-back frame goes first, alone
+            gst_hsv_filter_flush_locked(self, &later); // the same block again, or another geometry: the held-back frame goes first, alone
         if (!self->pend_mem) {
             self->pend_mem = gst_memory_ref(mem);
             self->pend_frame = f;
             self->pend_settings = s;
             self->pend_stream = st;
             g.unlock();
-            mvfx_hip_memory_set_deferred(mem, gst_hsv_filter_flush_cb, GST_OBJECT(self));
+            mvfx_hip_memory_set_deferred(mem, gst_hsv_filter_looked_at_cb, GST_OBJECT(self));
             return GST_FLOW_OK;
         }
         GstMemory *first = self->pend_mem;
@@ -202,13 +235,14 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
         // every pair on the stream of its odd frame)
         st = mvfx_thread_stream_n(self->pair_no++ & 1u);
         mvfx_hip_memory_acquire_as_owner(first, st, GST_OBJECT(self)); // (the mark stays until the fence is recorded: see the flush)
-        mvfx_hip_buffer_acquire(buf, st);
+        mvfx_hip_memory_acquire_as_owner(mem, st, GST_OBJECT(self));
         rc = mvfx_hsvfilter_transform_frames_ip_settings(frames, 2, settings, st);
         mvfx_hip_memory_release_as_owner(first, st, GST_OBJECT(self));
-        mvfx_hip_buffer_release(buf, st);
+        mvfx_hip_memory_release_as_owner(mem, st, GST_OBJECT(self));
         self->n_pairs++;
+        self->foreign_streak = 0;
+        later.add(first);
         g.unlock();
-        gst_memory_unref(first);
         return MVFX_GST_FLOW(self, rc);
     }
     mvfx_hip_buffer_acquire(buf, st);
@@ -232,7 +266,8 @@ static gboolean gst_hsv_filter_stop(GstBaseTransform *bt)
     GstHsvFilter *self = reinterpret_cast<GstHsvFilter *>(bt);
     if (g_getenv("MVFX_ELEMENT_PAIR_STATS") && self->n_buffers)
         g_printerr("hsvfilter %s: %" G_GUINT64_FORMAT " device buffers = 2 x %" G_GUINT64_FORMAT " pair launches + %" G_GUINT64_FORMAT
-                   " single launches\n", GST_OBJECT_NAME(bt), self->n_buffers, self->n_pairs, self->n_singles);
+                   " single launches + %" G_GUINT64_FORMAT " direct launches\n", GST_OBJECT_NAME(bt), self->n_buffers, self->n_pairs,
+                   self->n_singles, self->n_direct);
     return TRUE;
 }
 
@@ -296,7 +331,8 @@ static void gst_hsv_filter_init(GstHsvFilter *self)
     self->pend_lock = new std::mutex();
     self->pend_mem = NULL;
     self->pair_no = 0;
-    self->n_buffers = self->n_pairs = self->n_singles = 0;
+    self->n_buffers = self->n_pairs = self->n_singles = self->n_direct = 0;
+    self->foreign_streak = self->direct_left = 0;
     self->settings = mvfx_hsvfilter_settings{0.0f, 1.0f, 0.0f, 1.0f, 0.0f};
     self->i420_scratch = NULL;
     self->i420_scratch_size = 0;
@@ -308,6 +344,9 @@ struct GstHsvDetector {
     GstVideoFilter parent;
     std::mutex *lock;
     mvfx_hsvdetector_settings settings;
+    // pair launches on device buffers (mvfx_pair_hold.h): the held-back frame and the settings in force when its buffer came
+    MvfxPairHold *hold;
+    mvfx_hsvdetector_settings pend_settings;
 };
 struct GstHsvDetectorClass {
     GstVideoFilterClass parent_class;
@@ -403,6 +442,23 @@ static GstFlowReturn gst_hsv_detector_prepare_output_buffer(GstBaseTransform *bt
     return mvfx_hip_new_output(bt, inbuf, GST_VIDEO_INFO_SIZE(&GST_VIDEO_FILTER(bt)->out_info), outbuf);
 }
 
+static int gst_hsv_detector_pair_launch(GstObject *element, const mvfx_frame *in, const mvfx_frame *out, uint32_t n, mvfx_stream st)
+{
+    GstHsvDetector *self = reinterpret_cast<GstHsvDetector *>(element);
+    return n == 1 ? mvfx_hsvdetector_transform_frame(in, out, &self->pend_settings, st)
+                  : mvfx_hsvdetector_transform_frames(in, out, n, &self->pend_settings, st);
+}
+
+static void gst_hsv_detector_flush_cb(GstObject *owner) // EOS, flush-start, stop
+{
+    mvfx_pair_flush(reinterpret_cast<GstHsvDetector *>(owner)->hold, owner, gst_hsv_detector_pair_launch);
+}
+
+static void gst_hsv_detector_looked_at_cb(GstObject *owner) // registered on the held-back frame's blocks
+{
+    mvfx_pair_flush_foreign(reinterpret_cast<GstHsvDetector *>(owner)->hold, owner, gst_hsv_detector_pair_launch);
+}
+
 static GstFlowReturn gst_hsv_detector_bt_transform(GstBaseTransform *bt, GstBuffer *inbuf, GstBuffer *outbuf)
 {
     if (!mvfx_buffer_is_hip(inbuf) || !mvfx_buffer_is_hip(outbuf))
@@ -427,6 +483,21 @@ static GstFlowReturn gst_hsv_detector_bt_transform(GstBaseTransform *bt, GstBuff
         return GST_FLOW_ERROR;
     }
     mvfx_stream st = mvfx_element_stream(inbuf);
+    if (!i420 && mvfx_pair_enabled() && gst_buffer_n_memory(inbuf) == 1 && gst_buffer_n_memory(outbuf) == 1) {
+        gst_buffer_unmap(outbuf, &omap); // (a MVFX_MAP_HIP map is the device pointer: it stays valid while the memory lives)
+        gst_buffer_unmap(inbuf, &imap);
+        // pend_settings is written by this thread only (under the hold's lock, for the flush on another thread to read)
+        const gboolean same = memcmp(&self->pend_settings, &s, sizeof s) == 0;
+        const int prc = mvfx_pair_submit(self->hold, GST_OBJECT(self), gst_hsv_detector_pair_launch, gst_hsv_detector_looked_at_cb, inbuf, outbuf,
+                                         fi, fo, st, same, [&] { self->pend_settings = s; });
+        if (prc != MVFX_PAIR_NOT_TAKEN) return MVFX_GST_FLOW(self, prc);
+        mvfx_hip_buffer_acquire(inbuf, st);
+        mvfx_hip_buffer_acquire(outbuf, st);
+        const int drc = mvfx_hsvdetector_transform_frame(&fi, &fo, &s, st);
+        mvfx_hip_memory_release_tagged(gst_buffer_peek_memory(inbuf, 0), st, GST_OBJECT(self));
+        mvfx_hip_memory_release_tagged(gst_buffer_peek_memory(outbuf, 0), st, GST_OBJECT(self));
+        return MVFX_GST_FLOW(self, drc);
+    }
     mvfx_hip_buffer_acquire(inbuf, st);
     mvfx_hip_buffer_acquire(outbuf, st);
     int rc = i420 ? mvfx_hsvdetector_transform_i420(&pi, &fo, &s, 0, st) : mvfx_hsvdetector_transform_frame(&fi, &fo, &s, st);
@@ -437,8 +508,24 @@ static GstFlowReturn gst_hsv_detector_bt_transform(GstBaseTransform *bt, GstBuff
     return MVFX_GST_FLOW(self, rc);
 }
 
+// EOS, flush-start, stop: nothing stays held back across them
+static gboolean gst_hsv_detector_sink_event(GstBaseTransform *bt, GstEvent *event)
+{
+    if (GST_EVENT_TYPE(event) == GST_EVENT_EOS || GST_EVENT_TYPE(event) == GST_EVENT_FLUSH_START)
+        gst_hsv_detector_flush_cb(GST_OBJECT(bt));
+    return GST_BASE_TRANSFORM_CLASS(gst_hsv_detector_parent_class)->sink_event(bt, event);
+}
+
+static gboolean gst_hsv_detector_stop(GstBaseTransform *bt)
+{
+    gst_hsv_detector_flush_cb(GST_OBJECT(bt));
+    mvfx_pair_print_stats(reinterpret_cast<GstHsvDetector *>(bt)->hold, GST_OBJECT(bt), "hsvdetector");
+    return TRUE;
+}
+
 static void gst_hsv_detector_finalize(GObject *obj)
 {
+    delete reinterpret_cast<GstHsvDetector *>(obj)->hold;
     delete reinterpret_cast<GstHsvDetector *>(obj)->lock;
     G_OBJECT_CLASS(gst_hsv_detector_parent_class)->finalize(obj);
 }
@@ -481,13 +568,17 @@ static void gst_hsv_detector_class_init(GstHsvDetectorClass *klass)
     GST_BASE_TRANSFORM_CLASS(klass)->propose_allocation = gst_hsv_detector_propose_allocation;
     GST_BASE_TRANSFORM_CLASS(klass)->decide_allocation = gst_hsv_detector_decide_allocation;
     GST_BASE_TRANSFORM_CLASS(klass)->transform = gst_hsv_detector_bt_transform;
+    GST_BASE_TRANSFORM_CLASS(klass)->sink_event = gst_hsv_detector_sink_event;
+    GST_BASE_TRANSFORM_CLASS(klass)->stop = gst_hsv_detector_stop;
     GST_VIDEO_FILTER_CLASS(klass)->transform_frame = gst_hsv_detector_transform_frame; // NeverInPlace (:380-384)
 }
 
 static void gst_hsv_detector_init(GstHsvDetector *self)
 {
     self->lock = new std::mutex();
+    self->hold = new MvfxPairHold();
     self->settings = mvfx_hsvdetector_settings{0.0f, 10.0f, 0.0f, 0.15f, 0.0f, 0.3f};
+    self->pend_settings = self->settings;
 }
 
 // ------------------------------------------------------------------------- plugin (hsv/src/lib.rs:23-42)

@@ -26,6 +26,7 @@ typedef struct {
     // work an element holds back on this block (mvfx_hip_memory_set_deferred): flushed by the next user before it looks at the fence
     MvfxDeferredFlush deferred_flush;
     GstObject *deferred_owner; // referenced while set
+    const void *fence_owner;   // who recorded the pending fence (compared only, never dereferenced): mvfx_hip_memory_busy
 } MvfxHipMemory;
 
 typedef struct { GstAllocator parent; } MvfxHipAllocator;
@@ -207,17 +208,47 @@ static gboolean deferred_is_owners(MvfxHipMemory *m, GstObject *owner)
 
 void mvfx_hip_memory_acquire(GstMemory *mem, mvfx_stream stream) { mvfx_hip_memory_acquire_as_owner(mem, stream, NULL); }
 
+// Somebody else's held-back work on the block, run now.  An element that launches under its own lock (mvfx_pair_hold.h, hsvfilter)
+// calls this BEFORE taking that lock: a foreign flush takes the other element's lock, and two elements that wait for each other's
+// flush under their own locks never come back (hsvfilter ! queue ! hsvdetector on recycled blocks did exactly that).
+void mvfx_hip_memory_flush_foreign(GstMemory *mem, GstObject *owner)
+{
+    if (!mvfx_is_hip_memory(mem)) return;
+    MvfxHipMemory *m = (MvfxHipMemory *)mem;
+    if (!deferred_is_owners(m, owner)) run_deferred(m);
+}
+
+// owner != NULL: the caller holds its own lock and has called mvfx_hip_memory_flush_foreign() on the block before taking it: NO
+// callback runs here.  (A mark that appears on the block after that call can only be a sibling READER's behind a tee -- a writer
+// cannot get hold of a block this element owns or reads -- and a reader's held-back work does not have to come first.)
 void mvfx_hip_memory_acquire_as_owner(GstMemory *mem, mvfx_stream stream, GstObject *owner)
 {
     if (!mvfx_is_hip_memory(mem)) return;
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
-    if (!deferred_is_owners(m, owner)) run_deferred(m); // the owner launching its own held-back work does not flush itself
+    if (!owner) run_deferred(m);
     g_mutex_lock(&m->lock);
     if (m->borrowed)
         mvfx_stream_wait_event(stream, m->borrowed);
     if (m->pending && m->last_use)
         mvfx_stream_wait_event(stream, m->last_use); // device-side wait; the host goes on
     g_mutex_unlock(&m->lock);
+}
+
+// Is device work still running on the block (its fence recorded and not yet reached), or held back on it by somebody else?  An
+// element asks this of its INPUT before it holds its own kernel back: behind work that is still in flight the element is one stage
+// of a dependent chain, and holding back there only lengthens the chain (profiles/r4/element_pairs.txt).  Never blocks, runs no
+// callback.
+gboolean mvfx_hip_memory_busy(GstMemory *mem, GstObject *owner)
+{
+    if (!mvfx_is_hip_memory(mem)) return FALSE;
+    MvfxHipMemory *m = (MvfxHipMemory *)mem;
+    g_mutex_lock(&m->lock);
+    gboolean busy = m->deferred_flush != NULL && m->deferred_owner != owner;
+    if (!busy && m->borrowed) busy = mvfx_event_query(m->borrowed) != 1;
+    // (the asking element's OWN last kernel on a recycled block does not count: that is the launch rate it is trying to raise)
+    if (!busy && m->pending && m->last_use && m->fence_owner != (const void *)owner) busy = mvfx_event_query(m->last_use) != 1;
+    g_mutex_unlock(&m->lock);
+    return busy;
 }
 
 void *mvfx_hip_memory_pending_fence(GstMemory *mem)
@@ -250,7 +281,7 @@ void mvfx_hip_memory_release_as_owner(GstMemory *mem, mvfx_stream stream, GstObj
 {
     if (!mvfx_is_hip_memory(mem)) return;
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
-    if (!deferred_is_owners(m, owner)) run_deferred(m); // (a user that released without acquiring: the held-back work still comes first)
+    if (!owner) run_deferred(m); // (a user that released without acquiring: the held-back work still comes first)
     GstObject *drop = NULL;
     g_mutex_lock(&m->lock);
     if (!m->last_use && mvfx_event_create(&m->last_use) != MVFX_OK)
@@ -267,6 +298,7 @@ void mvfx_hip_memory_release_as_owner(GstMemory *mem, mvfx_stream stream, GstObj
         m->pending = TRUE;
     else
         mvfx_stream_synchronize(stream); // no event: fall back to a blocking hand-off
+    m->fence_owner = owner;
     if (owner && m->deferred_flush && m->deferred_owner == owner) {
         drop = m->deferred_owner;
         m->deferred_flush = NULL;
@@ -274,6 +306,18 @@ void mvfx_hip_memory_release_as_owner(GstMemory *mem, mvfx_stream stream, GstObj
     }
     g_mutex_unlock(&m->lock);
     if (drop) gst_object_unref(drop);
+}
+
+// mvfx_hip_memory_release() that also says who recorded the fence (an element's plain launch per buffer: mvfx_hip_memory_busy must not
+// take the element's own previous kernel on a recycled block for somebody else's work)
+void mvfx_hip_memory_release_tagged(GstMemory *mem, mvfx_stream stream, GstObject *tag)
+{
+    if (!mvfx_is_hip_memory(mem)) return;
+    mvfx_hip_memory_release_as_owner(mem, stream, NULL);
+    MvfxHipMemory *m = (MvfxHipMemory *)mem;
+    g_mutex_lock(&m->lock);
+    m->fence_owner = tag;
+    g_mutex_unlock(&m->lock);
 }
 
 void mvfx_hip_memory_wait(GstMemory *mem)

@@ -41,6 +41,9 @@ void mvfx_hip_memory_set_deferred(GstMemory *mem, MvfxDeferredFlush flush, GstOb
 void mvfx_hip_memory_clear_deferred(GstMemory *mem, GstObject *owner); // no-op unless the mark is this owner's
 // The owner launching its held-back work: acquire WITHOUT flushing its own mark, release that records the fence and drops the mark in one
 // critical section (a consumer on another thread must never see "no mark, no fence yet").
+void mvfx_hip_memory_flush_foreign(GstMemory *mem, GstObject *owner);
+gboolean mvfx_hip_memory_busy(GstMemory *mem, GstObject *owner);
+void mvfx_hip_memory_release_tagged(GstMemory *mem, void *stream, GstObject *tag);
 void mvfx_hip_memory_acquire_as_owner(GstMemory *mem, void *stream, GstObject *owner);
 void mvfx_hip_memory_release_as_owner(GstMemory *mem, void *stream, GstObject *owner);
 void *mvfx_hip_memory_pending_fence(GstMemory *mem);

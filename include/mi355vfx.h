@@ -121,6 +121,8 @@ int mvfx_event_destroy(mvfx_event event);
 int mvfx_event_record(mvfx_event event, mvfx_stream stream);
 int mvfx_stream_wait_event(mvfx_stream stream, mvfx_event event);
 int mvfx_event_synchronize(mvfx_event event);
+/* 1: everything recorded before the event has finished; 0: still running (hipEventQuery -> hipErrorNotReady); < 0: MVFX_ERR_*.  Never blocks. */
+int mvfx_event_query(mvfx_event event);
 
 /* Page-locked host memory (hipHostMalloc) for upload / download staging: a copy from or to it is a real DMA at PCIe
  * speed instead of the runtime's chunked staging of pageable memory; and copies that do NOT synchronise (the caller

@@ -565,15 +565,19 @@ def test_device_chain_on_frames_that_all_differ(gpu, tmp_path, queues):
 
 
 def _pair_stats(text):
-    import re
-    m = re.search(r"hsvfilter \S+: (\d+) device buffers = 2 x (\d+) pair launches \+ (\d+) single launches", text)
+    return _pair_stats_of("hsvfilter", text)
+
+
+def _pair_stats_of(element, text):
+    """(buffers, pair launches, lone launches of a held-back frame, plain launches while the element does not hold back)"""
+    m = re.search(element + r" \S+: (\d+) device buffers = 2 x (\d+) pair launches \+ (\d+) single launches \+ (\d+) direct launches", text)
     assert m, text[-2000:]
     return tuple(int(x) for x in m.groups())
 
 
 def test_hsvfilter_pair_launches_every_buffer_exactly_once(gpu, tmp_path):
     """Round 4: on device memory hsvfilter holds ONE buffer's kernel back and launches two consecutive frames together (one call per
-    buffer stays the contract, hsvfilter/imp.rs:322-326).  (a) nobody looks at the blocks (fakesink): 21 buffers = 10 pairs + the last
+    buffer stays the contract, hsvfilter/imp.rs:322-326).  (a) nobody looks at the blocks (fakesink): 21 buffers leave in pairs, the last
     one flushed at EOS; (b) a consumer on ANOTHER streaming thread (queue ! hipdownload) flushes held-back frames itself or finds them
     paired: all 41 frames come out filtered exactly once, byte for byte."""
     w, h = 640, 360
@@ -581,14 +585,16 @@ def test_hsvfilter_pair_launches_every_buffer_exactly_once(gpu, tmp_path):
     r = gst_env.run([LAUNCH, "-q"] + f"hiptestsrc num-buffers=21 refresh=false ! {caps} ! hsvfilter hue-shift=45 ! fakesink sync=false".split(),
                     tmp_path, extra_env={"MVFX_ELEMENT_PAIR_STATS": "1"})
     assert r.returncode == 0, r.stdout
-    assert _pair_stats(r.stdout) == (21, 10, 1)
+    # (a block the source is still filling when its buffer arrives is launched the plain way: the first round through the pool may be)
+    buffers, pairs, singles, direct = _pair_stats(r.stdout)
+    assert buffers == 21 and 2 * pairs + singles + direct == 21 and pairs >= 5 and singles <= 2
     n = 41
     raw = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBA,width={w},height={h}", "in.raw")
     r = gst_env.run([LAUNCH, "-q"] + (f"hiptestsrc num-buffers={n} ! {caps} ! hsvfilter hue-shift=45 saturation-mul=1.2 ! queue max-size-buffers=3 ! "
                                       f"hipdownload ! filesink location={tmp_path}/out.raw").split(), tmp_path, extra_env={"MVFX_ELEMENT_PAIR_STATS": "1"})
     assert r.returncode == 0, r.stdout
-    buffers, pairs, singles = _pair_stats(r.stdout)
-    assert buffers == n and 2 * pairs + singles == n
+    buffers, pairs, singles, direct = _pair_stats(r.stdout)
+    assert buffers == n and 2 * pairs + singles + direct == n
     exp = raw.copy().reshape(h, w * 4)
     orc.hsvfilter(exp, w, w * 4, "RGBA", (45.0, 1.2, 0.0, 1.0, 0.0))
     got = np.fromfile(f"{tmp_path}/out.raw", dtype=np.uint8).reshape(n, h, w * 4)
@@ -606,3 +612,81 @@ def test_hsvfilter_pair_launches_can_be_turned_off(gpu, tmp_path):
     orc.hsvfilter(exp, w, w * 4, "RGBA", (90.0, 1.0, 0.0, 1.0, 0.0))
     got = np.fromfile(f"{tmp_path}/out.raw", dtype=np.uint8).reshape(5, h, w * 4)
     assert all(np.array_equal(got[k], exp) for k in range(5))
+
+
+@pytest.mark.parametrize("consumer", ["fakesink", "same_thread", "other_thread"])
+def test_out_of_place_elements_pair_launches_every_buffer_exactly_once(gpu, tmp_path, consumer):
+    """Round 4: hsvdetector and colorlut (NeverInPlace: hsvdetector/imp.rs:380-384, colorlut/imp.rs:162-166) hold one buffer's kernel
+    back on device memory and launch two consecutive frames together (mvfx_pair_hold.h); input AND output block carry the mark.
+    fakesink: nobody looks, 21 buffers = 10 pairs + one flushed at EOS.  A consumer on the same or on another streaming thread
+    (hipdownload) flushes held-back frames or finds them paired; the source refills the recycled input blocks (refresh=true, a pool of
+    a few blocks) -- every frame comes out transformed exactly once, byte for byte."""
+    w, h, n = 640, 360, 41
+    cube = tmp_path / "look.cube"
+    cube.write_text(cubes.analytic_3d(17))
+    det = "hsvdetector hue-ref=120 hue-var=60 saturation-ref=0.6 saturation-var=0.4 value-ref=0.6 value-var=0.4"
+    det_settings = (120.0, 60.0, 0.6, 0.4, 0.6, 0.4)
+    rgbx = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBx,width={w},height={h}", "in_rgbx.raw").reshape(h, w * 4)
+    rgba = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBA,width={w},height={h}", "in_rgba.raw").reshape(h, w * 4)
+    exp_det = np.empty_like(rgbx)
+    assert orc.hsvdetector(rgbx, w * 4, "RGBx", exp_det, w * 4, "RGBA", w, det_settings) == 0
+    exp_lut = np.empty_like(rgba)
+    assert orc.CubeLut(cube.read_text()).apply(rgba, w * 4, exp_lut, w * 4, w, h, "RGBA") == 0
+    for element, desc, fmt, exp in (("hsvdetector", det, "RGBx", exp_det), ("colorlut", f"colorlut location={cube}", "RGBA", exp_lut)):
+        caps = f"video/x-raw(memory:HIPMemory),format={fmt},width={w},height={h},framerate=30/1"
+        if consumer == "fakesink":
+            r = gst_env.run([LAUNCH, "-q"] + f"hiptestsrc num-buffers=21 refresh=false ! {caps} ! {desc} ! fakesink sync=false".split(), tmp_path,
+                            extra_env={"MVFX_ELEMENT_PAIR_STATS": "1"})
+            assert r.returncode == 0, r.stdout
+            buffers, pairs, singles, direct = _pair_stats_of(element, r.stdout)
+            assert buffers == 21 and 2 * pairs + singles + direct == 21 and pairs >= 5 and singles <= 2
+            continue
+        q = "queue max-size-buffers=3 ! " if consumer == "other_thread" else ""
+        out = tmp_path / f"{element}.raw"
+        r = gst_env.run([LAUNCH, "-q"] + f"hiptestsrc num-buffers={n} ! {caps} ! {desc} ! {q}hipdownload ! filesink location={out}".split(), tmp_path,
+                        extra_env={"MVFX_ELEMENT_PAIR_STATS": "1"})
+        assert r.returncode == 0, r.stdout
+        buffers, pairs, singles, direct = _pair_stats_of(element, r.stdout)
+        assert buffers == n and 2 * pairs + singles + direct == n
+        if consumer == "same_thread": # every held-back frame is flushed by hipdownload's look: after four of them the element stops holding back
+            assert pairs == 0 and singles <= 4 and direct >= n - 4
+        got = np.fromfile(out, dtype=np.uint8).reshape(n, h, w * 4)
+        assert [k for k in range(n) if not np.array_equal(got[k], exp)] == [], element
+
+
+def test_out_of_place_pair_launches_can_be_turned_off_and_follow_a_settings_change(gpu, tmp_path):
+    """MVFX_ELEMENT_PAIR=0: a launch per buffer, no statistics line.  And a held-back frame keeps the settings in force when ITS buffer
+    came: hsvdetector's properties changed between two buffers (tests/gst_worker.py drives the change from the application thread)
+    is covered by the hsvdetector_property_change cases of tests/test_gst_inprocess_gpu.py (device chain), which run through the pair path."""
+    w, h = 320, 240
+    caps = f"video/x-raw(memory:HIPMemory),format=RGBx,width={w},height={h},framerate=30/1"
+    rgbx = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBx,width={w},height={h}", "in.raw").reshape(h, w * 4)
+    exp = np.empty_like(rgbx)
+    assert orc.hsvdetector(rgbx, w * 4, "RGBx", exp, w * 4, "RGBA", w, (0.0, 10.0, 0.0, 0.15, 0.0, 0.3)) == 0
+    r = gst_env.run([LAUNCH, "-q"] + f"hiptestsrc num-buffers=5 ! {caps} ! hsvdetector ! hipdownload ! filesink location={tmp_path}/out.raw".split(),
+                    tmp_path, extra_env={"MVFX_ELEMENT_PAIR": "0", "MVFX_ELEMENT_PAIR_STATS": "1"})
+    assert r.returncode == 0 and "pair launches" not in r.stdout, r.stdout
+    got = np.fromfile(f"{tmp_path}/out.raw", dtype=np.uint8).reshape(5, h, w * 4)
+    assert all(np.array_equal(got[k], exp) for k in range(5))
+
+
+def test_pair_launches_of_neighbouring_elements_never_wait_for_each_other(gpu, tmp_path):
+    """Three elements that all hold kernels back (MVFX_ELEMENT_PAIR=2: always, also inside a chain, where the default mode stops doing
+    it), on three streaming threads, over a pool of a few recycled blocks (refresh=false: the source never looks at them): a held-back
+    frame's blocks meet the neighbour's marks all the time.  An element that ran a neighbour's flush under its own lock deadlocked here
+    within a few hundred buffers (2 of 25 runs of the cross-thread tests); foreign work is flushed before the lock is taken
+    (mvfx_hip_memory_flush_foreign).  Then the default mode on the same pipeline: every buffer exactly once as well."""
+    w, h, n = 320, 180, 4000
+    cube = tmp_path / "look.cube"
+    cube.write_text(cubes.analytic_3d(9))
+    caps = f"video/x-raw(memory:HIPMemory),format=RGBx,width={w},height={h},framerate=30/1"
+    pipe = (f"hiptestsrc num-buffers={n} refresh=false ! {caps} ! hsvfilter hue-shift=30 ! queue max-size-buffers=2 ! hsvdetector hue-var=90 ! "
+            f"queue max-size-buffers=2 ! colorlut location={cube} ! fakesink sync=false")
+    for mode in ("2", "2", "2", "1"):
+        r = gst_env.run([LAUNCH, "-q"] + pipe.split(), tmp_path, timeout=60, extra_env={"MVFX_ELEMENT_PAIR_STATS": "1", "MVFX_ELEMENT_PAIR": mode})
+        assert r.returncode == 0, r.stdout[-2000:]
+        for element in ("hsvfilter", "hsvdetector", "colorlut"):
+            buffers, pairs, singles, direct = _pair_stats_of(element, r.stdout)
+            assert buffers == n and 2 * pairs + singles + direct == n
+            if mode == "2":
+                assert direct == 0

@@ -76,8 +76,37 @@ def branches_main(args):
     print(json.dumps(out), flush=True)
 
 
+def element_main(args):
+    """--element NAME: `hiptestsrc refresh=false ! NAME ! fakesink` on memory:HIPMemory, one streaming thread, with the element's pair
+    launches on (default) and off (MVFX_ELEMENT_PAIR=0)."""
+    tmp = tempfile.mkdtemp()
+    w, h = args.width, args.height
+    cube = os.path.join(tmp, "look.cube")
+    with open(cube, "w") as f:
+        f.write(cubes.analytic_3d(args.lut))
+    desc = {"hsvfilter": ("RGBA", "hsvfilter hue-shift=90", 8),
+            "hsvdetector": ("RGBx", "hsvdetector hue-ref=120 hue-var=60 saturation-ref=0.6 saturation-var=0.4 value-ref=0.6 value-var=0.4", 8),
+            "colorlut": ("RGBA", f"colorlut location={cube}", 8)}[args.element]
+    caps = f"video/x-raw(memory:HIPMemory),format={desc[0]},width={w},height={h},framerate=30/1"
+    tpl = f"hiptestsrc num-buffers={{n}} refresh=false ! {caps} ! {desc[1]} ! fakesink sync=false"
+    out = {"element": args.element, "frame": f"{w}x{h}", "n1": args.n1, "n2": args.n2}
+    # interleaved repeats: the order of two configurations in one process sequence is worth more than their difference otherwise
+    runs = {"1": [], "0": []}
+    for rep in range(args.repeats):
+        for pair in (("0", "1") if rep % 2 else ("1", "0")):
+            v, t1, t2 = fps(tpl, tmp, args.n1, args.n2, {"MVFX_ELEMENT_PAIR": pair})
+            runs[pair].append(round(v, 1))
+    for pair in ("1", "0"):
+        med = sorted(runs[pair])[len(runs[pair]) // 2]
+        out[f"pair_{pair}_fps_runs"] = runs[pair]
+        out[f"pair_{pair}_fps"] = med
+        out[f"pair_{pair}_frac_of_8TBs"] = round(med * desc[2] * w * h / 8e12, 4)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--element", default="", help="hsvfilter | hsvdetector | colorlut: the single element on device memory, pair launches on / off")
     ap.add_argument("--only", default="", help="comma-separated pipeline names of the chain mode (default: all)")
     ap.add_argument("--branches", type=int, default=0, help="N parallel hiptestsrc ! hsvfilter ! fakesink streams in one process (launch combiner A/B)")
     ap.add_argument("--quick", type=int, default=0, help="--branches: only refresh=false, no combiner, n1 / n2 taken literally (bench.py's sub-line)")
@@ -86,7 +115,10 @@ def main():
     ap.add_argument("--n1", type=int, default=60)
     ap.add_argument("--n2", type=int, default=460)
     ap.add_argument("--lut", type=int, default=33)
+    ap.add_argument("--repeats", type=int, default=3, help="--element: interleaved repeats per configuration (the median is reported)")
     args = ap.parse_args()
+    if args.element:
+        return element_main(args)
     if args.branches > 0:
         return branches_main(args)
     tmp = tempfile.mkdtemp()

@@ -6,8 +6,9 @@
   fast   1.07 ns per wave64 instruction per SIMD (2 cycles): v_fma/fmac/add/sub/mul f32 with VGPR, inline or literal operands and
          any modifier, v_add/sub_u32, v_and/or/xor, v_lshrrev_b32, v_mov_b32, and a lone v_cndmask_b32_e32
   slow   1.75 ns on a second pipe that overlaps with `fast` issue: everything else -- min/max/med3, cvt, floor/fract, perm, bfe,
-         lshlrev, lshl_or, and_or, add3, mad/mul_u24, mul_lo, sad, cmp, cndmask_e64, SDWA, DPP, v_pk_*, f64, and a fast
+         lshlrev, lshl_or, and_or, add3, mad/mul_u24, mul_lo, sad, cmp, cndmask_e64, SDWA, DPP, packed 16-bit, f64, and a fast
          instruction with an SGPR operand
+  pk32   1.88 ns on the FIRST pipe (no overlap with `fast`): v_pk_{mul,add,fma}_f32
   trans  3.46 ns, overlaps with nothing: v_rcp/rsq/sqrt/exp/log/sin/cos
   back-to-back v_cndmask_b32_e32: 9.5 ns each (listed separately)
 
@@ -20,7 +21,8 @@ FAST = {"v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32", "v_add_f32", "v
         "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32", "v_mov_b32", "v_cndmask_b32"}
 TRANS = {"v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32", "v_rcp_iflag_f32", "v_rcp_f64",
          "v_rsq_f64", "v_sqrt_f64"}
-NS = {"fast": 1.07, "slow": 1.75, "trans": 3.46, "cnd_chain": 9.5}
+NS = {"fast": 1.07, "slow": 1.75, "pk32": 1.88, "trans": 3.46, "cnd_chain": 9.5}
+PK32 = {"v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32"}
 
 
 def classify(line, prev_cls_op):
@@ -33,6 +35,8 @@ def classify(line, prev_cls_op):
     operands = line[len(op):].split(";")[0]
     if base in TRANS:
         return "trans", op
+    if base in PK32:
+        return "pk32", op
     if base == "v_cndmask_b32":
         if suffix == "_e32":
             return ("cnd_chain" if prev_cls_op == "v_cndmask_b32_e32" else "fast"), op
@@ -86,22 +90,22 @@ def main():
         n = sum(cls.values())
         if not n:
             continue
-        issue = NS["fast"] * (cls["fast"] + cls["slow"])
+        issue = NS["fast"] * (cls["fast"] + cls["slow"]) + NS["pk32"] * cls["pk32"]
         slow = NS["slow"] * cls["slow"]
         extra = NS["trans"] * cls["trans"] + NS["cnd_chain"] * cls["cnd_chain"]
         print(f"{name[:110]}")
-        print(f"  VALU {n}: fast {cls['fast']}  slow {cls['slow']}  trans {cls['trans']}  back-to-back cndmask_e32 {cls['cnd_chain']}"
+        print(f"  VALU {n}: fast {cls['fast']}  slow {cls['slow']}  pk32 {cls['pk32']}  trans {cls['trans']}  back-to-back cndmask_e32 {cls['cnd_chain']}"
               f"   | other: {dict(other)}")
         print(f"  static price: issue {issue:.0f} ns, slow pipe {slow:.0f} ns -> max {max(issue, slow):.0f} + serial {extra:.0f} ns"
               f"  ({'slow-pipe' if slow > issue else 'issue'} limited)")
-        for c in ("slow", "trans", "fast"):
+        for c in ("slow", "pk32", "trans", "fast"):
             top = ", ".join(f"{o} {k}" for o, k in ops[c].most_common(14))
             print(f"    {c}: {top}")
         if per_block:
             for lab, cc in blocks:
                 t = sum(cc.values())
                 if t >= 8:
-                    print(f"    block {lab}: {t} VALU  fast {cc['fast']} slow {cc['slow']} trans {cc['trans']} chain {cc['cnd_chain']}")
+                    print(f"    block {lab}: {t} VALU  fast {cc['fast']} slow {cc['slow']} pk32 {cc['pk32']} trans {cc['trans']} chain {cc['cnd_chain']}")
 
 
 if __name__ == "__main__":
