@@ -187,3 +187,29 @@ def test_threads_that_come_and_go_recycle_their_streams(gpu):
     # generation 0 may draw on streams that threads of earlier tests left in the pool; from then on nothing new is created
     # (without the pool: 6 x 64 distinct handles)
     assert len(set().union(*seen)) <= 2 * n_threads * 4, "later generations of threads did not get pooled streams back"
+
+
+def test_event_query_never_blocks_and_turns_one(gpu):
+    """mvfx_event_query (hipEventQuery behind the C ABI): 1 on an event nothing was recorded on and once the work before the record has
+    finished, 0 (not an error, mvfx_last_error untouched by the next call) while it is still running, MVFX_ERR_INVALID_ARGUMENT on
+    NULL.  The elements ask it of their input block before they hold a kernel back (host/gst/mvfx_pair_hold.h)."""
+    L = gpu.lib()
+    w, h, n = 3840, 2160, 24
+    ev = ctypes.c_void_p()
+    gpu.check(L.mvfx_event_create(ctypes.byref(ev)))
+    assert L.mvfx_event_query(ev) == 1
+    assert L.mvfx_event_query(None) < 0
+    host = frames.random_frame(7, w, h)
+    bufs = [gpu.DeviceBuffer(host.nbytes).upload(host) for _ in range(n)]
+    gpu.check(L.mvfx_stream_synchronize(None))
+    arr = (gpu.Frame * n)(*[gpu.make_frame(b.ptr, w, h, w * 4, "RGBA") for b in bufs])
+    s = gpu.HsvFilterSettings(90.0, 1.0, 0.0, 1.0, 0.0)
+    seen = set()
+    for _ in range(8):   # ~0.3 ms of device work per round, queried right behind the record
+        gpu.check(L.mvfx_hsvfilter_transform_frames_ip(arr, n, ctypes.byref(s), None))
+        gpu.check(L.mvfx_event_record(ev, None))
+        seen.add(L.mvfx_event_query(ev))
+        gpu.check(L.mvfx_stream_synchronize(None))
+        assert L.mvfx_event_query(ev) == 1
+    assert seen <= {0, 1} and 0 in seen
+    gpu.check(L.mvfx_event_destroy(ev))
