@@ -882,17 +882,31 @@ typedef const volatile __attribute__((address_space(3))) f32x2_t *lds_float2_t;
 #ifndef MVFX_XTILE_ROWS
 #define MVFX_XTILE_ROWS 4 // rows of four pixels per lane: the wave's block is 64 x (4 x rows) pixels
 #endif
+#ifndef MVFX_XTILE_SAMPLE_ROW
+#define MVFX_XTILE_SAMPLE_ROW 1 // ANCHOR4 == 7: which of the lane's rows the sample comes from
+#endif
+#ifndef MVFX_XTILE_SPREAD64
+#define MVFX_XTILE_SPREAD64 120 // ANCHOR4 == 7: corner samples (60 x 12 pixels apart) differ by more than this along both diagonals -> an edge
+#endif
+#ifndef MVFX_XTILE_SPREAD_LOW
+#define MVFX_XTILE_SPREAD_LOW 20 // ANCHOR4 == 7: four lanes around the centre agree this closely (sum of absolute byte differences along both diagonals) -> their mean
+#endif
 #ifndef MVFX_XTILE_ANCHOR4
-#define MVFX_XTILE_ANCHOR4 2 // where the window is anchored.  0: at the block's centre pixel (rounds 3 and 4 until its last day): one pixel carries the
+#define MVFX_XTILE_ANCHOR4 7 // where the window is anchored.  0: at the block's centre pixel (rounds 3 and 4 until its last day): one pixel carries the
                              // full noise of the picture, and every code the anchor is off shrinks the part of the window the other pixels can use.
                              // 1: at the mean of four pixels of the block (the centres of its quadrants) through scalar loads.
-                             // 2 (shipped): the same four samples through ONE vector load of lanes 0..3 ahead of the pixel loads, the mean only
+                             // 2: the same four samples through ONE vector load of lanes 0..3 ahead of the pixel loads, the mean only
                              // where they agree (across an edge the mean fits neither side: the first sample stands).
                              // Round 4, after the window reads became ds_read_b64 (profiles/r4/colorlut_anchor.txt, same box, 16 x 4K per launch):
                              //   noise +-0 / 3 / 5 / 8 / 16 / flat bars:  0: 76.4 / 73.2 / 59.9 / 39.2 / 23.9 / 64.5 k fps
                              //                                            1: 73.7 / 72.0 / 66.7 / 44.9 / 25.4 / 61.9 k
                              //                                            2: 76.6 / 74.0 / 68.1 / 46.3 / 25.0 / 63.7 k   one frame per launch 18.5 us (0: 19.0)
                              // (round 3, with ds_read2_b64 window reads, 2 cost the clean frames 1-2 % and a single frame 1 us: it stayed off)
+                             // 7 (shipped): samples out of the pixel registers, no load of their own -- the mean of four lanes around the centre where
+                             // they agree, of all sixty-four lanes elsewhere (see the kernel).  Same box as a run of 2:
+                             //   noise +-0 / 3 / 5 / 8 / 16:  2: 73.7 / 70.8 / 64.6 / 46.6 / 25.1 k fps     7: 72.9 / 70.4 / 64.8 / 52.0 / 26.9 k
+                             //   (sixteen samples through the vector load of 2: 69.7 / 68.1 / 65.0 / 49.2 / 25.7 k -- the load's own lines cost more
+                             //   than the better mean returns on clean frames)
 #endif
 #ifndef MVFX_XTILE_MIN_BLOCKS
 #define MVFX_XTILE_MIN_BLOCKS 1
@@ -933,6 +947,8 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
     const bool whole_block = bx + kTileW <= width && by + kTileH <= height;
     if (whole_block && lane < 4)
         smp = *reinterpret_cast<const uint32_t *>(in + ((by + kTileH / 4 + (lane >> 1) * (kTileH / 2)) * in_stride + (bx + kTileW / 4 + (lane & 1) * (kTileW / 2)) * 4));
+#elif MVFX_XTILE_ANCHOR4 == 7
+    const bool whole_block = bx + kTileW <= width && by + kTileH <= height;
 #endif
     // 1. every pixel of the lane, up front (four 16-byte loads in flight while the window is being fetched)
     uint32_t voff_in = y0 * in_stride + x * 4, voff_out = y0 * out_stride + x * 4; // the lane's byte offsets into rows y0 .. of the frames
@@ -967,6 +983,48 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
             const uint32_t od = ((q0 >> 8) & 0x00ff00ffu) + ((q1 >> 8) & 0x00ff00ffu) + ((q2 >> 8) & 0x00ff00ffu) + ((q3 >> 8) & 0x00ff00ffu) + 0x00020002u;
             const uint32_t mean = ((ev >> 2) & 0x00ff00ffu) | (((od >> 2) & 0x00ff00ffu) << 8);
             cpx = spread <= 72u ? mean : q0;
+        }
+        cpx = (uint32_t)__builtin_amdgcn_readfirstlane((int)cpx);
+#elif MVFX_XTILE_ANCHOR4 == 7
+        // Samples that cost no memory access at all: every lane's own pixel (x + 1, y0 + 1), out of the registers the pixel loads above
+        // fill -- a 16 x 4 lattice over the block.  (A separate sample load fetches lines of its own: with sixteen lanes taking part in it
+        // the clean frames lost 4-5 %, profiles/r4/colorlut_anchor.txt.)  The window fill now waits for the second row's pixel load
+        // instead of the sample load: the same memory round trip.  Where four lanes around the block's centre agree closely (clean
+        // content) their mean is the anchor; elsewhere (noise, texture) the mean of all sixty-four -- eight dependent DPP additions on the
+        // path the window fill waits for, which clean blocks do not pay.
+        // sixty-four samples that cost no memory access at all: every lane's own pixel (x + 1, y0 + 1), out of the registers the pixel loads
+        // above fill -- a 16 x 4 lattice over the block.  (A separate sample load fetches lines of its own: with sixteen lanes taking part
+        // in it the clean frames lost 4-5 %, profiles/r4/colorlut_anchor.txt.)  The window fill now waits for the second row's pixel load
+        // instead of the sample load: the same memory round trip.
+        if (__builtin_amdgcn_readfirstlane((int)whole_block)) {
+            const uint32_t mine = v[MVFX_XTILE_SAMPLE_ROW < kRows ? MVFX_XTILE_SAMPLE_ROW : 0].y;
+            const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 21) & 0xffffffu, i1 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 26) & 0xffffffu,
+                           i2 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 37) & 0xffffffu, i3 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 42) & 0xffffffu;
+            const uint32_t inner = __builtin_amdgcn_sad_u8(i0, i3, 0u) + __builtin_amdgcn_sad_u8(i1, i2, 0u);
+            if (inner <= (uint32_t)MVFX_XTILE_SPREAD_LOW) {
+                const uint32_t ev4 = (i0 & 0x00ff00ffu) + (i1 & 0x00ff00ffu) + (i2 & 0x00ff00ffu) + (i3 & 0x00ff00ffu) + 0x00020002u;
+                const uint32_t od4 = ((i0 >> 8) & 0x00ff00ffu) + ((i1 >> 8) & 0x00ff00ffu) + ((i2 >> 8) & 0x00ff00ffu) + ((i3 >> 8) & 0x00ff00ffu) + 0x00020002u;
+                cpx = ((ev4 >> 2) & 0x00ff00ffu) | (((od4 >> 2) & 0x000000ffu) << 8);
+            } else {
+            uint32_t ev = mine & 0x00ff00ffu, od = (mine >> 8) & 0x00ff00ffu;
+#define MVFX_ROW_ADD(v_, ctrl) v_ += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v_, ctrl, 0xf, 0xf, true)
+            MVFX_ROW_ADD(ev, 0x111); MVFX_ROW_ADD(od, 0x111);
+            MVFX_ROW_ADD(ev, 0x112); MVFX_ROW_ADD(od, 0x112);
+            MVFX_ROW_ADD(ev, 0x114); MVFX_ROW_ADD(od, 0x114);
+            MVFX_ROW_ADD(ev, 0x118); MVFX_ROW_ADD(od, 0x118);
+#undef MVFX_ROW_ADD
+            // lanes 15, 31, 47, 63 hold their row's sums (16 x 255 fits twelve bits; the four rows together fourteen)
+            const uint32_t sev = (uint32_t)__builtin_amdgcn_readlane((int)ev, 15) + (uint32_t)__builtin_amdgcn_readlane((int)ev, 31) +
+                                 (uint32_t)__builtin_amdgcn_readlane((int)ev, 47) + (uint32_t)__builtin_amdgcn_readlane((int)ev, 63) + 0x00200020u;
+            const uint32_t sod = (uint32_t)__builtin_amdgcn_readlane((int)od, 15) + (uint32_t)__builtin_amdgcn_readlane((int)od, 31) +
+                                 (uint32_t)__builtin_amdgcn_readlane((int)od, 47) + (uint32_t)__builtin_amdgcn_readlane((int)od, 63) + 0x00200020u;
+            const uint32_t mean = ((sev >> 6) & 0x00ff00ffu) | (((sod >> 6) & 0x000000ffu) << 8);
+            const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 0) & 0xffffffu, q1 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 15) & 0xffffffu,
+                           q2 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 48) & 0xffffffu, q3 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 63) & 0xffffffu;
+            const uint32_t spread = __builtin_amdgcn_sad_u8(q0, q3, 0u) + __builtin_amdgcn_sad_u8(q1, q2, 0u);
+            // across an edge the mean fits neither side: the lane next to the block's centre stands
+            cpx = spread <= (uint32_t)MVFX_XTILE_SPREAD64 ? mean : ((uint32_t)__builtin_amdgcn_readlane((int)mine, 40) & 0xffffffu);
+            }
         }
         cpx = (uint32_t)__builtin_amdgcn_readfirstlane((int)cpx);
 #elif MVFX_XTILE_ANCHOR4
