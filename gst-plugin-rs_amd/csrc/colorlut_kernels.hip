@@ -885,6 +885,9 @@ typedef const volatile __attribute__((address_space(3))) f32x2_t *lds_float2_t;
 #ifndef MVFX_XTILE_SAMPLE_ROW
 #define MVFX_XTILE_SAMPLE_ROW 1 // ANCHOR4 == 7: which of the lane's rows the sample comes from
 #endif
+#ifndef MVFX_I420_XTILE_MEAN
+#define MVFX_I420_XTILE_MEAN 1 // colorlut_i420_xtile_kernel: window anchored at the mean of the lanes' first pixels (0: lane 36's)
+#endif
 #ifndef MVFX_XTILE_SPREAD64
 #define MVFX_XTILE_SPREAD64 120 // ANCHOR4 == 7: corner samples (60 x 12 pixels apart) differ by more than this along both diagonals -> an edge
 #endif
@@ -1268,7 +1271,28 @@ __global__ __launch_bounds__(kI420Block) void colorlut_i420_xtile_kernel(I420Pla
         first = yuv_pixel(pl.iy[(uint64_t)y0 * pl.iys + x0], c, kin);
     }
     const uint32_t centre = __builtin_amdgcn_readlane((int)active, 36) ? 36u : 0u;
-    const uint32_t fpx = (uint32_t)__builtin_amdgcn_readlane((int)first, centre);
+    uint32_t fpx = (uint32_t)__builtin_amdgcn_readlane((int)first, centre);
+#if MVFX_I420_XTILE_MEAN
+    // a block that lies wholly inside the frame is anchored at the MEAN of its 64 lanes' first pixels (an 8 x 8 lattice over the
+    // 64 x 16 block, already in registers) unless its corners say an edge runs through it: colorlut_xtile_kernel, MVFX_XTILE_ANCHOR4 7
+    if (__ballot(active) == ~0ull) {
+        uint32_t ev = first & 0x00ff00ffu, od = (first >> 8) & 0x00ff00ffu;
+#define MVFX_ROW_ADD(v_, ctrl) v_ += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v_, ctrl, 0xf, 0xf, true)
+        MVFX_ROW_ADD(ev, 0x111); MVFX_ROW_ADD(od, 0x111);
+        MVFX_ROW_ADD(ev, 0x112); MVFX_ROW_ADD(od, 0x112);
+        MVFX_ROW_ADD(ev, 0x114); MVFX_ROW_ADD(od, 0x114);
+        MVFX_ROW_ADD(ev, 0x118); MVFX_ROW_ADD(od, 0x118);
+#undef MVFX_ROW_ADD
+        const uint32_t sev = (uint32_t)__builtin_amdgcn_readlane((int)ev, 15) + (uint32_t)__builtin_amdgcn_readlane((int)ev, 31) +
+                             (uint32_t)__builtin_amdgcn_readlane((int)ev, 47) + (uint32_t)__builtin_amdgcn_readlane((int)ev, 63) + 0x00200020u;
+        const uint32_t sod = (uint32_t)__builtin_amdgcn_readlane((int)od, 15) + (uint32_t)__builtin_amdgcn_readlane((int)od, 31) +
+                             (uint32_t)__builtin_amdgcn_readlane((int)od, 47) + (uint32_t)__builtin_amdgcn_readlane((int)od, 63) + 0x00200020u;
+        const uint32_t mean = ((sev >> 6) & 0x00ff00ffu) | (((sod >> 6) & 0x000000ffu) << 8);
+        const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)first, 0) & 0xffffffu, q1 = (uint32_t)__builtin_amdgcn_readlane((int)first, 7) & 0xffffffu,
+                       q2 = (uint32_t)__builtin_amdgcn_readlane((int)first, 56) & 0xffffffu, q3 = (uint32_t)__builtin_amdgcn_readlane((int)first, 63) & 0xffffffu;
+        if (__builtin_amdgcn_sad_u8(q0, q3, 0u) + __builtin_amdgcn_sad_u8(q1, q2, 0u) <= (uint32_t)MVFX_XTILE_SPREAD64) fpx = mean;
+    }
+#endif
     const uint32_t cr = fpx & 0xffu, cy = p.tile_tables[2 * (256 + ((fpx >> 8) & 0xffu))], cz = p.tile_tables[2 * (512 + ((fpx >> 16) & 0xffu))];
     const uint32_t ar = min((cr > RW / 2 ? cr - RW / 2 : 0u) & ~1u, 256u - RW);
     const uint32_t ay = min(cy > 0 ? cy - 1 : 0u, p.size - 3), az = min(cz > 0 ? cz - 1 : 0u, p.size - 3);

@@ -64,8 +64,11 @@ def report(name, ms, bytes_per_call, frames_per_call, extra=None):
     print(json.dumps(o), flush=True)
 
 
+NOISE = int(os.environ.get("MVFX_BENCH_NOISE", "3"))
+
+
 def natural_like_gpu(n, w, h, seed):
-    """Smooth 2-D colour gradients + sensor-like noise of +-3 codes: neighbouring pixels mostly share a LUT cell."""
+    """Smooth 2-D colour gradients + sensor-like noise of +-3 codes (MVFX_BENCH_NOISE): neighbouring pixels mostly share a LUT cell."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     x = torch.linspace(0, 1, w, device=dev).view(1, 1, w)
@@ -75,7 +78,7 @@ def natural_like_gpu(n, w, h, seed):
     gch = 0.5 + 0.45 * torch.sin(5.0 * y - 1.5 * x + 2 * ph)
     b = 0.5 + 0.45 * torch.cos(4.0 * x * y + ph)
     img = torch.stack([r.expand(n, h, w), gch.expand(n, h, w), b.expand(n, h, w), torch.ones((n, h, w), device=dev)], dim=-1) * 255.0
-    img = img + torch.randint(-3, 4, img.shape, device=dev, generator=g).float() * torch.tensor([1, 1, 1, 0], device=dev)
+    img = img + torch.randint(-NOISE, NOISE + 1, img.shape, device=dev, generator=g).float() * torch.tensor([1, 1, 1, 0], device=dev)
     return img.clamp(0, 255).to(torch.uint8).view(n, -1).contiguous()
 
 
