@@ -1635,7 +1635,7 @@ def main():
                          "been through hsvfilter repeatedly converge to low-entropy colours; the chip then draws less power and "
                          "clocks higher: profiles/r2/ab_fresh_vs_converged_data.txt). Default 0 = fresh uniform-random frames")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU baseline budget per leg (1 thread, then nproc threads)")
-    ap.add_argument("--cpu-all-seconds", type=float, default=3.0, help="headline CPU baseline on nproc threads (0 = skip)")
+    ap.add_argument("--cpu-all-seconds", type=float, default=2.5, help="headline CPU baseline on nproc threads (0 = skip)")
     ap.add_argument("--other-cpu-all-seconds", type=float, default=0.0,
                     help="configs 2-5: CPU baseline on nproc threads (0 = skip: the driver's command has to fit in a minute; the sub-lines quote the "
                          "one-thread rate, which is what the reference's one streaming thread does)")
@@ -1659,7 +1659,7 @@ def main():
                     help="0 skips the two launch-combiner legs: rocprofiler-sdk 7.2 (rocprofv3 --kernel-trace / --pmc) crashes inside its HSA queue "
                          "interceptor on the cross-stream hipStreamWaitEvent traffic they generate (profiles/r3/rocprofv3_crash_in_queue_interceptor.txt)")
     ap.add_argument("--side-leg-timeout", type=float, default=180.0, help="N > 1: watchdog of the band-sharded videocompare leg, seconds")
-    ap.add_argument("--other-cpu-seconds", type=float, default=1.0, help="CPU baseline budget per leg of configs 2-5 (1 thread, then nproc threads)")
+    ap.add_argument("--other-cpu-seconds", type=float, default=0.7, help="CPU baseline budget per leg of configs 2-5 (1 thread, then nproc threads)")
     ap.add_argument("--other-settle-seconds", type=float, default=0.3, help="untimed run before each leg of configs 2-5")
     ap.add_argument("--pct-steps", type=int, default=200,
                     help="extra steps with a HIP event between every two, for the p10/p50/p90 of the per-step time (0 = skip)")
