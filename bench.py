@@ -1586,11 +1586,12 @@ def hsvfilter_main(args):
 
 def gst_pipeline_leg(args):
     """The real element: `gst-launch-1.0 hiptestsrc ! video/x-raw(memory:HIPMemory),RGBA,3840x2160 ! hsvfilter ! fakesink` in child
-    processes (tools/bench_gst_pipeline.py --branches 1: two runs with N1 and N2 buffers, frames/s = (N2 - N1) / (t2 - t1))."""
+    process (tools/bench_gst_pipeline.py --branches 1 --quick 2: one run of N2 buffers, the rate between buffer N1 and the last one taken
+    inside the process by hiptestsrc at two instants where a recycled block is back with all downstream work on it finished)."""
     gst_dir = os.path.join(ROOT, "gst-plugin-rs_amd", "gst-plugins")
     if not os.path.isdir(gst_dir) or not os.path.exists("/opt/conda/bin/gst-launch-1.0"):
         return {"error": "no GStreamer on this box (the element layer is an optional build target)"}
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_gst_pipeline.py"), "--branches", "1", "--quick", "1",
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_gst_pipeline.py"), "--branches", "1", "--quick", "2",
            "--n1", str(args.gst_n1), "--n2", str(args.gst_n2)]
 
     def one(pair):

@@ -239,6 +239,7 @@ struct GstMi355HipTestSrc {
     gsize pattern_size;
     void *master;        // device copy of `pattern` (memory:HIPMemory caps)
     guint64 n;
+    gint64 rate_t0;      // MVFX_TESTSRC_RATE=N: monotonic time when the block of buffer N had come back from downstream, work done
 };
 struct GstMi355HipTestSrcClass { GstPushSrcClass parent_class; };
 G_DEFINE_TYPE(GstMi355HipTestSrc, gst_mi355_hip_test_src, GST_TYPE_PUSH_SRC)
@@ -373,6 +374,24 @@ static GstFlowReturn hiptestsrc_fill(GstPushSrc *psrc, GstBuffer *buf)
     GST_BUFFER_DURATION(buf) = dur;
     GST_BUFFER_OFFSET(buf) = self->n++;
     GstMemory *mem = gst_buffer_peek_memory(buf, 0);
+    // MVFX_TESTSRC_RATE=N (measurement aid, memory:HIPMemory): the buffers per second of the whole pipeline between buffer N and the last
+    // one of num-buffers, taken INSIDE the process at two like instants -- a recycled block is back AND everything downstream did on it
+    // has finished (a host wait on its fence) -- so neither process start-up nor the tear-down is in the figure
+    // (tools/bench_gst_pipeline.py had to difference two whole gst-launch runs for that)
+    static const gint64 rate_mark = g_getenv("MVFX_TESTSRC_RATE") ? g_ascii_strtoll(g_getenv("MVFX_TESTSRC_RATE"), NULL, 10) : 0;
+    if (rate_mark > 0 && self->hip && mvfx_buffer_is_hip(buf)) {
+        const guint64 idx = self->n - 1;
+        const gboolean last = GST_BASE_SRC(self)->num_buffers > 0 && idx + 1 == (guint64)GST_BASE_SRC(self)->num_buffers;
+        if (idx == (guint64)rate_mark || (last && self->rate_t0 && idx > (guint64)rate_mark)) {
+            mvfx_hip_memory_wait(mem);
+            const gint64 now = g_get_monotonic_time();
+            if (idx == (guint64)rate_mark)
+                self->rate_t0 = now;
+            else
+                g_printerr("hiptestsrc %s: %.1f buffers/s between buffer %" G_GINT64_FORMAT " and buffer %" G_GUINT64_FORMAT "\n", GST_OBJECT_NAME(self),
+                           (double)(idx - rate_mark) * 1e6 / (double)(now - self->rate_t0), rate_mark, idx);
+        }
+    }
     if (self->hip && self->master && mvfx_buffer_is_hip(buf)) {
         GstMapInfo map;
         if (!gst_buffer_map(buf, &map, (GstMapFlags)(MVFX_MAP_HIP | GST_MAP_WRITE))) return GST_FLOW_ERROR;
@@ -401,6 +420,7 @@ static GstFlowReturn hiptestsrc_fill(GstPushSrc *psrc, GstBuffer *buf)
 static gboolean hiptestsrc_start(GstBaseSrc *src)
 {
     ((GstMi355HipTestSrc *)src)->n = 0;
+    ((GstMi355HipTestSrc *)src)->rate_t0 = 0;
     return TRUE;
 }
 
@@ -459,6 +479,7 @@ static void gst_mi355_hip_test_src_init(GstMi355HipTestSrc *self)
     self->pattern_size = 0;
     self->master = NULL;
     self->n = 0;
+    self->rate_t0 = 0;
     gst_base_src_set_format(GST_BASE_SRC(self), GST_FORMAT_TIME);
 }
 

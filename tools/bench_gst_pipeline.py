@@ -45,6 +45,20 @@ def fps(template, tmp, n1, n2, extra_env=None):
     return (n2 - n1) / (t2 - t1), t1, t2
 
 
+def rate(template, tmp, n1, n2, extra_env=None):
+    """frames/s of ONE gst-launch run of n2 buffers, measured inside the process by hiptestsrc between buffer n1 and the last one
+    (MVFX_TESTSRC_RATE: two instants at which a recycled block is back with all downstream work on it finished)."""
+    import re
+    env = dict(extra_env or {}, MVFX_TESTSRC_RATE=str(n1))
+    r = gst_env.run([LAUNCH, "-q"] + template.format(n=n2).split(), tmp, timeout=900, extra_env=env)
+    if r.returncode != 0:
+        raise RuntimeError(r.stdout[-3000:])
+    m = re.findall(r"hiptestsrc \S+: ([0-9.]+) buffers/s between buffer", r.stdout)
+    if not m:
+        raise RuntimeError("no rate line: " + r.stdout[-1000:])
+    return sum(float(x) for x in m)  # one line per source (branches)
+
+
 def branches_main(args):
     """--branches N: N independent `hiptestsrc ! hsvfilter ! fakesink` streams in ONE process (each its own streaming thread and
     HIP stream, each hsvfilter with its own hue-shift), frames born in HBM.  Launch model of the elements: a launch per buffer
@@ -63,8 +77,13 @@ def branches_main(args):
             # ten times the buffers of the single-chain runs: 16 branches at tens of thousands of frames per second finish 500 buffers each
             # inside the noise of a process start
             mul = 1 if args.quick else 10
-            v, t1, t2 = fps(tpl, tmp, args.n1 * mul, args.n2 * mul, env)
             key = f"refresh_{refresh}_combine_{combine}"
+            if args.quick == 2:  # one run, rate taken inside the process (bench.py's sub-line)
+                run(tpl.format(n=min(args.n1, 2000)), tmp, env)  # page cache, registry
+                out[key + "_fps"] = round(rate(tpl, tmp, args.n1, args.n2, env), 1)
+                out[key + "_frac_of_8TBs"] = round(out[key + "_fps"] * 2 * w * h * 4 / 8e12, 4)
+                continue
+            v, t1, t2 = fps(tpl, tmp, args.n1 * mul, args.n2 * mul, env)
             out[key + "_fps"] = round(v * n, 1)
             out[key + "_frac_of_8TBs"] = round(v * n * 2 * w * h * 4 / 8e12, 4)
             if combine != "0":
@@ -109,7 +128,7 @@ def main():
     ap.add_argument("--element", default="", help="hsvfilter | hsvdetector | colorlut: the single element on device memory, pair launches on / off")
     ap.add_argument("--only", default="", help="comma-separated pipeline names of the chain mode (default: all)")
     ap.add_argument("--branches", type=int, default=0, help="N parallel hiptestsrc ! hsvfilter ! fakesink streams in one process (launch combiner A/B)")
-    ap.add_argument("--quick", type=int, default=0, help="--branches: only refresh=false, no combiner, n1 / n2 taken literally (bench.py's sub-line)")
+    ap.add_argument("--quick", type=int, default=0, help="--branches: only refresh=false, no combiner, n1 / n2 taken literally; 2: ONE run, the rate taken inside the process by hiptestsrc (bench.py's sub-line)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--n1", type=int, default=60)
