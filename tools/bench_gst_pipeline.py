@@ -107,19 +107,21 @@ def element_main(args):
             "hsvdetector": ("RGBx", "hsvdetector hue-ref=120 hue-var=60 saturation-ref=0.6 saturation-var=0.4 value-ref=0.6 value-var=0.4", 8),
             "colorlut": ("RGBA", f"colorlut location={cube}", 8)}[args.element]
     caps = f"video/x-raw(memory:HIPMemory),format={desc[0]},width={w},height={h},framerate=30/1"
-    tpl = f"hiptestsrc num-buffers={{n}} refresh=false ! {caps} ! {desc[1]} ! fakesink sync=false"
     out = {"element": args.element, "frame": f"{w}x{h}", "n1": args.n1, "n2": args.n2}
-    # interleaved repeats: the order of two configurations in one process sequence is worth more than their difference otherwise
-    runs = {"1": [], "0": []}
-    for rep in range(args.repeats):
-        for pair in (("0", "1") if rep % 2 else ("1", "0")):
-            v, t1, t2 = fps(tpl, tmp, args.n1, args.n2, {"MVFX_ELEMENT_PAIR": pair})
-            runs[pair].append(round(v, 1))
-    for pair in ("1", "0"):
-        med = sorted(runs[pair])[len(runs[pair]) // 2]
-        out[f"pair_{pair}_fps_runs"] = runs[pair]
-        out[f"pair_{pair}_fps"] = med
-        out[f"pair_{pair}_frac_of_8TBs"] = round(med * desc[2] * w * h / 8e12, 4)
+    # one run per figure, the rate taken inside the process (rate()); interleaved repeats, the median is reported
+    for refresh in ("false", "true"):
+        tpl = f"hiptestsrc num-buffers={{n}} refresh={refresh} ! {caps} ! {desc[1]} ! fakesink sync=false"
+        run(tpl.format(n=2000), tmp)  # page cache, registry
+        runs = {"1": [], "0": []}
+        for rep in range(args.repeats):
+            for pair in (("0", "1") if rep % 2 else ("1", "0")):
+                runs[pair].append(round(rate(tpl, tmp, args.n1, args.n2, {"MVFX_ELEMENT_PAIR": pair}), 1))
+        for pair in ("1", "0"):
+            med = sorted(runs[pair])[len(runs[pair]) // 2]
+            key = f"refresh_{refresh}_pair_{pair}"
+            out[key + "_fps_runs"] = runs[pair]
+            out[key + "_fps"] = med
+            out[key + "_frac_of_8TBs"] = round(med * desc[2] * w * h / 8e12, 4)
     print(json.dumps(out), flush=True)
 
 
