@@ -27,6 +27,12 @@ typedef struct {
     MvfxDeferredFlush deferred_flush;
     GstObject *deferred_owner; // referenced while set
     const void *fence_owner;   // who recorded the pending fence (compared only, never dereferenced): mvfx_hip_memory_busy
+    // which record the pending fence is and on which stream it was made; which record the last acquire saw, on which stream: a stream
+    // does not wait for its own earlier work, and a release that finds the fence its acquire already waited for does not wait again.
+    // (Three HIP calls per block and buffer -- wait, wait, record -- were most of the 14 us of host time a streaming thread spent per
+    // buffer in an out-of-place element: profiles/r4/element_pairs.txt)
+    guint64 fence_seq, acq_seq;
+    mvfx_stream fence_stream, acq_stream;
 } MvfxHipMemory;
 
 typedef struct { GstAllocator parent; } MvfxHipAllocator;
@@ -135,6 +141,7 @@ static GstMemory *mvfx_hip_alloc(GstAllocator *allocator, gsize size, GstAllocat
     m->device = device;
     m->last_use = ev;
     m->pending = pending;
+    m->fence_stream = m->acq_stream = (mvfx_stream)(gintptr)-1; // a fence that came with a recycled block: made on no stream anybody has
     g_mutex_init(&m->lock);
     return GST_MEMORY_CAST(m);
 }
@@ -229,8 +236,10 @@ void mvfx_hip_memory_acquire_as_owner(GstMemory *mem, mvfx_stream stream, GstObj
     g_mutex_lock(&m->lock);
     if (m->borrowed)
         mvfx_stream_wait_event(stream, m->borrowed);
-    if (m->pending && m->last_use)
-        mvfx_stream_wait_event(stream, m->last_use); // device-side wait; the host goes on
+    if (m->pending && m->last_use && m->fence_stream != stream)
+        mvfx_stream_wait_event(stream, m->last_use); // device-side wait; the host goes on (same stream: in order anyway)
+    m->acq_seq = m->fence_seq;
+    m->acq_stream = stream;
     g_mutex_unlock(&m->lock);
 }
 
@@ -288,7 +297,7 @@ void mvfx_hip_memory_release_as_owner(GstMemory *mem, mvfx_stream stream, GstObj
         m->last_use = NULL;
     // chain onto the fence another user may have left since our acquire (a second reader behind a tee): this stream waits
     // for it on the device, so the record below covers that user too; a no-op when the pending record is this stream's own
-    if (m->last_use && m->pending)
+    if (m->last_use && m->pending && m->fence_stream != stream && !(m->acq_seq == m->fence_seq && m->acq_stream == stream))
         mvfx_stream_wait_event(stream, m->last_use);
     if (m->borrowed) { // same chaining for a fence somebody else recorded; the own record below then covers it
         mvfx_stream_wait_event(stream, m->borrowed);
@@ -298,6 +307,8 @@ void mvfx_hip_memory_release_as_owner(GstMemory *mem, mvfx_stream stream, GstObj
         m->pending = TRUE;
     else
         mvfx_stream_synchronize(stream); // no event: fall back to a blocking hand-off
+    m->fence_seq++;
+    m->fence_stream = stream;
     m->fence_owner = owner;
     if (owner && m->deferred_flush && m->deferred_owner == owner) {
         drop = m->deferred_owner;
