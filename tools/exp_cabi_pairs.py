@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""tools/exp_cabi_pairs.py -- one host thread, two alternating streams, 4K frames through the bare C ABI: hsvfilter, hsvdetector and colorlut with
+one and with two frames per launch -- what the elements are measured against (profiles/r4/element_pairs.txt section 8)."""
 import ctypes, os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch, _pkg
