@@ -156,8 +156,7 @@ static GstFlowReturn gst_color_lut_bt_transform(GstBaseTransform *bt, GstBuffer 
         mvfx_hip_buffer_acquire(inbuf, st);
         mvfx_hip_buffer_acquire(outbuf, st);
         int rc = mvfx_colorlut_transform_i420(self->lut, &pi, &po, 0, st);
-        mvfx_hip_buffer_release(inbuf, st);
-        mvfx_hip_buffer_release(outbuf, st);
+        mvfx_hip_buffers_release(inbuf, outbuf, st); // one fence for both (the reader's too: the input block may be recycled and overwritten next)
         gst_buffer_unmap(outbuf, &omap);
         gst_buffer_unmap(inbuf, &imap);
         return MVFX_GST_FLOW(self, rc);
@@ -180,15 +179,14 @@ static GstFlowReturn gst_color_lut_bt_transform(GstBaseTransform *bt, GstBuffer 
         mvfx_hip_buffer_acquire(inbuf, st);
         mvfx_hip_buffer_acquire(outbuf, st);
         const int drc = mvfx_colorlut_transform_frame(self->lut, &fi, &fo, st);
-        mvfx_hip_memory_release_tagged(gst_buffer_peek_memory(inbuf, 0), st, GST_OBJECT(self));
-        mvfx_hip_memory_release_tagged(gst_buffer_peek_memory(outbuf, 0), st, GST_OBJECT(self));
+        GstMemory *const both[2] = {gst_buffer_peek_memory(inbuf, 0), gst_buffer_peek_memory(outbuf, 0)};
+        mvfx_hip_memories_release_tagged(both, 2, st, GST_OBJECT(self));
         return MVFX_GST_FLOW(self, drc);
     }
     mvfx_hip_buffer_acquire(inbuf, st);
     mvfx_hip_buffer_acquire(outbuf, st);
     int rc = mvfx_colorlut_transform_frame(self->lut, &fi, &fo, st);
-    mvfx_hip_buffer_release(inbuf, st);
-    mvfx_hip_buffer_release(outbuf, st);
+    mvfx_hip_buffers_release(inbuf, outbuf, st); // one fence for both (the reader's too: the input block may be recycled and overwritten next)
     gst_buffer_unmap(outbuf, &omap);
     gst_buffer_unmap(inbuf, &imap);
     return MVFX_GST_FLOW(self, rc);

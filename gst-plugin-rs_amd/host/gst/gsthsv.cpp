@@ -237,8 +237,8 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
         mvfx_hip_memory_acquire_as_owner(first, st, GST_OBJECT(self)); // (the mark stays until the fence is recorded: see the flush)
         mvfx_hip_memory_acquire_as_owner(mem, st, GST_OBJECT(self));
         rc = mvfx_hsvfilter_transform_frames_ip_settings(frames, 2, settings, st);
-        mvfx_hip_memory_release_as_owner(first, st, GST_OBJECT(self));
-        mvfx_hip_memory_release_as_owner(mem, st, GST_OBJECT(self));
+        GstMemory *const both[2] = {first, mem};
+        mvfx_hip_memories_release_as_owner(both, 2, st, GST_OBJECT(self)); // one fence for the pair
         self->n_pairs++;
         self->foreign_streak = 0;
         later.add(first);
@@ -494,15 +494,14 @@ static GstFlowReturn gst_hsv_detector_bt_transform(GstBaseTransform *bt, GstBuff
         mvfx_hip_buffer_acquire(inbuf, st);
         mvfx_hip_buffer_acquire(outbuf, st);
         const int drc = mvfx_hsvdetector_transform_frame(&fi, &fo, &s, st);
-        mvfx_hip_memory_release_tagged(gst_buffer_peek_memory(inbuf, 0), st, GST_OBJECT(self));
-        mvfx_hip_memory_release_tagged(gst_buffer_peek_memory(outbuf, 0), st, GST_OBJECT(self));
+        GstMemory *const both[2] = {gst_buffer_peek_memory(inbuf, 0), gst_buffer_peek_memory(outbuf, 0)};
+        mvfx_hip_memories_release_tagged(both, 2, st, GST_OBJECT(self));
         return MVFX_GST_FLOW(self, drc);
     }
     mvfx_hip_buffer_acquire(inbuf, st);
     mvfx_hip_buffer_acquire(outbuf, st);
     int rc = i420 ? mvfx_hsvdetector_transform_i420(&pi, &fo, &s, 0, st) : mvfx_hsvdetector_transform_frame(&fi, &fo, &s, st);
-    mvfx_hip_buffer_release(inbuf, st);  // the reader's fence too: the block may be recycled and overwritten next
-    mvfx_hip_buffer_release(outbuf, st);
+    mvfx_hip_buffers_release(inbuf, outbuf, st); // one fence for both (the reader's too: the input block may be recycled and overwritten next)
     gst_buffer_unmap(outbuf, &omap);
     gst_buffer_unmap(inbuf, &imap);
     return MVFX_GST_FLOW(self, rc);

@@ -447,8 +447,7 @@ static GstFlowReturn gst_rounded_corners_prepare_output_buffer(GstBaseTransform 
         mvfx_hip_buffer_acquire(inbuf, st);
         mvfx_hip_buffer_acquire(out, st);
         int rc = mvfx_roundedcorners_compose_a420(&pi, amap.data, (uint32_t)GST_VIDEO_INFO_PLANE_STRIDE(&self->out_info, 3), &po, st);
-        mvfx_hip_buffer_release(inbuf, st);
-        mvfx_hip_buffer_release(out, st);
+        mvfx_hip_buffers_release(inbuf, out, st); // one fence for both (the reader's too: the input block may be recycled and overwritten next)
         gst_memory_unmap(self->alpha_mem, &amap);
         gst_buffer_unmap(out, &omap);
         gst_buffer_unmap(inbuf, &imap);

@@ -66,8 +66,8 @@ static inline void mvfx_pair_flush_locked(MvfxPairHold *h, GstObject *element, M
     mvfx_hip_memory_acquire_as_owner(in, h->st, element);
     mvfx_hip_memory_acquire_as_owner(out, h->st, element);
     const int rc = launch(element, &h->fi, &h->fo, 1, h->st);
-    mvfx_hip_memory_release_as_owner(in, h->st, element);
-    mvfx_hip_memory_release_as_owner(out, h->st, element);
+    GstMemory *const both[2] = {in, out};
+    mvfx_hip_memories_release_as_owner(both, 2, h->st, element); // one fence for the launch, not one per block
     later->add(in);
     later->add(out);
     h->n_singles++;
@@ -150,10 +150,8 @@ static inline int mvfx_pair_submit(MvfxPairHold *h, GstObject *element, MvfxPair
     mvfx_hip_memory_acquire_as_owner(in, pst, element);
     mvfx_hip_memory_acquire_as_owner(out, pst, element);
     const int rc = launch(element, ins, outs, 2, pst);
-    mvfx_hip_memory_release_as_owner(first_in, pst, element);
-    mvfx_hip_memory_release_as_owner(first_out, pst, element);
-    mvfx_hip_memory_release_as_owner(in, pst, element);
-    mvfx_hip_memory_release_as_owner(out, pst, element);
+    GstMemory *const all[4] = {first_in, first_out, in, out};
+    mvfx_hip_memories_release_as_owner(all, 4, pst, element); // ONE fence for the four blocks: an event record costs the device a bubble
     h->n_pairs++;
     h->foreign_streak = 0;
     later.add(first_in);

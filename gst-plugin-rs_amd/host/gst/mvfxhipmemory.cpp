@@ -5,6 +5,54 @@
 
 #include <string.h>
 
+#include <initializer_list>
+
+// A fence = ONE recorded event, shared by every block the launch behind it touched (an out-of-place pair launch touches four).  An
+// event record is not free on the device -- a barrier packet with a completion signal between two kernels of the stream: the
+// hsvdetector element with one event per block ran at 71 k fps, with two records per pair launch instead of four at 89 k, with one at
+// 95 k (profiles/r4/element_pairs.txt) -- so blocks released together share one.  Fences are reference-counted and pooled: an event is
+// re-recorded only when no block points at it any more (a stream that already waits for it captured the earlier record).
+typedef struct { gint refs; mvfx_event ev; } MvfxFence;
+#define MVFX_FENCE_POOL_MAX 256
+static GMutex fence_pool_lock;
+static MvfxFence *fence_pool[MVFX_FENCE_POOL_MAX];
+static int fence_pool_n;
+
+static MvfxFence *fence_get(void) // one reference, event not recorded yet; NULL when no event can be created
+{
+    MvfxFence *f = NULL;
+    g_mutex_lock(&fence_pool_lock);
+    if (fence_pool_n > 0) f = fence_pool[--fence_pool_n];
+    g_mutex_unlock(&fence_pool_lock);
+    if (!f) {
+        mvfx_event ev = NULL;
+        if (mvfx_event_create(&ev) != MVFX_OK || !ev) return NULL;
+        f = g_new0(MvfxFence, 1);
+        f->ev = ev;
+    }
+    f->refs = 1;
+    return f;
+}
+
+static MvfxFence *fence_ref(MvfxFence *f)
+{
+    if (f) g_atomic_int_inc(&f->refs);
+    return f;
+}
+
+static void fence_unref(MvfxFence *f)
+{
+    if (!f || !g_atomic_int_dec_and_test(&f->refs)) return;
+    g_mutex_lock(&fence_pool_lock);
+    const gboolean kept = fence_pool_n < MVFX_FENCE_POOL_MAX;
+    if (kept) fence_pool[fence_pool_n++] = f;
+    g_mutex_unlock(&fence_pool_lock);
+    if (!kept) {
+        mvfx_event_destroy(f->ev);
+        g_free(f);
+    }
+}
+
 typedef struct {
     GstMemory mem;
     void *dptr;       // hipMalloc'ed
@@ -18,7 +66,7 @@ typedef struct {
     // Releases CHAIN: a stream that records while another stream's record is still pending first waits for that one (device
     // side), so that the single event always covers every user so far -- two readers of one buffer behind a `tee` on two
     // streaming threads must both have finished before a recycled block is written again.
-    mvfx_event last_use;
+    MvfxFence *fence;   // referenced; NULL: nothing was ever recorded on the block
     gboolean pending;
     // a fence recorded by somebody else on a stream of theirs (the launch combiner's batch event): not owned, never re-recorded
     // here; while set it is what the next user waits for, and the next release chains onto it like onto a pending own record
@@ -45,21 +93,21 @@ G_DEFINE_TYPE(MvfxHipAllocator, mvfx_hip_allocator, GST_TYPE_ALLOCATOR)
 // fence: work still in flight on it when the buffer was dropped orders before the next owner's first kernel.
 #define MVFX_FREELIST_MAX 16
 static GMutex freelist_lock;
-static struct { void *dptr; gsize size; int device; mvfx_event last_use; gboolean pending; } freelist[MVFX_FREELIST_MAX];
+static struct { void *dptr; gsize size; int device; MvfxFence *fence; gboolean pending; } freelist[MVFX_FREELIST_MAX];
 
 static int current_device(void)
 {
     return mvfx_current_device();
 }
 
-static gboolean freelist_take(gsize size, int device, void **dptr, mvfx_event *ev, gboolean *pending)
+static gboolean freelist_take(gsize size, int device, void **dptr, MvfxFence **ev, gboolean *pending)
 {
     gboolean found = FALSE;
     g_mutex_lock(&freelist_lock);
     for (int i = 0; i < MVFX_FREELIST_MAX && !found; i++)
         if (freelist[i].dptr && freelist[i].size == size && freelist[i].device == device) {
             *dptr = freelist[i].dptr;
-            *ev = freelist[i].last_use;
+            *ev = freelist[i].fence;
             *pending = freelist[i].pending;
             freelist[i].dptr = NULL;
             found = TRUE;
@@ -68,20 +116,20 @@ static gboolean freelist_take(gsize size, int device, void **dptr, mvfx_event *e
     return found;
 }
 
-static void release_block(void *dptr, mvfx_event ev, gboolean pending)
+static void release_block(void *dptr, MvfxFence *fence, gboolean pending)
 {
-    if (pending && ev) mvfx_event_synchronize(ev);
+    if (pending && fence) mvfx_event_synchronize(fence->ev);
     mvfx_device_free(dptr);
-    if (ev) mvfx_event_destroy(ev);
+    fence_unref(fence);
 }
 
 // Always keeps the block: when the list is full the OLDEST entry is evicted and freed (sizes of a previous negotiation would
 // otherwise occupy the slots for the rest of the process and send every later free down the device-synchronising hipFree path).
-static void freelist_give(void *dptr, gsize size, int device, mvfx_event ev, gboolean pending)
+static void freelist_give(void *dptr, gsize size, int device, MvfxFence *ev, gboolean pending)
 {
     static guint next_victim = 0;
     void *old_dptr = NULL;
-    mvfx_event old_ev = NULL;
+    MvfxFence *old_ev = NULL;
     gboolean old_pending = FALSE;
     g_mutex_lock(&freelist_lock);
     int slot = -1;
@@ -89,10 +137,10 @@ static void freelist_give(void *dptr, gsize size, int device, mvfx_event ev, gbo
         if (!freelist[i].dptr) slot = i;
     if (slot < 0) {
         slot = (int)(next_victim++ % MVFX_FREELIST_MAX);
-        old_dptr = freelist[slot].dptr; old_ev = freelist[slot].last_use; old_pending = freelist[slot].pending;
+        old_dptr = freelist[slot].dptr; old_ev = freelist[slot].fence; old_pending = freelist[slot].pending;
     }
     freelist[slot].dptr = dptr; freelist[slot].size = size; freelist[slot].device = device;
-    freelist[slot].last_use = ev; freelist[slot].pending = pending;
+    freelist[slot].fence = ev; freelist[slot].pending = pending;
     g_mutex_unlock(&freelist_lock);
     if (old_dptr) release_block(old_dptr, old_ev, old_pending);
 }
@@ -102,13 +150,13 @@ static void freelist_give(void *dptr, gsize size, int device, mvfx_event ev, gbo
 // another pipeline's alloc / free must not queue behind that on freelist_lock).
 static void freelist_trim(gsize size)
 {
-    struct { void *dptr; mvfx_event ev; gboolean pending; } victims[MVFX_FREELIST_MAX];
+    struct { void *dptr; MvfxFence *ev; gboolean pending; } victims[MVFX_FREELIST_MAX];
     int n = 0;
     const int device = current_device();
     g_mutex_lock(&freelist_lock);
     for (int i = 0; i < MVFX_FREELIST_MAX; i++)
         if (freelist[i].dptr && (size == 0 || (freelist[i].size == size && freelist[i].device == device))) {
-            victims[n].dptr = freelist[i].dptr; victims[n].ev = freelist[i].last_use; victims[n].pending = freelist[i].pending;
+            victims[n].dptr = freelist[i].dptr; victims[n].ev = freelist[i].fence; victims[n].pending = freelist[i].pending;
             n++;
             freelist[i].dptr = NULL;
         }
@@ -124,7 +172,7 @@ void mvfx_hip_allocator_trim(void)
 static GstMemory *mvfx_hip_alloc(GstAllocator *allocator, gsize size, GstAllocationParams *params)
 {
     void *dptr = NULL;
-    mvfx_event ev = NULL;
+    MvfxFence *ev = NULL;
     gboolean pending = FALSE;
     const int device = current_device();
     if (!freelist_take(size, device, &dptr, &ev, &pending)) {
@@ -139,7 +187,7 @@ static GstMemory *mvfx_hip_alloc(GstAllocator *allocator, gsize size, GstAllocat
     gst_memory_init(GST_MEMORY_CAST(m), GST_MEMORY_FLAG_NO_SHARE, allocator, NULL, size, 255, 0, size);
     m->dptr = dptr;
     m->device = device;
-    m->last_use = ev;
+    m->fence = ev;
     m->pending = pending;
     m->fence_stream = m->acq_stream = (mvfx_stream)(gintptr)-1; // a fence that came with a recycled block: made on no stream anybody has
     g_mutex_init(&m->lock);
@@ -158,7 +206,7 @@ static void mvfx_hip_free(GstAllocator *, GstMemory *mem)
         mvfx_event_synchronize(m->borrowed);
         m->borrowed = NULL;
     }
-    freelist_give(m->dptr, mem->maxsize, m->device, m->last_use, m->pending);
+    freelist_give(m->dptr, mem->maxsize, m->device, m->fence, m->pending);
     g_free(m->shadow);
     g_mutex_clear(&m->lock);
     g_free(m);
@@ -236,8 +284,8 @@ void mvfx_hip_memory_acquire_as_owner(GstMemory *mem, mvfx_stream stream, GstObj
     g_mutex_lock(&m->lock);
     if (m->borrowed)
         mvfx_stream_wait_event(stream, m->borrowed);
-    if (m->pending && m->last_use && m->fence_stream != stream)
-        mvfx_stream_wait_event(stream, m->last_use); // device-side wait; the host goes on (same stream: in order anyway)
+    if (m->pending && m->fence && m->fence_stream != stream)
+        mvfx_stream_wait_event(stream, m->fence->ev); // device-side wait; the host goes on (same stream: in order anyway)
     m->acq_seq = m->fence_seq;
     m->acq_stream = stream;
     g_mutex_unlock(&m->lock);
@@ -255,7 +303,7 @@ gboolean mvfx_hip_memory_busy(GstMemory *mem, GstObject *owner)
     gboolean busy = m->deferred_flush != NULL && m->deferred_owner != owner;
     if (!busy && m->borrowed) busy = mvfx_event_query(m->borrowed) != 1;
     // (the asking element's OWN last kernel on a recycled block does not count: that is the launch rate it is trying to raise)
-    if (!busy && m->pending && m->last_use && m->fence_owner != (const void *)owner) busy = mvfx_event_query(m->last_use) != 1;
+    if (!busy && m->pending && m->fence && m->fence_owner != (const void *)owner) busy = mvfx_event_query(m->fence->ev) != 1;
     g_mutex_unlock(&m->lock);
     return busy;
 }
@@ -267,7 +315,7 @@ void *mvfx_hip_memory_pending_fence(GstMemory *mem)
     run_deferred(m);
     g_mutex_lock(&m->lock);
     // the borrowed fence is always younger than the own record it was set behind (the combiner's launch waited for that one)
-    void *ev = m->borrowed ? m->borrowed : (m->pending ? m->last_use : NULL);
+    void *ev = m->borrowed ? m->borrowed : (m->pending && m->fence ? m->fence->ev : NULL);
     g_mutex_unlock(&m->lock);
     return ev;
 }
@@ -281,54 +329,107 @@ void mvfx_hip_memory_set_borrowed_fence(GstMemory *mem, void *event)
     g_mutex_unlock(&m->lock);
 }
 
+// ---- release: the stream's work on one or several blocks gets ONE fence ---------------------------------------------------------
+//
+// Phase A, per block under its lock: chain onto what other users left since our acquire (a second reader behind a tee; a borrowed
+// fence): the stream waits for it on the device, so the record covers them too.  Then the one record.  Phase B, per block under its
+// lock again: the block points at the fence, its held-back mark (if it is `owner`'s) goes away in the same critical section -- a
+// consumer on another thread either still sees the mark (its flush then waits for the owner's lock and finds the work launched) or
+// already sees the fence, never neither.  Somebody who recorded on a block between the two phases (the tee sibling again) is chained
+// onto there, and that block gets a fence of its own.
+static void release_group(GstMemory *const *mems, guint n, mvfx_stream stream, GstObject *owner, const void *tag)
+{
+    enum { kMax = 8 };
+    MvfxHipMemory *ms[kMax];
+    guint64 seen[kMax];
+    guint k = 0;
+    for (guint i = 0; i < n && k < kMax; i++)
+        if (mvfx_is_hip_memory(mems[i])) ms[k++] = (MvfxHipMemory *)mems[i];
+    if (k == 0) return;
+    for (guint i = 0; i < k; i++) {
+        MvfxHipMemory *m = ms[i];
+        g_mutex_lock(&m->lock);
+        if (m->fence && m->pending && m->fence_stream != stream && !(m->acq_seq == m->fence_seq && m->acq_stream == stream))
+            mvfx_stream_wait_event(stream, m->fence->ev);
+        if (m->borrowed) { // same chaining for a fence somebody else recorded; the record below then covers it
+            mvfx_stream_wait_event(stream, m->borrowed);
+            m->borrowed = NULL;
+        }
+        seen[i] = m->fence_seq;
+        g_mutex_unlock(&m->lock);
+    }
+    MvfxFence *f = fence_get();
+    if (f && mvfx_event_record(f->ev, stream) != MVFX_OK) {
+        fence_unref(f);
+        f = NULL;
+    }
+    if (!f) mvfx_stream_synchronize(stream); // no event: fall back to a blocking hand-off
+    for (guint i = 0; i < k; i++) {
+        MvfxHipMemory *m = ms[i];
+        MvfxFence *old = NULL, *mine = f ? fence_ref(f) : NULL;
+        GstObject *drop = NULL;
+        g_mutex_lock(&m->lock);
+        if (m->fence_seq != seen[i] && m->fence && m->pending) {
+            // recorded on in between: wait for that too, and a later fence of this block's own covers both
+            mvfx_stream_wait_event(stream, m->fence->ev);
+            fence_unref(mine);
+            mine = fence_get();
+            if (mine && mvfx_event_record(mine->ev, stream) != MVFX_OK) {
+                fence_unref(mine);
+                mine = NULL;
+            }
+            if (!mine) mvfx_stream_synchronize(stream);
+        }
+        old = m->fence;
+        m->fence = mine;
+        m->pending = mine != NULL;
+        m->fence_seq++;
+        m->fence_stream = stream;
+        m->fence_owner = tag;
+        if (owner && m->deferred_flush && m->deferred_owner == owner) {
+            drop = m->deferred_owner;
+            m->deferred_flush = NULL;
+            m->deferred_owner = NULL;
+        }
+        g_mutex_unlock(&m->lock);
+        fence_unref(old);
+        if (drop) gst_object_unref(drop);
+    }
+    fence_unref(f);
+}
+
 void mvfx_hip_memory_release(GstMemory *mem, mvfx_stream stream) { mvfx_hip_memory_release_as_owner(mem, stream, NULL); }
 
-// `owner` != NULL: the owner of the block's held-back work has just enqueued it on `stream`: the fence is recorded and the mark
-// goes away in ONE critical section of the block -- a consumer on another thread either still sees the mark (its flush then waits
-// for the owner's lock and finds the work launched) or already sees the fence, never neither.
+// `owner` != NULL: the owner of the block's held-back work has just enqueued it on `stream` (no callback runs: see
+// mvfx_hip_memory_acquire_as_owner); NULL: a plain user -- somebody's held-back work on the block still comes first.
 void mvfx_hip_memory_release_as_owner(GstMemory *mem, mvfx_stream stream, GstObject *owner)
 {
     if (!mvfx_is_hip_memory(mem)) return;
-    MvfxHipMemory *m = (MvfxHipMemory *)mem;
-    if (!owner) run_deferred(m); // (a user that released without acquiring: the held-back work still comes first)
-    GstObject *drop = NULL;
-    g_mutex_lock(&m->lock);
-    if (!m->last_use && mvfx_event_create(&m->last_use) != MVFX_OK)
-        m->last_use = NULL;
-    // chain onto the fence another user may have left since our acquire (a second reader behind a tee): this stream waits
-    // for it on the device, so the record below covers that user too; a no-op when the pending record is this stream's own
-    if (m->last_use && m->pending && m->fence_stream != stream && !(m->acq_seq == m->fence_seq && m->acq_stream == stream))
-        mvfx_stream_wait_event(stream, m->last_use);
-    if (m->borrowed) { // same chaining for a fence somebody else recorded; the own record below then covers it
-        mvfx_stream_wait_event(stream, m->borrowed);
-        m->borrowed = NULL;
-    }
-    if (m->last_use && mvfx_event_record(m->last_use, stream) == MVFX_OK)
-        m->pending = TRUE;
-    else
-        mvfx_stream_synchronize(stream); // no event: fall back to a blocking hand-off
-    m->fence_seq++;
-    m->fence_stream = stream;
-    m->fence_owner = owner;
-    if (owner && m->deferred_flush && m->deferred_owner == owner) {
-        drop = m->deferred_owner;
-        m->deferred_flush = NULL;
-        m->deferred_owner = NULL;
-    }
-    g_mutex_unlock(&m->lock);
-    if (drop) gst_object_unref(drop);
+    if (!owner) run_deferred((MvfxHipMemory *)mem);
+    release_group(&mem, 1, stream, owner, owner);
 }
 
-// mvfx_hip_memory_release() that also says who recorded the fence (an element's plain launch per buffer: mvfx_hip_memory_busy must not
-// take the element's own previous kernel on a recycled block for somebody else's work)
+// Several blocks one launch touched (the two frames of a pair launch, input and output of an out-of-place element): one fence.
+void mvfx_hip_memories_release_as_owner(GstMemory *const *mems, guint n, mvfx_stream stream, GstObject *owner)
+{
+    if (!owner)
+        for (guint i = 0; i < n; i++)
+            if (mvfx_is_hip_memory(mems[i])) run_deferred((MvfxHipMemory *)mems[i]);
+    release_group(mems, n, stream, owner, owner);
+}
+
+// Plain releases that also say who recorded the fence (an element's launch per buffer: mvfx_hip_memory_busy must not take the element's
+// own previous kernel on a recycled block for somebody else's work)
 void mvfx_hip_memory_release_tagged(GstMemory *mem, mvfx_stream stream, GstObject *tag)
 {
-    if (!mvfx_is_hip_memory(mem)) return;
-    mvfx_hip_memory_release_as_owner(mem, stream, NULL);
-    MvfxHipMemory *m = (MvfxHipMemory *)mem;
-    g_mutex_lock(&m->lock);
-    m->fence_owner = tag;
-    g_mutex_unlock(&m->lock);
+    mvfx_hip_memories_release_tagged(&mem, 1, stream, tag);
+}
+
+void mvfx_hip_memories_release_tagged(GstMemory *const *mems, guint n, mvfx_stream stream, GstObject *tag)
+{
+    for (guint i = 0; i < n; i++)
+        if (mvfx_is_hip_memory(mems[i])) run_deferred((MvfxHipMemory *)mems[i]);
+    release_group(mems, n, stream, NULL, tag);
 }
 
 void mvfx_hip_memory_wait(GstMemory *mem)
@@ -341,8 +442,8 @@ void mvfx_hip_memory_wait(GstMemory *mem)
         mvfx_event_synchronize(m->borrowed);
         m->borrowed = NULL;
     }
-    if (m->pending && m->last_use) {
-        mvfx_event_synchronize(m->last_use);
+    if (m->pending && m->fence) {
+        mvfx_event_synchronize(m->fence->ev);
         m->pending = FALSE;
     }
     g_mutex_unlock(&m->lock);
@@ -354,10 +455,22 @@ void mvfx_hip_buffer_acquire(GstBuffer *buf, mvfx_stream stream)
         mvfx_hip_memory_acquire(gst_buffer_peek_memory(buf, i), stream);
 }
 
-void mvfx_hip_buffer_release(GstBuffer *buf, mvfx_stream stream)
+void mvfx_hip_buffer_release(GstBuffer *buf, mvfx_stream stream) { mvfx_hip_buffers_release(buf, NULL, stream); }
+
+// input and output buffer of one launch: one fence for all their blocks
+void mvfx_hip_buffers_release(GstBuffer *a, GstBuffer *b, mvfx_stream stream)
 {
-    for (guint i = 0; buf && i < gst_buffer_n_memory(buf); i++)
-        mvfx_hip_memory_release(gst_buffer_peek_memory(buf, i), stream);
+    GstMemory *mems[8];
+    guint n = 0;
+    for (GstBuffer *buf : {a, b})
+        for (guint i = 0; buf && i < gst_buffer_n_memory(buf); i++) {
+            if (n == 8) { // (never with video buffers: flush what there is and go on)
+                mvfx_hip_memories_release_as_owner(mems, n, stream, NULL);
+                n = 0;
+            }
+            mems[n++] = gst_buffer_peek_memory(buf, i);
+        }
+    if (n) mvfx_hip_memories_release_as_owner(mems, n, stream, NULL);
 }
 
 static gpointer mvfx_hip_map_full(GstMemory *mem, GstMapInfo *info, gsize maxsize)

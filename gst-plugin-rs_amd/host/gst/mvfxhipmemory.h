@@ -44,6 +44,9 @@ void mvfx_hip_memory_clear_deferred(GstMemory *mem, GstObject *owner); // no-op 
 void mvfx_hip_memory_flush_foreign(GstMemory *mem, GstObject *owner);
 gboolean mvfx_hip_memory_busy(GstMemory *mem, GstObject *owner);
 void mvfx_hip_memory_release_tagged(GstMemory *mem, void *stream, GstObject *tag);
+void mvfx_hip_buffers_release(GstBuffer *a, GstBuffer *b, void *stream);
+void mvfx_hip_memories_release_tagged(GstMemory *const *mems, guint n, void *stream, GstObject *tag);
+void mvfx_hip_memories_release_as_owner(GstMemory *const *mems, guint n, void *stream, GstObject *owner);
 void mvfx_hip_memory_acquire_as_owner(GstMemory *mem, void *stream, GstObject *owner);
 void mvfx_hip_memory_release_as_owner(GstMemory *mem, void *stream, GstObject *owner);
 void *mvfx_hip_memory_pending_fence(GstMemory *mem);

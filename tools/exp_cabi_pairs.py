@@ -34,3 +34,26 @@ run("hsvdetector", lambda i, s: vfx.check(lib.mvfx_hsvdetector_transform_frame(a
     lambda i, s: vfx.check(lib.mvfx_hsvdetector_transform_frames(at(fa, i), at(fb, i), 2, ctypes.byref(ds), s)))
 run("colorlut", lambda i, s: vfx.check(lib.mvfx_colorlut_transform_frame(lut.h, at(fr, i), at(fb, i), s)),
     lambda i, s: vfx.check(lib.mvfx_colorlut_transform_frames(lut.h, at(fr, i), at(fb, i), 2, s)))
+
+# what do the fences of the element layer cost on the device?  the pair launches of hsvdetector again, with k event records (and as many
+# stream waits on events of the OTHER stream's previous launch) after every launch: the element does four records per pair launch
+evs = [[ctypes.c_void_p() for _ in range(4)] for _ in range(2)]
+for row in evs:
+    for e in row:
+        vfx.check(lib.mvfx_event_create(ctypes.byref(e)))
+        vfx.check(lib.mvfx_event_record(e, st[0]))
+for k_rec, k_wait in ((0, 0), (1, 0), (2, 0), (4, 0), (4, 4), (1, 1)):
+    def fn(k):
+        s, o = st[k & 1], (k & 1) ^ 1
+        for j in range(k_wait):
+            vfx.check(lib.mvfx_stream_wait_event(s, evs[o][j]))
+        vfx.check(lib.mvfx_hsvdetector_transform_frames(at(fa, (2 * k) % N), at(fb, (2 * k) % N), 2, ctypes.byref(ds), s))
+        for j in range(k_rec):
+            vfx.check(lib.mvfx_event_record(evs[k & 1][j], s))
+    res = []
+    for rep in range(3):
+        for k in range(200): fn(k)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for k in range(4000): fn(k)
+        torch.cuda.synchronize(); res.append(8000 / (time.perf_counter() - t0))
+    print(f"hsvdetector 2 frames/launch + {k_rec} event records + {k_wait} waits on the other stream's events per launch: {sorted(res)[1]:8.0f} frames/s", flush=True)
