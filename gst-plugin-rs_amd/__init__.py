@@ -135,6 +135,8 @@ SIGNATURES = {
     "mvfx_stream_wait_event": (c_int, [c_void_p, c_void_p]),
     "mvfx_event_synchronize": (c_int, [c_void_p]),
     "mvfx_event_query": (c_int, [c_void_p]),
+    "mvfx_thread_set_completion_event": (c_int, [c_void_p]),
+    "mvfx_thread_clear_completion_event": (c_int, []),
     "mvfx_host_alloc": (c_int, [POINTER(c_void_p), c_size_t]),
     "mvfx_host_free": (c_int, [c_void_p]),
     "mvfx_copy_to_device_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -13,6 +13,8 @@ namespace mvfx {
 namespace {
 thread_local char t_last_error[512] = "";
 thread_local uint32_t t_options = 0; // mvfx_thread_set_options
+thread_local hipEvent_t t_completion = nullptr; // mvfx_thread_set_completion_event
+thread_local uint32_t t_completion_uses = 0;
 
 struct Scratch {
     void *ptr = nullptr;
@@ -142,6 +144,9 @@ int fail(int status, const char *fmt, ...)
 }
 
 uint32_t thread_options() { return t_options; }
+
+hipEvent_t completion_event() { return t_completion; }
+void note_completion_event_used() { t_completion_uses++; }
 
 int require_device()
 {
@@ -434,6 +439,21 @@ int mvfx_event_synchronize(mvfx_event event)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "event_synchronize: NULL event");
     MVFX_HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)));
     return MVFX_OK;
+}
+
+int mvfx_thread_set_completion_event(mvfx_event event)
+{
+    t_completion = reinterpret_cast<hipEvent_t>(event);
+    t_completion_uses = 0;
+    return MVFX_OK;
+}
+
+int mvfx_thread_clear_completion_event(void)
+{
+    const uint32_t uses = t_completion_uses;
+    t_completion = nullptr;
+    t_completion_uses = 0;
+    return (int)uses;
 }
 
 int mvfx_event_query(mvfx_event event)

@@ -1443,7 +1443,7 @@ int ensure_uploaded(mvfx_cube_lut *h)
                 if (l.size >= 4) { // the x-prelerped table of colorlut_xtile_kernel, computed on the device from the two copies above
                     const size_t entries = (size_t)l.size * (l.size + 1) * 256;
                     MVFX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_xtable), entries * 6 * sizeof(float)));
-                    hipLaunchKernelGGL(colorlut_xtable_build_kernel, dim3((uint32_t)((entries + 255) / 256)), dim3(256), 0, nullptr,
+                    MVFX_LAUNCH(colorlut_xtable_build_kernel, dim3((uint32_t)((entries + 255) / 256)), dim3(256), 0, nullptr,
                                        reinterpret_cast<const float4 *>(h->d_rgba), h->d_tile_tables, l.size, h->d_xtable);
                     MVFX_HIP_TRY(hipGetLastError());
                     std::vector<uint32_t> xc(512 * 2);
@@ -1476,9 +1476,9 @@ int launch_one(bool use_lds, dim3 grid, size_t lds_bytes, hipStream_t st, const 
         auto k = colorlut_lds_kernel<IS3D, WIDE, LE, VEC>;
         MVFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds_bytes));
-        hipLaunchKernelGGL(k, grid, dim3(kLdsBlock), lds_bytes, st, in, out, width, rows, is, os, p);
+        MVFX_LAUNCH(k, grid, dim3(kLdsBlock), lds_bytes, st, in, out, width, rows, is, os, p);
     } else {
-        hipLaunchKernelGGL((colorlut_global_kernel<IS3D, WIDE, LE, VEC>), grid, dim3(kBlock), 0, st, in, out, width,
+        MVFX_LAUNCH((colorlut_global_kernel<IS3D, WIDE, LE, VEC>), grid, dim3(kBlock), 0, st, in, out, width,
                            rows, is, os, p);
     }
     MVFX_HIP_TRY(hipGetLastError());
@@ -1548,7 +1548,7 @@ int ensure_baked(mvfx_cube_lut *h, hipStream_t st)
         if (all) (void)hipFree(all);
         return fail(MVFX_ERR_OUT_OF_MEMORY, "colorlut: no memory for the baked table (2 x 64 MiB)");
     }
-    hipLaunchKernelGGL(colorlut_all_colours_kernel, dim3(kBakedSide * kBakedSide / 1024), dim3(256), 0, st, all);
+    MVFX_LAUNCH(colorlut_all_colours_kernel, dim3(kBakedSide * kBakedSide / 1024), dim3(256), 0, st, all);
     mvfx_frame fi{}, fo{};
     fi.data = all; fo.data = table;
     fi.width = fo.width = kBakedSide; fi.height = fo.height = kBakedSide;
@@ -1624,10 +1624,10 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
             return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: RGB10A2_LE frames must be 4-byte aligned");
         const dim3 g10((in->width + kBlock - 1) / kBlock, in->height < 65535u ? in->height : 65535u, n);
         if (l.is_3d)
-            hipLaunchKernelGGL(colorlut_rgb10a2_kernel<true>, g10, dim3(kBlock), 0, st, ifb10, ofb10, in->width, in->height, (uint64_t)in->stride,
+            MVFX_LAUNCH(colorlut_rgb10a2_kernel<true>, g10, dim3(kBlock), 0, st, ifb10, ofb10, in->width, in->height, (uint64_t)in->stride,
                                (uint64_t)out->stride, p);
         else
-            hipLaunchKernelGGL(colorlut_rgb10a2_kernel<false>, g10, dim3(kBlock), 0, st, ifb10, ofb10, in->width, in->height, (uint64_t)in->stride,
+            MVFX_LAUNCH(colorlut_rgb10a2_kernel<false>, g10, dim3(kBlock), 0, st, ifb10, ofb10, in->width, in->height, (uint64_t)in->stride,
                                (uint64_t)out->stride, p);
         MVFX_HIP_TRY(hipGetLastError());
         return MVFX_OK;
@@ -1658,7 +1658,7 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
         constexpr int kPerLane = 2;
         const uint64_t bx = (vecs + 256u * kPerLane - 1) / (256u * kPerLane);
         if (bx > 0x7fffffffull) return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: frame too large");
-        hipLaunchKernelGGL(colorlut_baked_kernel<kPerLane>, dim3((uint32_t)bx, rows < 65535u ? rows : 65535u, n), dim3(256), 0, st, ifb, ofb, vecs, rows,
+        MVFX_LAUNCH(colorlut_baked_kernel<kPerLane>, dim3((uint32_t)bx, rows < 65535u ? rows : 65535u, n), dim3(256), 0, st, ifb, ofb, vecs, rows,
                            is, os, h->d_baked);
         MVFX_HIP_TRY(hipGetLastError());
         return MVFX_OK;
@@ -1745,7 +1745,7 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
         if (!wide && h->d_xtable && opt_lut_placement() != 5) {
             const uint32_t tx_ = (in->width + 63) / 64, ty_ = (in->height + 4 * MVFX_XTILE_ROWS - 1) / (4 * MVFX_XTILE_ROWS);
             const dim3 xgrid((tx_ + kBlock / 64 - 1) / (kBlock / 64), ty_, n);
-            hipLaunchKernelGGL(colorlut_xtile_kernel<MVFX_XTILE_RW>, xgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p);
+            MVFX_LAUNCH(colorlut_xtile_kernel<MVFX_XTILE_RW>, xgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p);
             MVFX_HIP_TRY(hipGetLastError());
             return MVFX_OK;
         }
@@ -1753,7 +1753,7 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
         const uint32_t tile_w = wide_block ? 64 : 32, tile_h = 16;
         const uint32_t tiles_x = (in->width + tile_w - 1) / tile_w, tiles_y = (in->height + tile_h - 1) / tile_h;
         const dim3 tgrid((tiles_x + kBlock / 64 - 1) / (kBlock / 64), tiles_y, n);
-#define MVFX_TK(WIDE, LE, A, R) hipLaunchKernelGGL((colorlut_tile_kernel<WIDE, LE, A, R>), tgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p)
+#define MVFX_TK(WIDE, LE, A, R) MVFX_LAUNCH((colorlut_tile_kernel<WIDE, LE, A, R>), tgrid, dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p)
         if (wide_block) MVFX_TK(false, true, 16, 4);
         else if (!wide) MVFX_TK(false, true, 8, 2);
         else if (le) MVFX_TK(true, true, 16, 4);   // RGBA64: 16 lanes x 2 pixels = the same 32 x 16 block
@@ -1764,12 +1764,12 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
     }
     if (use_fast) {
 #define MVFX_FG(IS3D, CELLS, WIDE, LE) \
-    do { hipLaunchKernelGGL((colorlut_fast_global_kernel<IS3D, CELLS, WIDE, LE>), grid, dim3(kBlock), 0, st, ip, op, width, rows, is, os, p); \
+    do { MVFX_LAUNCH((colorlut_fast_global_kernel<IS3D, CELLS, WIDE, LE>), grid, dim3(kBlock), 0, st, ip, op, width, rows, is, os, p); \
          MVFX_HIP_TRY(hipGetLastError()); return MVFX_OK; } while (0)
 #define MVFX_FL(IS3D, WIDE, LE) \
     do { auto k = colorlut_fast_lds_kernel<IS3D, WIDE, LE>; \
          MVFX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-         hipLaunchKernelGGL(k, grid, dim3(kLdsBlock), lds_bytes, st, ip, op, width, rows, is, os, p); \
+         MVFX_LAUNCH(k, grid, dim3(kLdsBlock), lds_bytes, st, ip, op, width, rows, is, os, p); \
          MVFX_HIP_TRY(hipGetLastError()); return MVFX_OK; } while (0)
         if (use_lds) {
             if (l.is_3d) { if (!wide) MVFX_FL(true, false, true); else if (le) MVFX_FL(true, true, true); else MVFX_FL(true, true, false); }
@@ -1863,15 +1863,15 @@ int colorlut_i420_impl(mvfx_cube_lut *h, const mvfx_planar_frame *in, const mvfx
         if (l.is_3d && h->d_cells && h->d_tile_tables && hgt / 16 + 1 <= 65535u) {
             const dim3 tgrid((w + 255) / 256, (hgt + 15) / 16);
             if (h->d_xtable && opt_lut_placement() != 5)
-                hipLaunchKernelGGL(colorlut_i420_xtile_kernel, tgrid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);
+                MVFX_LAUNCH(colorlut_i420_xtile_kernel, tgrid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);
             else
-                hipLaunchKernelGGL(colorlut_i420_tile_kernel, tgrid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);
+                MVFX_LAUNCH(colorlut_i420_tile_kernel, tgrid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);
         } else if (l.is_3d && h->d_cells)
-            hipLaunchKernelGGL((colorlut_i420_kernel<true, true>), grid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);
+            MVFX_LAUNCH((colorlut_i420_kernel<true, true>), grid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);
         else if (l.is_3d)
-            hipLaunchKernelGGL((colorlut_i420_kernel<true, false>), grid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);
+            MVFX_LAUNCH((colorlut_i420_kernel<true, false>), grid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);
         else
-            hipLaunchKernelGGL((colorlut_i420_kernel<false, false>), grid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);
+            MVFX_LAUNCH((colorlut_i420_kernel<false, false>), grid, dim3(kI420Block), 0, st, pl, w, hgt, p, kin, kout);
         MVFX_HIP_TRY(hipGetLastError());
         return MVFX_OK;
     }

@@ -371,9 +371,9 @@ static int i420_to_rgba_impl(const mvfx_planar_frame *ins, const mvfx_frame *out
         constexpr int kCols = 4;
         const dim3 grid(((w + kCols - 1) / kCols + kCvtBlock - 1) / kCvtBlock, rows2, m);
         if (aligned)
-            hipLaunchKernelGGL((i420_to_rgba_kernel<true, kCols>), grid, dim3(kCvtBlock), 0, st, in, w, h, k, out, (uint64_t)rgba_out->stride);
+            MVFX_LAUNCH((i420_to_rgba_kernel<true, kCols>), grid, dim3(kCvtBlock), 0, st, in, w, h, k, out, (uint64_t)rgba_out->stride);
         else
-            hipLaunchKernelGGL((i420_to_rgba_kernel<false, kCols>), grid, dim3(kCvtBlock), 0, st, in, w, h, k, out, (uint64_t)rgba_out->stride);
+            MVFX_LAUNCH((i420_to_rgba_kernel<false, kCols>), grid, dim3(kCvtBlock), 0, st, in, w, h, k, out, (uint64_t)rgba_out->stride);
         MVFX_HIP_TRY(hipGetLastError());
     }
     return MVFX_OK;
@@ -425,8 +425,8 @@ static int rgba_to_i420_impl(const mvfx_frame *ins, const mvfx_planar_frame *out
         const bool dword_ok = (ain & 3) == 0;
         if (any_size) {
             const dim3 grid_any(((w + 1) / 2 + kCvtBlock - 1) / kCvtBlock, (h + 1) / 2, m);
-            if (nv12) hipLaunchKernelGGL((rgba_to_yuv420_any_kernel<true>), grid_any, dim3(kCvtBlock), 0, st, in, (uint64_t)rgba_in->stride, w, h, k, out, dword_ok);
-            else hipLaunchKernelGGL((rgba_to_yuv420_any_kernel<false>), grid_any, dim3(kCvtBlock), 0, st, in, (uint64_t)rgba_in->stride, w, h, k, out, dword_ok);
+            if (nv12) MVFX_LAUNCH((rgba_to_yuv420_any_kernel<true>), grid_any, dim3(kCvtBlock), 0, st, in, (uint64_t)rgba_in->stride, w, h, k, out, dword_ok);
+            else MVFX_LAUNCH((rgba_to_yuv420_any_kernel<false>), grid_any, dim3(kCvtBlock), 0, st, in, (uint64_t)rgba_in->stride, w, h, k, out, dword_ok);
             MVFX_HIP_TRY(hipGetLastError());
             continue;
         }
@@ -436,9 +436,9 @@ static int rgba_to_i420_impl(const mvfx_frame *ins, const mvfx_planar_frame *out
         constexpr int kCols = 8;
         const dim3 grid(((w + kCols - 1) / kCols + kCvtBlock - 1) / kCvtBlock, h / 2, m);
         if (aligned)
-            hipLaunchKernelGGL((rgba_to_i420_kernel<true, kCols>), grid, dim3(kCvtBlock), 0, st, in, (uint64_t)rgba_in->stride, w, h, k, out, dword_ok);
+            MVFX_LAUNCH((rgba_to_i420_kernel<true, kCols>), grid, dim3(kCvtBlock), 0, st, in, (uint64_t)rgba_in->stride, w, h, k, out, dword_ok);
         else
-            hipLaunchKernelGGL((rgba_to_i420_kernel<false, kCols>), grid, dim3(kCvtBlock), 0, st, in, (uint64_t)rgba_in->stride, w, h, k, out, dword_ok);
+            MVFX_LAUNCH((rgba_to_i420_kernel<false, kCols>), grid, dim3(kCvtBlock), 0, st, in, (uint64_t)rgba_in->stride, w, h, k, out, dword_ok);
         MVFX_HIP_TRY(hipGetLastError());
     }
     return MVFX_OK;
@@ -486,7 +486,7 @@ int mvfx_convert_nv12_to_rgba(const mvfx_planar_frame *nv12_in, const mvfx_frame
     const YuvToRgbCoef k = yuv_to_rgb_coef(std_);
     const bool aligned = ((reinterpret_cast<uintptr_t>(rgba_out->data) | rgba_out->stride) & 15) == 0;
     const dim3 grid(((w + 3) / 4 + kCvtBlock - 1) / kCvtBlock, h);
-    hipLaunchKernelGGL(nv12_to_rgba_kernel, grid, dim3(kCvtBlock), 0, as_stream(stream), static_cast<const uint8_t *>(nv12_in->data[0]),
+    MVFX_LAUNCH(nv12_to_rgba_kernel, grid, dim3(kCvtBlock), 0, as_stream(stream), static_cast<const uint8_t *>(nv12_in->data[0]),
                        static_cast<const uint8_t *>(nv12_in->data[1]), (uint64_t)nv12_in->stride[0], (uint64_t)nv12_in->stride[1], w, h, k,
                        std_ != 1, static_cast<uint8_t *>(rgba_out->data), (uint64_t)rgba_out->stride, aligned);
     MVFX_HIP_TRY(hipGetLastError());

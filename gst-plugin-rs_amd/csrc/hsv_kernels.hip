@@ -524,12 +524,12 @@ void launch_filter(int bpp, int off, bool bgr, const Geometry &g, const FrameBat
     const bool nontemporal = opt_nontemporal();
 
 #define MVFX_L4(O, B, M) \
-    hipLaunchKernelGGL((hsvfilter4_kernel<O, B, VARIANT, M>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p)
+    MVFX_LAUNCH((hsvfilter4_kernel<O, B, VARIANT, M>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p)
 #define MVFX_L4V(O, B, NT_) \
-    do { if (g.tile == kTile) hipLaunchKernelGGL((hsvfilter4_kernel<O, B, VARIANT, kModeVec4, NT_, kTile>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p); \
-         else hipLaunchKernelGGL((hsvfilter4_kernel<O, B, VARIANT, kModeVec4, NT_, 1>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p); } while (0)
+    do { if (g.tile == kTile) MVFX_LAUNCH((hsvfilter4_kernel<O, B, VARIANT, kModeVec4, NT_, kTile>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p); \
+         else MVFX_LAUNCH((hsvfilter4_kernel<O, B, VARIANT, kModeVec4, NT_, 1>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p); } while (0)
 #define MVFX_L3(B, M) \
-    hipLaunchKernelGGL((hsvfilter3_kernel<B, VARIANT, M>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p)
+    MVFX_LAUNCH((hsvfilter3_kernel<B, VARIANT, M>), g.grid, dim3(kBlock), 0, stream, fb, g.width, g.rows, g.stride, p)
     if (bpp == 4) {
         const int key = (off ? 2 : 0) | (bgr ? 1 : 0);
         switch (g.mode) {
@@ -744,11 +744,11 @@ int hsvfilter_i420_impl(const mvfx_planar_frame *in, const mvfx_planar_frame *ou
         const RgbToYuvCoef kout = rgb_to_yuv_coef(std_);
         const dim3 grid((w / 8 + kI420Block - 1) / kI420Block, h / 2);
         if (use_fast && std::signbit(s->hue_shift) && s->hue_shift != 0.0f)
-            hipLaunchKernelGGL(hsvfilter_i420_kernel<kFastNeg>, grid, dim3(kI420Block), 0, stream, pl, w, h, p, kin, kout);
+            MVFX_LAUNCH(hsvfilter_i420_kernel<kFastNeg>, grid, dim3(kI420Block), 0, stream, pl, w, h, p, kin, kout);
         else if (use_fast)
-            hipLaunchKernelGGL(hsvfilter_i420_kernel<kFast>, grid, dim3(kI420Block), 0, stream, pl, w, h, p, kin, kout);
+            MVFX_LAUNCH(hsvfilter_i420_kernel<kFast>, grid, dim3(kI420Block), 0, stream, pl, w, h, p, kin, kout);
         else
-            hipLaunchKernelGGL(hsvfilter_i420_kernel<kGeneral>, grid, dim3(kI420Block), 0, stream, pl, w, h, p, kin, kout);
+            MVFX_LAUNCH(hsvfilter_i420_kernel<kGeneral>, grid, dim3(kI420Block), 0, stream, pl, w, h, p, kin, kout);
         MVFX_HIP_TRY(hipGetLastError());
         return MVFX_OK;
     }
@@ -791,7 +791,7 @@ void launch_detect_out(bool a0, bool obgr, dim3 grid, hipStream_t stream, const 
                        const HsvDetectorParams &p)
 {
 #define MVFX_LD(A, B) \
-    hipLaunchKernelGGL((hsvdetector_kernel<IN_BPP, IN_OFF, IN_BGR, A, B, VARIANT, MODE>), grid, dim3(kBlock), 0, stream, in, out, width, rows, is, os, p)
+    MVFX_LAUNCH((hsvdetector_kernel<IN_BPP, IN_OFF, IN_BGR, A, B, VARIANT, MODE>), grid, dim3(kBlock), 0, stream, in, out, width, rows, is, os, p)
     if (a0) { if (obgr) MVFX_LD(true, true); else MVFX_LD(true, false); }
     else { if (obgr) MVFX_LD(false, true); else MVFX_LD(false, false); }
 #undef MVFX_LD
@@ -967,7 +967,7 @@ int hsvdetector_impl(const mvfx_frame *ins, const mvfx_frame *outs, uint32_t n,
             const uint32_t word3 = (4 + iR) | ((4 + iG) << 3) | ((4 + iB) << 6) | (10u << 15); // see hsvfilter_impl
             const uint32_t o0 = obgr ? iB : iR, o2 = obgr ? iR : iB; // detect_px4_fast's selector, formed at run time
             const uint32_t sel = a0 ? (4u | (o0 << 8) | (iG << 16) | (o2 << 24)) : (o0 | (iG << 8) | (o2 << 16) | (4u << 24));
-            hipLaunchKernelGGL(hsvdetector_typed_kernel, grid, dim3(kBlock), 0, stream, ifb, ofb, width, rows, is, os, p, word3, (uint32_t)in_bytes, sel);
+            MVFX_LAUNCH(hsvdetector_typed_kernel, grid, dim3(kBlock), 0, stream, ifb, ofb, width, rows, is, os, p, word3, (uint32_t)in_bytes, sel);
             MVFX_HIP_TRY(hipGetLastError());
             continue;
         }
@@ -1031,7 +1031,7 @@ int hsvdetector_i420_impl(const mvfx_planar_frame *in, const mvfx_frame *out, co
     const dim3 grid(((w + kCols - 1) / kCols + kBlock - 1) / kBlock, (h + 1) / 2);
     uint8_t *o = static_cast<uint8_t *>(out->data);
 #define MVFX_DI(A, B, V, AL) \
-    hipLaunchKernelGGL((hsvdetector_i420_kernel<A, B, V, AL, kCols>), grid, dim3(kBlock), 0, stream, yp, up, vp, (uint64_t)in->stride[0], \
+    MVFX_LAUNCH((hsvdetector_i420_kernel<A, B, V, AL, kCols>), grid, dim3(kBlock), 0, stream, yp, up, vp, (uint64_t)in->stride[0], \
                        (uint64_t)in->stride[1], (uint64_t)in->stride[2], w, h, k, p, o, (uint64_t)out->stride)
 #define MVFX_DI_V(A, B, AL) \
     do { if (variant == kDetFast) MVFX_DI(A, B, kDetFast, AL); else if (variant == kFast) MVFX_DI(A, B, kFast, AL); else MVFX_DI(A, B, kGeneral, AL); } while (0)
@@ -1163,8 +1163,8 @@ int mvfx_hsv_from_frame(const mvfx_frame *frame, float *hsv_out_device, mvfx_str
     const bool fast = opt_hsv_variant() != 1;
     const FastConsts kc = make_consts(nullptr);
 #define MVFX_LH(O, B) \
-    do { if (fast) hipLaunchKernelGGL((hsv_from_frame_kernel<O, B, kFast>), grid, dim3(kBlock), 0, st, in, hsv_out_device, frame->width, frame->height, (uint64_t)frame->stride, kc); \
-         else hipLaunchKernelGGL((hsv_from_frame_kernel<O, B, kGeneral>), grid, dim3(kBlock), 0, st, in, hsv_out_device, frame->width, frame->height, (uint64_t)frame->stride, kc); } while (0)
+    do { if (fast) MVFX_LAUNCH((hsv_from_frame_kernel<O, B, kFast>), grid, dim3(kBlock), 0, st, in, hsv_out_device, frame->width, frame->height, (uint64_t)frame->stride, kc); \
+         else MVFX_LAUNCH((hsv_from_frame_kernel<O, B, kGeneral>), grid, dim3(kBlock), 0, st, in, hsv_out_device, frame->width, frame->height, (uint64_t)frame->stride, kc); } while (0)
     if (off == 0) { if (bgr) MVFX_LH(0, true); else MVFX_LH(0, false); }
     else { if (bgr) MVFX_LH(1, true); else MVFX_LH(1, false); }
 #undef MVFX_LH

@@ -130,7 +130,7 @@ void launch_hsvfilter_typed(bool neg_shift, int tile, bool streaming, dim3 grid,
                             uint32_t rows, uint64_t stride, const FastConsts &p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr)
 {
 #define MVFX_LT(V, T_, NT_) \
-    hipLaunchKernelGGL((hsvfilter4_typed_kernel<V, T_, NT_>), grid, dim3(kBlock), 0, stream, fb, width, rows, stride, p, word3, frame_bytes, off, bgr)
+    MVFX_LAUNCH((hsvfilter4_typed_kernel<V, T_, NT_>), grid, dim3(kBlock), 0, stream, fb, width, rows, stride, p, word3, frame_bytes, off, bgr)
 #define MVFX_LT_NT(V, T_) do { if (streaming) MVFX_LT(V, T_, true); else MVFX_LT(V, T_, false); } while (0)
     if (tile == 2) { if (neg_shift) MVFX_LT_NT(kFastNeg, 2); else MVFX_LT_NT(kFast, 2); }
     else { if (neg_shift) MVFX_LT_NT(kFastNeg, 1); else MVFX_LT_NT(kFast, 1); }
@@ -143,7 +143,7 @@ void launch_hsvfilter_typed_frames(bool neg_shift, int tile, bool streaming, dim
                                    uint32_t frame_bytes, int off, bool bgr)
 {
 #define MVFX_LF(V, T_, NT_) \
-    hipLaunchKernelGGL((hsvfilter4_typed_frames_kernel<V, T_, NT_>), grid, dim3(kBlock), 0, stream, fb, width, rows, stride, p, fs, word3, frame_bytes, off, bgr)
+    MVFX_LAUNCH((hsvfilter4_typed_frames_kernel<V, T_, NT_>), grid, dim3(kBlock), 0, stream, fb, width, rows, stride, p, fs, word3, frame_bytes, off, bgr)
 #define MVFX_LF_NT(V, T_) do { if (streaming) MVFX_LF(V, T_, true); else MVFX_LF(V, T_, false); } while (0)
     if (tile == 2) { if (neg_shift) MVFX_LF_NT(kFastNeg, 2); else MVFX_LF_NT(kFast, 2); }
     else { if (neg_shift) MVFX_LF_NT(kFastNeg, 1); else MVFX_LF_NT(kFast, 1); }

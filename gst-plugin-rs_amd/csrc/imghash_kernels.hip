@@ -327,8 +327,8 @@ int gray_resize_impl(const mvfx_frame *frame, uint32_t nw, uint32_t nh, uint8_t 
         if (int rc = host_scratch((size_t)w * h, 2, &scratch); rc != MVFX_OK) return rc;
         uint8_t *out = static_cast<uint8_t *>(scratch);
         const dim3 grid((w * h + 255) / 256);
-        if (rgba) hipLaunchKernelGGL(gray_kernel<4>, grid, dim3(256), 0, st, plane, (uint64_t)frame->stride, w, h, out);
-        else hipLaunchKernelGGL(gray_kernel<3>, grid, dim3(256), 0, st, plane, (uint64_t)frame->stride, w, h, out);
+        if (rgba) MVFX_LAUNCH(gray_kernel<4>, grid, dim3(256), 0, st, plane, (uint64_t)frame->stride, w, h, out);
+        else MVFX_LAUNCH(gray_kernel<3>, grid, dim3(256), 0, st, plane, (uint64_t)frame->stride, w, h, out);
         MVFX_HIP_TRY(hipGetLastError());
         MVFX_HIP_TRY(hipMemcpyAsync(out_host, out, (size_t)w * h, hipMemcpyDeviceToHost, st));
         MVFX_HIP_TRY(hipStreamSynchronize(st));
@@ -341,21 +341,21 @@ int gray_resize_impl(const mvfx_frame *frame, uint32_t nw, uint32_t nh, uint8_t 
     if (nh <= kVBlockAll / 64) { // one pass over the frame, all output rows at once
         const dim3 bgrid((w + kVCols - 1) / kVCols);
         if (rgba && dword)
-            hipLaunchKernelGGL((vsample_block_kernel<4, true>), bgrid, dim3(kVBlockAll), 0, st, plane, (uint64_t)frame->stride, w, h, nh, plan->v, plan->weights, plan->tmp);
+            MVFX_LAUNCH((vsample_block_kernel<4, true>), bgrid, dim3(kVBlockAll), 0, st, plane, (uint64_t)frame->stride, w, h, nh, plan->v, plan->weights, plan->tmp);
         else if (rgba)
-            hipLaunchKernelGGL((vsample_block_kernel<4, false>), bgrid, dim3(kVBlockAll), 0, st, plane, (uint64_t)frame->stride, w, h, nh, plan->v, plan->weights, plan->tmp);
+            MVFX_LAUNCH((vsample_block_kernel<4, false>), bgrid, dim3(kVBlockAll), 0, st, plane, (uint64_t)frame->stride, w, h, nh, plan->v, plan->weights, plan->tmp);
         else
-            hipLaunchKernelGGL((vsample_block_kernel<3, false>), bgrid, dim3(kVBlockAll), 0, st, plane, (uint64_t)frame->stride, w, h, nh, plan->v, plan->weights, plan->tmp);
+            MVFX_LAUNCH((vsample_block_kernel<3, false>), bgrid, dim3(kVBlockAll), 0, st, plane, (uint64_t)frame->stride, w, h, nh, plan->v, plan->weights, plan->tmp);
     } else {
         const dim3 vgrid((w + kVBlock - 1) / kVBlock, nh);
         if (rgba && dword)
-            hipLaunchKernelGGL((vsample_kernel<4, true>), vgrid, dim3(kVBlock), 0, st, plane, (uint64_t)frame->stride, w, plan->v, plan->weights, plan->tmp);
+            MVFX_LAUNCH((vsample_kernel<4, true>), vgrid, dim3(kVBlock), 0, st, plane, (uint64_t)frame->stride, w, plan->v, plan->weights, plan->tmp);
         else if (rgba)
-            hipLaunchKernelGGL((vsample_kernel<4, false>), vgrid, dim3(kVBlock), 0, st, plane, (uint64_t)frame->stride, w, plan->v, plan->weights, plan->tmp);
+            MVFX_LAUNCH((vsample_kernel<4, false>), vgrid, dim3(kVBlock), 0, st, plane, (uint64_t)frame->stride, w, plan->v, plan->weights, plan->tmp);
         else
-            hipLaunchKernelGGL((vsample_kernel<3, false>), vgrid, dim3(kVBlock), 0, st, plane, (uint64_t)frame->stride, w, plan->v, plan->weights, plan->tmp);
+            MVFX_LAUNCH((vsample_kernel<3, false>), vgrid, dim3(kVBlock), 0, st, plane, (uint64_t)frame->stride, w, plan->v, plan->weights, plan->tmp);
     }
-    hipLaunchKernelGGL(hsample_kernel, dim3(nw, nh), dim3(kHBlock), 0, st, plan->tmp, w, plan->hz, plan->weights + plan->v_floats, plan->out, nw);
+    MVFX_LAUNCH(hsample_kernel, dim3(nw, nh), dim3(kHBlock), 0, st, plan->tmp, w, plan->hz, plan->weights + plan->v_floats, plan->out, nw);
     MVFX_HIP_TRY(hipGetLastError());
     MVFX_HIP_TRY(hipMemcpyAsync(out_host, plan->out, (size_t)nw * nh, hipMemcpyDeviceToHost, st));
     MVFX_HIP_TRY(hipStreamSynchronize(st));

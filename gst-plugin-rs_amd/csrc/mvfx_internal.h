@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdint>
@@ -61,6 +62,24 @@ hipStream_t host_stream();
 hipStream_t host_stream_n(uint32_t index); // 0 = host_stream(), 1..3 = further private streams of the calling thread
 // Grow-only device scratch keyed by (thread, device, stream): intermediate results handed from one launch to the next on `stream`.
 int stream_scratch(hipStream_t stream, size_t bytes, void **out);
+
+// The completion event of the calling thread (mvfx_thread_set_completion_event): while one is set, every kernel this thread launches
+// carries it as the STOP EVENT of its own dispatch packet (hipExtLaunchKernelGGL) -- the fence of the element layer without a barrier
+// packet behind the kernel: hipEventRecord behind every 4K launch costs 2.6 us of device time, the attached event nothing
+// (tools/probes/event_cost.hip: 78.4 k against 97.9 k launches/s, 98.5 k with no fence at all).  Several launches of one call
+// re-record it; the last one stands.
+hipEvent_t completion_event();
+void note_completion_event_used();
+#define MVFX_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                              \
+    do {                                                                                                                   \
+        hipEvent_t mvfx_done_ = ::mvfx::completion_event();                                                                \
+        if (mvfx_done_) {                                                                                                  \
+            ::mvfx::note_completion_event_used();                                                                          \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, mvfx_done_, 0, __VA_ARGS__);                 \
+        } else {                                                                                                           \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                           \
+        }                                                                                                                  \
+    } while (0)
 
 constexpr int kMaxBatch = 32; // frames per launch of the batched entry points
 

@@ -89,7 +89,7 @@ void launch_blend(uint8_t *frame, uint32_t frame_stride, const uint8_t *overlay,
                   float global_alpha, hipStream_t st)
 {
     const dim3 grid((c.cw + kBlock - 1) / kBlock, c.ch);
-    hipLaunchKernelGGL(overlay_blend_kernel, grid, dim3(kBlock), 0, st, frame, frame_stride, overlay, overlay_stride, c.cw, c.ch, c.dx0, c.dy0,
+    MVFX_LAUNCH(overlay_blend_kernel, grid, dim3(kBlock), 0, st, frame, frame_stride, overlay, overlay_stride, c.cw, c.ch, c.dx0, c.dy0,
                        c.ox0, c.oy0, l, (uint32_t)(int)(global_alpha * 255.0f), global_alpha != 1.0f);
 }
 

@@ -485,7 +485,7 @@ template <int MODE, int BPP>
 void launch_level(const LevelArgs &A, int cover_hi, hipStream_t st)
 {
     const dim3 grid((A.w + kTW - 1) / kTW, (cover_hi - A.cover_lo + kTH - 1) / kTH);
-    hipLaunchKernelGGL((ssim32_level_kernel<MODE, BPP>), grid, dim3(kThreads), 0, st, A);
+    MVFX_LAUNCH((ssim32_level_kernel<MODE, BPP>), grid, dim3(kThreads), 0, st, A);
 }
 
 int read_slots(const double *d_slots, double out[kScales], hipStream_t st)
@@ -608,7 +608,7 @@ int partial_deviation(const double mean[5], double deviation_sums_out[5], hipStr
     }
     if (most && S.scales) {
         const unsigned grid = (unsigned)std::min<size_t>((most + kThreads * 8 - 1) / (kThreads * 8), 2048);
-        hipLaunchKernelGGL(ssim32_dev_kernel, dim3(grid ? grid : 1, S.scales), dim3(kThreads), 0, st, D);
+        MVFX_LAUNCH(ssim32_dev_kernel, dim3(grid ? grid : 1, S.scales), dim3(kThreads), 0, st, D);
     }
     MVFX_HIP_TRY(hipGetLastError());
     double sums[kScales];

@@ -364,7 +364,7 @@ int ensure_scratch(SsimState &S, int w0, int h0, hipStream_t st)
 template <int kSeg, int kTileW>
 void launch_map_t(int w, int y0, int y1, hipStream_t st, const Planes &a, const Planes &b, double *map, double *sum)
 {
-    hipLaunchKernelGGL((ssim_map_kernel<kSeg, kTileW>), dim3((w + kTileW - 1) / kTileW, (y1 - y0 + kSeg - 1) / kSeg), dim3(kBlock), 0, st,
+    MVFX_LAUNCH((ssim_map_kernel<kSeg, kTileW>), dim3((w + kTileW - 1) / kTileW, (y1 - y0 + kSeg - 1) / kSeg), dim3(kBlock), 0, st,
                        a, b, y0, y1, map, sum);
 }
 
@@ -459,17 +459,17 @@ int mvfx_ssim_partial_sums(const mvfx_frame *reference_frame, const mvfx_frame *
                 const uint64_t stride = fr[i]->stride;
                 const bool wide = bpp == 4 && ((reinterpret_cast<uintptr_t>(src) | stride) & 3) == 0;
                 if (s == 0) {
-                    if (wide) hipLaunchKernelGGL((ssim_lab0_kernel<4, true>), grid, dim3(kBlock), 0, st, src, a[0], stride, S.d_lut, lab[i]);
-                    else if (bpp == 4) hipLaunchKernelGGL((ssim_lab0_kernel<4, false>), grid, dim3(kBlock), 0, st, src, a[0], stride, S.d_lut, lab[i]);
-                    else hipLaunchKernelGGL((ssim_lab0_kernel<3, false>), grid, dim3(kBlock), 0, st, src, a[0], stride, S.d_lut, lab[i]);
+                    if (wide) MVFX_LAUNCH((ssim_lab0_kernel<4, true>), grid, dim3(kBlock), 0, st, src, a[0], stride, S.d_lut, lab[i]);
+                    else if (bpp == 4) MVFX_LAUNCH((ssim_lab0_kernel<4, false>), grid, dim3(kBlock), 0, st, src, a[0], stride, S.d_lut, lab[i]);
+                    else MVFX_LAUNCH((ssim_lab0_kernel<3, false>), grid, dim3(kBlock), 0, st, src, a[0], stride, S.d_lut, lab[i]);
                 } else if (s == 1) {
-                    if (wide) hipLaunchKernelGGL((ssim_down1_kernel<4, true>), grid, dim3(kBlock), 0, st, src, a[1], stride, S.d_lut, out, lab[i]);
-                    else if (bpp == 4) hipLaunchKernelGGL((ssim_down1_kernel<4, false>), grid, dim3(kBlock), 0, st, src, a[1], stride, S.d_lut, out, lab[i]);
-                    else hipLaunchKernelGGL((ssim_down1_kernel<3, false>), grid, dim3(kBlock), 0, st, src, a[1], stride, S.d_lut, out, lab[i]);
+                    if (wide) MVFX_LAUNCH((ssim_down1_kernel<4, true>), grid, dim3(kBlock), 0, st, src, a[1], stride, S.d_lut, out, lab[i]);
+                    else if (bpp == 4) MVFX_LAUNCH((ssim_down1_kernel<4, false>), grid, dim3(kBlock), 0, st, src, a[1], stride, S.d_lut, out, lab[i]);
+                    else MVFX_LAUNCH((ssim_down1_kernel<3, false>), grid, dim3(kBlock), 0, st, src, a[1], stride, S.d_lut, out, lab[i]);
                 } else {
                     Planes in = (s & 1) ? S.quarter[i] : S.half[i];
                     in.w = ws[s - 1]; in.h = hs[s - 1];
-                    hipLaunchKernelGGL(ssim_downlab_kernel, grid, dim3(kBlock), 0, st, in, out, lab[i], a[s]);
+                    MVFX_LAUNCH(ssim_downlab_kernel, grid, dim3(kBlock), 0, st, in, out, lab[i], a[s]);
                 }
             }
         if (S.y1[s] > S.y0[s])
@@ -505,7 +505,7 @@ int mvfx_ssim_partial_deviation(const double mean[5], double deviation_sums_out[
     hipStream_t st = as_stream(stream);
     for (int s = 0; s < S.scales; s++)
         if (S.y1[s] > S.y0[s])
-            hipLaunchKernelGGL(ssim_dev_kernel, grid2d(S.w[s], S.y1[s] - S.y0[s]), dim3(kBlock), 0, st, S.map[s], S.w[s], S.y0[s],
+            MVFX_LAUNCH(ssim_dev_kernel, grid2d(S.w[s], S.y1[s] - S.y0[s]), dim3(kBlock), 0, st, S.map[s], S.w[s], S.y0[s],
                                S.y1[s], mean[s], S.d_sums + (kScales + s) * kSlots);
     MVFX_HIP_TRY(hipGetLastError());
     std::vector<double> slots((size_t)kScales * kSlots);

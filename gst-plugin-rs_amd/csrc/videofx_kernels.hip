@@ -447,13 +447,13 @@ int colordetect_hist_impl(const mvfx_frame *frames, uint32_t n_frames, uint32_t 
                 const int in_flight = 4; // 16-byte loads in flight per lane (8 and 12 measured: never faster)
                 const uint32_t step_mod = (uint32_t)(((uint64_t)kHistBlock * in_flight * 4) % quality);
                 if (quality < 4)
-                    hipLaunchKernelGGL((colordetect_hist4_kernel<true, 4>), dim3((uint32_t)groups, nf), dim3(kHistBlock), kHistLds, st, planes, done,
+                    MVFX_LAUNCH((colordetect_hist4_kernel<true, 4>), dim3((uint32_t)groups, nf), dim3(kHistBlock), kHistLds, st, planes, done,
                                        done + chunk_units, px_begin, px_end, (uint32_t)per_group, quality, step_mod, lay, part_f);
                 else
-                    hipLaunchKernelGGL((colordetect_hist4_kernel<false, 4>), dim3((uint32_t)groups, nf), dim3(kHistBlock), kHistLds, st, planes, done,
+                    MVFX_LAUNCH((colordetect_hist4_kernel<false, 4>), dim3((uint32_t)groups, nf), dim3(kHistBlock), kHistLds, st, planes, done,
                                        done + chunk_units, px_begin, px_end, (uint32_t)per_group, quality, step_mod, lay, part_f);
                 MVFX_HIP_TRY(hipGetLastError());
-                hipLaunchKernelGGL(colordetect_reduce_kernel, dim3(kReduceGroups, nf), dim3(kReduceBlock), 0, st, part_f, (uint32_t)groups,
+                MVFX_LAUNCH(colordetect_reduce_kernel, dim3(kReduceGroups, nf), dim3(kReduceBlock), 0, st, part_f, (uint32_t)groups,
                                    hist_dev + (size_t)f0 * (kHistBins + 8), minmax_dev + (size_t)f0 * (kHistBins + 8), launches > 0 ? 1 : 0);
                 MVFX_HIP_TRY(hipGetLastError());
             }
@@ -480,12 +480,12 @@ int colordetect_hist_impl(const mvfx_frame *frames, uint32_t n_frames, uint32_t 
             void *partials = nullptr;
             if (int rc = stream_scratch(st, (size_t)std::max<uint32_t>(groups, 1) * kPartialWords * sizeof(uint32_t), &partials); rc != MVFX_OK) return rc;
             if (groups) {
-                hipLaunchKernelGGL(colordetect_hist_kernel, dim3(groups), dim3(kHistBlock), kHistLds, st,
+                MVFX_LAUNCH(colordetect_hist_kernel, dim3(groups), dim3(kHistBlock), kHistLds, st,
                                    static_cast<const uint8_t *>(frames[f].data), byte_path_first + done, chunk, per_group, quality,
                                    lay, static_cast<uint32_t *>(partials));
                 MVFX_HIP_TRY(hipGetLastError());
             }
-            hipLaunchKernelGGL(colordetect_reduce_kernel, dim3(kReduceGroups, 1), dim3(kReduceBlock), 0, st,
+            MVFX_LAUNCH(colordetect_reduce_kernel, dim3(kReduceGroups, 1), dim3(kReduceBlock), 0, st,
                                static_cast<const uint32_t *>(partials), groups, hist_dev + (size_t)f * (kHistBins + 8),
                                minmax_dev + (size_t)f * (kHistBins + 8), frame_launches > 0 ? 1 : 0);
             MVFX_HIP_TRY(hipGetLastError());
@@ -731,11 +731,11 @@ int blockhash_slow_impl(const mvfx_frame *frames, uint32_t n_pads, uint32_t *sum
         }
         uint32_t *out = sums_dev + (size_t)first * 64;
         if (unit) {
-            if (bpp == 4) hipLaunchKernelGGL(blockhash_slow_unit_kernel<4>, dim3(64, n), dim3(64), 0, st, pads, b, out);
-            else hipLaunchKernelGGL(blockhash_slow_unit_kernel<3>, dim3(64, n), dim3(64), 0, st, pads, b, out);
+            if (bpp == 4) MVFX_LAUNCH(blockhash_slow_unit_kernel<4>, dim3(64, n), dim3(64), 0, st, pads, b, out);
+            else MVFX_LAUNCH(blockhash_slow_unit_kernel<3>, dim3(64, n), dim3(64), 0, st, pads, b, out);
         } else {
-            if (bpp == 4) hipLaunchKernelGGL(blockhash_slow_weighted_kernel<4>, dim3(n), dim3(64), 0, st, pads, b, out);
-            else hipLaunchKernelGGL(blockhash_slow_weighted_kernel<3>, dim3(n), dim3(64), 0, st, pads, b, out);
+            if (bpp == 4) MVFX_LAUNCH(blockhash_slow_weighted_kernel<4>, dim3(n), dim3(64), 0, st, pads, b, out);
+            else MVFX_LAUNCH(blockhash_slow_weighted_kernel<3>, dim3(n), dim3(64), 0, st, pads, b, out);
         }
         MVFX_HIP_TRY(hipGetLastError());
     }
@@ -803,14 +803,14 @@ int blockhash_sums_impl(const mvfx_frame *frames, uint32_t n_pads, uint32_t row_
         if (int rc = host_scratch((size_t)n * 64 * chunks * sizeof(uint32_t), 2, &scratch); rc != MVFX_OK) return rc;
         uint32_t *out = static_cast<uint32_t *>(scratch);
         if (bpp == 4 && vec)
-            hipLaunchKernelGGL((blockhash_sums_kernel<4, true>), grid, dim3(kSumBlock), 0, st, pads, bw, bh, row_begin, row_end, lx_log2, out);
+            MVFX_LAUNCH((blockhash_sums_kernel<4, true>), grid, dim3(kSumBlock), 0, st, pads, bw, bh, row_begin, row_end, lx_log2, out);
         else if (bpp == 4)
-            hipLaunchKernelGGL((blockhash_sums_kernel<4, false>), grid, dim3(kSumBlock), 0, st, pads, bw, bh, row_begin, row_end, lx_log2, out);
+            MVFX_LAUNCH((blockhash_sums_kernel<4, false>), grid, dim3(kSumBlock), 0, st, pads, bw, bh, row_begin, row_end, lx_log2, out);
         else if (vec)
-            hipLaunchKernelGGL((blockhash_sums_kernel<3, true>), grid, dim3(kSumBlock), 0, st, pads, bw, bh, row_begin, row_end, lx_log2, out);
+            MVFX_LAUNCH((blockhash_sums_kernel<3, true>), grid, dim3(kSumBlock), 0, st, pads, bw, bh, row_begin, row_end, lx_log2, out);
         else
-            hipLaunchKernelGGL((blockhash_sums_kernel<3, false>), grid, dim3(kSumBlock), 0, st, pads, bw, bh, row_begin, row_end, lx_log2, out);
-        hipLaunchKernelGGL(blockhash_reduce_kernel, dim3(64 * n), dim3(64), 0, st, out, chunks, sums_dev + (size_t)first * 64);
+            MVFX_LAUNCH((blockhash_sums_kernel<3, false>), grid, dim3(kSumBlock), 0, st, pads, bw, bh, row_begin, row_end, lx_log2, out);
+        MVFX_LAUNCH(blockhash_reduce_kernel, dim3(64 * n), dim3(64), 0, st, out, chunks, sums_dev + (size_t)first * 64);
         MVFX_HIP_TRY(hipGetLastError());
     }
     return MVFX_OK;
@@ -920,7 +920,7 @@ int launch_copy_planes(PlaneCopies pc, int n, hipStream_t st)
     uint64_t bx = (max_row / 16 + 255) / 256;
     if (bx < 1) bx = 1;
     if (bx > 65535u) bx = 65535u; // grid-stride covers the rest
-    hipLaunchKernelGGL(copy_planes_kernel, dim3((uint32_t)bx, max_rows < 65535u ? max_rows : 65535u, n), dim3(256), 0, st, pc);
+    MVFX_LAUNCH(copy_planes_kernel, dim3((uint32_t)bx, max_rows < 65535u ? max_rows : 65535u, n), dim3(256), 0, st, pc);
     MVFX_HIP_TRY(hipGetLastError());
     return MVFX_OK;
 }

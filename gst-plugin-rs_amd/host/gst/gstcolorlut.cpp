@@ -155,8 +155,10 @@ static GstFlowReturn gst_color_lut_bt_transform(GstBaseTransform *bt, GstBuffer 
         mvfx_stream st = mvfx_element_stream(inbuf);
         mvfx_hip_buffer_acquire(inbuf, st);
         mvfx_hip_buffer_acquire(outbuf, st);
+        MvfxFenceScope fs;
+        mvfx_hip_fence_begin_buffers(&fs, inbuf, outbuf, st);
         int rc = mvfx_colorlut_transform_i420(self->lut, &pi, &po, 0, st);
-        mvfx_hip_buffers_release(inbuf, outbuf, st); // one fence for both (the reader's too: the input block may be recycled and overwritten next)
+        mvfx_hip_fence_end(&fs, st, NULL, GST_OBJECT(self)); // one fence for both buffers, carried by the kernel
         gst_buffer_unmap(outbuf, &omap);
         gst_buffer_unmap(inbuf, &imap);
         return MVFX_GST_FLOW(self, rc);
@@ -178,15 +180,19 @@ static GstFlowReturn gst_color_lut_bt_transform(GstBaseTransform *bt, GstBuffer 
         if (prc != MVFX_PAIR_NOT_TAKEN) return MVFX_GST_FLOW(self, prc);
         mvfx_hip_buffer_acquire(inbuf, st);
         mvfx_hip_buffer_acquire(outbuf, st);
-        const int drc = mvfx_colorlut_transform_frame(self->lut, &fi, &fo, st);
         GstMemory *const both[2] = {gst_buffer_peek_memory(inbuf, 0), gst_buffer_peek_memory(outbuf, 0)};
-        mvfx_hip_memories_release_tagged(both, 2, st, GST_OBJECT(self));
+        MvfxFenceScope dfs;
+        mvfx_hip_fence_begin(&dfs, both, 2, st, TRUE);
+        const int drc = mvfx_colorlut_transform_frame(self->lut, &fi, &fo, st);
+        mvfx_hip_fence_end(&dfs, st, NULL, GST_OBJECT(self));
         return MVFX_GST_FLOW(self, drc);
     }
     mvfx_hip_buffer_acquire(inbuf, st);
     mvfx_hip_buffer_acquire(outbuf, st);
+    MvfxFenceScope fs;
+    mvfx_hip_fence_begin_buffers(&fs, inbuf, outbuf, st);
     int rc = mvfx_colorlut_transform_frame(self->lut, &fi, &fo, st);
-    mvfx_hip_buffers_release(inbuf, outbuf, st); // one fence for both (the reader's too: the input block may be recycled and overwritten next)
+    mvfx_hip_fence_end(&fs, st, NULL, GST_OBJECT(self)); // one fence for both buffers, carried by the kernel
     gst_buffer_unmap(outbuf, &omap);
     gst_buffer_unmap(inbuf, &imap);
     return MVFX_GST_FLOW(self, rc);

@@ -92,8 +92,10 @@ static void gst_hsv_filter_flush_locked(GstHsvFilter *self, MvfxUnrefLater *late
     // the mark stays on the block until its fence is recorded (release_as_owner): a consumer on another streaming thread that looks at
     // the block meanwhile runs into this element's lock, not past an unrecorded fence
     mvfx_hip_memory_acquire_as_owner(mem, self->pend_stream, GST_OBJECT(self));
+    MvfxFenceScope fs; // the fence rides on the kernel (mvfx_hip_fence_begin / _end): no event record behind it
+    mvfx_hip_fence_begin(&fs, &mem, 1, self->pend_stream, FALSE);
     const int rc = mvfx_hsvfilter_transform_frame_ip(&self->pend_frame, &self->pend_settings, self->pend_stream);
-    mvfx_hip_memory_release_as_owner(mem, self->pend_stream, GST_OBJECT(self));
+    mvfx_hip_fence_end(&fs, self->pend_stream, GST_OBJECT(self), GST_OBJECT(self));
     later->add(mem); // dropped after pend_lock is released (mvfx_pair_hold.h)
     self->n_singles++;
     if (rc != MVFX_OK)
@@ -211,8 +213,10 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
             gst_hsv_filter_flush_locked(self, &later);
             g.unlock();
             mvfx_hip_buffer_acquire(buf, st);
+            MvfxFenceScope dfs;
+            mvfx_hip_fence_begin(&dfs, &mem, 1, st, TRUE);
             rc = mvfx_hsvfilter_transform_frame_ip(&f, &s, st);
-            mvfx_hip_memory_release_tagged(mem, st, GST_OBJECT(self));
+            mvfx_hip_fence_end(&dfs, st, NULL, GST_OBJECT(self));
             return MVFX_GST_FLOW(self, rc);
         }
         if (self->pend_mem && (self->pend_mem == mem || self->pend_frame.width != f.width || self->pend_frame.height != f.height ||
@@ -236,9 +240,11 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
         st = mvfx_thread_stream_n(self->pair_no++ & 1u);
         mvfx_hip_memory_acquire_as_owner(first, st, GST_OBJECT(self)); // (the mark stays until the fence is recorded: see the flush)
         mvfx_hip_memory_acquire_as_owner(mem, st, GST_OBJECT(self));
-        rc = mvfx_hsvfilter_transform_frames_ip_settings(frames, 2, settings, st);
         GstMemory *const both[2] = {first, mem};
-        mvfx_hip_memories_release_as_owner(both, 2, st, GST_OBJECT(self)); // one fence for the pair
+        MvfxFenceScope fs; // one fence for the pair, carried by the kernel itself
+        mvfx_hip_fence_begin(&fs, both, 2, st, FALSE);
+        rc = mvfx_hsvfilter_transform_frames_ip_settings(frames, 2, settings, st);
+        mvfx_hip_fence_end(&fs, st, GST_OBJECT(self), GST_OBJECT(self));
         self->n_pairs++;
         self->foreign_streak = 0;
         later.add(first);
@@ -246,8 +252,10 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
         return MVFX_GST_FLOW(self, rc);
     }
     mvfx_hip_buffer_acquire(buf, st);
+    MvfxFenceScope fs; // the fence rides on the kernel; recorded behind it where no kernel of this thread took it (the combiner's launches)
+    mvfx_hip_fence_begin_buffers(&fs, buf, NULL, st);
     rc = combine == 1 ? mvfx_hsvfilter_transform_frame_ip_combined(&f, &s, st) : mvfx_hsvfilter_transform_frame_ip(&f, &s, st);
-    mvfx_hip_buffer_release(buf, st);
+    mvfx_hip_fence_end(&fs, st, NULL, GST_OBJECT(self));
     gst_buffer_unmap(buf, &map);
     return MVFX_GST_FLOW(self, rc);
 }
@@ -493,15 +501,19 @@ static GstFlowReturn gst_hsv_detector_bt_transform(GstBaseTransform *bt, GstBuff
         if (prc != MVFX_PAIR_NOT_TAKEN) return MVFX_GST_FLOW(self, prc);
         mvfx_hip_buffer_acquire(inbuf, st);
         mvfx_hip_buffer_acquire(outbuf, st);
-        const int drc = mvfx_hsvdetector_transform_frame(&fi, &fo, &s, st);
         GstMemory *const both[2] = {gst_buffer_peek_memory(inbuf, 0), gst_buffer_peek_memory(outbuf, 0)};
-        mvfx_hip_memories_release_tagged(both, 2, st, GST_OBJECT(self));
+        MvfxFenceScope dfs;
+        mvfx_hip_fence_begin(&dfs, both, 2, st, TRUE);
+        const int drc = mvfx_hsvdetector_transform_frame(&fi, &fo, &s, st);
+        mvfx_hip_fence_end(&dfs, st, NULL, GST_OBJECT(self));
         return MVFX_GST_FLOW(self, drc);
     }
     mvfx_hip_buffer_acquire(inbuf, st);
     mvfx_hip_buffer_acquire(outbuf, st);
+    MvfxFenceScope fs; // one fence for both buffers (the reader's too: the input block may be recycled and overwritten next), on the kernel
+    mvfx_hip_fence_begin_buffers(&fs, inbuf, outbuf, st);
     int rc = i420 ? mvfx_hsvdetector_transform_i420(&pi, &fo, &s, 0, st) : mvfx_hsvdetector_transform_frame(&fi, &fo, &s, st);
-    mvfx_hip_buffers_release(inbuf, outbuf, st); // one fence for both (the reader's too: the input block may be recycled and overwritten next)
+    mvfx_hip_fence_end(&fs, st, NULL, GST_OBJECT(self));
     gst_buffer_unmap(outbuf, &omap);
     gst_buffer_unmap(inbuf, &imap);
     return MVFX_GST_FLOW(self, rc);

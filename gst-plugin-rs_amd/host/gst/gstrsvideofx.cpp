@@ -446,8 +446,10 @@ static GstFlowReturn gst_rounded_corners_prepare_output_buffer(GstBaseTransform 
         const mvfx_stream st = mvfx_element_stream(inbuf);
         mvfx_hip_buffer_acquire(inbuf, st);
         mvfx_hip_buffer_acquire(out, st);
+        MvfxFenceScope fs; // one fence for both buffers (the reader's too: the input block may be recycled and overwritten next), on the kernel
+        mvfx_hip_fence_begin_buffers(&fs, inbuf, out, st);
         int rc = mvfx_roundedcorners_compose_a420(&pi, amap.data, (uint32_t)GST_VIDEO_INFO_PLANE_STRIDE(&self->out_info, 3), &po, st);
-        mvfx_hip_buffers_release(inbuf, out, st); // one fence for both (the reader's too: the input block may be recycled and overwritten next)
+        mvfx_hip_fence_end(&fs, st, NULL, GST_OBJECT(self));
         gst_memory_unmap(self->alpha_mem, &amap);
         gst_buffer_unmap(out, &omap);
         gst_buffer_unmap(inbuf, &imap);

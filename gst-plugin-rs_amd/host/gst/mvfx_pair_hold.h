@@ -65,9 +65,12 @@ static inline void mvfx_pair_flush_locked(MvfxPairHold *h, GstObject *element, M
     // the marks stay until the fences are recorded (release_as_owner): a user on another thread runs into the hold's lock meanwhile
     mvfx_hip_memory_acquire_as_owner(in, h->st, element);
     mvfx_hip_memory_acquire_as_owner(out, h->st, element);
-    const int rc = launch(element, &h->fi, &h->fo, 1, h->st);
+    // one fence for the launch, not one per block, and carried by the kernel itself (mvfx_hip_fence_begin / _end)
     GstMemory *const both[2] = {in, out};
-    mvfx_hip_memories_release_as_owner(both, 2, h->st, element); // one fence for the launch, not one per block
+    MvfxFenceScope fs;
+    mvfx_hip_fence_begin(&fs, both, 2, h->st, FALSE);
+    const int rc = launch(element, &h->fi, &h->fo, 1, h->st);
+    mvfx_hip_fence_end(&fs, h->st, element, element);
     later->add(in);
     later->add(out);
     h->n_singles++;
@@ -149,9 +152,12 @@ static inline int mvfx_pair_submit(MvfxPairHold *h, GstObject *element, MvfxPair
     mvfx_hip_memory_acquire_as_owner(first_out, pst, element);
     mvfx_hip_memory_acquire_as_owner(in, pst, element);
     mvfx_hip_memory_acquire_as_owner(out, pst, element);
-    const int rc = launch(element, ins, outs, 2, pst);
+    // ONE fence for the four blocks, carried by the kernel itself as its stop event: an event record costs the device a bubble
     GstMemory *const all[4] = {first_in, first_out, in, out};
-    mvfx_hip_memories_release_as_owner(all, 4, pst, element); // ONE fence for the four blocks: an event record costs the device a bubble
+    MvfxFenceScope fs;
+    mvfx_hip_fence_begin(&fs, all, 4, pst, FALSE);
+    const int rc = launch(element, ins, outs, 2, pst);
+    mvfx_hip_fence_end(&fs, pst, element, element);
     h->n_pairs++;
     h->foreign_streak = 0;
     later.add(first_in);

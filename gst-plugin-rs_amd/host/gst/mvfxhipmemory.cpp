@@ -337,39 +337,35 @@ void mvfx_hip_memory_set_borrowed_fence(GstMemory *mem, void *event)
 // consumer on another thread either still sees the mark (its flush then waits for the owner's lock and finds the work launched) or
 // already sees the fence, never neither.  Somebody who recorded on a block between the two phases (the tee sibling again) is chained
 // onto there, and that block gets a fence of its own.
-static void release_group(GstMemory *const *mems, guint n, mvfx_stream stream, GstObject *owner, const void *tag)
+static void group_phase_a(MvfxFenceScope *sc, GstMemory *const *mems, guint n, mvfx_stream stream)
 {
-    enum { kMax = 8 };
-    MvfxHipMemory *ms[kMax];
-    guint64 seen[kMax];
-    guint k = 0;
-    for (guint i = 0; i < n && k < kMax; i++)
-        if (mvfx_is_hip_memory(mems[i])) ms[k++] = (MvfxHipMemory *)mems[i];
-    if (k == 0) return;
-    for (guint i = 0; i < k; i++) {
-        MvfxHipMemory *m = ms[i];
+    sc->n = 0;
+    sc->fence = NULL;
+    for (guint i = 0; i < n && sc->n < 8; i++)
+        if (mvfx_is_hip_memory(mems[i])) sc->mems[sc->n++] = mems[i];
+    for (guint i = 0; i < sc->n; i++) {
+        MvfxHipMemory *m = (MvfxHipMemory *)sc->mems[i];
         g_mutex_lock(&m->lock);
         if (m->fence && m->pending && m->fence_stream != stream && !(m->acq_seq == m->fence_seq && m->acq_stream == stream))
             mvfx_stream_wait_event(stream, m->fence->ev);
-        if (m->borrowed) { // same chaining for a fence somebody else recorded; the record below then covers it
+        if (m->borrowed) { // same chaining for a fence somebody else recorded; the record then covers it
             mvfx_stream_wait_event(stream, m->borrowed);
             m->borrowed = NULL;
         }
-        seen[i] = m->fence_seq;
+        sc->seen[i] = m->fence_seq;
         g_mutex_unlock(&m->lock);
     }
-    MvfxFence *f = fence_get();
-    if (f && mvfx_event_record(f->ev, stream) != MVFX_OK) {
-        fence_unref(f);
-        f = NULL;
-    }
+}
+
+static void group_phase_b(MvfxFenceScope *sc, mvfx_stream stream, GstObject *owner, const void *tag, MvfxFence *f)
+{
     if (!f) mvfx_stream_synchronize(stream); // no event: fall back to a blocking hand-off
-    for (guint i = 0; i < k; i++) {
-        MvfxHipMemory *m = ms[i];
+    for (guint i = 0; i < sc->n; i++) {
+        MvfxHipMemory *m = (MvfxHipMemory *)sc->mems[i];
         MvfxFence *old = NULL, *mine = f ? fence_ref(f) : NULL;
         GstObject *drop = NULL;
         g_mutex_lock(&m->lock);
-        if (m->fence_seq != seen[i] && m->fence && m->pending) {
+        if (m->fence_seq != sc->seen[i] && m->fence && m->pending) {
             // recorded on in between: wait for that too, and a later fence of this block's own covers both
             mvfx_stream_wait_event(stream, m->fence->ev);
             fence_unref(mine);
@@ -396,6 +392,59 @@ static void release_group(GstMemory *const *mems, guint n, mvfx_stream stream, G
         if (drop) gst_object_unref(drop);
     }
     fence_unref(f);
+    sc->n = 0;
+}
+
+static void release_group(GstMemory *const *mems, guint n, mvfx_stream stream, GstObject *owner, const void *tag)
+{
+    MvfxFenceScope sc;
+    group_phase_a(&sc, mems, n, stream);
+    if (sc.n == 0) return;
+    MvfxFence *f = fence_get();
+    if (f && mvfx_event_record(f->ev, stream) != MVFX_OK) {
+        fence_unref(f);
+        f = NULL;
+    }
+    group_phase_b(&sc, stream, owner, tag, f);
+}
+
+// The same release split around the launch, so that the fence costs the device nothing: _begin does the chaining waits and sets the
+// fence's event as the calling thread's completion event (include/mi355vfx.h: the kernels of the next library call carry it as
+// their stop event), the caller launches, _end publishes the fence on the blocks -- or records it the ordinary way when no kernel
+// took it.  plain: the caller is an ordinary user of the blocks (somebody's held-back work on them comes first); otherwise it holds
+// its own lock and has flushed foreign work before (mvfx_hip_memory_flush_foreign).
+void mvfx_hip_fence_begin(MvfxFenceScope *sc, GstMemory *const *mems, guint n, mvfx_stream stream, gboolean plain)
+{
+    if (plain)
+        for (guint i = 0; i < n; i++)
+            if (mvfx_is_hip_memory(mems[i])) run_deferred((MvfxHipMemory *)mems[i]);
+    group_phase_a(sc, mems, n, stream);
+    if (sc->n == 0) return;
+    MvfxFence *f = fence_get();
+    sc->fence = f;
+    if (f) mvfx_thread_set_completion_event(f->ev);
+}
+
+// the blocks of one or two buffers as an ordinary user (input and output of an out-of-place launch)
+void mvfx_hip_fence_begin_buffers(MvfxFenceScope *sc, GstBuffer *a, GstBuffer *b, mvfx_stream stream)
+{
+    GstMemory *mems[8];
+    guint n = 0;
+    for (GstBuffer *buf : {a, b})
+        for (guint i = 0; buf && i < gst_buffer_n_memory(buf) && n < 8; i++) mems[n++] = gst_buffer_peek_memory(buf, i);
+    mvfx_hip_fence_begin(sc, mems, n, stream, TRUE);
+}
+
+void mvfx_hip_fence_end(MvfxFenceScope *sc, mvfx_stream stream, GstObject *owner, GstObject *tag)
+{
+    if (sc->n == 0) return;
+    MvfxFence *f = (MvfxFence *)sc->fence;
+    const int carried = f ? mvfx_thread_clear_completion_event() : 0;
+    if (f && carried <= 0 && mvfx_event_record(f->ev, stream) != MVFX_OK) {
+        fence_unref(f);
+        f = NULL;
+    }
+    group_phase_b(sc, stream, owner, tag, f);
 }
 
 void mvfx_hip_memory_release(GstMemory *mem, mvfx_stream stream) { mvfx_hip_memory_release_as_owner(mem, stream, NULL); }

@@ -45,6 +45,11 @@ void mvfx_hip_memory_flush_foreign(GstMemory *mem, GstObject *owner);
 gboolean mvfx_hip_memory_busy(GstMemory *mem, GstObject *owner);
 void mvfx_hip_memory_release_tagged(GstMemory *mem, void *stream, GstObject *tag);
 void mvfx_hip_buffers_release(GstBuffer *a, GstBuffer *b, void *stream);
+// one launch's fence, split around the launch (mvfxhipmemory.cpp): declare on the stack, _begin, launch through the C ABI, _end
+typedef struct { GstMemory *mems[8]; guint64 seen[8]; guint n; gpointer fence; } MvfxFenceScope;
+void mvfx_hip_fence_begin(MvfxFenceScope *scope, GstMemory *const *mems, guint n, void *stream, gboolean plain);
+void mvfx_hip_fence_begin_buffers(MvfxFenceScope *scope, GstBuffer *a, GstBuffer *b, void *stream);
+void mvfx_hip_fence_end(MvfxFenceScope *scope, void *stream, GstObject *owner, GstObject *tag);
 void mvfx_hip_memories_release_tagged(GstMemory *const *mems, guint n, void *stream, GstObject *tag);
 void mvfx_hip_memories_release_as_owner(GstMemory *const *mems, guint n, void *stream, GstObject *owner);
 void mvfx_hip_memory_acquire_as_owner(GstMemory *mem, void *stream, GstObject *owner);

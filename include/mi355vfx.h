@@ -123,6 +123,14 @@ int mvfx_stream_wait_event(mvfx_stream stream, mvfx_event event);
 int mvfx_event_synchronize(mvfx_event event);
 /* 1: everything recorded before the event has finished; 0: still running (hipEventQuery -> hipErrorNotReady); < 0: MVFX_ERR_*.  Never blocks. */
 int mvfx_event_query(mvfx_event event);
+/* The fence without a barrier packet.  While a completion event is set on the calling thread, every kernel the thread launches
+ * through this library carries it as the stop event of its own dispatch (hipExtLaunchKernelGGL): the event is recorded when the
+ * kernel finishes, with no packet of its own behind it -- hipEventRecord behind every 4K launch costs 2.6 us of device time
+ * (tools/probes/event_cost.hip).  Usage: set, make ONE library call, clear.  _clear returns how many launches carried the event:
+ * 0 means the call launched nothing (or took a path that does not launch kernels) and the caller records the event itself.
+ * Several launches of one call re-record the event; the last one stands, which is the fence of the whole call on an in-order stream. */
+int mvfx_thread_set_completion_event(mvfx_event event);
+int mvfx_thread_clear_completion_event(void);
 
 /* Page-locked host memory (hipHostMalloc) for upload / download staging: a copy from or to it is a real DMA at PCIe
  * speed instead of the runtime's chunked staging of pageable memory; and copies that do NOT synchronise (the caller
