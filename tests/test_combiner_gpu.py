@@ -213,3 +213,39 @@ def test_event_query_never_blocks_and_turns_one(gpu):
         assert L.mvfx_event_query(ev) == 1
     assert seen <= {0, 1} and 0 in seen
     gpu.check(L.mvfx_event_destroy(ev))
+
+
+def test_completion_event_rides_on_the_kernels_of_the_next_call(gpu):
+    """mvfx_thread_set_completion_event / _clear_completion_event: while an event is set every kernel the thread launches through the
+    library carries it as its stop event (hipExtLaunchKernelGGL, csrc/mvfx_internal.h MVFX_LAUNCH); _clear says how many did.  The event
+    then behaves like a recorded one: not reached right behind a long launch, reached after it, and a stream that waits for it sees the
+    kernel's bytes.  Nothing launched -> 0: the caller records it itself."""
+    L = gpu.lib()
+    w, h, n = 3840, 2160, 16
+    ev = ctypes.c_void_p()
+    gpu.check(L.mvfx_event_create(ctypes.byref(ev)))
+    gpu.check(L.mvfx_thread_set_completion_event(ev))
+    assert L.mvfx_thread_clear_completion_event() == 0
+    host = frames.random_frame(11, w, h)
+    bufs = [gpu.DeviceBuffer(host.nbytes).upload(host) for _ in range(n)]
+    gpu.check(L.mvfx_stream_synchronize(None))
+    arr = (gpu.Frame * n)(*[gpu.make_frame(b.ptr, w, h, w * 4, "RGBA") for b in bufs])
+    s = gpu.HsvFilterSettings(90.0, 1.25, -0.05, 0.9, 0.02)
+    seen = set()
+    for _ in range(6):
+        gpu.check(L.mvfx_thread_set_completion_event(ev))
+        gpu.check(L.mvfx_hsvfilter_transform_frames_ip(arr, n, ctypes.byref(s), None))
+        assert L.mvfx_thread_clear_completion_event() >= 1
+        seen.add(L.mvfx_event_query(ev))
+        gpu.check(L.mvfx_event_synchronize(ev))
+        assert L.mvfx_event_query(ev) == 1
+    assert 0 in seen and seen <= {0, 1}
+    # launches behind a cleared setting carry nothing: the event stays reached
+    gpu.check(L.mvfx_hsvfilter_transform_frames_ip(arr, n, ctypes.byref(s), None))
+    assert L.mvfx_event_query(ev) == 1
+    gpu.check(L.mvfx_stream_synchronize(None))
+    exp = host.copy()
+    for _ in range(7):
+        assert orc.hsvfilter(exp, w, w * 4, "RGBA", (90.0, 1.25, -0.05, 0.9, 0.02)) == 0
+    assert np.array_equal(bufs[3].download().reshape(h, w * 4), exp)
+    gpu.check(L.mvfx_event_destroy(ev))
