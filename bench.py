@@ -1591,7 +1591,7 @@ def gst_pipeline_leg(args):
     gst_dir = os.path.join(ROOT, "gst-plugin-rs_amd", "gst-plugins")
     if not os.path.isdir(gst_dir) or not os.path.exists("/opt/conda/bin/gst-launch-1.0"):
         return {"error": "no GStreamer on this box (the element layer is an optional build target)"}
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_gst_pipeline.py"), "--branches", "1", "--quick", "2",
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_gst_pipeline.py"), "--branches", "1", "--quick", "2", "--others", "1",
            "--n1", str(args.gst_n1), "--n2", str(args.gst_n2)]
 
     def one(pair):
@@ -1612,6 +1612,7 @@ def gst_pipeline_leg(args):
             "roofline": {"bound": "valu", "frac": fps * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS if fps else None},
             "sub_extra": {"pipeline": "gst-launch-1.0 hiptestsrc refresh=false ! video/x-raw(memory:HIPMemory),format=RGBA,3840x2160 ! hsvfilter ! fakesink",
                           "buffers": [d.get("n1"), d.get("n2")], "one_launch_per_buffer_fps": single,
+                          "hsvdetector_element_fps": d.get("hsvdetector_fps"), "colorlut_element_fps": d.get("colorlut_fps"),
                           "note": "the pool's four blocks are re-filtered: converged content clocks higher than fresh frames and 4 x 33 MB sit in the 256 MB Infinity Cache, so this can pass the HBM-only ceiling of `value`"},
             "detail": d}
 

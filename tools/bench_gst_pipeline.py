@@ -82,6 +82,16 @@ def branches_main(args):
                 run(tpl.format(n=min(args.n1, 2000)), tmp, env)  # page cache, registry
                 out[key + "_fps"] = round(rate(tpl, tmp, args.n1, args.n2, env), 1)
                 out[key + "_frac_of_8TBs"] = round(out[key + "_fps"] * 2 * w * h * 4 / 8e12, 4)
+                if args.others and n == 1:  # the two out-of-place elements the same way (one run each)
+                    cube = os.path.join(tmp, "look.cube")
+                    with open(cube, "w") as f:
+                        f.write(cubes.analytic_3d(args.lut))
+                    for name, fmt, desc in (("hsvdetector", "RGBx", "hsvdetector hue-ref=120 hue-var=60 saturation-ref=0.6 saturation-var=0.4 value-ref=0.6 value-var=0.4"),
+                                            ("colorlut", "RGBA", f"colorlut location={cube}")):
+                        c2 = f"video/x-raw(memory:HIPMemory),format={fmt},width={w},height={h},framerate=30/1"
+                        t2 = f"hiptestsrc num-buffers={{n}} refresh={refresh} ! {c2} ! {desc} ! fakesink sync=false"
+                        run(t2.format(n=2000), tmp, env)
+                        out[name + "_fps"] = round(rate(t2, tmp, args.n1, args.n2 * 2 // 3, env), 1)
                 continue
             v, t1, t2 = fps(tpl, tmp, args.n1 * mul, args.n2 * mul, env)
             out[key + "_fps"] = round(v * n, 1)
@@ -136,6 +146,7 @@ def main():
     ap.add_argument("--n1", type=int, default=60)
     ap.add_argument("--n2", type=int, default=460)
     ap.add_argument("--lut", type=int, default=33)
+    ap.add_argument("--others", type=int, default=0, help="--branches 1 --quick 2: also hsvdetector and colorlut as the single device element")
     ap.add_argument("--repeats", type=int, default=3, help="--element: interleaved repeats per configuration (the median is reported)")
     args = ap.parse_args()
     if args.element:
