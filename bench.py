@@ -1030,11 +1030,16 @@ def make_leg_videocompare(w, args, algo):
                   note="compulsory input bytes against HBM peak; the pyramid planes are extra traffic, see traffic_over_algorithmic")
     else:
         depth = max(1, args.pairs_in_flight)
-        ring_dev = torch.zeros((depth, 2, 64), dtype=torch.int32, device=dev)
         ring_host = torch.zeros((depth, 2, 64), dtype=torch.int32).pin_memory()
-        ring_evt = [torch.cuda.Event() for _ in range(depth)]
+        # the sums of a pair land in page-locked host memory straight from the reduce kernel's stores, and the pair's fence rides on that
+        # kernel (mvfx_thread_set_completion_event): no D2H copy packet and no event record behind it (2.6 us of device time each,
+        # tools/probes/event_cost.hip)
         ring_busy = [False] * depth
-
+        ring_evt = []
+        for _ in range(depth):
+            e = ctypes.c_void_p()
+            vfx.check(lib.mvfx_event_create(ctypes.byref(e)))
+            ring_evt.append(e)
         def bits(s):
             arr = (ctypes.c_uint32 * 64)(*[int(x) for x in s])
             out = ctypes.c_uint64()
@@ -1042,7 +1047,7 @@ def make_leg_videocompare(w, args, algo):
             return out.value
 
         def finish(slot):
-            ring_evt[slot].synchronize()
+            vfx.check(lib.mvfx_event_synchronize(ring_evt[slot]))
             h = [bits([int(v) & 0xFFFFFFFF for v in ring_host[slot, p].tolist()]) for p in range(2)]
             ring_busy[slot] = False
             last[0] = float(bin(h[0] ^ h[1]).count("1"))
@@ -1060,9 +1065,10 @@ def make_leg_videocompare(w, args, algo):
             slot = i % depth
             if ring_busy[slot]:
                 finish(slot)
-            vfx.check(lib.mvfx_blockhash_sums_pads(fr[i % pool], 2, H, 0, ctypes.c_void_p(ring_dev[slot].data_ptr()), sptr))
-            ring_host[slot].copy_(ring_dev[slot], non_blocking=True)
-            ring_evt[slot].record(stream)
+            vfx.check(lib.mvfx_thread_set_completion_event(ring_evt[slot]))
+            vfx.check(lib.mvfx_blockhash_sums_pads(fr[i % pool], 2, H, 0, ctypes.c_void_p(ring_host[slot].data_ptr()), sptr))
+            if lib.mvfx_thread_clear_completion_event() <= 0:
+                vfx.check(lib.mvfx_event_record(ring_evt[slot], sptr))
             ring_busy[slot] = True
         leg = Leg("videocompare_blockhash", "videocompare_blockhash_8k_rgba_pairs_per_sec", "pairs/s", 1, bytes_per_pair, "u32",
                   "synthetic uniform-random u8 RGBA 8K pairs (B = A with 1 % of the bytes perturbed), device-resident",
@@ -1071,7 +1077,7 @@ def make_leg_videocompare(w, args, algo):
                   step, ["blockhash_sums_kernel", "blockhash_reduce_kernel"],
                   cpu=(lambda s: cpu_baseline_blockhash(s, host_pair)) if host_pair else None, fixed_settle=400,
                   extra={"last_distance": last, "pairs_in_flight": depth},
-                  note="per pair incl. the D2H of the 128 block sums and the host bit derivation")
+                  note="per pair incl. the 128 block sums landing in page-locked host memory (the reduce kernel's own stores) and the host bit derivation")
         leg.drain = lambda: [finish(s) for s in range(depth) if ring_busy[s]]
     leg.keep = (full, fr)
     return leg

@@ -1067,6 +1067,22 @@ int mvfx_blockhash_bits(const uint32_t sums_host[64], uint32_t width, uint32_t h
 
 uint32_t mvfx_hash_distance(uint64_t a, uint64_t b) { return (uint32_t)__builtin_popcountll(a ^ b); }
 
+// 2 x 64 block sums land in page-locked host memory straight from the reduce kernel's stores (hipHostMalloc memory is device-accessible
+// and coherent): no D2H copy packet behind the kernel, and nothing staged through pageable memory.  One block per thread, kept.
+static uint32_t *pinned_sums()
+{
+    static thread_local uint32_t *p = nullptr;
+    if (!p) {
+        void *q = nullptr;
+        if (hipHostMalloc(&q, 128 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        p = static_cast<uint32_t *>(q);
+    }
+    return p;
+}
+
 static int blockhash_common(const mvfx_frame *dev_frame, uint64_t *hash_out, hipStream_t st)
 {
     if (!hash_out)
@@ -1074,10 +1090,16 @@ static int blockhash_common(const mvfx_frame *dev_frame, uint64_t *hash_out, hip
     void *scratch = nullptr;
     if (int rc = host_scratch(64 * sizeof(uint32_t), 3, &scratch); rc != MVFX_OK) return rc;
     uint32_t *sums_dev = static_cast<uint32_t *>(scratch);
-    if (int rc = blockhash_sums_impl(dev_frame, 1, 0, dev_frame ? dev_frame->height : 0, sums_dev, st); rc != MVFX_OK) return rc;
     uint32_t sums[64];
-    MVFX_HIP_TRY(hipMemcpyAsync(sums, sums_dev, sizeof(sums), hipMemcpyDeviceToHost, st));
-    MVFX_HIP_TRY(hipStreamSynchronize(st));
+    if (uint32_t *host = pinned_sums()) {
+        if (int rc = blockhash_sums_impl(dev_frame, 1, 0, dev_frame ? dev_frame->height : 0, host, st); rc != MVFX_OK) return rc;
+        MVFX_HIP_TRY(hipStreamSynchronize(st));
+        memcpy(sums, host, sizeof(sums));
+    } else {
+        if (int rc = blockhash_sums_impl(dev_frame, 1, 0, dev_frame ? dev_frame->height : 0, sums_dev, st); rc != MVFX_OK) return rc;
+        MVFX_HIP_TRY(hipMemcpyAsync(sums, sums_dev, sizeof(sums), hipMemcpyDeviceToHost, st));
+        MVFX_HIP_TRY(hipStreamSynchronize(st));
+    }
     *hash_out = blockhash_bits(sums, dev_frame->width, dev_frame->height);
     return MVFX_OK;
 }
@@ -1117,6 +1139,8 @@ int mvfx_videocompare_distance(const mvfx_frame *reference_frame, const mvfx_fra
     uint32_t *sums_dev = static_cast<uint32_t *>(scratch);
     hipStream_t st = as_stream(stream);
     uint32_t sums[128];
+    uint32_t *const host = pinned_sums();
+    if (host) sums_dev = host; // the reduce kernel stores into page-locked host memory: no copy behind it
     if (reference_frame->format == other_frame->format) {
         const mvfx_frame pair[2] = {*reference_frame, *other_frame};
         if (int rc = blockhash_sums_impl(pair, 2, 0, pair[0].height, sums_dev, st); rc != MVFX_OK) return rc;
@@ -1124,8 +1148,9 @@ int mvfx_videocompare_distance(const mvfx_frame *reference_frame, const mvfx_fra
         if (int rc = blockhash_sums_impl(reference_frame, 1, 0, reference_frame->height, sums_dev, st); rc != MVFX_OK) return rc;
         if (int rc = blockhash_sums_impl(other_frame, 1, 0, other_frame->height, sums_dev + 64, st); rc != MVFX_OK) return rc;
     }
-    MVFX_HIP_TRY(hipMemcpyAsync(sums, sums_dev, sizeof(sums), hipMemcpyDeviceToHost, st));
+    if (!host) MVFX_HIP_TRY(hipMemcpyAsync(sums, sums_dev, sizeof(sums), hipMemcpyDeviceToHost, st));
     MVFX_HIP_TRY(hipStreamSynchronize(st));
+    if (host) memcpy(sums, host, sizeof(sums));
     const uint64_t a = blockhash_bits(sums, reference_frame->width, reference_frame->height);
     const uint64_t b = blockhash_bits(sums + 64, other_frame->width, other_frame->height);
     *distance_out = (double)mvfx_hash_distance(a, b); // hashed_image.rs:70 `left.dist(right) as f64`
