@@ -490,8 +490,20 @@ void launch_level(const LevelArgs &A, int cover_hi, hipStream_t st)
 
 int read_slots(const double *d_slots, double out[kScales], hipStream_t st)
 {
-    std::vector<double> slots((size_t)kScales * kSlots);
-    MVFX_HIP_TRY(hipMemcpyAsync(slots.data(), d_slots, slots.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    // into page-locked memory (one block per thread, kept): a D2H copy to pageable memory is staged and blocks twice
+    static thread_local double *pinned = nullptr;
+    if (!pinned) {
+        void *q = nullptr;
+        if (hipHostMalloc(&q, sizeof(double) * kScales * kSlots, hipHostMallocDefault) == hipSuccess) pinned = static_cast<double *>(q);
+        else (void)hipGetLastError();
+    }
+    std::vector<double> pageable;
+    double *slots = pinned;
+    if (!slots) {
+        pageable.resize((size_t)kScales * kSlots);
+        slots = pageable.data();
+    }
+    MVFX_HIP_TRY(hipMemcpyAsync(slots, d_slots, sizeof(double) * kScales * kSlots, hipMemcpyDeviceToHost, st));
     MVFX_HIP_TRY(hipStreamSynchronize(st));
     for (int s = 0; s < kScales; s++) {
         out[s] = 0.0;
