@@ -975,10 +975,22 @@ static int palette_common(const mvfx_frame *dev_frame, uint32_t quality, uint32_
     if (int rc = host_scratch((kHistBins + 8) * sizeof(uint32_t), 3, &scratch); rc != MVFX_OK) return rc;
     uint32_t *hist_dev = static_cast<uint32_t *>(scratch), *mm_dev = hist_dev + kHistBins;
     if (int rc = colordetect_hist_impl(dev_frame, 1, quality, 0, ~0ull, hist_dev, mm_dev, st); rc != MVFX_OK) return rc;
-    std::vector<uint32_t> host(kHistBins + 8);
-    MVFX_HIP_TRY(hipMemcpyAsync(host.data(), hist_dev, (kHistBins + 6) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    // the 128 KiB histogram into page-locked memory (one block per thread, kept): a D2H copy to pageable memory is staged
+    static thread_local uint32_t *pinned = nullptr;
+    if (!pinned) {
+        void *q = nullptr;
+        if (hipHostMalloc(&q, (kHistBins + 8) * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) pinned = static_cast<uint32_t *>(q);
+        else (void)hipGetLastError();
+    }
+    std::vector<uint32_t> pageable;
+    uint32_t *host = pinned;
+    if (!host) {
+        pageable.resize(kHistBins + 8);
+        host = pageable.data();
+    }
+    MVFX_HIP_TRY(hipMemcpyAsync(host, hist_dev, (kHistBins + 6) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     MVFX_HIP_TRY(hipStreamSynchronize(st));
-    return mvfx_mmcq_palette_from_histogram(host.data(), host.data() + kHistBins, max_colors, palette_out, n_out);
+    return mvfx_mmcq_palette_from_histogram(host, host + kHistBins, max_colors, palette_out, n_out);
 }
 
 int mvfx_colordetect_palette(const mvfx_frame *frame, uint32_t quality, uint32_t max_colors, uint32_t *palette_out,
