@@ -33,10 +33,13 @@ the per-launch time; HBM traffic per launch from the committed rocprofv3 PMC pas
 same run) and, at N=1, `cpu_baseline` (the oracle's loop on one host thread -- what the reference does on its one streaming
 thread -- and on nproc threads, bounded sample).
 
-At N=1 the same run then measures BASELINE configs 2-5 (`config.other_configs`: hsv1080p, colorlut 33^3 on natural-like and
-uniform-random frames, videofx, videocompare blockhash and dssim), each with its own roofline fractions, per-step
-percentiles, committed PMC traffic and a bounded CPU-port baseline; at N>1 the band-sharded videocompare leg with its RCCL
-all-reduce.  `--workload <name>` prints one of them as its own line (what tools/r3_traffic.sh profiles).
+At N=1 the same run then measures BASELINE configs 2-5 and the side legs as SUB-LINES: one JSON line each (<= 1 KB, `"sub":
+"<name>"`), printed BEFORE the final line -- hsv1080p, hsvfilter_rgb, hsvdetector_rgb, colorlut_natural (with the noise sweep),
+colorlut_random, videofx, videocompare_blockhash, videocompare_dssim, gst_element_pipeline -- each with its own roofline fraction,
+per-step percentiles, committed PMC traffic and a bounded CPU-port baseline.  The final line (the LAST line of stdout, <= 3 000
+bytes) is the contract line of the headline only; the whole document is also written to bench_out/last_run.json.  At N>1 the
+band-sharded videocompare leg with its RCCL all-reduce is a sub-line too.  `--workload <name>` prints one leg as its own final
+line (what tools/r5_traffic.sh profiles).
 """
 import argparse
 import ctypes
@@ -156,7 +159,7 @@ def compact_headline(out):
     """The driver's line: what the bench contract names and nothing else (the whole document is FULL_DOC)."""
     c = out.get("config", {})
     cfg = {k: c[k] for k in ("workload", "launch_model", "frame_content", "frames_per_step_per_gpu", "parallelism", "rccl_ranks",
-                             "rendezvous_backend", "collective") if c.get(k) is not None}
+                             "rendezvous_backend", "collective", "error") if c.get(k) is not None}
     for k in ("per_rank_frames_per_sec", "per_rank_units_per_sec"):
         if k in c:
             cfg[k] = [_r(v, 5) for v in c[k]]
@@ -222,7 +225,19 @@ def emit(doc, subs=(), full=False):
             line["config"].pop(k, None)
         line["data"] = line["data"][:60]
         s = json.dumps(line)
-    assert len(s) <= FINAL_LINE_LIMIT, len(s)
+    if len(s) > FINAL_LINE_LIMIT:  # still too long (many ranks, long notes): keep shedding -- a valid short line beats no line at all
+        for shed in (lambda: line.get("cpu_baseline", {}).pop("sample", None),
+                     lambda: line.__setitem__("roofline", {k: v for k, v in line.get("roofline", {}).items()
+                                                           if k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}),
+                     lambda: line.__setitem__("config", {k: v for k, v in line["config"].items() if k in ("workload", "full_document", "error")}),
+                     lambda: line["config"].__setitem__("workload", str(line["config"].get("workload", ""))[:200])):
+            shed()
+            s = json.dumps(line)
+            if len(s) <= FINAL_LINE_LIMIT:
+                break
+    if len(s) > FINAL_LINE_LIMIT:
+        s = json.dumps({k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                                 "scaling", "vs_baseline", "dtype")} | {"config": {"full_document": os.path.relpath(FULL_DOC, ROOT)}})
     print(s, flush=True)
 
 
@@ -1565,15 +1580,22 @@ def hsvfilter_main(args):
         th.start()
         th.join(timeout=args.side_leg_timeout)
         late = {"error": f"no result within {args.side_leg_timeout} s (watchdog)"}
-        stuck = th.is_alive()
         sides = {"videocompare_blockhash_sharded": box.get("r", late), "videocompare_dssim_sharded": box.get("d", late)}
         out["config"]["other_configs"] = sides
         subs = list(sides.items())
-        if stuck:
+        # A rank stuck in the collective is a FAILURE of the run: the ranks agree over the rendezvous store (plain TCP, no GPU
+        # collective -- the device queue of a stuck rank may never drain), rank 0 still prints the headline (with an `error` entry),
+        # and every rank leaves with a non-zero code so that the launcher / the spawning parent reports the run as failed.
+        stuck_ranks = agree_on_stuck(w, th.is_alive(), args.side_leg_timeout)
+        if stuck_ranks:
             if rank == 0:
+                out["config"]["error"] = f"side leg stuck in its collective on rank(s) {stuck_ranks}; exit code {EXIT_SIDE_LEG_STUCK}"
                 out["wall_s"] = time.perf_counter() - t_start
                 emit(out, subs, full=bool(args.full))
-            os._exit(0)  # the stuck thread holds the communicator: no orderly teardown
+                mark_emitted(w)
+            else:
+                wait_emitted(w, 20.0)
+            os._exit(EXIT_SIDE_LEG_STUCK)  # the stuck thread holds the communicator: no orderly teardown; never exec from here
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         t1 = time.perf_counter()
         ALL_CORES_SECONDS[0] = args.cpu_all_seconds
@@ -1588,6 +1610,47 @@ def hsvfilter_main(args):
         out["timing_s"] = timing
         emit(out, subs, full=bool(args.full))
     w.finish()
+
+
+EXIT_SIDE_LEG_STUCK = 5
+
+
+def _store(w):
+    from torch.distributed import distributed_c10d
+    return distributed_c10d._get_default_store()
+
+
+def agree_on_stuck(w, stuck, patience_s, store=None):
+    """Every rank publishes whether its side-leg thread is still alive; returns the sorted list of stuck ranks as every rank sees it.
+    A rank that never publishes (dead, or hung before this point) counts as stuck.  Keys live in the rendezvous store: no collective."""
+    import datetime
+    store = store or _store(w)
+    store.set(f"mvfx_side_stuck_{w.rank}", "1" if stuck else "0")
+    bad = []
+    for r in range(w.world):
+        try:
+            store.wait([f"mvfx_side_stuck_{r}"], datetime.timedelta(seconds=max(5.0, min(60.0, patience_s))))
+            if store.get(f"mvfx_side_stuck_{r}") != b"0":
+                bad.append(r)
+        except Exception:  # noqa: BLE001  (timeout: the rank never arrived)
+            bad.append(r)
+    return bad
+
+
+def mark_emitted(w, store=None):
+    try:
+        (store or _store(w)).set("mvfx_side_emitted", "1")
+    except Exception:  # noqa: BLE001
+        pass
+
+
+def wait_emitted(w, seconds, store=None):
+    """ranks other than 0 hold their non-zero exit until rank 0 has printed: a launcher ends every rank at the first failure"""
+    import datetime
+    try:
+        (store or _store(w)).wait(["mvfx_side_emitted"], datetime.timedelta(seconds=seconds))
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def gst_pipeline_leg(args):

@@ -110,3 +110,57 @@ def test_a_failed_side_leg_is_a_small_error_line(tmp_path, capsys, monkeypatch):
     bench.emit(doc, [("videofx", {"error": "RuntimeError: " + "y" * 5000})])
     lines = capsys.readouterr().out.strip().splitlines()
     assert len(lines) == 2 and len(lines[0]) < 1000 and json.loads(lines[0])["sub"] == "videofx" and len(lines[1]) < 3000
+
+
+def test_a_hung_side_leg_fails_the_run_and_ends_the_survivors():
+    """a rank stuck in the collective is a failure.  Rank 0 prints its line and leaves non-zero; the parent relays the
+    line, ends the hung rank (exactly the PID it started) and exits non-zero itself."""
+    r, dt = _run("stuck-side-leg", 2, 2)
+    assert r.returncode != 0 and "worker(s) failed" in r.stderr and "(0, 5)" in r.stderr
+    assert json.loads(r.stdout.strip().splitlines()[-1])["config"]["error"] == "side leg stuck"
+    assert dt < 60
+
+
+def test_ranks_agree_on_who_is_stuck_without_a_collective():
+    """bench.agree_on_stuck: flags over the rendezvous store; a rank that never reports counts as stuck"""
+    sys.path.insert(0, ROOT)
+    import threading
+    import torch.distributed as dist
+    import bench
+    store = dist.HashStore()
+    res = {}
+
+    def rank(r, stuck):
+        res[r] = bench.agree_on_stuck(argparse.Namespace(rank=r, world=3), stuck, 5.0, store=store)
+
+    ths = [threading.Thread(target=rank, args=(r, r == 1)) for r in range(3)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert res == {0: [1], 1: [1], 2: [1]}
+    store = dist.HashStore()
+    res.clear()
+    ths = [threading.Thread(target=rank, args=(r, False)) for r in (0, 2)]  # rank 1 never arrives
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert res == {0: [1], 2: [1]}
+    store = dist.HashStore()
+    assert bench.agree_on_stuck(argparse.Namespace(rank=0, world=1), False, 5.0, store=store) == []
+    bench.mark_emitted(None, store=store)
+    t0 = time.time()
+    bench.wait_emitted(None, 5.0, store=store)
+    assert time.time() - t0 < 2
+
+
+def test_final_line_sheds_instead_of_asserting(tmp_path, capsys, monkeypatch):
+    """advisor r4: a line that is still too long after the first shedding must come out shorter, not as an AssertionError"""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "FULL_DOC", str(tmp_path / "last_run.json"))
+    doc = _fat_document()
+    doc["config"]["workload"] = "w" * 4000
+    doc["config"]["rccl_ranks"] = 8
+    bench.emit(doc, [])
+    last = capsys.readouterr().out.strip().splitlines()[-1]
+    assert len(last) <= 3000
+    d = json.loads(last)
+    assert d["metric"] == doc["metric"] and d["value"] > 0 and d["config"]["full_document"]
