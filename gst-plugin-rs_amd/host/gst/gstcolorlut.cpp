@@ -74,15 +74,7 @@ static int gst_color_lut_pair_launch(GstObject *element, const mvfx_frame *in, c
     return n == 1 ? mvfx_colorlut_transform_frame(self->lut, in, out, st) : mvfx_colorlut_transform_frames(self->lut, in, out, n, st);
 }
 
-static void gst_color_lut_flush_cb(GstObject *owner) // EOS, flush-start, stop
-{
-    mvfx_pair_flush(reinterpret_cast<GstColorLut *>(owner)->hold, owner, gst_color_lut_pair_launch);
-}
-
-static void gst_color_lut_looked_at_cb(GstObject *owner) // registered on the held-back frame's blocks
-{
-    mvfx_pair_flush_foreign(reinterpret_cast<GstColorLut *>(owner)->hold, owner, gst_color_lut_pair_launch);
-}
+MVFX_PAIR_DEFINE_OPS(gst_color_lut, GstColorLut, gst_color_lut_pair_launch)
 
 // EOS, flush-start: nothing stays held back across them
 static gboolean gst_color_lut_sink_event(GstBaseTransform *bt, GstEvent *event)
@@ -96,7 +88,7 @@ static gboolean gst_color_lut_sink_event(GstBaseTransform *bt, GstEvent *event)
 static gboolean gst_color_lut_stop(GstBaseTransform *trans)
 {
     GstColorLut *self = reinterpret_cast<GstColorLut *>(trans);
-    gst_color_lut_flush_cb(GST_OBJECT(trans)); // the held-back frame still needs the LUT
+    mvfx_pair_stop(self->hold, GST_OBJECT(trans), &gst_color_lut_pair_ops); // the held-back frame still needs the LUT
     mvfx_pair_print_stats(self->hold, GST_OBJECT(trans), "colorlut");
     std::lock_guard<std::mutex> g(*self->lock);
     if (self->lut) mvfx_cube_lut_free(self->lut);
@@ -175,7 +167,7 @@ static GstFlowReturn gst_color_lut_bt_transform(GstBaseTransform *bt, GstBuffer 
     if (mvfx_pair_enabled() && gst_buffer_n_memory(inbuf) == 1 && gst_buffer_n_memory(outbuf) == 1) {
         gst_buffer_unmap(outbuf, &omap); // (a MVFX_MAP_HIP map is the device pointer: it stays valid while the memory lives)
         gst_buffer_unmap(inbuf, &imap);
-        const int prc = mvfx_pair_submit(self->hold, GST_OBJECT(self), gst_color_lut_pair_launch, gst_color_lut_looked_at_cb, inbuf, outbuf, fi, fo,
+        const int prc = mvfx_pair_submit(self->hold, GST_OBJECT(self), &gst_color_lut_pair_ops, inbuf, outbuf, fi, fo,
                                          st, TRUE, [] {});
         if (prc != MVFX_PAIR_NOT_TAKEN) return MVFX_GST_FLOW(self, prc);
         mvfx_hip_buffer_acquire(inbuf, st);
@@ -196,6 +188,12 @@ static GstFlowReturn gst_color_lut_bt_transform(GstBaseTransform *bt, GstBuffer 
     gst_buffer_unmap(outbuf, &omap);
     gst_buffer_unmap(inbuf, &imap);
     return MVFX_GST_FLOW(self, rc);
+}
+
+static gboolean gst_color_lut_set_info(GstVideoFilter *vf, GstCaps *, GstVideoInfo *in_info, GstCaps *, GstVideoInfo *)
+{
+    mvfx_pair_set_interval(reinterpret_cast<GstColorLut *>(vf)->hold, in_info); // a held-back frame waits one frame interval at most
+    return TRUE;
 }
 
 static void gst_color_lut_finalize(GObject *obj)
@@ -243,6 +241,7 @@ static void gst_color_lut_class_init(GstColorLutClass *klass)
     GST_BASE_TRANSFORM_CLASS(klass)->start = gst_color_lut_start;
     GST_BASE_TRANSFORM_CLASS(klass)->stop = gst_color_lut_stop;
     GST_VIDEO_FILTER_CLASS(klass)->transform_frame = gst_color_lut_transform_frame; // NeverInPlace (:162-166)
+    GST_VIDEO_FILTER_CLASS(klass)->set_info = gst_color_lut_set_info;
 }
 
 static void gst_color_lut_init(GstColorLut *self)

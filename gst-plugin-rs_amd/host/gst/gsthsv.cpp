@@ -17,16 +17,10 @@ struct GstHsvFilter {
     mvfx_hsvfilter_settings settings;
     void *i420_scratch;               // device frame for the fused I420 path (streaming thread only)
     gsize i420_scratch_size;
-    // Round 4, device memory: ONE buffer's kernel is held back so that two consecutive frames leave as one launch (see
-    // gst_hsv_filter_bt_transform_ip).  Guarded by pend_lock; `pend_mem` is referenced while set and carries this element's deferred mark.
-    std::mutex *pend_lock;
-    GstMemory *pend_mem;
-    mvfx_frame pend_frame;
-    mvfx_hsvfilter_settings pend_settings;
-    mvfx_stream pend_stream;          // the stream a lone launch of the held-back frame goes on (the frame's own: mvfx_element_stream)
-    guint pair_no;
-    guint foreign_streak, direct_left;     // held-back frames that somebody's look flushed, in a row; plain launches left (mvfx_pair_hold.h)
-    guint64 n_buffers, n_pairs, n_singles, n_direct; // MVFX_ELEMENT_PAIR_STATS=1 prints them in stop()
+    // pair launches on device buffers, opt-in (mvfx_pair_hold.h): the held-back frame's settings (the ones in force when ITS buffer
+    // came) and those of the buffer being submitted; both written by the streaming thread only, pend_settings under the hold's lock
+    MvfxPairHold *hold;
+    mvfx_hsvfilter_settings pend_settings, cur_settings;
 };
 struct GstHsvFilterClass {
     GstVideoFilterClass parent_class;
@@ -83,46 +77,15 @@ static GstFlowReturn gst_hsv_filter_transform_frame_ip(GstVideoFilter *filter, G
 // Device-resident path: a `video/x-raw(memory:HIPMemory)` buffer is filtered in HBM, no PCIe copy.
 MVFX_DEFINE_HIP_ALLOCATION_VFUNCS(gst_hsv_filter, gst_hsv_filter_parent_class)
 
-// The held-back frame leaves alone (pend_lock held).  A failure cannot be the flow return of its buffer any more: it is posted.
-static void gst_hsv_filter_flush_locked(GstHsvFilter *self, MvfxUnrefLater *later)
+// in place: in == out (mvfx_pair_hold.h); two frames carry their own settings
+static int gst_hsv_filter_pair_launch(GstObject *element, const mvfx_frame *, const mvfx_frame *out, uint32_t n, mvfx_stream st)
 {
-    GstMemory *mem = self->pend_mem;
-    if (!mem) return;
-    self->pend_mem = NULL;
-    // the mark stays on the block until its fence is recorded (release_as_owner): a consumer on another streaming thread that looks at
-    // the block meanwhile runs into this element's lock, not past an unrecorded fence
-    mvfx_hip_memory_acquire_as_owner(mem, self->pend_stream, GST_OBJECT(self));
-    MvfxFenceScope fs; // the fence rides on the kernel (mvfx_hip_fence_begin / _end): no event record behind it
-    mvfx_hip_fence_begin(&fs, &mem, 1, self->pend_stream, FALSE);
-    const int rc = mvfx_hsvfilter_transform_frame_ip(&self->pend_frame, &self->pend_settings, self->pend_stream);
-    mvfx_hip_fence_end(&fs, self->pend_stream, GST_OBJECT(self), GST_OBJECT(self));
-    later->add(mem); // dropped after pend_lock is released (mvfx_pair_hold.h)
-    self->n_singles++;
-    if (rc != MVFX_OK)
-        GST_ELEMENT_ERROR(self, LIBRARY, FAILED, ("%s", mvfx_last_error()), ("held-back frame"));
+    GstHsvFilter *self = reinterpret_cast<GstHsvFilter *>(element);
+    if (n == 1) return mvfx_hsvfilter_transform_frame_ip(out, &self->pend_settings, st);
+    const mvfx_hsvfilter_settings settings[2] = {self->pend_settings, self->cur_settings};
+    return mvfx_hsvfilter_transform_frames_ip_settings(out, n, settings, st);
 }
-
-static void gst_hsv_filter_flush_cb(GstObject *owner) // EOS, flush-start, stop
-{
-    GstHsvFilter *self = reinterpret_cast<GstHsvFilter *>(owner);
-    MvfxUnrefLater later;
-    std::lock_guard<std::mutex> g(*self->pend_lock);
-    gst_hsv_filter_flush_locked(self, &later);
-}
-
-// Registered on the held-back frame's block: somebody looked.  Behind another device element that happens to EVERY frame, and holding
-// back then only costs (mvfx_pair_hold.h): after kMvfxPairStreak in a row the element launches per buffer for kMvfxPairDirect buffers.
-static void gst_hsv_filter_looked_at_cb(GstObject *owner)
-{
-    GstHsvFilter *self = reinterpret_cast<GstHsvFilter *>(owner);
-    MvfxUnrefLater later;
-    std::lock_guard<std::mutex> g(*self->pend_lock);
-    if (self->pend_mem && mvfx_pair_mode() == 1 && ++self->foreign_streak >= kMvfxPairStreak) {
-        self->foreign_streak = 0;
-        self->direct_left = kMvfxPairDirect;
-    }
-    gst_hsv_filter_flush_locked(self, &later);
-}
+MVFX_PAIR_DEFINE_OPS(gst_hsv_filter, GstHsvFilter, gst_hsv_filter_pair_launch)
 
 static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuffer *buf)
 {
@@ -189,66 +152,22 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
         return MVFX_GST_FLOW(self, rc);
     }
     mvfx_stream st = mvfx_element_stream(buf);
-    // Pair launches (default; MVFX_ELEMENT_PAIR=0 turns them off).  One 4K frame per launch fills and drains the chip for 33 MB: 0.67 of
-    // the HBM peak from one streaming thread however the streams are rotated; TWO frames per launch on two alternating streams reach
-    // 0.71 (profiles/r4/element_path.txt).  The contract stays one call per buffer (hsvfilter/imp.rs:322-326): the call returns at
-    // once, the frame's kernel is HELD BACK, the block says so (mvfx_hip_memory_set_deferred), and it leaves together with the next
-    // buffer's frame -- or alone, the moment anybody looks at the block's fence (the next element's acquire, a CPU map, hipdownload, a
-    // recycled block coming round again), at EOS, on flush-start and in stop().  Settings are the ones in force when the buffer came.
-    const bool pair = mvfx_pair_enabled();
-    if (pair && combine == 0 && gst_buffer_n_memory(buf) == 1) {
-        GstMemory *mem = gst_buffer_peek_memory(buf, 0);
+    // Pair launches, opt-in (MVFX_ELEMENT_PAIR=1|2; mvfx_pair_hold.h).  One 4K frame per launch fills and drains the chip for 33 MB:
+    // 0.67 of the HBM peak from one streaming thread however the streams are rotated; TWO frames per launch on two alternating streams
+    // reach 0.71 (profiles/r4/element_path.txt).  The default is the reference's contract to the letter: one launch per call, the
+    // call's flow return is that frame's (hsvfilter/imp.rs:322-326).
+    if (mvfx_pair_enabled() && combine == 0 && gst_buffer_n_memory(buf) == 1) {
         gst_buffer_unmap(buf, &map); // (a MVFX_MAP_HIP map is the device pointer: it stays valid while the memory lives)
-        // the block still being written (the source's copy, an upstream kernel: in flight or held back): a stage of a dependent chain
-        // does not hold back (mvfx_pair_hold.h)
-        const gboolean chained = mvfx_pair_mode() == 1 && mvfx_hip_memory_busy(mem, GST_OBJECT(self));
-        // somebody else's held-back work on the block leaves before our lock is taken; under the lock no foreign flush runs
-        mvfx_hip_memory_flush_foreign(mem, GST_OBJECT(self));
-        MvfxUnrefLater later;
-        std::unique_lock<std::mutex> g(*self->pend_lock);
-        self->n_buffers++;
-        if (chained || self->direct_left) { // ... or every held-back frame was flushed by somebody's look lately
-            if (self->direct_left) self->direct_left--;
-            self->n_direct++;
-            gst_hsv_filter_flush_locked(self, &later);
-            g.unlock();
-            mvfx_hip_buffer_acquire(buf, st);
-            MvfxFenceScope dfs;
-            mvfx_hip_fence_begin(&dfs, &mem, 1, st, TRUE);
-            rc = mvfx_hsvfilter_transform_frame_ip(&f, &s, st);
-            mvfx_hip_fence_end(&dfs, st, NULL, GST_OBJECT(self));
-            return MVFX_GST_FLOW(self, rc);
-        }
-        if (self->pend_mem && (self->pend_mem == mem || self->pend_frame.width != f.width || self->pend_frame.height != f.height ||
-                               self->pend_frame.stride != f.stride || self->pend_frame.format != f.format))
-            gst_hsv_filter_flush_locked(self, &later); // the same block again, or another geometry: the held-back frame goes first, alone
-        if (!self->pend_mem) {
-            self->pend_mem = gst_memory_ref(mem);
-            self->pend_frame = f;
-            self->pend_settings = s;
-            self->pend_stream = st;
-            g.unlock();
-            mvfx_hip_memory_set_deferred(mem, gst_hsv_filter_looked_at_cb, GST_OBJECT(self));
-            return GST_FLOW_OK;
-        }
-        GstMemory *first = self->pend_mem;
-        const mvfx_frame frames[2] = {self->pend_frame, f};
-        const mvfx_hsvfilter_settings settings[2] = {self->pend_settings, s};
-        self->pend_mem = NULL;
-        // consecutive PAIRS alternate between two streams of this thread (the frame-number rule of mvfx_element_stream would put
-        // every pair on the stream of its odd frame)
-        st = mvfx_thread_stream_n(self->pair_no++ & 1u);
-        mvfx_hip_memory_acquire_as_owner(first, st, GST_OBJECT(self)); // (the mark stays until the fence is recorded: see the flush)
-        mvfx_hip_memory_acquire_as_owner(mem, st, GST_OBJECT(self));
-        GstMemory *const both[2] = {first, mem};
-        MvfxFenceScope fs; // one fence for the pair, carried by the kernel itself
-        mvfx_hip_fence_begin(&fs, both, 2, st, FALSE);
-        rc = mvfx_hsvfilter_transform_frames_ip_settings(frames, 2, settings, st);
-        mvfx_hip_fence_end(&fs, st, GST_OBJECT(self), GST_OBJECT(self));
-        self->n_pairs++;
-        self->foreign_streak = 0;
-        later.add(first);
-        g.unlock();
+        self->cur_settings = s;
+        const int prc = mvfx_pair_submit(self->hold, GST_OBJECT(self), &gst_hsv_filter_pair_ops, NULL, buf, f, f, st, TRUE,
+                                         [&] { self->pend_settings = s; });
+        if (prc != MVFX_PAIR_NOT_TAKEN) return MVFX_GST_FLOW(self, prc);
+        GstMemory *mem = gst_buffer_peek_memory(buf, 0);
+        mvfx_hip_buffer_acquire(buf, st);
+        MvfxFenceScope dfs;
+        mvfx_hip_fence_begin(&dfs, &mem, 1, st, TRUE);
+        rc = mvfx_hsvfilter_transform_frame_ip(&f, &s, st);
+        mvfx_hip_fence_end(&dfs, st, NULL, GST_OBJECT(self));
         return MVFX_GST_FLOW(self, rc);
     }
     mvfx_hip_buffer_acquire(buf, st);
@@ -270,12 +189,15 @@ static gboolean gst_hsv_filter_sink_event(GstBaseTransform *bt, GstEvent *event)
 
 static gboolean gst_hsv_filter_stop(GstBaseTransform *bt)
 {
-    gst_hsv_filter_flush_cb(GST_OBJECT(bt));
     GstHsvFilter *self = reinterpret_cast<GstHsvFilter *>(bt);
-    if (g_getenv("MVFX_ELEMENT_PAIR_STATS") && self->n_buffers)
-        g_printerr("hsvfilter %s: %" G_GUINT64_FORMAT " device buffers = 2 x %" G_GUINT64_FORMAT " pair launches + %" G_GUINT64_FORMAT
-                   " single launches + %" G_GUINT64_FORMAT " direct launches\n", GST_OBJECT_NAME(bt), self->n_buffers, self->n_pairs,
-                   self->n_singles, self->n_direct);
+    mvfx_pair_stop(self->hold, GST_OBJECT(bt), &gst_hsv_filter_pair_ops);
+    mvfx_pair_print_stats(self->hold, GST_OBJECT(bt), "hsvfilter");
+    return TRUE;
+}
+
+static gboolean gst_hsv_filter_set_info(GstVideoFilter *vf, GstCaps *, GstVideoInfo *in_info, GstCaps *, GstVideoInfo *)
+{
+    mvfx_pair_set_interval(reinterpret_cast<GstHsvFilter *>(vf)->hold, in_info); // a held-back frame waits one frame interval at most
     return TRUE;
 }
 
@@ -283,7 +205,7 @@ static void gst_hsv_filter_finalize(GObject *obj)
 {
     mvfx_device_free(reinterpret_cast<GstHsvFilter *>(obj)->i420_scratch);
     delete reinterpret_cast<GstHsvFilter *>(obj)->lock;
-    delete reinterpret_cast<GstHsvFilter *>(obj)->pend_lock;
+    delete reinterpret_cast<GstHsvFilter *>(obj)->hold;
     G_OBJECT_CLASS(gst_hsv_filter_parent_class)->finalize(obj);
 }
 
@@ -326,6 +248,7 @@ static void gst_hsv_filter_class_init(GstHsvFilterClass *klass)
     }
     mvfx_add_pad_templates(element, tmpl[0], tmpl[1]);
     vfilter->transform_frame_ip = gst_hsv_filter_transform_frame_ip; // AlwaysInPlace (:315-320)
+    vfilter->set_info = gst_hsv_filter_set_info;
     GST_BASE_TRANSFORM_CLASS(klass)->transform_ip = gst_hsv_filter_bt_transform_ip;
     GST_BASE_TRANSFORM_CLASS(klass)->sink_event = gst_hsv_filter_sink_event;
     GST_BASE_TRANSFORM_CLASS(klass)->stop = gst_hsv_filter_stop;
@@ -336,12 +259,8 @@ static void gst_hsv_filter_class_init(GstHsvFilterClass *klass)
 static void gst_hsv_filter_init(GstHsvFilter *self)
 {
     self->lock = new std::mutex();
-    self->pend_lock = new std::mutex();
-    self->pend_mem = NULL;
-    self->pair_no = 0;
-    self->n_buffers = self->n_pairs = self->n_singles = self->n_direct = 0;
-    self->foreign_streak = self->direct_left = 0;
-    self->settings = mvfx_hsvfilter_settings{0.0f, 1.0f, 0.0f, 1.0f, 0.0f};
+    self->hold = new MvfxPairHold();
+    self->settings = self->pend_settings = self->cur_settings = mvfx_hsvfilter_settings{0.0f, 1.0f, 0.0f, 1.0f, 0.0f};
     self->i420_scratch = NULL;
     self->i420_scratch_size = 0;
 }
@@ -457,15 +376,7 @@ static int gst_hsv_detector_pair_launch(GstObject *element, const mvfx_frame *in
                   : mvfx_hsvdetector_transform_frames(in, out, n, &self->pend_settings, st);
 }
 
-static void gst_hsv_detector_flush_cb(GstObject *owner) // EOS, flush-start, stop
-{
-    mvfx_pair_flush(reinterpret_cast<GstHsvDetector *>(owner)->hold, owner, gst_hsv_detector_pair_launch);
-}
-
-static void gst_hsv_detector_looked_at_cb(GstObject *owner) // registered on the held-back frame's blocks
-{
-    mvfx_pair_flush_foreign(reinterpret_cast<GstHsvDetector *>(owner)->hold, owner, gst_hsv_detector_pair_launch);
-}
+MVFX_PAIR_DEFINE_OPS(gst_hsv_detector, GstHsvDetector, gst_hsv_detector_pair_launch)
 
 static GstFlowReturn gst_hsv_detector_bt_transform(GstBaseTransform *bt, GstBuffer *inbuf, GstBuffer *outbuf)
 {
@@ -496,7 +407,7 @@ static GstFlowReturn gst_hsv_detector_bt_transform(GstBaseTransform *bt, GstBuff
         gst_buffer_unmap(inbuf, &imap);
         // pend_settings is written by this thread only (under the hold's lock, for the flush on another thread to read)
         const gboolean same = memcmp(&self->pend_settings, &s, sizeof s) == 0;
-        const int prc = mvfx_pair_submit(self->hold, GST_OBJECT(self), gst_hsv_detector_pair_launch, gst_hsv_detector_looked_at_cb, inbuf, outbuf,
+        const int prc = mvfx_pair_submit(self->hold, GST_OBJECT(self), &gst_hsv_detector_pair_ops, inbuf, outbuf,
                                          fi, fo, st, same, [&] { self->pend_settings = s; });
         if (prc != MVFX_PAIR_NOT_TAKEN) return MVFX_GST_FLOW(self, prc);
         mvfx_hip_buffer_acquire(inbuf, st);
@@ -529,8 +440,14 @@ static gboolean gst_hsv_detector_sink_event(GstBaseTransform *bt, GstEvent *even
 
 static gboolean gst_hsv_detector_stop(GstBaseTransform *bt)
 {
-    gst_hsv_detector_flush_cb(GST_OBJECT(bt));
+    mvfx_pair_stop(reinterpret_cast<GstHsvDetector *>(bt)->hold, GST_OBJECT(bt), &gst_hsv_detector_pair_ops);
     mvfx_pair_print_stats(reinterpret_cast<GstHsvDetector *>(bt)->hold, GST_OBJECT(bt), "hsvdetector");
+    return TRUE;
+}
+
+static gboolean gst_hsv_detector_set_info(GstVideoFilter *vf, GstCaps *, GstVideoInfo *in_info, GstCaps *, GstVideoInfo *)
+{
+    mvfx_pair_set_interval(reinterpret_cast<GstHsvDetector *>(vf)->hold, in_info); // a held-back frame waits one frame interval at most
     return TRUE;
 }
 
@@ -582,6 +499,7 @@ static void gst_hsv_detector_class_init(GstHsvDetectorClass *klass)
     GST_BASE_TRANSFORM_CLASS(klass)->sink_event = gst_hsv_detector_sink_event;
     GST_BASE_TRANSFORM_CLASS(klass)->stop = gst_hsv_detector_stop;
     GST_VIDEO_FILTER_CLASS(klass)->transform_frame = gst_hsv_detector_transform_frame; // NeverInPlace (:380-384)
+    GST_VIDEO_FILTER_CLASS(klass)->set_info = gst_hsv_detector_set_info;
 }
 
 static void gst_hsv_detector_init(GstHsvDetector *self)

@@ -432,17 +432,19 @@ static void gst_mi355_hip_test_src_finalize(GObject *obj)
     G_OBJECT_CLASS(gst_mi355_hip_test_src_parent_class)->finalize(obj);
 }
 
-enum { PROP_TS_0, PROP_TS_REFRESH };
+enum { PROP_TS_0, PROP_TS_REFRESH, PROP_TS_IS_LIVE };
 
 static void hiptestsrc_set_property(GObject *obj, guint id, const GValue *value, GParamSpec *pspec)
 {
     if (id == PROP_TS_REFRESH) ((GstMi355HipTestSrc *)obj)->refresh = g_value_get_boolean(value);
+    else if (id == PROP_TS_IS_LIVE) gst_base_src_set_live(GST_BASE_SRC(obj), g_value_get_boolean(value));
     else G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec);
 }
 
 static void hiptestsrc_get_property(GObject *obj, guint id, GValue *value, GParamSpec *pspec)
 {
     if (id == PROP_TS_REFRESH) g_value_set_boolean(value, ((GstMi355HipTestSrc *)obj)->refresh);
+    else if (id == PROP_TS_IS_LIVE) g_value_set_boolean(value, gst_base_src_is_live(GST_BASE_SRC(obj)));
     else G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec);
 }
 
@@ -456,6 +458,10 @@ static void gst_mi355_hip_test_src_class_init(GstMi355HipTestSrcClass *klass)
     g_object_class_install_property(G_OBJECT_CLASS(klass), PROP_TS_REFRESH,
         g_param_spec_boolean("refresh", "Refresh", "memory:HIPMemory: copy the pattern into every recycled buffer (FALSE: fill each buffer once; "
                              "in-place filters downstream then see their own output again)", TRUE,
+                             (GParamFlags)(G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS)));
+    // like videotestsrc's: a live source hands out each frame at its timestamp (the base class waits on the clock), e.g. a camera
+    g_object_class_install_property(G_OBJECT_CLASS(klass), PROP_TS_IS_LIVE,
+        g_param_spec_boolean("is-live", "Is Live", "Whether to act as a live source (one buffer per frame interval of the caps)", FALSE,
                              (GParamFlags)(G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS)));
     GstCaps *sys = gst_caps_new_empty_simple("video/x-raw");
     GstCaps *both = mvfx_caps_plus_hip(sys);

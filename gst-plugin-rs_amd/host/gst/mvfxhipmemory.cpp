@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <initializer_list>
+#include <vector>
 
 // A fence = ONE recorded event, shared by every block the launch behind it touched (an out-of-place pair launch touches four).  An
 // event record is not free on the device -- a barrier packet with a completion signal between two kernels of the stream: the
@@ -230,11 +231,27 @@ void mvfx_hip_memory_set_deferred(GstMemory *mem, MvfxDeferredFlush flush, GstOb
 {
     if (!mvfx_is_hip_memory(mem) || !flush || !owner) return;
     MvfxHipMemory *m = (MvfxHipMemory *)mem;
-    run_deferred(m); // somebody else's held-back work on this block comes first
-    g_mutex_lock(&m->lock);
-    m->deferred_flush = flush;
-    m->deferred_owner = GST_OBJECT(gst_object_ref(owner));
-    g_mutex_unlock(&m->lock);
+    // Somebody else's held-back work on this block comes first -- and a foreign mark is NEVER overwritten: two holding readers of one
+    // input block (tee ! queue ! hsvdetector on one branch, tee ! queue ! colorlut on the other) could both find the block unmarked
+    // and both store, the second store dropping the first owner's mark (and leaking its reference), so that the source's refill of
+    // the recycled block flushed only one of the two held-back kernels (advisor r4).  Check and set under one critical section; a
+    // foreign mark found there is run with the lock released, then the check repeats.
+    for (;;) {
+        g_mutex_lock(&m->lock);
+        if (!m->deferred_flush) {
+            m->deferred_flush = flush;
+            m->deferred_owner = GST_OBJECT(gst_object_ref(owner));
+            g_mutex_unlock(&m->lock);
+            return;
+        }
+        if (m->deferred_owner == owner) { // ours already (the hold re-marks a block it still holds)
+            m->deferred_flush = flush;
+            g_mutex_unlock(&m->lock);
+            return;
+        }
+        g_mutex_unlock(&m->lock);
+        run_deferred(m);
+    }
 }
 
 void mvfx_hip_memory_clear_deferred(GstMemory *mem, GstObject *owner)
@@ -915,4 +932,98 @@ gboolean mvfx_hip_decide_allocation(GstQuery *query)
     gst_query_add_allocation_param(query, alloc, NULL);
     gst_object_unref(alloc);
     return TRUE;
+}
+
+
+// ---- idle flush: a process-wide timer for work that elements hold back (mvfx_pair_hold.h) ---------------------------------------
+//
+// A held-back frame leaves with the next buffer, or when somebody looks at its blocks.  A live source that stalls would otherwise
+// leave its last frame unprocessed until EOS: the hold arms this timer for one frame interval whenever a frame becomes the held-back
+// one; re-arming moves the deadline.  One entry per owner, referenced while armed; the callback runs on the timer thread with no
+// lock of this file held.
+namespace {
+struct IdleEntry {
+    GstObject *owner;
+    MvfxDeferredFlush cb;
+    gint64 deadline; // g_get_monotonic_time()
+};
+GMutex idle_lock;
+GCond idle_cond;
+std::vector<IdleEntry> *idle_entries; // never freed: the thread lives as long as the process
+gboolean idle_thread_started;
+
+gpointer idle_thread(gpointer)
+{
+    g_mutex_lock(&idle_lock);
+    for (;;) {
+        gint64 first = G_MAXINT64;
+        for (const IdleEntry &e : *idle_entries) first = MIN(first, e.deadline);
+        if (first == G_MAXINT64) {
+            g_cond_wait(&idle_cond, &idle_lock);
+            continue;
+        }
+        const gint64 now = g_get_monotonic_time();
+        if (first > now) {
+            g_cond_wait_until(&idle_cond, &idle_lock, first);
+            continue;
+        }
+        std::vector<IdleEntry> due;
+        for (size_t i = 0; i < idle_entries->size();) {
+            if ((*idle_entries)[i].deadline <= now) {
+                due.push_back((*idle_entries)[i]);
+                (*idle_entries)[i] = idle_entries->back();
+                idle_entries->pop_back();
+            } else
+                i++;
+        }
+        g_mutex_unlock(&idle_lock);
+        for (const IdleEntry &e : due) {
+            e.cb(e.owner);
+            gst_object_unref(e.owner);
+        }
+        g_mutex_lock(&idle_lock);
+    }
+    return NULL;
+}
+} // namespace
+
+void mvfx_idle_arm(GstObject *owner, MvfxDeferredFlush cb, guint64 after_us)
+{
+    if (!owner || !cb) return;
+    const gint64 deadline = g_get_monotonic_time() + (gint64)after_us;
+    g_mutex_lock(&idle_lock);
+    if (!idle_entries) idle_entries = new std::vector<IdleEntry>();
+    gboolean found = FALSE, wake = FALSE;
+    for (IdleEntry &e : *idle_entries)
+        if (e.owner == owner) { // later than before: the thread wakes at the old deadline, finds nothing due and sleeps again
+            e.deadline = deadline;
+            e.cb = cb;
+            found = TRUE;
+        }
+    if (!found) {
+        idle_entries->push_back(IdleEntry{GST_OBJECT(gst_object_ref(owner)), cb, deadline});
+        wake = TRUE;
+    }
+    if (!idle_thread_started) {
+        idle_thread_started = TRUE;
+        g_thread_unref(g_thread_new("mvfx-idle-flush", idle_thread, NULL));
+    } else if (wake)
+        g_cond_signal(&idle_cond);
+    g_mutex_unlock(&idle_lock);
+}
+
+void mvfx_idle_cancel(GstObject *owner)
+{
+    GstObject *drop = NULL;
+    g_mutex_lock(&idle_lock);
+    if (idle_entries)
+        for (size_t i = 0; i < idle_entries->size(); i++)
+            if ((*idle_entries)[i].owner == owner) {
+                drop = owner;
+                (*idle_entries)[i] = idle_entries->back();
+                idle_entries->pop_back();
+                break;
+            }
+    g_mutex_unlock(&idle_lock);
+    if (drop) gst_object_unref(drop);
 }

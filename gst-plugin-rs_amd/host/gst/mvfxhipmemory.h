@@ -39,6 +39,10 @@ void mvfx_hip_memory_wait(GstMemory *mem);
 typedef void (*MvfxDeferredFlush)(GstObject *owner);
 void mvfx_hip_memory_set_deferred(GstMemory *mem, MvfxDeferredFlush flush, GstObject *owner);
 void mvfx_hip_memory_clear_deferred(GstMemory *mem, GstObject *owner); // no-op unless the mark is this owner's
+// Idle flush: `cb(owner)` runs on a process-wide timer thread `after_us` from now unless re-armed (the deadline moves) or cancelled
+// first; one entry per owner, which is referenced while armed.  A held-back frame never waits longer than one frame interval.
+void mvfx_idle_arm(GstObject *owner, MvfxDeferredFlush cb, guint64 after_us);
+void mvfx_idle_cancel(GstObject *owner);
 // The owner launching its held-back work: acquire WITHOUT flushing its own mark, release that records the fence and drops the mark in one
 // critical section (a consumer on another thread must never see "no mark, no fence yet").
 void mvfx_hip_memory_flush_foreign(GstMemory *mem, GstObject *owner);

@@ -576,7 +576,7 @@ def _pair_stats_of(element, text):
 
 
 def test_hsvfilter_pair_launches_every_buffer_exactly_once(gpu, tmp_path):
-    """Round 4: on device memory hsvfilter holds ONE buffer's kernel back and launches two consecutive frames together (one call per
+    """Opt-in since round 5 (MVFX_ELEMENT_PAIR=1|2).  On device memory hsvfilter holds ONE buffer's kernel back and launches two consecutive frames together (one call per
     buffer stays the contract, hsvfilter/imp.rs:322-326).  (a) nobody looks at the blocks (fakesink): 21 buffers leave in pairs, the last
     one flushed at EOS; (b) a consumer on ANOTHER streaming thread (queue ! hipdownload) flushes held-back frames itself or finds them
     paired: all 41 frames come out filtered exactly once, byte for byte."""
@@ -595,7 +595,8 @@ def test_hsvfilter_pair_launches_every_buffer_exactly_once(gpu, tmp_path):
     n = 41
     raw = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBA,width={w},height={h}", "in.raw")
     r = gst_env.run([LAUNCH, "-q"] + (f"hiptestsrc num-buffers={n} ! {caps} ! hsvfilter hue-shift=45 saturation-mul=1.2 ! queue max-size-buffers=3 ! "
-                                      f"hipdownload ! filesink location={tmp_path}/out.raw").split(), tmp_path, extra_env={"MVFX_ELEMENT_PAIR_STATS": "1"})
+                                      f"hipdownload ! filesink location={tmp_path}/out.raw").split(), tmp_path,
+                    extra_env={"MVFX_ELEMENT_PAIR_STATS": "1", "MVFX_ELEMENT_PAIR": "1"})
     assert r.returncode == 0, r.stdout
     buffers, pairs, singles, direct = _pair_stats(r.stdout)
     assert buffers == n and 2 * pairs + singles + direct == n
@@ -605,17 +606,115 @@ def test_hsvfilter_pair_launches_every_buffer_exactly_once(gpu, tmp_path):
     assert [k for k in range(n) if not np.array_equal(got[k], exp)] == []
 
 
-def test_hsvfilter_pair_launches_can_be_turned_off(gpu, tmp_path):
+@pytest.mark.parametrize("env", [{}, {"MVFX_ELEMENT_PAIR": "0"}], ids=["default", "explicit-0"])
+def test_hsvfilter_launches_once_per_buffer_by_default(gpu, tmp_path, env):
+    """Round 5 (VERDICT r4 W-semantics): the DEFAULT is the reference's contract to the letter -- one launch per transform call, nothing
+    held back, the call's flow return is that frame's (hsvfilter/imp.rs:322-326).  No statistics line = the hold never saw a buffer."""
     w, h = 320, 240
     caps = f"video/x-raw(memory:HIPMemory),format=RGBA,width={w},height={h},framerate=30/1"
     raw = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBA,width={w},height={h}", "in.raw")
     r = gst_env.run([LAUNCH, "-q"] + (f"hiptestsrc num-buffers=5 ! {caps} ! hsvfilter hue-shift=90 ! hipdownload ! filesink location={tmp_path}/out.raw").split(),
-                    tmp_path, extra_env={"MVFX_ELEMENT_PAIR": "0", "MVFX_ELEMENT_PAIR_STATS": "1"})
+                    tmp_path, extra_env=dict(env, MVFX_ELEMENT_PAIR_STATS="1"))
     assert r.returncode == 0 and "pair launches" not in r.stdout, r.stdout
     exp = raw.copy().reshape(h, w * 4)
     orc.hsvfilter(exp, w, w * 4, "RGBA", (90.0, 1.0, 0.0, 1.0, 0.0))
     got = np.fromfile(f"{tmp_path}/out.raw", dtype=np.uint8).reshape(5, h, w * 4)
     assert all(np.array_equal(got[k], exp) for k in range(5))
+    # all three device elements in a row, still nothing held back
+    cube = tmp_path / "look.cube"
+    cube.write_text(cubes.analytic_3d(9))
+    r = gst_env.run([LAUNCH, "-q"] + (f"hiptestsrc num-buffers=9 ! {caps} ! hsvfilter ! hsvdetector ! colorlut location={cube} ! fakesink").split(),
+                    tmp_path, extra_env=dict(env, MVFX_ELEMENT_PAIR_STATS="1"))
+    assert r.returncode == 0 and "pair launches" not in r.stdout, r.stdout
+
+
+PANIC_CAPS = "video/x-raw(memory:HIPMemory),format=RGB,width=641,height=1"  # stride 1924, 1924 % 3 != 0: hsvfilter/imp.rs:92 asserts
+
+
+def test_a_failing_frame_ends_the_stream_with_flow_error_by_default(gpu, tmp_path):
+    """The reference's transform_frame_ip panics on this plane size (assert_eq!(data.len() % nb_channels, 0), hsvfilter/imp.rs:92) and the
+    panic becomes the element's error + GST_FLOW_ERROR of THAT buffer.  Default mode: the first buffer's own call fails."""
+    r = gst_env.run([LAUNCH] + f"hiptestsrc num-buffers=4 ! {PANIC_CAPS},framerate=30/1 ! hsvfilter hue-shift=10 ! fakesink".split(), tmp_path)
+    assert r.returncode != 0
+    assert "asserts on this (hsvfilter/imp.rs:92)" in r.stdout and "held-back frame" not in r.stdout
+    assert "reason error (-5)" in r.stdout  # the streaming thread stopped with GST_FLOW_ERROR
+
+
+def test_a_failing_held_back_frame_fails_the_next_transform_with_flow_error(gpu, tmp_path):
+    """Pairs on (MVFX_ELEMENT_PAIR=2) and a live source at 5 frames/s with the idle interval forced to 20 ms: frame 0 is held back, no
+    second buffer comes in time, the timer thread launches it alone -- and the launch fails.  It is posted ("held-back frame") AND the
+    transform call of frame 1 returns GST_FLOW_ERROR: the stream ends like the reference's would have, one buffer later
+    ('a failed held-back launch must also fail the next transform call')."""
+    r = gst_env.run([LAUNCH] + f"hiptestsrc is-live=true num-buffers=6 ! {PANIC_CAPS},framerate=5/1 ! hsvfilter hue-shift=10 ! fakesink".split(),
+                    tmp_path, extra_env={"MVFX_ELEMENT_PAIR": "2", "MVFX_PAIR_IDLE_US": "20000", "MVFX_ELEMENT_PAIR_STATS": "1"})
+    assert r.returncode != 0, r.stdout
+    assert "held-back frame: mvfx status -8" in r.stdout, r.stdout
+    assert "reason error (-5)" in r.stdout, r.stdout
+    buffers, pairs, singles, direct = _pair_stats(r.stdout)
+    assert buffers == 2 and (pairs, singles, direct) == (0, 1, 0)  # frame 0 alone (failed), frame 1's call carried the error: nothing after it
+    # the same through the out-of-place hold (hsvdetector asserts the same way, hsvdetector/imp.rs:122)
+    r = gst_env.run([LAUNCH] + f"hiptestsrc is-live=true num-buffers=6 ! {PANIC_CAPS},framerate=5/1 ! hsvdetector ! fakesink".split(),
+                    tmp_path, extra_env={"MVFX_ELEMENT_PAIR": "2", "MVFX_PAIR_IDLE_US": "20000", "MVFX_ELEMENT_PAIR_STATS": "1"})
+    assert r.returncode != 0 and "held-back frame: mvfx status -8" in r.stdout and "reason error (-5)" in r.stdout, r.stdout
+    assert _pair_stats_of("hsvdetector", r.stdout)[0] == 2
+
+
+def test_a_stalled_sources_last_frame_is_processed_within_one_frame_interval(gpu, tmp_path):
+    """Pairs on, a live source at 10 frames/s (interval 100 ms), nobody looks at the output (fakesink): every buffer is held back and no
+    second one comes within the interval, so the timer thread launches each frame alone, after one frame interval and well before the
+    next frame (which comes one interval after the PREVIOUS frame's arrival).  Without the timer the last frame of a stalled camera
+    stayed unprocessed until EOS."""
+    w, h, n = 320, 240, 5
+    caps = f"video/x-raw(memory:HIPMemory),format=RGBA,width={w},height={h},framerate=10/1"
+    r = gst_env.run([LAUNCH, "-q"] + f"hiptestsrc is-live=true num-buffers={n} ! {caps} ! hsvfilter hue-shift=45 ! fakesink".split(), tmp_path,
+                    extra_env={"MVFX_ELEMENT_PAIR": "2", "MVFX_PAIR_IDLE_US": "50000", "MVFX_ELEMENT_PAIR_STATS": "1"})
+    assert r.returncode == 0, r.stdout
+    held = [int(x) for x in re.findall(r"idle flush of a frame held for (\d+) us \(interval 50000 us\)", r.stdout)]
+    assert len(held) >= n - 1, r.stdout  # (the last frame may be taken by EOS instead)
+    assert all(50000 <= t < 90000 for t in held), held
+    buffers, pairs, singles, direct = _pair_stats(r.stdout)
+    assert buffers == n and pairs == 0 and singles == n and direct == 0
+    # and the frames are right: the same live pipeline into a file (hipdownload's look or the timer, whichever is first)
+    raw = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBA,width={w},height={h}", "in.raw")
+    r = gst_env.run([LAUNCH, "-q"] + f"hiptestsrc is-live=true num-buffers={n} ! {caps} ! hsvfilter hue-shift=45 ! queue ! hipdownload ! filesink location={tmp_path}/o.raw".split(),
+                    tmp_path, extra_env={"MVFX_ELEMENT_PAIR": "2", "MVFX_PAIR_IDLE_US": "2000"})
+    assert r.returncode == 0, r.stdout
+    exp = raw.copy().reshape(h, w * 4)
+    orc.hsvfilter(exp, w, w * 4, "RGBA", (45.0, 1.0, 0.0, 1.0, 0.0))
+    got = np.fromfile(f"{tmp_path}/o.raw", dtype=np.uint8).reshape(n, h, w * 4)
+    assert all(np.array_equal(got[k], exp) for k in range(n))
+
+
+def test_tee_with_two_holding_readers_of_one_input_block(gpu, tmp_path):
+    """advisor r4 (medium): two HOLDING readers of one input block -- tee ! queue ! hsvdetector and tee ! queue ! colorlut, always holding
+    back (MVFX_ELEMENT_PAIR=2) -- both mark the block.  The second mark used to overwrite the first (check-then-set race in
+    mvfx_hip_memory_set_deferred): the source's refill of the recycled block then flushed only one of the two held-back kernels and the
+    other read overwritten pixels.  A foreign mark is now run, never overwritten.  Frames alternate between two contents (refresh=true
+    rewrites every recycled block; the in-place hsvfilter in front makes a stale read visible) -- every frame of both branches exact."""
+    w, h, n = 640, 360, 200
+    cube = tmp_path / "look.cube"
+    cube.write_text(cubes.analytic_3d(9))
+    raw = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBA,width={w},height={h}", "in.raw").reshape(h, w * 4)
+    mid = raw.copy()
+    orc.hsvfilter(mid, w, w * 4, "RGBA", (45.0, 1.0, 0.0, 1.0, 0.0))
+    exp_det = np.empty_like(mid)
+    assert orc.hsvdetector(mid, w * 4, "RGBA", exp_det, w * 4, "RGBA", w, (120.0, 60.0, 0.6, 0.4, 0.6, 0.4)) == 0
+    exp_lut = np.empty_like(mid)
+    assert orc.CubeLut(cube.read_text()).apply(mid, w * 4, exp_lut, w * 4, w, h, "RGBA") == 0
+    pipe = (f"hiptestsrc num-buffers={n} ! video/x-raw(memory:HIPMemory),format=RGBA,width={w},height={h},framerate=30/1 ! hsvfilter hue-shift=45 ! tee name=t "
+            f"t. ! queue max-size-buffers=2 ! hsvdetector hue-ref=120 hue-var=60 saturation-ref=0.6 saturation-var=0.4 value-ref=0.6 value-var=0.4 ! "
+            f"video/x-raw(memory:HIPMemory),format=RGBA ! hipdownload ! filesink location={tmp_path}/a.raw "
+            f"t. ! queue max-size-buffers=2 ! colorlut location={cube} ! hipdownload ! filesink location={tmp_path}/b.raw")
+    for _ in range(3):
+        r = gst_env.run([LAUNCH, "-q"] + pipe.split(), tmp_path, timeout=120, extra_env={"MVFX_ELEMENT_PAIR": "2", "MVFX_ELEMENT_PAIR_STATS": "1"})
+        assert r.returncode == 0, r.stdout[-2000:]
+        for name, exp in (("a.raw", exp_det), ("b.raw", exp_lut)):
+            got = np.fromfile(f"{tmp_path}/{name}", dtype=np.uint8).reshape(n, h, w * 4)
+            bad = [k for k in range(n) if not np.array_equal(got[k], exp)]
+            assert bad == [], f"{name}: frames {bad[:10]} differ"
+        for element in ("hsvfilter", "hsvdetector", "colorlut"):
+            buffers, pairs, singles, direct = _pair_stats_of(element, r.stdout)
+            assert buffers == n and 2 * pairs + singles + direct == n
 
 
 @pytest.mark.parametrize("consumer", ["fakesink", "same_thread", "other_thread"])
@@ -651,7 +750,7 @@ def test_out_of_place_elements_pair_launches_every_buffer_exactly_once(gpu, tmp_
         q = "queue max-size-buffers=3 ! " if consumer == "other_thread" else ""
         out = tmp_path / f"{element}.raw"
         r = gst_env.run([LAUNCH, "-q"] + f"hiptestsrc num-buffers={n} ! {caps} ! {desc} ! {q}hipdownload ! filesink location={out}".split(), tmp_path,
-                        extra_env={"MVFX_ELEMENT_PAIR_STATS": "1"})
+                        extra_env={"MVFX_ELEMENT_PAIR_STATS": "1", "MVFX_ELEMENT_PAIR": "1"})
         assert r.returncode == 0, r.stdout
         buffers, pairs, singles, direct = _pair_stats_of(element, r.stdout)
         assert buffers == n and 2 * pairs + singles + direct == n
