@@ -220,7 +220,7 @@ int mvfx_videocompare_sharded_distances(mvfx_comm *comm, const mvfx_frame *bands
     // the totals of a block never exceed 765 x (w/8) x (h/8) < 2^32 for every frame a u32 block sum can describe at all
     if (int rc = mvfx_comm_allreduce(comm, sums_dev, (size_t)n_pads * 64, MVFX_DTYPE_U32, MVFX_REDUCE_SUM, stream); rc != MVFX_OK) return rc;
     const uint64_t half_block_value = (uint64_t)765 * (bands[0].width / 8) * (full_height / 8) / 2;
-    hipLaunchKernelGGL(blockhash_bits_distance_kernel, dim3(1), dim3(64 * n_pads), 0, st, sums_dev, n_pads, half_block_value, hash_dev, dist_dev);
+    MVFX_LAUNCH(blockhash_bits_distance_kernel, dim3(1), dim3(64 * n_pads), 0, st, sums_dev, n_pads, half_block_value, hash_dev, dist_dev);
     MVFX_HIP_TRY(hipGetLastError());
     uint32_t dist[kMaxShardedPads] = {};
     uint64_t hashes[kMaxShardedPads] = {};

@@ -456,10 +456,25 @@ void mvfx_hip_fence_end(MvfxFenceScope *sc, mvfx_stream stream, GstObject *owner
 {
     if (sc->n == 0) return;
     MvfxFence *f = (MvfxFence *)sc->fence;
+    // CONTRACT of every C-ABI entry called between _begin and _end: its LAST device operation is an MVFX_LAUNCH kernel on `stream`
+    // (the kernel carries the fence's event as the stop event of its dispatch packet).  An entry that ends with a hipMemcpyAsync /
+    // hipMemsetAsync, a launch on a partner stream or a raw hipLaunchKernelGGL would publish a premature fence (advisor r4).  Nothing in
+    // the type system enforces that, so MVFX_FENCE_CHECK=1 (tests/test_gst_pipelines_gpu.py runs the device chains under it) checks it
+    // at run time: once the stream has drained, a carried fence must have fired.
     const int carried = f ? mvfx_thread_clear_completion_event() : 0;
     if (f && carried <= 0 && mvfx_event_record(f->ev, stream) != MVFX_OK) {
         fence_unref(f);
         f = NULL;
+    }
+    static const gboolean check = g_getenv("MVFX_FENCE_CHECK") != NULL && atoi(g_getenv("MVFX_FENCE_CHECK")) != 0;
+    if (check && f && carried > 0) {
+        // the stream drained, so the fence must have fired (the other direction -- a fence that fires BEFORE a trailing copy of the call
+        // has finished -- cannot be seen from here; the contract above is kept by review: every entry the elements call under a fence
+        // scope ends in MVFX_LAUNCH, `grep -n hipLaunchKernelGGL csrc/` finds only the macro itself)
+        mvfx_stream_synchronize(stream);
+        if (mvfx_event_query(f->ev) != 1)
+            g_critical("MVFX_FENCE_CHECK: the fence carried by the last library call has not fired although its stream has drained: "
+                       "no kernel of the call took the completion event");
     }
     group_phase_b(sc, stream, owner, tag, f);
 }
