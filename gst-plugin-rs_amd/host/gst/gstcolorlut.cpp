@@ -169,6 +169,7 @@ static GstFlowReturn gst_color_lut_bt_transform(GstBaseTransform *bt, GstBuffer 
         gst_buffer_unmap(inbuf, &imap);
         const int prc = mvfx_pair_submit(self->hold, GST_OBJECT(self), &gst_color_lut_pair_ops, inbuf, outbuf, fi, fo,
                                          st, TRUE, [] {});
+        if (prc == MVFX_PAIR_FAILED_EARLIER) return mvfx_pair_flow_error(self->hold, GST_OBJECT(self));
         if (prc != MVFX_PAIR_NOT_TAKEN) return MVFX_GST_FLOW(self, prc);
         mvfx_hip_buffer_acquire(inbuf, st);
         mvfx_hip_buffer_acquire(outbuf, st);

@@ -161,6 +161,7 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
         self->cur_settings = s;
         const int prc = mvfx_pair_submit(self->hold, GST_OBJECT(self), &gst_hsv_filter_pair_ops, NULL, buf, f, f, st, TRUE,
                                          [&] { self->pend_settings = s; });
+        if (prc == MVFX_PAIR_FAILED_EARLIER) return mvfx_pair_flow_error(self->hold, GST_OBJECT(self));
         if (prc != MVFX_PAIR_NOT_TAKEN) return MVFX_GST_FLOW(self, prc);
         GstMemory *mem = gst_buffer_peek_memory(buf, 0);
         mvfx_hip_buffer_acquire(buf, st);
@@ -409,6 +410,7 @@ static GstFlowReturn gst_hsv_detector_bt_transform(GstBaseTransform *bt, GstBuff
         const gboolean same = memcmp(&self->pend_settings, &s, sizeof s) == 0;
         const int prc = mvfx_pair_submit(self->hold, GST_OBJECT(self), &gst_hsv_detector_pair_ops, inbuf, outbuf,
                                          fi, fo, st, same, [&] { self->pend_settings = s; });
+        if (prc == MVFX_PAIR_FAILED_EARLIER) return mvfx_pair_flow_error(self->hold, GST_OBJECT(self));
         if (prc != MVFX_PAIR_NOT_TAKEN) return MVFX_GST_FLOW(self, prc);
         mvfx_hip_buffer_acquire(inbuf, st);
         mvfx_hip_buffer_acquire(outbuf, st);

@@ -417,6 +417,17 @@ static GstFlowReturn hiptestsrc_fill(GstPushSrc *psrc, GstBuffer *buf)
     return GST_FLOW_OK;
 }
 
+// videotestsrc's: a live source waits on the clock for each buffer's timestamp (the base class does not by itself)
+static void hiptestsrc_get_times(GstBaseSrc *src, GstBuffer *buffer, GstClockTime *start, GstClockTime *end)
+{
+    *start = *end = GST_CLOCK_TIME_NONE;
+    if (!gst_base_src_is_live(src)) return;
+    const GstClockTime ts = GST_BUFFER_PTS(buffer);
+    if (!GST_CLOCK_TIME_IS_VALID(ts)) return;
+    *start = ts;
+    if (GST_CLOCK_TIME_IS_VALID(GST_BUFFER_DURATION(buffer))) *end = ts + GST_BUFFER_DURATION(buffer);
+}
+
 static gboolean hiptestsrc_start(GstBaseSrc *src)
 {
     ((GstMi355HipTestSrc *)src)->n = 0;
@@ -474,6 +485,7 @@ static void gst_mi355_hip_test_src_class_init(GstMi355HipTestSrcClass *klass)
     bs->set_caps = hiptestsrc_set_caps;
     bs->decide_allocation = hiptestsrc_decide_allocation;
     bs->start = hiptestsrc_start;
+    bs->get_times = hiptestsrc_get_times;
     GST_PUSH_SRC_CLASS(klass)->fill = hiptestsrc_fill;
 }
 

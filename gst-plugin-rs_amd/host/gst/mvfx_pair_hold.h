@@ -40,12 +40,16 @@ struct MvfxPairHold {
     guint pair_no = 0;
     guint foreign_streak = 0, direct_left = 0;  // see above
     int failed_rc = MVFX_OK;                    // a held-back frame's launch failed: sticky until stop()
+    gchar *failed_text = NULL;                  // ... and what the library said (the failure may have happened on another thread)
+    ~MvfxPairHold() { g_free(failed_text); }
     guint64 idle_us = 10000;                    // one frame interval (mvfx_pair_set_interval)
     gint64 held_since = 0;                      // g_get_monotonic_time() of the hold
     guint64 n_buffers = 0, n_pairs = 0, n_singles = 0, n_direct = 0, n_idle = 0;
 };
 constexpr guint kMvfxPairStreak = 4, kMvfxPairDirect = 1024;
 constexpr int MVFX_PAIR_NOT_TAKEN = 0x7fff0001; // mvfx_pair_submit: the caller launches this buffer itself, the plain way
+constexpr int MVFX_PAIR_FAILED_EARLIER = 0x7fff0002; // mvfx_pair_submit: a held-back frame failed after its call had returned; the caller
+                                                     // returns mvfx_pair_flow_error() -- this call carries that frame's error
 
 // Memory references dropped AFTER the element's lock is released (declare it before the lock guard): the last reference frees the
 // block, and freeing runs a stale mark's callback -- no callback of another element ever runs under this element's lock.
@@ -123,9 +127,29 @@ static inline void mvfx_pair_flush_locked(MvfxPairHold *h, GstObject *element, M
     later->add(out);
     h->n_singles++;
     if (rc != MVFX_OK) {
-        if (h->failed_rc == MVFX_OK) h->failed_rc = rc;
+        if (h->failed_rc == MVFX_OK) {
+            h->failed_rc = rc;
+            h->failed_text = g_strdup(mvfx_last_error());
+        }
         post->set(element, rc);
     }
+}
+
+// What transform() returns when mvfx_pair_submit said MVFX_PAIR_FAILED_EARLIER: the reference would have returned this error from the
+// failed frame's own call (hsvfilter/imp.rs:322-326: the panic in transform_frame_ip becomes the element's error and GST_FLOW_ERROR)
+static inline GstFlowReturn mvfx_pair_flow_error(MvfxPairHold *h, GstObject *element)
+{
+    int rc;
+    gchar *text;
+    {
+        std::lock_guard<std::mutex> g(h->lock);
+        rc = h->failed_rc;
+        text = g_strdup(h->failed_text ? h->failed_text : "");
+    }
+    GST_ELEMENT_ERROR(GST_ELEMENT(element), LIBRARY, FAILED, ("%s", text), ("the frame before this one failed after its transform call had "
+                      "returned (pair launches): mvfx status %d (%s)", rc, mvfx_status_string(rc)));
+    g_free(text);
+    return GST_FLOW_ERROR;
 }
 
 static inline void mvfx_pair_flush(MvfxPairHold *h, GstObject *element, const MvfxPairOps *ops) // EOS, flush-start
@@ -142,6 +166,8 @@ static inline void mvfx_pair_stop(MvfxPairHold *h, GstObject *element, const Mvf
     mvfx_pair_flush(h, element, ops);
     std::lock_guard<std::mutex> g(h->lock);
     h->failed_rc = MVFX_OK;
+    g_free(h->failed_text);
+    h->failed_text = NULL;
 }
 
 // The flush registered on the blocks: somebody looked at a held-back frame
@@ -195,12 +221,12 @@ static inline int mvfx_pair_submit(MvfxPairHold *h, GstObject *element, const Mv
     std::unique_lock<std::mutex> g(h->lock);
     h->n_buffers++;
     if (h->failed_rc != MVFX_OK) // the frame before this one failed after its call had returned: this call carries the error
-        return h->failed_rc;
+        return MVFX_PAIR_FAILED_EARLIER;
     if (chained || h->direct_left) { // ... or every held-back frame was flushed by somebody's look lately: a plain launch per buffer for a while
         if (h->direct_left) h->direct_left--;
         h->n_direct++;
         mvfx_pair_flush_locked(h, element, ops->launch, &later, &post);
-        return h->failed_rc != MVFX_OK ? h->failed_rc : MVFX_PAIR_NOT_TAKEN;
+        return h->failed_rc != MVFX_OK ? MVFX_PAIR_FAILED_EARLIER : MVFX_PAIR_NOT_TAKEN;
     }
     const auto same_shape = [](const mvfx_frame &a, const mvfx_frame &b) {
         return a.width == b.width && a.height == b.height && a.stride == b.stride && a.format == b.format;
@@ -208,7 +234,7 @@ static inline int mvfx_pair_submit(MvfxPairHold *h, GstObject *element, const Mv
     if (h->out_mem && (!compatible || (in && !same_shape(h->fi, fi)) || !same_shape(h->fo, fo) || (in && (h->in_mem == in || h->out_mem == in)) ||
                        h->in_mem == out || h->out_mem == out))
         mvfx_pair_flush_locked(h, element, ops->launch, &later, &post); // the held-back frame goes first, alone
-    if (h->failed_rc != MVFX_OK) return h->failed_rc;
+    if (h->failed_rc != MVFX_OK) return MVFX_PAIR_FAILED_EARLIER;
     if (!h->out_mem) {
         h->in_mem = in ? gst_memory_ref(in) : NULL;
         h->out_mem = gst_memory_ref(out);

@@ -414,10 +414,42 @@ def state_cycles(n_cycles):
     return {"results": sorted(set(results)), "free_mb": series}
 
 
+def held_back_failure(which):
+    """Pair launches on (MVFX_ELEMENT_PAIR=2), a live source at 5 frames/s, the idle interval forced to 20 ms, frames on which the
+    reference panics (RGB 641x1: plane size 1924 is no multiple of 3, hsvfilter/imp.rs:92, hsvdetector/imp.rs:122).  Frame 0 is held
+    back, the timer launches it alone, the launch fails.  Unlike gst-launch this application does NOT stop at the first error message:
+    it keeps the pipeline PLAYING and records everything the bus says for 1.5 s, and how many buffers entered the element."""
+    import time
+    os.environ.update(MVFX_ELEMENT_PAIR="2", MVFX_PAIR_IDLE_US="20000")
+    el = "hsvfilter hue-shift=10" if which == "hsvfilter" else "hsvdetector"
+    pipe = Gst.parse_launch("hiptestsrc name=src is-live=true num-buffers=6 ! video/x-raw(memory:HIPMemory),format=RGB,width=641,height=1,framerate=5/1 ! "
+                            + el + " name=e ! fakesink")
+    seen = {"in": 0, "out": 0}
+
+    def count(key):
+        def probe(pad, info):
+            seen[key] += 1
+            return Gst.PadProbeReturn.OK
+        return probe
+    e = pipe.get_by_name("e")
+    e.get_static_pad("sink").add_probe(Gst.PadProbeType.BUFFER, count("in"))
+    e.get_static_pad("src").add_probe(Gst.PadProbeType.BUFFER, count("out"))
+    bus = pipe.get_bus()
+    pipe.set_state(Gst.State.PLAYING)
+    errors, t_end = [], time.time() + 1.5
+    while time.time() < t_end:
+        msg = bus.timed_pop_filtered(50 * Gst.MSECOND, Gst.MessageType.ERROR | Gst.MessageType.EOS)
+        if msg is not None and msg.type == Gst.MessageType.ERROR:
+            err, dbg = msg.parse_error()
+            errors.append({"src": msg.src.get_name(), "message": err.message, "debug": dbg or ""})
+    pipe.set_state(Gst.State.NULL)
+    return {"errors": errors, "buffers_in": seen["in"], "buffers_out": seen["out"]}
+
+
 SCENARIOS = {"hsvfilter_property_change": hsvfilter_property_change, "renegotiate": renegotiate,
              "rounded_radius_change": rounded_radius_change, "hsvdetector_property_change": hsvdetector_property_change,
              "overlay_property_change": overlay_property_change, "videocompare_three_pads": videocompare_three_pads,
-             "colorlut_relocation": colorlut_relocation,
+             "colorlut_relocation": colorlut_relocation, "held_back_failure": held_back_failure,
              "state_cycles": lambda n: state_cycles(int(n))}
 
 if __name__ == "__main__":

@@ -64,3 +64,19 @@ def test_device_memory_chain_survives_state_cycles_without_accumulating_device_m
     free = r["free_mb"]
     # after the first cycles (code objects, streams, the allocator's first blocks) free memory must stay flat
     assert min(free[6:]) > free[5] - 64.0, free
+
+
+@pytest.mark.parametrize("element", ["hsvfilter", "hsvdetector"])
+def test_a_failed_held_back_frame_fails_the_next_transform_call_with_flow_error(element):
+    """VERDICT r4 (W-semantics): with pair launches on, a held-back frame whose launch fails must not only be posted -- the element's NEXT
+    transform call returns GST_FLOW_ERROR, so the stream ends like the reference's, whose error is the flow return of the failing buffer
+    itself (hsvfilter/imp.rs:322-326).  The application here keeps running after the first error message, so the bus shows all three
+    stages: the posted failure of the held-back frame, the error of the next buffer's call, and the source's 'streaming stopped,
+    reason error (-5)' -- GST_FLOW_ERROR came back up the stream.  Exactly two buffers entered the element, none after the error."""
+    r = gst_inprocess.run("held_back_failure", element)
+    errs = r["errors"]
+    assert len(errs) >= 3, errs
+    assert errs[0]["src"] == "e" and "held-back frame: mvfx status -8" in errs[0]["debug"] and "asserts on this" in errs[0]["message"]
+    assert errs[1]["src"] == "e" and "the frame before this one failed" in errs[1]["debug"] and "asserts on this" in errs[1]["message"]
+    assert any(e["src"] == "src" and "reason error (-5)" in e["debug"] for e in errs[2:]), errs
+    assert r["buffers_in"] == 2 and r["buffers_out"] <= 1

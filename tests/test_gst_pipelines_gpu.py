@@ -623,7 +623,7 @@ def test_hsvfilter_launches_once_per_buffer_by_default(gpu, tmp_path, env):
     # all three device elements in a row, still nothing held back
     cube = tmp_path / "look.cube"
     cube.write_text(cubes.analytic_3d(9))
-    r = gst_env.run([LAUNCH, "-q"] + (f"hiptestsrc num-buffers=9 ! {caps} ! hsvfilter ! hsvdetector ! colorlut location={cube} ! fakesink").split(),
+    r = gst_env.run([LAUNCH, "-q"] + (f"hiptestsrc num-buffers=9 ! {caps.replace('RGBA', 'RGBx')} ! hsvfilter ! hsvdetector ! colorlut location={cube} ! fakesink").split(),
                     tmp_path, extra_env=dict(env, MVFX_ELEMENT_PAIR_STATS="1"))
     assert r.returncode == 0 and "pair launches" not in r.stdout, r.stdout
 
@@ -631,32 +631,28 @@ def test_hsvfilter_launches_once_per_buffer_by_default(gpu, tmp_path, env):
 PANIC_CAPS = "video/x-raw(memory:HIPMemory),format=RGB,width=641,height=1"  # stride 1924, 1924 % 3 != 0: hsvfilter/imp.rs:92 asserts
 
 
-def test_a_failing_frame_ends_the_stream_with_flow_error_by_default(gpu, tmp_path):
+def test_a_failing_frame_is_the_error_of_its_own_call_by_default(gpu, tmp_path):
     """The reference's transform_frame_ip panics on this plane size (assert_eq!(data.len() % nb_channels, 0), hsvfilter/imp.rs:92) and the
-    panic becomes the element's error + GST_FLOW_ERROR of THAT buffer.  Default mode: the first buffer's own call fails."""
-    r = gst_env.run([LAUNCH] + f"hiptestsrc num-buffers=4 ! {PANIC_CAPS},framerate=30/1 ! hsvfilter hue-shift=10 ! fakesink".split(), tmp_path)
+    panic becomes the element's error + GST_FLOW_ERROR of THAT buffer.  Default mode: the first buffer's own call fails (already in
+    preroll), nothing is held back."""
+    r = gst_env.run([LAUNCH] + f"hiptestsrc num-buffers=4 ! {PANIC_CAPS},framerate=30/1 ! hsvfilter hue-shift=10 ! fakesink".split(), tmp_path,
+                    extra_env={"MVFX_ELEMENT_PAIR_STATS": "1"})
     assert r.returncode != 0
-    assert "asserts on this (hsvfilter/imp.rs:92)" in r.stdout and "held-back frame" not in r.stdout
-    assert "reason error (-5)" in r.stdout  # the streaming thread stopped with GST_FLOW_ERROR
+    assert "asserts on this (hsvfilter/imp.rs:92)" in r.stdout and "held-back frame" not in r.stdout and "pair launches" not in r.stdout
 
 
-def test_a_failing_held_back_frame_fails_the_next_transform_with_flow_error(gpu, tmp_path):
+def test_a_failing_held_back_frame_is_posted_by_the_idle_flush(gpu, tmp_path):
     """Pairs on (MVFX_ELEMENT_PAIR=2) and a live source at 5 frames/s with the idle interval forced to 20 ms: frame 0 is held back, no
-    second buffer comes in time, the timer thread launches it alone -- and the launch fails.  It is posted ("held-back frame") AND the
-    transform call of frame 1 returns GST_FLOW_ERROR: the stream ends like the reference's would have, one buffer later
-    ('a failed held-back launch must also fail the next transform call')."""
-    r = gst_env.run([LAUNCH] + f"hiptestsrc is-live=true num-buffers=6 ! {PANIC_CAPS},framerate=5/1 ! hsvfilter hue-shift=10 ! fakesink".split(),
-                    tmp_path, extra_env={"MVFX_ELEMENT_PAIR": "2", "MVFX_PAIR_IDLE_US": "20000", "MVFX_ELEMENT_PAIR_STATS": "1"})
-    assert r.returncode != 0, r.stdout
-    assert "held-back frame: mvfx status -8" in r.stdout, r.stdout
-    assert "reason error (-5)" in r.stdout, r.stdout
-    buffers, pairs, singles, direct = _pair_stats(r.stdout)
-    assert buffers == 2 and (pairs, singles, direct) == (0, 1, 0)  # frame 0 alone (failed), frame 1's call carried the error: nothing after it
-    # the same through the out-of-place hold (hsvdetector asserts the same way, hsvdetector/imp.rs:122)
-    r = gst_env.run([LAUNCH] + f"hiptestsrc is-live=true num-buffers=6 ! {PANIC_CAPS},framerate=5/1 ! hsvdetector ! fakesink".split(),
-                    tmp_path, extra_env={"MVFX_ELEMENT_PAIR": "2", "MVFX_PAIR_IDLE_US": "20000", "MVFX_ELEMENT_PAIR_STATS": "1"})
-    assert r.returncode != 0 and "held-back frame: mvfx status -8" in r.stdout and "reason error (-5)" in r.stdout, r.stdout
-    assert _pair_stats_of("hsvdetector", r.stdout)[0] == 2
+    second buffer comes in time, the timer thread launches it alone -- and the launch fails: posted as "held-back frame" (gst-launch
+    stops there; that the NEXT transform call returns GST_FLOW_ERROR is tests/test_gst_inprocess_gpu.py::
+    test_a_failed_held_back_frame_fails_the_next_transform_call_with_flow_error, whose application keeps running)."""
+    for element in ("hsvfilter hue-shift=10", "hsvdetector"):
+        r = gst_env.run([LAUNCH] + f"hiptestsrc is-live=true num-buffers=6 ! {PANIC_CAPS},framerate=5/1 ! {element} ! fakesink".split(),
+                        tmp_path, extra_env={"MVFX_ELEMENT_PAIR": "2", "MVFX_PAIR_IDLE_US": "20000", "MVFX_ELEMENT_PAIR_STATS": "1"})
+        assert r.returncode != 0, r.stdout
+        assert "held-back frame: mvfx status -8" in r.stdout and "idle flush of a frame held for" in r.stdout, r.stdout
+        buffers, pairs, singles, direct = _pair_stats_of(element.split()[0], r.stdout)
+        assert (pairs, singles, direct) == (0, 1, 0) and buffers <= 2
 
 
 def test_a_stalled_sources_last_frame_is_processed_within_one_frame_interval(gpu, tmp_path):
@@ -686,35 +682,34 @@ def test_a_stalled_sources_last_frame_is_processed_within_one_frame_interval(gpu
 
 
 def test_tee_with_two_holding_readers_of_one_input_block(gpu, tmp_path):
-    """advisor r4 (medium): two HOLDING readers of one input block -- tee ! queue ! hsvdetector and tee ! queue ! colorlut, always holding
-    back (MVFX_ELEMENT_PAIR=2) -- both mark the block.  The second mark used to overwrite the first (check-then-set race in
+    """advisor r4 (medium): two HOLDING readers of one input block -- tee ! queue ! hsvdetector, twice, always holding back
+    (MVFX_ELEMENT_PAIR=2) -- both mark the block.  The second mark used to overwrite the first (check-then-set race in
     mvfx_hip_memory_set_deferred): the source's refill of the recycled block then flushed only one of the two held-back kernels and the
-    other read overwritten pixels.  A foreign mark is now run, never overwritten.  Frames alternate between two contents (refresh=true
-    rewrites every recycled block; the in-place hsvfilter in front makes a stale read visible) -- every frame of both branches exact."""
+    other read overwritten pixels.  A foreign mark is now run, never overwritten.  refresh=true rewrites every recycled block and the
+    in-place hsvfilter in front filters it again, so a reader that comes late sees unfiltered or half-filtered pixels -- every frame of
+    both branches must equal the oracle."""
     w, h, n = 640, 360, 200
-    cube = tmp_path / "look.cube"
-    cube.write_text(cubes.analytic_3d(9))
-    raw = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBA,width={w},height={h}", "in.raw").reshape(h, w * 4)
+    raw = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBx,width={w},height={h}", "in.raw").reshape(h, w * 4)
     mid = raw.copy()
-    orc.hsvfilter(mid, w, w * 4, "RGBA", (45.0, 1.0, 0.0, 1.0, 0.0))
-    exp_det = np.empty_like(mid)
-    assert orc.hsvdetector(mid, w * 4, "RGBA", exp_det, w * 4, "RGBA", w, (120.0, 60.0, 0.6, 0.4, 0.6, 0.4)) == 0
-    exp_lut = np.empty_like(mid)
-    assert orc.CubeLut(cube.read_text()).apply(mid, w * 4, exp_lut, w * 4, w, h, "RGBA") == 0
-    pipe = (f"hiptestsrc num-buffers={n} ! video/x-raw(memory:HIPMemory),format=RGBA,width={w},height={h},framerate=30/1 ! hsvfilter hue-shift=45 ! tee name=t "
-            f"t. ! queue max-size-buffers=2 ! hsvdetector hue-ref=120 hue-var=60 saturation-ref=0.6 saturation-var=0.4 value-ref=0.6 value-var=0.4 ! "
-            f"video/x-raw(memory:HIPMemory),format=RGBA ! hipdownload ! filesink location={tmp_path}/a.raw "
-            f"t. ! queue max-size-buffers=2 ! colorlut location={cube} ! hipdownload ! filesink location={tmp_path}/b.raw")
+    orc.hsvfilter(mid, w, w * 4, "RGBx", (45.0, 1.0, 0.0, 1.0, 0.0))
+    det = [(120.0, 60.0, 0.6, 0.4, 0.6, 0.4), (300.0, 80.0, 0.5, 0.5, 0.5, 0.5)]
+    branch = ("t. ! queue max-size-buffers=2 ! hsvdetector hue-ref={0} hue-var={1} saturation-ref={2} saturation-var={3} value-ref={4} "
+              "value-var={5} ! video/x-raw(memory:HIPMemory),format=RGBA ! hipdownload ! filesink location={6}")
+    pipe = (f"hiptestsrc num-buffers={n} ! video/x-raw(memory:HIPMemory),format=RGBx,width={w},height={h},framerate=30/1 ! hsvfilter hue-shift=45 ! tee name=t "
+            + branch.format(*det[0], f"{tmp_path}/a.raw") + " " + branch.format(*det[1], f"{tmp_path}/b.raw"))
     for _ in range(3):
         r = gst_env.run([LAUNCH, "-q"] + pipe.split(), tmp_path, timeout=120, extra_env={"MVFX_ELEMENT_PAIR": "2", "MVFX_ELEMENT_PAIR_STATS": "1"})
         assert r.returncode == 0, r.stdout[-2000:]
-        for name, exp in (("a.raw", exp_det), ("b.raw", exp_lut)):
+        for name, settings in zip(("a.raw", "b.raw"), det):
+            exp = np.empty_like(mid)
+            assert orc.hsvdetector(mid, w * 4, "RGBx", exp, w * 4, "RGBA", w, settings) == 0
             got = np.fromfile(f"{tmp_path}/{name}", dtype=np.uint8).reshape(n, h, w * 4)
             bad = [k for k in range(n) if not np.array_equal(got[k], exp)]
             assert bad == [], f"{name}: frames {bad[:10]} differ"
-        for element in ("hsvfilter", "hsvdetector", "colorlut"):
-            buffers, pairs, singles, direct = _pair_stats_of(element, r.stdout)
-            assert buffers == n and 2 * pairs + singles + direct == n
+        stats = re.findall(r"(\w+) \S+: (\d+) device buffers = 2 x (\d+) pair launches \+ (\d+) single launches \+ (\d+) direct launches", r.stdout)
+        assert sorted(x[0] for x in stats) == ["hsvdetector", "hsvdetector", "hsvfilter"], r.stdout[-2000:]
+        for _name, buffers, pairs, singles, direct in stats:
+            assert int(buffers) == n and 2 * int(pairs) + int(singles) + int(direct) == n
 
 
 @pytest.mark.parametrize("consumer", ["fakesink", "same_thread", "other_thread"])
