@@ -526,8 +526,7 @@ int mvfx_thread_set_options(uint32_t options)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options 0x%x: unknown bits 0x%x", options, options & ~known);
     if ((options & MVFX_OPT_HSV_LITERAL) && (options & MVFX_OPT_HSV_FORCE_FAST))
         return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options: MVFX_OPT_HSV_LITERAL and MVFX_OPT_HSV_FORCE_FAST exclude each other");
-    if (((options & MVFX_OPT_LUT_PLACEMENT_MASK) >> MVFX_OPT_LUT_PLACEMENT_SHIFT) > 6)
-        return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options: colorlut placement must be 0 (auto) .. 6 (baked table)");
+    // (every value of the three-bit field is a placement since round 5: 7 = round 4's per-wave windows)
     t_options = options;
     return MVFX_OK;
 }

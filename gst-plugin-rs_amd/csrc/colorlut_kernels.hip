@@ -23,6 +23,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <algorithm>
@@ -37,6 +38,12 @@ struct mvfx_cube_lut {
     float *d_rgba = nullptr;
     uint32_t *d_tile_tables = nullptr; // tile kernel: 3 x 256 x (cell index, fraction) per byte value + 192 neighbourhood piece offsets
     uint32_t *d_xcoord = nullptr; // colorlut_xtile_kernel: per byte value of g and b {cell index x LDS row pitch, fraction bits}
+    uint32_t *d_xcoord_wg = nullptr; // colorlut_xwg_kernel: the same with its window's pitches (cubes of 5+ points)
+    // Content probe (round 5, see colorlut_probe_kernel): which of the two window kernels the automatic choice takes for this LUT's frames.
+    // The probe kernel writes its verdict into a page-locked host word; the launcher reads it without synchronising (a verdict a few
+    // launches old is as good: pictures of a stream resemble their predecessors) -- advisory state, both kernels produce the same bytes.
+    uint32_t *h_probe = nullptr;            // [0]: 0 = no verdict yet, 1 = calm, 2 = busy; [1]: busy blocks of the last probe (of 256)
+    std::atomic<uint32_t> probe_calls{0};
     float *d_xtable = nullptr; // x-prelerped table of colorlut_xtile_kernel: [y][z][r byte] x (X.rgb, D.rgb) f32 = 24 B (3-D, 4 <= size <= kCellMaxSize)
     float *d_cells = nullptr; // cell-packed copy: size^3 cells x 8 corners x (r,g,b) f32 = 96 B (3-D, size <= kCellMaxSize)
     float *d_table[3] = {nullptr, nullptr, nullptr};
@@ -74,6 +81,7 @@ struct LutParams {
     const uint32_t *tile_tables; // colorlut_tile_kernel: coordinate tables + neighbourhood piece offsets
     const float4 *xtable; // colorlut_xtile_kernel: the x-prelerped table, addressed in 16-byte pieces (or nullptr)
     const uint2 *xcoord;  // colorlut_xtile_kernel: 512 x {cell index x row pitch, fraction bits} (g, then b)
+    const uint2 *xcoord_wg; // colorlut_xwg_kernel: the same with its window's pitches (or nullptr: cube smaller than its window)
     const float4 *cube;   // 3-D nodes
     const float *t[3];    // 1-D tables
     uint32_t size;
@@ -1184,6 +1192,265 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
     for (uint32_t row = 1; row < kRows; row++) do_row(row);
 }
 
+// ---------------------------------------------------------------- the workgroup-window kernel (round 5)
+//
+// What round 4's per-wave windows cost, measured by leaving parts of colorlut_xtile_kernel out (profiles/r5/colorlut_experiments.txt, 16 x 4K
+// natural-like frames per launch): with the pixels outside the window simply left wrong the kernel runs 72-75 k fps at EVERY noise level --
+// the miss service is the whole price of noisy content (+-8 codes: 2.1-2.9 % of the pixels outside a window of 24 r bytes x 3 x 3 cells, but
+// 55 % of a wave's (row, j) passes have one; +-16: 61 %), the LDS conflicts of scattered colours cost 10 %.  Serving the misses later, in
+// one dense pass per wave (two round trips instead of eleven), bought +5 % at +-8 and nothing at +-16; four blocks per wave with the next
+// block's pixels prefetched and the window kept where the anchor stays put bought nothing either (the patch of both: profiles/r5/).  A
+// bigger window per wave costs occupancy faster than it saves misses (24 x 4 x 4: 63 k fps on clean frames against 77 k).
+// The four waves of a workgroup keep four near-identical windows.  Here they keep ONE: the workgroup owns a 128 x 40 block of pixels (2 x 2
+// waves of 64 x 20), the window is 38 r bytes x 5 y cells x 5 z cells (6 z rows) = 27 360 bytes -- the LDS of four 24 x 3 x 3 windows --
+// anchored at the mean of the four waves' means.  CPU model of the hit rate on the bench's frames (tools/sim/colorlut_shared_sim.py):
+// outside pixels at +-8 codes of noise 2.1 % -> 0.0 %, at +-16 codes 61 % -> 4 %.  Same entries, same arithmetic as colorlut_xtile_kernel:
+// same bits.  The rare outside pixel is served in its row pass from the x table in global memory, as in rounds 3 and 4.
+constexpr uint32_t kWgRW = 38, kWgNY = 5, kWgNZ = 5, kWgNZR = kWgNZ + 1;
+constexpr uint32_t kWgPitchZ = kWgRW * 24, kWgPitchY = kWgNZR * kWgPitchZ, kWgWinBytes = kWgNY * kWgPitchY;
+static_assert(kWgRW % 2 == 0, "window rows start and end on 16-byte pieces");
+static_assert(kWgWinBytes + 4096 + 16 <= 32000, "five workgroups per CU (LDS comes in granules of 1280 bytes: 25 per workgroup)");
+
+__global__ __launch_bounds__(kBlock) void colorlut_xwg_kernel(FrameBatch in_fb, FrameBatch out_fb, uint32_t width, uint32_t height, uint32_t in_stride,
+                                                             uint32_t out_stride, LutParams p)
+{
+    constexpr uint32_t kAcross = 16, kRows = MVFX_XTILE_ROWS, kTileW = 64, kTileH = 4 * kRows, RW = kWgRW;
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) uint8_t win[kWgWinBytes];
+    __shared__ uint2 coord[512]; // {cell index x LDS pitch, fraction bits} per byte value of the g and b channels (this kernel's pitches)
+    __shared__ uint32_t wave_anchor[4];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t gx = blockIdx.x, gy = blockIdx.y, gz = blockIdx.z;
+    const uint8_t *in = in_fb.base[gz];
+    uint8_t *out = out_fb.base[gz];
+    const uint32_t bx = (gx * 2 + (wave & 1u)) * kTileW, by = (gy * 2 + (wave >> 1)) * kTileH; // the wave's block
+    const uint32_t x = bx + (lane % kAcross) * 4, y0 = by + (lane / kAcross) * kRows;
+    // 1. every pixel of the lane, up front
+    uint32_t voff_in = y0 * in_stride + x * 4, voff_out = y0 * out_stride + x * 4; // the lane's byte offsets into rows y0 .. of the frames
+    asm volatile("" : "+v"(voff_in), "+v"(voff_out)); // both formed HERE (colorlut_xtile_kernel)
+    uint4 v[kRows];
+#pragma unroll
+    for (uint32_t row = 0; row < kRows; row++) {
+        v[row] = make_uint4(0, 0, 0, 0);
+        if (x < width && y0 + row < height) {
+            const u32x4_t *src = reinterpret_cast<const u32x4_t *>(in + (size_t)row * in_stride + voff_in);
+            const u32x4_t t = MVFX_XTILE_NT ? __builtin_nontemporal_load(src) : *src;
+            v[row] = make_uint4(t.x, t.y, t.z, t.w);
+        }
+    }
+    coord[threadIdx.x] = p.xcoord_wg[threadIdx.x];
+    coord[kBlock + threadIdx.x] = p.xcoord_wg[kBlock + threadIdx.x];
+    // 2. the wave's mean colour out of its pixel registers: every lane's own pixel (x + 1, y0 + 1), a 16 x 4 lattice over the block, summed
+    // by DPP row additions (colorlut_xtile_kernel, anchor 7).  A block that sticks out of the frame offers its top-left pixel; one that lies
+    // wholly outside offers nothing.  Bit 31 says "offered".
+    uint32_t mine_mean = 0;
+    if (bx + kTileW <= width && by + kTileH <= height) { // wave-uniform
+        const uint32_t mine = v[MVFX_XTILE_SAMPLE_ROW < kRows ? MVFX_XTILE_SAMPLE_ROW : 0].y;
+        uint32_t ev = mine & 0x00ff00ffu, od = (mine >> 8) & 0x00ff00ffu;
+#define MVFX_ROW_ADD(v_, ctrl) v_ += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v_, ctrl, 0xf, 0xf, true)
+        MVFX_ROW_ADD(ev, 0x111); MVFX_ROW_ADD(od, 0x111);
+        MVFX_ROW_ADD(ev, 0x112); MVFX_ROW_ADD(od, 0x112);
+        MVFX_ROW_ADD(ev, 0x114); MVFX_ROW_ADD(od, 0x114);
+        MVFX_ROW_ADD(ev, 0x118); MVFX_ROW_ADD(od, 0x118);
+#undef MVFX_ROW_ADD
+        const uint32_t sev = (uint32_t)__builtin_amdgcn_readlane((int)ev, 15) + (uint32_t)__builtin_amdgcn_readlane((int)ev, 31) +
+                             (uint32_t)__builtin_amdgcn_readlane((int)ev, 47) + (uint32_t)__builtin_amdgcn_readlane((int)ev, 63) + 0x00200020u;
+        const uint32_t sod = (uint32_t)__builtin_amdgcn_readlane((int)od, 15) + (uint32_t)__builtin_amdgcn_readlane((int)od, 31) +
+                             (uint32_t)__builtin_amdgcn_readlane((int)od, 47) + (uint32_t)__builtin_amdgcn_readlane((int)od, 63) + 0x00200020u;
+        mine_mean = ((sev >> 6) & 0x00ff00ffu) | (((sod >> 6) & 0x000000ffu) << 8) | 0x80000000u;
+    } else if (bx < width && by < height) {
+        mine_mean = ((uint32_t)__builtin_amdgcn_readlane((int)v[0].x, 0) & 0xffffffu) | 0x80000000u;
+    }
+    if (lane == 0) wave_anchor[wave] = mine_mean;
+    __syncthreads(); // the coordinate table and the four means
+    // 3. the workgroup's window, anchored at the mean of the means on offer (1, 2 or 4 of them: waves drop out by column or by row)
+    uint32_t ar, ayp, azp, ccpx;
+    {
+        uint32_t sev = 0, sod = 0, n = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_anchor[k]);
+            if (a >> 31) {
+                sev += a & 0x00ff00ffu;
+                sod += (a >> 8) & 0x000000ffu;
+                n++;
+            }
+        }
+        const uint32_t sh = n == 4 ? 2u : n == 2 ? 1u : 0u, half = (1u << sh) >> 1; // (n == 3 cannot happen on a 2 x 2 grid; it would keep the sum of... guarded below)
+        uint32_t cpx = (((sev + half * 0x00010001u) >> sh) & 0x00ff00ffu) | ((((sod + half) >> sh) & 0xffu) << 8);
+        if (n == 3 || n == 0) cpx = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_anchor[0]) & 0xffffffu;
+        ccpx = cpx;
+        const uint32_t cr = cpx & 0xffu;
+        const uint32_t cy = p.tile_tables[2 * (256 + ((cpx >> 8) & 0xffu))], cz = p.tile_tables[2 * (512 + ((cpx >> 16) & 0xffu))];
+        ar = min((cr > RW / 2 ? cr - RW / 2 : 0u) & ~1u, 256u - RW); // even: a window row starts on a 16-byte piece
+        const uint32_t ay = min(cy > kWgNY / 2 ? cy - kWgNY / 2 : 0u, p.size - kWgNY), az = min(cz > kWgNZ / 2 ? cz - kWgNZ / 2 : 0u, p.size - kWgNZ); // z rows run 0 .. size
+        ayp = ay * kWgPitchY;
+        azp = az * kWgPitchZ;
+        // NY x NZR rows of RW entries of the x table, global -> LDS directly, 16-byte pieces (xtile_fill_window; here all four waves fill)
+        typedef __attribute__((address_space(3))) void *lds_void_t;
+        typedef const __attribute__((address_space(1))) void *global_void_t;
+        constexpr uint32_t kRowP = RW * 3 / 2, kPieces = kWgNY * kWgNZR * kRowP;
+        const uint32_t base = (ay * (p.size + 1) + az) * kXRowPieces + ar * 3 / 2; // workgroup-uniform
+#pragma unroll
+        for (uint32_t q0 = 0; q0 < kPieces; q0 += kBlock) {
+            const uint32_t q = q0 + threadIdx.x;
+            if (q0 + kBlock <= kPieces || q < kPieces) {
+                const uint32_t wr = q / kRowP, k = q - wr * kRowP; // window row = dy * NZR + dz
+                __builtin_amdgcn_global_load_lds((global_void_t)(p.xtable + (base + ((wr / kWgNZR) * (p.size + 1) + (wr % kWgNZR)) * kXRowPieces + k)),
+                                                 (lds_void_t)(win + (q0 + wave * 64u) * 16u), 16, 0, 0);
+            }
+        }
+    }
+    __syncthreads(); // the window
+    const uint32_t lds_k = 0u - ayp - azp - ar * 24u, ar24 = ar * 24u;
+    // 4. the rows (colorlut_xtile_kernel's row pass; the outside pixel is patched from the x table in global memory in ONE branch per row)
+    auto do_row = [&](const uint32_t row) -> bool { // true: row 0 found the block "far" (uniform-random colours) -- nothing served, nothing stored
+        const bool valid = x < width && y0 + row < height; // width % 4 == 0 (launcher)
+        uint32_t px[4] = {v[row].x, v[row].y, v[row].z, v[row].w};
+        f32x2_t e0[4][3], e1[4][3];
+        float ty[4], tz[4];
+        bool miss[4];
+        bool any_miss = false;
+        uint32_t outside = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t pxj = px[j];
+            const uint2 eg = coord[(pxj >> 8) & 0xffu], eb = coord[256 + ((pxj >> 16) & 0xffu)];
+            ty[j] = __uint_as_float(eg.y);
+            tz[j] = __uint_as_float(eb.y);
+            uint32_t r24;
+            asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r24) : "v"(pxj), "v"(24u));
+            const uint32_t dr24 = r24 - ar24, dyp = eg.x - ayp, dzp = eb.x - azp; // unsigned: below the anchor wraps to a huge value
+            miss[j] = (dr24 >= RW * 24u) | (dyp >= kWgNY * kWgPitchY) | (dzp >= kWgNZ * kWgPitchZ);
+            any_miss = any_miss | miss[j];
+            if (MVFX_XTILE_FAR_GATHER && row == 0) outside += (uint32_t)__popcll(__ballot(miss[j] & valid));
+            const uint32_t off = miss[j] ? 0u : eg.x + eb.x + (r24 + lds_k);
+            const lds_float2_t q0 = (lds_float2_t)((lds_bytes_t)&win[0] + off), q1 = (lds_float2_t)((lds_bytes_t)&win[0] + off + kWgPitchZ);
+            e0[j][0] = q0[0]; e0[j][1] = q0[1]; e0[j][2] = q0[2];
+            e1[j][0] = q1[0]; e1[j][1] = q1[1]; e1[j][2] = q1[2];
+        }
+        if (MVFX_XTILE_FAR_GATHER && row == 0 && outside > 248u) { // wave-uniform, rare (colorlut_xtile_kernel has the reasoning)
+            uint32_t far = 0, alike = 0, fpx = 0;
+            bool found = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t b = __ballot(miss[j] & valid);
+                if (b != 0 && !found) {
+                    fpx = (uint32_t)__builtin_amdgcn_readlane((int)px[j], __builtin_ctzll(b)); // the first outside pixel
+                    found = true;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                far += (uint32_t)__popcll(__ballot(miss[j] & valid & (__builtin_amdgcn_sad_u8(px[j] & 0x00ffff00u, ccpx & 0x00ffff00u, 0u) > (uint32_t)MVFX_XTILE_FAR)));
+                alike += (uint32_t)__popcll(__ballot(miss[j] & valid & (((px[j] ^ fpx) & 0x00f0f000u) == 0u)));
+            }
+            if (far * 4u > outside * 3u && alike * 4u < outside) return true;
+        }
+        if (any_miss) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (miss[j]) {
+                    const uint32_t pxj = px[j];
+                    const uint32_t iy = coord[(pxj >> 8) & 0xffu].x / kWgPitchY, iz = coord[256 + ((pxj >> 16) & 0xffu)].x / kWgPitchZ, r = pxj & 0xffu;
+                    const f32x2_t *g0p = reinterpret_cast<const f32x2_t *>(p.xtable) + (uint64_t)((iy * (p.size + 1) + iz) * 256u + r) * 3, *g1p = g0p + 256 * 3;
+                    e0[j][0] = g0p[0]; e0[j][1] = g0p[1]; e0[j][2] = g0p[2];
+                    e1[j][0] = g1p[0]; e1[j][1] = g1p[1]; e1[j][2] = g1p[2];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // entry = (X.r, X.g) (X.b, D.r) (D.g, D.b)
+            const float c0r = e0[j][0].x + e0[j][1].y * ty[j], c0g = e0[j][0].y + e0[j][2].x * ty[j], c0b = e0[j][1].x + e0[j][2].y * ty[j];
+            const float c1r = e1[j][0].x + e1[j][1].y * ty[j], c1g = e1[j][0].y + e1[j][2].x * ty[j], c1b = e1[j][1].x + e1[j][2].y * ty[j];
+            const float rr = lf_add_clamp(c0r, (c1r - c0r) * tz[j]), gg = lf_add_clamp(c0g, (c1g - c0g) * tz[j]),
+                        bb = lf_add_clamp(c0b, (c1b - c0b) * tz[j]);
+            // float_to_u8 (imp.rs:537-539) as ONE fused multiply-add + truncation (tools/prove_exact.c P15, exhaustive)
+            const float yr = __builtin_fmaf(rr, p.fast.out_scale, p.fast.pred_half), yg = __builtin_fmaf(gg, p.fast.out_scale, p.fast.pred_half),
+                        yb = __builtin_fmaf(bb, p.fast.out_scale, p.fast.pred_half);
+            uint32_t w = px[j];
+            asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yr));
+            asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yg));
+            asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
+            px[j] = w;
+        }
+        if (valid) {
+            u32x4_t *dst = reinterpret_cast<u32x4_t *>(out + (size_t)row * out_stride + voff_out);
+            const u32x4_t t = {px[0], px[1], px[2], px[3]};
+            if (MVFX_XTILE_NT) __builtin_nontemporal_store(t, dst);
+            else *dst = t;
+        }
+        return false;
+    };
+    if (do_row(0)) { // wave-uniform, rare: every lane gathers its own pixels' cells (no barrier follows: the other waves go on)
+        CellCache cache;
+#pragma unroll
+        for (uint32_t hr = 0; hr < kRows; hr++) {
+            uint4 q = v[hr];
+            q.x = lf_px8<true, true>(q.x, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
+            q.y = lf_px8<true, true>(q.y, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
+            q.z = lf_px8<true, true>(q.z, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
+            q.w = lf_px8<true, true>(q.w, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
+            if (x < width && y0 + hr < height) {
+                u32x4_t *dst = reinterpret_cast<u32x4_t *>(out + (size_t)hr * out_stride + voff_out);
+                const u32x4_t t = {q.x, q.y, q.z, q.w};
+                if (MVFX_XTILE_NT) __builtin_nontemporal_store(t, dst);
+                else *dst = t;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (uint32_t row = 1; row < kRows; row++) do_row(row);
+}
+
+// ---------------------------------------------------------------- content probe: which window kernel suits the stream (round 5)
+//
+// colorlut_xtile_kernel (a 24 x 3 x 3 window per wave) is the faster kernel on calm pictures -- 16 x 4K per launch, same box: 76-78 k fps
+// on smooth gradients, 74-76 k with +-3 codes of noise, 70-72 k with +-5 -- and collapses where the colours of a 64 x 20 block scatter:
+// 54 k at +-8, 26 k at +-16.  colorlut_xwg_kernel (one 38 x 5 x 5 window per workgroup) runs 70 / 69 / 68 / 67.5 / 47 k on the same
+// frames (profiles/r5/colorlut_experiments.txt).  The pictures of a stream resemble their predecessors, so the choice is made from a look at
+// an earlier frame: one workgroup, 256 blocks of 64 x 20 pixels spread over the frame, sixteen pixels of each (a 4 x 4 lattice); a block
+// is BUSY when the sampled bytes of a channel span more than kProbeSpan codes (sixteen samples of +-5 codes of noise on a gradient span
+// about 15, of +-8 about 20).  More than kProbeBusy busy blocks of 256 make the picture busy.  Every thread of the launch writes nothing
+// but thread 0, which stores the verdict into page-locked host memory; the launcher reads that word whenever it launches -- never
+// waiting for it -- and runs the probe again every kProbeEvery launches.  Both kernels produce the same bytes: the verdict only moves time.
+constexpr uint32_t kProbeSpan = 17, kProbeBusy = 38, kProbeEvery = 32;
+
+__global__ __launch_bounds__(256) void colorlut_probe_kernel(const uint8_t *__restrict__ frame, uint32_t width, uint32_t height, uint32_t stride,
+                                                            uint32_t *__restrict__ verdict)
+{
+    __shared__ uint32_t busy_blocks;
+    if (threadIdx.x == 0) busy_blocks = 0;
+    __syncthreads();
+    const uint32_t tiles_x = width / 64u, tiles_y = height / 20u; // whole blocks only; (0, 0) when the frame is smaller than one
+    bool busy = false;
+    if (tiles_x != 0 && tiles_y != 0) {
+        // block (i, j) of a 16 x 16 lattice over the whole blocks of the frame
+        const uint32_t tx = (uint32_t)(((uint64_t)(threadIdx.x & 15u) * 2u + 1u) * tiles_x / 32u), ty = (uint32_t)(((uint64_t)(threadIdx.x >> 4) * 2u + 1u) * tiles_y / 32u);
+        uint32_t lo[3] = {255u, 255u, 255u}, hi[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) {
+            const uint32_t px = *reinterpret_cast<const uint32_t *>(frame + (size_t)(ty * 20u + 2u + 5u * (k >> 2)) * stride + (tx * 64u + 8u + 16u * (k & 3u)) * 4u);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const uint32_t b = (px >> (8 * c)) & 0xffu;
+                lo[c] = min(lo[c], b);
+                hi[c] = max(hi[c], b);
+            }
+        }
+        busy = max(max(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]) > kProbeSpan;
+    }
+    const uint32_t n = (uint32_t)__popcll(__ballot(busy));
+    if ((threadIdx.x & 63u) == 0 && n != 0) atomicAdd(&busy_blocks, n);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        verdict[1] = busy_blocks;
+        __atomic_store_n(&verdict[0], busy_blocks > kProbeBusy ? 2u : 1u, __ATOMIC_RELAXED);
+    }
+}
+
 // ---------------------------------------------------------------- colorlut on I420 frames, fused
 //
 // `videoconvert ! colorlut ! videoconvert` of the reference's example pipeline (colorlut/imp.rs:17-19) in ONE kernel:
@@ -1388,6 +1655,7 @@ int ensure_uploaded(mvfx_cube_lut *h)
     if (h->d_cells) { (void)hipFree(h->d_cells); h->d_cells = nullptr; }
     if (h->d_xtable) { (void)hipFree(h->d_xtable); h->d_xtable = nullptr; }
     if (h->d_xcoord) { (void)hipFree(h->d_xcoord); h->d_xcoord = nullptr; }
+    if (h->d_xcoord_wg) { (void)hipFree(h->d_xcoord_wg); h->d_xcoord_wg = nullptr; }
     if (h->d_tile_tables) { (void)hipFree(h->d_tile_tables); h->d_tile_tables = nullptr; }
     if (h->d_baked) { (void)hipFree(h->d_baked); h->d_baked = nullptr; }
     for (auto &t : h->d_table) if (t) { (void)hipFree(t); t = nullptr; }
@@ -1453,6 +1721,21 @@ int ensure_uploaded(mvfx_cube_lut *h)
                     }
                     MVFX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_xcoord), xc.size() * sizeof(uint32_t)));
                     MVFX_HIP_TRY(hipMemcpy(h->d_xcoord, xc.data(), xc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                    if (l.size >= kWgNY && l.size >= kWgNZ) { // colorlut_xwg_kernel's window is 5 x 5 cells
+                        for (int b = 0; b < 256; b++) {
+                            xc[2 * b] = tt[(256 + b) * 2] * kWgPitchY;
+                            xc[2 * (256 + b)] = tt[(512 + b) * 2] * kWgPitchZ;
+                        }
+                        MVFX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->d_xcoord_wg), xc.size() * sizeof(uint32_t)));
+                        MVFX_HIP_TRY(hipMemcpy(h->d_xcoord_wg, xc.data(), xc.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                        if (!h->h_probe) { // (without it the automatic choice is always the workgroup-window kernel)
+                            void *q = nullptr;
+                            if (hipHostMalloc(&q, 64, hipHostMallocDefault) == hipSuccess) {
+                                std::memset(q, 0, 64);
+                                h->h_probe = static_cast<uint32_t *>(q);
+                            }
+                        }
+                    }
                     MVFX_HIP_TRY(hipStreamSynchronize(nullptr));
                 }
             }
@@ -1703,6 +1986,7 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
     p.tile_tables = h->d_tile_tables;
     p.xtable = reinterpret_cast<const float4 *>(h->d_xtable);
     p.xcoord = reinterpret_cast<const uint2 *>(h->d_xcoord);
+    p.xcoord_wg = reinterpret_cast<const uint2 *>(h->d_xcoord_wg);
     p.fast.c_hi = wide ? 1.0f / 65535.0f : 1.0f / 255.0f;
     p.fast.c_lo = (float)((wide ? 1.0 / 65535.0 : 1.0 / 255.0) - (double)p.fast.c_hi);
     p.fast.out_scale = wide ? 65535.0f : 255.0f;
@@ -1742,6 +2026,26 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
         //   32 x 16 (8 x 8, 2 rows)             57.0 k      21.5     28.1     37.8     32.4
         //   64 x 32 (16 x 4, 8 rows) 60.2 k / 31.0 us;  32 x 32 59.1 k / 23.9;  64 x 8 56.3 k / 22.4;  32 x 64 47.4 k / 34.3
         // RGBA8 on cubes of 4+ points: the x-prelerped kernel (placement 5 keeps the kernel below for A/B runs)
+        // RGBA8 on cubes of 5+ points: the workgroup-window kernel (round 5); placement 7 keeps round 4's per-wave windows for A/B runs
+        // Which of the two: by the content probe's last verdict (colorlut_probe_kernel) -- busy or no verdict yet: the workgroup window.
+        // MVFX_XWG (environment, read once; experiments): 1 always the workgroup window, 0 never.
+        bool wg_window = !wide && h->d_xtable && h->d_xcoord_wg && opt_lut_placement() != 5 && opt_lut_placement() != 7;
+        if (wg_window) {
+            static const int forced = [] { const char *e = std::getenv("MVFX_XWG"); return e ? std::atoi(e) : -1; }();
+            if (forced >= 0) {
+                wg_window = forced != 0;
+            } else if (h->h_probe) {
+                if (h->probe_calls.fetch_add(1, std::memory_order_relaxed) % kProbeEvery == 0) // (not MVFX_LAUNCH: the probe is no part of the frame's work)
+                    hipLaunchKernelGGL(colorlut_probe_kernel, dim3(1), dim3(256), 0, st, ifb.base[0], in->width, in->height, in->stride, h->h_probe);
+                wg_window = __atomic_load_n(&h->h_probe[0], __ATOMIC_RELAXED) != 1u;
+            }
+        }
+        if (wg_window) {
+            const uint32_t tx_ = (in->width + 127) / 128, ty_ = (in->height + 8 * MVFX_XTILE_ROWS - 1) / (8 * MVFX_XTILE_ROWS);
+            MVFX_LAUNCH(colorlut_xwg_kernel, dim3(tx_, ty_, n), dim3(kBlock), 0, st, ip, op, in->width, in->height, in->stride, out->stride, p);
+            MVFX_HIP_TRY(hipGetLastError());
+            return MVFX_OK;
+        }
         if (!wide && h->d_xtable && opt_lut_placement() != 5) {
             const uint32_t tx_ = (in->width + 63) / 64, ty_ = (in->height + 4 * MVFX_XTILE_ROWS - 1) / (4 * MVFX_XTILE_ROWS);
             const dim3 xgrid((tx_ + kBlock / 64 - 1) / (kBlock / 64), ty_, n);
@@ -1860,6 +2164,8 @@ int colorlut_i420_impl(mvfx_cube_lut *h, const mvfx_planar_frame *in, const mvfx
         p.tile_tables = h->d_tile_tables;
         p.xtable = reinterpret_cast<const float4 *>(h->d_xtable);
         p.xcoord = reinterpret_cast<const uint2 *>(h->d_xcoord);
+        p.xcoord_wg = reinterpret_cast<const uint2 *>(h->d_xcoord_wg);
+    p.xcoord_wg = reinterpret_cast<const uint2 *>(h->d_xcoord_wg);
         if (l.is_3d && h->d_cells && h->d_tile_tables && hgt / 16 + 1 <= 65535u) {
             const dim3 tgrid((w + 255) / 256, (hgt + 15) / 16);
             if (h->d_xtable && opt_lut_placement() != 5)
@@ -1935,6 +2241,8 @@ void mvfx_cube_lut_free(mvfx_cube_lut *lut)
     if (lut->d_cells) (void)hipFree(lut->d_cells);
     if (lut->d_xtable) (void)hipFree(lut->d_xtable);
     if (lut->d_xcoord) (void)hipFree(lut->d_xcoord);
+    if (lut->d_xcoord_wg) (void)hipFree(lut->d_xcoord_wg);
+    if (lut->h_probe) (void)hipHostFree(lut->h_probe);
     if (lut->d_tile_tables) (void)hipFree(lut->d_tile_tables);
     if (lut->d_baked) (void)hipFree(lut->d_baked);
     for (auto &t : lut->d_table) if (t) (void)hipFree(t);

@@ -156,7 +156,8 @@ int mvfx_copy_device_to_device_async(void *dst_device, const void *src_device, s
                                           conversion, exact for all 256 byte values: tools/probe_unorm.hip) */
 #define MVFX_OPT_LUT_PLACEMENT_SHIFT 4 /* colorlut LUT placement: 0 auto | 1 node layout in global/L2 | 2 LDS |         */
 #define MVFX_OPT_LUT_PLACEMENT_MASK 0x70u /* 3 cell-packed global | 4 literal kernels | 5 tile kernel (wave-local LUT     */
-                                          /* window in LDS, the automatic choice for 3-D cubes) | 6 baked table (RGBA8 only); */
+                                          /* window in LDS, the automatic choice for 3-D cubes) | 6 baked table (RGBA8 only)  */
+                                          /* | 7 round 4's per-wave x-prelerped windows instead of the workgroup window (A/B); */
                                           /* (placement << SHIFT) & MASK */
 #define MVFX_OPT_SSIM_F64 0x80u        /* hash-algo=dssim: f64 planes and window sums (round 2's pipeline, within 1e-9 of the f64
                                           checker) instead of the default f32 pipeline (what dssim-core computes in) */
