@@ -48,16 +48,18 @@ OPT_HSV_FORCE_FAST = 0x04
 OPT_HSV_VALU_UNORM = 0x08
 OPT_LUT_PLACEMENT_SHIFT = 4
 OPT_SSIM_F64 = 0x80
+OPT_LUT_WG_WINDOW = 0x100
 
 
 class options:
     """``with vfx.options(variant=1, typed=False): ...`` -- sets the calling thread's kernel options
     (mvfx_thread_set_options) for the block and restores the previous word.  variant: 0 auto, 1 literal,
     2 force strength-reduced; placement: colorlut LUT placement 0..6 (include/mi355vfx.h: 0 auto, 1 node layout in global/L2,
-    2 LDS, 3 cell-packed global, 4 literal kernels, 5 tile kernel, 6 baked table of all 2^24 colours)."""
+    2 LDS, 3 cell-packed global, 4 literal kernels, 5 tile kernel, 6 baked table of all 2^24 colours, 7 round 4's per-wave windows);
+    wg_window: colorlut always through the workgroup-window kernel instead of asking the content probe."""
 
-    def __init__(self, variant=0, nontemporal=False, typed=True, placement=0, ssim_f64=False):
-        self.word = ((OPT_SSIM_F64 if ssim_f64 else 0) | (OPT_NONTEMPORAL if nontemporal else 0) | (OPT_HSV_LITERAL if variant == 1 else 0) |
+    def __init__(self, variant=0, nontemporal=False, typed=True, placement=0, ssim_f64=False, wg_window=False):
+        self.word = ((OPT_LUT_WG_WINDOW if wg_window else 0) | (OPT_SSIM_F64 if ssim_f64 else 0) | (OPT_NONTEMPORAL if nontemporal else 0) | (OPT_HSV_LITERAL if variant == 1 else 0) |
                      (OPT_HSV_FORCE_FAST if variant == 2 else 0) | (0 if typed else OPT_HSV_VALU_UNORM) |
                      (placement << OPT_LUT_PLACEMENT_SHIFT))
 
@@ -161,6 +163,7 @@ SIGNATURES = {
     "mvfx_cube_lut_free": (None, [c_void_p]),
     "mvfx_cube_lut_is_3d": (c_int, [c_void_p]),
     "mvfx_cube_lut_size": (c_uint32, [c_void_p]),
+    "mvfx_cube_lut_content_verdict": (c_int, [c_void_p, POINTER(c_uint32)]),
     "mvfx_cube_lut_domain": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float)]),
     "mvfx_cube_lut_rgba": (POINTER(c_float), [c_void_p]),
     "mvfx_cube_lut_table_1d": (POINTER(c_float), [c_void_p, c_int]),

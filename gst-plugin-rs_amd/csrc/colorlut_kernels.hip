@@ -2034,6 +2034,8 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
             static const int forced = [] { const char *e = std::getenv("MVFX_XWG"); return e ? std::atoi(e) : -1; }();
             if (forced >= 0) {
                 wg_window = forced != 0;
+            } else if (thread_options() & MVFX_OPT_LUT_WG_WINDOW) {
+                // asked for by the caller
             } else if (h->h_probe) {
                 if (h->probe_calls.fetch_add(1, std::memory_order_relaxed) % kProbeEvery == 0) // (not MVFX_LAUNCH: the probe is no part of the frame's work)
                     hipLaunchKernelGGL(colorlut_probe_kernel, dim3(1), dim3(256), 0, st, ifb.base[0], in->width, in->height, in->stride, h->h_probe);
@@ -2267,6 +2269,15 @@ void mvfx_free_text(char *text) { free(text); }
 
 int mvfx_cube_lut_is_3d(const mvfx_cube_lut *lut) { return lut && lut->lut.is_3d ? 1 : 0; }
 uint32_t mvfx_cube_lut_size(const mvfx_cube_lut *lut) { return lut ? lut->lut.size : 0; }
+int mvfx_cube_lut_content_verdict(const mvfx_cube_lut *lut, uint32_t *busy_blocks)
+{
+    if (!lut || !lut->h_probe) {
+        if (busy_blocks) *busy_blocks = 0;
+        return 0;
+    }
+    if (busy_blocks) *busy_blocks = __atomic_load_n(&lut->h_probe[1], __ATOMIC_RELAXED);
+    return (int)__atomic_load_n(&lut->h_probe[0], __ATOMIC_RELAXED);
+}
 
 int mvfx_cube_lut_domain(const mvfx_cube_lut *lut, float scale[3], float offset[3])
 {

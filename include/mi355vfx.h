@@ -161,6 +161,9 @@ int mvfx_copy_device_to_device_async(void *dst_device, const void *src_device, s
                                           /* (placement << SHIFT) & MASK */
 #define MVFX_OPT_SSIM_F64 0x80u        /* hash-algo=dssim: f64 planes and window sums (round 2's pipeline, within 1e-9 of the f64
                                           checker) instead of the default f32 pipeline (what dssim-core computes in) */
+#define MVFX_OPT_LUT_WG_WINDOW 0x100u  /* colorlut, placement 0 on RGBA8 frames and cubes of 5+ points: always the workgroup-window kernel
+                                          (by default a content probe of an earlier frame of the LUT's stream chooses between it -- busy
+                                          pictures -- and the per-wave windows of placement 7 -- calm ones; same bytes either way) */
 int mvfx_thread_set_options(uint32_t options);
 uint32_t mvfx_thread_options(void);
 
@@ -269,6 +272,9 @@ int mvfx_cube_lut_parse_file(const char *path, mvfx_cube_lut **out);
 void mvfx_cube_lut_free(mvfx_cube_lut *lut);
 int mvfx_cube_lut_is_3d(const mvfx_cube_lut *lut);
 uint32_t mvfx_cube_lut_size(const mvfx_cube_lut *lut);
+/* Diagnostic: the last verdict of the LUT's content probe (see MVFX_OPT_LUT_WG_WINDOW) -- 0 none yet, 1 calm, 2 busy -- and, when
+ * `busy_blocks` is not NULL, how many of the 256 sampled blocks of the probed frame were busy.  Never synchronises. */
+int mvfx_cube_lut_content_verdict(const mvfx_cube_lut *lut, uint32_t *busy_blocks);
 int mvfx_cube_lut_domain(const mvfx_cube_lut *lut, float scale[3], float offset[3]);
 const float *mvfx_cube_lut_rgba(const mvfx_cube_lut *lut);               /* host, size^3*4 or NULL */
 const float *mvfx_cube_lut_table_1d(const mvfx_cube_lut *lut, int channel); /* host, size or NULL */

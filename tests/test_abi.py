@@ -89,7 +89,10 @@ def test_argument_validation_needs_no_device(vfx):
     assert lib.mvfx_hsvfilter_transform_frame_ip_host(ctypes.byref(f), ctypes.byref(s)) == vfx.ERR_UNSUPPORTED_FORMAT
     assert lib.mvfx_thread_set_options(0x1000) == vfx.ERR_INVALID_ARGUMENT                       # unknown bit
     assert lib.mvfx_thread_set_options(vfx.OPT_HSV_LITERAL | vfx.OPT_HSV_FORCE_FAST) == vfx.ERR_INVALID_ARGUMENT
-    assert lib.mvfx_thread_set_options(7 << vfx.OPT_LUT_PLACEMENT_SHIFT) == vfx.ERR_INVALID_ARGUMENT  # placement 0..6
+    assert lib.mvfx_thread_set_options(7 << vfx.OPT_LUT_PLACEMENT_SHIFT) == 0   # placement 7 (round 5): round 4's per-wave windows
+    assert lib.mvfx_thread_set_options(vfx.OPT_LUT_WG_WINDOW) == 0 and lib.mvfx_thread_options() == vfx.OPT_LUT_WG_WINDOW
+    assert lib.mvfx_thread_set_options(0) == 0
+    assert lib.mvfx_cube_lut_content_verdict(None, None) == 0                    # diagnostic accessor: no LUT, no verdict
     assert lib.mvfx_thread_options() == 0
 
 

@@ -169,12 +169,15 @@ def test_colorlut_4k_rgba_33(gpu, luts):
 
 
 @pytest.mark.parametrize("name", ["analytic33", "domain33", "analytic65", "analytic9", "nan_nodes4"])
-@pytest.mark.parametrize("placement", [0, 5], ids=["x-prelerped", "tile-round2"])
+@pytest.mark.parametrize("placement", ["wg", 7, 5], ids=["workgroup-window", "per-wave-windows", "tile-round2"])
 def test_colorlut_window_kernels(gpu, luts, name, placement):
-    """The two window kernels on the frames that exercise their windows: smooth gradients + noise (most pixels inside the wave's window,
-    some outside), flat bars (everything inside), uniform-random (everything outside: the per-lane global path), at sizes that are not
-    multiples of the 64 x 16 wave block (partial blocks, a last workgroup whose trailing waves lie outside the frame), batched.
-    placement 0 = colorlut_xtile_kernel (x-prelerped table), 5 = colorlut_tile_kernel (3 x 3 x 3 cell window): the oracle's bytes."""
+    """The three window kernels on the frames that exercise their windows: smooth gradients + noise (most pixels inside the window, some
+    outside), flat bars (everything inside), uniform-random (everything outside: the per-lane global path), gradients with +-8 and +-16
+    codes of noise (round 5: what the workgroup window is for), at sizes that are not multiples of the wave block or of the workgroup's
+    128 x 40 block (partial blocks, a last workgroup whose trailing waves lie outside the frame), batched.
+    "wg" = colorlut_xwg_kernel (MVFX_OPT_LUT_WG_WINDOW: no content probe in the way; cubes below 5 points fall through to the per-wave
+    kernel), 7 = colorlut_xtile_kernel (x-prelerped table, per-wave windows), 5 = colorlut_tile_kernel (3 x 3 x 3 cell window): the
+    oracle's bytes from all of them."""
     if name == "nan_nodes4":
         text = "LUT_3D_SIZE 4\n" + "".join(("nan 0.5 inf\n" if (i * 7) % 5 == 0 else ("0.25 -inf 2\n" if i % 3 == 0 else f"{i / 64:.6f} {1 - i / 64:.6f} 0.5\n"))
                                             for i in range(64))
@@ -184,14 +187,22 @@ def test_colorlut_window_kernels(gpu, luts, name, placement):
     else:
         dev, o = luts[name]
     L = gpu.lib()
-    gpu.check(L.mvfx_thread_set_options(gpu.options(placement=placement).word))
+    gpu.check(L.mvfx_thread_set_options((gpu.options(wg_window=True) if placement == "wg" else gpu.options(placement=placement)).word))
     try:
-        for (w, h) in ((3840, 2160), (1000, 250), (68, 20)):
-            n = 2 if w > 2000 else 3
+        for (w, h) in ((3840, 2160), (1000, 250), (68, 20), (132, 44)):
+            n = 2 if w > 2000 else 5
             srcs = []
             for k in range(n):
-                kind = (k + (w // 4)) % 3
-                f = frames.natural_like(w, h, 0x5EED0C00 + k) if kind == 0 else (frames.smpte_like(w, h) if kind == 1 else frames.random_frame(0x5EED0C10 + k, w, h))
+                kind = (k + (w // 4)) % 3 if k < 3 else k
+                if kind in (0, 3, 4): # gradients + noise of the generator's own, then +-8 / +-16 codes on top
+                    f = np.ascontiguousarray(frames.natural_like(w, h, 0x5EED0C00 + k)).reshape(h, w, 4)
+                    if kind >= 3:
+                        amp = 8 if kind == 3 else 16
+                        nz = np.random.default_rng(0x5EED0C20 + k).integers(-amp, amp + 1, (h, w, 3))
+                        f = f.copy()
+                        f[..., :3] = np.clip(f[..., :3].astype(np.int32) + nz, 0, 255).astype(np.uint8)
+                else:
+                    f = frames.smpte_like(w, h) if kind == 1 else frames.random_frame(0x5EED0C10 + k, w, h)
                 srcs.append(np.ascontiguousarray(f).reshape(h, w * 4))
             din = [gpu.DeviceBuffer(f.nbytes).upload(f) for f in srcs]
             dout = [gpu.DeviceBuffer(f.nbytes) for f in srcs]
@@ -267,3 +278,36 @@ def test_colorlut_rgb10a2_le_matches_oracle(gpu, which):
     got = do.download().reshape(h, stride)
     assert np.array_equal(got[:, :w * 4], want[:, :w * 4])
     assert not got[:, w * 4:].any()  # row padding untouched
+
+
+def test_colorlut_content_probe_picks_the_kernel_and_never_the_bytes(gpu):
+    """Round 5: placement 0 asks a content probe (one workgroup looking at 256 blocks of an earlier frame of the LUT's stream) whether the
+    pictures are calm -- per-wave windows -- or busy -- the workgroup window.  The verdict moves time, never bytes: frames of both kinds
+    through the automatic choice equal the oracle before a verdict exists, after a calm one and after a busy one; and the verdict is the
+    right one (diagnostic accessor mvfx_cube_lut_content_verdict)."""
+    import ctypes
+    text = cubes.analytic_3d(33)
+    o = orc.CubeLut(text)
+    dev = gpu.CubeLut(text)
+    L = gpu.lib()
+    w, h = 1920, 1080
+    calm = np.ascontiguousarray(frames.natural_like(w, h, 0x5EED0D00)).reshape(h, w, 4)
+    busy = calm.copy()
+    busy[..., :3] = np.clip(busy[..., :3].astype(np.int32) + np.random.default_rng(0x5EED0D01).integers(-12, 13, (h, w, 3)), 0, 255).astype(np.uint8)
+    busy_n = ctypes.c_uint32()
+    assert L.mvfx_cube_lut_content_verdict(dev.h, ctypes.byref(busy_n)) == 0
+    seen = []
+    for f in (calm, busy, calm):
+        f2 = f.reshape(h, w * 4)
+        exp = np.empty_like(f2)
+        assert o.apply(f2, w * 4, exp, w * 4, w, h, "RGBA") == 0
+        src = gpu.DeviceBuffer(f2.nbytes).upload(f2)
+        dst = gpu.DeviceBuffer(f2.nbytes)
+        for i in range(70): # the probe looks at every 32nd call's frame; its verdict lands a little later
+            dev.apply_device(src.ptr, w * 4, dst.ptr, w * 4, w, h, "RGBA")
+            if i in (0, 40, 69):
+                gpu.check(L.mvfx_stream_synchronize(None))
+                assert np.array_equal(dst.download().reshape(h, w * 4), exp)
+        seen.append((L.mvfx_cube_lut_content_verdict(dev.h, ctypes.byref(busy_n)), busy_n.value))
+    assert [v for v, _ in seen] == [1, 2, 1], seen
+    assert seen[0][1] < 20 and seen[1][1] > 200, seen
