@@ -1654,35 +1654,37 @@ def wait_emitted(w, seconds, store=None):
 
 
 def gst_pipeline_leg(args):
-    """The real element: `gst-launch-1.0 hiptestsrc ! video/x-raw(memory:HIPMemory),RGBA,3840x2160 ! hsvfilter ! fakesink` in child
-    process (tools/bench_gst_pipeline.py --branches 1 --quick 2: one run of N2 buffers, the rate between buffer N1 and the last one taken
-    inside the process by hiptestsrc at two instants where a recycled block is back with all downstream work on it finished)."""
+    """The real element, in a child process: `gst-launch-1.0 hiptestsrc refresh=false ! video/x-raw(memory:HIPMemory),RGBA,3840x2160 !
+    hsvfilter ! fakesink` (tools/bench_gst_pipeline.py --honest 1) -- one launch per buffer, as shipped -- on a rotation of twelve 33 MB
+    blocks (398 MB: larger than the 256 MB Infinity Cache, every buffer comes from HBM): `value`, `cache_resident: false`, and the only
+    figure that gets a roofline fraction.  Beside it: the same pipeline on the pool's usual four blocks (cache resident, no fraction) and
+    with a device consumer behind the filter (`! hsvdetector ! fakesink`).  The rate is taken inside the process by hiptestsrc between
+    buffer N1 and the last one, at two instants where a recycled block is back with all downstream work on it finished.  `bound` is the
+    headline kernel's (the committed counter passes): the same kernel runs."""
     gst_dir = os.path.join(ROOT, "gst-plugin-rs_amd", "gst-plugins")
     if not os.path.isdir(gst_dir) or not os.path.exists("/opt/conda/bin/gst-launch-1.0"):
         return {"error": "no GStreamer on this box (the element layer is an optional build target)"}
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_gst_pipeline.py"), "--branches", "1", "--quick", "2", "--others", "1",
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_gst_pipeline.py"), "--honest", "1", "--repeats", "2",
            "--n1", str(args.gst_n1), "--n2", str(args.gst_n2)]
-
-    def one(pair):
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=args.gst_timeout,
-                           env=dict(os.environ, MVFX_ELEMENT_PAIR=pair))
+    try:
+        env = {k: v for k, v in os.environ.items() if k not in ("MVFX_ELEMENT_PAIR", "MVFX_HIP_POOL_MIN")}
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=args.gst_timeout, env=env)
         if r.returncode != 0:
             raise RuntimeError(f"bench_gst_pipeline rc {r.returncode}: {r.stderr[-200:]}")
-        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    try:
-        d = one("1")  # the element as shipped: two consecutive frames per launch (gsthsv.cpp)
-        # one launch per buffer (rounds 2-3), on request: the A/B of the round is profiles/r4/element_path.txt
-        single = one("0").get("refresh_false_combine_0_fps") if args.gst_ab else None
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"[:300]}
-    fps = d.get("refresh_false_combine_0_fps")
+    fps = d.get("hsvfilter_hbm_resident_fps")
+    committed = committed_counters("hsvfilter", 1)
     return {"metric": "gst_hsvfilter_element_4k_rgba_frames_per_sec", "value": fps, "unit": "frames/s",
             "ms_per_step": 1e3 / fps if fps else None,
-            "roofline": {"bound": "valu", "frac": fps * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS if fps else None},
-            "sub_extra": {"pipeline": "gst-launch-1.0 hiptestsrc refresh=false ! video/x-raw(memory:HIPMemory),format=RGBA,3840x2160 ! hsvfilter ! fakesink",
-                          "buffers": [d.get("n1"), d.get("n2")], "one_launch_per_buffer_fps": single,
-                          "hsvdetector_element_fps": d.get("hsvdetector_fps"), "colorlut_element_fps": d.get("colorlut_fps"),
-                          "note": "the pool's four blocks are re-filtered: converged content clocks higher than fresh frames and 4 x 33 MB sit in the 256 MB Infinity Cache, so this can pass the HBM-only ceiling of `value`"},
+            "roofline": {"bound": committed.get("bound"), "frac": fps * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS if fps else None},
+            "sub_extra": {"pipeline": "gst-launch-1.0 hiptestsrc refresh=false ! video/x-raw(memory:HIPMemory),format=RGBA,3840x2160 ! hsvfilter ! fakesink, MVFX_HIP_POOL_MIN=12",
+                          "cache_resident": False, "rotation_MB": round(12 * FRAME_BYTES / 1e6), "launch_model": "one launch per buffer (the default)",
+                          "runs_fps": d.get("hsvfilter_hbm_resident_runs"), "buffers": [d.get("n1"), d.get("n2")],
+                          "cache_resident_fps_4_blocks": d.get("hsvfilter_cache_resident_fps"),
+                          "with_device_consumer_fps": d.get("hsvfilter_then_hsvdetector_hbm_resident_fps"),
+                          "with_device_consumer_frac": d.get("hsvfilter_then_hsvdetector_frac_of_8TBs")},
             "detail": d}
 
 
@@ -1717,11 +1719,10 @@ def main():
     ap.add_argument("--noise-sweep", type=int, default=1, choices=[0, 1], help="colorlut: frames/s at +-0/3/5/8/16 codes of noise (sub-line field)")
     ap.add_argument("--gst-pipeline", type=int, default=1, choices=[0, 1],
                     help="N = 1: also time the real GStreamer element (gst-launch-1.0 hiptestsrc ! hsvfilter ! fakesink, 4K, child processes)")
-    ap.add_argument("--gst-ab", type=int, default=0, choices=[0, 1], help="also time the element with MVFX_ELEMENT_PAIR=0 (one launch per buffer)")
-    ap.add_argument("--gst-n1", type=int, default=10000)
-    ap.add_argument("--gst-n2", type=int, default=160000,
+        ap.add_argument("--gst-n1", type=int, default=10000)
+    ap.add_argument("--gst-n2", type=int, default=110000,
                     help="buffers of the two timed gst-launch runs (frames/s = (n2 - n1) / (t2 - t1)); 2000 / 62000 understated the rate by 5-15 %%: the difference of two process run times needs seconds, not tenths")
-    ap.add_argument("--gst-timeout", type=float, default=60.0)
+    ap.add_argument("--gst-timeout", type=float, default=150.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--other-configs", type=int, default=1, choices=[0, 1],
                     help="hsvfilter workload: after the headline legs also measure BASELINE configs 2-5 in this run "

@@ -135,8 +135,37 @@ def element_main(args):
     print(json.dumps(out), flush=True)
 
 
+def honest_main(args):
+    """--honest 1 (round 5, VERDICT r4 missing-2 / W5): the real element on blocks that do NOT sit in the 256 MB Infinity Cache.
+    `hiptestsrc refresh=false ! hsvfilter ! fakesink` with MVFX_HIP_POOL_MIN=12: twelve 33 MB blocks in rotation (398 MB), every buffer's
+    kernel reads its block from HBM; the same with the pool's usual four blocks (133 MB: cache resident -- reported without a roofline
+    fraction); and with a device consumer behind the filter (`! hsvdetector ! fakesink`, RGBx -> RGBA, twelve-block pools on both sides).
+    The elements run as shipped: one launch per buffer (MVFX_ELEMENT_PAIR unset)."""
+    tmp = tempfile.mkdtemp()
+    w, h = args.width, args.height
+    size = f"width={w},height={h},framerate=30/1"
+    out = {"frame": f"{w}x{h}", "n1": args.n1, "n2": args.n2, "pool_blocks_hbm": 12, "pool_blocks_cache": 4}
+    flt = f"hiptestsrc num-buffers={{n}} refresh=false ! video/x-raw(memory:HIPMemory),format=RGBA,{size} ! hsvfilter hue-shift=90 saturation-mul=1.25 saturation-off=-0.05 value-mul=0.9 value-off=0.02 ! fakesink sync=false"
+    det = (f"hiptestsrc num-buffers={{n}} refresh=false ! video/x-raw(memory:HIPMemory),format=RGBx,{size} ! hsvfilter hue-shift=90 saturation-mul=1.25 saturation-off=-0.05 value-mul=0.9 value-off=0.02 ! "
+           "hsvdetector hue-ref=120 hue-var=60 saturation-ref=0.6 saturation-var=0.4 value-ref=0.6 value-var=0.4 ! fakesink sync=false")
+    run(flt.format(n=min(args.n1, 2000)), tmp)  # page cache, registry
+    reps = max(1, args.repeats)
+    med = lambda v: sorted(v)[len(v) // 2]
+    a = [rate(flt, tmp, args.n1, args.n2, {"MVFX_HIP_POOL_MIN": "12"}) for _ in range(reps)]
+    b = [rate(flt, tmp, args.n1, args.n2, {"MVFX_HIP_POOL_MIN": "4"})]
+    c = [rate(det, tmp, args.n1, args.n2 * 2 // 3, {"MVFX_HIP_POOL_MIN": "12"})]
+    out["hsvfilter_hbm_resident_fps"] = round(med(a), 1)
+    out["hsvfilter_hbm_resident_runs"] = [round(x, 1) for x in a]
+    out["hsvfilter_hbm_resident_frac_of_8TBs"] = round(med(a) * 2 * w * h * 4 / 8e12, 4)
+    out["hsvfilter_cache_resident_fps"] = round(med(b), 1)
+    out["hsvfilter_then_hsvdetector_hbm_resident_fps"] = round(med(c), 1)
+    out["hsvfilter_then_hsvdetector_frac_of_8TBs"] = round(med(c) * 4 * w * h * 4 / 8e12, 4)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--honest", type=int, default=0, help="1: the single element on a rotation larger than the Infinity Cache, and with a device consumer (bench.py's sub-line)")
     ap.add_argument("--element", default="", help="hsvfilter | hsvdetector | colorlut: the single element on device memory, pair launches on / off")
     ap.add_argument("--only", default="", help="comma-separated pipeline names of the chain mode (default: all)")
     ap.add_argument("--branches", type=int, default=0, help="N parallel hiptestsrc ! hsvfilter ! fakesink streams in one process (launch combiner A/B)")
@@ -149,6 +178,8 @@ def main():
     ap.add_argument("--others", type=int, default=0, help="--branches 1 --quick 2: also hsvdetector and colorlut as the single device element")
     ap.add_argument("--repeats", type=int, default=3, help="--element: interleaved repeats per configuration (the median is reported)")
     args = ap.parse_args()
+    if args.honest:
+        return honest_main(args)
     if args.element:
         return element_main(args)
     if args.branches > 0:
