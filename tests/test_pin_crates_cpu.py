@@ -29,3 +29,28 @@ def test_comparer_runs_on_the_committed_frames():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "every compared output agrees" in r.stdout and "DIFFERS" not in r.stdout and "MISSING" not in r.stdout
     assert r.stdout.count("PINNED") > 100
+
+
+def test_dssim_explainer_baseline_is_the_oracle_and_a_changed_constant_is_found():
+    """Round 5: when the crate's dssim differs, compare.py says WHICH choice of the restatement to look at.  Checked
+    without cargo: (a) the numpy twin's baseline equals oracle/ssim_oracle.c on the committed pairs (so its variants are variants of the
+    oracle), (b) a 'crate' that differs from the restatement in one constant -- here: the 3x3 kernel applied twice instead of the
+    binomial window -- is named by the report."""
+    sys.path.insert(0, PIN)
+    sys.path.insert(0, ROOT)
+    import compare
+    import dssim_variants as dv
+    from tests import oracle_binding as orc
+    frames = compare.load_frames()
+    names = list(frames)
+    W, H = compare.W, compare.H
+    pairs = {}
+    for i, a in enumerate(names):
+        for b in names[i:]:
+            ours = dv.dssim(frames[a], frames[b], W, H, dv.BASELINE)
+            rc, d, _ = orc.ssim_distance(frames[a], frames[b], W, H, W * 4, W * 4, "RGBA")
+            assert rc == 0 and abs(ours - d) <= 1e-9 * max(abs(d), 1e-12), (a, b, ours, d)
+            pairs[f"{a}|{b}"] = {"dssim": dv.dssim(frames[a], frames[b], W, H, dict(dv.BASELINE, window="gauss3x3_twice"))}
+    lines = dv.explain(frames, pairs, W, H)
+    assert lines[1].lstrip().startswith("MATCHES window=gauss3x3_twice"), lines[:4]
+    assert "`window=gauss3x3_twice` reproduces the crate" in lines[-1]

@@ -56,6 +56,8 @@ def main():
     ap.add_argument("crates_json", nargs="?")
     ap.add_argument("--self-test", action="store_true", help="compare the restatement with itself (checks this script, pins nothing)")
     ap.add_argument("--dssim-rtol", type=float, default=1e-4, help="relative tolerance of the dssim value (f32 library against the f64 restatement)")
+    ap.add_argument("--explain", action="store_true",
+                    help="always print the per-constant report of the dssim restatement (dssim_variants.py); printed anyway when a dssim value differs")
     args = ap.parse_args()
     if not args.self_test and not args.crates_json:
         ap.error("crates.json (the output of `cargo run --release` in tools/pin_crates) or --self-test")
@@ -63,10 +65,13 @@ def main():
     frames = load_frames()
     bad = 0
 
+    report_lines = []
+
     def report(what, ours, theirs, ok):
         nonlocal bad
         bad += 0 if ok else 1
-        print(f"{'PINNED ' if ok else 'DIFFERS'} {what}: ours {ours} crate {theirs}")
+        report_lines.append(f"{'PINNED ' if ok else 'DIFFERS'} {what}: ours {ours} crate {theirs}")
+        print(report_lines[-1])
 
     for name, f in frames.items():
         r = ref["frames"].get(name)
@@ -104,6 +109,12 @@ def main():
             rc, d, _ = orc.ssim_distance(fa, fb, W, H, W * 4, W * 4, "RGBA")
             ok = rc == 0 and (abs(d - r["dssim"]) <= args.dssim_rtol * max(abs(r["dssim"]), 1e-12) or (d == 0.0 and r["dssim"] == 0.0))
             report(f"{a}|{b} dssim", f"{d:.9e}", f"{r['dssim']:.9e}", ok)
+    dssim_differs = any(ln.startswith("DIFFERS") and " dssim:" in ln for ln in report_lines)
+    if args.explain or dssim_differs:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import dssim_variants
+        for ln in dssim_variants.explain(frames, ref["pairs"], W, H, args.dssim_rtol):
+            print(ln)
     print(f"{bad} output(s) differ or are missing" if bad else "every compared output agrees with the crates")
     return 1 if bad else 0
 
