@@ -1565,6 +1565,11 @@ def hsvfilter_main(args):
         box = {}
 
         def side_leg():
+            if os.environ.get("MVFX_BENCH_TEST_STUCK_RANK") == str(rank):  # tests/test_distributed_gpu.py: a rank that never comes back
+                time.sleep(10 ** 6)
+            if w.backend != "nccl":  # the two-ranks-on-one-GPU test mode: RCCL does not run two ranks on one device, nothing to measure
+                box["r"] = box["d"] = {"error": "not run: the ranks share one GPU (MVFX_BENCH_TEST_SHARED_GPU), RCCL needs a device per rank"}
+                return
             try:
                 torch.cuda.set_device(w.device_index)
                 vfx.check(lib.mvfx_set_device(w.device_index))
@@ -1719,9 +1724,9 @@ def main():
     ap.add_argument("--noise-sweep", type=int, default=1, choices=[0, 1], help="colorlut: frames/s at +-0/3/5/8/16 codes of noise (sub-line field)")
     ap.add_argument("--gst-pipeline", type=int, default=1, choices=[0, 1],
                     help="N = 1: also time the real GStreamer element (gst-launch-1.0 hiptestsrc ! hsvfilter ! fakesink, 4K, child processes)")
-        ap.add_argument("--gst-n1", type=int, default=10000)
+    ap.add_argument("--gst-n1", type=int, default=10000)
     ap.add_argument("--gst-n2", type=int, default=110000,
-                    help="buffers of the two timed gst-launch runs (frames/s = (n2 - n1) / (t2 - t1)); 2000 / 62000 understated the rate by 5-15 %%: the difference of two process run times needs seconds, not tenths")
+                    help="the element sub-line: the rate is taken inside ONE gst-launch run of n2 buffers, between buffer n1 and the last one")
     ap.add_argument("--gst-timeout", type=float, default=150.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--other-configs", type=int, default=1, choices=[0, 1],

@@ -65,6 +65,17 @@ def main():
     out["ssim"] = D.ssim_sharded(lambda: gpu.ssim_partial_sums(fa, fb, y0, y1, sptr), lambda mean: gpu.ssim_partial_deviation(mean, sptr),
                                  gpu.ssim_combine, cpu)
     out["ssim_band"] = [y0, y1]
+    # the same with a height that does not split evenly: 250 rows = 16 units of 16 rows, the last rank takes the remainder (122 rows)
+    uh = 250
+    ua, ub = frames.random_frame(0x5EED0007, sw, uh), None
+    ub = ua.copy()
+    ub[3::5, 1:sw * 4:13] ^= 0x21
+    tua, tub = torch.from_numpy(ua.reshape(-1)).to(dev), torch.from_numpy(ub.reshape(-1)).to(dev)
+    fua, fub = gpu.make_frame(tua.data_ptr(), sw, uh, sw * 4, "RGBA"), gpu.make_frame(tub.data_ptr(), sw, uh, sw * 4, "RGBA")
+    u0, u1 = D.ssim_band_rows(uh, rank, world)
+    out["ssim_uneven"] = D.ssim_sharded(lambda: gpu.ssim_partial_sums(fua, fub, u0, u1, sptr), lambda mean: gpu.ssim_partial_deviation(mean, sptr),
+                                        gpu.ssim_combine, cpu)
+    out["ssim_uneven_band"] = [u0, u1]
 
     # colordetect: this rank bins samples [first, first + n) of the quality-10 sample sequence
     hist = torch.zeros(32768 + 8, dtype=torch.int32, device=dev)

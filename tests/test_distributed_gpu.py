@@ -125,6 +125,16 @@ def test_world2_ssim_and_colordetect(world2_results):
         assert r["ssim"] == pytest.approx(want, rel=1e-5, abs=2e-9)  # the default f32 pipeline
         assert r["palette"] == [int(x) for x in want_pal]
     assert world2_results[0]["ssim"] == world2_results[1]["ssim"]      # every rank derives the same value
+    # unequal bands: 250 rows -> [0, 128) and the remainder rank's [128, 250); the sharded value is the whole frame's
+    assert [r["ssim_uneven_band"] for r in world2_results] == [[0, 128], [128, 250]]
+    ua = frames.random_frame(0x5EED0007, w, 250)
+    ub = ua.copy()
+    ub[3::5, 1:w * 4:13] ^= 0x21
+    rc3, want_u, _ = orc.ssim_distance(ua, ub, w, 250, w * 4, w * 4, "RGBA")
+    assert rc3 == 0
+    for r in world2_results:
+        assert r["ssim_uneven"] == pytest.approx(want_u, rel=1e-5, abs=2e-9)
+    assert world2_results[0]["ssim_uneven"] == world2_results[1]["ssim_uneven"]
 
 
 def test_bench_two_ranks_control_flow_on_one_gpu(gpu, tmp_path):
@@ -161,3 +171,24 @@ def test_bench_two_ranks_control_flow_on_one_gpu(gpu, tmp_path):
         side = subs[key]
         assert "error" in side or side["n_gpus"] == 2, key
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
+
+
+def test_bench_a_rank_stuck_in_the_side_leg_fails_the_run_after_the_line(gpu, tmp_path):
+    """a rank that never comes back from the sharded leg (here: rank 1 sleeps, MVFX_BENCH_TEST_STUCK_RANK) is a FAILED
+    run.  The ranks agree over the rendezvous store who is stuck, rank 0 still prints the headline line -- with `config.error` -- and
+    every rank leaves with exit code 5, so the launcher reports failure (round 4 left with 0)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MVFX_BENCH_TEST_SHARED_GPU="1", MVFX_BENCH_TEST_STUCK_RANK="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--pool", "6",
+           "--settle-seconds", "0.1", "--content-sweep", "0", "--side-leg-timeout", "6"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode != 0, r.stdout[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, (r.stdout[-1000:], r.stderr[-2000:])
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "stuck in its collective on rank(s) [1]" in d["config"]["error"]
+    assert "exitcode  : 5" in r.stderr or "exitcode: 5" in r.stderr or "exit code 5" in d["config"]["error"]
