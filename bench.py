@@ -852,9 +852,10 @@ def make_leg_colorlut(w, args, content):
                 "frac_wall": fps / w.world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS}
     leg = Leg("colorlut_" + content, "colorlut_frames_per_sec", "frames/s", nb, nb * 2 * FRAME_BYTES, "f32", data,
               f"colorlut 33^3 .cube (575 KB of nodes), {nb} streams of 3840x2160 RGBA per launch, content={content}; 4 + 4 algorithmic B/px "
-              "(the LUT gathers are content dependent: random colours are the worst case, flat bars the best); kernel: the x-prelerped tile "
-              "kernel (6.9 MB table of the four x-lerps + the y-difference per r byte, built once per LUT; window staged in LDS)",
-              step, ["colorlut_xtile_kernel"],
+              "(the LUT gathers are content dependent: random colours are the worst case, flat bars the best); kernels: the x-prelerped window "
+              "kernels (6.9 MB table of the four x-lerps + the y-difference per r byte, built once per LUT) -- per-wave windows on calm pictures, "
+              "one window per workgroup on busy ones, chosen by a content probe of an earlier frame",
+              step, ["colorlut_xtile_kernel", "colorlut_xwg_kernel"],
               cpu=(lambda s: cpu_baseline_colorlut(s, host, cube_text, content)) if host else None)
     def noise_sweep():
         """frames/s of the same batched launch on natural-like frames with +-0 / 3 / 5 / 8 / 16 codes of noise (camera footage is
@@ -862,7 +863,7 @@ def make_leg_colorlut(w, args, content):
         res = {}
         for amp in (0, 3, 5, 8, 16):
             fill_frames(torch, dev, gen, src, "natural", W, H, first_frame=w.rank * pool * nb, noise=amp)
-            for i in range(6):
+            for i in range(40):  # (the content probe of the LUT looks at every 32nd launch's frame: its verdict for the new content is in by then)
                 step(i)
             secs_, ev_ms_ = w.timed(step, 30, events=True)
             res[str(amp)] = round(nb * w.world / (ev_ms_ * 1e-3))
