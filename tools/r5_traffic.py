@@ -231,8 +231,8 @@ for wl in sorted(d for d in os.listdir(out) if os.path.isdir(os.path.join(out, d
         ld = counters(os.path.join(base, "LDS")).get(dom, {})
         gui = avg(ld, "GRBM_GUI_ACTIVE")
         if gui and avg(ld, "SQ_LDS_IDX_ACTIVE") is not None:
-            # SQ_LDS_IDX_ACTIVE sums the LDS-array cycles of all CUs (256); GRBM_GUI_ACTIVE counts the launch's cycles once
-            evidence["lds_array_busy_frac"] = avg(ld, "SQ_LDS_IDX_ACTIVE") / (gui * 256.0)
+            # LDS-array cycles summed over the chip per cycle of the launch: "so many of the 256 LDS arrays busy on average"
+            evidence["lds_arrays_busy_of_256"] = avg(ld, "SQ_LDS_IDX_ACTIVE") / gui
             if avg(ld, "SQ_LDS_BANK_CONFLICT") is not None and avg(ld, "SQ_LDS_IDX_ACTIVE"):
                 evidence["lds_conflict_share"] = avg(ld, "SQ_LDS_BANK_CONFLICT") / avg(ld, "SQ_LDS_IDX_ACTIVE")
         print(f"# evidence for `bound`, dominant kernel {dom}: " + ", ".join(f"{k} {v:.3g}" for k, v in evidence.items() if v is not None))

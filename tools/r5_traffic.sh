@@ -46,5 +46,8 @@ if want calib; then
 fi
 cd $REPO
 python3 tools/r5_traffic.py $O > $O/summary.txt 2>&1
-find $O -name "*counter_collection.csv" -size +1M -delete; find $O -name "*.db" -delete
+cp $O/summary.txt $O/traffic.json $REPO/gpurun_out/ 2>/dev/null  # the two results, beside the raw files
+# (the raw per-dispatch files are large: what comes back is the summary, traffic.json and the small csv; never re-run r5_traffic.py on the
+# pruned directory -- its result would miss the pruned workloads)
+find $O -name "*counter_collection.csv" -size +1M -delete; find $O -name "*kernel_trace.csv" -size +2M -delete; find $O -name "*.db" -delete
 cat $O/summary.txt | head -150
