@@ -910,7 +910,7 @@ def make_leg_hsv3(w, args, which):
             return cpu_baseline_of(make_unit, seconds, "frames/s", "3840x2160 RGB frame through orc_hsvfilter_transform_frame_ip (oracle/hsv_oracle.c)")
         leg = Leg("hsvfilter_rgb", "hsvfilter_4k_rgb_frames_per_sec", "frames/s", nb, nb * 2 * W * H * 3, "f32",
                   "synthetic videotestsrc pattern=smpte frames packed to RGB, device-resident",
-                  f"hsvfilter 3840x2160 RGB (3 B/px) in place, {nb} streams per launch; 3 + 3 algorithmic B/px", step, ["hsvfilter3_kernel"],
+                  f"hsvfilter 3840x2160 RGB (3 B/px) in place, {nb} streams per launch; 3 + 3 algorithmic B/px", step, ["hsvfilter3_typed_kernel"],
                   cpu=cpu if host else None)
         leg.keep = (src, fi)
         return leg
@@ -936,7 +936,7 @@ def make_leg_hsv3(w, args, which):
         return cpu_baseline_of(make_unit, seconds, "frames/s", "3840x2160 RGB frame through orc_hsvdetector_transform_frame (oracle/hsv_oracle.c)")
     leg = Leg("hsvdetector_rgb", "hsvdetector_4k_rgb_in_frames_per_sec", "frames/s", nb, nb * W * H * 7, "f32",
               "synthetic videotestsrc pattern=smpte frames packed to RGB, device-resident",
-              f"hsvdetector 3840x2160 RGB -> RGBA, {nb} streams per launch; 3 + 4 algorithmic B/px", step, ["hsvdetector_kernel"],
+              f"hsvdetector 3840x2160 RGB -> RGBA, {nb} streams per launch; 3 + 4 algorithmic B/px", step, ["hsvdetector3_typed_kernel"],
               cpu=cpu if host else None)
     leg.keep = (src, dst, fi, fo)
     return leg

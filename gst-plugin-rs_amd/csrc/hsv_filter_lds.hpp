@@ -38,6 +38,8 @@ void launch_hsvfilter_typed(bool neg_shift, int tile, bool streaming, dim3 grid,
                             uint32_t rows, uint64_t stride, const FastConsts &p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr);
 
 // the same with per-frame settings in the kernel arguments (all frames: hue_shift of one sign)
+void launch_hsvfilter3_typed(bool neg_shift, int tile, bool streaming, dim3 grid, hipStream_t stream, const FrameBatch &fb, uint64_t width,
+                             uint32_t rows, uint64_t stride, const FastConsts &p, uint32_t word3a, uint32_t word3b, uint32_t frame_bytes, bool bgr);
 void launch_hsvfilter_typed_frames(bool neg_shift, int tile, bool streaming, dim3 grid, hipStream_t stream, const FrameBatch &fb, uint64_t width,
                                    uint32_t rows, uint64_t stride, const FastConsts &p, const FrameSettingsBatch &fs, uint32_t word3,
                                    uint32_t frame_bytes, int off, bool bgr);

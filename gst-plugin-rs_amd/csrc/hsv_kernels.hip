@@ -326,6 +326,58 @@ __global__ __launch_bounds__(kBlock) void hsvdetector_typed_kernel(FrameBatch in
     }
 }
 
+// The same for 3-byte inputs (RGB / BGR -> any 4-byte output), round 5: typed loads at unaligned byte offsets (hsvfilter3_typed_kernel in
+// hsv_typed_kernels.hip has the probe and the two-descriptor scheme: a lane reads its own twelve bytes only).  The output pixel's three
+// colour bytes come out of the raw twelve bytes with one two-source v_perm_b32 per pixel (selectors from the host: they depend on the
+// two layouts only), the alpha byte is the hit mask through one v_and_or_b32.
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+__global__ __launch_bounds__(kBlock) void hsvdetector3_typed_kernel(FrameBatch in_fb, FrameBatch out_fb, uint64_t width, uint32_t rows,
+                                                                    uint64_t in_stride, uint64_t out_stride, HsvDetectorParams p,
+                                                                    uint32_t word3a, uint32_t word3b, uint32_t frame_bytes, uint4 perm_sel,
+                                                                    uint32_t alpha_mask)
+{
+    const uint64_t a = reinterpret_cast<uint64_t>(in_fb.base[blockIdx.z]);
+    uint8_t *out = out_fb.base[blockIdx.z];
+    i32x4 ra, rb;
+    ra.x = rb.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    ra.y = rb.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));
+    ra.z = rb.z = __builtin_amdgcn_readfirstlane((int)frame_bytes);
+    ra.w = __builtin_amdgcn_readfirstlane((int)word3a);
+    rb.w = __builtin_amdgcn_readfirstlane((int)word3b);
+    const uint32_t s0 = __builtin_amdgcn_readfirstlane(perm_sel.x), s1 = __builtin_amdgcn_readfirstlane(perm_sel.y),
+                   s2 = __builtin_amdgcn_readfirstlane(perm_sel.z), s3 = __builtin_amdgcn_readfirstlane(perm_sel.w);
+    const uint32_t am = __builtin_amdgcn_readfirstlane(alpha_mask);
+    for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        uint8_t *oline = out + (uint64_t)row * out_stride;
+        const uint32_t line_off = (uint32_t)((uint64_t)row * in_stride);
+        const uint64_t groups = width >> 2; // the launcher guarantees width % 4 == 0
+        for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (uint64_t)gridDim.x * kBlock) {
+            u32x3_t raw;
+            f32x3 c[4];
+            const uint32_t voff = line_off + (uint32_t)g * 12u;
+            asm volatile("buffer_load_dwordx3 %0, %5, %6, 0 offen\n\t"
+                         "buffer_load_format_xyz %1, %5, %6, 0 offen\n\t"
+                         "buffer_load_format_xyz %2, %5, %6, 0 offen offset:3\n\t"
+                         "buffer_load_format_xyz %3, %5, %6, 0 offen offset:6\n\t"
+                         "buffer_load_format_xyz %4, %5, %7, 0 offen offset:8\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(raw), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+                         : "v"(voff), "s"(ra), "s"(rb)
+                         : "memory");
+            // pixel j's three bytes sit in (lo, hi) = (a, a), (a, b), (b, c), (c, c)   (v_perm: selector bytes 0-3 = S1 = lo, 4-7 = S0 = hi)
+            const uint32_t lo[4] = {raw.x, raw.x, raw.y, raw.z}, hi[4] = {raw.x, raw.y, raw.z, raw.z}, sel[4] = {s0, s1, s2, s3};
+            uint32_t r[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const HsvN hsv = from_unit_rgb_fast_n(c[j].x, c[j].y, c[j].z, p.consts);
+                const uint32_t colour = __builtin_amdgcn_perm(hi[j], lo[j], sel[j]);
+                r[j] = (~detect_miss_mask_fast(hsv, p) & am) | colour;
+            }
+            *reinterpret_cast<uint4 *>(oline + (g << 4)) = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+    }
+}
+
 template <int IN_BPP, int IN_OFF, bool IN_BGR, bool OUT_A0, bool OUT_BGR, int VARIANT, int MODE>
 __global__ __launch_bounds__(kBlock) void hsvdetector_kernel(FrameBatch in_fb, FrameBatch out_fb,
                                                              uint64_t width, uint32_t rows,
@@ -627,6 +679,19 @@ int hsvfilter_impl(const mvfx_frame *frames, uint32_t n, const mvfx_hsvfilter_se
             const bool neg = std::signbit(s->hue_shift) && s->hue_shift != 0.0f;
             launch_hsvfilter_typed(neg, g.tile == kTile ? kTile : 1, opt_nontemporal(), g.grid, stream, fb, g.width, g.rows, g.stride, p, word3,
                                    (uint32_t)frame_bytes, off, bgr);
+            MVFX_HIP_TRY(hipGetLastError());
+            continue;
+        }
+        if (opt_typed_loads() && use_fast && bpp == 3 && g.mode == kModeVec4 && (g.width & 3) == 0 && frame_bytes < (1ull << 32)) {
+            // RGB / BGR by typed loads at unaligned byte offsets (hsvfilter3_typed_kernel): descriptor A delivers bytes 0, 1, 2 of the four
+            // fetched, descriptor B bytes 1, 2, 3 (a lane's fourth pixel, read from byte offset 8 of its twelve)
+            const uint32_t r0 = bgr ? 2 : 0, b0 = bgr ? 0 : 2;
+            const uint32_t word3a = (4 + r0) | (5u << 3) | ((4 + b0) << 6) | (10u << 15), word3b = (5 + r0) | (6u << 3) | ((5 + b0) << 6) | (10u << 15);
+            const bool neg = std::signbit(s->hue_shift) && s->hue_shift != 0.0f;
+            const int tile3 = (g.width / 4) * m >= kTileMinGroups ? kTile : 1;
+            dim3 grid3 = g.grid;
+            if (tile3 > 1) grid3.x = (uint32_t)std::max<uint64_t>(1, (g.width / 4 + (uint64_t)kBlock * tile3 - 1) / ((uint64_t)kBlock * tile3));
+            launch_hsvfilter3_typed(neg, tile3, opt_nontemporal(), grid3, stream, fb, g.width, g.rows, g.stride, p, word3a, word3b, (uint32_t)frame_bytes, bgr);
             MVFX_HIP_TRY(hipGetLastError());
             continue;
         }
@@ -968,6 +1033,24 @@ int hsvdetector_impl(const mvfx_frame *ins, const mvfx_frame *outs, uint32_t n,
             const uint32_t o0 = obgr ? iB : iR, o2 = obgr ? iR : iB; // detect_px4_fast's selector, formed at run time
             const uint32_t sel = a0 ? (4u | (o0 << 8) | (iG << 16) | (o2 << 24)) : (o0 | (iG << 8) | (o2 << 16) | (4u << 24));
             MVFX_LAUNCH(hsvdetector_typed_kernel, grid, dim3(kBlock), 0, stream, ifb, ofb, width, rows, is, os, p, word3, (uint32_t)in_bytes, sel);
+            MVFX_HIP_TRY(hipGetLastError());
+            continue;
+        }
+        if (opt_typed_loads() && vec && variant == kDetFast && bpp == 3 && (width & 3) == 0 && in_bytes < (1ull << 32)) {
+            // 3-byte input by typed loads (hsvdetector3_typed_kernel).  Descriptor A delivers bytes 0, 1, 2 of the four fetched as R, G, B,
+            // descriptor B bytes 1, 2, 3 (the lane's fourth pixel).  Colour selectors: the first byte of pixel j among the eight of its
+            // (lo, hi) dword pair is 0, 3, 2, 1; the output keeps or swaps the outer two; 0x0c = constant zero for the alpha byte
+            const uint32_t r0 = ibgr ? 2 : 0, b0 = ibgr ? 0 : 2;
+            const uint32_t word3a = (4 + r0) | (5u << 3) | ((4 + b0) << 6) | (10u << 15), word3b = (5 + r0) | (6u << 3) | ((5 + b0) << 6) | (10u << 15);
+            const uint32_t first[4] = {0, 3, 2, 1};
+            uint32_t sels[4];
+            for (int j = 0; j < 4; j++) {
+                const uint32_t c0 = first[j], c1 = first[j] + 1, c2 = first[j] + 2;
+                const uint32_t o0 = ibgr != obgr ? c2 : c0, o2 = ibgr != obgr ? c0 : c2;
+                sels[j] = a0 ? (0x0cu | (o0 << 8) | (c1 << 16) | (o2 << 24)) : (o0 | (c1 << 8) | (o2 << 16) | (0x0cu << 24));
+            }
+            MVFX_LAUNCH(hsvdetector3_typed_kernel, grid, dim3(kBlock), 0, stream, ifb, ofb, width, rows, is, os, p, word3a, word3b, (uint32_t)in_bytes,
+                        make_uint4(sels[0], sels[1], sels[2], sels[3]), a0 ? 0x000000ffu : 0xff000000u);
             MVFX_HIP_TRY(hipGetLastError());
             continue;
         }

@@ -124,7 +124,107 @@ __global__ __launch_bounds__(kBlock) void hsvfilter4_typed_frames_kernel(FrameBa
 }
 
 
+// ---- 3-byte formats (RGB / BGR) with typed loads (round 5) -----------------------------------------------------------------------
+// A typed buffer load of DATA_FORMAT 8_8_8_8 does not need a 4-byte aligned address on gfx950 (tools/probes/typed_unaligned.hip: byte
+// offsets 1, 2, 3 x lane, all 1 024 channel values exact), so a packed RGB pixel at byte 3 i is fetched like an RGBA one: four bytes
+// from 3 i, the first three delivered as RN(byte / 255).  The VALU kernel (hsvfilter3_kernel) spends 13 of its 67 instructions per pixel
+// on taking the twelve bytes of a lane apart and dividing them; here the texture unit does both.  A lane owns 12 bytes = 4 pixels and
+// never reads outside them: pixels 0..2 from byte offsets 0, 3, 6 through descriptor A (DST_SEL x, y, z = bytes 0, 1, 2), pixel 3 from
+// byte offset 8 through descriptor B (bytes 1, 2, 3) -- the last pixel of a frame is read without touching the byte behind it.  The four
+// result dwords [c0 c1 c2 .] are packed into three with three v_perm_b32.
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+
+template <int VARIANT, int TILE, bool NT>
+__global__ __launch_bounds__(kBlock) void hsvfilter3_typed_kernel(FrameBatch fb, uint64_t width, uint32_t rows, uint64_t stride, FastConsts p,
+                                                                  uint32_t word3a, uint32_t word3b, uint32_t frame_bytes, bool bgr)
+{
+    static_assert(VARIANT == kFast || VARIANT == kFastNeg, "strength-reduced variants only");
+    __shared__ FilterLds lds;
+    init_filter_lds<VARIANT>(lds, 0, bgr);
+    uint8_t *frame = fb.base[blockIdx.z];
+    const uint64_t a = reinterpret_cast<uint64_t>(frame);
+    i32x4 ra, rb;
+    ra.x = rb.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    ra.y = rb.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu)); // stride 0: raw byte offsets
+    ra.z = rb.z = __builtin_amdgcn_readfirstlane((int)frame_bytes);
+    ra.w = __builtin_amdgcn_readfirstlane((int)word3a);
+    rb.w = __builtin_amdgcn_readfirstlane((int)word3b);
+    for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        uint8_t *line = frame + (uint64_t)row * stride;
+        const uint32_t line_off = (uint32_t)((uint64_t)row * stride);
+        const uint64_t groups = width >> 2; // the launcher guarantees width % 4 == 0
+        for (uint64_t t0 = (uint64_t)blockIdx.x * (kBlock * TILE); t0 < groups; t0 += (uint64_t)gridDim.x * (kBlock * TILE)) {
+            f32x3 c[TILE][4];
+            uint32_t voff[TILE];
+#pragma unroll
+            for (int u = 0; u < TILE; u++) // groups past the end: the buffer bounds check returns zeros, nothing is stored
+                voff[u] = line_off + (uint32_t)(t0 + (uint64_t)u * kBlock + threadIdx.x) * 12u;
+            // all loads of a lane and their wait are ONE asm statement: the compiler does not track asm loads, so nothing may touch their
+            // registers in between (hsvfilter4_typed_body)
+#define MVFX_TYPED3_2(NTS)                                                                        \
+    asm volatile("buffer_load_format_xyz %0, %8, %10, 0 offen" NTS "\n\t"                          \
+                 "buffer_load_format_xyz %1, %8, %10, 0 offen offset:3" NTS "\n\t"                 \
+                 "buffer_load_format_xyz %2, %8, %10, 0 offen offset:6" NTS "\n\t"                 \
+                 "buffer_load_format_xyz %3, %8, %11, 0 offen offset:8" NTS "\n\t"                 \
+                 "buffer_load_format_xyz %4, %9, %10, 0 offen" NTS "\n\t"                          \
+                 "buffer_load_format_xyz %5, %9, %10, 0 offen offset:3" NTS "\n\t"                 \
+                 "buffer_load_format_xyz %6, %9, %10, 0 offen offset:6" NTS "\n\t"                 \
+                 "buffer_load_format_xyz %7, %9, %11, 0 offen offset:8" NTS "\n\t"                 \
+                 "s_waitcnt vmcnt(0)"                                                               \
+                 : "=&v"(c[0][0]), "=&v"(c[0][1]), "=&v"(c[0][2]), "=&v"(c[0][3]), "=&v"(c[1][0]), "=&v"(c[1][1]), "=&v"(c[1][2]), "=&v"(c[1][3]) \
+                 : "v"(voff[0]), "v"(voff[1]), "s"(ra), "s"(rb)                                     \
+                 : "memory")
+#define MVFX_TYPED3_1(NTS)                                                                        \
+    asm volatile("buffer_load_format_xyz %0, %4, %5, 0 offen" NTS "\n\t"                           \
+                 "buffer_load_format_xyz %1, %4, %5, 0 offen offset:3" NTS "\n\t"                  \
+                 "buffer_load_format_xyz %2, %4, %5, 0 offen offset:6" NTS "\n\t"                  \
+                 "buffer_load_format_xyz %3, %4, %6, 0 offen offset:8" NTS "\n\t"                  \
+                 "s_waitcnt vmcnt(0)"                                                               \
+                 : "=&v"(c[0][0]), "=&v"(c[0][1]), "=&v"(c[0][2]), "=&v"(c[0][3])                   \
+                 : "v"(voff[0]), "s"(ra), "s"(rb)                                                   \
+                 : "memory")
+            if constexpr (TILE == 2) {
+                if constexpr (NT) MVFX_TYPED3_2(" nt"); else MVFX_TYPED3_2("");
+            } else {
+                if constexpr (NT) MVFX_TYPED3_1(" nt"); else MVFX_TYPED3_1("");
+            }
+#undef MVFX_TYPED3_2
+#undef MVFX_TYPED3_1
+#pragma unroll
+            for (int u = 0; u < TILE; u++) {
+                const uint64_t g = t0 + (uint64_t)u * kBlock + threadIdx.x;
+                if (g < groups) {
+                    uint32_t w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t T;
+                        const uint32_t sel_off = hsvfilter_fast_unit<VARIANT == kFastNeg>(c[u][j].x, c[u][j].y, c[u][j].z, p, T);
+                        w[j] = __builtin_amdgcn_perm(T, 0u, sextant_at(lds.sextant, sel_off)); // [c0 c1 c2 0] in memory order
+                    }
+                    // twelve bytes: p0 = d0[0..2], p1 = d0[3] d1[0..1], p2 = d1[2..3] d2[0], p3 = d2[1..3]   (v_perm: bytes 0-3 = S1, 4-7 = S0)
+                    const u32x3 t = {__builtin_amdgcn_perm(w[1], w[0], 0x04020100u), __builtin_amdgcn_perm(w[2], w[1], 0x05040201u),
+                                     __builtin_amdgcn_perm(w[3], w[2], 0x06050402u)};
+                    if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<u32x3 *>(line + g * 12));
+                    else *reinterpret_cast<u32x3 *>(line + g * 12) = t;
+                }
+            }
+        }
+    }
+}
+
 } // namespace
+
+void launch_hsvfilter3_typed(bool neg_shift, int tile, bool streaming, dim3 grid, hipStream_t stream, const FrameBatch &fb, uint64_t width,
+                             uint32_t rows, uint64_t stride, const FastConsts &p, uint32_t word3a, uint32_t word3b, uint32_t frame_bytes, bool bgr)
+{
+#define MVFX_LT3(V, T_, NT_) \
+    MVFX_LAUNCH((hsvfilter3_typed_kernel<V, T_, NT_>), grid, dim3(kBlock), 0, stream, fb, width, rows, stride, p, word3a, word3b, frame_bytes, bgr)
+#define MVFX_LT3_NT(V, T_) do { if (streaming) MVFX_LT3(V, T_, true); else MVFX_LT3(V, T_, false); } while (0)
+    if (tile == 2) { if (neg_shift) MVFX_LT3_NT(kFastNeg, 2); else MVFX_LT3_NT(kFast, 2); }
+    else { if (neg_shift) MVFX_LT3_NT(kFastNeg, 1); else MVFX_LT3_NT(kFast, 1); }
+#undef MVFX_LT3_NT
+#undef MVFX_LT3
+}
 
 void launch_hsvfilter_typed(bool neg_shift, int tile, bool streaming, dim3 grid, hipStream_t stream, const FrameBatch &fb, uint64_t width,
                             uint32_t rows, uint64_t stride, const FastConsts &p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr)
