@@ -285,10 +285,14 @@ __device__ __forceinline__ uint32_t detect_px4_fast(uint32_t px, const HsvDetect
 // test.  The descriptor's DST_SEL delivers (R, G, B); the v_perm selector that builds the output pixel from the raw
 // input dword and the hit mask is a kernel argument (it depends on the two layouts only), so one instantiation serves
 // all 16 format pairs.
+#ifndef MVFX_DET_TILE
+#define MVFX_DET_TILE 2 // 16-byte pixel groups per lane of hsvdetector_typed_kernel (round 5; 1 = rounds 3/4)
+#endif
 __global__ __launch_bounds__(kBlock) void hsvdetector_typed_kernel(FrameBatch in_fb, FrameBatch out_fb, uint64_t width, uint32_t rows,
                                                                    uint64_t in_stride, uint64_t out_stride, HsvDetectorParams p,
                                                                    uint32_t word3, uint32_t frame_bytes, uint32_t perm_sel)
 {
+    constexpr int TILE = MVFX_DET_TILE;
     const uint64_t a = reinterpret_cast<uint64_t>(in_fb.base[blockIdx.z]);
     uint8_t *out = out_fb.base[blockIdx.z];
     i32x4 rs;
@@ -301,27 +305,54 @@ __global__ __launch_bounds__(kBlock) void hsvdetector_typed_kernel(FrameBatch in
         uint8_t *oline = out + (uint64_t)row * out_stride;
         const uint32_t line_off = (uint32_t)((uint64_t)row * in_stride);
         const uint64_t groups = width >> 2; // the launcher guarantees width % 4 == 0
-        for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (uint64_t)gridDim.x * kBlock) {
-            u32x4 raw;
-            f32x3 c[4];
-            const uint32_t voff = line_off + (uint32_t)(g << 4);
-            asm volatile("buffer_load_dwordx4 %0, %5, %6, 0 offen\n\t"
-                         "buffer_load_format_xyz %1, %5, %6, 0 offen\n\t"
-                         "buffer_load_format_xyz %2, %5, %6, 0 offen offset:4\n\t"
-                         "buffer_load_format_xyz %3, %5, %6, 0 offen offset:8\n\t"
-                         "buffer_load_format_xyz %4, %5, %6, 0 offen offset:12\n\t"
-                         "s_waitcnt vmcnt(0)"
-                         : "=&v"(raw), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
-                         : "v"(voff), "s"(rs)
-                         : "memory");
-            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-            uint32_t r[4];
+        for (uint64_t t0 = (uint64_t)blockIdx.x * (kBlock * TILE); t0 < groups; t0 += (uint64_t)gridDim.x * (kBlock * TILE)) {
+            u32x4 raw[TILE];
+            f32x3 c[TILE][4];
+            uint32_t voff[TILE];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const HsvN hsv = from_unit_rgb_fast_n(c[j].x, c[j].y, c[j].z, p.consts);
-                r[j] = __builtin_amdgcn_perm(~detect_miss_mask_fast(hsv, p), w[j], sel); // selector byte 4 = the hit mask
+            for (int u = 0; u < TILE; u++) // groups past the end: the buffer bounds check returns zeros, nothing is stored
+                voff[u] = line_off + (uint32_t)((t0 + (uint64_t)u * kBlock + threadIdx.x) << 4);
+            if constexpr (TILE == 2) {
+                asm volatile("buffer_load_dwordx4 %0, %10, %12, 0 offen\n\t"
+                             "buffer_load_dwordx4 %1, %11, %12, 0 offen\n\t"
+                             "buffer_load_format_xyz %2, %10, %12, 0 offen\n\t"
+                             "buffer_load_format_xyz %3, %10, %12, 0 offen offset:4\n\t"
+                             "buffer_load_format_xyz %4, %10, %12, 0 offen offset:8\n\t"
+                             "buffer_load_format_xyz %5, %10, %12, 0 offen offset:12\n\t"
+                             "buffer_load_format_xyz %6, %11, %12, 0 offen\n\t"
+                             "buffer_load_format_xyz %7, %11, %12, 0 offen offset:4\n\t"
+                             "buffer_load_format_xyz %8, %11, %12, 0 offen offset:8\n\t"
+                             "buffer_load_format_xyz %9, %11, %12, 0 offen offset:12\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(raw[0]), "=&v"(raw[TILE - 1]), "=&v"(c[0][0]), "=&v"(c[0][1]), "=&v"(c[0][2]), "=&v"(c[0][3]),
+                               "=&v"(c[TILE - 1][0]), "=&v"(c[TILE - 1][1]), "=&v"(c[TILE - 1][2]), "=&v"(c[TILE - 1][3])
+                             : "v"(voff[0]), "v"(voff[TILE - 1]), "s"(rs)
+                             : "memory");
+            } else {
+                asm volatile("buffer_load_dwordx4 %0, %5, %6, 0 offen\n\t"
+                             "buffer_load_format_xyz %1, %5, %6, 0 offen\n\t"
+                             "buffer_load_format_xyz %2, %5, %6, 0 offen offset:4\n\t"
+                             "buffer_load_format_xyz %3, %5, %6, 0 offen offset:8\n\t"
+                             "buffer_load_format_xyz %4, %5, %6, 0 offen offset:12\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(raw[0]), "=&v"(c[0][0]), "=&v"(c[0][1]), "=&v"(c[0][2]), "=&v"(c[0][3])
+                             : "v"(voff[0]), "s"(rs)
+                             : "memory");
             }
-            *reinterpret_cast<uint4 *>(oline + (g << 4)) = make_uint4(r[0], r[1], r[2], r[3]);
+#pragma unroll
+            for (int u = 0; u < TILE; u++) {
+                const uint64_t g = t0 + (uint64_t)u * kBlock + threadIdx.x;
+                if (g < groups) {
+                    const uint32_t w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+                    uint32_t r[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const HsvN hsv = from_unit_rgb_fast_n(c[u][j].x, c[u][j].y, c[u][j].z, p.consts);
+                        r[j] = __builtin_amdgcn_perm(~detect_miss_mask_fast(hsv, p), w[j], sel); // selector byte 4 = the hit mask
+                    }
+                    *reinterpret_cast<uint4 *>(oline + (g << 4)) = make_uint4(r[0], r[1], r[2], r[3]);
+                }
+            }
         }
     }
 }
@@ -1032,7 +1063,9 @@ int hsvdetector_impl(const mvfx_frame *ins, const mvfx_frame *outs, uint32_t n,
             const uint32_t word3 = (4 + iR) | ((4 + iG) << 3) | ((4 + iB) << 6) | (10u << 15); // see hsvfilter_impl
             const uint32_t o0 = obgr ? iB : iR, o2 = obgr ? iR : iB; // detect_px4_fast's selector, formed at run time
             const uint32_t sel = a0 ? (4u | (o0 << 8) | (iG << 16) | (o2 << 24)) : (o0 | (iG << 8) | (o2 << 16) | (4u << 24));
-            MVFX_LAUNCH(hsvdetector_typed_kernel, grid, dim3(kBlock), 0, stream, ifb, ofb, width, rows, is, os, p, word3, (uint32_t)in_bytes, sel);
+            dim3 tgrid = grid; // MVFX_DET_TILE groups per lane
+            tgrid.x = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((work + (uint64_t)kBlock * MVFX_DET_TILE - 1) / ((uint64_t)kBlock * MVFX_DET_TILE), 65535u * 16u));
+            MVFX_LAUNCH(hsvdetector_typed_kernel, tgrid, dim3(kBlock), 0, stream, ifb, ofb, width, rows, is, os, p, word3, (uint32_t)in_bytes, sel);
             MVFX_HIP_TRY(hipGetLastError());
             continue;
         }
