@@ -1057,7 +1057,23 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
         cpx = (uint32_t)__builtin_amdgcn_readfirstlane((int)cpx); // wave-uniform by construction: keeps the two table look-ups below scalar
 #endif
         const uint32_t cr = cpx & 0xffu;
-        const uint32_t cy = p.tile_tables[2 * (256 + ((cpx >> 8) & 0xffu))], cz = p.tile_tables[2 * (512 + ((cpx >> 16) & 0xffu))];
+#ifndef MVFX_XTILE_ANCHOR_ARITH
+#define MVFX_XTILE_ANCHOR_ARITH 1 // 1 (round 5): the anchor's y / z cells by arithmetic instead of two scalar loads from the coordinate table
+#endif
+        uint32_t cy, cz;
+        if (MVFX_XTILE_ANCHOR_ARITH) {
+            // Where the window goes decides how many pixels find their entries in it, never what they compute: the anchor's cell may be
+            // formed any way.  The two table look-ups of rounds 3 and 4 are scalar loads whose address depends on the pixels -- one more
+            // memory round trip on the chain pixel loads -> anchor -> window fill that every wave walks before its first row; the same
+            // lattice arithmetic in a handful of VALU operations on the (uniform) anchor colour gives the cell the table would have given.
+            const float gy = (float)((cpx >> 8) & 0xffu) * (1.0f / 255.0f), bz = (float)((cpx >> 16) & 0xffu) * (1.0f / 255.0f);
+            const float ny = fminf(fmaxf(gy * p.scale[1] + p.offset[1], 0.0f), 1.0f) * p.size_m1, nz = fminf(fmaxf(bz * p.scale[2] + p.offset[2], 0.0f), 1.0f) * p.size_m1;
+            cy = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((uint32_t)ny, p.size - 1));
+            cz = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((uint32_t)nz, p.size - 1));
+        } else {
+            cy = p.tile_tables[2 * (256 + ((cpx >> 8) & 0xffu))];
+            cz = p.tile_tables[2 * (512 + ((cpx >> 16) & 0xffu))];
+        }
         ccpx = cpx;
         ar = min((cr > RW / 2 ? cr - RW / 2 : 0u) & ~1u, 256u - RW); // even: a window row starts on a 16-byte piece
         const uint32_t ay = min(cy > 0 ? cy - 1 : 0u, p.size - 3), az = min(cz > 0 ? cz - 1 : 0u, p.size - 3); // z rows run 0 .. size
@@ -1281,7 +1297,16 @@ __global__ __launch_bounds__(kBlock) void colorlut_xwg_kernel(FrameBatch in_fb, 
         if (n == 3 || n == 0) cpx = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_anchor[0]) & 0xffffffu;
         ccpx = cpx;
         const uint32_t cr = cpx & 0xffu;
-        const uint32_t cy = p.tile_tables[2 * (256 + ((cpx >> 8) & 0xffu))], cz = p.tile_tables[2 * (512 + ((cpx >> 16) & 0xffu))];
+        uint32_t cy, cz;
+        if (MVFX_XTILE_ANCHOR_ARITH) { // the anchor's cells by arithmetic, not by two dependent scalar loads (colorlut_xtile_kernel)
+            const float gy = (float)((cpx >> 8) & 0xffu) * (1.0f / 255.0f), bz = (float)((cpx >> 16) & 0xffu) * (1.0f / 255.0f);
+            const float ny = fminf(fmaxf(gy * p.scale[1] + p.offset[1], 0.0f), 1.0f) * p.size_m1, nz = fminf(fmaxf(bz * p.scale[2] + p.offset[2], 0.0f), 1.0f) * p.size_m1;
+            cy = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((uint32_t)ny, p.size - 1));
+            cz = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((uint32_t)nz, p.size - 1));
+        } else {
+            cy = p.tile_tables[2 * (256 + ((cpx >> 8) & 0xffu))];
+            cz = p.tile_tables[2 * (512 + ((cpx >> 16) & 0xffu))];
+        }
         ar = min((cr > RW / 2 ? cr - RW / 2 : 0u) & ~1u, 256u - RW); // even: a window row starts on a 16-byte piece
         const uint32_t ay = min(cy > kWgNY / 2 ? cy - kWgNY / 2 : 0u, p.size - kWgNY), az = min(cz > kWgNZ / 2 ? cz - kWgNZ / 2 : 0u, p.size - kWgNZ); // z rows run 0 .. size
         ayp = ay * kWgPitchY;
