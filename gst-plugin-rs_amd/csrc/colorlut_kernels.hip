@@ -594,7 +594,14 @@ constexpr int kTileNbPieces = kTileNbCells * 6;        // 16-byte pieces
 #endif
 constexpr int kTileCellPitch = MVFX_TILE_CELL_PITCH;
 #ifndef MVFX_XTILE_RW
-#define MVFX_XTILE_RW 24 // r bytes per window row of colorlut_xtile_kernel
+#define MVFX_XTILE_RW 18 // r bytes per window row of colorlut_xtile_kernel.  24 in rounds 3 and 4; round 5 (with two-pixel row passes, below): what the
+                         // kernel is short of is waves -- 94 VGPRs and 32 KB of LDS per workgroup allowed five per SIMD.  Two pixels per pass
+                         // need 56-60 VGPRs, and 18 r bytes x 3 x 4 rows = 5 184 bytes per wave put six workgroups on a CU:
+                         //   16 x 4K per launch, noise +-0 / 3 / 5 / 8:  24 r bytes, four-pixel passes (round 4)  78.4 / 75.4 / 70.0 / 54.8 k fps
+                         //                                             24, two-pixel passes (five workgroups)    75.4 / 73.0 / 69.8 / 55.0
+                         //                                             18, two-pixel passes (six)                80.5 / 78.1 / 69.9 / 41.1
+                         //                                             16 (seven)  83.0 / 78.3 / 62.5 / 39.1     12 (eight)  83.7 / 60.7 / 41.0 / 36.9
+                         // (busy pictures go to colorlut_xwg_kernel: the content probe; profiles/r5/colorlut_experiments.txt, section 9)
 #endif
 constexpr int kTileWaveLdsFloat4 = kTileNbCells * kTileCellPitch + 2;  // +32 bytes: de-phases the four waves' regions over the banks
 
@@ -814,12 +821,28 @@ constexpr uint32_t kXRowPieces = 384;    // 16-byte pieces per (y, z) row of the
                           // (r, y, z) and (r, y + 1, z) sit on the SAME banks, and lanes of one ds_read whose g bytes fall into neighbouring
                           // cells -- every block of a noisy picture -- serialise
 #endif
-constexpr uint32_t kXPitchZ = MVFX_XTILE_RW * 24, kXPitchY = 4 * kXPitchZ + MVFX_XTILE_YPAD; // LDS bytes between z rows / y cells of a window
+#ifndef MVFX_XTILE_NY
+#define MVFX_XTILE_NY 3 // y cells of a window
+#endif
+#ifndef MVFX_XTILE_NZ
+#define MVFX_XTILE_NZ 3 // z cells of a window (NZ + 1 z rows: a pixel reads rows z0 and z0 + 1)
+#endif
+constexpr uint32_t kXNY = MVFX_XTILE_NY, kXNZ = MVFX_XTILE_NZ, kXNZR = kXNZ + 1;
+constexpr uint32_t kXPitchZ = MVFX_XTILE_RW * 24, kXPitchY = kXNZR * kXPitchZ + MVFX_XTILE_YPAD; // LDS bytes between z rows / y cells of a window
 // LDS of a wave's window.  The workgroup's total (4 windows + the 4 KB coordinate table) must stay within 32000 bytes: LDS is handed out
 // in granules of 1280 bytes and five workgroups per CU need 5 x 25 granules = 160000 <= 163840; one granule more per workgroup costs a
 // workgroup per CU (measured: -6 % on every content).  Unpadded: 6912 + 32 spare bytes; padded: no pad behind the last slab, no spare.
-constexpr uint32_t kXWaveBytes = MVFX_XTILE_YPAD ? 3 * kXPitchY - MVFX_XTILE_YPAD : 3 * kXPitchY + 32;
-static_assert(4 * kXWaveBytes + 4096 <= 32000, "five workgroups per CU");
+constexpr uint32_t kXWaveBytes = MVFX_XTILE_YPAD ? kXNY * kXPitchY - MVFX_XTILE_YPAD : kXNY * kXPitchY + 32;
+static_assert(4 * kXWaveBytes + 4096 <= 32000, "at least five workgroups per CU (six with the shipped 18 r bytes: 24 960 bytes)");
+// the window's first cell along an axis of NCELLS cells for an anchor at lattice coordinate `c` (cell + fraction): the anchor's cell in
+// the middle (odd), or -- even -- the half of its cell the anchor lies in decides which side gets the extra cell
+template <uint32_t NCELLS>
+__device__ __forceinline__ uint32_t xtile_first_cell(float c, uint32_t size)
+{
+    const uint32_t cell = min((uint32_t)c, size - 1);
+    const uint32_t below = (NCELLS & 1u) ? (NCELLS - 1u) / 2u : NCELLS / 2u - ((c - (float)cell) >= 0.5f ? 1u : 0u);
+    return min(cell > below ? cell - below : 0u, size - NCELLS);
+}
 
 // The wave's window: 3 y slabs x 4 z rows x RW entries of the x table, global -> LDS directly (global_load_lds_dwordx4: LDS address =
 // wave-uniform base + lane x 16, which is the window's piece order inside a slab): no staging registers, no ds_write pass.
@@ -828,21 +851,21 @@ __device__ __forceinline__ void xtile_fill_window(const float4 *xtable, uint32_t
 {
     typedef __attribute__((address_space(3))) void *lds_void_t;
     typedef const __attribute__((address_space(1))) void *global_void_t;
-    constexpr uint32_t kRowP = MVFX_XTILE_RW * 3 / 2, kSlabP = 4 * kRowP;
+    constexpr uint32_t kRowP = MVFX_XTILE_RW * 3 / 2, kSlabP = kXNZR * kRowP;
     if constexpr (MVFX_XTILE_YPAD == 0) {
-        constexpr uint32_t kPieces = 3 * kSlabP;
+        constexpr uint32_t kPieces = kXNY * kSlabP;
 #pragma unroll
         for (uint32_t q0 = 0; q0 < kPieces; q0 += 64) {
             const uint32_t q = q0 + lane;
             if (q0 + 64 <= kPieces || q < kPieces) {
-                const uint32_t wr = q / kRowP, k = q - wr * kRowP; // window row = dy * 4 + dz
-                __builtin_amdgcn_global_load_lds((global_void_t)(xtable + (base + ((wr >> 2) * (size + 1) + (wr & 3u)) * kXRowPieces + k)),
+                const uint32_t wr = q / kRowP, k = q - wr * kRowP; // window row = dy * (NZ + 1) + dz
+                __builtin_amdgcn_global_load_lds((global_void_t)(xtable + (base + ((wr / kXNZR) * (size + 1) + (wr % kXNZR)) * kXRowPieces + k)),
                                                  (lds_void_t)(lds_region + q0 * 16), 16, 0, 0);
             }
         }
     } else {
 #pragma unroll
-        for (uint32_t dy = 0; dy < 3; dy++) {
+        for (uint32_t dy = 0; dy < kXNY; dy++) {
 #pragma unroll
             for (uint32_t q0 = 0; q0 < kSlabP; q0 += 64) {
                 const uint32_t q = q0 + lane;
@@ -1060,23 +1083,16 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
 #ifndef MVFX_XTILE_ANCHOR_ARITH
 #define MVFX_XTILE_ANCHOR_ARITH 1 // 1 (round 5): the anchor's y / z cells by arithmetic instead of two scalar loads from the coordinate table
 #endif
-        uint32_t cy, cz;
-        if (MVFX_XTILE_ANCHOR_ARITH) {
-            // Where the window goes decides how many pixels find their entries in it, never what they compute: the anchor's cell may be
-            // formed any way.  The two table look-ups of rounds 3 and 4 are scalar loads whose address depends on the pixels -- one more
-            // memory round trip on the chain pixel loads -> anchor -> window fill that every wave walks before its first row; the same
-            // lattice arithmetic in a handful of VALU operations on the (uniform) anchor colour gives the cell the table would have given.
-            const float gy = (float)((cpx >> 8) & 0xffu) * (1.0f / 255.0f), bz = (float)((cpx >> 16) & 0xffu) * (1.0f / 255.0f);
-            const float ny = fminf(fmaxf(gy * p.scale[1] + p.offset[1], 0.0f), 1.0f) * p.size_m1, nz = fminf(fmaxf(bz * p.scale[2] + p.offset[2], 0.0f), 1.0f) * p.size_m1;
-            cy = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((uint32_t)ny, p.size - 1));
-            cz = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((uint32_t)nz, p.size - 1));
-        } else {
-            cy = p.tile_tables[2 * (256 + ((cpx >> 8) & 0xffu))];
-            cz = p.tile_tables[2 * (512 + ((cpx >> 16) & 0xffu))];
-        }
+        // Where the window goes decides how many pixels find their entries in it, never what they compute: the anchor's lattice
+        // coordinates may be formed any way.  The two table look-ups of rounds 3 and 4 were scalar loads whose address depends on the
+        // pixels -- one more memory round trip on the chain pixel loads -> anchor -> window fill that every wave walks before its first
+        // row; the same lattice arithmetic in a handful of VALU operations on the (uniform) anchor colour: +0.7 % calm, +3 % at +-8.
+        const float gy = (float)((cpx >> 8) & 0xffu) * (1.0f / 255.0f), bz = (float)((cpx >> 16) & 0xffu) * (1.0f / 255.0f);
+        const float ny = fminf(fmaxf(gy * p.scale[1] + p.offset[1], 0.0f), 1.0f) * p.size_m1, nz = fminf(fmaxf(bz * p.scale[2] + p.offset[2], 0.0f), 1.0f) * p.size_m1;
         ccpx = cpx;
         ar = min((cr > RW / 2 ? cr - RW / 2 : 0u) & ~1u, 256u - RW); // even: a window row starts on a 16-byte piece
-        const uint32_t ay = min(cy > 0 ? cy - 1 : 0u, p.size - 3), az = min(cz > 0 ? cz - 1 : 0u, p.size - 3); // z rows run 0 .. size
+        const uint32_t ay = (uint32_t)__builtin_amdgcn_readfirstlane((int)xtile_first_cell<kXNY>(ny, p.size)),
+                       az = (uint32_t)__builtin_amdgcn_readfirstlane((int)xtile_first_cell<kXNZ>(nz, p.size)); // z rows run 0 .. size
         ayp = ay * kXPitchY;
         azp = az * kXPitchZ;
         const uint32_t base = (ay * (p.size + 1) + az) * kXRowPieces + ar * 3 / 2; // wave-uniform
@@ -1103,6 +1119,75 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
     // dead window and serving them densely from a second 6 x 6 x 6 node window: +8 % at +- 8 codes of noise, +7 % at +- 16, -3 % at
     // +- 5, -7 % on flat bars, and 98 VGPRs -- a wave per SIMD less for every block; profiles/r4/colorlut_dense_pass.txt and the
     // commit before this one.)
+#ifndef MVFX_XTILE_PP
+#define MVFX_XTILE_PP 2 // pixels per pass of a row.  2 (round 5): a row of four pixels in two passes of two -- 56-60 VGPRs instead of 94, which with the
+                        // narrower window (MVFX_XTILE_RW) puts six waves on a SIMD.  This version has no "far" test (a block of uniform-random
+                        // colours): pictures like that are the other kernel's (the content probe), a stray block is served pixel by pixel.
+                        // 4: rounds 3 and 4 (kept for A/B builds).
+#endif
+#if MVFX_XTILE_PP == 2
+    auto do_row = [&](const uint32_t row) -> bool {
+        const bool valid = x < width && y0 + row < height;
+        uint32_t px[4] = {v[row].x, v[row].y, v[row].z, v[row].w};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            f32x2_t e0[2][3], e1[2][3];
+            float ty[2], tz[2];
+            bool miss[2];
+            bool any_miss = false;
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const uint32_t pxj = px[2 * h + jj];
+                const uint2 eg = coord[(pxj >> 8) & 0xffu], eb = coord[256 + ((pxj >> 16) & 0xffu)];
+                ty[jj] = __uint_as_float(eg.y);
+                tz[jj] = __uint_as_float(eb.y);
+                uint32_t r24;
+                asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r24) : "v"(pxj), "v"(24u));
+                const uint32_t dr24 = r24 - ar24, dyp = eg.x - ayp, dzp = eb.x - azp;
+                miss[jj] = (dr24 >= (uint32_t)RW * 24u) | (dyp >= kXNY * kXPitchY) | (dzp >= kXNZ * kXPitchZ);
+                any_miss = any_miss | miss[jj];
+                const uint32_t off = miss[jj] ? wave_lds : eg.x + eb.x + (r24 + lds_k);
+                const lds_float2_t q0 = (lds_float2_t)((lds_bytes_t)&win[0] + off), q1 = (lds_float2_t)((lds_bytes_t)&win[0] + off + kXPitchZ);
+                e0[jj][0] = q0[0]; e0[jj][1] = q0[1]; e0[jj][2] = q0[2];
+                e1[jj][0] = q1[0]; e1[jj][1] = q1[1]; e1[jj][2] = q1[2];
+            }
+            if (any_miss) {
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    if (miss[jj]) {
+                        const uint32_t pxj = px[2 * h + jj];
+                        const uint32_t iy = coord[(pxj >> 8) & 0xffu].x / kXPitchY, iz = coord[256 + ((pxj >> 16) & 0xffu)].x / kXPitchZ, r = pxj & 0xffu;
+                        const f32x2_t *g0p = reinterpret_cast<const f32x2_t *>(p.xtable) + (uint64_t)((iy * (p.size + 1) + iz) * 256u + r) * 3, *g1p = g0p + 256 * 3;
+                        e0[jj][0] = g0p[0]; e0[jj][1] = g0p[1]; e0[jj][2] = g0p[2];
+                        e1[jj][0] = g1p[0]; e1[jj][1] = g1p[1]; e1[jj][2] = g1p[2];
+                    }
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const float c0r = e0[jj][0].x + e0[jj][1].y * ty[jj], c0g = e0[jj][0].y + e0[jj][2].x * ty[jj], c0b = e0[jj][1].x + e0[jj][2].y * ty[jj];
+                const float c1r = e1[jj][0].x + e1[jj][1].y * ty[jj], c1g = e1[jj][0].y + e1[jj][2].x * ty[jj], c1b = e1[jj][1].x + e1[jj][2].y * ty[jj];
+                const float rr = lf_add_clamp(c0r, (c1r - c0r) * tz[jj]), gg = lf_add_clamp(c0g, (c1g - c0g) * tz[jj]),
+                            bb = lf_add_clamp(c0b, (c1b - c0b) * tz[jj]);
+                const float yr = __builtin_fmaf(rr, p.fast.out_scale, p.fast.pred_half), yg = __builtin_fmaf(gg, p.fast.out_scale, p.fast.pred_half),
+                            yb = __builtin_fmaf(bb, p.fast.out_scale, p.fast.pred_half);
+                uint32_t w = px[2 * h + jj];
+                asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yr));
+                asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yg));
+                asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
+                px[2 * h + jj] = w;
+            }
+            __builtin_amdgcn_sched_barrier(0); // the two halves stay two passes
+        }
+        if (valid) {
+            u32x4_t *dst = reinterpret_cast<u32x4_t *>(out + (size_t)row * out_stride + voff_out);
+            const u32x4_t t = {px[0], px[1], px[2], px[3]};
+            if (MVFX_XTILE_NT) __builtin_nontemporal_store(t, dst);
+            else *dst = t;
+        }
+        return false;
+    };
+#else
     auto do_row = [&](const uint32_t row) -> bool { // true: row 0 found the block "far" -- nothing served, nothing stored
         const bool valid = x < width && y0 + row < height; // width % 4 == 0 (launcher)
         uint32_t px[4] = {v[row].x, v[row].y, v[row].z, v[row].w};
@@ -1121,7 +1206,7 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
             asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r24) : "v"(pxj), "v"(24u));
             const uint32_t dr24 = r24 - ar24, dyp = eg.x - ayp, dzp = eb.x - azp; // unsigned: below the anchor wraps to a huge value
             // (bitwise |: with || the compiler turns the second and third test into branches behind the LDS wait)
-            miss[j] = (dr24 >= (uint32_t)RW * 24u) | (dyp >= 3u * kXPitchY) | (dzp >= 3u * kXPitchZ);
+            miss[j] = (dr24 >= (uint32_t)RW * 24u) | (dyp >= kXNY * kXPitchY) | (dzp >= kXNZ * kXPitchZ);
             any_miss = any_miss | miss[j];
             if (MVFX_XTILE_FAR_GATHER && row == 0) outside += (uint32_t)__popcll(__ballot(miss[j] & valid));
             const uint32_t off = miss[j] ? wave_lds : eg.x + eb.x + (r24 + lds_k);
@@ -1186,6 +1271,7 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
         }
         return false;
     };
+#endif
     if (do_row(0)) { // wave-uniform, rare
         CellCache cache;
 #pragma unroll
@@ -1222,7 +1308,13 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
 // anchored at the mean of the four waves' means.  CPU model of the hit rate on the bench's frames (tools/sim/colorlut_shared_sim.py):
 // outside pixels at +-8 codes of noise 2.1 % -> 0.0 %, at +-16 codes 61 % -> 4 %.  Same entries, same arithmetic as colorlut_xtile_kernel:
 // same bits.  The rare outside pixel is served in its row pass from the x table in global memory, as in rounds 3 and 4.
-constexpr uint32_t kWgRW = 38, kWgNY = 5, kWgNZ = 5, kWgNZR = kWgNZ + 1;
+#ifndef MVFX_XWG_RW
+#define MVFX_XWG_RW 38 // r bytes of the workgroup's window
+#endif
+#ifndef MVFX_XWG_N
+#define MVFX_XWG_N 5   // y and z cells of the workgroup's window
+#endif
+constexpr uint32_t kWgRW = MVFX_XWG_RW, kWgNY = MVFX_XWG_N, kWgNZ = MVFX_XWG_N, kWgNZR = kWgNZ + 1;
 constexpr uint32_t kWgPitchZ = kWgRW * 24, kWgPitchY = kWgNZR * kWgPitchZ, kWgWinBytes = kWgNY * kWgPitchY;
 static_assert(kWgRW % 2 == 0, "window rows start and end on 16-byte pieces");
 static_assert(kWgWinBytes + 4096 + 16 <= 32000, "five workgroups per CU (LDS comes in granules of 1280 bytes: 25 per workgroup)");
@@ -1329,6 +1421,10 @@ __global__ __launch_bounds__(kBlock) void colorlut_xwg_kernel(FrameBatch in_fb, 
     __syncthreads(); // the window
     const uint32_t lds_k = 0u - ayp - azp - ar * 24u, ar24 = ar * 24u;
     // 4. the rows (colorlut_xtile_kernel's row pass; the outside pixel is patched from the x table in global memory in ONE branch per row)
+#ifndef MVFX_XWG_PP
+#define MVFX_XWG_PP 4 // pixels per pass of a row (2: two passes of two pixels, fewer live registers)
+#endif
+    constexpr int PP = MVFX_XWG_PP;
     auto do_row = [&](const uint32_t row) -> bool { // true: row 0 found the block "far" (uniform-random colours) -- nothing served, nothing stored
         const bool valid = x < width && y0 + row < height; // width % 4 == 0 (launcher)
         uint32_t px[4] = {v[row].x, v[row].y, v[row].z, v[row].w};
@@ -1337,8 +1433,21 @@ __global__ __launch_bounds__(kBlock) void colorlut_xwg_kernel(FrameBatch in_fb, 
         bool miss[4];
         bool any_miss = false;
         uint32_t outside = 0;
+        if (PP == 2 && row == 0 && MVFX_XTILE_FAR_GATHER) { // the far test needs the whole row's misses: a cheap pass of its own (row 0 only)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < 4; j++) {
+                const uint32_t pxj = px[j];
+                const uint2 eg = coord[(pxj >> 8) & 0xffu], eb = coord[256 + ((pxj >> 16) & 0xffu)];
+                const uint32_t dr24 = (pxj & 0xffu) * 24u - ar24, dyp = eg.x - ayp, dzp = eb.x - azp;
+                miss[j] = (dr24 >= RW * 24u) | (dyp >= kWgNY * kWgPitchY) | (dzp >= kWgNZ * kWgPitchZ);
+                outside += (uint32_t)__popcll(__ballot(miss[j] & valid));
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 4 / PP; h++) {
+        if (PP == 2 && h == 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = h * PP; j < (h + 1) * PP; j++) {
             const uint32_t pxj = px[j];
             const uint2 eg = coord[(pxj >> 8) & 0xffu], eb = coord[256 + ((pxj >> 16) & 0xffu)];
             ty[j] = __uint_as_float(eg.y);
@@ -1348,13 +1457,13 @@ __global__ __launch_bounds__(kBlock) void colorlut_xwg_kernel(FrameBatch in_fb, 
             const uint32_t dr24 = r24 - ar24, dyp = eg.x - ayp, dzp = eb.x - azp; // unsigned: below the anchor wraps to a huge value
             miss[j] = (dr24 >= RW * 24u) | (dyp >= kWgNY * kWgPitchY) | (dzp >= kWgNZ * kWgPitchZ);
             any_miss = any_miss | miss[j];
-            if (MVFX_XTILE_FAR_GATHER && row == 0) outside += (uint32_t)__popcll(__ballot(miss[j] & valid));
+            if (PP == 4 && MVFX_XTILE_FAR_GATHER && row == 0) outside += (uint32_t)__popcll(__ballot(miss[j] & valid));
             const uint32_t off = miss[j] ? 0u : eg.x + eb.x + (r24 + lds_k);
             const lds_float2_t q0 = (lds_float2_t)((lds_bytes_t)&win[0] + off), q1 = (lds_float2_t)((lds_bytes_t)&win[0] + off + kWgPitchZ);
             e0[j][0] = q0[0]; e0[j][1] = q0[1]; e0[j][2] = q0[2];
             e1[j][0] = q1[0]; e1[j][1] = q1[1]; e1[j][2] = q1[2];
         }
-        if (MVFX_XTILE_FAR_GATHER && row == 0 && outside > 248u) { // wave-uniform, rare (colorlut_xtile_kernel has the reasoning)
+        if (MVFX_XTILE_FAR_GATHER && row == 0 && h == 0 && outside > 248u) { // wave-uniform, rare (colorlut_xtile_kernel has the reasoning)
             uint32_t far = 0, alike = 0, fpx = 0;
             bool found = false;
 #pragma unroll
@@ -1374,7 +1483,7 @@ __global__ __launch_bounds__(kBlock) void colorlut_xwg_kernel(FrameBatch in_fb, 
         }
         if (any_miss) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = h * PP; j < (h + 1) * PP; j++) {
                 if (miss[j]) {
                     const uint32_t pxj = px[j];
                     const uint32_t iy = coord[(pxj >> 8) & 0xffu].x / kWgPitchY, iz = coord[256 + ((pxj >> 16) & 0xffu)].x / kWgPitchZ, r = pxj & 0xffu;
@@ -1385,7 +1494,7 @@ __global__ __launch_bounds__(kBlock) void colorlut_xwg_kernel(FrameBatch in_fb, 
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = h * PP; j < (h + 1) * PP; j++) {
             // entry = (X.r, X.g) (X.b, D.r) (D.g, D.b)
             const float c0r = e0[j][0].x + e0[j][1].y * ty[j], c0g = e0[j][0].y + e0[j][2].x * ty[j], c0b = e0[j][1].x + e0[j][2].y * ty[j];
             const float c1r = e1[j][0].x + e1[j][1].y * ty[j], c1g = e1[j][0].y + e1[j][2].x * ty[j], c1b = e1[j][1].x + e1[j][2].y * ty[j];
@@ -1400,6 +1509,8 @@ __global__ __launch_bounds__(kBlock) void colorlut_xwg_kernel(FrameBatch in_fb, 
             asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
             px[j] = w;
         }
+        if (PP == 2) any_miss = false; // per pass
+        } // passes
         if (valid) {
             u32x4_t *dst = reinterpret_cast<u32x4_t *>(out + (size_t)row * out_stride + voff_out);
             const u32x4_t t = {px[0], px[1], px[2], px[3]};
@@ -1589,7 +1700,7 @@ __global__ __launch_bounds__(kI420Block) void colorlut_i420_xtile_kernel(I420Pla
 #endif
     const uint32_t cr = fpx & 0xffu, cy = p.tile_tables[2 * (256 + ((fpx >> 8) & 0xffu))], cz = p.tile_tables[2 * (512 + ((fpx >> 16) & 0xffu))];
     const uint32_t ar = min((cr > RW / 2 ? cr - RW / 2 : 0u) & ~1u, 256u - RW);
-    const uint32_t ay = min(cy > 0 ? cy - 1 : 0u, p.size - 3), az = min(cz > 0 ? cz - 1 : 0u, p.size - 3);
+    const uint32_t ay = min(cy > (kXNY - 1) / 2 ? cy - (kXNY - 1) / 2 : 0u, p.size - kXNY), az = min(cz > (kXNZ - 1) / 2 ? cz - (kXNZ - 1) / 2 : 0u, p.size - kXNZ);
     const uint32_t ayp = ay * kXPitchY, azp = az * kXPitchZ, ar24 = ar * 24u;
     {
         const uint32_t base = (ay * (p.size + 1) + az) * kXRowPieces + ar * 3 / 2;
@@ -1603,7 +1714,7 @@ __global__ __launch_bounds__(kI420Block) void colorlut_i420_xtile_kernel(I420Pla
         uint32_t r24;
         asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r24) : "v"(px), "v"(24u));
         const uint32_t dr24 = r24 - ar24, dyp = eg.x - ayp, dzp = eb.x - azp;
-        const bool miss = (dr24 >= RW * 24u) | (dyp >= 3u * kXPitchY) | (dzp >= 3u * kXPitchZ);
+        const bool miss = (dr24 >= RW * 24u) | (dyp >= kXNY * kXPitchY) | (dzp >= kXNZ * kXPitchZ);
         const uint32_t off = miss ? wave_lds : eg.x + eb.x + (r24 + lds_k);
         const lds_float2_t q0 = (lds_float2_t)((lds_bytes_t)&win[0] + off), q1 = (lds_float2_t)((lds_bytes_t)&win[0] + off + kXPitchZ);
         f32x2_t e0[3] = {q0[0], q0[1], q0[2]}, e1[3] = {q1[0], q1[1], q1[2]};
