@@ -28,7 +28,7 @@ run() { # <key> <bench args...>
     timeout 400 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS GRBM_GUI_ACTIVE -f csv -d $O/$K/LDS -o pmc -- python3 $REPO/bench.py $COMMON "$@" > $O/$K/LDS.json 2> $O/$K/LDS.err
 }
 WL=${1:-all}
-want() { [ "$WL" = all ] || [ "$WL" = "$1" ]; }
+want() { [ "$WL" = all ] || case ",$WL," in *",$1,"*) true;; *) false;; esac; }  # WL: all | one name | a comma-separated list
 want hsvfilter && run hsvfilter --steps 30
 want hsv1080p && run hsv1080p --workload hsv1080p --steps 30
 want colorlut_natural && run colorlut_natural --workload colorlut --content natural --steps 20
