@@ -1135,10 +1135,24 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
             float ty[2], tz[2];
             bool miss[2];
             bool any_miss = false;
+#ifndef MVFX_XTILE_PP2_COORD_FIRST
+#define MVFX_XTILE_PP2_COORD_FIRST 1 // the four coordinate reads of a pass before its entry reads (two LDS round trips per pass instead of three: +1 % on calm
+                                     // frames; with four-pixel passes the same idea cost a wave per SIMD and 6 %)
+#endif
+            uint2 egs[2], ebs[2];
+            if (MVFX_XTILE_PP2_COORD_FIRST) {
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    egs[jj] = coord[(px[2 * h + jj] >> 8) & 0xffu];
+                    ebs[jj] = coord[256 + ((px[2 * h + jj] >> 16) & 0xffu)];
+                }
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) asm volatile("" : "+v"(egs[jj]), "+v"(ebs[jj]));
+            }
 #pragma unroll
             for (int jj = 0; jj < 2; jj++) {
                 const uint32_t pxj = px[2 * h + jj];
-                const uint2 eg = coord[(pxj >> 8) & 0xffu], eb = coord[256 + ((pxj >> 16) & 0xffu)];
+                const uint2 eg = MVFX_XTILE_PP2_COORD_FIRST ? egs[jj] : coord[(pxj >> 8) & 0xffu], eb = MVFX_XTILE_PP2_COORD_FIRST ? ebs[jj] : coord[256 + ((pxj >> 16) & 0xffu)];
                 ty[jj] = __uint_as_float(eg.y);
                 tz[jj] = __uint_as_float(eb.y);
                 uint32_t r24;
