@@ -810,8 +810,8 @@ __global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb,
 // which is what z1 = min(z0 + 1, max) selects there, so the second entry is ALWAYS the next z row -- 256 x size x (size + 1) entries
 // of 24 bytes (33^3: 6.9 MB), built on the device by colorlut_xtable_build_kernel from the node layout and the r channel's
 // coordinate table.
-// A wave owns a 64 x 16 block of pixels (as colorlut_tile_kernel) and keeps in wave-private LDS the entries of RW consecutive r
-// bytes x 3 y cells x 4 z rows around the block's centre pixel: 12 rows of RW x 24 contiguous bytes; pixels outside the window read
+// A wave owns a 64 x 20 block of pixels and keeps in wave-private LDS the entries of RW consecutive r bytes x 3 y cells x 4 z rows
+// around a mean colour of the block (18 r bytes since round 5: see MVFX_XTILE_RW): 12 rows of RW x 24 contiguous bytes; pixels outside the window read
 // their two entries from the table in global memory.  The per-byte coordinate entries of g and b hold the cell index already
 // multiplied by the window's LDS pitch of that axis, so the in-window test and the LDS address are three subtractions, three
 // compares, one add3 and one mad.
@@ -1557,10 +1557,10 @@ __global__ __launch_bounds__(kBlock) void colorlut_xwg_kernel(FrameBatch in_fb, 
 
 // ---------------------------------------------------------------- content probe: which window kernel suits the stream (round 5)
 //
-// colorlut_xtile_kernel (a 24 x 3 x 3 window per wave) is the faster kernel on calm pictures -- 16 x 4K per launch, same box: 76-78 k fps
-// on smooth gradients, 74-76 k with +-3 codes of noise, 70-72 k with +-5 -- and collapses where the colours of a 64 x 20 block scatter:
-// 54 k at +-8, 26 k at +-16.  colorlut_xwg_kernel (one 38 x 5 x 5 window per workgroup) runs 70 / 69 / 68 / 67.5 / 47 k on the same
-// frames (profiles/r5/colorlut_experiments.txt).  The pictures of a stream resemble their predecessors, so the choice is made from a look at
+// colorlut_xtile_kernel (an 18 x 3 x 3 window per wave, six workgroups per CU) is the faster kernel on calm pictures -- 16 x 4K per launch,
+// same box: 80-82 k fps on smooth gradients, 78-79 k with +-3 codes of noise, 69-70 k with +-5 -- and collapses where the colours of a
+// 64 x 20 block scatter: 41 k at +-8.  colorlut_xwg_kernel (one 38 x 5 x 5 window per workgroup) runs 74 / 72 / 70.5 / 69 / 47 k at
+// +-0 / 3 / 5 / 8 / 16 on the same frames (profiles/r5/colorlut_experiments.txt).  The pictures of a stream resemble their predecessors, so the choice is made from a look at
 // an earlier frame: one workgroup, 256 blocks of 64 x 20 pixels spread over the frame, sixteen pixels of each (a 4 x 4 lattice); a block
 // is BUSY when the sampled bytes of a channel span more than kProbeSpan codes (sixteen samples of +-5 codes of noise on a gradient span
 // about 15, of +-8 about 20).  More than kProbeBusy busy blocks of 256 make the picture busy.  Every thread of the launch writes nothing
