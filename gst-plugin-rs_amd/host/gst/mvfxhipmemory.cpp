@@ -470,7 +470,8 @@ void mvfx_hip_fence_end(MvfxFenceScope *sc, mvfx_stream stream, GstObject *owner
     if (check && f && carried > 0) {
         // the stream drained, so the fence must have fired (the other direction -- a fence that fires BEFORE a trailing copy of the call
         // has finished -- cannot be seen from here; the contract above is kept by review: every entry the elements call under a fence
-        // scope ends in MVFX_LAUNCH, `grep -n hipLaunchKernelGGL csrc/` finds only the macro itself)
+        // scope ends in MVFX_LAUNCH; `grep -n hipLaunchKernelGGL csrc/` finds the macro itself and colorlut's content probe, which is launched
+        // BEFORE the frame's kernel and touches no output)
         mvfx_stream_synchronize(stream);
         if (mvfx_event_query(f->ev) != 1)
             g_critical("MVFX_FENCE_CHECK: the fence carried by the last library call has not fired although its stream has drained: "
