@@ -1328,7 +1328,13 @@ __global__ __launch_bounds__(kBlock, MVFX_XTILE_MIN_BLOCKS) void colorlut_xtile_
 #ifndef MVFX_XWG_N
 #define MVFX_XWG_N 5   // y and z cells of the workgroup's window
 #endif
-constexpr uint32_t kWgRW = MVFX_XWG_RW, kWgNY = MVFX_XWG_N, kWgNZ = MVFX_XWG_N, kWgNZR = kWgNZ + 1;
+#ifndef MVFX_XWG_NY
+#define MVFX_XWG_NY MVFX_XWG_N
+#endif
+#ifndef MVFX_XWG_NZ
+#define MVFX_XWG_NZ MVFX_XWG_N
+#endif
+constexpr uint32_t kWgRW = MVFX_XWG_RW, kWgNY = MVFX_XWG_NY, kWgNZ = MVFX_XWG_NZ, kWgNZR = kWgNZ + 1;
 constexpr uint32_t kWgPitchZ = kWgRW * 24, kWgPitchY = kWgNZR * kWgPitchZ, kWgWinBytes = kWgNY * kWgPitchY;
 static_assert(kWgRW % 2 == 0, "window rows start and end on 16-byte pieces");
 static_assert(kWgWinBytes + 4096 + 16 <= 32000, "five workgroups per CU (LDS comes in granules of 1280 bytes: 25 per workgroup)");
@@ -1403,18 +1409,12 @@ __global__ __launch_bounds__(kBlock) void colorlut_xwg_kernel(FrameBatch in_fb, 
         if (n == 3 || n == 0) cpx = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_anchor[0]) & 0xffffffu;
         ccpx = cpx;
         const uint32_t cr = cpx & 0xffu;
-        uint32_t cy, cz;
-        if (MVFX_XTILE_ANCHOR_ARITH) { // the anchor's cells by arithmetic, not by two dependent scalar loads (colorlut_xtile_kernel)
-            const float gy = (float)((cpx >> 8) & 0xffu) * (1.0f / 255.0f), bz = (float)((cpx >> 16) & 0xffu) * (1.0f / 255.0f);
-            const float ny = fminf(fmaxf(gy * p.scale[1] + p.offset[1], 0.0f), 1.0f) * p.size_m1, nz = fminf(fmaxf(bz * p.scale[2] + p.offset[2], 0.0f), 1.0f) * p.size_m1;
-            cy = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((uint32_t)ny, p.size - 1));
-            cz = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((uint32_t)nz, p.size - 1));
-        } else {
-            cy = p.tile_tables[2 * (256 + ((cpx >> 8) & 0xffu))];
-            cz = p.tile_tables[2 * (512 + ((cpx >> 16) & 0xffu))];
-        }
+        // the anchor's lattice coordinates by arithmetic, not by two dependent scalar loads (colorlut_xtile_kernel)
+        const float gy = (float)((cpx >> 8) & 0xffu) * (1.0f / 255.0f), bz = (float)((cpx >> 16) & 0xffu) * (1.0f / 255.0f);
+        const float ny = fminf(fmaxf(gy * p.scale[1] + p.offset[1], 0.0f), 1.0f) * p.size_m1, nz = fminf(fmaxf(bz * p.scale[2] + p.offset[2], 0.0f), 1.0f) * p.size_m1;
         ar = min((cr > RW / 2 ? cr - RW / 2 : 0u) & ~1u, 256u - RW); // even: a window row starts on a 16-byte piece
-        const uint32_t ay = min(cy > kWgNY / 2 ? cy - kWgNY / 2 : 0u, p.size - kWgNY), az = min(cz > kWgNZ / 2 ? cz - kWgNZ / 2 : 0u, p.size - kWgNZ); // z rows run 0 .. size
+        const uint32_t ay = (uint32_t)__builtin_amdgcn_readfirstlane((int)xtile_first_cell<kWgNY>(ny, p.size)),
+                       az = (uint32_t)__builtin_amdgcn_readfirstlane((int)xtile_first_cell<kWgNZ>(nz, p.size)); // z rows run 0 .. size
         ayp = ay * kWgPitchY;
         azp = az * kWgPitchZ;
         // NY x NZR rows of RW entries of the x table, global -> LDS directly, 16-byte pieces (xtile_fill_window; here all four waves fill)
