@@ -170,6 +170,8 @@ def compact_headline(out):
     line = {k: _r(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                      "vs_baseline", "dtype") if k in out}
     line["data"] = out.get("data", "synthetic")[:160]
+    if "verified" in out:
+        line["verified"] = out["verified"]
     line["config"] = cfg
     line["roofline"] = compact_roofline(out.get("roofline", {}))
     if out.get("cpu_baseline"):
@@ -192,10 +194,14 @@ def compact_sub(key, r):
         out["cpu_value"] = _r(cpu["value"])
         out["cpu_all_cores"] = _r(cpu.get("all_cores", {}).get("value"))
         out["cpu_cores"] = cpu.get("all_cores", {}).get("cores")
-    for k in ("element_model", "last_distance", "n_gpus", "allreduce_us"):
+    for k in ("element_model", "last_distance", "n_gpus", "allreduce_us", "value_p10", "value_p50", "value_p90"):
         v = r.get("config", {}).get(k, r.get(k))
         if v is not None and not isinstance(v, (list, dict)):
-            out[k] = _r(v)
+            out[k] = _r(v, 5)
+    if "verified" in r:
+        out["verified"] = r["verified"]
+        if r.get("verified") is False:
+            out["verified_what"] = str(r.get("verified_what"))[:200]
     out.update(r.get("sub_extra", {}))
     return {k: v for k, v in out.items() if v is not None}
 
@@ -507,6 +513,7 @@ def cpu_rate(make_unit, seconds, n_threads):
     return sum(c / s for c, s in zip(counts, spans) if s > 0), sum(counts), max(spans)
 
 
+NO_VERIFY = [False]       # --no-verify
 ALL_CORES_SECONDS = [None]  # budget of the nproc-thread leg (None: same as the 1-thread leg; 0: skip it) -- set from the command line
 
 
@@ -735,6 +742,8 @@ def measure_leg(w, leg, steps, warmup, settle_seconds, pct_steps, cpu_seconds):
     steps with a HIP event between every two (p10 / p50 / p90 of the per-step time) -> the CPU port on the host cores."""
     executed = [0]
     t_measure = time.perf_counter()
+    verified = run_verify(w, leg)
+    t_verified = time.perf_counter()
 
     def counted(i):
         executed[0] += 1
@@ -764,11 +773,34 @@ def measure_leg(w, leg, steps, warmup, settle_seconds, pct_steps, cpu_seconds):
     }
     if pct:
         out["config"]["value_p50"] = leg.units_per_step * (world if leg.scaling == "weak" else 1) / (pct["p50"] * 1e-6)
+        for q in ("p10", "p90"):  # the spread of the event-timed steps, as rates: p10 of the step time is the FAST end
+            out["config"]["value_" + q] = leg.units_per_step * (world if leg.scaling == "weak" else 1) / (pct[q] * 1e-6)
+    out.update(verified)
     t_gpu = time.perf_counter()
     if leg.cpu is not None and w.rank == 0 and world == 1 and cpu_seconds > 0:
         out["cpu_baseline"] = leg.cpu(cpu_seconds)
-    out["measure_seconds"] = {"gpu": t_gpu - t_measure, "cpu": time.perf_counter() - t_gpu}
+    out["measure_seconds"] = {"gpu": t_gpu - t_verified, "verify": t_verified - t_measure, "cpu": time.perf_counter() - t_gpu}
     return out
+
+
+def run_verify(w, leg):
+    """{"verified": true | false | null, "verified_what": ...}: ONE step of the leg -- the same C entry, the same batch shape, the leg's own
+    frames -- compared with the CPU oracle (tests/oracle_binding) before anything is timed.  The oracle is the checker here, never the thing
+    measured.  null: the leg has no verifier on this rank (N > 1 ranks other than 0)."""
+    fn = getattr(leg, "verify", None)
+    if fn is None or w.rank != 0 or NO_VERIFY[0]:
+        return {"verified": None}
+    try:
+        what = fn()
+        return {"verified": True, "verified_what": what}
+    except Exception as e:  # noqa: BLE001  a mismatch is reported in the line, the measurement still runs (and is worthless)
+        return {"verified": False, "verified_what": f"{type(e).__name__}: {e}"[:300]}
+
+
+def _same(got, want, what):
+    import numpy as np
+    if not np.array_equal(got, want):
+        raise AssertionError(f"{what}: {int(np.count_nonzero(np.asarray(got) != np.asarray(want)))} of {np.asarray(want).size} values differ from the oracle")
 
 
 def make_leg_hsv1080p(w, args):
@@ -798,6 +830,23 @@ def make_leg_hsv1080p(w, args):
               step, ["hsvfilter4_typed_kernel", "hsvdetector_typed_kernel"],
               cpu=(lambda s: cpu_baseline_hsv1080p(s, host)) if host else None)
     leg.keep = (src, dst, fi, fo)
+
+    def verify():
+        import numpy as np
+        from tests import oracle_binding as orc
+        picks = (0, nb - 1)
+        before = {i: src[i].cpu().numpy().reshape(H, W * 4).copy() for i in picks}
+        step(0)
+        w.sync()
+        for i in picks:
+            mid = before[i]
+            orc.hsvfilter(mid, W, W * 4, "RGBx", SETTINGS)
+            _same(src[i].cpu().numpy().reshape(H, W * 4), mid, f"hsvfilter frame {i}")
+            want = np.empty_like(mid)
+            orc.hsvdetector(mid, W * 4, "RGBx", want, W * 4, "RGBA", W, DETECT_SETTINGS)
+            _same(dst[i].cpu().numpy().reshape(H, W * 4), want, f"hsvdetector frame {i}")
+        return f"frames 0 and {nb - 1} of the first {nb}-frame step, every byte of both outputs, against oracle/hsv_oracle.c"
+    leg.verify = verify
     return leg
 
 
@@ -869,6 +918,20 @@ def make_leg_colorlut(w, args, content):
             res[str(amp)] = round(nb * w.world / (ev_ms_ * 1e-3))
         return res
     leg.keep = (src, dst, fi, fo, lut)
+
+    def verify():
+        import numpy as np
+        from tests import oracle_binding as orc
+        olut = orc.CubeLut(cube_text)
+        step(0)
+        w.sync()
+        for i in (0, nb - 1):
+            a = src[i].cpu().numpy().reshape(H, W * 4)
+            want = np.empty_like(a)
+            olut.apply(a, W * 4, want, W * 4, W, H, "RGBA")
+            _same(dst[i].cpu().numpy().reshape(H, W * 4), want, f"colorlut frame {i}")
+        return f"frames 0 and {nb - 1} of the first {nb}-frame step, every byte, against oracle/colorlut_oracle.c"
+    leg.verify = verify
     leg.streams_leg = streams_leg
     leg.noise_sweep = noise_sweep
     return leg
@@ -913,6 +976,18 @@ def make_leg_hsv3(w, args, which):
                   f"hsvfilter 3840x2160 RGB (3 B/px) in place, {nb} streams per launch; 3 + 3 algorithmic B/px", step, ["hsvfilter3_typed_kernel"],
                   cpu=cpu if host else None)
         leg.keep = (src, fi)
+
+        def verify():
+            from tests import oracle_binding as orc
+            picks = (0, nb - 1)
+            before = {i: src[i].cpu().numpy().reshape(H, stride3).copy() for i in picks}
+            step(0)
+            w.sync()
+            for i in picks:
+                orc.hsvfilter(before[i], W, stride3, "RGB", SETTINGS)
+                _same(src[i].cpu().numpy().reshape(H, stride3), before[i], f"hsvfilter RGB frame {i}")
+            return f"frames 0 and {nb - 1} of the first {nb}-frame step, every byte, against oracle/hsv_oracle.c"
+        leg.verify = verify
         return leg
     dst = torch.empty((pool * nb, FRAME_BYTES), dtype=torch.uint8, device=dev)
     fo = [(vfx.Frame * nb)(*[vfx.make_frame(dst[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
@@ -939,6 +1014,19 @@ def make_leg_hsv3(w, args, which):
               f"hsvdetector 3840x2160 RGB -> RGBA, {nb} streams per launch; 3 + 4 algorithmic B/px", step, ["hsvdetector3_typed_kernel"],
               cpu=cpu if host else None)
     leg.keep = (src, dst, fi, fo)
+
+    def verify():
+        import numpy as np
+        from tests import oracle_binding as orc
+        step(0)
+        w.sync()
+        for i in (0, nb - 1):
+            a = src[i].cpu().numpy().reshape(H, stride3)
+            want = np.empty((H, W * 4), dtype=np.uint8)
+            orc.hsvdetector(a, stride3, "RGB", want, W * 4, "RGBA", W, DETECT_SETTINGS)
+            _same(dst[i].cpu().numpy().reshape(H, W * 4), want, f"hsvdetector RGB->RGBA frame {i}")
+        return f"frames 0 and {nb - 1} of the first {nb}-frame step, every byte, against oracle/hsv_oracle.c"
+    leg.verify = verify
     return leg
 
 
@@ -994,6 +1082,24 @@ def make_leg_videofx(w, args):
               step, ["copy_planes_kernel", "colordetect_hist_kernel"],
               cpu=(lambda s: cpu_baseline_videofx(s, host)) if host else None)
     leg.keep = (i420, a420, rgba, mask, hist, planes, fr)
+
+    def verify():
+        import numpy as np
+        from tests import oracle_binding as orc
+        hist.zero_()
+        a420[0].zero_()
+        step(0)
+        w.sync()
+        torch.cuda.synchronize()
+        out = a420[0].cpu().numpy()
+        _same(out[:offs[3]], i420[0].cpu().numpy(), "roundedcorners A420 planes 0-2 (the I420 planes, copied)")
+        _same(out[offs[3]:], mask.cpu().numpy(), "roundedcorners A420 plane 3 (the r=100 mask: libcairo's, tests/golden)")
+        rc, want, mm, n = orc.colordetect_histogram(rgba[0].cpu().numpy(), "RGBA", 10)
+        got = hist.cpu().numpy()
+        _same(got[:32768].view(np.uint32), want.astype(np.uint32), "colordetect histogram (32 768 bins)")
+        _same(got[32768:32774].view(np.uint32).tolist(), mm, "colordetect min/max")
+        return "step 0: the A420 frame byte for byte (planes = input, alpha = mask) and the 32 768-bin histogram + min/max against oracle/videofx_oracle.c"
+    leg.verify = verify
     if second:
         ev_a, ev_b = ctypes.c_void_p(), ctypes.c_void_p()
         vfx.check(lib.mvfx_event_create(ctypes.byref(ev_a)))
@@ -1096,6 +1202,38 @@ def make_leg_videocompare(w, args, algo):
                   note="per pair incl. the 128 block sums landing in page-locked host memory (the reduce kernel's own stores) and the host bit derivation")
         leg.drain = lambda: [finish(s) for s in range(depth) if ring_busy[s]]
     leg.keep = (full, fr)
+    if host_pair is not None and algo == "blockhash":
+        def verify():
+            from tests import oracle_binding as orc
+            step(0)
+            leg.drain()
+            w.sync()
+            _, ha = orc.blockhash(host_pair[0], W, H, W * 4, "RGBA")
+            _, hb = orc.blockhash(host_pair[1], W, H, W * 4, "RGBA")
+            want = float(orc.hamming(ha, hb))
+            if last[0] != want:
+                raise AssertionError(f"Hamming distance of pair 0: {last[0]} from the device path, {want} from the oracle")
+            out = ctypes.c_uint64()
+            for p_, hw in ((0, ha), (1, hb)):  # and the two 64-bit hashes themselves, through the synchronous entry
+                vfx.check(lib.mvfx_blockhash(ctypes.byref(fr[0][p_]), ctypes.byref(out), sptr))
+                if out.value != hw:
+                    raise AssertionError(f"blockhash of frame {p_} of pair 0: {out.value:#018x} from the device path, {hw:#018x} from the oracle")
+            return "pair 0: both 64-bit hashes and the Hamming distance of the step's own path against oracle/videofx_oracle.c (bit-exact)"
+        leg.verify = verify
+    elif host_pair is not None:
+        def verify():
+            from tests import oracle_binding as orc
+            cw, ch = 960, 540
+            crop = [full[0, p_].view(H, W * 4)[:ch, :cw * 4].contiguous() for p_ in range(2)]
+            fa, fb = (vfx.make_frame(crop[p_].data_ptr(), cw, ch, cw * 4, "RGBA") for p_ in range(2))
+            d = ctypes.c_double()
+            vfx.check(lib.mvfx_ssim_distance(ctypes.byref(fa), ctypes.byref(fb), ctypes.byref(d), sptr))
+            rc, want, _ = orc.ssim_distance(host_pair[0], host_pair[1], cw, ch, cw * 4, cw * 4, "RGBA")
+            if rc != 0 or abs(d.value - want) > 1e-5 * abs(want) + 2e-9:
+                raise AssertionError(f"dssim of the 960x540 crop of pair 0: {d.value!r} from the device path, {want!r} from the f64 oracle (rc {rc})")
+            return ("the 960x540 crop of pair 0 through the same C entry against the f64 restatement oracle/ssim_oracle.c, 1e-5 relative (the tests' tolerance; "
+                    "a whole 8K pair is ~18 s of oracle time); the restatement itself is NOT pinned against dssim-core")
+        leg.verify = verify
     return leg
 
 
@@ -1333,6 +1471,24 @@ def hsvfilter_main(args):
         secs, k_ms = w.max_over_ranks(secs, k_ms)
         return n_settle, secs, k_ms
 
+    def verify():
+        """one launch of the timed entry on the first scratch batch, two of its frames compared byte for byte with the oracle"""
+        from tests import oracle_binding as orc
+        picks = (0, args.batch - 1)
+        before = {i: frames[pool, i].cpu().numpy().reshape(H4K, W4K * 4).copy() for i in picks}
+        launch(pool)
+        w.sync()
+        for i in picks:
+            orc.hsvfilter(before[i], W4K, W4K * 4, "RGBA", SETTINGS)
+            _same(frames[pool, i].cpu().numpy().reshape(H4K, W4K * 4), before[i], f"hsvfilter frame {i}")
+        return (f"frames 0 and {args.batch - 1} of one {args.batch}-frame launch of the timed entry (a scratch batch, before the settle), every byte, "
+                "against oracle/hsv_oracle.c")
+
+    class _Headline:
+        pass
+    _Headline.verify = staticmethod(verify)
+    verified = run_verify(w, _Headline) if not args.no_verify else {"verified": None}
+    n_launches[0] = 0
     settle_steps, elapsed, kernel_ms = batch_leg()
     batch_fps_rank = w.gather(args.steps * args.batch / elapsed)
     batch_fps = args.steps * args.batch * world / elapsed
@@ -1540,6 +1696,7 @@ def hsvfilter_main(args):
                    "u8_to_unit_float": "typed buffer loads (texture-unit UNORM8, exact)" if args.typed_loads else "VALU (cvt + mul + fmac)"},
         "roofline": roof,
     }
+    out.update(verified)
     timing["headline_gpu_legs"] = time.perf_counter() - t_start
     del frames, flat_frames, frame_arrays
     torch.cuda.empty_cache()
@@ -1583,6 +1740,9 @@ def hsvfilter_main(args):
                 box["d"] = {"error": f"{type(e).__name__}: {e}"}
 
         th = threading.Thread(target=side_leg, daemon=True)
+        # every rank gets here within the skew of the headline's closing barrier: the common deadline for the "who is stuck" flags is this
+        # instant + the watchdog + slack (advisor r5: 60 s per missing rank was shorter than the 180 s watchdog of the other ranks)
+        flags_deadline = time.monotonic() + args.side_leg_timeout + SIDE_LEG_FLAG_SLACK_S
         th.start()
         th.join(timeout=args.side_leg_timeout)
         late = {"error": f"no result within {args.side_leg_timeout} s (watchdog)"}
@@ -1592,15 +1752,15 @@ def hsvfilter_main(args):
         # A rank stuck in the collective is a FAILURE of the run: the ranks agree over the rendezvous store (plain TCP, no GPU
         # collective -- the device queue of a stuck rank may never drain), rank 0 still prints the headline (with an `error` entry),
         # and every rank leaves with a non-zero code so that the launcher / the spawning parent reports the run as failed.
-        stuck_ranks = agree_on_stuck(w, th.is_alive(), args.side_leg_timeout)
+        stuck_ranks = agree_on_stuck(w, th.is_alive(), args.side_leg_timeout, deadline=flags_deadline)
         if stuck_ranks:
             if rank == 0:
                 out["config"]["error"] = f"side leg stuck in its collective on rank(s) {stuck_ranks}; exit code {EXIT_SIDE_LEG_STUCK}"
                 out["wall_s"] = time.perf_counter() - t_start
                 emit(out, subs, full=bool(args.full))
                 mark_emitted(w)
-            else:
-                wait_emitted(w, 20.0)
+            else:  # rank 0 prints once ITS flag loop is through, which is the common deadline at the latest
+                wait_emitted(w, max(20.0, flags_deadline - time.monotonic() + 20.0))
             os._exit(EXIT_SIDE_LEG_STUCK)  # the stuck thread holds the communicator: no orderly teardown; never exec from here
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         t1 = time.perf_counter()
@@ -1619,6 +1779,7 @@ def hsvfilter_main(args):
 
 
 EXIT_SIDE_LEG_STUCK = 5
+SIDE_LEG_FLAG_SLACK_S = 30.0  # beyond --side-leg-timeout: how long a rank waits for the other ranks' "stuck / not stuck" flags
 
 
 def _store(w):
@@ -1626,16 +1787,23 @@ def _store(w):
     return distributed_c10d._get_default_store()
 
 
-def agree_on_stuck(w, stuck, patience_s, store=None):
+def agree_on_stuck(w, stuck, patience_s, store=None, deadline=None, clock=time.monotonic):
     """Every rank publishes whether its side-leg thread is still alive; returns the sorted list of stuck ranks as every rank sees it.
-    A rank that never publishes (dead, or hung before this point) counts as stuck.  Keys live in the rendezvous store: no collective."""
+    A rank that never publishes (dead, or hung before this point) counts as stuck.  Keys live in the rendezvous store: no collective.
+
+    ONE deadline is shared by the whole loop (`deadline`, on `clock`; default now + patience_s): the ranks' watchdogs run independently, so a
+    rank whose leg fails at once publishes up to --side-leg-timeout before the ranks that sit out their watchdog in the rendezvous -- it has to
+    wait for THEIR flags that long, or it would count them as never arrived, leave early and (a launcher ends every rank at the first non-zero
+    exit) take rank 0 down before the headline line.  With a common deadline every rank that publishes in time is seen by all, so the lists agree."""
     import datetime
     store = store or _store(w)
+    if deadline is None:
+        deadline = clock() + max(5.0, patience_s)
     store.set(f"mvfx_side_stuck_{w.rank}", "1" if stuck else "0")
     bad = []
     for r in range(w.world):
         try:
-            store.wait([f"mvfx_side_stuck_{r}"], datetime.timedelta(seconds=max(5.0, min(60.0, patience_s))))
+            store.wait([f"mvfx_side_stuck_{r}"], datetime.timedelta(seconds=max(1.0, deadline - clock())))
             if store.get(f"mvfx_side_stuck_{r}") != b"0":
                 bad.append(r)
         except Exception:  # noqa: BLE001  (timeout: the rank never arrived)
@@ -1670,16 +1838,25 @@ def gst_pipeline_leg(args):
     gst_dir = os.path.join(ROOT, "gst-plugin-rs_amd", "gst-plugins")
     if not os.path.isdir(gst_dir) or not os.path.exists("/opt/conda/bin/gst-launch-1.0"):
         return {"error": "no GStreamer on this box (the element layer is an optional build target)"}
+    import shutil
+    import tempfile
+    dump = tempfile.mkdtemp(prefix="mvfx_gst_verify_") if not NO_VERIFY[0] else ""
     cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_gst_pipeline.py"), "--honest", "1", "--repeats", "2",
-           "--n1", str(args.gst_n1), "--n2", str(args.gst_n2)]
+           "--n1", str(args.gst_n1), "--n2", str(args.gst_n2)] + (["--dump-dir", dump] if dump else [])
+    verified = {"verified": None}
     try:
         env = {k: v for k, v in os.environ.items() if k not in ("MVFX_ELEMENT_PAIR", "MVFX_HIP_POOL_MIN")}
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=args.gst_timeout, env=env)
         if r.returncode != 0:
             raise RuntimeError(f"bench_gst_pipeline rc {r.returncode}: {r.stderr[-200:]}")
         d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        if d.get("dump"):
+            verified = verify_gst_dump(d.pop("dump"))
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"[:300]}
+    finally:
+        if dump:
+            shutil.rmtree(dump, ignore_errors=True)
     fps = d.get("hsvfilter_hbm_resident_fps")
     committed = committed_counters("hsvfilter", 1)
     return {"metric": "gst_hsvfilter_element_4k_rgba_frames_per_sec", "value": fps, "unit": "frames/s",
@@ -1691,7 +1868,26 @@ def gst_pipeline_leg(args):
                           "cache_resident_fps_4_blocks": d.get("hsvfilter_cache_resident_fps"),
                           "with_device_consumer_fps": d.get("hsvfilter_then_hsvdetector_hbm_resident_fps"),
                           "with_device_consumer_frac": d.get("hsvfilter_then_hsvdetector_frac_of_8TBs")},
-            "detail": d}
+            "detail": d, **verified}
+
+
+def verify_gst_dump(dump):
+    """three buffers out of `hiptestsrc ! (memory:HIPMemory) ! hsvfilter <bench settings> ! hipdownload` against the oracle on the source's frame"""
+    try:
+        import numpy as np
+        from tests import oracle_binding as orc
+        W, H = dump["width"], dump["height"]
+        want = np.fromfile(dump["in"], dtype=np.uint8).reshape(H, W * 4).copy()
+        orc.hsvfilter(want, W, W * 4, "RGBA", SETTINGS)
+        got = np.fromfile(dump["out"], dtype=np.uint8)
+        if got.size != dump["frames_out"] * want.size:
+            raise AssertionError(f"the element pipeline wrote {got.size} bytes, expected {dump['frames_out']} frames of {want.size}")
+        for k in range(dump["frames_out"]):
+            _same(got[k * want.size:(k + 1) * want.size].reshape(H, W * 4), want, f"hsvfilter element, buffer {k}")
+        return {"verified": True, "verified_what": "three buffers of the timed element (same caps and properties) downloaded and compared byte for byte with "
+                                                   "oracle/hsv_oracle.c on the source's frame"}
+    except Exception as e:  # noqa: BLE001
+        return {"verified": False, "verified_what": f"{type(e).__name__}: {e}"[:300]}
 
 
 def main():
@@ -1730,6 +1926,7 @@ def main():
                     help="the element sub-line: the rate is taken inside ONE gst-launch run of n2 buffers, between buffer n1 and the last one")
     ap.add_argument("--gst-timeout", type=float, default=150.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of one step of every leg (profiling runs)")
     ap.add_argument("--other-configs", type=int, default=1, choices=[0, 1],
                     help="hsvfilter workload: after the headline legs also measure BASELINE configs 2-5 in this run "
                          "(config.other_configs); N > 1: the band-sharded videocompare leg with its RCCL all-reduce")
@@ -1774,6 +1971,7 @@ def main():
     args = ap.parse_args()
     if args.no_cpu_baseline:
         args.other_cpu_seconds = 0.0
+    NO_VERIFY[0] = bool(args.no_verify)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_workers(args, sys.argv[1:])  # the parent never touches the GPU
     if args.workload == "videocompare":

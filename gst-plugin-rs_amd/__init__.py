@@ -158,6 +158,7 @@ SIGNATURES = {
     "mvfx_hsvdetector_transform_frames": (c_int, [POINTER(Frame), POINTER(Frame), c_uint32, POINTER(HsvDetectorSettings), c_void_p]),
     "mvfx_hsvdetector_transform_frame_host": (c_int, [POINTER(Frame), POINTER(Frame), POINTER(HsvDetectorSettings)]),
     "mvfx_hsv_from_frame": (c_int, [POINTER(Frame), c_void_p, c_void_p]),
+    "mvfx_selftest_typed_unorm8": (c_int, [POINTER(c_uint32), POINTER(c_uint32)]),
     "mvfx_cube_lut_parse": (c_int, [c_char_p, c_size_t, POINTER(c_void_p)]),
     "mvfx_cube_lut_parse_file": (c_int, [c_char_p, POINTER(c_void_p)]),
     "mvfx_cube_lut_free": (None, [c_void_p]),

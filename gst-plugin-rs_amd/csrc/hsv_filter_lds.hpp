@@ -35,7 +35,7 @@ struct FrameSettingsBatch {
 
 // hsv_typed_kernels.hip: hsvfilter4_typed_kernel<neg ? kFastNeg : kFast, tile (1 | 2), streaming>
 void launch_hsvfilter_typed(bool neg_shift, int tile, bool streaming, dim3 grid, hipStream_t stream, const FrameBatch &fb, uint64_t width,
-                            uint32_t rows, uint64_t stride, const FastConsts &p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr);
+                            uint32_t rows, uint64_t stride, const FastConsts &p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr, int iters = 1);
 
 // the same with per-frame settings in the kernel arguments (all frames: hue_shift of one sign)
 void launch_hsvfilter3_typed(bool neg_shift, int tile, bool streaming, dim3 grid, hipStream_t stream, const FrameBatch &fb, uint64_t width,

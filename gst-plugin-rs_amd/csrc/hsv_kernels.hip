@@ -708,6 +708,19 @@ int hsvfilter_impl(const mvfx_frame *frames, uint32_t n, const mvfx_hsvfilter_se
             const uint32_t iR = off + (bgr ? 2 : 0), iG = off + 1, iB = off + (bgr ? 0 : 2);
             const uint32_t word3 = (4 + iR) | ((4 + iG) << 3) | ((4 + iB) << 6) | (10u << 15);
             const bool neg = std::signbit(s->hue_shift) && s->hue_shift != 0.0f;
+            // EXPERIMENT (round 6): MVFX_EXP_SINGLE=tile,iters[,maxgrid] -- the launch shape of ONE-frame calls
+            static const char *exp_single = getenv("MVFX_EXP_SINGLE");
+            if (exp_single && m == 1 && !neg && opt_nontemporal() && g.rows == 1) {
+                int et = 2, ei = 1, eg = 0;
+                sscanf(exp_single, "%d,%d,%d", &et, &ei, &eg);
+                const uint64_t per = (uint64_t)kBlock * et * ei;
+                dim3 eg3 = g.grid;
+                eg3.x = (uint32_t)((g.width / 4 + per - 1) / per);
+                if (eg > 0 && eg3.x > (uint32_t)eg) eg3.x = (uint32_t)eg;
+                launch_hsvfilter_typed(false, et, true, eg3, stream, fb, g.width, g.rows, g.stride, p, word3, (uint32_t)frame_bytes, off, bgr, ei);
+                MVFX_HIP_TRY(hipGetLastError());
+                continue;
+            }
             launch_hsvfilter_typed(neg, g.tile == kTile ? kTile : 1, opt_nontemporal(), g.grid, stream, fb, g.width, g.rows, g.stride, p, word3,
                                    (uint32_t)frame_bytes, off, bgr);
             MVFX_HIP_TRY(hipGetLastError());

@@ -1,8 +1,11 @@
 // hsvfilter4_typed_kernel: hsvfilter on 4-byte formats with the three `byte / 255.0` divisions of every pixel done by
 // the texture unit (video/hsv/src/hsvutils.rs:45-55 `let r = in_p[0] as f32 / 255.0` ...).  Own translation unit: built
-// with LLVM's default GCN scheduler (+0.9 % over the ILP strategy hsv_kernels.hip is built with, which is worth +3.8 % on
-// the VALU-only kernels there; gst-plugin-rs_amd/Makefile).
+// with the max-memory-clause scheduling strategy (gst-plugin-rs_amd/Makefile HSVTYPED_EXTRA: 88.2 k fps against 87.6 k with
+// LLVM's default GCN scheduler and 86.2 k with the iterative-ilp strategy hsv_kernels.hip is built with).
 #include "hsv_filter_lds.hpp"
+
+#include <cstring>
+#include <vector>
 
 namespace mvfx {
 namespace {
@@ -20,7 +23,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <int VARIANT, int TILE, bool NT>
+template <int VARIANT, int TILE, bool NT, int ITERS = 1>
 __device__ __forceinline__ void hsvfilter4_typed_body(const FrameBatch &fb, uint64_t width, uint32_t rows, uint64_t stride,
                                                       const FastConsts &p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr)
 {
@@ -38,7 +41,13 @@ __device__ __forceinline__ void hsvfilter4_typed_body(const FrameBatch &fb, uint
         uint8_t *line = frame + (uint64_t)row * stride;
         const uint32_t line_off = (uint32_t)((uint64_t)row * stride);
         const uint64_t groups = width >> 2; // the launcher guarantees width % 4 == 0
-        for (uint64_t t0 = (uint64_t)blockIdx.x * (kBlock * TILE); t0 < groups; t0 += (uint64_t)gridDim.x * (kBlock * TILE)) {
+        // ITERS > 1 (the one-frame launch shape): a workgroup walks ITERS ADJACENT chunks, so the grid is 1 / ITERS of the one-shot grid while
+        // the chip still sweeps the frame in address order
+        for (uint64_t tb = (uint64_t)blockIdx.x * (kBlock * TILE * ITERS); tb < groups; tb += (uint64_t)gridDim.x * (kBlock * TILE * ITERS))
+#pragma unroll 1
+        for (int it = 0; it < ITERS; it++) {
+            const uint64_t t0 = tb + (uint64_t)it * (kBlock * TILE);
+            if (ITERS > 1 && t0 >= groups) break;
             u32x4 raw[TILE];
             f32x3 c[TILE][4];
             uint32_t voff[TILE];
@@ -98,11 +107,11 @@ __device__ __forceinline__ void hsvfilter4_typed_body(const FrameBatch &fb, uint
     }
 }
 
-template <int VARIANT, int TILE, bool NT>
+template <int VARIANT, int TILE, bool NT, int ITERS = 1>
 __global__ __launch_bounds__(kBlock) void hsvfilter4_typed_kernel(FrameBatch fb, uint64_t width, uint32_t rows, uint64_t stride,
                                                                   FastConsts p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr)
 {
-    hsvfilter4_typed_body<VARIANT, TILE, NT>(fb, width, rows, stride, p, word3, frame_bytes, off, bgr);
+    hsvfilter4_typed_body<VARIANT, TILE, NT, ITERS>(fb, width, rows, stride, p, word3, frame_bytes, off, bgr);
 }
 
 // The same kernel with the settings of every frame of the launch in the argument block (blockIdx.z = frame = stream): what the
@@ -212,6 +221,39 @@ __global__ __launch_bounds__(kBlock) void hsvfilter3_typed_kernel(FrameBatch fb,
     }
 }
 
+
+// ---- self-test of the hardware property the 3-byte kernels rest on ----------------------------------------------------------------
+// Lane i issues exactly the four loads of a lane of hsvfilter3_typed_kernel / hsvdetector3_typed_kernel -- descriptor A at immediate
+// offsets 0, 3, 6, descriptor B at 8 -- from byte address i, so the 1 024 lanes cover every address alignment (i mod 4) with every byte
+// value in every channel (the host fills position 4 k + r with a bijection of k).  Twelve floats per lane go back for the host to compare
+// with RN(byte / 255).
+__global__ __launch_bounds__(kBlock) void typed_unorm8_selftest_kernel(const uint8_t *bytes, float *out, uint32_t n_bytes, uint32_t word3a,
+                                                                       uint32_t word3b, uint32_t lanes)
+{
+    const uint64_t a = reinterpret_cast<uint64_t>(bytes);
+    i32x4 ra, rb;
+    ra.x = rb.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    ra.y = rb.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));
+    ra.z = rb.z = __builtin_amdgcn_readfirstlane((int)n_bytes);
+    ra.w = __builtin_amdgcn_readfirstlane((int)word3a);
+    rb.w = __builtin_amdgcn_readfirstlane((int)word3b);
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    f32x3 c[4];
+    asm volatile("buffer_load_format_xyz %0, %4, %5, 0 offen\n\t"
+                 "buffer_load_format_xyz %1, %4, %5, 0 offen offset:3\n\t"
+                 "buffer_load_format_xyz %2, %4, %5, 0 offen offset:6\n\t"
+                 "buffer_load_format_xyz %3, %4, %6, 0 offen offset:8\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+                 : "v"(i), "s"(ra), "s"(rb)
+                 : "memory");
+    if (i < lanes) {
+        float *o = out + (size_t)i * 12;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { o[3 * j] = c[j].x; o[3 * j + 1] = c[j].y; o[3 * j + 2] = c[j].z; }
+    }
+}
+
 } // namespace
 
 void launch_hsvfilter3_typed(bool neg_shift, int tile, bool streaming, dim3 grid, hipStream_t stream, const FrameBatch &fb, uint64_t width,
@@ -227,8 +269,15 @@ void launch_hsvfilter3_typed(bool neg_shift, int tile, bool streaming, dim3 grid
 }
 
 void launch_hsvfilter_typed(bool neg_shift, int tile, bool streaming, dim3 grid, hipStream_t stream, const FrameBatch &fb, uint64_t width,
-                            uint32_t rows, uint64_t stride, const FastConsts &p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr)
+                            uint32_t rows, uint64_t stride, const FastConsts &p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr, int iters)
 {
+    if (iters > 1) { // EXPERIMENT (round 6): adjacent chunks per workgroup; positive hue-shift, non-temporal only
+#define MVFX_LTI(T_, I_) MVFX_LAUNCH((hsvfilter4_typed_kernel<kFast, T_, true, I_>), grid, dim3(kBlock), 0, stream, fb, width, rows, stride, p, word3, frame_bytes, off, bgr)
+        if (tile == 2) { if (iters == 2) MVFX_LTI(2, 2); else if (iters == 3) MVFX_LTI(2, 3); else if (iters == 4) MVFX_LTI(2, 4); else MVFX_LTI(2, 8); }
+        else { if (iters == 2) MVFX_LTI(1, 2); else if (iters == 4) MVFX_LTI(1, 4); else MVFX_LTI(1, 8); }
+#undef MVFX_LTI
+        return;
+    }
 #define MVFX_LT(V, T_, NT_) \
     MVFX_LAUNCH((hsvfilter4_typed_kernel<V, T_, NT_>), grid, dim3(kBlock), 0, stream, fb, width, rows, stride, p, word3, frame_bytes, off, bgr)
 #define MVFX_LT_NT(V, T_) do { if (streaming) MVFX_LT(V, T_, true); else MVFX_LT(V, T_, false); } while (0)
@@ -252,3 +301,47 @@ void launch_hsvfilter_typed_frames(bool neg_shift, int tile, bool streaming, dim
 }
 
 } // namespace mvfx
+
+extern "C" int mvfx_selftest_typed_unorm8(uint32_t *checked_out, uint32_t *mismatches_out)
+{
+    using namespace mvfx;
+    if (!checked_out || !mismatches_out)
+        return fail(MVFX_ERR_INVALID_ARGUMENT, "selftest_typed_unorm8: NULL argument");
+    *checked_out = *mismatches_out = 0;
+    if (int rc = require_device(); rc != MVFX_OK) return rc;
+    constexpr uint32_t kLanes = 1024, kBytes = kLanes + 12;
+    std::vector<uint8_t> h(kBytes);
+    for (uint32_t pos = 0; pos < kBytes; pos++) // position 4 k + r holds (167 k + 59 r) mod 256: all 256 values at every residue r
+        h[pos] = (uint8_t)((pos >> 2) * 167u + (pos & 3u) * 59u);
+    uint8_t *d = nullptr;
+    float *o = nullptr;
+    std::vector<float> got((size_t)kLanes * 12);
+    MVFX_HIP_TRY(hipMalloc(&d, kBytes));
+    if (hipMalloc(&o, got.size() * sizeof(float)) != hipSuccess) { (void)hipFree(d); return fail(MVFX_ERR_OUT_OF_MEMORY, "selftest_typed_unorm8: hipMalloc"); }
+    int rc = MVFX_OK;
+    uint32_t checked = 0, bad = 0;
+    for (int bgr = 0; bgr < 2 && rc == MVFX_OK; bgr++) {
+        // the descriptor words of hsvfilter_impl's 3-byte branch (hsv_kernels.hip): A = bytes 0, 1, 2, B = bytes 1, 2, 3 of the four fetched
+        const uint32_t r0 = bgr ? 2 : 0, b0 = bgr ? 0 : 2;
+        const uint32_t word3a = (4 + r0) | (5u << 3) | ((4 + b0) << 6) | (10u << 15), word3b = (5 + r0) | (6u << 3) | ((5 + b0) << 6) | (10u << 15);
+        if (hipMemcpy(d, h.data(), kBytes, hipMemcpyHostToDevice) != hipSuccess || hipMemset(o, 0xff, got.size() * sizeof(float)) != hipSuccess) { rc = MVFX_ERR_DEVICE; break; }
+        hipLaunchKernelGGL(typed_unorm8_selftest_kernel, dim3(kLanes / kBlock), dim3(kBlock), 0, nullptr, d, o, kBytes, word3a, word3b, kLanes);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(got.data(), o, got.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { rc = MVFX_ERR_DEVICE; break; }
+        static const uint32_t first[4] = {0, 3, 6, 9}; // pixel j of a lane starts at byte 3 j (pixel 3: fetched from byte 8, bytes 1..3 delivered)
+        for (uint32_t i = 0; i < kLanes; i++)
+            for (int j = 0; j < 4; j++)
+                for (int ch = 0; ch < 3; ch++) {
+                    const uint32_t byte_index = i + first[j] + (ch == 1 ? 1u : (ch == 0 ? r0 : b0));
+                    const float want = (float)h[byte_index] / 255.0f; // IEEE division: this file is built with -ffp-contract=off -fno-fast-math
+                    const float have = got[(size_t)i * 12 + 3 * j + ch];
+                    checked++;
+                    if (std::memcmp(&want, &have, sizeof want) != 0) bad++;
+                }
+    }
+    (void)hipFree(d);
+    (void)hipFree(o);
+    if (rc != MVFX_OK) return fail(rc, "selftest_typed_unorm8: HIP call failed");
+    *checked_out = checked;
+    *mismatches_out = bad;
+    return MVFX_OK;
+}

@@ -258,6 +258,14 @@ int mvfx_hsvdetector_transform_frame_host(const mvfx_frame *in_frame, const mvfx
  * an element never calls it). */
 int mvfx_hsv_from_frame(const mvfx_frame *frame, float *hsv_out_device, mvfx_stream stream);
 
+/* Diagnostic: checks on the current device the hardware property the RGB / BGR (3-byte) hsvfilter and hsvdetector kernels rest on --
+ * a typed buffer load (DATA_FORMAT 8_8_8_8, NUM_FORMAT UNORM) at a byte address that is NOT a multiple of four delivers
+ * RN(byte / 255.0f) of the bytes AT that address, through both descriptors and the four immediate offsets the kernels use, for every
+ * byte value at every address alignment, in RGB and BGR channel order (`let r = in_p[0] as f32 / 255.0`, hsvutils.rs:45-55, done
+ * by the texture unit).  *checked_out = comparisons made (24 576), *mismatches_out = how many differed bit-wise from the IEEE
+ * division.  Synchronous; tests call it, an element never does. */
+int mvfx_selftest_typed_unorm8(uint32_t *checked_out, uint32_t *mismatches_out);
+
 /* ---- colorlut : video/colorlut/src/parser.rs + colorlut/imp.rs ----
  * mvfx_cube_lut mirrors `CubeLut` (parser.rs:68-74): domain_scale/offset + 1-D tables or the
  * 3-D [r,g,b,1.0] node array, R fastest.  Parsing is host-only (works without a GPU); the device

@@ -151,6 +151,46 @@ def test_ranks_agree_on_who_is_stuck_without_a_collective():
     assert time.time() - t0 < 2
 
 
+def test_an_early_rank_waits_for_the_late_ranks_flags_until_the_common_deadline():
+    """advisor r5: a rank whose side leg fails at once publishes up to --side-leg-timeout (180 s) before the ranks that sit out their watchdog.
+    With the old 60 s-per-rank patience it counted them as never arrived and left; with ONE deadline of watchdog + slack it waits.  Simulated
+    time: the late rank publishes at t = 70 s of a clock that runs 100 x real time; both ranks must return the same list, and the early
+    rank must not have returned before the late one published."""
+    sys.path.insert(0, ROOT)
+    import threading
+    import torch.distributed as dist
+    import bench
+    store = dist.HashStore()
+    t0 = time.monotonic()
+    clock = lambda: (time.monotonic() - t0) * 100.0   # simulated seconds
+    deadline = 180.0 + bench.SIDE_LEG_FLAG_SLACK_S
+    res, returned_at = {}, {}
+
+    class FastStore:
+        """store.wait() timeouts are real time: scale them like the clock"""
+        def __init__(self, inner): self.inner = inner
+        def set(self, k, v): self.inner.set(k, v)
+        def get(self, k): return self.inner.get(k)
+        def wait(self, keys, td): self.inner.wait(keys, td / 100.0)
+
+    def rank(r, publish_at):
+        while clock() < publish_at:
+            time.sleep(0.005)
+        res[r] = bench.agree_on_stuck(argparse.Namespace(rank=r, world=2), r == 1, 180.0, store=FastStore(store), deadline=deadline, clock=clock)
+        returned_at[r] = clock()
+
+    ths = [threading.Thread(target=rank, args=(0, 0.0)), threading.Thread(target=rank, args=(1, 70.0))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert res == {0: [1], 1: [1]}
+    assert returned_at[0] >= 70.0 and returned_at[0] < deadline
+    # a rank that never publishes: the others give up AT the deadline, not 60 s per rank later
+    store2 = dist.HashStore()
+    t0 = time.monotonic()
+    got = bench.agree_on_stuck(argparse.Namespace(rank=0, world=3), False, 180.0, store=FastStore(store2), deadline=deadline, clock=clock)
+    assert got == [1, 2] and clock() < deadline + 150.0   # (each wait has a floor of one simulated second x the real-time store)
+
+
 def test_final_line_sheds_instead_of_asserting(tmp_path, capsys, monkeypatch):
     """advisor r4: a line that is still too long after the first shedding must come out shorter, not as an AssertionError"""
     sys.path.insert(0, ROOT)

@@ -409,3 +409,175 @@ def test_typed_loads_hsvdetector_all_triples(gpu):
                 assert np.array_equal(got, want), (in_fmt, out_fmt, typed, int(np.count_nonzero(got != want)))
     finally:
         gpu.check(gpu.lib().mvfx_thread_set_options(gpu.options(typed=bool(1)).word))
+
+
+# ---------------------------------------------------------------- RGB / BGR through the typed 3-byte kernels (round 5's default path)
+# hsvfilter3_typed_kernel / hsvdetector3_typed_kernel take every 3-byte frame whose width is a multiple of four (hsv_kernels.hip,
+# hsvfilter_impl / hsvdetector_impl).  Their proofs, like the 4-byte kernels': all 2^24 colours against the oracle.
+
+def exhaustive_rgb3() -> np.ndarray:
+    """4096 x 4096 packed 3-byte frame (stride 12 288) holding all 2^24 (c0, c1, c2) triples, in the pixel order of frames.exhaustive_rgbx()"""
+    return np.ascontiguousarray(frames.exhaustive_rgbx().reshape(-1, 4)[:, :3]).reshape(4096, 4096 * 3)
+
+
+@pytest.fixture(scope="module")
+def exhaustive3():
+    return exhaustive_rgb3()
+
+
+def test_typed_unorm8_loads_at_unaligned_addresses(gpu):
+    """tools/probes/typed_unaligned.hip as a test: buffer_load_format_xyz of 8_8_8_8 UNORM at byte addresses 4 k + 0 / 1 / 2 / 3, through
+    both descriptors and the immediate offsets 0 / 3 / 6 / 8 of the 3-byte kernels: RN(byte / 255) for all 256 values, RGB and BGR order"""
+    checked, bad = ctypes.c_uint32(), ctypes.c_uint32(0xFFFFFFFF)
+    gpu.check(gpu.lib().mvfx_selftest_typed_unorm8(ctypes.byref(checked), ctypes.byref(bad)))
+    assert checked.value == 2 * 1024 * 12 and bad.value == 0, (checked.value, bad.value)
+
+
+RGB3_FILTER_SETTINGS = [BENCH_SETTINGS, (-123.4, 0.5, 0.3, 1.7, -0.2), (0.0, 1.0, 0.0, 1.0, 0.0)]
+
+
+@pytest.mark.parametrize("fmt", ["RGB", "BGR"])
+@pytest.mark.parametrize("settings", RGB3_FILTER_SETTINGS, ids=["bench", "negative-shift", "defaults"])
+@pytest.mark.parametrize("nontemporal", [False, True], ids=["cached", "nt"])
+def test_hsvfilter_rgb3_typed_exhaustive(gpu, exhaustive3, fmt, settings, nontemporal):
+    """All 2^24 triples packed as RGB / BGR through mvfx_hsvfilter_transform_frame_ip: the whole 4096 x 4096 frame takes the two-groups-per-lane
+    instantiation (TILE = 2: >= 3840 x 2160 / 4 groups), its four 4096 x 1024 bands TILE = 1; positive and negative hue-shift (kFast / kFastNeg);
+    cached and non-temporal; bit-exact against the oracle."""
+    W, H, stride = 4096, 4096, 4096 * 3
+    expect = exhaustive3.copy()
+    assert orc.hsvfilter(expect, W, stride, fmt, settings) == 0
+    s = gpu.HsvFilterSettings(*settings)
+    gpu.check(gpu.lib().mvfx_thread_set_options(gpu.options(nontemporal=nontemporal).word))
+    try:
+        buf = gpu.DeviceBuffer(exhaustive3.nbytes).upload(exhaustive3)
+        gpu.hsvfilter_device(buf.ptr, W, H, stride, fmt, s)
+        gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+        got = buf.download().reshape(H, stride)
+        assert np.array_equal(got, expect), f"whole frame: {int(np.count_nonzero(got != expect))} bytes differ"
+        buf.upload(exhaustive3)
+        for band in range(4):
+            gpu.hsvfilter_device(buf.ptr + band * 1024 * stride, W, 1024, stride, fmt, s)
+        gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+        got = buf.download().reshape(H, stride)
+        assert np.array_equal(got, expect), f"bands: {int(np.count_nonzero(got != expect))} bytes differ"
+    finally:
+        gpu.check(gpu.lib().mvfx_thread_set_options(0))
+
+
+@pytest.mark.parametrize("fmt", ["RGB", "BGR"])
+def test_hsvfilter_rgb3_typed_and_valu_paths_agree(gpu, exhaustive3, fmt):
+    """the VALU kernel hsvfilter3_kernel (MVFX_OPT_HSV_VALU_UNORM; also what widths that are not multiples of four take) on the same
+    2^24 triples, and a 256 x 64 frame (TILE = 1, rows = 1 flat walk) through both"""
+    W, H, stride = 4096, 4096, 4096 * 3
+    for settings in (BENCH_SETTINGS, (-45.0, 0.8, 0.1, 1.1, -0.03)):
+        expect = exhaustive3.copy()
+        assert orc.hsvfilter(expect, W, stride, fmt, settings) == 0
+        small = frames.random_frame(0x5EED0A00, 256, 64, 3)
+        small_expect = small.copy()
+        assert orc.hsvfilter(small_expect, 256, 256 * 3, fmt, settings) == 0
+        try:
+            for typed in (False, True):
+                gpu.check(gpu.lib().mvfx_thread_set_options(gpu.options(typed=typed).word))
+                buf = gpu.DeviceBuffer(exhaustive3.nbytes).upload(exhaustive3)
+                gpu.hsvfilter_device(buf.ptr, W, H, stride, fmt, gpu.HsvFilterSettings(*settings))
+                sb = gpu.DeviceBuffer(small.nbytes).upload(small)
+                gpu.hsvfilter_device(sb.ptr, 256, 64, 256 * 3, fmt, gpu.HsvFilterSettings(*settings))
+                gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+                assert np.array_equal(buf.download().reshape(H, stride), expect), (fmt, settings, typed)
+                assert np.array_equal(sb.download().reshape(64, 256 * 3), small_expect), (fmt, settings, typed)
+        finally:
+            gpu.check(gpu.lib().mvfx_thread_set_options(0))
+
+
+RGB3_DETECT_SETTINGS = [DETECT_SETTINGS[3], DETECT_SETTINGS[0], DETECT_SETTINGS[1], DETECT_SETTINGS[4]]
+
+
+@pytest.mark.parametrize("in_fmt", ["RGB", "BGR"])
+@pytest.mark.parametrize("out_fmt", DET_OUT)
+def test_hsvdetector_rgb3_typed_exhaustive(gpu, exhaustive3, in_fmt, out_fmt):
+    """All 2^24 triples packed as RGB / BGR -> every output layout through mvfx_hsvdetector_transform_frame (hsvdetector3_typed_kernel);
+    bench settings + both edges of the hue test's domain + a wrap through 0"""
+    W, H, istride, ostride = 4096, 4096, 4096 * 3, 4096 * 4
+    src = gpu.DeviceBuffer(exhaustive3.nbytes).upload(exhaustive3)
+    dst = gpu.DeviceBuffer(H * ostride)
+    fi = gpu.make_frame(src.ptr, W, H, istride, in_fmt)
+    fo = gpu.make_frame(dst.ptr, W, H, ostride, out_fmt)
+    for settings in RGB3_DETECT_SETTINGS:
+        expect = np.empty((H, ostride), dtype=np.uint8)
+        assert orc.hsvdetector(exhaustive3, istride, in_fmt, expect, ostride, out_fmt, W, settings) == 0
+        gpu.check(gpu.lib().mvfx_hsvdetector_transform_frame(ctypes.byref(fi), ctypes.byref(fo), ctypes.byref(gpu.HsvDetectorSettings(*settings)), None))
+        gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+        got = dst.download().reshape(H, ostride)
+        assert np.array_equal(got, expect), (in_fmt, out_fmt, settings, int(np.count_nonzero(got != expect)))
+
+
+def _vts_rgb3(n):
+    """n consecutive videotestsrc pattern=smpte 3840 x 2160 frames packed to RGB (what bench.py's hsvfilter_rgb / hsvdetector_rgb legs time)"""
+    w, h = 3840, 2160
+    vts, _ = frames.videotestsrc_smpte(w, h, n)
+    return [np.ascontiguousarray(vts[k].reshape(h, w, 4)[..., :3]).reshape(h, w * 3) for k in range(n)]
+
+
+@pytest.mark.parametrize("nontemporal", [True, False], ids=["nt", "cached"])
+def test_hsv_rgb3_bench_legs_full_compare(gpu, nontemporal):
+    """bench.py's two RGB legs themselves: 16 x 3840 x 2160 RGB videotestsrc frames through mvfx_hsvfilter_transform_frames_ip (in place) and
+    mvfx_hsvdetector_transform_frames (-> RGBA), every byte of every frame against the oracle"""
+    w, h, n = 3840, 2160, 16
+    stride3 = w * 3
+    host = _vts_rgb3(n)
+    din = [gpu.DeviceBuffer(f.nbytes).upload(f) for f in host]
+    dout = [gpu.DeviceBuffer(h * w * 4) for _ in range(n)]
+    fi = (gpu.Frame * n)(*[gpu.make_frame(b.ptr, w, h, stride3, "RGB") for b in din])
+    fo = (gpu.Frame * n)(*[gpu.make_frame(b.ptr, w, h, w * 4, "RGBA") for b in dout])
+    ds = DETECT_SETTINGS[3]
+    gpu.check(gpu.lib().mvfx_thread_set_options(gpu.options(nontemporal=nontemporal).word))
+    try:
+        gpu.check(gpu.lib().mvfx_hsvdetector_transform_frames(fi, fo, n, ctypes.byref(gpu.HsvDetectorSettings(*ds)), None))
+        gpu.check(gpu.lib().mvfx_hsvfilter_transform_frames_ip(fi, n, ctypes.byref(gpu.HsvFilterSettings(*BENCH_SETTINGS)), None))
+        gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    finally:
+        gpu.check(gpu.lib().mvfx_thread_set_options(0))
+    for k in range(n):
+        expect_det = np.empty((h, w * 4), dtype=np.uint8)
+        assert orc.hsvdetector(host[k], stride3, "RGB", expect_det, w * 4, "RGBA", w, ds) == 0
+        assert np.array_equal(dout[k].download().reshape(h, w * 4), expect_det), f"detector frame {k}"
+        expect = host[k].copy()
+        assert orc.hsvfilter(expect, w, stride3, "RGB", BENCH_SETTINGS) == 0
+        assert np.array_equal(din[k].download().reshape(h, stride3), expect), f"filter frame {k}"
+
+
+@pytest.mark.parametrize("fmt", ["RGB", "BGR"])
+@pytest.mark.parametrize("geom", [(256, 64, 16), (1920, 1080, 0), (3840, 2160, 32), (8, 3, 12), (4, 1, 0)], ids=lambda g: f"{g[0]}x{g[1]}+pad{g[2]}")
+def test_hsv_rgb3_typed_never_touches_a_byte_outside_the_frame(gpu, fmt, geom):
+    """The typed 3-byte kernels lean on the buffer descriptor's bounds (num_records = stride x height) and read a lane's fourth pixel through a
+    second descriptor: the frame sits in the middle of a larger allocation filled with a sentinel, the row padding is non-zero random bytes, and
+    (a) the result equals the oracle's, (b) padding and sentinel are untouched, (c) the detector's output allocation likewise -- also with the
+    frame ending exactly at the last byte of its allocation (the last lane's loads end at num_records)."""
+    w, h, pad = geom
+    stride = w * 3 + pad
+    while (stride * h) % 3 or stride % 4:
+        stride += 4
+    frame = frames.random_frame(0x5EED0B00 + w, w, h, 3, stride)
+    expect = frame.copy()
+    assert orc.hsvfilter(expect, w, stride, fmt, BENCH_SETTINGS) == 0
+    ostride = w * 4 + 16
+    expect_det = np.full((h, ostride), 0xC3, dtype=np.uint8)
+    assert orc.hsvdetector(frame, stride, fmt, expect_det, ostride, "ARGB", w, DETECT_SETTINGS[3]) == 0
+    for lead, trail in ((256, 256), (4096, 0)):
+        total = lead + frame.nbytes + trail
+        host = np.full(total, 0x5A, dtype=np.uint8)
+        host[lead:lead + frame.nbytes] = frame.reshape(-1)
+        buf = gpu.DeviceBuffer(total).upload(host)
+        ototal = lead + h * ostride + trail
+        obuf = gpu.DeviceBuffer(ototal).upload(np.full(ototal, 0xC3, dtype=np.uint8))
+        fi = gpu.make_frame(buf.ptr + lead, w, h, stride, fmt)
+        fo = gpu.make_frame(obuf.ptr + lead, w, h, ostride, "ARGB")
+        gpu.check(gpu.lib().mvfx_hsvdetector_transform_frame(ctypes.byref(fi), ctypes.byref(fo), ctypes.byref(gpu.HsvDetectorSettings(*DETECT_SETTINGS[3])), None))
+        gpu.hsvfilter_device(buf.ptr + lead, w, h, stride, fmt, gpu.HsvFilterSettings(*BENCH_SETTINGS))
+        gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+        out = buf.download()
+        assert np.array_equal(out[lead:lead + frame.nbytes].reshape(h, stride), expect)
+        assert (out[:lead] == 0x5A).all() and (out[lead + frame.nbytes:] == 0x5A).all()
+        oout = obuf.download()
+        assert np.array_equal(oout[lead:lead + h * ostride].reshape(h, ostride), expect_det)
+        assert (oout[:lead] == 0xC3).all() and (oout[lead + h * ostride:] == 0xC3).all()

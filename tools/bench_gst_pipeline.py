@@ -154,6 +154,13 @@ def honest_main(args):
     a = [rate(flt, tmp, args.n1, args.n2, {"MVFX_HIP_POOL_MIN": "12"}) for _ in range(reps)]
     b = [rate(flt, tmp, args.n1, args.n2, {"MVFX_HIP_POOL_MIN": "4"})]
     c = [rate(det, tmp, args.n1, args.n2 * 2 // 3, {"MVFX_HIP_POOL_MIN": "12"})]
+    if args.dump_dir:
+        # for bench.py's `verified`: the source's frame as system memory, and three buffers of the timed pipeline's element (same caps, same
+        # properties, refresh=true so that every buffer is the filtered master frame) downloaded into a file; bench.py compares them with the oracle
+        os.makedirs(args.dump_dir, exist_ok=True)
+        run(f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBA,{size} ! filesink location={args.dump_dir}/in.raw", tmp)
+        run(flt.format(n=3).replace(" refresh=false", "").replace("fakesink sync=false", f"hipdownload ! filesink location={args.dump_dir}/out.raw"), tmp)
+        out["dump"] = {"in": f"{args.dump_dir}/in.raw", "out": f"{args.dump_dir}/out.raw", "frames_out": 3, "width": w, "height": h}
     out["hsvfilter_hbm_resident_fps"] = round(med(a), 1)
     out["hsvfilter_hbm_resident_runs"] = [round(x, 1) for x in a]
     out["hsvfilter_hbm_resident_frac_of_8TBs"] = round(med(a) * 2 * w * h * 4 / 8e12, 4)
@@ -165,6 +172,7 @@ def honest_main(args):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--dump-dir", default="", help="--honest: also write the source frame and three filtered buffers of the element there (bench.py compares them with the oracle)")
     ap.add_argument("--honest", type=int, default=0, help="1: the single element on a rotation larger than the Infinity Cache, and with a device consumer (bench.py's sub-line)")
     ap.add_argument("--element", default="", help="hsvfilter | hsvdetector | colorlut: the single element on device memory, pair launches on / off")
     ap.add_argument("--only", default="", help="comma-separated pipeline names of the chain mode (default: all)")
