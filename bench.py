@@ -166,6 +166,9 @@ def compact_headline(out):
     for k in ("element_path", "value_p50", "last_distance", "allreduce_us", "side_legs"):
         if c.get(k) is not None:
             cfg[k] = _r(c[k]) if not isinstance(c[k], dict) else c[k]
+    sweep = c.get("other_frame_contents") or {}
+    if sweep:  # the same timed leg on the other frame contents (SURVEY 8d ii: smpte bars are never the only input): fraction of 8 TB/s over the wall clock
+        cfg["other_contents_frac"] = {k: _r(v.get("frac_wall"), 4) for k, v in sweep.items()}
     cfg["full_document"] = os.path.relpath(FULL_DOC, ROOT)
     line = {k: _r(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                      "vs_baseline", "dtype") if k in out}

@@ -165,6 +165,7 @@ SIGNATURES = {
     "mvfx_cube_lut_is_3d": (c_int, [c_void_p]),
     "mvfx_cube_lut_size": (c_uint32, [c_void_p]),
     "mvfx_cube_lut_content_verdict": (c_int, [c_void_p, POINTER(c_uint32)]),
+    "mvfx_cube_lut_device_copies": (c_int, [c_void_p]),
     "mvfx_cube_lut_domain": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float)]),
     "mvfx_cube_lut_rgba": (POINTER(c_float), [c_void_p]),
     "mvfx_cube_lut_table_1d": (POINTER(c_float), [c_void_p, c_int]),

@@ -1,0 +1,925 @@
+// colorlut: the LDS window kernels -- RGBA8 (and RGBA64) through a 3-D LUT with the entries a block of pixels needs staged in LDS instead of
+// gathered per lane (video/colorlut/src/colorlut/imp.rs:431-449, 493-539: transform_rgba_3d / sample_3d; same arithmetic, same bits as the
+// gather kernels of colorlut_kernels.hip), the content probe that chooses between the two x-prelerped forms, and the fused I420 forms.
+// Every constant below is the shipped value; the experiments that chose them are recorded in profiles/r3 ... r5 (patches of the variants
+// that lost: profiles/r5/*.patch).
+#include "colorlut_device.hpp"
+
+namespace mvfx {
+namespace {
+
+// ---------------------------------------------------------------- RGBA8 through a 3-D LUT, wave-local cell neighbourhood in LDS
+//
+// What bounds the per-lane gather kernel above is the vector L1's tag look-up rate, on natural content as much as on random
+// content (rocprofv3, profiles/r2/colorlut_counters_*_before.txt: TCP busy 97 %, 3.2 / 6.1 look-ups per pixel at ~1.2 per
+// clock per CU; VALUBusy 64 % / 28 %): every lane that needs a cell pays 6 look-ups for its 96 bytes, whoever else in the
+// wave wants the same bytes.  Pictures are locally coherent in colour: this kernel gives a wave a compact pixel BLOCK (64 x 16 or 32 x 16)
+// (spatially compact, unlike 256 consecutive pixels of a row), takes the LUT cell of the tile's centre pixel as anchor and
+// loads the 3 x 3 x 3 cells around it -- nine runs of 288 contiguous bytes, 162 coalesced 16-byte pieces in three wave
+// loads, ~54 look-ups -- into the wave's 2.6 KB of LDS.  A pixel whose cell lies in that neighbourhood (a cell of a 33^3
+// cube spans 8 code values per axis, the window 24) reads its 24 floats with six ds_read_b128 (lanes on one cell
+// broadcast); the others gather from the cell table in global memory/L2 exactly as before.  Same arithmetic (lf_coord,
+// lf_trilinear<true>): bit-identical results.
+constexpr int kTileNbCells = 27;                       // 3 x 3 x 3 cells
+constexpr int kTileNbPieces = kTileNbCells * 6;        // 16-byte pieces
+// LDS pitch of a window cell in 16-byte pieces.  Round 3: 7 (112 bytes), not 6: a ds_read_b128 serves 16 lanes at a time, a
+// 16-byte piece covers 4 of the 64 banks, so piece i of cell n sits on bank group (pitch * n + i) mod 16 -- with pitch 6 the cells n
+// and n + 8 of the 27 (e.g. the x-neighbour and the z-neighbour of the centre cell, dx - 1 against dz - 1) share their banks and
+// lanes of one group that want both serialise (profiles/r2/colorlut_block_counters.txt: SQ_LDS_BANK_CONFLICT 2.6e7 of 9.3e7 LDS
+// cycles per 16-frame launch, the LDS busy 56 % of the launch); with pitch 7 only cells 16 apart collide, which are never neighbours.
+constexpr int kTileCellPitch = 7;
+constexpr int kTileWaveLdsFloat4 = kTileNbCells * kTileCellPitch + 2;  // +32 bytes: de-phases the four waves' regions over the banks
+
+// The lattice coordinate of a channel depends on its byte value only: (cell index, fraction) come from a 3 x 256 entry
+// table in LDS (built on the host with the same f32 steps, ensure_uploaded) instead of 7 VALU instructions per channel --
+// the kernel is VALU-bound once the gathers are gone (rocprofv3: VALUBusy 100 %, profiles/r2/colorlut_tile_counters.txt).
+// (Typed buffer loads for u8/255 and several tiles per wave were tried and measured slower here: -4 % and -7 %.  A 5 x 5 x 5
+// window for big cubes -- a cell of a 65^3 cube spans only 4 code values, natural-like 4K frame 37.7 us against 24.0 us with
+// 33^3 -- costs more than its hits save: 12 KB of cells per tile in twelve wave loads, 48 KB of LDS per workgroup; 65^3
+// natural 54.4 us, flat bars 57 us against 30 us, and 33^3 natural 52 us.)
+
+// The 24 floats of the cell (ix, iy, iz): from the wave's LDS window when the cell lies in it, otherwise this lane's own gather
+// from the cell table in global memory / L2 (six 16-byte loads).  A quad-cooperative form of the gather (the four lanes of a
+// quad fetch one cell with two coalesced loads and hand it over through LDS: 2.8 instead of 6.1 L1 look-ups per pixel) was
+// built and measured: no faster on uniform-random colours -- there the L1's miss path is the floor (a cell is two 64-byte L2
+// requests, ~0.39 requests per clock per CU) -- and slower when only a few pixels of a tile fall outside
+// (profiles/r2/colorlut_random_floor.txt).
+// `nbr_base` is an LDS-address-space pointer on purpose: through a generic pointer the six reads become flat loads (the
+// kernel then runs at 60 % of its speed).
+typedef const __attribute__((address_space(3))) char *lds_bytes_t;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) f32x4_t *lds_float4_t;
+
+__device__ __forceinline__ void tile_cell(lds_bytes_t nbr_base, uint32_t wave_lds_bytes, const LutParams &p, uint32_t ix, uint32_t iy,
+                                          uint32_t iz, uint32_t ax, uint32_t ay, uint32_t az, float4 (&c)[8])
+{
+    const uint32_t dx = ix - ax, dy = iy - ay, dz = iz - az; // unsigned: below the anchor wraps to a huge value
+    float4 c6[6];
+    if (dx < 3u && dy < 3u && dz < 3u) {
+        // 24-bit multiply-adds, the last one spelled out: plain `mine + index * 6` compiles to three quarter-rate v_mad_u64_u32
+        const uint32_t nbi = __umul24(dz, 9u) + __umul24(dy, 3u) + dx;
+        uint32_t off;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(nbi), "s"((uint32_t)(kTileCellPitch * 16)), "v"(wave_lds_bytes));
+        lds_float4_t cell = (lds_float4_t)(nbr_base + off);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const f32x4_t v = cell[i];
+            c6[i] = make_float4(v.x, v.y, v.z, v.w);
+        }
+    } else {
+        const float4 *cell = p.cells + __umul24(__umul24(__umul24(iz, p.size) + iy, p.size) + ix, kCellF4); // < 2^24 (size <= 65)
+#pragma unroll
+        for (int i = 0; i < 6; i++) c6[i] = cell[i];
+    }
+    const float f[24] = {c6[0].x, c6[0].y, c6[0].z, c6[0].w, c6[1].x, c6[1].y, c6[1].z, c6[1].w, c6[2].x, c6[2].y, c6[2].z, c6[2].w,
+                         c6[3].x, c6[3].y, c6[3].z, c6[3].w, c6[4].x, c6[4].y, c6[4].z, c6[4].w, c6[5].x, c6[5].y, c6[5].z, c6[5].w};
+#pragma unroll
+    for (int i = 0; i < 8; i++) c[i] = make_float4(f[3 * i], f[3 * i + 1], f[3 * i + 2], 0.0f);
+}
+
+// The wave's 3 x 3 x 3 window: anchor = the cell (cx, cy, cz) of the wave's centre pixel minus one per axis, shifted to stay
+// inside the table (cell indices run 0 .. size-1; the launchers guarantee size >= 3); three coalesced wave loads into `mine`.
+// (A 4 x 4 x 4 window with the three cell indices packed into one word -- one subtraction, one mask test and one v_dot4 for the
+// LDS offset instead of nine instructions -- was built on top of the 64 x 16 blocks and measured: 33^3 natural-like 61.6 k -> 52.6 k
+// fps, flat bars 24.3 -> 33.6 us per 4K frame, 65^3 unchanged: the three extra wave loads per block and the 6 KB of LDS per wave cost
+// more than the simpler test and the wider window return.  A 2 x 2 x 2 window anchored by the centre pixel's position in its cell
+// (one wave load): flat bars unchanged, natural-like 61.6 k -> 37.2 k fps -- too many pixels fall outside.)
+struct TileRel {
+    uint32_t r0, r1, r2; // offsets of this lane's three pieces of the window relative to the anchor cell (float4 units)
+};
+
+__device__ __forceinline__ TileRel tile_rel(uint32_t lane, const LutParams &p) // issue early: the values are needed after the coordinates
+{
+    return {p.tile_tables[2 * kCoordEntries + lane], p.tile_tables[2 * kCoordEntries + 64 + lane], p.tile_tables[2 * kCoordEntries + 128 + lane]};
+}
+
+__device__ __forceinline__ void tile_load_window(float4 *mine, uint32_t lane, const LutParams &p, const TileRel &rel, uint32_t cx, uint32_t cy,
+                                                 uint32_t cz, uint32_t &ax, uint32_t &ay, uint32_t &az)
+{
+    const uint32_t rel0 = rel.r0, rel1 = rel.r1, rel2 = rel.r2;
+    const uint32_t hi = p.size - 3;
+    ax = min(cx > 0 ? cx - 1 : 0u, hi); ay = min(cy > 0 ? cy - 1 : 0u, hi); az = min(cz > 0 ? cz - 1 : 0u, hi);
+    const uint32_t anchor = (ax + p.size * (ay + p.size * az)) * kCellF4; // float4 units; wave-uniform
+    // piece q = 6 n + i of the window goes to pitch * n + i (lane-constant indices: q / 6 by multiplication, q < 192)
+    auto slot = [](uint32_t q) { const uint32_t n = (q * 171u) >> 10; return n * (uint32_t)kTileCellPitch + (q - n * 6u); };
+    mine[slot(lane)] = p.cells[anchor + rel0];
+    mine[slot(64 + lane)] = p.cells[anchor + rel1];
+    if (lane < (uint32_t)kTileNbPieces - 128u) mine[slot(128 + lane)] = p.cells[anchor + rel2];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// WIDE: RGBA64 (LE: little endian) -- a lane's four pixels are 32 bytes (two 16-byte loads), the lattice coordinates come from
+// lf_coord on the 16-bit values (the byte-indexed LDS table does not exist for 65536 values; same arithmetic as the gather
+// kernel's lf_px16), the output is lf_px16's.  Round 2: 4K natural-like RGBA64 frame 43.4 us with the per-lane gathers.
+// A wave's block: ACROSS lanes x (64 / ACROSS) lanes, every lane ROWS rows of four pixels: 4 ACROSS x (64 / ACROSS) ROWS pixels.
+// <16, 4> = 64 x 16 and <8, 2> = 32 x 16 are built (the launcher explains the choice): the coordinate table and the window are set
+// up once per 1024 / 512 pixels; the first version's 16 x 16 tile (<4, 1>) paid that set-up every 256 pixels and reached 47.0 k fps
+// where 64 x 16 reaches 61.6 k.
+template <bool WIDE, bool LE, int ACROSS, int ROWS>
+__global__ __launch_bounds__(kBlock) void colorlut_tile_kernel(FrameBatch in_fb, FrameBatch out_fb, uint32_t width, uint32_t height,
+                                                               uint32_t in_stride, uint32_t out_stride, LutParams p)
+{
+    constexpr uint32_t kBpp = WIDE ? 8 : 4;
+    // pixels per lane and row: one 16-byte load / store per lane, contiguous over the lanes (RGBA64: two pixels; with four -- two
+    // instructions whose lanes sit 32 bytes apart -- a 4K natural-like RGBA64 frame took 32.4 us instead of 30.0 us)
+    constexpr int PX = WIDE ? 2 : 4;
+    constexpr uint32_t kAcross = ACROSS, kTileW = PX * ACROSS, kDown = 64 / ACROSS, kTileH = kDown * ROWS,
+                       kCentreLane = (kDown / 2) * ACROSS + ACROSS / 2;
+    __shared__ float4 nbr[kBlock / 64][kTileWaveLdsFloat4];
+    __shared__ uint2 coord[WIDE ? 1 : kCoordEntries]; // {cell index, fraction bits} per channel and byte value
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if constexpr (!WIDE) {
+        const uint2 *src = reinterpret_cast<const uint2 *>(p.tile_tables);
+#pragma unroll
+        for (uint32_t i = 0; i < kCoordEntries / kBlock; i++) coord[i * kBlock + threadIdx.x] = src[i * kBlock + threadIdx.x];
+    }
+    // workgroup = four horizontally adjacent tiles (grid x), one tile row per grid y
+    const uint32_t x = (blockIdx.x * (kBlock / 64) + wave) * kTileW + (lane % kAcross) * PX, y0 = blockIdx.y * kTileH + (lane / kAcross) * ROWS;
+    const uint8_t *in = in_fb.base[blockIdx.z];
+    uint8_t *out = out_fb.base[blockIdx.z];
+    const TileRel rel = tile_rel(lane, p);
+    uint32_t ax = 0, ay = 0, az = 0;
+    const uint32_t wave_lds_bytes = wave * (uint32_t)(kTileWaveLdsFloat4 * sizeof(float4));
+#pragma unroll
+    for (int row = 0; row < ROWS; row++) {
+        const uint32_t y = y0 + row;
+        const bool valid = x < width && y < height; // width % 4 == 0 (launcher): a lane's pixels are all inside or all outside
+        uint4 v = make_uint4(0, 0, 0, 0);
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        if (valid) {
+            if constexpr (WIDE) { // streamed once: non-temporal, the cell table keeps the L2 (as in colorlut_xtile_kernel)
+                const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(in + (y * in_stride + x * kBpp)));
+                v = make_uint4(t.x, t.y, t.z, t.w);
+            } else
+                v = *reinterpret_cast<const uint4 *>(in + (y * in_stride + x * kBpp));
+        }
+        if (row == 0) {
+            if constexpr (!WIDE) __syncthreads(); // coordinate table complete
+        }
+        uint32_t px[4] = {v.x, v.y, v.z, v.w};      // RGBA8: the four pixels; RGBA64: low words (r | g << 16) of the two pixels
+        uint32_t px_hi[4] = {0, 0, 0, 0};           // RGBA64: high words (b | a << 16)
+        if constexpr (WIDE) { px[0] = v.x; px_hi[0] = v.y; px[1] = v.z; px_hi[1] = v.w; }
+        uint32_t ix[4], iy[4], iz[4];
+        float fx[4], fy[4], fz[4];
+#pragma unroll
+        for (int j = 0; j < PX; j++) {
+            if constexpr (WIDE) {
+                uint32_t rv = px[j] & 0xffffu, gv = px[j] >> 16, bv = px_hi[j] & 0xffffu;
+                if constexpr (!LE) { rv = bswap16(rv); gv = bswap16(gv); bv = bswap16(bv); }
+                lf_coord((float)rv, p.fast, p.scale[0], p.offset[0], p.size_m1, ix[j], fx[j]);
+                lf_coord((float)gv, p.fast, p.scale[1], p.offset[1], p.size_m1, iy[j], fy[j]);
+                lf_coord((float)bv, p.fast, p.scale[2], p.offset[2], p.size_m1, iz[j], fz[j]);
+            } else {
+                const uint2 er = coord[px[j] & 0xffu], eg = coord[256 + ((px[j] >> 8) & 0xffu)], eb = coord[512 + ((px[j] >> 16) & 0xffu)];
+                ix[j] = er.x; fx[j] = __uint_as_float(er.y);
+                iy[j] = eg.x; fy[j] = __uint_as_float(eg.y);
+                iz[j] = eb.x; fz[j] = __uint_as_float(eb.y);
+            }
+        }
+        if (row == 0) {
+            // anchor: the cell of the block's centre pixel (64 x 16: lane 40 = rows 8..11, columns 32..35, its first row)
+            // (a block that sticks out of the frame on the right or at the bottom may have its centre outside: lane 0 then)
+            const uint32_t centre = __builtin_amdgcn_readlane((int)valid, kCentreLane) ? kCentreLane : 0u;
+            const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)ix[0], centre),
+                           cy = (uint32_t)__builtin_amdgcn_readlane((int)iy[0], centre),
+                           cz = (uint32_t)__builtin_amdgcn_readlane((int)iz[0], centre);
+            tile_load_window(nbr[wave], lane, p, rel, cx, cy, cz, ax, ay, az);
+        }
+#pragma unroll
+        for (int j = 0; j < PX; j++) {
+            float4 c[8];
+            tile_cell((lds_bytes_t)&nbr[0][0], wave_lds_bytes, p, ix[j], iy[j], iz[j], ax, ay, az, c);
+            float r, g, b;
+            lf_trilinear<true>(c, fx[j], fy[j], fz[j], r, g, b);
+            // RGBA64: float_to_u16 as one fused multiply-add, trunc(fma(v, 65535, 0.5)) == round(v * 65535) for every float v in [0, 1]
+            // (tools/prove_exact.c P15; with pred(0.5) two floats fail for 65535, with 0.5 none); RGBA8 keeps mul + add (P10) here --
+            // this kernel is the round-2 reference of the A/B runs
+            const float yr = WIDE ? __builtin_fmaf(r, p.fast.out_scale, 0.5f) : r * p.fast.out_scale + p.fast.pred_half,
+                        yg = WIDE ? __builtin_fmaf(g, p.fast.out_scale, 0.5f) : g * p.fast.out_scale + p.fast.pred_half,
+                        yb = WIDE ? __builtin_fmaf(b, p.fast.out_scale, 0.5f) : b * p.fast.out_scale + p.fast.pred_half;
+            if constexpr (WIDE) {
+                uint32_t ro = (uint32_t)__float2uint_rz(yr), go = (uint32_t)__float2uint_rz(yg), bo = (uint32_t)__float2uint_rz(yb);
+                if constexpr (!LE) { ro = bswap16(ro); go = bswap16(go); bo = bswap16(bo); }
+                px[j] = ro | (go << 16);
+                px_hi[j] = bo | (px_hi[j] & 0xffff0000u);
+            } else {
+                uint32_t w = px[j];
+                asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yr));
+                asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yg));
+                asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
+                px[j] = w;
+            }
+        }
+        if (valid) {
+            if constexpr (WIDE) {
+                const u32x4_t t = {px[0], px_hi[0], px[1], px_hi[1]};
+                __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t *>(out + (y * out_stride + x * kBpp)));
+            } else {
+                *reinterpret_cast<uint4 *>(out + (y * out_stride + x * 4)) = make_uint4(px[0], px[1], px[2], px[3]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- the x-prelerped tile kernel (round 3)
+//
+// An RGBA8 pixel's r byte fixes (x0, tx), so the four x-lerps of sample_3d (imp.rs:515-518) depend on (r byte, y node, z node) only:
+//   X[y][z][r] = c(x0,y,z) + (c(x1,y,z) - c(x0,y,z)) * tx          (the reference's own three roundings, done once per LUT)
+// and the difference the y-lerp subtracts, D[y][z][r] = RN(X[min(y+1,max)][z][r] - X[y][z][r]), is fixed with it.  Per pixel that
+// leaves  c0 = X[y0][z0][r] + D[y0][z0][r] * ty,  c1 = X[y0][z1][r] + D[y0][z1][r] * ty,  out = c0 + (c1 - c0) * tz -- 21 f32
+// operations instead of 51, two 24-byte LDS reads instead of six 16-byte ones, same bits (every operation that remains is one the
+// reference performs, on the same operands).  Table: [y][z][r] with z running to size inclusive -- row `size` repeats row size - 1,
+// which is what z1 = min(z0 + 1, max) selects there, so the second entry is ALWAYS the next z row -- 256 x size x (size + 1) entries
+// of 24 bytes (33^3: 6.9 MB), built on the device by colorlut_xtable_build_kernel from the node layout and the r channel's
+// coordinate table.
+// A wave owns a 64 x 20 block of pixels and keeps in wave-private LDS the entries of RW consecutive r bytes x 3 y cells x 4 z rows
+// around a mean colour of the block (18 r bytes since round 5: kXRW): 12 rows of RW x 24 contiguous bytes; pixels outside the window read
+// their two entries from the table in global memory.  The per-byte coordinate entries of g and b hold the cell index already
+// multiplied by the window's LDS pitch of that axis, so the in-window test and the LDS address are three subtractions, three
+// compares, one add3 and one mad.
+// (bytes of padding between the y slabs -- a slab is 4 x 432 = 1 728 bytes -- were tried against the bank conflicts of noisy blocks and cost a
+// workgroup per CU: profiles/r4, profiles/r5/colorlut_experiments.txt)
+// (kXNY = 3 y cells, kXNZ = 3 z cells, kXNZR = 4 z rows -- a pixel reads rows z0 and z0 + 1 -- of a window: colorlut_device.hpp)
+// LDS of a wave's window.  The workgroup's total (4 windows + the 4 KB coordinate table) must stay within 32000 bytes: LDS is handed out
+// in granules of 1280 bytes and five workgroups per CU need 5 x 25 granules = 160000 <= 163840; one granule more per workgroup costs a
+// workgroup per CU (measured: -6 % on every content).  5 184 + 32 spare bytes (the spare de-phases the four waves' windows over the banks).
+constexpr uint32_t kXWaveBytes = kXNY * kXPitchY + 32;
+static_assert(4 * kXWaveBytes + 4096 <= 32000, "at least five workgroups per CU (six with the shipped 18 r bytes: 24 960 bytes)");
+// the window's first cell along an axis of NCELLS cells for an anchor at lattice coordinate `c` (cell + fraction): the anchor's cell in
+// the middle (odd), or -- even -- the half of its cell the anchor lies in decides which side gets the extra cell
+template <uint32_t NCELLS>
+__device__ __forceinline__ uint32_t xtile_first_cell(float c, uint32_t size)
+{
+    const uint32_t cell = min((uint32_t)c, size - 1);
+    const uint32_t below = (NCELLS & 1u) ? (NCELLS - 1u) / 2u : NCELLS / 2u - ((c - (float)cell) >= 0.5f ? 1u : 0u);
+    return min(cell > below ? cell - below : 0u, size - NCELLS);
+}
+
+// The wave's window: 3 y slabs x 4 z rows x RW entries of the x table, global -> LDS directly (global_load_lds_dwordx4: LDS address =
+// wave-uniform base + lane x 16, which is the window's piece order inside a slab): no staging registers, no ds_write pass.
+// `base` = the table piece of (ay, az, ar), wave-uniform.
+__device__ __forceinline__ void xtile_fill_window(const float4 *xtable, uint32_t base, uint32_t size, uint8_t *lds_region, uint32_t lane)
+{
+    typedef __attribute__((address_space(3))) void *lds_void_t;
+    typedef const __attribute__((address_space(1))) void *global_void_t;
+    constexpr uint32_t kRowP = kXRW * 3 / 2, kPieces = kXNY * kXNZR * kRowP;
+#pragma unroll
+    for (uint32_t q0 = 0; q0 < kPieces; q0 += 64) {
+        const uint32_t q = q0 + lane;
+        if (q0 + 64 <= kPieces || q < kPieces) {
+            const uint32_t wr = q / kRowP, k = q - wr * kRowP; // window row = dy * (NZ + 1) + dz
+            __builtin_amdgcn_global_load_lds((global_void_t)(xtable + (base + ((wr / kXNZR) * (size + 1) + (wr % kXNZR)) * kXRowPieces + k)),
+                                             (lds_void_t)(lds_region + q0 * 16), 16, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void colorlut_xtable_build_kernel(const float4 *__restrict__ cube, const uint32_t *__restrict__ tile_tables,
+                                                                    uint32_t size, float *__restrict__ xtable)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x; // = (y * (size + 1) + zrow) * 256 + r
+    if (i >= size * (size + 1) * 256u) return;
+    const uint32_t r = i & 255u, yz = i >> 8, zrow = yz % (size + 1), y = yz / (size + 1), m = size - 1, s2 = size * size;
+    const uint32_t z = min(zrow, m);
+    const uint32_t x0 = tile_tables[2 * r], x1 = min(x0 + 1, m), y1 = min(y + 1, m);
+    const float tx = __uint_as_float(tile_tables[2 * r + 1]);
+    const float4 a0 = cube[x0 + y * size + z * s2], b0 = cube[x1 + y * size + z * s2];
+    const float4 a1 = cube[x0 + y1 * size + z * s2], b1 = cube[x1 + y1 * size + z * s2];
+    const float X0[3] = {lf_lerp(a0.x, b0.x, tx), lf_lerp(a0.y, b0.y, tx), lf_lerp(a0.z, b0.z, tx)};
+    const float X1[3] = {lf_lerp(a1.x, b1.x, tx), lf_lerp(a1.y, b1.y, tx), lf_lerp(a1.z, b1.z, tx)};
+    float *e = xtable + (uint64_t)i * 6;
+    e[0] = X0[0]; e[1] = X0[1]; e[2] = X0[2];
+    e[3] = X1[0] - X0[0]; e[4] = X1[1] - X0[1]; e[5] = X1[2] - X0[2];
+}
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// volatile: the six 8-byte reads of a pixel stay six ds_read_b64.  Left alone the compiler pairs them into three ds_read2_b64, which the
+// LDS serves at HALF the rate (8 array cycles for 16 bytes per lane, 16-lane groups on 32 banks, against 2 x 2 cycles, 32-lane groups on
+// 64 banks: MI355X_MICROARCH.md, LDS table)
+typedef const volatile __attribute__((address_space(3))) f32x2_t *lds_float2_t;
+
+// The window's anchor is a mean colour of the block, formed out of the pixel registers (no load of its own): every lane offers its pixel (x + 1, y0 + 1),
+// a 16 x 4 lattice over the block.  Where the four lanes around the centre agree within kXSpreadLow (sum of absolute byte differences along both
+// diagonals) their mean is the anchor; elsewhere the mean of all sixty-four, unless the corner samples differ by more than kXSpread64 along both diagonals
+// (an edge: the mean fits neither side, the lane next to the centre stands).  Anchors tried before this one (the centre pixel; four samples by scalar
+// loads; by one vector load): profiles/r3/colorlut_anchor4.txt, profiles/r4/colorlut_anchor.txt.
+constexpr uint32_t kXSampleRow = 1, kXSpreadLow = 20, kXSpread64 = 120;
+// |g - centre g| + |b - centre b| above which an outside pixel counts as far (colorlut_xwg_kernel's test for blocks of uniform-random colours)
+constexpr uint32_t kXFar = 64;
+// Pixel loads and stores are non-temporal (16 x 4K natural-like 70.7 k -> 73.1 k fps, one frame 21.8 -> 19.1 us: the pixels stream through once,
+// the table stays in L2).
+__global__ __launch_bounds__(kBlock) void colorlut_xtile_kernel(FrameBatch in_fb, FrameBatch out_fb, uint32_t width, uint32_t height,
+                                                                uint32_t in_stride, uint32_t out_stride, LutParams p)
+{
+    constexpr uint32_t RW = kXRW;
+    static_assert(RW % 2 == 0 && RW <= 64, "window rows start and end on 16-byte pieces");
+    constexpr uint32_t kAcross = 16, kRows = kXRows, kTileW = 64, kTileH = 4 * kRows;
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    constexpr uint32_t kWaveBytes = kXWaveBytes;
+    __shared__ __attribute__((aligned(16))) uint8_t win[(kBlock / 64) * kWaveBytes];
+    __shared__ uint2 coord[512]; // {cell index x LDS pitch, fraction bits} per byte value of the g and b channels
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (giving every XCD a contiguous run of the workgroup order -- whole frames of a batch, a band of a single frame -- so that its L2
+    // holds a smaller part of the table: 71.6 k vs 72.3 k fps, one frame 20.8 vs 19.1 us; with non-temporal pixel accesses the table
+    // misses are 8 % of the pixel bytes already, FETCH_SIZE 572 MB vs 540 MB per 16 frames)
+    const uint32_t gx = blockIdx.x, gy = blockIdx.y, gz = blockIdx.z;
+    const uint8_t *in = in_fb.base[gz];
+    uint8_t *out = out_fb.base[gz];
+    const uint32_t bx = (gx * (kBlock / 64) + wave) * kTileW, by = gy * kTileH; // the wave's block
+    const uint32_t x = bx + (lane % kAcross) * 4, y0 = by + (lane / kAcross) * kRows;
+    const bool whole_block = bx + kTileW <= width && by + kTileH <= height;
+    // 1. every pixel of the lane, up front (four 16-byte loads in flight while the window is being fetched)
+    uint32_t voff_in = y0 * in_stride + x * 4, voff_out = y0 * out_stride + x * 4; // the lane's byte offsets into rows y0 .. of the frames
+    asm volatile("" : "+v"(voff_in), "+v"(voff_out)); // both formed HERE (left alone the compiler re-forms the second one late from a 64-bit x * 4 that it spills)
+    uint4 v[kRows];
+#pragma unroll
+    for (uint32_t row = 0; row < kRows; row++) {
+        v[row] = make_uint4(0, 0, 0, 0);
+        if (x < width && y0 + row < height) {
+            const u32x4_t *src = reinterpret_cast<const u32x4_t *>(in + (size_t)row * in_stride + voff_in); // uniform row base + one 32-bit lane offset
+            const u32x4_t t = __builtin_nontemporal_load(src);
+            v[row] = make_uint4(t.x, t.y, t.z, t.w);
+        }
+    }
+    // 2. the window, anchored at the block's centre pixel (its top-left pixel when the centre lies outside the frame): the pixel and
+    // its two coordinate entries come through the scalar cache, so this chain does not wait for the vector loads above
+    uint32_t ar, ayp, azp; // anchor: first r byte, y cell x kXPitchY, z row x kXPitchZ
+    {
+        // (a wave of the last workgroup of a row may lie wholly right of the frame: it reads pixel (0, 0) and stores nothing)
+        const uint32_t cxp = bx + kTileW / 2 < width ? bx + kTileW / 2 : bx, cyp = by + kTileH / 2 < height ? by + kTileH / 2 : by;
+        const uint32_t coff = (uint32_t)__builtin_amdgcn_readfirstlane((int)(bx < width ? cyp * in_stride + cxp * 4 : 0u));
+        uint32_t cpx = *reinterpret_cast<const uint32_t *>(in + coff);
+        // Samples that cost no memory access at all: every lane's own pixel (x + 1, y0 + 1), out of the registers the pixel loads above
+        // fill -- a 16 x 4 lattice over the block.  (A separate sample load fetches lines of its own: with sixteen lanes taking part in it
+        // the clean frames lost 4-5 %, profiles/r4/colorlut_anchor.txt.)  The window fill waits for the second row's pixel load.  Where four
+        // lanes around the block's centre agree closely (clean content) their mean is the anchor; elsewhere (noise, texture) the mean of all
+        // sixty-four -- eight dependent DPP additions on the path the window fill waits for, which clean blocks do not pay.
+        if (__builtin_amdgcn_readfirstlane((int)whole_block)) {
+            const uint32_t mine = v[kXSampleRow].y;
+            const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 21) & 0xffffffu, i1 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 26) & 0xffffffu,
+                           i2 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 37) & 0xffffffu, i3 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 42) & 0xffffffu;
+            const uint32_t inner = __builtin_amdgcn_sad_u8(i0, i3, 0u) + __builtin_amdgcn_sad_u8(i1, i2, 0u);
+            if (inner <= kXSpreadLow) {
+                const uint32_t ev4 = (i0 & 0x00ff00ffu) + (i1 & 0x00ff00ffu) + (i2 & 0x00ff00ffu) + (i3 & 0x00ff00ffu) + 0x00020002u;
+                const uint32_t od4 = ((i0 >> 8) & 0x00ff00ffu) + ((i1 >> 8) & 0x00ff00ffu) + ((i2 >> 8) & 0x00ff00ffu) + ((i3 >> 8) & 0x00ff00ffu) + 0x00020002u;
+                cpx = ((ev4 >> 2) & 0x00ff00ffu) | (((od4 >> 2) & 0x000000ffu) << 8);
+            } else {
+            uint32_t ev = mine & 0x00ff00ffu, od = (mine >> 8) & 0x00ff00ffu;
+#define MVFX_ROW_ADD(v_, ctrl) v_ += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v_, ctrl, 0xf, 0xf, true)
+            MVFX_ROW_ADD(ev, 0x111); MVFX_ROW_ADD(od, 0x111);
+            MVFX_ROW_ADD(ev, 0x112); MVFX_ROW_ADD(od, 0x112);
+            MVFX_ROW_ADD(ev, 0x114); MVFX_ROW_ADD(od, 0x114);
+            MVFX_ROW_ADD(ev, 0x118); MVFX_ROW_ADD(od, 0x118);
+#undef MVFX_ROW_ADD
+            // lanes 15, 31, 47, 63 hold their row's sums (16 x 255 fits twelve bits; the four rows together fourteen)
+            const uint32_t sev = (uint32_t)__builtin_amdgcn_readlane((int)ev, 15) + (uint32_t)__builtin_amdgcn_readlane((int)ev, 31) +
+                                 (uint32_t)__builtin_amdgcn_readlane((int)ev, 47) + (uint32_t)__builtin_amdgcn_readlane((int)ev, 63) + 0x00200020u;
+            const uint32_t sod = (uint32_t)__builtin_amdgcn_readlane((int)od, 15) + (uint32_t)__builtin_amdgcn_readlane((int)od, 31) +
+                                 (uint32_t)__builtin_amdgcn_readlane((int)od, 47) + (uint32_t)__builtin_amdgcn_readlane((int)od, 63) + 0x00200020u;
+            const uint32_t mean = ((sev >> 6) & 0x00ff00ffu) | (((sod >> 6) & 0x000000ffu) << 8);
+            const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 0) & 0xffffffu, q1 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 15) & 0xffffffu,
+                           q2 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 48) & 0xffffffu, q3 = (uint32_t)__builtin_amdgcn_readlane((int)mine, 63) & 0xffffffu;
+            const uint32_t spread = __builtin_amdgcn_sad_u8(q0, q3, 0u) + __builtin_amdgcn_sad_u8(q1, q2, 0u);
+            // across an edge the mean fits neither side: the lane next to the block's centre stands
+            cpx = spread <= kXSpread64 ? mean : ((uint32_t)__builtin_amdgcn_readlane((int)mine, 40) & 0xffffffu);
+            }
+        }
+        cpx = (uint32_t)__builtin_amdgcn_readfirstlane((int)cpx);
+        const uint32_t cr = cpx & 0xffu;
+        // Where the window goes decides how many pixels find their entries in it, never what they compute: the anchor's lattice
+        // coordinates may be formed any way.  The two table look-ups of rounds 3 and 4 were scalar loads whose address depends on the
+        // pixels -- one more memory round trip on the chain pixel loads -> anchor -> window fill that every wave walks before its first
+        // row; the same lattice arithmetic in a handful of VALU operations on the (uniform) anchor colour: +0.7 % calm, +3 % at +-8.
+        const float gy = (float)((cpx >> 8) & 0xffu) * (1.0f / 255.0f), bz = (float)((cpx >> 16) & 0xffu) * (1.0f / 255.0f);
+        const float ny = fminf(fmaxf(gy * p.scale[1] + p.offset[1], 0.0f), 1.0f) * p.size_m1, nz = fminf(fmaxf(bz * p.scale[2] + p.offset[2], 0.0f), 1.0f) * p.size_m1;
+        ar = min((cr > RW / 2 ? cr - RW / 2 : 0u) & ~1u, 256u - RW); // even: a window row starts on a 16-byte piece
+        const uint32_t ay = (uint32_t)__builtin_amdgcn_readfirstlane((int)xtile_first_cell<kXNY>(ny, p.size)),
+                       az = (uint32_t)__builtin_amdgcn_readfirstlane((int)xtile_first_cell<kXNZ>(nz, p.size)); // z rows run 0 .. size
+        ayp = ay * kXPitchY;
+        azp = az * kXPitchZ;
+        const uint32_t base = (ay * (p.size + 1) + az) * kXRowPieces + ar * 3 / 2; // wave-uniform
+        xtile_fill_window(p.xtable, base, p.size, win + wave * kWaveBytes, lane);
+    }
+    coord[threadIdx.x] = p.xcoord[threadIdx.x];
+    coord[kBlock + threadIdx.x] = p.xcoord[kBlock + threadIdx.x];
+    __syncthreads(); // coordinate table and (a fortiori) this wave's window complete
+    // LDS byte address of entry (y cell, z row, r) = yp + zp + 24 r + lds_k, with the anchor folded into the wave-uniform lds_k
+    const uint32_t lds_k = wave * kWaveBytes - ayp - azp - ar * 24u, ar24 = ar * 24u, wave_lds = wave * kWaveBytes;
+    // One row of four pixels per lane: their entries from the window; a pixel outside it reads the window's first entry and is patched
+    // in ONE branch per row (the scalar side of an if / else costs about five instructions) with its two entries of the x table from
+    // global memory.
+    // A row of four pixels goes in two passes of two (round 5: 56-60 VGPRs instead of the 94 of four-pixel passes, which with the 18-byte
+    // window puts six workgroups on a CU).  No "far" test here (a block of uniform-random colours, see colorlut_xwg_kernel): pictures like
+    // that are the other kernel's -- the content probe decides --, a stray block is served pixel by pixel.
+    // (Built and measured in round 4, bit-exact, not shipped: listing the outside pixels per wave (ballot + mbcnt) in the LDS of the dead
+    // window and serving them densely from a second 6 x 6 x 6 node window: +8 % at +-8 codes of noise, +7 % at +-16, -3 % at +-5, -7 % on
+    // flat bars, and 98 VGPRs -- a wave per SIMD less for every block; profiles/r4/colorlut_dense_pass.txt.)
+    auto do_row = [&](const uint32_t row) {
+        const bool valid = x < width && y0 + row < height;
+        uint32_t px[4] = {v[row].x, v[row].y, v[row].z, v[row].w};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            f32x2_t e0[2][3], e1[2][3];
+            float ty[2], tz[2];
+            bool miss[2];
+            bool any_miss = false;
+            // the four coordinate reads of a pass before its entry reads (two LDS round trips per pass instead of three: +1 % on calm frames;
+            // with four-pixel passes the same idea cost a wave per SIMD and 6 %)
+            uint2 egs[2], ebs[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                egs[jj] = coord[(px[2 * h + jj] >> 8) & 0xffu];
+                ebs[jj] = coord[256 + ((px[2 * h + jj] >> 16) & 0xffu)];
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) asm volatile("" : "+v"(egs[jj]), "+v"(ebs[jj]));
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const uint32_t pxj = px[2 * h + jj];
+                const uint2 eg = egs[jj], eb = ebs[jj];
+                ty[jj] = __uint_as_float(eg.y);
+                tz[jj] = __uint_as_float(eb.y);
+                uint32_t r24;
+                asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r24) : "v"(pxj), "v"(24u));
+                const uint32_t dr24 = r24 - ar24, dyp = eg.x - ayp, dzp = eb.x - azp;
+                miss[jj] = (dr24 >= (uint32_t)RW * 24u) | (dyp >= kXNY * kXPitchY) | (dzp >= kXNZ * kXPitchZ);
+                any_miss = any_miss | miss[jj];
+                const uint32_t off = miss[jj] ? wave_lds : eg.x + eb.x + (r24 + lds_k);
+                const lds_float2_t q0 = (lds_float2_t)((lds_bytes_t)&win[0] + off), q1 = (lds_float2_t)((lds_bytes_t)&win[0] + off + kXPitchZ);
+                e0[jj][0] = q0[0]; e0[jj][1] = q0[1]; e0[jj][2] = q0[2];
+                e1[jj][0] = q1[0]; e1[jj][1] = q1[1]; e1[jj][2] = q1[2];
+            }
+            if (any_miss) {
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    if (miss[jj]) {
+                        const uint32_t pxj = px[2 * h + jj];
+                        const uint32_t iy = coord[(pxj >> 8) & 0xffu].x / kXPitchY, iz = coord[256 + ((pxj >> 16) & 0xffu)].x / kXPitchZ, r = pxj & 0xffu;
+                        const f32x2_t *g0p = reinterpret_cast<const f32x2_t *>(p.xtable) + (uint64_t)((iy * (p.size + 1) + iz) * 256u + r) * 3, *g1p = g0p + 256 * 3;
+                        e0[jj][0] = g0p[0]; e0[jj][1] = g0p[1]; e0[jj][2] = g0p[2];
+                        e1[jj][0] = g1p[0]; e1[jj][1] = g1p[1]; e1[jj][2] = g1p[2];
+                    }
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const float c0r = e0[jj][0].x + e0[jj][1].y * ty[jj], c0g = e0[jj][0].y + e0[jj][2].x * ty[jj], c0b = e0[jj][1].x + e0[jj][2].y * ty[jj];
+                const float c1r = e1[jj][0].x + e1[jj][1].y * ty[jj], c1g = e1[jj][0].y + e1[jj][2].x * ty[jj], c1b = e1[jj][1].x + e1[jj][2].y * ty[jj];
+                const float rr = lf_add_clamp(c0r, (c1r - c0r) * tz[jj]), gg = lf_add_clamp(c0g, (c1g - c0g) * tz[jj]),
+                            bb = lf_add_clamp(c0b, (c1b - c0b) * tz[jj]);
+                const float yr = __builtin_fmaf(rr, p.fast.out_scale, p.fast.pred_half), yg = __builtin_fmaf(gg, p.fast.out_scale, p.fast.pred_half),
+                            yb = __builtin_fmaf(bb, p.fast.out_scale, p.fast.pred_half);
+                uint32_t w = px[2 * h + jj];
+                asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yr));
+                asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yg));
+                asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
+                px[2 * h + jj] = w;
+            }
+            __builtin_amdgcn_sched_barrier(0); // the two halves stay two passes
+        }
+        if (valid) {
+            u32x4_t *dst = reinterpret_cast<u32x4_t *>(out + (size_t)row * out_stride + voff_out);
+            const u32x4_t t = {px[0], px[1], px[2], px[3]};
+            __builtin_nontemporal_store(t, dst);
+        }
+    };
+#pragma unroll
+    for (uint32_t row = 0; row < kRows; row++) do_row(row);
+}
+
+// ---------------------------------------------------------------- the workgroup-window kernel (round 5)
+//
+// What round 4's per-wave windows cost, measured by leaving parts of colorlut_xtile_kernel out (profiles/r5/colorlut_experiments.txt, 16 x 4K
+// natural-like frames per launch): with the pixels outside the window simply left wrong the kernel runs 72-75 k fps at EVERY noise level --
+// the miss service is the whole price of noisy content (+-8 codes: 2.1-2.9 % of the pixels outside a window of 24 r bytes x 3 x 3 cells, but
+// 55 % of a wave's (row, j) passes have one; +-16: 61 %), the LDS conflicts of scattered colours cost 10 %.  Serving the misses later, in
+// one dense pass per wave (two round trips instead of eleven), bought +5 % at +-8 and nothing at +-16; four blocks per wave with the next
+// block's pixels prefetched and the window kept where the anchor stays put bought nothing either (the patch of both: profiles/r5/).  A
+// bigger window per wave costs occupancy faster than it saves misses (24 x 4 x 4: 63 k fps on clean frames against 77 k).
+// The four waves of a workgroup keep four near-identical windows.  Here they keep ONE: the workgroup owns a 128 x 40 block of pixels (2 x 2
+// waves of 64 x 20), the window is 38 r bytes x 5 y cells x 5 z cells (6 z rows) = 27 360 bytes -- the LDS of four 24 x 3 x 3 windows --
+// anchored at the mean of the four waves' means.  CPU model of the hit rate on the bench's frames (tools/sim/colorlut_shared_sim.py):
+// outside pixels at +-8 codes of noise 2.1 % -> 0.0 %, at +-16 codes 61 % -> 4 %.  Same entries, same arithmetic as colorlut_xtile_kernel:
+// same bits.  The rare outside pixel is served in its row pass from the x table in global memory, as in rounds 3 and 4.
+static_assert(kWgRW % 2 == 0, "window rows start and end on 16-byte pieces");
+static_assert(kWgWinBytes + 4096 + 16 <= 32000, "five workgroups per CU (LDS comes in granules of 1280 bytes: 25 per workgroup)");
+
+__global__ __launch_bounds__(kBlock) void colorlut_xwg_kernel(FrameBatch in_fb, FrameBatch out_fb, uint32_t width, uint32_t height, uint32_t in_stride,
+                                                             uint32_t out_stride, LutParams p)
+{
+    constexpr uint32_t kAcross = 16, kRows = kXRows, kTileW = 64, kTileH = 4 * kRows, RW = kWgRW;
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) uint8_t win[kWgWinBytes];
+    __shared__ uint2 coord[512]; // {cell index x LDS pitch, fraction bits} per byte value of the g and b channels (this kernel's pitches)
+    __shared__ uint32_t wave_anchor[4];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t gx = blockIdx.x, gy = blockIdx.y, gz = blockIdx.z;
+    const uint8_t *in = in_fb.base[gz];
+    uint8_t *out = out_fb.base[gz];
+    const uint32_t bx = (gx * 2 + (wave & 1u)) * kTileW, by = (gy * 2 + (wave >> 1)) * kTileH; // the wave's block
+    const uint32_t x = bx + (lane % kAcross) * 4, y0 = by + (lane / kAcross) * kRows;
+    // 1. every pixel of the lane, up front
+    uint32_t voff_in = y0 * in_stride + x * 4, voff_out = y0 * out_stride + x * 4; // the lane's byte offsets into rows y0 .. of the frames
+    asm volatile("" : "+v"(voff_in), "+v"(voff_out)); // both formed HERE (colorlut_xtile_kernel)
+    uint4 v[kRows];
+#pragma unroll
+    for (uint32_t row = 0; row < kRows; row++) {
+        v[row] = make_uint4(0, 0, 0, 0);
+        if (x < width && y0 + row < height) {
+            const u32x4_t *src = reinterpret_cast<const u32x4_t *>(in + (size_t)row * in_stride + voff_in);
+            const u32x4_t t = __builtin_nontemporal_load(src);
+            v[row] = make_uint4(t.x, t.y, t.z, t.w);
+        }
+    }
+    coord[threadIdx.x] = p.xcoord_wg[threadIdx.x];
+    coord[kBlock + threadIdx.x] = p.xcoord_wg[kBlock + threadIdx.x];
+    // 2. the wave's mean colour out of its pixel registers: every lane's own pixel (x + 1, y0 + 1), a 16 x 4 lattice over the block, summed
+    // by DPP row additions (colorlut_xtile_kernel, anchor 7).  A block that sticks out of the frame offers its top-left pixel; one that lies
+    // wholly outside offers nothing.  Bit 31 says "offered".
+    uint32_t mine_mean = 0;
+    if (bx + kTileW <= width && by + kTileH <= height) { // wave-uniform
+        const uint32_t mine = v[kXSampleRow].y;
+        uint32_t ev = mine & 0x00ff00ffu, od = (mine >> 8) & 0x00ff00ffu;
+#define MVFX_ROW_ADD(v_, ctrl) v_ += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v_, ctrl, 0xf, 0xf, true)
+        MVFX_ROW_ADD(ev, 0x111); MVFX_ROW_ADD(od, 0x111);
+        MVFX_ROW_ADD(ev, 0x112); MVFX_ROW_ADD(od, 0x112);
+        MVFX_ROW_ADD(ev, 0x114); MVFX_ROW_ADD(od, 0x114);
+        MVFX_ROW_ADD(ev, 0x118); MVFX_ROW_ADD(od, 0x118);
+#undef MVFX_ROW_ADD
+        const uint32_t sev = (uint32_t)__builtin_amdgcn_readlane((int)ev, 15) + (uint32_t)__builtin_amdgcn_readlane((int)ev, 31) +
+                             (uint32_t)__builtin_amdgcn_readlane((int)ev, 47) + (uint32_t)__builtin_amdgcn_readlane((int)ev, 63) + 0x00200020u;
+        const uint32_t sod = (uint32_t)__builtin_amdgcn_readlane((int)od, 15) + (uint32_t)__builtin_amdgcn_readlane((int)od, 31) +
+                             (uint32_t)__builtin_amdgcn_readlane((int)od, 47) + (uint32_t)__builtin_amdgcn_readlane((int)od, 63) + 0x00200020u;
+        mine_mean = ((sev >> 6) & 0x00ff00ffu) | (((sod >> 6) & 0x000000ffu) << 8) | 0x80000000u;
+    } else if (bx < width && by < height) {
+        mine_mean = ((uint32_t)__builtin_amdgcn_readlane((int)v[0].x, 0) & 0xffffffu) | 0x80000000u;
+    }
+    if (lane == 0) wave_anchor[wave] = mine_mean;
+    __syncthreads(); // the coordinate table and the four means
+    // 3. the workgroup's window, anchored at the mean of the means on offer (1, 2 or 4 of them: waves drop out by column or by row)
+    uint32_t ar, ayp, azp, ccpx;
+    {
+        uint32_t sev = 0, sod = 0, n = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_anchor[k]);
+            if (a >> 31) {
+                sev += a & 0x00ff00ffu;
+                sod += (a >> 8) & 0x000000ffu;
+                n++;
+            }
+        }
+        const uint32_t sh = n == 4 ? 2u : n == 2 ? 1u : 0u, half = (1u << sh) >> 1; // (n == 3 cannot happen on a 2 x 2 grid; it would keep the sum of... guarded below)
+        uint32_t cpx = (((sev + half * 0x00010001u) >> sh) & 0x00ff00ffu) | ((((sod + half) >> sh) & 0xffu) << 8);
+        if (n == 3 || n == 0) cpx = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_anchor[0]) & 0xffffffu;
+        ccpx = cpx;
+        const uint32_t cr = cpx & 0xffu;
+        // the anchor's lattice coordinates by arithmetic, not by two dependent scalar loads (colorlut_xtile_kernel)
+        const float gy = (float)((cpx >> 8) & 0xffu) * (1.0f / 255.0f), bz = (float)((cpx >> 16) & 0xffu) * (1.0f / 255.0f);
+        const float ny = fminf(fmaxf(gy * p.scale[1] + p.offset[1], 0.0f), 1.0f) * p.size_m1, nz = fminf(fmaxf(bz * p.scale[2] + p.offset[2], 0.0f), 1.0f) * p.size_m1;
+        ar = min((cr > RW / 2 ? cr - RW / 2 : 0u) & ~1u, 256u - RW); // even: a window row starts on a 16-byte piece
+        const uint32_t ay = (uint32_t)__builtin_amdgcn_readfirstlane((int)xtile_first_cell<kWgNY>(ny, p.size)),
+                       az = (uint32_t)__builtin_amdgcn_readfirstlane((int)xtile_first_cell<kWgNZ>(nz, p.size)); // z rows run 0 .. size
+        ayp = ay * kWgPitchY;
+        azp = az * kWgPitchZ;
+        // NY x NZR rows of RW entries of the x table, global -> LDS directly, 16-byte pieces (xtile_fill_window; here all four waves fill)
+        typedef __attribute__((address_space(3))) void *lds_void_t;
+        typedef const __attribute__((address_space(1))) void *global_void_t;
+        constexpr uint32_t kRowP = RW * 3 / 2, kPieces = kWgNY * kWgNZR * kRowP;
+        const uint32_t base = (ay * (p.size + 1) + az) * kXRowPieces + ar * 3 / 2; // workgroup-uniform
+#pragma unroll
+        for (uint32_t q0 = 0; q0 < kPieces; q0 += kBlock) {
+            const uint32_t q = q0 + threadIdx.x;
+            if (q0 + kBlock <= kPieces || q < kPieces) {
+                const uint32_t wr = q / kRowP, k = q - wr * kRowP; // window row = dy * NZR + dz
+                __builtin_amdgcn_global_load_lds((global_void_t)(p.xtable + (base + ((wr / kWgNZR) * (p.size + 1) + (wr % kWgNZR)) * kXRowPieces + k)),
+                                                 (lds_void_t)(win + (q0 + wave * 64u) * 16u), 16, 0, 0);
+            }
+        }
+    }
+    __syncthreads(); // the window
+    const uint32_t lds_k = 0u - ayp - azp - ar * 24u, ar24 = ar * 24u;
+    // 4. the rows (colorlut_xtile_kernel's row pass; the outside pixel is patched from the x table in global memory in ONE branch per row)
+    // (all four pixels of a row in one pass: two passes of two, colorlut_xtile_kernel's form, save registers this kernel's occupancy -- bound by
+    // its 27 KB window -- cannot use)
+    auto do_row = [&](const uint32_t row) -> bool { // true: row 0 found the block "far" (uniform-random colours) -- nothing served, nothing stored
+        const bool valid = x < width && y0 + row < height; // width % 4 == 0 (launcher)
+        uint32_t px[4] = {v[row].x, v[row].y, v[row].z, v[row].w};
+        f32x2_t e0[4][3], e1[4][3];
+        float ty[4], tz[4];
+        bool miss[4];
+        bool any_miss = false;
+        uint32_t outside = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t pxj = px[j];
+            const uint2 eg = coord[(pxj >> 8) & 0xffu], eb = coord[256 + ((pxj >> 16) & 0xffu)];
+            ty[j] = __uint_as_float(eg.y);
+            tz[j] = __uint_as_float(eb.y);
+            uint32_t r24;
+            asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r24) : "v"(pxj), "v"(24u));
+            const uint32_t dr24 = r24 - ar24, dyp = eg.x - ayp, dzp = eb.x - azp; // unsigned: below the anchor wraps to a huge value
+            miss[j] = (dr24 >= RW * 24u) | (dyp >= kWgNY * kWgPitchY) | (dzp >= kWgNZ * kWgPitchZ);
+            any_miss = any_miss | miss[j];
+            if (row == 0) outside += (uint32_t)__popcll(__ballot(miss[j] & valid));
+            const uint32_t off = miss[j] ? 0u : eg.x + eb.x + (r24 + lds_k);
+            const lds_float2_t q0 = (lds_float2_t)((lds_bytes_t)&win[0] + off), q1 = (lds_float2_t)((lds_bytes_t)&win[0] + off + kWgPitchZ);
+            e0[j][0] = q0[0]; e0[j][1] = q0[1]; e0[j][2] = q0[2];
+            e1[j][0] = q1[0]; e1[j][1] = q1[1]; e1[j][2] = q1[2];
+        }
+        if (row == 0 && outside > 248u) { // wave-uniform, rare
+            uint32_t far = 0, alike = 0, fpx = 0;
+            bool found = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t b = __ballot(miss[j] & valid);
+                if (b != 0 && !found) {
+                    fpx = (uint32_t)__builtin_amdgcn_readlane((int)px[j], __builtin_ctzll(b)); // the first outside pixel
+                    found = true;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                far += (uint32_t)__popcll(__ballot(miss[j] & valid & (__builtin_amdgcn_sad_u8(px[j] & 0x00ffff00u, ccpx & 0x00ffff00u, 0u) > kXFar)));
+                alike += (uint32_t)__popcll(__ballot(miss[j] & valid & (((px[j] ^ fpx) & 0x00f0f000u) == 0u)));
+            }
+            if (far * 4u > outside * 3u && alike * 4u < outside) return true;
+        }
+        if (any_miss) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (miss[j]) {
+                    const uint32_t pxj = px[j];
+                    const uint32_t iy = coord[(pxj >> 8) & 0xffu].x / kWgPitchY, iz = coord[256 + ((pxj >> 16) & 0xffu)].x / kWgPitchZ, r = pxj & 0xffu;
+                    const f32x2_t *g0p = reinterpret_cast<const f32x2_t *>(p.xtable) + (uint64_t)((iy * (p.size + 1) + iz) * 256u + r) * 3, *g1p = g0p + 256 * 3;
+                    e0[j][0] = g0p[0]; e0[j][1] = g0p[1]; e0[j][2] = g0p[2];
+                    e1[j][0] = g1p[0]; e1[j][1] = g1p[1]; e1[j][2] = g1p[2];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // entry = (X.r, X.g) (X.b, D.r) (D.g, D.b)
+            const float c0r = e0[j][0].x + e0[j][1].y * ty[j], c0g = e0[j][0].y + e0[j][2].x * ty[j], c0b = e0[j][1].x + e0[j][2].y * ty[j];
+            const float c1r = e1[j][0].x + e1[j][1].y * ty[j], c1g = e1[j][0].y + e1[j][2].x * ty[j], c1b = e1[j][1].x + e1[j][2].y * ty[j];
+            const float rr = lf_add_clamp(c0r, (c1r - c0r) * tz[j]), gg = lf_add_clamp(c0g, (c1g - c0g) * tz[j]),
+                        bb = lf_add_clamp(c0b, (c1b - c0b) * tz[j]);
+            // float_to_u8 (imp.rs:537-539) as ONE fused multiply-add + truncation (tools/prove_exact.c P15, exhaustive)
+            const float yr = __builtin_fmaf(rr, p.fast.out_scale, p.fast.pred_half), yg = __builtin_fmaf(gg, p.fast.out_scale, p.fast.pred_half),
+                        yb = __builtin_fmaf(bb, p.fast.out_scale, p.fast.pred_half);
+            uint32_t w = px[j];
+            asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yr));
+            asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yg));
+            asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(w) : "v"(yb));
+            px[j] = w;
+        }
+        if (valid) {
+            u32x4_t *dst = reinterpret_cast<u32x4_t *>(out + (size_t)row * out_stride + voff_out);
+            const u32x4_t t = {px[0], px[1], px[2], px[3]};
+            __builtin_nontemporal_store(t, dst);
+        }
+        return false;
+    };
+    if (do_row(0)) { // wave-uniform, rare: every lane gathers its own pixels' cells (no barrier follows: the other waves go on)
+        CellCache cache;
+#pragma unroll
+        for (uint32_t hr = 0; hr < kRows; hr++) {
+            uint4 q = v[hr];
+            q.x = lf_px8<true, true>(q.x, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
+            q.y = lf_px8<true, true>(q.y, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
+            q.z = lf_px8<true, true>(q.z, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
+            q.w = lf_px8<true, true>(q.w, p, p.cube, p.t[0], p.t[1], p.t[2], cache);
+            if (x < width && y0 + hr < height) {
+                u32x4_t *dst = reinterpret_cast<u32x4_t *>(out + (size_t)hr * out_stride + voff_out);
+                const u32x4_t t = {q.x, q.y, q.z, q.w};
+                __builtin_nontemporal_store(t, dst);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (uint32_t row = 1; row < kRows; row++) do_row(row);
+}
+
+// ---------------------------------------------------------------- content probe: which window kernel suits the stream (round 5)
+//
+// colorlut_xtile_kernel (an 18 x 3 x 3 window per wave, six workgroups per CU) is the faster kernel on calm pictures -- 16 x 4K per launch,
+// same box: 80-82 k fps on smooth gradients, 78-79 k with +-3 codes of noise, 69-70 k with +-5 -- and collapses where the colours of a
+// 64 x 20 block scatter: 41 k at +-8.  colorlut_xwg_kernel (one 38 x 5 x 5 window per workgroup) runs 74 / 72 / 70.5 / 69 / 47 k at
+// +-0 / 3 / 5 / 8 / 16 on the same frames (profiles/r5/colorlut_experiments.txt).  The pictures of a stream resemble their predecessors, so the choice is made from a look at
+// an earlier frame: one workgroup, 256 blocks of 64 x 20 pixels spread over the frame, sixteen pixels of each (a 4 x 4 lattice); a block
+// is BUSY when the sampled bytes of a channel span more than kProbeSpan codes (sixteen samples of +-3 codes of noise on a gradient span
+// about 10, of +-5 about 15, of +-8 about 20).  (colorlut takes RGBA only -- colorlut/imp.rs:122-134 --, so bytes 0..2 of a pixel are its colour.)  More than kProbeBusy busy blocks of 256 make the picture busy.  Every thread of the launch writes nothing
+// but thread 0, which stores the verdict into page-locked host memory; the launcher reads that word whenever it launches -- never
+// waiting for it -- and runs the probe again every kProbeEvery launches.  Both kernels produce the same bytes: the verdict only moves time.
+// Round 6: span 13 / 24 blocks (round 5: 17 / 38, which sent +-5 codes of noise to the per-wave windows although the workgroup window is the faster
+// kernel from there on: the driver's sweep read 67.3 k at +-5 below 67.7 k at +-8; tools/exp_colorlut_probe_sweep.py)
+constexpr uint32_t kProbeSpan = 13, kProbeBusy = 24; // (kProbeEvery: colorlut_device.hpp)
+
+__global__ __launch_bounds__(256) void colorlut_probe_kernel(const uint8_t *__restrict__ frame, uint32_t width, uint32_t height, uint32_t stride,
+                                                            uint32_t *__restrict__ verdict)
+{
+    __shared__ uint32_t busy_blocks;
+    if (threadIdx.x == 0) busy_blocks = 0;
+    __syncthreads();
+    const uint32_t tiles_x = width / 64u, tiles_y = height / 20u; // whole blocks only; (0, 0) when the frame is smaller than one
+    bool busy = false;
+    if (tiles_x != 0 && tiles_y != 0) {
+        // block (i, j) of a 16 x 16 lattice over the whole blocks of the frame
+        const uint32_t tx = (uint32_t)(((uint64_t)(threadIdx.x & 15u) * 2u + 1u) * tiles_x / 32u), ty = (uint32_t)(((uint64_t)(threadIdx.x >> 4) * 2u + 1u) * tiles_y / 32u);
+        uint32_t lo[3] = {255u, 255u, 255u}, hi[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) {
+            const uint32_t px = *reinterpret_cast<const uint32_t *>(frame + (size_t)(ty * 20u + 2u + 5u * (k >> 2)) * stride + (tx * 64u + 8u + 16u * (k & 3u)) * 4u);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const uint32_t b = (px >> (8 * c)) & 0xffu;
+                lo[c] = min(lo[c], b);
+                hi[c] = max(hi[c], b);
+            }
+        }
+        busy = max(max(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]) > kProbeSpan;
+    }
+    const uint32_t n = (uint32_t)__popcll(__ballot(busy));
+    if ((threadIdx.x & 63u) == 0 && n != 0) atomicAdd(&busy_blocks, n);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        verdict[1] = busy_blocks;
+        __atomic_store_n(&verdict[0], busy_blocks > kProbeBusy ? 2u : 1u, __ATOMIC_RELAXED);
+    }
+}
+
+// The fused I420 kernel with the wave-local window: the compact walk of convert_math.hpp (a wave = 64 x 16 pixels, each lane an
+// 8 x 2 strip of it), the window anchored at the cell of the wave's centre pixel (the first pixel of lane 36 = column 32, row 8 of the
+// block; lane 0's when the centre lies outside the frame), coordinates from the byte table.  On natural-like content the per-lane
+// gathers of colorlut_i420_kernel were the bound: 38.7 us per 4K frame against 31.7 us on one flat colour (no gathers at all;
+// 27.7 us with the coordinates from the byte table).  This kernel: 30.5 us natural-like, 29.4 us flat.
+__global__ __launch_bounds__(kI420Block) void colorlut_i420_tile_kernel(I420Planes pl, uint32_t width, uint32_t height, LutParams p,
+                                                                        YuvToRgbCoef kin, RgbToYuvCoef kout)
+{
+    __shared__ int2 edge[kI420Block];
+    __shared__ uint2 coord[kCoordEntries];
+    __shared__ float4 nbr[kI420Block / 64][kTileWaveLdsFloat4];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    {
+        const uint2 *src = reinterpret_cast<const uint2 *>(p.tile_tables);
+#pragma unroll
+        for (uint32_t i = 0; i < kCoordEntries / kI420Block; i++) coord[i * kI420Block + threadIdx.x] = src[i * kI420Block + threadIdx.x];
+    }
+    uint32_t x0, y0, edge_index;
+    bool has_left;
+    i420_lane_origin<true>(x0, y0, edge_index, has_left);
+    const bool active = x0 < width && y0 < height;
+    uint32_t first = 0xff000000u;
+    if (active) {
+        const uint32_t crow = y0 / 2;
+        const ChromaTerms c = chroma_terms(pl.iu[(uint64_t)crow * pl.ius + x0 / 2], pl.iv[(uint64_t)crow * pl.ivs + x0 / 2], kin);
+        first = yuv_pixel(pl.iy[(uint64_t)y0 * pl.iys + x0], c, kin);
+    }
+    const TileRel rel = tile_rel(lane, p);
+    __syncthreads(); // coordinate table complete
+    const uint32_t centre = __builtin_amdgcn_readlane((int)active, 36) ? 36u : 0u;
+    const uint32_t fpx = (uint32_t)__builtin_amdgcn_readlane((int)first, centre);
+    const uint32_t cx = coord[fpx & 0xffu].x, cy = coord[256 + ((fpx >> 8) & 0xffu)].x, cz = coord[512 + ((fpx >> 16) & 0xffu)].x;
+    uint32_t ax, ay, az;
+    tile_load_window(nbr[wave], lane, p, rel, cx, cy, cz, ax, ay, az);
+    const uint32_t wave_lds_bytes = wave * (uint32_t)(kTileWaveLdsFloat4 * sizeof(float4));
+    i420_fused_tile<true>(pl, width, height, kin, kout, edge, [&](uint32_t px) {
+        const uint2 er = coord[px & 0xffu], eg = coord[256 + ((px >> 8) & 0xffu)], eb = coord[512 + ((px >> 16) & 0xffu)];
+        float4 c[8];
+        tile_cell((lds_bytes_t)&nbr[0][0], wave_lds_bytes, p, er.x, eg.x, eb.x, ax, ay, az, c);
+        float r, g, b;
+        lf_trilinear<true>(c, __uint_as_float(er.y), __uint_as_float(eg.y), __uint_as_float(eb.y), r, g, b);
+        const float yr = r * p.fast.out_scale + p.fast.pred_half, yg = g * p.fast.out_scale + p.fast.pred_half,
+                    yb = b * p.fast.out_scale + p.fast.pred_half;
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(yr));
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(yg));
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(yb));
+        return px;
+    });
+}
+
+// The fused I420 kernel on the x-prelerped table (round 3): the compact walk of convert_math.hpp as above, the LUT step of
+// colorlut_xtile_kernel -- window of kXRW r bytes x 3 y cells x 4 z rows around the first pixel of lane 36 (lane 0's when
+// the block's centre lies outside the frame), filled by global_load_lds, premultiplied coordinate entries for g and b.
+__global__ __launch_bounds__(kI420Block) void colorlut_i420_xtile_kernel(I420Planes pl, uint32_t width, uint32_t height, LutParams p,
+                                                                         YuvToRgbCoef kin, RgbToYuvCoef kout)
+{
+    constexpr uint32_t RW = kXRW, kWaveBytes = kXWaveBytes;
+    __shared__ int2 edge[kI420Block];
+    __shared__ uint2 coord[512];
+    __shared__ __attribute__((aligned(16))) uint8_t win[(kI420Block / 64) * kWaveBytes];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t i = threadIdx.x; i < 512; i += kI420Block) coord[i] = p.xcoord[i];
+    uint32_t x0, y0, edge_index;
+    bool has_left;
+    i420_lane_origin<true>(x0, y0, edge_index, has_left);
+    const bool active = x0 < width && y0 < height;
+    uint32_t first = 0xff000000u;
+    if (active) {
+        const uint32_t crow = y0 / 2;
+        const ChromaTerms c = chroma_terms(pl.iu[(uint64_t)crow * pl.ius + x0 / 2], pl.iv[(uint64_t)crow * pl.ivs + x0 / 2], kin);
+        first = yuv_pixel(pl.iy[(uint64_t)y0 * pl.iys + x0], c, kin);
+    }
+    const uint32_t centre = __builtin_amdgcn_readlane((int)active, 36) ? 36u : 0u;
+    uint32_t fpx = (uint32_t)__builtin_amdgcn_readlane((int)first, centre);
+    // a block that lies wholly inside the frame is anchored at the MEAN of its 64 lanes' first pixels (an 8 x 8 lattice over the
+    // 64 x 16 block, already in registers) unless its corners say an edge runs through it: colorlut_xtile_kernel's anchor
+    if (__ballot(active) == ~0ull) {
+        uint32_t ev = first & 0x00ff00ffu, od = (first >> 8) & 0x00ff00ffu;
+#define MVFX_ROW_ADD(v_, ctrl) v_ += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v_, ctrl, 0xf, 0xf, true)
+        MVFX_ROW_ADD(ev, 0x111); MVFX_ROW_ADD(od, 0x111);
+        MVFX_ROW_ADD(ev, 0x112); MVFX_ROW_ADD(od, 0x112);
+        MVFX_ROW_ADD(ev, 0x114); MVFX_ROW_ADD(od, 0x114);
+        MVFX_ROW_ADD(ev, 0x118); MVFX_ROW_ADD(od, 0x118);
+#undef MVFX_ROW_ADD
+        const uint32_t sev = (uint32_t)__builtin_amdgcn_readlane((int)ev, 15) + (uint32_t)__builtin_amdgcn_readlane((int)ev, 31) +
+                             (uint32_t)__builtin_amdgcn_readlane((int)ev, 47) + (uint32_t)__builtin_amdgcn_readlane((int)ev, 63) + 0x00200020u;
+        const uint32_t sod = (uint32_t)__builtin_amdgcn_readlane((int)od, 15) + (uint32_t)__builtin_amdgcn_readlane((int)od, 31) +
+                             (uint32_t)__builtin_amdgcn_readlane((int)od, 47) + (uint32_t)__builtin_amdgcn_readlane((int)od, 63) + 0x00200020u;
+        const uint32_t mean = ((sev >> 6) & 0x00ff00ffu) | (((sod >> 6) & 0x000000ffu) << 8);
+        const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)first, 0) & 0xffffffu, q1 = (uint32_t)__builtin_amdgcn_readlane((int)first, 7) & 0xffffffu,
+                       q2 = (uint32_t)__builtin_amdgcn_readlane((int)first, 56) & 0xffffffu, q3 = (uint32_t)__builtin_amdgcn_readlane((int)first, 63) & 0xffffffu;
+        if (__builtin_amdgcn_sad_u8(q0, q3, 0u) + __builtin_amdgcn_sad_u8(q1, q2, 0u) <= kXSpread64) fpx = mean;
+    }
+    const uint32_t cr = fpx & 0xffu, cy = p.tile_tables[2 * (256 + ((fpx >> 8) & 0xffu))], cz = p.tile_tables[2 * (512 + ((fpx >> 16) & 0xffu))];
+    const uint32_t ar = min((cr > RW / 2 ? cr - RW / 2 : 0u) & ~1u, 256u - RW);
+    const uint32_t ay = min(cy > (kXNY - 1) / 2 ? cy - (kXNY - 1) / 2 : 0u, p.size - kXNY), az = min(cz > (kXNZ - 1) / 2 ? cz - (kXNZ - 1) / 2 : 0u, p.size - kXNZ);
+    const uint32_t ayp = ay * kXPitchY, azp = az * kXPitchZ, ar24 = ar * 24u;
+    {
+        const uint32_t base = (ay * (p.size + 1) + az) * kXRowPieces + ar * 3 / 2;
+        xtile_fill_window(p.xtable, base, p.size, win + wave * kWaveBytes, lane);
+    }
+    __syncthreads(); // coordinate table and window complete
+    const uint32_t wave_lds = wave * kWaveBytes, lds_k = wave_lds - ayp - azp - ar24;
+    i420_fused_tile<true>(pl, width, height, kin, kout, edge, [&](uint32_t px) {
+        const uint2 eg = coord[(px >> 8) & 0xffu], eb = coord[256 + ((px >> 16) & 0xffu)];
+        const float ty = __uint_as_float(eg.y), tz = __uint_as_float(eb.y);
+        uint32_t r24;
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r24) : "v"(px), "v"(24u));
+        const uint32_t dr24 = r24 - ar24, dyp = eg.x - ayp, dzp = eb.x - azp;
+        const bool miss = (dr24 >= RW * 24u) | (dyp >= kXNY * kXPitchY) | (dzp >= kXNZ * kXPitchZ);
+        const uint32_t off = miss ? wave_lds : eg.x + eb.x + (r24 + lds_k);
+        const lds_float2_t q0 = (lds_float2_t)((lds_bytes_t)&win[0] + off), q1 = (lds_float2_t)((lds_bytes_t)&win[0] + off + kXPitchZ);
+        f32x2_t e0[3] = {q0[0], q0[1], q0[2]}, e1[3] = {q1[0], q1[1], q1[2]};
+        if (miss) {
+            const uint32_t iy = eg.x / kXPitchY, iz = eb.x / kXPitchZ, r = px & 0xffu;
+            const f32x2_t *g0 = reinterpret_cast<const f32x2_t *>(p.xtable) + (uint64_t)((iy * (p.size + 1) + iz) * 256u + r) * 3, *g1 = g0 + 256 * 3;
+            e0[0] = g0[0]; e0[1] = g0[1]; e0[2] = g0[2];
+            e1[0] = g1[0]; e1[1] = g1[1]; e1[2] = g1[2];
+        }
+        const float c0r = e0[0].x + e0[1].y * ty, c0g = e0[0].y + e0[2].x * ty, c0b = e0[1].x + e0[2].y * ty;
+        const float c1r = e1[0].x + e1[1].y * ty, c1g = e1[0].y + e1[2].x * ty, c1b = e1[1].x + e1[2].y * ty;
+        const float rr = lf_add_clamp(c0r, (c1r - c0r) * tz), gg = lf_add_clamp(c0g, (c1g - c0g) * tz), bb = lf_add_clamp(c0b, (c1b - c0b) * tz);
+        const float yr = __builtin_fmaf(rr, p.fast.out_scale, p.fast.pred_half), yg = __builtin_fmaf(gg, p.fast.out_scale, p.fast.pred_half),
+                    yb = __builtin_fmaf(bb, p.fast.out_scale, p.fast.pred_half); // P15
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(yr));
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(yg));
+        asm("v_cvt_u32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(px) : "v"(yb));
+        return px;
+    });
+}
+} // namespace
+
+void launch_colorlut_xtable_build(const float4 *cube, const uint32_t *tile_tables, uint32_t size, float *xtable, uint64_t entries)
+{
+    MVFX_LAUNCH(colorlut_xtable_build_kernel, dim3((uint32_t)((entries + 255) / 256)), dim3(256), 0, nullptr, cube, tile_tables, size, xtable);
+}
+
+void launch_colorlut_xtile(dim3 grid, hipStream_t st, const FrameBatch &in, const FrameBatch &out, uint32_t width, uint32_t height, uint32_t in_stride,
+                           uint32_t out_stride, const LutParams &p)
+{
+    MVFX_LAUNCH(colorlut_xtile_kernel, grid, dim3(kBlock), 0, st, in, out, width, height, in_stride, out_stride, p);
+}
+
+void launch_colorlut_xwg(dim3 grid, hipStream_t st, const FrameBatch &in, const FrameBatch &out, uint32_t width, uint32_t height, uint32_t in_stride,
+                         uint32_t out_stride, const LutParams &p)
+{
+    MVFX_LAUNCH(colorlut_xwg_kernel, grid, dim3(kBlock), 0, st, in, out, width, height, in_stride, out_stride, p);
+}
+
+void launch_colorlut_probe(hipStream_t st, const uint8_t *frame, uint32_t width, uint32_t height, uint32_t stride, uint32_t *verdict)
+{
+    hipLaunchKernelGGL(colorlut_probe_kernel, dim3(1), dim3(256), 0, st, frame, width, height, stride, verdict); // (not MVFX_LAUNCH: no part of the frame's work)
+}
+
+void launch_colorlut_tile(bool wide, bool le, bool narrow, dim3 grid, hipStream_t st, const FrameBatch &in, const FrameBatch &out, uint32_t width,
+                          uint32_t height, uint32_t in_stride, uint32_t out_stride, const LutParams &p)
+{
+#define MVFX_TK(WIDE, LE, A, R) MVFX_LAUNCH((colorlut_tile_kernel<WIDE, LE, A, R>), grid, dim3(kBlock), 0, st, in, out, width, height, in_stride, out_stride, p)
+    if (wide) { if (le) MVFX_TK(true, true, 16, 4); else MVFX_TK(true, false, 16, 4); }
+    else if (narrow) MVFX_TK(false, true, 8, 2);
+    else MVFX_TK(false, true, 16, 4);
+#undef MVFX_TK
+}
+
+void launch_colorlut_i420_window(bool xtile, dim3 grid, hipStream_t st, const I420Planes &pl, uint32_t width, uint32_t height, const LutParams &p,
+                                 const YuvToRgbCoef &kin, const RgbToYuvCoef &kout)
+{
+    if (xtile) MVFX_LAUNCH(colorlut_i420_xtile_kernel, grid, dim3(kI420Block), 0, st, pl, width, height, p, kin, kout);
+    else MVFX_LAUNCH(colorlut_i420_tile_kernel, grid, dim3(kI420Block), 0, st, pl, width, height, p, kin, kout);
+}
+
+} // namespace mvfx

@@ -14,6 +14,7 @@ struct GstMi355HipCopy {
     GstVideoInfo info;
     gboolean have_info;
     GstBufferPool *pinned; // hipdownload: page-locked system-memory output buffers (D2H is then a plain DMA)
+    gint device_id;        // hipupload, property: the device its blocks live on (-1: the streaming thread's current device)
 };
 struct GstMi355HipCopyClass {
     GstBaseTransformClass parent_class;
@@ -55,6 +56,8 @@ static GstFlowReturn hipcopy_prepare_output_buffer(GstBaseTransform *trans, GstB
     if (!self->have_info)
         return GST_FLOW_NOT_NEGOTIATED;
     *outbuf = NULL;
+    if (upload && !mvfx_hip_select_device(self->device_id, GST_ELEMENT(trans))) // this streaming thread allocates (and copies) on `device-id`
+        return GST_FLOW_ERROR;
     if (upload) { // device buffers come from the pool negotiated with downstream (hipcopy_decide_allocation)
         GstBufferPool *pool = gst_base_transform_get_buffer_pool(trans);
         if (pool) {
@@ -139,6 +142,11 @@ static GstFlowReturn hipcopy_transform(GstBaseTransform *trans, GstBuffer *inbuf
     int rc = MVFX_OK;
     // the copies run on this thread's stream behind the fence of the device block (its producer, or the last reader of a
     // recycled block); the system-memory side is only borrowed, so the call returns when the copy has landed
+    if (!mvfx_hip_follow_device(dev, GST_OBJECT(trans))) { // hipdownload: the device of the incoming memory; hipupload: of the block just allocated
+        gst_buffer_unmap(dev, &dmap);
+        gst_video_frame_unmap(&frame);
+        return GST_FLOW_ERROR;
+    }
     mvfx_stream st = mvfx_thread_stream();
     mvfx_hip_buffer_acquire(dev, st);
     // device buffers always use the default GstVideoInfo layout (offsets / strides of `info`)
@@ -160,6 +168,28 @@ static GstFlowReturn hipcopy_transform(GstBaseTransform *trans, GstBuffer *inbuf
     gst_buffer_unmap(dev, &dmap);
     gst_video_frame_unmap(&frame);
     return MVFX_GST_FLOW(trans, rc);
+}
+
+enum { PROP_COPY_0, PROP_COPY_DEVICE_ID };
+
+static void hipcopy_set_property(GObject *obj, guint id, const GValue *value, GParamSpec *pspec)
+{
+    if (id == PROP_COPY_DEVICE_ID) ((GstMi355HipCopy *)obj)->device_id = g_value_get_int(value);
+    else G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec);
+}
+
+static void hipcopy_get_property(GObject *obj, guint id, GValue *value, GParamSpec *pspec)
+{
+    if (id == PROP_COPY_DEVICE_ID) g_value_set_int(value, ((GstMi355HipCopy *)obj)->device_id);
+    else G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec);
+}
+
+// start(): a `device-id` that does not exist fails HERE, as a RESOURCE error of the element, not in the first buffer
+static gboolean hipcopy_start(GstBaseTransform *trans)
+{
+    GstMi355HipCopy *self = (GstMi355HipCopy *)trans;
+    const gboolean upload = ((GstMi355HipCopyClass *)G_OBJECT_GET_CLASS(trans))->upload;
+    return !upload || mvfx_hip_select_device(self->device_id, GST_ELEMENT(trans));
 }
 
 static gboolean hipcopy_stop(GstBaseTransform *trans)
@@ -195,8 +225,17 @@ static void hipcopy_class_init_common(GstMi355HipCopyClass *klass, gboolean uplo
     bt->decide_allocation = hipcopy_decide_allocation;
     bt->propose_allocation = hipcopy_propose_allocation;
     bt->transform = hipcopy_transform;
+    bt->start = hipcopy_start;
     bt->stop = hipcopy_stop;
     bt->passthrough_on_same_caps = FALSE;
+    if (upload) {
+        G_OBJECT_CLASS(klass)->set_property = hipcopy_set_property;
+        G_OBJECT_CLASS(klass)->get_property = hipcopy_get_property;
+        g_object_class_install_property(G_OBJECT_CLASS(klass), PROP_COPY_DEVICE_ID,
+            g_param_spec_int("device-id", "Device ID", "HIP device the uploaded frames live on (-1 = the streaming thread's current device); the "
+                             "elements downstream follow the device of their input memory", -1, G_MAXINT, -1,
+                             (GParamFlags)(G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS)));
+    }
 }
 
 static void hipupload_class_init(gpointer klass, gpointer) { hipcopy_class_init_common((GstMi355HipCopyClass *)klass, TRUE); }
@@ -205,6 +244,7 @@ static void hipcopy_init(GTypeInstance *inst, gpointer)
 {
     ((GstMi355HipCopy *)inst)->have_info = FALSE;
     ((GstMi355HipCopy *)inst)->pinned = NULL;
+    ((GstMi355HipCopy *)inst)->device_id = -1;
 }
 
 static GType hipcopy_register(const gchar *name, GClassInitFunc class_init)
@@ -235,6 +275,7 @@ struct GstMi355HipTestSrc {
     GstVideoInfo info;
     gboolean have_info, hip;
     gboolean refresh;    // property: re-copy the master into every recycled device block (default); FALSE: fill each block once
+    gint device_id;      // property: the device the frames are born on (-1: the streaming thread's current device)
     guint8 *pattern;
     gsize pattern_size;
     void *master;        // device copy of `pattern` (memory:HIPMemory caps)
@@ -332,6 +373,7 @@ static gboolean hiptestsrc_set_caps(GstBaseSrc *src, GstCaps *caps)
         self->master = NULL;
     }
     if (self->hip) {
+        if (!mvfx_hip_select_device(self->device_id, GST_ELEMENT(self))) return FALSE; // the master and (below) the pool's blocks on `device-id`
         if (mvfx_device_alloc(&self->master, self->pattern_size) != MVFX_OK ||
             mvfx_copy_to_device(self->master, self->pattern, self->pattern_size, NULL) != MVFX_OK) {
             GST_ELEMENT_ERROR(self, RESOURCE, FAILED, ("hiptestsrc: %s", mvfx_last_error()), (NULL));
@@ -344,6 +386,8 @@ static gboolean hiptestsrc_set_caps(GstBaseSrc *src, GstCaps *caps)
 
 static gboolean hiptestsrc_decide_allocation(GstBaseSrc *src, GstQuery *query)
 {
+    // (the base class allocates the first buffer on this thread right after: a HIP thread keeps its current device)
+    if (((GstMi355HipTestSrc *)src)->hip && !mvfx_hip_select_device(((GstMi355HipTestSrc *)src)->device_id, GST_ELEMENT(src))) return FALSE;
     // HIP pool when the caps carry memory:HIPMemory; otherwise downstream's pool (hipupload offers page-locked buffers) or,
     // when nobody proposed one, a plain video buffer pool of our own -- buffers must be RECYCLED for the fill-once scheme
     if (!mvfx_hip_decide_allocation(query) && gst_query_get_n_allocation_pools(query) == 0) {
@@ -430,6 +474,8 @@ static void hiptestsrc_get_times(GstBaseSrc *src, GstBuffer *buffer, GstClockTim
 
 static gboolean hiptestsrc_start(GstBaseSrc *src)
 {
+    // a `device-id` that does not exist fails here, as a RESOURCE error of the element
+    if (!mvfx_hip_select_device(((GstMi355HipTestSrc *)src)->device_id, GST_ELEMENT(src))) return FALSE;
     ((GstMi355HipTestSrc *)src)->n = 0;
     ((GstMi355HipTestSrc *)src)->rate_t0 = 0;
     return TRUE;
@@ -443,12 +489,13 @@ static void gst_mi355_hip_test_src_finalize(GObject *obj)
     G_OBJECT_CLASS(gst_mi355_hip_test_src_parent_class)->finalize(obj);
 }
 
-enum { PROP_TS_0, PROP_TS_REFRESH, PROP_TS_IS_LIVE };
+enum { PROP_TS_0, PROP_TS_REFRESH, PROP_TS_IS_LIVE, PROP_TS_DEVICE_ID };
 
 static void hiptestsrc_set_property(GObject *obj, guint id, const GValue *value, GParamSpec *pspec)
 {
     if (id == PROP_TS_REFRESH) ((GstMi355HipTestSrc *)obj)->refresh = g_value_get_boolean(value);
     else if (id == PROP_TS_IS_LIVE) gst_base_src_set_live(GST_BASE_SRC(obj), g_value_get_boolean(value));
+    else if (id == PROP_TS_DEVICE_ID) ((GstMi355HipTestSrc *)obj)->device_id = g_value_get_int(value);
     else G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec);
 }
 
@@ -456,6 +503,7 @@ static void hiptestsrc_get_property(GObject *obj, guint id, GValue *value, GPara
 {
     if (id == PROP_TS_REFRESH) g_value_set_boolean(value, ((GstMi355HipTestSrc *)obj)->refresh);
     else if (id == PROP_TS_IS_LIVE) g_value_set_boolean(value, gst_base_src_is_live(GST_BASE_SRC(obj)));
+    else if (id == PROP_TS_DEVICE_ID) g_value_set_int(value, ((GstMi355HipTestSrc *)obj)->device_id);
     else G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, pspec);
 }
 
@@ -474,6 +522,9 @@ static void gst_mi355_hip_test_src_class_init(GstMi355HipTestSrcClass *klass)
     g_object_class_install_property(G_OBJECT_CLASS(klass), PROP_TS_IS_LIVE,
         g_param_spec_boolean("is-live", "Is Live", "Whether to act as a live source (one buffer per frame interval of the caps)", FALSE,
                              (GParamFlags)(G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS)));
+    g_object_class_install_property(G_OBJECT_CLASS(klass), PROP_TS_DEVICE_ID,
+        g_param_spec_int("device-id", "Device ID", "memory:HIPMemory: HIP device the frames are born on (-1 = the streaming thread's current device)",
+                         -1, G_MAXINT, -1, (GParamFlags)(G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS)));
     GstCaps *sys = gst_caps_new_empty_simple("video/x-raw");
     GstCaps *both = mvfx_caps_plus_hip(sys);
     gst_element_class_add_pad_template(element, gst_pad_template_new("src", GST_PAD_SRC, GST_PAD_ALWAYS, both));
@@ -493,6 +544,7 @@ static void gst_mi355_hip_test_src_init(GstMi355HipTestSrc *self)
 {
     self->have_info = self->hip = FALSE;
     self->refresh = TRUE;
+    self->device_id = -1;
     self->pattern = NULL;
     self->pattern_size = 0;
     self->master = NULL;

@@ -141,6 +141,8 @@ static inline gboolean mvfx_hip_map_i420(GstBuffer *buf, const GstVideoInfo *inf
 static inline GstFlowReturn mvfx_hip_new_output(GstBaseTransform *trans, GstBuffer *inbuf, gsize size, GstBuffer **outbuf)
 {
     *outbuf = NULL;
+    if (!mvfx_hip_follow_device(inbuf, GST_OBJECT(trans))) // the output block is allocated on the input's device
+        return GST_FLOW_ERROR;
     GstBufferPool *pool = gst_base_transform_get_buffer_pool(trans); // negotiated by decide_allocation
     if (pool) {
         if (mvfx_is_hip_buffer_pool(pool)) {
@@ -150,6 +152,11 @@ static inline GstFlowReturn mvfx_hip_new_output(GstBaseTransform *trans, GstBuff
                 *outbuf = NULL;
         }
         gst_object_unref(pool);
+    }
+    if (*outbuf && mvfx_buffer_is_hip(inbuf) && mvfx_hip_buffer_device(*outbuf) != mvfx_hip_buffer_device(inbuf)) {
+        // the pool's blocks are from the device the stream was on before the incoming memory changed device: a one-off block on the new one
+        gst_buffer_unref(*outbuf);
+        *outbuf = NULL;
     }
     if (!*outbuf) { // no ALLOCATION query answered yet / foreign pool: a one-off device buffer
         GstAllocator *alloc = mvfx_hip_allocator_get();
@@ -192,6 +199,9 @@ static inline GstFlowReturn mvfx_hip_new_output(GstBaseTransform *trans, GstBuff
 #endif
 static inline mvfx_stream mvfx_element_stream(GstBuffer *buf)
 {
+    // the streaming thread adopts the device of the incoming memory first (d3d12colorlut/imp.rs:494-542): the streams below, the LUT replica, the
+    // output blocks are then that device's.  One compare per buffer when nothing changes.
+    mvfx_hip_follow_device(buf, NULL);
     static const guint n = [] {
         const gchar *e = g_getenv("MVFX_ELEMENT_STREAMS");
         const int v = e ? atoi(e) : MVFX_ELEMENT_STREAMS_DEFAULT;

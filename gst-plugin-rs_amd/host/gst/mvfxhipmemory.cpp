@@ -648,6 +648,46 @@ gboolean mvfx_is_hip_memory(GstMemory *mem)
     return mem && mem->allocator && g_strcmp0(mem->allocator->mem_type, MVFX_HIP_MEMORY_TYPE) == 0;
 }
 
+int mvfx_hip_memory_device(GstMemory *mem)
+{
+    return mvfx_is_hip_memory(mem) ? ((MvfxHipMemory *)mem)->device : -1;
+}
+
+int mvfx_hip_buffer_device(GstBuffer *buf)
+{
+    return buf && gst_buffer_n_memory(buf) > 0 ? mvfx_hip_memory_device(gst_buffer_peek_memory(buf, 0)) : -1;
+}
+
+gboolean mvfx_hip_follow_device(GstBuffer *buf, GstObject *owner)
+{
+    const int want = mvfx_hip_buffer_device(buf);
+    if (want < 0) return TRUE;
+    const int have = mvfx_current_device(); // (hipGetDevice: a thread-local read inside the runtime)
+    if (have == want) return TRUE;
+    if (mvfx_set_device(want) != MVFX_OK) {
+        if (owner && GST_IS_ELEMENT(owner))
+            GST_ELEMENT_ERROR(GST_ELEMENT(owner), RESOURCE, FAILED, ("cannot select device %d of the incoming memory: %s", want, mvfx_last_error()), (NULL));
+        return FALSE;
+    }
+    if (owner) GST_INFO_OBJECT(owner, "Device updated from %d to %d", have, want);
+    return TRUE;
+}
+
+gboolean mvfx_hip_select_device(gint device_id, GstElement *owner)
+{
+    if (device_id < 0) return TRUE;
+    const int n = mvfx_device_count();
+    if (device_id >= n) {
+        if (owner) GST_ELEMENT_ERROR(owner, RESOURCE, NOT_FOUND, ("device-id %d: only %d HIP device(s) visible", device_id, n), (NULL));
+        return FALSE;
+    }
+    if (mvfx_current_device() != device_id && mvfx_set_device(device_id) != MVFX_OK) {
+        if (owner) GST_ELEMENT_ERROR(owner, RESOURCE, FAILED, ("device-id %d: %s", device_id, mvfx_last_error()), (NULL));
+        return FALSE;
+    }
+    return TRUE;
+}
+
 gboolean mvfx_buffer_is_hip(GstBuffer *buf)
 {
     return buf && gst_buffer_n_memory(buf) == 1 && mvfx_is_hip_memory(gst_buffer_peek_memory(buf, 0));

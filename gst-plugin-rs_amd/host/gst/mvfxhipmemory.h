@@ -63,6 +63,18 @@ void mvfx_hip_memory_set_borrowed_fence(GstMemory *mem, void *event);
 void mvfx_hip_buffer_acquire(GstBuffer *buf, void *stream);
 void mvfx_hip_buffer_release(GstBuffer *buf, void *stream);
 gboolean mvfx_is_hip_memory(GstMemory *mem);
+// ---- devices (round 6).  A block lives on the device that was the allocating thread's current one; `hipupload` / `hiptestsrc` choose it with
+// their `device-id` property.  Every element that works on device buffers adopts the device of its INPUT memory before it acquires the block
+// (the reference's d3d12colorlut: "Device updated from ... to ...", video/colorlut/src/d3d12colorlut/imp.rs:494-542): the streaming thread's
+// current device is set, so its private streams, scratch, output blocks and LUT replica are that device's.
+int mvfx_hip_memory_device(GstMemory *mem);            // ordinal, -1 for memory that is not ours
+int mvfx_hip_buffer_device(GstBuffer *buf);            // of the buffer's first memory
+// Makes the device of `buf`'s memory the calling thread's current device.  TRUE when it already was or the switch succeeded (`owner`, may be NULL,
+// logs the switch); FALSE + GST_ELEMENT_ERROR(RESOURCE) on `owner` when the device cannot be selected.  Buffers that are not HIP memory: TRUE.
+gboolean mvfx_hip_follow_device(GstBuffer *buf, GstObject *owner);
+// `device-id` of an element that CREATES device buffers: -1 keeps the calling thread's current device; otherwise validates the ordinal against
+// the visible devices and makes it current.  FALSE + GST_ELEMENT_ERROR(RESOURCE, NOT_FOUND) when there is no such device.
+gboolean mvfx_hip_select_device(gint device_id, GstElement *owner);
 gboolean mvfx_buffer_is_hip(GstBuffer *buf);          // single HIP memory holding the whole frame
 gboolean mvfx_caps_has_hip_feature(const GstCaps *caps);
 // "video/x-raw(memory:HIPMemory), format={...}, ..." twin of a system-memory caps

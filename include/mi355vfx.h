@@ -158,7 +158,10 @@ int mvfx_copy_device_to_device_async(void *dst_device, const void *src_device, s
 #define MVFX_OPT_LUT_PLACEMENT_MASK 0x70u /* 3 cell-packed global | 4 literal kernels | 5 tile kernel (wave-local LUT     */
                                           /* window in LDS, the automatic choice for 3-D cubes) | 6 baked table (RGBA8 only)  */
                                           /* | 7 round 4's per-wave x-prelerped windows instead of the workgroup window (A/B); */
-                                          /* (placement << SHIFT) & MASK */
+                                          /* (placement << SHIFT) & MASK.  5 and 7 are preferences, not demands: frames the */
+                                          /* window kernels cannot take (1-D LUTs, cubes above 65 points, non-finite domains, */
+                                          /* widths that are not multiples of 4, rows that are not 16-byte aligned) run the */
+                                          /* kernel the automatic choice would have picked for them -- same bytes either way */
 #define MVFX_OPT_SSIM_F64 0x80u        /* hash-algo=dssim: f64 planes and window sums (round 2's pipeline, within 1e-9 of the f64
                                           checker) instead of the default f32 pipeline (what dssim-core computes in) */
 #define MVFX_OPT_LUT_WG_WINDOW 0x100u  /* colorlut, placement 0 on RGBA8 frames and cubes of 5+ points: always the workgroup-window kernel
@@ -280,6 +283,10 @@ int mvfx_cube_lut_parse_file(const char *path, mvfx_cube_lut **out);
 void mvfx_cube_lut_free(mvfx_cube_lut *lut);
 int mvfx_cube_lut_is_3d(const mvfx_cube_lut *lut);
 uint32_t mvfx_cube_lut_size(const mvfx_cube_lut *lut);
+/* Diagnostic: on how many devices the handle holds a device copy.  The copy of a device is made by the first transform a thread makes there and is
+ * shared by every later user of the handle on that device; a handle used from streaming threads on several GPUs keeps one per GPU (the reference's
+ * d3d12colorlut rebuilds its context when the device of the incoming memory changes, d3d12colorlut/imp.rs:494-542) until mvfx_cube_lut_free. */
+int mvfx_cube_lut_device_copies(const mvfx_cube_lut *lut);
 /* Diagnostic: the last verdict of the LUT's content probe (see MVFX_OPT_LUT_WG_WINDOW) -- 0 none yet, 1 calm, 2 busy -- and, when
  * `busy_blocks` is not NULL, how many of the 256 sampled blocks of the probed frame were busy.  Never synchronises. */
 int mvfx_cube_lut_content_verdict(const mvfx_cube_lut *lut, uint32_t *busy_blocks);

@@ -791,3 +791,43 @@ def test_pair_launches_of_neighbouring_elements_never_wait_for_each_other(gpu, t
             assert buffers == n and 2 * pairs + singles + direct == n
             if mode == "2":
                 assert direct == 0
+
+
+# ---------------------------------------------------------------- devices (round 6): `device-id` and device following
+
+def test_device_id_zero_is_the_default_device(gpu, tmp_path):
+    """`device-id=0` on the elements that create device buffers (hiptestsrc, hipupload) gives the bytes of the default; the elements behind
+    them take the device from their input memory (one GPU on this box: ordinal 0 either way)"""
+    w, h = 320, 240
+    cube = tmp_path / "look.cube"
+    cube.write_text(cubes.analytic_3d(9))
+    hip = f"video/x-raw(memory:HIPMemory),format=RGBA,width={w},height={h},framerate=30/1"
+    chain = f"hsvfilter hue-shift=45 saturation-mul=1.2 ! colorlut location={cube} ! hipdownload"
+    want = _capture(tmp_path, f"hiptestsrc num-buffers=3 ! {hip} ! {chain}", "default.raw")
+    got = _capture(tmp_path, f"hiptestsrc num-buffers=3 device-id=0 ! {hip} ! {chain}", "dev0.raw")
+    assert want.size == 3 * w * h * 4 and np.array_equal(got, want)
+    sysc = f"video/x-raw,format=RGBA,width={w},height={h},framerate=30/1"
+    got = _capture(tmp_path, f"hiptestsrc num-buffers=3 ! {sysc} ! hipupload device-id=0 ! {chain}", "up0.raw")
+    assert np.array_equal(got, want)
+    # and the result is the oracle's
+    raw = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! {sysc}", "in.raw").reshape(h, w * 4)
+    mid = raw.copy()
+    assert orc.hsvfilter(mid, w, w * 4, "RGBA", (45.0, 1.2, 0.0, 1.0, 0.0)) == 0
+    exp = np.empty_like(mid)
+    assert orc.CubeLut(cubes.analytic_3d(9)).apply(mid, w * 4, exp, w * 4, w, h, "RGBA") == 0
+    assert np.array_equal(want[:w * h * 4].reshape(h, w * 4), exp)
+
+
+@pytest.mark.parametrize("pipeline", [
+    "hiptestsrc num-buffers=3 device-id=7 ! video/x-raw(memory:HIPMemory),format=RGBA,width=64,height=48 ! hsvfilter ! fakesink",
+    "hiptestsrc num-buffers=3 ! video/x-raw,format=RGBA,width=64,height=48 ! hipupload device-id=7 ! hsvfilter ! fakesink"],
+    ids=["hiptestsrc", "hipupload"])
+def test_a_device_id_that_does_not_exist_is_a_resource_error_in_start(gpu, tmp_path, pipeline):
+    """no GPU 7 on this box: the element fails its start() with GST_ELEMENT_ERROR(RESOURCE, NOT_FOUND) -- gst-launch reports the error and
+    leaves with status 1; nothing aborts (G_DEBUG=fatal-warnings is on), nothing crashes"""
+    if gpu.lib().mvfx_device_count() > 7:
+        pytest.skip("this box really has a device 7")
+    r = gst_env.run([LAUNCH] + pipeline.split(), tmp_path)
+    assert r.returncode in (1, 255), (r.returncode, r.stdout[-1500:])  # gst-launch's "ERROR: Pipeline doesn't want to pause": an exit, no signal
+    assert "device-id 7: only" in r.stdout and "HIP device(s) visible" in r.stdout, r.stdout[-1500:]
+    assert "Segmentation" not in r.stdout and "Aborted" not in r.stdout

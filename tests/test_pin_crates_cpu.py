@@ -54,3 +54,31 @@ def test_dssim_explainer_baseline_is_the_oracle_and_a_changed_constant_is_found(
     lines = dv.explain(frames, pairs, W, H)
     assert lines[1].lstrip().startswith("MATCHES window=gauss3x3_twice"), lines[:4]
     assert "`window=gauss3x3_twice` reproduces the crate" in lines[-1]
+
+
+def test_comparer_consumes_a_document_in_the_harness_output_format_end_to_end():
+    """Round 6: tests/golden/pin_crates_output_format_sample.json has exactly the layout src/main.rs prints (the keys the
+    harness emits per frame and per pair, hashes as hex strings, distances as integers, dssim as a float) -- values: the restatement's own, the
+    dssim values with ONE constant changed.  compare.py must read it, report the hashes / palettes / names PINNED, the non-trivial dssim values
+    DIFFERS, name the changed constant in its per-constant report and leave with status 1; the README's commands are the ones tested here."""
+    import json
+    sample = os.path.join(ROOT, "tests", "golden", "pin_crates_output_format_sample.json")
+    doc = json.load(open(sample))
+    src = open(os.path.join(PIN, "src", "main.rs")).read()
+    # the sample's keys are the keys the harness prints
+    frame_keys = set(next(iter(doc["frames"].values())))
+    for q, n in ((10, 2), (1, 8), (5, 5), (10, 255)):
+        assert {f"palette_q{q}_n{n}", f"name_q{q}_n{n}"} <= frame_keys
+    assert 'format!("\\"palette_q{q}_n{n}\\": {}"' in src and 'format!("\\"name_q{q}_n{n}\\": \\"{}\\""' in src
+    for algo in ("mean", "gradient", "vertgradient", "doublegradient", "blockhash"):
+        assert algo in frame_keys and f'("{algo}", HashAlg::' in src
+    assert set(next(iter(doc["pairs"].values()))) == {"dssim", "mean", "gradient", "vertgradient", "doublegradient", "blockhash"}
+    assert len(doc["frames"]) == 5 and len(doc["pairs"]) == 15 and "FORMAT SAMPLE" in doc["crates"]
+    r = subprocess.run([sys.executable, os.path.join(PIN, "compare.py"), sample], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    differs = [ln for ln in r.stdout.splitlines() if ln.startswith("DIFFERS")]
+    assert differs and all(" dssim:" in ln for ln in differs), differs[:3]
+    assert r.stdout.count("PINNED") > 100 and "MISSING" not in r.stdout
+    assert "MATCHES window=gauss3x3_twice" in r.stdout and "`window=gauss3x3_twice` reproduces the crate" in r.stdout
+    readme = open(os.path.join(PIN, "README.md")).read()
+    assert "cargo run --release -- ../../tests/golden > crates.json" in readme and "compare.py tools/pin_crates/crates.json --explain" in readme

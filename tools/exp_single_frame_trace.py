@@ -23,7 +23,7 @@ def main():
     s = vfx.HsvFilterSettings(90.0, 1.25, -0.05, 0.9, 0.02)
     streams = [ctypes.c_void_p(lib.mvfx_thread_stream_n(k)) for k in range(2)]
     for mode, pick in (("one stream", lambda i: streams[0]), ("two streams alternating", lambda i: streams[i & 1])):
-        for i in range(400):
+        for i in range(400):  # (warm-up)
             vfx.check(lib.mvfx_hsvfilter_transform_frame_ip(ctypes.byref(fr[i % N]), ctypes.byref(s), pick(i)))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
