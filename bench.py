@@ -1600,6 +1600,31 @@ def hsvfilter_main(args):
             fpsn = nthr * n1 * world / med
             return {"launch_model": f"{nthr} threads x 2 frames per launch, each alternating between 2 private HIP streams", "value": fpsn,
                     "unit": "frames/s", "statistic": "median of 5 repetitions", "frac_wall": fpsn / world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS}
+        def direct_leg(options):
+            """the element's contract through the direct-dispatch lane (round 6, MVFX_OPT_DIRECT_DISPATCH): one thread, one single-frame call per
+            buffer, a fence per frame, the kernels on the library's own two HSA queues as AQL packets without a release fence (write-through stores)"""
+            n1 = 2000
+            secs = (ctypes.c_double * reps)()
+            took = ctypes.c_uint64()
+            w.sync()
+            w.barrier()
+            rc = hb.mvfxbench_hsvfilter_direct(w.device_index, 200, n1, reps, flat, nthr * fpt, ctypes.byref(settings), options, secs, ctypes.byref(took))
+            if rc != 0:
+                raise RuntimeError(f"mvfxbench status {rc}: {vfx.last_error()}")
+            w.barrier()
+            (med,) = w.max_over_ranks(sorted(secs)[reps // 2])
+            fps1 = n1 * world / med
+            return {"launch_model": "1 thread x single-frame calls through the direct-dispatch lane (own HSA queues, AQL packets with acquire = agent, release = none, "
+                                    "write-through stores; a completion signal per frame as its fence)", "value": fps1, "unit": "frames/s", "launches": n1,
+                    "statistic": "median of 5 repetitions", "share_through_the_lane": took.value / float(reps * n1),
+                    "frac_wall": fps1 / world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS}
+        try:
+            hb.mvfxbench_hsvfilter_direct.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
+                                                      ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+            single_stream["direct_lane"] = direct_leg(opts)                       # the cache policy of the other legs (non-temporal loads by default)
+            single_stream["direct_lane_cached"] = direct_leg(opts & ~vfx.OPT_NONTEMPORAL)  # what the element uses (the next element reads the frame)
+        except Exception as e:  # noqa: BLE001  (a box without the lane still prints its line)
+            single_stream["direct_lane"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         if fpt >= 2:
             single_stream["threads_pairs"] = threads_pairs_leg()
         if args.combiner_legs:  # (0: a profiling run -- rocprofv3's queue interceptor crashes on this leg's cross-stream event waits)
@@ -1664,6 +1689,9 @@ def hsvfilter_main(args):
             if "pairs_two_streams" in single_stream:
                 element_path.update({"one_thread_pairs_fps": _r(single_stream["pairs_two_streams"]["value"], 5),
                                      "one_thread_pairs_frac": _r(single_stream["pairs_two_streams"]["frac_wall"], 4)})
+            if single_stream.get("direct_lane_cached", {}).get("value"):
+                element_path.update({"one_thread_direct_fps": _r(single_stream["direct_lane_cached"]["value"], 5),
+                                     "one_thread_direct_frac": _r(single_stream["direct_lane_cached"]["frac_wall"], 4)})
             if "threads_pairs" in single_stream:
                 element_path.update({"threads16_pairs_fps": _r(single_stream["threads_pairs"]["value"], 5),
                                      "threads16_pairs_frac": _r(single_stream["threads_pairs"]["frac_wall"], 4)})

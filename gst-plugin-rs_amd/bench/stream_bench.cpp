@@ -247,4 +247,48 @@ int mvfxbench_colorlut_streams(int device, uint32_t n_threads, uint32_t warmup, 
     return MVFX_OK;
 }
 
+// The element's contract through the direct-dispatch lane (round 6, MVFX_OPT_DIRECT_DISPATCH): ONE thread, one single-frame call per buffer, every
+// frame with its own fence -- an event out of a ring of 32, re-used when its frame has finished, as the element layer's fence pool does -- and
+// nothing enqueued on a stream.  *direct_out = how many of the timed launches the lane took (0: no lane on this box, the figure is the stream's).
+int mvfxbench_hsvfilter_direct(int device, uint32_t warmup, uint32_t launches, uint32_t reps, const mvfx_frame *frames, uint32_t n_frames,
+                               const mvfx_hsvfilter_settings *settings, uint32_t options, double *seconds_out, uint64_t *direct_out)
+{
+    if (!frames || !settings || !seconds_out || n_frames == 0 || reps == 0) return MVFX_ERR_INVALID_ARGUMENT;
+    int rc = MVFX_OK;
+    uint64_t direct = 0;
+    std::thread th([&] {
+        rc = mvfx_set_device(device);
+        constexpr uint32_t kEvents = 32;
+        mvfx_event ev[kEvents] = {};
+        for (uint32_t k = 0; k < kEvents && rc == MVFX_OK; k++) rc = mvfx_event_create(&ev[k]);
+        mvfx_stream st = mvfx_thread_stream();
+        uint64_t n = 0;
+        auto one = [&](uint32_t i, bool count) {
+            mvfx_event e = ev[n % kEvents];
+            if (n >= kEvents) rc = mvfx_event_synchronize(e);
+            n++;
+            if (rc != MVFX_OK) return;
+            mvfx_thread_set_options(options | MVFX_OPT_DIRECT_DISPATCH);
+            mvfx_thread_set_completion_event(e);
+            rc = mvfx_hsvfilter_transform_frame_ip(&frames[i % n_frames], settings, st);
+            if (mvfx_thread_clear_completion_event() <= 0 && rc == MVFX_OK) rc = mvfx_event_record(e, st);
+            if (count && mvfx_event_is_direct(e)) direct++;
+        };
+        auto drain = [&] { for (uint32_t k = 0; k < kEvents && rc == MVFX_OK; k++) if (n > k) rc = mvfx_event_synchronize(ev[k]); };
+        for (uint32_t i = 0; i < warmup && rc == MVFX_OK; i++) one(i, false);
+        drain();
+        for (uint32_t r = 0; r < reps && rc == MVFX_OK; r++) {
+            const double t0 = now_s();
+            for (uint32_t i = 0; i < launches && rc == MVFX_OK; i++) one(r * launches + i, true);
+            drain();
+            seconds_out[r] = now_s() - t0;
+        }
+        mvfx_thread_set_options(0);
+        for (uint32_t k = 0; k < kEvents; k++) if (ev[k]) mvfx_event_destroy(ev[k]);
+    });
+    th.join();
+    if (direct_out) *direct_out = direct;
+    return rc;
+}
+
 } // extern "C"

@@ -1,6 +1,7 @@
 // Library-level pieces of the C ABI: error reporting, device selection, device buffers,
 // the staging scratch behind the *_host entry points.
 #include "mvfx_internal.h"
+#include "direct_dispatch.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -273,6 +274,16 @@ hipStream_t host_stream()
     return d.stream;
 }
 
+// 0..3 when `stream` is one of the calling thread's private streams on the current device, else -1
+int thread_stream_index(hipStream_t stream)
+{
+    DeviceState &d = t_state.current();
+    if (stream && stream == d.stream) return 0;
+    for (int k = 0; k < 3; k++)
+        if (stream && stream == d.extra[k]) return k + 1;
+    return -1;
+}
+
 hipStream_t host_stream_n(uint32_t index)
 {
     index %= 4; // documented: the index is taken modulo 4 (4 is stream 0 again)
@@ -419,6 +430,7 @@ int mvfx_event_create(mvfx_event *out)
 int mvfx_event_destroy(mvfx_event event)
 {
     if (!event) return MVFX_OK;
+    direct_event_destroy(reinterpret_cast<hipEvent_t>(event)); // (waits for a lane dispatch the event still stands for)
     MVFX_HIP_TRY(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
     return MVFX_OK;
 }
@@ -427,6 +439,7 @@ int mvfx_event_record(mvfx_event event, mvfx_stream stream)
 {
     if (!event)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "event_record: NULL event");
+    direct_event_forget(reinterpret_cast<hipEvent_t>(event)); // from here on the event means this record
     MVFX_HIP_TRY(hipEventRecord(reinterpret_cast<hipEvent_t>(event), as_stream(stream)));
     return MVFX_OK;
 }
@@ -435,6 +448,13 @@ int mvfx_stream_wait_event(mvfx_stream stream, mvfx_event event)
 {
     if (!event)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "stream_wait_event: NULL event");
+    // A direct fence (the completion signal of a frame that went out on the library's own queue, MVFX_OPT_DIRECT_DISPATCH) is nothing a HIP stream
+    // can wait for on the device: finished (the usual case: a recycled block) -> nothing to do, not even a HIP call; still running -> the CALLING
+    // THREAD waits (tens of microseconds), after which the stream needs no wait either.
+    if (const int st = direct_event_state(reinterpret_cast<hipEvent_t>(event)); st != 0) {
+        if (st == 2) direct_event_wait(reinterpret_cast<hipEvent_t>(event));
+        return MVFX_OK;
+    }
     MVFX_HIP_TRY(hipStreamWaitEvent(as_stream(stream), reinterpret_cast<hipEvent_t>(event), 0));
     return MVFX_OK;
 }
@@ -443,12 +463,16 @@ int mvfx_event_synchronize(mvfx_event event)
 {
     if (!event)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "event_synchronize: NULL event");
+    if (direct_event_state(reinterpret_cast<hipEvent_t>(event)) != 0) return direct_event_wait(reinterpret_cast<hipEvent_t>(event));
     MVFX_HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)));
     return MVFX_OK;
 }
 
 int mvfx_thread_set_completion_event(mvfx_event event)
 {
+    // whatever carries the event next (a kernel's stop event, or the lane's completion signal) gives it its meaning: an earlier lane dispatch it
+    // may still stand for is finished first (never pending in practice: the element layer re-uses a fence only when no block points at it)
+    if (event) direct_event_forget(reinterpret_cast<hipEvent_t>(event));
     t_completion = reinterpret_cast<hipEvent_t>(event);
     t_completion_uses = 0;
     return MVFX_OK;
@@ -466,6 +490,7 @@ int mvfx_event_query(mvfx_event event)
 {
     if (!event)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "event_query: NULL event");
+    if (const int st = direct_event_state(reinterpret_cast<hipEvent_t>(event)); st != 0) return st == 1 ? 1 : 0;
     const hipError_t e = hipEventQuery(reinterpret_cast<hipEvent_t>(event));
     if (e == hipSuccess) return 1;
     if (e == hipErrorNotReady) {
@@ -474,6 +499,10 @@ int mvfx_event_query(mvfx_event event)
     }
     return fail(MVFX_ERR_DEVICE, "event_query: %s", hipGetErrorString(e));
 }
+
+int mvfx_event_is_direct(mvfx_event event) { return event && direct_event_state(reinterpret_cast<hipEvent_t>(event)) != 0 ? 1 : 0; }
+int mvfx_event_direct_queue(mvfx_event event) { return event ? direct_event_queue(reinterpret_cast<hipEvent_t>(event)) : -1; }
+int mvfx_direct_queue_of_stream(mvfx_stream stream) { return direct_queue_hint(as_stream(stream)); }
 
 int mvfx_host_alloc(void **out_ptr, size_t bytes)
 {
@@ -527,7 +556,7 @@ int mvfx_copy_device_to_device_async(void *dst_device, const void *src_device, s
 int mvfx_thread_set_options(uint32_t options)
 {
     const uint32_t known = MVFX_OPT_NONTEMPORAL | MVFX_OPT_HSV_LITERAL | MVFX_OPT_HSV_FORCE_FAST | MVFX_OPT_HSV_VALU_UNORM |
-                           MVFX_OPT_LUT_PLACEMENT_MASK | MVFX_OPT_SSIM_F64 | MVFX_OPT_LUT_WG_WINDOW;
+                           MVFX_OPT_LUT_PLACEMENT_MASK | MVFX_OPT_SSIM_F64 | MVFX_OPT_LUT_WG_WINDOW | MVFX_OPT_DIRECT_DISPATCH | MVFX_OPT_DIRECT_ONLY;
     if (options & ~known)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options 0x%x: unknown bits 0x%x", options, options & ~known);
     if ((options & MVFX_OPT_HSV_LITERAL) && (options & MVFX_OPT_HSV_FORCE_FAST))

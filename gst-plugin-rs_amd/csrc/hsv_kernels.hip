@@ -22,6 +22,7 @@
 //   dependent chain and the four pixels of a group have to be interleaved by the scheduler (+3.8 %).
 #include "hsv_math.hpp"
 #include "hsv_filter_lds.hpp"
+#include "direct_dispatch.h"
 #include "convert_math.hpp"
 #include "mvfx_internal.h"
 
@@ -702,12 +703,32 @@ int hsvfilter_impl(const mvfx_frame *frames, uint32_t n, const mvfx_hsvfilter_se
             fb.base[i] = static_cast<uint8_t *>(frames[done + i].data);
         const Geometry g = plan(frames + done, m, bpp, m, bpp == 4 ? kTile : 1);
         const uint64_t frame_bytes = (uint64_t)frames[0].stride * frames[0].height;
-        if (opt_typed_loads() && use_fast && bpp == 4 && g.mode == kModeVec4 && (g.width & 3) == 0 && frame_bytes < (1ull << 32)) {
+        const bool typed4 = opt_typed_loads() && use_fast && bpp == 4 && g.mode == kModeVec4 && (g.width & 3) == 0 && frame_bytes < (1ull << 32);
+        if (opt_direct_only() && !(typed4 && m == 1 && n == 1 && g.rows == 1 && completion_event()))
+            return fail(MVFX_ERR_DIRECT_UNAVAILABLE, "hsvfilter: not a frame the direct-dispatch lane takes (one unpadded 4-byte frame, strength-reduced settings, a completion event)");
+        if (typed4) {
             // descriptor word 3: DST_SEL x/y/z = the bytes holding R, G, B (4 + byte index), w = 0; NUM_FORMAT UNORM (0);
             // DATA_FORMAT 8_8_8_8 (10)
             const uint32_t iR = off + (bgr ? 2 : 0), iG = off + 1, iB = off + (bgr ? 0 : 2);
             const uint32_t word3 = (4 + iR) | ((4 + iG) << 3) | ((4 + iB) << 6) | (10u << 15);
             const bool neg = std::signbit(s->hue_shift) && s->hue_shift != 0.0f;
+            // the direct-dispatch lane (direct_dispatch.h): ONE flat frame whose dependencies have finished and whose completion the caller takes
+            // from the thread's completion event goes out as an AQL packet without the barrier bit on the library's own queue
+            if (m == 1 && n == 1 && opt_direct() && g.rows == 1 && completion_event()) {
+                DirectHsvArgs da{};
+                da.frame = fb.base[0];
+                da.groups = (uint32_t)(g.width / 4);
+                da.word3 = word3;
+                da.frame_bytes = (uint32_t)frame_bytes;
+                da.off = off;
+                da.bgr = bgr ? 1 : 0;
+                da.p = p;
+                const int drc = direct_hsvfilter_submit(da, neg, opt_nontemporal(), direct_queue_hint(stream));
+                if (drc == MVFX_OK) continue;
+                if (drc < 0) return drc;
+                // (1: the lane is not available here -- the launch below, on `stream`)
+            }
+            if (opt_direct_only()) return fail(MVFX_ERR_DIRECT_UNAVAILABLE, "hsvfilter: the direct-dispatch lane cannot take this frame");
             // EXPERIMENT (round 6): MVFX_EXP_SINGLE=tile,iters[,maxgrid] -- the launch shape of ONE-frame calls
             static const char *exp_single = getenv("MVFX_EXP_SINGLE");
             if (exp_single && m == 1 && !neg && opt_nontemporal() && g.rows == 1) {
@@ -1071,11 +1092,30 @@ int hsvdetector_impl(const mvfx_frame *ins, const mvfx_frame *outs, uint32_t n,
         if (bx > 65535u * 16u) bx = 65535u * 16u;
         const dim3 grid((uint32_t)bx, rows < 65535u ? rows : 65535u, m);
         const uint64_t in_bytes = (uint64_t)in->stride * in->height;
-        if (opt_typed_loads() && vec && variant == kDetFast && bpp == 4 && (width & 3) == 0 && in_bytes < (1ull << 32)) {
+        const bool typed4 = opt_typed_loads() && vec && variant == kDetFast && bpp == 4 && (width & 3) == 0 && in_bytes < (1ull << 32);
+        if (opt_direct_only() && !(typed4 && m == 1 && n == 1 && flat && completion_event() && (uint64_t)out->stride * out->height < (1ull << 32)))
+            return fail(MVFX_ERR_DIRECT_UNAVAILABLE, "hsvdetector: not a frame pair the direct-dispatch lane takes (unpadded 4-byte frames, strength-reduced settings, a completion event)");
+        if (typed4) {
             const uint32_t iR = off + (ibgr ? 2 : 0), iG = off + 1, iB = off + (ibgr ? 0 : 2);
             const uint32_t word3 = (4 + iR) | ((4 + iG) << 3) | ((4 + iB) << 6) | (10u << 15); // see hsvfilter_impl
             const uint32_t o0 = obgr ? iB : iR, o2 = obgr ? iR : iB; // detect_px4_fast's selector, formed at run time
             const uint32_t sel = a0 ? (4u | (o0 << 8) | (iG << 16) | (o2 << 24)) : (o0 | (iG << 8) | (o2 << 16) | (4u << 24));
+            // the direct-dispatch lane (direct_dispatch.h), as in hsvfilter_impl: one flat frame pair whose dependencies have finished or sit in front
+            // of it on the lane queue it takes
+            if (m == 1 && n == 1 && opt_direct() && flat && completion_event() && (uint64_t)out->stride * out->height < (1ull << 32)) {
+                DirectDetArgs da{};
+                da.in = ifb.base[0];
+                da.out = ofb.base[0];
+                da.groups = (uint32_t)(width / 4);
+                da.word3 = word3;
+                da.in_bytes = (uint32_t)in_bytes;
+                da.perm_sel = sel;
+                da.p = p;
+                const int drc = direct_hsvdetector_submit(da, direct_queue_hint(stream));
+                if (drc == MVFX_OK) continue;
+                if (drc < 0) return drc;
+            }
+            if (opt_direct_only()) return fail(MVFX_ERR_DIRECT_UNAVAILABLE, "hsvdetector: the direct-dispatch lane cannot take this frame");
             dim3 tgrid = grid; // MVFX_DET_TILE groups per lane
             tgrid.x = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((work + (uint64_t)kBlock * MVFX_DET_TILE - 1) / ((uint64_t)kBlock * MVFX_DET_TILE), 65535u * 16u));
             MVFX_LAUNCH(hsvdetector_typed_kernel, tgrid, dim3(kBlock), 0, stream, ifb, ofb, width, rows, is, os, p, word3, (uint32_t)in_bytes, sel);

@@ -54,12 +54,15 @@ uint32_t thread_options();
 inline int opt_hsv_variant() { const uint32_t o = thread_options(); return (o & MVFX_OPT_HSV_LITERAL) ? 1 : ((o & MVFX_OPT_HSV_FORCE_FAST) ? 2 : 0); }
 inline bool opt_nontemporal() { return (thread_options() & MVFX_OPT_NONTEMPORAL) != 0; }
 inline bool opt_typed_loads() { return (thread_options() & MVFX_OPT_HSV_VALU_UNORM) == 0; }
+inline bool opt_direct() { return (thread_options() & MVFX_OPT_DIRECT_DISPATCH) != 0; }
+inline bool opt_direct_only() { return (thread_options() & (MVFX_OPT_DIRECT_DISPATCH | MVFX_OPT_DIRECT_ONLY)) == (MVFX_OPT_DIRECT_DISPATCH | MVFX_OPT_DIRECT_ONLY); }
 inline int opt_lut_placement() { return (int)((thread_options() & MVFX_OPT_LUT_PLACEMENT_MASK) >> MVFX_OPT_LUT_PLACEMENT_SHIFT); }
 
 // Grow-only device scratch used by the *_host entry points (one per thread and device).
 int host_scratch(size_t bytes, int slot, void **out);
 hipStream_t host_stream();
 hipStream_t host_stream_n(uint32_t index); // 0 = host_stream(), 1..3 = further private streams of the calling thread
+int thread_stream_index(hipStream_t stream); // 0..3: `stream` is that private stream of the calling thread (current device); -1: it is not
 // Grow-only device scratch keyed by (thread, device, stream): intermediate results handed from one launch to the next on `stream`.
 int stream_scratch(hipStream_t stream, size_t bytes, void **out);
 

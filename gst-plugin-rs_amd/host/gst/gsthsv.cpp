@@ -171,8 +171,24 @@ static GstFlowReturn gst_hsv_filter_bt_transform_ip(GstBaseTransform *bt, GstBuf
         mvfx_hip_fence_end(&dfs, st, NULL, GST_OBJECT(self));
         return MVFX_GST_FLOW(self, rc);
     }
-    mvfx_hip_buffer_acquire(buf, st);
+    // The direct-dispatch lane (round 6, MVFX_OPT_DIRECT_DISPATCH): when nothing is pending on the block -- the usual state of a recycled block --
+    // the library may send the frame's kernel out on its own queue, without the release fence a stream's kernel packets carry: one call per buffer
+    // faster than a batched launch on a stream (csrc/direct_dispatch.h).  Not when a consumer close behind had to wait for such a fence on its thread
+    // (mvfx_direct_discouraged), not with the launch combiner.
     MvfxFenceScope fs; // the fence rides on the kernel; recorded behind it where no kernel of this thread took it (the combiner's launches)
+    if (combine == 0 && !mvfx_direct_discouraged(self) && mvfx_hip_buffer_acquire_direct(buf, st, mvfx_direct_queue_of_stream(st))) {
+        mvfx_hip_fence_begin_buffers(&fs, buf, NULL, st);
+        mvfx_thread_set_options(MVFX_OPT_DIRECT_DISPATCH | MVFX_OPT_DIRECT_ONLY);
+        rc = mvfx_hsvfilter_transform_frame_ip(&f, &s, st);
+        mvfx_thread_set_options(0);
+        if (rc != MVFX_ERR_DIRECT_UNAVAILABLE) {
+            mvfx_hip_fence_end(&fs, st, NULL, GST_OBJECT(self));
+            gst_buffer_unmap(buf, &map);
+            return MVFX_GST_FLOW(self, rc);
+        }
+        mvfx_hip_fence_cancel(&fs); // not a frame for the lane (row padding, RGB / BGR, literal-kernel settings, no HSA queue): the stream it is
+    }
+    mvfx_hip_buffer_acquire(buf, st);
     mvfx_hip_fence_begin_buffers(&fs, buf, NULL, st);
     rc = combine == 1 ? mvfx_hsvfilter_transform_frame_ip_combined(&f, &s, st) : mvfx_hsvfilter_transform_frame_ip(&f, &s, st);
     mvfx_hip_fence_end(&fs, st, NULL, GST_OBJECT(self));
@@ -193,6 +209,7 @@ static gboolean gst_hsv_filter_stop(GstBaseTransform *bt)
     GstHsvFilter *self = reinterpret_cast<GstHsvFilter *>(bt);
     mvfx_pair_stop(self->hold, GST_OBJECT(bt), &gst_hsv_filter_pair_ops);
     mvfx_pair_print_stats(self->hold, GST_OBJECT(bt), "hsvfilter");
+    mvfx_direct_reset(self); // the next run finds out again whether somebody waits close behind its frames
     return TRUE;
 }
 
@@ -421,9 +438,26 @@ static GstFlowReturn gst_hsv_detector_bt_transform(GstBaseTransform *bt, GstBuff
         mvfx_hip_fence_end(&dfs, st, NULL, GST_OBJECT(self));
         return MVFX_GST_FLOW(self, drc);
     }
+    MvfxFenceScope fs; // one fence for both buffers (the reader's too: the input block may be recycled and overwritten next), on the kernel
+    // The direct-dispatch lane, as in hsvfilter: the frame pair goes out on the lane queue its stream maps to -- the queue the filter in front of
+    // this element used for the same frame (both pick the stream from the buffer's frame number), so the filter's kernel sits in front of ours in
+    // an in-order queue and nobody waits for anybody on a host thread.
+    const int lane_queue = mvfx_direct_queue_of_stream(st);
+    if (!i420 && !mvfx_direct_discouraged(self) && mvfx_hip_buffer_acquire_direct(inbuf, st, lane_queue) && mvfx_hip_buffer_acquire_direct(outbuf, st, lane_queue)) {
+        mvfx_hip_fence_begin_buffers(&fs, inbuf, outbuf, st);
+        mvfx_thread_set_options(MVFX_OPT_DIRECT_DISPATCH | MVFX_OPT_DIRECT_ONLY);
+        const int drc = mvfx_hsvdetector_transform_frame(&fi, &fo, &s, st);
+        mvfx_thread_set_options(0);
+        if (drc != MVFX_ERR_DIRECT_UNAVAILABLE) {
+            mvfx_hip_fence_end(&fs, st, NULL, GST_OBJECT(self));
+            gst_buffer_unmap(outbuf, &omap);
+            gst_buffer_unmap(inbuf, &imap);
+            return MVFX_GST_FLOW(self, drc);
+        }
+        mvfx_hip_fence_cancel(&fs);
+    }
     mvfx_hip_buffer_acquire(inbuf, st);
     mvfx_hip_buffer_acquire(outbuf, st);
-    MvfxFenceScope fs; // one fence for both buffers (the reader's too: the input block may be recycled and overwritten next), on the kernel
     mvfx_hip_fence_begin_buffers(&fs, inbuf, outbuf, st);
     int rc = i420 ? mvfx_hsvdetector_transform_i420(&pi, &fo, &s, 0, st) : mvfx_hsvdetector_transform_frame(&fi, &fo, &s, st);
     mvfx_hip_fence_end(&fs, st, NULL, GST_OBJECT(self));
@@ -444,6 +478,7 @@ static gboolean gst_hsv_detector_stop(GstBaseTransform *bt)
 {
     mvfx_pair_stop(reinterpret_cast<GstHsvDetector *>(bt)->hold, GST_OBJECT(bt), &gst_hsv_detector_pair_ops);
     mvfx_pair_print_stats(reinterpret_cast<GstHsvDetector *>(bt)->hold, GST_OBJECT(bt), "hsvdetector");
+    mvfx_direct_reset(bt);
     return TRUE;
 }
 

@@ -278,6 +278,101 @@ static gboolean deferred_is_owners(MvfxHipMemory *m, GstObject *owner)
     return mine;
 }
 
+// ---- producers whose direct fences a consumer had to wait for on its own thread (mvfxhipmemory.h) ----
+#define MVFX_DISCOURAGED_MAX 64
+static GMutex discouraged_lock;
+static const void *discouraged[MVFX_DISCOURAGED_MAX];
+static gint discouraged_n; // read without the lock on the fast path
+
+gboolean mvfx_direct_discouraged(const void *tag)
+{
+    if (!tag || g_atomic_int_get(&discouraged_n) == 0) return FALSE;
+    gboolean hit = FALSE;
+    g_mutex_lock(&discouraged_lock);
+    for (gint i = 0; i < discouraged_n && !hit; i++) hit = discouraged[i] == tag;
+    g_mutex_unlock(&discouraged_lock);
+    return hit;
+}
+
+static void direct_discourage(const void *tag)
+{
+    if (!tag) return;
+    g_mutex_lock(&discouraged_lock);
+    gboolean hit = FALSE;
+    for (gint i = 0; i < discouraged_n && !hit; i++) hit = discouraged[i] == tag;
+    if (!hit && discouraged_n < MVFX_DISCOURAGED_MAX) {
+        discouraged[discouraged_n] = tag;
+        g_atomic_int_set(&discouraged_n, discouraged_n + 1);
+    }
+    g_mutex_unlock(&discouraged_lock);
+}
+
+void mvfx_direct_reset(const void *tag)
+{
+    g_mutex_lock(&discouraged_lock);
+    for (gint i = 0; i < discouraged_n; i++)
+        if (discouraged[i] == tag) {
+            discouraged[i] = discouraged[discouraged_n - 1];
+            g_atomic_int_set(&discouraged_n, discouraged_n - 1);
+            break;
+        }
+    g_mutex_unlock(&discouraged_lock);
+}
+
+// a consumer's stream "waits" for a block's fence: a direct fence that has not fired makes the calling thread wait -- its producer is told
+static void wait_for_fence(mvfx_stream stream, mvfx_event ev, const void *producer_tag)
+{
+    if (producer_tag && mvfx_event_is_direct(ev) && mvfx_event_query(ev) != 1) direct_discourage(producer_tag);
+    mvfx_stream_wait_event(stream, ev);
+}
+
+gboolean mvfx_hip_buffer_acquire_direct(GstBuffer *buf, mvfx_stream stream, int queue)
+{
+    for (guint i = 0; buf && i < gst_buffer_n_memory(buf); i++) {
+        GstMemory *mem = gst_buffer_peek_memory(buf, i);
+        if (!mvfx_is_hip_memory(mem)) return FALSE;
+        MvfxHipMemory *m = (MvfxHipMemory *)mem;
+        MvfxFence *other = NULL;
+        g_mutex_lock(&m->lock);
+        gboolean ok = m->deferred_flush == NULL && (!m->borrowed || mvfx_event_query(m->borrowed) == 1);
+        if (ok && m->pending && m->fence) {
+            if (mvfx_event_query(m->fence->ev) == 1)
+                m->pending = FALSE; // seen finished: nobody has to wait for it any more
+            else if (!mvfx_event_is_direct(m->fence->ev))
+                ok = FALSE;         // an ordinary fence still pending: this frame's place is behind it on a stream
+            else if (mvfx_event_direct_queue(m->fence->ev) != queue)
+                other = fence_ref(m->fence); // a direct dispatch on the lane's OTHER queue: waited for below
+            // (else: a direct dispatch in front of ours on the same lane queue -- the queue is in order, nothing to do)
+        }
+        g_mutex_unlock(&m->lock);
+        if (other) {
+            // e.g. this element's own dispatch on the block a pool's worth of frames ago (an odd pool): the streaming thread is that far ahead of the
+            // device, and waiting here is the back-pressure a bounded queue gives -- the device has the frames in between to work on
+            mvfx_event_synchronize(other->ev);
+            g_mutex_lock(&m->lock);
+            ok = m->fence == other && m->deferred_flush == NULL && !m->borrowed; // (nobody else came in between)
+            if (ok) m->pending = FALSE;
+            g_mutex_unlock(&m->lock);
+            fence_unref(other);
+        }
+        if (!ok) return FALSE;
+        g_mutex_lock(&m->lock);
+        m->acq_seq = m->fence_seq; // (the fence scope's chaining then has nothing to wait for on `stream`)
+        m->acq_stream = stream;
+        g_mutex_unlock(&m->lock);
+    }
+    return buf != NULL;
+}
+
+void mvfx_hip_fence_cancel(MvfxFenceScope *sc)
+{
+    if (sc->n == 0) return;
+    mvfx_thread_clear_completion_event();
+    fence_unref((MvfxFence *)sc->fence);
+    sc->fence = NULL;
+    sc->n = 0;
+}
+
 void mvfx_hip_memory_acquire(GstMemory *mem, mvfx_stream stream) { mvfx_hip_memory_acquire_as_owner(mem, stream, NULL); }
 
 // Somebody else's held-back work on the block, run now.  An element that launches under its own lock (mvfx_pair_hold.h, hsvfilter)
@@ -302,7 +397,7 @@ void mvfx_hip_memory_acquire_as_owner(GstMemory *mem, mvfx_stream stream, GstObj
     if (m->borrowed)
         mvfx_stream_wait_event(stream, m->borrowed);
     if (m->pending && m->fence && m->fence_stream != stream)
-        mvfx_stream_wait_event(stream, m->fence->ev); // device-side wait; the host goes on (same stream: in order anyway)
+        wait_for_fence(stream, m->fence->ev, m->fence_owner); // device-side wait; the host goes on (same stream: in order anyway)
     m->acq_seq = m->fence_seq;
     m->acq_stream = stream;
     g_mutex_unlock(&m->lock);
@@ -364,7 +459,7 @@ static void group_phase_a(MvfxFenceScope *sc, GstMemory *const *mems, guint n, m
         MvfxHipMemory *m = (MvfxHipMemory *)sc->mems[i];
         g_mutex_lock(&m->lock);
         if (m->fence && m->pending && m->fence_stream != stream && !(m->acq_seq == m->fence_seq && m->acq_stream == stream))
-            mvfx_stream_wait_event(stream, m->fence->ev);
+            wait_for_fence(stream, m->fence->ev, m->fence_owner);
         if (m->borrowed) { // same chaining for a fence somebody else recorded; the record then covers it
             mvfx_stream_wait_event(stream, m->borrowed);
             m->borrowed = NULL;
@@ -376,6 +471,8 @@ static void group_phase_a(MvfxFenceScope *sc, GstMemory *const *mems, guint n, m
 
 static void group_phase_b(MvfxFenceScope *sc, mvfx_stream stream, GstObject *owner, const void *tag, MvfxFence *f)
 {
+    // a DIRECT fence (the launch went out on the library's own queue): no stream of anybody's is ordered behind the work it stands for
+    const gboolean direct = f && mvfx_event_is_direct(f->ev);
     if (!f) mvfx_stream_synchronize(stream); // no event: fall back to a blocking hand-off
     for (guint i = 0; i < sc->n; i++) {
         MvfxHipMemory *m = (MvfxHipMemory *)sc->mems[i];
@@ -385,6 +482,7 @@ static void group_phase_b(MvfxFenceScope *sc, mvfx_stream stream, GstObject *own
         if (m->fence_seq != sc->seen[i] && m->fence && m->pending) {
             // recorded on in between: wait for that too, and a later fence of this block's own covers both
             mvfx_stream_wait_event(stream, m->fence->ev);
+            if (direct) mvfx_stream_wait_event(stream, f->ev); // (the new record must cover the lane's kernel as well: the calling thread waits for it)
             fence_unref(mine);
             mine = fence_get();
             if (mine && mvfx_event_record(mine->ev, stream) != MVFX_OK) {
@@ -397,7 +495,7 @@ static void group_phase_b(MvfxFenceScope *sc, mvfx_stream stream, GstObject *own
         m->fence = mine;
         m->pending = mine != NULL;
         m->fence_seq++;
-        m->fence_stream = stream;
+        m->fence_stream = direct && mine == f ? (mvfx_stream)(gintptr)-1 : stream;
         m->fence_owner = tag;
         if (owner && m->deferred_flush && m->deferred_owner == owner) {
             drop = m->deferred_owner;
@@ -467,7 +565,7 @@ void mvfx_hip_fence_end(MvfxFenceScope *sc, mvfx_stream stream, GstObject *owner
         f = NULL;
     }
     static const gboolean check = g_getenv("MVFX_FENCE_CHECK") != NULL && atoi(g_getenv("MVFX_FENCE_CHECK")) != 0;
-    if (check && f && carried > 0) {
+    if (check && f && carried > 0 && !mvfx_event_is_direct(f->ev)) { // (a direct fence is not on the stream: its draining says nothing)
         // the stream drained, so the fence must have fired (the other direction -- a fence that fires BEFORE a trailing copy of the call
         // has finished -- cannot be seen from here; the contract above is kept by review: every entry the elements call under a fence
         // scope ends in MVFX_LAUNCH; `grep -n hipLaunchKernelGGL csrc/` finds the macro itself and colorlut's content probe, which is launched

@@ -59,6 +59,22 @@ void mvfx_hip_memories_release_as_owner(GstMemory *const *mems, guint n, void *s
 void mvfx_hip_memory_acquire_as_owner(GstMemory *mem, void *stream, GstObject *owner);
 void mvfx_hip_memory_release_as_owner(GstMemory *mem, void *stream, GstObject *owner);
 void *mvfx_hip_memory_pending_fence(GstMemory *mem);
+// ---- the direct-dispatch lane (round 6; include/mi355vfx.h MVFX_OPT_DIRECT_DISPATCH) as the elements use it ----
+// The acquire of a frame that is to go out on lane queue `queue` (mvfx_direct_queue_of_stream(stream)).  TRUE when every block of the buffer is
+// free to be worked on by such a dispatch: no held-back work, no borrowed fence still running, and the block's own fence either fired, or a direct
+// dispatch IN FRONT of ours on the same lane queue (the queues are in order: a filter's frame and the detector that reads it), or a direct dispatch
+// on the other queue -- for which the streaming thread waits here (a pool's worth of frames ahead of the device: the back-pressure of a bounded
+// queue).  FALSE: an ordinary stream fence is still pending (a source's copy, a stream kernel): acquire and launch on the stream as ever.
+// After TRUE the element opens its fence scope and calls the library with MVFX_OPT_DIRECT_DISPATCH | MVFX_OPT_DIRECT_ONLY; on
+// MVFX_ERR_DIRECT_UNAVAILABLE it cancels the scope (mvfx_hip_fence_cancel) and takes the ordinary path.
+gboolean mvfx_hip_buffer_acquire_direct(GstBuffer *buf, void *stream, int queue);
+void mvfx_hip_fence_cancel(MvfxFenceScope *scope);
+// A consumer that found a direct fence still PENDING had to wait on its own thread (a HIP stream cannot wait for it on the device): the producer
+// named by the fence's tag is told, and goes back to launching on its streams -- a direct dispatch pays where nobody is close behind the frame
+// (hsvfilter ! fakesink, ! queue ! encoder ...), inside a tight device chain (hsvfilter ! hsvdetector on one thread) the stream order is the
+// better fence.  _reset at start().
+gboolean mvfx_direct_discouraged(const void *producer_tag);
+void mvfx_direct_reset(const void *producer_tag);
 void mvfx_hip_memory_set_borrowed_fence(GstMemory *mem, void *event);
 void mvfx_hip_buffer_acquire(GstBuffer *buf, void *stream);
 void mvfx_hip_buffer_release(GstBuffer *buf, void *stream);

@@ -68,7 +68,8 @@ typedef enum mvfx_status {
     MVFX_ERR_IO = -7,                /* .cube file unreadable (CubeParseError::Io) */
     MVFX_ERR_REFERENCE_PANIC = -8,   /* input on which the reference panics (assert_eq!, slice range) */
     MVFX_ERR_NO_LUT = -9,            /* colorlut without a parsed LUT (colorlut/imp.rs:209-213) */
-    MVFX_ERR_OUT_OF_MEMORY = -10
+    MVFX_ERR_OUT_OF_MEMORY = -10,
+    MVFX_ERR_DIRECT_UNAVAILABLE = -11 /* MVFX_OPT_DIRECT_ONLY: the direct-dispatch lane cannot take this frame; nothing was launched */
 } mvfx_status;
 
 /* hipStream_t passed through as an opaque pointer; NULL selects the null stream. */
@@ -123,6 +124,14 @@ int mvfx_stream_wait_event(mvfx_stream stream, mvfx_event event);
 int mvfx_event_synchronize(mvfx_event event);
 /* 1: everything recorded before the event has finished; 0: still running (hipEventQuery -> hipErrorNotReady); < 0: MVFX_ERR_*.  Never blocks. */
 int mvfx_event_query(mvfx_event event);
+/* 1: the event's last "record" was a direct dispatch (MVFX_OPT_DIRECT_DISPATCH): no stream is ordered behind the work it stands for.  0: an ordinary
+ * event (recorded on a stream, or carried by a kernel of a stream as its stop event), or never used. */
+int mvfx_event_is_direct(mvfx_event event);
+/* The lane queue (0 or 1) of the dispatch a direct fence stands for, -1 when the event is not a direct fence; and the queue a call with
+ * MVFX_OPT_DIRECT_DISPATCH and this `stream` takes: the parity of the stream's index among the calling thread's private streams
+ * (mvfx_thread_stream_n), a pointer hash for other streams.  Two dispatches on one queue run in the order they were made. */
+int mvfx_event_direct_queue(mvfx_event event);
+int mvfx_direct_queue_of_stream(mvfx_stream stream);
 /* The fence without a barrier packet.  While a completion event is set on the calling thread, every kernel the thread launches
  * through this library carries it as the stop event of its own dispatch (hipExtLaunchKernelGGL): the event is recorded when the
  * kernel finishes, with no packet of its own behind it -- hipEventRecord behind every 4K launch costs 2.6 us of device time
@@ -167,6 +176,23 @@ int mvfx_copy_device_to_device_async(void *dst_device, const void *src_device, s
 #define MVFX_OPT_LUT_WG_WINDOW 0x100u  /* colorlut, placement 0 on RGBA8 frames and cubes of 5+ points: always the workgroup-window kernel
                                           (by default a content probe of an earlier frame of the LUT's stream chooses between it -- busy
                                           pictures -- and the per-wave windows of placement 7 -- calm ones; same bytes either way) */
+#define MVFX_OPT_DIRECT_DISPATCH 0x200u /* hsvfilter, ONE frame per call (mvfx_hsvfilter_transform_frame_ip), packed 4-byte formats without row padding, settings in
+                                          the strength-reduced kernels' domain, a completion event set on the thread: the library may enqueue the frame's
+                                          kernel on a queue of ITS OWN instead of `stream` -- a hand-written AQL packet without the release fence every
+                                          kernel dispatch of a HIP stream carries (an L2 write-back walk on eight XCDs; the lane's kernels store
+                                          write-through instead): one 4K frame per call 12.3 us on two alternating streams, 11.0 this way
+                                          (csrc/direct_dispatch.h).  Also mvfx_hsvdetector_transform_frame, 4-byte input formats.  What the caller promises
+                                          by setting the bit: (1) everything the frame depends on has FINISHED (nothing of it is merely enqueued on `stream`)
+                                          or is itself a direct dispatch on the lane queue this call takes -- mvfx_direct_queue_of_stream(stream); the lane's
+                                          two queues are each in order --, (2) it takes the frame's completion from the thread's completion event only, NOT
+                                          from the order of `stream`.
+                                          That event is then a DIRECT fence: mvfx_event_query / _synchronize work as ever; mvfx_stream_wait_event returns at
+                                          once when it has fired and otherwise makes the calling THREAD wait (a HIP stream cannot wait for it on the device).
+                                          A frame or a box the lane cannot take (row padding, RGB / BGR, literal-kernel settings, MVFX_DIRECT_DISPATCH=0, no
+                                          HSA queue) is launched on `stream` as if the bit were clear; mvfx_event_is_direct says which it was.  Same bytes. */
+#define MVFX_OPT_DIRECT_ONLY 0x400u     /* with MVFX_OPT_DIRECT_DISPATCH: a frame the lane cannot take is NOT launched on `stream`; the call returns
+                                          MVFX_ERR_DIRECT_UNAVAILABLE and has done nothing (a caller whose promise (1) rests on the lane's queue order must
+                                          not be moved to a stream behind its back) */
 int mvfx_thread_set_options(uint32_t options);
 uint32_t mvfx_thread_options(void);
 

@@ -40,11 +40,39 @@ static hsa_status_t pick_region(hsa_region_t r, void *)
     return HSA_STATUS_SUCCESS;
 }
 
+static hsa_agent_t g_cpu;
+static bool g_have_cpu = false;
+static hsa_amd_memory_pool_t g_devpool;
+static bool g_have_devpool = false;
+static hsa_status_t pick_cpu(hsa_agent_t a, void *)
+{
+    hsa_device_type_t t;
+    hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t);
+    if (t == HSA_DEVICE_TYPE_CPU && !g_have_cpu) { g_cpu = a; g_have_cpu = true; }
+    return HSA_STATUS_SUCCESS;
+}
+static hsa_status_t pick_devpool(hsa_amd_memory_pool_t p, void *)
+{
+    hsa_amd_segment_t seg;
+    uint32_t flags = 0;
+    bool alloc = false;
+    hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg);
+    hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+    hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc);
+    if (seg == HSA_AMD_SEGMENT_GLOBAL && (flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_COARSE_GRAINED) && alloc && !g_have_devpool) { g_devpool = p; g_have_devpool = true; }
+    return HSA_STATUS_SUCCESS;
+}
+
 struct Args { uint8_t *base; uint32_t n_groups; uint32_t key; };
+// the argument block of the library's direct-dispatch kernels (gst-plugin-rs_amd/csrc/direct_dispatch.h), for `aql_scope.bin <hsaco> <kernel>.kd`:
+// the real hsvfilter kernel through the same packets (timing only: the 20 floats are arbitrary finite values)
+struct DirectArgs { uint8_t *frame; uint32_t groups, word3, frame_bytes; int32_t off, bgr; uint32_t reserved; float p[20]; };
 
 int main(int argc, char **argv)
 {
     const char *hsaco = argc > 1 ? argv[1] : "tools/probes/aql_scope_kernel.hsaco";
+    const char *kname = argc > 2 ? argv[2] : "rmw_kernel.kd";
+    const bool real = argc > 2;
     HIP_OK(hipSetDevice(0));
     const uint32_t W = 3840, H = 2160, NF = 16;
     const size_t FB = (size_t)W * H * 4;
@@ -73,7 +101,7 @@ int main(int argc, char **argv)
     HSA_OK(hsa_executable_load_agent_code_object(exe, g_gpu, reader, nullptr, nullptr));
     HSA_OK(hsa_executable_freeze(exe, nullptr));
     hsa_executable_symbol_t sym;
-    HSA_OK(hsa_executable_get_symbol_by_name(exe, "rmw_kernel.kd", &g_gpu, &sym));
+    HSA_OK(hsa_executable_get_symbol_by_name(exe, kname, &g_gpu, &sym));
     uint64_t kobj = 0; uint32_t kasize = 0, lds = 0, priv = 0;
     HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &kobj));
     HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &kasize));
@@ -82,10 +110,34 @@ int main(int argc, char **argv)
     printf("# kernel object %#llx, kernarg %u B, LDS %u, private %u\n", (unsigned long long)kobj, kasize, lds, priv);
     const uint32_t slot = (kasize + 63u) & ~63u, nslots = 4096;
     char *kargs = nullptr;
-    HSA_OK(hsa_memory_allocate(g_kernarg, (size_t)slot * nslots, reinterpret_cast<void **>(&kargs)));
+    // AQL_DEV_KERNARG=1: the argument blocks in DEVICE memory (the GPU's coarse-grained pool, made accessible to the CPU: written through the BAR), as
+    // HIP places them (HIP_FORCE_DEV_KERNARG): a wave's first s_load then reads HBM instead of crossing PCIe to host memory
+    const bool devk = getenv("AQL_DEV_KERNARG") && atoi(getenv("AQL_DEV_KERNARG"));
+    if (devk) {
+        HSA_OK(hsa_iterate_agents(pick_cpu, nullptr));
+        HSA_OK(hsa_amd_agent_iterate_memory_pools(g_gpu, pick_devpool, nullptr));
+        if (!g_have_cpu || !g_have_devpool) { fprintf(stderr, "no CPU agent / device pool\n"); return 2; }
+        HSA_OK(hsa_amd_memory_pool_allocate(g_devpool, (size_t)slot * nslots, 0, reinterpret_cast<void **>(&kargs)));
+        HSA_OK(hsa_amd_agents_allow_access(1, &g_cpu, nullptr, kargs));
+        printf("# kernel arguments in device memory %p (written by the CPU through the BAR)\n", (void *)kargs);
+    } else {
+        HSA_OK(hsa_memory_allocate(g_kernarg, (size_t)slot * nslots, reinterpret_cast<void **>(&kargs)));
+    }
     memset(kargs, 0, (size_t)slot * nslots);
     const uint32_t n_groups = W * H / 4, wgs = (n_groups + 511) / 512;
-    for (uint32_t i = 0; i < nslots; i++) { Args a{pool + (size_t)(i % NF) * FB, n_groups, 0x01010101u * (1 + i % 3)}; memcpy(kargs + (size_t)i * slot, &a, sizeof a); }
+    for (uint32_t i = 0; i < nslots; i++) {
+        if (real) {
+            DirectArgs a{};
+            a.frame = pool + (size_t)(i % NF) * FB; a.groups = n_groups; a.word3 = 4u | (5u << 3) | (6u << 6) | (10u << 15); a.frame_bytes = (uint32_t)FB;
+            for (int k = 0; k < 20; k++) a.p[k] = 0.25f + 0.01f * k;
+            if (sizeof a != kasize) { fprintf(stderr, "argument block %zu != kernarg %u\n", sizeof a, kasize); return 2; }
+            memcpy(kargs + (size_t)i * slot, &a, sizeof a);
+        } else {
+            Args a{pool + (size_t)(i % NF) * FB, n_groups, 0x01010101u * (1 + i % 3)};
+            memcpy(kargs + (size_t)i * slot, &a, sizeof a);
+        }
+    }
+    if (devk) { __builtin_ia32_sfence(); volatile char sink = kargs[(size_t)slot * nslots - 1]; (void)sink; } // the writes have landed
     hsa_queue_t *q[2];
     for (int k = 0; k < 2; k++) HSA_OK(hsa_queue_create(g_gpu, 4096, HSA_QUEUE_TYPE_MULTI, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q[k]));
     const int kSig = 64;
@@ -140,7 +192,7 @@ int main(int argc, char **argv)
     const char *names[3] = {"none", "agent", "system"};
     printf("# us per 4K frame (33.2 MB read + 33.2 MB written per dispatch); 11.06 us = 6.0 TB/s\n");
     printf("# %-7s %-7s %-7s %-6s %-10s %s\n", "acquire", "release", "barrier", "queues", "signal", "us/frame");
-    const int combos[][2] = {{2, 2}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
+    const int combos[][2] = {{1, 1}, {1, 0}, {0, 0}};
     for (int nq = 1; nq <= 2; nq++)
         for (int barrier = 1; barrier >= 0; barrier--)
             for (const auto &c : combos)
