@@ -1608,7 +1608,9 @@ def hsvfilter_main(args):
             took = ctypes.c_uint64()
             w.sync()
             w.barrier()
-            rc = hb.mvfxbench_hsvfilter_direct(w.device_index, 200, n1, reps, flat, nthr * fpt, ctypes.byref(settings), options, secs, ctypes.byref(took))
+            # (its own settle: the leg starts a thread, builds the lane on first use and creates its events -- milliseconds of idle GPU during which the
+            # clock governor steps down, and 200 launches are 2.4 ms)
+            rc = hb.mvfxbench_hsvfilter_direct(w.device_index, 12000, n1, reps, flat, nthr * fpt, ctypes.byref(settings), options, secs, ctypes.byref(took))
             if rc != 0:
                 raise RuntimeError(f"mvfxbench status {rc}: {vfx.last_error()}")
             w.barrier()

@@ -261,9 +261,12 @@ int mvfxbench_hsvfilter_direct(int device, uint32_t warmup, uint32_t launches, u
         constexpr uint32_t kEvents = 32;
         mvfx_event ev[kEvents] = {};
         for (uint32_t k = 0; k < kEvents && rc == MVFX_OK; k++) rc = mvfx_event_create(&ev[k]);
-        mvfx_stream st = mvfx_thread_stream();
+        // consecutive frames alternate between the thread's first two streams, as the elements do (mvfx_element_stream: by frame number): the
+        // stream decides which of the lane's two in-order queues a dispatch takes
+        mvfx_stream sts[2] = {mvfx_thread_stream_n(0), mvfx_thread_stream_n(1)};
         uint64_t n = 0;
         auto one = [&](uint32_t i, bool count) {
+            mvfx_stream st = sts[n & 1];
             mvfx_event e = ev[n % kEvents];
             if (n >= kEvents) rc = mvfx_event_synchronize(e);
             n++;

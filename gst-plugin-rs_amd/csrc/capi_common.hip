@@ -135,12 +135,6 @@ struct ThreadState {
 thread_local ThreadState t_state;
 } // namespace
 
-int exp_launch_flags()
-{
-    static const int f = [] { const char *e = getenv("MVFX_EXP_ANYORDER"); return e && atoi(e) ? (int)hipExtAnyOrderLaunch : 0; }();
-    return f;
-}
-
 int fail(int status, const char *fmt, ...)
 {
     va_list ap;

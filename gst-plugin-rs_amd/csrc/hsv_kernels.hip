@@ -729,21 +729,19 @@ int hsvfilter_impl(const mvfx_frame *frames, uint32_t n, const mvfx_hsvfilter_se
                 // (1: the lane is not available here -- the launch below, on `stream`)
             }
             if (opt_direct_only()) return fail(MVFX_ERR_DIRECT_UNAVAILABLE, "hsvfilter: the direct-dispatch lane cannot take this frame");
-            // EXPERIMENT (round 6): MVFX_EXP_SINGLE=tile,iters[,maxgrid] -- the launch shape of ONE-frame calls
-            static const char *exp_single = getenv("MVFX_EXP_SINGLE");
-            if (exp_single && m == 1 && !neg && opt_nontemporal() && g.rows == 1) {
-                int et = 2, ei = 1, eg = 0;
-                sscanf(exp_single, "%d,%d,%d", &et, &ei, &eg);
-                const uint64_t per = (uint64_t)kBlock * et * ei;
-                dim3 eg3 = g.grid;
-                eg3.x = (uint32_t)((g.width / 4 + per - 1) / per);
-                if (eg > 0 && eg3.x > (uint32_t)eg) eg3.x = (uint32_t)eg;
-                launch_hsvfilter_typed(false, et, true, eg3, stream, fb, g.width, g.rows, g.stride, p, word3, (uint32_t)frame_bytes, off, bgr, ei);
-                MVFX_HIP_TRY(hipGetLastError());
-                continue;
-            }
             launch_hsvfilter_typed(neg, g.tile == kTile ? kTile : 1, opt_nontemporal(), g.grid, stream, fb, g.width, g.rows, g.stride, p, word3,
                                    (uint32_t)frame_bytes, off, bgr);
+            MVFX_HIP_TRY(hipGetLastError());
+            continue;
+        }
+        if (opt_typed_loads() && use_fast && bpp == 3 && g.mode == kModeVec4 && (g.width & 3) != 0 && g.rows > 1 && frame_bytes < (1ull << 32) &&
+            (uint64_t)g.rows * (g.width / 4) * (g.width / 4) < (1ull << 32)) {
+            // a width that is not a multiple of four (the frame is row-padded: plan() did not flatten it): the frame's groups as ONE index space +
+            // a lane per trailing pixel (hsvfilter3_typed_rows_kernel; the condition above keeps its reciprocal division exact)
+            const uint32_t r0 = bgr ? 2 : 0, b0 = bgr ? 0 : 2;
+            const uint32_t word3a = (4 + r0) | (5u << 3) | ((4 + b0) << 6) | (10u << 15), word3b = (5 + r0) | (6u << 3) | ((5 + b0) << 6) | (10u << 15);
+            const bool neg = std::signbit(s->hue_shift) && s->hue_shift != 0.0f;
+            launch_hsvfilter3_typed_rows(neg, opt_nontemporal(), m, stream, fb, (uint32_t)g.width, g.rows, (uint32_t)g.stride, p, word3a, word3b, (uint32_t)frame_bytes, bgr);
             MVFX_HIP_TRY(hipGetLastError());
             continue;
         }

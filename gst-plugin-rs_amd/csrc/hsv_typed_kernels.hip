@@ -4,6 +4,7 @@
 // LLVM's default GCN scheduler and 86.2 k with the iterative-ilp strategy hsv_kernels.hip is built with).
 #include "hsv_filter_lds.hpp"
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -23,7 +24,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <int VARIANT, int TILE, bool NT, int ITERS = 1>
+template <int VARIANT, int TILE, bool NT>
 __device__ __forceinline__ void hsvfilter4_typed_body(const FrameBatch &fb, uint64_t width, uint32_t rows, uint64_t stride,
                                                       const FastConsts &p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr)
 {
@@ -41,13 +42,9 @@ __device__ __forceinline__ void hsvfilter4_typed_body(const FrameBatch &fb, uint
         uint8_t *line = frame + (uint64_t)row * stride;
         const uint32_t line_off = (uint32_t)((uint64_t)row * stride);
         const uint64_t groups = width >> 2; // the launcher guarantees width % 4 == 0
-        // ITERS > 1 (the one-frame launch shape): a workgroup walks ITERS ADJACENT chunks, so the grid is 1 / ITERS of the one-shot grid while
-        // the chip still sweeps the frame in address order
-        for (uint64_t tb = (uint64_t)blockIdx.x * (kBlock * TILE * ITERS); tb < groups; tb += (uint64_t)gridDim.x * (kBlock * TILE * ITERS))
-#pragma unroll 1
-        for (int it = 0; it < ITERS; it++) {
-            const uint64_t t0 = tb + (uint64_t)it * (kBlock * TILE);
-            if (ITERS > 1 && t0 >= groups) break;
+        // (one-shot grid, one chunk per workgroup: workgroups walking 2 / 3 / 4 / 8 adjacent chunks, capped grids and one group per lane were measured
+        // for the one-frame launch and all lose 2-15 %: profiles/r6/single_frame_launch_shapes.txt)
+        for (uint64_t t0 = (uint64_t)blockIdx.x * (kBlock * TILE); t0 < groups; t0 += (uint64_t)gridDim.x * (kBlock * TILE)) {
             u32x4 raw[TILE];
             f32x3 c[TILE][4];
             uint32_t voff[TILE];
@@ -107,11 +104,11 @@ __device__ __forceinline__ void hsvfilter4_typed_body(const FrameBatch &fb, uint
     }
 }
 
-template <int VARIANT, int TILE, bool NT, int ITERS = 1>
+template <int VARIANT, int TILE, bool NT>
 __global__ __launch_bounds__(kBlock) void hsvfilter4_typed_kernel(FrameBatch fb, uint64_t width, uint32_t rows, uint64_t stride,
                                                                   FastConsts p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr)
 {
-    hsvfilter4_typed_body<VARIANT, TILE, NT, ITERS>(fb, width, rows, stride, p, word3, frame_bytes, off, bgr);
+    hsvfilter4_typed_body<VARIANT, TILE, NT>(fb, width, rows, stride, p, word3, frame_bytes, off, bgr);
 }
 
 // The same kernel with the settings of every frame of the launch in the argument block (blockIdx.z = frame = stream): what the
@@ -161,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void hsvfilter3_typed_kernel(FrameBatch fb,
     for (uint32_t row = blockIdx.y; row < rows; row += gridDim.y) {
         uint8_t *line = frame + (uint64_t)row * stride;
         const uint32_t line_off = (uint32_t)((uint64_t)row * stride);
-        const uint64_t groups = width >> 2; // the launcher guarantees width % 4 == 0
+        const uint64_t groups = width >> 2; // the launcher guarantees width % 4 == 0 (other widths: hsvfilter3_typed_rows_kernel)
         for (uint64_t t0 = (uint64_t)blockIdx.x * (kBlock * TILE); t0 < groups; t0 += (uint64_t)gridDim.x * (kBlock * TILE)) {
             f32x3 c[TILE][4];
             uint32_t voff[TILE];
@@ -254,6 +251,93 @@ __global__ __launch_bounds__(kBlock) void typed_unorm8_selftest_kernel(const uin
     }
 }
 
+// RGB / BGR frames whose width is NOT a multiple of four (854, 1366 ... : round 6).  Such a frame always has row padding (the
+// stride is a multiple of four, three times such a width is not), so it cannot be walked as one run of pixels, and walking it row by row leaves
+// most lanes of the last workgroup of every row idle (1366 wide: 341 groups = 1.33 workgroups per row).  Here the WHOLE frame's groups are one
+// index space: lane L takes group (L / gpr, L mod gpr) with the division by a precomputed reciprocal (exact for L x gpr < 2^32: the launcher
+// checks), two groups per lane, the typed loads of hsvfilter3_typed_kernel.  Workgroups with blockIdx.y == 1 serve the rows' last 1..3 pixels,
+// one lane per pixel: the same typed load -- four bytes from the pixel's first byte, of which the row's padding supplies the fourth -- and three
+// byte stores.
+template <int VARIANT, bool NT>
+__global__ __launch_bounds__(kBlock) void hsvfilter3_typed_rows_kernel(FrameBatch fb, uint32_t width, uint32_t rows, uint32_t stride, FastConsts p, uint32_t word3a,
+                                                                       uint32_t word3b, uint32_t frame_bytes, bool bgr, uint32_t gpr, uint32_t gpr_magic)
+{
+    constexpr int TILE = 2;
+    __shared__ FilterLds lds;
+    init_filter_lds<VARIANT>(lds, 0, bgr);
+    uint8_t *frame = fb.base[blockIdx.z];
+    const uint64_t a = reinterpret_cast<uint64_t>(frame);
+    i32x4 ra, rb;
+    ra.x = rb.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    ra.y = rb.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));
+    ra.z = rb.z = __builtin_amdgcn_readfirstlane((int)frame_bytes);
+    ra.w = __builtin_amdgcn_readfirstlane((int)word3a);
+    rb.w = __builtin_amdgcn_readfirstlane((int)word3b);
+    if (blockIdx.y == 0) {
+        const uint32_t total = rows * gpr;
+        for (uint32_t t0 = blockIdx.x * (uint32_t)(kBlock * TILE); t0 < total; t0 += gridDim.x * (uint32_t)(kBlock * TILE)) {
+            f32x3 c[TILE][4];
+            uint32_t voff[TILE], at[TILE];
+            bool valid[TILE];
+#pragma unroll
+            for (int u = 0; u < TILE; u++) {
+                const uint32_t L = t0 + (uint32_t)u * kBlock + threadIdx.x;
+                valid[u] = L < total;
+                const uint32_t Lc = valid[u] ? L : 0u;
+                const uint32_t row = gpr_magic ? __umulhi(Lc, gpr_magic) : Lc, col = Lc - row * gpr; // (magic 0: one group per row)
+                at[u] = row * stride + col * 12u;
+                voff[u] = valid[u] ? at[u] : frame_bytes; // past the end: the bounds check returns zeros, nothing is stored
+            }
+#define MVFX_TYPED3R(NTS)                                                                        \
+    asm volatile("buffer_load_format_xyz %0, %8, %10, 0 offen" NTS "\n\t"                          \
+                 "buffer_load_format_xyz %1, %8, %10, 0 offen offset:3" NTS "\n\t"                 \
+                 "buffer_load_format_xyz %2, %8, %10, 0 offen offset:6" NTS "\n\t"                 \
+                 "buffer_load_format_xyz %3, %8, %11, 0 offen offset:8" NTS "\n\t"                 \
+                 "buffer_load_format_xyz %4, %9, %10, 0 offen" NTS "\n\t"                          \
+                 "buffer_load_format_xyz %5, %9, %10, 0 offen offset:3" NTS "\n\t"                 \
+                 "buffer_load_format_xyz %6, %9, %10, 0 offen offset:6" NTS "\n\t"                 \
+                 "buffer_load_format_xyz %7, %9, %11, 0 offen offset:8" NTS "\n\t"                 \
+                 "s_waitcnt vmcnt(0)"                                                               \
+                 : "=&v"(c[0][0]), "=&v"(c[0][1]), "=&v"(c[0][2]), "=&v"(c[0][3]), "=&v"(c[1][0]), "=&v"(c[1][1]), "=&v"(c[1][2]), "=&v"(c[1][3]) \
+                 : "v"(voff[0]), "v"(voff[1]), "s"(ra), "s"(rb)                                     \
+                 : "memory")
+            if constexpr (NT) MVFX_TYPED3R(" nt"); else MVFX_TYPED3R("");
+#undef MVFX_TYPED3R
+#pragma unroll
+            for (int u = 0; u < TILE; u++) {
+                if (valid[u]) {
+                    uint32_t w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t T;
+                        const uint32_t sel_off = hsvfilter_fast_unit<VARIANT == kFastNeg>(c[u][j].x, c[u][j].y, c[u][j].z, p, T);
+                        w[j] = __builtin_amdgcn_perm(T, 0u, sextant_at(lds.sextant, sel_off));
+                    }
+                    const u32x3 t = {__builtin_amdgcn_perm(w[1], w[0], 0x04020100u), __builtin_amdgcn_perm(w[2], w[1], 0x05040201u),
+                                     __builtin_amdgcn_perm(w[3], w[2], 0x06050402u)};
+                    if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<u32x3 *>(frame + at[u]));
+                    else *reinterpret_cast<u32x3 *>(frame + at[u]) = t;
+                }
+            }
+        }
+    } else {
+        const uint32_t tail = width & 3u, total = rows * tail;
+        for (uint32_t L = blockIdx.x * (uint32_t)kBlock + threadIdx.x; L < total; L += gridDim.x * (uint32_t)kBlock) {
+            const uint32_t row = tail == 1 ? L : (tail == 2 ? L >> 1 : L / 3u), k = L - row * tail;
+            const uint32_t at1 = row * stride + gpr * 12u + k * 3u;
+            f32x3 c1;
+            asm volatile("buffer_load_format_xyz %0, %1, %2, 0 offen\n\ts_waitcnt vmcnt(0)" : "=&v"(c1) : "v"(at1), "s"(ra) : "memory");
+            uint32_t T;
+            const uint32_t sel_off = hsvfilter_fast_unit<VARIANT == kFastNeg>(c1.x, c1.y, c1.z, p, T);
+            const uint32_t w1 = __builtin_amdgcn_perm(T, 0u, sextant_at(lds.sextant, sel_off)); // [c0 c1 c2 0] in memory order
+            uint8_t *q = frame + at1;
+            q[0] = (uint8_t)w1;
+            q[1] = (uint8_t)(w1 >> 8);
+            q[2] = (uint8_t)(w1 >> 16);
+        }
+    }
+}
+
 } // namespace
 
 void launch_hsvfilter3_typed(bool neg_shift, int tile, bool streaming, dim3 grid, hipStream_t stream, const FrameBatch &fb, uint64_t width,
@@ -268,16 +352,24 @@ void launch_hsvfilter3_typed(bool neg_shift, int tile, bool streaming, dim3 grid
 #undef MVFX_LT3
 }
 
-void launch_hsvfilter_typed(bool neg_shift, int tile, bool streaming, dim3 grid, hipStream_t stream, const FrameBatch &fb, uint64_t width,
-                            uint32_t rows, uint64_t stride, const FastConsts &p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr, int iters)
+void launch_hsvfilter3_typed_rows(bool neg_shift, bool streaming, uint32_t n_frames, hipStream_t stream, const FrameBatch &fb, uint32_t width, uint32_t rows,
+                                  uint32_t stride, const FastConsts &p, uint32_t word3a, uint32_t word3b, uint32_t frame_bytes, bool bgr)
 {
-    if (iters > 1) { // EXPERIMENT (round 6): adjacent chunks per workgroup; positive hue-shift, non-temporal only
-#define MVFX_LTI(T_, I_) MVFX_LAUNCH((hsvfilter4_typed_kernel<kFast, T_, true, I_>), grid, dim3(kBlock), 0, stream, fb, width, rows, stride, p, word3, frame_bytes, off, bgr)
-        if (tile == 2) { if (iters == 2) MVFX_LTI(2, 2); else if (iters == 3) MVFX_LTI(2, 3); else if (iters == 4) MVFX_LTI(2, 4); else MVFX_LTI(2, 8); }
-        else { if (iters == 2) MVFX_LTI(1, 2); else if (iters == 4) MVFX_LTI(1, 4); else MVFX_LTI(1, 8); }
-#undef MVFX_LTI
-        return;
-    }
+    const uint32_t gpr = width >> 2, magic = gpr > 1 ? (uint32_t)((1ull << 32) / gpr) + 1u : 0u; // floor(2^32 / gpr) + 1: exact quotients while L x gpr < 2^32
+    const uint64_t groups = (uint64_t)rows * gpr, tails = (uint64_t)rows * (width & 3u);
+    const uint64_t per = (uint64_t)kBlock * 2;
+    const uint32_t gx = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((groups + per - 1) / per, 1), 65535u * 16u);
+    (void)tails;
+    const dim3 grid(gx, 2, n_frames); // y = 0: whole groups; y = 1: the rows' last pixels (grid-stride: a few workgroups do)
+#define MVFX_LR(V, NT_) MVFX_LAUNCH((hsvfilter3_typed_rows_kernel<V, NT_>), grid, dim3(kBlock), 0, stream, fb, width, rows, stride, p, word3a, word3b, frame_bytes, bgr, gpr, magic)
+    if (neg_shift) { if (streaming) MVFX_LR(kFastNeg, true); else MVFX_LR(kFastNeg, false); }
+    else { if (streaming) MVFX_LR(kFast, true); else MVFX_LR(kFast, false); }
+#undef MVFX_LR
+}
+
+void launch_hsvfilter_typed(bool neg_shift, int tile, bool streaming, dim3 grid, hipStream_t stream, const FrameBatch &fb, uint64_t width,
+                            uint32_t rows, uint64_t stride, const FastConsts &p, uint32_t word3, uint32_t frame_bytes, int off, bool bgr)
+{
 #define MVFX_LT(V, T_, NT_) \
     MVFX_LAUNCH((hsvfilter4_typed_kernel<V, T_, NT_>), grid, dim3(kBlock), 0, stream, fb, width, rows, stride, p, word3, frame_bytes, off, bgr)
 #define MVFX_LT_NT(V, T_) do { if (streaming) MVFX_LT(V, T_, true); else MVFX_LT(V, T_, false); } while (0)

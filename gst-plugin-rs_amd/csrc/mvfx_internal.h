@@ -73,14 +73,12 @@ int stream_scratch(hipStream_t stream, size_t bytes, void **out);
 // re-record it; the last one stands.
 hipEvent_t completion_event();
 void note_completion_event_used();
-int exp_launch_flags(); // EXPERIMENT (round 6): MVFX_EXP_ANYORDER=1 -> hipExtAnyOrderLaunch on every launch
 #define MVFX_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                              \
     do {                                                                                                                   \
         hipEvent_t mvfx_done_ = ::mvfx::completion_event();                                                                \
-        const int mvfx_flags_ = ::mvfx::exp_launch_flags();                                                                \
-        if (mvfx_done_ || mvfx_flags_) {                                                                                   \
-            if (mvfx_done_) ::mvfx::note_completion_event_used();                                                          \
-            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, mvfx_done_, mvfx_flags_, __VA_ARGS__);       \
+        if (mvfx_done_) {                                                                                                  \
+            ::mvfx::note_completion_event_used();                                                                          \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, mvfx_done_, 0, __VA_ARGS__);                 \
         } else {                                                                                                           \
             hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                           \
         }                                                                                                                  \

@@ -581,3 +581,34 @@ def test_hsv_rgb3_typed_never_touches_a_byte_outside_the_frame(gpu, fmt, geom):
         oout = obuf.download()
         assert np.array_equal(oout[lead:lead + h * ostride].reshape(h, ostride), expect_det)
         assert (oout[:lead] == 0xC3).all() and (oout[lead + h * ostride:] == 0xC3).all()
+
+
+@pytest.mark.parametrize("fmt", ["RGB", "BGR"])
+@pytest.mark.parametrize("w,h", [(854, 480), (1366, 768), (2001, 1501), (5, 3), (2, 4), (7, 1)])
+def test_hsvfilter_rgb3_widths_that_are_not_multiples_of_four(gpu, fmt, w, h):
+    """Round 6: 3-byte frames whose width is not a multiple of four take the typed kernel too -- whole groups of four pixels as ever,
+    a row's last 1..3 pixels by one lane each (a typed load of the pixel's own bytes + the first padding byte, three byte stores).  Device entry,
+    GStreamer's stride (round_up_4(3 w)), random padding bytes that must stay; both signs of hue-shift; also as a 3-frame batch."""
+    stride = (3 * w + 3) // 4 * 4
+    while (stride * h) % 3:
+        stride += 4
+    f = frames.random_frame(0x5EED0E50 + w, w, h, 3, stride)
+    for settings in (BENCH_SETTINGS, (-45.0, 0.8, 0.1, 1.1, -0.03)):
+        want = f.copy()
+        assert orc.hsvfilter(want, w, stride, fmt, settings) == 0
+        lead = 64
+        host = np.full(lead + f.nbytes + 64, 0x5A, dtype=np.uint8)
+        host[lead:lead + f.nbytes] = f.reshape(-1)
+        buf = gpu.DeviceBuffer(host.nbytes).upload(host)
+        gpu.hsvfilter_device(buf.ptr + lead, w, h, stride, fmt, gpu.HsvFilterSettings(*settings))
+        gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+        out = buf.download()
+        assert np.array_equal(out[lead:lead + f.nbytes].reshape(h, stride), want), (fmt, w, h, settings)
+        assert (out[:lead] == 0x5A).all() and (out[lead + f.nbytes:] == 0x5A).all()
+    bufs = [gpu.DeviceBuffer(f.nbytes).upload(f) for _ in range(3)]
+    gpu.hsvfilter_device_batch([b.ptr for b in bufs], w, h, stride, fmt, gpu.HsvFilterSettings(*BENCH_SETTINGS))
+    gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+    want = f.copy()
+    assert orc.hsvfilter(want, w, stride, fmt, BENCH_SETTINGS) == 0
+    for b in bufs:
+        assert np.array_equal(b.download().reshape(h, stride), want)

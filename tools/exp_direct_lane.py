@@ -21,13 +21,15 @@ def main():
     dev = torch.device("cuda", 0)
     vfx.check(lib.mvfx_set_device(0))
     settings = vfx.HsvFilterSettings(90.0, 1.25, -0.05, 0.9, 0.02)
-    fpt = 16
-    vts, _ = _frames.videotestsrc_smpte(W, H, fpt)
-    pool = torch.from_numpy(vts.reshape(fpt, -1)).to(dev).contiguous()
+    fpt = int(sys.argv[1]) if len(sys.argv) > 1 else 16   # distinct frames in rotation (33 MB each)
+    vts, _ = _frames.videotestsrc_smpte(W, H, min(fpt, 16))
+    base = torch.from_numpy(vts.reshape(min(fpt, 16), -1)).to(dev)
+    pool = base.repeat((fpt + base.shape[0] - 1) // base.shape[0], 1)[:fpt].contiguous()
     torch.cuda.synchronize()
     fr = (vfx.Frame * fpt)(*[vfx.make_frame(pool[i].data_ptr(), W, H, W * 4, "RGBA") for i in range(fpt)])
     n = 3000
-    for rep in range(2):
+    print(f"# {fpt} frames in rotation = {fpt * W * H * 4 / 1e6:.0f} MB")
+    for rep in range(1):
         for name, opt in (("cached", 0), ("non-temporal", vfx.OPT_NONTEMPORAL)):
             secs = (ctypes.c_double * 5)()
             per = (ctypes.c_double * 1)()

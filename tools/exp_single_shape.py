@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/exp_single_shape.py -- round 6: the launch shape of ONE 4K RGBA frame per hsvfilter call (the element's contract, hsvfilter/imp.rs:322-326).
+"""tools/exp_single_shape.py -- round 6 (NEEDS the MVFX_EXP_SINGLE hook of commit b1acdc1: it was removed with the negative result; kept as the record of what was measured): the launch shape of ONE 4K RGBA frame per hsvfilter call (the element's contract, hsvfilter/imp.rs:322-326).
 One host thread, single-frame mvfx_hsvfilter_transform_frame_ip calls rotating over 1 / 2 / 3 private streams, 16 distinct 33 MB frames (531 MB:
 nothing stays in the Infinity Cache), non-temporal accesses.  MVFX_EXP_SINGLE=tile,iters[,maxgrid] picks the experimental shape (hsv_kernels.hip):
 `tile` 16-byte groups per lane with the loads issued together, `iters` adjacent chunks per workgroup, grid capped at `maxgrid` workgroups.
