@@ -385,6 +385,24 @@ static GstFlowReturn gst_rounded_corners_prepare_output_buffer(GstBaseTransform 
         GST_ELEMENT_ERROR(self, CORE, NEGOTIATION, ("Have no state yet"), (NULL));
         return GST_FLOW_NOT_NEGOTIATED;
     }
+    if (self->hip && mvfx_buffer_is_hip(inbuf) && GST_VIDEO_INFO_FORMAT(&self->out_info) != GST_VIDEO_FORMAT_I420) {
+        // the mask lives where the frames live (round 6): the streaming thread adopts the device of the incoming memory, and a mask that was
+        // made on another device -- set_caps ran before the first buffer, or the stream changed device -- is made again there
+        // (d3d12colorlut/imp.rs:494-542 rebuilds its context the same way)
+        if (!mvfx_hip_follow_device(inbuf, GST_OBJECT(self))) return GST_FLOW_ERROR;
+        if (mvfx_hip_memory_device(self->alpha_mem) != mvfx_hip_buffer_device(inbuf)) {
+            GstAllocator *alloc = mvfx_hip_allocator_get();
+            GstMemory *fresh = gst_allocator_alloc(alloc, self->alpha_mem->maxsize, NULL);
+            gst_object_unref(alloc);
+            if (!fresh) {
+                GST_ELEMENT_ERROR(self, RESOURCE, NO_SPACE_LEFT, ("%s", mvfx_last_error()), (NULL));
+                return GST_FLOW_ERROR;
+            }
+            gst_memory_unref(self->alpha_mem);
+            self->alpha_mem = fresh;
+            self->changed = TRUE;
+        }
+    }
     if (self->changed) {
         self->changed = FALSE;
         GST_CAT_DEBUG_OBJECT(roundedcorners_debug, self, "Caps or border radius changed, generating alpha mask");

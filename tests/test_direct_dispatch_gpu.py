@@ -292,3 +292,67 @@ def test_direct_only_refuses_instead_of_moving_a_frame_to_the_stream(gpu):
     finally:
         L.mvfx_thread_set_options(0)
     assert np.array_equal(buf.download().reshape(64, 1024), f)
+
+
+def test_four_threads_share_the_lane(gpu):
+    """the lane's queues are multi-producer: four threads, each with its own streams and fences, push 48 frames each through it at once"""
+    import threading
+    w, h, per = 1920, 1080, 48
+    src = frames.random_frame(0x5EED0FA0, w, h)
+    want = src.copy()
+    assert orc.hsvfilter(want, w, w * 4, "RGBA", BENCH) == 0
+    L = gpu.lib()
+    bad = []
+
+    def worker(t):
+        try:
+            gpu.check(L.mvfx_set_device(0))
+            bufs = [gpu.DeviceBuffer(src.nbytes).upload(src) for _ in range(8)]
+            evs = [Event(gpu) for _ in range(8)]
+            streams = [ctypes.c_void_p(L.mvfx_thread_stream_n(k)) for k in range(2)]
+            for i in range(per):
+                k = i % 8
+                if i >= 8:
+                    gpu.check(L.mvfx_event_synchronize(evs[k].h))
+                    if not np.array_equal(bufs[k].download().reshape(h, w * 4), want):
+                        bad.append((t, i - 8))
+                    bufs[k].upload(src)
+                rc, carried, direct = direct_filter(gpu, bufs[k].ptr, w, h, w * 4, "RGBA", BENCH, evs[k], stream=streams[i & 1])
+                if rc != 0 or direct != 1:
+                    bad.append((t, i, rc, direct))
+            for k in range(8):
+                gpu.check(L.mvfx_event_synchronize(evs[k].h))
+                if not np.array_equal(bufs[k].download().reshape(h, w * 4), want):
+                    bad.append((t, "tail", k))
+        except Exception as e:  # noqa: BLE001
+            bad.append((t, repr(e)))
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not bad, bad[:5]
+
+
+def test_the_lane_can_be_switched_off_by_the_environment(gpu, tmp_path):
+    """MVFX_DIRECT_DISPATCH=0: the option bit is accepted and ignored, the frame goes out on the stream, the event is an ordinary one"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, ctypes; sys.path.insert(0, %r)\n"
+        "import numpy as np, _pkg\n"
+        "from tests import frames\n"
+        "from tests import oracle_binding as orc\n"
+        "vfx = _pkg.vfx; L = vfx.lib(); vfx.check(L.mvfx_set_device(0))\n"
+        "f = frames.random_frame(7, 256, 64); want = f.copy(); orc.hsvfilter(want, 256, 1024, 'RGBA', (90.0, 1.25, -0.05, 0.9, 0.02))\n"
+        "buf = vfx.DeviceBuffer(f.nbytes).upload(f); ev = ctypes.c_void_p(); vfx.check(L.mvfx_event_create(ctypes.byref(ev)))\n"
+        "fr = vfx.make_frame(buf.ptr, 256, 64, 1024, 'RGBA'); st = ctypes.c_void_p(L.mvfx_thread_stream())\n"
+        "vfx.check(L.mvfx_thread_set_options(vfx.OPT_DIRECT_DISPATCH)); vfx.check(L.mvfx_thread_set_completion_event(ev))\n"
+        "vfx.check(L.mvfx_hsvfilter_transform_frame_ip(ctypes.byref(fr), ctypes.byref(vfx.HsvFilterSettings(90.0, 1.25, -0.05, 0.9, 0.02)), st))\n"
+        "carried = L.mvfx_thread_clear_completion_event(); L.mvfx_thread_set_options(0)\n"
+        "vfx.check(L.mvfx_event_synchronize(ev))\n"
+        "print('direct', L.mvfx_event_is_direct(ev), 'carried', carried, 'equal', bool(np.array_equal(buf.download().reshape(64, 1024), want)))\n" % root)
+    for env_val, expect in (("0", "direct 0 carried 1 equal True"), ("1", "direct 1 carried 1 equal True")):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MVFX_DIRECT_DISPATCH=env_val), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=300)
+        assert r.returncode == 0 and expect in r.stdout, (env_val, r.stdout[-500:], r.stderr[-500:])
