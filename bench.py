@@ -902,6 +902,32 @@ def make_leg_colorlut(w, args, content):
         return {"launch_model": f"{nthr} threads x 1 frame (own HIP stream each, single-frame mvfx_colorlut_transform_frame)",
                 "value": fps, "unit": "frames/s", "launches_per_thread": launches, "statistic": "median of 5 repetitions",
                 "frac_wall": fps / w.world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS}
+    def lane_leg():
+        """the element's contract through the direct-dispatch lane: ONE thread, one mvfx_colorlut_transform_frame per frame pair, a fence per frame; the
+        frames are independent, so the packets go out without the barrier bit (MVFX_OPT_DIRECT_UNORDERED: what the element does when neither buffer's
+        acquire rested on queue order)"""
+        hb = bench_harness()
+        nfr = min(pool * nb, 12)
+        fin = (vfx.Frame * nfr)(*[vfx.make_frame(src[k].data_ptr(), W, H, W * 4, "RGBA") for k in range(nfr)])
+        fout = (vfx.Frame * nfr)(*[vfx.make_frame(dst[k].data_ptr(), W, H, W * 4, "RGBA") for k in range(nfr)])
+        launches, reps = 1500, 5
+        res = {}
+        for name, opt in (("two_streams", 0), ("lane_in_order", vfx.OPT_DIRECT_DISPATCH), ("lane", vfx.OPT_DIRECT_DISPATCH | vfx.OPT_DIRECT_UNORDERED)):
+            secs, took = (ctypes.c_double * reps)(), ctypes.c_uint64()
+            w.sync()
+            w.barrier()
+            rc = hb.mvfxbench_colorlut_direct(w.device_index, 3000, launches, reps, lut.h, fin, fout, nfr, opt, secs, ctypes.byref(took))
+            if rc != 0:
+                raise RuntimeError(f"mvfxbench status {rc}: {vfx.last_error()}")
+            w.barrier()
+            (med,) = w.max_over_ranks(sorted(secs)[reps // 2])
+            fps = launches * w.world / med
+            res[name] = {"value": fps, "unit": "frames/s", "frac_wall": fps / w.world * 2 * FRAME_BYTES / 1e9 / HBM_PEAK_GBS,
+                         "share_through_the_lane": took.value / float(reps * launches)}
+        res["launch_model"] = ("1 thread x single-frame mvfx_colorlut_transform_frame, a fence per frame: on two alternating HIP streams / as packets of the "
+                               "library's own queues in queue order / the same without the barrier bit (independent frames)")
+        res["statistic"] = "median of 5 repetitions x 1500 frames"
+        return res
     leg = Leg("colorlut_" + content, "colorlut_frames_per_sec", "frames/s", nb, nb * 2 * FRAME_BYTES, "f32", data,
               f"colorlut 33^3 .cube (575 KB of nodes), {nb} streams of 3840x2160 RGBA per launch, content={content}; 4 + 4 algorithmic B/px "
               "(the LUT gathers are content dependent: random colours are the worst case, flat bars the best); kernels: the x-prelerped window "
@@ -936,6 +962,7 @@ def make_leg_colorlut(w, args, content):
         return f"frames 0 and {nb - 1} of the first {nb}-frame step, every byte, against oracle/colorlut_oracle.c"
     leg.verify = verify
     leg.streams_leg = streams_leg
+    leg.lane_leg = lane_leg
     leg.noise_sweep = noise_sweep
     return leg
 
@@ -1275,6 +1302,11 @@ def other_config_legs(w, args):
             if key == "colorlut_natural" and args.stream_threads > 0:
                 r["config"]["other_launch_model"] = leg.streams_leg()
                 r["config"]["element_model"] = r["config"]["other_launch_model"]["value"]
+            if key == "colorlut_natural" and args.stream_threads > 0:
+                try:
+                    r["config"]["one_frame_per_call"] = leg.lane_leg()
+                except Exception as e:  # noqa: BLE001
+                    r["config"]["one_frame_per_call"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             if key == "colorlut_natural" and args.noise_sweep:
                 r["sub_extra"] = {"noise_fps": leg.noise_sweep()}
             if "last_distance" in r["config"]:

@@ -51,6 +51,7 @@ OPT_SSIM_F64 = 0x80
 OPT_LUT_WG_WINDOW = 0x100
 OPT_DIRECT_DISPATCH = 0x200
 OPT_DIRECT_ONLY = 0x400
+OPT_DIRECT_UNORDERED = 0x800
 ERR_DIRECT_UNAVAILABLE = -11
 
 
@@ -60,10 +61,11 @@ class options:
     2 force strength-reduced; placement: colorlut LUT placement 0..6 (include/mi355vfx.h: 0 auto, 1 node layout in global/L2,
     2 LDS, 3 cell-packed global, 4 literal kernels, 5 tile kernel, 6 baked table of all 2^24 colours, 7 round 4's per-wave windows);
     wg_window: colorlut always through the workgroup-window kernel instead of asking the content probe; direct: one-frame hsvfilter calls may go
-    out on the library's own queue (MVFX_OPT_DIRECT_DISPATCH: needs a completion event on the thread)."""
+    out on the library's own queue (MVFX_OPT_DIRECT_DISPATCH: needs a completion event on the thread); unordered: colorlut's lane packets without the
+    barrier bit (MVFX_OPT_DIRECT_UNORDERED)."""
 
-    def __init__(self, variant=0, nontemporal=False, typed=True, placement=0, ssim_f64=False, wg_window=False, direct=False):
-        self.word = ((OPT_DIRECT_DISPATCH if direct else 0) | (OPT_LUT_WG_WINDOW if wg_window else 0) | (OPT_SSIM_F64 if ssim_f64 else 0) | (OPT_NONTEMPORAL if nontemporal else 0) | (OPT_HSV_LITERAL if variant == 1 else 0) |
+    def __init__(self, variant=0, nontemporal=False, typed=True, placement=0, ssim_f64=False, wg_window=False, direct=False, unordered=False):
+        self.word = ((OPT_DIRECT_DISPATCH if direct else 0) | (OPT_DIRECT_UNORDERED if unordered else 0) | (OPT_LUT_WG_WINDOW if wg_window else 0) | (OPT_SSIM_F64 if ssim_f64 else 0) | (OPT_NONTEMPORAL if nontemporal else 0) | (OPT_HSV_LITERAL if variant == 1 else 0) |
                      (OPT_HSV_FORCE_FAST if variant == 2 else 0) | (0 if typed else OPT_HSV_VALU_UNORM) |
                      (placement << OPT_LUT_PLACEMENT_SHIFT))
 

@@ -294,4 +294,48 @@ int mvfxbench_hsvfilter_direct(int device, uint32_t warmup, uint32_t launches, u
     return rc;
 }
 
+// The same for colorlut: frame i goes from ins[i % n_frames] to outs[i % n_frames], one call per frame, one fence per frame; without
+// MVFX_OPT_DIRECT_DISPATCH in `options` the calls are the ordinary single-frame launches on the thread's two streams (the element's round-5 path).
+int mvfxbench_colorlut_direct(int device, uint32_t warmup, uint32_t launches, uint32_t reps, mvfx_cube_lut *lut, const mvfx_frame *ins, const mvfx_frame *outs,
+                              uint32_t n_frames, uint32_t options, double *seconds_out, uint64_t *direct_out)
+{
+    if (!lut || !ins || !outs || !seconds_out || n_frames == 0 || reps == 0) return MVFX_ERR_INVALID_ARGUMENT;
+    int rc = MVFX_OK;
+    uint64_t direct = 0;
+    std::thread th([&] {
+        rc = mvfx_set_device(device);
+        constexpr uint32_t kEvents = 32;
+        mvfx_event ev[kEvents] = {};
+        for (uint32_t k = 0; k < kEvents && rc == MVFX_OK; k++) rc = mvfx_event_create(&ev[k]);
+        mvfx_stream sts[2] = {mvfx_thread_stream_n(0), mvfx_thread_stream_n(1)};
+        uint64_t n = 0;
+        auto one = [&](uint32_t i, bool count) {
+            mvfx_stream st = sts[n & 1];
+            mvfx_event e = ev[n % kEvents];
+            if (n >= kEvents) rc = mvfx_event_synchronize(e);
+            n++;
+            if (rc != MVFX_OK) return;
+            mvfx_thread_set_options(options);
+            mvfx_thread_set_completion_event(e);
+            rc = mvfx_colorlut_transform_frame(lut, &ins[i % n_frames], &outs[i % n_frames], st);
+            if (mvfx_thread_clear_completion_event() <= 0 && rc == MVFX_OK) rc = mvfx_event_record(e, st);
+            if (count && mvfx_event_is_direct(e)) direct++;
+        };
+        auto drain = [&] { for (uint32_t k = 0; k < kEvents && rc == MVFX_OK; k++) if (n > k) rc = mvfx_event_synchronize(ev[k]); };
+        for (uint32_t i = 0; i < warmup && rc == MVFX_OK; i++) one(i, false);
+        drain();
+        for (uint32_t r = 0; r < reps && rc == MVFX_OK; r++) {
+            const double t0 = now_s();
+            for (uint32_t i = 0; i < launches && rc == MVFX_OK; i++) one(r * launches + i, true);
+            drain();
+            seconds_out[r] = now_s() - t0;
+        }
+        mvfx_thread_set_options(0);
+        for (uint32_t k = 0; k < kEvents; k++) if (ev[k]) mvfx_event_destroy(ev[k]);
+    });
+    th.join();
+    if (direct_out) *direct_out = direct;
+    return rc;
+}
+
 } // extern "C"

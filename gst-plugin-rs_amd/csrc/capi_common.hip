@@ -550,7 +550,7 @@ int mvfx_copy_device_to_device_async(void *dst_device, const void *src_device, s
 int mvfx_thread_set_options(uint32_t options)
 {
     const uint32_t known = MVFX_OPT_NONTEMPORAL | MVFX_OPT_HSV_LITERAL | MVFX_OPT_HSV_FORCE_FAST | MVFX_OPT_HSV_VALU_UNORM |
-                           MVFX_OPT_LUT_PLACEMENT_MASK | MVFX_OPT_SSIM_F64 | MVFX_OPT_LUT_WG_WINDOW | MVFX_OPT_DIRECT_DISPATCH | MVFX_OPT_DIRECT_ONLY;
+                           MVFX_OPT_LUT_PLACEMENT_MASK | MVFX_OPT_SSIM_F64 | MVFX_OPT_LUT_WG_WINDOW | MVFX_OPT_DIRECT_DISPATCH | MVFX_OPT_DIRECT_ONLY | MVFX_OPT_DIRECT_UNORDERED;
     if (options & ~known)
         return fail(MVFX_ERR_INVALID_ARGUMENT, "thread options 0x%x: unknown bits 0x%x", options, options & ~known);
     if ((options & MVFX_OPT_HSV_LITERAL) && (options & MVFX_OPT_HSV_FORCE_FAST))

@@ -17,6 +17,7 @@
 // in LDS.
 // Pixels: RGBA8 -> one lane owns 4 pixels (16 B in, 16 B out); RGBA64 -> 2 pixels (16 B).
 #include "colorlut_device.hpp"
+#include "direct_dispatch_colorlut.h"
 
 #include "cube_parser.h"
 #include "device_replicas.h"
@@ -606,7 +607,11 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
     p.size = l.size;
     p.size_m1 = (float)l.size - 1.0f;
 
+    // MVFX_OPT_DIRECT_ONLY (the caller holds a direct fence open on a lane queue): only a launch the lane takes may happen
+    const bool direct_only = opt_direct_only() && !baking;
+    const auto no_lane = [] { return fail(MVFX_ERR_DIRECT_UNAVAILABLE, "colorlut: the direct-dispatch lane does not take this call"); };
     if (in->format == MVFX_FORMAT_RGB10A2_LE) {
+        if (direct_only) return no_lane();
         FrameBatch ifb10{}, ofb10{};
         uint64_t bits = (uint64_t)in->stride | out->stride;
         for (uint32_t i = 0; i < n; i++) {
@@ -645,6 +650,7 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
     const bool vec = (align_or & 15) == 0;
 
     if (!baking && !wide && opt_lut_placement() == 6) {
+        if (direct_only) return no_lane();
         if (!vec || (!flat && (in->width & 3) != 0) || (flat && (width & 3) != 0))
             return fail(MVFX_ERR_INVALID_ARGUMENT, "colorlut: the baked table kernel needs 16-byte aligned rows and a width that is a multiple of 4");
         if (int rc = ensure_baked(h, d, st); rc != MVFX_OK) return rc;
@@ -692,6 +698,9 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
         break;
     }
     if (!use_fast) use_cells = false; // the literal kernels read the node layout
+    // what the lane takes: one RGBA8 frame through one of the two x-prelerped window kernels (csrc/direct/colorlut_direct_kernels.hip)
+    const bool lane_kernels = use_fast && use_tiles && !wide && n == 1 && d->d_xtable && opt_lut_placement() != 5;
+    if (direct_only && !lane_kernels) return no_lane();
     const size_t lds_bytes = l.is_3d ? (size_t)l.size * l.size * l.size * 16 : (size_t)l.size * 12;
     p.cells = reinterpret_cast<const float4 *>(d->d_cells);
     p.tile_tables = d->d_tile_tables;
@@ -755,6 +764,19 @@ int colorlut_impl(mvfx_cube_lut *h, const mvfx_frame *ins, const mvfx_frame *out
                     launch_colorlut_probe(st, ifb.base[0], in->width, in->height, in->stride, d->h_probe);
                 wg_window = __atomic_load_n(&d->h_probe[0], __ATOMIC_RELAXED) != 1u;
             }
+        }
+        if (lane_kernels && opt_direct() && !baking) {
+            // The direct-dispatch lane: the same kernel bodies with write-through stores, as a packet of the library's own without a release fence
+            // (direct_dispatch.h).  Needs the thread's completion event -- it becomes the frame's direct fence; the content probe above stays on `st`.
+            DirectLutArgs da{};
+            da.in = ifb.base[0];
+            da.out = ofb.base[0];
+            da.width = in->width; da.height = in->height; da.in_stride = in->stride; da.out_stride = out->stride;
+            da.p = p;
+            const int rc = direct_colorlut_submit(da, wg_window, direct_queue_hint(st), !opt_direct_unordered());
+            if (rc == MVFX_OK) return MVFX_OK;
+            if (rc < 0) return rc;
+            if (direct_only) return no_lane();
         }
         if (wg_window) {
             const uint32_t tx_ = (in->width + 127) / 128, ty_ = (in->height + 8 * kXRows - 1) / (8 * kXRows);

@@ -42,8 +42,9 @@ struct DirectDetArgs {
     HsvDetectorParams p;
 };
 
-// kernels 0..3: hsvfilter, index = neg_shift * 2 + nontemporal loads; 4: hsvdetector
-constexpr int kDirectKernels = 5;
+// kernels 0..3: hsvfilter, index = neg_shift * 2 + nontemporal loads; 4: hsvdetector; 5, 6: colorlut, per-wave windows / workgroup window
+// (direct_dispatch_colorlut.h)
+constexpr int kDirectKernels = 7;
 extern const char *const kDirectKernelNames[kDirectKernels];
 
 // The lane has two queues, each IN ORDER (its packets carry the barrier bit): which one a dispatch takes is a function of the `stream` the caller

@@ -1,7 +1,8 @@
-// Host side of the direct-dispatch lane (direct_dispatch.h has the why): per device an HSA queue of the library's own, the lane's kernels loaded
-// from the code object embedded in this library (build/direct_blob.o: csrc/direct/hsv_direct_kernels.hip as a bare gfx950 ELF), a ring of kernel
-// argument blocks, and the table that turns an mvfx_event into a direct fence (an HSA completion signal).
+// Host side of the direct-dispatch lane (direct_dispatch.h has the why): per device two HSA queues of the library's own, the lane's kernels loaded
+// from the code objects embedded in this library (build/direct_blob.o: csrc/direct/hsv_direct_kernels.hip and colorlut_direct_kernels.hip as bare
+// gfx950 ELFs), a ring of kernel argument blocks, and the table that turns an mvfx_event into a direct fence (an HSA completion signal).
 #include "direct_dispatch.h"
+#include "direct_dispatch_colorlut.h"
 #include "mvfx_internal.h"
 
 #include <hsa/hsa.h>
@@ -17,16 +18,22 @@
 
 extern "C" const char mvfx_direct_hsaco[];
 extern "C" const char mvfx_direct_hsaco_end[];
+extern "C" const char mvfx_direct_lut_hsaco[];
+extern "C" const char mvfx_direct_lut_hsaco_end[];
 
 namespace mvfx {
 
 const char *const kDirectKernelNames[kDirectKernels] = {"mvfx_direct_hsvfilter4_pos.kd", "mvfx_direct_hsvfilter4_pos_nt.kd",
-                                                        "mvfx_direct_hsvfilter4_neg.kd", "mvfx_direct_hsvfilter4_neg_nt.kd", "mvfx_direct_hsvdetector4.kd"};
+                                                        "mvfx_direct_hsvfilter4_neg.kd", "mvfx_direct_hsvfilter4_neg_nt.kd", "mvfx_direct_hsvdetector4.kd",
+                                                        "mvfx_direct_colorlut_xtile.kd", "mvfx_direct_colorlut_xwg.kd"};
 
 namespace {
 
 constexpr uint32_t kQueuePackets = 1024, kArgSlots = 1024, kArgSlotBytes = 192, kQueues = 2;
-static_assert(sizeof(DirectHsvArgs) <= kArgSlotBytes && sizeof(DirectDetArgs) <= kArgSlotBytes, "one kernel argument block per slot");
+static_assert(sizeof(DirectHsvArgs) <= kArgSlotBytes && sizeof(DirectDetArgs) <= kArgSlotBytes && sizeof(DirectLutArgs) <= kArgSlotBytes,
+              "one kernel argument block per slot");
+constexpr size_t kKernelArgBytes[kDirectKernels] = {sizeof(DirectHsvArgs), sizeof(DirectHsvArgs), sizeof(DirectHsvArgs), sizeof(DirectHsvArgs), sizeof(DirectDetArgs),
+                                                    sizeof(DirectLutArgs), sizeof(DirectLutArgs)};
 
 struct Lane {
     bool ok = false;
@@ -36,7 +43,6 @@ struct Lane {
     char *args = nullptr;              // kArgSlots x kArgSlotBytes in DEVICE memory, written by the CPU through the BAR
     uint64_t kernel[kDirectKernels] = {};
     uint32_t kernel_lds[kDirectKernels] = {};
-    uint32_t lds = 0, priv = 0;
     hsa_executable_t exe{};
     // the completion signal of the dispatch that used an argument slot last: the slot is written again only when that kernel has finished (its
     // workgroups read the block as they start).  Signals are never destroyed (free list below), so a stale handle is still a signal.
@@ -110,10 +116,12 @@ void build_lane(Lane &l, int device)
     if (hsa_amd_agent_memory_pool_get_info(cpu.agent, pool.pool, HSA_AMD_AGENT_MEMORY_POOL_INFO_ACCESS, &access) != HSA_STATUS_SUCCESS ||
         access == HSA_AMD_MEMORY_POOL_ACCESS_NEVER_ALLOWED)
         return;
-    hsa_code_object_reader_t reader;
+    hsa_code_object_reader_t reader, lut_reader;
     if (hsa_code_object_reader_create_from_memory(mvfx_direct_hsaco, (size_t)(mvfx_direct_hsaco_end - mvfx_direct_hsaco), &reader) != HSA_STATUS_SUCCESS) return;
+    if (hsa_code_object_reader_create_from_memory(mvfx_direct_lut_hsaco, (size_t)(mvfx_direct_lut_hsaco_end - mvfx_direct_lut_hsaco), &lut_reader) != HSA_STATUS_SUCCESS) return;
     if (hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &l.exe) != HSA_STATUS_SUCCESS) return;
     if (hsa_executable_load_agent_code_object(l.exe, l.agent, reader, nullptr, nullptr) != HSA_STATUS_SUCCESS) return;
+    if (hsa_executable_load_agent_code_object(l.exe, l.agent, lut_reader, nullptr, nullptr) != HSA_STATUS_SUCCESS) return;
     if (hsa_executable_freeze(l.exe, nullptr) != HSA_STATUS_SUCCESS) return;
     for (int k = 0; k < kDirectKernels; k++) {
         hsa_executable_symbol_t sym;
@@ -123,9 +131,8 @@ void build_lane(Lane &l, int device)
         (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &kasize);
         (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &lds);
         (void)hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &priv);
-        if (kasize != (k == 4 ? sizeof(DirectDetArgs) : sizeof(DirectHsvArgs)) || priv != 0) return; // the argument block is the struct and nothing else (no implicit arguments, no scratch)
+        if (kasize != kKernelArgBytes[k] || priv != 0) return; // the argument block is the struct and nothing else (no implicit arguments, no scratch)
         l.kernel_lds[k] = lds;
-        l.lds = lds > l.lds ? lds : l.lds;
     }
     if (hsa_amd_memory_pool_allocate(pool.pool, (size_t)kArgSlots * kArgSlotBytes, 0, reinterpret_cast<void **>(&l.args)) != HSA_STATUS_SUCCESS) return;
     if (hsa_amd_agents_allow_access(1, &cpu.agent, nullptr, l.args) != HSA_STATUS_SUCCESS) return;
@@ -247,8 +254,8 @@ void direct_event_destroy(hipEvent_t e)
 }
 
 namespace {
-// one dispatch: `bytes` of kernel arguments, kernel `k`, `wgs` workgroups of 256 lanes, on lane queue `queue`
-int submit(const void *args, size_t bytes, int k, uint32_t wgs, int queue)
+// one dispatch: `bytes` of kernel arguments, kernel `k`, `wgs_x` x `wgs_y` workgroups of 256 lanes, on lane queue `queue`; in_order: with the barrier bit
+int submit(const void *args, size_t bytes, int k, uint32_t wgs_x, uint32_t wgs_y, int queue, bool in_order = true)
 {
     if (!enabled()) return 1;
     hipEvent_t ev = completion_event();
@@ -283,7 +290,7 @@ int submit(const void *args, size_t bytes, int k, uint32_t wgs, int queue)
     while (idx - hsa_queue_load_read_index_scacquire(q) >= q->size) {} // queue full: 1024 frames in flight on it
     hsa_kernel_dispatch_packet_t *p = reinterpret_cast<hsa_kernel_dispatch_packet_t *>(q->base_address) + (idx & (q->size - 1));
     p->workgroup_size_x = 256; p->workgroup_size_y = 1; p->workgroup_size_z = 1; p->reserved0 = 0;
-    p->grid_size_x = wgs * 256u; p->grid_size_y = 1; p->grid_size_z = 1;
+    p->grid_size_x = wgs_x * 256u; p->grid_size_y = wgs_y; p->grid_size_z = 1;
     p->private_segment_size = 0;
     p->group_segment_size = l->kernel_lds[k];
     p->kernel_object = l->kernel[k];
@@ -298,11 +305,14 @@ int submit(const void *args, size_t bytes, int k, uint32_t wgs, int queue)
     // The RELEASE fence is the cost: an L2 write-back walk on all eight XCDs at the end of every dispatch, whoever else is running.  The lane's
     // kernels store write-through and drain (csrc/direct/hsv_direct_kernels.hip), so there is nothing for it to write back: release NONE.  The
     // acquire stays at agent scope (the frame was written by somebody else's kernel or copy; cheap).  Barrier bit set: each of the two queues
-    // is in order, like a stream -- without it the same kernel ran no faster (one queue) or slower (two).
-    const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+    // is in order, like a stream -- without it the same kernel ran no faster (one queue) or slower (two).  colorlut's kernels are another matter (a
+    // one-frame grid is 1.05 occupancy rounds of workgroups that each fill a window before their first pixel): without the bit the next frame's
+    // workgroups start in the tail of this one's, as the frames of a batched launch do -- per-wave windows, natural-like 4K: 70.3 k fps in order,
+    // 75-76 k without (two HIP streams: 69-70 k; profiles/r6/colorlut_lane.txt).  Only for a caller that says nothing in front matters to it.
+    const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | ((in_order ? 1 : 0) << HSA_PACKET_HEADER_BARRIER) |
                                        (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
                                        (HSA_FENCE_SCOPE_NONE << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
-    const uint16_t setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+    const uint16_t setup = (uint16_t)((wgs_y > 1 ? 2 : 1) << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS);
     __atomic_store_n(reinterpret_cast<uint32_t *>(p), (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
     hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)idx);
     return MVFX_OK;
@@ -311,12 +321,20 @@ int submit(const void *args, size_t bytes, int k, uint32_t wgs, int queue)
 
 int direct_hsvfilter_submit(const DirectHsvArgs &args, bool neg_shift, bool nontemporal, int queue)
 {
-    return submit(&args, sizeof args, (neg_shift ? 2 : 0) + (nontemporal ? 1 : 0), (args.groups + 511u) / 512u, queue);
+    return submit(&args, sizeof args, (neg_shift ? 2 : 0) + (nontemporal ? 1 : 0), (args.groups + 511u) / 512u, 1, queue);
 }
 
 int direct_hsvdetector_submit(const DirectDetArgs &args, int queue)
 {
-    return submit(&args, sizeof args, 4, (args.groups + 511u) / 512u, queue);
+    return submit(&args, sizeof args, 4, (args.groups + 511u) / 512u, 1, queue);
+}
+
+int direct_colorlut_submit(const DirectLutArgs &args, bool wg_window, int queue, bool in_order)
+{
+    if (wg_window) // the workgroup owns 128 x 40 pixels (colorlut_xwg_body)
+        return submit(&args, sizeof args, 6, (args.width + 127u) / 128u, (args.height + 8u * kXRows - 1u) / (8u * kXRows), queue, in_order);
+    // a wave owns 64 x 20 pixels, four waves side by side (colorlut_xtile_body)
+    return submit(&args, sizeof args, 5, ((args.width + 63u) / 64u + 3u) / 4u, (args.height + 4u * kXRows - 1u) / (4u * kXRows), queue, in_order);
 }
 
 } // namespace mvfx

@@ -56,6 +56,7 @@ inline bool opt_nontemporal() { return (thread_options() & MVFX_OPT_NONTEMPORAL)
 inline bool opt_typed_loads() { return (thread_options() & MVFX_OPT_HSV_VALU_UNORM) == 0; }
 inline bool opt_direct() { return (thread_options() & MVFX_OPT_DIRECT_DISPATCH) != 0; }
 inline bool opt_direct_only() { return (thread_options() & (MVFX_OPT_DIRECT_DISPATCH | MVFX_OPT_DIRECT_ONLY)) == (MVFX_OPT_DIRECT_DISPATCH | MVFX_OPT_DIRECT_ONLY); }
+inline bool opt_direct_unordered() { return (thread_options() & MVFX_OPT_DIRECT_UNORDERED) != 0; }
 inline int opt_lut_placement() { return (int)((thread_options() & MVFX_OPT_LUT_PLACEMENT_MASK) >> MVFX_OPT_LUT_PLACEMENT_SHIFT); }
 
 // Grow-only device scratch used by the *_host entry points (one per thread and device).

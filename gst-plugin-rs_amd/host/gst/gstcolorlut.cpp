@@ -90,6 +90,7 @@ static gboolean gst_color_lut_stop(GstBaseTransform *trans)
     GstColorLut *self = reinterpret_cast<GstColorLut *>(trans);
     mvfx_pair_stop(self->hold, GST_OBJECT(trans), &gst_color_lut_pair_ops); // the held-back frame still needs the LUT
     mvfx_pair_print_stats(self->hold, GST_OBJECT(trans), "colorlut");
+    mvfx_direct_reset(self);
     std::lock_guard<std::mutex> g(*self->lock);
     if (self->lut) mvfx_cube_lut_free(self->lut);
     self->lut = nullptr;
@@ -180,9 +181,30 @@ static GstFlowReturn gst_color_lut_bt_transform(GstBaseTransform *bt, GstBuffer 
         mvfx_hip_fence_end(&dfs, st, NULL, GST_OBJECT(self));
         return MVFX_GST_FLOW(self, drc);
     }
+    MvfxFenceScope fs;
+    // The direct-dispatch lane (csrc/direct_dispatch.h), as in hsvfilter / hsvdetector (gsthsv.cpp): the frame pair goes out as a packet of the library's
+    // own on the lane queue its stream maps to, its completion signal is the fence of both buffers.  RGBA8 through a 3-D LUT only; anything else
+    // comes back MVFX_ERR_DIRECT_UNAVAILABLE with nothing done and takes the stream.  In queue order the lane buys this kernel nothing; what does
+    // (+8-13 %) is the packet WITHOUT the barrier bit, which lets the next frame's workgroups start in the tail of this one's, as the frames of a batched
+    // launch do -- allowed when neither buffer's acquire rested on the queue's order (the usual case: the input's producer has finished or is a source).
+    const int lane_queue = mvfx_direct_queue_of_stream(st);
+    gboolean in_order = FALSE;
+    if (!mvfx_direct_discouraged(self) && mvfx_hip_buffer_acquire_direct_ordered(inbuf, st, lane_queue, &in_order) &&
+        mvfx_hip_buffer_acquire_direct_ordered(outbuf, st, lane_queue, &in_order)) {
+        mvfx_hip_fence_begin_buffers(&fs, inbuf, outbuf, st);
+        mvfx_thread_set_options(MVFX_OPT_DIRECT_DISPATCH | MVFX_OPT_DIRECT_ONLY | (in_order ? 0u : MVFX_OPT_DIRECT_UNORDERED));
+        const int drc = mvfx_colorlut_transform_frame(self->lut, &fi, &fo, st);
+        mvfx_thread_set_options(0);
+        if (drc != MVFX_ERR_DIRECT_UNAVAILABLE) {
+            mvfx_hip_fence_end(&fs, st, NULL, GST_OBJECT(self));
+            gst_buffer_unmap(outbuf, &omap);
+            gst_buffer_unmap(inbuf, &imap);
+            return MVFX_GST_FLOW(self, drc);
+        }
+        mvfx_hip_fence_cancel(&fs);
+    }
     mvfx_hip_buffer_acquire(inbuf, st);
     mvfx_hip_buffer_acquire(outbuf, st);
-    MvfxFenceScope fs;
     mvfx_hip_fence_begin_buffers(&fs, inbuf, outbuf, st);
     int rc = mvfx_colorlut_transform_frame(self->lut, &fi, &fo, st);
     mvfx_hip_fence_end(&fs, st, NULL, GST_OBJECT(self)); // one fence for both buffers, carried by the kernel

@@ -326,7 +326,9 @@ static void wait_for_fence(mvfx_stream stream, mvfx_event ev, const void *produc
     mvfx_stream_wait_event(stream, ev);
 }
 
-gboolean mvfx_hip_buffer_acquire_direct(GstBuffer *buf, mvfx_stream stream, int queue)
+gboolean mvfx_hip_buffer_acquire_direct(GstBuffer *buf, mvfx_stream stream, int queue) { return mvfx_hip_buffer_acquire_direct_ordered(buf, stream, queue, NULL); }
+
+gboolean mvfx_hip_buffer_acquire_direct_ordered(GstBuffer *buf, mvfx_stream stream, int queue, gboolean *relied_on_order)
 {
     for (guint i = 0; buf && i < gst_buffer_n_memory(buf); i++) {
         GstMemory *mem = gst_buffer_peek_memory(buf, i);
@@ -342,7 +344,9 @@ gboolean mvfx_hip_buffer_acquire_direct(GstBuffer *buf, mvfx_stream stream, int 
                 ok = FALSE;         // an ordinary fence still pending: this frame's place is behind it on a stream
             else if (mvfx_event_direct_queue(m->fence->ev) != queue)
                 other = fence_ref(m->fence); // a direct dispatch on the lane's OTHER queue: waited for below
-            // (else: a direct dispatch in front of ours on the same lane queue -- the queue is in order, nothing to do)
+            else if (relied_on_order)
+                *relied_on_order = TRUE;     // a direct dispatch in front of ours on the same lane queue: fine as long as our packet keeps its place
+            // (without the out parameter: the caller's packets always carry the barrier bit -- the queue is in order, nothing to do)
         }
         g_mutex_unlock(&m->lock);
         if (other) {

@@ -68,6 +68,9 @@ void *mvfx_hip_memory_pending_fence(GstMemory *mem);
 // After TRUE the element opens its fence scope and calls the library with MVFX_OPT_DIRECT_DISPATCH | MVFX_OPT_DIRECT_ONLY; on
 // MVFX_ERR_DIRECT_UNAVAILABLE it cancels the scope (mvfx_hip_fence_cancel) and takes the ordinary path.
 gboolean mvfx_hip_buffer_acquire_direct(GstBuffer *buf, void *stream, int queue);
+// The same; *relied_on_order is SET (never cleared) when a block's fence was found pending on the same lane queue, i.e. when the TRUE rests on that
+// queue being in order.  An element whose buffers all came back without it may send its packet without the barrier bit (MVFX_OPT_DIRECT_UNORDERED).
+gboolean mvfx_hip_buffer_acquire_direct_ordered(GstBuffer *buf, void *stream, int queue, gboolean *relied_on_order);
 void mvfx_hip_fence_cancel(MvfxFenceScope *scope);
 // A consumer that found a direct fence still PENDING had to wait on its own thread (a HIP stream cannot wait for it on the device): the producer
 // named by the fence's tag is told, and goes back to launching on its streams -- a direct dispatch pays where nobody is close behind the frame

@@ -176,7 +176,7 @@ int mvfx_copy_device_to_device_async(void *dst_device, const void *src_device, s
 #define MVFX_OPT_LUT_WG_WINDOW 0x100u  /* colorlut, placement 0 on RGBA8 frames and cubes of 5+ points: always the workgroup-window kernel
                                           (by default a content probe of an earlier frame of the LUT's stream chooses between it -- busy
                                           pictures -- and the per-wave windows of placement 7 -- calm ones; same bytes either way) */
-#define MVFX_OPT_DIRECT_DISPATCH 0x200u /* hsvfilter, ONE frame per call (mvfx_hsvfilter_transform_frame_ip), packed 4-byte formats without row padding, settings in
+#define MVFX_OPT_DIRECT_DISPATCH 0x200u /* (colorlut: see below) hsvfilter, ONE frame per call (mvfx_hsvfilter_transform_frame_ip), packed 4-byte formats without row padding, settings in
                                           the strength-reduced kernels' domain, a completion event set on the thread: the library may enqueue the frame's
                                           kernel on a queue of ITS OWN instead of `stream` -- a hand-written AQL packet without the release fence every
                                           kernel dispatch of a HIP stream carries (an L2 write-back walk on eight XCDs; the lane's kernels store
@@ -189,10 +189,18 @@ int mvfx_copy_device_to_device_async(void *dst_device, const void *src_device, s
                                           That event is then a DIRECT fence: mvfx_event_query / _synchronize work as ever; mvfx_stream_wait_event returns at
                                           once when it has fired and otherwise makes the calling THREAD wait (a HIP stream cannot wait for it on the device).
                                           A frame or a box the lane cannot take (row padding, RGB / BGR, literal-kernel settings, MVFX_DIRECT_DISPATCH=0, no
-                                          HSA queue) is launched on `stream` as if the bit were clear; mvfx_event_is_direct says which it was.  Same bytes. */
+                                          HSA queue) is launched on `stream` as if the bit were clear; mvfx_event_is_direct says which it was.  Same bytes.
+                                          Also mvfx_colorlut_transform_frame: ONE RGBA8 frame pair through a 3-D LUT of 4+ points with the window kernels
+                                          (placement 0 or 7; width a multiple of four, rows 16-byte aligned -- row padding is fine here).  In queue order
+                                          the lane buys colorlut little (its kernel is not bound by the release fence); see MVFX_OPT_DIRECT_UNORDERED. */
 #define MVFX_OPT_DIRECT_ONLY 0x400u     /* with MVFX_OPT_DIRECT_DISPATCH: a frame the lane cannot take is NOT launched on `stream`; the call returns
                                           MVFX_ERR_DIRECT_UNAVAILABLE and has done nothing (a caller whose promise (1) rests on the lane's queue order must
                                           not be moved to a stream behind its back) */
+#define MVFX_OPT_DIRECT_UNORDERED 0x800u /* with MVFX_OPT_DIRECT_DISPATCH, colorlut only (the hsv kernels gain nothing from it): the caller promises that everything
+                                          the frame depends on has FINISHED -- promise (1) without its second half -- and the packet goes out WITHOUT the
+                                          barrier bit: it may start while earlier packets of its lane queue still run, as the frames of a batched launch do
+                                          (one 4K frame per call through a 33^3 LUT, natural-like content: 66-70 k fps on two streams, 70-72 k on the lane in
+                                          order, 75-76 k this way; 16 frames per launch: 81 k).  Later packets WITH the bit still wait for it. */
 int mvfx_thread_set_options(uint32_t options);
 uint32_t mvfx_thread_options(void);
 

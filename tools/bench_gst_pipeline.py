@@ -161,6 +161,16 @@ def honest_main(args):
         run(f"hiptestsrc num-buffers=1 ! video/x-raw,format=RGBA,{size} ! filesink location={args.dump_dir}/in.raw", tmp)
         run(flt.format(n=3).replace(" refresh=false", "").replace("fakesink sync=false", f"hipdownload ! filesink location={args.dump_dir}/out.raw"), tmp)
         out["dump"] = {"in": f"{args.dump_dir}/in.raw", "out": f"{args.dump_dir}/out.raw", "frames_out": 3, "width": w, "height": h}
+    if args.lut_element:
+        # colorlut as the single device element on the same rotation (twelve input blocks + twelve output blocks): 4 + 4 algorithmic B/px
+        cube = os.path.join(tmp, "look.cube")
+        with open(cube, "w") as f:
+            f.write(cubes.analytic_3d(args.lut))
+        lut = f"hiptestsrc num-buffers={{n}} refresh=false ! video/x-raw(memory:HIPMemory),format=RGBA,{size} ! colorlut location={cube} ! fakesink sync=false"
+        run(lut.format(n=min(args.n1, 2000)), tmp)
+        l = [rate(lut, tmp, args.n1, args.n2 * 2 // 3, {"MVFX_HIP_POOL_MIN": "12"}) for _ in range(reps)]
+        out["colorlut_hbm_resident_fps"] = round(med(l), 1)
+        out["colorlut_hbm_resident_frac_of_8TBs"] = round(med(l) * 2 * w * h * 4 / 8e12, 4)
     out["hsvfilter_hbm_resident_fps"] = round(med(a), 1)
     out["hsvfilter_hbm_resident_runs"] = [round(x, 1) for x in a]
     out["hsvfilter_hbm_resident_frac_of_8TBs"] = round(med(a) * 2 * w * h * 4 / 8e12, 4)
@@ -172,6 +182,7 @@ def honest_main(args):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--lut-element", type=int, default=0, help="--honest: also the colorlut element alone on the HBM-resident rotation")
     ap.add_argument("--dump-dir", default="", help="--honest: also write the source frame and three filtered buffers of the element there (bench.py compares them with the oracle)")
     ap.add_argument("--honest", type=int, default=0, help="1: the single element on a rotation larger than the Infinity Cache, and with a device consumer (bench.py's sub-line)")
     ap.add_argument("--element", default="", help="hsvfilter | hsvdetector | colorlut: the single element on device memory, pair launches on / off")
