@@ -1304,11 +1304,13 @@ def other_config_legs(w, args):
                 r["config"]["element_model"] = r["config"]["other_launch_model"]["value"]
             if key == "colorlut_natural" and args.stream_threads > 0:
                 try:
-                    r["config"]["one_frame_per_call"] = leg.lane_leg()
+                    one = leg.lane_leg()
+                    r["config"]["one_frame_per_call"] = one
+                    r.setdefault("sub_extra", {})["one_frame_per_call_fps"] = {k: round(one[k]["value"]) for k in ("two_streams", "lane_in_order", "lane")}
                 except Exception as e:  # noqa: BLE001
                     r["config"]["one_frame_per_call"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             if key == "colorlut_natural" and args.noise_sweep:
-                r["sub_extra"] = {"noise_fps": leg.noise_sweep()}
+                r.setdefault("sub_extra", {})["noise_fps"] = leg.noise_sweep()
             if "last_distance" in r["config"]:
                 r["config"]["last_distance"] = r["config"]["last_distance"][0]
             r["measure_seconds"]["make"] = t_made

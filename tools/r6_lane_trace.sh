@@ -1,10 +1,13 @@
 #!/bin/bash
-# tools/r6_lane_trace.sh: rocprofv3 kernel trace of tools/exp_direct_lane.py; per kernel name: count, median duration, median start-to-start
+# tools/r6_lane_trace.sh [tool.py [args ...]]: rocprofv3 kernel trace of tools/exp_direct_lane.py (or of another tool of tools/, with its arguments);
+# per kernel name: count, median duration, median start-to-start
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/ltrace_$$
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -f csv -d "$OUT" -o t -- python3 "$R/tools/exp_direct_lane.py" > "$OUT.log" 2>&1
+TOOL=${1:-exp_direct_lane.py}
+shift || true
+rocprofv3 --kernel-trace -f csv -d "$OUT" -o t -- python3 "$R/tools/$TOOL" "$@" > "$OUT.log" 2>&1
 cat "$OUT.log" | tail -5
 cd "$R"
 python3 - "$OUT" <<'PY'
