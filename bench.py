@@ -404,7 +404,7 @@ def measured_rmw_ceiling(w, base_ptr, bytes_per_launch, regions):
     16-byte non-temporal load + store per lane, in place; the out-of-place twin for the filters that write another frame)."""
     hb = bench_harness()
     out = {}
-    for mode, key in ((0, "in_place_nt"), (1, "in_place_cached"), (2, "out_of_place_nt")):
+    for mode, key in ((0, "in_place_nt"), (1, "in_place_cached"), (2, "out_of_place_nt"), (3, "in_place_write_through")):
         gbs, us = ctypes.c_double(), ctypes.c_double()
         n = 4 * regions  # every region XOR-ed an even number of times: the pool is left as it was
         rc = hb.mvfxbench_rmw_ceiling(ctypes.c_void_p(base_ptr), bytes_per_launch, regions, n, n, mode, w.sptr,
@@ -517,6 +517,8 @@ def cpu_rate(make_unit, seconds, n_threads):
 
 
 NO_VERIFY = [False]       # --no-verify
+# MVFX_BENCH_SIDE_NT=0 (A/B runs against older libraries): the hsv side legs without MVFX_OPT_NONTEMPORAL, as rounds 1-5 ran them
+SIDE_NT = [int(os.environ.get("MVFX_BENCH_SIDE_NT", "1"))]
 ALL_CORES_SECONDS = [None]  # budget of the nproc-thread leg (None: same as the 1-thread leg; 0: skip it) -- set from the command line
 
 
@@ -823,10 +825,16 @@ def make_leg_hsv1080p(w, args):
     fo = [(vfx.Frame * nb)(*[vfx.make_frame(dst[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
     host = [src[k].cpu().numpy().reshape(H, W * 4).copy() for k in range(4)] if w.rank == 0 and w.world == 1 else None
 
+    nt = SIDE_NT[0] and vfx.OPT_NONTEMPORAL
+
     def step(i):
+        # the filter's output is the detector's input (ordinary cached stores: the detector finds the frame in the caches); the detector's output
+        # is read by nobody on the device: MVFX_OPT_NONTEMPORAL = write-through stores (csrc/device_store.hpp)
         k = i % pool
         vfx.check(lib.mvfx_hsvfilter_transform_frames_ip(fi[k], nb, ctypes.byref(fs), sptr))
+        lib.mvfx_thread_set_options(nt)
         vfx.check(lib.mvfx_hsvdetector_transform_frames(fi[k], fo[k], nb, ctypes.byref(ds), sptr))
+        lib.mvfx_thread_set_options(0)
     leg = Leg("hsv1080p", "hsv1080p_frames_per_sec", "frames/s", nb, nb * 4 * W * H * 4, "f32",
               "synthetic videotestsrc pattern=smpte 1920x1080 RGBx frames, device-resident",
               f"hsvfilter (RGBx, in place) + hsvdetector RGBx->RGBA, {nb} streams of 1920x1080 per launch; 8 + 8 algorithmic B/px",
@@ -985,8 +993,10 @@ def make_leg_hsv3(w, args, which):
     fs = vfx.HsvFilterSettings(*SETTINGS)
     ds = vfx.HsvDetectorSettings(*DETECT_SETTINGS)
     if which == "filter":
-        def step(i):
+        def step(i):  # a filter alone: its output is not read again soon (MVFX_OPT_NONTEMPORAL, as the headline)
+            lib.mvfx_thread_set_options(SIDE_NT[0] and vfx.OPT_NONTEMPORAL)
             vfx.check(lib.mvfx_hsvfilter_transform_frames_ip(fi[i % pool], nb, ctypes.byref(fs), sptr))
+            lib.mvfx_thread_set_options(0)
 
         def cpu(seconds):
             import numpy as np
@@ -1023,7 +1033,9 @@ def make_leg_hsv3(w, args, which):
     fo = [(vfx.Frame * nb)(*[vfx.make_frame(dst[b * nb + i].data_ptr(), W, H, W * 4, "RGBA") for i in range(nb)]) for b in range(pool)]
 
     def step(i):
+        lib.mvfx_thread_set_options(SIDE_NT[0] and vfx.OPT_NONTEMPORAL)
         vfx.check(lib.mvfx_hsvdetector_transform_frames(fi[i % pool], fo[i % pool], nb, ctypes.byref(ds), sptr))
+        lib.mvfx_thread_set_options(0)
 
     def cpu(seconds):
         import numpy as np
@@ -1703,7 +1715,7 @@ def hsvfilter_main(args):
     use_streams = args.launch_model == "streams" and streams is not None
     head, other = (streams, batch_model) if use_streams else (batch_model, streams)
     total_frames = args.steps * args.batch * world
-    ceil_gbs = ceiling["in_place_nt"]["GBs"]
+    ceil_gbs = max(ceiling["in_place_nt"]["GBs"], ceiling["in_place_write_through"]["GBs"])  # the better of the two streaming shapes
     kernel_name = "hsvfilter4_typed_kernel" if args.typed_loads else "hsvfilter4_kernel<RGBA, vec4>"
     # wall seconds per launch of the model `value` reports (per GPU: every rank runs its own launches)
     wall_per_launch = args.batch * world / head["value"]
@@ -1712,8 +1724,9 @@ def hsvfilter_main(args):
                  "read_side_GBs": roof["achieved_kernel"] / 2, "ceiling_measured_GBs": ceil_gbs,
                  "frac_of_measured_ceiling": roof["achieved_kernel"] / ceil_gbs if ceil_gbs else None, "ceilings": ceiling,
                  "ceiling_note": "in-tree RMW probe (gst-plugin-rs_amd/bench/probe_rmw.hip): the kernel's own memory shape -- one 16-byte "
-                                 "non-temporal load + store per lane, in place, trivial arithmetic -- over the same resident pool, timed with "
-                                 "HIP events in this run after the timed legs; in_place_cached / out_of_place_nt are the shapes of the other filters",
+                                 "load + store per lane, in place, trivial arithmetic -- over the same resident pool, timed with HIP events in this "
+                                 "run after the timed legs; the better of non-temporal load + store (rounds 1-5) and cached load + write-through "
+                                 "store (what the kernel does since round 6); in_place_cached / out_of_place_nt are the shapes of the other filters",
                  "launch_model": batch_model["launch_model"]})
     # what ONE drop-in hsvfilter element does (one call per buffer, hsvfilter/imp.rs:322-326), beside the batched entry `value` reports
     element_path = None
@@ -2007,8 +2020,8 @@ def main():
                     help="extra steps with a HIP event between every two, for the p10/p50/p90 of the per-step time (0 = skip)")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 literal kernel, 2 strength-reduced")
     ap.add_argument("--streaming", type=int, default=1,
-                    help="MVFX_OPT_NONTEMPORAL: 1 = non-temporal loads/stores (the frames of this workload are not "
-                         "read again on the GPU: standalone filter), 0 = normal caching (element chains)")
+                    help="MVFX_OPT_NONTEMPORAL: 1 = the frames of this workload are not read again on the GPU (standalone filter): "
+                         "write-through stores with the non-temporal hint (round 6, csrc/device_store.hpp), 0 = ordinary cached stores (element chains)")
     ap.add_argument("--frame-content", default="videotestsrc", choices=list(FRAME_CONTENTS),
                     help="hsvfilter workload: what the frames hold. videotestsrc = pattern=smpte frames exactly as GStreamer's "
                          "videotestsrc renders them (the buffers BASELINE.json's workload names); natural = smooth gradients + "

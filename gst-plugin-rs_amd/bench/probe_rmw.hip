@@ -18,6 +18,17 @@ __global__ __launch_bounds__(256) void mvfxbench_rmw_kernel(u32x4 *buf, size_t n
     if (NT) __builtin_nontemporal_store(v, buf + i); else buf[i] = v;
 }
 
+// The same shape with the stores of round 6's streaming kernels (csrc/device_store.hpp): cached 16-byte load, write-through store with the
+// non-temporal hint.  (s_nop 2: the wait states an inline-asm store of more than 64 bits of data needs.)
+__global__ __launch_bounds__(256) void mvfxbench_rmw_wt_kernel(u32x4 *buf, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    u32x4 v = buf[i];
+    v.x ^= 0x00010203u; v.y ^= 0x00010203u; v.z ^= 0x00010203u; v.w ^= 0x00010203u;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 2" : : "v"(buf + i), "v"(v) : "memory");
+}
+
 // Out-of-place twin (16-byte load from src, 16-byte store to dst): the shape of hsvdetector / colorlut / the converters.
 __global__ __launch_bounds__(256) void mvfxbench_copy_kernel(const u32x4 *src, u32x4 *dst, size_t n)
 {
@@ -32,8 +43,8 @@ extern "C" {
 
 // `regions` regions of `bytes_per_launch` bytes (multiple of 16) starting at `buf`, visited round-robin, one launch each;
 // `warm` untimed launches, then `launches` timed ones between two HIP events on `stream`.  mode 0: in place, non-temporal;
-// 1: in place, cached; 2: out of place (region k -> region k+1, non-temporal).  Every region is XOR-ed an even number of
-// times when (warm + launches) is a multiple of 2 * regions (modes 0/1), i.e. the pool is left as it was.
+// 1: in place, cached; 2: out of place (region k -> region k+1, non-temporal); 3: in place, cached load + write-through store.  Every region is
+// XOR-ed an even number of times when (warm + launches) is a multiple of 2 * regions (modes 0/1/3), i.e. the pool is left as it was.
 int mvfxbench_rmw_ceiling(void *buf, size_t bytes_per_launch, uint32_t regions, uint32_t warm, uint32_t launches, int mode,
                           void *stream, double *gbs_out, double *us_per_launch_out)
 {
@@ -46,6 +57,7 @@ int mvfxbench_rmw_ceiling(void *buf, size_t bytes_per_launch, uint32_t regions, 
         u32x4 *p = (u32x4 *)((char *)buf + (size_t)(k % regions) * bytes_per_launch);
         if (mode == 0) hipLaunchKernelGGL(mvfxbench_rmw_kernel<true>, dim3(grid), dim3(256), 0, st, p, n);
         else if (mode == 1) hipLaunchKernelGGL(mvfxbench_rmw_kernel<false>, dim3(grid), dim3(256), 0, st, p, n);
+        else if (mode == 3) hipLaunchKernelGGL(mvfxbench_rmw_wt_kernel, dim3(grid), dim3(256), 0, st, p, n);
         else hipLaunchKernelGGL(mvfxbench_copy_kernel, dim3(grid), dim3(256), 0, st, p,
                                 (u32x4 *)((char *)buf + (size_t)((k + 1) % regions) * bytes_per_launch), n);
     };

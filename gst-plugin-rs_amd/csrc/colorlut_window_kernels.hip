@@ -243,6 +243,8 @@ __global__ __launch_bounds__(256) void colorlut_xtable_build_kernel(const float4
 }
 
 // the HIP kernels of the two window forms (bodies: colorlut_xwindow.hpp); blockIdx.z = the frame of the batch
+// (non-temporal stores, not the write-through ones of csrc/device_store.hpp: measured equal on pictures, 8 % slower on uniform-random colours --
+// profiles/r6/store_policy_ab.txt)
 __global__ __launch_bounds__(kBlock) void colorlut_xtile_kernel(FrameBatch in_fb, FrameBatch out_fb, uint32_t width, uint32_t height,
                                                                 uint32_t in_stride, uint32_t out_stride, LutParams p)
 {

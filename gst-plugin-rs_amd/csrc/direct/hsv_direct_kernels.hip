@@ -17,7 +17,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // The stores are WRITE-THROUGH at system scope (sc0 sc1) and drained before the wave ends: the lane's packets carry NO release fence (an L2
 // write-back walk on eight XCDs per dispatch, 1.2 us of every 4K frame: profiles/r6/aql_probe_real_kernel_store_policies.txt), so the bytes must be
 // in memory when the completion signal fires -- the write-through publish of MI355X_MICROARCH.md ("sc1 stores + vmcnt(0)"); whoever reads them next
-// does its own acquire.  NT: the LOADS are non-temporal (the frame is read once).
+// does its own acquire.  NT (MVFX_OPT_NONTEMPORAL: nobody on the device reads the frame next): the stores carry the non-temporal hint as well.
 template <int VARIANT, bool NT>
 __device__ __forceinline__ void direct_hsvfilter4(const DirectHsvArgs &a)
 {
@@ -54,7 +54,7 @@ __device__ __forceinline__ void direct_hsvfilter4(const DirectHsvArgs &a)
                    "=&v"(c[1][0]), "=&v"(c[1][1]), "=&v"(c[1][2]), "=&v"(c[1][3])                 \
                  : "v"(voff[0]), "v"(voff[1]), "s"(rs)                                            \
                  : "memory")
-    if constexpr (NT) MVFX_DIRECT_LOADS2(" nt"); else MVFX_DIRECT_LOADS2("");
+    MVFX_DIRECT_LOADS2(""); // (cached loads in both forms: `nt` loads lose 3 % here, profiles/r6/direct_lane_one_thread.txt)
 #undef MVFX_DIRECT_LOADS2
 #pragma unroll
     for (int u = 0; u < TILE; u++) {
@@ -71,7 +71,9 @@ __device__ __forceinline__ void direct_hsvfilter4(const DirectHsvArgs &a)
             u32x4 *dst = reinterpret_cast<u32x4 *>(a.frame + ((uint64_t)g << 4));
             // (s_nop: a VMEM store of more than 64 bits reads its data registers up to two wait states after issue, and the compiler -- which
             // inserts those wait states behind its own stores -- does not know this asm is one: without them ~0.2 % of the pixels came out wrong)
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" : : "v"(dst), "v"(t) : "memory");
+            // NT (MVFX_OPT_NONTEMPORAL: nobody on the device reads the frame next): the non-temporal hint on top, as csrc/device_store.hpp
+            if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 2" : : "v"(dst), "v"(t) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" : : "v"(dst), "v"(t) : "memory");
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store of this wave acknowledged (the compiler does not count asm stores)

@@ -22,6 +22,7 @@
 //   dependent chain and the four pixels of a group have to be interleaved by the scheduler (+3.8 %).
 #include "hsv_math.hpp"
 #include "hsv_filter_lds.hpp"
+#include "device_store.hpp"
 #include "direct_dispatch.h"
 #include "convert_math.hpp"
 #include "mvfx_internal.h"
@@ -289,6 +290,7 @@ __device__ __forceinline__ uint32_t detect_px4_fast(uint32_t px, const HsvDetect
 #ifndef MVFX_DET_TILE
 #define MVFX_DET_TILE 2 // 16-byte pixel groups per lane of hsvdetector_typed_kernel (round 5; 1 = rounds 3/4)
 #endif
+template <bool STREAM> // the output is not read again soon (MVFX_OPT_NONTEMPORAL): write-through stores (device_store.hpp)
 __global__ __launch_bounds__(kBlock) void hsvdetector_typed_kernel(FrameBatch in_fb, FrameBatch out_fb, uint64_t width, uint32_t rows,
                                                                    uint64_t in_stride, uint64_t out_stride, HsvDetectorParams p,
                                                                    uint32_t word3, uint32_t frame_bytes, uint32_t perm_sel)
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void hsvdetector_typed_kernel(FrameBatch in
                         const HsvN hsv = from_unit_rgb_fast_n(c[u][j].x, c[u][j].y, c[u][j].z, p.consts);
                         r[j] = __builtin_amdgcn_perm(~detect_miss_mask_fast(hsv, p), w[j], sel); // selector byte 4 = the hit mask
                     }
-                    *reinterpret_cast<uint4 *>(oline + (g << 4)) = make_uint4(r[0], r[1], r[2], r[3]);
+                    stream_store16<STREAM>(oline + (g << 4), store_u32x4{r[0], r[1], r[2], r[3]});
                 }
             }
         }
@@ -363,6 +365,7 @@ __global__ __launch_bounds__(kBlock) void hsvdetector_typed_kernel(FrameBatch in
 // colour bytes come out of the raw twelve bytes with one two-source v_perm_b32 per pixel (selectors from the host: they depend on the
 // two layouts only), the alpha byte is the hit mask through one v_and_or_b32.
 typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+template <bool STREAM>
 __global__ __launch_bounds__(kBlock) void hsvdetector3_typed_kernel(FrameBatch in_fb, FrameBatch out_fb, uint64_t width, uint32_t rows,
                                                                     uint64_t in_stride, uint64_t out_stride, HsvDetectorParams p,
                                                                     uint32_t word3a, uint32_t word3b, uint32_t frame_bytes, uint4 perm_sel,
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void hsvdetector3_typed_kernel(FrameBatch i
                 const uint32_t colour = __builtin_amdgcn_perm(hi[j], lo[j], sel[j]);
                 r[j] = (~detect_miss_mask_fast(hsv, p) & am) | colour;
             }
-            *reinterpret_cast<uint4 *>(oline + (g << 4)) = make_uint4(r[0], r[1], r[2], r[3]);
+            stream_store16<STREAM>(oline + (g << 4), store_u32x4{r[0], r[1], r[2], r[3]});
         }
     }
 }
@@ -1116,7 +1119,8 @@ int hsvdetector_impl(const mvfx_frame *ins, const mvfx_frame *outs, uint32_t n,
             if (opt_direct_only()) return fail(MVFX_ERR_DIRECT_UNAVAILABLE, "hsvdetector: the direct-dispatch lane cannot take this frame");
             dim3 tgrid = grid; // MVFX_DET_TILE groups per lane
             tgrid.x = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((work + (uint64_t)kBlock * MVFX_DET_TILE - 1) / ((uint64_t)kBlock * MVFX_DET_TILE), 65535u * 16u));
-            MVFX_LAUNCH(hsvdetector_typed_kernel, tgrid, dim3(kBlock), 0, stream, ifb, ofb, width, rows, is, os, p, word3, (uint32_t)in_bytes, sel);
+            if (opt_nontemporal()) MVFX_LAUNCH(hsvdetector_typed_kernel<true>, tgrid, dim3(kBlock), 0, stream, ifb, ofb, width, rows, is, os, p, word3, (uint32_t)in_bytes, sel);
+            else MVFX_LAUNCH(hsvdetector_typed_kernel<false>, tgrid, dim3(kBlock), 0, stream, ifb, ofb, width, rows, is, os, p, word3, (uint32_t)in_bytes, sel);
             MVFX_HIP_TRY(hipGetLastError());
             continue;
         }
@@ -1133,8 +1137,10 @@ int hsvdetector_impl(const mvfx_frame *ins, const mvfx_frame *outs, uint32_t n,
                 const uint32_t o0 = ibgr != obgr ? c2 : c0, o2 = ibgr != obgr ? c0 : c2;
                 sels[j] = a0 ? (0x0cu | (o0 << 8) | (c1 << 16) | (o2 << 24)) : (o0 | (c1 << 8) | (o2 << 16) | (0x0cu << 24));
             }
-            MVFX_LAUNCH(hsvdetector3_typed_kernel, grid, dim3(kBlock), 0, stream, ifb, ofb, width, rows, is, os, p, word3a, word3b, (uint32_t)in_bytes,
-                        make_uint4(sels[0], sels[1], sels[2], sels[3]), a0 ? 0x000000ffu : 0xff000000u);
+            const uint4 sel4 = make_uint4(sels[0], sels[1], sels[2], sels[3]);
+            const uint32_t alpha_mask = a0 ? 0x000000ffu : 0xff000000u;
+            if (opt_nontemporal()) MVFX_LAUNCH(hsvdetector3_typed_kernel<true>, grid, dim3(kBlock), 0, stream, ifb, ofb, width, rows, is, os, p, word3a, word3b, (uint32_t)in_bytes, sel4, alpha_mask);
+            else MVFX_LAUNCH(hsvdetector3_typed_kernel<false>, grid, dim3(kBlock), 0, stream, ifb, ofb, width, rows, is, os, p, word3a, word3b, (uint32_t)in_bytes, sel4, alpha_mask);
             MVFX_HIP_TRY(hipGetLastError());
             continue;
         }

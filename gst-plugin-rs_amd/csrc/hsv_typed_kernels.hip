@@ -3,6 +3,7 @@
 // with the max-memory-clause scheduling strategy (gst-plugin-rs_amd/Makefile HSVTYPED_EXTRA: 88.2 k fps against 87.6 k with
 // LLVM's default GCN scheduler and 86.2 k with the iterative-ilp strategy hsv_kernels.hip is built with).
 #include "hsv_filter_lds.hpp"
+#include "device_store.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -78,9 +79,9 @@ __device__ __forceinline__ void hsvfilter4_typed_body(const FrameBatch &fb, uint
                  : "v"(voff[0]), "s"(rs)                                                          \
                  : "memory")
             if constexpr (TILE == 2) {
-                if constexpr (NT) MVFX_TYPED_LOADS2(" nt"); else MVFX_TYPED_LOADS2("");
+                if constexpr (NT && MVFX_STREAM_NT_LOADS) MVFX_TYPED_LOADS2(" nt"); else MVFX_TYPED_LOADS2("");
             } else {
-                if constexpr (NT) MVFX_TYPED_LOADS1(" nt"); else MVFX_TYPED_LOADS1("");
+                if constexpr (NT && MVFX_STREAM_NT_LOADS) MVFX_TYPED_LOADS1(" nt"); else MVFX_TYPED_LOADS1("");
             }
 #undef MVFX_TYPED_LOADS2
 #undef MVFX_TYPED_LOADS1
@@ -96,8 +97,7 @@ __device__ __forceinline__ void hsvfilter4_typed_body(const FrameBatch &fb, uint
                         w[j] = __builtin_amdgcn_perm(T, w[j], sextant_at(lds.sextant, sel_off));
                     }
                     const u32x4 t = {w[0], w[1], w[2], w[3]};
-                    if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(line + (g << 4)));
-                    else *reinterpret_cast<u32x4 *>(line + (g << 4)) = t;
+                    stream_store16<NT>(line + (g << 4), t);
                 }
             }
         }
@@ -190,9 +190,9 @@ __global__ __launch_bounds__(kBlock) void hsvfilter3_typed_kernel(FrameBatch fb,
                  : "v"(voff[0]), "s"(ra), "s"(rb)                                                   \
                  : "memory")
             if constexpr (TILE == 2) {
-                if constexpr (NT) MVFX_TYPED3_2(" nt"); else MVFX_TYPED3_2("");
+                if constexpr (NT && MVFX_STREAM_NT_LOADS) MVFX_TYPED3_2(" nt"); else MVFX_TYPED3_2("");
             } else {
-                if constexpr (NT) MVFX_TYPED3_1(" nt"); else MVFX_TYPED3_1("");
+                if constexpr (NT && MVFX_STREAM_NT_LOADS) MVFX_TYPED3_1(" nt"); else MVFX_TYPED3_1("");
             }
 #undef MVFX_TYPED3_2
 #undef MVFX_TYPED3_1
@@ -210,8 +210,7 @@ __global__ __launch_bounds__(kBlock) void hsvfilter3_typed_kernel(FrameBatch fb,
                     // twelve bytes: p0 = d0[0..2], p1 = d0[3] d1[0..1], p2 = d1[2..3] d2[0], p3 = d2[1..3]   (v_perm: bytes 0-3 = S1, 4-7 = S0)
                     const u32x3 t = {__builtin_amdgcn_perm(w[1], w[0], 0x04020100u), __builtin_amdgcn_perm(w[2], w[1], 0x05040201u),
                                      __builtin_amdgcn_perm(w[3], w[2], 0x06050402u)};
-                    if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<u32x3 *>(line + g * 12));
-                    else *reinterpret_cast<u32x3 *>(line + g * 12) = t;
+                    stream_store12<NT>(line + g * 12, t);
                 }
             }
         }
@@ -301,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void hsvfilter3_typed_rows_kernel(FrameBatc
                  : "=&v"(c[0][0]), "=&v"(c[0][1]), "=&v"(c[0][2]), "=&v"(c[0][3]), "=&v"(c[1][0]), "=&v"(c[1][1]), "=&v"(c[1][2]), "=&v"(c[1][3]) \
                  : "v"(voff[0]), "v"(voff[1]), "s"(ra), "s"(rb)                                     \
                  : "memory")
-            if constexpr (NT) MVFX_TYPED3R(" nt"); else MVFX_TYPED3R("");
+            if constexpr (NT && MVFX_STREAM_NT_LOADS) MVFX_TYPED3R(" nt"); else MVFX_TYPED3R("");
 #undef MVFX_TYPED3R
 #pragma unroll
             for (int u = 0; u < TILE; u++) {
@@ -315,8 +314,7 @@ __global__ __launch_bounds__(kBlock) void hsvfilter3_typed_rows_kernel(FrameBatc
                     }
                     const u32x3 t = {__builtin_amdgcn_perm(w[1], w[0], 0x04020100u), __builtin_amdgcn_perm(w[2], w[1], 0x05040201u),
                                      __builtin_amdgcn_perm(w[3], w[2], 0x06050402u)};
-                    if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<u32x3 *>(frame + at[u]));
-                    else *reinterpret_cast<u32x3 *>(frame + at[u]) = t;
+                    stream_store12<NT>(frame + at[u], t);
                 }
             }
         }

@@ -155,9 +155,12 @@ int mvfx_copy_device_to_device_async(void *dst_device, const void *src_device, s
  * and these options are thread-local, so elements on different streaming threads never see each other's choice and
  * an element that shares a thread with others sets its word before its call (one TLS store).  Every combination
  * produces the same bytes; the options pick cache policy and kernel variant.  0 (default) = automatic. */
-#define MVFX_OPT_NONTEMPORAL 0x01u     /* hsvfilter: non-temporal loads/stores -- the frame leaves the GPU or is not re-read
-                                          before ~256 MB of other traffic (+3 % on a standalone stream); leave clear when
-                                          the next element reads it on the GPU (hsvfilter ! hsvdetector: +4 % for the pair) */
+#define MVFX_OPT_NONTEMPORAL 0x01u     /* hsvfilter, hsvdetector: the OUTPUT leaves the GPU or is not read again before ~256 MB of other traffic -- the
+                                          typed kernels store it WRITE-THROUGH with the non-temporal hint (`sc0 sc1 nt`; round 6, csrc/device_store.hpp):
+                                          nothing stays dirty in the L2s, the release fence at the end of the dispatch has nothing to write back (16 x 4K
+                                          per launch +2-5 %, one frame per call on a stream 81 k -> 90.7 k fps).  Leave clear when the next kernel reads
+                                          the frame (hsvfilter ! hsvdetector on 1080p: 3 % for the pair); the VALU kernels take it as non-temporal
+                                          loads / stores, as rounds 1-5 did */
 #define MVFX_OPT_HSV_LITERAL 0x02u     /* hsvfilter/hsvdetector: force the literal transcription (IEEE divides, fmodf) */
 #define MVFX_OPT_HSV_FORCE_FAST 0x04u  /* force the strength-reduced kernels; MVFX_ERR_INVALID_ARGUMENT when the settings
                                           are outside their proven domain instead of silently running the literal ones */

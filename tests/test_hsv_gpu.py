@@ -33,9 +33,9 @@ GENERAL_ONLY_SETTINGS = [               # outside the strength-reduced kernel's 
 ]
 
 
-def _device_filter(vfx, host_frame, w, h, stride, fmt, settings, variant=0, batch=False):
+def _device_filter(vfx, host_frame, w, h, stride, fmt, settings, variant=0, batch=False, nontemporal=False):
     buf = vfx.DeviceBuffer(host_frame.nbytes).upload(host_frame)
-    vfx.check(vfx.lib().mvfx_thread_set_options(vfx.options(variant=variant).word))
+    vfx.check(vfx.lib().mvfx_thread_set_options(vfx.options(variant=variant, nontemporal=nontemporal).word))
     try:
         s = vfx.HsvFilterSettings(*settings)
         if batch:
@@ -188,17 +188,14 @@ def test_hsvfilter_batch_matches_single(gpu):
 
 @pytest.mark.parametrize("w,h", [(3840, 2160), (1021, 7), (8, 1), (2047, 3)])
 def test_hsvfilter_streaming_policy_same_bytes(gpu, w, h):
-    """MVFX_OPT_NONTEMPORAL (non-temporal loads/stores, 2 pixel groups per lane) changes no byte;
-    sizes with partial tiles / 1-3 pixel tails included."""
+    """MVFX_OPT_NONTEMPORAL (write-through stores since round 6, csrc/device_store.hpp) changes no byte; sizes with partial tiles / 1-3 pixel tails
+    included.  (Until round 6 the helper reset the option word before the call: the option was not what this test ran.)"""
     frame = frames.random_frame(0x5EED0400 + w, w, h)
     expect = frame.copy()
     assert orc.hsvfilter(expect, w, w * 4, "RGBA", BENCH_SETTINGS) == 0
-    try:
-        gpu.check(gpu.lib().mvfx_thread_set_options(gpu.options(nontemporal=bool(1)).word))
-        got = _device_filter(gpu, frame, w, h, w * 4, "RGBA", BENCH_SETTINGS, 0)
-    finally:
-        gpu.check(gpu.lib().mvfx_thread_set_options(gpu.options(nontemporal=bool(0)).word))
-    assert np.array_equal(got, expect)
+    for batch in (False, True):
+        got = _device_filter(gpu, frame, w, h, w * 4, "RGBA", BENCH_SETTINGS, 0, batch=batch, nontemporal=True)
+        assert np.array_equal(got, expect), batch
 
 
 def test_hsvfilter_4k_full_size(gpu):
@@ -612,3 +609,63 @@ def test_hsvfilter_rgb3_widths_that_are_not_multiples_of_four(gpu, fmt, w, h):
     assert orc.hsvfilter(want, w, stride, fmt, BENCH_SETTINGS) == 0
     for b in bufs:
         assert np.array_equal(b.download().reshape(h, stride), want)
+
+
+# ---------------------------------------------------------------- MVFX_OPT_NONTEMPORAL = write-through stores (round 6, csrc/device_store.hpp)
+# With the option the typed kernels store `global_store_dwordx4 / x3 ... sc0 sc1 nt` through inline asm (the hsvdetector kernels gained the
+# instantiation in round 6).  New store instructions => their own proofs: all 2^24 colours, every kernel that has the form.
+
+@pytest.mark.parametrize("fmt", ["RGBA", "xBGR"])
+@pytest.mark.parametrize("settings", [BENCH_SETTINGS, (-123.4, 0.5, 0.3, 1.7, -0.2)], ids=["bench", "negative"])
+def test_hsvfilter_streaming_stores_exhaustive(gpu, exhaustive, fmt, settings):
+    want = exhaustive.copy()
+    assert orc.hsvfilter(want, 4096, 4096 * 4, fmt, settings) == 0
+    s = gpu.HsvFilterSettings(*settings)
+    try:
+        gpu.check(gpu.lib().mvfx_thread_set_options(gpu.options(nontemporal=True).word))
+        for batch in (False, True):
+            buf = gpu.DeviceBuffer(exhaustive.nbytes).upload(exhaustive)
+            if batch:
+                gpu.hsvfilter_device_batch([buf.ptr], 4096, 4096, 4096 * 4, fmt, s)
+            else:
+                gpu.hsvfilter_device(buf.ptr, 4096, 4096, 4096 * 4, fmt, s)
+            gpu.check(gpu.lib().mvfx_stream_synchronize(None))
+            got = buf.download().reshape(exhaustive.shape)
+            assert np.array_equal(got, want), (batch, int(np.count_nonzero(got != want)))
+    finally:
+        gpu.check(gpu.lib().mvfx_thread_set_options(0))
+
+
+@pytest.mark.parametrize("in_fmt,out_fmt", [("RGBx", "RGBA"), ("xBGR", "ARGB"), ("RGB", "BGRA"), ("BGR", "ABGR")])
+def test_hsvdetector_streaming_stores_exhaustive(gpu, exhaustive, exhaustive3, in_fmt, out_fmt):
+    """hsvdetector_typed_kernel<true> / hsvdetector3_typed_kernel<true>: all 2^24 colours, two settings, and a frame with row padding on the output
+    (kept) whose last groups are partial tiles"""
+    L = gpu.lib()
+    three = in_fmt in ("RGB", "BGR")
+    ex = exhaustive3 if three else exhaustive
+    istride = 4096 * (3 if three else 4)
+    src = gpu.DeviceBuffer(ex.nbytes).upload(ex)
+    dst = gpu.DeviceBuffer(4096 * 4096 * 4)
+    fi, fo = gpu.make_frame(src.ptr, 4096, 4096, istride, in_fmt), gpu.make_frame(dst.ptr, 4096, 4096, 4096 * 4, out_fmt)
+    try:
+        gpu.check(L.mvfx_thread_set_options(gpu.options(nontemporal=True).word))
+        for settings in (DETECT_SETTINGS[0], DETECT_SETTINGS[3]):
+            want = np.empty((4096, 4096 * 4), np.uint8)
+            assert orc.hsvdetector(ex, istride, in_fmt, want, 4096 * 4, out_fmt, 4096, settings) == 0
+            gpu.check(L.mvfx_hsvdetector_transform_frame(ctypes.byref(fi), ctypes.byref(fo), ctypes.byref(gpu.HsvDetectorSettings(*settings)), None))
+            gpu.check(L.mvfx_stream_synchronize(None))
+            got = dst.download().reshape(want.shape)
+            assert np.array_equal(got, want), (settings, int(np.count_nonzero(got != want)))
+        w, h, bpp = 1004, 37, 3 if three else 4
+        istr, ostr = w * bpp + (12 if three else 16), w * 4 + 16  # (four pixels of padding on both sides: what the reference's row zip accepts)
+        f = frames.random_frame(0x5EED1200 + bpp, w, h, bpp, istr)
+        fill = np.full((h, ostr), 0x6B, np.uint8)
+        want = fill.copy()
+        assert orc.hsvdetector(f, istr, in_fmt, want, ostr, out_fmt, w, DETECT_SETTINGS[0]) == 0
+        a, b = gpu.DeviceBuffer(f.nbytes).upload(f), gpu.DeviceBuffer(fill.nbytes).upload(fill)
+        fa, fb = gpu.make_frame(a.ptr, w, h, istr, in_fmt), gpu.make_frame(b.ptr, w, h, ostr, out_fmt)
+        gpu.check(L.mvfx_hsvdetector_transform_frame(ctypes.byref(fa), ctypes.byref(fb), ctypes.byref(gpu.HsvDetectorSettings(*DETECT_SETTINGS[0])), None))
+        gpu.check(L.mvfx_stream_synchronize(None))
+        assert np.array_equal(b.download().reshape(h, ostr), want)
+    finally:
+        gpu.check(L.mvfx_thread_set_options(0))
