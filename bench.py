@@ -920,6 +920,7 @@ def make_leg_colorlut(w, args, content):
         fout = (vfx.Frame * nfr)(*[vfx.make_frame(dst[k].data_ptr(), W, H, W * 4, "RGBA") for k in range(nfr)])
         launches, reps = 1500, 5
         res = {}
+        settle(step, 0.4, w.sync)  # (the CPU baseline of the leg ran in between: the clocks are down, and 3000 warm-up frames are 45 ms)
         for name, opt in (("two_streams", 0), ("lane_in_order", vfx.OPT_DIRECT_DISPATCH), ("lane", vfx.OPT_DIRECT_DISPATCH | vfx.OPT_DIRECT_UNORDERED)):
             secs, took = (ctypes.c_double * reps)(), ctypes.c_uint64()
             w.sync()

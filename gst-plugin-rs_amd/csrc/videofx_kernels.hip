@@ -873,7 +873,7 @@ struct PlaneCopies {
 // non-temporal: the planes stream through once; alone the kernel runs the same 11 us per 4K compose, beside colordetect on another
 // stream the pair gains 2.7 % (44.0 k -> 45.2 k frames/s: the histogram partials keep the L2)
 #ifndef MVFX_COPY_PLANES_NT
-#define MVFX_COPY_PLANES_NT 1
+#define MVFX_COPY_PLANES_NT 2
 #endif
 __global__ __launch_bounds__(256) void copy_planes_kernel(PlaneCopies pc)
 {
@@ -886,7 +886,11 @@ __global__ __launch_bounds__(256) void copy_planes_kernel(PlaneCopies pc)
         if (vec) {
             const uint64_t n16 = c.row_bytes >> 4;
             for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += step) {
-#if MVFX_COPY_PLANES_NT
+#if MVFX_COPY_PLANES_NT == 2 // non-temporal load + the write-through store of csrc/device_store.hpp: 4K I420 -> A420 compose 89.1 k -> 91.4-92.2 k fps
+                typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(s) + i);
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 2" : : "v"(reinterpret_cast<u32x4_t *>(d) + i), "v"(t) : "memory");
+#elif MVFX_COPY_PLANES_NT // (rounds 3-5: non-temporal load + store)
                 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
                 __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(s) + i), reinterpret_cast<u32x4_t *>(d) + i);
 #else
