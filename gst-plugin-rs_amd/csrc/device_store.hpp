@@ -12,6 +12,8 @@
 // The inline-asm store needs the wait states the compiler inserts behind its own wide stores: a VMEM store of more than 64 bits of data reads its
 // data registers up to two wait states after issue (without `s_nop 2` 0.2 % of the pixels came out wrong -- caught by the 2^24 proofs).  The
 // compiler does not count an asm store in vmcnt; on gfx9 vmcnt retires in order, so its own waits only become conservative.
+// (Which bit: `sc1 nt` -- agent scope -- runs like `sc0 sc1 nt`, `sc0 nt` like `nt` alone: what counts is that the store is written through
+// past the L2, which on a part with eight non-coherent L2s agent scope already demands.)
 // MVFX_STORE_POLICY=0 (A/B builds): `nt` stores as in rounds 2-5.
 #pragma once
 
