@@ -973,6 +973,7 @@ void mvfx_cube_lut_free(mvfx_cube_lut *lut)
     const bool have_dev = hipGetDevice(&before) == hipSuccess;
     lut->copies.for_each([&](int dev, LutDeviceCopy &d) {
         if (have_dev && dev != before) (void)hipSetDevice(dev);
+        mvfx::direct_quiesce(dev); // a lane kernel of the last frames may still be reading the tables: hipFree does not wait for queues of our own
         mvfx::free_device_copy(d);
     });
     if (have_dev) { int now = -1; if (hipGetDevice(&now) == hipSuccess && now != before) (void)hipSetDevice(before); }

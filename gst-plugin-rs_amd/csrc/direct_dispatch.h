@@ -59,6 +59,11 @@ int direct_queue_hint(hipStream_t stream);
 int direct_hsvfilter_submit(const DirectHsvArgs &args, bool neg_shift, bool nontemporal, int queue);
 int direct_hsvdetector_submit(const DirectDetArgs &args, int queue);
 
+// Every lane dispatch made so far on `device` has FINISHED when this returns (a barrier packet behind each of the lane's queues, waited for on the
+// calling thread).  For whoever frees memory a lane kernel may still be reading: hipFree waits for the HIP streams of the device, not for queues it
+// does not know (the LUT tables of a mvfx_cube_lut; frame blocks carry their own fence and need none of this).  No lane on the device: returns at once.
+void direct_quiesce(int device);
+
 // ---- direct fences: an mvfx_event whose last "record" was a lane dispatch ------------------------------------------------------------
 // state 0: the event is an ordinary HIP event (or was never used); 1: complete direct fence; 2: pending direct fence
 int direct_event_state(hipEvent_t e);

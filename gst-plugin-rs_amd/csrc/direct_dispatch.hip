@@ -36,7 +36,7 @@ constexpr size_t kKernelArgBytes[kDirectKernels] = {sizeof(DirectHsvArgs), sizeo
                                                     sizeof(DirectLutArgs), sizeof(DirectLutArgs)};
 
 struct Lane {
-    bool ok = false;
+    std::atomic<bool> ok{false};
     hsa_agent_t agent{};
     hsa_queue_t *queue[kQueues] = {};  // frames alternate between them (each in order: its packets carry the barrier bit)
     std::atomic<uint64_t> next{0};     // dispatch counter: argument slot = next % kArgSlots
@@ -140,17 +140,17 @@ void build_lane(Lane &l, int device)
     for (auto &s : l.slot_signal) s.store(0, std::memory_order_relaxed);
     for (uint32_t k = 0; k < kQueues; k++)
         if (hsa_queue_create(l.agent, kQueuePackets, HSA_QUEUE_TYPE_MULTI, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &l.queue[k]) != HSA_STATUS_SUCCESS) return;
-    l.ok = true;
+    l.ok.store(true, std::memory_order_release);
 }
 
 constexpr int kMaxDevices = 64;
+Lane g_lanes[kMaxDevices];
+std::once_flag g_lane_once[kMaxDevices];
 Lane *lane_of(int device)
 {
-    static Lane lanes[kMaxDevices];
-    static std::once_flag once[kMaxDevices];
     if (device < 0 || device >= kMaxDevices) return nullptr;
-    std::call_once(once[device], [device] { build_lane(lanes[device], device); });
-    return lanes[device].ok ? &lanes[device] : nullptr;
+    std::call_once(g_lane_once[device], [device] { build_lane(g_lanes[device], device); });
+    return g_lanes[device].ok.load(std::memory_order_acquire) ? &g_lanes[device] : nullptr;
 }
 
 // ---- direct fences ----------------------------------------------------------------------------------------------------------------
@@ -200,6 +200,31 @@ void wait_signal(hsa_signal_t s)
 }
 
 } // namespace
+
+void direct_quiesce(int device)
+{
+    if (device < 0 || device >= kMaxDevices || !g_lanes[device].ok.load(std::memory_order_acquire)) return; // (never builds a lane)
+    Lane &l = g_lanes[device];
+    hsa_signal_t done[kQueues] = {};
+    uint32_t n = 0;
+    for (uint32_t k = 0; k < kQueues; k++) {
+        if (hsa_signal_create(1, 0, nullptr, &done[n]) != HSA_STATUS_SUCCESS) continue;
+        hsa_queue_t *q = l.queue[k];
+        const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 1);
+        while (idx - hsa_queue_load_read_index_scacquire(q) >= q->size) {}
+        hsa_barrier_and_packet_t *p = reinterpret_cast<hsa_barrier_and_packet_t *>(q->base_address) + (idx & (q->size - 1));
+        std::memset(reinterpret_cast<char *>(p) + 4, 0, sizeof *p - 4); // no dependency signals: the barrier BIT is what waits for everything in front
+        p->completion_signal = done[n];
+        const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER));
+        __atomic_store_n(reinterpret_cast<uint32_t *>(p), (uint32_t)header, __ATOMIC_RELEASE);
+        hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)idx);
+        n++;
+    }
+    for (uint32_t k = 0; k < n; k++) {
+        wait_signal(done[k]);
+        (void)hsa_signal_destroy(done[k]);
+    }
+}
 
 int direct_event_state(hipEvent_t e)
 {

@@ -247,3 +247,27 @@ def test_an_in_order_packet_behind_unordered_ones_waits_for_them(gpu, luts):
         assert L.mvfx_event_query(e1.h) == 1
         assert np.array_equal(dc.download().reshape(h, w * 4), c), rep
         assert np.array_equal(db.download().reshape(h, w * 4), b), rep
+
+
+def test_freeing_the_lut_waits_for_the_lane(gpu):
+    """mvfx_cube_lut_free with lane kernels of the LUT still in flight: hipFree waits for HIP streams only, so the free quiesces the lane's queues first
+    (direct_quiesce) -- every fence has fired when it returns, and the frames hold the oracle's bytes (the tables were not pulled from under a kernel)"""
+    text = cubes.analytic_3d(33)
+    o = orc.CubeLut(text)
+    dev = gpu.CubeLut(text)
+    L = gpu.lib()
+    w, h, n = 3840, 2160, 24
+    sts = [ctypes.c_void_p(L.mvfx_thread_stream_n(0)), ctypes.c_void_p(L.mvfx_thread_stream_n(1))]
+    src = np.ascontiguousarray(frames.natural_like(w, h, 0x5EED1300)).reshape(h, w * 4)
+    exp = np.empty_like(src)
+    assert o.apply(src, w * 4, exp, w * 4, w, h, "RGBA") == 0
+    din = gpu.DeviceBuffer(src.nbytes).upload(src)
+    dout = [gpu.DeviceBuffer(src.nbytes) for _ in range(n)]
+    evs = [Event(gpu) for _ in range(n)]
+    for k in range(n):
+        rc, _, direct = direct_lut(gpu, dev, din.ptr, w * 4, dout[k].ptr, w * 4, w, h, evs[k], sts[k & 1], wg_window=bool(k & 2), only=True, unordered=bool(k & 1))
+        assert rc == 0 and direct == 1, (k, rc, direct)
+    dev.free()
+    assert all(L.mvfx_event_query(e.h) == 1 for e in evs)
+    for k in (0, 1, n - 2, n - 1):
+        assert np.array_equal(dout[k].download().reshape(h, w * 4), exp), k
