@@ -338,4 +338,44 @@ int mvfxbench_colorlut_direct(int device, uint32_t warmup, uint32_t launches, ui
     return rc;
 }
 
+// Several threads share the lane, each with a SMALL ring of fences (as the element layer's fence pool under a small buffer pool): `threads` threads,
+// each making `launches` one-frame hsvfilter calls through the lane on its own frames, re-using `events_per_thread` events (waiting for an event's
+// previous frame before re-using it).  What it is for: the lane's argument-slot ring (1024 slots) wraps many times and every slot's "last user" is
+// one of a handful of signals that are armed again and again -- the constellation in which round 6's first lane deadlocked two streaming threads.
+// Returns MVFX_OK when every thread has finished; a deadlock never returns (the test has a timeout).  *direct_out: launches the lane took.
+int mvfxbench_lane_threads(int device, uint32_t threads, uint32_t events_per_thread, uint32_t launches, const mvfx_frame *frames, uint32_t frames_per_thread,
+                           const mvfx_hsvfilter_settings *settings, uint64_t *direct_out)
+{
+    if (!frames || !settings || threads == 0 || events_per_thread == 0 || events_per_thread > 64 || frames_per_thread == 0) return MVFX_ERR_INVALID_ARGUMENT;
+    std::vector<int> rcs(threads, MVFX_OK);
+    std::vector<uint64_t> took(threads, 0);
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < threads; t++)
+        pool.emplace_back([&, t] {
+            int rc = mvfx_set_device(device);
+            mvfx_event ev[64] = {};
+            for (uint32_t k = 0; k < events_per_thread && rc == MVFX_OK; k++) rc = mvfx_event_create(&ev[k]);
+            mvfx_stream sts[2] = {mvfx_thread_stream_n(0), mvfx_thread_stream_n(1)};
+            for (uint32_t i = 0; i < launches && rc == MVFX_OK; i++) {
+                mvfx_event e = ev[i % events_per_thread];
+                if (i >= events_per_thread) rc = mvfx_event_synchronize(e);
+                if (rc != MVFX_OK) break;
+                mvfx_thread_set_options(MVFX_OPT_DIRECT_DISPATCH);
+                mvfx_thread_set_completion_event(e);
+                rc = mvfx_hsvfilter_transform_frame_ip(&frames[t * frames_per_thread + i % frames_per_thread], settings, sts[i & 1]);
+                if (mvfx_thread_clear_completion_event() <= 0 && rc == MVFX_OK) rc = mvfx_event_record(e, sts[i & 1]);
+                if (mvfx_event_is_direct(e)) took[t]++;
+            }
+            for (uint32_t k = 0; k < events_per_thread; k++) if (ev[k]) { if (rc == MVFX_OK) rc = mvfx_event_synchronize(ev[k]); mvfx_event_destroy(ev[k]); }
+            mvfx_thread_set_options(0);
+            rcs[t] = rc;
+        });
+    for (auto &th : pool) th.join();
+    uint64_t all = 0;
+    for (uint32_t t = 0; t < threads; t++) all += took[t];
+    if (direct_out) *direct_out = all;
+    for (int rc : rcs) if (rc != MVFX_OK) return rc;
+    return MVFX_OK;
+}
+
 } // extern "C"

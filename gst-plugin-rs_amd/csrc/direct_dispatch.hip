@@ -292,17 +292,22 @@ int submit(const void *args, size_t bytes, int k, uint32_t wgs_x, uint32_t wgs_y
     DirectFence *f = fence_get(ev);
     if (!f) return 1;
     if (f->direct.load(std::memory_order_acquire)) wait_signal(f->sig); // this event's previous lane dispatch (never pending in practice: fences are re-used when unreferenced)
-    hsa_signal_store_relaxed(f->sig, 1);
-    f->queue.store((int)((uint32_t)queue % kQueues), std::memory_order_relaxed);
-    f->direct.store(true, std::memory_order_release);
-    note_completion_event_used();
 
     const uint64_t n = l->next.fetch_add(1, std::memory_order_relaxed);
     hsa_queue_t *q = l->queue[(uint32_t)queue % kQueues];
     // the argument block: a slot of its own until the kernel that read it last has finished
     char *slot = l->args + (size_t)(n % kArgSlots) * kArgSlotBytes;
     if (const uint64_t last = l->slot_signal[n % kArgSlots].exchange(f->sig.handle, std::memory_order_acq_rel); last != 0 && last != f->sig.handle)
-        wait_signal(hsa_signal_t{last}); // (1024 dispatches ago: long finished)
+        wait_signal(hsa_signal_t{last}); // (1024 dispatches ago: long finished -- unless the signal has been armed again since, then for that dispatch)
+    // ARM THE FENCE ONLY NOW, behind the last wait of this function: an armed signal is one whose dispatch goes out without waiting for anybody.
+    // (Until round 6's soak the signal was armed in front of the slot wait.  Signals are few and re-armed all the time, so the slot's "last user"
+    // is usually a signal somebody has armed again: two streaming threads -- a `queue` between two lane elements -- each armed their own and then
+    // waited for the other's, which was never submitted.  tools/soak_lane_chain.py; tests/test_direct_dispatch_gpu.py::test_two_threads_few_fences.)
+    hsa_signal_store_relaxed(f->sig, 1);
+    f->queue.store((int)((uint32_t)queue % kQueues), std::memory_order_relaxed);
+    f->direct.store(true, std::memory_order_release);
+    note_completion_event_used();
+
     std::memcpy(slot, args, bytes);
     // device memory written through the BAR: the writes must have LANDED before the doorbell can lead a wave to them -- store fence, the last
     // byte once more, full fence, read it back (what the HIP runtime does for its own device-memory argument blocks)

@@ -356,3 +356,29 @@ def test_the_lane_can_be_switched_off_by_the_environment(gpu, tmp_path):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MVFX_DIRECT_DISPATCH=env_val), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                            text=True, timeout=300)
         assert r.returncode == 0 and expect in r.stdout, (env_val, r.stdout[-500:], r.stderr[-500:])
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("shape", [(128, 64, 2, 60000), (1920, 1080, 3, 8000)], ids=["2_threads_small_frames", "3_threads_1080p"])
+def test_threads_with_few_fences_share_the_lane(gpu, shape):
+    """Threads share the lane, each re-using THREE fences over thousands of one-frame calls (libmvfxbench.so: mvfxbench_lane_threads): the argument-slot
+    ring wraps, every slot's last user is a signal that has been armed again since.  Round 6's first lane armed a dispatch's signal in front of the slot wait,
+    and two streaming threads (a `queue` between two lane elements) then waited for each other's unsubmitted dispatches -- found by
+    tools/soak_lane_chain.py; here as a test with a timeout: with the arming order of that lane BOTH shapes deadlock within seconds, every time
+    (tools/check_lane_threads.py).  The bytes of lane dispatches are the business of the tests above."""
+    import os
+    bench = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gst-plugin-rs_amd", "libmvfxbench.so"))
+    L = gpu.lib()
+    w, h, threads, launches = shape
+    per = 2
+    identity = (0.0, 1.0, 0.0, 1.0, 0.0)
+    host = [frames.random_frame(0x5EED1400 + k, w, h) for k in range(threads * per)]
+    bufs = [gpu.DeviceBuffer(f.nbytes).upload(f) for f in host]
+    fr = (gpu.Frame * (threads * per))(*[gpu.make_frame(b.ptr, w, h, w * 4, "RGBA") for b in bufs])
+    s = gpu.HsvFilterSettings(*identity)
+    took = ctypes.c_uint64()
+    rc = bench.mvfxbench_lane_threads(0, threads, 3, launches, fr, per, ctypes.byref(s), ctypes.byref(took))
+    assert rc == 0, gpu.last_error()
+    if took.value == 0:
+        pytest.skip("no lane on this box")
+    assert took.value == threads * launches
