@@ -498,6 +498,12 @@ int mvfx_event_is_direct(mvfx_event event) { return event && direct_event_state(
 int mvfx_event_direct_queue(mvfx_event event) { return event ? direct_event_queue(reinterpret_cast<hipEvent_t>(event)) : -1; }
 int mvfx_direct_queue_of_stream(mvfx_stream stream) { return direct_queue_hint(as_stream(stream)); }
 
+int mvfx_direct_queue_wait_event(int queue, mvfx_event event)
+{
+    if (!event) return fail(MVFX_ERR_INVALID_ARGUMENT, "direct_queue_wait_event: NULL event");
+    return direct_queue_wait(reinterpret_cast<hipEvent_t>(event), queue);
+}
+
 int mvfx_host_alloc(void **out_ptr, size_t bytes)
 {
     if (!out_ptr)

@@ -59,6 +59,14 @@ int direct_queue_hint(hipStream_t stream);
 int direct_hsvfilter_submit(const DirectHsvArgs &args, bool neg_shift, bool nontemporal, int queue);
 int direct_hsvdetector_submit(const DirectDetArgs &args, int queue);
 
+// A dependency ACROSS the lane's queues, waited for on the device: when `e` is a direct fence that has not fired and stands for a dispatch on the
+// lane's OTHER queue, a barrier packet with that dispatch's completion signal as its dependency goes into lane queue `queue` (current device) -- the
+// next dispatch on `queue` that carries the barrier bit runs behind it; what a HIP stream does with hipStreamWaitEvent, without a host thread waiting.
+// Returns 1: the caller's next dispatch on `queue` must keep its barrier bit (a barrier packet went in, or the dispatch `e` stands for sits in `queue`
+// itself), and `e` must not be used for ANOTHER dispatch until that next dispatch has finished (its signal would be armed again under the barrier
+// packet); 0: nothing to wait for (not a direct fence, or it has fired); < 0: MVFX_ERR_*.
+int direct_queue_wait(hipEvent_t e, int queue);
+
 // Every lane dispatch made so far on `device` has FINISHED when this returns (a barrier packet behind each of the lane's queues, waited for on the
 // calling thread).  For whoever frees memory a lane kernel may still be reading: hipFree waits for the HIP streams of the device, not for queues it
 // does not know (the LUT tables of a mvfx_cube_lut; frame blocks carry their own fence and need none of this).  No lane on the device: returns at once.

@@ -201,6 +201,30 @@ void wait_signal(hsa_signal_t s)
 
 } // namespace
 
+int direct_queue_wait(hipEvent_t e, int queue)
+{
+    DirectFence *f = fence_find(e);
+    if (!f || !f->direct.load(std::memory_order_acquire) || hsa_signal_load_scacquire(f->sig) < 1) return 0;
+    const uint32_t mine = (uint32_t)queue % kQueues;
+    if ((uint32_t)f->queue.load(std::memory_order_relaxed) % kQueues == mine) return 1; // in front of the caller in the same in-order queue
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); return fail(MVFX_ERR_DEVICE, "direct_queue_wait: no current device"); }
+    Lane *l = lane_of(device);
+    if (!l) return fail(MVFX_ERR_DIRECT_UNAVAILABLE, "direct_queue_wait: no lane on device %d", device);
+    hsa_queue_t *q = l->queue[mine];
+    const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 1);
+    while (idx - hsa_queue_load_read_index_scacquire(q) >= q->size) {}
+    hsa_barrier_and_packet_t *p = reinterpret_cast<hsa_barrier_and_packet_t *>(q->base_address) + (idx & (q->size - 1));
+    std::memset(reinterpret_cast<char *>(p) + 4, 0, sizeof *p - 4);
+    p->dep_signal[0] = f->sig; // satisfied when the signal is 0: the other queue's dispatch has finished
+    // no barrier bit on the barrier packet itself (it waits for its dependency, not for what is in front of it here); the caller's kernel packet behind
+    // it carries the bit and so waits for this packet
+    const uint16_t header = (uint16_t)(HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE);
+    __atomic_store_n(reinterpret_cast<uint32_t *>(p), (uint32_t)header, __ATOMIC_RELEASE);
+    hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)idx);
+    return 1;
+}
+
 void direct_quiesce(int device)
 {
     if (device < 0 || device >= kMaxDevices || !g_lanes[device].ok.load(std::memory_order_acquire)) return; // (never builds a lane)

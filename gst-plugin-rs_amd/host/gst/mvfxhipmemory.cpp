@@ -13,11 +13,25 @@
 // hsvdetector element with one event per block ran at 71 k fps, with two records per pair launch instead of four at 89 k, with one at
 // 95 k (profiles/r4/element_pairs.txt) -- so blocks released together share one.  Fences are reference-counted and pooled: an event is
 // re-recorded only when no block points at it any more (a stream that already waits for it captured the earlier record).
-typedef struct { gint refs; mvfx_event ev; } MvfxFence;
+// deps (round 6): fences of OTHER dispatches that a lane dispatch under this fence waits for on the device (a barrier packet across the lane's queues,
+// mvfx_direct_queue_wait_event).  They stay referenced -- so that nobody arms their signals again under the barrier packet -- until this fence's own
+// dispatch is known to have finished: when the fence is taken out of the pool again, or destroyed.
+#define MVFX_FENCE_MAX_DEPS 8
+typedef struct MvfxFence_ { gint refs; mvfx_event ev; struct MvfxFence_ *deps[MVFX_FENCE_MAX_DEPS]; int ndeps; } MvfxFence;
 #define MVFX_FENCE_POOL_MAX 256
 static GMutex fence_pool_lock;
 static MvfxFence *fence_pool[MVFX_FENCE_POOL_MAX];
 static int fence_pool_n;
+static void fence_unref(MvfxFence *f);
+
+// the dispatch under `f` (if any) has finished -> the fences it waited for on the device may go
+static void fence_drop_deps(MvfxFence *f)
+{
+    if (f->ndeps == 0) return;
+    mvfx_event_synchronize(f->ev); // (long fired in practice: the fence comes out of the pool a pool's worth of frames later)
+    for (int i = 0; i < f->ndeps; i++) fence_unref(f->deps[i]);
+    f->ndeps = 0;
+}
 
 static MvfxFence *fence_get(void) // one reference, event not recorded yet; NULL when no event can be created
 {
@@ -25,6 +39,7 @@ static MvfxFence *fence_get(void) // one reference, event not recorded yet; NULL
     g_mutex_lock(&fence_pool_lock);
     if (fence_pool_n > 0) f = fence_pool[--fence_pool_n];
     g_mutex_unlock(&fence_pool_lock);
+    if (f) fence_drop_deps(f);
     if (!f) {
         mvfx_event ev = NULL;
         if (mvfx_event_create(&ev) != MVFX_OK || !ev) return NULL;
@@ -49,9 +64,49 @@ static void fence_unref(MvfxFence *f)
     if (kept) fence_pool[fence_pool_n++] = f;
     g_mutex_unlock(&fence_pool_lock);
     if (!kept) {
+        fence_drop_deps(f);
         mvfx_event_destroy(f->ev);
         g_free(f);
     }
+}
+
+// MVFX_LANE_STATS=1: what the lane's acquires did, printed when the process ends (gst-launch runs)
+static gint lane_stat[8]; // 0 taken, 1 refused: ordinary fence pending, 2 refused: held-back work / borrowed fence, 3 device-side waits armed,
+                          // 4 host waits in the acquire, 5 host waits of a stream consumer for a direct fence, 6 relied on queue order, 7 refused: other
+static void lane_stats_print(void)
+{
+    g_printerr("mvfx lane: %d acquires taken (%d rested on queue order, %d device-side waits, %d host waits), refused: %d ordinary fence pending, "
+               "%d held-back work or borrowed fence, %d other; %d host waits of stream consumers for direct fences\n", lane_stat[0], lane_stat[6],
+               lane_stat[3], lane_stat[4], lane_stat[1], lane_stat[2], lane_stat[7], lane_stat[5]);
+}
+static inline void lane_count(int what)
+{
+    static const gboolean on = [] {
+        const gchar *e = g_getenv("MVFX_LANE_STATS");
+        const gboolean v = e && atoi(e) != 0;
+        if (v) atexit(lane_stats_print);
+        return v;
+    }();
+    if (on) g_atomic_int_inc(&lane_stat[what]);
+}
+
+static const gint kLaneSeed = 512;
+static gint lane_seed_budget = kLaneSeed; // (see "SEEDING" in mvfx_hip_buffer_acquire_direct_ordered; refilled by mvfx_direct_reset)
+
+// Dependencies the calling thread's next lane dispatch waits for on the device (stashed by mvfx_hip_buffer_acquire_direct*, moved onto the dispatch's
+// fence by mvfx_hip_fence_begin): each entry holds a reference.
+static thread_local MvfxFence *tls_lane_deps[MVFX_FENCE_MAX_DEPS];
+static thread_local int tls_lane_ndeps = 0;
+
+// the lane dispatch they were stashed for is not going to happen: wait for them on this thread (the barrier packets already in the queue then pass),
+// and let them go
+static void lane_deps_abandon(void)
+{
+    for (int i = 0; i < tls_lane_ndeps; i++) {
+        mvfx_event_synchronize(tls_lane_deps[i]->ev);
+        fence_unref(tls_lane_deps[i]);
+    }
+    tls_lane_ndeps = 0;
 }
 
 typedef struct {
@@ -279,9 +334,14 @@ static gboolean deferred_is_owners(MvfxHipMemory *m, GstObject *owner)
 }
 
 // ---- producers whose direct fences a consumer had to wait for on its own thread (mvfxhipmemory.h) ----
+// With hysteresis since round 6's chain soak: a producer goes back to its streams only when consumers had to wait kDiscourageAfter times (the first
+// frames of a pipeline always produce a wait or two -- the source's blocks carry stream fences, an element takes the stream once, the next one waits for
+// the one before it -- and ONE such wait used to switch the lane off for the rest of the run: thread-separated chains then ran at 10 k fps in a run
+// and 19 k in the next), and it tries the lane again after kDiscourageFrames frames.
 #define MVFX_DISCOURAGED_MAX 64
+static const guint kDiscourageAfter = 8, kDiscourageFrames = 2048;
 static GMutex discouraged_lock;
-static const void *discouraged[MVFX_DISCOURAGED_MAX];
+static struct { const void *tag; guint waits, skipped; } discouraged[MVFX_DISCOURAGED_MAX];
 static gint discouraged_n; // read without the lock on the fast path
 
 gboolean mvfx_direct_discouraged(const void *tag)
@@ -289,7 +349,12 @@ gboolean mvfx_direct_discouraged(const void *tag)
     if (!tag || g_atomic_int_get(&discouraged_n) == 0) return FALSE;
     gboolean hit = FALSE;
     g_mutex_lock(&discouraged_lock);
-    for (gint i = 0; i < discouraged_n && !hit; i++) hit = discouraged[i] == tag;
+    for (gint i = 0; i < discouraged_n; i++)
+        if (discouraged[i].tag == tag) {
+            hit = discouraged[i].waits >= kDiscourageAfter;
+            if (hit && ++discouraged[i].skipped >= kDiscourageFrames) discouraged[i].waits = discouraged[i].skipped = 0; // the next frame tries again
+            break;
+        }
     g_mutex_unlock(&discouraged_lock);
     return hit;
 }
@@ -298,20 +363,25 @@ static void direct_discourage(const void *tag)
 {
     if (!tag) return;
     g_mutex_lock(&discouraged_lock);
-    gboolean hit = FALSE;
-    for (gint i = 0; i < discouraged_n && !hit; i++) hit = discouraged[i] == tag;
-    if (!hit && discouraged_n < MVFX_DISCOURAGED_MAX) {
-        discouraged[discouraged_n] = tag;
+    gint at = -1;
+    for (gint i = 0; i < discouraged_n && at < 0; i++)
+        if (discouraged[i].tag == tag) at = i;
+    if (at < 0 && discouraged_n < MVFX_DISCOURAGED_MAX) {
+        at = discouraged_n;
+        discouraged[at].tag = tag;
+        discouraged[at].waits = discouraged[at].skipped = 0;
         g_atomic_int_set(&discouraged_n, discouraged_n + 1);
     }
+    if (at >= 0 && discouraged[at].waits < kDiscourageAfter) discouraged[at].waits++;
     g_mutex_unlock(&discouraged_lock);
 }
 
 void mvfx_direct_reset(const void *tag)
 {
+    g_atomic_int_set(&lane_seed_budget, kLaneSeed);
     g_mutex_lock(&discouraged_lock);
     for (gint i = 0; i < discouraged_n; i++)
-        if (discouraged[i] == tag) {
+        if (discouraged[i].tag == tag) {
             discouraged[i] = discouraged[discouraged_n - 1];
             g_atomic_int_set(&discouraged_n, discouraged_n - 1);
             break;
@@ -322,7 +392,10 @@ void mvfx_direct_reset(const void *tag)
 // a consumer's stream "waits" for a block's fence: a direct fence that has not fired makes the calling thread wait -- its producer is told
 static void wait_for_fence(mvfx_stream stream, mvfx_event ev, const void *producer_tag)
 {
-    if (producer_tag && mvfx_event_is_direct(ev) && mvfx_event_query(ev) != 1) direct_discourage(producer_tag);
+    if (mvfx_event_is_direct(ev) && mvfx_event_query(ev) != 1) {
+        lane_count(5);
+        if (producer_tag) direct_discourage(producer_tag);
+    }
     mvfx_stream_wait_event(stream, ev);
 }
 
@@ -332,34 +405,65 @@ gboolean mvfx_hip_buffer_acquire_direct_ordered(GstBuffer *buf, mvfx_stream stre
 {
     for (guint i = 0; buf && i < gst_buffer_n_memory(buf); i++) {
         GstMemory *mem = gst_buffer_peek_memory(buf, i);
-        if (!mvfx_is_hip_memory(mem)) return FALSE;
+        if (!mvfx_is_hip_memory(mem)) { lane_deps_abandon(); return FALSE; }
         MvfxHipMemory *m = (MvfxHipMemory *)mem;
         MvfxFence *other = NULL;
+        gboolean seeding = FALSE;
         g_mutex_lock(&m->lock);
         gboolean ok = m->deferred_flush == NULL && (!m->borrowed || mvfx_event_query(m->borrowed) == 1);
+        if (!ok) lane_count(2);
         if (ok && m->pending && m->fence) {
             if (mvfx_event_query(m->fence->ev) == 1)
                 m->pending = FALSE; // seen finished: nobody has to wait for it any more
-            else if (!mvfx_event_is_direct(m->fence->ev))
-                ok = FALSE;         // an ordinary fence still pending: this frame's place is behind it on a stream
-            else if (mvfx_event_direct_queue(m->fence->ev) != queue)
+            else if (!mvfx_event_is_direct(m->fence->ev)) {
+                if (g_atomic_int_get(&lane_seed_budget) > 0 && g_atomic_int_add(&lane_seed_budget, -1) > 0) {
+                    other = fence_ref(m->fence); // seeding (below): waited for on this thread, once
+                    seeding = TRUE;
+                } else {
+                    ok = FALSE;     // an ordinary fence still pending: this frame's place is behind it on a stream
+                    lane_count(1);
+                }
+            } else if (mvfx_event_direct_queue(m->fence->ev) != queue)
                 other = fence_ref(m->fence); // a direct dispatch on the lane's OTHER queue: waited for below
-            else if (relied_on_order)
-                *relied_on_order = TRUE;     // a direct dispatch in front of ours on the same lane queue: fine as long as our packet keeps its place
-            // (without the out parameter: the caller's packets always carry the barrier bit -- the queue is in order, nothing to do)
+            else {
+                lane_count(6);
+                if (relied_on_order) *relied_on_order = TRUE; // a direct dispatch in front of ours on the same lane queue: fine as long as our packet keeps its place
+                // (without the out parameter: the caller's packets always carry the barrier bit -- the queue is in order, nothing to do)
+            }
         }
         g_mutex_unlock(&m->lock);
         if (other) {
-            // e.g. this element's own dispatch on the block a pool's worth of frames ago (an odd pool): the streaming thread is that far ahead of the
-            // device, and waiting here is the back-pressure a bounded queue gives -- the device has the frames in between to work on
-            mvfx_event_synchronize(other->ev);
+            // A dispatch on the lane's OTHER queue (this element's own on the block a pool's worth of frames ago -- an odd pool --, or another
+            // element's on another streaming thread, whose blocks come back in no particular order): waited for ON THE DEVICE, by a barrier packet in
+            // our queue (mvfx_direct_queue_wait_event), as a HIP stream waits for an event.  Until round 6's chain soak the streaming thread waited
+            // here itself: three lane elements with queues between them ran at 10-12 k fps where HIP streams gave 17-22 k
+            // (profiles/r6/lane_chain_soak.txt).  The fence stays referenced until our own dispatch has finished (MvfxFence::deps).
+            // SEEDING.  Whether a block is worked on by lane dispatches or by stream kernels perpetuates itself: an element that finds a stream fence
+            // pending on a block takes the stream, so the next element finds a stream fence on it ... and a thread-separated chain on device-born
+            // frames settled wherever its first frames had put each block -- five of twelve blocks on streams for good, 14 k fps where the all-lane
+            // state gives 19 k.  The first kLaneSeed stream fences a pipeline meets are therefore waited for on the streaming thread (they are the
+            // source's fills and the first frames' kernels: microseconds), which starts every block on the lane.  Frames whose producers stay on
+            // streams (hipupload's copies, an element without lane kernels) use the budget up in their first seconds and are refused as ever.
+            const int armed = seeding ? -1 : tls_lane_ndeps < MVFX_FENCE_MAX_DEPS ? mvfx_direct_queue_wait_event(queue, other->ev) : -1;
+            lane_count(armed == 1 ? 3 : armed < 0 ? 4 : 0 /* fired meanwhile */);
+            if (armed < 0) mvfx_event_synchronize(other->ev); // (no lane, no room: the old way)
             g_mutex_lock(&m->lock);
             ok = m->fence == other && m->deferred_flush == NULL && !m->borrowed; // (nobody else came in between)
-            if (ok) m->pending = FALSE;
+            if (ok && armed <= 0) m->pending = FALSE;                             // seen finished
             g_mutex_unlock(&m->lock);
-            fence_unref(other);
+            if (armed == 1) {
+                tls_lane_deps[tls_lane_ndeps++] = other; // (keeps the reference)
+                if (relied_on_order) *relied_on_order = TRUE;
+            } else {
+                fence_unref(other);
+            }
         }
-        if (!ok) return FALSE;
+        if (!ok) {
+            if (other) lane_count(7);
+            lane_deps_abandon();
+            return FALSE;
+        }
+        lane_count(0);
         g_mutex_lock(&m->lock);
         m->acq_seq = m->fence_seq; // (the fence scope's chaining then has nothing to wait for on `stream`)
         m->acq_stream = stream;
@@ -370,8 +474,17 @@ gboolean mvfx_hip_buffer_acquire_direct_ordered(GstBuffer *buf, mvfx_stream stre
 
 void mvfx_hip_fence_cancel(MvfxFenceScope *sc)
 {
+    lane_deps_abandon(); // (a scope with no device blocks took none of them)
     if (sc->n == 0) return;
     mvfx_thread_clear_completion_event();
+    if (MvfxFence *f = (MvfxFence *)sc->fence) {
+        // the dispatch the barrier packets were for is not coming: wait for the dependencies here, the packets then pass and the fences may go
+        for (int i = 0; i < f->ndeps; i++) {
+            mvfx_event_synchronize(f->deps[i]->ev);
+            fence_unref(f->deps[i]);
+        }
+        f->ndeps = 0;
+    }
     fence_unref((MvfxFence *)sc->fence);
     sc->fence = NULL;
     sc->n = 0;
@@ -538,10 +651,16 @@ void mvfx_hip_fence_begin(MvfxFenceScope *sc, GstMemory *const *mems, guint n, m
         for (guint i = 0; i < n; i++)
             if (mvfx_is_hip_memory(mems[i])) run_deferred((MvfxHipMemory *)mems[i]);
     group_phase_a(sc, mems, n, stream);
-    if (sc->n == 0) return;
+    if (sc->n == 0) { lane_deps_abandon(); return; }
     MvfxFence *f = fence_get();
     sc->fence = f;
-    if (f) mvfx_thread_set_completion_event(f->ev);
+    if (f) {
+        for (int i = 0; i < tls_lane_ndeps; i++) f->deps[f->ndeps++] = tls_lane_deps[i]; // (fence_get left ndeps == 0; the references move)
+        tls_lane_ndeps = 0;
+        mvfx_thread_set_completion_event(f->ev);
+    } else {
+        lane_deps_abandon();
+    }
 }
 
 // the blocks of one or two buffers as an ordinary user (input and output of an out-of-place launch)

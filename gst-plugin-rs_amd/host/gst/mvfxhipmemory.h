@@ -75,7 +75,7 @@ void mvfx_hip_fence_cancel(MvfxFenceScope *scope);
 // A consumer that found a direct fence still PENDING had to wait on its own thread (a HIP stream cannot wait for it on the device): the producer
 // named by the fence's tag is told, and goes back to launching on its streams -- a direct dispatch pays where nobody is close behind the frame
 // (hsvfilter ! fakesink, ! queue ! encoder ...), inside a tight device chain (hsvfilter ! hsvdetector on one thread) the stream order is the
-// better fence.  _reset at start().
+// better fence.  With hysteresis: after eight such waits, and for 2048 frames, then the producer tries the lane again.  _reset at stop().
 gboolean mvfx_direct_discouraged(const void *producer_tag);
 void mvfx_direct_reset(const void *producer_tag);
 void mvfx_hip_memory_set_borrowed_fence(GstMemory *mem, void *event);

@@ -132,6 +132,12 @@ int mvfx_event_is_direct(mvfx_event event);
  * (mvfx_thread_stream_n), a pointer hash for other streams.  Two dispatches on one queue run in the order they were made. */
 int mvfx_event_direct_queue(mvfx_event event);
 int mvfx_direct_queue_of_stream(mvfx_stream stream);
+/* A dependency across the lane's two queues, waited for ON THE DEVICE (what mvfx_stream_wait_event is to HIP streams): when `event` is a direct fence
+ * that has not fired, the caller's NEXT direct dispatch on lane queue `queue` (current device) runs behind the dispatch the fence stands for -- a
+ * barrier packet with its completion signal goes into `queue` when that dispatch sits in the other queue.  1: armed -- the next dispatch on `queue` must
+ * be an in-order one (not MVFX_OPT_DIRECT_UNORDERED), and `event` must not be set as the completion event of another call until that dispatch has
+ * finished; 0: nothing to wait for (an ordinary event, or the fence has fired); < 0: MVFX_ERR_*. */
+int mvfx_direct_queue_wait_event(int queue, mvfx_event event);
 /* The fence without a barrier packet.  While a completion event is set on the calling thread, every kernel the thread launches
  * through this library carries it as the stop event of its own dispatch (hipExtLaunchKernelGGL): the event is recorded when the
  * kernel finishes, with no packet of its own behind it -- hipEventRecord behind every 4K launch costs 2.6 us of device time

@@ -382,3 +382,39 @@ def test_threads_with_few_fences_share_the_lane(gpu, shape):
     if took.value == 0:
         pytest.skip("no lane on this box")
     assert took.value == threads * launches
+
+
+def test_a_dependency_across_the_lane_queues_is_waited_for_on_the_device(gpu):
+    """hsvfilter in place on lane queue 0, then -- no host wait -- hsvdetector reading that frame on lane queue 1 behind mvfx_direct_queue_wait_event(1, fence
+    of the filter): a barrier packet with the filter's completion signal goes into queue 1, the detector's packet (barrier bit) runs behind it.  What the
+    element layer does when a block's last dispatch sits in the other queue (round 6: before, the streaming thread waited itself)."""
+    L = gpu.lib()
+    w, h = 3840, 2160
+    s0, s1 = ctypes.c_void_p(L.mvfx_thread_stream_n(0)), ctypes.c_void_p(L.mvfx_thread_stream_n(1))
+    assert L.mvfx_direct_queue_of_stream(s0) == 0 and L.mvfx_direct_queue_of_stream(s1) == 1
+    armed = 0
+    for rep in range(10):
+        f = np.ascontiguousarray(frames.natural_like(w, h, 0x5EED1500 + rep)).reshape(h, w * 4)
+        mid = f.copy()
+        assert orc.hsvfilter(mid, w, w * 4, "RGBx", BENCH) == 0
+        want = np.empty_like(mid)
+        assert orc.hsvdetector(mid, w * 4, "RGBx", want, w * 4, "RGBA", w, DET) == 0
+        a, b = gpu.DeviceBuffer(f.nbytes).upload(f), gpu.DeviceBuffer(f.nbytes)
+        e1, e2 = Event(gpu), Event(gpu)
+        rc, _, direct = direct_filter(gpu, a.ptr, w, h, w * 4, "RGBx", BENCH, e1, stream=s0)
+        assert rc == 0 and direct == 1 and L.mvfx_event_direct_queue(e1.h) == 0
+        got = L.mvfx_direct_queue_wait_event(1, e1.h)
+        assert got in (0, 1), gpu.last_error()   # 0: the 11 us kernel had finished before we asked
+        armed += got
+        rc, _, direct = direct_detect(gpu, a.ptr, b.ptr, w, h, "RGBx", "RGBA", DET, e2, s1, only=True)
+        assert rc == 0 and direct == 1 and L.mvfx_event_direct_queue(e2.h) == 1
+        gpu.check(L.mvfx_event_synchronize(e2.h))
+        assert L.mvfx_event_query(e1.h) == 1
+        assert np.array_equal(b.download().reshape(h, w * 4), want), rep
+    assert armed >= 1, "never saw the filter still running: the device-side wait was not exercised"
+    # an ordinary event, a fired fence, the same queue
+    ev = Event(gpu)
+    gpu.check(L.mvfx_event_record(ev.h, s0))
+    assert L.mvfx_direct_queue_wait_event(1, ev.h) == 0
+    gpu.check(L.mvfx_event_synchronize(ev.h))
+    assert L.mvfx_direct_queue_wait_event(0, e1.h) == 0

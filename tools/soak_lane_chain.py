@@ -20,18 +20,20 @@ def main():
     cube = os.path.join(tmp, "look.cube")
     with open(cube, "w") as f:
         f.write(cubes.analytic_3d(33))
-    caps = "video/x-raw(memory:HIPMemory),format=RGBA,width=3840,height=2160"
-    chains = {
-        "hsvfilter ! colorlut": f"hsvfilter hue-shift=90 ! colorlut location={cube}",
-        "hsvfilter ! colorlut ! hsvdetector": f"hsvfilter hue-shift=90 ! colorlut location={cube} ! video/x-raw(memory:HIPMemory),format=RGBx ! hsvdetector hue-ref=120 hue-var=40",
-        "colorlut ! queue ! hsvfilter": f"colorlut location={cube} ! queue max-size-buffers=4 ! hsvfilter hue-shift=-123.4",
-        "hsvfilter ! queue ! colorlut ! queue ! colorlut": f"hsvfilter ! queue max-size-buffers=3 ! colorlut location={cube} ! queue max-size-buffers=3 ! colorlut location={cube}",
+    size = "width=3840,height=2160"
+    hip = "video/x-raw(memory:HIPMemory)"
+    chains = {  # name: (source format, chain)
+        "hsvfilter ! colorlut": ("RGBA", f"hsvfilter hue-shift=90 ! colorlut location={cube}"),
+        "hsvfilter ! hsvdetector ! colorlut": ("RGBx", f"hsvfilter hue-shift=90 ! hsvdetector hue-ref=120 hue-var=40 ! {hip},format=RGBA ! colorlut location={cube}"),
+        "colorlut ! queue ! hsvfilter": ("RGBA", f"colorlut location={cube} ! queue max-size-buffers=4 ! hsvfilter hue-shift=-123.4"),
+        "hsvfilter ! queue ! colorlut ! queue ! colorlut": ("RGBA", f"hsvfilter ! queue max-size-buffers=3 ! colorlut location={cube} ! queue max-size-buffers=3 ! colorlut location={cube}"),
+        "hsvfilter ! queue ! hsvdetector ! queue ! colorlut": ("RGBx", f"hsvfilter ! queue max-size-buffers=2 ! hsvdetector ! queue max-size-buffers=2 ! {hip},format=RGBA ! colorlut location={cube}"),
     }
     for pool in ("5", "12"):
-        for name, chain in chains.items():
-            pipe = f"hiptestsrc num-buffers={n} refresh=false ! {caps} ! {chain} ! fakesink sync=false"
+        for name, (fmt, chain) in chains.items():
+            pipe = f"hiptestsrc num-buffers={n} refresh=false ! {hip},format={fmt},{size} ! {chain} ! fakesink sync=false"
             t0 = time.perf_counter()
-            r = gst_env.run([launch, "-q"] + pipe.split(), tmp, timeout=600, extra_env={"MVFX_HIP_POOL_MIN": pool})
+            r = gst_env.run([launch, "-q"] + pipe.split(), tmp, timeout=600, extra_env=dict({"MVFX_HIP_POOL_MIN": pool}, **{k: v for k, v in os.environ.items() if k.startswith("MVFX_DIRECT")}))
             dt = time.perf_counter() - t0
             status = "ok" if r.returncode == 0 else f"FAILED rc {r.returncode}: {r.stdout[-400:]}"
             print(f"pool {pool:>2}  {name:<48} {n} buffers in {dt:6.1f} s = {n / dt:8.0f} fps  {status}", flush=True)
