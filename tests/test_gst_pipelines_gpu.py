@@ -831,3 +831,44 @@ def test_a_device_id_that_does_not_exist_is_a_resource_error_in_start(gpu, tmp_p
     assert r.returncode in (1, 255), (r.returncode, r.stdout[-1500:])  # gst-launch's "ERROR: Pipeline doesn't want to pause": an exit, no signal
     assert "device-id 7: only" in r.stdout and "HIP device(s) visible" in r.stdout, r.stdout[-1500:]
     assert "Segmentation" not in r.stdout and "Aborted" not in r.stdout
+
+
+# ---------------------------------------------------------------- the lane in chains across streaming threads (round 6's chain soak)
+
+@pytest.mark.parametrize("pool", ["5", "8"], ids=["odd_pool", "even_pool"])
+def test_lane_elements_on_three_streaming_threads_every_frame_checked(gpu, tmp_path, pool):
+    """hsvdetector ! queue ! colorlut ! queue ! hipdownload on static device frames (refresh=false: every block holds the same picture, both elements
+    write other blocks), 3000 frames, every output frame against the oracle.  Both elements take the direct-dispatch lane on their own streaming threads;
+    a recycled block's last dispatch sits in the lane's other queue every so often (always, with the odd pool) and is then waited for ON THE DEVICE by
+    a barrier packet (mvfx_direct_queue_wait_event) -- before round 6's soak the streaming thread waited, and before that fix two threads could
+    deadlock in the lane (tools/soak_lane_chain.py; profiles/r6/lane_chain_soak.txt).  MVFX_LANE_STATS says what the acquires did."""
+    w, h, n = 320, 180, 3000
+    cube = tmp_path / "look.cube"
+    cube.write_text(cubes.analytic_3d(9))
+    det = (120.0, 60.0, 0.6, 0.4, 0.6, 0.4)
+    sysc = f"video/x-raw,format=RGBx,width={w},height={h},framerate=30/1"
+    raw = _capture(tmp_path, f"hiptestsrc num-buffers=1 ! {sysc}", "in.raw").reshape(h, w * 4)
+    mid = np.empty_like(raw)
+    assert orc.hsvdetector(raw, w * 4, "RGBx", mid, w * 4, "RGBA", w, det) == 0
+    exp = np.empty_like(mid)
+    assert orc.CubeLut(cubes.analytic_3d(9)).apply(mid, w * 4, exp, w * 4, w, h, "RGBA") == 0
+    out = tmp_path / "out.raw"
+    hip = "video/x-raw(memory:HIPMemory)"
+    pipe = (f"hiptestsrc num-buffers={n} refresh=false ! {hip},format=RGBx,width={w},height={h},framerate=30/1 ! "
+            f"hsvdetector hue-ref={det[0]} hue-var={det[1]} saturation-ref={det[2]} saturation-var={det[3]} value-ref={det[4]} value-var={det[5]} ! "
+            f"{hip},format=RGBA ! queue max-size-buffers=3 ! colorlut location={cube} ! queue max-size-buffers=6 ! hipdownload ! filesink location={out}")
+    r = gst_env.run([LAUNCH, "-q"] + pipe.split(), tmp_path, timeout=120, extra_env={"MVFX_HIP_POOL_MIN": pool, "MVFX_LANE_STATS": "1"})
+    assert r.returncode == 0, r.stdout[-2000:]
+    got = np.fromfile(out, dtype=np.uint8)
+    assert got.size == n * h * w * 4
+    got = got.reshape(n, h, w * 4)
+    bad = [k for k in range(n) if not np.array_equal(got[k], exp)]
+    assert bad == [], (len(bad), bad[:10])
+    stats = [ln for ln in r.stdout.splitlines() if ln.startswith("mvfx lane:")]
+    assert stats, r.stdout[-500:]
+    taken = int(stats[-1].split()[2])
+    if taken == 0:
+        pytest.skip("no lane on this box: " + stats[-1])
+    # (how many of the 2 x 3000 acquires the lane took depends on how close behind the download is -- a consumer that has to wait for a direct fence on
+    #  its thread sends the producer back to its streams for a while: mvfx_direct_discouraged -- ; that it took a good part is all this asserts)
+    assert taken >= n // 2, stats[-1]
