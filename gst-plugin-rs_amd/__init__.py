@@ -147,6 +147,7 @@ SIGNATURES = {
     "mvfx_event_direct_queue": (c_int, [c_void_p]),
     "mvfx_direct_queue_of_stream": (c_int, [c_void_p]),
     "mvfx_direct_queue_wait_event": (c_int, [c_int, c_void_p]),
+    "mvfx_direct_lane_park": (c_int, []),
     "mvfx_thread_set_completion_event": (c_int, [c_void_p]),
     "mvfx_thread_clear_completion_event": (c_int, []),
     "mvfx_host_alloc": (c_int, [POINTER(c_void_p), c_size_t]),

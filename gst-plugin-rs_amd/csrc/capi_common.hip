@@ -498,6 +498,13 @@ int mvfx_event_is_direct(mvfx_event event) { return event && direct_event_state(
 int mvfx_event_direct_queue(mvfx_event event) { return event ? direct_event_queue(reinterpret_cast<hipEvent_t>(event)) : -1; }
 int mvfx_direct_queue_of_stream(mvfx_stream stream) { return direct_queue_hint(as_stream(stream)); }
 
+int mvfx_direct_lane_park(void)
+{
+    int device = 0;
+    MVFX_HIP_TRY(hipGetDevice(&device));
+    return direct_park(device);
+}
+
 int mvfx_direct_queue_wait_event(int queue, mvfx_event event)
 {
     if (!event) return fail(MVFX_ERR_INVALID_ARGUMENT, "direct_queue_wait_event: NULL event");

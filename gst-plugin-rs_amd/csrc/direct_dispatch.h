@@ -72,6 +72,12 @@ int direct_queue_wait(hipEvent_t e, int queue);
 // does not know (the LUT tables of a mvfx_cube_lut; frame blocks carry their own fence and need none of this).  No lane on the device: returns at once.
 void direct_quiesce(int device);
 
+// PARKING.  A process's hardware queues are few: with HIP's four (GPU_MAX_HW_QUEUES) and the lane's two, kernels on HIP streams run at about half their
+// speed when several streams are busy -- whether or not the lane's queues carry anything (hsvfilter ! tee ! 2 x hsvdetector on three threads: 19.6 k fps
+// without the lane's queues, 10.5 k with them idle; six HIP queues and no lane: 10 k as well; profiles/r6/lane_chain_soak.txt).  So the queues exist only
+// while the lane is in use: direct_park drains and destroys them (1: parked now; 0: no lane, or parked already), the next dispatch makes them again.
+int direct_park(int device);
+
 // ---- direct fences: an mvfx_event whose last "record" was a lane dispatch ------------------------------------------------------------
 // state 0: the event is an ordinary HIP event (or was never used); 1: complete direct fence; 2: pending direct fence
 int direct_event_state(hipEvent_t e);

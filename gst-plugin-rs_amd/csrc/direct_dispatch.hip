@@ -47,7 +47,39 @@ struct Lane {
     // the completion signal of the dispatch that used an argument slot last: the slot is written again only when that kernel has finished (its
     // workgroups read the block as they start).  Signals are never destroyed (free list below), so a stale handle is still a signal.
     std::atomic<uint64_t> slot_signal[kArgSlots];
+    // PARKING (direct_park): the two hardware queues exist only while the lane is in use.  Dispatchers hold `qmu` shared while they touch a queue;
+    // parking and un-parking take it exclusively.
+    std::shared_mutex qmu;
+    bool parked = false;
 };
+
+bool create_queues(Lane &l)
+{
+    for (uint32_t k = 0; k < kQueues; k++)
+        if (hsa_queue_create(l.agent, kQueuePackets, HSA_QUEUE_TYPE_MULTI, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &l.queue[k]) != HSA_STATUS_SUCCESS) {
+            for (uint32_t j = 0; j < k; j++) { (void)hsa_queue_destroy(l.queue[j]); l.queue[j] = nullptr; }
+            l.queue[k] = nullptr;
+            return false;
+        }
+    return true;
+}
+
+// called with l.qmu held shared: the lane's queues exist, or the lock is swapped for the exclusive one while they are made again
+bool ensure_unparked(Lane &l, std::shared_lock<std::shared_mutex> &lk)
+{
+    while (l.parked) {
+        lk.unlock();
+        {
+            std::unique_lock<std::shared_mutex> x(l.qmu);
+            if (l.parked) {
+                if (!create_queues(l)) { lk.lock(); return false; }
+                l.parked = false;
+            }
+        }
+        lk.lock();
+    }
+    return true;
+}
 
 bool enabled()
 {
@@ -138,8 +170,7 @@ void build_lane(Lane &l, int device)
     if (hsa_amd_agents_allow_access(1, &cpu.agent, nullptr, l.args) != HSA_STATUS_SUCCESS) return;
     std::memset(l.args, 0, (size_t)kArgSlots * kArgSlotBytes);
     for (auto &s : l.slot_signal) s.store(0, std::memory_order_relaxed);
-    for (uint32_t k = 0; k < kQueues; k++)
-        if (hsa_queue_create(l.agent, kQueuePackets, HSA_QUEUE_TYPE_MULTI, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &l.queue[k]) != HSA_STATUS_SUCCESS) return;
+    if (!create_queues(l)) return;
     l.ok.store(true, std::memory_order_release);
 }
 
@@ -211,6 +242,8 @@ int direct_queue_wait(hipEvent_t e, int queue)
     if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); return fail(MVFX_ERR_DEVICE, "direct_queue_wait: no current device"); }
     Lane *l = lane_of(device);
     if (!l) return fail(MVFX_ERR_DIRECT_UNAVAILABLE, "direct_queue_wait: no lane on device %d", device);
+    std::shared_lock<std::shared_mutex> lk(l->qmu);
+    if (!ensure_unparked(*l, lk)) return fail(MVFX_ERR_DIRECT_UNAVAILABLE, "direct_queue_wait: the lane's queues could not be made again");
     hsa_queue_t *q = l->queue[mine];
     const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 1);
     while (idx - hsa_queue_load_read_index_scacquire(q) >= q->size) {}
@@ -225,10 +258,10 @@ int direct_queue_wait(hipEvent_t e, int queue)
     return 1;
 }
 
-void direct_quiesce(int device)
+namespace {
+// a barrier packet behind each queue, waited for here; the caller holds l.qmu (shared or exclusive) and the lane is not parked
+void quiesce_locked(Lane &l)
 {
-    if (device < 0 || device >= kMaxDevices || !g_lanes[device].ok.load(std::memory_order_acquire)) return; // (never builds a lane)
-    Lane &l = g_lanes[device];
     hsa_signal_t done[kQueues] = {};
     uint32_t n = 0;
     for (uint32_t k = 0; k < kQueues; k++) {
@@ -248,6 +281,30 @@ void direct_quiesce(int device)
         wait_signal(done[k]);
         (void)hsa_signal_destroy(done[k]);
     }
+}
+} // namespace
+
+void direct_quiesce(int device)
+{
+    if (device < 0 || device >= kMaxDevices || !g_lanes[device].ok.load(std::memory_order_acquire)) return; // (never builds a lane)
+    Lane &l = g_lanes[device];
+    std::shared_lock<std::shared_mutex> lk(l.qmu);
+    if (!l.parked) quiesce_locked(l); // (a parked lane was drained when it was parked)
+}
+
+int direct_park(int device)
+{
+    if (device < 0 || device >= kMaxDevices || !g_lanes[device].ok.load(std::memory_order_acquire)) return 0;
+    Lane &l = g_lanes[device];
+    std::unique_lock<std::shared_mutex> x(l.qmu);
+    if (l.parked) return 0;
+    quiesce_locked(l);
+    for (uint32_t k = 0; k < kQueues; k++) {
+        (void)hsa_queue_destroy(l.queue[k]);
+        l.queue[k] = nullptr;
+    }
+    l.parked = true;
+    return 1;
 }
 
 int direct_event_state(hipEvent_t e)
@@ -316,6 +373,8 @@ int submit(const void *args, size_t bytes, int k, uint32_t wgs_x, uint32_t wgs_y
     DirectFence *f = fence_get(ev);
     if (!f) return 1;
     if (f->direct.load(std::memory_order_acquire)) wait_signal(f->sig); // this event's previous lane dispatch (never pending in practice: fences are re-used when unreferenced)
+    std::shared_lock<std::shared_mutex> lk(l->qmu); // (the queues stay until this dispatch is in one)
+    if (!ensure_unparked(*l, lk)) return 1;
 
     const uint64_t n = l->next.fetch_add(1, std::memory_order_relaxed);
     hsa_queue_t *q = l->queue[(uint32_t)queue % kQueues];

@@ -72,11 +72,11 @@ static void fence_unref(MvfxFence *f)
 
 // MVFX_LANE_STATS=1: what the lane's acquires did, printed when the process ends (gst-launch runs)
 static gint lane_stat[8]; // 0 taken, 1 refused: ordinary fence pending, 2 refused: held-back work / borrowed fence, 3 device-side waits armed,
-                          // 4 host waits in the acquire, 5 host waits of a stream consumer for a direct fence, 6 relied on queue order, 7 refused: other
+                          // 4 host waits in the acquire, 5 host waits of a stream consumer for a direct fence, 6 relied on queue order, 7 times parked
 static void lane_stats_print(void)
 {
     g_printerr("mvfx lane: %d acquires taken (%d rested on queue order, %d device-side waits, %d host waits), refused: %d ordinary fence pending, "
-               "%d held-back work or borrowed fence, %d other; %d host waits of stream consumers for direct fences\n", lane_stat[0], lane_stat[6],
+               "%d held-back work or borrowed fence; parked %d times; %d host waits of stream consumers for direct fences\n", lane_stat[0], lane_stat[6],
                lane_stat[3], lane_stat[4], lane_stat[1], lane_stat[2], lane_stat[7], lane_stat[5]);
 }
 static inline void lane_count(int what)
@@ -88,6 +88,33 @@ static inline void lane_count(int what)
         return v;
     }();
     if (on) g_atomic_int_inc(&lane_stat[what]);
+}
+
+// PARKING (csrc/direct_dispatch.h): when the lane's acquires are mostly refused -- the frames keep meeting stream fences: tee siblings, an element without
+// lane kernels in the chain, a source that copies every frame -- the lane's two hardware queues only slow the streams down (hardware queues are few).
+// Over windows of kLaneWindow acquires: three quarters refused -> the queues are destroyed (mvfx_direct_lane_park) and nobody asks for the lane for the
+// next kLaneParkedFor acquires; then it is tried again.
+static const gint kLaneWindow = 2048, kLaneParkedFor = 65536;
+static gint lane_win_taken, lane_win_refused, lane_parked_left;
+
+static inline gboolean lane_parked(void)
+{
+    for (gint v = g_atomic_int_get(&lane_parked_left); v > 0; v = g_atomic_int_get(&lane_parked_left))
+        if (g_atomic_int_compare_and_exchange(&lane_parked_left, v, v - 1)) return TRUE;
+    return FALSE;
+}
+
+static void lane_window(gboolean taken)
+{
+    const gint t = taken ? g_atomic_int_add(&lane_win_taken, 1) + 1 : g_atomic_int_get(&lane_win_taken);
+    const gint r = taken ? g_atomic_int_get(&lane_win_refused) : g_atomic_int_add(&lane_win_refused, 1) + 1;
+    if (t + r < kLaneWindow) return;
+    g_atomic_int_set(&lane_win_taken, 0);
+    g_atomic_int_set(&lane_win_refused, 0);
+    if (r >= 3 * t && g_atomic_int_compare_and_exchange(&lane_parked_left, 0, kLaneParkedFor)) {
+        lane_count(7);
+        mvfx_direct_lane_park();
+    }
 }
 
 static const gint kLaneSeed = 512;
@@ -379,6 +406,9 @@ static void direct_discourage(const void *tag)
 void mvfx_direct_reset(const void *tag)
 {
     g_atomic_int_set(&lane_seed_budget, kLaneSeed);
+    g_atomic_int_set(&lane_parked_left, 0); // (a new run finds out for itself)
+    g_atomic_int_set(&lane_win_taken, 0);
+    g_atomic_int_set(&lane_win_refused, 0);
     g_mutex_lock(&discouraged_lock);
     for (gint i = 0; i < discouraged_n; i++)
         if (discouraged[i].tag == tag) {
@@ -403,6 +433,10 @@ gboolean mvfx_hip_buffer_acquire_direct(GstBuffer *buf, mvfx_stream stream, int 
 
 gboolean mvfx_hip_buffer_acquire_direct_ordered(GstBuffer *buf, mvfx_stream stream, int queue, gboolean *relied_on_order)
 {
+    if (lane_parked()) {
+        lane_deps_abandon();
+        return FALSE;
+    }
     for (guint i = 0; buf && i < gst_buffer_n_memory(buf); i++) {
         GstMemory *mem = gst_buffer_peek_memory(buf, i);
         if (!mvfx_is_hip_memory(mem)) { lane_deps_abandon(); return FALSE; }
@@ -422,6 +456,7 @@ gboolean mvfx_hip_buffer_acquire_direct_ordered(GstBuffer *buf, mvfx_stream stre
                 } else {
                     ok = FALSE;     // an ordinary fence still pending: this frame's place is behind it on a stream
                     lane_count(1);
+                    lane_window(FALSE);
                 }
             } else if (mvfx_event_direct_queue(m->fence->ev) != queue)
                 other = fence_ref(m->fence); // a direct dispatch on the lane's OTHER queue: waited for below
@@ -459,11 +494,11 @@ gboolean mvfx_hip_buffer_acquire_direct_ordered(GstBuffer *buf, mvfx_stream stre
             }
         }
         if (!ok) {
-            if (other) lane_count(7);
             lane_deps_abandon();
             return FALSE;
         }
         lane_count(0);
+        lane_window(TRUE);
         g_mutex_lock(&m->lock);
         m->acq_seq = m->fence_seq; // (the fence scope's chaining then has nothing to wait for on `stream`)
         m->acq_stream = stream;

@@ -138,6 +138,10 @@ int mvfx_direct_queue_of_stream(mvfx_stream stream);
  * be an in-order one (not MVFX_OPT_DIRECT_UNORDERED), and `event` must not be set as the completion event of another call until that dispatch has
  * finished; 0: nothing to wait for (an ordinary event, or the fence has fired); < 0: MVFX_ERR_*. */
 int mvfx_direct_queue_wait_event(int queue, mvfx_event event);
+/* The lane's two hardware queues of the current device are drained and destroyed (1), or there were none (0); the next direct dispatch makes them again.
+ * For a caller that sees its frames go to streams anyway: hardware queues are few, and two idle ones beside HIP's four slow kernels on busy HIP streams
+ * down to half (csrc/direct_dispatch.h, "PARKING"). */
+int mvfx_direct_lane_park(void);
 /* The fence without a barrier packet.  While a completion event is set on the calling thread, every kernel the thread launches
  * through this library carries it as the stop event of its own dispatch (hipExtLaunchKernelGGL): the event is recorded when the
  * kernel finishes, with no packet of its own behind it -- hipEventRecord behind every 4K launch costs 2.6 us of device time

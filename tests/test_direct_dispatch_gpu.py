@@ -418,3 +418,26 @@ def test_a_dependency_across_the_lane_queues_is_waited_for_on_the_device(gpu):
     assert L.mvfx_direct_queue_wait_event(1, ev.h) == 0
     gpu.check(L.mvfx_event_synchronize(ev.h))
     assert L.mvfx_direct_queue_wait_event(0, e1.h) == 0
+
+
+def test_the_lane_can_be_parked_and_comes_back(gpu):
+    """mvfx_direct_lane_park: the lane's two hardware queues are drained and destroyed (hardware queues are few: idle ones beside HIP's slow busy HIP streams
+    down, csrc/direct_dispatch.h "PARKING"); dispatches in flight finish first, the next dispatch makes the queues again -- same bytes throughout"""
+    L = gpu.lib()
+    w, h = 3840, 2160
+    f = frames.random_frame(0x5EED1600, w, h)
+    want = f.copy()
+    assert orc.hsvfilter(want, w, w * 4, "RGBA", BENCH) == 0
+    assert L.mvfx_direct_lane_park() in (0, 1)
+    for rep in range(3):
+        bufs = [gpu.DeviceBuffer(f.nbytes).upload(f) for _ in range(6)]
+        evs = [Event(gpu) for _ in range(6)]
+        sts = [ctypes.c_void_p(L.mvfx_thread_stream_n(k & 1)) for k in range(6)]
+        for k in range(6):
+            rc, _, direct = direct_filter(gpu, bufs[k].ptr, w, h, w * 4, "RGBA", BENCH, evs[k], stream=sts[k])
+            assert rc == 0 and direct == 1, (rep, k, rc, direct, gpu.last_error())
+        assert L.mvfx_direct_lane_park() == 1           # six 4K frames in flight: drained first
+        assert all(L.mvfx_event_query(e.h) == 1 for e in evs)
+        assert L.mvfx_direct_lane_park() == 0           # parked already
+        for k in range(6):
+            assert np.array_equal(bufs[k].download().reshape(h, w * 4), want), (rep, k)
