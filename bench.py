@@ -936,6 +936,7 @@ def make_leg_colorlut(w, args, content):
         res["launch_model"] = ("1 thread x single-frame mvfx_colorlut_transform_frame, a fence per frame: on two alternating HIP streams / as packets of the "
                                "library's own queues in queue order / the same without the barrier bit (independent frames)")
         res["statistic"] = "median of 5 repetitions x 1500 frames"
+        lib.mvfx_direct_lane_park()  # (the legs that follow run on streams: no idle hardware queues beside them)
         return res
     leg = Leg("colorlut_" + content, "colorlut_frames_per_sec", "frames/s", nb, nb * 2 * FRAME_BYTES, "f32", data,
               f"colorlut 33^3 .cube (575 KB of nodes), {nb} streams of 3840x2160 RGBA per launch, content={content}; 4 + 4 algorithmic B/px "
@@ -1674,6 +1675,9 @@ def hsvfilter_main(args):
             single_stream["direct_lane_cached"] = direct_leg(opts & ~vfx.OPT_NONTEMPORAL)  # what the element uses (the next element reads the frame)
         except Exception as e:  # noqa: BLE001  (a box without the lane still prints its line)
             single_stream["direct_lane"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        # the lane's two hardware queues go again: idle ones beside HIP's four slow kernels on busy HIP streams down (csrc/direct_dispatch.h, "PARKING"),
+        # and the legs that follow run on streams
+        lib.mvfx_direct_lane_park()
         if fpt >= 2:
             single_stream["threads_pairs"] = threads_pairs_leg()
         if args.combiner_legs:  # (0: a profiling run -- rocprofv3's queue interceptor crashes on this leg's cross-stream event waits)
