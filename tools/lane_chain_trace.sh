@@ -1,6 +1,7 @@
 #!/bin/bash
-# tools/lane_chain_trace.sh: rocprofv3 kernel trace of the three-thread chain hsvfilter ! queue ! colorlut ! queue ! colorlut (4K, pool of 12) with the
-# lane on and off: per kernel name count / median duration, and the span of the whole trace per frame
+# tools/lane_chain_trace.sh: rocprofv3 kernel trace of a device-only chain (CHAIN=..., CUBE = the 33^3 .cube; default: the three-thread chain
+# hsvfilter ! queue ! colorlut ! queue ! colorlut), 4K, pool of POOL (12) blocks, with the lane on and off: per kernel name count / median duration, and
+# the span of the whole trace per frame
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 T=$(mktemp -d /tmp/lanetrace.XXXX)
 python3 -c "
@@ -10,7 +11,8 @@ open('$T/look.cube', 'w').write(cubes.analytic_3d(33))"
 export PATH=/opt/conda/bin:$PATH GST_PLUGIN_SYSTEM_PATH=/opt/conda/lib/gstreamer-1.0 GST_PLUGIN_PATH=$R/gst-plugin-rs_amd/gst-plugins GST_REGISTRY=$T/registry.bin GST_REGISTRY_FORK=no
 export MVFX_HIP_POOL_MIN=${POOL:-12} MVFX_LANE_STATS=1
 N=${N:-30000}
-PIPE="hiptestsrc num-buffers=$N refresh=false ! video/x-raw(memory:HIPMemory),format=RGBA,width=3840,height=2160 ! hsvfilter ! queue max-size-buffers=3 ! colorlut location=$T/look.cube ! queue max-size-buffers=3 ! colorlut location=$T/look.cube ! fakesink sync=false"
+CHAIN=${CHAIN:-"hsvfilter ! queue max-size-buffers=3 ! colorlut location=CUBE ! queue max-size-buffers=3 ! colorlut location=CUBE"}
+PIPE="hiptestsrc num-buffers=$N refresh=false ! video/x-raw(memory:HIPMemory),format=RGBA,width=3840,height=2160 ! ${CHAIN//CUBE/$T/look.cube} ! fakesink sync=false"
 /opt/conda/bin/gst-launch-1.0 -q $PIPE > /dev/null 2>&1   # registry
 cd /tmp && export TMPDIR=/tmp
 for lane in 1 0; do
