@@ -37,7 +37,7 @@ def main():
                                                                 "t. ! queue max-size-buffers=3 ! hsvdetector hue-ref=200"),
     }
     only = os.environ.get("ONLY", "")
-    for pool in ("5", "12"):
+    for pool in os.environ.get("POOLS", "5,12").split(","):
         for name, (fmt, chain) in chains.items():
             if only and only not in name:
                 continue
