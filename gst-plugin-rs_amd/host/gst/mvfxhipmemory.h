@@ -63,8 +63,10 @@ void *mvfx_hip_memory_pending_fence(GstMemory *mem);
 // The acquire of a frame that is to go out on lane queue `queue` (mvfx_direct_queue_of_stream(stream)).  TRUE when every block of the buffer is
 // free to be worked on by such a dispatch: no held-back work, no borrowed fence still running, and the block's own fence either fired, or a direct
 // dispatch IN FRONT of ours on the same lane queue (the queues are in order: a filter's frame and the detector that reads it), or a direct dispatch
-// on the other queue -- for which the streaming thread waits here (a pool's worth of frames ahead of the device: the back-pressure of a bounded
-// queue).  FALSE: an ordinary stream fence is still pending (a source's copy, a stream kernel): acquire and launch on the stream as ever.
+// on the other queue -- which our queue then waits for ON THE DEVICE (a barrier packet with its completion signal: mvfx_direct_queue_wait_event; the
+// fence stays referenced by ours until our dispatch has finished).  FALSE: an ordinary stream fence is still pending (a source's copy, a stream
+// kernel) and the pipeline's start-up budget of waits for such fences ("seeding") is used up, or the lane is parked because its acquires were mostly
+// refused (mvfxhipmemory.cpp, "PARKING"): acquire and launch on the stream as ever.
 // After TRUE the element opens its fence scope and calls the library with MVFX_OPT_DIRECT_DISPATCH | MVFX_OPT_DIRECT_ONLY; on
 // MVFX_ERR_DIRECT_UNAVAILABLE it cancels the scope (mvfx_hip_fence_cancel) and takes the ordinary path.
 gboolean mvfx_hip_buffer_acquire_direct(GstBuffer *buf, void *stream, int queue);
