@@ -24,8 +24,8 @@ def main():
         s = vfx.HsvFilterSettings(90.0, 1.25, -0.05, 0.9, 0.02)
         st = torch.cuda.current_stream(dev)
         sp = ctypes.c_void_p(st.cuda_stream)
-        for name, typed in (("typed + row tail", True), ("VALU kernel", False)):
-            vfx.check(lib.mvfx_thread_set_options(vfx.options(typed=typed).word))
+        for name, typed, nt in (("typed + row tail", True, False), ("typed, write-through", True, True), ("VALU kernel", False, False)):
+            vfx.check(lib.mvfx_thread_set_options(vfx.options(typed=typed, nontemporal=nt).word))
             for i in range(400):
                 vfx.check(lib.mvfx_hsvfilter_transform_frames_ip(fi[i % pool], nb, ctypes.byref(s), sp))
             torch.cuda.synchronize()
@@ -37,7 +37,7 @@ def main():
             e1.record(st)
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / n
-            print(f"{W}x{H} RGB x {nb} per launch, {name:>17}: {us:7.2f} us per launch, {nb / (us * 1e-6):9.0f} fps, frac of 8 TB/s {nb * 6 * W * H / (us * 1e-6) / 8e12:.3f}", flush=True)
+            print(f"{W}x{H} RGB x {nb} per launch, {name:>21}: {us:7.2f} us per launch, {nb / (us * 1e-6):9.0f} fps, frac of 8 TB/s {nb * 6 * W * H / (us * 1e-6) / 8e12:.3f}", flush=True)
         lib.mvfx_thread_set_options(0)
 
 
